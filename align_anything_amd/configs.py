@@ -1,0 +1,75 @@
+"""Plain-dict model geometry for the native path (no HF objects on the hot path).
+
+`from_hf_config` converts a HuggingFace config (what `AnyModel.from_pretrained` reads from config.json,
+align_anything/models/model_registry.py:134-175) into the dicts the native modules and the oracle use.
+The named constructors give the BASELINE.json geometries without touching the network.
+"""
+from __future__ import annotations
+
+
+def llama_cfg(hidden_size, intermediate_size, num_layers, num_heads, num_kv_heads, vocab_size,
+              rms_eps=1e-5, rope_theta=10000.0, head_dim=None, max_position_embeddings=4096):
+    return {
+        'kind': 'llama', 'hidden_size': hidden_size, 'intermediate_size': intermediate_size,
+        'num_layers': num_layers, 'num_heads': num_heads, 'num_kv_heads': num_kv_heads,
+        'head_dim': head_dim or hidden_size // num_heads, 'vocab_size': vocab_size, 'rms_eps': rms_eps,
+        'rope_theta': rope_theta, 'max_position_embeddings': max_position_embeddings,
+    }
+
+
+def clip_vision_cfg(hidden_size, intermediate_size, num_layers, num_heads, image_size, patch_size,
+                    ln_eps=1e-5, num_channels=3):
+    return {
+        'kind': 'clip_vision', 'hidden_size': hidden_size, 'intermediate_size': intermediate_size,
+        'num_layers': num_layers, 'num_heads': num_heads, 'image_size': image_size,
+        'patch_size': patch_size, 'ln_eps': ln_eps, 'num_channels': num_channels,
+    }
+
+
+def llava_cfg(text, vision, image_token_id, vision_feature_layer=-2, pad_token_id=None):
+    return {'kind': 'llava', 'text': text, 'vision': vision, 'image_token_id': image_token_id,
+            'vision_feature_layer': vision_feature_layer, 'pad_token_id': pad_token_id}
+
+
+def opt_cfg(hidden_size, ffn_dim, num_layers, num_heads, vocab_size, max_position_embeddings=2048):
+    return {'kind': 'opt', 'hidden_size': hidden_size, 'ffn_dim': ffn_dim, 'num_layers': num_layers,
+            'num_heads': num_heads, 'vocab_size': vocab_size,
+            'max_position_embeddings': max_position_embeddings}
+
+
+def llava_1_5_7b(num_layers=32, vision_layers=24):
+    """LLaVA-1.5-7B geometry (BASELINE.json config 2): CLIP-L/14-336 + Vicuna-7B, V = 32064."""
+    text = llama_cfg(4096, 11008, num_layers, 32, 32, 32064, rms_eps=1e-5)
+    vision = clip_vision_cfg(1024, 4096, vision_layers, 16, 336, 14)
+    return llava_cfg(text, vision, image_token_id=32000, pad_token_id=32001)
+
+
+def opt_125m():
+    """facebook/opt-125m geometry (BASELINE.json config 1), dropout forced to 0 for parity."""
+    return opt_cfg(768, 3072, 12, 12, 50272, 2048)
+
+
+def from_hf_config(c) -> dict:
+    mt = getattr(c, 'model_type', None)
+    if mt == 'llava':
+        t, v = c.text_config, c.vision_config
+        rp = getattr(t, 'rope_parameters', None) or {}
+        theta = rp.get('rope_theta', getattr(t, 'rope_theta', 10000.0))
+        text = llama_cfg(t.hidden_size, t.intermediate_size, t.num_hidden_layers, t.num_attention_heads,
+                         t.num_key_value_heads, t.vocab_size, t.rms_norm_eps, theta,
+                         getattr(t, 'head_dim', None), t.max_position_embeddings)
+        vision = clip_vision_cfg(v.hidden_size, v.intermediate_size, v.num_hidden_layers,
+                                 v.num_attention_heads, v.image_size, v.patch_size, v.layer_norm_eps,
+                                 v.num_channels)
+        return llava_cfg(text, vision, c.image_token_id, c.vision_feature_layer,
+                         getattr(c, 'pad_token_id', None))
+    if mt == 'llama':
+        rp = getattr(c, 'rope_parameters', None) or {}
+        theta = rp.get('rope_theta', getattr(c, 'rope_theta', 10000.0))
+        return llama_cfg(c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads,
+                         c.num_key_value_heads, c.vocab_size, c.rms_norm_eps, theta,
+                         getattr(c, 'head_dim', None), c.max_position_embeddings)
+    if mt == 'opt':
+        return opt_cfg(c.hidden_size, c.ffn_dim, c.num_hidden_layers, c.num_attention_heads, c.vocab_size,
+                       c.max_position_embeddings)
+    raise ValueError(f'model_type {mt!r} has no native MI355X implementation (llava, llama, opt are built)')

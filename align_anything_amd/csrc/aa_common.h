@@ -1,0 +1,93 @@
+// Shared device/host helpers for the MI355X (gfx950) DPO/PPO hot-path kernels.
+// gfx950 only: wave = 64 lanes, bf16 MFMA 16x16x32, LDS 160 KiB/CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef unsigned short bf16_t;  // raw bf16 storage (torch.bfloat16 bit pattern)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+
+#define AA_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t u) {
+    return __builtin_bit_cast(float, (uint32_t)u << 16);
+}
+// round-to-nearest-even, lowers to v_cvt_pk_bf16_f32 on gfx950 (same rounding as torch)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+// round a float through bf16 (emulates a bf16 intermediate of the HF graph)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x == NT (multiple of 64, <= 1024). `red` is >= NT/64 floats of LDS.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+template <int NT>
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// ---------------------------------------------------------------- host side
+extern "C" const char* aa_last_error(void);
+void aa_set_error(const char* fmt, ...);
+
+#define AA_OK 0
+#define AA_ERR_ARG (-1)
+#define AA_ERR_LAUNCH (-2)
+
+#define AA_REQUIRE(cond, ...)                      \
+    do {                                           \
+        if (!(cond)) {                             \
+            aa_set_error(__VA_ARGS__);             \
+            return AA_ERR_ARG;                     \
+        }                                          \
+    } while (0)
+
+#define AA_CHECK_LAUNCH(name)                                                   \
+    do {                                                                        \
+        hipError_t e__ = hipGetLastError();                                     \
+        if (e__ != hipSuccess) {                                                \
+            aa_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return AA_ERR_LAUNCH;                                               \
+        }                                                                       \
+    } while (0)
+
+static inline int aa_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,802 @@
+// HBM-bound block kernels of the transformer forward/backward for gfx950: RMSNorm, LayerNorm, RoPE,
+// SwiGLU, GELU/quick-GELU/ReLU (+backward), embedding gather / image-feature scatter, transposes,
+// column reductions (bias gradients), CLIP patch im2col.  All loads/stores are 16 B per lane;
+// reductions use wave shuffles + LDS.  Numerics follow the installed HF transformers graph that the
+// reference executes (SURVEY.md §8 a'): fp32 internal math, bf16 rounding at the same points.
+#include "aa_common.h"
+
+// ================================================================== RMSNorm
+// hf:models/llama/modeling_llama.py:62-67 : y = w * bf16(x_f32 * rsqrt(mean(x^2)+eps))
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y,
+                                                          float* __restrict__ rstd_out, int rows,
+                                                          int h, float eps) {
+    __shared__ float red[8];
+    const int nv = h >> 3;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const bf16_t* xr = x + row * h;
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < nv; i += 256) {
+            u16x8 v = *reinterpret_cast<const u16x8*>(xr + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); ss += f * f; }
+        }
+        ss = block_sum<256>(ss, red);
+        const float rstd = rsqrtf(ss / (float)h + eps);
+        if (threadIdx.x == 0 && rstd_out) rstd_out[row] = rstd;
+        bf16_t* yr = y + row * h;
+        for (int i = threadIdx.x; i < nv; i += 256) {
+            u16x8 v = *reinterpret_cast<const u16x8*>(xr + i * 8);
+            u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
+            u16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * rbf(bf2f(v[j]) * rstd));
+            *reinterpret_cast<u16x8*>(yr + i * 8) = o;
+        }
+    }
+}
+
+// dx = rstd * (dy*w - xhat * mean(dy*w*xhat)),  dw[c] += sum_rows dy*bf16(xhat)
+// dw partials are kept per thread in registers across the block's rows and flushed with fp32 atomics.
+template <int MAXV>  // max 16-byte vectors per thread (h <= 256*8*MAXV)
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy,
+                                                          const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w,
+                                                          const float* __restrict__ rstd_in,
+                                                          bf16_t* __restrict__ dx,
+                                                          float* __restrict__ dw, int rows, int h,
+                                                          int add_to_dx) {
+    __shared__ float red[8];
+    const int nv = h >> 3;
+    float dwacc[MAXV][8];
+#pragma unroll
+    for (int a = 0; a < MAXV; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwacc[a][j] = 0.f;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float rstd = rstd_in[row];
+        const bf16_t* xr = x + row * h;
+        const bf16_t* gr = dy + row * h;
+        float dot = 0.f;
+#pragma unroll
+        for (int a = 0; a < MAXV; ++a) {
+            const int i = threadIdx.x + a * 256;
+            if (i < nv) {
+                u16x8 xv = *reinterpret_cast<const u16x8*>(xr + i * 8);
+                u16x8 gv = *reinterpret_cast<const u16x8*>(gr + i * 8);
+                u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = bf2f(xv[j]) * rstd;
+                    const float g = bf2f(gv[j]);
+                    dot += g * bf2f(wv[j]) * xh;
+                    dwacc[a][j] += g * rbf(xh);
+                }
+            }
+        }
+        dot = block_sum<256>(dot, red) / (float)h;
+        bf16_t* dxr = dx + row * h;
+#pragma unroll
+        for (int a = 0; a < MAXV; ++a) {
+            const int i = threadIdx.x + a * 256;
+            if (i < nv) {
+                u16x8 xv = *reinterpret_cast<const u16x8*>(xr + i * 8);
+                u16x8 gv = *reinterpret_cast<const u16x8*>(gr + i * 8);
+                u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
+                u16x8 o;
+                if (add_to_dx) o = *reinterpret_cast<const u16x8*>(dxr + i * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = bf2f(xv[j]) * rstd;
+                    float d = rstd * (bf2f(gv[j]) * bf2f(wv[j]) - xh * dot);
+                    if (add_to_dx) d += bf2f(o[j]);
+                    o[j] = f2bf(d);
+                }
+                *reinterpret_cast<u16x8*>(dxr + i * 8) = o;
+            }
+        }
+    }
+    if (dw) {
+#pragma unroll
+        for (int a = 0; a < MAXV; ++a) {
+            const int i = threadIdx.x + a * 256;
+            if (i < nv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(dw + i * 8 + j, dwacc[a][j]);
+            }
+        }
+    }
+}
+
+extern "C" int aa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int h,
+                              float eps, void* stream) {
+    AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0, "aa_rmsnorm_fwd: hidden %d must be a multiple of 8", h);
+    if (rows == 0) return AA_OK;
+    const int grid = rows < 4096 ? rows : 4096;
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, h, eps);
+    AA_CHECK_LAUNCH("aa_rmsnorm_fwd");
+    return AA_OK;
+}
+
+extern "C" int aa_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd,
+                              void* dx, float* dw, int rows, int h, int add_to_dx, void* stream) {
+    AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0 && h <= 8 * 256 * 8,
+               "aa_rmsnorm_bwd: hidden %d must be a multiple of 8 and <= 16384", h);
+    if (rows == 0) return AA_OK;
+    const int grid = rows < 1024 ? rows : 1024;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_RMSB(MV)                                                                             \
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy,     \
+                       (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, dw, rows, h, add_to_dx)
+    if (h <= 2048) LAUNCH_RMSB(1);
+    else if (h <= 4096) LAUNCH_RMSB(2);
+    else if (h <= 8192) LAUNCH_RMSB(4);
+    else LAUNCH_RMSB(8);
+#undef LAUNCH_RMSB
+    AA_CHECK_LAUNCH("aa_rmsnorm_bwd");
+    return AA_OK;
+}
+
+// ================================================================== LayerNorm
+// torch F.layer_norm on bf16: fp32 stats, y = bf16((x-mean)*rstd*w + b)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ b,
+                                                            bf16_t* __restrict__ y,
+                                                            float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, int rows,
+                                                            int h, float eps) {
+    __shared__ float red[8];
+    const int nv = h >> 3;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const bf16_t* xr = x + row * h;
+        float s = 0.f;
+        for (int i = threadIdx.x; i < nv; i += 256) {
+            u16x8 v = *reinterpret_cast<const u16x8*>(xr + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += bf2f(v[j]);
+        }
+        const float mean = block_sum<256>(s, red) / (float)h;
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < nv; i += 256) {
+            u16x8 v = *reinterpret_cast<const u16x8*>(xr + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = bf2f(v[j]) - mean; ss += d * d; }
+        }
+        const float rstd = rsqrtf(block_sum<256>(ss, red) / (float)h + eps);
+        if (threadIdx.x == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+        bf16_t* yr = y + row * h;
+        for (int i = threadIdx.x; i < nv; i += 256) {
+            u16x8 v = *reinterpret_cast<const u16x8*>(xr + i * 8);
+            u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
+            u16x8 bv = *reinterpret_cast<const u16x8*>(b + i * 8);
+            u16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j] = f2bf((bf2f(v[j]) - mean) * rstd * bf2f(wv[j]) + bf2f(bv[j]));
+            *reinterpret_cast<u16x8*>(yr + i * 8) = o;
+        }
+    }
+}
+
+// dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)), dxhat = dy*w ; dw += dy*xhat ; db += dy
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy,
+                                                            const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ w,
+                                                            const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in,
+                                                            bf16_t* __restrict__ dx,
+                                                            float* __restrict__ dw,
+                                                            float* __restrict__ db, int rows, int h,
+                                                            int add_to_dx) {
+    __shared__ float red[8];
+    const int nv = h >> 3;
+    float dwacc[MAXV][8], dbacc[MAXV][8];
+#pragma unroll
+    for (int a = 0; a < MAXV; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dwacc[a][j] = 0.f; dbacc[a][j] = 0.f; }
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        const bf16_t* xr = x + row * h;
+        const bf16_t* gr = dy + row * h;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < MAXV; ++a) {
+            const int i = threadIdx.x + a * 256;
+            if (i < nv) {
+                u16x8 xv = *reinterpret_cast<const u16x8*>(xr + i * 8);
+                u16x8 gv = *reinterpret_cast<const u16x8*>(gr + i * 8);
+                u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (bf2f(xv[j]) - mean) * rstd;
+                    const float g = bf2f(gv[j]);
+                    const float dxh = g * bf2f(wv[j]);
+                    s1 += dxh; s2 += dxh * xh;
+                    dwacc[a][j] += g * xh; dbacc[a][j] += g;
+                }
+            }
+        }
+        s1 = block_sum<256>(s1, red) / (float)h;
+        s2 = block_sum<256>(s2, red) / (float)h;
+        bf16_t* dxr = dx + row * h;
+#pragma unroll
+        for (int a = 0; a < MAXV; ++a) {
+            const int i = threadIdx.x + a * 256;
+            if (i < nv) {
+                u16x8 xv = *reinterpret_cast<const u16x8*>(xr + i * 8);
+                u16x8 gv = *reinterpret_cast<const u16x8*>(gr + i * 8);
+                u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
+                u16x8 o;
+                if (add_to_dx) o = *reinterpret_cast<const u16x8*>(dxr + i * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (bf2f(xv[j]) - mean) * rstd;
+                    float d = rstd * (bf2f(gv[j]) * bf2f(wv[j]) - s1 - xh * s2);
+                    if (add_to_dx) d += bf2f(o[j]);
+                    o[j] = f2bf(d);
+                }
+                *reinterpret_cast<u16x8*>(dxr + i * 8) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < MAXV; ++a) {
+        const int i = threadIdx.x + a * 256;
+        if (i < nv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (dw) atomicAdd(dw + i * 8 + j, dwacc[a][j]);
+                if (db) atomicAdd(db + i * 8 + j, dbacc[a][j]);
+            }
+        }
+    }
+}
+
+extern "C" int aa_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean,
+                                float* rstd, int rows, int h, float eps, void* stream) {
+    AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0, "aa_layernorm_fwd: hidden %d must be a multiple of 8", h);
+    if (rows == 0) return AA_OK;
+    const int grid = rows < 4096 ? rows : 4096;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, mean, rstd,
+                       rows, h, eps);
+    AA_CHECK_LAUNCH("aa_layernorm_fwd");
+    return AA_OK;
+}
+
+extern "C" int aa_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean,
+                                const float* rstd, void* dx, float* dw, float* db, int rows, int h,
+                                int add_to_dx, void* stream) {
+    AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0 && h <= 8 * 256 * 4,
+               "aa_layernorm_bwd: hidden %d must be a multiple of 8 and <= 8192", h);
+    if (rows == 0) return AA_OK;
+    const int grid = rows < 1024 ? rows : 1024;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_LNB(MV)                                                                              \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy,   \
+                       (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, dw, db, rows, h, \
+                       add_to_dx)
+    if (h <= 2048) LAUNCH_LNB(1);
+    else if (h <= 4096) LAUNCH_LNB(2);
+    else LAUNCH_LNB(4);
+#undef LAUNCH_LNB
+    AA_CHECK_LAUNCH("aa_layernorm_bwd");
+    return AA_OK;
+}
+
+// ================================================================== RoPE (in place on a [M, ld] buffer)
+// hf:models/llama/modeling_llama.py:113-160: cos/sin are bf16 tables [maxpos, hd/2];
+// q' = bf16(bf16(q*cos) + bf16(rotate_half(q)*sin)), half-split layout.  Applied to `nheads`
+// consecutive heads starting at column col0 of every row; position of row r is pos[r].
+// inverse != 0 applies the transpose rotation (backward).
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ buf, long ld, int col0,
+                                                   int nheads, int hd,
+                                                   const int* __restrict__ pos,
+                                                   const bf16_t* __restrict__ cos_t,
+                                                   const bf16_t* __restrict__ sin_t, long rows,
+                                                   int inverse) {
+    const int half = hd >> 1;
+    const int vec_per_head = half >> 3;  // 8 bf16 per lane from each half
+    const long total = rows * nheads * vec_per_head;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int v = (int)(idx % vec_per_head);
+        const long t = idx / vec_per_head;
+        const int head = (int)(t % nheads);
+        const long row = t / nheads;
+        const int p = pos[row];
+        bf16_t* base = buf + row * ld + col0 + head * hd + v * 8;
+        u16x8 x1 = *reinterpret_cast<const u16x8*>(base);
+        u16x8 x2 = *reinterpret_cast<const u16x8*>(base + half);
+        u16x8 c = *reinterpret_cast<const u16x8*>(cos_t + (long)p * half + v * 8);
+        u16x8 s = *reinterpret_cast<const u16x8*>(sin_t + (long)p * half + v * 8);
+        u16x8 o1, o2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = bf2f(x1[j]), b = bf2f(x2[j]), cc = bf2f(c[j]);
+            const float ss = inverse ? -bf2f(s[j]) : bf2f(s[j]);
+            o1[j] = f2bf(rbf(a * cc) + rbf(-b * ss));
+            o2[j] = f2bf(rbf(b * cc) + rbf(a * ss));
+        }
+        *reinterpret_cast<u16x8*>(base) = o1;
+        *reinterpret_cast<u16x8*>(base + half) = o2;
+    }
+}
+
+extern "C" int aa_rope_inplace(void* buf, long ld, int col0, int nheads, int hd, const int* pos,
+                               const void* cos_t, const void* sin_t, long rows, int inverse,
+                               void* stream) {
+    AA_REQUIRE(hd > 0 && (hd % 16) == 0 && nheads > 0, "aa_rope_inplace: head_dim %d must be a multiple of 16", hd);
+    AA_REQUIRE((ld & 7) == 0 && (col0 & 7) == 0, "aa_rope_inplace: ld/col0 must be multiples of 8");
+    if (rows == 0) return AA_OK;
+    const long total = rows * nheads * (hd >> 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)buf, ld,
+                       col0, nheads, hd, pos, (const bf16_t*)cos_t, (const bf16_t*)sin_t, rows, inverse);
+    AA_CHECK_LAUNCH("aa_rope_inplace");
+    return AA_OK;
+}
+
+// ================================================================== gated / pointwise activations
+// act codes shared with the GEMM epilogue
+#define AA_ACT_NONE 0
+#define AA_ACT_GELU 1        // erf GELU (LLaVA projector)
+#define AA_ACT_QUICK_GELU 2  // x*sigmoid(1.702x) (CLIP)
+#define AA_ACT_RELU 3        // OPT
+#define AA_ACT_SILU 4
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    switch (act) {
+        case AA_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+        case AA_ACT_QUICK_GELU: return x / (1.f + expf(-1.702f * x));
+        case AA_ACT_RELU: return x > 0.f ? x : 0.f;
+        case AA_ACT_SILU: return x / (1.f + expf(-x));
+        default: return x;
+    }
+}
+__device__ __forceinline__ float act_grad(float x, int act) {
+    switch (act) {
+        case AA_ACT_GELU: {
+            const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+            const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        case AA_ACT_QUICK_GELU: {
+            const float s = 1.f / (1.f + expf(-1.702f * x));
+            return s + 1.702f * x * s * (1.f - s);
+        }
+        case AA_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case AA_ACT_SILU: {
+            const float s = 1.f / (1.f + expf(-x));
+            return s * (1.f + x * (1.f - s));
+        }
+        default: return 1.f;
+    }
+}
+
+// SwiGLU: gu = [gate | up] as [M, 2F] ; act = bf16(bf16(silu(gate)) * up)
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu,
+                                                         bf16_t* __restrict__ out, long M, int F) {
+    const int nv = F >> 3;
+    const long total = M * nv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / nv;
+        const int v = (int)(idx % nv);
+        u16x8 g = *reinterpret_cast<const u16x8*>(gu + row * 2 * F + v * 8);
+        u16x8 u = *reinterpret_cast<const u16x8*>(gu + row * 2 * F + F + v * 8);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gf = bf2f(g[j]);
+            o[j] = f2bf(rbf(gf / (1.f + expf(-gf))) * bf2f(u[j]));
+        }
+        *reinterpret_cast<u16x8*>(out + row * F + v * 8) = o;
+    }
+}
+// dgu = [dact*up*silu'(gate) | dact*silu(gate)]
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu,
+                                                         const bf16_t* __restrict__ dact,
+                                                         bf16_t* __restrict__ dgu, long M, int F) {
+    const int nv = F >> 3;
+    const long total = M * nv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / nv;
+        const int v = (int)(idx % nv);
+        u16x8 g = *reinterpret_cast<const u16x8*>(gu + row * 2 * F + v * 8);
+        u16x8 u = *reinterpret_cast<const u16x8*>(gu + row * 2 * F + F + v * 8);
+        u16x8 d = *reinterpret_cast<const u16x8*>(dact + row * F + v * 8);
+        u16x8 og, ou;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gf = bf2f(g[j]), uf = bf2f(u[j]), df = bf2f(d[j]);
+            const float s = 1.f / (1.f + expf(-gf));
+            og[j] = f2bf(df * uf * s * (1.f + gf * (1.f - s)));
+            ou[j] = f2bf(df * gf * s);
+        }
+        *reinterpret_cast<u16x8*>(dgu + row * 2 * F + v * 8) = og;
+        *reinterpret_cast<u16x8*>(dgu + row * 2 * F + F + v * 8) = ou;
+    }
+}
+
+extern "C" int aa_swiglu_fwd(const void* gate_up, void* out, long M, int F, void* stream) {
+    AA_REQUIRE(F > 0 && (F & 7) == 0, "aa_swiglu_fwd: ffn %d must be a multiple of 8", F);
+    if (M == 0) return AA_OK;
+    const long total = M * (F >> 3);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)gate_up, (bf16_t*)out, M, F);
+    AA_CHECK_LAUNCH("aa_swiglu_fwd");
+    return AA_OK;
+}
+extern "C" int aa_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, long M, int F,
+                             void* stream) {
+    AA_REQUIRE(F > 0 && (F & 7) == 0, "aa_swiglu_bwd: ffn %d must be a multiple of 8", F);
+    if (M == 0) return AA_OK;
+    const long total = M * (F >> 3);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)gate_up, (const bf16_t*)dact, (bf16_t*)dgate_up, M, F);
+    AA_CHECK_LAUNCH("aa_swiglu_bwd");
+    return AA_OK;
+}
+
+// pointwise activation backward: dx = dy * act'(pre)   (pre = saved pre-activation, bf16)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* __restrict__ pre,
+                                                      const bf16_t* __restrict__ dy,
+                                                      bf16_t* __restrict__ dx, long n8, int act) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n8; idx += (long)gridDim.x * 256) {
+        u16x8 p = *reinterpret_cast<const u16x8*>(pre + idx * 8);
+        u16x8 d = *reinterpret_cast<const u16x8*>(dy + idx * 8);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(d[j]) * act_grad(bf2f(p[j]), act));
+        *reinterpret_cast<u16x8*>(dx + idx * 8) = o;
+    }
+}
+__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t* __restrict__ x,
+                                                      bf16_t* __restrict__ y, long n8, int act) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n8; idx += (long)gridDim.x * 256) {
+        u16x8 p = *reinterpret_cast<const u16x8*>(x + idx * 8);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(act_fwd(bf2f(p[j]), act));
+        *reinterpret_cast<u16x8*>(y + idx * 8) = o;
+    }
+}
+extern "C" int aa_act_fwd(const void* x, void* y, long n, int act, void* stream) {
+    AA_REQUIRE((n & 7) == 0, "aa_act_fwd: element count %ld must be a multiple of 8", n);
+    if (n == 0) return AA_OK;
+    const long n8 = n >> 3;
+    const int grid = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (bf16_t*)y, n8, act);
+    AA_CHECK_LAUNCH("aa_act_fwd");
+    return AA_OK;
+}
+extern "C" int aa_act_bwd(const void* pre, const void* dy, void* dx, long n, int act, void* stream) {
+    AA_REQUIRE((n & 7) == 0, "aa_act_bwd: element count %ld must be a multiple of 8", n);
+    if (n == 0) return AA_OK;
+    const long n8 = n >> 3;
+    const int grid = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)pre, (const bf16_t*)dy, (bf16_t*)dx, n8, act);
+    AA_CHECK_LAUNCH("aa_act_bwd");
+    return AA_OK;
+}
+
+// y = a + b (bf16, rounded once) -- residual adds that are not fused into a GEMM epilogue
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a,
+                                                  const bf16_t* __restrict__ b,
+                                                  bf16_t* __restrict__ y, long n8) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n8; idx += (long)gridDim.x * 256) {
+        u16x8 p = *reinterpret_cast<const u16x8*>(a + idx * 8);
+        u16x8 q = *reinterpret_cast<const u16x8*>(b + idx * 8);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(p[j]) + bf2f(q[j]));
+        *reinterpret_cast<u16x8*>(y + idx * 8) = o;
+    }
+}
+extern "C" int aa_add(const void* a, const void* b, void* y, long n, void* stream) {
+    AA_REQUIRE((n & 7) == 0, "aa_add: element count %ld must be a multiple of 8", n);
+    if (n == 0) return AA_OK;
+    const long n8 = n >> 3;
+    const int grid = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
+                       (const bf16_t*)b, (bf16_t*)y, n8);
+    AA_CHECK_LAUNCH("aa_add");
+    return AA_OK;
+}
+
+// ================================================================== embedding gather + image scatter
+// hf:models/llava/modeling_llava.py:234-248 : inputs_embeds = embed(ids); rows where ids ==
+// image_token_id are replaced, in row-major order of occurrence, by the projector outputs.
+// slot[t] = running index among image tokens, or -1.  Single-workgroup scan (n <= a few 10k).
+__global__ __launch_bounds__(1024) void image_slot_kernel(const int64_t* __restrict__ ids, int n,
+                                                          int64_t image_token_id,
+                                                          int* __restrict__ slot,
+                                                          int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int f = (i < n && ids[i] == image_token_id) ? 1 : 0;
+        const unsigned long long bal = __ballot(f);
+        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wid] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int c = carry;
+        if (i < n) slot[i] = f ? (c + woff + prefix) : -1;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            carry = c + tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && count) *count = carry;
+}
+
+extern "C" int aa_image_slot_index(const int64_t* ids, int n, int64_t image_token_id, int* slot,
+                                   int* count, void* stream) {
+    AA_REQUIRE(n >= 0, "aa_image_slot_index: n must be >= 0");
+    hipLaunchKernelGGL(image_slot_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, n,
+                       image_token_id, slot, count);
+    AA_CHECK_LAUNCH("aa_image_slot_index");
+    return AA_OK;
+}
+
+// out[t,:] = slot[t] >= 0 ? feat[slot[t],:] : E[ids[t],:] (+ pos_emb[pos[t],:] when given, OPT)
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids,
+                                                        const int* __restrict__ slot,
+                                                        const bf16_t* __restrict__ E,
+                                                        const bf16_t* __restrict__ feat,
+                                                        const int* __restrict__ pos,
+                                                        const bf16_t* __restrict__ P,
+                                                        bf16_t* __restrict__ out, long n, int h,
+                                                        int vocab) {
+    const int nv = h >> 3;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n * nv; idx += (long)gridDim.x * 256) {
+        const long t = idx / nv;
+        const int v = (int)(idx % nv);
+        const int s = slot ? slot[t] : -1;
+        u16x8 r;
+        if (s >= 0) {
+            r = *reinterpret_cast<const u16x8*>(feat + (long)s * h + v * 8);
+        } else {
+            long id = ids[t];
+            if (id < 0 || id >= vocab) id = 0;  // host validates; never fault
+            r = *reinterpret_cast<const u16x8*>(E + id * h + v * 8);
+        }
+        if (P) {
+            u16x8 p = *reinterpret_cast<const u16x8*>(P + (long)pos[t] * h + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = f2bf(bf2f(r[j]) + bf2f(p[j]));
+        }
+        *reinterpret_cast<u16x8*>(out + t * h + v * 8) = r;
+    }
+}
+// backward: dfeat[slot] = dx (gather, unique rows) ; dE[ids] += dx (fp32 atomics) ; dP[pos] += dx
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids,
+                                                        const int* __restrict__ slot,
+                                                        const int* __restrict__ pos,
+                                                        const bf16_t* __restrict__ dx,
+                                                        float* __restrict__ dE,
+                                                        bf16_t* __restrict__ dfeat,
+                                                        float* __restrict__ dP, long n, int h,
+                                                        int vocab) {
+    const int nv = h >> 3;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n * nv; idx += (long)gridDim.x * 256) {
+        const long t = idx / nv;
+        const int v = (int)(idx % nv);
+        const int s = slot ? slot[t] : -1;
+        u16x8 r = *reinterpret_cast<const u16x8*>(dx + t * h + v * 8);
+        if (s >= 0) {
+            if (dfeat) *reinterpret_cast<u16x8*>(dfeat + (long)s * h + v * 8) = r;
+        } else if (dE) {
+            const long id = ids[t];
+            if (id >= 0 && id < vocab) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(dE + id * h + v * 8 + j, bf2f(r[j]));
+            }
+        }
+        if (dP) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(dP + (long)pos[t] * h + v * 8 + j, bf2f(r[j]));
+        }
+    }
+}
+
+extern "C" int aa_embed_fwd(const int64_t* ids, const int* slot, const void* E, const void* feat,
+                            const int* pos, const void* P, void* out, long n, int h, int vocab,
+                            void* stream) {
+    AA_REQUIRE(h > 0 && (h & 7) == 0, "aa_embed_fwd: hidden %d must be a multiple of 8", h);
+    AA_REQUIRE((slot == nullptr) || (feat != nullptr), "aa_embed_fwd: slot given without features");
+    if (n == 0) return AA_OK;
+    const long total = n * (h >> 3);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, slot,
+                       (const bf16_t*)E, (const bf16_t*)feat, pos, (const bf16_t*)P, (bf16_t*)out, n, h,
+                       vocab);
+    AA_CHECK_LAUNCH("aa_embed_fwd");
+    return AA_OK;
+}
+extern "C" int aa_embed_bwd(const int64_t* ids, const int* slot, const int* pos, const void* dx,
+                            float* dE, void* dfeat, float* dP, long n, int h, int vocab,
+                            void* stream) {
+    AA_REQUIRE(h > 0 && (h & 7) == 0, "aa_embed_bwd: hidden %d must be a multiple of 8", h);
+    if (n == 0) return AA_OK;
+    const long total = n * (h >> 3);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, slot, pos,
+                       (const bf16_t*)dx, dE, (bf16_t*)dfeat, dP, n, h, vocab);
+    AA_CHECK_LAUNCH("aa_embed_bwd");
+    return AA_OK;
+}
+
+// ================================================================== bf16 2-D transpose  out[C,R] = in[R,C]^T
+// 64x64 tile through LDS (padded rows): coalesced 128-B row segments on both sides.
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, long ldi,
+                                                        bf16_t* __restrict__ out, long ldo, int R,
+                                                        int C) {
+    __shared__ bf16_t tile[64][66];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(long)r * ldi + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) out[(long)c * ldo + r] = tile[tx][i];
+    }
+}
+extern "C" int aa_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C,
+                                 void* stream) {
+    AA_REQUIRE(R >= 0 && C >= 0 && ldi >= C && ldo >= R, "aa_transpose_bf16: bad shape R=%d C=%d", R, C);
+    if (R == 0 || C == 0) return AA_OK;
+    hipLaunchKernelGGL(transpose_kernel, dim3(aa_cdiv(C, 64), aa_cdiv(R, 64)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, R, C);
+    AA_CHECK_LAUNCH("aa_transpose_bf16");
+    return AA_OK;
+}
+
+// ================================================================== column sum (bias gradient)
+// out[c] += sum_r in[r, c]   (fp32 atomics; each block reduces a 256-row slab of 64*8 columns)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ in, long ld, long R,
+                                                     int C, float* __restrict__ out) {
+    // thread layout: 64 lanes x 8 columns wide (512 columns per block), 4 row groups
+    __shared__ float part[4][512];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 512 + lane * 8;
+    const long r0 = (long)blockIdx.y * 256;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < C) {
+        for (long r = r0 + rg; r < R && r < r0 + 256; r += 4) {
+            u16x8 v = *reinterpret_cast<const u16x8*>(in + r * ld + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[rg][lane * 8 + j] = acc[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int cc = blockIdx.x * 512 + i;
+        if (cc < C) atomicAdd(out + cc, part[0][i] + part[1][i] + part[2][i] + part[3][i]);
+    }
+}
+extern "C" int aa_colsum_bf16(const void* in, long ld, long R, int C, float* out, void* stream) {
+    AA_REQUIRE(C > 0 && (C & 7) == 0 && (ld & 7) == 0, "aa_colsum_bf16: C=%d / ld must be multiples of 8", C);
+    if (R == 0) return AA_OK;
+    hipLaunchKernelGGL(colsum_kernel, dim3(aa_cdiv(C, 512), aa_cdiv(R, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)in, ld, R, C, out);
+    AA_CHECK_LAUNCH("aa_colsum_bf16");
+    return AA_OK;
+}
+
+// ================================================================== CLIP patch im2col
+// hf:models/clip/modeling_clip.py:138-218: Conv2d(3->h, k=s=P, no bias) == GEMM over
+// patches[n*G*G + gy*G + gx, c*P*P + py*P + px] = pixel[n, c, gy*P+py, gx*P+px]; K padded to Kp with 0.
+template <typename TIN>
+__global__ __launch_bounds__(256) void im2col_kernel(const TIN* __restrict__ pix,
+                                                     bf16_t* __restrict__ out, int n_img, int Cc,
+                                                     int H, int P, int Kp) {
+    const int G = H / P;
+    const int K = Cc * P * P;
+    const long total = (long)n_img * G * G * Kp;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % Kp);
+        const long prow = idx / Kp;
+        float v = 0.f;
+        if (k < K) {
+            const int px = k % P, py = (k / P) % P, c = k / (P * P);
+            const int gx = (int)(prow % G), gy = (int)((prow / G) % G);
+            const long n = prow / ((long)G * G);
+            const long src = ((n * Cc + c) * H + (gy * P + py)) * H + gx * P + px;
+            if constexpr (sizeof(TIN) == 2) v = bf2f(pix[src]); else v = pix[src];
+        }
+        out[idx] = f2bf(v);
+    }
+}
+extern "C" int aa_patch_im2col(const void* pixels, int pix_dtype, void* out, int n_img, int channels,
+                               int image_size, int patch, int Kp, void* stream) {
+    AA_REQUIRE(image_size % patch == 0 && Kp >= channels * patch * patch,
+               "aa_patch_im2col: image %d / patch %d / Kp %d mismatch", image_size, patch, Kp);
+    if (n_img == 0) return AA_OK;
+    const int G = image_size / patch;
+    const long total = (long)n_img * G * G * Kp;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (pix_dtype == 0)
+        hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)pixels, (bf16_t*)out, n_img, channels, image_size, patch, Kp);
+    else
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)pixels, (bf16_t*)out, n_img, channels, image_size, patch, Kp);
+    AA_CHECK_LAUNCH("aa_patch_im2col");
+    return AA_OK;
+}
+
+// ================================================================== casts / fills
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in,
+                                                          bf16_t* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = f2bf(in[i]);
+}
+extern "C" int aa_f32_to_bf16(const float* in, void* out, long n, void* stream) {
+    if (n == 0) return AA_OK;
+    const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in,
+                       (bf16_t*)out, n);
+    AA_CHECK_LAUNCH("aa_f32_to_bf16");
+    return AA_OK;
+}
+
+// CLIP embeddings: x[n, 0, :] = cls + pos[0]; x[n, 1+p, :] = patch[n*G2+p, :] + pos[1+p]
+__global__ __launch_bounds__(256) void clip_embed_kernel(const bf16_t* __restrict__ patch,
+                                                         const bf16_t* __restrict__ cls,
+                                                         const bf16_t* __restrict__ pos,
+                                                         bf16_t* __restrict__ out, int n_img, int G2,
+                                                         int h) {
+    const int nv = h >> 3;
+    const long total = (long)n_img * (G2 + 1) * nv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int v = (int)(idx % nv);
+        const long t = idx / nv;
+        const int p = (int)(t % (G2 + 1));
+        const long n = t / (G2 + 1);
+        u16x8 a = (p == 0) ? *reinterpret_cast<const u16x8*>(cls + v * 8)
+                           : *reinterpret_cast<const u16x8*>(patch + (n * G2 + p - 1) * h + v * 8);
+        u16x8 b = *reinterpret_cast<const u16x8*>(pos + (long)p * h + v * 8);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(a[j]) + bf2f(b[j]));
+        *reinterpret_cast<u16x8*>(out + t * h + v * 8) = o;
+    }
+}
+extern "C" int aa_clip_embed(const void* patch, const void* cls, const void* pos, void* out,
+                             int n_img, int G2, int h, void* stream) {
+    AA_REQUIRE(h > 0 && (h & 7) == 0, "aa_clip_embed: hidden %d must be a multiple of 8", h);
+    if (n_img == 0) return AA_OK;
+    const long total = (long)n_img * (G2 + 1) * (h >> 3);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(clip_embed_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)patch, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)out, n_img,
+                       G2, h);
+    AA_CHECK_LAUNCH("aa_clip_embed");
+    return AA_OK;
+}

@@ -1,0 +1,368 @@
+// bf16 MFMA GEMM for gfx950 (CDNA4):  C[M,N] (+)= op(A)[M,K] * op(B)[K,N]  with fp32 accumulation.
+//
+// Replaces the torch/rocBLAS `nn.Linear` calls that `model(**batch)` executes in the reference hot path
+// (align_anything/trainers/text_to_text/dpo.py:128 -> hf:models/llama/modeling_llama.py q/k/v/o/gate/up/down,
+//  hf:models/llava/modeling_llava.py:87-106 projector, :361 lm_head) and their autograd backward.
+//
+// Design (MI355X-first):
+//  * 64-lane waves, v_mfma_f32_16x16x32_bf16, operands swapped (D = Wfrag x Afrag) so each lane owns 4
+//    consecutive output columns -> 8-byte bf16x4 epilogue stores.
+//  * Operand tiles go HBM -> LDS with direct-to-LDS DMA (global_load_lds_dwordx4, 1 KiB per wave
+//    instruction), double-buffered over BK = 64, one barrier per K-tile.
+//  * LDS images are lane-linear (DMA constraint); bank-conflict-free reads come from an XOR swizzle
+//    applied to the per-lane *source* address and mirrored on the ds_read side.
+//  * Layouts: an operand is either K-contiguous (row-major [rows][K], read with ds_read_b128) or
+//    row-contiguous ([K][rows], read with the gfx950 transpose read ds_read_b64_tr_b16), which gives
+//    NT (forward), NN (dX = dY*W) and TN (dW = dY^T*X) without materialising transposes.
+//  * 1-D grid with a bijective XCD-aware remap + grouped tile order so neighbouring tiles share an L2.
+#include "aa_common.h"
+
+#define AA_ACT_NONE 0
+#define AA_ACT_GELU 1
+#define AA_ACT_QUICK_GELU 2
+#define AA_ACT_RELU 3
+#define AA_ACT_SILU 4
+
+// flags
+#define AA_GEMM_A_T 1         // A stored [K][M] (M contiguous) instead of [M][K]
+#define AA_GEMM_B_N 2         // B stored [K][N] (N contiguous) instead of [N][K]
+#define AA_GEMM_OUT_F32 4     // C is fp32 (default bf16)
+#define AA_GEMM_ACCUM 8       // C += result
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ float gemm_act(float x, int act) {
+    switch (act) {
+        case AA_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+        case AA_ACT_QUICK_GELU: return x / (1.f + expf(-1.702f * x));
+        case AA_ACT_RELU: return x > 0.f ? x : 0.f;
+        case AA_ACT_SILU: return x / (1.f + expf(-x));
+        default: return x;
+    }
+}
+
+struct GemmParams {
+    const bf16_t* A; const bf16_t* B; void* C;
+    const bf16_t* bias;      // [N] or null
+    const bf16_t* residual;  // [M, ldr] or null (added after bf16 rounding, like HF's `residual + x`)
+    int M, N, K;
+    long lda, ldb, ldc, ldr;
+    int act, flags;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BK = 64;
+
+// K-contiguous tile: [R rows][64 k] bf16, row = 128 B = 8 slots of 16 B; slot ^= (row>>1)&7.
+// row-contiguous tile: [64 k rows][R cols] bf16; 32-B unit ^= (krow&3) | ((krow>>3)&1)<<2.
+__device__ __forceinline__ int tr_swz(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_N>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1)
+void gemm_kernel(const GemmParams p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int A_IT = (A_BYTES / 1024) / NW, B_IT = (B_BYTES / 1024) / NW;
+    static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for the wave count");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- XCD-aware bijective remap, then grouped (GM rows of tiles) order
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GM = 8;
+    const int per_group = GM * p.tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (wg % per_group) % gsz;
+    const int tn = (wg % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-lane DMA source pointers (advance by one K-tile per stage)
+    const bf16_t* srcA[A_IT];
+    const bf16_t* srcB[B_IT];
+    long stepA, stepB;
+    if constexpr (!A_T) {
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            const int c = wave + j * NW;
+            const int r = c * 8 + (lane >> 3);
+            const int ks = (lane & 7) ^ ((r >> 1) & 7);
+            const int gr = min(m0 + r, p.M - 1);
+            srcA[j] = p.A + (long)gr * p.lda + ks * 8;
+        }
+        stepA = BK;
+    } else {
+        // tile [64 k][BM]: one DMA = 1 KiB = RPI k-rows of BM*2 bytes
+        constexpr int RPI = 1024 / (BM * 2);
+        constexpr int SPR = BM * 2 / 16;  // 16-B slots per k-row
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            const int c = wave + j * NW;
+            const int kr = c * RPI + lane / SPR;
+            const int s = lane % SPR;
+            const int unit = (s >> 1) ^ tr_swz(kr);
+            int col = m0 + unit * 16 + (s & 1) * 8;
+            col = min(col, p.M - 8);  // M % 8 == 0 enforced on host for transposed operands
+            srcA[j] = p.A + (long)kr * p.lda + col;
+        }
+        stepA = (long)BK * p.lda;
+    }
+    if constexpr (!B_N) {
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const int c = wave + j * NW;
+            const int r = c * 8 + (lane >> 3);
+            const int ks = (lane & 7) ^ ((r >> 1) & 7);
+            const int gr = min(n0 + r, p.N - 1);
+            srcB[j] = p.B + (long)gr * p.ldb + ks * 8;
+        }
+        stepB = BK;
+    } else {
+        constexpr int RPI = 1024 / (BN * 2);
+        constexpr int SPR = BN * 2 / 16;
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const int c = wave + j * NW;
+            const int kr = c * RPI + lane / SPR;
+            const int s = lane % SPR;
+            const int unit = (s >> 1) ^ tr_swz(kr);
+            int col = n0 + unit * 16 + (s & 1) * 8;
+            col = min(col, p.N - 8);
+            srcB[j] = p.B + (long)kr * p.ldb + col;
+        }
+        stepB = (long)BK * p.ldb;
+    }
+
+    auto stage = [&](int buf) {
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)srcA[j], (lptr_t)(base + (wave + j * NW) * 1024), 16, 0, 0);
+            srcA[j] += stepA;
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)srcB[j], (lptr_t)(base + A_BYTES + (wave + j * NW) * 1024), 16, 0, 0);
+            srcB[j] += stepB;
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-lane LDS read offsets
+    const int l15 = lane & 15, g = lane >> 4;
+    // K-contiguous: row = base16 + l15 ; slot = (kk*4+g) ^ ((l15>>1)&7)
+    int offK[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) offK[kk] = l15 * 128 + (((kk * 4 + g) ^ ((l15 >> 1) & 7)) << 4);
+    // row-contiguous (transpose read): k-row = kk*32 + 8g + 4*hh + (l15>>2), col = base16 + (l15&3)*4
+
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[FM], bfr[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if constexpr (!A_T) {
+                    af[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * TM + i * 16) * 128 + offK[kk]);
+                } else {
+                    bf16x4 h[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int kr = kk * 32 + g * 8 + hh * 4 + (l15 >> 2);
+                        const int colb = wm * TM + i * 16;  // multiple of 16 -> unit index
+                        const int unit = (colb >> 4) ^ tr_swz(kr);
+                        const char* a = sa + kr * (BM * 2) + unit * 32 + (l15 & 3) * 8;
+                        h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a);
+                    }
+                    af[i] = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (!B_N) {
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(sb + (wn * TN + j * 16) * 128 + offK[kk]);
+                } else {
+                    bf16x4 h[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int kr = kk * 32 + g * 8 + hh * 4 + (l15 >> 2);
+                        const int colb = wn * TN + j * 16;
+                        const int unit = (colb >> 4) ^ tr_swz(kr);
+                        const char* a = sb + kr * (BN * 2) + unit * 32 + (l15 & 3) * 8;
+                        h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a);
+                    }
+                    bfr[j] = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nt = p.K / BK;
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) stage(cur ^ 1);
+        compute(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns C[m][n..n+3], m = .. + l15, n = .. + g*4
+    const bool out_f32 = p.flags & AA_GEMM_OUT_F32;
+    const bool accum = p.flags & AA_GEMM_ACCUM;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * TM + i * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * TN + j * 16 + g * 4;
+            if (n >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.bias) {
+                const u16x4 b = *reinterpret_cast<const u16x4*>(p.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
+            }
+            if (p.act != AA_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gemm_act(rbf(v[e]), p.act);
+            }
+            if (p.residual) {
+                const u16x4 r = *reinterpret_cast<const u16x4*>(p.residual + (long)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) + bf2f(r[e]);
+            }
+            if (out_f32) {
+                float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+                f32x4 o = {v[0], v[1], v[2], v[3]};
+                if (accum) { const f32x4 old = *reinterpret_cast<const f32x4*>(c); o += old; }
+                *reinterpret_cast<f32x4*>(c) = o;
+            } else {
+                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
+                if (accum) {
+                    const u16x4 old = *reinterpret_cast<const u16x4*>(c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bf2f(old[e]);
+                }
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+                *reinterpret_cast<u16x4*>(c) = o;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_N>
+static int launch_cfg(GemmParams& p, hipStream_t st) {
+    p.tiles_m = aa_cdiv(p.M, BM);
+    p.tiles_n = aa_cdiv(p.N, BN);
+    constexpr int lds = 2 * (BM + BN) * BK * 2;
+    auto kern = gemm_kernel<BM, BN, WM, WN, A_T, B_N>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            aa_set_error("aa_gemm_bf16: cannot reserve %d B LDS: %s", lds, hipGetErrorString(e));
+            return AA_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), lds, st, p);
+    AA_CHECK_LAUNCH("aa_gemm_bf16");
+    return AA_OK;
+}
+
+template <bool A_T, bool B_N>
+static int launch_layout(GemmParams& p, int tile, hipStream_t st) {
+    switch (tile) {
+        case 0: return launch_cfg<256, 256, 2, 4, A_T, B_N>(p, st);
+        case 1: return launch_cfg<128, 128, 2, 2, A_T, B_N>(p, st);
+        case 2: return launch_cfg<256, 128, 4, 2, A_T, B_N>(p, st);
+        case 3: return launch_cfg<128, 256, 2, 4, A_T, B_N>(p, st);
+        default: aa_set_error("aa_gemm_bf16: unknown tile config %d", tile); return AA_ERR_ARG;
+    }
+}
+
+static int g_force_tile = -2;  // -2: read env once ; -1: heuristic
+
+// waves-quantisation heuristic over the 256-CU chip
+static int pick_tile(int M, int N) {
+    if (g_force_tile == -2) {
+        const char* e = getenv("AA_GEMM_TILE");
+        g_force_tile = e ? atoi(e) : -1;
+    }
+    if (g_force_tile >= 0) return g_force_tile;
+    struct Cfg { int bm, bn, slots; float eff; };
+    // slots = concurrently resident tiles on the chip; eff = relative per-flop efficiency of the config
+    const Cfg cfgs[4] = {{256, 256, 256, 1.00f}, {128, 128, 512, 0.72f}, {256, 128, 256, 0.86f}, {128, 256, 256, 0.86f}};
+    int best = 1; float best_t = 1e30f;
+    for (int c = 0; c < 4; ++c) {
+        const long tiles = (long)aa_cdiv(M, cfgs[c].bm) * aa_cdiv(N, cfgs[c].bn);
+        const long rounds = (tiles + cfgs[c].slots - 1) / cfgs[c].slots;
+        // time ~ rounds * (tile flops / (eff * per-slot rate)); per-slot rate halves when 2 tiles share a CU
+        const float per = (float)cfgs[c].bm * cfgs[c].bn / cfgs[c].eff * (cfgs[c].slots / 256.f);
+        const float t = rounds * per;
+        if (t < best_t) { best_t = t; best = c; }
+    }
+    return best;
+}
+
+extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda,
+                            long ldb, long ldc, const void* bias, const void* residual, long ldr,
+                            int act, int flags, void* stream) {
+    AA_REQUIRE(M > 0 && N > 0 && K > 0, "aa_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+    AA_REQUIRE(K % BK == 0, "aa_gemm_bf16: K=%d must be a multiple of %d (zero-pad the operands)", K, BK);
+    AA_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "aa_gemm_bf16: N=%d and ldc=%ld must be multiples of 4", N, ldc);
+    AA_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "aa_gemm_bf16: lda=%ld / ldb=%ld must be multiples of 8", lda, ldb);
+    AA_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0,
+               "aa_gemm_bf16: operands must be 16-byte aligned");
+    const bool a_t = flags & AA_GEMM_A_T, b_n = flags & AA_GEMM_B_N;
+    if (a_t) AA_REQUIRE(M % 8 == 0, "aa_gemm_bf16: transposed A needs M %% 8 == 0 (got %d)", M);
+    if (b_n) AA_REQUIRE(N % 8 == 0, "aa_gemm_bf16: N-contiguous B needs N %% 8 == 0 (got %d)", N);
+    if (residual) AA_REQUIRE(ldr % 4 == 0, "aa_gemm_bf16: ldr=%ld must be a multiple of 4", ldr);
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+    p.bias = (const bf16_t*)bias; p.residual = (const bf16_t*)residual;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
+    p.act = act; p.flags = flags;
+    const int tile = pick_tile(M, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (!a_t && !b_n) return launch_layout<false, false>(p, tile, st);
+    if (!a_t && b_n) return launch_layout<false, true>(p, tile, st);
+    if (a_t && b_n) return launch_layout<true, true>(p, tile, st);
+    aa_set_error("aa_gemm_bf16: layout A^T with K-contiguous B is not built (unused by the hot path)");
+    return AA_ERR_ARG;
+}
+
+// test hook: force a tile config (-1 = heuristic)
+extern "C" int aa_gemm_set_tile(int tile) { g_force_tile = tile; return AA_OK; }

@@ -1,0 +1,149 @@
+// Flat-buffer optimizer kernels for gfx950 (HBM-bound, 28 B/param/step).
+// Replaces DeepSpeed FusedAdam (adam_w_mode, bias_correction) + global-L2 gradient clipping used at
+// align_anything/trainers/base/supervised_trainer.py:245-249 with configs/deepspeed/*.json
+// "gradient_clipping".  MI355X-first layout: all parameters of one group live in ONE flat bf16
+// buffer with matching flat fp32 master/m/v buffers, so a step is a handful of streaming launches
+// instead of a multi-tensor pointer table.
+#include "aa_common.h"
+
+// sum of squares of a flat gradient buffer -> atomically accumulated into *out (fp32).
+// scale is applied before squaring (e.g. 1/world after a SUM all-reduce).
+template <typename TG>
+__global__ __launch_bounds__(256) void sumsq_kernel(const TG* __restrict__ g, long n, float scale,
+                                                    float* __restrict__ out) {
+    __shared__ float red[8];
+    float acc = 0.f;
+    if constexpr (sizeof(TG) == 2) {
+        const long n8 = n >> 3;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+            u16x8 v = *reinterpret_cast<const u16x8*>(g + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]) * scale; acc += f * f; }
+        }
+        for (long i = (n8 << 3) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            const float f = bf2f(g[i]) * scale; acc += f * f;
+        }
+    } else {
+        const long n4 = n >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(g + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float f = v[j] * scale; acc += f * f; }
+        }
+        for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            const float f = g[i] * scale; acc += f * f;
+        }
+    }
+    acc = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+
+extern "C" int aa_grad_sumsq(const void* g, int g_dtype, long n, float scale, float* out_accum,
+                             void* stream) {
+    AA_REQUIRE(g_dtype == 0 || g_dtype == 1, "aa_grad_sumsq: dtype must be 0 (bf16) or 1 (f32)");
+    if (n == 0) return AA_OK;
+    const long work = n / 8 / 256 + 1;
+    const int grid = (int)(work < 2048 ? work : 2048);
+    if (g_dtype == 0)
+        hipLaunchKernelGGL(sumsq_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)g, n, scale, out_accum);
+    else
+        hipLaunchKernelGGL(sumsq_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)g, n, scale, out_accum);
+    AA_CHECK_LAUNCH("aa_grad_sumsq");
+    return AA_OK;
+}
+
+// clip_coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)) ; norm_out = sqrt(sumsq)  (device-side, no host sync)
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm,
+                                 float* __restrict__ coef, float* __restrict__ norm_out) {
+    const float nrm = sqrtf(*sumsq);
+    if (norm_out) *norm_out = nrm;
+    float c = 1.f;
+    if (max_norm > 0.f) c = fminf(1.f, max_norm / (nrm + 1e-6f));
+    *coef = c;
+}
+extern "C" int aa_clip_coef(const float* sumsq, float max_norm, float* coef_out, float* norm_out,
+                            void* stream) {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm,
+                       coef_out, norm_out);
+    AA_CHECK_LAUNCH("aa_clip_coef");
+    return AA_OK;
+}
+
+// AdamW on flat buffers.  g' = g * gscale * (*clip_coef)
+//   m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2
+//   p = p - lr * ( (m/bc1) / (sqrt(v/bc2) + eps) + wd * p )       (DeepSpeed FusedAdam ADAM_MODE_1)
+// master/m/v fp32, p16 = bf16 shadow written from the updated master.
+template <typename TG>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ p16,
+                                                    const TG* __restrict__ g, long n, float lr,
+                                                    float b1, float b2, float eps, float wd,
+                                                    float bc1, float bc2, float gscale,
+                                                    const float* __restrict__ clip_coef) {
+    const float gs = gscale * (clip_coef ? *clip_coef : 1.f);
+    const float inv_bc1 = 1.f / bc1, inv_bc2 = 1.f / bc2;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 pw = *reinterpret_cast<const f32x4*>(master + i * 4);
+        f32x4 mm = *reinterpret_cast<const f32x4*>(m + i * 4);
+        f32x4 vv = *reinterpret_cast<const f32x4*>(v + i * 4);
+        float gg[4];
+        if constexpr (sizeof(TG) == 2) {
+            u16x4 gr = *reinterpret_cast<const u16x4*>(g + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gg[j] = bf2f(gr[j]) * gs;
+        } else {
+            f32x4 gr = *reinterpret_cast<const f32x4*>(g + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gg[j] = gr[j] * gs;
+        }
+        u16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mm[j] = b1 * mm[j] + (1.f - b1) * gg[j];
+            vv[j] = b2 * vv[j] + (1.f - b2) * gg[j] * gg[j];
+            const float denom = sqrtf(vv[j] * inv_bc2) + eps;
+            const float upd = (mm[j] * inv_bc1) / denom + wd * pw[j];
+            pw[j] = pw[j] - lr * upd;
+            o[j] = f2bf(pw[j]);
+        }
+        *reinterpret_cast<f32x4*>(master + i * 4) = pw;
+        *reinterpret_cast<f32x4*>(m + i * 4) = mm;
+        *reinterpret_cast<f32x4*>(v + i * 4) = vv;
+        *reinterpret_cast<u16x4*>(p16 + i * 4) = o;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float gq;
+        if constexpr (sizeof(TG) == 2) gq = bf2f(g[i]) * gs; else gq = g[i] * gs;
+        const float mq = b1 * m[i] + (1.f - b1) * gq;
+        const float vq = b2 * v[i] + (1.f - b2) * gq * gq;
+        const float denom = sqrtf(vq * inv_bc2) + eps;
+        const float pq = master[i] - lr * ((mq * inv_bc1) / denom + wd * master[i]);
+        master[i] = pq; m[i] = mq; v[i] = vq; p16[i] = f2bf(pq);
+    }
+}
+
+extern "C" int aa_adamw_flat(float* master, float* m, float* v, void* p16, const void* g, int g_dtype,
+                             long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int step, float gscale, const float* clip_coef, void* stream) {
+    AA_REQUIRE(g_dtype == 0 || g_dtype == 1, "aa_adamw_flat: dtype must be 0 (bf16) or 1 (f32)");
+    AA_REQUIRE(step >= 1, "aa_adamw_flat: step must be >= 1 (got %d)", step);
+    if (n == 0) return AA_OK;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+    const long work = n / 4 / 256 + 1;
+    const int grid = (int)(work < 4096 ? work : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_dtype == 0)
+        hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, master, m, v,
+                           (bf16_t*)p16, (const bf16_t*)g, n, lr, beta1, beta2, eps, weight_decay, bc1,
+                           bc2, gscale, clip_coef);
+    else
+        hipLaunchKernelGGL(adamw_kernel<float>, dim3(grid), dim3(256), 0, st, master, m, v,
+                           (bf16_t*)p16, (const float*)g, n, lr, beta1, beta2, eps, weight_decay, bc1,
+                           bc2, gscale, clip_coef);
+    AA_CHECK_LAUNCH("aa_adamw_flat");
+    return AA_OK;
+}

@@ -1,0 +1,318 @@
+"""Thin torch-tensor wrappers over the C ABI (include/aa_hip.h).
+
+torch is used here only as the owner of device memory and streams: every function passes raw device
+pointers, sizes and the current HIP stream to libaa_hip.so.  Nothing in this module computes on the
+CPU or falls back to torch ops.
+"""
+from __future__ import annotations
+
+import torch
+
+from .lib import call
+
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3, 4
+GEMM_A_T, GEMM_B_N, GEMM_OUT_F32, GEMM_ACCUM = 1, 2, 4, 8
+ACT_CODES = {None: 0, 'none': 0, 'gelu': 1, 'quick_gelu': 2, 'relu': 3, 'silu': 4}
+
+bf16 = torch.bfloat16
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f'{name}: tensor must live on the GPU (the hot path has no CPU fallback)')
+    if t.dtype != dtype:
+        raise RuntimeError(f'{name}: expected {dtype}, got {t.dtype}')
+
+
+def _row_major(t: torch.Tensor, name: str):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError(f'{name}: expected a 2-D tensor with unit inner stride, got {tuple(t.shape)} / {t.stride()}')
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=False, out_f32=False,
+         accumulate=False):
+    """C[M,N] (+)= op(A) @ op(B)^T-ish:  a is [M,K] (or [K,M] when a_t), b is [N,K] (or [K,N] when b_n)."""
+    _chk(a, bf16, 'gemm.a'); _chk(b, bf16, 'gemm.b')
+    _row_major(a, 'gemm.a'); _row_major(b, 'gemm.b')
+    if a_t:
+        K, M = a.shape
+    else:
+        M, K = a.shape
+    if b_n:
+        Kb, N = b.shape
+    else:
+        N, Kb = b.shape
+    if K != Kb:
+        raise RuntimeError(f'gemm: contraction mismatch {K} vs {Kb}')
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else bf16, device=a.device)
+    else:
+        _row_major(out, 'gemm.out')
+        if tuple(out.shape) != (M, N):
+            raise RuntimeError(f'gemm: out shape {tuple(out.shape)} != {(M, N)}')
+    flags = (GEMM_A_T if a_t else 0) | (GEMM_B_N if b_n else 0) | \
+            (GEMM_OUT_F32 if out.dtype == torch.float32 else 0) | (GEMM_ACCUM if accumulate else 0)
+    ldr = residual.stride(0) if residual is not None else 0
+    call('aa_gemm_bf16', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0),
+         out.stride(0), _p(bias), _p(residual), ldr, int(act), flags, stream())
+    return out
+
+
+def gemm_set_tile(tile: int) -> None:
+    call('aa_gemm_set_tile', int(tile))
+
+
+# ------------------------------------------------------------------ norms
+def rmsnorm_fwd(x, w, eps, out=None, rstd=None):
+    rows, h = x.shape
+    out = torch.empty_like(x) if out is None else out
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if rstd is None else rstd
+    call('aa_rmsnorm_fwd', x.data_ptr(), w.data_ptr(), out.data_ptr(), rstd.data_ptr(), rows, h, float(eps), stream())
+    return out, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dw, dx=None, add_to_dx=False):
+    rows, h = x.shape
+    dx = torch.empty_like(x) if dx is None else dx
+    call('aa_rmsnorm_bwd', dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dw),
+         rows, h, int(add_to_dx), stream())
+    return dx
+
+
+def layernorm_fwd(x, w, b, eps, out=None, want_stats=True):
+    rows, h = x.shape
+    out = torch.empty_like(x) if out is None else out
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call('aa_layernorm_fwd', x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), _p(mean), _p(rstd),
+         rows, h, float(eps), stream())
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dx=None, add_to_dx=False):
+    rows, h = x.shape
+    dx = torch.empty_like(x) if dx is None else dx
+    call('aa_layernorm_bwd', dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+         dx.data_ptr(), _p(dw), _p(db), rows, h, int(add_to_dx), stream())
+    return dx
+
+
+# ------------------------------------------------------------------ pointwise
+def rope_(buf, col0, nheads, hd, pos, cos_t, sin_t, inverse=False):
+    rows = buf.shape[0]
+    call('aa_rope_inplace', buf.data_ptr(), buf.stride(0), int(col0), int(nheads), int(hd), pos.data_ptr(),
+         cos_t.data_ptr(), sin_t.data_ptr(), rows, int(inverse), stream())
+    return buf
+
+
+def swiglu_fwd(gate_up, out=None):
+    M, F2 = gate_up.shape
+    F = F2 // 2
+    out = torch.empty((M, F), dtype=bf16, device=gate_up.device) if out is None else out
+    call('aa_swiglu_fwd', gate_up.data_ptr(), out.data_ptr(), M, F, stream())
+    return out
+
+
+def swiglu_bwd(gate_up, dact, out=None):
+    M, F2 = gate_up.shape
+    out = torch.empty_like(gate_up) if out is None else out
+    call('aa_swiglu_bwd', gate_up.data_ptr(), dact.data_ptr(), out.data_ptr(), M, F2 // 2, stream())
+    return out
+
+
+def act_fwd(x, act, out=None):
+    out = torch.empty_like(x) if out is None else out
+    call('aa_act_fwd', x.data_ptr(), out.data_ptr(), x.numel(), int(act), stream())
+    return out
+
+
+def act_bwd(pre, dy, act, out=None):
+    out = torch.empty_like(pre) if out is None else out
+    call('aa_act_bwd', pre.data_ptr(), dy.data_ptr(), out.data_ptr(), pre.numel(), int(act), stream())
+    return out
+
+
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    call('aa_add', a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), stream())
+    return out
+
+
+# ------------------------------------------------------------------ embedding
+def image_slot_index(ids_flat, image_token_id):
+    n = ids_flat.numel()
+    slot = torch.empty(n, dtype=torch.int32, device=ids_flat.device)
+    count = torch.empty(1, dtype=torch.int32, device=ids_flat.device)
+    call('aa_image_slot_index', ids_flat.data_ptr(), n, int(image_token_id), slot.data_ptr(), count.data_ptr(), stream())
+    return slot, count
+
+
+def embed_fwd(ids_flat, E, slot=None, feat=None, pos=None, P=None):
+    n = ids_flat.numel()
+    vocab, h = E.shape
+    out = torch.empty((n, h), dtype=bf16, device=E.device)
+    call('aa_embed_fwd', ids_flat.data_ptr(), _p(slot), E.data_ptr(), _p(feat), _p(pos), _p(P), out.data_ptr(),
+         n, h, vocab, stream())
+    return out
+
+
+def embed_bwd(ids_flat, dx, vocab, slot=None, pos=None, dE=None, dfeat=None, dP=None):
+    n, h = dx.shape
+    call('aa_embed_bwd', ids_flat.data_ptr(), _p(slot), _p(pos), dx.data_ptr(), _p(dE), _p(dfeat), _p(dP), n, h,
+         int(vocab), stream())
+
+
+def transpose(x, out=None, pad_cols_to=None):
+    """out[C, R(+pad)] = x[R, C]^T ; padding columns (if any) must already be zero in `out`."""
+    R, C = x.shape
+    if out is None:
+        Rp = R if pad_cols_to is None else pad_cols_to
+        out = torch.zeros((C, Rp), dtype=bf16, device=x.device) if Rp != R else \
+            torch.empty((C, R), dtype=bf16, device=x.device)
+    call('aa_transpose_bf16', x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, C, stream())
+    return out
+
+
+def colsum_(x, out_f32):
+    R, C = x.shape
+    call('aa_colsum_bf16', x.data_ptr(), x.stride(0), R, C, out_f32.data_ptr(), stream())
+    return out_f32
+
+
+def patch_im2col(pixels, patch, Kp):
+    n_img, ch, H, W = pixels.shape
+    G = H // patch
+    out = torch.empty((n_img * G * G, Kp), dtype=bf16, device=pixels.device)
+    dt = 0 if pixels.dtype == bf16 else 1
+    if pixels.dtype not in (bf16, torch.float32):
+        raise RuntimeError(f'patch_im2col: pixel dtype {pixels.dtype} not supported')
+    call('aa_patch_im2col', pixels.data_ptr(), dt, out.data_ptr(), n_img, ch, H, int(patch), int(Kp), stream())
+    return out
+
+
+def clip_embed(patch_emb, cls, pos, n_img, G2):
+    h = patch_emb.shape[1]
+    out = torch.empty((n_img * (G2 + 1), h), dtype=bf16, device=patch_emb.device)
+    call('aa_clip_embed', patch_emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), n_img, G2, h, stream())
+    return out
+
+
+def f32_to_bf16(x, out=None):
+    out = torch.empty(x.shape, dtype=bf16, device=x.device) if out is None else out
+    call('aa_f32_to_bf16', x.data_ptr(), out.data_ptr(), x.numel(), stream())
+    return out
+
+
+# ------------------------------------------------------------------ attention
+def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None):
+    """q/k/v: 2-D views [N*T, >=H*hd] (column slices of the fused qkv buffer are fine)."""
+    out = torch.empty((N * T, H * hd), dtype=bf16, device=q.device) if out is None else out
+    lse = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
+    call('aa_attn_fwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(start),
+         q.stride(0), k.stride(0), v.stride(0), out.stride(0), N, T, H, Hkv, hd, int(causal), float(scale), stream())
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start=None):
+    delta = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
+    call('aa_attn_bwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+         delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(start), q.stride(0), k.stride(0),
+         v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), N, T, H, Hkv, hd,
+         int(causal), float(scale), stream())
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------ RLHF math
+def logprob_gather_fwd(logits, labels, round_bf16=False):
+    rows, V = logits.shape
+    dt = 0 if logits.dtype == bf16 else 1
+    logp = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    call('aa_logprob_gather_fwd', logits.data_ptr(), logits.stride(0), labels.data_ptr(), logp.data_ptr(),
+         lse.data_ptr(), rows, V, dt, int(round_bf16), stream())
+    return logp, lse
+
+
+def logprob_gather_bwd(logits, labels, lse, dlogp, out=None):
+    rows, V = logits.shape
+    dt = 0 if logits.dtype == bf16 else 1
+    out = torch.empty_like(logits) if out is None else out
+    call('aa_logprob_gather_bwd', logits.data_ptr(), logits.stride(0), labels.data_ptr(), lse.data_ptr(),
+         dlogp.data_ptr(), out.data_ptr(), out.stride(0), rows, V, dt, stream())
+    return out
+
+
+def dpo_loss(pol_logp, ref_logp, seq_off, B, beta, want_grad=True):
+    dev = pol_logp.device
+    out6 = torch.empty(6, dtype=torch.float32, device=dev)
+    per = torch.empty((4, B), dtype=torch.float32, device=dev)
+    dlogp = torch.empty_like(pol_logp) if want_grad else None
+    call('aa_dpo_loss_fwd_bwd', pol_logp.data_ptr(), ref_logp.data_ptr(), seq_off.data_ptr(), int(B), float(beta),
+         out6.data_ptr(), per.data_ptr(), _p(dlogp), stream())
+    return out6, per, dlogp
+
+
+def kl_reward(reward, logp, ref_logp, mask_u8, kl_coeff, clip):
+    B, L = logp.shape
+    out = torch.empty_like(logp)
+    end = torch.empty(B, dtype=torch.int32, device=logp.device)
+    call('aa_kl_reward', reward.data_ptr(), logp.data_ptr(), ref_logp.data_ptr(), mask_u8.data_ptr(), B, L,
+         float(kl_coeff), float(clip), out.data_ptr(), end.data_ptr(), stream())
+    return out, end
+
+
+def gae(values, rewards, mask_u8, start, gamma, lam):
+    B, L = values.shape
+    adv = torch.empty((B, L - start), dtype=torch.float32, device=values.device)
+    ret = torch.empty_like(adv)
+    call('aa_gae', values.data_ptr(), rewards.data_ptr(), mask_u8.data_ptr(), B, L, int(start), float(gamma),
+         float(lam), adv.data_ptr(), ret.data_ptr(), stream())
+    return adv, ret
+
+
+def ppo_actor_loss(logp, old_logp, adv, mask_u8, clip_ratio, want_grad=True):
+    B, L = logp.shape
+    scratch = torch.empty(B, dtype=torch.float32, device=logp.device)
+    loss = torch.empty(1, dtype=torch.float32, device=logp.device)
+    d = torch.empty_like(logp) if want_grad else None
+    call('aa_ppo_actor_loss', logp.data_ptr(), old_logp.data_ptr(), adv.data_ptr(), mask_u8.data_ptr(), B, L,
+         float(clip_ratio), scratch.data_ptr(), loss.data_ptr(), _p(d), stream())
+    return loss, d
+
+
+def ppo_critic_loss(values, old_values, returns, mask_u8, clip_value, want_grad=True):
+    B, L = values.shape
+    scratch = torch.empty(B, dtype=torch.float32, device=values.device)
+    loss = torch.empty(1, dtype=torch.float32, device=values.device)
+    d = torch.empty_like(values) if want_grad else None
+    call('aa_ppo_critic_loss', values.data_ptr(), old_values.data_ptr(), returns.data_ptr(), mask_u8.data_ptr(), B, L,
+         float(clip_value), scratch.data_ptr(), loss.data_ptr(), _p(d), stream())
+    return loss, d
+
+
+# ------------------------------------------------------------------ optimizer
+def grad_sumsq_(g, out_accum, scale=1.0):
+    dt = 0 if g.dtype == bf16 else 1
+    call('aa_grad_sumsq', g.data_ptr(), dt, g.numel(), float(scale), out_accum.data_ptr(), stream())
+
+
+def clip_coef(sumsq, max_norm, coef_out, norm_out=None):
+    call('aa_clip_coef', sumsq.data_ptr(), float(max_norm), coef_out.data_ptr(), _p(norm_out), stream())
+
+
+def adamw_flat_(master, m, v, p16, g, lr, beta1, beta2, eps, wd, step, gscale=1.0, clip=None):
+    dt = 0 if g.dtype == bf16 else 1
+    call('aa_adamw_flat', master.data_ptr(), m.data_ptr(), v.data_ptr(), p16.data_ptr(), g.data_ptr(), dt,
+         master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), float(gscale),
+         _p(clip), stream())

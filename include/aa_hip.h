@@ -1,0 +1,139 @@
+/*
+ * aa_hip.h -- C ABI of libaa_hip.so, the MI355X (gfx950) drop-in for the DPO/PPO inner loop of
+ * PKU-Alignment/align-anything.
+ *
+ * The reference has no FFI: its hot path reaches accelerated code only through Python APIs
+ * (torch ops, HF transformers modules, DeepSpeed FusedAdam).  Each entry point below replaces one
+ * of those calls; the citation names the reference (or, prefixed hf:, the HuggingFace transformers)
+ * site it stands in for.  INTEGRATION.md shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions: every pointer is a DEVICE pointer owned by the caller unless stated otherwise;
+ * `stream` is a hipStream_t; bf16 tensors are raw 16-bit words (torch.bfloat16 layout), row-major with
+ * an explicit leading dimension in ELEMENTS; functions return 0 on success, <0 on error, and
+ * aa_last_error() then returns a thread-local message (the Python side raises RuntimeError).
+ * No function synchronises the device or allocates memory.
+ */
+#ifndef AA_HIP_H
+#define AA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activation codes (GEMM epilogue, aa_act_*) */
+#define AA_ACT_NONE 0
+#define AA_ACT_GELU 1
+#define AA_ACT_QUICK_GELU 2
+#define AA_ACT_RELU 3
+#define AA_ACT_SILU 4
+/* aa_gemm_bf16 flags */
+#define AA_GEMM_A_T 1     /* A stored [K][M] */
+#define AA_GEMM_B_N 2     /* B stored [K][N] */
+#define AA_GEMM_OUT_F32 4 /* C is fp32 */
+#define AA_GEMM_ACCUM 8   /* C += A*B */
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+const char* aa_last_error(void);
+int aa_version(void);
+int aa_device_info(int* cu_count, int* lds_per_cu, int* wave_size, char* arch, int arch_len);
+int aa_event_create(void** ev);
+int aa_event_record(void* ev, void* stream);
+int aa_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+int aa_event_destroy(void* ev);
+int aa_probe_mfma(float* out256, int row_sel, void* stream);
+int aa_probe_tr16(const int* addr64, float* out256, void* stream);
+
+/* ---- RLHF scalar math ----------------------------------------------------------------------- */
+/* align_anything/utils/tools.py:402-413 gather_log_probabilities = log_softmax + gather.
+ * logits [rows, V] (dtype 0 = bf16, 1 = f32), labels int64[rows] -> logp f32[rows], lse f32[rows].
+ * round_bf16 != 0 rounds logp through bf16 (what the reference returns for bf16 logits). */
+int aa_logprob_gather_fwd(const void* logits, long ld, const int64_t* labels, float* logp, float* lse,
+                          int rows, int V, int dtype, int round_bf16, void* stream);
+/* autograd backward of the above; dlogits may alias logits */
+int aa_logprob_gather_bwd(const void* logits, long ld, const int64_t* labels, const float* lse,
+                          const float* dlogp, void* dlogits, long ldd, int rows, int V, int dtype,
+                          void* stream);
+/* align_anything/trainers/text_to_text/dpo.py:144-203 DPOTrainer.loss (forward + d loss/d logp).
+ * sequences [0,B) better, [B,2B) worse; per-token log-probs flat, sequence s = rows
+ * [seq_off[s], seq_off[s+1]).  out6 = loss, reward_accuracy, mean reward, mean better, mean worse,
+ * mean margin; per_sample4B = better_reward[B], worse_reward[B], reward[B], margin[B]. */
+int aa_dpo_loss_fwd_bwd(const float* pol_logp, const float* ref_logp, const int* seq_off, int B,
+                        float beta, float* out6, float* per_sample4B, float* dlogp, void* stream);
+/* trainers/text_to_text/ppo.py:528-547 add_kl_divergence_regularization */
+int aa_kl_reward(const float* reward, const float* logp, const float* ref_logp, const uint8_t* mask,
+                 int B, int L, float kl_coeff, float clip, float* rewards_out, int* end_index_out,
+                 void* stream);
+/* trainers/text_to_text/ppo.py:487-508 get_advantages_and_returns (adv/ret are [B, L-start]) */
+int aa_gae(const float* values, const float* rewards, const uint8_t* mask, int B, int L, int start,
+           float gamma, float lam, float* adv, float* ret, void* stream);
+/* trainers/text_to_text/ppo.py:291-307 actor_loss_fn (+ utils/tools.py:460-467 masked_mean) */
+int aa_ppo_actor_loss(const float* logp, const float* old_logp, const float* adv, const uint8_t* mask,
+                      int B, int L, float clip_ratio, float* row_scratch, float* loss_out, float* dlogp,
+                      void* stream);
+/* trainers/text_to_text/ppo.py:510-526 critic_loss_fn */
+int aa_ppo_critic_loss(const float* values, const float* old_values, const float* returns,
+                       const uint8_t* mask, int B, int L, float clip_value, float* row_scratch,
+                       float* loss_out, float* dvalues, void* stream);
+
+/* ---- transformer blocks (what model(**batch).logits executes, dpo.py:128) -------------------- */
+/* torch nn.Linear / its backward: C[M,N] (+)= op(A) op(B), fp32 accumulate, fused bias/act/residual.
+ * K % 64 == 0 (zero-pad), N % 4 == 0. */
+int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,
+                 long ldc, const void* bias, const void* residual, long ldr, int act, int flags,
+                 void* stream);
+int aa_gemm_set_tile(int tile);
+/* hf:models/llama/modeling_llama.py:62-67 LlamaRMSNorm */
+int aa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int h, float eps,
+                   void* stream);
+int aa_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, float* dw,
+                   int rows, int h, int add_to_dx, void* stream);
+/* torch F.layer_norm (CLIP, OPT) */
+int aa_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
+                     int rows, int h, float eps, void* stream);
+int aa_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
+                     void* dx, float* dw, float* db, int rows, int h, int add_to_dx, void* stream);
+/* hf:models/llama/modeling_llama.py:113-160 rotary embedding, in place, inverse = backward */
+int aa_rope_inplace(void* buf, long ld, int col0, int nheads, int hd, const int* pos, const void* cos_t,
+                    const void* sin_t, long rows, int inverse, void* stream);
+/* hf:models/llama/modeling_llama.py:163-176 LlamaMLP gate: silu(gate)*up on [M, 2F] -> [M, F] */
+int aa_swiglu_fwd(const void* gate_up, void* out, long M, int F, void* stream);
+int aa_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, long M, int F, void* stream);
+int aa_act_fwd(const void* x, void* y, long n, int act, void* stream);
+int aa_act_bwd(const void* pre, const void* dy, void* dx, long n, int act, void* stream);
+int aa_add(const void* a, const void* b, void* y, long n, void* stream);
+/* hf:models/llava/modeling_llava.py:234-248 embed_tokens + masked_scatter of image features */
+int aa_image_slot_index(const int64_t* ids, int n, int64_t image_token_id, int* slot, int* count,
+                        void* stream);
+int aa_embed_fwd(const int64_t* ids, const int* slot, const void* E, const void* feat, const int* pos,
+                 const void* P, void* out, long n, int h, int vocab, void* stream);
+int aa_embed_bwd(const int64_t* ids, const int* slot, const int* pos, const void* dx, float* dE,
+                 void* dfeat, float* dP, long n, int h, int vocab, void* stream);
+int aa_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C, void* stream);
+int aa_colsum_bf16(const void* in, long ld, long R, int C, float* out, void* stream);
+/* hf:models/clip/modeling_clip.py:138-218 CLIPVisionEmbeddings (patch conv as im2col + GEMM) */
+int aa_patch_im2col(const void* pixels, int pix_dtype, void* out, int n_img, int channels,
+                    int image_size, int patch, int Kp, void* stream);
+int aa_clip_embed(const void* patch, const void* cls, const void* pos, void* out, int n_img, int G2,
+                  int h, void* stream);
+int aa_f32_to_bf16(const float* in, void* out, long n, void* stream);
+/* torch SDPA in hf:models/llama/modeling_llama.py:243-281 / clip :289 / opt attention.
+ * start[n] = first valid key of left-padded sequence n (or NULL). lse f32[N,H,T]. */
+int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, const int* start,
+                long ldq, long ldk, long ldv, long ldo, int N, int T, int H, int Hkv, int hd, int causal,
+                float scale, void* stream);
+int aa_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                const float* lse, float* delta, void* dQ, void* dK, void* dV, const int* start, long ldq,
+                long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, int N, int T,
+                int H, int Hkv, int hd, int causal, float scale, void* stream);
+
+/* ---- optimizer (DeepSpeed FusedAdam + gradient_clipping, supervised_trainer.py:245-249) ------ */
+int aa_grad_sumsq(const void* g, int g_dtype, long n, float scale, float* out_accum, void* stream);
+int aa_clip_coef(const float* sumsq, float max_norm, float* coef_out, float* norm_out, void* stream);
+int aa_adamw_flat(float* master, float* m, float* v, void* p16, const void* g, int g_dtype, long n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  float gscale, const float* clip_coef, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AA_HIP_H */

@@ -1,0 +1,232 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by running the REFERENCE ITSELF
+(/root/reference, imported unmodified through oracle/_shim.py) and HuggingFace model classes on CPU.
+
+Runs only in the build container (the reference is not present on the GPU box); the produced
+fixtures are committed.   python -m oracle.gen_golden
+"""
+from __future__ import annotations
+
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import _shim  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def bf16_bits(t: torch.Tensor) -> np.ndarray:
+    return t.detach().to(torch.bfloat16).contiguous().view(torch.int16).numpy().astype(np.uint16)
+
+
+def gen_rl_math():
+    from align_anything.trainers.text_to_text.ppo import PPOTrainer
+    from align_anything.utils.tools import gather_log_probabilities, masked_mean
+
+    g = torch.Generator().manual_seed(20250921)
+    out = {}
+    # --- gather_log_probabilities (utils/tools.py:402-413), fp32 and bf16 logits
+    rows, V = 37, 1000
+    logits = torch.randn(1, rows, V, generator=g) * 3.0
+    labels = torch.randint(0, V, (1, rows), generator=g)
+    out['glp_logits'] = logits[0].numpy()
+    out['glp_labels'] = labels[0].numpy()
+    out['glp_out_f32'] = gather_log_probabilities(logits, labels)[0].numpy()
+    lb = logits.to(torch.bfloat16)
+    out['glp_logits_bf16'] = bf16_bits(lb[0])
+    out['glp_out_bf16'] = gather_log_probabilities(lb, labels)[0].float().numpy()
+    # --- masked_mean (utils/tools.py:460-467)
+    B, L = 5, 23
+    x = torch.randn(B, L, generator=g)
+    mask = torch.rand(B, L, generator=g) > 0.3
+    mask[:, 0] = True
+    out['mm_x'] = x.numpy(); out['mm_mask'] = mask.numpy()
+    out['mm_out'] = masked_mean(x, mask).numpy()
+    # --- PPO pieces, called unbound on a bare namespace carrying the hyper-parameters
+    hp = SimpleNamespace(kl_coeff=0.02, clip_range_score=50.0, gamma=1.0, gae_lambda=0.95,
+                         clip_range_ratio=0.2, clip_range_value=5.0)
+    logp = -torch.rand(B, L, generator=g) * 4
+    ref = -torch.rand(B, L, generator=g) * 4
+    reward = torch.randn(B, generator=g) * 30  # large enough that the clamp sometimes bites
+    seqmask = torch.zeros(B, L, dtype=torch.bool)
+    for b, n in enumerate([23, 17, 9, 1, 20]):
+        seqmask[b, :n] = True
+    rew = PPOTrainer.add_kl_divergence_regularization(hp, reward, logp, ref, seqmask)
+    out.update(ppo_logp=logp.numpy(), ppo_ref=ref.numpy(), ppo_reward=reward.numpy(), ppo_mask=seqmask.numpy(),
+               ppo_kl_rewards=rew.numpy())
+    values = torch.randn(B, L, generator=g)
+    for start in (0, 4):
+        adv, ret = PPOTrainer.get_advantages_and_returns(hp, values, rew, seqmask, start)
+        out[f'ppo_adv_s{start}'] = adv.numpy(); out[f'ppo_ret_s{start}'] = ret.numpy()
+    out['ppo_values'] = values.numpy()
+    adv0 = torch.from_numpy(out['ppo_adv_s0'])
+    ret0 = torch.from_numpy(out['ppo_ret_s0'])
+    new_logp = (logp + 0.3 * torch.randn(B, L, generator=g)).requires_grad_(True)
+    al = PPOTrainer.actor_loss_fn(hp, new_logp, logp, adv0, seqmask)
+    al.backward()
+    out.update(ppo_new_logp=new_logp.detach().numpy(), ppo_actor_loss=al.detach().numpy(),
+               ppo_actor_grad=new_logp.grad.numpy())
+    new_values = (values + 3.0 * torch.randn(B, L, generator=g)).requires_grad_(True)
+    cl = PPOTrainer.critic_loss_fn(hp, new_values, values, ret0, seqmask)
+    cl.backward()
+    out.update(ppo_new_values=new_values.detach().numpy(), ppo_critic_loss=cl.detach().numpy(),
+               ppo_critic_grad=new_values.grad.numpy())
+    np.savez_compressed(os.path.join(GOLD, 'rl_math.npz'), **out)
+    print('rl_math.npz', {k: v.shape for k, v in out.items()})
+
+
+def tiny_llava():
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig, LlavaForConditionalGeneration
+    vc = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                          image_size=28, patch_size=14)
+    tc = LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                     num_key_value_heads=2, vocab_size=320, rms_norm_eps=1e-5, max_position_embeddings=256)
+    cfg = LlavaConfig(vision_config=vc, text_config=tc, image_token_id=300, image_seq_length=4)
+    torch.manual_seed(42)
+    m = LlavaForConditionalGeneration(cfg)
+    # random-init at std 0.02 gives near-uniform logits; widen so the parity check is informative
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+            # store bf16-representable values so bf16 and fp32 runs share the same weights
+            p.copy_(p.to(torch.bfloat16).to(torch.float32))
+    return cfg, m.eval()
+
+
+def make_llava_batch(g, B=2, T=48, n_img_tok=4, pad_id=301, image_id=300, left_pad=(0, 5, 0, 3), resp=(12, 9, 7, 12)):
+    """PreferenceCollator layout (datasets/text_image_to_text/preference.py:215-263): rows [0,B) chosen,
+    [B,2B) rejected, LEFT padded, same image for chosen/rejected."""
+    N = 2 * B
+    ids = torch.full((N, T), pad_id, dtype=torch.long)
+    mask = torch.zeros((N, T), dtype=torch.long)
+    for r in range(N):
+        lp = left_pad[r]
+        n_txt = T - lp - 1 - n_img_tok
+        row = torch.cat([torch.tensor([1]), torch.full((n_img_tok,), image_id),
+                         torch.randint(3, 299, (n_txt,), generator=g)])
+        ids[r, lp:] = row
+        mask[r, lp:] = 1
+    pix1 = torch.randn(B, 3, 28, 28, generator=g)
+    pixel_values = torch.cat([pix1, pix1], 0)
+    return {'input_ids': ids, 'attention_mask': mask, 'pixel_values': pixel_values,
+            'meta_info': {'response_lens': list(resp)}}
+
+
+def gen_llava_dpo():
+    """Drive the reference's unmodified DPOTrainer.loss / compute_log_probs
+    (trainers/text_image_to_text/dpo.py:85-166) on a tiny random LLaVA, fp32, CPU."""
+    from align_anything.trainers.text_image_to_text.dpo import DPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+
+    cfg, policy = tiny_llava()
+    _, refm = tiny_llava()
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():  # perturb the reference model so the log-ratio is non-trivial
+        for p in refm.parameters():
+            p.add_((0.02 * torch.randn(p.shape, generator=g)))
+            p.copy_(p.to(torch.bfloat16).to(torch.float32))
+    batch = make_llava_batch(g)
+    tr = DPOTrainer.__new__(DPOTrainer)
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+    tr.tokenizer = SimpleNamespace(pad_token_id=301)
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    tr.model = SimpleNamespace(module=policy)
+    tr.reference_model = SimpleNamespace(module=refm)
+    policy.zero_grad()
+    seq_lp = tr.compute_log_probs(policy, batch)
+    ref_lp = tr.compute_log_probs(refm, batch).detach()
+    ld = tr.loss(batch)
+    ld['loss'].backward()
+    with torch.no_grad():
+        logits = policy(**tr.infer_batch(batch)).logits
+    out = {
+        'input_ids': batch['input_ids'].numpy(), 'attention_mask': batch['attention_mask'].numpy(),
+        'pixel_values': batch['pixel_values'].numpy(), 'response_lens': np.array(batch['meta_info']['response_lens']),
+        'pad_token_id': np.array(301), 'scale_coeff': np.array(0.1),
+        'policy_logits': logits.numpy(), 'seq_log_probs': seq_lp.detach().numpy(), 'ref_seq_log_probs': ref_lp.numpy(),
+    }
+    for k, v in ld.items():
+        out['loss_' + k] = v.detach().numpy()
+    for n, p in policy.named_parameters():
+        out['w.' + n] = bf16_bits(p)
+        if p.grad is not None:
+            out['g.' + n] = p.grad.numpy()
+    for n, p in refm.named_parameters():
+        out['r.' + n] = bf16_bits(p)
+    cfgd = {'vision': dict(hidden_size=128, intermediate_size=256, num_layers=3, num_heads=2, image_size=28, patch_size=14),
+            'text': dict(hidden_size=128, intermediate_size=256, num_layers=2, num_heads=2, num_kv_heads=2, vocab_size=320)}
+    out['cfg_json'] = np.array(repr(cfgd))
+    np.savez_compressed(os.path.join(GOLD, 'llava_tiny_dpo.npz'), **out)
+    print('llava_tiny_dpo.npz loss', float(ld['loss']), 'acc', float(ld['reward_accuracy']),
+          'n arrays', len(out))
+
+
+def gen_opt_dpo():
+    """Same for the text-to-text trainer (trainers/text_to_text/dpo.py:122-203) on a tiny OPT
+    (hf:models/opt/modeling_opt.py), dropout 0, with a left-padded row."""
+    from transformers import OPTConfig, OPTForCausalLM
+    from align_anything.trainers.text_to_text.dpo import DPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+
+    oc = OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=320,
+                   max_position_embeddings=128, word_embed_proj_dim=128, dropout=0.0, attention_dropout=0.0,
+                   pad_token_id=1)
+    torch.manual_seed(3)
+    policy = OPTForCausalLM(oc).eval()
+    torch.manual_seed(3)
+    refm = OPTForCausalLM(oc).eval()
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for p in policy.parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+            p.copy_(p.to(torch.bfloat16).to(torch.float32))
+        policy.model.decoder.embed_tokens.weight[1].zero_()  # padding_idx row stays zero in HF
+        for p, q in zip(refm.parameters(), policy.parameters()):
+            p.copy_((q + 0.02 * torch.randn(q.shape, generator=g)).to(torch.bfloat16).to(torch.float32))
+    N, T = 4, 40
+    ids = torch.full((N, T), 1, dtype=torch.long)
+    mask = torch.zeros((N, T), dtype=torch.long)
+    for r, lp in enumerate((0, 6, 2, 0)):
+        ids[r, lp:] = torch.randint(3, 320, (T - lp,), generator=g)
+        mask[r, lp:] = 1
+    batch = {'input_ids': ids, 'attention_mask': mask, 'meta_info': {'response_lens': [10, 8, 12, 5]}}
+    tr = DPOTrainer.__new__(DPOTrainer)
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+    tr.tokenizer = SimpleNamespace(pad_token_id=1)
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    tr.model = SimpleNamespace(module=policy)
+    tr.reference_model = SimpleNamespace(module=refm)
+    seq_lp = tr.compute_log_probs(policy, batch)
+    ld = tr.loss(batch)
+    ld['loss'].backward()
+    with torch.no_grad():
+        logits = policy(input_ids=ids, attention_mask=mask).logits
+    out = {'input_ids': ids.numpy(), 'attention_mask': mask.numpy(), 'response_lens': np.array([10, 8, 12, 5]),
+           'pad_token_id': np.array(1), 'scale_coeff': np.array(0.1), 'policy_logits': logits.numpy(),
+           'seq_log_probs': seq_lp.detach().numpy()}
+    for k, v in ld.items():
+        out['loss_' + k] = v.detach().numpy()
+    for n, p in policy.state_dict().items():
+        out['w.' + n] = bf16_bits(p)
+    for n, p in policy.named_parameters():
+        if p.grad is not None:
+            out['g.' + n] = p.grad.numpy()
+    for n, p in refm.state_dict().items():
+        out['r.' + n] = bf16_bits(p)
+    np.savez_compressed(os.path.join(GOLD, 'opt_tiny_dpo.npz'), **out)
+    print('opt_tiny_dpo.npz loss', float(ld['loss']))
+
+
+if __name__ == '__main__':
+    _shim.install()
+    os.makedirs(GOLD, exist_ok=True)
+    gen_rl_math()
+    gen_llava_dpo()
+    gen_opt_dpo()

@@ -1,0 +1,125 @@
+"""CPU: pin the oracle (oracle/*.py) against fixtures produced by the reference itself
+(oracle/gen_golden.py ran /root/reference's unmodified functions + HF modules)."""
+import numpy as np
+import torch
+
+from oracle import models as om
+from oracle import rl_math as orl
+from tests.util import bits_to_bf16, load_golden, state_dict_from_golden, tiny_llava_cfg, tiny_opt_cfg
+
+T = torch.from_numpy
+
+
+def test_gather_log_probabilities_matches_reference():
+    z = load_golden('rl_math.npz')
+    out = orl.gather_log_probabilities(T(z['glp_logits'])[None], T(z['glp_labels'])[None])[0]
+    assert torch.equal(out, T(z['glp_out_f32']))  # same torch ops -> bit-exact
+    lb = bits_to_bf16(z['glp_logits_bf16'])
+    outb = orl.gather_log_probabilities(lb[None], T(z['glp_labels'])[None])[0].float()
+    assert torch.equal(outb, T(z['glp_out_bf16']))
+
+
+def test_masked_mean_and_ppo_math_match_reference():
+    z = load_golden('rl_math.npz')
+    assert torch.equal(orl.masked_mean(T(z['mm_x']), T(z['mm_mask'])), T(z['mm_out']))
+    mask = T(z['ppo_mask'])
+    rew = orl.add_kl_divergence_regularization(T(z['ppo_reward']), T(z['ppo_logp']), T(z['ppo_ref']), mask, 0.02, 50.0)
+    assert torch.equal(rew, T(z['ppo_kl_rewards']))
+    for start in (0, 4):
+        adv, ret = orl.get_advantages_and_returns(T(z['ppo_values']), rew, mask, start, 1.0, 0.95)
+        assert torch.equal(adv, T(z[f'ppo_adv_s{start}']))
+        assert torch.equal(ret, T(z[f'ppo_ret_s{start}']))
+    nl = T(z['ppo_new_logp']).clone().requires_grad_(True)
+    al = orl.actor_loss_fn(nl, T(z['ppo_logp']), T(z['ppo_adv_s0']), mask, 0.2)
+    al.backward()
+    assert torch.equal(al.detach(), T(z['ppo_actor_loss']))
+    assert torch.equal(nl.grad, T(z['ppo_actor_grad']))
+    nv = T(z['ppo_new_values']).clone().requires_grad_(True)
+    cl = orl.critic_loss_fn(nv, T(z['ppo_values']), T(z['ppo_ret_s0']), mask, 5.0)
+    cl.backward()
+    assert torch.equal(cl.detach(), T(z['ppo_critic_loss']))
+    assert torch.equal(nv.grad, T(z['ppo_critic_grad']))
+
+
+def _llava_oracle_run(z, prefix):
+    sd = state_dict_from_golden(z, prefix)
+    for v in sd.values():
+        v.requires_grad_(True)
+    cfg = tiny_llava_cfg()
+    logits = om.llava_logits(sd, cfg, T(z['input_ids']), T(z['attention_mask']), T(z['pixel_values']))
+    return sd, logits
+
+
+def test_llava_oracle_matches_reference_dpo_loss_and_grads():
+    """oracle model + oracle DPO loss == reference DPOTrainer.loss on HF LlavaForConditionalGeneration."""
+    z = load_golden('llava_tiny_dpo.npz')
+    sd, logits = _llava_oracle_run(z, 'w.')
+    valid = T(z['attention_mask']).bool()
+    ref_logits = T(z['policy_logits'])
+    assert torch.allclose(logits[valid], ref_logits[valid], atol=2e-4, rtol=1e-4)
+    lens = [int(x) for x in z['response_lens']]
+    lp = orl.compute_log_probs(logits, T(z['input_ids']), lens, int(z['pad_token_id']))
+    assert lp.shape == T(z['seq_log_probs']).shape
+    assert torch.allclose(lp, T(z['seq_log_probs']), atol=2e-4)
+    # zero padding layout must be identical (integer/window logic)
+    assert torch.equal(lp == 0, T(z['seq_log_probs']) == 0)
+    with torch.no_grad():
+        _, rlogits = _llava_oracle_run(z, 'r.')
+        rlp = orl.compute_log_probs(rlogits, T(z['input_ids']), lens, int(z['pad_token_id']))
+    assert torch.allclose(rlp, T(z['ref_seq_log_probs']), atol=2e-4)
+    ld = orl.dpo_loss(lp, rlp, float(z['scale_coeff']))
+    for k in ('loss', 'reward', 'better_sample_reward', 'worse_sample_reward', 'reward_accuracy', 'reward_margin'):
+        assert torch.allclose(ld[k], T(z['loss_' + k]), atol=1e-4), k
+    ld['loss'].backward()
+    checked = 0
+    for k in z.files:
+        if k.startswith('g.'):
+            name = k[2:]
+            g = sd[name].grad
+            ref = T(z[k])
+            if g is None:
+                assert float(ref.abs().max()) == 0.0, name
+                continue
+            assert torch.allclose(g, ref, atol=2e-5 + 1e-3 * float(ref.abs().max())), name
+            checked += 1
+    assert checked > 20
+
+
+def test_opt_oracle_matches_reference_dpo_loss():
+    z = load_golden('opt_tiny_dpo.npz')
+    sd = state_dict_from_golden(z, 'w.')
+    logits = om.opt_logits(sd, tiny_opt_cfg(), T(z['input_ids']), T(z['attention_mask']))
+    valid = T(z['attention_mask']).bool()
+    assert torch.allclose(logits[valid], T(z['policy_logits'])[valid], atol=2e-4, rtol=1e-4)
+    lens = [int(x) for x in z['response_lens']]
+    lp = orl.compute_log_probs(logits, T(z['input_ids']), lens, int(z['pad_token_id']))
+    assert torch.allclose(lp, T(z['seq_log_probs']), atol=2e-4)
+    sdr = state_dict_from_golden(z, 'r.')
+    rl = om.opt_logits(sdr, tiny_opt_cfg(), T(z['input_ids']), T(z['attention_mask']))
+    rlp = orl.compute_log_probs(rl, T(z['input_ids']), lens, int(z['pad_token_id']))
+    ld = orl.dpo_loss(lp, rlp, float(z['scale_coeff']))
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < 1e-4
+
+
+def test_response_window_indexing_is_exact():
+    z = load_golden('llava_tiny_dpo.npz')
+    ids = T(z['input_ids'])
+    Tn = ids.shape[1]
+    for r, R in enumerate(z['response_lens']):
+        pos, labels = orl.response_window(ids[r], int(z['pad_token_id']), int(R), Tn)
+        assert pos.tolist() == list(range(Tn - int(R), Tn - 1))
+        assert torch.equal(labels, ids[r][ids[r] != int(z['pad_token_id'])][-int(R):][1:])
+
+
+def test_adamw_restatement_matches_torch_adamw():
+    """DeepSpeed FusedAdam is absent here; the restated update must agree with torch.optim.AdamW."""
+    torch.manual_seed(0)
+    p = torch.randn(1000); g = torch.randn(1000)
+    pt = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    m = torch.zeros(1000); v = torch.zeros(1000); q = p.clone()
+    for step in range(1, 6):
+        gs = g * step
+        pt.grad = gs.clone(); opt.step()
+        orl.adamw_step(q, gs, m, v, step, 1e-3, 0.9, 0.95, 1e-8, 0.05)
+    assert torch.allclose(q, pt.detach(), atol=1e-6)
