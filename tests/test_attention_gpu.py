@@ -1,0 +1,86 @@
+"""GPU: fused attention forward/backward (csrc/attention.hip) vs an explicit fp32 softmax reference."""
+import math
+
+import pytest
+import torch
+
+from tests.gpu_util import assert_close, dev, randn_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_attention(q, k, v, do, N, T, H, Hkv, hd, causal, scale, start):
+    """fp32 autograd reference on [N*T, H*hd] layouts; returns o, dq, dk, dv (pad rows zeroed)."""
+    qf = q.float().view(N, T, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    kf = k.float().view(N, T, Hkv, hd).transpose(1, 2).detach().requires_grad_(True)
+    vf = v.float().view(N, T, Hkv, hd).transpose(1, 2).detach().requires_grad_(True)
+    rep = H // Hkv
+    kk = kf.repeat_interleave(rep, 1); vv = vf.repeat_interleave(rep, 1)
+    s = (qf @ kk.transpose(-1, -2)) * scale
+    idx = torch.arange(T, device=q.device)
+    mask = torch.zeros(N, 1, T, T, dtype=torch.bool, device=q.device)
+    if causal:
+        mask = mask | (idx[None, :] > idx[:, None])[None, None]
+    valid = torch.ones(N, T, dtype=torch.bool, device=q.device)
+    if start is not None:
+        valid = idx[None, :] >= start[:, None].long()
+        mask = mask | ~valid[:, None, None, :]
+    s = s.masked_fill(mask, float('-inf'))
+    row_ok = ~mask.all(-1, keepdim=True)
+    p = torch.softmax(s.masked_fill(~row_ok, 0.0), -1) * row_ok
+    o = p @ vv
+    dof = do.float().view(N, T, H, hd).transpose(1, 2) * valid[:, None, :, None]
+    (o * dof).sum().backward()
+    back = lambda t, h: t.transpose(1, 2).reshape(N * T, h * hd)
+    return back(o.detach(), H), back(qf.grad, H), back(kf.grad, Hkv), back(vf.grad, Hkv), valid.reshape(N * T)
+
+
+CASES = [
+    # N, T, H, Hkv, hd, causal, starts
+    (2, 256, 2, 2, 128, True, [0, 37]),
+    (1, 200, 2, 2, 128, True, [70]),
+    (2, 577, 2, 2, 64, False, None),
+    (2, 128, 4, 2, 64, True, [0, 5]),
+    (1, 64, 1, 1, 128, True, None),
+    (3, 48, 2, 2, 64, True, [0, 6, 2]),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_attention_forward_backward(case):
+    from align_anything_amd import ops
+    N, T, H, Hkv, hd, causal, starts = case
+    scale = hd ** -0.5
+    qkv = randn_bf16(N * T, (H + 2 * Hkv) * hd, seed=11)
+    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:(H + Hkv) * hd], qkv[:, (H + Hkv) * hd:]
+    do = randn_bf16(N * T, H * hd, seed=12)
+    start = torch.tensor(starts, dtype=torch.int32, device=dev()) if starts is not None else None
+    o, lse = ops.attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start)
+    dqkv = torch.zeros_like(qkv)
+    dq, dk, dv = dqkv[:, :H * hd], dqkv[:, H * hd:(H + Hkv) * hd], dqkv[:, (H + Hkv) * hd:]
+    # zero dO at pad rows, as the real backward does (no loss gradient reaches pad positions)
+    ro, rdq, rdk, rdv, valid = ref_attention(q, k, v, do, N, T, H, Hkv, hd, causal, scale, start)
+    do = do * valid[:, None].to(do.dtype)
+    ops.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
+    vm = valid[:, None].float()
+    assert_close(o.float() * vm, ro * vm, rtol=2e-2, atol=2e-2, what=f'O {case}')
+    assert float((o.float() * (1 - vm)).abs().max()) == 0.0, 'pad query rows must be exactly 0'
+    g = max(float(rdq.abs().max()), 1e-3)
+    assert_close(dq.float() * vm, rdq * vm, rtol=3e-2, atol=2e-2 * g, what=f'dQ {case}')
+    assert_close(dk, rdk, rtol=3e-2, atol=2e-2 * max(float(rdk.abs().max()), 1e-3), what=f'dK {case}')
+    assert_close(dv, rdv, rtol=3e-2, atol=2e-2 * max(float(rdv.abs().max()), 1e-3), what=f'dV {case}')
+    # LSE against the reference on valid rows
+    qf = q.float().view(N, T, H, hd).transpose(1, 2)
+    kf = k.float().view(N, T, Hkv, hd).transpose(1, 2).repeat_interleave(H // Hkv, 1)
+    s = (qf @ kf.transpose(-1, -2)) * scale
+    idx = torch.arange(T, device=dev())
+    m = torch.zeros(N, 1, T, T, dtype=torch.bool, device=dev())
+    if causal:
+        m = m | (idx[None, :] > idx[:, None])[None, None]
+    if start is not None:
+        m = m | ~(idx[None, :] >= start[:, None].long())[:, None, None, :]
+    ref_lse = torch.logsumexp(s.masked_fill(m, float('-inf')), -1)
+    ok = torch.isfinite(ref_lse)
+    assert_close(lse[ok], ref_lse[ok], rtol=1e-3, atol=2e-2, what='lse')

@@ -1,0 +1,80 @@
+"""GPU: bf16 MFMA GEMM (csrc/gemm.hip) vs a plain fp32 torch matmul of the same bf16 operands."""
+import pytest
+import torch
+
+from tests.gpu_util import assert_close, dev, randn_bf16
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(128, 128, 64), (256, 256, 128), (300, 200, 192), (1154, 1024, 640), (1024, 2048, 1024), (64, 320, 128)]
+
+
+def _ref(a, b, a_t, b_n):
+    A = a.float().t() if a_t else a.float()
+    B = b.float() if b_n else b.float().t()
+    return A @ B
+
+
+@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+@pytest.mark.parametrize('layout', ['nt', 'nn', 'tn'])
+def test_gemm_layouts_and_tiles(tile, layout):
+    from align_anything_amd import ops
+    ops.gemm_set_tile(tile)
+    try:
+        for (M, N, K) in SHAPES:
+            a_t = layout == 'tn'
+            b_n = layout in ('nn', 'tn')
+            if a_t and M % 8:
+                continue
+            if b_n and N % 8:
+                continue
+            a = randn_bf16(K, M, seed=1) if a_t else randn_bf16(M, K, seed=1)
+            b = randn_bf16(K, N, seed=2) if b_n else randn_bf16(N, K, seed=2)
+            out = ops.gemm(a, b, a_t=a_t, b_n=b_n)
+            torch.cuda.synchronize()
+            ref = _ref(a, b, a_t, b_n)
+            assert_close(out, ref, rtol=1e-2, atol=1e-2 * float(ref.abs().mean()), what=f'{layout} tile{tile} {M}x{N}x{K}')
+    finally:
+        ops.gemm_set_tile(-1)
+
+
+def test_gemm_epilogues_match_hf_rounding_points():
+    from align_anything_amd import ops
+    M, N, K = 384, 512, 256
+    a, w = randn_bf16(M, K, seed=3), randn_bf16(N, K, scale=0.1, seed=4)
+    bias, res = randn_bf16(N, seed=5), randn_bf16(M, N, seed=6)
+    acc = a.float() @ w.float().t()
+    # bias + quick_gelu (CLIP fc1): bf16(act(bf16(acc + bias)))
+    out = ops.gemm(a, w, bias=bias, act=ops.ACT_QUICK_GELU)
+    y = (acc + bias.float()).to(torch.bfloat16).float()
+    ref = (y * torch.sigmoid(1.702 * y))
+    assert_close(out, ref, rtol=1e-2, atol=2e-2, what='bias+quick_gelu')
+    # bias + erf gelu
+    out = ops.gemm(a, w, bias=bias, act=ops.ACT_GELU)
+    assert_close(out, torch.nn.functional.gelu(y), rtol=1e-2, atol=2e-2, what='bias+gelu')
+    # residual: bf16(bf16(acc) + res)
+    out = ops.gemm(a, w, residual=res)
+    assert_close(out, acc.to(torch.bfloat16).float() + res.float(), rtol=1e-2, atol=2e-2, what='residual')
+    # in-place residual (C aliases residual)
+    buf = res.clone()
+    ops.gemm(a, w, out=buf, residual=buf)
+    assert_close(buf, acc.to(torch.bfloat16).float() + res.float(), rtol=1e-2, atol=2e-2, what='residual inplace')
+    # accumulate + fp32 out
+    c32 = torch.ones((M, N), dtype=torch.float32, device=dev())
+    ops.gemm(a, w, out=c32, accumulate=True)
+    assert_close(c32, acc + 1.0, rtol=1e-3, atol=1e-2, what='accum f32')
+    cb = res.clone()
+    ops.gemm(a, w, out=cb, accumulate=True)
+    assert_close(cb, acc + res.float(), rtol=1e-2, atol=3e-2, what='accum bf16')
+    # strided views (column slices of a wider buffer), as the fused qkv / gate_up buffers are used
+    wide = randn_bf16(M, 2 * K, seed=7)
+    out = ops.gemm(wide[:, K:], w)
+    assert_close(out, wide[:, K:].float() @ w.float().t(), rtol=1e-2, atol=2e-2, what='strided A')
+
+
+def test_gemm_rejects_bad_arguments_loudly():
+    from align_anything_amd import ops
+    from align_anything_amd.lib import AAHipError
+    a, b = randn_bf16(64, 100), randn_bf16(64, 100)
+    with pytest.raises(AAHipError):
+        ops.gemm(a, b)  # K not a multiple of 64

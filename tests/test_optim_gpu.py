@@ -1,0 +1,33 @@
+"""GPU: flat AdamW + global-norm clip (csrc/optim.hip) vs the oracle restatement of FusedAdam."""
+import pytest
+import torch
+
+from oracle import rl_math as orl
+from tests.gpu_util import assert_close, dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('gdtype', [torch.bfloat16, torch.float32])
+def test_adamw_flat_five_steps(gdtype):
+    from align_anything_amd import ops
+    n = 100003
+    gen = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=gen)
+    master = p0.clone().to(dev()); m = torch.zeros(n, device=dev()); v = torch.zeros(n, device=dev())
+    p16 = torch.empty(n, dtype=torch.bfloat16, device=dev())
+    q, qm, qv = p0.clone(), torch.zeros(n), torch.zeros(n)
+    sumsq = torch.zeros(1, device=dev()); coef = torch.zeros(1, device=dev()); nrm = torch.zeros(1, device=dev())
+    for step in range(1, 6):
+        g = (torch.randn(n, generator=gen) * 0.01 * step).to(gdtype)
+        gd = g.to(dev())
+        sumsq.zero_()
+        ops.grad_sumsq_(gd, sumsq)
+        ops.clip_coef(sumsq, 1.0, coef, nrm)
+        ops.adamw_flat_(master, m, v, p16, gd, 1e-3, 0.9, 0.95, 1e-8, 0.05, step, clip=coef)
+        c, tot = orl.clip_coef([g], 1.0)
+        assert abs(nrm.item() - tot.item()) < 1e-3 * tot.item()
+        orl.adamw_step(q, g.float() * c, qm, qv, step, 1e-3, 0.9, 0.95, 1e-8, 0.05)
+    torch.cuda.synchronize()
+    assert_close(master.cpu(), q, rtol=1e-5, atol=2e-6, what='master')
+    assert torch.equal(p16, master.to(torch.bfloat16)), 'bf16 shadow must be RNE of the fp32 master'

@@ -1,0 +1,98 @@
+"""GPU: RLHF scalar math kernels (csrc/rl_math.hip) vs the oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rl_math as orl
+from tests.gpu_util import assert_close, dev, randn_bf16
+from tests.util import bits_to_bf16, load_golden
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def test_logprob_gather_golden_and_index_path():
+    from align_anything_amd import ops
+    z = load_golden('rl_math.npz')
+    labels = T(z['glp_labels']).to(dev())
+    lg = T(z['glp_logits']).to(dev())
+    lp, lse = ops.logprob_gather_fwd(lg, labels)
+    assert_close(lp, T(z['glp_out_f32']).to(dev()), rtol=1e-5, atol=2e-5, what='logp f32 golden')
+    lb = bits_to_bf16(z['glp_logits_bf16']).to(dev())
+    lpb, _ = ops.logprob_gather_fwd(lb, labels, round_bf16=True)
+    gold = T(z['glp_out_bf16']).to(dev())
+    # the reference returns bf16(x - lse) from torch's CPU kernel; ours rounds the fp32 result once.
+    # They may differ by one bf16 ulp where x - lse sits on a rounding tie (3/37 rows of this fixture,
+    # where the exactly-rounded value is OURS: checked against an fp64 log_softmax below).
+    assert_close(lpb, gold, rtol=8e-3, atol=0, what='logp bf16 golden (<= 1 bf16 ulp)')
+    truth = torch.log_softmax(lb.double(), -1)[torch.arange(lb.shape[0]), labels]
+    exact = truth.float().to(torch.bfloat16).float()
+    assert (lpb == exact).float().mean().item() >= (gold == exact).float().mean().item()
+    # index path is bit-exact: lp + lse == logits[row, label] exactly as stored
+    lp32, lse32 = ops.logprob_gather_fwd(lb, labels)
+    picked = lb.float()[torch.arange(lb.shape[0]), labels]
+    assert torch.equal(lp32, picked - lse32)
+
+
+@pytest.mark.parametrize('rows,V', [(5, 32064), (3, 50272), (7, 1000), (2, 8), (4, 33)])
+def test_logprob_gather_fwd_bwd_vs_oracle(rows, V):
+    from align_anything_amd import ops
+    logits = randn_bf16(rows, V, scale=2.0, seed=V)
+    labels = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(1)).to(dev())
+    lp, lse = ops.logprob_gather_fwd(logits, labels)
+    lf = logits.float().cpu().requires_grad_(True)
+    ref = orl.gather_log_probabilities(lf[None], labels.cpu()[None])[0]
+    assert_close(lp.cpu(), ref.detach(), rtol=1e-5, atol=3e-5, what='logp')
+    dlp = torch.randn(rows, generator=torch.Generator().manual_seed(2))
+    ref.backward(dlp)
+    d = ops.logprob_gather_bwd(logits, labels, lse, dlp.to(dev()))
+    assert_close(d.cpu(), lf.grad, rtol=1e-2, atol=1e-6 + 4e-3 * float(lf.grad.abs().max()), what='dlogits')
+    # in place
+    buf = logits.clone()
+    ops.logprob_gather_bwd(buf, labels, lse, dlp.to(dev()), out=buf)
+    assert torch.equal(buf, d)
+
+
+def test_dpo_loss_vs_oracle():
+    from align_anything_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B = 3
+    lens = [11, 1, 300, 7, 64, 2]
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    pol = -torch.rand(int(off[-1]), generator=g) * 5
+    ref = -torch.rand(int(off[-1]), generator=g) * 5
+    out6, per, dlogp = ops.dpo_loss(pol.to(dev()), ref.to(dev()), off.to(dev()), B, 0.1)
+    L = max(lens)
+    pad = lambda v: torch.nn.utils.rnn.pad_sequence([v[off[i]:off[i + 1]] for i in range(2 * B)], batch_first=True)
+    pp = pad(pol).requires_grad_(True)
+    ld = orl.dpo_loss(pp, pad(ref), 0.1)
+    ld['loss'].backward()
+    o = out6.cpu()
+    assert abs(o[0].item() - ld['loss'].item()) < 1e-5
+    assert abs(o[1].item() - ld['reward_accuracy'].item()) < 1e-6
+    assert_close(per[0].cpu(), ld['better_sample_reward'], rtol=1e-5, atol=1e-5)
+    assert_close(per[1].cpu(), ld['worse_sample_reward'], rtol=1e-5, atol=1e-5)
+    assert_close(per[2].cpu(), ld['reward'], rtol=1e-5, atol=1e-5)
+    assert_close(per[3].cpu(), ld['reward_margin'], rtol=1e-5, atol=1e-5)
+    dref = torch.cat([pp.grad[i, :lens[i]] for i in range(2 * B)])
+    assert_close(dlogp.cpu(), dref, rtol=1e-4, atol=1e-7, what='dlogp')
+
+
+def test_ppo_math_matches_reference_golden():
+    from align_anything_amd import ops
+    z = load_golden('rl_math.npz')
+    d = lambda k: T(z[k]).to(dev())
+    mask = d('ppo_mask').to(torch.uint8)
+    rew, end = ops.kl_reward(d('ppo_reward'), d('ppo_logp'), d('ppo_ref'), mask, 0.02, 50.0)
+    assert_close(rew, d('ppo_kl_rewards'), rtol=1e-6, atol=1e-6, what='kl rewards')
+    assert end.cpu().tolist() == [int(m.nonzero()[-1]) for m in T(z['ppo_mask'])]  # bit-exact index
+    for start in (0, 4):
+        adv, ret = ops.gae(d('ppo_values'), d('ppo_kl_rewards'), mask, start, 1.0, 0.95)
+        assert_close(adv, d(f'ppo_adv_s{start}'), rtol=1e-5, atol=1e-5, what='adv')
+        assert_close(ret, d(f'ppo_ret_s{start}'), rtol=1e-5, atol=1e-5, what='ret')
+    loss, g = ops.ppo_actor_loss(d('ppo_new_logp'), d('ppo_logp'), d('ppo_adv_s0'), mask, 0.2)
+    assert abs(loss.item() - float(z['ppo_actor_loss'])) < 1e-5
+    assert_close(g, d('ppo_actor_grad'), rtol=1e-4, atol=1e-6, what='actor grad')
+    loss, g = ops.ppo_critic_loss(d('ppo_new_values'), d('ppo_values'), d('ppo_ret_s0'), mask, 5.0)
+    assert abs(loss.item() - float(z['ppo_critic_loss'])) < 1e-4 * max(1.0, abs(float(z['ppo_critic_loss'])))
+    assert_close(g, d('ppo_critic_grad'), rtol=1e-4, atol=1e-6, what='critic grad')
