@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ w,
                                                           const float* __restrict__ rstd_in,
                                                           bf16_t* __restrict__ dx,
-                                                          float* __restrict__ dw, int rows, int h,
+                                                          float* __restrict__ dw_part, int rows, int h,
                                                           int add_to_dx) {
     __shared__ float red[8];
     const int nv = h >> 3;
@@ -97,16 +97,35 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
             }
         }
     }
-    if (dw) {
+    if (dw_part) {  // per-block partial row, reduced by reduce_rows_kernel (no atomics on the hot path)
+        float* pr = dw_part + (long)blockIdx.x * h;
 #pragma unroll
         for (int a = 0; a < MAXV; ++a) {
             const int i = threadIdx.x + a * 256;
             if (i < nv) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) atomicAdd(dw + i * 8 + j, dwacc[a][j]);
+                *reinterpret_cast<f32x4*>(pr + i * 8) = f32x4{dwacc[a][0], dwacc[a][1], dwacc[a][2], dwacc[a][3]};
+                *reinterpret_cast<f32x4*>(pr + i * 8 + 4) = f32x4{dwacc[a][4], dwacc[a][5], dwacc[a][6], dwacc[a][7]};
             }
         }
     }
+}
+
+// out[c] += sum_r part[r, c]; grid = (ceil(h/64), RS); block = 256 (64 columns x 4 row lanes)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int nrows,
+                                                          int h, float* __restrict__ out) {
+    __shared__ float sm[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < h)
+        for (int r = blockIdx.y * 4 + rl; r < nrows; r += gridDim.y * 4) acc += part[(long)r * h + c];
+    sm[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < h) atomicAdd(out + c, sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+static void launch_reduce_rows(const float* part, int nrows, int h, float* out, hipStream_t st) {
+    int rs = nrows / 16; if (rs < 1) rs = 1; if (rs > 32) rs = 32;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(aa_cdiv(h, 64), rs), dim3(256), 0, st, part, nrows, h, out);
 }
 
 extern "C" int aa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int h,
@@ -121,20 +140,25 @@ extern "C" int aa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd
 }
 
 extern "C" int aa_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd,
-                              void* dx, float* dw, int rows, int h, int add_to_dx, void* stream) {
+                              void* dx, float* dw, float* ws, int ws_rows, int rows, int h,
+                              int add_to_dx, void* stream) {
     AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0 && h <= 8 * 256 * 8,
                "aa_rmsnorm_bwd: hidden %d must be a multiple of 8 and <= 16384", h);
+    AA_REQUIRE(dw == nullptr || (ws != nullptr && ws_rows > 0), "aa_rmsnorm_bwd: dw needs a [ws_rows, h] fp32 workspace");
     if (rows == 0) return AA_OK;
-    const int grid = rows < 1024 ? rows : 1024;
+    int grid = rows < 1024 ? rows : 1024;
+    if (dw && grid > ws_rows) grid = ws_rows;
+    float* part = dw ? ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_RMSB(MV)                                                                             \
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy,     \
-                       (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, dw, rows, h, add_to_dx)
+                       (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, part, rows, h, add_to_dx)
     if (h <= 2048) LAUNCH_RMSB(1);
     else if (h <= 4096) LAUNCH_RMSB(2);
     else if (h <= 8192) LAUNCH_RMSB(4);
     else LAUNCH_RMSB(8);
 #undef LAUNCH_RMSB
+    if (dw) launch_reduce_rows(part, grid, h, dw, st);
     AA_CHECK_LAUNCH("aa_rmsnorm_bwd");
     return AA_OK;
 }
@@ -192,8 +216,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
                                                             const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in,
                                                             bf16_t* __restrict__ dx,
-                                                            float* __restrict__ dw,
-                                                            float* __restrict__ db, int rows, int h,
+                                                            float* __restrict__ dw_part,
+                                                            float* __restrict__ db_part, int rows, int h,
                                                             int add_to_dx) {
     __shared__ float red[8];
     const int nv = h >> 3;
@@ -251,10 +275,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     for (int a = 0; a < MAXV; ++a) {
         const int i = threadIdx.x + a * 256;
         if (i < nv) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (dw) atomicAdd(dw + i * 8 + j, dwacc[a][j]);
-                if (db) atomicAdd(db + i * 8 + j, dbacc[a][j]);
+            if (dw_part) {
+                float* pr = dw_part + (long)blockIdx.x * h + i * 8;
+                *reinterpret_cast<f32x4*>(pr) = f32x4{dwacc[a][0], dwacc[a][1], dwacc[a][2], dwacc[a][3]};
+                *reinterpret_cast<f32x4*>(pr + 4) = f32x4{dwacc[a][4], dwacc[a][5], dwacc[a][6], dwacc[a][7]};
+            }
+            if (db_part) {
+                float* pr = db_part + (long)blockIdx.x * h + i * 8;
+                *reinterpret_cast<f32x4*>(pr) = f32x4{dbacc[a][0], dbacc[a][1], dbacc[a][2], dbacc[a][3]};
+                *reinterpret_cast<f32x4*>(pr + 4) = f32x4{dbacc[a][4], dbacc[a][5], dbacc[a][6], dbacc[a][7]};
             }
         }
     }
@@ -273,21 +302,28 @@ extern "C" int aa_layernorm_fwd(const void* x, const void* w, const void* b, voi
 }
 
 extern "C" int aa_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean,
-                                const float* rstd, void* dx, float* dw, float* db, int rows, int h,
-                                int add_to_dx, void* stream) {
+                                const float* rstd, void* dx, float* dw, float* db, float* ws,
+                                int ws_rows, int rows, int h, int add_to_dx, void* stream) {
     AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0 && h <= 8 * 256 * 4,
                "aa_layernorm_bwd: hidden %d must be a multiple of 8 and <= 8192", h);
+    AA_REQUIRE((dw == nullptr && db == nullptr) || (ws != nullptr && ws_rows > 0),
+               "aa_layernorm_bwd: dw/db need a [2, ws_rows, h] fp32 workspace");
     if (rows == 0) return AA_OK;
-    const int grid = rows < 1024 ? rows : 1024;
+    int grid = rows < 1024 ? rows : 1024;
+    if ((dw || db) && grid > ws_rows) grid = ws_rows;
+    float* dwp = dw ? ws : nullptr;
+    float* dbp = db ? ws + (long)ws_rows * h : nullptr;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_LNB(MV)                                                                              \
     hipLaunchKernelGGL(layernorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy,   \
-                       (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, dw, db, rows, h, \
+                       (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, dwp, dbp, rows, h, \
                        add_to_dx)
     if (h <= 2048) LAUNCH_LNB(1);
     else if (h <= 4096) LAUNCH_LNB(2);
     else LAUNCH_LNB(4);
 #undef LAUNCH_LNB
+    if (dw) launch_reduce_rows(dwp, grid, h, dw, st);
+    if (db) launch_reduce_rows(dbp, grid, h, db, st);
     AA_CHECK_LAUNCH("aa_layernorm_bwd");
     return AA_OK;
 }

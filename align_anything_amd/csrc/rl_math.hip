@@ -401,3 +401,50 @@ extern "C" int aa_ppo_critic_loss(const float* values, const float* old_values, 
     AA_CHECK_LAUNCH("aa_ppo_critic_loss");
     return AA_OK;
 }
+
+// ------------------------------------------------------------------ response-window labels
+// align_anything/trainers/text_to_text/dpo.py:131-137: raw = strip_pad(ids[n]); labels = raw[-R:][1:].
+// Pure integer work, reproduced exactly (including pad ids inside the text being dropped): a non-pad
+// token whose inclusive non-pad suffix count is `rank` (1 = last token) is element R - rank of raw[-R:],
+// i.e. label slot R - 1 - rank for 1 <= rank <= R - 1.  One workgroup per sequence, scanning from the end.
+__global__ __launch_bounds__(256) void window_labels_kernel(const int64_t* __restrict__ ids, int T,
+                                                            int64_t pad_id,
+                                                            const int* __restrict__ resp_len,
+                                                            const int* __restrict__ row_off,
+                                                            int64_t* __restrict__ labels) {
+    __shared__ int wsum[4];
+    __shared__ int carry;
+    const int n = blockIdx.x;
+    const int R = resp_len[n];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 256) {
+        const int k = base + threadIdx.x;  // distance from the end
+        const int p = T - 1 - k;
+        const int64_t tok = (p >= 0) ? ids[(long)n * T + p] : pad_id;
+        const int f = (p >= 0 && tok != pad_id) ? 1 : 0;
+        const unsigned long long bal = __ballot(f);
+        const int incl = __popcll(bal & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
+        if (lane == 0) wsum[wid] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int c = carry;
+        const int rank = c + woff + incl;
+        if (f && rank >= 1 && rank <= R - 1) labels[row_off[n] + (R - 1 - rank)] = tok;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+        if (carry >= R) break;  // uniform: carry is shared
+    }
+}
+
+extern "C" int aa_window_labels(const int64_t* ids, int N, int T, int64_t pad_id, const int* resp_len,
+                                const int* row_off, int64_t* labels, void* stream) {
+    AA_REQUIRE(N > 0 && T > 0, "aa_window_labels: bad shape N=%d T=%d", N, T);
+    hipLaunchKernelGGL(window_labels_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ids, T, pad_id,
+                       resp_len, row_off, labels);
+    AA_CHECK_LAUNCH("aa_window_labels");
+    return AA_OK;
+}

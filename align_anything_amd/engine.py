@@ -1,0 +1,228 @@
+"""DeepSpeedEngine-shaped native engine for one GPU of a data-parallel job.
+
+The reference drives `deepspeed.initialize(...)` engines (align_anything/trainers/base/supervised_trainer.py:
+234-271) and calls `.module`, `.backward(loss)`, `.step()`, `.optimizer.param_groups[0]['lr']`, `.train()`,
+`.eval()`, `.tput_timer.update_epoch_count()`, `.gradient_checkpointing_enable()`,
+`.save_16bit_model(dir, save_filename=)`, `.save_checkpoint(dir)`, `.load_checkpoint(load_dir=)` on them
+(SURVEY.md §8b).  This class offers that surface over the native model:
+
+  * backward(): runs the model's explicit backward (HIP kernels); as each decoder layer finishes, its slice
+    of the flat bf16 gradient buffer is all-reduced over RCCL/xGMI on a side HIP stream (one ~400 MB bucket
+    per 7B layer -- large buckets suit point-to-point xGMI links), overlapping with the remaining backward.
+  * step(): global-L2 clip (device-side coefficient, no host sync) + flat AdamW (csrc/optim.hip) + LR schedule.
+
+ZeRO is not reproduced: at 288 GB/GPU the whole optimizer state of a 7B model fits one device, so pure
+data parallelism needs exactly one collective per step (the gradient all-reduce); DeepSpeed's per-layer
+parameter all-gathers disappear.
+"""
+from __future__ import annotations
+
+import math
+import os
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def cosine_with_warmup(step: int, base_lr: float, warmup: int, total: int) -> float:
+    """transformers.get_scheduler('cosine') (supervised_trainer.py:251-257): linear warmup, half-cosine decay."""
+    if step < warmup:
+        return base_lr * step / max(1, warmup)
+    prog = (step - warmup) / max(1, total - warmup)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * min(1.0, prog))))
+
+
+class GradReducer:
+    """Bucketed SUM all-reduce of flat gradient slices on a side stream (backend-agnostic: RCCL on GPU,
+    gloo in the CPU tests).  The 1/world scaling is folded into the optimizer kernels (gscale)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.handles = []
+        self.comm_stream = None
+
+    def reduce_async(self, flat_slice: torch.Tensor):
+        if self.world == 1 or flat_slice.numel() == 0:
+            return
+        if flat_slice.is_cuda:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                h = dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.handles.append(h)
+        else:
+            self.handles.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
+class NativeEngine:
+    def __init__(self, module, *, lr=1e-6, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
+                 total_steps=1, warmup_steps=0, lr_scheduler_type='cosine', group=None, trainable=True):
+        self.module = module
+        self.trainable = trainable
+        self.base_lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(float(b) for b in betas), eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.total_steps, self.warmup_steps, self.sched = total_steps, warmup_steps, lr_scheduler_type
+        self.global_steps = 0
+        self.reducer = GradReducer(group)
+        self.world = self.reducer.world
+        self.tput_timer = SimpleNamespace(update_epoch_count=lambda: None)
+        lr0 = self._lr_at(0)
+        self.optimizer = SimpleNamespace(param_groups=[{'lr': lr0, 'weight_decay': weight_decay},
+                                                        {'lr': lr0, 'weight_decay': 0.0}])
+        self._pending = None
+        if trainable:
+            module.init_training()
+            dev = module.device
+            self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._coef = torch.ones(1, dtype=torch.float32, device=dev)
+            self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._layer_slices = self._compute_layer_slices()
+
+    # ---- DeepSpeedEngine-shaped conveniences
+    def train(self, mode=True):
+        self.module.train(mode)
+        return self
+
+    def eval(self):
+        self.module.eval()
+        return self
+
+    def gradient_checkpointing_enable(self):
+        return None  # nothing is recomputed: activations fit in 288 GB HBM
+
+    def __call__(self, *a, **k):
+        raise RuntimeError('NativeEngine is not callable: use trainer.compute_log_probs(engine.module, batch)')
+
+    def _lr_at(self, step):
+        if self.sched == 'cosine':
+            return cosine_with_warmup(step, self.base_lr, self.warmup_steps, self.total_steps)
+        if self.sched == 'constant':
+            return self.base_lr
+        raise ValueError(f'lr_scheduler_type {self.sched!r} not supported (cosine, constant)')
+
+    def _compute_layer_slices(self):
+        """For every decoder layer: the contiguous range of the flat 'mat' gradient buffer it owns."""
+        st = self.module.store
+        out = {}
+        stack = getattr(self.module, 'stack', None)
+        if stack is None or 'mat' not in st.gflat:
+            return out
+        for L in stack.layers:
+            names = [v.wname for v in L.values() if hasattr(v, 'wname')]
+            specs = [st.specs[n] for n in names if st.specs[n]['group'] == 'mat']
+            if specs:
+                lo = min(s['offset'] for s in specs)
+                hi = max(s['offset'] + s['numel'] for s in specs)
+                out[id(L)] = (lo, hi)
+        return out
+
+    # ---- backward / step
+    def set_pending(self, dlogp):
+        self._pending = dlogp
+
+    def backward(self, loss=None):
+        """engine.backward(loss) of the reference (dpo.py:212): seeds come from the fused loss kernel."""
+        if self._pending is None:
+            raise RuntimeError('backward() without a pending loss gradient: call trainer.loss(batch) first')
+        st = self.module.store
+        st.zero_grad()
+        done = set()
+
+        def on_layer_done(L):
+            rng = self._layer_slices.get(id(L))
+            if rng is not None:
+                self.reducer.reduce_async(st.gflat['mat'][rng[0]:rng[1]])
+                done.add(rng)
+
+        hook = on_layer_done if self.world > 1 else None
+        self.module.backward_from_dlogp(self._pending, hook)
+        self._pending = None
+        if self.world > 1:
+            # whatever was not covered by a per-layer bucket (lm_head, projector, embeddings, vectors)
+            mat = st.gflat.get('mat')
+            if mat is not None:
+                covered = sorted(done)
+                pos = 0
+                for lo, hi in covered:
+                    if lo > pos:
+                        self.reducer.reduce_async(mat[pos:lo])
+                    pos = max(pos, hi)
+                if pos < mat.numel():
+                    self.reducer.reduce_async(mat[pos:])
+            for g in ('emb', 'vec'):
+                if g in st.gflat:
+                    self.reducer.reduce_async(st.gflat[g])
+
+    def step(self):
+        st = self.module.store
+        self.reducer.wait()
+        self.global_steps += 1
+        gscale = 1.0 / self.world
+        # HF schedulers are stepped AFTER optimizer.step(): update k (1-based) uses lr(k-1); the value the
+        # trainer logs as train/lr after the step is lr(k)
+        lr_used = self._lr_at(self.global_steps - 1)
+        lr = self._lr_at(self.global_steps)
+        self._sumsq.zero_()
+        groups = st.trainable_groups()
+        for g in groups:
+            ops.grad_sumsq_(st.gflat[g], self._sumsq, gscale)
+        ops.clip_coef(self._sumsq, self.max_grad_norm if self.max_grad_norm else 0.0, self._coef, self._gnorm)
+        for g in groups:
+            wd = 0.0 if g == 'vec' else self.weight_decay
+            ops.adamw_flat_(st.master[g], st.m[g], st.v[g], st.flat[g], st.gflat[g], lr_used, self.betas[0],
+                            self.betas[1], self.eps, wd, self.global_steps, gscale, self._coef)
+        for pg in self.optimizer.param_groups:
+            pg['lr'] = lr
+
+    def grad_norm(self) -> float:
+        return float(self._gnorm.item())
+
+    # ---- checkpoints (HF layout, supervised_trainer.py:404-450)
+    def save_16bit_model(self, save_dir, save_filename='pytorch_model.bin'):
+        os.makedirs(save_dir, exist_ok=True)
+        sd = {k: v.cpu() for k, v in self.module.state_dict().items()}
+        path = os.path.join(save_dir, save_filename)
+        if save_filename.endswith('.safetensors'):
+            from safetensors.torch import save_file
+            save_file({k: v.contiguous() for k, v in sd.items() if k != 'lm_head.weight' or self.module.kind != 'opt'},
+                      path, metadata={'format': 'pt'})
+        else:
+            torch.save(sd, path)
+        return path
+
+    def save_checkpoint(self, save_dir, tag=None):
+        """Full training state (fp32 masters + Adam moments + step), the analogue of DeepSpeed's checkpoint."""
+        os.makedirs(save_dir, exist_ok=True)
+        st = self.module.store
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        if rank == 0:
+            torch.save({'global_steps': self.global_steps,
+                        'master': {g: t.cpu() for g, t in st.master.items()},
+                        'm': {g: t.cpu() for g, t in st.m.items()},
+                        'v': {g: t.cpu() for g, t in st.v.items()}},
+                       os.path.join(save_dir, f'native_engine_{tag or "latest"}.pt'))
+
+    def load_checkpoint(self, load_dir, tag=None):
+        st = self.module.store
+        ck = torch.load(os.path.join(load_dir, f'native_engine_{tag or "latest"}.pt'), map_location='cpu')
+        self.global_steps = ck['global_steps']
+        for g in st.master:
+            st.master[g].copy_(ck['master'][g])
+            st.m[g].copy_(ck['m'][g])
+            st.v[g].copy_(ck['v'][g])
+            ops.f32_to_bf16(st.master[g], out=st.flat[g])
+        return load_dir, {}

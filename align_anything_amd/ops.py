@@ -72,6 +72,20 @@ def gemm_set_tile(tile: int) -> None:
 
 
 # ------------------------------------------------------------------ norms
+NORM_WS_ROWS = 512
+_ws_cache: dict = {}
+
+
+def _norm_ws(device, h, planes):
+    """Scratch for the per-workgroup dw/db partial rows of the norm backward kernels (stream-ordered reuse)."""
+    key = (device, h, planes)
+    t = _ws_cache.get(key)
+    if t is None:
+        t = torch.empty((planes * NORM_WS_ROWS, h), dtype=torch.float32, device=device)
+        _ws_cache[key] = t
+    return t
+
+
 def rmsnorm_fwd(x, w, eps, out=None, rstd=None):
     rows, h = x.shape
     out = torch.empty_like(x) if out is None else out
@@ -83,8 +97,9 @@ def rmsnorm_fwd(x, w, eps, out=None, rstd=None):
 def rmsnorm_bwd(dy, x, w, rstd, dw, dx=None, add_to_dx=False):
     rows, h = x.shape
     dx = torch.empty_like(x) if dx is None else dx
+    ws = _norm_ws(x.device, h, 1) if dw is not None else None
     call('aa_rmsnorm_bwd', dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dw),
-         rows, h, int(add_to_dx), stream())
+         _p(ws), NORM_WS_ROWS, rows, h, int(add_to_dx), stream())
     return dx
 
 
@@ -103,8 +118,9 @@ def layernorm_fwd(x, w, b, eps, out=None, want_stats=True):
 def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dx=None, add_to_dx=False):
     rows, h = x.shape
     dx = torch.empty_like(x) if dx is None else dx
+    ws = _norm_ws(x.device, h, 2) if (dw is not None or db is not None) else None
     call('aa_layernorm_bwd', dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-         dx.data_ptr(), _p(dw), _p(db), rows, h, int(add_to_dx), stream())
+         dx.data_ptr(), _p(dw), _p(db), _p(ws), NORM_WS_ROWS, rows, h, int(add_to_dx), stream())
     return dx
 
 
@@ -251,6 +267,13 @@ def logprob_gather_bwd(logits, labels, lse, dlogp, out=None):
     call('aa_logprob_gather_bwd', logits.data_ptr(), logits.stride(0), labels.data_ptr(), lse.data_ptr(),
          dlogp.data_ptr(), out.data_ptr(), out.stride(0), rows, V, dt, stream())
     return out
+
+
+def window_labels(ids, pad_id, resp_len_i32, row_off_i32, labels_out):
+    N, T = ids.shape
+    call('aa_window_labels', ids.data_ptr(), N, T, int(pad_id), resp_len_i32.data_ptr(), row_off_i32.data_ptr(),
+         labels_out.data_ptr(), stream())
+    return labels_out
 
 
 def dpo_loss(pol_logp, ref_logp, seq_off, B, beta, want_grad=True):

@@ -1,0 +1,90 @@
+"""Host-side plumbing shared by the native trainers: response-window index building (integer work on
+python ints that the collator already holds on the host), metric reduction, config access."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import ops
+
+
+def pad64(n: int) -> int:
+    return max(64, (n + 63) // 64 * 64)
+
+
+def build_window(input_ids: torch.Tensor, response_lens, pad_token_id: int):
+    """Index plan for `logits[idx][-R:][:-1]` x `strip_pad(ids[idx])[-R:][1:]`
+    (align_anything/trainers/text_to_text/dpo.py:131-139).  response_lens are host ints
+    (batch['meta_info']['response_lens']), so the positional part is built on the CPU with no device sync; the
+    label part depends on where pad ids sit and is computed on the device (aa_window_labels)."""
+    N, T = input_ids.shape
+    dev = input_ids.device
+    R = np.asarray([int(r) for r in response_lens], dtype=np.int64)
+    if len(R) != N:
+        raise ValueError(f'response_lens has {len(R)} entries for {N} rows')
+    if (R < 1).any() or (R > T).any():
+        raise ValueError(f'response_lens must be within [1, {T}]: {R.tolist()}')
+    cnt = R - 1
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    rows = int(off[-1])
+    rows_pad = pad64(rows)
+    Mp = (N * T + 63) // 64 * 64
+    row_idx = np.zeros(rows_pad, dtype=np.int64)
+    seq_of_row = np.zeros(rows, dtype=np.int64)
+    col_of_row = np.zeros(rows, dtype=np.int64)
+    for n in range(N):
+        j = np.arange(cnt[n])
+        row_idx[off[n]:off[n + 1]] = n * T + (T - R[n]) + j
+        seq_of_row[off[n]:off[n + 1]] = n
+        col_of_row[off[n]:off[n + 1]] = j
+    inv = np.full(Mp, -1, dtype=np.int32)
+    inv[row_idx[:rows]] = np.arange(rows, dtype=np.int32)
+    w = {
+        'N': N, 'T': T, 'rows': rows, 'rows_pad': rows_pad, 'max_len': int(cnt.max()) if N else 0,
+        'row_idx': torch.from_numpy(row_idx).to(dev, non_blocking=True),
+        'inv_map': torch.from_numpy(inv).to(dev, non_blocking=True),
+        'seq_off': torch.from_numpy(off.astype(np.int32)).to(dev, non_blocking=True),
+        'flat_to_padded': torch.from_numpy(seq_of_row * max(int(cnt.max()), 1) + col_of_row).to(dev, non_blocking=True),
+        'resp_len': torch.from_numpy(R.astype(np.int32)).to(dev, non_blocking=True),
+        'row_off': torch.from_numpy(off[:-1].astype(np.int32)).to(dev, non_blocking=True),
+    }
+    labels = torch.zeros(rows_pad, dtype=torch.int64, device=dev)
+    ops.window_labels(input_ids.contiguous(), pad_token_id, w['resp_len'], w['row_off'], labels)
+    w['labels'] = labels
+    return w
+
+
+def flat_to_padded(flat_logp: torch.Tensor, w) -> torch.Tensor:
+    """pad_sequence(..., padding_value=0.0) layout of dpo.py:140-142: [N, max(R)-1], right padded with 0."""
+    L = max(w['max_len'], 1)
+    out = torch.zeros(w['N'] * L, dtype=flat_logp.dtype, device=flat_logp.device)
+    out[w['flat_to_padded']] = flat_logp[:w['rows']]
+    return out.view(w['N'], L)[:, :w['max_len']]
+
+
+def get_all_reduce_mean(t: torch.Tensor) -> torch.Tensor:
+    """align_anything/utils/multi_process.py:74-82."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.AVG if t.is_cuda else dist.ReduceOp.SUM)
+        if not t.is_cuda:
+            t /= dist.get_world_size()
+    return t
+
+
+def get_all_reduce_max(t: torch.Tensor) -> torch.Tensor:
+    """align_anything/utils/multi_process.py:85-89."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def cfg_get(cfgs, path: str, default=None):
+    """Read `a.b.c` from a namedtuple / namespace / dict config (missing -> default), mirroring the reference's
+    dict_to_namedtuple objects whose missing attributes read as None (utils/tools.py:87-93)."""
+    cur = cfgs
+    for part in path.split('.'):
+        if cur is None:
+            return default
+        cur = cur.get(part) if isinstance(cur, dict) else getattr(cur, part, None)
+    return default if cur is None else cur

@@ -1,0 +1,174 @@
+"""Native DPO trainer -- the reference's DPOTrainer surface over the MI355X hot path.
+
+Mirrors align_anything/trainers/text_to_text/dpo.py:57-321 and trainers/text_image_to_text/dpo.py:50-166:
+same method set (init_models / init_engines / compute_log_probs / loss / train_step / train / eval / save),
+same batch contract (PreferenceCollator: rows [0,B) chosen, [B,2B) rejected, left padded, meta_info.response_lens),
+same metric keys.  What differs is what executes: policy/reference forwards, the log-prob gather, the DPO
+loss (+ its gradient), backward, clip, AdamW and the gradient all-reduce are HIP kernels / RCCL behind
+include/aa_hip.h; python only sequences them.
+
+Deliberate numerical difference: the reference sums bf16 log-probs in bf16, which quantises
+sum(logp) to 8 mantissa bits; here per-token log-probs are fp32 and reduced in fp32.  `emulate_bf16_logp=True`
+reproduces the reference's bf16 rounding of the per-token values for A/B checks.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any
+
+import torch
+
+from .. import ops
+from ..engine import NativeEngine
+from ..modeling import build_model
+from .common import build_window, cfg_get, flat_to_padded, get_all_reduce_mean
+
+
+class DPOTrainer:
+    def __init__(self, cfgs, ds_cfgs=None, *, model_cfg: dict | None = None, policy_state=None, reference_state=None,
+                 train_dataloader=None, tokenizer=None, device='cuda:0', share_vision_tower=True,
+                 emulate_bf16_logp=False):
+        self.cfgs, self.ds_train_cfgs = cfgs, ds_cfgs
+        self.device = torch.device(device)
+        self.model_cfg = model_cfg
+        self.train_dataloader, self.eval_dataloader = train_dataloader, None
+        self.tokenizer = tokenizer
+        self.global_step = 0
+        self.emulate_bf16_logp = emulate_bf16_logp
+        self.share_vision_tower = share_vision_tower
+        self.infer_batch = lambda batch: {k: v for k, v in batch.items() if k != 'meta_info'}
+        self.init_check()
+        self.init_models(policy_state, reference_state)
+        self.init_engines()
+        self.init_logger()
+
+    # ------------------------------------------------------------------ init_*
+    def init_check(self) -> None:
+        if self.model_cfg is None:
+            raise ValueError('model_cfg (align_anything_amd.configs dict) is required')
+        self.scale_coeff = float(cfg_get(self.cfgs, 'train_cfgs.scale_coeff', 0.1))
+        self.pad_token_id = cfg_get(self.cfgs, 'model_cfgs.pad_token_id', None)
+        if self.pad_token_id is None:
+            self.pad_token_id = getattr(self.tokenizer, 'pad_token_id', None)
+        if self.pad_token_id is None:
+            self.pad_token_id = self.model_cfg.get('pad_token_id')
+        if self.pad_token_id is None:
+            raise ValueError('pad_token_id is required (tokenizer.pad_token_id or model_cfgs.pad_token_id)')
+
+    def init_models(self, policy_state=None, reference_state=None) -> None:
+        """text_image_to_text/dpo.py:58-83: policy with freeze flags, frozen reference from the same checkpoint."""
+        freeze = {}
+        if self.model_cfg['kind'] == 'llava':
+            freeze = dict(freeze_mm_proj=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_mm_proj', False)),
+                          freeze_language_model=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_language_model', False)),
+                          freeze_vision_tower=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_vision_tower', True)))
+        self.policy = build_model(self.model_cfg, self.device, trainable=True, **freeze)
+        self.reference = build_model(self.model_cfg, self.device, trainable=False)
+        if policy_state is not None:
+            self.policy.load_state_dict(policy_state)
+            self.reference.load_state_dict(reference_state if reference_state is not None else policy_state)
+
+    def init_engines(self) -> None:
+        """base/supervised_trainer.py:234-271 + dpo.py:114-120, with the native engine in DeepSpeed's place."""
+        t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
+        steps_per_epoch = len(self.train_dataloader) if self.train_dataloader is not None and hasattr(self.train_dataloader, '__len__') else 1
+        gas = int(t('gradient_accumulation_steps', 1))
+        total = int(t('epochs', 1)) * ((steps_per_epoch + gas - 1) // gas)
+        total = int(t('total_training_steps', total))
+        betas = [float(b) for b in t('adam_betas', [0.9, 0.95])]
+        self.model = NativeEngine(self.policy, lr=float(t('learning_rate', 1e-6)), betas=betas,
+                                  eps=float(t('adam_epsilon', 1e-8)), weight_decay=float(t('weight_decay', 0.0)),
+                                  max_grad_norm=float(cfg_get(self.ds_train_cfgs, 'gradient_clipping', 1.0)),
+                                  total_steps=total, warmup_steps=int(float(t('lr_warmup_ratio', 0.03)) * total),
+                                  lr_scheduler_type=t('lr_scheduler_type', 'cosine'), trainable=True)
+        self.reference_model = NativeEngine(self.reference, trainable=False)
+
+    def init_logger(self) -> None:
+        self.logger = None  # observability is out of scope; train() returns the metrics
+
+    # ------------------------------------------------------------------ hot path
+    def _features(self, batch):
+        """Frozen CLIP tower once per unique image (collator stacks images*2: rows [0,B) == rows [B,2B),
+        datasets/text_image_to_text/preference.py:219-222), shared by policy and reference."""
+        pv = batch.get('pixel_values')
+        if pv is None or self.policy.kind != 'llava':
+            return None
+        if '_vision_features' in batch:
+            return batch['_vision_features']
+        tower = self.policy if self.share_vision_tower else None
+        n = pv.shape[0]
+        if tower is not None and n % 2 == 0:
+            f = tower.vision_features(pv[: n // 2])
+            f = torch.cat([f, f], 0)
+        else:
+            f = None
+        batch['_vision_features'] = f
+        return f
+
+    def _window(self, batch):
+        if '_window' not in batch:
+            batch['_window'] = build_window(batch['input_ids'], batch['meta_info']['response_lens'], self.pad_token_id)
+        return batch['_window']
+
+    def _flat_log_probs(self, module, batch, save):
+        w = self._window(batch)
+        feats = self._features(batch) if (self.share_vision_tower or module is self.policy) else None
+        return module.response_logprobs(batch['input_ids'], batch.get('attention_mask'), w,
+                                        pixel_values=batch.get('pixel_values') if feats is None else None,
+                                        save=save, image_features=feats, round_bf16=self.emulate_bf16_logp)
+
+    def compute_log_probs(self, model, batch) -> torch.Tensor:
+        """dpo.py:122-142: [2B, max(R)-1] response-window log-probs, right-padded with 0.0 (fp32 here)."""
+        module = getattr(model, 'module', model)
+        flat = self._flat_log_probs(module, batch, save=False)
+        return flat_to_padded(flat, self._window(batch))
+
+    def loss(self, batch) -> dict[str, torch.Tensor]:
+        """dpo.py:144-203.  Also stages d loss / d logp for engine.backward (the loss kernel emits both)."""
+        w = self._window(batch)
+        B = w['N'] // 2
+        pol = self._flat_log_probs(self.model.module, batch, save=True)
+        ref = self._flat_log_probs(self.reference_model.module, batch, save=False)
+        out6, per, dlogp = ops.dpo_loss(pol, ref, w['seq_off'], B, self.scale_coeff, want_grad=True)
+        self.model.set_pending(dlogp)
+        return {
+            'loss': out6[0], 'reward': per[2], 'better_sample_reward': per[0], 'worse_sample_reward': per[1],
+            'reward_accuracy': out6[1], 'reward_margin': per[3], '_means': out6,
+        }
+
+    def train_step(self, batch) -> dict[str, Any]:
+        """dpo.py:205-237; the six scalar all-reduces + six .item() syncs are fused into one each."""
+        loss_dict = self.loss(batch)
+        self.model.backward(loss_dict['loss'])
+        self.model.step()
+        means = get_all_reduce_mean(loss_dict['_means'].clone())
+        m = means.tolist()  # the single device->host sync of the step
+        return {
+            'train/loss': m[0], 'train/reward': m[2], 'train/better_sample_reward': m[3],
+            'train/worse_sample_reward': m[4], 'train/reward_accuracy': m[1], 'train/reward_margin': m[5],
+            'train/lr': self.model.optimizer.param_groups[0]['lr'],
+        }
+
+    def train(self) -> list[dict[str, Any]]:
+        """dpo.py:239-308 without the per-step torch_gc() (a ZeRO-3 memory work-around)."""
+        history = []
+        epochs = int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))
+        self.model.train()
+        for epoch in range(epochs):
+            for batch in self.train_dataloader:
+                info = self.train_step(batch)
+                self.global_step += 1
+                info['train/epoch'] = self.global_step / max(1, len(self.train_dataloader))
+                history.append(info)
+            self.model.tput_timer.update_epoch_count()
+        return history
+
+    def eval(self) -> dict[str, Any]:
+        return {}  # the reference's DPO eval is a stub (dpo.py:310-313)
+
+    def save(self, model=None, tag=None, output_dir=None) -> str:
+        """base/supervised_trainer.py:404-450 layout: <output_dir>/slice_<tag|end>/{config.json, pytorch_model.bin}."""
+        out = output_dir or cfg_get(self.cfgs, 'logger_cfgs.output_dir', './output')
+        d = os.path.join(out, f'slice_{tag or "end"}')
+        (model or self.model).save_16bit_model(d, save_filename='pytorch_model.bin')
+        return d

@@ -53,6 +53,10 @@ int aa_logprob_gather_fwd(const void* logits, long ld, const int64_t* labels, fl
 int aa_logprob_gather_bwd(const void* logits, long ld, const int64_t* labels, const float* lse,
                           const float* dlogp, void* dlogits, long ldd, int rows, int V, int dtype,
                           void* stream);
+/* align_anything/trainers/text_to_text/dpo.py:131-137: labels = strip_pad(ids[n])[-R_n:][1:], written at
+ * labels[row_off[n] .. row_off[n] + R_n - 1); bit-exact integer path. ids int64[N,T]. */
+int aa_window_labels(const int64_t* ids, int N, int T, int64_t pad_id, const int* resp_len,
+                     const int* row_off, int64_t* labels, void* stream);
 /* align_anything/trainers/text_to_text/dpo.py:144-203 DPOTrainer.loss (forward + d loss/d logp).
  * sequences [0,B) better, [B,2B) worse; per-token log-probs flat, sequence s = rows
  * [seq_off[s], seq_off[s+1]).  out6 = loss, reward_accuracy, mean reward, mean better, mean worse,
@@ -85,13 +89,15 @@ int aa_gemm_set_tile(int tile);
 /* hf:models/llama/modeling_llama.py:62-67 LlamaRMSNorm */
 int aa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int h, float eps,
                    void* stream);
+/* dw (fp32 [h], accumulated) needs ws = fp32 [ws_rows, h] scratch (per-workgroup partial rows) */
 int aa_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, float* dw,
-                   int rows, int h, int add_to_dx, void* stream);
+                   float* ws, int ws_rows, int rows, int h, int add_to_dx, void* stream);
 /* torch F.layer_norm (CLIP, OPT) */
 int aa_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
                      int rows, int h, float eps, void* stream);
 int aa_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
-                     void* dx, float* dw, float* db, int rows, int h, int add_to_dx, void* stream);
+                     void* dx, float* dw, float* db, float* ws /* [2, ws_rows, h] */, int ws_rows, int rows,
+                     int h, int add_to_dx, void* stream);
 /* hf:models/llama/modeling_llama.py:113-160 rotary embedding, in place, inverse = backward */
 int aa_rope_inplace(void* buf, long ld, int col0, int nheads, int hd, const int* pos, const void* cos_t,
                     const void* sin_t, long rows, int inverse, void* stream);

@@ -1,0 +1,139 @@
+"""CPU: host-side logic of the native path (no compute calls): C-ABI loading/symbols, flat parameter
+store <-> HF state dict, response-window index plan, LR schedule, config access."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import ROOT, load_golden, state_dict_from_golden, tiny_llava_cfg, tiny_opt_cfg
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from align_anything_amd import build, lib
+    build.build()
+    protos = lib.parse_header()
+    assert len(protos) >= 40
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), f'{name} declared in include/aa_hip.h but not exported'
+    # and the other way round: every extern "C" aa_* definition is declared in the header
+    defined = set()
+    for f in os.listdir(os.path.join(ROOT, 'align_anything_amd', 'csrc')):
+        if f.endswith('.hip'):
+            src = open(os.path.join(ROOT, 'align_anything_amd', 'csrc', f)).read()
+            defined |= set(re.findall(r'extern "C"\s+(?:const char\*|int)\s+(aa_\w+)\s*\(', src))
+    assert defined == set(protos), (defined ^ set(protos))
+    lib.LIB.load()
+    assert lib.LIB._dll.aa_version() == 100
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from align_anything_amd import lib
+    l = lib._Lib()
+    monkeypatch.setattr(lib, 'LIB_PATH', '/nonexistent/libaa_hip.so')
+    with pytest.raises(lib.AAHipError):
+        l.load()
+
+
+def test_ops_refuse_cpu_tensors():
+    from align_anything_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16))
+
+
+def test_param_store_roundtrips_hf_state_dict_llava():
+    from align_anything_amd.modeling import build_model
+    z = load_golden('llava_tiny_dpo.npz')
+    sd = state_dict_from_golden(z, 'w.', torch.bfloat16)
+    m = build_model(tiny_llava_cfg(), 'cpu', trainable=True)
+    missing = m.load_state_dict(sd)
+    assert missing == []
+    out = m.state_dict()
+    assert set(out) == set(sd)
+    for k in sd:
+        assert out[k].shape == sd[k].shape, k
+        assert torch.equal(out[k], sd[k]), k
+    # fused blocks really are contiguous views of the HF tensors
+    st = m.store
+    q = st.view('model.language_model.layers.0.self_attn.q_proj.weight')
+    blk = st.p['model.language_model.layers.0.self_attn.qkv_fused']
+    assert q.data_ptr() == blk.data_ptr() and blk.shape == (3 * 128, 128)
+    # optimizer grouping follows utils/tools.py:241-270
+    assert st.specs['model.language_model.norm.weight']['group'] == 'vec'
+    assert st.specs['model.multi_modal_projector.linear_1.bias']['group'] == 'vec'
+    assert st.specs['lm_head.weight']['group'] == 'mat'
+    assert st.specs['model.language_model.embed_tokens.weight']['group'] == 'emb'
+    assert st.specs['model.vision_tower.post_layernorm.weight']['group'] == 'frozen'
+    m.init_training()
+    assert st.grad_view('model.language_model.layers.1.mlp.up_proj.weight').shape == (256, 128)
+    assert st.master['mat'].dtype == torch.float32 and st.gflat['mat'].dtype == torch.bfloat16
+
+
+def test_param_store_roundtrips_hf_state_dict_opt_with_tied_head():
+    from align_anything_amd.modeling import build_model
+    z = load_golden('opt_tiny_dpo.npz')
+    sd = state_dict_from_golden(z, 'w.', torch.bfloat16)
+    m = build_model(tiny_opt_cfg(), 'cpu')
+    m.load_state_dict(sd)
+    out = m.state_dict()
+    assert set(out) == set(sd)
+    for k in sd:
+        assert torch.equal(out[k], sd[k]), k
+
+
+def test_window_plan_matches_reference_slicing():
+    """positions/labels of logits[idx][-R:][:-1] x strip_pad(ids)[-R:][1:] (dpo.py:131-139), CPU part."""
+    from oracle import rl_math as orl
+    from align_anything_amd.trainers import common
+    z = load_golden('llava_tiny_dpo.npz')
+    ids = torch.from_numpy(z['input_ids'])
+    N, T = ids.shape
+    lens = [int(x) for x in z['response_lens']]
+    import align_anything_amd.ops as ops
+    orig = ops.window_labels
+    ops.window_labels = lambda *a, **k: None  # device kernel; checked in the gpu suite
+    try:
+        w = common.build_window(ids, lens, int(z['pad_token_id']))
+    finally:
+        ops.window_labels = orig
+    off = 0
+    for n, R in enumerate(lens):
+        pos, _ = orl.response_window(ids[n], int(z['pad_token_id']), R, T)
+        assert w['row_idx'][off:off + R - 1].tolist() == (pos + n * T).tolist()
+        off += R - 1
+    assert w['rows'] == sum(lens) - N and w['rows_pad'] % 64 == 0
+    inv = w['inv_map']
+    assert int((inv >= 0).sum()) == w['rows']
+    assert inv[w['row_idx'][:w['rows']]].tolist() == list(range(w['rows']))
+    flat = torch.arange(1, w['rows_pad'] + 1, dtype=torch.float32)
+    padded = common.flat_to_padded(flat, w)
+    assert padded.shape == (N, max(lens) - 1)
+    for n, R in enumerate(lens):
+        assert (padded[n, R - 1:] == 0).all() and (padded[n, :R - 1] != 0).all()
+    with pytest.raises(ValueError):
+        common.build_window(ids, [1, 2], 301)
+
+
+def test_cosine_schedule_matches_hf_get_scheduler():
+    from transformers import get_scheduler
+    from align_anything_amd.engine import cosine_with_warmup
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1e-6)
+    sch = get_scheduler('cosine', opt, num_warmup_steps=3, num_training_steps=40)
+    for step in range(40):
+        assert abs(opt.param_groups[0]['lr'] - cosine_with_warmup(step, 1e-6, 3, 40)) < 1e-15
+        opt.step(); sch.step()
+
+
+def test_cfg_get_reads_namedtuple_dict_and_missing():
+    from collections import namedtuple
+    from align_anything_amd.trainers.common import cfg_get
+    Tc = namedtuple('Tc', ['scale_coeff'])
+    C = namedtuple('C', ['train_cfgs'])
+    c = C(Tc(0.2))
+    assert cfg_get(c, 'train_cfgs.scale_coeff') == 0.2
+    assert cfg_get(c, 'train_cfgs.missing', 7) == 7
+    assert cfg_get({'a': {'b': 3}}, 'a.b') == 3 and cfg_get({'a': None}, 'a.b', 1) == 1

@@ -1,0 +1,154 @@
+"""GPU: the native model + DPO step (align_anything_amd) against (a) fixtures produced by the REFERENCE's own
+DPOTrainer on HF models (tests/golden, fp32) and (b) the CPU oracle run live.  Tolerances are bf16-level: the
+native path computes in bf16 with fp32 accumulation, the fixtures are fp32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as om
+from oracle import rl_math as orl
+from tests.gpu_util import assert_close, dev, dump
+from tests.util import load_golden, rel_err, state_dict_from_golden, tiny_llava_cfg, tiny_opt_cfg
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _batch(z, with_pixels=True):
+    b = {'input_ids': T(z['input_ids']).to(dev()), 'attention_mask': T(z['attention_mask']).to(dev()),
+         'meta_info': {'response_lens': [int(x) for x in z['response_lens']]}}
+    if with_pixels:
+        b['pixel_values'] = T(z['pixel_values']).to(dev())
+    return b
+
+
+def _trainer(z, cfg, share=False, **train_cfgs):
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    cfgs = {'train_cfgs': dict({'scale_coeff': float(z['scale_coeff']), 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0,
+                                'lr_scheduler_type': 'constant', 'weight_decay': 0.05, 'adam_betas': [0.9, 0.95]}, **train_cfgs),
+            'model_cfgs': {'pad_token_id': int(z['pad_token_id'])}}
+    pol = state_dict_from_golden(z, 'w.', torch.bfloat16)
+    ref = state_dict_from_golden(z, 'r.', torch.bfloat16)
+    return DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, policy_state=pol, reference_state=ref,
+                      device='cuda:0', share_vision_tower=share)
+
+
+def test_llava_logits_match_reference_fixture():
+    z = load_golden('llava_tiny_dpo.npz')
+    tr = _trainer(z, tiny_llava_cfg())
+    b = _batch(z)
+    logits = tr.policy.logits(b['input_ids'], b['attention_mask'], b['pixel_values']).float().cpu()
+    tr.policy.validate_batch()
+    valid = T(z['attention_mask']).bool()
+    ref = T(z['policy_logits'])
+    e = rel_err(logits[valid], ref[valid])
+    dump('parity_llava_logits.txt', f'rel_err={e:.5f} max_abs={(logits[valid]-ref[valid]).abs().max():.5f} ref_rms={ref[valid].pow(2).mean().sqrt():.4f}\n')
+    assert e < 2e-2, e
+
+
+def test_llava_dpo_loss_logprobs_and_grads_match_reference_fixture():
+    z = load_golden('llava_tiny_dpo.npz')
+    tr = _trainer(z, tiny_llava_cfg())
+    b = _batch(z)
+    lp = tr.compute_log_probs(tr.model, b).cpu()
+    gold = T(z['seq_log_probs'])
+    assert lp.shape == gold.shape
+    assert torch.equal(lp == 0, gold == 0), 'zero-padding layout (window/index logic) must be identical'
+    assert_close(lp, gold, rtol=2e-2, atol=5e-2, what='seq log probs')
+    ld = tr.loss(b)
+    report = []
+    for k in ('loss', 'reward', 'better_sample_reward', 'worse_sample_reward', 'reward_accuracy', 'reward_margin'):
+        got, want = ld[k].float().cpu(), T(z['loss_' + k]).float()
+        report.append(f'{k}: got {got.tolist()} want {want.tolist()}')
+        assert_close(got, want, rtol=5e-2, atol=3e-2, what=k)
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < 1e-2
+    tr.model.backward(ld['loss'])
+    torch.cuda.synchronize()
+    st = tr.policy.store
+    worst = 0.0
+    n_checked = 0
+    for k in z.files:
+        if not k.startswith('g.'):
+            continue
+        name = k[2:]
+        if name.startswith('model.vision_tower'):
+            continue  # frozen in the native trainer (reference default), fixture has grads because HF ran unfrozen
+        g = st.grad_view(name)
+        assert g is not None, name
+        want = T(z[k]).float()
+        got = g.float().cpu().reshape(want.shape) if g.numel() == want.numel() else None
+        assert got is not None, (name, g.shape, want.shape)
+        e = rel_err(got, want)
+        report.append(f'grad {name}: rel_err {e:.4f} |want| {want.norm():.3e}')
+        worst = max(worst, e)
+        n_checked += 1
+        assert e < 6e-2, (name, e)
+    dump('parity_llava_dpo.txt', '\n'.join(report) + f'\nworst grad rel err {worst:.4f} over {n_checked} tensors\n')
+    assert n_checked > 20
+
+
+def test_opt_dpo_matches_reference_fixture():
+    z = load_golden('opt_tiny_dpo.npz')
+    tr = _trainer(z, tiny_opt_cfg())
+    b = _batch(z, with_pixels=False)
+    logits = tr.policy.logits(b['input_ids'], b['attention_mask']).float().cpu()
+    valid = T(z['attention_mask']).bool()
+    e = rel_err(logits[valid], T(z['policy_logits'])[valid])
+    assert e < 2e-2, e
+    lp = tr.compute_log_probs(tr.model, b).cpu()
+    assert torch.equal(lp == 0, T(z['seq_log_probs']) == 0)
+    assert_close(lp, T(z['seq_log_probs']), rtol=2e-2, atol=5e-2, what='opt seq log probs')
+    ld = tr.loss(b)
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < 1e-2
+    tr.model.backward(ld['loss'])
+    torch.cuda.synchronize()
+    st = tr.policy.store
+    rep = []
+    for k in z.files:
+        if k.startswith('g.'):
+            name = k[2:]
+            if name == 'lm_head.weight':
+                continue
+            want = T(z[k]).float()
+            got = st.grad_view(name).float().cpu().reshape(want.shape)
+            e = rel_err(got, want)
+            rep.append(f'{name} {e:.4f}')
+            assert e < 6e-2, (name, e)
+    dump('parity_opt_dpo.txt', '\n'.join(rep) + '\n')
+
+
+def test_dpo_training_curve_tracks_fp32_oracle():
+    """Several optimizer steps: native (bf16 compute, fp32 master/Adam) vs the CPU oracle (fp32 model through
+    autograd + the restated FusedAdam).  SURVEY.md §8(d) config-1 style check at a tiny geometry."""
+    z = load_golden('opt_tiny_dpo.npz')
+    cfg = tiny_opt_cfg()
+    tr = _trainer(z, cfg)
+    b = _batch(z, with_pixels=False)
+    sd = state_dict_from_golden(z, 'w.')
+    sd.pop('lm_head.weight', None)
+    for v in sd.values():
+        v.requires_grad_(True)
+    sdr = state_dict_from_golden(z, 'r.')
+    ids, am = T(z['input_ids']), T(z['attention_mask'])
+    lens = [int(x) for x in z['response_lens']]
+    pad = int(z['pad_token_id'])
+    with torch.no_grad():
+        rlp = orl.compute_log_probs(om.opt_logits(sdr, cfg, ids, am), ids, lens, pad)
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    vv = {k: torch.zeros_like(v) for k, v in sd.items()}
+    from align_anything_amd.params import is_no_decay
+    native, oracle = [], []
+    for step in range(1, 5):
+        native.append(tr.train_step(b)['train/loss'])
+        lp = orl.compute_log_probs(om.opt_logits(sd, cfg, ids, am), ids, lens, pad)
+        loss = orl.dpo_loss(lp, rlp, 0.1)['loss']
+        oracle.append(float(loss))
+        grads = torch.autograd.grad(loss, list(sd.values()))
+        coef, _ = orl.clip_coef(grads, 1.0)
+        with torch.no_grad():
+            for (k, p), g in zip(sd.items(), grads):
+                orl.adamw_step(p, g * coef, m[k], vv[k], step, 1e-3, 0.9, 0.95, 1e-8, 0.0 if is_no_decay(k) else 0.05)
+    dump('parity_opt_curve.txt', f'native {native}\noracle {oracle}\n')
+    assert oracle[-1] < oracle[0], 'oracle loss should go down at lr 1e-3'
+    for a, o in zip(native, oracle):
+        assert abs(a - o) < 2e-2, (native, oracle)
