@@ -437,12 +437,15 @@ class NativeLlava(NativeCausalLM):
         slot = feat = f1 = a1 = vfeat = None
         if pixel_values is not None or image_features is not None:
             vfeat = image_features if image_features is not None else self.vision.forward(pixel_values)
+            n_feat = vfeat.shape[0]
+            if n_feat % 64:  # rows are the contraction dim of the projector dW GEMMs (K % 64); pad rows are zero
+                vfeat = torch.cat([vfeat, torch.zeros((_pad64(n_feat) - n_feat, vfeat.shape[1]), dtype=bf16, device=vfeat.device)])
             f1 = self.proj1.fwd(vfeat)
             a1 = ops.act_fwd(f1, ops.ACT_GELU)
             feat = self.proj2.fwd(a1)
             slot, count = ops.image_slot_index(ids, self.cfg['image_token_id'])
             self._last_image_token_count = count  # device scalar; checked lazily by validate_batch()
-            self._last_feature_rows = feat.shape[0]
+            self._last_feature_rows = n_feat
         x = ops.embed_fwd(ids, P[self.embed], slot, feat)
         if save:
             self._ctx = dict(ids=ids, slot=slot, f1=f1, a1=a1, vfeat=vfeat, N=N, T=T, start=start, pos=pos)

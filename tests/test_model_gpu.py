@@ -111,6 +111,9 @@ def test_opt_dpo_matches_reference_fixture():
                 continue
             want = T(z[k]).float()
             got = st.grad_view(name).float().cpu().reshape(want.shape)
+            if float(want.norm()) < 1e-6:  # mathematically zero gradient (e.g. k_proj.bias: softmax shift invariance)
+                assert float(got.norm()) < 1e-3, (name, float(got.norm()))
+                continue
             e = rel_err(got, want)
             rep.append(f'{name} {e:.4f}')
             assert e < 6e-2, (name, e)
