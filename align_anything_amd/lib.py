@@ -63,6 +63,13 @@ class _Lib:
                 f'{LIB_PATH} not found: build it with `python -m align_anything_amd.build` '
                 '(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.'
             )
+        # In a torch process the HIP runtime torch ships must be the one this library binds to (same
+        # SONAME): load torch first so both share one runtime / device context.  The library itself has no
+        # torch dependency.
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # pure-ctypes host: the system ROCm runtime is used
+            pass
         dll = ctypes.CDLL(LIB_PATH)
         for name, (ret, args) in self.protos.items():
             fn = getattr(dll, name)  # AttributeError if the .so does not export a declared symbol

@@ -62,9 +62,33 @@ def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=Fals
     flags = (GEMM_A_T if a_t else 0) | (GEMM_B_N if b_n else 0) | \
             (GEMM_OUT_F32 if out.dtype == torch.float32 else 0) | (GEMM_ACCUM if accumulate else 0)
     ldr = residual.stride(0) if residual is not None else 0
+    prof = GEMM_PROF
+    if prof is not None:
+        e0 = event_record()
     call('aa_gemm_bf16', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0),
          out.stride(0), _p(bias), _p(residual), ldr, int(act), flags, stream())
+    if prof is not None:
+        prof.append((e0, event_record(), 2.0 * M * N * K))
     return out
+
+
+# HIP events on the launch stream (bench.py roofline: per-launch GEMM durations over the timed region)
+GEMM_PROF = None
+
+
+def event_record():
+    import ctypes
+    ev = ctypes.c_void_p()
+    call('aa_event_create', ctypes.byref(ev))
+    call('aa_event_record', ev, stream())
+    return ev
+
+
+def event_elapsed_ms(e0, e1) -> float:
+    import ctypes
+    ms = ctypes.c_float()
+    call('aa_event_elapsed_ms', e0, e1, ctypes.byref(ms))
+    return float(ms.value)
 
 
 def gemm_set_tile(tile: int) -> None:

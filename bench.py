@@ -1,0 +1,230 @@
+"""bench.py -- DPO-step throughput of the MI355X-native hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N=1 default)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full DPO optimizer step on one synthetic micro-batch per GPU, exactly what
+DPOTrainer.train_step does (align_anything/trainers/text_to_text/dpo.py:205-237): policy forward on the 2B
+chosen/rejected rows + reference forward + fused log-prob/DPO loss + policy backward + (N>1) bucketed RCCL
+gradient all-reduce overlapped with backward + global-norm clip + AdamW.  Workload = BASELINE.json configs[1]:
+LLaVA-1.5-7B geometry (CLIP-L/14-336 + Llama 32x4096, V=32064), bf16, T=2048 = BOS + 576 image tokens + text,
+response R=512, random-init weights, synthetic ids/pixels (no network).  Nothing is skipped or cached inside
+the timed region; inputs are resident in HBM before it starts.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the bf16 MFMA GEMM, measured with
+HIP events around every GEMM launch of the timed steps) and `cpu_baseline` (the CPU oracle port, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_pair(cfg, T, R, n_img_tok, vision_passes=4):
+    """algorithmic FLOPs of one preference pair (causal attention at half, no recompute,
+    lm_head over all T positions as the reference executes it, vision tower `vision_passes` times)."""
+    t, v = cfg['text'], cfg['vision']
+    h, F, L, V = t['hidden_size'], t['intermediate_size'], t['num_layers'], t['vocab_size']
+    gemm = 2.0 * T * (L * (4 * h * h + 3 * h * F) + h * V)
+    attn = L * 2.0 * T * T * h
+    vt = (v['image_size'] // v['patch_size']) ** 2 + 1
+    vis = 2.0 * vt * v['num_layers'] * (4 * v['hidden_size'] ** 2 + 2 * v['hidden_size'] * v['intermediate_size']) \
+        + v['num_layers'] * 4.0 * vt * vt * v['hidden_size'] + 2.0 * (vt - 1) * 588 * v['hidden_size']
+    proj = 2.0 * n_img_tok * (v['hidden_size'] * h + h * h)
+    f_seq = gemm + attn + vis + proj
+    # policy fwd (2 rows) + ref fwd (2 rows) + policy bwd of LLM + projector (2x fwd)
+    total = 4 * (gemm + attn + proj) + vision_passes * vis + 2 * 2 * (gemm + attn) + 2 * 2 * proj
+    return total, f_seq
+
+
+def make_batch(cfg, B, T, R, device, seed):
+    """PreferenceCollator layout (datasets/text_image_to_text/preference.py:215-263): rows [0,B) chosen,
+    [B,2B) rejected, one image per pair shared by both rows, no padding (fixed (image_patches, seq_len))."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    n_img = (cfg['vision']['image_size'] // cfg['vision']['patch_size']) ** 2
+    N = 2 * B
+    ids = torch.randint(3, cfg['image_token_id'], (N, T), generator=g)
+    ids[:, 0] = 1
+    ids[:, 1:1 + n_img] = cfg['image_token_id']
+    # prompt (BOS + image + text) is shared by chosen and rejected; responses differ
+    ids[B:, :T - R] = ids[:B, :T - R]
+    S = cfg['vision']['image_size']
+    pix = torch.randn(B, 3, S, S, generator=g)
+    return {
+        'input_ids': ids.to(device), 'attention_mask': torch.ones(N, T, dtype=torch.long, device=device),
+        'pixel_values': torch.cat([pix, pix], 0).to(device), 'meta_info': {'response_lens': [R] * N},
+    }
+
+
+def random_init_(model, seed, std=0.02):
+    """Random-init weights of the named architecture (no checkpoints offline): N(0, std) matrices and
+    embeddings, norm weights 1, biases 0 -- directly on the device."""
+    g = torch.Generator(device=model.device).manual_seed(seed)
+    st = model.store
+    for name, s in st.specs.items():
+        p = st.p[name]
+        if len(s['shape']) >= 2:
+            p.normal_(0.0, std, generator=g)
+        elif 'norm' in name and name.endswith('weight'):
+            p.fill_(1.0)
+        else:
+            p.zero_()
+    if 'model.vision_tower.embeddings.patch_embedding.weight' in st.p:
+        st.p['model.vision_tower.embeddings.patch_embedding.weight'][:, 588:].zero_()
+
+
+def cpu_baseline(cfg, T, seconds_budget=30.0):
+    """The CPU oracle (port of the reference path) on a bounded sample: ONE Llama decoder layer of the 7B
+    geometry, forward + backward over the 2 rows of one pair at T=2048 in fp32, extrapolated linearly to
+    the per-pair cost (32 layers; policy fwd+bwd = 3 forward units, reference fwd = 1: x 4/3).  lm_head,
+    vision tower and optimizer are NOT included, so this flatters the CPU."""
+    from oracle import models as om
+    t = dict(cfg['text'])
+    t['num_layers'] = 1
+    torch.manual_seed(0)
+    h, F, H, hd = t['hidden_size'], t['intermediate_size'], t['num_heads'], t['head_dim']
+    p = 'model.language_model.'
+    sd = {p + 'layers.0.input_layernorm.weight': torch.ones(h), p + 'layers.0.post_attention_layernorm.weight': torch.ones(h),
+          p + 'norm.weight': torch.ones(h)}
+    for n, shape in (('self_attn.q_proj', (H * hd, h)), ('self_attn.k_proj', (H * hd, h)), ('self_attn.v_proj', (H * hd, h)),
+                     ('self_attn.o_proj', (h, H * hd)), ('mlp.gate_proj', (F, h)), ('mlp.up_proj', (F, h)), ('mlp.down_proj', (h, F))):
+        sd[p + f'layers.0.{n}.weight'] = (torch.randn(shape) * 0.02).requires_grad_(True)
+    x = torch.randn(2, T, h) * 0.1
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    out = om.llama_decoder(sd, t, x, None)
+    out.float().pow(2).mean().backward()
+    dt = time.time() - t0
+    per_pair = dt * cfg['text']['num_layers'] * 4.0 / 3.0
+    return {'value': 1.0 / per_pair, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/models.py llama_decoder, 1 of {cfg["text"]["num_layers"]} layers, fwd+bwd fp32, 2x{T} tokens: '
+                      f'{dt:.1f} s; extrapolated x{cfg["text"]["num_layers"]} layers x4/3 (policy fwd+bwd + ref fwd); '
+                      'lm_head/vision/optimizer excluded'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--pairs-per-gpu', type=int, default=int(os.environ.get('AA_BENCH_PAIRS', 2)))
+    ap.add_argument('--seq-len', type=int, default=2048)
+    ap.add_argument('--response-len', type=int, default=512)
+    ap.add_argument('--layers', type=int, default=32, help='LLM depth (32 = LLaVA-1.5-7B; anything else is NOT the headline config)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-gemm-events', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from align_anything_amd import configs, ops
+    from align_anything_amd.trainers.dpo import DPOTrainer
+
+    cfg = configs.llava_1_5_7b(num_layers=args.layers)
+    B, T, R = args.pairs_per_gpu, args.seq_len, args.response_len
+    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-6, 'lr_warmup_ratio': 0.03, 'weight_decay': 0.0,
+                           'adam_betas': [0.9, 0.95], 'lr_scheduler_type': 'cosine',
+                           'total_training_steps': args.steps + args.warmup, 'freeze_mm_proj': False,
+                           'freeze_language_model': False, 'freeze_vision_tower': True},
+            'model_cfgs': {'pad_token_id': cfg['pad_token_id']}}
+    tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, device=device)
+    random_init_(tr.policy, seed=42)
+    # reference = same checkpoint as the policy (dpo.py:89-99 loads both from model_name_or_path)
+    tr.reference.load_state_dict(tr.policy.state_dict())
+    for g in tr.policy.store.master:
+        tr.policy.store.master[g].copy_(tr.policy.store.flat[g])
+    batches = [make_batch(cfg, B, T, R, device, seed=1234 + rank * 1000 + i) for i in range(2)]
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        tr.train_step(batches[i % 2])
+    torch.cuda.synchronize()
+    barrier()
+
+    gemm_events = None if args.no_gemm_events else []
+    ops.GEMM_PROF = gemm_events
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    losses = []
+    for i in range(args.steps):
+        last = tr.train_step(batches[i % 2])
+        losses.append(round(last['train/loss'], 5))
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.GEMM_PROF = None
+
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    if rank == 0:
+        n_img = (cfg['vision']['image_size'] // cfg['vision']['patch_size']) ** 2
+        fl_pair, _ = flops_per_pair(cfg, T, R, n_img)
+        pairs = B * world * args.steps
+        value = pairs / dt
+        step_tflops = fl_pair * B / (dt / args.steps) / 1e12   # per GPU
+        out = {
+            'metric': 'preference-pairs/sec (DPO step, LLaVA-1.5-7B geometry, seq=2048), whole job',
+            'value': value, 'unit': 'pairs/s', 'per_gpu': value / world, 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[1]: LLaVA-1.5-7B DPO, bf16, 336px/576 patches, seq_len={T}, response={R}, '
+                                   f'{B} pairs/GPU/step, policy+ref fwd, bwd, clip, AdamW' + ('' if args.layers == 32 else f' [REDUCED DEPTH {args.layers}]'),
+                       'global_batch_pairs': B * world, 'seq_len': T, 'parallelism': f'dp{world}',
+                       'trainable_params': tr.policy.store.num_trainable(), 'losses_timed_steps': losses},
+            'step_mfma': {'algorithmic_tflop_per_pair': fl_pair / 1e12, 'achieved_tflops_per_gpu': step_tflops,
+                          'frac_of_dense_bf16_peak': step_tflops / PEAK_BF16_TFLOPS,
+                          'note': 'SURVEY.md §8(d) accounting (lm_head over all T, 4 vision passes); executed work is smaller: '
+                                  'lm_head only on response rows, vision tower once per image'},
+        }
+        if gemm_events:
+            tot_ms, tot_fl = 0.0, 0.0
+            for ev0, ev1, fl in gemm_events:
+                tot_ms += ops.event_elapsed_ms(ev0, ev1)
+                tot_fl += fl
+            n = len(gemm_events)
+            ach = tot_fl / tot_ms / 1e9
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel<BM,BN,...> (csrc/gemm.hip), all launches of the timed steps',
+                               'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
+                               'traffic': None, 'launches': n, 'avg_launch_ms': tot_ms / n,
+                               'avg_flops_per_launch': tot_fl / n, 'gemm_share_of_step_time': tot_ms / (dt * 1e3)}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out['cpu_baseline'] = cpu_baseline(cfg, T)
+            except Exception as ex:  # the bench line must still be printed
+                out['cpu_baseline'] = {'error': repr(ex)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
