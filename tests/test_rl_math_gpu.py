@@ -96,3 +96,39 @@ def test_ppo_math_matches_reference_golden():
     loss, g = ops.ppo_critic_loss(d('ppo_new_values'), d('ppo_values'), d('ppo_ret_s0'), mask, 5.0)
     assert abs(loss.item() - float(z['ppo_critic_loss'])) < 1e-4 * max(1.0, abs(float(z['ppo_critic_loss'])))
     assert_close(g, d('ppo_critic_grad'), rtol=1e-4, atol=1e-6, what='critic grad')
+
+
+def test_ppo_math_module_has_reference_signatures_and_values():
+    from align_anything_amd.trainers.ppo import PPOMath, gather_log_probabilities
+    z = load_golden('rl_math.npz')
+    d = lambda k: T(z[k]).to(dev())
+    pm = PPOMath()
+    mask = d('ppo_mask')
+    rew = pm.add_kl_divergence_regularization(d('ppo_reward'), d('ppo_logp'), d('ppo_ref'), mask)
+    assert_close(rew, d('ppo_kl_rewards'), rtol=1e-6, atol=1e-6)
+    adv, ret = pm.get_advantages_and_returns(d('ppo_values'), rew, mask, 4)
+    assert_close(adv, d('ppo_adv_s4'), rtol=1e-5, atol=1e-5)
+    loss, g = pm.actor_loss_fn(d('ppo_new_logp'), d('ppo_logp'), d('ppo_adv_s0'), mask)
+    assert abs(loss.item() - float(z['ppo_actor_loss'])) < 1e-5
+    lg = d('glp_logits')[None]
+    out = gather_log_probabilities(lg, d('glp_labels')[None])
+    assert_close(out[0], d('glp_out_f32'), rtol=1e-5, atol=2e-5)
+
+
+def test_window_labels_are_bit_exact_including_inner_pad_ids():
+    """strip_pad(ids)[-R:][1:] (dpo.py:131-137) -- integer path, including pad ids INSIDE the text."""
+    from align_anything_amd.trainers.common import build_window
+    g = torch.Generator().manual_seed(5)
+    N, Tn, pad = 6, 700, 1
+    ids = torch.randint(2, 50, (N, Tn), generator=g)
+    lens = [10, 300, 1, 77, 512, 2]
+    for n, lp in enumerate((0, 13, 255, 300, 1, 64)):
+        ids[n, :lp] = pad
+    ids[1, 500] = pad; ids[1, 650] = pad; ids[4, Tn - 3] = pad   # pad ids inside the sequence
+    w = build_window(ids.to(dev()), lens, pad)
+    lab = w['labels'].cpu()
+    off = 0
+    for n, R in enumerate(lens):
+        _, want = orl.response_window(ids[n], pad, R, Tn)
+        assert torch.equal(lab[off:off + R - 1], want), n
+        off += R - 1
