@@ -30,23 +30,33 @@ template <int HD> __device__ __forceinline__ int unit_swz(int row) {
 }
 
 // DMA a [ROWS][HD] bf16 tile (rows row0.. of one sequence/head, clamped to max_row-1) into LDS.
+// The per-lane (row-in-tile, column) pairs depend only on the lane: computed once (DmaLane), so a tile
+// issue costs one min + one 64-bit mad per 1-KiB piece.
 template <int HD, int ROWS, int NW>
-__device__ __forceinline__ void dma_tile(const bf16_t* gbase, long ld, int row0, int max_row,
-                                         char* lds, int wave, int lane) {
-    constexpr int ROW_B = HD * 2, RPI = 1024 / ROW_B, SPR = ROW_B / 16;
-    constexpr int IT = (ROWS / RPI) / NW;
+struct DmaLane {
+    static constexpr int ROW_B = HD * 2, RPI = 1024 / ROW_B, SPR = ROW_B / 16;
+    static constexpr int IT = (ROWS / RPI) / NW;
     static_assert(IT >= 1, "tile too small");
+    int r[IT], col[IT], chunk[IT];
+    __device__ __forceinline__ void init(int wave, int lane) {
 #pragma unroll
-    for (int j = 0; j < IT; ++j) {
-        const int c = wave + j * NW;
-        const int r = c * RPI + lane / SPR;
-        const int s = lane % SPR;
-        const int unit = (s >> 1) ^ unit_swz<HD>(r);
-        const int gr = min(row0 + r, max_row - 1);
-        const bf16_t* src = gbase + (long)gr * ld + unit * 16 + (s & 1) * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + c * 1024), 16, 0, 0);
+        for (int j = 0; j < IT; ++j) {
+            const int c = wave + j * NW;
+            r[j] = c * RPI + lane / SPR;
+            const int s = lane % SPR;
+            col[j] = (((s >> 1) ^ unit_swz<HD>(r[j])) << 4) + (s & 1) * 8;
+            chunk[j] = c * 1024;
+        }
     }
-}
+    __device__ __forceinline__ void issue(const bf16_t* gbase, long ld, int row0, int max_row, char* lds) const {
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int gr = min(row0 + r[j], max_row - 1);
+            const bf16_t* src = gbase + (long)gr * ld + col[j];
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + chunk[j]), 16, 0, 0);
+        }
+    }
+};
 
 // 16-byte fragment read: tile row `row`, 16-B slot index `slot16` (8 bf16 along HD)
 template <int HD>
@@ -71,12 +81,21 @@ __device__ __forceinline__ bf16x8 lds_tr_pair(const char* tile, int a16, int b16
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x4& a, const f32x4& b) {
-    bf16x8 r;
-    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
-    r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
-    return r;
+    // 2-wide converts lower to v_cvt_pk_bf16_f32 (one instruction per pair)
+    const bf16x2 p0 = __builtin_convertvector(f32x2{a[0], a[1]}, bf16x2);
+    const bf16x2 p1 = __builtin_convertvector(f32x2{a[2], a[3]}, bf16x2);
+    const bf16x2 p2 = __builtin_convertvector(f32x2{b[0], b[1]}, bf16x2);
+    const bf16x2 p3 = __builtin_convertvector(f32x2{b[2], b[3]}, bf16x2);
+    const bf16x4 lo = __builtin_shufflevector(p0, p1, 0, 1, 2, 3);
+    const bf16x4 hi = __builtin_shufflevector(p2, p3, 0, 1, 2, 3);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// v_exp_f32 without the denormal-range fix-up of exp2f(): arguments here are <= 0 and results that would be
+// denormal contribute nothing to a softmax sum
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct AttnParams {
     const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
@@ -90,22 +109,29 @@ struct AttnParams {
 };
 
 // ================================================================== forward
-// grid = (ceil(T/128), H, N), 256 threads: wave w owns queries q0 + 32w .. +31 (two 16-query groups)
+// 1-D grid, heaviest (latest) query blocks first and heads fastest, so the 8 XCDs (block b -> XCD b % 8) get
+// equal causal work and short blocks fill the tail.  256 threads: wave w owns queries q0 + 32w .. +31.
 template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KS = HD / 32, DB = HD / 16;
     constexpr int TILE_B = 64 * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = blockIdx.z, h = blockIdx.y, hk = h / (p.H / p.Hkv);
-    const int q0 = blockIdx.x * 128, qw = q0 + wave * 32;
+    const int HN = p.H * p.N;
+    const int nqb = (p.T + 127) / 128;
+    const int hn = blockIdx.x % HN;
+    const int qb = nqb - 1 - blockIdx.x / HN;
+    const int n = hn / p.H, h = hn % p.H, hk = h / (p.H / p.Hkv);
+    const int q0 = qb * 128, qw = q0 + wave * 32;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
     const bf16_t* Qb = p.Q + (long)n * T * p.ldq + h * HD;
     const bf16_t* Kb = p.K + (long)n * T * p.ldk + hk * HD;
     const bf16_t* Vb = p.V + (long)n * T * p.ldv + hk * HD;
     const float c2 = p.scale * LOG2E_F;
+    DmaLane<HD, 64, 4> dma;
+    dma.init(wave, lane);
 
     // Q fragments (B operand of S^T): lane -> query l15, d = ks*32 + g*8 ..+7
     bf16x8 qf[2][KS];
@@ -127,8 +153,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const int kv_end = p.causal ? min(T, q0 + 128) : T;
     const int ntile = (kv_end - kv_begin + 63) / 64;
     if (ntile > 0) {
-        dma_tile<HD, 64, 4>(Kb, p.ldk, kv_begin, T, smem, wave, lane);
-        dma_tile<HD, 64, 4>(Vb, p.ldv, kv_begin, T, smem + TILE_B, wave, lane);
+        dma.issue(Kb, p.ldk, kv_begin, T, smem);
+        dma.issue(Vb, p.ldv, kv_begin, T, smem + TILE_B);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -136,8 +162,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         const int cur = t & 1;
         const int kv0 = kv_begin + t * 64;
         if (t + 1 < ntile) {
-            dma_tile<HD, 64, 4>(Kb, p.ldk, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B, wave, lane);
-            dma_tile<HD, 64, 4>(Vb, p.ldv, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B + TILE_B, wave, lane);
+            dma.issue(Kb, p.ldk, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B);
+            dma.issue(Vb, p.ldv, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B + TILE_B);
         }
         const char* kt = smem + cur * 2 * TILE_B;
         const char* vt = kt + TILE_B;
@@ -158,39 +184,55 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
                     for (int qi = 0; qi < 2; ++qi)
                         sacc[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], sacc[qi][kb], 0, 0, 0);
                 }
+            // masks only where a mask can bite: diagonal tile, left-pad boundary, ragged end (wave-uniform)
+            const bool need_mask = (p.causal && kv0 + 63 > qw) || kv0 < start || kv0 + 64 > T;
             bf16x8 pf[2][2];
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi) {
-                const int qg = qw + qi * 16 + l15;
                 float mx = -INFINITY;
+                if (need_mask) {
+                    const int qg = qw + qi * 16 + l15;
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
+                    for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kv = kv0 + kb * 16 + g * 4 + r;
-                        const bool ok = kv >= start && kv < T && (!p.causal || kv <= qg);
-                        const float s = ok ? sacc[qi][kb][r] * c2 : -INFINITY;
-                        sacc[qi][kb][r] = s;
-                        mx = fmaxf(mx, s);
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            const int kv = kv0 + kb * 16 + g * 4 + r;
+                            const bool ok = kv >= start && kv < T && (!p.causal || kv <= qg);
+                            const float s = ok ? sacc[qi][kb][r] * c2 : -INFINITY;
+                            sacc[qi][kb][r] = s;
+                            mx = fmaxf(mx, s);
+                        }
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float s = sacc[qi][kb][r] * c2;
+                            sacc[qi][kb][r] = s;
+                            mx = fmaxf(mx, s);
+                        }
+                }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float mn = fmaxf(m2[qi], mx);
                 const float ms = (mn == -INFINITY) ? 0.f : mn;
-                const float alpha = exp2f(m2[qi] - ms);
+                const float alpha = fast_exp2(m2[qi] - ms);
                 m2[qi] = mn;
                 float ps = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pe = exp2f(sacc[qi][kb][r] - ms);
+                        const float pe = fast_exp2(sacc[qi][kb][r] - ms);
                         sacc[qi][kb][r] = pe;
                         ps += pe;
                     }
                 lsum[qi] = lsum[qi] * alpha + ps;
+                // exact skip of the O rescale while the running max is unchanged for the whole wave
+                if (!__all(alpha == 1.f)) {
 #pragma unroll
-                for (int db = 0; db < DB; ++db) oacc[qi][db] *= alpha;
+                    for (int db = 0; db < DB; ++db) oacc[qi][db] *= alpha;
+                }
                 pf[qi][0] = pack_bf16x8(sacc[qi][0], sacc[qi][1]);
                 pf[qi][1] = pack_bf16x8(sacc[qi][2], sacc[qi][3]);
             }
@@ -254,16 +296,20 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
 }
 
 // ================================================================== backward: dQ
-// same structure as forward; dQ^T[d][q] += K^T[d][kv] * dS^T[kv][q]
+// same structure / block order as forward; dQ^T[d][q] += K^T[d][kv] * dS^T[kv][q]
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
     constexpr int KS = HD / 32, DB = HD / 16;
     constexpr int TILE_B = 64 * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = blockIdx.z, h = blockIdx.y, hk = h / (p.H / p.Hkv);
-    const int q0 = blockIdx.x * 128, qw = q0 + wave * 32;
+    const int HN = p.H * p.N;
+    const int nqb = (p.T + 127) / 128;
+    const int hn = blockIdx.x % HN;
+    const int qb = nqb - 1 - blockIdx.x / HN;
+    const int n = hn / p.H, h = hn % p.H, hk = h / (p.H / p.Hkv);
+    const int q0 = qb * 128, qw = q0 + wave * 32;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
     const bf16_t* Qb = p.Q + (long)n * T * p.ldq + h * HD;
@@ -271,6 +317,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
     const bf16_t* Kb = p.K + (long)n * T * p.ldk + hk * HD;
     const bf16_t* Vb = p.V + (long)n * T * p.ldv + hk * HD;
     const float c2 = p.scale * LOG2E_F;
+    DmaLane<HD, 64, 4> dma;
+    dma.init(wave, lane);
 
     bf16x8 qf[2][KS], dof[2][KS];
     float lse2[2], dl[2];
@@ -295,8 +343,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
     const int kv_end = p.causal ? min(T, q0 + 128) : T;
     const int ntile = (kv_end - kv_begin + 63) / 64;
     if (ntile > 0) {
-        dma_tile<HD, 64, 4>(Kb, p.ldk, kv_begin, T, smem, wave, lane);
-        dma_tile<HD, 64, 4>(Vb, p.ldv, kv_begin, T, smem + TILE_B, wave, lane);
+        dma.issue(Kb, p.ldk, kv_begin, T, smem);
+        dma.issue(Vb, p.ldv, kv_begin, T, smem + TILE_B);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -304,8 +352,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
         const int cur = t & 1;
         const int kv0 = kv_begin + t * 64;
         if (t + 1 < ntile) {
-            dma_tile<HD, 64, 4>(Kb, p.ldk, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B, wave, lane);
-            dma_tile<HD, 64, 4>(Vb, p.ldv, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B + TILE_B, wave, lane);
+            dma.issue(Kb, p.ldk, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B);
+            dma.issue(Vb, p.ldv, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B + TILE_B);
         }
         const char* kt = smem + cur * 2 * TILE_B;
         const char* vt = kt + TILE_B;
@@ -331,6 +379,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
                         dpacc[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qi][ks], dpacc[qi][kb], 0, 0, 0);
                     }
                 }
+            const bool need_mask = (p.causal && kv0 + 63 > qw) || kv0 < start || kv0 + 64 > T || qw + 32 > T;
             bf16x8 dsf[2][2];
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi) {
@@ -339,9 +388,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int kv = kv0 + kb * 16 + g * 4 + r;
-                        const bool ok = kv >= start && kv < T && (!p.causal || kv <= qg) && qg < T;
-                        const float pe = ok ? exp2f(sacc[qi][kb][r] * c2 - lse2[qi]) : 0.f;
+                        float pe = fast_exp2(sacc[qi][kb][r] * c2 - lse2[qi]);
+                        if (need_mask) {
+                            const int kv = kv0 + kb * 16 + g * 4 + r;
+                            const bool ok = kv >= start && kv < T && (!p.causal || kv <= qg) && qg < T;
+                            pe = ok ? pe : 0.f;
+                        }
                         sacc[qi][kb][r] = pe * (dpacc[qi][kb][r] - dl[qi]) * p.scale;
                     }
                 dsf[qi][0] = pack_bf16x8(sacc[qi][0], sacc[qi][1]);
@@ -376,27 +428,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
 }
 
 // ================================================================== backward: dK, dV
-// grid = (ceil(T/64), Hkv, N); wave w owns keys kvw = kv0 + 16w .. +15; loops over 64-query tiles
-// (and over the H/Hkv query heads sharing this kv head).
+// 1-D grid: kv block = blockIdx / (Hkv*N) ascending (block 0 sees every query tile under a causal mask: heaviest
+// first), kv heads fastest.  Wave w owns keys kv0 + 16w .. +15 and loops over 64-query tiles (and over the
+// H/Hkv query heads sharing this kv head).
 //   S[q][kv] = Q K^T, dP[q][kv] = dO V^T          (lane: kv = lane&15, q = 16qb + 4g + r)
 //   dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
     constexpr int KS = HD / 32, DB = HD / 16;
     constexpr int TILE_B = 64 * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q tile | dO tile] + [2][64 lse | 64 delta]
     float* stat = reinterpret_cast<float*>(smem + 4 * TILE_B);
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = blockIdx.z, hk = blockIdx.y;
+    const int HkN = p.Hkv * p.N;
+    const int hn = blockIdx.x % HkN;
+    const int n = hn / p.Hkv, hk = hn % p.Hkv;
     const int group = p.H / p.Hkv;
-    const int kv0 = blockIdx.x * 64, kvw = kv0 + wave * 16;
+    const int kv0 = (blockIdx.x / HkN) * 64, kvw = kv0 + wave * 16;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
     const bf16_t* Kb = p.K + (long)n * T * p.ldk + hk * HD;
     const bf16_t* Vb = p.V + (long)n * T * p.ldv + hk * HD;
     const float c2 = p.scale * LOG2E_F;
     const int kvg = kvw + l15;
+    DmaLane<HD, 64, 4> dma;
+    dma.init(wave, lane);
 
     bf16x8 kf[KS], vf[KS];
     {
@@ -421,8 +478,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
         const int qt0 = q_begin + (it % ntq) * 64;
         const bf16_t* Qb = p.Q + (long)n * T * p.ldq + hh * HD;
         const bf16_t* dOb = p.dO + (long)n * T * p.lddo + hh * HD;
-        dma_tile<HD, 64, 4>(Qb, p.ldq, qt0, T, smem + buf * 2 * TILE_B, wave, lane);
-        dma_tile<HD, 64, 4>(dOb, p.lddo, qt0, T, smem + buf * 2 * TILE_B + TILE_B, wave, lane);
+        dma.issue(Qb, p.ldq, qt0, T, smem + buf * 2 * TILE_B);
+        dma.issue(dOb, p.lddo, qt0, T, smem + buf * 2 * TILE_B + TILE_B);
         if (threadIdx.x < 128) {
             const int i = threadIdx.x & 63;
             const int qr = min(qt0 + i, T - 1);
@@ -455,6 +512,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
                     sacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sacc[qb], 0, 0, 0);
                     dpacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dpacc[qb], 0, 0, 0);
                 }
+            const bool need_mask = (p.causal && qt0 < kvw + 15) || kvw < start || kvw + 16 > T || qt0 + 64 > T;
             bf16x8 pfr[2], dsfr[2];
             f32x4 pv[4], dsv[4];
 #pragma unroll
@@ -462,9 +520,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ql = qb * 16 + g * 4 + r;
-                    const int qg = qt0 + ql;
-                    const bool ok = kvg >= start && kvg < T && qg < T && (!p.causal || kvg <= qg);
-                    const float pe = ok ? exp2f(sacc[qb][r] * c2 - st[ql]) : 0.f;
+                    float pe = fast_exp2(sacc[qb][r] * c2 - st[ql]);
+                    if (need_mask) {
+                        const int qg = qt0 + ql;
+                        const bool ok = kvg >= start && kvg < T && qg < T && (!p.causal || kvg <= qg);
+                        pe = ok ? pe : 0.f;
+                    }
                     pv[qb][r] = pe;
                     dsv[qb][r] = pe * (dpacc[qb][r] - st[64 + ql]) * p.scale;
                 }
@@ -531,7 +592,7 @@ extern "C" int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O,
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O;
     p.lse = lse; p.start = start; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
-    dim3 grid(aa_cdiv(T, 128), H, N);
+    dim3 grid(aa_cdiv(T, 128) * H * N);
     const int lds = 4 * 64 * hd * 2;
     if (hd == 128) {
         if ((rc = set_lds(attn_fwd_kernel<128>, lds, "aa_attn_fwd"))) return rc;
@@ -562,18 +623,19 @@ extern "C" int aa_attn_bwd(const void* Q, const void* K, const void* V, const vo
     hipStream_t st = (hipStream_t)stream;
     const long groups = (long)N * T * H;
     const int lds = 4 * 64 * hd * 2;
+    const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
     if (hd == 128) {
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(aa_cdiv(groups * 16, 256)), dim3(256), 0, st, p);
         if ((rc = set_lds(attn_bwd_dq_kernel<128>, lds, "aa_attn_bwd"))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, dim3(aa_cdiv(T, 128), H, N), dim3(256), lds, st, p);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), lds, st, p);
         if ((rc = set_lds(attn_bwd_dkv_kernel<128>, lds + 1024, "aa_attn_bwd"))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, dim3(aa_cdiv(T, 64), Hkv, N), dim3(256), lds + 1024, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gkv, dim3(256), lds + 1024, st, p);
     } else {
         hipLaunchKernelGGL(attn_delta_kernel<64>, dim3(aa_cdiv(groups * 8, 256)), dim3(256), 0, st, p);
         if ((rc = set_lds(attn_bwd_dq_kernel<64>, lds, "aa_attn_bwd"))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3(aa_cdiv(T, 128), H, N), dim3(256), lds, st, p);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), lds, st, p);
         if ((rc = set_lds(attn_bwd_dkv_kernel<64>, lds + 1024, "aa_attn_bwd"))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3(aa_cdiv(T, 64), Hkv, N), dim3(256), lds + 1024, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gkv, dim3(256), lds + 1024, st, p);
     }
     AA_CHECK_LAUNCH("aa_attn_bwd");
     return AA_OK;

@@ -130,7 +130,8 @@ if __name__ == '__main__':
             res.append(dict(kernel=fn.__name__, error=repr(ex)))
             print('ERROR', fn.__name__, ex, flush=True)
     try:
-        bench_gemm(res, quick)
+        if '--no-gemm' not in sys.argv:
+            bench_gemm(res, quick)
     except Exception as ex:
         res.append(dict(kernel='gemm', error=repr(ex)))
         print('ERROR gemm', ex, flush=True)
