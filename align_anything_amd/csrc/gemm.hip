@@ -58,7 +58,7 @@ constexpr int BK = 64;
 // row-contiguous tile: [64 k rows][R cols] bf16; 32-B unit ^= (krow&3) | ((krow>>3)&1)<<2.
 __device__ __forceinline__ int tr_swz(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
-template <int BM, int BN, int WM, int WN, bool A_T, bool B_N>
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1)
 void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
@@ -174,64 +174,96 @@ void gemm_kernel(const GemmParams p) {
     for (int kk = 0; kk < 2; ++kk) offK[kk] = l15 * 128 + (((kk * 4 + g) ^ ((l15 >> 1) & 7)) << 4);
     // row-contiguous (transpose read): k-row = kk*32 + 8g + 4*hh + (l15>>2), col = base16 + (l15&3)*4
 
-    auto compute = [&](int buf) {
+    // fragment loads for one 32-deep k-step (kk) of buffer `buf` into a named register set
+    auto load_frags = [&](int buf, int kk, bf16x8 (&af)[FM], bf16x8 (&bfr)[FN]) {
         const char* sa = smem + buf * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[FM], bfr[FN];
+        for (int i = 0; i < FM; ++i) {
+            if constexpr (!A_T) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * TM + i * 16) * 128 + offK[kk]);
+            } else {
+                bf16x4 h[2];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                if constexpr (!A_T) {
-                    af[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * TM + i * 16) * 128 + offK[kk]);
-                } else {
-                    bf16x4 h[2];
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const int kr = kk * 32 + g * 8 + hh * 4 + (l15 >> 2);
-                        const int colb = wm * TM + i * 16;  // multiple of 16 -> unit index
-                        const int unit = (colb >> 4) ^ tr_swz(kr);
-                        const char* a = sa + kr * (BM * 2) + unit * 32 + (l15 & 3) * 8;
-                        h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a);
-                    }
-                    af[i] = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int kr = kk * 32 + g * 8 + hh * 4 + (l15 >> 2);
+                    const int colb = wm * TM + i * 16;  // multiple of 16 -> unit index
+                    const int unit = (colb >> 4) ^ tr_swz(kr);
+                    const char* a = sa + kr * (BM * 2) + unit * 32 + (l15 & 3) * 8;
+                    h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a);
                 }
+                af[i] = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
             }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                if constexpr (!B_N) {
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(sb + (wn * TN + j * 16) * 128 + offK[kk]);
-                } else {
-                    bf16x4 h[2];
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const int kr = kk * 32 + g * 8 + hh * 4 + (l15 >> 2);
-                        const int colb = wn * TN + j * 16;
-                        const int unit = (colb >> 4) ^ tr_swz(kr);
-                        const char* a = sb + kr * (BN * 2) + unit * 32 + (l15 & 3) * 8;
-                        h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a);
-                    }
-                    bfr[j] = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            if constexpr (!B_N) {
+                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + (wn * TN + j * 16) * 128 + offK[kk]);
+            } else {
+                bf16x4 h[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int kr = kk * 32 + g * 8 + hh * 4 + (l15 >> 2);
+                    const int colb = wn * TN + j * 16;
+                    const int unit = (colb >> 4) ^ tr_swz(kr);
+                    const char* a = sb + kr * (BN * 2) + unit * 32 + (l15 & 3) * 8;
+                    h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a);
+                }
+                bfr[j] = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+    };
+    auto mfma_step = [&](const bf16x8 (&af)[FM], const bf16x8 (&bfr)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     };
 
     const int nt = p.K / BK;
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) stage(cur ^ 1);
-        compute(cur);
+    if constexpr (!PIPE) {
+        // simple schedule: one barrier per K-tile, fragment reads interleaved by the compiler
+        stage(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt) stage(cur ^ 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[FM], bfr[FN];
+                load_frags(cur, kk, af, bfr);
+                mfma_step(af, bfr);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        // software-pipelined schedule: two named fragment sets; every batch of ds_reads is issued BEFORE a
+        // 32-MFMA batch that does not depend on it, and the barrier sits between the two batches of a tile:
+        //   A: F1 <- tile t (kk=1)      | MFMA(F0)          B: wait DMA(t+1), barrier
+        //   C: F0 <- tile t+1 (kk=0), DMA tile t+2 -> freed buffer | MFMA(F1)
+        bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];
+        stage(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        load_frags(0, 0, a0, b0);
+        if (nt > 1) stage(1);
+        for (int t = 0; t < nt; ++t) {
+            const int cur = t & 1;
+            load_frags(cur, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // tile t+1 landed for everyone; every wave is done reading buf[cur]
+            if (t + 1 < nt) load_frags(cur ^ 1, 0, a0, b0);
+            if (t + 2 < nt) stage(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- epilogue: lane owns C[m][n..n+3], m = .. + l15, n = .. + g*4
@@ -281,12 +313,14 @@ void gemm_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_T, bool B_N>
-static int launch_cfg(GemmParams& p, hipStream_t st) {
+static int g_pipe = 1;  // 1: software-pipelined K loop (default), 0: simple schedule
+
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE>
+static int launch_cfg2(GemmParams& p, hipStream_t st) {
     p.tiles_m = aa_cdiv(p.M, BM);
     p.tiles_n = aa_cdiv(p.N, BN);
     constexpr int lds = 2 * (BM + BN) * BK * 2;
-    auto kern = gemm_kernel<BM, BN, WM, WN, A_T, B_N>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, A_T, B_N, PIPE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -300,6 +334,11 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), lds, st, p);
     AA_CHECK_LAUNCH("aa_gemm_bf16");
     return AA_OK;
+}
+
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_N>
+static int launch_cfg(GemmParams& p, hipStream_t st) {
+    return g_pipe ? launch_cfg2<BM, BN, WM, WN, A_T, B_N, true>(p, st) : launch_cfg2<BM, BN, WM, WN, A_T, B_N, false>(p, st);
 }
 
 template <bool A_T, bool B_N>
@@ -366,3 +405,5 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
 
 // test hook: force a tile config (-1 = heuristic)
 extern "C" int aa_gemm_set_tile(int tile) { g_force_tile = tile; return AA_OK; }
+// test/bench hook: 1 = software-pipelined K loop (default), 0 = simple one-barrier schedule
+extern "C" int aa_gemm_set_pipeline(int on) { g_pipe = on ? 1 : 0; return AA_OK; }
