@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libaa_hip.so')
-SOURCES = ['runtime.hip', 'rl_math.hip', 'elementwise.hip', 'optim.hip', 'gemm.hip', 'attention.hip']
+SOURCES = ['runtime.hip', 'rl_math.hip', 'elementwise.hip', 'optim.hip', 'gemm.hip', 'gemm32.hip', 'attention.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wno-unused-result']
 
@@ -26,8 +26,8 @@ def _newer(a: str, b: str) -> bool:
 def _compile(src: str) -> str:
     s = os.path.join(CSRC, src)
     o = os.path.join(OBJ, src.replace('.hip', '.o'))
-    hdr = os.path.join(CSRC, 'aa_common.h')
-    if _newer(s, o) or _newer(hdr, o):
+    hdrs = [os.path.join(CSRC, h) for h in ('aa_common.h', 'gemm_params.h')]
+    if _newer(s, o) or any(_newer(h, o) for h in hdrs if os.path.exists(h)):
         cmd = [HIPCC, *FLAGS, '-c', s, '-o', o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

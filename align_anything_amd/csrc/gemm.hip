@@ -17,48 +17,13 @@
 //  * 1-D grid with a bijective XCD-aware remap + grouped tile order so neighbouring tiles share an L2.
 #include "aa_common.h"
 
-#define AA_ACT_NONE 0
-#define AA_ACT_GELU 1
-#define AA_ACT_QUICK_GELU 2
-#define AA_ACT_RELU 3
-#define AA_ACT_SILU 4
-
-// flags
-#define AA_GEMM_A_T 1         // A stored [K][M] (M contiguous) instead of [M][K]
-#define AA_GEMM_B_N 2         // B stored [K][N] (N contiguous) instead of [N][K]
-#define AA_GEMM_OUT_F32 4     // C is fp32 (default bf16)
-#define AA_GEMM_ACCUM 8       // C += result
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-__device__ __forceinline__ float gemm_act(float x, int act) {
-    switch (act) {
-        case AA_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
-        case AA_ACT_QUICK_GELU: return x / (1.f + expf(-1.702f * x));
-        case AA_ACT_RELU: return x > 0.f ? x : 0.f;
-        case AA_ACT_SILU: return x / (1.f + expf(-x));
-        default: return x;
-    }
-}
-
-struct GemmParams {
-    const bf16_t* A; const bf16_t* B; void* C;
-    const bf16_t* bias;      // [N] or null
-    const bf16_t* residual;  // [M, ldr] or null (added after bf16 rounding, like HF's `residual + x`)
-    int M, N, K;
-    long lda, ldb, ldc, ldr;
-    int act, flags;
-    int tiles_m, tiles_n;
-};
-
-constexpr int BK = 64;
+#include "gemm_params.h"
 
 // K-contiguous tile: [R rows][64 k] bf16, row = 128 B = 8 slots of 16 B; slot ^= (row>>1)&7.
 // row-contiguous tile: [64 k rows][R cols] bf16; 32-B unit ^= (krow&3) | ((krow>>3)&1)<<2.
 __device__ __forceinline__ int tr_swz(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
-template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE>
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE, bool ILV>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1)
 void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
@@ -245,24 +210,62 @@ void gemm_kernel(const GemmParams p) {
         //   A: F1 <- tile t (kk=1)      | MFMA(F0)          B: wait DMA(t+1), barrier
         //   C: F0 <- tile t+1 (kk=0), DMA tile t+2 -> freed buffer | MFMA(F1)
         bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];
-        stage(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        load_frags(0, 0, a0, b0);
-        if (nt > 1) stage(1);
-        for (int t = 0; t < nt; ++t) {
-            const int cur = t & 1;
-            load_frags(cur, 1, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_step(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
+        // ds_read instructions per fragment set and the MFMA:ds_read interleave ratio used when ILV is on
+        constexpr int NREADS = (A_T ? 2 * FM : FM) + (B_N ? 2 * FN : FN);
+        constexpr int NMFMA = FM * FN;
+        constexpr int RATIO = (NMFMA / NREADS) > 0 ? (NMFMA / NREADS) : 1;
+        if constexpr (!ILV) {
+            stage(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // tile t+1 landed for everyone; every wave is done reading buf[cur]
-            if (t + 1 < nt) load_frags(cur ^ 1, 0, a0, b0);
-            if (t + 2 < nt) stage(cur);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_step(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            load_frags(0, 0, a0, b0);
+            if (nt > 1) stage(1);
+            for (int t = 0; t < nt; ++t) {
+                const int cur = t & 1;
+                load_frags(cur, 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();  // tile t+1 landed for everyone; every wave is done reading buf[cur]
+                if (t + 1 < nt) load_frags(cur ^ 1, 0, a0, b0);
+                if (t + 2 < nt) stage(cur);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // Measured best (profiles/r01_gemm_schedule_ab.json): trickle the LDS reads of the next fragment set
+            // between the MFMAs of phase A (the matrix pipe starts at once after the barrier-free boundary), keep
+            // phase C as reads -> DMA issue -> MFMAs.  A fully branch-free body with the DMA issues interleaved
+            // as well measured 3-6 % slower on the NT shapes.
+            stage(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            load_frags(0, 0, a0, b0);
+            if (nt > 1) stage(1);
+            for (int t = 0; t < nt; ++t) {
+                const int cur = t & 1;
+                load_frags(cur, 1, a1, b1);
+                mfma_step(a0, b0);
+#pragma unroll
+                for (int i = 0; i < NREADS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, RATIO, 0);  // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();  // tile t+1 landed for everyone; every wave is done reading buf[cur]
+                load_frags(cur ^ 1, 0, a0, b0);  // (last iteration: stale buffer, result unused)
+                if (t + 2 < nt) stage(cur);
+                mfma_step(a1, b1);
+#pragma unroll
+                for (int i = 0; i < NREADS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, RATIO, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
@@ -313,14 +316,17 @@ void gemm_kernel(const GemmParams p) {
     }
 }
 
+static int g_mfma32 = 0;  // 1: route 256x256 tiles to the 32x32x16-MFMA kernel (gemm32.hip)
 static int g_pipe = 1;  // 1: software-pipelined K loop (default), 0: simple schedule
 
-template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE>
+static int g_ilv = 1;   // 1: interleave ds_reads with MFMAs via sched_group_barrier (256x256 tile only)
+
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE, bool ILV>
 static int launch_cfg2(GemmParams& p, hipStream_t st) {
     p.tiles_m = aa_cdiv(p.M, BM);
     p.tiles_n = aa_cdiv(p.N, BN);
     constexpr int lds = 2 * (BM + BN) * BK * 2;
-    auto kern = gemm_kernel<BM, BN, WM, WN, A_T, B_N, PIPE>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, A_T, B_N, PIPE, ILV>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -338,7 +344,10 @@ static int launch_cfg2(GemmParams& p, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, bool A_T, bool B_N>
 static int launch_cfg(GemmParams& p, hipStream_t st) {
-    return g_pipe ? launch_cfg2<BM, BN, WM, WN, A_T, B_N, true>(p, st) : launch_cfg2<BM, BN, WM, WN, A_T, B_N, false>(p, st);
+    if constexpr (BM == 256 && BN == 256) {
+        if (g_pipe && g_ilv) return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, true>(p, st);
+    }
+    return g_pipe ? launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, false>(p, st) : launch_cfg2<BM, BN, WM, WN, A_T, B_N, false, false>(p, st);
 }
 
 template <bool A_T, bool B_N>
@@ -396,6 +405,7 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
     p.act = act; p.flags = flags;
     const int tile = pick_tile(M, N);
     hipStream_t st = (hipStream_t)stream;
+    if (g_mfma32 && tile == 0 && !(a_t && !b_n)) return aa_gemm32_dispatch(p, a_t, b_n, st);
     if (!a_t && !b_n) return launch_layout<false, false>(p, tile, st);
     if (!a_t && b_n) return launch_layout<false, true>(p, tile, st);
     if (a_t && b_n) return launch_layout<true, true>(p, tile, st);
@@ -406,4 +416,6 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
 // test hook: force a tile config (-1 = heuristic)
 extern "C" int aa_gemm_set_tile(int tile) { g_force_tile = tile; return AA_OK; }
 // test/bench hook: 1 = software-pipelined K loop (default), 0 = simple one-barrier schedule
+extern "C" int aa_gemm_set_interleave(int on) { g_ilv = on ? 1 : 0; return AA_OK; }
+extern "C" int aa_gemm_set_mfma32(int on) { g_mfma32 = on ? 1 : 0; return AA_OK; }
 extern "C" int aa_gemm_set_pipeline(int on) { g_pipe = on ? 1 : 0; return AA_OK; }

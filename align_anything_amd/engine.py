@@ -84,6 +84,9 @@ class NativeEngine:
         self.optimizer = SimpleNamespace(param_groups=[{'lr': lr0, 'weight_decay': weight_decay},
                                                         {'lr': lr0, 'weight_decay': 0.0}])
         self._pending = None
+        self.async_optimizer = True
+        self._opt_stream = None
+        self._opt_done = None
         if trainable:
             module.init_training()
             dev = module.device
@@ -139,6 +142,7 @@ class NativeEngine:
         if self._pending is None:
             raise RuntimeError('backward() without a pending loss gradient: call trainer.loss(batch) first')
         st = self.module.store
+        self.wait_optimizer()
         st.zero_grad()
         done = set()
 
@@ -168,6 +172,10 @@ class NativeEngine:
                     self.reducer.reduce_async(st.gflat[g])
 
     def step(self):
+        """Clip + AdamW.  On a GPU the optimizer kernels (HBM-bound, ~28 B/param) are enqueued on a side HIP
+        stream so they overlap with whatever the main stream does next that does not touch the policy -- in the
+        DPO step that is the (MFMA-bound) reference forward of the NEXT batch.  `wait_optimizer()` is the
+        join; the trainer calls it before the next policy forward, and every reader of the weights goes through it."""
         st = self.module.store
         self.reducer.wait()
         self.global_steps += 1
@@ -176,23 +184,46 @@ class NativeEngine:
         # trainer logs as train/lr after the step is lr(k)
         lr_used = self._lr_at(self.global_steps - 1)
         lr = self._lr_at(self.global_steps)
-        self._sumsq.zero_()
-        groups = st.trainable_groups()
-        for g in groups:
-            ops.grad_sumsq_(st.gflat[g], self._sumsq, gscale)
-        ops.clip_coef(self._sumsq, self.max_grad_norm if self.max_grad_norm else 0.0, self._coef, self._gnorm)
-        for g in groups:
-            wd = 0.0 if g == 'vec' else self.weight_decay
-            ops.adamw_flat_(st.master[g], st.m[g], st.v[g], st.flat[g], st.gflat[g], lr_used, self.betas[0],
-                            self.betas[1], self.eps, wd, self.global_steps, gscale, self._coef)
+
+        def launch():
+            self._sumsq.zero_()
+            groups = st.trainable_groups()
+            for g in groups:
+                ops.grad_sumsq_(st.gflat[g], self._sumsq, gscale)
+            ops.clip_coef(self._sumsq, self.max_grad_norm if self.max_grad_norm else 0.0, self._coef, self._gnorm)
+            for g in groups:
+                wd = 0.0 if g == 'vec' else self.weight_decay
+                ops.adamw_flat_(st.master[g], st.m[g], st.v[g], st.flat[g], st.gflat[g], lr_used, self.betas[0],
+                                self.betas[1], self.eps, wd, self.global_steps, gscale, self._coef)
+
+        if self.async_optimizer and self.module.device.type == 'cuda':
+            if self._opt_stream is None:
+                self._opt_stream = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self._opt_stream):
+                self._opt_stream.wait_event(ev)
+                launch()
+                self._opt_done = torch.cuda.Event()
+                self._opt_done.record(self._opt_stream)
+        else:
+            launch()
         for pg in self.optimizer.param_groups:
             pg['lr'] = lr
 
+    def wait_optimizer(self):
+        """Make the current stream wait for the last (asynchronous) optimizer update."""
+        if self._opt_done is not None:
+            torch.cuda.current_stream().wait_event(self._opt_done)
+            self._opt_done = None
+
     def grad_norm(self) -> float:
+        self.wait_optimizer()
         return float(self._gnorm.item())
 
     # ---- checkpoints (HF layout, supervised_trainer.py:404-450)
     def save_16bit_model(self, save_dir, save_filename='pytorch_model.bin'):
+        self.wait_optimizer()
         os.makedirs(save_dir, exist_ok=True)
         sd = {k: v.cpu() for k, v in self.module.state_dict().items()}
         path = os.path.join(save_dir, save_filename)
@@ -206,6 +237,7 @@ class NativeEngine:
 
     def save_checkpoint(self, save_dir, tag=None):
         """Full training state (fp32 masters + Adam moments + step), the analogue of DeepSpeed's checkpoint."""
+        self.wait_optimizer()
         os.makedirs(save_dir, exist_ok=True)
         st = self.module.store
         rank = dist.get_rank() if dist.is_initialized() else 0

@@ -95,6 +95,14 @@ def gemm_set_tile(tile: int) -> None:
     call('aa_gemm_set_tile', int(tile))
 
 
+def gemm_set_interleave(on: bool) -> None:
+    call('aa_gemm_set_interleave', int(bool(on)))
+
+
+def gemm_set_mfma32(on: bool) -> None:
+    call('aa_gemm_set_mfma32', int(bool(on)))
+
+
 def gemm_set_pipeline(on: bool) -> None:
     call('aa_gemm_set_pipeline', int(bool(on)))
 

@@ -120,6 +120,8 @@ class DPOTrainer:
     def compute_log_probs(self, model, batch) -> torch.Tensor:
         """dpo.py:122-142: [2B, max(R)-1] response-window log-probs, right-padded with 0.0 (fp32 here)."""
         module = getattr(model, 'module', model)
+        if hasattr(model, 'wait_optimizer'):
+            model.wait_optimizer()
         flat = self._flat_log_probs(module, batch, save=False)
         return flat_to_padded(flat, self._window(batch))
 
@@ -127,8 +129,11 @@ class DPOTrainer:
         """dpo.py:144-203.  Also stages d loss / d logp for engine.backward (the loss kernel emits both)."""
         w = self._window(batch)
         B = w['N'] // 2
-        pol = self._flat_log_probs(self.model.module, batch, save=True)
+        # reference first: it does not read the policy, so it overlaps with the previous step's asynchronous
+        # optimizer update (NativeEngine.step); the policy forward then joins on it
         ref = self._flat_log_probs(self.reference_model.module, batch, save=False)
+        self.model.wait_optimizer()
+        pol = self._flat_log_probs(self.model.module, batch, save=True)
         out6, per, dlogp = ops.dpo_loss(pol, ref, w['seq_off'], B, self.scale_coeff, want_grad=True)
         self.model.set_pending(dlogp)
         return {

@@ -87,6 +87,8 @@ int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, lon
                  void* stream);
 int aa_gemm_set_tile(int tile);
 int aa_gemm_set_pipeline(int on);
+int aa_gemm_set_mfma32(int on);
+int aa_gemm_set_interleave(int on);
 /* hf:models/llama/modeling_llama.py:62-67 LlamaRMSNorm */
 int aa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int h, float eps,
                    void* stream);

@@ -15,11 +15,13 @@ def _ref(a, b, a_t, b_n):
     return A @ B
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 32])
 @pytest.mark.parametrize('layout', ['nt', 'nn', 'tn'])
 def test_gemm_layouts_and_tiles(tile, layout):
+    """tile 0-3: 16x16x32-MFMA tile configs; 32: the 32x32x16-MFMA 256x256 kernel (gemm32.hip)."""
     from align_anything_amd import ops
-    ops.gemm_set_tile(tile)
+    ops.gemm_set_mfma32(tile == 32)
+    ops.gemm_set_tile(0 if tile == 32 else tile)
     try:
         for (M, N, K) in SHAPES:
             a_t = layout == 'tn'
@@ -36,10 +38,14 @@ def test_gemm_layouts_and_tiles(tile, layout):
             assert_close(out, ref, rtol=1e-2, atol=1e-2 * float(ref.abs().mean()), what=f'{layout} tile{tile} {M}x{N}x{K}')
     finally:
         ops.gemm_set_tile(-1)
+        ops.gemm_set_mfma32(False)
 
 
-def test_gemm_epilogues_match_hf_rounding_points():
+@pytest.mark.parametrize('mfma32', [False, True])
+def test_gemm_epilogues_match_hf_rounding_points(mfma32):
     from align_anything_amd import ops
+    ops.gemm_set_mfma32(mfma32)
+    ops.gemm_set_tile(0 if mfma32 else -1)
     M, N, K = 384, 512, 256
     a, w = randn_bf16(M, K, seed=3), randn_bf16(N, K, scale=0.1, seed=4)
     bias, res = randn_bf16(N, seed=5), randn_bf16(M, N, seed=6)
@@ -70,6 +76,8 @@ def test_gemm_epilogues_match_hf_rounding_points():
     wide = randn_bf16(M, 2 * K, seed=7)
     out = ops.gemm(wide[:, K:], w)
     assert_close(out, wide[:, K:].float() @ w.float().t(), rtol=1e-2, atol=2e-2, what='strided A')
+    ops.gemm_set_mfma32(False)
+    ops.gemm_set_tile(-1)
 
 
 def test_gemm_rejects_bad_arguments_loudly():

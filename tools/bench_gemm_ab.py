@@ -28,10 +28,15 @@ for name, M, N, K in shapes:
         fl = 2.0 * m * n * k
         row = dict(name=name, layout=layout, m=m, n=n, k=k)
         for rep in range(2):
-            for pipe in (0, 1):
-                ops.gemm_set_pipeline(pipe)
+            for ilv in (0, 1):
+                ops.gemm_set_interleave(ilv)
                 ms = timeit(lambda: ops.gemm(a, b, out=out, a_t=a_t, b_n=b_n))
-                row[f'pipe{pipe}_tf_{rep}'] = round(fl / ms / 1e9, 1)
+                row[f'ilv{ilv}_tf_{rep}'] = round(fl / ms / 1e9, 1)
+                if rep == 0 and ilv == 1:
+                    ref = (A_ref := (a.t() if a_t else a).float()[:64]) @ (b if b_n else b.t()).float()
+                    err = (out[:64].float() - ref).abs().max().item() / ref.abs().max().item()
+                    row['ilv1_relerr'] = round(err, 5)
+        ops.gemm_set_interleave(0)
         A = a.t() if a_t else a; B = b if b_n else b.t()
         ms = timeit(lambda: torch.matmul(A, B, out=out))
         row['hipblaslt_tf'] = round(fl / ms / 1e9, 1)
