@@ -836,3 +836,99 @@ extern "C" int aa_clip_embed(const void* patch, const void* cls, const void* pos
     AA_CHECK_LAUNCH("aa_clip_embed");
     return AA_OK;
 }
+
+// ================================================================== score head  (Linear(h -> 1, bias=False))
+// align_anything/models/opt.py:59-60 / models/llava.py:60: scores = score_head(last_hidden_state).float()
+// out[r] = float(bf16(sum_c x[r,c] * w[c]))   (the bf16 Linear output, upcast)
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* __restrict__ x,
+                                                         const bf16_t* __restrict__ w,
+                                                         float* __restrict__ out, long rows, int h) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nv = h >> 3;
+    for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
+        const bf16_t* xr = x + row * h;
+        float acc = 0.f;
+        for (int i = lane; i < nv; i += 64) {
+            u16x8 a = *reinterpret_cast<const u16x8*>(xr + i * 8);
+            u16x8 b = *reinterpret_cast<const u16x8*>(w + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += bf2f(a[j]) * bf2f(b[j]);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[row] = rbf(acc);
+    }
+}
+// dx[r,c] = dy[r] * w[c] ; dw_part[block, c] = sum over the block's rows of dy[r] * x[r,c]
+template <int MAXV>
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dy,
+                                                         const bf16_t* __restrict__ x,
+                                                         const bf16_t* __restrict__ w,
+                                                         bf16_t* __restrict__ dx,
+                                                         float* __restrict__ dw_part, long rows, int h) {
+    const int nv = h >> 3;
+    float dwacc[MAXV][8];
+#pragma unroll
+    for (int a = 0; a < MAXV; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwacc[a][j] = 0.f;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float g = dy[row];
+#pragma unroll
+        for (int a = 0; a < MAXV; ++a) {
+            const int i = threadIdx.x + a * 256;
+            if (i < nv) {
+                u16x8 xv = *reinterpret_cast<const u16x8*>(x + row * h + i * 8);
+                u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
+                u16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    dwacc[a][j] += g * bf2f(xv[j]);
+                    o[j] = f2bf(g * bf2f(wv[j]));
+                }
+                *reinterpret_cast<u16x8*>(dx + row * h + i * 8) = o;
+            }
+        }
+    }
+    if (dw_part) {
+        float* pr = dw_part + (long)blockIdx.x * h;
+#pragma unroll
+        for (int a = 0; a < MAXV; ++a) {
+            const int i = threadIdx.x + a * 256;
+            if (i < nv) {
+                *reinterpret_cast<f32x4*>(pr + i * 8) = f32x4{dwacc[a][0], dwacc[a][1], dwacc[a][2], dwacc[a][3]};
+                *reinterpret_cast<f32x4*>(pr + i * 8 + 4) = f32x4{dwacc[a][4], dwacc[a][5], dwacc[a][6], dwacc[a][7]};
+            }
+        }
+    }
+}
+
+extern "C" int aa_rowdot_fwd(const void* x, const void* w, float* out, long rows, int h, void* stream) {
+    AA_REQUIRE(h > 0 && (h & 7) == 0, "aa_rowdot_fwd: hidden %d must be a multiple of 8", h);
+    if (rows == 0) return AA_OK;
+    const long nb = (rows + 3) / 4;
+    hipLaunchKernelGGL(rowdot_fwd_kernel, dim3((int)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)w, out, rows, h);
+    AA_CHECK_LAUNCH("aa_rowdot_fwd");
+    return AA_OK;
+}
+extern "C" int aa_rowdot_bwd(const float* dy, const void* x, const void* w, void* dx, float* dw, float* ws,
+                             int ws_rows, long rows, int h, void* stream) {
+    AA_REQUIRE(h > 0 && (h & 7) == 0 && h <= 8 * 256 * 8, "aa_rowdot_bwd: hidden %d must be a multiple of 8 and <= 16384", h);
+    AA_REQUIRE(dw == nullptr || (ws != nullptr && ws_rows > 0), "aa_rowdot_bwd: dw needs a [ws_rows, h] fp32 workspace");
+    if (rows == 0) return AA_OK;
+    int grid = (int)(rows < 1024 ? rows : 1024);
+    if (dw && grid > ws_rows) grid = ws_rows;
+    float* part = dw ? ws : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_RDB(MV)                                                                                \
+    hipLaunchKernelGGL(rowdot_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, dy, (const bf16_t*)x,      \
+                       (const bf16_t*)w, (bf16_t*)dx, part, rows, h)
+    if (h <= 2048) LAUNCH_RDB(1);
+    else if (h <= 4096) LAUNCH_RDB(2);
+    else if (h <= 8192) LAUNCH_RDB(4);
+    else LAUNCH_RDB(8);
+#undef LAUNCH_RDB
+    if (dw) launch_reduce_rows(part, grid, h, dw, st);
+    AA_CHECK_LAUNCH("aa_rowdot_bwd");
+    return AA_OK;
+}

@@ -296,6 +296,52 @@ class LMHead:
         return ops.embed_fwd(zeros_ids, zero_row, slot=inv_map, feat=d_sel)
 
 
+class ScoreHead:
+    """final norm -> score_head Linear(h -> 1, no bias) on the selected rows: the reward / critic models of the
+    reference (align_anything/models/opt.py:45-97, models/llava.py:47-76; `scores` fp32)."""
+
+    def __init__(self, store, norm_kind, norm_w, norm_b, score_w, eps, trainable):
+        self.store, self.kind, self.norm_w, self.norm_b, self.score_w = store, norm_kind, norm_w, norm_b, score_w
+        self.eps, self.trainable = eps, trainable
+        self.saved = None
+
+    def _norm(self, x, stats):
+        P = self.store.p
+        if self.kind == 'rms':
+            n, rstd = ops.rmsnorm_fwd(x, P[self.norm_w], self.eps)
+            return n, None, rstd
+        n, mean, rstd = ops.layernorm_fwd(x, P[self.norm_w], P[self.norm_b], self.eps, want_stats=stats)
+        return n, mean, rstd
+
+    def forward(self, x_last, row_idx, labels=None, save=False, round_bf16=False):
+        sel = ops.embed_fwd(row_idx, x_last)
+        n, mean, rstd = self._norm(sel, True)
+        scores = ops.rowdot_fwd(n, self.store.p[self.score_w].view(-1))
+        self.saved = (sel, mean, rstd, n) if save else None
+        return scores
+
+    def hidden_all(self, x_last):
+        return self._norm(x_last, False)[0]
+
+    def scores_all(self, x_last):
+        return ops.rowdot_fwd(self.hidden_all(x_last), self.store.p[self.score_w].view(-1))
+
+    def backward(self, dscores, inv_map, zero_row):
+        sel, mean, rstd, n = self.saved
+        P, G = self.store.p, self.store.g
+        tr = self.trainable
+        gw = G.get(self.score_w) if tr else None
+        d_n = ops.rowdot_bwd(dscores, n, P[self.score_w].view(-1), gw.view(-1) if gw is not None else None)
+        if self.kind == 'rms':
+            d_sel = ops.rmsnorm_bwd(d_n, sel, P[self.norm_w], rstd, G.get(self.norm_w) if tr else None)
+        else:
+            d_sel = ops.layernorm_bwd(d_n, sel, P[self.norm_w], mean, rstd, G.get(self.norm_w) if tr else None,
+                                      G.get(self.norm_b) if tr else None)
+        self.saved = None
+        zeros_ids = torch.zeros(inv_map.shape[0], dtype=torch.int64, device=inv_map.device)
+        return ops.embed_fwd(zeros_ids, zero_row, slot=inv_map, feat=d_sel)
+
+
 # ====================================================================== model base
 class NativeCausalLM:
     """Common driver: batch contract of the reference collators in, per-token response log-probs out."""
@@ -369,6 +415,20 @@ class NativeCausalLM:
             self._ctx['window'] = window
         return logp
 
+    def response_scores(self, input_ids, attention_mask, window, pixel_values=None, save=False, image_features=None):
+        """Score-head models: fp32 scores on the window rows (critic values / reward scores)."""
+        x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features)
+        sc = self.head.forward(x, window['row_idx'], None, save)
+        if save:
+            self._ctx['window'] = window
+        return sc
+
+    def scores(self, input_ids, attention_mask=None, pixel_values=None):
+        """ScoreModelOutput.scores [N, T] (fp32) for every position."""
+        N, T = input_ids.shape
+        x = self.forward_stream(input_ids, attention_mask, pixel_values, save=False)
+        return self.head.scores_all(x)[:N * T].view(N, T)
+
     def backward_from_dlogp(self, dlogp, on_layer_done=None):
         dres = self.head.backward(dlogp, self._ctx['window']['inv_map'], self._zero_row)
         self.backward_stream(dres, on_layer_done)
@@ -393,8 +453,9 @@ class NativeLlava(NativeCausalLM):
     kind = 'llava'
 
     def __init__(self, cfg, device, trainable=True, freeze_mm_proj=False, freeze_language_model=False,
-                 freeze_vision_tower=True):
+                 freeze_vision_tower=True, head='lm'):
         super().__init__(cfg, device, trainable)
+        self.head_kind = head
         if not freeze_vision_tower and trainable:
             raise NotImplementedError('training the CLIP vision tower is not built (the reference default freezes '
                                       'it, configs/train/text_image_to_text/dpo.yaml:60)')
@@ -411,8 +472,12 @@ class NativeLlava(NativeCausalLM):
                             st.add('model.multi_modal_projector.linear_2.bias', (t['hidden_size'],), self.train_proj))
         self.embed = st.add('model.language_model.embed_tokens.weight', (t['vocab_size'], t['hidden_size']), self.train_lm, f32_grad=True)
         self.stack = LlamaStack(t, st, 'model.language_model.', self.train_lm)
-        lm = st.add('lm_head.weight', (t['vocab_size'], t['hidden_size']), self.train_lm)
-        self.head = LMHead(st, 'rms', self.stack.norm, None, lm, t['rms_eps'], self.train_lm)
+        if head == 'lm':
+            lm = st.add('lm_head.weight', (t['vocab_size'], t['hidden_size']), self.train_lm)
+            self.head = LMHead(st, 'rms', self.stack.norm, None, lm, t['rms_eps'], self.train_lm)
+        else:  # reward / critic: AccustomedLlavaRewardModel (models/llava.py:35-76)
+            sw = st.add('score_head.weight', (1, t['hidden_size']), trainable, f32_grad=True)
+            self.head = ScoreHead(st, 'rms', self.stack.norm, None, sw, t['rms_eps'], trainable)
         self.finalize()
 
     def _padcols(self):
@@ -553,8 +618,9 @@ class NativeOPT(NativeCausalLM):
 
     kind = 'opt'
 
-    def __init__(self, cfg, device, trainable=True):
+    def __init__(self, cfg, device, trainable=True, head='lm'):
         super().__init__(cfg, device, trainable)
+        self.head_kind = head
         h = cfg['hidden_size']
         self.hidden_size = h
         if (h // cfg['num_heads']) not in (64, 128):
@@ -565,7 +631,11 @@ class NativeOPT(NativeCausalLM):
         self.fln_w = st.add('model.decoder.final_layer_norm.weight', (h,), trainable)
         self.fln_b = st.add('model.decoder.final_layer_norm.bias', (h,), trainable)
         self.stack = OPTStack(cfg, st, 'model.decoder.', trainable)
-        self.head = LMHead(st, 'ln', self.fln_w, self.fln_b, self.embed, 1e-5, trainable)
+        if head == 'lm':
+            self.head = LMHead(st, 'ln', self.fln_w, self.fln_b, self.embed, 1e-5, trainable)
+        else:  # AccustomedOPTRewardModel (models/opt.py:34-97)
+            sw = st.add('score_head.weight', (1, h), trainable, f32_grad=True)
+            self.head = ScoreHead(st, 'ln', self.fln_w, self.fln_b, sw, 1e-5, trainable)
         self.finalize()
 
     def load_state_dict(self, sd, strict=True):
@@ -575,7 +645,8 @@ class NativeOPT(NativeCausalLM):
 
     def state_dict(self):
         sd = super().state_dict()
-        sd['lm_head.weight'] = sd['model.decoder.embed_tokens.weight']
+        if self.head_kind == 'lm':
+            sd['lm_head.weight'] = sd['model.decoder.embed_tokens.weight']
         return sd
 
     def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None):
@@ -606,9 +677,10 @@ class NativeOPT(NativeCausalLM):
                           dE=G[self.embed], dP=G[self.pos_emb])
 
 
-def build_model(cfg: dict, device, trainable=True, **freeze):
+def build_model(cfg: dict, device, trainable=True, head='lm', **freeze):
+    """head='lm': causal LM (actor / reference); head='score': reward / critic model with a score head."""
     if cfg['kind'] == 'llava':
-        return NativeLlava(cfg, device, trainable, **freeze)
+        return NativeLlava(cfg, device, trainable, head=head, **freeze)
     if cfg['kind'] == 'opt':
-        return NativeOPT(cfg, device, trainable)
+        return NativeOPT(cfg, device, trainable, head=head)
     raise ValueError(f"no native model for kind {cfg['kind']!r}")

@@ -160,6 +160,22 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dx=None, add_to_dx=False):
     return dx
 
 
+def rowdot_fwd(x, w):
+    rows, h = x.shape
+    out = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call('aa_rowdot_fwd', x.data_ptr(), w.data_ptr(), out.data_ptr(), rows, h, stream())
+    return out
+
+
+def rowdot_bwd(dy, x, w, dw):
+    rows, h = x.shape
+    dx = torch.empty_like(x)
+    ws = _norm_ws(x.device, h, 1) if dw is not None else None
+    call('aa_rowdot_bwd', dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dw), _p(ws), NORM_WS_ROWS,
+         rows, h, stream())
+    return dx
+
+
 # ------------------------------------------------------------------ pointwise
 def rope_(buf, col0, nheads, hd, pos, cos_t, sin_t, inverse=False):
     rows = buf.shape[0]

@@ -88,3 +88,34 @@ def cfg_get(cfgs, path: str, default=None):
             return default
         cur = cur.get(part) if isinstance(cur, dict) else getattr(cur, part, None)
     return default if cur is None else cur
+
+
+def build_span_window(input_ids: torch.Tensor, start: int):
+    """Rows for `gather_log_probabilities(logits[:, :-1], input_ids[:, 1:])[:, start:]` and
+    `scores[:, :-1][:, start:]` (align_anything/trainers/text_to_text/ppo.py:339-356): row (n, j) for
+    j in [start, T-2] reads hidden position j and is labelled with token j+1.  Pure positional -> host built."""
+    N, T = input_ids.shape
+    dev = input_ids.device
+    W = T - 1 - start
+    if W < 1:
+        raise ValueError(f'prompt_idx {start} leaves no response positions in a length-{T} sequence')
+    rows = N * W
+    rows_pad = pad64(rows)
+    Mp = (N * T + 63) // 64 * 64
+    j = np.arange(start, T - 1)
+    row_idx = np.zeros(rows_pad, dtype=np.int64)
+    row_idx[:rows] = (np.arange(N)[:, None] * T + j[None, :]).reshape(-1)
+    inv = np.full(Mp, -1, dtype=np.int32)
+    inv[row_idx[:rows]] = np.arange(rows, dtype=np.int32)
+    labels = torch.zeros(rows_pad, dtype=torch.int64, device=dev)
+    labels[:rows] = input_ids[:, start + 1:].reshape(-1)
+    return {'N': N, 'T': T, 'W': W, 'rows': rows, 'rows_pad': rows_pad,
+            'row_idx': torch.from_numpy(row_idx).to(dev, non_blocking=True),
+            'inv_map': torch.from_numpy(inv).to(dev, non_blocking=True), 'labels': labels}
+
+
+def pad_rows(flat_2d: torch.Tensor, rows_pad: int) -> torch.Tensor:
+    """[B, W] gradient -> flat fp32 [rows_pad] with zero tail (the pad rows of a window carry no gradient)."""
+    out = torch.zeros(rows_pad, dtype=torch.float32, device=flat_2d.device)
+    out[:flat_2d.numel()] = flat_2d.reshape(-1)
+    return out

@@ -7,8 +7,8 @@ which `NativeEngine.backward` consumes the same way the DPO step does (set_pendi
 reference's GAE (4*L kernel launches) is one launch here; the per-row `.nonzero()` host syncs of the KL reward are
 a device-side last-index scan.
 
-Round-1 scope: the math + actor log-prob path.  Rollout (`generate`), reward/critic score-head models and the
-four-engine rl_step are the §8(f) "next" rows.
+`PPOTrainer` below is the native four-engine `rl_step` (actor train, reference eval, reward eval, critic train) and
+`reward_model_step`; only the autoregressive rollout (`generate`) is still the §8(f) "next" row (HIP KV-cache decode).
 """
 from __future__ import annotations
 
@@ -54,3 +54,112 @@ def gather_log_probabilities(logits: torch.Tensor, labels: torch.Tensor) -> torc
     B, L, V = logits.shape
     lp, _ = ops.logprob_gather_fwd(logits.reshape(B * L, V), labels.reshape(-1).to(torch.int64).contiguous())
     return lp.view(B, L)
+
+
+from ..engine import NativeEngine
+from ..modeling import build_model
+from .common import build_span_window, cfg_get, get_all_reduce_max, get_all_reduce_mean, pad_rows
+
+
+class PPOTrainer(PPOMath):
+    """Native counterpart of align_anything/trainers/text_to_text/ppo.py::PPOTrainer for the update phase:
+    `reward_model_step` (:224-242) and `rl_step` (:309-398) on four DeepSpeedEngine-shaped native engines
+    (base/rl_trainer.py:217-272).  The rollout batch (sequences from `generate`) is an input."""
+
+    def __init__(self, cfgs, ds_cfgs=None, *, model_cfg, reward_model_cfg=None, actor_state=None, reward_state=None,
+                 critic_state=None, device='cuda:0'):
+        t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
+        PPOMath.__init__(self, kl_coeff=float(t('kl_coeff', 0.02)), clip_range_score=float(t('clip_range_score', 50.0)),
+                         gamma=float(t('gamma', 1.0)), gae_lambda=float(t('gae_lambda', 0.95)),
+                         clip_range_ratio=float(t('clip_range_ratio', 0.2)), clip_range_value=float(t('clip_range_value', 5.0)))
+        self.cfgs, self.device = cfgs, torch.device(device)
+        rcfg = reward_model_cfg or model_cfg
+        actor = build_model(model_cfg, device, trainable=True)
+        ref = build_model(model_cfg, device, trainable=False)
+        reward = build_model(rcfg, device, trainable=False, head='score')
+        critic = build_model(rcfg, device, trainable=True, head='score')
+        if actor_state is not None:
+            actor.load_state_dict(actor_state)
+            ref.load_state_dict(actor_state)
+        if reward_state is not None:
+            reward.load_state_dict(reward_state)
+            critic.load_state_dict(critic_state if critic_state is not None else reward_state)
+        clip = float(cfg_get(ds_cfgs, 'gradient_clipping', 1.0))
+        betas = [float(b) for b in t('actor_betas', t('adam_betas', [0.9, 0.95]))]
+        total = int(t('total_training_steps', 1))
+        self.actor_model = NativeEngine(actor, lr=float(t('actor_lr', 1e-5)), betas=betas, weight_decay=float(t('actor_weight_decay', 0.01)),
+                                        max_grad_norm=clip, total_steps=total, warmup_steps=int(float(t('actor_lr_warmup_ratio', 0.03)) * total),
+                                        lr_scheduler_type=t('actor_lr_scheduler_type', 'cosine'))
+        self.reward_critic_model = NativeEngine(critic, lr=float(t('critic_lr', 5e-6)), betas=betas, weight_decay=float(t('critic_weight_decay', 0.0)),
+                                                max_grad_norm=clip, total_steps=total, warmup_steps=int(float(t('critic_lr_warmup_ratio', 0.03)) * total),
+                                                lr_scheduler_type=t('critic_lr_scheduler_type', 'constant'))
+        self.actor_reference_model = NativeEngine(ref, trainable=False)
+        self.reward_model = NativeEngine(reward, trainable=False)
+
+    # ------------------------------------------------------------------ scoring (ppo.py:224-242)
+    def reward_model_step(self, input_ids, attention_mask):
+        """reward = end score of the reward model (last attended token, models/opt.py:67-89);
+        reward_values = critic scores[:, :-1]."""
+        N, T = input_ids.shape
+        scores = self.reward_model.module.scores(input_ids, attention_mask)
+        end = (attention_mask.to(torch.int64) * torch.arange(T, device=input_ids.device)[None]).argmax(dim=1)
+        reward = scores[torch.arange(N, device=scores.device), end]
+        self.reward_critic_model.wait_optimizer()
+        values = self.reward_critic_model.module.scores(input_ids, attention_mask)[:, :-1]
+        return {'reward': reward, 'reward_values': values}
+
+    def sequence_log_probs(self, engine, input_ids, attention_mask, start=0, save=False):
+        """gather_log_probabilities(logits[:, :-1], input_ids[:, 1:])[:, start:] -> fp32 [B, T-1-start]."""
+        w = build_span_window(input_ids, start)
+        if hasattr(engine, 'wait_optimizer'):
+            engine.wait_optimizer()
+        lp = engine.module.response_logprobs(input_ids, attention_mask, w, save=save)
+        return lp[:w['rows']].view(w['N'], w['W']), w
+
+    # ------------------------------------------------------------------ update (ppo.py:309-398)
+    def rl_step(self, inference_batch, training_batch):
+        old_log_probs = training_batch['log_probs'].float()
+        ref_log_probs = training_batch['ref_log_probs'].float()
+        reward = training_batch['reward'].float()
+        old_reward_values = training_batch['reward_values'].float()
+        start = int(training_batch['prompt_idx'])
+        input_ids, attention_mask = inference_batch['input_ids'], inference_batch['attention_mask']
+        sequence_mask = attention_mask[:, 1:].bool()
+        mask_s = sequence_mask[:, start:].contiguous()
+
+        old_rewards = self.add_kl_divergence_regularization(reward, old_log_probs, ref_log_probs, sequence_mask)
+        reward_advantages, reward_returns = self.get_advantages_and_returns(old_reward_values, old_rewards, sequence_mask, start)
+
+        log_probs, w = self.sequence_log_probs(self.actor_model, input_ids, attention_mask, start, save=True)
+        actor_loss, dlogp = self.actor_loss_fn(log_probs.contiguous(), old_log_probs[:, start:].contiguous(),
+                                               reward_advantages, mask_s)
+        self.actor_model.set_pending(pad_rows(dlogp, w['rows_pad']))
+        self.actor_model.backward(actor_loss)
+        self.actor_model.step()
+
+        self.reward_critic_model.wait_optimizer()
+        values = self.reward_critic_model.module.response_scores(input_ids, attention_mask, w, save=True)
+        reward_values = values[:w['rows']].view(w['N'], w['W'])
+        critic_loss, dvalues = self.critic_loss_fn(reward_values.contiguous(), old_reward_values[:, start:].contiguous(),
+                                                   reward_returns, mask_s)
+        self.reward_critic_model.set_pending(pad_rows(dvalues, w['rows_pad']))
+        self.reward_critic_model.backward(critic_loss)
+        self.reward_critic_model.step()
+
+        m = mask_s.float()
+        cnt = m.sum(-1)
+        mm = lambda x: ((x * m).sum(-1) / cnt).mean()
+        stats = torch.stack([actor_loss, critic_loss, reward.mean(), (old_rewards[:, start:] * m).sum(-1).mean(),
+                             mm(reward_advantages), mm(reward_returns), mm(reward_values),
+                             ((old_log_probs - ref_log_probs)[:, start:] * m).sum(-1).mean(), cnt.mean()])
+        stats = get_all_reduce_mean(stats)
+        mx = get_all_reduce_max(cnt.max().reshape(1))
+        s = stats.tolist()
+        return {
+            'train/actor_loss': s[0], 'train/reward_critic_loss': s[1], 'train/reward': s[2],
+            'train/reward_with_kl_penalty': s[3], 'train/reward_advantage': s[4], 'train/reward_return': s[5],
+            'train/reward_value': s[6], 'train/kl_divergence': s[7],
+            'train/actor_lr': self.actor_model.optimizer.param_groups[0]['lr'],
+            'train/reward_critic_lr': self.reward_critic_model.optimizer.param_groups[0]['lr'],
+            'train/mean_generated_length': s[8], 'train/max_generated_length': float(mx.item()),
+        }

@@ -119,6 +119,11 @@ int aa_embed_bwd(const int64_t* ids, const int* slot, const int* pos, const void
                  void* dfeat, float* dP, long n, int h, int vocab, void* stream);
 int aa_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C, void* stream);
 int aa_colsum_bf16(const void* in, long ld, long R, int C, float* out, void* stream);
+/* score head Linear(h->1, no bias) of the reward / critic models: align_anything/models/opt.py:59-60,
+ * models/llava.py:60.  out f32[rows] = float(bf16(x . w)); backward gives dx and accumulates dw (fp32). */
+int aa_rowdot_fwd(const void* x, const void* w, float* out, long rows, int h, void* stream);
+int aa_rowdot_bwd(const float* dy, const void* x, const void* w, void* dx, float* dw, float* ws, int ws_rows,
+                  long rows, int h, void* stream);
 /* hf:models/clip/modeling_clip.py:138-218 CLIPVisionEmbeddings (patch conv as im2col + GEMM) */
 int aa_patch_im2col(const void* pixels, int pix_dtype, void* out, int n_img, int channels,
                     int image_size, int patch, int Kp, void* stream);

@@ -160,7 +160,7 @@ def llama_logits(sd, cfg, input_ids, attention_mask, prefix='model.'):
 
 
 # ------------------------------------------------------------------ OPT
-def opt_logits(sd, cfg, input_ids, attention_mask, dropout_p=0.0):
+def opt_logits(sd, cfg, input_ids, attention_mask, dropout_p=0.0, return_hidden=False):
     """hf:models/opt/modeling_opt.py:45-70 (learned positions = cumsum(mask)*mask - 1 + 2), :191-251
     (pre-LN decoder layer, biased projections, ReLU MLP), :283-310, lm_head tied to embed_tokens.
     Dropout must be 0 for parity (SURVEY.md §7 hard parts)."""
@@ -187,6 +187,8 @@ def opt_logits(sd, cfg, input_ids, attention_mask, dropout_p=0.0):
         y = F.relu(linear(y, sd, p + 'fc1'))
         x = r + linear(y, sd, p + 'fc2')
     x = F.layer_norm(x, (h,), sd['model.decoder.final_layer_norm.weight'], sd['model.decoder.final_layer_norm.bias'], 1e-5)
+    if return_hidden:
+        return x
     return F.linear(x, sd.get('lm_head.weight', emb))
 
 

@@ -1,0 +1,103 @@
+"""GPU: native PPO update phase (trainers/ppo.py::PPOTrainer.rl_step, reward_model_step) against the CPU oracle:
+reference math (oracle/rl_math.py, pinned to the reference's golden vectors) on the oracle OPT model with
+autograd.  Mirrors align_anything/trainers/text_to_text/ppo.py:224-242, 309-398."""
+import pytest
+import torch
+
+from oracle import models as om
+from oracle import rl_math as orl
+from tests.gpu_util import assert_close, dev, dump
+from tests.util import load_golden, rel_err, state_dict_from_golden, tiny_opt_cfg
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _setup():
+    from align_anything_amd.trainers.ppo import PPOTrainer
+    z = load_golden('opt_tiny_dpo.npz')
+    cfg = tiny_opt_cfg()
+    g = torch.Generator().manual_seed(21)
+    actor_sd = state_dict_from_golden(z, 'w.', torch.bfloat16)
+    old_sd = state_dict_from_golden(z, 'r.', torch.float32)          # "old policy" that produced the rollout
+    score_w = (torch.randn(1, cfg['hidden_size'], generator=g) * 0.2).to(torch.bfloat16)
+    rm_sd = {k: v for k, v in actor_sd.items() if k != 'lm_head.weight'}
+    rm_sd['score_head.weight'] = score_w
+    cfgs = {'train_cfgs': {'actor_lr': 1e-3, 'critic_lr': 1e-3, 'actor_weight_decay': 0.0, 'critic_weight_decay': 0.0,
+                           'actor_lr_warmup_ratio': 0.0, 'critic_lr_warmup_ratio': 0.0, 'actor_lr_scheduler_type': 'constant',
+                           'critic_lr_scheduler_type': 'constant', 'kl_coeff': 0.02, 'clip_range_ratio': 0.2,
+                           'clip_range_value': 5.0, 'clip_range_score': 50.0, 'gamma': 1.0, 'gae_lambda': 0.95}}
+    tr = PPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, reward_state=rm_sd, device='cuda:0')
+    # rollout-shaped batch: left-padded prompt (start = 12 prompt positions) + response, right padding after "EOS"
+    N, Tn, start = 3, 40, 12
+    ids = torch.randint(3, 320, (N, Tn), generator=g)
+    mask = torch.ones(N, Tn, dtype=torch.long)
+    for n, (lp, rp) in enumerate(((0, 0), (5, 7), (2, 15))):
+        mask[n, :lp] = 0; ids[n, :lp] = 1
+        if rp:
+            mask[n, Tn - rp:] = 0; ids[n, Tn - rp:] = 1
+    return tr, z, cfg, actor_sd, old_sd, rm_sd, ids, mask, start
+
+
+def test_reward_model_step_and_rl_step_match_oracle():
+    tr, z, cfg, actor_sd, old_sd, rm_sd, ids, mask, start = _setup()
+    # ---------------- oracle side (fp32 CPU)
+    f32 = lambda sd: {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    a_sd = f32({k: v for k, v in actor_sd.items() if k != 'lm_head.weight'})
+    c_sd = f32(rm_sd)
+    with torch.no_grad():
+        old_lp = orl.gather_log_probabilities(om.opt_logits(old_sd, cfg, ids, mask)[:, :-1], ids[:, 1:])
+        ref_lp = orl.gather_log_probabilities(om.opt_logits({k: v.detach() for k, v in a_sd.items()}, cfg, ids, mask)[:, :-1], ids[:, 1:])
+        hid = om.opt_logits({k: v.detach() for k, v in c_sd.items()}, cfg, ids, mask, return_hidden=True)
+        scores = (hid @ c_sd['score_head.weight'].detach().t()).squeeze(-1)
+        end = torch.stack([m.nonzero()[-1].squeeze() for m in mask])
+        o_reward = scores[torch.arange(ids.shape[0]), end]
+        o_values = scores[:, :-1]
+    # ---------------- native scoring
+    d = lambda t: t.to(dev())
+    rs = tr.reward_model_step(d(ids), d(mask))
+    assert_close(rs['reward'].cpu(), o_reward, rtol=3e-2, atol=3e-2, what='reward (end score at last attended token)')
+    sm = mask[:, 1:].bool()
+    # position j predicts token j+1: compare where BOTH are attended.  (j = last left-pad position is inside
+    # sequence_mask but its query row is fully masked -- HF and the native kernel both return don't-care values
+    # there; PPO never uses it because prompt_idx lies beyond the left padding.)
+    both = sm & mask[:, :-1].bool()
+    assert_close(rs['reward_values'].cpu()[both], o_values[both], rtol=3e-2, atol=3e-2, what='critic values')
+    nat_old, _ = tr.sequence_log_probs(tr.actor_reference_model, d(ids), d(mask), 0)
+    assert_close(nat_old.cpu()[both], ref_lp[both], rtol=2e-2, atol=5e-2, what='reference log-probs')
+    # ---------------- one rl_step on identical rollout statistics (oracle values fed to both sides)
+    reward = o_reward * 3.0
+    old_values = o_values + 0.3 * torch.randn(o_values.shape, generator=torch.Generator().manual_seed(3))
+    tb = {'log_probs': d(old_lp), 'ref_log_probs': d(ref_lp), 'reward': d(reward), 'reward_values': d(old_values), 'prompt_idx': start}
+    info = tr.rl_step({'input_ids': d(ids), 'attention_mask': d(mask)}, tb)
+    old_rewards = orl.add_kl_divergence_regularization(reward, old_lp, ref_lp, sm, 0.02, 50.0)
+    adv, ret = orl.get_advantages_and_returns(old_values, old_rewards, sm, start, 1.0, 0.95)
+    lp = orl.gather_log_probabilities(om.opt_logits(a_sd, cfg, ids, mask)[:, :-1], ids[:, 1:])
+    a_loss = orl.actor_loss_fn(lp[:, start:], old_lp[:, start:], adv, sm[:, start:], 0.2)
+    vals = (om.opt_logits(c_sd, cfg, ids, mask, return_hidden=True) @ c_sd['score_head.weight'].t()).squeeze(-1)[:, :-1]
+    c_loss = orl.critic_loss_fn(vals[:, start:], old_values[:, start:], ret, sm[:, start:], 5.0)
+    rep = [f"actor_loss native {info['train/actor_loss']:.5f} oracle {a_loss.item():.5f}",
+           f"critic_loss native {info['train/reward_critic_loss']:.5f} oracle {c_loss.item():.5f}"]
+    assert abs(info['train/actor_loss'] - a_loss.item()) < 3e-2 * max(1.0, abs(a_loss.item()))
+    assert abs(info['train/reward_critic_loss'] - c_loss.item()) < 3e-2 * max(1.0, abs(c_loss.item()))
+    m = sm[:, start:].float()
+    assert abs(info['train/kl_divergence'] - float(((old_lp - ref_lp)[:, start:] * m).sum(-1).mean())) < 1e-3
+    assert abs(info['train/reward_with_kl_penalty'] - float((old_rewards[:, start:] * m).sum(-1).mean())) < 1e-3
+    assert info['train/max_generated_length'] == float(m.sum(-1).max())
+    # gradients the step consumed (still in the flat buffers)
+    a_loss.backward(); c_loss.backward()
+    for eng, sd, names in ((tr.actor_model, a_sd, ['model.decoder.layers.1.fc1.weight', 'model.decoder.layers.0.self_attn.q_proj.weight',
+                                                   'model.decoder.final_layer_norm.weight']),
+                           (tr.reward_critic_model, c_sd, ['score_head.weight', 'model.decoder.layers.1.fc2.weight',
+                                                           'model.decoder.layers.0.self_attn.v_proj.bias'])):
+        eng.wait_optimizer()
+        torch.cuda.synchronize()
+        for n in names:
+            got = eng.module.store.grad_view(n).float().cpu().reshape(sd[n].grad.shape)
+            e = rel_err(got, sd[n].grad)
+            rep.append(f'{n}: rel_err {e:.4f}')
+            assert e < 8e-2, (n, e)
+    dump('parity_ppo_rl_step.txt', '\n'.join(rep) + '\n')
+    # a second step must run and keep the losses finite (weights were updated by both engines)
+    info2 = tr.rl_step({'input_ids': d(ids), 'attention_mask': d(mask)}, tb)
+    assert all(map(lambda v: v == v and abs(v) < 1e6, info2.values()))
