@@ -68,7 +68,7 @@ def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=Fals
     call('aa_gemm_bf16', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0),
          out.stride(0), _p(bias), _p(residual), ldr, int(act), flags, stream())
     if prof is not None:
-        prof.append((e0, event_record(), 2.0 * M * N * K))
+        prof.append((e0, event_record(), 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N))
     return out
 
 

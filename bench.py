@@ -119,7 +119,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--pairs-per-gpu', type=int, default=int(os.environ.get('AA_BENCH_PAIRS', 2)))
+    ap.add_argument('--pairs-per-gpu', type=int, default=int(os.environ.get('AA_BENCH_PAIRS', 4)))
     ap.add_argument('--seq-len', type=int, default=2048)
     ap.add_argument('--response-len', type=int, default=512)
     ap.add_argument('--layers', type=int, default=32, help='LLM depth (32 = LLaVA-1.5-7B; anything else is NOT the headline config)')
@@ -207,14 +207,25 @@ def main():
         }
         if gemm_events:
             tot_ms, tot_fl = 0.0, 0.0
-            for ev0, ev1, fl in gemm_events:
+            for ev0, ev1, fl, _ in gemm_events:
                 tot_ms += ops.event_elapsed_ms(ev0, ev1)
                 tot_fl += fl
             n = len(gemm_events)
             ach = tot_fl / tot_ms / 1e9
+            # HBM bytes per GEMM launch from the PMC counters: rocprofv3 cannot run inside this process, so the
+            # number is the one measured by the separate --pmc passes of tools/gpu_traffic.sh (FETCH_SIZE doubled
+            # per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is), committed under profiles/
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'r01_gemm_traffic.json')) as f:
+                    traffic = json.load(f)['gemm_hbm_bytes_per_launch']
+            except Exception:
+                pass
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel<BM,BN,...> (csrc/gemm.hip), all launches of the timed steps',
                                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                               'traffic': None, 'launches': n, 'avg_launch_ms': tot_ms / n,
+                               'traffic': traffic, 'traffic_unit': 'HBM bytes per GEMM launch (PMC, profiles/r01_gemm_traffic.json)',
+                               'algorithmic_bytes_per_launch': sum(e[3] for e in gemm_events) / n,
+                               'launches': n, 'avg_launch_ms': tot_ms / n,
                                'avg_flops_per_launch': tot_fl / n, 'gemm_share_of_step_time': tot_ms / (dt * 1e3)}
         if not args.no_cpu_baseline and world == 1:
             try:
