@@ -448,3 +448,40 @@ extern "C" int aa_window_labels(const int64_t* ids, int N, int T, int64_t pad_id
     AA_CHECK_LAUNCH("aa_window_labels");
     return AA_OK;
 }
+
+// ------------------------------------------------------------------ reward-model pairwise loss (fwd + bwd)
+// align_anything/trainers/text_to_text/rm.py:97-132: end scores [2B] (higher = [0,B), lower = [B,2B)):
+//   loss = mean(-logsigmoid(h - l)) + reg * mean(concat(l, h)^2) ; accuracy = mean(h > l)
+// out[0] = loss, out[1] = accuracy ; dscores[2B] = d loss / d end score.
+__global__ __launch_bounds__(256) void rm_loss_kernel(const float* __restrict__ end_scores, int B, float reg,
+                                                      float* __restrict__ out, float* __restrict__ dscores) {
+    __shared__ float red[8];
+    float l = 0.f, a = 0.f, sq = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const float h = end_scores[i], w = end_scores[B + i];
+        const float z = h - w;
+        l += fmaxf(-z, 0.f) + log1pf(expf(-fabsf(z)));
+        a += (h > w) ? 1.f : 0.f;
+        sq += h * h + w * w;
+        if (dscores) {
+            const float sg = 1.f / (1.f + expf(z));  // sigmoid(-z)
+            dscores[i] = -sg / (float)B + reg * 2.f * h / (float)(2 * B);
+            dscores[B + i] = sg / (float)B + reg * 2.f * w / (float)(2 * B);
+        }
+    }
+    l = block_sum<256>(l, red);
+    a = block_sum<256>(a, red);
+    sq = block_sum<256>(sq, red);
+    if (threadIdx.x == 0) {
+        out[0] = l / (float)B + reg * sq / (float)(2 * B);
+        out[1] = a / (float)B;
+    }
+}
+extern "C" int aa_rm_loss_fwd_bwd(const float* end_scores, int B, float regularization, float* out2,
+                                  float* dscores, void* stream) {
+    AA_REQUIRE(B > 0, "aa_rm_loss_fwd_bwd: B must be > 0 (got %d)", B);
+    hipLaunchKernelGGL(rm_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, end_scores, B, regularization,
+                       out2, dscores);
+    AA_CHECK_LAUNCH("aa_rm_loss_fwd_bwd");
+    return AA_OK;
+}

@@ -539,6 +539,45 @@ class NativeLlava(NativeCausalLM):
             self.proj1.dw(d_f1, cx['vfeat'])
 
 
+# ====================================================================== Llama (text only)
+class NativeLlama(NativeCausalLM):
+    """hf:models/llama/modeling_llama.py LlamaForCausalLM (MHA or GQA, head_dim 64/128): the text-to-text trainers'
+    backbone for Llama-family checkpoints (align_anything/models/llama.py)."""
+
+    kind = 'llama'
+
+    def __init__(self, cfg, device, trainable=True, head='lm'):
+        super().__init__(cfg, device, trainable)
+        self.head_kind = head
+        self.hidden_size = cfg['hidden_size']
+        st = self.store
+        self.embed = st.add('model.embed_tokens.weight', (cfg['vocab_size'], cfg['hidden_size']), trainable, f32_grad=True)
+        self.stack = LlamaStack(cfg, st, 'model.', trainable)
+        if head == 'lm':
+            lm = st.add('lm_head.weight', (cfg['vocab_size'], cfg['hidden_size']), trainable)
+            self.head = LMHead(st, 'rms', self.stack.norm, None, lm, cfg['rms_eps'], trainable)
+        else:
+            sw = st.add('score_head.weight', (1, cfg['hidden_size']), trainable, f32_grad=True)
+            self.head = ScoreHead(st, 'rms', self.stack.norm, None, sw, cfg['rms_eps'], trainable)
+        self.finalize()
+
+    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None):
+        N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask)
+        ids = input_ids.reshape(-1)
+        if Mp != N * T:
+            ids = torch.cat([ids, torch.zeros(Mp - N * T, dtype=ids.dtype, device=ids.device)])
+        x = ops.embed_fwd(ids, self.store.p[self.embed])
+        if save:
+            self._ctx = dict(ids=ids, N=N, T=T, start=start, pos=pos)
+        return self.stack.forward(x, N, T, start, pos, save)
+
+    def backward_stream(self, dres, on_layer_done=None):
+        cx = self._ctx
+        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done)
+        if self.trainable:
+            ops.embed_bwd(cx['ids'], dx, self.cfg['vocab_size'], dE=self.store.g[self.embed])
+
+
 # ====================================================================== OPT
 class OPTStack:
     """hf:models/opt/modeling_opt.py:191-251 pre-LN decoder layer (biased projections, ReLU MLP)."""
@@ -683,4 +722,6 @@ def build_model(cfg: dict, device, trainable=True, head='lm', **freeze):
         return NativeLlava(cfg, device, trainable, head=head, **freeze)
     if cfg['kind'] == 'opt':
         return NativeOPT(cfg, device, trainable, head=head)
+    if cfg['kind'] == 'llama':
+        return NativeLlama(cfg, device, trainable, head=head)
     raise ValueError(f"no native model for kind {cfg['kind']!r}")

@@ -338,6 +338,13 @@ def dpo_loss(pol_logp, ref_logp, seq_off, B, beta, want_grad=True):
     return out6, per, dlogp
 
 
+def rm_loss(end_scores, B, regularization, want_grad=True):
+    out2 = torch.empty(2, dtype=torch.float32, device=end_scores.device)
+    d = torch.empty_like(end_scores) if want_grad else None
+    call('aa_rm_loss_fwd_bwd', end_scores.data_ptr(), int(B), float(regularization), out2.data_ptr(), _p(d), stream())
+    return out2, d
+
+
 def kl_reward(reward, logp, ref_logp, mask_u8, kl_coeff, clip):
     B, L = logp.shape
     out = torch.empty_like(logp)

@@ -1,0 +1,60 @@
+"""Native reward-model trainer step (align_anything/trainers/text_to_text/rm.py:97-147): score-head model forward,
+pairwise -logsigmoid(r+ - r-) + L2 regularisation on the end scores, backward, step.  Batches are RIGHT padded
+(rm.py:81); the end score is the score at the last attended token (models/opt.py:67-89)."""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from ..engine import NativeEngine
+from ..modeling import build_model
+from .common import cfg_get, get_all_reduce_mean, pad64
+
+
+class RMTrainer:
+    def __init__(self, cfgs, ds_cfgs=None, *, model_cfg, state=None, device='cuda:0'):
+        t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
+        self.cfgs, self.device = cfgs, torch.device(device)
+        self.regularization = float(t('regularization', 0.001))
+        module = build_model(model_cfg, device, trainable=True, head='score')
+        if state is not None:
+            module.load_state_dict(state)
+        total = int(t('total_training_steps', 1))
+        self.model = NativeEngine(module, lr=float(t('learning_rate', 2e-5)), betas=[float(b) for b in t('adam_betas', [0.9, 0.95])],
+                                  weight_decay=float(t('weight_decay', 0.1)), max_grad_norm=float(cfg_get(ds_cfgs, 'gradient_clipping', 1.0)),
+                                  total_steps=total, warmup_steps=int(float(t('lr_warmup_ratio', 0.03)) * total),
+                                  lr_scheduler_type=t('lr_scheduler_type', 'cosine'))
+
+    def _end_window(self, input_ids, attention_mask):
+        """One row per sequence: the last attended position (device-side index math, no host sync)."""
+        N, T = input_ids.shape
+        dev = input_ids.device
+        end = (attention_mask.to(torch.int64) * torch.arange(1, T + 1, device=dev)[None]).argmax(dim=1)
+        rows_pad = pad64(N)
+        row_idx = torch.zeros(rows_pad, dtype=torch.int64, device=dev)
+        row_idx[:N] = torch.arange(N, device=dev) * T + end
+        Mp = (N * T + 63) // 64 * 64
+        inv = torch.full((Mp,), -1, dtype=torch.int32, device=dev)
+        inv[row_idx[:N]] = torch.arange(N, dtype=torch.int32, device=dev)
+        return {'N': N, 'T': T, 'rows': N, 'rows_pad': rows_pad, 'row_idx': row_idx, 'inv_map': inv,
+                'labels': torch.zeros(rows_pad, dtype=torch.int64, device=dev)}, end
+
+    def loss(self, batch):
+        ids, am = batch['input_ids'], batch['attention_mask']
+        B = ids.shape[0] // 2
+        w, end = self._end_window(ids, am)
+        self.model.wait_optimizer()
+        end_scores = self.model.module.response_scores(ids, am, w, pixel_values=batch.get('pixel_values'), save=True)
+        out2, d = ops.rm_loss(end_scores[:2 * B].contiguous(), B, self.regularization)
+        dpad = torch.zeros(w['rows_pad'], dtype=torch.float32, device=ids.device)
+        dpad[:2 * B] = d
+        self.model.set_pending(dpad)
+        return {'loss': out2[0], 'accuracy': out2[1], 'higher_end_reward': end_scores[:B], 'lower_end_reward': end_scores[B:2 * B],
+                '_stats': out2}
+
+    def train_step(self, batch):
+        ld = self.loss(batch)
+        self.model.backward(ld['loss'])
+        self.model.step()
+        s = get_all_reduce_mean(ld['_stats'].clone()).tolist()
+        return {'train/loss': s[0], 'train/accuracy': s[1], 'train/lr': self.model.optimizer.param_groups[0]['lr']}

@@ -63,6 +63,9 @@ int aa_window_labels(const int64_t* ids, int N, int T, int64_t pad_id, const int
  * mean margin; per_sample4B = better_reward[B], worse_reward[B], reward[B], margin[B]. */
 int aa_dpo_loss_fwd_bwd(const float* pol_logp, const float* ref_logp, const int* seq_off, int B,
                         float beta, float* out6, float* per_sample4B, float* dlogp, void* stream);
+/* trainers/text_to_text/rm.py:97-132 reward-model pairwise loss (+ L2 regularisation) and its gradient */
+int aa_rm_loss_fwd_bwd(const float* end_scores, int B, float regularization, float* out2, float* dscores,
+                       void* stream);
 /* trainers/text_to_text/ppo.py:528-547 add_kl_divergence_regularization */
 int aa_kl_reward(const float* reward, const float* logp, const float* ref_logp, const uint8_t* mask,
                  int B, int L, float kl_coeff, float clip, float* rewards_out, int* end_index_out,

@@ -101,3 +101,51 @@ def test_reward_model_step_and_rl_step_match_oracle():
     # a second step must run and keep the losses finite (weights were updated by both engines)
     info2 = tr.rl_step({'input_ids': d(ids), 'attention_mask': d(mask)}, tb)
     assert all(map(lambda v: v == v and abs(v) < 1e6, info2.values()))
+
+
+def test_rm_loss_and_llama_text_model_vs_oracle():
+    """Reward-model step (rm.py:97-132) on a GQA Llama backbone: end scores, loss, accuracy and gradients vs the
+    oracle (fp32 autograd); also covers NativeLlama (text-only) with num_kv_heads < num_heads."""
+    from align_anything_amd import configs
+    from align_anything_amd.trainers.rm import RMTrainer
+    cfg = configs.llama_cfg(128, 256, 2, 2, 1, 320, rms_eps=1e-5, max_position_embeddings=128)   # GQA: 2 q heads, 1 kv head
+    g = torch.Generator().manual_seed(4)
+    names = {'model.embed_tokens.weight': (320, 128), 'model.norm.weight': (128,), 'score_head.weight': (1, 128)}
+    for i in range(2):
+        p = f'model.layers.{i}.'
+        names.update({p + 'input_layernorm.weight': (128,), p + 'post_attention_layernorm.weight': (128,),
+                      p + 'self_attn.q_proj.weight': (128, 128), p + 'self_attn.k_proj.weight': (64, 128),
+                      p + 'self_attn.v_proj.weight': (64, 128), p + 'self_attn.o_proj.weight': (128, 128),
+                      p + 'mlp.gate_proj.weight': (256, 128), p + 'mlp.up_proj.weight': (256, 128), p + 'mlp.down_proj.weight': (128, 256)})
+    sd = {k: ((torch.randn(s, generator=g) * 0.06) if len(s) == 2 else 1 + 0.1 * torch.randn(s, generator=g)).to(torch.bfloat16) for k, s in names.items()}
+    tr = RMTrainer({'train_cfgs': {'regularization': 0.01, 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant',
+                                   'weight_decay': 0.0}}, {'gradient_clipping': 1.0}, model_cfg=cfg, state=sd, device='cuda:0')
+    N, Tn = 4, 48
+    ids = torch.randint(3, 320, (N, Tn), generator=g)
+    mask = torch.ones(N, Tn, dtype=torch.long)
+    for n, rp in enumerate((0, 9, 20, 3)):   # RIGHT padding
+        if rp:
+            mask[n, Tn - rp:] = 0; ids[n, Tn - rp:] = 0
+    batch = {'input_ids': ids.to(dev()), 'attention_mask': mask.to(dev())}
+    ld = tr.loss(batch)
+    f = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    x = torch.nn.functional.embedding(ids, f['model.embed_tokens.weight'])
+    hid = om.llama_decoder(f, cfg, x, mask.bool(), prefix='model.')
+    scores = (hid @ f['score_head.weight'].t()).squeeze(-1)
+    end = torch.stack([m.nonzero()[-1].squeeze() for m in mask])
+    es = scores[torch.arange(N), end]
+    hi, lo = es[:2], es[2:]
+    o_loss = -torch.nn.functional.logsigmoid(hi - lo).mean() + 0.01 * torch.stack([lo, hi]).square().mean()
+    got_es = torch.cat([ld['higher_end_reward'], ld['lower_end_reward']]).cpu()
+    assert_close(got_es, es.detach(), rtol=3e-2, atol=3e-2, what='end scores')
+    assert abs(float(ld['loss']) - float(o_loss)) < 2e-2
+    assert float(ld['accuracy']) == float((hi > lo).float().mean())
+    tr.model.backward(ld['loss'])
+    torch.cuda.synchronize()
+    o_loss.backward()
+    for n in ('score_head.weight', 'model.layers.1.mlp.down_proj.weight', 'model.layers.0.self_attn.k_proj.weight', 'model.norm.weight'):
+        got = tr.model.module.store.grad_view(n).float().cpu().reshape(f[n].grad.shape)
+        assert rel_err(got, f[n].grad) < 8e-2, (n, rel_err(got, f[n].grad))
+    tr.model.step()
+    info = tr.train_step(batch)
+    assert info['train/loss'] == info['train/loss']
