@@ -23,7 +23,7 @@
 // row-contiguous tile: [64 k rows][R cols] bf16; 32-B unit ^= (krow&3) | ((krow>>3)&1)<<2.
 __device__ __forceinline__ int tr_swz(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
-template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE, bool ILV>
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE, int ILV>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1)
 void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
@@ -214,7 +214,7 @@ void gemm_kernel(const GemmParams p) {
         constexpr int NREADS = (A_T ? 2 * FM : FM) + (B_N ? 2 * FN : FN);
         constexpr int NMFMA = FM * FN;
         constexpr int RATIO = (NMFMA / NREADS) > 0 ? (NMFMA / NREADS) : 1;
-        if constexpr (!ILV) {
+        if constexpr (ILV == 0) {
             stage(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -232,6 +232,66 @@ void gemm_kernel(const GemmParams p) {
                 if (t + 2 < nt) stage(cur);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_step(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (ILV == 2) {
+            // Peeled variant: the main loop body is branch-free (tile t+2 is always staged), so phase C is one
+            // scheduling region too: LDS reads of the next fragment set trickle between the first MFMAs and the
+            // DMA issues between the last ones; the two final iterations (nothing left to stage) are peeled.
+            constexpr int NDMA = A_IT + B_IT;
+            constexpr int RATIO_C = ((NMFMA - NDMA) / NREADS) > 0 ? ((NMFMA - NDMA) / NREADS) : 1;
+            stage(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            load_frags(0, 0, a0, b0);
+            if (nt > 1) stage(1);
+            int t = 0;
+            for (; t + 2 < nt; ++t) {
+                const int cur = t & 1;
+                load_frags(cur, 1, a1, b1);
+                mfma_step(a0, b0);
+#pragma unroll
+                for (int i = 0; i < NREADS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, RATIO, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                load_frags(cur ^ 1, 0, a0, b0);
+                stage(cur);
+                mfma_step(a1, b1);
+#pragma unroll
+                for (int i = 0; i < NREADS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, RATIO_C, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < NDMA; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (; t < nt; ++t) {
+                const int cur = t & 1;
+                load_frags(cur, 1, a1, b1);
+                mfma_step(a0, b0);
+#pragma unroll
+                for (int i = 0; i < NREADS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, RATIO, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                load_frags(cur ^ 1, 0, a0, b0);  // (last iteration: stale buffer, result unused)
+                mfma_step(a1, b1);
+#pragma unroll
+                for (int i = 0; i < NREADS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, RATIO, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -319,9 +379,9 @@ void gemm_kernel(const GemmParams p) {
 static int g_mfma32 = 0;  // 1: route 256x256 tiles to the 32x32x16-MFMA kernel (gemm32.hip)
 static int g_pipe = 1;  // 1: software-pipelined K loop (default), 0: simple schedule
 
-static int g_ilv = 1;   // 1: interleave ds_reads with MFMAs via sched_group_barrier (256x256 tile only)
+static int g_ilv = -1;   // 1: interleave ds_reads with MFMAs via sched_group_barrier (256x256 tile only)
 
-template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE, bool ILV>
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE, int ILV>
 static int launch_cfg2(GemmParams& p, hipStream_t st) {
     p.tiles_m = aa_cdiv(p.M, BM);
     p.tiles_n = aa_cdiv(p.N, BN);
@@ -345,9 +405,17 @@ static int launch_cfg2(GemmParams& p, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, bool A_T, bool B_N>
 static int launch_cfg(GemmParams& p, hipStream_t st) {
     if constexpr (BM == 256 && BN == 256) {
-        if (g_pipe && g_ilv) return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, true>(p, st);
+        // schedule variants exist for the hot 256x256 tile only (A/B data: profiles/r01_gemm_*_ab.json):
+        //   g_ilv = -1 (auto): NN -> fully interleaved peeled loop (2), NT / TN -> phase-A interleave (1)
+        if (!g_pipe) return launch_cfg2<BM, BN, WM, WN, A_T, B_N, false, 0>(p, st);
+        int mode = g_ilv;
+        if (mode < 0) mode = (!A_T && B_N) ? 2 : 1;
+        if (mode == 2) return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 2>(p, st);
+        if (mode == 1) return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 1>(p, st);
+        return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 0>(p, st);
+    } else {
+        return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 0>(p, st);
     }
-    return g_pipe ? launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, false>(p, st) : launch_cfg2<BM, BN, WM, WN, A_T, B_N, false, false>(p, st);
 }
 
 template <bool A_T, bool B_N>
@@ -416,6 +484,6 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
 // test hook: force a tile config (-1 = heuristic)
 extern "C" int aa_gemm_set_tile(int tile) { g_force_tile = tile; return AA_OK; }
 // test/bench hook: 1 = software-pipelined K loop (default), 0 = simple one-barrier schedule
-extern "C" int aa_gemm_set_interleave(int on) { g_ilv = on ? 1 : 0; return AA_OK; }
+extern "C" int aa_gemm_set_interleave(int mode) { g_ilv = mode; return AA_OK; }  // -1 auto, 0 off, 1 phase A, 2 both phases (peeled)
 extern "C" int aa_gemm_set_mfma32(int on) { g_mfma32 = on ? 1 : 0; return AA_OK; }
 extern "C" int aa_gemm_set_pipeline(int on) { g_pipe = on ? 1 : 0; return AA_OK; }

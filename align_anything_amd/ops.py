@@ -95,8 +95,8 @@ def gemm_set_tile(tile: int) -> None:
     call('aa_gemm_set_tile', int(tile))
 
 
-def gemm_set_interleave(on: bool) -> None:
-    call('aa_gemm_set_interleave', int(bool(on)))
+def gemm_set_interleave(mode: int) -> None:
+    call('aa_gemm_set_interleave', int(mode))
 
 
 def gemm_set_mfma32(on: bool) -> None:

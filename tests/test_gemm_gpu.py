@@ -86,3 +86,26 @@ def test_gemm_rejects_bad_arguments_loudly():
     a, b = randn_bf16(64, 100), randn_bf16(64, 100)
     with pytest.raises(AAHipError):
         ops.gemm(a, b)  # K not a multiple of 64
+
+
+@pytest.mark.parametrize('mode', [-1, 0, 1, 2])
+@pytest.mark.parametrize('layout', ['nt', 'nn', 'tn'])
+def test_gemm_k_loop_schedules_agree(mode, layout):
+    """The K-loop schedule variants of the 256x256 tile (simple pipeline, phase-A interleave, peeled full
+    interleave) are scheduling-only changes: identical results on ragged and short-K shapes (nt = 1, 2, 3 tiles)."""
+    from align_anything_amd import ops
+    ops.gemm_set_tile(0)
+    ops.gemm_set_interleave(mode)
+    try:
+        for (M, N, K) in [(264, 520, 64), (256, 256, 128), (300, 200, 192), (1154, 1024, 640), (512, 768, 2048)]:
+            a_t, b_n = layout == 'tn', layout in ('nn', 'tn')
+            if (a_t and M % 8) or (b_n and N % 8):
+                continue
+            a = randn_bf16(K, M, seed=1) if a_t else randn_bf16(M, K, seed=1)
+            b = randn_bf16(K, N, seed=2) if b_n else randn_bf16(N, K, seed=2)
+            out = ops.gemm(a, b, a_t=a_t, b_n=b_n)
+            ref = _ref(a, b, a_t, b_n)
+            assert_close(out, ref, rtol=1e-2, atol=1e-2 * float(ref.abs().mean()), what=f'{layout} ilv{mode} {M}x{N}x{K}')
+    finally:
+        ops.gemm_set_tile(-1)
+        ops.gemm_set_interleave(-1)

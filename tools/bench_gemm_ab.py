@@ -14,7 +14,7 @@ def timeit(fn, iters=20, warm=3):
     return s.elapsed_time(e) / iters
 res = []
 shapes = [('qkv', 8192, 12288, 4096), ('o', 8192, 4096, 4096), ('gate_up', 8192, 22016, 4096), ('down', 8192, 4096, 11008)]
-ops.gemm_set_tile(int(os.environ.get('TILE', 0)))
+
 for name, M, N, K in shapes:
     for layout in ('nt', 'nn', 'tn'):
         a_t, b_n = layout == 'tn', layout in ('nn', 'tn')
@@ -28,15 +28,16 @@ for name, M, N, K in shapes:
         fl = 2.0 * m * n * k
         row = dict(name=name, layout=layout, m=m, n=n, k=k)
         for rep in range(2):
-            for ilv in (0, 1):
+            for ilv in (1, 2):
+                ops.gemm_set_tile(0)
                 ops.gemm_set_interleave(ilv)
                 ms = timeit(lambda: ops.gemm(a, b, out=out, a_t=a_t, b_n=b_n))
                 row[f'ilv{ilv}_tf_{rep}'] = round(fl / ms / 1e9, 1)
-                if rep == 0 and ilv == 1:
+                if rep == 0 and ilv == 2:
                     ref = (A_ref := (a.t() if a_t else a).float()[:64]) @ (b if b_n else b.t()).float()
                     err = (out[:64].float() - ref).abs().max().item() / ref.abs().max().item()
-                    row['ilv1_relerr'] = round(err, 5)
-        ops.gemm_set_interleave(0)
+                    row['ilv2_relerr'] = round(err, 5)
+        ops.gemm_set_interleave(-1)
         A = a.t() if a_t else a; B = b if b_n else b.t()
         ms = timeit(lambda: torch.matmul(A, B, out=out))
         row['hipblaslt_tf'] = round(fl / ms / 1e9, 1)
