@@ -1,0 +1,84 @@
+"""Native autoregressive rollout: the replacement of HF `generate` in the PPO loop
+(align_anything/trainers/text_to_text/ppo.py:209-222, text_image_to_text/ppo.py:174-204).
+
+Prefill = the ordinary native forward with a KV sink; every later token is one pass of HBM-streaming kernels
+(csrc/decode.hip): skinny GEMMs, cache attention, norm, sampling.  HF semantics that are reproduced:
+  * left-padded prompts; position ids derived from the attention mask (cumsum - 1), i.e. NOT the arange
+    positions of the training forward (a reference quirk, SURVEY.md §8 a');
+  * TemperatureLogitsWarper / TopPLogitsWarper (repetition_penalty must be 1.0, the reference default);
+  * finished rows keep emitting pad_token_id; generation stops when every row has produced EOS or the length
+    cap (GenerationConfig.max_length = model_max_length) is reached; `synced_gpus` is not needed (pure DP).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+@torch.no_grad()
+def generate(model, input_ids, attention_mask, *, max_length=None, max_new_tokens=None, do_sample=True,
+             temperature=1.0, top_p=1.0, repetition_penalty=1.0, eos_token_id=None, pad_token_id=0,
+             pixel_values=None, generator=None, sync_every=8):
+    """Returns sequences [N, T_prompt + n_new] (int64), right-padded with pad_token_id after EOS."""
+    if repetition_penalty != 1.0:
+        raise NotImplementedError('repetition_penalty != 1.0 is not built (reference default is 1.0, ppo.yaml:156)')
+    N, T = input_ids.shape
+    dev = input_ids.device
+    if max_new_tokens is None:
+        if max_length is None:
+            raise ValueError('give max_length (GenerationConfig.max_length) or max_new_tokens')
+        max_new_tokens = max_length - T
+    if max_new_tokens <= 0:
+        return input_ids
+    Tmax = T + max_new_tokens
+    stack = model.stack
+    kvw = stack.kv_width()
+    cache = [torch.zeros((N * Tmax, kvw), dtype=torch.bfloat16, device=dev) for _ in stack.layers]
+
+    am = attention_mask.to(torch.int64)
+    valid = am.sum(dim=1)                                    # real prompt tokens per row
+    position_ids = (torch.cumsum(am, dim=1) - 1).clamp_(min=0)
+    start = am.to(torch.int32).argmax(dim=1).to(torch.int32)
+
+    def kv_sink(li, kv):  # kv: [N*T, kvw] of layer li
+        cache[li].view(N, Tmax, kvw)[:, :T] = kv.view(N, T, kvw)
+
+    x = model.forward_stream(input_ids, attention_mask, pixel_values, save=False, position_ids=position_ids,
+                             kv_sink=kv_sink)
+    last_rows = torch.arange(N, device=dev) * T + (T - 1)
+    logits = model.head.logits_rows(ops.embed_fwd(last_rows, x))
+
+    out = torch.full((N, Tmax), pad_token_id, dtype=torch.int64, device=dev)
+    out[:, :T] = input_ids
+    unfinished = torch.ones(N, dtype=torch.bool, device=dev)
+    n_new = 0
+    is_opt = getattr(model, 'kind', '') == 'opt'
+    for step in range(max_new_tokens):
+        if do_sample:
+            u = torch.rand(N, device=dev, generator=generator)
+            nxt = ops.sample_top_p(logits, temperature, top_p, u)
+        else:
+            nxt = ops.argmax_rows(logits)
+        nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad_token_id))
+        t = T + step
+        out[:, t] = nxt
+        n_new = step + 1
+        if eos_token_id is not None:
+            unfinished = unfinished & (nxt != eos_token_id)
+            if (step % sync_every == sync_every - 1) and not bool(unfinished.any()):
+                break
+        if step + 1 == max_new_tokens:
+            break
+        pos = (valid + step).to(torch.int32)                  # HF: cumsum(mask) - 1 continues past the prompt
+        emb_pos = (pos + 2) if is_opt else None               # OPT learned positions carry an offset of 2
+        xt = model.embed_tokens(nxt, emb_pos)
+        length = torch.full((N,), t + 1, dtype=torch.int32, device=dev)
+        xt = stack.decode_step(xt, cache, t, Tmax, pos, start, length)
+        logits = model.head.logits_rows(xt)
+    seq = out[:, :T + n_new]
+    if eos_token_id is not None:
+        # drop trailing columns that are pad for every row (rows that finished before the last sync point)
+        keep = int((seq != pad_token_id).any(dim=0).nonzero().max().item()) + 1 if bool((seq != pad_token_id).any()) else T
+        seq = seq[:, :max(keep, T)]
+    return seq

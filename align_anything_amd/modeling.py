@@ -98,16 +98,18 @@ class LlamaStack:
             n = max(T, self.cfg.get('max_position_embeddings', 0) or T)
             self.cos, self.sin = rope_tables(n, self.cfg['head_dim'], self.cfg['rope_theta'], self.store.device)
 
-    def forward(self, x, N, T, start, pos, save):
+    def forward(self, x, N, T, start, pos, save, kv_sink=None):
         c, P = self.cfg, self.store.p
         H, Hkv, hd, eps = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps']
         self._tables(T)
         self.saved = []
         qw, kw = H * hd, Hkv * hd
-        for L in self.layers:
+        for li, L in enumerate(self.layers):
             n1, rstd1 = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
             qkv = L['qkv'].fwd(n1)
             ops.rope_(qkv, 0, H + Hkv, hd, pos, self.cos, self.sin)
+            if kv_sink is not None:
+                kv_sink(li, qkv[:N * T, qw:])  # post-RoPE keys | values of this layer -> KV cache (prefill)
             attn, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
                                      hd ** -0.5, start, out=self._attn_out(x, N * T, H * hd))
             x_mid = L['o'].fwd(attn, residual=x)
@@ -118,6 +120,31 @@ class LlamaStack:
             if save:
                 self.saved.append((x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act))
             x = x_out
+        return x
+
+    def kv_width(self):
+        return 2 * self.cfg['num_kv_heads'] * self.cfg['head_dim']
+
+    def decode_step(self, x, cache, t, Tmax, pos, start, length):
+        """One new token per sequence (x [N, h]) against the KV cache (csrc/decode.hip): every GEMM streams its
+        weight once through the skinny kernel.  cache[l]: [N*Tmax, 2*kw] (keys | values), slot t is written here."""
+        c, P = self.cfg, self.store.p
+        H, Hkv, hd, eps = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps']
+        qw, kw = H * hd, Hkv * hd
+        N = x.shape[0]
+        self._tables(Tmax)
+        for li, L in enumerate(self.layers):
+            n1, _ = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
+            qkv = ops.linear_small(n1, L['qkv'].w)
+            ops.rope_(qkv, 0, H + Hkv, hd, pos, self.cos, self.sin)
+            cl = cache[li]
+            cl.view(N, Tmax, 2 * kw)[:, t] = qkv[:, qw:]
+            attn = ops.attn_decode(qkv[:, :qw], cl, cl[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
+            x_mid = ops.linear_small(attn, L['o'].w, residual=x)
+            n2, _ = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
+            gu = ops.linear_small(n2, L['gu'].w)
+            act = ops.swiglu_fwd(gu)
+            x = ops.linear_small(act, L['down'].w, residual=x_mid)
         return x
 
     @staticmethod
@@ -268,6 +295,15 @@ class LMHead:
             n, _, _ = ops.layernorm_fwd(x_last, P[self.norm_w], P[self.norm_b], self.eps, want_stats=False)
         return ops.gemm(n, self._w())
 
+    def logits_rows(self, x_rows):
+        """Logits of a handful of rows (decode): norm + skinny lm_head."""
+        P = self.store.p
+        if self.kind == 'rms':
+            n, _ = ops.rmsnorm_fwd(x_rows, P[self.norm_w], self.eps)
+        else:
+            n, _, _ = ops.layernorm_fwd(x_rows, P[self.norm_w], P[self.norm_b], self.eps, want_stats=False)
+        return ops.linear_small(n, self._w())
+
     def hidden_all(self, x_last):
         P = self.store.p
         if self.kind == 'rms':
@@ -386,19 +422,23 @@ class NativeCausalLM:
         self.store.init_training()
 
     # -- geometry helpers
-    def _token_geometry(self, input_ids, attention_mask):
+    def _token_geometry(self, input_ids, attention_mask, position_ids=None):
         N, T = input_ids.shape
         Mp = _pad64(N * T)
         if attention_mask is not None:
             start = attention_mask.to(torch.int32).argmax(dim=1).to(torch.int32)  # first attended key
         else:
             start = None
-        pos = torch.arange(T, dtype=torch.int32, device=self.device).repeat(N)
+        if position_ids is not None:  # HF generate(): positions from the mask (SURVEY.md §8 a' quirk)
+            pos = position_ids.to(torch.int32).reshape(-1)
+        else:
+            pos = torch.arange(T, dtype=torch.int32, device=self.device).repeat(N)
         if Mp != N * T:
             pos = torch.cat([pos, torch.zeros(Mp - N * T, dtype=torch.int32, device=self.device)])
         return N, T, Mp, start, pos
 
-    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None):
+    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
+                       position_ids=None, kv_sink=None):
         raise NotImplementedError
 
     def backward_stream(self, dres, on_layer_done=None):
@@ -493,8 +533,9 @@ class NativeLlava(NativeCausalLM):
         chosen/rejected rows and between policy and reference (the reference runs it 4x per pair)."""
         return self.vision.forward(pixel_values)
 
-    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None):
-        N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask)
+    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
+                       position_ids=None, kv_sink=None):
+        N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask, position_ids)
         P = self.store.p
         ids = input_ids.reshape(-1)
         if Mp != N * T:
@@ -514,7 +555,10 @@ class NativeLlava(NativeCausalLM):
         x = ops.embed_fwd(ids, P[self.embed], slot, feat)
         if save:
             self._ctx = dict(ids=ids, slot=slot, f1=f1, a1=a1, vfeat=vfeat, N=N, T=T, start=start, pos=pos)
-        return self.stack.forward(x, N, T, start, pos, save)
+        return self.stack.forward(x, N, T, start, pos, save, kv_sink)
+
+    def embed_tokens(self, ids, pos=None):
+        return ops.embed_fwd(ids, self.store.p[self.embed])
 
     def validate_batch(self):
         """hf:models/llava/modeling_llava.py:191-213 raises when #image tokens != #features; this is the same
@@ -561,15 +605,19 @@ class NativeLlama(NativeCausalLM):
             self.head = ScoreHead(st, 'rms', self.stack.norm, None, sw, cfg['rms_eps'], trainable)
         self.finalize()
 
-    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None):
-        N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask)
+    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
+                       position_ids=None, kv_sink=None):
+        N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask, position_ids)
         ids = input_ids.reshape(-1)
         if Mp != N * T:
             ids = torch.cat([ids, torch.zeros(Mp - N * T, dtype=ids.dtype, device=ids.device)])
         x = ops.embed_fwd(ids, self.store.p[self.embed])
         if save:
             self._ctx = dict(ids=ids, N=N, T=T, start=start, pos=pos)
-        return self.stack.forward(x, N, T, start, pos, save)
+        return self.stack.forward(x, N, T, start, pos, save, kv_sink)
+
+    def embed_tokens(self, ids, pos=None):
+        return ops.embed_fwd(ids, self.store.p[self.embed])
 
     def backward_stream(self, dres, on_layer_done=None):
         cx = self._ctx
@@ -606,14 +654,37 @@ class OPTStack:
             self.layers.append(L)
         self.saved = []
 
-    def forward(self, x, N, T, start, save):
+    def kv_width(self):
+        return 2 * self.cfg['hidden_size']
+
+    def decode_step(self, x, cache, t, Tmax, pos, start, length):
+        c, P = self.cfg, self.store.p
+        h, H = c['hidden_size'], c['num_heads']
+        hd = h // H
+        N = x.shape[0]
+        for li, L in enumerate(self.layers):
+            y1, _, _ = ops.layernorm_fwd(x, P[L['ln1w']], P[L['ln1b']], 1e-5, want_stats=False)
+            qkv = ops.linear_small(y1, L['qkv'].w, bias=L['qkv'].b)
+            cl = cache[li]
+            cl.view(N, Tmax, 2 * h)[:, t] = qkv[:, h:]
+            attn = ops.attn_decode(qkv[:, :h], cl, cl[:, h:], Tmax, start, length, N, H, H, hd, hd ** -0.5)
+            x_mid = ops.linear_small(attn, L['out'].w, bias=L['out'].b, residual=x)
+            y2, _, _ = ops.layernorm_fwd(x_mid, P[L['ln2w']], P[L['ln2b']], 1e-5, want_stats=False)
+            f1 = ops.linear_small(y2, L['fc1'].w, bias=L['fc1'].b)
+            a1 = ops.act_fwd(f1, ops.ACT_RELU)
+            x = ops.linear_small(a1, L['fc2'].w, bias=L['fc2'].b, residual=x_mid)
+        return x
+
+    def forward(self, x, N, T, start, save, kv_sink=None):
         c, P = self.cfg, self.store.p
         h, H = c['hidden_size'], c['num_heads']
         hd = h // H
         self.saved = []
-        for L in self.layers:
+        for li, L in enumerate(self.layers):
             y1, mean1, rstd1 = ops.layernorm_fwd(x, P[L['ln1w']], P[L['ln1b']], 1e-5)
             qkv = L['qkv'].fwd(y1)
+            if kv_sink is not None:
+                kv_sink(li, qkv[:N * T, h:])
             attn, lse = ops.attn_fwd(qkv[:, :h], qkv[:, h:2 * h], qkv[:, 2 * h:], N, T, H, H, hd, True, hd ** -0.5, start,
                                      out=torch.zeros_like(x) if x.shape[0] != N * T else None)
             x_mid = L['out'].fwd(attn, residual=x)
@@ -688,7 +759,12 @@ class NativeOPT(NativeCausalLM):
             sd['lm_head.weight'] = sd['model.decoder.embed_tokens.weight']
         return sd
 
-    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None):
+    def embed_tokens(self, ids, pos=None):
+        P = self.store.p
+        return ops.embed_fwd(ids, P[self.embed], pos=pos, P=P[self.pos_emb])
+
+    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
+                       position_ids=None, kv_sink=None):
         N, T, Mp, start, _ = self._token_geometry(input_ids, attention_mask)
         P = self.store.p
         am = attention_mask if attention_mask is not None else torch.ones_like(input_ids)
@@ -704,7 +780,7 @@ class NativeOPT(NativeCausalLM):
             x[N * T:].zero_()
         if save:
             self._ctx = dict(ids=ids, pos=pos, N=N, T=T, start=start)
-        return self.stack.forward(x, N, T, start, save)
+        return self.stack.forward(x, N, T, start, save, kv_sink)
 
     def backward_stream(self, dres, on_layer_done=None):
         cx = self._ctx

@@ -398,3 +398,39 @@ def adamw_flat_(master, m, v, p16, g, lr, beta1, beta2, eps, wd, step, gscale=1.
     call('aa_adamw_flat', master.data_ptr(), m.data_ptr(), v.data_ptr(), p16.data_ptr(), g.data_ptr(), dt,
          master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), float(gscale),
          _p(clip), stream())
+
+
+# ------------------------------------------------------------------ decode
+def linear_small(x, w, bias=None, residual=None, out=None):
+    """y = x W^T for a handful of rows (decode): HBM-streaming skinny kernel for M <= 16, tiled GEMM beyond."""
+    M, K = x.shape
+    N = w.shape[0]
+    if M > 16:
+        return gemm(x, w, out=out, bias=bias, residual=residual)
+    out = torch.empty((M, N), dtype=bf16, device=x.device) if out is None else out
+    ldr = residual.stride(0) if residual is not None else 0
+    call('aa_gemm_skinny_bf16', x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, x.stride(0), w.stride(0),
+         out.stride(0), _p(bias), _p(residual), ldr, stream())
+    return out
+
+
+def attn_decode(q, kcache, vcache, Tmax, start, length, N, H, Hkv, hd, scale):
+    out = torch.empty((N, H * hd), dtype=bf16, device=q.device)
+    call('aa_attn_decode', q.data_ptr(), q.stride(0), kcache.data_ptr(), vcache.data_ptr(), kcache.stride(0), int(Tmax),
+         _p(start), length.data_ptr(), out.data_ptr(), out.stride(0), N, H, Hkv, hd, float(scale), stream())
+    return out
+
+
+def argmax_rows(logits):
+    rows, V = logits.shape
+    out = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    call('aa_argmax_rows', logits.data_ptr(), logits.stride(0), rows, V, out.data_ptr(), stream())
+    return out
+
+
+def sample_top_p(logits, temperature, top_p, uniform):
+    rows, V = logits.shape
+    out = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    call('aa_sample_top_p', logits.data_ptr(), logits.stride(0), rows, V, float(temperature), float(top_p),
+         uniform.data_ptr(), out.data_ptr(), stream())
+    return out

@@ -143,6 +143,18 @@ int aa_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
                 long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, int N, int T,
                 int H, int Hkv, int hd, int causal, float scale, void* stream);
 
+/* ---- autoregressive decode (replaces HF generate in the PPO rollout, trainers/text_to_text/ppo.py:209-222) ---- */
+/* out[M<=16, N] = x[M,K] W[N,K]^T (+bias) (+residual, HF rounding); K % 32 == 0; HBM-streaming skinny GEMM */
+int aa_gemm_skinny_bf16(const void* x, const void* W, void* out, int M, int N, int K, long ldx, long ldw, long ldo,
+                        const void* bias, const void* residual, long ldr, void* stream);
+/* one query per sequence against the token-major KV cache [N, Tmax, Hkv*hd] (row stride ldc); keys [start[n], len[n]) */
+int aa_attn_decode(const void* q, long ldq, const void* Kc, const void* Vc, long ldc, int Tmax, const int* start,
+                   const int* len, void* o, long ldo, int N, int H, int Hkv, int hd, float scale, void* stream);
+/* greedy token (first index of the max, torch.argmax rule) and temperature/top-p sampling (HF logits warpers) */
+int aa_argmax_rows(const void* logits, long ld, int rows, int V, int64_t* out, void* stream);
+int aa_sample_top_p(const void* logits, long ld, int rows, int V, float temperature, float top_p,
+                    const float* uniform, int64_t* out, void* stream);
+
 /* ---- optimizer (DeepSpeed FusedAdam + gradient_clipping, supervised_trainer.py:245-249) ------ */
 int aa_grad_sumsq(const void* g, int g_dtype, long n, float scale, float* out_accum, void* stream);
 int aa_clip_coef(const float* sumsq, float max_norm, float* coef_out, float* norm_out, void* stream);
