@@ -96,6 +96,31 @@ class PPOTrainer(PPOMath):
         self.actor_reference_model = NativeEngine(ref, trainable=False)
         self.reward_model = NativeEngine(reward, trainable=False)
 
+    # ------------------------------------------------------------------ rollout (ppo.py:209-222, 244-289)
+    def actor_step(self, prompt_batch, generator=None):
+        """`self.actor_model.module.generate(**batch, generation_config=..., do_sample=True)` natively."""
+        from ..generation import generate
+        m = lambda k, d: cfg_get(self.cfgs, 'model_cfgs.' + k, d)
+        pad = m('pad_token_id', 0)
+        self.actor_model.wait_optimizer()
+        seq = generate(self.actor_model.module, prompt_batch['input_ids'], prompt_batch['attention_mask'],
+                       max_length=int(m('model_max_length', 2048)), do_sample=True, temperature=float(m('temperature', 1.0)),
+                       top_p=float(m('top_p', 1.0)), repetition_penalty=float(m('repetition_penalty', 1.0)),
+                       eos_token_id=m('eos_token_id', None), pad_token_id=pad,
+                       pixel_values=prompt_batch.get('pixel_values'), generator=generator)
+        return {'input_ids': seq, 'attention_mask': seq.ne(pad)}
+
+    def rollout(self, prompt_only_batch, generator=None):
+        """One micro-batch of experience: generate, score, log-probs of actor and reference (all no-grad)."""
+        actor_batch = self.actor_step(prompt_only_batch, generator)
+        ids, am = actor_batch['input_ids'], actor_batch['attention_mask'].to(torch.int64)
+        scored = self.reward_model_step(ids, am)
+        log_probs, _ = self.sequence_log_probs(self.actor_model, ids, am, 0)
+        ref_log_probs, _ = self.sequence_log_probs(self.actor_reference_model, ids, am, 0)
+        training = {'prompt_idx': prompt_only_batch['input_ids'].size(-1) - 1, 'log_probs': log_probs,
+                    'ref_log_probs': ref_log_probs, 'reward': scored['reward'], 'reward_values': scored['reward_values']}
+        return {'input_ids': ids, 'attention_mask': am}, training
+
     # ------------------------------------------------------------------ scoring (ppo.py:224-242)
     def reward_model_step(self, input_ids, attention_mask):
         """reward = end score of the reward model (last attended token, models/opt.py:67-89);
