@@ -12,13 +12,14 @@
 #define LOG2E_D 1.4426950408889634f
 
 // ------------------------------------------------------------------ skinny GEMM (M <= 16)
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ x, long ldx,
-                                                          const bf16_t* __restrict__ W, long ldw,
-                                                          bf16_t* __restrict__ out, long ldo,
-                                                          const bf16_t* __restrict__ bias,
-                                                          const bf16_t* __restrict__ residual, long ldr,
-                                                          int M, int N, int K) {
-    __shared__ float red[4][16][17];
+template <int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                                  const bf16_t* __restrict__ W, long ldw,
+                                                                  bf16_t* __restrict__ out, long ldo,
+                                                                  const bf16_t* __restrict__ bias,
+                                                                  const bf16_t* __restrict__ residual, long ldr,
+                                                                  int M, int N, int K) {
+    __shared__ float red[NWAVE][16][17];
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16;
@@ -26,35 +27,41 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
     const int mrow = min(l15, M - 1);
     const bf16_t* wp = W + (long)nrow * ldw + g * 8;
     const bf16_t* xp = x + (long)mrow * ldx + g * 8;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    // wave w owns k in [w*K/4, (w+1)*K/4) rounded to 32; 4 MFMA k-steps (128 k) per trip -> 8 loads in flight
-    const int kq = ((K / 4 + 31) / 32) * 32;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // wave w owns k in [w*kq, (w+1)*kq), kq = K/NWAVE rounded up to 32; 8 MFMA k-steps (256 k) per trip keep
+    // 16 x 16-B loads per lane in flight (the weight stream is read exactly once: no LDS round trip)
+    const int kq = ((K / NWAVE + 31) / 32) * 32;
     const int k_lo = wave * kq, k_hi = min(K, k_lo + kq);
     int k = k_lo;
-    for (; k + 128 <= k_hi; k += 128) {
-        bf16x8 wf[4], xf[4];
+    for (; k + 256 <= k_hi; k += 256) {
+        bf16x8 wf[8], xf[8];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            wf[s] = *reinterpret_cast<const bf16x8*>(wp + k + s * 32);
+        for (int s = 0; s < 8; ++s) {
+            wf[s] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + k + s * 32));
             xf[s] = *reinterpret_cast<const bf16x8*>(xp + k + s * 32);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf[s], acc, 0, 0, 0);
+        for (int s = 0; s < 8; s += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s + 1], xf[s + 1], acc1, 0, 0, 0);
+        }
     }
     for (; k < k_hi; k += 32) {
-        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wp + k);
+        const bf16x8 wf = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + k));
         const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + k);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc0, 0, 0, 0);
     }
     // D[i = n (4g + r)][j = m (l15)]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][l15] = acc[r];
+    for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][l15] = acc0[r] + acc1[r];
     __syncthreads();
-    // thread t -> (m = t / 16, n = t % 16)
+    // thread t < 256 -> (m = t / 16, n = t % 16)
     const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
     const int n = n0 + nn;
-    if (m < M && n < N) {
-        float v = red[0][nn][m] + red[1][nn][m] + red[2][nn][m] + red[3][nn][m];
+    if (threadIdx.x < 256 && m < M && n < N) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) v += red[w][nn][m];
         if (bias) v += bf2f(bias[n]);
         if (residual) v = rbf(v) + bf2f(residual[(long)m * ldr + n]);
         out[(long)m * ldo + n] = f2bf(v);
@@ -67,9 +74,16 @@ extern "C" int aa_gemm_skinny_bf16(const void* x, const void* W, void* out, int 
     AA_REQUIRE(M >= 1 && M <= 16, "aa_gemm_skinny_bf16: M=%d must be in [1, 16] (use aa_gemm_bf16 beyond)", M);
     AA_REQUIRE(N > 0 && K > 0 && K % 32 == 0, "aa_gemm_skinny_bf16: K=%d must be a multiple of 32", K);
     AA_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0, "aa_gemm_skinny_bf16: ldx/ldw must be multiples of 8");
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(aa_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
-                       (const bf16_t*)residual, ldr, M, N, K);
+    // few column strips (N/16 < ~3 per CU): split K over 8 waves so enough loads are in flight per CU
+    const bool wide = (N / 16) >= 768 || K < 2048;
+    if (wide)
+        hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(aa_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
+                           (const bf16_t*)residual, ldr, M, N, K);
+    else
+        hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3(aa_cdiv(N, 16)), dim3(512), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
+                           (const bf16_t*)residual, ldr, M, N, K);
     AA_CHECK_LAUNCH("aa_gemm_skinny_bf16");
     return AA_OK;
 }

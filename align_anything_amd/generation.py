@@ -19,7 +19,7 @@ from . import ops
 @torch.no_grad()
 def generate(model, input_ids, attention_mask, *, max_length=None, max_new_tokens=None, do_sample=True,
              temperature=1.0, top_p=1.0, repetition_penalty=1.0, eos_token_id=None, pad_token_id=0,
-             pixel_values=None, generator=None, sync_every=8):
+             pixel_values=None, generator=None, sync_every=8, use_graph=False):
     """Returns sequences [N, T_prompt + n_new] (int64), right-padded with pad_token_id after EOS."""
     if repetition_penalty != 1.0:
         raise NotImplementedError('repetition_penalty != 1.0 is not built (reference default is 1.0, ppo.yaml:156)')
@@ -51,31 +51,83 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
 
     out = torch.full((N, Tmax), pad_token_id, dtype=torch.int64, device=dev)
     out[:, :T] = input_ids
-    unfinished = torch.ones(N, dtype=torch.bool, device=dev)
-    n_new = 0
     is_opt = getattr(model, 'kind', '') == 'opt'
-    for step in range(max_new_tokens):
+    eos = -1 if eos_token_id is None else int(eos_token_id)
+    # ---- static device state of the decode loop (everything a step needs lives in these buffers, so one step
+    # is a fixed launch sequence: captured once in a hipGraph and replayed -- the per-step host cost of ~300
+    # ctypes/torch launches (launch-bound at 7B: ~17 us x 320) collapses to one graph launch)
+    st = {
+        'logits': logits.clone(), 'unfinished': torch.ones(N, dtype=torch.bool, device=dev),
+        'tslot': torch.full((N,), T, dtype=torch.int64, device=dev), 'pos': valid.to(torch.int32).clone(),
+        'length': torch.full((N,), T + 1, dtype=torch.int32, device=dev), 'step': torch.zeros(1, dtype=torch.int64, device=dev),
+        'U': torch.rand((max_new_tokens, N), device=dev, generator=generator) if do_sample else None,
+    }
+    padv = torch.full((N,), pad_token_id, dtype=torch.int64, device=dev)
+
+    def one_step():
+        """select token from st['logits'], record it, run one decode pass, leave next logits in st['logits']."""
         if do_sample:
-            u = torch.rand(N, device=dev, generator=generator)
-            nxt = ops.sample_top_p(logits, temperature, top_p, u)
+            u = st['U'].index_select(0, st['step'])[0]
+            nxt = ops.sample_top_p(st['logits'], temperature, top_p, u)
         else:
-            nxt = ops.argmax_rows(logits)
-        nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad_token_id))
-        t = T + step
-        out[:, t] = nxt
-        n_new = step + 1
-        if eos_token_id is not None:
-            unfinished = unfinished & (nxt != eos_token_id)
-            if (step % sync_every == sync_every - 1) and not bool(unfinished.any()):
-                break
-        if step + 1 == max_new_tokens:
-            break
-        pos = (valid + step).to(torch.int32)                  # HF: cumsum(mask) - 1 continues past the prompt
-        emb_pos = (pos + 2) if is_opt else None               # OPT learned positions carry an offset of 2
+            nxt = ops.argmax_rows(st['logits'])
+        nxt = torch.where(st['unfinished'], nxt, padv)
+        out.scatter_(1, st['tslot'][:, None], nxt[:, None])
+        if eos >= 0:
+            st['unfinished'].logical_and_(nxt != eos)
+        emb_pos = (st['pos'] + 2) if is_opt else None        # OPT learned positions carry an offset of 2
         xt = model.embed_tokens(nxt, emb_pos)
-        length = torch.full((N,), t + 1, dtype=torch.int32, device=dev)
-        xt = stack.decode_step(xt, cache, t, Tmax, pos, start, length)
-        logits = model.head.logits_rows(xt)
+        xt = stack.decode_step(xt, cache, st['tslot'], Tmax, st['pos'], start, st['length'])
+        st['logits'].copy_(model.head.logits_rows(xt))
+        st['tslot'].add_(1); st['pos'].add_(1); st['length'].add_(1); st['step'].add_(1)
+
+    graph = None
+    if use_graph and max_new_tokens > 4:
+        try:
+            snap = {k: v.clone() for k, v in st.items() if v is not None and k != 'U'}
+            out_snap = out.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                one_step()                                      # warm-up on a side stream (allocator, lazy inits)
+            torch.cuda.current_stream().wait_stream(side)
+            for k, v in snap.items():
+                st[k].copy_(v)
+            out.copy_(out_snap)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                one_step()
+            for k, v in snap.items():                           # capture does not execute: state is still pristine,
+                st[k].copy_(v)                                  # but make that explicit
+            out.copy_(out_snap)
+        except Exception:                                       # capture unsupported -> eager launches
+            graph = None
+            for k, v in snap.items():
+                st[k].copy_(v)
+            out.copy_(out_snap)
+
+    generate.last_used_graph = graph is not None
+    n_new = 0
+    # the last selected token needs no decode pass, but running it keeps the loop a single replayed graph;
+    # the cache has Tmax slots, so the final pass writes slot Tmax-1 at most
+    for step in range(max_new_tokens):
+        if step + 1 == max_new_tokens:
+            # final token: selection only
+            if do_sample:
+                nxt = ops.sample_top_p(st['logits'], temperature, top_p, st['U'][step])
+            else:
+                nxt = ops.argmax_rows(st['logits'])
+            nxt = torch.where(st['unfinished'], nxt, padv)
+            out[:, T + step] = nxt
+            n_new = step + 1
+            break
+        if graph is not None:
+            graph.replay()
+        else:
+            one_step()
+        n_new = step + 1
+        if eos >= 0 and (step % sync_every == sync_every - 1) and not bool(st['unfinished'].any()):
+            break
     seq = out[:, :T + n_new]
     if eos_token_id is not None:
         # drop trailing columns that are pad for every row (rows that finished before the last sync point)

@@ -133,12 +133,13 @@ class LlamaStack:
         qw, kw = H * hd, Hkv * hd
         N = x.shape[0]
         self._tables(Tmax)
+        rows = torch.arange(N, device=x.device)
         for li, L in enumerate(self.layers):
             n1, _ = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
             qkv = ops.linear_small(n1, L['qkv'].w)
             ops.rope_(qkv, 0, H + Hkv, hd, pos, self.cos, self.sin)
             cl = cache[li]
-            cl.view(N, Tmax, 2 * kw)[:, t] = qkv[:, qw:]
+            cl.view(N, Tmax, 2 * kw).index_put_((rows, t), qkv[:, qw:])   # t: device int64 [N] (graph-capturable)
             attn = ops.attn_decode(qkv[:, :qw], cl, cl[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
             x_mid = ops.linear_small(attn, L['o'].w, residual=x)
             n2, _ = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
@@ -662,11 +663,12 @@ class OPTStack:
         h, H = c['hidden_size'], c['num_heads']
         hd = h // H
         N = x.shape[0]
+        rows = torch.arange(N, device=x.device)
         for li, L in enumerate(self.layers):
             y1, _, _ = ops.layernorm_fwd(x, P[L['ln1w']], P[L['ln1b']], 1e-5, want_stats=False)
             qkv = ops.linear_small(y1, L['qkv'].w, bias=L['qkv'].b)
             cl = cache[li]
-            cl.view(N, Tmax, 2 * h)[:, t] = qkv[:, h:]
+            cl.view(N, Tmax, 2 * h).index_put_((rows, t), qkv[:, h:])
             attn = ops.attn_decode(qkv[:, :h], cl, cl[:, h:], Tmax, start, length, N, H, H, hd, hd ** -0.5)
             x_mid = ops.linear_small(attn, L['out'].w, bias=L['out'].b, residual=x)
             y2, _, _ = ops.layernorm_fwd(x_mid, P[L['ln2w']], P[L['ln2b']], 1e-5, want_stats=False)
