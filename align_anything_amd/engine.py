@@ -249,6 +249,7 @@ class NativeEngine:
                        os.path.join(save_dir, f'native_engine_{tag or "latest"}.pt'))
 
     def load_checkpoint(self, load_dir, tag=None):
+        self.wait_optimizer()
         st = self.module.store
         ck = torch.load(os.path.join(load_dir, f'native_engine_{tag or "latest"}.pt'), map_location='cpu')
         self.global_steps = ck['global_steps']
