@@ -474,6 +474,7 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
     const int tile = pick_tile(M, N);
     hipStream_t st = (hipStream_t)stream;
     if (g_mfma32 && tile == 0 && !(a_t && !b_n)) return aa_gemm32_dispatch(p, a_t, b_n, st);
+    if (g_ilv == 3 && g_pipe && tile == 0 && !(a_t && !b_n) && K >= 4 * BK) return aa_gemm_ring_dispatch(p, a_t, b_n, st);
     if (!a_t && !b_n) return launch_layout<false, false>(p, tile, st);
     if (!a_t && b_n) return launch_layout<false, true>(p, tile, st);
     if (a_t && b_n) return launch_layout<true, true>(p, tile, st);
@@ -484,6 +485,6 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
 // test hook: force a tile config (-1 = heuristic)
 extern "C" int aa_gemm_set_tile(int tile) { g_force_tile = tile; return AA_OK; }
 // test/bench hook: 1 = software-pipelined K loop (default), 0 = simple one-barrier schedule
-extern "C" int aa_gemm_set_interleave(int mode) { g_ilv = mode; return AA_OK; }  // -1 auto, 0 off, 1 phase A, 2 both phases (peeled)
+extern "C" int aa_gemm_set_interleave(int mode) { g_ilv = mode; return AA_OK; }  // -1 auto, 0 off, 1 phase A, 2 both phases (peeled), 3 split-K ring (gemm_ring.hip)
 extern "C" int aa_gemm_set_mfma32(int on) { g_mfma32 = on ? 1 : 0; return AA_OK; }
 extern "C" int aa_gemm_set_pipeline(int on) { g_pipe = on ? 1 : 0; return AA_OK; }

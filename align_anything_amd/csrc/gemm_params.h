@@ -40,5 +40,44 @@ struct GemmParams {
 constexpr int BK = 64;
 
 
+// Epilogue of one lane-owned group of 4 consecutive output columns C[m][n..n+3] (HF rounding points: bias,
+// activation on the bf16-rounded value, residual added after bf16 rounding, optional accumulate / fp32 out).
+__device__ __forceinline__ void gemm_store4(const GemmParams& p, int m, int n, float v0, float v1, float v2, float v3) {
+    float v[4] = {v0, v1, v2, v3};
+    if (p.bias) {
+        const u16x4 b = *reinterpret_cast<const u16x4*>(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
+    }
+    if (p.act != AA_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gemm_act(rbf(v[e]), p.act);
+    }
+    if (p.residual) {
+        const u16x4 r = *reinterpret_cast<const u16x4*>(p.residual + (long)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) + bf2f(r[e]);
+    }
+    if (p.flags & AA_GEMM_OUT_F32) {
+        float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        if (p.flags & AA_GEMM_ACCUM) { const f32x4 old = *reinterpret_cast<const f32x4*>(c); o += old; }
+        *reinterpret_cast<f32x4*>(c) = o;
+    } else {
+        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
+        if (p.flags & AA_GEMM_ACCUM) {
+            const u16x4 old = *reinterpret_cast<const u16x4*>(c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bf2f(old[e]);
+        }
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        *reinterpret_cast<u16x4*>(c) = o;
+    }
+}
+
+// split-K-ring 256x256 kernel (gemm_ring.hip)
+int aa_gemm_ring_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
 // 32x32x16-MFMA 256x256 kernel (gemm32.hip)
 int aa_gemm32_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);

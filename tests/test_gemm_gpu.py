@@ -88,16 +88,17 @@ def test_gemm_rejects_bad_arguments_loudly():
         ops.gemm(a, b)  # K not a multiple of 64
 
 
-@pytest.mark.parametrize('mode', [-1, 0, 1, 2])
+@pytest.mark.parametrize('mode', [-1, 0, 1, 2, 3])
 @pytest.mark.parametrize('layout', ['nt', 'nn', 'tn'])
 def test_gemm_k_loop_schedules_agree(mode, layout):
     """The K-loop schedule variants of the 256x256 tile (simple pipeline, phase-A interleave, peeled full
-    interleave) are scheduling-only changes: identical results on ragged and short-K shapes (nt = 1, 2, 3 tiles)."""
+    interleave, split-K ring with counted vmcnt = mode 3) are scheduling-only changes: identical results on ragged and short-K shapes (nt = 1, 2, 3 tiles)."""
     from align_anything_amd import ops
     ops.gemm_set_tile(0)
     ops.gemm_set_interleave(mode)
     try:
-        for (M, N, K) in [(264, 520, 64), (256, 256, 128), (300, 200, 192), (1154, 1024, 640), (512, 768, 2048)]:
+        for (M, N, K) in [(264, 520, 64), (256, 256, 128), (300, 200, 192), (1154, 1024, 640), (512, 768, 2048),
+                          (520, 264, 256), (256, 512, 320), (2048, 1024, 4096)]:
             a_t, b_n = layout == 'tn', layout in ('nn', 'tn')
             if (a_t and M % 8) or (b_n and N % 8):
                 continue

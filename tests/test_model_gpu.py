@@ -195,3 +195,25 @@ def test_checkpoint_roundtrip_hf_layout_and_engine_state(tmp_path):
     for g, t in before.items():
         assert torch.equal(tr.policy.store.master[g], t)
         assert torch.equal(tr.policy.store.flat[g], t.to(torch.bfloat16))
+
+
+def test_native_bf16_loss_is_inside_the_references_own_bf16_envelope():
+    """The reference trains in bf16 (pretrained_model.py:172).  Its own bf16 arithmetic (same torch ops, bf16
+    tensors, per-token log-probs summed in bf16, dpo.py:136-139) deviates from its fp32 run; the native path
+    (bf16 compute, fp32 log-prob reduction) must deviate from the fp32 fixture by no more than that."""
+    z = load_golden('llava_tiny_dpo.npz')
+    tr = _trainer(z, tiny_llava_cfg())
+    native = float(tr.loss(_batch(z))['loss'])
+    fp32 = float(z['loss_loss'])
+    cfg = tiny_llava_cfg()
+    ids, am, pix = T(z['input_ids']), T(z['attention_mask']), T(z['pixel_values'])
+    lens = [int(x) for x in z['response_lens']]
+    sd = state_dict_from_golden(z, 'w.', torch.bfloat16)
+    sdr = state_dict_from_golden(z, 'r.', torch.bfloat16)
+    with torch.no_grad():
+        lp = orl.compute_log_probs(om.llava_logits(sd, cfg, ids, am, pix.to(torch.bfloat16)), ids, lens, int(z['pad_token_id']))
+        rlp = orl.compute_log_probs(om.llava_logits(sdr, cfg, ids, am, pix.to(torch.bfloat16)), ids, lens, int(z['pad_token_id']))
+        ref_bf16 = float(orl.dpo_loss(lp, rlp, float(z['scale_coeff']))['loss'])
+    dump('parity_bf16_envelope.txt', f'fp32 reference {fp32:.6f}\nreference arithmetic in bf16 {ref_bf16:.6f} (dev {abs(ref_bf16-fp32):.2e})\n'
+                                     f'native MI355X {native:.6f} (dev {abs(native-fp32):.2e})\n')
+    assert abs(native - fp32) <= abs(ref_bf16 - fp32) + 2e-3

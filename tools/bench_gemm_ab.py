@@ -28,15 +28,15 @@ for name, M, N, K in shapes:
         fl = 2.0 * m * n * k
         row = dict(name=name, layout=layout, m=m, n=n, k=k)
         for rep in range(2):
-            for ilv in (1, 2):
+            for ilv in (1, 3):
                 ops.gemm_set_tile(0)
                 ops.gemm_set_interleave(ilv)
                 ms = timeit(lambda: ops.gemm(a, b, out=out, a_t=a_t, b_n=b_n))
                 row[f'ilv{ilv}_tf_{rep}'] = round(fl / ms / 1e9, 1)
-                if rep == 0 and ilv == 2:
+                if rep == 0 and ilv == 3:
                     ref = (A_ref := (a.t() if a_t else a).float()[:64]) @ (b if b_n else b.t()).float()
                     err = (out[:64].float() - ref).abs().max().item() / ref.abs().max().item()
-                    row['ilv2_relerr'] = round(err, 5)
+                    row['ilv3_relerr'] = round(err, 5)
         ops.gemm_set_interleave(-1)
         A = a.t() if a_t else a; B = b if b_n else b.t()
         ms = timeit(lambda: torch.matmul(A, B, out=out))
