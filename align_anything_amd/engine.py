@@ -70,7 +70,8 @@ class GradReducer:
 
 class NativeEngine:
     def __init__(self, module, *, lr=1e-6, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
-                 total_steps=1, warmup_steps=0, lr_scheduler_type='cosine', group=None, trainable=True):
+                 total_steps=1, warmup_steps=0, lr_scheduler_type='cosine', group=None, trainable=True,
+                 gradient_accumulation_steps=1):
         self.module = module
         self.trainable = trainable
         self.base_lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(float(b) for b in betas), eps, weight_decay
@@ -84,6 +85,8 @@ class NativeEngine:
         self.optimizer = SimpleNamespace(param_groups=[{'lr': lr0, 'weight_decay': weight_decay},
                                                         {'lr': lr0, 'weight_decay': 0.0}])
         self._pending = None
+        self.gas = max(1, int(gradient_accumulation_steps))
+        self.micro_steps = 0
         self.async_optimizer = True
         self._opt_stream = None
         self._opt_done = None
@@ -143,7 +146,16 @@ class NativeEngine:
             raise RuntimeError('backward() without a pending loss gradient: call trainer.loss(batch) first')
         st = self.module.store
         self.wait_optimizer()
-        st.zero_grad()
+        # gradient accumulation (DeepSpeed semantics: backward() scales the loss by 1/gas, step() is a no-op until the
+        # boundary): the first micro-batch overwrites / zeroes, later ones accumulate (store.accumulate is read by the
+        # dW GEMMs); gradients are exchanged between ranks only at the boundary.
+        first = (self.micro_steps % self.gas) == 0
+        boundary = ((self.micro_steps + 1) % self.gas) == 0
+        st.accumulate = not first
+        if first:
+            st.zero_grad()
+        if self.gas > 1:
+            self._pending = self._pending * (1.0 / self.gas)
         done = set()
 
         def on_layer_done(L):
@@ -152,10 +164,12 @@ class NativeEngine:
                 self.reducer.reduce_async(st.gflat['mat'][rng[0]:rng[1]])
                 done.add(rng)
 
-        hook = on_layer_done if self.world > 1 else None
+        hook = on_layer_done if (self.world > 1 and boundary) else None
         self.module.backward_from_dlogp(self._pending, hook)
         self._pending = None
-        if self.world > 1:
+        st.accumulate = False
+        self.micro_steps += 1
+        if self.world > 1 and boundary:
             # whatever was not covered by a per-layer bucket (lm_head, projector, embeddings, vectors)
             mat = st.gflat.get('mat')
             if mat is not None:
@@ -177,6 +191,8 @@ class NativeEngine:
         DPO step that is the (MFMA-bound) reference forward of the NEXT batch.  `wait_optimizer()` is the
         join; the trainer calls it before the next policy forward, and every reader of the weights goes through it."""
         st = self.module.store
+        if self.micro_steps % self.gas != 0:
+            return  # not at a gradient-accumulation boundary (DeepSpeedEngine.step semantics)
         self.reducer.wait()
         self.global_steps += 1
         gscale = 1.0 / self.world

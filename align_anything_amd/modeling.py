@@ -58,7 +58,7 @@ class Linear:
     def dw(self, dy, x):
         gw = self.store.g.get(self.wname)
         if gw is not None:
-            ops.gemm(dy, x, out=gw, a_t=True, b_n=True, accumulate=(gw.dtype == torch.float32))
+            ops.gemm(dy, x, out=gw, a_t=True, b_n=True, accumulate=(gw.dtype == torch.float32) or self.store.accumulate)
         if self.bname is not None and self.bname in self.store.g:
             ops.colsum_(dy, self.store.g[self.bname])
 
@@ -321,7 +321,7 @@ class LMHead:
             gw = G.get(self.lm_w)
             if gw is None:
                 gw = self.store.grad_view(self.lm_w)
-            ops.gemm(logits, n, out=gw, a_t=True, b_n=True, accumulate=(gw.dtype == torch.float32))
+            ops.gemm(logits, n, out=gw, a_t=True, b_n=True, accumulate=(gw.dtype == torch.float32) or self.store.accumulate)
         tr = self.trainable
         if self.kind == 'rms':
             d_sel = ops.rmsnorm_bwd(d_n, sel, P[self.norm_w], rstd, G.get(self.norm_w) if tr else None)

@@ -39,6 +39,7 @@ class ParamStore:
         self.p: dict[str, torch.Tensor] = {}
         self.g: dict[str, torch.Tensor] = {}
         self.sizes: dict[str, int] = {}
+        self.accumulate = False   # set by NativeEngine during gradient accumulation (bf16 dW GEMMs then add)
 
     # ---- registration
     def add(self, name, shape, trainable=True, f32_grad=False):

@@ -80,7 +80,8 @@ class DPOTrainer:
                                   eps=float(t('adam_epsilon', 1e-8)), weight_decay=float(t('weight_decay', 0.0)),
                                   max_grad_norm=float(cfg_get(self.ds_train_cfgs, 'gradient_clipping', 1.0)),
                                   total_steps=total, warmup_steps=int(float(t('lr_warmup_ratio', 0.03)) * total),
-                                  lr_scheduler_type=t('lr_scheduler_type', 'cosine'), trainable=True)
+                                  lr_scheduler_type=t('lr_scheduler_type', 'cosine'), trainable=True,
+                                  gradient_accumulation_steps=gas)
         self.reference_model = NativeEngine(self.reference, trainable=False)
 
     def init_logger(self) -> None:

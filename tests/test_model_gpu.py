@@ -217,3 +217,30 @@ def test_native_bf16_loss_is_inside_the_references_own_bf16_envelope():
     dump('parity_bf16_envelope.txt', f'fp32 reference {fp32:.6f}\nreference arithmetic in bf16 {ref_bf16:.6f} (dev {abs(ref_bf16-fp32):.2e})\n'
                                      f'native MI355X {native:.6f} (dev {abs(native-fp32):.2e})\n')
     assert abs(native - fp32) <= abs(ref_bf16 - fp32) + 2e-3
+
+
+def test_gradient_accumulation_two_micro_batches_equal_one_batch():
+    """gradient_accumulation_steps=2 over two single-pair micro-batches == one step on the 2-pair batch (the
+    mean over pairs), up to bf16 accumulation of the matrix gradients (DeepSpeed engine semantics, dpo.py:212-213)."""
+    z = load_golden('opt_tiny_dpo.npz')
+    b = _batch(z, with_pixels=False)
+    full = _trainer(z, tiny_opt_cfg())
+    full.train_step(b)
+    acc = _trainer(z, tiny_opt_cfg(), gradient_accumulation_steps=2)
+    rows = {0: [0, 2], 1: [1, 3]}   # pair i = (chosen i, rejected i)
+    for i in (0, 1):
+        mb = {'input_ids': b['input_ids'][rows[i]], 'attention_mask': b['attention_mask'][rows[i]],
+              'meta_info': {'response_lens': [b['meta_info']['response_lens'][r] for r in rows[i]]}}
+        acc.train_step(mb)
+        if i == 0:
+            assert acc.model.global_steps == 0, 'no optimizer update before the accumulation boundary'
+    assert acc.model.global_steps == 1 and full.model.global_steps == 1
+    full.model.wait_optimizer(); acc.model.wait_optimizer()
+    torch.cuda.synchronize()
+    for g in full.policy.store.master:
+        a, f = acc.policy.store.master[g], full.policy.store.master[g]
+        # Adam's first step moves every weight by ~lr*sign(g) = 1e-3: a sign flip of a near-zero gradient
+        # component costs 2e-3, everything else must agree closely
+        assert (a - f).abs().max().item() <= 2.1e-3, (g, (a - f).abs().max().item())
+        agree = ((a - f).abs() < 1e-4).float().mean().item()
+        assert agree > 0.97, (g, agree)
