@@ -137,3 +137,44 @@ def test_cfg_get_reads_namedtuple_dict_and_missing():
     assert cfg_get(c, 'train_cfgs.scale_coeff') == 0.2
     assert cfg_get(c, 'train_cfgs.missing', 7) == 7
     assert cfg_get({'a': {'b': 3}}, 'a.b') == 3 and cfg_get({'a': None}, 'a.b', 1) == 1
+
+
+def test_dp_gradient_buckets_partition_the_flat_buffer():
+    """NativeEngine all-reduces one contiguous slice of the flat bf16 gradient buffer per decoder layer plus the
+    gaps (projector, lm_head): together they must cover every element exactly once."""
+    from align_anything_amd.engine import NativeEngine
+    from align_anything_amd.modeling import build_model
+    for cfg in (tiny_llava_cfg(), tiny_opt_cfg()):
+        m = build_model(cfg, 'cpu', trainable=True)
+        eng = NativeEngine(m, lr=1e-6)
+        n = m.store.gflat['mat'].numel()
+        slices = sorted(eng._layer_slices.values())
+        assert len(slices) == len(m.stack.layers)
+        hits = torch.zeros(n, dtype=torch.int32)
+        pos = 0
+        for lo, hi in slices:
+            assert lo >= pos, 'layer buckets overlap'
+            if lo > pos:
+                hits[pos:lo] += 1      # gap bucket issued after backward
+            hits[lo:hi] += 1
+            pos = hi
+        if pos < n:
+            hits[pos:] += 1
+        assert int(hits.min()) == 1 and int(hits.max()) == 1
+        # every matrix parameter of every layer lies inside its layer's bucket
+        for L, (lo, hi) in zip(m.stack.layers, [eng._layer_slices[id(L)] for L in m.stack.layers]):
+            for v in L.values():
+                if hasattr(v, 'wname'):
+                    s = m.store.specs[v.wname]
+                    assert s['group'] != 'mat' or (lo <= s['offset'] and s['offset'] + s['numel'] <= hi)
+
+
+def test_engine_lr_schedule_and_accumulation_bookkeeping():
+    from align_anything_amd.engine import NativeEngine
+    from align_anything_amd.modeling import build_model
+    m = build_model(tiny_opt_cfg(), 'cpu', trainable=True)
+    eng = NativeEngine(m, lr=1e-3, total_steps=10, warmup_steps=2, gradient_accumulation_steps=3)
+    assert eng.optimizer.param_groups[0]['lr'] == 0.0          # cosine with warm-up starts at 0
+    eng.micro_steps = 1
+    eng.step()                                                  # not at a boundary: no update, no kernel call
+    assert eng.global_steps == 0
