@@ -8,8 +8,9 @@ from __future__ import annotations
 
 
 def llama_cfg(hidden_size, intermediate_size, num_layers, num_heads, num_kv_heads, vocab_size,
-              rms_eps=1e-5, rope_theta=10000.0, head_dim=None, max_position_embeddings=4096):
+              rms_eps=1e-5, rope_theta=10000.0, head_dim=None, max_position_embeddings=4096, attention_bias=False):
     return {
+        'attention_bias': attention_bias,
         'kind': 'llama', 'hidden_size': hidden_size, 'intermediate_size': intermediate_size,
         'num_layers': num_layers, 'num_heads': num_heads, 'num_kv_heads': num_kv_heads,
         'head_dim': head_dim or hidden_size // num_heads, 'vocab_size': vocab_size, 'rms_eps': rms_eps,
@@ -69,7 +70,15 @@ def from_hf_config(c) -> dict:
         return llama_cfg(c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads,
                          c.num_key_value_heads, c.vocab_size, c.rms_norm_eps, theta,
                          getattr(c, 'head_dim', None), c.max_position_embeddings)
+    if mt == 'qwen2':   # Llama block + q/k/v biases (align_anything/models/qwen2.py -> hf Qwen2ForCausalLM)
+        rp = getattr(c, 'rope_parameters', None) or {}
+        theta = rp.get('rope_theta', getattr(c, 'rope_theta', 1000000.0))
+        if getattr(c, 'use_sliding_window', False):
+            raise ValueError('qwen2 with sliding-window attention has no native implementation yet')
+        return llama_cfg(c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads,
+                         c.num_key_value_heads, c.vocab_size, c.rms_norm_eps, theta, getattr(c, 'head_dim', None),
+                         c.max_position_embeddings, attention_bias=True)
     if mt == 'opt':
         return opt_cfg(c.hidden_size, c.ffn_dim, c.num_hidden_layers, c.num_attention_heads, c.vocab_size,
                        c.max_position_embeddings)
-    raise ValueError(f'model_type {mt!r} has no native MI355X implementation (llava, llama, opt are built)')
+    raise ValueError(f'model_type {mt!r} has no native MI355X implementation (llava, llama, qwen2, opt are built)')

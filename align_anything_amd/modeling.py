@@ -81,7 +81,15 @@ class LlamaStack:
             blk = store.add_fused(p + 'self_attn.qkv_fused', [(p + 'self_attn.q_proj.weight', H * hd, h),
                                                               (p + 'self_attn.k_proj.weight', Hkv * hd, h),
                                                               (p + 'self_attn.v_proj.weight', Hkv * hd, h)], trainable)
-            L['qkv'] = Linear(store, blk)
+            bq = None
+            if cfg.get('attention_bias'):   # Qwen2-style q/k/v biases (hf:models/qwen2/modeling_qwen2.py), fused [q|k|v]
+                bq = store.add(p + 'self_attn.qkv_fused.bias', ((H + 2 * Hkv) * hd,), trainable)
+                del store.alias[bq]
+                off = 0
+                for nm, rows in (('q', H * hd), ('k', Hkv * hd), ('v', Hkv * hd)):
+                    store.alias[p + f'self_attn.{nm}_proj.bias'] = (bq, off, (rows,))
+                    off += rows
+            L['qkv'] = Linear(store, blk, bq)
             L['o'] = Linear(store, store.add(p + 'self_attn.o_proj.weight', (h, H * hd), trainable))
             L['ln2'] = store.add(p + 'post_attention_layernorm.weight', (h,), trainable)
             blk = store.add_fused(p + 'mlp.gate_up_fused', [(p + 'mlp.gate_proj.weight', F, h),
@@ -136,7 +144,7 @@ class LlamaStack:
         rows = torch.arange(N, device=x.device)
         for li, L in enumerate(self.layers):
             n1, _ = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
-            qkv = ops.linear_small(n1, L['qkv'].w)
+            qkv = ops.linear_small(n1, L['qkv'].w, bias=L['qkv'].b)
             ops.rope_(qkv, 0, H + Hkv, hd, pos, self.cos, self.sin)
             cl = cache[li]
             cl.view(N, Tmax, 2 * kw).index_put_((rows, t), qkv[:, qw:])   # t: device int64 [N] (graph-capturable)

@@ -170,3 +170,48 @@ def test_full_ppo_iteration_rollout_then_update():
     info = tr.rl_step(inf, trn)
     assert all(v == v for v in info.values())
     assert abs(info['train/kl_divergence']) < 1e-4
+
+
+def test_qwen2_style_text_model_dpo_step_vs_oracle():
+    """Llama block with q/k/v biases and GQA (Qwen2 family, from_hf_config 'qwen2'): DPO loss and gradients
+    (incl. the fused bias gradient) against the oracle."""
+    from align_anything_amd import configs
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    cfg = configs.llama_cfg(128, 256, 2, 2, 1, 320, rms_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=128, attention_bias=True)
+    g = torch.Generator().manual_seed(9)
+    names = {'model.embed_tokens.weight': (320, 128), 'model.norm.weight': (128,), 'lm_head.weight': (320, 128)}
+    for i in range(2):
+        p = f'model.layers.{i}.'
+        names.update({p + 'input_layernorm.weight': (128,), p + 'post_attention_layernorm.weight': (128,),
+                      p + 'self_attn.q_proj.weight': (128, 128), p + 'self_attn.k_proj.weight': (64, 128),
+                      p + 'self_attn.v_proj.weight': (64, 128), p + 'self_attn.o_proj.weight': (128, 128),
+                      p + 'self_attn.q_proj.bias': (128,), p + 'self_attn.k_proj.bias': (64,), p + 'self_attn.v_proj.bias': (64,),
+                      p + 'mlp.gate_proj.weight': (256, 128), p + 'mlp.up_proj.weight': (256, 128), p + 'mlp.down_proj.weight': (128, 256)})
+    def init(k, s):
+        if k.endswith('norm.weight'):
+            return 1 + 0.1 * torch.randn(s, generator=g)
+        return torch.randn(s, generator=g) * (0.3 if k.endswith('bias') else 0.06)
+    sd = {k: init(k, s).to(torch.bfloat16) for k, s in names.items()}
+    sdr = {k: (v.float() + 0.02 * torch.randn(v.shape, generator=g)).to(torch.bfloat16) for k, v in sd.items()}
+    tr = DPOTrainer({'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant'},
+                     'model_cfgs': {'pad_token_id': 0}}, {'gradient_clipping': 1.0}, model_cfg=cfg, policy_state=sd, reference_state=sdr, device='cuda:0')
+    N, Tn = 4, 48
+    ids = torch.randint(3, 320, (N, Tn), generator=g); mask = torch.ones(N, Tn, dtype=torch.long)
+    for n, lp in enumerate((0, 7, 3, 0)):
+        ids[n, :lp] = 0; mask[n, :lp] = 0
+    lens = [9, 12, 5, 16]
+    batch = {'input_ids': ids.to(dev()), 'attention_mask': mask.to(dev()), 'meta_info': {'response_lens': lens}}
+    ld = tr.loss(batch)
+    f = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    fr = {k: v.float() for k, v in sdr.items()}
+    lp = orl.compute_log_probs(om.llama_logits(f, cfg, ids, mask), ids, lens, 0)
+    with torch.no_grad():
+        rlp = orl.compute_log_probs(om.llama_logits(fr, cfg, ids, mask), ids, lens, 0)
+    o = orl.dpo_loss(lp, rlp, 0.1)
+    assert abs(float(ld['loss']) - float(o['loss'])) < 1e-2
+    tr.model.backward(ld['loss']); torch.cuda.synchronize()
+    o['loss'].backward()
+    for n in ('model.layers.0.self_attn.q_proj.bias', 'model.layers.1.self_attn.v_proj.bias', 'model.layers.1.self_attn.k_proj.weight',
+              'model.layers.0.mlp.up_proj.weight', 'lm_head.weight'):
+        got = tr.policy.store.grad_view(n).float().cpu().reshape(f[n].grad.shape)
+        assert rel_err(got, f[n].grad) < 8e-2, (n, rel_err(got, f[n].grad))
