@@ -485,3 +485,96 @@ extern "C" int aa_rm_loss_fwd_bwd(const float* end_scores, int B, float regulari
     AA_CHECK_LAUNCH("aa_rm_loss_fwd_bwd");
     return AA_OK;
 }
+
+// ------------------------------------------------------------------ GRPO (trainers/text_to_text/grpo.py:257-329)
+// group-normalised advantage: rewards [B, G] -> (r - mean_g) / (std_g + 1e-4), std unbiased (torch.std, grpo.py:272-276)
+__global__ __launch_bounds__(64) void group_advantage_kernel(const float* __restrict__ rewards, int G,
+                                                             float* __restrict__ adv) {
+    const int b = blockIdx.x, l = threadIdx.x;
+    float s = 0.f;
+    for (int i = l; i < G; i += 64) s += rewards[b * G + i];
+    const float mean = wave_sum(s) / (float)G;
+    float ss = 0.f;
+    for (int i = l; i < G; i += 64) { const float d = rewards[b * G + i] - mean; ss += d * d; }
+    const float sd = sqrtf(wave_sum(ss) / (float)(G - 1)) + 1e-4f;
+    for (int i = l; i < G; i += 64) adv[b * G + i] = (rewards[b * G + i] - mean) / sd;
+}
+extern "C" int aa_group_advantage(const float* rewards, int B, int G, float* adv, void* stream) {
+    AA_REQUIRE(B > 0 && G > 1, "aa_group_advantage: need B > 0 and G > 1 (got B=%d G=%d)", B, G);
+    hipLaunchKernelGGL(group_advantage_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, rewards, G, adv);
+    AA_CHECK_LAUNCH("aa_group_advantage");
+    return AA_OK;
+}
+
+// completion mask: 1 up to and including the first eos of each row, 0 after (grpo.py:305-313)
+__global__ __launch_bounds__(64) void completion_mask_kernel(const int64_t* __restrict__ tok, long ld, int L,
+                                                             int64_t eos, uint8_t* __restrict__ mask) {
+    const int r = blockIdx.x, l = threadIdx.x;
+    int first = L;  // no eos -> everything counts
+    for (int j = l; j < L; j += 64) if (tok[(long)r * ld + j] == eos) first = min(first, j);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+    for (int j = l; j < L; j += 64) mask[(long)r * L + j] = (j <= first) ? 1 : 0;
+}
+extern "C" int aa_completion_mask(const int64_t* tokens, long ld, int rows, int L, int64_t eos, uint8_t* mask,
+                                  void* stream) {
+    AA_REQUIRE(rows > 0 && L > 0 && ld >= L, "aa_completion_mask: bad shape rows=%d L=%d", rows, L);
+    hipLaunchKernelGGL(completion_mask_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, tokens, ld, L, eos, mask);
+    AA_CHECK_LAUNCH("aa_completion_mask");
+    return AA_OK;
+}
+
+// loss = sum(mask * -(A - beta*KL)) / sum(mask), KL = exp(ref-logp) - (ref-logp) - 1   (value of
+// exp(logp - stopgrad(logp)) is 1; its gradient carries A).  d loss/d logp = mask*(-A + beta*(1 - exp(ref-logp)))/sum(mask)
+__global__ __launch_bounds__(64) void grpo_rows_kernel(const float* __restrict__ logp, const float* __restrict__ ref,
+                                                       const float* __restrict__ adv, const uint8_t* __restrict__ mask,
+                                                       int L, float beta, float* __restrict__ row_num,
+                                                       float* __restrict__ row_cnt) {
+    const int r = blockIdx.x, l = threadIdx.x;
+    float num = 0.f, cnt = 0.f;
+    const float a = adv[r];
+    for (int j = l; j < L; j += 64) {
+        const long i = (long)r * L + j;
+        const float mk = mask[i] ? 1.f : 0.f;
+        const float d = ref[i] - logp[i];
+        num += mk * (-(a - beta * (expf(d) - d - 1.f)));
+        cnt += mk;
+    }
+    num = wave_sum(num); cnt = wave_sum(cnt);
+    if (l == 0) { row_num[r] = num; row_cnt[r] = cnt; }
+}
+__global__ __launch_bounds__(256) void grpo_finish_kernel(const float* __restrict__ logp, const float* __restrict__ ref,
+                                                          const float* __restrict__ adv, const uint8_t* __restrict__ mask,
+                                                          int rows, int L, float beta, const float* __restrict__ row_num,
+                                                          const float* __restrict__ row_cnt, float* __restrict__ loss,
+                                                          float* __restrict__ dlogp) {
+    __shared__ float red[8];
+    float n = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 256) { n += row_num[i]; c += row_cnt[i]; }
+    n = block_sum<256>(n, red);
+    c = block_sum<256>(c, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) loss[0] = n / c;
+    if (dlogp) {
+        const float inv = 1.f / c;
+        const long total = (long)rows * L;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const float mk = mask[i] ? 1.f : 0.f;
+            const float a = adv[i / L];
+            dlogp[i] = mk * (-a + beta * (1.f - expf(ref[i] - logp[i]))) * inv;
+        }
+    }
+}
+extern "C" int aa_grpo_loss_fwd_bwd(const float* logp, const float* ref_logp, const float* adv, const uint8_t* mask,
+                                    int rows, int L, float beta, float* row_scratch2, float* loss_out, float* dlogp,
+                                    void* stream) {
+    AA_REQUIRE(rows > 0 && L > 0, "aa_grpo_loss_fwd_bwd: bad shape rows=%d L=%d", rows, L);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(grpo_rows_kernel, dim3(rows), dim3(64), 0, st, logp, ref_logp, adv, mask, L, beta, row_scratch2,
+                       row_scratch2 + rows);
+    const long total = (long)rows * L;
+    const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(grpo_finish_kernel, dim3(grid), dim3(256), 0, st, logp, ref_logp, adv, mask, rows, L, beta,
+                       row_scratch2, row_scratch2 + rows, loss_out, dlogp);
+    AA_CHECK_LAUNCH("aa_grpo_loss_fwd_bwd");
+    return AA_OK;
+}

@@ -383,6 +383,29 @@ def ppo_critic_loss(values, old_values, returns, mask_u8, clip_value, want_grad=
     return loss, d
 
 
+def group_advantage(rewards, B, G):
+    adv = torch.empty_like(rewards)
+    call('aa_group_advantage', rewards.data_ptr(), int(B), int(G), adv.data_ptr(), stream())
+    return adv
+
+
+def completion_mask(tokens, eos):
+    rows, L = tokens.shape
+    mask = torch.empty((rows, L), dtype=torch.uint8, device=tokens.device)
+    call('aa_completion_mask', tokens.data_ptr(), tokens.stride(0), rows, L, int(eos), mask.data_ptr(), stream())
+    return mask
+
+
+def grpo_loss(logp, ref_logp, adv, mask_u8, beta, want_grad=True):
+    rows, L = logp.shape
+    scratch = torch.empty(2 * rows, dtype=torch.float32, device=logp.device)
+    loss = torch.empty(1, dtype=torch.float32, device=logp.device)
+    d = torch.empty_like(logp) if want_grad else None
+    call('aa_grpo_loss_fwd_bwd', logp.data_ptr(), ref_logp.data_ptr(), adv.data_ptr(), mask_u8.data_ptr(), rows, L,
+         float(beta), scratch.data_ptr(), loss.data_ptr(), _p(d), stream())
+    return loss, d
+
+
 # ------------------------------------------------------------------ optimizer
 def grad_sumsq_(g, out_accum, scale=1.0):
     dt = 0 if g.dtype == bf16 else 1

@@ -1,0 +1,118 @@
+"""Native GRPO step: align_anything/trainers/text_to_text/grpo.py::GRPOTrainer (train_step :257-329) on the MI355X engines.
+
+Per step: G sampled completions per prompt (`generate_completions` :212-227), a reward per completion from a score
+model on the completion truncated after its first EOS (`compute_rewards` :229-255), group-normalised advantages,
+per-token log-probs of actor and reference on the completion window (`_get_per_token_logps` :199-210), the k3-KL
+regularised loss (:291-316), backward and optimizer step.  All tensor math runs in the HIP kernels of rl_math.hip
+(`aa_group_advantage`, `aa_completion_mask`, `aa_grpo_loss_fwd_bwd`); there is no torch fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from ..engine import NativeEngine
+from ..modeling import build_model
+from .common import build_span_window, cfg_get, get_all_reduce_mean, pad_rows
+
+
+class GRPOTrainer:
+    """Three engines as in grpo.py:153-196: trainable actor, frozen actor reference, frozen reward (score) model.
+    The reference re-tokenises completions for the reward model (`batch_retokenize`); here actor and reward model
+    share one tokenizer, so the masked completion ids are scored directly (`reward_fn` overrides that)."""
+
+    def __init__(self, cfgs, ds_cfgs=None, *, model_cfg, reward_model_cfg=None, actor_state=None, reference_state=None,
+                 reward_state=None, reward_fn=None, device='cuda:0'):
+        t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
+        self.cfgs, self.device = cfgs, torch.device(device)
+        self.beta = float(t('beta', 0.04))                       # grpo.py:67 default
+        self.num_generations = int(t('num_generations', 4))      # grpo.py:66
+        self.pad_token_id = int(cfg_get(cfgs, 'model_cfgs.pad_token_id', 0))
+        self.eos_token_id = int(cfg_get(cfgs, 'model_cfgs.eos_token_id', 2))
+        self.reward_fn = reward_fn
+        actor = build_model(model_cfg, device, trainable=True)
+        ref = build_model(model_cfg, device, trainable=False)
+        if actor_state is not None:
+            actor.load_state_dict(actor_state)
+        if reference_state is not None or actor_state is not None:
+            ref.load_state_dict(reference_state if reference_state is not None else actor_state)
+        total = int(t('total_training_steps', 1))
+        self.actor_model = NativeEngine(
+            actor, lr=float(t('actor_lr', 1e-6)), betas=[float(b) for b in t('adam_betas', [0.9, 0.95])],
+            weight_decay=float(t('actor_weight_decay', 0.01)), max_grad_norm=float(cfg_get(ds_cfgs, 'gradient_clipping', 1.0)),
+            total_steps=total, warmup_steps=int(float(t('actor_lr_warmup_ratio', 0.03)) * total),
+            lr_scheduler_type=t('actor_lr_scheduler_type', 'cosine'))
+        self.actor_reference_model = NativeEngine(ref, trainable=False)
+        self.reward_model = None
+        if reward_fn is None:
+            reward = build_model(reward_model_cfg or model_cfg, device, trainable=False, head='score')
+            if reward_state is not None:
+                reward.load_state_dict(reward_state)
+            self.reward_model = NativeEngine(reward, trainable=False)
+
+    # ------------------------------------------------------------------ grpo.py:212-227
+    def generate_completions(self, prompt_batch, generator=None):
+        """`generate(num_return_sequences=G, do_sample=True)`: row b*G+g is sample g of prompt b (HF expands the
+        batch with repeat_interleave before sampling)."""
+        from ..generation import generate
+        m = lambda k, d: cfg_get(self.cfgs, 'model_cfgs.' + k, d)
+        G = self.num_generations
+        self.actor_model.wait_optimizer()
+        return generate(self.actor_model.module, prompt_batch['input_ids'].repeat_interleave(G, 0),
+                        prompt_batch['attention_mask'].repeat_interleave(G, 0), max_length=int(m('model_max_length', 2048)),
+                        do_sample=True, temperature=float(m('temperature', 1.0)), top_p=float(m('top_p', 1.0)),
+                        repetition_penalty=float(m('repetition_penalty', 1.0)), eos_token_id=self.eos_token_id,
+                        pad_token_id=self.pad_token_id, generator=generator)
+
+    # ------------------------------------------------------------------ grpo.py:229-255
+    def compute_rewards(self, sequences, prompt_length):
+        completions = sequences[:, prompt_length:]
+        keep = ops.completion_mask(completions, self.eos_token_id)
+        if self.reward_fn is not None:
+            return self.reward_fn(completions * keep.to(completions.dtype)).to(torch.float32)
+        # same-tokenizer form of batch_retokenize(skip_special_tokens=True): the kept tokens are the reward model's
+        # input, everything after the first EOS is padding
+        ids = torch.where(keep.bool(), completions, torch.full_like(completions, self.pad_token_id))
+        am = keep.to(torch.int64)
+        T = ids.shape[1]
+        scores = self.reward_model.module.scores(ids, am)
+        end = (am * torch.arange(T, device=ids.device)[None]).argmax(dim=1)
+        return scores[torch.arange(ids.shape[0], device=ids.device), end].float()
+
+    # ------------------------------------------------------------------ grpo.py:199-210
+    def _get_per_token_logps(self, engine, input_ids, attention_mask, logits_to_keep, save=False):
+        """log_softmax(logits[:, :-1][:, -K:]).gather(input_ids[:, -K:]) -> fp32 [N, K]: hidden position j in
+        [T-1-K, T-2] predicts token j+1.  Only those N*K rows go through the lm_head."""
+        w = build_span_window(input_ids, input_ids.shape[1] - 1 - logits_to_keep)
+        if hasattr(engine, 'wait_optimizer'):
+            engine.wait_optimizer()
+        lp = engine.module.response_logprobs(input_ids, attention_mask, w, save=save)
+        return lp[:w['rows']].view(w['N'], w['W']), w
+
+    # ------------------------------------------------------------------ grpo.py:257-329
+    def train_step(self, prompt_batch, generator=None, sequences=None, rewards=None):
+        """`sequences` / `rewards` may be injected (tests, external samplers or rule-based rewards); otherwise they come
+        from `generate_completions` / `compute_rewards` as in the reference."""
+        prompt_batch = {k: v.to(self.device) for k, v in prompt_batch.items()}
+        P = prompt_batch['input_ids'].size(1)
+        B, G = prompt_batch['input_ids'].size(0), self.num_generations
+        if sequences is None:
+            sequences = self.generate_completions(prompt_batch, generator)
+        sequences = sequences.to(self.device).contiguous()
+        if rewards is None:
+            rewards = self.compute_rewards(sequences, P)
+        rewards = rewards.to(self.device, torch.float32).contiguous()
+        advantages = ops.group_advantage(rewards, B, G)
+
+        attention_mask = (sequences != self.pad_token_id).long()
+        K = sequences.size(1) - P
+        ref_logps, _ = self._get_per_token_logps(self.actor_reference_model, sequences, attention_mask, K)
+        logps, w = self._get_per_token_logps(self.actor_model, sequences, attention_mask, K, save=True)
+        cmask = ops.completion_mask(sequences[:, P:], self.eos_token_id)
+        loss, dlogp = ops.grpo_loss(logps.contiguous(), ref_logps.contiguous(), advantages, cmask, self.beta)
+
+        self.actor_model.set_pending(pad_rows(dlogp, w['rows_pad']))
+        self.actor_model.backward(loss)
+        self.actor_model.step()
+        s = get_all_reduce_mean(torch.stack([loss.reshape(()), rewards.mean()])).tolist()
+        return {'train/loss': s[0], 'train/reward': s[1]}

@@ -82,6 +82,14 @@ int aa_ppo_critic_loss(const float* values, const float* old_values, const float
                        const uint8_t* mask, int B, int L, float clip_value, float* row_scratch,
                        float* loss_out, float* dvalues, void* stream);
 
+/* trainers/text_to_text/grpo.py:257-329: group-normalised advantage (unbiased std + 1e-4), first-EOS completion
+ * mask, and the masked GRPO loss  sum(mask * -(A - beta * k3KL)) / sum(mask)  with its gradient w.r.t. logp.
+ * row_scratch2 = fp32 [2 * rows]. */
+int aa_group_advantage(const float* rewards, int B, int G, float* adv, void* stream);
+int aa_completion_mask(const int64_t* tokens, long ld, int rows, int L, int64_t eos, uint8_t* mask, void* stream);
+int aa_grpo_loss_fwd_bwd(const float* logp, const float* ref_logp, const float* adv, const uint8_t* mask, int rows,
+                         int L, float beta, float* row_scratch2, float* loss_out, float* dlogp, void* stream);
+
 /* ---- transformer blocks (what model(**batch).logits executes, dpo.py:128) -------------------- */
 /* torch nn.Linear / its backward: C[M,N] (+)= op(A) op(B), fp32 accumulate, fused bias/act/residual.
  * K % 64 == 0 (zero-pad), N % 4 == 0. */

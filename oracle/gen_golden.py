@@ -224,9 +224,75 @@ def gen_opt_dpo():
     print('opt_tiny_dpo.npz loss', float(ld['loss']))
 
 
+def gen_grpo():
+    """Drive the reference's unmodified GRPOTrainer.train_step (trainers/text_to_text/grpo.py:257-329) with a fake
+    engine around a tiny HF OPT model, fixed 'generated' sequences and fixed rewards; record loss and gradients."""
+    from transformers import OPTConfig, OPTForCausalLM
+    from align_anything.trainers.text_to_text.grpo import GRPOTrainer
+    import align_anything.trainers.text_to_text.grpo as grpo_mod
+    grpo_mod.get_all_reduce_mean = lambda x: x     # no process group in this script
+
+    oc = OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=320,
+                   max_position_embeddings=128, word_embed_proj_dim=128, dropout=0.0, attention_dropout=0.0, pad_token_id=1)
+    torch.manual_seed(5)
+    actor = OPTForCausalLM(oc).eval()
+    torch.manual_seed(5)
+    ref = OPTForCausalLM(oc).eval()
+    g = torch.Generator().manual_seed(13)
+    with torch.no_grad():
+        for p in actor.parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+            p.copy_(p.to(torch.bfloat16).to(torch.float32))
+        actor.model.decoder.embed_tokens.weight[1].zero_()
+        for p, q in zip(ref.parameters(), actor.parameters()):
+            p.copy_((q + 0.03 * torch.randn(q.shape, generator=g)).to(torch.bfloat16).to(torch.float32))
+
+    class Engine:   # the DeepSpeedEngine calls train_step makes
+        def __init__(self, m): self.module = m
+        def __call__(self, **kw): return self.module(**kw)
+        def train(self): pass
+        def eval(self): pass
+        def zero_grad(self): self.module.zero_grad()
+        def backward(self, loss): loss.backward()
+        def step(self): pass
+
+    B, G, P, L, EOS, PAD = 2, 3, 10, 14, 2, 1
+    prompts = torch.randint(3, 320, (B, P), generator=g)
+    seqs = torch.cat([prompts.repeat_interleave(G, 0), torch.randint(3, 320, (B * G, L), generator=g)], 1)
+    seqs[1, P + 4] = EOS; seqs[1, P + 5:] = PAD          # finished early -> padded
+    seqs[4, P + L - 1] = EOS
+    seqs[3, P + 2] = EOS; seqs[3, P + 3:] = PAD
+    rewards = torch.randn(B * G, generator=g) * 2
+    tr = GRPOTrainer.__new__(GRPOTrainer)
+    tr.actor_model, tr.actor_reference_model = Engine(actor), Engine(ref)
+    tr.tokenizer = SimpleNamespace(pad_token_id=PAD, eos_token_id=EOS)
+    tr.beta, tr.num_generations = 0.04, G
+    tr.generate_completions = lambda pb: seqs
+    tr.compute_rewards = lambda s, pl: rewards
+    out = tr.train_step({'input_ids': prompts, 'attention_mask': torch.ones_like(prompts)})
+    res = {'prompts': prompts.numpy(), 'sequences': seqs.numpy(), 'rewards': rewards.numpy(), 'B': np.array(B), 'G': np.array(G),
+           'eos': np.array(EOS), 'pad': np.array(PAD), 'beta': np.array(0.04), 'loss': np.array(out['train/loss']),
+           'reward_mean': np.array(out['train/reward'])}
+    with torch.no_grad():
+        am = (seqs != PAD).long()
+        res['per_token_logps'] = tr._get_per_token_logps(tr.actor_model, seqs, am, L).numpy()
+        res['ref_per_token_logps'] = tr._get_per_token_logps(tr.actor_reference_model, seqs, am, L).numpy()
+    for n, p in actor.state_dict().items():
+        res['w.' + n] = bf16_bits(p)
+    for n, p in ref.state_dict().items():
+        res['r.' + n] = bf16_bits(p)
+    for n, p in actor.named_parameters():
+        if p.grad is not None and (n.endswith('fc1.weight') or n.endswith('q_proj.weight') or 'final_layer_norm' in n or n.endswith('fc2.bias')):
+            res['g.' + n] = p.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'grpo_tiny.npz'), **res)
+    print('grpo_tiny.npz loss', out['train/loss'], 'reward', out['train/reward'])
+
+
 if __name__ == '__main__':
     _shim.install()
     os.makedirs(GOLD, exist_ok=True)
     gen_rl_math()
     gen_llava_dpo()
     gen_opt_dpo()
+    gen_grpo()

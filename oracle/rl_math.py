@@ -133,3 +133,20 @@ def clip_coef(grads, max_norm: float):
     """configs/deepspeed/ds_z3_config.json:21 gradient_clipping (global L2), torch clip_grad_norm_ form."""
     total = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
     return torch.clamp(max_norm / (total + 1e-6), max=1.0), total
+
+
+def grpo_loss(per_token_logps, ref_per_token_logps, rewards, B, G, completion_tokens, eos_token_id, beta):
+    """trainers/text_to_text/grpo.py:270-316: group-normalised advantages (torch.std is unbiased), per-token k3 KL,
+    loss = -(exp(logp - logp.detach()) * A - beta * KL), masked mean over tokens up to and including the first EOS."""
+    r = rewards.view(B, G)
+    adv = ((r - r.mean(dim=1, keepdim=True)) / (r.std(dim=1, keepdim=True) + 1e-4)).view(-1, 1)
+    kl = torch.exp(ref_per_token_logps - per_token_logps) - (ref_per_token_logps - per_token_logps) - 1
+    L = per_token_logps.size(1)
+    per_token_loss = -(torch.exp(per_token_logps - per_token_logps.detach()) * adv.expand(-1, L) - beta * kl)
+    mask = torch.ones_like(completion_tokens)
+    for i in range(completion_tokens.size(0)):
+        pos = (completion_tokens[i] == eos_token_id).nonzero(as_tuple=False)
+        if pos.numel() > 0:
+            mask[i, pos[0].item() + 1:] = 0
+    mask = mask.to(per_token_loss.dtype)
+    return (per_token_loss * mask).sum() / mask.sum(), adv.view(-1), mask

@@ -5,7 +5,7 @@ import torch
 
 from oracle import models as om
 from oracle import rl_math as orl
-from tests.util import bits_to_bf16, load_golden, state_dict_from_golden, tiny_llava_cfg, tiny_opt_cfg
+from tests.util import bits_to_bf16, load_golden, rel_err, state_dict_from_golden, tiny_llava_cfg, tiny_opt_cfg
 
 T = torch.from_numpy
 
@@ -123,3 +123,31 @@ def test_adamw_restatement_matches_torch_adamw():
         pt.grad = gs.clone(); opt.step()
         orl.adamw_step(q, gs, m, v, step, 1e-3, 0.9, 0.95, 1e-8, 0.05)
     assert torch.allclose(q, pt.detach(), atol=1e-6)
+
+
+def test_grpo_oracle_matches_reference_train_step():
+    """oracle/rl_math.py::grpo_loss + oracle OPT model vs the loss / reward / grads the reference's unmodified
+    GRPOTrainer.train_step produced (tests/golden/grpo_tiny.npz, oracle/gen_golden.py::gen_grpo)."""
+    z = load_golden('grpo_tiny.npz')
+    cfg = tiny_opt_cfg()
+    seqs, rewards = T(z['sequences']), T(z['rewards'])
+    B, G, P = int(z['B']), int(z['G']), z['prompts'].shape[1]
+    K = seqs.shape[1] - P
+    am = (seqs != int(z['pad'])).long()
+    sd = {k: v.clone().requires_grad_(True) for k, v in state_dict_from_golden(z, 'w.').items() if k != 'lm_head.weight'}
+    rsd = state_dict_from_golden(z, 'r.')
+    lp = orl.gather_log_probabilities(om.opt_logits(sd, cfg, seqs, am)[:, :-1][:, -K:], seqs[:, -K:])
+    with torch.no_grad():
+        rlp = orl.gather_log_probabilities(om.opt_logits(rsd, cfg, seqs, am)[:, :-1][:, -K:], seqs[:, -K:])
+    np.testing.assert_allclose(lp.detach().numpy(), z['per_token_logps'], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(rlp.numpy(), z['ref_per_token_logps'], rtol=2e-4, atol=2e-4)
+    loss, adv, mask = orl.grpo_loss(lp, rlp, rewards, B, G, seqs[:, P:], int(z['eos']), float(z['beta']))
+    assert abs(loss.item() - float(z['loss'])) < 2e-5
+    assert abs(rewards.mean().item() - float(z['reward_mean'])) < 1e-6
+    assert mask.sum().item() < mask.numel()          # the fixture has rows cut at an early EOS
+    loss.backward()
+    for k in z.files:
+        if k.startswith('g.'):
+            n = k[2:]
+            if n in sd:
+                assert rel_err(sd[n].grad, T(z[k])) < 2e-3, n
