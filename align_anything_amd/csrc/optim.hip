@@ -6,11 +6,13 @@
 // instead of a multi-tensor pointer table.
 #include "aa_common.h"
 
-// sum of squares of a flat gradient buffer -> atomically accumulated into *out (fp32).
+// sum of squares of a flat gradient buffer, accumulated into *out (fp32).  DETERMINISTIC: every block writes one
+// partial into ws[blockIdx.x], a single-block kernel adds them in a fixed tree -- no float atomics, so the clip
+// coefficient (and with it every weight) is bit-identical on all data-parallel ranks and from run to run.
 // scale is applied before squaring (e.g. 1/world after a SUM all-reduce).
 template <typename TG>
 __global__ __launch_bounds__(256) void sumsq_kernel(const TG* __restrict__ g, long n, float scale,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ ws) {
     __shared__ float red[8];
     float acc = 0.f;
     if constexpr (sizeof(TG) == 2) {
@@ -35,21 +37,32 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const TG* __restrict__ g, lo
         }
     }
     acc = block_sum<256>(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, acc);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ ws, int nparts,
+                                                           float* __restrict__ out) {
+    __shared__ float red[8];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += ws[i];
+    acc = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) *out += acc;
 }
 
 extern "C" int aa_grad_sumsq(const void* g, int g_dtype, long n, float scale, float* out_accum,
-                             void* stream) {
+                             float* ws, void* stream) {
     AA_REQUIRE(g_dtype == 0 || g_dtype == 1, "aa_grad_sumsq: dtype must be 0 (bf16) or 1 (f32)");
+    AA_REQUIRE(ws != nullptr, "aa_grad_sumsq: ws (AA_SUMSQ_WS floats of scratch) is required");
     if (n == 0) return AA_OK;
     const long work = n / 8 / 256 + 1;
     const int grid = (int)(work < 2048 ? work : 2048);
     if (g_dtype == 0)
         hipLaunchKernelGGL(sumsq_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)g, n, scale, out_accum);
+                           (const bf16_t*)g, n, scale, ws);
     else
         hipLaunchKernelGGL(sumsq_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)g, n, scale, out_accum);
+                           (const float*)g, n, scale, ws);
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, grid, out_accum);
     AA_CHECK_LAUNCH("aa_grad_sumsq");
     return AA_OK;
 }

@@ -96,6 +96,7 @@ class NativeEngine:
             self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
             self._coef = torch.ones(1, dtype=torch.float32, device=dev)
             self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._sumsq_ws = torch.empty(ops.SUMSQ_WS, dtype=torch.float32, device=dev)
             self._layer_slices = self._compute_layer_slices()
 
     # ---- DeepSpeedEngine-shaped conveniences
@@ -205,7 +206,7 @@ class NativeEngine:
             self._sumsq.zero_()
             groups = st.trainable_groups()
             for g in groups:
-                ops.grad_sumsq_(st.gflat[g], self._sumsq, gscale)
+                ops.grad_sumsq_(st.gflat[g], self._sumsq, gscale, self._sumsq_ws)
             ops.clip_coef(self._sumsq, self.max_grad_norm if self.max_grad_norm else 0.0, self._coef, self._gnorm)
             for g in groups:
                 wd = 0.0 if g == 'vec' else self.weight_decay

@@ -407,9 +407,14 @@ def grpo_loss(logp, ref_logp, adv, mask_u8, beta, want_grad=True):
 
 
 # ------------------------------------------------------------------ optimizer
-def grad_sumsq_(g, out_accum, scale=1.0):
+SUMSQ_WS = 2048   # AA_SUMSQ_WS
+
+
+def grad_sumsq_(g, out_accum, scale=1.0, ws=None):
     dt = 0 if g.dtype == bf16 else 1
-    call('aa_grad_sumsq', g.data_ptr(), dt, g.numel(), float(scale), out_accum.data_ptr(), stream())
+    if ws is None:
+        ws = torch.empty(SUMSQ_WS, dtype=torch.float32, device=g.device)
+    call('aa_grad_sumsq', g.data_ptr(), dt, g.numel(), float(scale), out_accum.data_ptr(), ws.data_ptr(), stream())
 
 
 def clip_coef(sumsq, max_norm, coef_out, norm_out=None):

@@ -132,11 +132,20 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    # AA_BENCH_ONE_DEVICE=1 (+ AA_BENCH_BACKEND=gloo) is a FUNCTIONAL check of the N>1 code path on a 1-GPU box:
+    # all ranks share cuda:0 and the collectives go through gloo.  Never a performance number.
+    one_device = os.environ.get('AA_BENCH_ONE_DEVICE') == '1'
+    backend = os.environ.get('AA_BENCH_BACKEND', 'nccl')
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)      # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from align_anything_amd import configs, ops
     from align_anything_amd.trainers.dpo import DPOTrainer
@@ -197,7 +206,8 @@ def main():
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: LLaVA-1.5-7B DPO, bf16, 336px/576 patches, seq_len={T}, response={R}, '
-                                   f'{B} pairs/GPU/step, policy+ref fwd, bwd, clip, AdamW' + ('' if args.layers == 32 else f' [REDUCED DEPTH {args.layers}]'),
+                                   f'{B} pairs/GPU/step, policy+ref fwd, bwd, clip, AdamW' + ('' if args.layers == 32 else f' [REDUCED DEPTH {args.layers}]')
+                                   + (' [FUNCTIONAL CHECK: ranks share one device, gloo]' if one_device or backend != 'nccl' else ''),
                        'global_batch_pairs': B * world, 'seq_len': T, 'parallelism': f'dp{world}',
                        'trainable_params': tr.policy.store.num_trainable(), 'losses_timed_steps': losses},
             'step_mfma': {'algorithmic_tflop_per_pair': fl_pair / 1e12, 'achieved_tflops_per_gpu': step_tflops,

@@ -164,7 +164,10 @@ int aa_sample_top_p(const void* logits, long ld, int rows, int V, float temperat
                     const float* uniform, int64_t* out, void* stream);
 
 /* ---- optimizer (DeepSpeed FusedAdam + gradient_clipping, supervised_trainer.py:245-249) ------ */
-int aa_grad_sumsq(const void* g, int g_dtype, long n, float scale, float* out_accum, void* stream);
+/* *out_accum += sum((g*scale)^2); deterministic (no float atomics): ws = caller-owned scratch of AA_SUMSQ_WS floats, so the
+   clip coefficient is bit-identical on every data-parallel rank */
+#define AA_SUMSQ_WS 2048
+int aa_grad_sumsq(const void* g, int g_dtype, long n, float scale, float* out_accum, float* ws, void* stream);
 int aa_clip_coef(const float* sumsq, float max_norm, float* coef_out, float* norm_out, void* stream);
 int aa_adamw_flat(float* master, float* m, float* v, void* p16, const void* g, int g_dtype, long n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,

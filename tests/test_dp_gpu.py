@@ -1,0 +1,39 @@
+"""GPU: data-parallel step equivalence on hardware.  Two ranks (one pair each; both on cuda:0 with gloo collectives,
+since the test box has one GPU) must produce the same update as ONE rank stepping on the 2-pair batch: the DP mean of
+per-rank gradients == the batch-mean gradient (DeepSpeed engine semantics, trainers/text_to_text/dpo.py:205-237),
+and the logged loss is the all-reduce mean (utils/multi_process.py:74-89)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests.test_model_gpu import _batch, _trainer
+from tests.util import ROOT, load_golden, tiny_opt_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_rank_dp_step_equals_single_rank_full_batch(tmp_path):
+    out = str(tmp_path / 'dp2.pt')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'tests', 'dp_worker.py'), out]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        from tests.gpu_util import dump
+        dump('dp_worker_failure.log', r.stdout + '\n' + r.stderr)
+    assert r.returncode == 0, r.stderr[-3000:]
+    dp = torch.load(out)
+    z = load_golden('opt_tiny_dpo.npz')
+    full = _trainer(z, tiny_opt_cfg())
+    info = full.train_step(_batch(z, with_pixels=False))
+    full.model.wait_optimizer()
+    torch.cuda.synchronize()
+    assert abs(dp['info']['train/loss'] - info['train/loss']) < 2e-3, (dp['info']['train/loss'], info['train/loss'])
+    for g, f in full.policy.store.master.items():
+        a, f = dp['master'][g], f.cpu()
+        # Adam's first step moves every weight by ~lr = 1e-3; a sign flip of a near-zero gradient component costs 2e-3
+        assert (a - f).abs().max().item() <= 2.1e-3, (g, (a - f).abs().max().item())
+        assert ((a - f).abs() < 1e-4).float().mean().item() > 0.97, g
