@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libaa_hip.so')
-SOURCES = ['runtime.hip', 'rl_math.hip', 'elementwise.hip', 'optim.hip', 'gemm.hip', 'gemm32.hip', 'gemm_ring.hip', 'attention.hip', 'decode.hip']
+SOURCES = ['runtime.hip', 'rl_math.hip', 'elementwise.hip', 'elementwise_f32.hip', 'optim.hip', 'gemm.hip', 'gemm32.hip', 'gemm_ring.hip', 'attention.hip', 'decode.hip',
+           'gemm_f32.hip', 'attention_f32.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wno-unused-result']
 
@@ -27,6 +28,8 @@ def _compile(src: str) -> str:
     s = os.path.join(CSRC, src)
     o = os.path.join(OBJ, src.replace('.hip', '.o'))
     hdrs = [os.path.join(CSRC, h) for h in ('aa_common.h', 'gemm_params.h')]
+    if src.endswith('_f32.hip') and os.path.exists(os.path.join(CSRC, src.replace('_f32.hip', '.hip'))):
+        hdrs.append(os.path.join(CSRC, src.replace('_f32.hip', '.hip')))   # twin instantiation includes the bf16 source
     if _newer(s, o) or any(_newer(h, o) for h in hdrs if os.path.exists(h)):
         cmd = [HIPCC, *FLAGS, '-c', s, '-o', o]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -28,6 +28,34 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 // round a float through bf16 (emulates a bf16 intermediate of the HF graph)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
+// ---------------------------------------------------------------- element type of the block kernels
+// elementwise.hip is written against elem_t / ev8 / ev4 / e2f / f2e / ernd and compiled twice: as is (bf16
+// activations, HF rounding points kept: the production path) and through elementwise_f32.hip with AA_ELEM_F32
+// (fp32 activations, rounding points vanish: the fp32 parity mode that tracks the reference's fp32 CPU trainer).
+// AA_FN() appends _f32 to the C-ABI names of the second instantiation.
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+#ifdef AA_ELEM_F32
+typedef float elem_t;
+typedef f32x8 ev8;
+typedef f32x4 ev4;
+__device__ __forceinline__ float e2f(float x) { return x; }
+__device__ __forceinline__ float f2e(float x) { return x; }
+__device__ __forceinline__ float ernd(float x) { return x; }
+#define AA_FN(name) name##_f32
+#define AA_FN2(name, name_f32) name_f32
+#define AA_ELEM_NS aa_elem_f32
+#else
+typedef bf16_t elem_t;
+typedef u16x8 ev8;
+typedef u16x4 ev4;
+__device__ __forceinline__ float e2f(bf16_t x) { return bf2f(x); }
+__device__ __forceinline__ bf16_t f2e(float x) { return f2bf(x); }
+__device__ __forceinline__ float ernd(float x) { return rbf(x); }
+#define AA_FN(name) name
+#define AA_FN2(name, name_f32) name
+#define AA_ELEM_NS aa_elem_bf16
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

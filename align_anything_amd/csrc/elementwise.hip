@@ -5,34 +5,36 @@
 // reference executes (SURVEY.md §8 a'): fp32 internal math, bf16 rounding at the same points.
 #include "aa_common.h"
 
+namespace AA_ELEM_NS {
+
 // ================================================================== RMSNorm
 // hf:models/llama/modeling_llama.py:62-67 : y = w * bf16(x_f32 * rsqrt(mean(x^2)+eps))
-__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x,
-                                                          const bf16_t* __restrict__ w,
-                                                          bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const elem_t* __restrict__ x,
+                                                          const elem_t* __restrict__ w,
+                                                          elem_t* __restrict__ y,
                                                           float* __restrict__ rstd_out, int rows,
                                                           int h, float eps) {
     __shared__ float red[8];
     const int nv = h >> 3;
     for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-        const bf16_t* xr = x + row * h;
+        const elem_t* xr = x + row * h;
         float ss = 0.f;
         for (int i = threadIdx.x; i < nv; i += 256) {
-            u16x8 v = *reinterpret_cast<const u16x8*>(xr + i * 8);
+            ev8 v = *reinterpret_cast<const ev8*>(xr + i * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); ss += f * f; }
+            for (int j = 0; j < 8; ++j) { const float f = e2f(v[j]); ss += f * f; }
         }
         ss = block_sum<256>(ss, red);
         const float rstd = rsqrtf(ss / (float)h + eps);
         if (threadIdx.x == 0 && rstd_out) rstd_out[row] = rstd;
-        bf16_t* yr = y + row * h;
+        elem_t* yr = y + row * h;
         for (int i = threadIdx.x; i < nv; i += 256) {
-            u16x8 v = *reinterpret_cast<const u16x8*>(xr + i * 8);
-            u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
-            u16x8 o;
+            ev8 v = *reinterpret_cast<const ev8*>(xr + i * 8);
+            ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
+            ev8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * rbf(bf2f(v[j]) * rstd));
-            *reinterpret_cast<u16x8*>(yr + i * 8) = o;
+            for (int j = 0; j < 8; ++j) o[j] = f2e(e2f(wv[j]) * ernd(e2f(v[j]) * rstd));
+            *reinterpret_cast<ev8*>(yr + i * 8) = o;
         }
     }
 }
@@ -40,11 +42,11 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 // dx = rstd * (dy*w - xhat * mean(dy*w*xhat)),  dw[c] += sum_rows dy*bf16(xhat)
 // dw partials are kept per thread in registers across the block's rows and flushed with fp32 atomics.
 template <int MAXV>  // max 16-byte vectors per thread (h <= 256*8*MAXV)
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy,
-                                                          const bf16_t* __restrict__ x,
-                                                          const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const elem_t* __restrict__ dy,
+                                                          const elem_t* __restrict__ x,
+                                                          const elem_t* __restrict__ w,
                                                           const float* __restrict__ rstd_in,
-                                                          bf16_t* __restrict__ dx,
+                                                          elem_t* __restrict__ dx,
                                                           float* __restrict__ dw_part, int rows, int h,
                                                           int add_to_dx) {
     __shared__ float red[8];
@@ -56,44 +58,44 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
         for (int j = 0; j < 8; ++j) dwacc[a][j] = 0.f;
     for (long row = blockIdx.x; row < rows; row += gridDim.x) {
         const float rstd = rstd_in[row];
-        const bf16_t* xr = x + row * h;
-        const bf16_t* gr = dy + row * h;
+        const elem_t* xr = x + row * h;
+        const elem_t* gr = dy + row * h;
         float dot = 0.f;
 #pragma unroll
         for (int a = 0; a < MAXV; ++a) {
             const int i = threadIdx.x + a * 256;
             if (i < nv) {
-                u16x8 xv = *reinterpret_cast<const u16x8*>(xr + i * 8);
-                u16x8 gv = *reinterpret_cast<const u16x8*>(gr + i * 8);
-                u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
+                ev8 xv = *reinterpret_cast<const ev8*>(xr + i * 8);
+                ev8 gv = *reinterpret_cast<const ev8*>(gr + i * 8);
+                ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float xh = bf2f(xv[j]) * rstd;
-                    const float g = bf2f(gv[j]);
-                    dot += g * bf2f(wv[j]) * xh;
-                    dwacc[a][j] += g * rbf(xh);
+                    const float xh = e2f(xv[j]) * rstd;
+                    const float g = e2f(gv[j]);
+                    dot += g * e2f(wv[j]) * xh;
+                    dwacc[a][j] += g * ernd(xh);
                 }
             }
         }
         dot = block_sum<256>(dot, red) / (float)h;
-        bf16_t* dxr = dx + row * h;
+        elem_t* dxr = dx + row * h;
 #pragma unroll
         for (int a = 0; a < MAXV; ++a) {
             const int i = threadIdx.x + a * 256;
             if (i < nv) {
-                u16x8 xv = *reinterpret_cast<const u16x8*>(xr + i * 8);
-                u16x8 gv = *reinterpret_cast<const u16x8*>(gr + i * 8);
-                u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
-                u16x8 o;
-                if (add_to_dx) o = *reinterpret_cast<const u16x8*>(dxr + i * 8);
+                ev8 xv = *reinterpret_cast<const ev8*>(xr + i * 8);
+                ev8 gv = *reinterpret_cast<const ev8*>(gr + i * 8);
+                ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
+                ev8 o;
+                if (add_to_dx) o = *reinterpret_cast<const ev8*>(dxr + i * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float xh = bf2f(xv[j]) * rstd;
-                    float d = rstd * (bf2f(gv[j]) * bf2f(wv[j]) - xh * dot);
-                    if (add_to_dx) d += bf2f(o[j]);
-                    o[j] = f2bf(d);
+                    const float xh = e2f(xv[j]) * rstd;
+                    float d = rstd * (e2f(gv[j]) * e2f(wv[j]) - xh * dot);
+                    if (add_to_dx) d += e2f(o[j]);
+                    o[j] = f2e(d);
                 }
-                *reinterpret_cast<u16x8*>(dxr + i * 8) = o;
+                *reinterpret_cast<ev8*>(dxr + i * 8) = o;
             }
         }
     }
@@ -128,18 +130,18 @@ static void launch_reduce_rows(const float* part, int nrows, int h, float* out, 
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(aa_cdiv(h, 64), rs), dim3(256), 0, st, part, nrows, h, out);
 }
 
-extern "C" int aa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int h,
+extern "C" int AA_FN(aa_rmsnorm_fwd)(const void* x, const void* w, void* y, float* rstd, int rows, int h,
                               float eps, void* stream) {
     AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0, "aa_rmsnorm_fwd: hidden %d must be a multiple of 8", h);
     if (rows == 0) return AA_OK;
     const int grid = rows < 4096 ? rows : 4096;
     hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, h, eps);
+                       (const elem_t*)x, (const elem_t*)w, (elem_t*)y, rstd, rows, h, eps);
     AA_CHECK_LAUNCH("aa_rmsnorm_fwd");
     return AA_OK;
 }
 
-extern "C" int aa_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd,
+extern "C" int AA_FN(aa_rmsnorm_bwd)(const void* dy, const void* x, const void* w, const float* rstd,
                               void* dx, float* dw, float* ws, int ws_rows, int rows, int h,
                               int add_to_dx, void* stream) {
     AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0 && h <= 8 * 256 * 8,
@@ -151,8 +153,8 @@ extern "C" int aa_rmsnorm_bwd(const void* dy, const void* x, const void* w, cons
     float* part = dw ? ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_RMSB(MV)                                                                             \
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy,     \
-                       (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, part, rows, h, add_to_dx)
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const elem_t*)dy,     \
+                       (const elem_t*)x, (const elem_t*)w, rstd, (elem_t*)dx, part, rows, h, add_to_dx)
     if (h <= 2048) LAUNCH_RMSB(1);
     else if (h <= 4096) LAUNCH_RMSB(2);
     else if (h <= 8192) LAUNCH_RMSB(4);
@@ -165,57 +167,57 @@ extern "C" int aa_rmsnorm_bwd(const void* dy, const void* x, const void* w, cons
 
 // ================================================================== LayerNorm
 // torch F.layer_norm on bf16: fp32 stats, y = bf16((x-mean)*rstd*w + b)
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x,
-                                                            const bf16_t* __restrict__ w,
-                                                            const bf16_t* __restrict__ b,
-                                                            bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const elem_t* __restrict__ x,
+                                                            const elem_t* __restrict__ w,
+                                                            const elem_t* __restrict__ b,
+                                                            elem_t* __restrict__ y,
                                                             float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out, int rows,
                                                             int h, float eps) {
     __shared__ float red[8];
     const int nv = h >> 3;
     for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-        const bf16_t* xr = x + row * h;
+        const elem_t* xr = x + row * h;
         float s = 0.f;
         for (int i = threadIdx.x; i < nv; i += 256) {
-            u16x8 v = *reinterpret_cast<const u16x8*>(xr + i * 8);
+            ev8 v = *reinterpret_cast<const ev8*>(xr + i * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += bf2f(v[j]);
+            for (int j = 0; j < 8; ++j) s += e2f(v[j]);
         }
         const float mean = block_sum<256>(s, red) / (float)h;
         float ss = 0.f;
         for (int i = threadIdx.x; i < nv; i += 256) {
-            u16x8 v = *reinterpret_cast<const u16x8*>(xr + i * 8);
+            ev8 v = *reinterpret_cast<const ev8*>(xr + i * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = bf2f(v[j]) - mean; ss += d * d; }
+            for (int j = 0; j < 8; ++j) { const float d = e2f(v[j]) - mean; ss += d * d; }
         }
         const float rstd = rsqrtf(block_sum<256>(ss, red) / (float)h + eps);
         if (threadIdx.x == 0) {
             if (mean_out) mean_out[row] = mean;
             if (rstd_out) rstd_out[row] = rstd;
         }
-        bf16_t* yr = y + row * h;
+        elem_t* yr = y + row * h;
         for (int i = threadIdx.x; i < nv; i += 256) {
-            u16x8 v = *reinterpret_cast<const u16x8*>(xr + i * 8);
-            u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
-            u16x8 bv = *reinterpret_cast<const u16x8*>(b + i * 8);
-            u16x8 o;
+            ev8 v = *reinterpret_cast<const ev8*>(xr + i * 8);
+            ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
+            ev8 bv = *reinterpret_cast<const ev8*>(b + i * 8);
+            ev8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                o[j] = f2bf((bf2f(v[j]) - mean) * rstd * bf2f(wv[j]) + bf2f(bv[j]));
-            *reinterpret_cast<u16x8*>(yr + i * 8) = o;
+                o[j] = f2e((e2f(v[j]) - mean) * rstd * e2f(wv[j]) + e2f(bv[j]));
+            *reinterpret_cast<ev8*>(yr + i * 8) = o;
         }
     }
 }
 
 // dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)), dxhat = dy*w ; dw += dy*xhat ; db += dy
 template <int MAXV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy,
-                                                            const bf16_t* __restrict__ x,
-                                                            const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const elem_t* __restrict__ dy,
+                                                            const elem_t* __restrict__ x,
+                                                            const elem_t* __restrict__ w,
                                                             const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in,
-                                                            bf16_t* __restrict__ dx,
+                                                            elem_t* __restrict__ dx,
                                                             float* __restrict__ dw_part,
                                                             float* __restrict__ db_part, int rows, int h,
                                                             int add_to_dx) {
@@ -228,21 +230,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
         for (int j = 0; j < 8; ++j) { dwacc[a][j] = 0.f; dbacc[a][j] = 0.f; }
     for (long row = blockIdx.x; row < rows; row += gridDim.x) {
         const float mean = mean_in[row], rstd = rstd_in[row];
-        const bf16_t* xr = x + row * h;
-        const bf16_t* gr = dy + row * h;
+        const elem_t* xr = x + row * h;
+        const elem_t* gr = dy + row * h;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int a = 0; a < MAXV; ++a) {
             const int i = threadIdx.x + a * 256;
             if (i < nv) {
-                u16x8 xv = *reinterpret_cast<const u16x8*>(xr + i * 8);
-                u16x8 gv = *reinterpret_cast<const u16x8*>(gr + i * 8);
-                u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
+                ev8 xv = *reinterpret_cast<const ev8*>(xr + i * 8);
+                ev8 gv = *reinterpret_cast<const ev8*>(gr + i * 8);
+                ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float xh = (bf2f(xv[j]) - mean) * rstd;
-                    const float g = bf2f(gv[j]);
-                    const float dxh = g * bf2f(wv[j]);
+                    const float xh = (e2f(xv[j]) - mean) * rstd;
+                    const float g = e2f(gv[j]);
+                    const float dxh = g * e2f(wv[j]);
                     s1 += dxh; s2 += dxh * xh;
                     dwacc[a][j] += g * xh; dbacc[a][j] += g;
                 }
@@ -250,24 +252,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
         }
         s1 = block_sum<256>(s1, red) / (float)h;
         s2 = block_sum<256>(s2, red) / (float)h;
-        bf16_t* dxr = dx + row * h;
+        elem_t* dxr = dx + row * h;
 #pragma unroll
         for (int a = 0; a < MAXV; ++a) {
             const int i = threadIdx.x + a * 256;
             if (i < nv) {
-                u16x8 xv = *reinterpret_cast<const u16x8*>(xr + i * 8);
-                u16x8 gv = *reinterpret_cast<const u16x8*>(gr + i * 8);
-                u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
-                u16x8 o;
-                if (add_to_dx) o = *reinterpret_cast<const u16x8*>(dxr + i * 8);
+                ev8 xv = *reinterpret_cast<const ev8*>(xr + i * 8);
+                ev8 gv = *reinterpret_cast<const ev8*>(gr + i * 8);
+                ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
+                ev8 o;
+                if (add_to_dx) o = *reinterpret_cast<const ev8*>(dxr + i * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float xh = (bf2f(xv[j]) - mean) * rstd;
-                    float d = rstd * (bf2f(gv[j]) * bf2f(wv[j]) - s1 - xh * s2);
-                    if (add_to_dx) d += bf2f(o[j]);
-                    o[j] = f2bf(d);
+                    const float xh = (e2f(xv[j]) - mean) * rstd;
+                    float d = rstd * (e2f(gv[j]) * e2f(wv[j]) - s1 - xh * s2);
+                    if (add_to_dx) d += e2f(o[j]);
+                    o[j] = f2e(d);
                 }
-                *reinterpret_cast<u16x8*>(dxr + i * 8) = o;
+                *reinterpret_cast<ev8*>(dxr + i * 8) = o;
             }
         }
     }
@@ -289,19 +291,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     }
 }
 
-extern "C" int aa_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean,
+extern "C" int AA_FN(aa_layernorm_fwd)(const void* x, const void* w, const void* b, void* y, float* mean,
                                 float* rstd, int rows, int h, float eps, void* stream) {
     AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0, "aa_layernorm_fwd: hidden %d must be a multiple of 8", h);
     if (rows == 0) return AA_OK;
     const int grid = rows < 4096 ? rows : 4096;
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, mean, rstd,
+                       (const elem_t*)x, (const elem_t*)w, (const elem_t*)b, (elem_t*)y, mean, rstd,
                        rows, h, eps);
     AA_CHECK_LAUNCH("aa_layernorm_fwd");
     return AA_OK;
 }
 
-extern "C" int aa_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean,
+extern "C" int AA_FN(aa_layernorm_bwd)(const void* dy, const void* x, const void* w, const float* mean,
                                 const float* rstd, void* dx, float* dw, float* db, float* ws,
                                 int ws_rows, int rows, int h, int add_to_dx, void* stream) {
     AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0 && h <= 8 * 256 * 4,
@@ -315,8 +317,8 @@ extern "C" int aa_layernorm_bwd(const void* dy, const void* x, const void* w, co
     float* dbp = db ? ws + (long)ws_rows * h : nullptr;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_LNB(MV)                                                                              \
-    hipLaunchKernelGGL(layernorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy,   \
-                       (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, dwp, dbp, rows, h, \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const elem_t*)dy,   \
+                       (const elem_t*)x, (const elem_t*)w, mean, rstd, (elem_t*)dx, dwp, dbp, rows, h, \
                        add_to_dx)
     if (h <= 2048) LAUNCH_LNB(1);
     else if (h <= 4096) LAUNCH_LNB(2);
@@ -333,11 +335,11 @@ extern "C" int aa_layernorm_bwd(const void* dy, const void* x, const void* w, co
 // q' = bf16(bf16(q*cos) + bf16(rotate_half(q)*sin)), half-split layout.  Applied to `nheads`
 // consecutive heads starting at column col0 of every row; position of row r is pos[r].
 // inverse != 0 applies the transpose rotation (backward).
-__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ buf, long ld, int col0,
+__global__ __launch_bounds__(256) void rope_kernel(elem_t* __restrict__ buf, long ld, int col0,
                                                    int nheads, int hd,
                                                    const int* __restrict__ pos,
-                                                   const bf16_t* __restrict__ cos_t,
-                                                   const bf16_t* __restrict__ sin_t, long rows,
+                                                   const elem_t* __restrict__ cos_t,
+                                                   const elem_t* __restrict__ sin_t, long rows,
                                                    int inverse) {
     const int half = hd >> 1;
     const int vec_per_head = half >> 3;  // 8 bf16 per lane from each half
@@ -348,25 +350,25 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ buf, lon
         const int head = (int)(t % nheads);
         const long row = t / nheads;
         const int p = pos[row];
-        bf16_t* base = buf + row * ld + col0 + head * hd + v * 8;
-        u16x8 x1 = *reinterpret_cast<const u16x8*>(base);
-        u16x8 x2 = *reinterpret_cast<const u16x8*>(base + half);
-        u16x8 c = *reinterpret_cast<const u16x8*>(cos_t + (long)p * half + v * 8);
-        u16x8 s = *reinterpret_cast<const u16x8*>(sin_t + (long)p * half + v * 8);
-        u16x8 o1, o2;
+        elem_t* base = buf + row * ld + col0 + head * hd + v * 8;
+        ev8 x1 = *reinterpret_cast<const ev8*>(base);
+        ev8 x2 = *reinterpret_cast<const ev8*>(base + half);
+        ev8 c = *reinterpret_cast<const ev8*>(cos_t + (long)p * half + v * 8);
+        ev8 s = *reinterpret_cast<const ev8*>(sin_t + (long)p * half + v * 8);
+        ev8 o1, o2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float a = bf2f(x1[j]), b = bf2f(x2[j]), cc = bf2f(c[j]);
-            const float ss = inverse ? -bf2f(s[j]) : bf2f(s[j]);
-            o1[j] = f2bf(rbf(a * cc) + rbf(-b * ss));
-            o2[j] = f2bf(rbf(b * cc) + rbf(a * ss));
+            const float a = e2f(x1[j]), b = e2f(x2[j]), cc = e2f(c[j]);
+            const float ss = inverse ? -e2f(s[j]) : e2f(s[j]);
+            o1[j] = f2e(ernd(a * cc) + ernd(-b * ss));
+            o2[j] = f2e(ernd(b * cc) + ernd(a * ss));
         }
-        *reinterpret_cast<u16x8*>(base) = o1;
-        *reinterpret_cast<u16x8*>(base + half) = o2;
+        *reinterpret_cast<ev8*>(base) = o1;
+        *reinterpret_cast<ev8*>(base + half) = o2;
     }
 }
 
-extern "C" int aa_rope_inplace(void* buf, long ld, int col0, int nheads, int hd, const int* pos,
+extern "C" int AA_FN(aa_rope_inplace)(void* buf, long ld, int col0, int nheads, int hd, const int* pos,
                                const void* cos_t, const void* sin_t, long rows, int inverse,
                                void* stream) {
     AA_REQUIRE(hd > 0 && (hd % 16) == 0 && nheads > 0, "aa_rope_inplace: head_dim %d must be a multiple of 16", hd);
@@ -374,8 +376,8 @@ extern "C" int aa_rope_inplace(void* buf, long ld, int col0, int nheads, int hd,
     if (rows == 0) return AA_OK;
     const long total = rows * nheads * (hd >> 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)buf, ld,
-                       col0, nheads, hd, pos, (const bf16_t*)cos_t, (const bf16_t*)sin_t, rows, inverse);
+    hipLaunchKernelGGL(rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (elem_t*)buf, ld,
+                       col0, nheads, hd, pos, (const elem_t*)cos_t, (const elem_t*)sin_t, rows, inverse);
     AA_CHECK_LAUNCH("aa_rope_inplace");
     return AA_OK;
 }
@@ -418,135 +420,135 @@ __device__ __forceinline__ float act_grad(float x, int act) {
 }
 
 // SwiGLU: gu = [gate | up] as [M, 2F] ; act = bf16(bf16(silu(gate)) * up)
-__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu,
-                                                         bf16_t* __restrict__ out, long M, int F) {
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const elem_t* __restrict__ gu,
+                                                         elem_t* __restrict__ out, long M, int F) {
     const int nv = F >> 3;
     const long total = M * nv;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const long row = idx / nv;
         const int v = (int)(idx % nv);
-        u16x8 g = *reinterpret_cast<const u16x8*>(gu + row * 2 * F + v * 8);
-        u16x8 u = *reinterpret_cast<const u16x8*>(gu + row * 2 * F + F + v * 8);
-        u16x8 o;
+        ev8 g = *reinterpret_cast<const ev8*>(gu + row * 2 * F + v * 8);
+        ev8 u = *reinterpret_cast<const ev8*>(gu + row * 2 * F + F + v * 8);
+        ev8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float gf = bf2f(g[j]);
-            o[j] = f2bf(rbf(gf / (1.f + expf(-gf))) * bf2f(u[j]));
+            const float gf = e2f(g[j]);
+            o[j] = f2e(ernd(gf / (1.f + expf(-gf))) * e2f(u[j]));
         }
-        *reinterpret_cast<u16x8*>(out + row * F + v * 8) = o;
+        *reinterpret_cast<ev8*>(out + row * F + v * 8) = o;
     }
 }
 // dgu = [dact*up*silu'(gate) | dact*silu(gate)]
-__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu,
-                                                         const bf16_t* __restrict__ dact,
-                                                         bf16_t* __restrict__ dgu, long M, int F) {
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const elem_t* __restrict__ gu,
+                                                         const elem_t* __restrict__ dact,
+                                                         elem_t* __restrict__ dgu, long M, int F) {
     const int nv = F >> 3;
     const long total = M * nv;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const long row = idx / nv;
         const int v = (int)(idx % nv);
-        u16x8 g = *reinterpret_cast<const u16x8*>(gu + row * 2 * F + v * 8);
-        u16x8 u = *reinterpret_cast<const u16x8*>(gu + row * 2 * F + F + v * 8);
-        u16x8 d = *reinterpret_cast<const u16x8*>(dact + row * F + v * 8);
-        u16x8 og, ou;
+        ev8 g = *reinterpret_cast<const ev8*>(gu + row * 2 * F + v * 8);
+        ev8 u = *reinterpret_cast<const ev8*>(gu + row * 2 * F + F + v * 8);
+        ev8 d = *reinterpret_cast<const ev8*>(dact + row * F + v * 8);
+        ev8 og, ou;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float gf = bf2f(g[j]), uf = bf2f(u[j]), df = bf2f(d[j]);
+            const float gf = e2f(g[j]), uf = e2f(u[j]), df = e2f(d[j]);
             const float s = 1.f / (1.f + expf(-gf));
-            og[j] = f2bf(df * uf * s * (1.f + gf * (1.f - s)));
-            ou[j] = f2bf(df * gf * s);
+            og[j] = f2e(df * uf * s * (1.f + gf * (1.f - s)));
+            ou[j] = f2e(df * gf * s);
         }
-        *reinterpret_cast<u16x8*>(dgu + row * 2 * F + v * 8) = og;
-        *reinterpret_cast<u16x8*>(dgu + row * 2 * F + F + v * 8) = ou;
+        *reinterpret_cast<ev8*>(dgu + row * 2 * F + v * 8) = og;
+        *reinterpret_cast<ev8*>(dgu + row * 2 * F + F + v * 8) = ou;
     }
 }
 
-extern "C" int aa_swiglu_fwd(const void* gate_up, void* out, long M, int F, void* stream) {
+extern "C" int AA_FN(aa_swiglu_fwd)(const void* gate_up, void* out, long M, int F, void* stream) {
     AA_REQUIRE(F > 0 && (F & 7) == 0, "aa_swiglu_fwd: ffn %d must be a multiple of 8", F);
     if (M == 0) return AA_OK;
     const long total = M * (F >> 3);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)gate_up, (bf16_t*)out, M, F);
+                       (const elem_t*)gate_up, (elem_t*)out, M, F);
     AA_CHECK_LAUNCH("aa_swiglu_fwd");
     return AA_OK;
 }
-extern "C" int aa_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, long M, int F,
+extern "C" int AA_FN(aa_swiglu_bwd)(const void* gate_up, const void* dact, void* dgate_up, long M, int F,
                              void* stream) {
     AA_REQUIRE(F > 0 && (F & 7) == 0, "aa_swiglu_bwd: ffn %d must be a multiple of 8", F);
     if (M == 0) return AA_OK;
     const long total = M * (F >> 3);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)gate_up, (const bf16_t*)dact, (bf16_t*)dgate_up, M, F);
+                       (const elem_t*)gate_up, (const elem_t*)dact, (elem_t*)dgate_up, M, F);
     AA_CHECK_LAUNCH("aa_swiglu_bwd");
     return AA_OK;
 }
 
 // pointwise activation backward: dx = dy * act'(pre)   (pre = saved pre-activation, bf16)
-__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* __restrict__ pre,
-                                                      const bf16_t* __restrict__ dy,
-                                                      bf16_t* __restrict__ dx, long n8, int act) {
+__global__ __launch_bounds__(256) void act_bwd_kernel(const elem_t* __restrict__ pre,
+                                                      const elem_t* __restrict__ dy,
+                                                      elem_t* __restrict__ dx, long n8, int act) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n8; idx += (long)gridDim.x * 256) {
-        u16x8 p = *reinterpret_cast<const u16x8*>(pre + idx * 8);
-        u16x8 d = *reinterpret_cast<const u16x8*>(dy + idx * 8);
-        u16x8 o;
+        ev8 p = *reinterpret_cast<const ev8*>(pre + idx * 8);
+        ev8 d = *reinterpret_cast<const ev8*>(dy + idx * 8);
+        ev8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(d[j]) * act_grad(bf2f(p[j]), act));
-        *reinterpret_cast<u16x8*>(dx + idx * 8) = o;
+        for (int j = 0; j < 8; ++j) o[j] = f2e(e2f(d[j]) * act_grad(e2f(p[j]), act));
+        *reinterpret_cast<ev8*>(dx + idx * 8) = o;
     }
 }
-__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t* __restrict__ x,
-                                                      bf16_t* __restrict__ y, long n8, int act) {
+__global__ __launch_bounds__(256) void act_fwd_kernel(const elem_t* __restrict__ x,
+                                                      elem_t* __restrict__ y, long n8, int act) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n8; idx += (long)gridDim.x * 256) {
-        u16x8 p = *reinterpret_cast<const u16x8*>(x + idx * 8);
-        u16x8 o;
+        ev8 p = *reinterpret_cast<const ev8*>(x + idx * 8);
+        ev8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(act_fwd(bf2f(p[j]), act));
-        *reinterpret_cast<u16x8*>(y + idx * 8) = o;
+        for (int j = 0; j < 8; ++j) o[j] = f2e(act_fwd(e2f(p[j]), act));
+        *reinterpret_cast<ev8*>(y + idx * 8) = o;
     }
 }
-extern "C" int aa_act_fwd(const void* x, void* y, long n, int act, void* stream) {
+extern "C" int AA_FN(aa_act_fwd)(const void* x, void* y, long n, int act, void* stream) {
     AA_REQUIRE((n & 7) == 0, "aa_act_fwd: element count %ld must be a multiple of 8", n);
     if (n == 0) return AA_OK;
     const long n8 = n >> 3;
     const int grid = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                       (bf16_t*)y, n8, act);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x,
+                       (elem_t*)y, n8, act);
     AA_CHECK_LAUNCH("aa_act_fwd");
     return AA_OK;
 }
-extern "C" int aa_act_bwd(const void* pre, const void* dy, void* dx, long n, int act, void* stream) {
+extern "C" int AA_FN(aa_act_bwd)(const void* pre, const void* dy, void* dx, long n, int act, void* stream) {
     AA_REQUIRE((n & 7) == 0, "aa_act_bwd: element count %ld must be a multiple of 8", n);
     if (n == 0) return AA_OK;
     const long n8 = n >> 3;
     const int grid = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)pre, (const bf16_t*)dy, (bf16_t*)dx, n8, act);
+                       (const elem_t*)pre, (const elem_t*)dy, (elem_t*)dx, n8, act);
     AA_CHECK_LAUNCH("aa_act_bwd");
     return AA_OK;
 }
 
 // y = a + b (bf16, rounded once) -- residual adds that are not fused into a GEMM epilogue
-__global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a,
-                                                  const bf16_t* __restrict__ b,
-                                                  bf16_t* __restrict__ y, long n8) {
+__global__ __launch_bounds__(256) void add_kernel(const elem_t* __restrict__ a,
+                                                  const elem_t* __restrict__ b,
+                                                  elem_t* __restrict__ y, long n8) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n8; idx += (long)gridDim.x * 256) {
-        u16x8 p = *reinterpret_cast<const u16x8*>(a + idx * 8);
-        u16x8 q = *reinterpret_cast<const u16x8*>(b + idx * 8);
-        u16x8 o;
+        ev8 p = *reinterpret_cast<const ev8*>(a + idx * 8);
+        ev8 q = *reinterpret_cast<const ev8*>(b + idx * 8);
+        ev8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(p[j]) + bf2f(q[j]));
-        *reinterpret_cast<u16x8*>(y + idx * 8) = o;
+        for (int j = 0; j < 8; ++j) o[j] = f2e(e2f(p[j]) + e2f(q[j]));
+        *reinterpret_cast<ev8*>(y + idx * 8) = o;
     }
 }
-extern "C" int aa_add(const void* a, const void* b, void* y, long n, void* stream) {
+extern "C" int AA_FN(aa_add)(const void* a, const void* b, void* y, long n, void* stream) {
     AA_REQUIRE((n & 7) == 0, "aa_add: element count %ld must be a multiple of 8", n);
     if (n == 0) return AA_OK;
     const long n8 = n >> 3;
     const int grid = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
-    hipLaunchKernelGGL(add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
-                       (const bf16_t*)b, (bf16_t*)y, n8);
+    hipLaunchKernelGGL(add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const elem_t*)a,
+                       (const elem_t*)b, (elem_t*)y, n8);
     AA_CHECK_LAUNCH("aa_add");
     return AA_OK;
 }
@@ -586,6 +588,7 @@ __global__ __launch_bounds__(1024) void image_slot_kernel(const int64_t* __restr
     if (threadIdx.x == 0 && count) *count = carry;
 }
 
+#ifndef AA_ELEM_F32   // integer work: one instantiation
 extern "C" int aa_image_slot_index(const int64_t* ids, int n, int64_t image_token_id, int* slot,
                                    int* count, void* stream) {
     AA_REQUIRE(n >= 0, "aa_image_slot_index: n must be >= 0");
@@ -594,44 +597,45 @@ extern "C" int aa_image_slot_index(const int64_t* ids, int n, int64_t image_toke
     AA_CHECK_LAUNCH("aa_image_slot_index");
     return AA_OK;
 }
+#endif
 
 // out[t,:] = slot[t] >= 0 ? feat[slot[t],:] : E[ids[t],:] (+ pos_emb[pos[t],:] when given, OPT)
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids,
                                                         const int* __restrict__ slot,
-                                                        const bf16_t* __restrict__ E,
-                                                        const bf16_t* __restrict__ feat,
+                                                        const elem_t* __restrict__ E,
+                                                        const elem_t* __restrict__ feat,
                                                         const int* __restrict__ pos,
-                                                        const bf16_t* __restrict__ P,
-                                                        bf16_t* __restrict__ out, long n, int h,
+                                                        const elem_t* __restrict__ P,
+                                                        elem_t* __restrict__ out, long n, int h,
                                                         int vocab) {
     const int nv = h >> 3;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n * nv; idx += (long)gridDim.x * 256) {
         const long t = idx / nv;
         const int v = (int)(idx % nv);
         const int s = slot ? slot[t] : -1;
-        u16x8 r;
+        ev8 r;
         if (s >= 0) {
-            r = *reinterpret_cast<const u16x8*>(feat + (long)s * h + v * 8);
+            r = *reinterpret_cast<const ev8*>(feat + (long)s * h + v * 8);
         } else {
             long id = ids[t];
             if (id < 0 || id >= vocab) id = 0;  // host validates; never fault
-            r = *reinterpret_cast<const u16x8*>(E + id * h + v * 8);
+            r = *reinterpret_cast<const ev8*>(E + id * h + v * 8);
         }
         if (P) {
-            u16x8 p = *reinterpret_cast<const u16x8*>(P + (long)pos[t] * h + v * 8);
+            ev8 p = *reinterpret_cast<const ev8*>(P + (long)pos[t] * h + v * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = f2bf(bf2f(r[j]) + bf2f(p[j]));
+            for (int j = 0; j < 8; ++j) r[j] = f2e(e2f(r[j]) + e2f(p[j]));
         }
-        *reinterpret_cast<u16x8*>(out + t * h + v * 8) = r;
+        *reinterpret_cast<ev8*>(out + t * h + v * 8) = r;
     }
 }
 // backward: dfeat[slot] = dx (gather, unique rows) ; dE[ids] += dx (fp32 atomics) ; dP[pos] += dx
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids,
                                                         const int* __restrict__ slot,
                                                         const int* __restrict__ pos,
-                                                        const bf16_t* __restrict__ dx,
+                                                        const elem_t* __restrict__ dx,
                                                         float* __restrict__ dE,
-                                                        bf16_t* __restrict__ dfeat,
+                                                        elem_t* __restrict__ dfeat,
                                                         float* __restrict__ dP, long n, int h,
                                                         int vocab) {
     const int nv = h >> 3;
@@ -639,24 +643,24 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
         const long t = idx / nv;
         const int v = (int)(idx % nv);
         const int s = slot ? slot[t] : -1;
-        u16x8 r = *reinterpret_cast<const u16x8*>(dx + t * h + v * 8);
+        ev8 r = *reinterpret_cast<const ev8*>(dx + t * h + v * 8);
         if (s >= 0) {
-            if (dfeat) *reinterpret_cast<u16x8*>(dfeat + (long)s * h + v * 8) = r;
+            if (dfeat) *reinterpret_cast<ev8*>(dfeat + (long)s * h + v * 8) = r;
         } else if (dE) {
             const long id = ids[t];
             if (id >= 0 && id < vocab) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) atomicAdd(dE + id * h + v * 8 + j, bf2f(r[j]));
+                for (int j = 0; j < 8; ++j) atomicAdd(dE + id * h + v * 8 + j, e2f(r[j]));
             }
         }
         if (dP) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(dP + (long)pos[t] * h + v * 8 + j, bf2f(r[j]));
+            for (int j = 0; j < 8; ++j) atomicAdd(dP + (long)pos[t] * h + v * 8 + j, e2f(r[j]));
         }
     }
 }
 
-extern "C" int aa_embed_fwd(const int64_t* ids, const int* slot, const void* E, const void* feat,
+extern "C" int AA_FN(aa_embed_fwd)(const int64_t* ids, const int* slot, const void* E, const void* feat,
                             const int* pos, const void* P, void* out, long n, int h, int vocab,
                             void* stream) {
     AA_REQUIRE(h > 0 && (h & 7) == 0, "aa_embed_fwd: hidden %d must be a multiple of 8", h);
@@ -665,12 +669,12 @@ extern "C" int aa_embed_fwd(const int64_t* ids, const int* slot, const void* E, 
     const long total = n * (h >> 3);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, slot,
-                       (const bf16_t*)E, (const bf16_t*)feat, pos, (const bf16_t*)P, (bf16_t*)out, n, h,
+                       (const elem_t*)E, (const elem_t*)feat, pos, (const elem_t*)P, (elem_t*)out, n, h,
                        vocab);
     AA_CHECK_LAUNCH("aa_embed_fwd");
     return AA_OK;
 }
-extern "C" int aa_embed_bwd(const int64_t* ids, const int* slot, const int* pos, const void* dx,
+extern "C" int AA_FN(aa_embed_bwd)(const int64_t* ids, const int* slot, const int* pos, const void* dx,
                             float* dE, void* dfeat, float* dP, long n, int h, int vocab,
                             void* stream) {
     AA_REQUIRE(h > 0 && (h & 7) == 0, "aa_embed_bwd: hidden %d must be a multiple of 8", h);
@@ -678,22 +682,22 @@ extern "C" int aa_embed_bwd(const int64_t* ids, const int* slot, const int* pos,
     const long total = n * (h >> 3);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, slot, pos,
-                       (const bf16_t*)dx, dE, (bf16_t*)dfeat, dP, n, h, vocab);
+                       (const elem_t*)dx, dE, (elem_t*)dfeat, dP, n, h, vocab);
     AA_CHECK_LAUNCH("aa_embed_bwd");
     return AA_OK;
 }
 
 // ================================================================== bf16 2-D transpose  out[C,R] = in[R,C]^T
 // 64x64 tile through LDS (padded rows): coalesced 128-B row segments on both sides.
-__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, long ldi,
-                                                        bf16_t* __restrict__ out, long ldo, int R,
+__global__ __launch_bounds__(256) void transpose_kernel(const elem_t* __restrict__ in, long ldi,
+                                                        elem_t* __restrict__ out, long ldo, int R,
                                                         int C) {
-    __shared__ bf16_t tile[64][66];
+    __shared__ elem_t tile[64][66];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < C) ? in[(long)r * ldi + c] : (bf16_t)0;
+        tile[i][tx] = (r < R && c < C) ? in[(long)r * ldi + c] : (elem_t)0;
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
@@ -701,19 +705,19 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
         if (c < C && r < R) out[(long)c * ldo + r] = tile[tx][i];
     }
 }
-extern "C" int aa_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C,
+extern "C" int AA_FN2(aa_transpose_bf16, aa_transpose_f32)(const void* in, long ldi, void* out, long ldo, int R, int C,
                                  void* stream) {
     AA_REQUIRE(R >= 0 && C >= 0 && ldi >= C && ldo >= R, "aa_transpose_bf16: bad shape R=%d C=%d", R, C);
     if (R == 0 || C == 0) return AA_OK;
     hipLaunchKernelGGL(transpose_kernel, dim3(aa_cdiv(C, 64), aa_cdiv(R, 64)), dim3(256), 0,
-                       (hipStream_t)stream, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, R, C);
+                       (hipStream_t)stream, (const elem_t*)in, ldi, (elem_t*)out, ldo, R, C);
     AA_CHECK_LAUNCH("aa_transpose_bf16");
     return AA_OK;
 }
 
 // ================================================================== column sum (bias gradient)
 // out[c] += sum_r in[r, c]   (fp32 atomics; each block reduces a 256-row slab of 64*8 columns)
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ in, long ld, long R,
+__global__ __launch_bounds__(256) void colsum_kernel(const elem_t* __restrict__ in, long ld, long R,
                                                      int C, float* __restrict__ out) {
     // thread layout: 64 lanes x 8 columns wide (512 columns per block), 4 row groups
     __shared__ float part[4][512];
@@ -723,9 +727,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c < C) {
         for (long r = r0 + rg; r < R && r < r0 + 256; r += 4) {
-            u16x8 v = *reinterpret_cast<const u16x8*>(in + r * ld + c);
+            ev8 v = *reinterpret_cast<const ev8*>(in + r * ld + c);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+            for (int j = 0; j < 8; ++j) acc[j] += e2f(v[j]);
         }
     }
 #pragma unroll
@@ -736,11 +740,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
         if (cc < C) atomicAdd(out + cc, part[0][i] + part[1][i] + part[2][i] + part[3][i]);
     }
 }
-extern "C" int aa_colsum_bf16(const void* in, long ld, long R, int C, float* out, void* stream) {
+extern "C" int AA_FN2(aa_colsum_bf16, aa_colsum_f32)(const void* in, long ld, long R, int C, float* out, void* stream) {
     AA_REQUIRE(C > 0 && (C & 7) == 0 && (ld & 7) == 0, "aa_colsum_bf16: C=%d / ld must be multiples of 8", C);
     if (R == 0) return AA_OK;
     hipLaunchKernelGGL(colsum_kernel, dim3(aa_cdiv(C, 512), aa_cdiv(R, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const bf16_t*)in, ld, R, C, out);
+                       (hipStream_t)stream, (const elem_t*)in, ld, R, C, out);
     AA_CHECK_LAUNCH("aa_colsum_bf16");
     return AA_OK;
 }
@@ -750,7 +754,7 @@ extern "C" int aa_colsum_bf16(const void* in, long ld, long R, int C, float* out
 // patches[n*G*G + gy*G + gx, c*P*P + py*P + px] = pixel[n, c, gy*P+py, gx*P+px]; K padded to Kp with 0.
 template <typename TIN>
 __global__ __launch_bounds__(256) void im2col_kernel(const TIN* __restrict__ pix,
-                                                     bf16_t* __restrict__ out, int n_img, int Cc,
+                                                     elem_t* __restrict__ out, int n_img, int Cc,
                                                      int H, int P, int Kp) {
     const int G = H / P;
     const int K = Cc * P * P;
@@ -766,10 +770,10 @@ __global__ __launch_bounds__(256) void im2col_kernel(const TIN* __restrict__ pix
             const long src = ((n * Cc + c) * H + (gy * P + py)) * H + gx * P + px;
             if constexpr (sizeof(TIN) == 2) v = bf2f(pix[src]); else v = pix[src];
         }
-        out[idx] = f2bf(v);
+        out[idx] = f2e(v);
     }
 }
-extern "C" int aa_patch_im2col(const void* pixels, int pix_dtype, void* out, int n_img, int channels,
+extern "C" int AA_FN(aa_patch_im2col)(const void* pixels, int pix_dtype, void* out, int n_img, int channels,
                                int image_size, int patch, int Kp, void* stream) {
     AA_REQUIRE(image_size % patch == 0 && Kp >= channels * patch * patch,
                "aa_patch_im2col: image %d / patch %d / Kp %d mismatch", image_size, patch, Kp);
@@ -779,34 +783,36 @@ extern "C" int aa_patch_im2col(const void* pixels, int pix_dtype, void* out, int
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (pix_dtype == 0)
         hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)pixels, (bf16_t*)out, n_img, channels, image_size, patch, Kp);
+                           (const bf16_t*)pixels, (elem_t*)out, n_img, channels, image_size, patch, Kp);
     else
         hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)pixels, (bf16_t*)out, n_img, channels, image_size, patch, Kp);
+                           (const float*)pixels, (elem_t*)out, n_img, channels, image_size, patch, Kp);
     AA_CHECK_LAUNCH("aa_patch_im2col");
     return AA_OK;
 }
 
+#ifndef AA_ELEM_F32
 // ================================================================== casts / fills
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in,
-                                                          bf16_t* __restrict__ out, long n) {
+                                                          elem_t* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-        out[i] = f2bf(in[i]);
+        out[i] = f2e(in[i]);
 }
 extern "C" int aa_f32_to_bf16(const float* in, void* out, long n, void* stream) {
     if (n == 0) return AA_OK;
     const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in,
-                       (bf16_t*)out, n);
+                       (elem_t*)out, n);
     AA_CHECK_LAUNCH("aa_f32_to_bf16");
     return AA_OK;
 }
+#endif
 
 // CLIP embeddings: x[n, 0, :] = cls + pos[0]; x[n, 1+p, :] = patch[n*G2+p, :] + pos[1+p]
-__global__ __launch_bounds__(256) void clip_embed_kernel(const bf16_t* __restrict__ patch,
-                                                         const bf16_t* __restrict__ cls,
-                                                         const bf16_t* __restrict__ pos,
-                                                         bf16_t* __restrict__ out, int n_img, int G2,
+__global__ __launch_bounds__(256) void clip_embed_kernel(const elem_t* __restrict__ patch,
+                                                         const elem_t* __restrict__ cls,
+                                                         const elem_t* __restrict__ pos,
+                                                         elem_t* __restrict__ out, int n_img, int G2,
                                                          int h) {
     const int nv = h >> 3;
     const long total = (long)n_img * (G2 + 1) * nv;
@@ -815,23 +821,23 @@ __global__ __launch_bounds__(256) void clip_embed_kernel(const bf16_t* __restric
         const long t = idx / nv;
         const int p = (int)(t % (G2 + 1));
         const long n = t / (G2 + 1);
-        u16x8 a = (p == 0) ? *reinterpret_cast<const u16x8*>(cls + v * 8)
-                           : *reinterpret_cast<const u16x8*>(patch + (n * G2 + p - 1) * h + v * 8);
-        u16x8 b = *reinterpret_cast<const u16x8*>(pos + (long)p * h + v * 8);
-        u16x8 o;
+        ev8 a = (p == 0) ? *reinterpret_cast<const ev8*>(cls + v * 8)
+                           : *reinterpret_cast<const ev8*>(patch + (n * G2 + p - 1) * h + v * 8);
+        ev8 b = *reinterpret_cast<const ev8*>(pos + (long)p * h + v * 8);
+        ev8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(a[j]) + bf2f(b[j]));
-        *reinterpret_cast<u16x8*>(out + t * h + v * 8) = o;
+        for (int j = 0; j < 8; ++j) o[j] = f2e(e2f(a[j]) + e2f(b[j]));
+        *reinterpret_cast<ev8*>(out + t * h + v * 8) = o;
     }
 }
-extern "C" int aa_clip_embed(const void* patch, const void* cls, const void* pos, void* out,
+extern "C" int AA_FN(aa_clip_embed)(const void* patch, const void* cls, const void* pos, void* out,
                              int n_img, int G2, int h, void* stream) {
     AA_REQUIRE(h > 0 && (h & 7) == 0, "aa_clip_embed: hidden %d must be a multiple of 8", h);
     if (n_img == 0) return AA_OK;
     const long total = (long)n_img * (G2 + 1) * (h >> 3);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(clip_embed_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)patch, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)out, n_img,
+                       (const elem_t*)patch, (const elem_t*)cls, (const elem_t*)pos, (elem_t*)out, n_img,
                        G2, h);
     AA_CHECK_LAUNCH("aa_clip_embed");
     return AA_OK;
@@ -840,30 +846,30 @@ extern "C" int aa_clip_embed(const void* patch, const void* cls, const void* pos
 // ================================================================== score head  (Linear(h -> 1, bias=False))
 // align_anything/models/opt.py:59-60 / models/llava.py:60: scores = score_head(last_hidden_state).float()
 // out[r] = float(bf16(sum_c x[r,c] * w[c]))   (the bf16 Linear output, upcast)
-__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* __restrict__ x,
-                                                         const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const elem_t* __restrict__ x,
+                                                         const elem_t* __restrict__ w,
                                                          float* __restrict__ out, long rows, int h) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nv = h >> 3;
     for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
-        const bf16_t* xr = x + row * h;
+        const elem_t* xr = x + row * h;
         float acc = 0.f;
         for (int i = lane; i < nv; i += 64) {
-            u16x8 a = *reinterpret_cast<const u16x8*>(xr + i * 8);
-            u16x8 b = *reinterpret_cast<const u16x8*>(w + i * 8);
+            ev8 a = *reinterpret_cast<const ev8*>(xr + i * 8);
+            ev8 b = *reinterpret_cast<const ev8*>(w + i * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc += bf2f(a[j]) * bf2f(b[j]);
+            for (int j = 0; j < 8; ++j) acc += e2f(a[j]) * e2f(b[j]);
         }
         acc = wave_sum(acc);
-        if (lane == 0) out[row] = rbf(acc);
+        if (lane == 0) out[row] = ernd(acc);
     }
 }
 // dx[r,c] = dy[r] * w[c] ; dw_part[block, c] = sum over the block's rows of dy[r] * x[r,c]
 template <int MAXV>
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dy,
-                                                         const bf16_t* __restrict__ x,
-                                                         const bf16_t* __restrict__ w,
-                                                         bf16_t* __restrict__ dx,
+                                                         const elem_t* __restrict__ x,
+                                                         const elem_t* __restrict__ w,
+                                                         elem_t* __restrict__ dx,
                                                          float* __restrict__ dw_part, long rows, int h) {
     const int nv = h >> 3;
     float dwacc[MAXV][8];
@@ -877,15 +883,15 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
         for (int a = 0; a < MAXV; ++a) {
             const int i = threadIdx.x + a * 256;
             if (i < nv) {
-                u16x8 xv = *reinterpret_cast<const u16x8*>(x + row * h + i * 8);
-                u16x8 wv = *reinterpret_cast<const u16x8*>(w + i * 8);
-                u16x8 o;
+                ev8 xv = *reinterpret_cast<const ev8*>(x + row * h + i * 8);
+                ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
+                ev8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    dwacc[a][j] += g * bf2f(xv[j]);
-                    o[j] = f2bf(g * bf2f(wv[j]));
+                    dwacc[a][j] += g * e2f(xv[j]);
+                    o[j] = f2e(g * e2f(wv[j]));
                 }
-                *reinterpret_cast<u16x8*>(dx + row * h + i * 8) = o;
+                *reinterpret_cast<ev8*>(dx + row * h + i * 8) = o;
             }
         }
     }
@@ -902,16 +908,16 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
     }
 }
 
-extern "C" int aa_rowdot_fwd(const void* x, const void* w, float* out, long rows, int h, void* stream) {
+extern "C" int AA_FN(aa_rowdot_fwd)(const void* x, const void* w, float* out, long rows, int h, void* stream) {
     AA_REQUIRE(h > 0 && (h & 7) == 0, "aa_rowdot_fwd: hidden %d must be a multiple of 8", h);
     if (rows == 0) return AA_OK;
     const long nb = (rows + 3) / 4;
     hipLaunchKernelGGL(rowdot_fwd_kernel, dim3((int)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (const bf16_t*)w, out, rows, h);
+                       (const elem_t*)x, (const elem_t*)w, out, rows, h);
     AA_CHECK_LAUNCH("aa_rowdot_fwd");
     return AA_OK;
 }
-extern "C" int aa_rowdot_bwd(const float* dy, const void* x, const void* w, void* dx, float* dw, float* ws,
+extern "C" int AA_FN(aa_rowdot_bwd)(const float* dy, const void* x, const void* w, void* dx, float* dw, float* ws,
                              int ws_rows, long rows, int h, void* stream) {
     AA_REQUIRE(h > 0 && (h & 7) == 0 && h <= 8 * 256 * 8, "aa_rowdot_bwd: hidden %d must be a multiple of 8 and <= 16384", h);
     AA_REQUIRE(dw == nullptr || (ws != nullptr && ws_rows > 0), "aa_rowdot_bwd: dw needs a [ws_rows, h] fp32 workspace");
@@ -921,8 +927,8 @@ extern "C" int aa_rowdot_bwd(const float* dy, const void* x, const void* w, void
     float* part = dw ? ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_RDB(MV)                                                                                \
-    hipLaunchKernelGGL(rowdot_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, dy, (const bf16_t*)x,      \
-                       (const bf16_t*)w, (bf16_t*)dx, part, rows, h)
+    hipLaunchKernelGGL(rowdot_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, dy, (const elem_t*)x,      \
+                       (const elem_t*)w, (elem_t*)dx, part, rows, h)
     if (h <= 2048) LAUNCH_RDB(1);
     else if (h <= 4096) LAUNCH_RDB(2);
     else if (h <= 8192) LAUNCH_RDB(4);
@@ -932,3 +938,5 @@ extern "C" int aa_rowdot_bwd(const float* dy, const void* x, const void* w, void
     AA_CHECK_LAUNCH("aa_rowdot_bwd");
     return AA_OK;
 }
+
+}  // namespace AA_ELEM_NS

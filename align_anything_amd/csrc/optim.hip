@@ -87,7 +87,8 @@ extern "C" int aa_clip_coef(const float* sumsq, float max_norm, float* coef_out,
 // AdamW on flat buffers.  g' = g * gscale * (*clip_coef)
 //   m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2
 //   p = p - lr * ( (m/bc1) / (sqrt(v/bc2) + eps) + wd * p )       (DeepSpeed FusedAdam ADAM_MODE_1)
-// master/m/v fp32, p16 = bf16 shadow written from the updated master.
+// master/m/v fp32, p16 = bf16 shadow written from the updated master (NULL in the fp32 parity mode, where the
+// model computes directly on the fp32 masters).
 template <typename TG>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ p16,
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
         *reinterpret_cast<f32x4*>(master + i * 4) = pw;
         *reinterpret_cast<f32x4*>(m + i * 4) = mm;
         *reinterpret_cast<f32x4*>(v + i * 4) = vv;
-        *reinterpret_cast<u16x4*>(p16 + i * 4) = o;
+        if (p16) *reinterpret_cast<u16x4*>(p16 + i * 4) = o;
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float gq;
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
         const float vq = b2 * v[i] + (1.f - b2) * gq * gq;
         const float denom = sqrtf(vq * inv_bc2) + eps;
         const float pq = master[i] - lr * ((mq * inv_bc1) / denom + wd * master[i]);
-        master[i] = pq; m[i] = mq; v[i] = vq; p16[i] = f2bf(pq);
+        master[i] = pq; m[i] = mq; v[i] = vq;
+        if (p16) p16[i] = f2bf(pq);
     }
 }
 

@@ -210,7 +210,7 @@ class NativeEngine:
             ops.clip_coef(self._sumsq, self.max_grad_norm if self.max_grad_norm else 0.0, self._coef, self._gnorm)
             for g in groups:
                 wd = 0.0 if g == 'vec' else self.weight_decay
-                ops.adamw_flat_(st.master[g], st.m[g], st.v[g], st.flat[g], st.gflat[g], lr_used, self.betas[0],
+                ops.adamw_flat_(st.master[g], st.m[g], st.v[g], None if st.master[g] is st.flat[g] else st.flat[g], st.gflat[g], lr_used, self.betas[0],
                                 self.betas[1], self.eps, wd, self.global_steps, gscale, self._coef)
 
         if self.async_optimizer and self.module.device.type == 'cuda':
@@ -274,5 +274,6 @@ class NativeEngine:
             st.master[g].copy_(ck['master'][g])
             st.m[g].copy_(ck['m'][g])
             st.v[g].copy_(ck['v'][g])
-            ops.f32_to_bf16(st.master[g], out=st.flat[g])
+            if st.master[g] is not st.flat[g]:
+                ops.f32_to_bf16(st.master[g], out=st.flat[g])
         return load_dir, {}

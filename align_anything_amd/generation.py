@@ -25,6 +25,8 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
         raise NotImplementedError('repetition_penalty != 1.0 is not built (reference default is 1.0, ppo.yaml:156)')
     N, T = input_ids.shape
     dev = input_ids.device
+    if getattr(model, 'dtype', torch.bfloat16) != torch.bfloat16:
+        raise RuntimeError('generate: the HIP decode kernels are bf16 only (the fp32 parity mode covers training steps)')
     if max_new_tokens is None:
         if max_length is None:
             raise ValueError('give max_length (GenerationConfig.max_length) or max_new_tokens')

@@ -1,4 +1,4 @@
-"""ctypes binding of libaa_hip.so (C ABI declared in include/aa_hip.h).
+"""ctypes binding of libaa_hip.so (C ABI declared in include/aa_hip.h and include/aa_hip_f32.h).
 
 The prototypes are parsed from the header itself so the header stays the single source of truth.
 There is NO CPU fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
@@ -12,6 +12,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libaa_hip.so')
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'aa_hip.h')
+HEADER_F32 = os.path.join(os.path.dirname(HERE), 'include', 'aa_hip_f32.h')   # fp32 parity-mode twins
 
 _SCALARS = {
     'int': ctypes.c_int,
@@ -53,7 +54,7 @@ class AAHipError(RuntimeError):
 class _Lib:
     def __init__(self) -> None:
         self._dll = None
-        self.protos = parse_header()
+        self.protos = {**parse_header(HEADER), **parse_header(HEADER_F32)}
 
     def load(self):
         if self._dll is not None:

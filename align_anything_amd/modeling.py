@@ -28,11 +28,11 @@ def _pad64(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
-def rope_tables(max_pos: int, hd: int, theta: float, device):
-    """hf:models/llama/modeling_llama.py:113-127: inv_freq / freqs in fp32, cos & sin cast to bf16."""
+def rope_tables(max_pos: int, hd: int, theta: float, device, dtype=bf16):
+    """hf:models/llama/modeling_llama.py:113-127: inv_freq / freqs in fp32, cos & sin cast to the activation dtype."""
     inv_freq = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.int64).to(torch.float32) / hd))
     freqs = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv_freq[None, :]
-    return freqs.cos().to(bf16).to(device).contiguous(), freqs.sin().to(bf16).to(device).contiguous()
+    return freqs.cos().to(dtype).to(device).contiguous(), freqs.sin().to(dtype).to(device).contiguous()
 
 
 class Linear:
@@ -104,7 +104,7 @@ class LlamaStack:
     def _tables(self, T):
         if self.cos is None or self.cos.shape[0] < T:
             n = max(T, self.cfg.get('max_position_embeddings', 0) or T)
-            self.cos, self.sin = rope_tables(n, self.cfg['head_dim'], self.cfg['rope_theta'], self.store.device)
+            self.cos, self.sin = rope_tables(n, self.cfg['head_dim'], self.cfg['rope_theta'], self.store.device, self.store.dtype)
 
     def forward(self, x, N, T, start, pos, save, kv_sink=None):
         c, P = self.cfg, self.store.p
@@ -159,7 +159,7 @@ class LlamaStack:
     @staticmethod
     def _attn_out(x, real_rows, width):
         # pad rows (Mp > N*T) are never written by the attention kernel: they must read as zeros
-        return None if x.shape[0] == real_rows else torch.zeros((x.shape[0], width), dtype=bf16, device=x.device)
+        return None if x.shape[0] == real_rows else torch.zeros((x.shape[0], width), dtype=x.dtype, device=x.device)
 
     def backward(self, dres, N, T, start, pos, on_layer_done=None):
         """dres: gradient of the residual stream after the last layer [Mp, h]; updated in place and returned
@@ -250,7 +250,7 @@ class ClipVisionTower:
         n = pixel_values.shape[0]
         h, H = c['hidden_size'], c['num_heads']
         hd, eps, T = h // H, c['ln_eps'], self.G2 + 1
-        col = ops.patch_im2col(pixel_values.contiguous(), c['patch_size'], self.Kp)
+        col = ops.patch_im2col(pixel_values.contiguous(), c['patch_size'], self.Kp, self.store.dtype)
         pe = ops.gemm(col, P[self.patch_w])
         x = ops.clip_embed(pe, P[self.cls], P[self.pos], n, self.G2)
         x, _, _ = ops.layernorm_fwd(x, P[self.pre_w], P[self.pre_b], eps, want_stats=False)
@@ -393,9 +393,10 @@ class NativeCausalLM:
 
     kind = 'base'
 
-    def __init__(self, cfg: dict, device, trainable: bool = True):
+    def __init__(self, cfg: dict, device, trainable: bool = True, dtype=bf16):
         self.cfg, self.device, self.trainable = cfg, torch.device(device), trainable
-        self.store = ParamStore(device)
+        self.dtype = dtype          # bf16 = production; float32 = parity mode (include/aa_hip_f32.h kernels)
+        self.store = ParamStore(device, dtype)
         self.training = trainable
         self._ctx = None
         self._zero_row = None
@@ -425,7 +426,7 @@ class NativeCausalLM:
 
     def finalize(self):
         self.store.allocate()
-        self._zero_row = torch.zeros((1, self.hidden_size), dtype=bf16, device=self.device)
+        self._zero_row = torch.zeros((1, self.hidden_size), dtype=self.dtype, device=self.device)
 
     def init_training(self):
         self.store.init_training()
@@ -502,8 +503,8 @@ class NativeLlava(NativeCausalLM):
     kind = 'llava'
 
     def __init__(self, cfg, device, trainable=True, freeze_mm_proj=False, freeze_language_model=False,
-                 freeze_vision_tower=True, head='lm'):
-        super().__init__(cfg, device, trainable)
+                 freeze_vision_tower=True, head='lm', dtype=bf16):
+        super().__init__(cfg, device, trainable, dtype)
         self.head_kind = head
         if not freeze_vision_tower and trainable:
             raise NotImplementedError('training the CLIP vision tower is not built (the reference default freezes '
@@ -554,7 +555,7 @@ class NativeLlava(NativeCausalLM):
             vfeat = image_features if image_features is not None else self.vision.forward(pixel_values)
             n_feat = vfeat.shape[0]
             if n_feat % 64:  # rows are the contraction dim of the projector dW GEMMs (K % 64); pad rows are zero
-                vfeat = torch.cat([vfeat, torch.zeros((_pad64(n_feat) - n_feat, vfeat.shape[1]), dtype=bf16, device=vfeat.device)])
+                vfeat = torch.cat([vfeat, torch.zeros((_pad64(n_feat) - n_feat, vfeat.shape[1]), dtype=vfeat.dtype, device=vfeat.device)])
             f1 = self.proj1.fwd(vfeat)
             a1 = ops.act_fwd(f1, ops.ACT_GELU)
             feat = self.proj2.fwd(a1)
@@ -581,7 +582,7 @@ class NativeLlava(NativeCausalLM):
         dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done)
         G = self.store.g
         want_feat = cx['slot'] is not None and self.train_proj
-        dfeat = torch.zeros((cx['vfeat'].shape[0], self.hidden_size), dtype=bf16, device=self.device) if want_feat else None
+        dfeat = torch.zeros((cx['vfeat'].shape[0], self.hidden_size), dtype=self.dtype, device=self.device) if want_feat else None
         if self.train_lm or want_feat:
             ops.embed_bwd(cx['ids'], dx, self.cfg['text']['vocab_size'], slot=cx['slot'],
                           dE=G.get(self.embed) if self.train_lm else None, dfeat=dfeat)
@@ -599,8 +600,8 @@ class NativeLlama(NativeCausalLM):
 
     kind = 'llama'
 
-    def __init__(self, cfg, device, trainable=True, head='lm'):
-        super().__init__(cfg, device, trainable)
+    def __init__(self, cfg, device, trainable=True, head='lm', dtype=bf16):
+        super().__init__(cfg, device, trainable, dtype)
         self.head_kind = head
         self.hidden_size = cfg['hidden_size']
         st = self.store
@@ -738,8 +739,8 @@ class NativeOPT(NativeCausalLM):
 
     kind = 'opt'
 
-    def __init__(self, cfg, device, trainable=True, head='lm'):
-        super().__init__(cfg, device, trainable)
+    def __init__(self, cfg, device, trainable=True, head='lm', dtype=bf16):
+        super().__init__(cfg, device, trainable, dtype)
         self.head_kind = head
         h = cfg['hidden_size']
         self.hidden_size = h
@@ -802,12 +803,13 @@ class NativeOPT(NativeCausalLM):
                           dE=G[self.embed], dP=G[self.pos_emb])
 
 
-def build_model(cfg: dict, device, trainable=True, head='lm', **freeze):
-    """head='lm': causal LM (actor / reference); head='score': reward / critic model with a score head."""
+def build_model(cfg: dict, device, trainable=True, head='lm', dtype=bf16, **freeze):
+    """head='lm': causal LM (actor / reference); head='score': reward / critic model with a score head.
+    dtype=torch.float32 selects the fp32 parity mode (weights, activations and gradients fp32)."""
     if cfg['kind'] == 'llava':
-        return NativeLlava(cfg, device, trainable, head=head, **freeze)
+        return NativeLlava(cfg, device, trainable, head=head, dtype=dtype, **freeze)
     if cfg['kind'] == 'opt':
-        return NativeOPT(cfg, device, trainable, head=head)
+        return NativeOPT(cfg, device, trainable, head=head, dtype=dtype)
     if cfg['kind'] == 'llama':
-        return NativeLlama(cfg, device, trainable, head=head)
+        return NativeLlama(cfg, device, trainable, head=head, dtype=dtype)
     raise ValueError(f"no native model for kind {cfg['kind']!r}")

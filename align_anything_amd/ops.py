@@ -15,6 +15,18 @@ GEMM_A_T, GEMM_B_N, GEMM_OUT_F32, GEMM_ACCUM = 1, 2, 4, 8
 ACT_CODES = {None: 0, 'none': 0, 'gelu': 1, 'quick_gelu': 2, 'relu': 3, 'silu': 4}
 
 bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+def _sfx(t: torch.Tensor, name: str) -> str:
+    """'' for the bf16 production kernels, '_f32' for the fp32 parity-mode twins (include/aa_hip_f32.h)."""
+    if not t.is_cuda:
+        raise RuntimeError(f'{name}: tensor must live on the GPU (the hot path has no CPU fallback)')
+    if t.dtype == bf16:
+        return ''
+    if t.dtype == f32:
+        return '_f32'
+    raise RuntimeError(f'{name}: expected bfloat16 or float32 activations, got {t.dtype}')
 
 
 def stream() -> int:
@@ -41,7 +53,8 @@ def _row_major(t: torch.Tensor, name: str):
 def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=False, out_f32=False,
          accumulate=False):
     """C[M,N] (+)= op(A) @ op(B)^T-ish:  a is [M,K] (or [K,M] when a_t), b is [N,K] (or [K,N] when b_n)."""
-    _chk(a, bf16, 'gemm.a'); _chk(b, bf16, 'gemm.b')
+    sfx = _sfx(a, 'gemm.a')
+    _chk(b, a.dtype, 'gemm.b')
     _row_major(a, 'gemm.a'); _row_major(b, 'gemm.b')
     if a_t:
         K, M = a.shape
@@ -54,7 +67,7 @@ def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=Fals
     if K != Kb:
         raise RuntimeError(f'gemm: contraction mismatch {K} vs {Kb}')
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else bf16, device=a.device)
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
     else:
         _row_major(out, 'gemm.out')
         if tuple(out.shape) != (M, N):
@@ -65,10 +78,12 @@ def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=Fals
     prof = GEMM_PROF
     if prof is not None:
         e0 = event_record()
-    call('aa_gemm_bf16', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0),
-         out.stride(0), _p(bias), _p(residual), ldr, int(act), flags, stream())
+    if sfx and out.dtype != f32:
+        raise RuntimeError('gemm: fp32 operands need an fp32 output')
+    call('aa_gemm_f32' if sfx else 'aa_gemm_bf16', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0),
+         b.stride(0), out.stride(0), _p(bias), _p(residual), ldr, int(act), flags, stream())
     if prof is not None:
-        prof.append((e0, event_record(), 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N))
+        prof.append((e0, event_record(), 2.0 * M * N * K, float(a.element_size()) * (M * K + N * K) + out.element_size() * M * N))
     return out
 
 
@@ -126,7 +141,7 @@ def rmsnorm_fwd(x, w, eps, out=None, rstd=None):
     rows, h = x.shape
     out = torch.empty_like(x) if out is None else out
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if rstd is None else rstd
-    call('aa_rmsnorm_fwd', x.data_ptr(), w.data_ptr(), out.data_ptr(), rstd.data_ptr(), rows, h, float(eps), stream())
+    call('aa_rmsnorm_fwd' + _sfx(x, 'rmsnorm_fwd'), x.data_ptr(), w.data_ptr(), out.data_ptr(), rstd.data_ptr(), rows, h, float(eps), stream())
     return out, rstd
 
 
@@ -134,7 +149,7 @@ def rmsnorm_bwd(dy, x, w, rstd, dw, dx=None, add_to_dx=False):
     rows, h = x.shape
     dx = torch.empty_like(x) if dx is None else dx
     ws = _norm_ws(x.device, h, 1) if dw is not None else None
-    call('aa_rmsnorm_bwd', dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dw),
+    call('aa_rmsnorm_bwd' + _sfx(x, 'rmsnorm_bwd'), dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dw),
          _p(ws), NORM_WS_ROWS, rows, h, int(add_to_dx), stream())
     return dx
 
@@ -146,7 +161,7 @@ def layernorm_fwd(x, w, b, eps, out=None, want_stats=True):
     if want_stats:
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    call('aa_layernorm_fwd', x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), _p(mean), _p(rstd),
+    call('aa_layernorm_fwd' + _sfx(x, 'layernorm_fwd'), x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), _p(mean), _p(rstd),
          rows, h, float(eps), stream())
     return out, mean, rstd
 
@@ -155,7 +170,7 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dx=None, add_to_dx=False):
     rows, h = x.shape
     dx = torch.empty_like(x) if dx is None else dx
     ws = _norm_ws(x.device, h, 2) if (dw is not None or db is not None) else None
-    call('aa_layernorm_bwd', dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+    call('aa_layernorm_bwd' + _sfx(x, 'layernorm_bwd'), dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
          dx.data_ptr(), _p(dw), _p(db), _p(ws), NORM_WS_ROWS, rows, h, int(add_to_dx), stream())
     return dx
 
@@ -163,7 +178,7 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dx=None, add_to_dx=False):
 def rowdot_fwd(x, w):
     rows, h = x.shape
     out = torch.empty(rows, dtype=torch.float32, device=x.device)
-    call('aa_rowdot_fwd', x.data_ptr(), w.data_ptr(), out.data_ptr(), rows, h, stream())
+    call('aa_rowdot_fwd' + _sfx(x, 'rowdot_fwd'), x.data_ptr(), w.data_ptr(), out.data_ptr(), rows, h, stream())
     return out
 
 
@@ -171,7 +186,7 @@ def rowdot_bwd(dy, x, w, dw):
     rows, h = x.shape
     dx = torch.empty_like(x)
     ws = _norm_ws(x.device, h, 1) if dw is not None else None
-    call('aa_rowdot_bwd', dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dw), _p(ws), NORM_WS_ROWS,
+    call('aa_rowdot_bwd' + _sfx(x, 'rowdot_bwd'), dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dw), _p(ws), NORM_WS_ROWS,
          rows, h, stream())
     return dx
 
@@ -179,7 +194,7 @@ def rowdot_bwd(dy, x, w, dw):
 # ------------------------------------------------------------------ pointwise
 def rope_(buf, col0, nheads, hd, pos, cos_t, sin_t, inverse=False):
     rows = buf.shape[0]
-    call('aa_rope_inplace', buf.data_ptr(), buf.stride(0), int(col0), int(nheads), int(hd), pos.data_ptr(),
+    call('aa_rope_inplace' + _sfx(buf, 'rope_'), buf.data_ptr(), buf.stride(0), int(col0), int(nheads), int(hd), pos.data_ptr(),
          cos_t.data_ptr(), sin_t.data_ptr(), rows, int(inverse), stream())
     return buf
 
@@ -187,33 +202,33 @@ def rope_(buf, col0, nheads, hd, pos, cos_t, sin_t, inverse=False):
 def swiglu_fwd(gate_up, out=None):
     M, F2 = gate_up.shape
     F = F2 // 2
-    out = torch.empty((M, F), dtype=bf16, device=gate_up.device) if out is None else out
-    call('aa_swiglu_fwd', gate_up.data_ptr(), out.data_ptr(), M, F, stream())
+    out = torch.empty((M, F), dtype=gate_up.dtype, device=gate_up.device) if out is None else out
+    call('aa_swiglu_fwd' + _sfx(gate_up, 'swiglu_fwd'), gate_up.data_ptr(), out.data_ptr(), M, F, stream())
     return out
 
 
 def swiglu_bwd(gate_up, dact, out=None):
     M, F2 = gate_up.shape
     out = torch.empty_like(gate_up) if out is None else out
-    call('aa_swiglu_bwd', gate_up.data_ptr(), dact.data_ptr(), out.data_ptr(), M, F2 // 2, stream())
+    call('aa_swiglu_bwd' + _sfx(gate_up, 'swiglu_bwd'), gate_up.data_ptr(), dact.data_ptr(), out.data_ptr(), M, F2 // 2, stream())
     return out
 
 
 def act_fwd(x, act, out=None):
     out = torch.empty_like(x) if out is None else out
-    call('aa_act_fwd', x.data_ptr(), out.data_ptr(), x.numel(), int(act), stream())
+    call('aa_act_fwd' + _sfx(x, 'act_fwd'), x.data_ptr(), out.data_ptr(), x.numel(), int(act), stream())
     return out
 
 
 def act_bwd(pre, dy, act, out=None):
     out = torch.empty_like(pre) if out is None else out
-    call('aa_act_bwd', pre.data_ptr(), dy.data_ptr(), out.data_ptr(), pre.numel(), int(act), stream())
+    call('aa_act_bwd' + _sfx(pre, 'act_bwd'), pre.data_ptr(), dy.data_ptr(), out.data_ptr(), pre.numel(), int(act), stream())
     return out
 
 
 def add(a, b, out=None):
     out = torch.empty_like(a) if out is None else out
-    call('aa_add', a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), stream())
+    call('aa_add' + _sfx(a, 'add'), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), stream())
     return out
 
 
@@ -229,15 +244,15 @@ def image_slot_index(ids_flat, image_token_id):
 def embed_fwd(ids_flat, E, slot=None, feat=None, pos=None, P=None):
     n = ids_flat.numel()
     vocab, h = E.shape
-    out = torch.empty((n, h), dtype=bf16, device=E.device)
-    call('aa_embed_fwd', ids_flat.data_ptr(), _p(slot), E.data_ptr(), _p(feat), _p(pos), _p(P), out.data_ptr(),
+    out = torch.empty((n, h), dtype=E.dtype, device=E.device)
+    call('aa_embed_fwd' + _sfx(E, 'embed_fwd'), ids_flat.data_ptr(), _p(slot), E.data_ptr(), _p(feat), _p(pos), _p(P), out.data_ptr(),
          n, h, vocab, stream())
     return out
 
 
 def embed_bwd(ids_flat, dx, vocab, slot=None, pos=None, dE=None, dfeat=None, dP=None):
     n, h = dx.shape
-    call('aa_embed_bwd', ids_flat.data_ptr(), _p(slot), _p(pos), dx.data_ptr(), _p(dE), _p(dfeat), _p(dP), n, h,
+    call('aa_embed_bwd' + _sfx(dx, 'embed_bwd'), ids_flat.data_ptr(), _p(slot), _p(pos), dx.data_ptr(), _p(dE), _p(dfeat), _p(dP), n, h,
          int(vocab), stream())
 
 
@@ -246,33 +261,33 @@ def transpose(x, out=None, pad_cols_to=None):
     R, C = x.shape
     if out is None:
         Rp = R if pad_cols_to is None else pad_cols_to
-        out = torch.zeros((C, Rp), dtype=bf16, device=x.device) if Rp != R else \
-            torch.empty((C, R), dtype=bf16, device=x.device)
-    call('aa_transpose_bf16', x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, C, stream())
+        out = torch.zeros((C, Rp), dtype=x.dtype, device=x.device) if Rp != R else \
+            torch.empty((C, R), dtype=x.dtype, device=x.device)
+    call('aa_transpose_f32' if _sfx(x, 'transpose') else 'aa_transpose_bf16', x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, C, stream())
     return out
 
 
 def colsum_(x, out_f32):
     R, C = x.shape
-    call('aa_colsum_bf16', x.data_ptr(), x.stride(0), R, C, out_f32.data_ptr(), stream())
+    call('aa_colsum_f32' if _sfx(x, 'colsum_') else 'aa_colsum_bf16', x.data_ptr(), x.stride(0), R, C, out_f32.data_ptr(), stream())
     return out_f32
 
 
-def patch_im2col(pixels, patch, Kp):
+def patch_im2col(pixels, patch, Kp, dtype=bf16):
     n_img, ch, H, W = pixels.shape
     G = H // patch
-    out = torch.empty((n_img * G * G, Kp), dtype=bf16, device=pixels.device)
+    out = torch.empty((n_img * G * G, Kp), dtype=dtype, device=pixels.device)
     dt = 0 if pixels.dtype == bf16 else 1
     if pixels.dtype not in (bf16, torch.float32):
         raise RuntimeError(f'patch_im2col: pixel dtype {pixels.dtype} not supported')
-    call('aa_patch_im2col', pixels.data_ptr(), dt, out.data_ptr(), n_img, ch, H, int(patch), int(Kp), stream())
+    call('aa_patch_im2col' + _sfx(out, 'patch_im2col'), pixels.data_ptr(), dt, out.data_ptr(), n_img, ch, H, int(patch), int(Kp), stream())
     return out
 
 
 def clip_embed(patch_emb, cls, pos, n_img, G2):
     h = patch_emb.shape[1]
-    out = torch.empty((n_img * (G2 + 1), h), dtype=bf16, device=patch_emb.device)
-    call('aa_clip_embed', patch_emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), n_img, G2, h, stream())
+    out = torch.empty((n_img * (G2 + 1), h), dtype=patch_emb.dtype, device=patch_emb.device)
+    call('aa_clip_embed' + _sfx(patch_emb, 'clip_embed'), patch_emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), n_img, G2, h, stream())
     return out
 
 
@@ -285,16 +300,16 @@ def f32_to_bf16(x, out=None):
 # ------------------------------------------------------------------ attention
 def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None):
     """q/k/v: 2-D views [N*T, >=H*hd] (column slices of the fused qkv buffer are fine)."""
-    out = torch.empty((N * T, H * hd), dtype=bf16, device=q.device) if out is None else out
+    out = torch.empty((N * T, H * hd), dtype=q.dtype, device=q.device) if out is None else out
     lse = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
-    call('aa_attn_fwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(start),
+    call('aa_attn_fwd' + _sfx(q, 'attn_fwd'), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(start),
          q.stride(0), k.stride(0), v.stride(0), out.stride(0), N, T, H, Hkv, hd, int(causal), float(scale), stream())
     return out, lse
 
 
 def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start=None):
     delta = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
-    call('aa_attn_bwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+    call('aa_attn_bwd' + _sfx(q, 'attn_bwd'), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
          delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(start), q.stride(0), k.stride(0),
          v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), N, T, H, Hkv, hd,
          int(causal), float(scale), stream())
@@ -423,7 +438,7 @@ def clip_coef(sumsq, max_norm, coef_out, norm_out=None):
 
 def adamw_flat_(master, m, v, p16, g, lr, beta1, beta2, eps, wd, step, gscale=1.0, clip=None):
     dt = 0 if g.dtype == bf16 else 1
-    call('aa_adamw_flat', master.data_ptr(), m.data_ptr(), v.data_ptr(), p16.data_ptr(), g.data_ptr(), dt,
+    call('aa_adamw_flat', master.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p16), g.data_ptr(), dt,
          master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), float(gscale),
          _p(clip), stream())
 

@@ -27,8 +27,13 @@ def is_no_decay(name: str) -> bool:
 
 
 class ParamStore:
-    def __init__(self, device):
+    def __init__(self, device, dtype=torch.bfloat16):
         self.device = torch.device(device)
+        # bfloat16 = production layout (bf16 weights + fp32 masters); float32 = parity mode: the model computes on the
+        # fp32 masters themselves (flat[g] IS master[g]), every gradient is fp32
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError(f'ParamStore dtype must be bfloat16 or float32, got {dtype}')
+        self.dtype = dtype
         self.specs: OrderedDict[str, dict] = OrderedDict()   # storage blocks
         self.alias: dict[str, tuple[str, int, tuple]] = {}    # hf name -> (block, row offset, shape)
         self.flat: dict[str, torch.Tensor] = {}
@@ -81,7 +86,7 @@ class ParamStore:
             offs[g] = o + (n + ALIGN - 1) // ALIGN * ALIGN
         self.sizes = offs
         for g, n in offs.items():
-            self.flat[g] = torch.zeros(n, dtype=torch.bfloat16, device=self.device)
+            self.flat[g] = torch.zeros(n, dtype=self.dtype, device=self.device)
         for name, s in self.specs.items():
             self.p[name] = self.flat[s['group']][s['offset']:s['offset'] + s['numel']].view(s['shape'])
 
@@ -90,9 +95,9 @@ class ParamStore:
         for g, n in self.sizes.items():
             if g == 'frozen':
                 continue
-            gd = torch.bfloat16 if g == 'mat' else torch.float32
+            gd = torch.bfloat16 if (g == 'mat' and self.dtype == torch.bfloat16) else torch.float32
             self.gflat[g] = torch.zeros(n, dtype=gd, device=self.device)
-            self.master[g] = self.flat[g].to(torch.float32)
+            self.master[g] = self.flat[g] if self.dtype == torch.float32 else self.flat[g].to(torch.float32)
             self.m[g] = torch.zeros(n, dtype=torch.float32, device=self.device)
             self.v[g] = torch.zeros(n, dtype=torch.float32, device=self.device)
         for name, s in self.specs.items():
@@ -100,9 +105,10 @@ class ParamStore:
                 self.g[name] = self.gflat[s['group']][s['offset']:s['offset'] + s['numel']].view(s['shape'])
 
     def zero_grad(self):
-        # 'mat' gradients are fully overwritten by the dW GEMMs each step; fp32 groups are accumulated into
+        # bf16 'mat' gradients are fully overwritten by the dW GEMMs each step; fp32 gradient buffers (emb / vec, and
+        # every group in the fp32 parity mode) are accumulated into (Linear.dw: accumulate iff the target is fp32)
         for g, t in self.gflat.items():
-            if g != 'mat':
+            if t.dtype == torch.float32:
                 t.zero_()
 
     def trainable_groups(self):
@@ -141,15 +147,16 @@ class ParamStore:
             if pad_cols and hf_name in pad_cols:  # zero-padded K (CLIP patch embedding 588 -> 640)
                 src = src.reshape(src.shape[0], -1)
                 dst.zero_()
-                dst[:, :src.shape[1]].copy_(src.to(torch.bfloat16))
+                dst[:, :src.shape[1]].copy_(src.to(self.dtype))
             else:
                 if tuple(src.shape) != tuple(dst.shape):
                     raise RuntimeError(f'{hf_name}: checkpoint shape {tuple(src.shape)} != {tuple(dst.shape)}')
-                dst.copy_(src.to(torch.bfloat16))
+                dst.copy_(src.to(self.dtype))
         if strict and missing:
             raise RuntimeError(f'missing keys in checkpoint: {missing[:8]}{"..." if len(missing) > 8 else ""}')
         for g in self.master:
-            self.master[g].copy_(self.flat[g])
+            if self.master[g] is not self.flat[g]:
+                self.master[g].copy_(self.flat[g])
         return missing
 
     def state_dict(self, unpad: dict | None = None) -> dict:

@@ -119,3 +119,15 @@ def pad_rows(flat_2d: torch.Tensor, rows_pad: int) -> torch.Tensor:
     out = torch.zeros(rows_pad, dtype=torch.float32, device=flat_2d.device)
     out[:flat_2d.numel()] = flat_2d.reshape(-1)
     return out
+
+
+def compute_dtype(name):
+    """'bf16' | 'fp32' (or a torch dtype) -> torch dtype of weights/activations on the native path."""
+    if isinstance(name, torch.dtype):
+        if name in (torch.bfloat16, torch.float32):
+            return name
+        raise ValueError(f'compute dtype {name} not supported (bfloat16, float32)')
+    table = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'fp32': torch.float32, 'float32': torch.float32}
+    if str(name).lower() not in table:
+        raise ValueError(f'compute dtype {name!r} not supported (bf16, fp32)')
+    return table[str(name).lower()]

@@ -21,14 +21,17 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import build_window, cfg_get, flat_to_padded, get_all_reduce_mean
+from .common import build_window, cfg_get, compute_dtype, flat_to_padded, get_all_reduce_mean
 
 
 class DPOTrainer:
     def __init__(self, cfgs, ds_cfgs=None, *, model_cfg: dict | None = None, policy_state=None, reference_state=None,
                  train_dataloader=None, tokenizer=None, device='cuda:0', share_vision_tower=True,
-                 emulate_bf16_logp=False):
+                 emulate_bf16_logp=False, dtype=None):
         self.cfgs, self.ds_train_cfgs = cfgs, ds_cfgs
+        # compute dtype: bf16 (the reference's `bf16: True`, configs/train/*/dpo.yaml) or fp32 = parity mode that
+        # tracks the reference's fp32 CPU trainer (include/aa_hip_f32.h); also selectable as train_cfgs.compute_dtype
+        self.dtype = compute_dtype(dtype if dtype is not None else cfg_get(cfgs, 'train_cfgs.compute_dtype', 'bf16'))
         self.device = torch.device(device)
         self.model_cfg = model_cfg
         self.train_dataloader, self.eval_dataloader = train_dataloader, None
@@ -62,8 +65,8 @@ class DPOTrainer:
             freeze = dict(freeze_mm_proj=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_mm_proj', False)),
                           freeze_language_model=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_language_model', False)),
                           freeze_vision_tower=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_vision_tower', True)))
-        self.policy = build_model(self.model_cfg, self.device, trainable=True, **freeze)
-        self.reference = build_model(self.model_cfg, self.device, trainable=False)
+        self.policy = build_model(self.model_cfg, self.device, trainable=True, dtype=self.dtype, **freeze)
+        self.reference = build_model(self.model_cfg, self.device, trainable=False, dtype=self.dtype)
         if policy_state is not None:
             self.policy.load_state_dict(policy_state)
             self.reference.load_state_dict(reference_state if reference_state is not None else policy_state)

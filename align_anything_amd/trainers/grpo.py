@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import build_span_window, cfg_get, get_all_reduce_mean, pad_rows
+from .common import build_span_window, cfg_get, compute_dtype, get_all_reduce_mean, pad_rows
 
 
 class GRPOTrainer:
@@ -30,8 +30,9 @@ class GRPOTrainer:
         self.pad_token_id = int(cfg_get(cfgs, 'model_cfgs.pad_token_id', 0))
         self.eos_token_id = int(cfg_get(cfgs, 'model_cfgs.eos_token_id', 2))
         self.reward_fn = reward_fn
-        actor = build_model(model_cfg, device, trainable=True)
-        ref = build_model(model_cfg, device, trainable=False)
+        dt = compute_dtype(t('compute_dtype', 'bf16'))   # fp32 = parity mode (sequences / rewards must then be injected)
+        actor = build_model(model_cfg, device, trainable=True, dtype=dt)
+        ref = build_model(model_cfg, device, trainable=False, dtype=dt)
         if actor_state is not None:
             actor.load_state_dict(actor_state)
         if reference_state is not None or actor_state is not None:
@@ -45,7 +46,7 @@ class GRPOTrainer:
         self.actor_reference_model = NativeEngine(ref, trainable=False)
         self.reward_model = None
         if reward_fn is None:
-            reward = build_model(reward_model_cfg or model_cfg, device, trainable=False, head='score')
+            reward = build_model(reward_model_cfg or model_cfg, device, trainable=False, head='score', dtype=dt)
             if reward_state is not None:
                 reward.load_state_dict(reward_state)
             self.reward_model = NativeEngine(reward, trainable=False)

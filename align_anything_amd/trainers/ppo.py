@@ -58,7 +58,7 @@ def gather_log_probabilities(logits: torch.Tensor, labels: torch.Tensor) -> torc
 
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import build_span_window, cfg_get, get_all_reduce_max, get_all_reduce_mean, pad_rows
+from .common import build_span_window, cfg_get, compute_dtype, get_all_reduce_max, get_all_reduce_mean, pad_rows
 
 
 class PPOTrainer(PPOMath):
@@ -74,10 +74,11 @@ class PPOTrainer(PPOMath):
                          clip_range_ratio=float(t('clip_range_ratio', 0.2)), clip_range_value=float(t('clip_range_value', 5.0)))
         self.cfgs, self.device = cfgs, torch.device(device)
         rcfg = reward_model_cfg or model_cfg
-        actor = build_model(model_cfg, device, trainable=True)
-        ref = build_model(model_cfg, device, trainable=False)
-        reward = build_model(rcfg, device, trainable=False, head='score')
-        critic = build_model(rcfg, device, trainable=True, head='score')
+        dt = compute_dtype(t('compute_dtype', 'bf16'))   # fp32 = parity mode for the update phase (rollouts need bf16)
+        actor = build_model(model_cfg, device, trainable=True, dtype=dt)
+        ref = build_model(model_cfg, device, trainable=False, dtype=dt)
+        reward = build_model(rcfg, device, trainable=False, head='score', dtype=dt)
+        critic = build_model(rcfg, device, trainable=True, head='score', dtype=dt)
         if actor_state is not None:
             actor.load_state_dict(actor_state)
             ref.load_state_dict(actor_state)

@@ -8,7 +8,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import cfg_get, get_all_reduce_mean, pad64
+from .common import cfg_get, compute_dtype, get_all_reduce_mean, pad64
 
 
 class RMTrainer:
@@ -16,7 +16,7 @@ class RMTrainer:
         t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
         self.cfgs, self.device = cfgs, torch.device(device)
         self.regularization = float(t('regularization', 0.001))
-        module = build_model(model_cfg, device, trainable=True, head='score')
+        module = build_model(model_cfg, device, trainable=True, head='score', dtype=compute_dtype(t('compute_dtype', 'bf16')))
         if state is not None:
             module.load_state_dict(state)
         total = int(t('total_training_steps', 1))

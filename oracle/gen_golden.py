@@ -16,6 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import _shim  # noqa: E402
+from oracle.synthetic import opt125m_config1  # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
@@ -289,6 +290,61 @@ def gen_grpo():
     print('grpo_tiny.npz loss', out['train/loss'], 'reward', out['train/reward'])
 
 
+def gen_opt125m_curve(threads=8, alt_threads=3):
+    """The 'loss curves matching reference to 1e-4' target of BASELINE.json: drive the reference's unmodified
+    DPOTrainer.train_step (trainers/text_to_text/dpo.py:205-237) for 64 steps, fp32, on config 1, with the DeepSpeed
+    engine replaced by torch.optim.AdamW(fp32, betas .9/.95, eps 1e-8) over the reference's own parameter groups
+    (utils/tools.py:241-270) + clip_grad_norm_(1.0) + HF cosine schedule with 3 % warm-up.
+
+    Runs twice: with `threads` CPU threads (the fixture curve `metrics`) and with `alt_threads` (`metrics_3threads`), the
+    only difference being the fp32 summation order inside torch's CPU GEMMs -- the spread between the two is the
+    reference's own reproducibility floor, which tests/test_f32_gpu.py holds the native curve to."""
+    import time
+    from transformers import get_scheduler
+    from align_anything.trainers.text_to_text.dpo import DPOTrainer
+    import align_anything.trainers.text_to_text.dpo as dpo_mod
+    from align_anything.utils.tools import dict_to_namedtuple, get_optimizer_grouped_parameters
+    dpo_mod.get_all_reduce_mean = lambda x: x
+    keys = ['train/loss', 'train/reward', 'train/better_sample_reward', 'train/worse_sample_reward', 'train/reward_accuracy',
+            'train/reward_margin', 'train/lr']
+
+    def run(nthreads):
+        torch.set_num_threads(nthreads)
+        oc, policy, refm, batches = opt125m_config1()
+        steps = len(batches)
+        opt = torch.optim.AdamW(get_optimizer_grouped_parameters(policy, 0.05), lr=1e-6, betas=(0.9, 0.95), eps=1e-8)
+        sched = get_scheduler('cosine', opt, num_warmup_steps=int(0.03 * steps), num_training_steps=steps)
+
+        class Engine:
+            def __init__(self, m): self.module, self.optimizer = m, opt
+            def backward(self, loss): loss.backward()
+            def step(self):
+                torch.nn.utils.clip_grad_norm_(self.module.parameters(), 1.0)
+                opt.step(); sched.step(); opt.zero_grad(set_to_none=True)
+
+        tr = DPOTrainer.__new__(DPOTrainer)
+        tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+        tr.tokenizer = SimpleNamespace(pad_token_id=oc.pad_token_id)
+        tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+        tr.model, tr.reference_model = Engine(policy), SimpleNamespace(module=refm)
+        checksum = {n: float(p.double().sum()) for n, p in policy.state_dict().items()}
+        rows, t0 = [], time.time()
+        for i, b in enumerate(batches):
+            info = tr.train_step(b)
+            rows.append([info[k] for k in keys])
+            if i % 8 == 0:
+                print(f'[{nthreads} threads] step {i} loss {info["train/loss"]:.6f} lr {info["train/lr"]:.3e} ({time.time() - t0:.0f}s)', flush=True)
+        return np.array(rows, dtype=np.float64), checksum, batches
+
+    rows, checksum, batches = run(threads)
+    rows_alt, _, _ = run(alt_threads)
+    names = sorted(checksum)
+    np.savez_compressed(os.path.join(GOLD, 'opt125m_curve.npz'), metrics=rows, metrics_3threads=rows_alt, keys=np.array(keys),
+                        checksum_names=np.array(names), checksum=np.array([checksum[n] for n in names]),
+                        first_ids=batches[0]['input_ids'].numpy(), last_ids=batches[-1]['input_ids'].numpy())
+    print('opt125m_curve.npz', rows[:8, 0].round(5), 'reference self-deviation (threads)', np.abs(rows[:, 0] - rows_alt[:, 0]).max())
+
+
 if __name__ == '__main__':
     _shim.install()
     os.makedirs(GOLD, exist_ok=True)
@@ -296,3 +352,4 @@ if __name__ == '__main__':
     gen_llava_dpo()
     gen_opt_dpo()
     gen_grpo()
+    gen_opt125m_curve()
