@@ -353,6 +353,40 @@ def dpo_loss(pol_logp, ref_logp, seq_off, B, beta, want_grad=True):
     return out6, per, dlogp
 
 
+PREF_KINDS = {'simpo': 0, 'orpo': 1, 'kto': 2}
+
+
+def pair_slice_index(ids, mask, seq_off, B):
+    """Flat-row slice ranges of the reference's [diverge_index, end_index + 1) window slicing (simpo.py:64-77)."""
+    N, T = ids.shape
+    dev = ids.device
+    lo = torch.empty(N, dtype=torch.int32, device=dev)
+    hi = torch.empty(N, dtype=torch.int32, device=dev)
+    ln = torch.empty(N, dtype=torch.int32, device=dev)
+    keep = torch.empty(B, dtype=torch.uint8, device=dev)
+    ids = ids.contiguous(); mask = mask.to(torch.int64).contiguous()
+    call('aa_pair_slice_index', ids.data_ptr(), mask.data_ptr(), int(B), T, seq_off.data_ptr(), lo.data_ptr(), hi.data_ptr(),
+         ln.data_ptr(), keep.data_ptr(), stream())
+    return lo, hi, ln, keep
+
+
+def pref_loss(kind, pol_logp, ref_logp, lo, hi, ln, keep, B, beta, p1=0.0, p2=0.0, p3=0.0, want_grad=True):
+    dev = pol_logp.device
+    out7 = torch.empty(7, dtype=torch.float32, device=dev)
+    per = torch.empty((4, B), dtype=torch.float32, device=dev)
+    dlogp = torch.empty_like(pol_logp) if want_grad else None     # the kernel zero-fills it
+    call('aa_pref_loss_fwd_bwd', PREF_KINDS[kind], pol_logp.data_ptr(), _p(ref_logp), lo.data_ptr(), hi.data_ptr(),
+         ln.data_ptr(), keep.data_ptr(), int(B), pol_logp.numel(), float(beta), float(p1), float(p2), float(p3),
+         out7.data_ptr(), per.data_ptr(), _p(dlogp), stream())
+    return out7, per, dlogp
+
+
+def window_kl(pol_logp, ref_logp, rows, denom):
+    out = torch.empty(1, dtype=torch.float32, device=pol_logp.device)
+    call('aa_window_kl', pol_logp.data_ptr(), ref_logp.data_ptr(), int(rows), float(denom), out.data_ptr(), stream())
+    return out
+
+
 def rm_loss(end_scores, B, regularization, want_grad=True):
     out2 = torch.empty(2, dtype=torch.float32, device=end_scores.device)
     d = torch.empty_like(end_scores) if want_grad else None

@@ -25,6 +25,8 @@ from .common import build_window, cfg_get, compute_dtype, flat_to_padded, get_al
 
 
 class DPOTrainer:
+    uses_reference = True     # SimPO / ORPO (trainers/pref.py) never evaluate the reference model
+
     def __init__(self, cfgs, ds_cfgs=None, *, model_cfg: dict | None = None, policy_state=None, reference_state=None,
                  train_dataloader=None, tokenizer=None, device='cuda:0', share_vision_tower=True,
                  emulate_bf16_logp=False, dtype=None):
@@ -66,10 +68,11 @@ class DPOTrainer:
                           freeze_language_model=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_language_model', False)),
                           freeze_vision_tower=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_vision_tower', True)))
         self.policy = build_model(self.model_cfg, self.device, trainable=True, dtype=self.dtype, **freeze)
-        self.reference = build_model(self.model_cfg, self.device, trainable=False, dtype=self.dtype)
+        self.reference = build_model(self.model_cfg, self.device, trainable=False, dtype=self.dtype) if self.uses_reference else None
         if policy_state is not None:
             self.policy.load_state_dict(policy_state)
-            self.reference.load_state_dict(reference_state if reference_state is not None else policy_state)
+            if self.reference is not None:
+                self.reference.load_state_dict(reference_state if reference_state is not None else policy_state)
 
     def init_engines(self) -> None:
         """base/supervised_trainer.py:234-271 + dpo.py:114-120, with the native engine in DeepSpeed's place."""
@@ -85,7 +88,7 @@ class DPOTrainer:
                                   total_steps=total, warmup_steps=int(float(t('lr_warmup_ratio', 0.03)) * total),
                                   lr_scheduler_type=t('lr_scheduler_type', 'cosine'), trainable=True,
                                   gradient_accumulation_steps=gas)
-        self.reference_model = NativeEngine(self.reference, trainable=False)
+        self.reference_model = NativeEngine(self.reference, trainable=False) if self.reference is not None else None
 
     def init_logger(self) -> None:
         self.logger = None  # observability is out of scope; train() returns the metrics

@@ -90,6 +90,20 @@ int aa_completion_mask(const int64_t* tokens, long ld, int rows, int L, int64_t 
 int aa_grpo_loss_fwd_bwd(const float* logp, const float* ref_logp, const float* adv, const uint8_t* mask, int rows,
                          int L, float beta, float* row_scratch2, float* loss_out, float* dlogp, void* stream);
 
+/* Sibling preference losses on the same response-window log-probs: SimPO (trainers/text_to_text/simpo.py:41-108),
+ * ORPO (orpo.py:41-112), KTO (kto.py:83-160).  aa_pair_slice_index reproduces the reference's slice of the padded
+ * window tensor by ABSOLUTE positions [diverge_index, end_index + 1) as flat-row ranges lo/hi (int[2B]), the row lengths
+ * len = end_index + 1 and keep[i] = chosen/rejected rows differ (identical pairs are skipped, :64-65).
+ * aa_pref_loss_fwd_bwd: kind 0 SimPO (p1 = gamma), 1 ORPO, 2 KTO (p1 = scale_better, p2 = scale_worse, p3 = kl; needs
+ * ref_logp); out7 = loss, reward_accuracy, mean reward / better / worse / margin, #kept pairs; dlogp fp32[total_rows].
+ * aa_window_kl: kto.py:74-81, max(mean over the padded [2B, W] tensor of (logp - ref_logp), 0), denom = 2B * W. */
+int aa_pair_slice_index(const int64_t* ids, const int64_t* mask, int B, int T, const int* seq_off, int* lo, int* hi,
+                        int* len, uint8_t* keep, void* stream);
+int aa_pref_loss_fwd_bwd(int kind, const float* pol_logp, const float* ref_logp, const int* lo, const int* hi,
+                         const int* len, const uint8_t* keep, int B, int total_rows, float scale_coeff, float p1,
+                         float p2, float p3, float* out7, float* per_sample4B, float* dlogp, void* stream);
+int aa_window_kl(const float* pol_logp, const float* ref_logp, int rows, float denom, float* out, void* stream);
+
 /* ---- transformer blocks (what model(**batch).logits executes, dpo.py:128) -------------------- */
 /* torch nn.Linear / its backward: C[M,N] (+)= op(A) op(B), fp32 accumulate, fused bias/act/residual.
  * K % 64 == 0 (zero-pad), N % 4 == 0. */

@@ -225,6 +225,67 @@ def gen_opt_dpo():
     print('opt_tiny_dpo.npz loss', float(ld['loss']))
 
 
+def gen_pref():
+    """SimPO / ORPO / KTO: the reference's unmodified `loss` overrides (trainers/text_to_text/simpo.py:41-108,
+    orpo.py:41-112, kto.py:83-160) on the tiny OPT of opt_tiny_dpo.npz (weights are read back from that fixture, so
+    the GPU tests load them from there).  Batch: pair 0 shares a 31-token prompt and diverges INSIDE the window width,
+    pair 1 is identical (skipped by the reference), pair 2 is left-padded by different amounts (diverge index 0)."""
+    from transformers import OPTConfig, OPTForCausalLM
+    from align_anything.trainers.text_to_text.kto import KTOTrainer
+    from align_anything.trainers.text_to_text.orpo import ORPOTrainer
+    from align_anything.trainers.text_to_text.simpo import SimPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+
+    z = np.load(os.path.join(GOLD, 'opt_tiny_dpo.npz'))
+    bits = lambda a: torch.from_numpy(a.astype(np.int16)).view(torch.bfloat16).float()
+    oc = OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=320,
+                   max_position_embeddings=128, word_embed_proj_dim=128, dropout=0.0, attention_dropout=0.0, pad_token_id=1)
+    policy, refm = OPTForCausalLM(oc).eval(), OPTForCausalLM(oc).eval()
+    policy.load_state_dict({k[2:]: bits(z[k]) for k in z.files if k.startswith('w.')})
+    refm.load_state_dict({k[2:]: bits(z[k]) for k in z.files if k.startswith('r.')})
+    g = torch.Generator().manual_seed(29)
+    B, T = 3, 40
+    ids = torch.full((2 * B, T), 1, dtype=torch.long)
+    mask = torch.zeros((2 * B, T), dtype=torch.long)
+    for r, lp in enumerate((0, 0, 4, 0, 0, 1)):
+        ids[r, lp:] = torch.randint(3, 320, (T - lp,), generator=g)
+        mask[r, lp:] = 1
+    ids[3, :5] = ids[0, :5]            # pair 0: first 5 ids equal -> diverge_index 5, inside the window width (11)
+    ids[4] = ids[1]                    # pair 1: identical rows -> skipped
+    resp = [12, 9, 7, 10, 9, 12]
+    batch = {'input_ids': ids, 'attention_mask': mask, 'meta_info': {'response_lens': resp}}
+    out = {'input_ids': ids.numpy(), 'attention_mask': mask.numpy(), 'response_lens': np.array(resp), 'pad_token_id': np.array(1)}
+    hp = {'scale_coeff': 0.5, 'gamma': 0.3, 'scale_better': 1.0, 'scale_worse': 0.7}
+    for name, cls in (('simpo', SimPOTrainer), ('orpo', ORPOTrainer), ('kto', KTOTrainer)):
+        tr = cls.__new__(cls)
+        tr.cfgs = dict_to_namedtuple({'train_cfgs': hp})
+        tr.tokenizer = SimpleNamespace(pad_token_id=1)
+        tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+        tr.model, tr.reference_model = SimpleNamespace(module=policy), SimpleNamespace(module=refm)
+        if name == 'kto':
+            with torch.no_grad():   # kto.py:64-81 on this batch
+                kl = (tr.compute_log_probs(policy, batch) - tr.compute_log_probs(refm, batch)).mean()
+            tr.kl = max(kl, 0)
+            out['kto_kl'] = np.array(float(tr.kl))
+            out['kto_kl_raw'] = np.array(float(kl))
+        policy.zero_grad()
+        ld = tr.loss(batch)
+        ld['loss'].backward()
+        for k, v in ld.items():
+            out[f'{name}_{k}'] = v.detach().numpy()
+        for n, p in policy.named_parameters():
+            if n.endswith('layers.1.fc1.weight') or n.endswith('layers.0.self_attn.q_proj.weight') or n.endswith('final_layer_norm.weight') \
+                    or n.endswith('embed_tokens.weight'):
+                out[f'{name}_g.{n}'] = p.grad.numpy().copy()
+        print(name, 'loss', float(ld['loss']), 'kept pairs', ld['reward'].numel())
+    for k, v in hp.items():
+        out[k] = np.array(v)
+    with torch.no_grad():
+        out['seq_log_probs'] = tr.compute_log_probs(policy, batch).numpy()
+        out['ref_seq_log_probs'] = tr.compute_log_probs(refm, batch).numpy()
+    np.savez_compressed(os.path.join(GOLD, 'opt_tiny_pref.npz'), **out)
+
+
 def gen_grpo():
     """Drive the reference's unmodified GRPOTrainer.train_step (trainers/text_to_text/grpo.py:257-329) with a fake
     engine around a tiny HF OPT model, fixed 'generated' sequences and fixed rewards; record loss and gradients."""
@@ -351,5 +412,6 @@ if __name__ == '__main__':
     gen_rl_math()
     gen_llava_dpo()
     gen_opt_dpo()
+    gen_pref()
     gen_grpo()
     gen_opt125m_curve()

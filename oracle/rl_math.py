@@ -150,3 +150,79 @@ def grpo_loss(per_token_logps, ref_per_token_logps, rewards, B, G, completion_to
             mask[i, pos[0].item() + 1:] = 0
     mask = mask.to(per_token_loss.dtype)
     return (per_token_loss * mask).sum() / mask.sum(), adv.view(-1), mask
+
+
+def _pair_slices(better_ids, worse_ids, better_mask, worse_mask, i):
+    """simpo.py:64-77 (identical in orpo.py / kto.py): None for identical rows, else (better_slice, worse_slice,
+    better_length, worse_length) in ABSOLUTE positions -- applied by the callers to the padded window tensor."""
+    if torch.all(torch.eq(better_ids[i], worse_ids[i])).item():
+        return None
+    be = better_mask[i].nonzero()[-1].squeeze().item()
+    we = worse_mask[i].nonzero()[-1].squeeze().item()
+    d = (better_ids[i] != worse_ids[i]).nonzero()[0].squeeze().item()
+    return slice(d, be + 1), slice(d, we + 1), be + 1, we + 1
+
+
+def _pref_metrics(losses, br, wr):
+    br, wr = torch.stack(br), torch.stack(wr)
+    return {'loss': torch.stack(losses).mean(), 'reward': br + wr, 'better_sample_reward': br, 'worse_sample_reward': wr,
+            'reward_accuracy': (br > wr).float().mean(), 'reward_margin': br - wr}
+
+
+def simpo_loss(seq_logp, input_ids, attention_mask, scale_coeff, gamma):
+    """trainers/text_to_text/simpo.py:41-108 given the padded [2B, L-1] window log-probs."""
+    b, w = seq_logp.chunk(2, dim=0)
+    bi, wi = input_ids.chunk(2, dim=0)
+    bm, wm = attention_mask.chunk(2, dim=0)
+    losses, brs, wrs = [], [], []
+    for i in range(bi.size(0)):
+        sl = _pair_slices(bi, wi, bm, wm, i)
+        if sl is None:
+            continue
+        blr = b[i, sl[0]].sum(-1) / sl[2]
+        wlr = w[i, sl[1]].sum(-1) / sl[3]
+        losses.append(-F.logsigmoid(scale_coeff * (blr - wlr) - gamma))
+        brs.append(scale_coeff * blr.detach()); wrs.append(scale_coeff * wlr.detach())
+    return _pref_metrics(losses, brs, wrs)
+
+
+def orpo_loss(seq_logp, input_ids, attention_mask, scale_coeff):
+    """trainers/text_to_text/orpo.py:41-112."""
+    b, w = seq_logp.chunk(2, dim=0)
+    bi, wi = input_ids.chunk(2, dim=0)
+    bm, wm = attention_mask.chunk(2, dim=0)
+    losses, brs, wrs = [], [], []
+    for i in range(bi.size(0)):
+        sl = _pair_slices(bi, wi, bm, wm, i)
+        if sl is None:
+            continue
+        blr = b[i, sl[0]].sum(-1) / sl[2]
+        wlr = w[i, sl[1]].sum(-1) / sl[3]
+        log_odds = (blr - wlr) - (torch.log1p(-torch.exp(blr)) - torch.log1p(-torch.exp(wlr)))
+        losses.append(-blr + scale_coeff * -F.logsigmoid(log_odds))
+        brs.append(scale_coeff * blr.detach()); wrs.append(scale_coeff * wlr.detach())
+    return _pref_metrics(losses, brs, wrs)
+
+
+def kto_loss(seq_logp, ref_seq_logp, input_ids, attention_mask, scale_coeff, scale_better, scale_worse, kl):
+    """trainers/text_to_text/kto.py:83-160 (the minus in front of the worse term is the reference's)."""
+    b, w = seq_logp.chunk(2, dim=0)
+    rb, rw = ref_seq_logp.chunk(2, dim=0)
+    bi, wi = input_ids.chunk(2, dim=0)
+    bm, wm = attention_mask.chunk(2, dim=0)
+    losses, brs, wrs = [], [], []
+    for i in range(bi.size(0)):
+        sl = _pair_slices(bi, wi, bm, wm, i)
+        if sl is None:
+            continue
+        blr = b[i, sl[0]].sum(-1) - rb[i, sl[0]].sum(-1)
+        wlr = w[i, sl[1]].sum(-1) - rw[i, sl[1]].sum(-1)
+        losses.append(scale_better * (1 - torch.sigmoid(scale_coeff * (blr - kl)))
+                      - scale_worse * (1 - torch.sigmoid(scale_coeff * (kl - wlr))))
+        brs.append(scale_coeff * blr.detach()); wrs.append(scale_coeff * wlr.detach())
+    return _pref_metrics(losses, brs, wrs)
+
+
+def kto_kl(seq_logp, ref_seq_logp):
+    """kto.py:74-81: mean over the padded tensors, clamped at 0."""
+    return torch.clamp((seq_logp - ref_seq_logp).mean(), min=0.0)

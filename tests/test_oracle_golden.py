@@ -151,3 +151,27 @@ def test_grpo_oracle_matches_reference_train_step():
             n = k[2:]
             if n in sd:
                 assert rel_err(sd[n].grad, T(z[k])) < 2e-3, n
+
+
+def test_simpo_orpo_kto_oracle_matches_reference_losses():
+    """oracle/rl_math.py::{simpo,orpo,kto}_loss on the reference's own window log-probs vs what the reference's
+    unmodified SimPO/ORPO/KTO `loss` overrides returned (tests/golden/opt_tiny_pref.npz)."""
+    z = load_golden('opt_tiny_pref.npz')
+    lp, rlp = T(z['seq_log_probs']), T(z['ref_seq_log_probs'])
+    ids, mask = T(z['input_ids']), T(z['attention_mask'])
+    beta = float(z['scale_coeff'])
+    got = {'simpo': orl.simpo_loss(lp, ids, mask, beta, float(z['gamma'])),
+           'orpo': orl.orpo_loss(lp, ids, mask, beta),
+           'kto': orl.kto_loss(lp, rlp, ids, mask, beta, float(z['scale_better']), float(z['scale_worse']), float(z['kto_kl']))}
+    for name, ld in got.items():
+        for k, v in ld.items():
+            want = z[f'{name}_{k}']
+            assert v.shape == tuple(want.shape), (name, k)            # identical pair skipped -> 2 kept pairs
+            np.testing.assert_allclose(v.numpy(), want, rtol=1e-5, atol=1e-6, err_msg=f'{name} {k}')
+    assert abs(float(orl.kto_kl(lp, rlp)) - float(z['kto_kl'])) < 1e-7
+    # the model path too: oracle OPT -> window log-probs == the reference's compute_log_probs
+    zw = load_golden('opt_tiny_dpo.npz')
+    sd = {k: v for k, v in state_dict_from_golden(zw, 'w.').items() if k != 'lm_head.weight'}
+    logits = om.opt_logits(sd, tiny_opt_cfg(), ids, mask)
+    mine = orl.compute_log_probs(logits, ids, [int(r) for r in z['response_lens']], int(z['pad_token_id']))
+    np.testing.assert_allclose(mine.numpy(), z['seq_log_probs'], rtol=2e-4, atol=2e-4)
