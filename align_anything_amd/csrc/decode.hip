@@ -179,14 +179,46 @@ extern "C" int aa_attn_decode(const void* q, long ldq, const void* Kc, const voi
 
 // ------------------------------------------------------------------ token selection
 // greedy: first index of the row maximum (torch.argmax tie rule)
+// hf:generation/logits_process.py RepetitionPenaltyLogitsProcessor (applied to the fp32 scores before the warpers):
+// tokens already in the row's sequence (`seen` bitmap, prompt incl. its pad ids + everything generated) get
+// score < 0 ? score * penalty : score / penalty.
+__device__ __forceinline__ float penalised(const bf16_t* __restrict__ x, const uint8_t* __restrict__ seen, int i, float pen) {
+    float v = bf2f(x[i]);
+    if (seen && seen[i]) v = v < 0.f ? v * pen : v / pen;
+    return v;
+}
+
+// seen[row, ids[row, j]] = 1 for every j (ids outside [0, V) are ignored)
+__global__ __launch_bounds__(256) void mark_seen_kernel(const int64_t* __restrict__ ids, long ld, int rows, int L,
+                                                        uint8_t* __restrict__ seen, long ld_seen, int V) {
+    const long total = (long)rows * L;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long r = t / L;
+        const int64_t id = ids[r * ld + (t % L)];
+        if (id >= 0 && id < V) seen[r * ld_seen + id] = 1;
+    }
+}
+extern "C" int aa_mark_seen(const int64_t* ids, long ld, int rows, int L, uint8_t* seen, long ld_seen, int V,
+                            void* stream) {
+    AA_REQUIRE(rows >= 0 && L >= 0 && V > 0, "aa_mark_seen: bad shape rows=%d L=%d V=%d", rows, L, V);
+    if (rows == 0 || L == 0) return AA_OK;
+    const long total = (long)rows * L;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(mark_seen_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, ld, rows, L, seen, ld_seen, V);
+    AA_CHECK_LAUNCH("aa_mark_seen");
+    return AA_OK;
+}
+
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16_t* __restrict__ logits, long ld, int V,
+                                                          const uint8_t* __restrict__ seen_all, long ld_seen, float pen,
                                                           int64_t* __restrict__ out) {
     __shared__ float bv[256];
     __shared__ int bi[256];
     const bf16_t* x = logits + (long)blockIdx.x * ld;
+    const uint8_t* seen = seen_all ? seen_all + (long)blockIdx.x * ld_seen : nullptr;
     float best = -INFINITY; int idx = 0x7fffffff;
     for (int i = threadIdx.x; i < V; i += 256) {
-        const float v = bf2f(x[i]);
+        const float v = penalised(x, seen, i, pen);
         if (v > best || (v == best && i < idx)) { best = v; idx = i; }
     }
     bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
@@ -200,9 +232,12 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16_t* __restri
     }
     if (threadIdx.x == 0) out[blockIdx.x] = bi[0];
 }
-extern "C" int aa_argmax_rows(const void* logits, long ld, int rows, int V, int64_t* out, void* stream) {
+extern "C" int aa_argmax_rows(const void* logits, long ld, int rows, int V, const uint8_t* seen, long ld_seen,
+                              float repetition_penalty, int64_t* out, void* stream) {
     AA_REQUIRE(rows > 0 && V > 0, "aa_argmax_rows: bad shape rows=%d V=%d", rows, V);
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V, out);
+    AA_REQUIRE(repetition_penalty > 0.f, "aa_argmax_rows: repetition_penalty must be > 0");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
+                       seen, ld_seen, repetition_penalty, out);
     AA_CHECK_LAUNCH("aa_argmax_rows");
     return AA_OK;
 }
@@ -214,15 +249,17 @@ extern "C" int aa_argmax_rows(const void* logits, long ld, int rows, int V, int6
 __global__ __launch_bounds__(256) void sample_top_p_kernel(const bf16_t* __restrict__ logits, long ld, int V,
                                                            float inv_temp, float top_p,
                                                            const float* __restrict__ u,
+                                                           const uint8_t* __restrict__ seen_all, long ld_seen, float pen,
                                                            int64_t* __restrict__ out) {
     __shared__ float red[8];
     __shared__ float part[256];
     const bf16_t* x = logits + (long)blockIdx.x * ld;
+    const uint8_t* seen = seen_all ? seen_all + (long)blockIdx.x * ld_seen : nullptr;
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < V; i += 256) mx = fmaxf(mx, bf2f(x[i]) * inv_temp);
+    for (int i = threadIdx.x; i < V; i += 256) mx = fmaxf(mx, penalised(x, seen, i, pen) * inv_temp);
     mx = block_max<256>(mx, red);
     float z = 0.f;
-    for (int i = threadIdx.x; i < V; i += 256) z += expf(bf2f(x[i]) * inv_temp - mx);
+    for (int i = threadIdx.x; i < V; i += 256) z += expf(penalised(x, seen, i, pen) * inv_temp - mx);
     z = block_sum<256>(z, red);
     const float invz = 1.f / z;
     // bisection: largest tau with mass(p >= tau) >= top_p   (p in (0, 1], p_max = 1/z * 1)
@@ -232,7 +269,7 @@ __global__ __launch_bounds__(256) void sample_top_p_kernel(const bf16_t* __restr
             const float tau = 0.5f * (lo + hi);
             float ms = 0.f;
             for (int i = threadIdx.x; i < V; i += 256) {
-                const float p = expf(bf2f(x[i]) * inv_temp - mx) * invz;
+                const float p = expf(penalised(x, seen, i, pen) * inv_temp - mx) * invz;
                 ms += (p >= tau) ? p : 0.f;
             }
             ms = block_sum<256>(ms, red);
@@ -242,7 +279,7 @@ __global__ __launch_bounds__(256) void sample_top_p_kernel(const bf16_t* __restr
     const float tau = lo;
     float kept = 0.f;
     for (int i = threadIdx.x; i < V; i += 256) {
-        const float p = expf(bf2f(x[i]) * inv_temp - mx) * invz;
+        const float p = expf(penalised(x, seen, i, pen) * inv_temp - mx) * invz;
         kept += (p >= tau) ? p : 0.f;
     }
     kept = block_sum<256>(kept, red);
@@ -252,7 +289,7 @@ __global__ __launch_bounds__(256) void sample_top_p_kernel(const bf16_t* __restr
     const int b = threadIdx.x * per, e = min(V, b + per);
     float mine = 0.f;
     for (int i = b; i < e; ++i) {
-        const float p = expf(bf2f(x[i]) * inv_temp - mx) * invz;
+        const float p = expf(penalised(x, seen, i, pen) * inv_temp - mx) * invz;
         mine += (p >= tau) ? p : 0.f;
     }
     part[threadIdx.x] = mine;
@@ -268,7 +305,7 @@ __global__ __launch_bounds__(256) void sample_top_p_kernel(const bf16_t* __restr
         float c = part[0];
         int pick = -1, last_kept = -1;
         for (int i = b; i < e; ++i) {
-            const float p = expf(bf2f(x[i]) * inv_temp - mx) * invz;
+            const float p = expf(penalised(x, seen, i, pen) * inv_temp - mx) * invz;
             if (p >= tau) { last_kept = i; c += p; if (c > target) { pick = i; break; } }
         }
         if (pick < 0) pick = last_kept >= 0 ? last_kept : (e > b ? b : V - 1);
@@ -276,11 +313,13 @@ __global__ __launch_bounds__(256) void sample_top_p_kernel(const bf16_t* __restr
     }
 }
 extern "C" int aa_sample_top_p(const void* logits, long ld, int rows, int V, float temperature, float top_p,
-                               const float* uniform, int64_t* out, void* stream) {
+                               const float* uniform, const uint8_t* seen, long ld_seen, float repetition_penalty,
+                               int64_t* out, void* stream) {
     AA_REQUIRE(rows > 0 && V > 0, "aa_sample_top_p: bad shape rows=%d V=%d", rows, V);
+    AA_REQUIRE(repetition_penalty > 0.f, "aa_sample_top_p: repetition_penalty must be > 0");
     AA_REQUIRE(temperature > 0.f && top_p > 0.f && top_p <= 1.f, "aa_sample_top_p: temperature=%f / top_p=%f out of range", temperature, top_p);
     hipLaunchKernelGGL(sample_top_p_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
-                       1.f / temperature, top_p, uniform, out);
+                       1.f / temperature, top_p, uniform, seen, ld_seen, repetition_penalty, out);
     AA_CHECK_LAUNCH("aa_sample_top_p");
     return AA_OK;
 }

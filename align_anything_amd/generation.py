@@ -5,7 +5,7 @@ Prefill = the ordinary native forward with a KV sink; every later token is one p
 (csrc/decode.hip): skinny GEMMs, cache attention, norm, sampling.  HF semantics that are reproduced:
   * left-padded prompts; position ids derived from the attention mask (cumsum - 1), i.e. NOT the arange
     positions of the training forward (a reference quirk, SURVEY.md §8 a');
-  * TemperatureLogitsWarper / TopPLogitsWarper (repetition_penalty must be 1.0, the reference default);
+  * RepetitionPenaltyLogitsProcessor, then TemperatureLogitsWarper / TopPLogitsWarper;
   * finished rows keep emitting pad_token_id; generation stops when every row has produced EOS or the length
     cap (GenerationConfig.max_length = model_max_length) is reached; `synced_gpus` is not needed (pure DP).
 """
@@ -21,8 +21,8 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
              temperature=1.0, top_p=1.0, repetition_penalty=1.0, eos_token_id=None, pad_token_id=0,
              pixel_values=None, generator=None, sync_every=8, use_graph=False):
     """Returns sequences [N, T_prompt + n_new] (int64), right-padded with pad_token_id after EOS."""
-    if repetition_penalty != 1.0:
-        raise NotImplementedError('repetition_penalty != 1.0 is not built (reference default is 1.0, ppo.yaml:156)')
+    if repetition_penalty <= 0.0:
+        raise ValueError('repetition_penalty must be > 0')
     N, T = input_ids.shape
     dev = input_ids.device
     if getattr(model, 'dtype', torch.bfloat16) != torch.bfloat16:
@@ -65,16 +65,22 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
         'U': torch.rand((max_new_tokens, N), device=dev, generator=generator) if do_sample else None,
     }
     padv = torch.full((N,), pad_token_id, dtype=torch.int64, device=dev)
+    seen = None
+    if repetition_penalty != 1.0:   # HF penalises every id of `input_ids` (left-pad ids included) and every generated one
+        seen = ops.mark_seen_(torch.zeros((N, logits.shape[1]), dtype=torch.uint8, device=dev), input_ids.contiguous())
+
+    def select(lg, u):
+        if do_sample:
+            return ops.sample_top_p(lg, temperature, top_p, u, seen, repetition_penalty)
+        return ops.argmax_rows(lg, seen, repetition_penalty)
 
     def one_step():
         """select token from st['logits'], record it, run one decode pass, leave next logits in st['logits']."""
-        if do_sample:
-            u = st['U'].index_select(0, st['step'])[0]
-            nxt = ops.sample_top_p(st['logits'], temperature, top_p, u)
-        else:
-            nxt = ops.argmax_rows(st['logits'])
+        nxt = select(st['logits'], st['U'].index_select(0, st['step'])[0] if do_sample else None)
         nxt = torch.where(st['unfinished'], nxt, padv)
         out.scatter_(1, st['tslot'][:, None], nxt[:, None])
+        if seen is not None:
+            ops.mark_seen_(seen, nxt[:, None])
         if eos >= 0:
             st['unfinished'].logical_and_(nxt != eos)
         emb_pos = (st['pos'] + 2) if is_opt else None        # OPT learned positions carry an offset of 2
@@ -115,10 +121,7 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
     for step in range(max_new_tokens):
         if step + 1 == max_new_tokens:
             # final token: selection only
-            if do_sample:
-                nxt = ops.sample_top_p(st['logits'], temperature, top_p, st['U'][step])
-            else:
-                nxt = ops.argmax_rows(st['logits'])
+            nxt = select(st['logits'], st['U'][step] if do_sample else None)
             nxt = torch.where(st['unfinished'], nxt, padv)
             out[:, T + step] = nxt
             n_new = step + 1

@@ -498,16 +498,25 @@ def attn_decode(q, kcache, vcache, Tmax, start, length, N, H, Hkv, hd, scale):
     return out
 
 
-def argmax_rows(logits):
+def mark_seen_(seen, ids):
+    """seen[row, ids[row, j]] = 1 (uint8 [rows, V]); ids [rows, L] int64 with unit inner stride."""
+    rows, L = ids.shape
+    call('aa_mark_seen', ids.data_ptr(), ids.stride(0), rows, L, seen.data_ptr(), seen.stride(0), seen.shape[1], stream())
+    return seen
+
+
+def argmax_rows(logits, seen=None, repetition_penalty=1.0):
     rows, V = logits.shape
     out = torch.empty(rows, dtype=torch.int64, device=logits.device)
-    call('aa_argmax_rows', logits.data_ptr(), logits.stride(0), rows, V, out.data_ptr(), stream())
+    call('aa_argmax_rows', logits.data_ptr(), logits.stride(0), rows, V, _p(seen), seen.stride(0) if seen is not None else 0,
+         float(repetition_penalty), out.data_ptr(), stream())
     return out
 
 
-def sample_top_p(logits, temperature, top_p, uniform):
+def sample_top_p(logits, temperature, top_p, uniform, seen=None, repetition_penalty=1.0):
     rows, V = logits.shape
     out = torch.empty(rows, dtype=torch.int64, device=logits.device)
     call('aa_sample_top_p', logits.data_ptr(), logits.stride(0), rows, V, float(temperature), float(top_p),
-         uniform.data_ptr(), out.data_ptr(), stream())
+         uniform.data_ptr(), _p(seen), seen.stride(0) if seen is not None else 0, float(repetition_penalty),
+         out.data_ptr(), stream())
     return out

@@ -173,9 +173,14 @@ int aa_gemm_skinny_bf16(const void* x, const void* W, void* out, int M, int N, i
 int aa_attn_decode(const void* q, long ldq, const void* Kc, const void* Vc, long ldc, int Tmax, const int* start,
                    const int* len, void* o, long ldo, int N, int H, int Hkv, int hd, float scale, void* stream);
 /* greedy token (first index of the max, torch.argmax rule) and temperature/top-p sampling (HF logits warpers) */
-int aa_argmax_rows(const void* logits, long ld, int rows, int V, int64_t* out, void* stream);
+/* seen (uint8 [rows, ld_seen], NULL = off) + repetition_penalty: hf RepetitionPenaltyLogitsProcessor on the fp32 scores
+ * before the warpers; aa_mark_seen sets seen[row, ids[row, j]] = 1 (prompt ids incl. pads, then each new token) */
+int aa_mark_seen(const int64_t* ids, long ld, int rows, int L, uint8_t* seen, long ld_seen, int V, void* stream);
+int aa_argmax_rows(const void* logits, long ld, int rows, int V, const uint8_t* seen, long ld_seen,
+                   float repetition_penalty, int64_t* out, void* stream);
 int aa_sample_top_p(const void* logits, long ld, int rows, int V, float temperature, float top_p,
-                    const float* uniform, int64_t* out, void* stream);
+                    const float* uniform, const uint8_t* seen, long ld_seen, float repetition_penalty, int64_t* out,
+                    void* stream);
 
 /* ---- optimizer (DeepSpeed FusedAdam + gradient_clipping, supervised_trainer.py:245-249) ------ */
 /* *out_accum += sum((g*scale)^2); deterministic (no float atomics): ws = caller-owned scratch of AA_SUMSQ_WS floats, so the

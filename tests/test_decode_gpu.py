@@ -53,13 +53,31 @@ def test_token_selection_kernels():
     logits[1, V - 1] = 40.0
     idx = ops.argmax_rows(logits)
     assert idx.tolist() == torch.argmax(logits.float(), dim=-1).tolist() and idx[0].item() == 77
+    # repetition penalty: seen tokens get score < 0 ? score * p : score / p before the argmax
+    bitmap = torch.zeros(6, V, dtype=torch.uint8, device=dev())
+    seen_ids = torch.randint(0, V, (6, 4000), generator=torch.Generator().manual_seed(3)).to(dev())
+    seen_ids[0, 0] = 77; seen_ids[1, 0] = V - 1; seen_ids[2, 1] = -5; seen_ids[3, 2] = V + 9     # out-of-range ids are ignored
+    ops.mark_seen_(bitmap, seen_ids)
+    want_map = torch.zeros(6, V, dtype=torch.bool)
+    for r in range(6):
+        ok = seen_ids[r].cpu(); ok = ok[(ok >= 0) & (ok < V)]
+        want_map[r, ok] = True
+    assert torch.equal(bitmap.cpu().bool(), want_map)
+    lf = logits.float().cpu()
+    pen_ref = torch.where(want_map, torch.where(lf < 0, lf * 1.5, lf / 1.5), lf)
+    idx = ops.argmax_rows(logits, bitmap, 1.5)
+    assert idx.tolist() == torch.argmax(pen_ref, dim=-1).tolist() and idx[0].item() == 12345   # 77 is penalised, its twin wins
     # nucleus sampling against a straightforward CPU implementation of the same rule (HF TopPLogitsWarper:
     # smallest set of top tokens with mass >= top_p; draw by inverse CDF in index order with the given u)
     small = randn_bf16(64, 500, scale=3.0, seed=6)
     u = torch.rand(64, generator=torch.Generator().manual_seed(1)).to(dev())
-    for temp, top_p in ((1.0, 1.0), (0.7, 0.9), (1.3, 0.5)):
-        got = ops.sample_top_p(small, temp, top_p, u).cpu()
-        p = torch.softmax(small.float().cpu() / temp, -1)
+    seen = (torch.rand(64, 500, generator=torch.Generator().manual_seed(2)) < 0.3).to(torch.uint8).to(dev())
+    for temp, top_p, pen in ((1.0, 1.0, 1.0), (0.7, 0.9, 1.0), (1.3, 0.5, 1.0), (0.9, 0.8, 1.7), (1.0, 1.0, 0.6)):
+        got = ops.sample_top_p(small, temp, top_p, u, seen if pen != 1.0 else None, pen).cpu()
+        eff = small.float().cpu()
+        if pen != 1.0:   # hf RepetitionPenaltyLogitsProcessor on the fp32 scores, before temperature / top-p
+            eff = torch.where(seen.cpu().bool(), torch.where(eff < 0, eff * pen, eff / pen), eff)
+        p = torch.softmax(eff / temp, -1)
         for r in range(64):
             sp, si = torch.sort(p[r], descending=True)
             k = int((torch.cumsum(sp, 0) < top_p).sum()) + 1 if top_p < 1.0 else p.shape[1]
@@ -72,12 +90,15 @@ def test_token_selection_kernels():
                 assert abs(float(c[got[r]] - c[want])) < 1e-3 * float(pk.sum()) + float(p[r][got[r]]) + float(p[r][want])
 
 
-def _greedy_oracle(logits_fn, ids, mask, n_new, eos, pad):
+def _greedy_oracle(logits_fn, ids, mask, n_new, eos, pad, penalty=1.0):
     ids, mask = ids.clone(), mask.clone()
     unfinished = torch.ones(ids.shape[0], dtype=torch.bool)
     margins = []
     for _ in range(n_new):
         lg = logits_fn(ids, mask)[:, -1]
+        if penalty != 1.0:   # hf RepetitionPenaltyLogitsProcessor.__call__
+            sc = torch.gather(lg, 1, ids)
+            lg = lg.scatter(1, ids, torch.where(sc < 0, sc * penalty, sc / penalty))
         top2 = torch.topk(lg, 2, dim=-1).values
         margins.append(top2[:, 0] - top2[:, 1])
         nxt = torch.where(unfinished, lg.argmax(-1), torch.full((ids.shape[0],), pad))
@@ -88,11 +109,11 @@ def _greedy_oracle(logits_fn, ids, mask, n_new, eos, pad):
     return ids, torch.stack(margins, 1)
 
 
-def _check_greedy(model, logits_fn, ids, mask, n_new, eos, pad, tag, pixel_values=None):
+def _check_greedy(model, logits_fn, ids, mask, n_new, eos, pad, tag, pixel_values=None, penalty=1.0):
     from align_anything_amd.generation import generate
     seq = generate(model, ids.to(dev()), mask.to(dev()), max_new_tokens=n_new, do_sample=False, eos_token_id=eos,
-                   pad_token_id=pad, pixel_values=pixel_values, sync_every=2).cpu()
-    want, margins = _greedy_oracle(logits_fn, ids, mask, n_new, eos, pad)
+                   pad_token_id=pad, pixel_values=pixel_values, sync_every=2, repetition_penalty=penalty).cpu()
+    want, margins = _greedy_oracle(logits_fn, ids, mask, n_new, eos, pad, penalty)
     Tn = ids.shape[1]
     assert torch.equal(seq[:, :Tn], ids)
     agree = 0
@@ -125,6 +146,9 @@ def test_generate_greedy_opt_and_eos_padding():
     seq2 = _check_greedy(m, fn, ids, mask, 12, eos, 1, 'opt_eos')
     first = (seq2[0, 24:] == eos).nonzero()[0].item()
     assert (seq2[0, 24 + first + 1:] == 1).all()
+    # repetition penalty (hf RepetitionPenaltyLogitsProcessor): a strong penalty forbids repeats and changes the path
+    seq3 = _check_greedy(m, fn, ids, mask, 12, None, 1, 'opt_reppen', penalty=4.0)
+    assert not torch.equal(seq3, seq)
 
 
 def test_generate_greedy_llava_with_image_prefill():
@@ -151,5 +175,6 @@ def test_generate_sampling_runs_and_respects_length_cap():
     g = torch.Generator(device='cuda').manual_seed(0)
     b = generate(m, ids, mask, max_length=32, do_sample=True, temperature=0.8, top_p=0.9, pad_token_id=1, generator=g)
     assert a.shape == (4, 32) and torch.equal(a, b) and int(a.max()) < 320 and int(a.min()) >= 0
-    with pytest.raises(NotImplementedError):
-        generate(m, ids, mask, max_length=32, repetition_penalty=1.2)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    c = generate(m, ids, mask, max_length=32, do_sample=True, temperature=0.8, top_p=0.9, pad_token_id=1, generator=g, repetition_penalty=1.3)
+    assert c.shape == (4, 32) and torch.equal(c[:, :20], ids) and not torch.equal(c, a)
