@@ -1,0 +1,133 @@
+"""Input pipeline either side of the hot path.
+
+The reference's `PreferenceCollator.__call__` (align_anything/datasets/text_image_to_text/preference.py:215-263) runs the
+HF processor on the raw conversations and images EVERY step -- tokenisation and image preprocessing are synchronous CPU
+work inside the training loop -- and then does a blocking `.to(device)` per tensor.  Here:
+
+* `TokenizedPreferenceCache` runs the processor ONCE per sample (both conversations + the image) and keeps the unpadded
+  token ids, the pixel tensor and the response lengths in pinned host memory;
+* `CachedPreferenceCollator` builds the batch of the same contract from the cache (rows [0,B) better, [B,2B) worse,
+  padded to the longest row on `padding_side`, `pixel_values` = images * 2, `meta_info.response_lens`) -- integer work
+  that must equal the reference collator's output exactly;
+* `DevicePrefetcher` stages batch k+1 host->HBM on a side HIP stream while step k computes, and pre-builds the response
+  window index plan (`trainers/common.py::build_window`) so the step starts with no host work.
+"""
+from __future__ import annotations
+
+import threading
+from queue import Queue
+
+import torch
+
+
+def _pin(t: torch.Tensor) -> torch.Tensor:
+    return t.pin_memory() if torch.cuda.is_available() and not t.is_pinned() else t
+
+
+class TokenizedPreferenceCache:
+    """samples: the dicts `PreferenceDataset.preprocess` returns (better_conversation, worse_conversation, image,
+    better_response_lens, worse_response_lens; preference.py:132-160).  processor(text=..., images=..., return_tensors='pt')
+    is called once per conversation, without padding."""
+
+    def __init__(self, samples, processor, has_images: bool = True):
+        self.items = []
+        for s in samples:
+            img = s.get('image') if has_images else None
+            kw = {'images': img} if img is not None else {}
+            b = processor(text=s['better_conversation'], return_tensors='pt', **kw)
+            w = processor(text=s['worse_conversation'], return_tensors='pt', **kw)
+            item = {'better_ids': _pin(b['input_ids'][0].to(torch.int64).contiguous()),
+                    'worse_ids': _pin(w['input_ids'][0].to(torch.int64).contiguous()),
+                    'better_response_lens': int(s['better_response_lens']), 'worse_response_lens': int(s['worse_response_lens'])}
+            if 'pixel_values' in b:
+                item['pixel_values'] = _pin(b['pixel_values'][0].contiguous())
+            self.items.append(item)
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+class CachedPreferenceCollator:
+    def __init__(self, pad_token_id: int, padding_side: str = 'left'):
+        if padding_side not in ('left', 'right'):
+            raise ValueError(f'padding_side must be left or right, got {padding_side!r}')
+        self.pad_token_id, self.padding_side = int(pad_token_id), padding_side
+
+    def __call__(self, items) -> dict:
+        rows = [it['better_ids'] for it in items] + [it['worse_ids'] for it in items]
+        T = max(int(r.numel()) for r in rows)
+        ids = torch.full((len(rows), T), self.pad_token_id, dtype=torch.int64)
+        mask = torch.zeros((len(rows), T), dtype=torch.int64)
+        for r, row in enumerate(rows):
+            n = int(row.numel())
+            if self.padding_side == 'left':
+                ids[r, T - n:] = row; mask[r, T - n:] = 1
+            else:
+                ids[r, :n] = row; mask[r, :n] = 1
+        batch = {'input_ids': _pin(ids), 'attention_mask': _pin(mask),
+                 'meta_info': {'response_lens': [it['better_response_lens'] for it in items] + [it['worse_response_lens'] for it in items]}}
+        if 'pixel_values' in items[0]:
+            pv = torch.stack([it['pixel_values'] for it in items])
+            batch['pixel_values'] = _pin(torch.cat([pv, pv], 0))      # images * 2 (preference.py:219-222)
+        return batch
+
+
+class DevicePrefetcher:
+    """Iterates a host dataloader one batch ahead: the next batch's tensors are copied to the device on a side stream
+    (non_blocking from pinned memory) and its window plan is built, while the current step runs.  `pad_token_id` given
+    -> `_window` is attached (DPOTrainer._window then finds it)."""
+
+    def __init__(self, loader, device, pad_token_id=None, depth: int = 2):
+        self.loader, self.device, self.pad_token_id, self.depth = loader, torch.device(device), pad_token_id, max(1, depth)
+        self.stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch):
+        out = {}
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                for k, v in batch.items():
+                    out[k] = v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            out['_ready'] = ev
+        else:
+            out = dict(batch)
+        return out
+
+    def _finish(self, out):
+        ev = out.pop('_ready', None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        if self.pad_token_id is not None and 'meta_info' in out and 'response_lens' in out['meta_info']:
+            from .trainers.common import build_window
+            out['_window'] = build_window(out['input_ids'], out['meta_info']['response_lens'], self.pad_token_id)
+        return out
+
+    def __iter__(self):
+        q: Queue = Queue(maxsize=self.depth)
+        stop = object()
+
+        def producer():
+            try:
+                for b in self.loader:
+                    q.put(self._stage(b))
+            except BaseException as ex:   # surface loader errors in the consumer
+                q.put(ex)
+            q.put(stop)
+
+        t = threading.Thread(target=producer, daemon=True)
+        t.start()
+        while True:
+            item = q.get()
+            if item is stop:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield self._finish(item)
+        t.join()

@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import _shim  # noqa: E402
-from oracle.synthetic import opt125m_config1  # noqa: E402
+from oracle.synthetic import StubProcessor, opt125m_config1, preference_samples  # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
@@ -286,6 +286,24 @@ def gen_pref():
     np.savez_compressed(os.path.join(GOLD, 'opt_tiny_pref.npz'), **out)
 
 
+def gen_collator():
+    """The reference's unmodified PreferenceCollator (datasets/text_image_to_text/preference.py:199-263) on synthetic
+    samples with the stub processor: the batch the native cached pipeline (align_anything_amd/data.py) must reproduce."""
+    import align_anything.datasets.text_image_to_text.preference as pref
+    pref.get_current_device = lambda: torch.device('cpu')
+    proc = StubProcessor()
+    samples = preference_samples()
+    out = {}
+    for side in ('left', 'right'):
+        batch = pref.PreferenceCollator(proc.pad_token_id, proc, side)(samples)
+        out[f'{side}_input_ids'] = batch['input_ids'].numpy()
+        out[f'{side}_attention_mask'] = batch['attention_mask'].numpy()
+        out[f'{side}_pixel_values'] = batch['pixel_values'].numpy()
+        out[f'{side}_response_lens'] = np.array(batch['meta_info']['response_lens'])
+    np.savez_compressed(os.path.join(GOLD, 'collator.npz'), **out)
+    print('collator.npz', {k: v.shape for k, v in out.items()})
+
+
 def gen_grpo():
     """Drive the reference's unmodified GRPOTrainer.train_step (trainers/text_to_text/grpo.py:257-329) with a fake
     engine around a tiny HF OPT model, fixed 'generated' sequences and fixed rewards; record loss and gradients."""
@@ -413,5 +431,6 @@ if __name__ == '__main__':
     gen_llava_dpo()
     gen_opt_dpo()
     gen_pref()
+    gen_collator()
     gen_grpo()
     gen_opt125m_curve()

@@ -179,3 +179,36 @@ def test_engine_lr_schedule_and_accumulation_bookkeeping():
     eng.micro_steps = 1
     eng.step()                                                  # not at a boundary: no update, no kernel call
     assert eng.global_steps == 0
+
+
+def test_cached_input_pipeline_reproduces_the_reference_collator_batch():
+    """align_anything_amd/data.py (tokenise once, collate from the cache, prefetch) vs the batch the reference's own
+    PreferenceCollator produced on the same samples (tests/golden/collator.npz): integer work -> exact."""
+    import numpy as np
+    from oracle.synthetic import StubProcessor, preference_samples
+    from align_anything_amd.data import CachedPreferenceCollator, DevicePrefetcher, TokenizedPreferenceCache
+    from tests.util import load_golden
+    z = load_golden('collator.npz')
+    proc = StubProcessor()
+    calls = {'n': 0}
+    counting = lambda **kw: (calls.__setitem__('n', calls['n'] + 1), proc(**kw))[1]
+    cache = TokenizedPreferenceCache(preference_samples(), counting)
+    assert calls['n'] == 2 * len(cache)                                   # the processor ran once per conversation...
+    for side in ('left', 'right'):
+        batch = CachedPreferenceCollator(proc.pad_token_id, side)([cache[i] for i in range(len(cache))])
+        assert np.array_equal(batch['input_ids'].numpy(), z[f'{side}_input_ids'])
+        assert np.array_equal(batch['attention_mask'].numpy(), z[f'{side}_attention_mask'])
+        assert np.array_equal(batch['pixel_values'].numpy(), z[f'{side}_pixel_values'])
+        assert batch['meta_info']['response_lens'] == z[f'{side}_response_lens'].tolist()
+    assert calls['n'] == 2 * len(cache)                                   # ...and never again while collating
+    # prefetcher: same batches, same order, window plan attached (CPU path: no stream)
+    coll = CachedPreferenceCollator(proc.pad_token_id, 'left')
+    loader = [coll([cache[i], cache[i + 1]]) for i in range(0, 4, 2)]
+    got = list(DevicePrefetcher(loader, 'cpu'))
+    assert len(got) == 2 and all(torch.equal(g['input_ids'], b['input_ids']) for g, b in zip(got, loader))
+
+    def boom():
+        yield loader[0]
+        raise RuntimeError('loader failed')
+    with pytest.raises(RuntimeError, match='loader failed'):
+        list(DevicePrefetcher(boom(), 'cpu'))

@@ -244,3 +244,22 @@ def test_gradient_accumulation_two_micro_batches_equal_one_batch():
         assert (a - f).abs().max().item() <= 2.1e-3, (g, (a - f).abs().max().item())
         agree = ((a - f).abs() < 1e-4).float().mean().item()
         assert agree > 0.97, (g, agree)
+
+
+def test_device_prefetcher_feeds_identical_steps():
+    """align_anything_amd/data.py on the GPU: batches staged on a side stream (with their window plan) give exactly the
+    same training steps as batches moved synchronously."""
+    from oracle.synthetic import StubProcessor, preference_samples
+    from align_anything_amd.data import CachedPreferenceCollator, DevicePrefetcher, TokenizedPreferenceCache
+    z = load_golden('llava_tiny_dpo.npz')
+    proc = StubProcessor()
+    cache = TokenizedPreferenceCache(preference_samples(6, seed=9), proc)
+    coll = CachedPreferenceCollator(proc.pad_token_id, 'left')
+    loader = [coll([cache[i], cache[i + 1]]) for i in range(0, 6, 2)]
+    a, b = _trainer(z, tiny_llava_cfg()), _trainer(z, tiny_llava_cfg())
+    a.train_dataloader = DevicePrefetcher(loader, 'cuda:0', pad_token_id=proc.pad_token_id)
+    hist = a.train()
+    assert len(hist) == 3
+    for h, hb in zip(hist, loader):
+        info = b.train_step({k: (v.to(dev()) if isinstance(v, torch.Tensor) else v) for k, v in hb.items()})
+        assert info['train/loss'] == h['train/loss'] and info['train/reward_margin'] == h['train/reward_margin']
