@@ -32,6 +32,21 @@ def llava_cfg(text, vision, image_token_id, vision_feature_layer=-2, pad_token_i
             'vision_feature_layer': vision_feature_layer, 'pad_token_id': pad_token_id}
 
 
+def qwen2vl_vision_cfg(embed_dim, depth, num_heads, mlp_ratio, hidden_size, patch_size=14, temporal_patch_size=2,
+                       spatial_merge_size=2, in_channels=3):
+    return {'kind': 'qwen2vl_vision', 'embed_dim': embed_dim, 'depth': depth, 'num_heads': num_heads, 'mlp_ratio': mlp_ratio,
+            'hidden_size': hidden_size, 'patch_size': patch_size, 'temporal_patch_size': temporal_patch_size,
+            'spatial_merge_size': spatial_merge_size, 'in_channels': in_channels}
+
+
+def qwen2vl_cfg(text, vision, image_token_id, mrope_section, pad_token_id=None):
+    """text = llama_cfg(..., attention_bias=True) (the Qwen2 decoder) + the multimodal-RoPE split of head_dim/2."""
+    if sum(mrope_section) != text['head_dim'] // 2:
+        raise ValueError(f"mrope_section {mrope_section} must sum to head_dim/2 = {text['head_dim'] // 2}")
+    text = dict(text, mrope_section=list(mrope_section))
+    return {'kind': 'qwen2vl', 'text': text, 'vision': vision, 'image_token_id': image_token_id, 'pad_token_id': pad_token_id}
+
+
 def opt_cfg(hidden_size, ffn_dim, num_layers, num_heads, vocab_size, max_position_embeddings=2048):
     return {'kind': 'opt', 'hidden_size': hidden_size, 'ffn_dim': ffn_dim, 'num_layers': num_layers,
             'num_heads': num_heads, 'vocab_size': vocab_size,
@@ -78,7 +93,17 @@ def from_hf_config(c) -> dict:
         return llama_cfg(c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads,
                          c.num_key_value_heads, c.vocab_size, c.rms_norm_eps, theta, getattr(c, 'head_dim', None),
                          c.max_position_embeddings, attention_bias=True)
+    if mt == 'qwen2_vl':   # align_anything/models/qwen2_vl.py -> hf Qwen2VLForConditionalGeneration
+        t, v = c.text_config, c.vision_config
+        rp = getattr(t, 'rope_parameters', None) or getattr(t, 'rope_scaling', None) or {}
+        theta = rp.get('rope_theta', getattr(t, 'rope_theta', 1000000.0))
+        text = llama_cfg(t.hidden_size, t.intermediate_size, t.num_hidden_layers, t.num_attention_heads, t.num_key_value_heads,
+                         t.vocab_size, t.rms_norm_eps, theta, getattr(t, 'head_dim', None), t.max_position_embeddings,
+                         attention_bias=True)
+        vision = qwen2vl_vision_cfg(v.embed_dim, v.depth, v.num_heads, v.mlp_ratio, v.hidden_size, v.patch_size,
+                                    v.temporal_patch_size, v.spatial_merge_size, v.in_channels)
+        return qwen2vl_cfg(text, vision, c.image_token_id, rp['mrope_section'], getattr(c, 'pad_token_id', None))
     if mt == 'opt':
         return opt_cfg(c.hidden_size, c.ffn_dim, c.num_hidden_layers, c.num_attention_heads, c.vocab_size,
                        c.max_position_embeddings)
-    raise ValueError(f'model_type {mt!r} has no native MI355X implementation (llava, llama, qwen2, opt are built)')
+    raise ValueError(f'model_type {mt!r} has no native MI355X implementation (llava, llama, qwen2, qwen2_vl, opt are built)')

@@ -331,37 +331,55 @@ extern "C" int AA_FN(aa_layernorm_bwd)(const void* dy, const void* x, const void
 }
 
 // ================================================================== RoPE (in place on a [M, ld] buffer)
-// hf:models/llama/modeling_llama.py:113-160: cos/sin are bf16 tables [maxpos, hd/2];
-// q' = bf16(bf16(q*cos) + bf16(rotate_half(q)*sin)), half-split layout.  Applied to `nheads`
-// consecutive heads starting at column col0 of every row; position of row r is pos[r].
+// hf:models/llama/modeling_llama.py:113-160: cos/sin are tables [maxpos, hd/2] in the activation dtype;
+// q' = bf16(bf16(q*cos) + bf16(rotate_half(q)*sin)), half-split layout.  Applied to `nheads` heads of rotary width hd
+// starting at column col0 of every row, consecutive heads `head_stride` columns apart (== hd unless the heads are
+// zero-padded, e.g. Qwen2-VL's 80-wide vision heads stored 128 wide); position of row r is pos[r].
 // inverse != 0 applies the transpose rotation (backward).
+// precise != 0: hf:models/qwen2_vl/modeling_qwen2_vl.py:225-236 apply_rotary_pos_emb_vision -- fp32 tables (cos_t / sin_t
+// are float*), fp32 arithmetic, one rounding of the result.
 __global__ __launch_bounds__(256) void rope_kernel(elem_t* __restrict__ buf, long ld, int col0,
-                                                   int nheads, int hd,
+                                                   int nheads, int hd, int head_stride,
                                                    const int* __restrict__ pos,
-                                                   const elem_t* __restrict__ cos_t,
-                                                   const elem_t* __restrict__ sin_t, long rows,
-                                                   int inverse) {
+                                                   const void* __restrict__ cos_v,
+                                                   const void* __restrict__ sin_v, long rows,
+                                                   int inverse, int precise) {
     const int half = hd >> 1;
-    const int vec_per_head = half >> 3;  // 8 bf16 per lane from each half
+    const int vec_per_head = half >> 3;  // 8 elements per lane from each half
     const long total = rows * nheads * vec_per_head;
+    const elem_t* cos_t = reinterpret_cast<const elem_t*>(cos_v);
+    const elem_t* sin_t = reinterpret_cast<const elem_t*>(sin_v);
+    const float* cos_f = reinterpret_cast<const float*>(cos_v);
+    const float* sin_f = reinterpret_cast<const float*>(sin_v);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int v = (int)(idx % vec_per_head);
         const long t = idx / vec_per_head;
         const int head = (int)(t % nheads);
         const long row = t / nheads;
         const int p = pos[row];
-        elem_t* base = buf + row * ld + col0 + head * hd + v * 8;
+        elem_t* base = buf + row * ld + col0 + (long)head * head_stride + v * 8;
         ev8 x1 = *reinterpret_cast<const ev8*>(base);
         ev8 x2 = *reinterpret_cast<const ev8*>(base + half);
-        ev8 c = *reinterpret_cast<const ev8*>(cos_t + (long)p * half + v * 8);
-        ev8 s = *reinterpret_cast<const ev8*>(sin_t + (long)p * half + v * 8);
         ev8 o1, o2;
+        if (precise) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float a = e2f(x1[j]), b = e2f(x2[j]), cc = e2f(c[j]);
-            const float ss = inverse ? -e2f(s[j]) : e2f(s[j]);
-            o1[j] = f2e(ernd(a * cc) + ernd(-b * ss));
-            o2[j] = f2e(ernd(b * cc) + ernd(a * ss));
+            for (int j = 0; j < 8; ++j) {
+                const float a = e2f(x1[j]), b = e2f(x2[j]);
+                const float cc = cos_f[(long)p * half + v * 8 + j];
+                const float ss = inverse ? -sin_f[(long)p * half + v * 8 + j] : sin_f[(long)p * half + v * 8 + j];
+                o1[j] = f2e(a * cc - b * ss);
+                o2[j] = f2e(b * cc + a * ss);
+            }
+        } else {
+            ev8 c = *reinterpret_cast<const ev8*>(cos_t + (long)p * half + v * 8);
+            ev8 s = *reinterpret_cast<const ev8*>(sin_t + (long)p * half + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = e2f(x1[j]), b = e2f(x2[j]), cc = e2f(c[j]);
+                const float ss = inverse ? -e2f(s[j]) : e2f(s[j]);
+                o1[j] = f2e(ernd(a * cc) + ernd(-b * ss));
+                o2[j] = f2e(ernd(b * cc) + ernd(a * ss));
+            }
         }
         *reinterpret_cast<ev8*>(base) = o1;
         *reinterpret_cast<ev8*>(base + half) = o2;
@@ -369,16 +387,48 @@ __global__ __launch_bounds__(256) void rope_kernel(elem_t* __restrict__ buf, lon
 }
 
 extern "C" int AA_FN(aa_rope_inplace)(void* buf, long ld, int col0, int nheads, int hd, const int* pos,
-                               const void* cos_t, const void* sin_t, long rows, int inverse,
-                               void* stream) {
+                               const void* cos_t, const void* sin_t, long rows, int inverse, int head_stride,
+                               int precise, void* stream) {
     AA_REQUIRE(hd > 0 && (hd % 16) == 0 && nheads > 0, "aa_rope_inplace: head_dim %d must be a multiple of 16", hd);
     AA_REQUIRE((ld & 7) == 0 && (col0 & 7) == 0, "aa_rope_inplace: ld/col0 must be multiples of 8");
+    if (head_stride <= 0) head_stride = hd;
+    AA_REQUIRE(head_stride >= hd && (head_stride & 7) == 0, "aa_rope_inplace: head_stride %d must be >= head_dim and a multiple of 8", head_stride);
     if (rows == 0) return AA_OK;
     const long total = rows * nheads * (hd >> 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (elem_t*)buf, ld,
-                       col0, nheads, hd, pos, (const elem_t*)cos_t, (const elem_t*)sin_t, rows, inverse);
+                       col0, nheads, hd, head_stride, pos, cos_t, sin_t, rows, inverse, precise);
     AA_CHECK_LAUNCH("aa_rope_inplace");
+    return AA_OK;
+}
+
+// hf:models/qwen2_vl/modeling_qwen2_vl.py:156-222 (Qwen2VLRotaryEmbedding + apply_multimodal_rotary_pos_emb): per-token
+// cos/sin rows for multimodal RoPE.  pos3 = [3, rows] (temporal, height, width position of every token); frequency f of
+// the half-dim uses component 0 for f < sec0, 1 for f < sec0 + sec1, else 2.  Tables are [rows, half] in the activation
+// dtype (fp32 angle, fp32 cos/sin, one rounding) and are consumed by aa_rope_inplace with pos[row] = row.
+__global__ __launch_bounds__(256) void mrope_tables_kernel(const int* __restrict__ pos3, long rows,
+                                                           const float* __restrict__ inv_freq, int half, int sec0,
+                                                           int sec1, elem_t* __restrict__ cos_t,
+                                                           elem_t* __restrict__ sin_t) {
+    const long total = rows * half;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int f = (int)(idx % half);
+        const long r = idx / half;
+        const int c = f < sec0 ? 0 : (f < sec0 + sec1 ? 1 : 2);
+        const float ang = inv_freq[f] * (float)pos3[(long)c * rows + r];
+        cos_t[idx] = f2e(cosf(ang));
+        sin_t[idx] = f2e(sinf(ang));
+    }
+}
+extern "C" int AA_FN(aa_mrope_tables)(const int* pos3, long rows, const float* inv_freq, int half, int sec0, int sec1,
+                                      void* cos_t, void* sin_t, void* stream) {
+    AA_REQUIRE(half > 0 && sec0 >= 0 && sec1 >= 0 && sec0 + sec1 <= half, "aa_mrope_tables: bad sections %d/%d of %d", sec0, sec1, half);
+    if (rows == 0) return AA_OK;
+    const long total = rows * half;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(mrope_tables_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pos3, rows, inv_freq, half,
+                       sec0, sec1, (elem_t*)cos_t, (elem_t*)sin_t);
+    AA_CHECK_LAUNCH("aa_mrope_tables");
     return AA_OK;
 }
 

@@ -192,11 +192,26 @@ def rowdot_bwd(dy, x, w, dw):
 
 
 # ------------------------------------------------------------------ pointwise
-def rope_(buf, col0, nheads, hd, pos, cos_t, sin_t, inverse=False):
+def rope_(buf, col0, nheads, hd, pos, cos_t, sin_t, inverse=False, head_stride=0, precise=False):
     rows = buf.shape[0]
+    if precise and (cos_t.dtype != f32 or sin_t.dtype != f32):
+        raise RuntimeError('rope_: precise mode takes fp32 cos/sin tables')
+    if not precise and cos_t.dtype != buf.dtype:
+        raise RuntimeError(f'rope_: tables are {cos_t.dtype}, activations {buf.dtype}')
     call('aa_rope_inplace' + _sfx(buf, 'rope_'), buf.data_ptr(), buf.stride(0), int(col0), int(nheads), int(hd), pos.data_ptr(),
-         cos_t.data_ptr(), sin_t.data_ptr(), rows, int(inverse), stream())
+         cos_t.data_ptr(), sin_t.data_ptr(), rows, int(inverse), int(head_stride), int(precise), stream())
     return buf
+
+
+def mrope_tables(pos3, inv_freq, sections, dtype):
+    """pos3 int32 [3, rows] -> (cos, sin) [rows, half] for multimodal RoPE (sections = mrope_section, sums to half)."""
+    rows = pos3.shape[1]
+    half = inv_freq.numel()
+    cos = torch.empty((rows, half), dtype=dtype, device=pos3.device)
+    sin = torch.empty_like(cos)
+    call('aa_mrope_tables' + _sfx(cos, 'mrope_tables'), pos3.data_ptr(), rows, inv_freq.data_ptr(), half, int(sections[0]),
+         int(sections[1]), cos.data_ptr(), sin.data_ptr(), stream())
+    return cos, sin
 
 
 def swiglu_fwd(gate_up, out=None):

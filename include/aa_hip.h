@@ -126,9 +126,15 @@ int aa_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float
 int aa_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
                      void* dx, float* dw, float* db, float* ws /* [2, ws_rows, h] */, int ws_rows, int rows,
                      int h, int add_to_dx, void* stream);
-/* hf:models/llama/modeling_llama.py:113-160 rotary embedding, in place, inverse = backward */
+/* hf:models/llama/modeling_llama.py:113-160 rotary embedding, in place, inverse = backward.  head_stride = columns
+ * between consecutive heads (0 -> hd; > hd for zero-padded heads); precise = 1: fp32 tables (float*) and fp32 arithmetic
+ * with one rounding, hf:models/qwen2_vl/modeling_qwen2_vl.py:225-236 (vision rotary) */
 int aa_rope_inplace(void* buf, long ld, int col0, int nheads, int hd, const int* pos, const void* cos_t,
-                    const void* sin_t, long rows, int inverse, void* stream);
+                    const void* sin_t, long rows, int inverse, int head_stride, int precise, void* stream);
+/* hf:models/qwen2_vl/modeling_qwen2_vl.py:156-222 multimodal RoPE: per-token cos/sin rows [rows, half] from the 3-D position
+ * ids pos3 [3, rows]; frequency f uses component 0 / 1 / 2 for f < sec0 / < sec0 + sec1 / else */
+int aa_mrope_tables(const int* pos3, long rows, const float* inv_freq, int half, int sec0, int sec1, void* cos_t,
+                    void* sin_t, void* stream);
 /* hf:models/llama/modeling_llama.py:163-176 LlamaMLP gate: silu(gate)*up on [M, 2F] -> [M, F] */
 int aa_swiglu_fwd(const void* gate_up, void* out, long M, int F, void* stream);
 int aa_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, long M, int F, void* stream);

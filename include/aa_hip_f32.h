@@ -33,7 +33,10 @@ int aa_layernorm_bwd_f32(const void* dy, const void* x, const void* w, const flo
                          void* stream);
 /* fp32 twin of aa_rope_inplace */
 int aa_rope_inplace_f32(void* buf, long ld, int col0, int nheads, int hd, const int* pos, const void* cos_t,
-                        const void* sin_t, long rows, int inverse, void* stream);
+                        const void* sin_t, long rows, int inverse, int head_stride, int precise, void* stream);
+/* fp32 twin of aa_mrope_tables */
+int aa_mrope_tables_f32(const int* pos3, long rows, const float* inv_freq, int half, int sec0, int sec1, void* cos_t,
+                        void* sin_t, void* stream);
 /* fp32 twin of aa_swiglu_fwd */
 int aa_swiglu_fwd_f32(const void* gate_up, void* out, long M, int F, void* stream);
 /* fp32 twin of aa_swiglu_bwd */

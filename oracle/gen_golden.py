@@ -225,6 +225,86 @@ def gen_opt_dpo():
     print('opt_tiny_dpo.npz loss', float(ld['loss']))
 
 
+def tiny_qwen2vl():
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+    cfg = Qwen2VLConfig(
+        text_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                         vocab_size=320, max_position_embeddings=256, rms_norm_eps=1e-6,
+                         rope_parameters={'rope_type': 'default', 'rope_theta': 10000.0, 'mrope_section': [8, 12, 12]}),
+        vision_config=dict(depth=2, embed_dim=160, hidden_size=128, num_heads=2, mlp_ratio=2, patch_size=14, temporal_patch_size=2,
+                           spatial_merge_size=2, in_channels=3),      # head_dim 80, like the real tower (1280 / 16)
+        image_token_id=300, video_token_id=301, vision_start_token_id=302, vision_end_token_id=303, bos_token_id=1, eos_token_id=2)
+    torch.manual_seed(17)
+    m = Qwen2VLForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+            p.copy_(p.to(torch.bfloat16).to(torch.float32))
+    return cfg, m.eval()
+
+
+def gen_qwen2vl_dpo():
+    """BASELINE configs[2] backbone: the reference's unmodified text_image_to_text DPOTrainer.{compute_log_probs, loss}
+    (trainers/text_image_to_text/dpo.py:85-166) on a tiny random HF Qwen2VLForConditionalGeneration (align_anything/models/
+    qwen2_vl.py), fp32, CPU.  Batch = what the Qwen2-VL processor + PreferenceCollator hand over: flattened patches,
+    image_grid_thw, mm_token_type_ids, left padding, the pair's image repeated for chosen and rejected."""
+    from align_anything.trainers.text_image_to_text.dpo import DPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+
+    cfg, policy = tiny_qwen2vl()
+    _, refm = tiny_qwen2vl()
+    g = torch.Generator().manual_seed(23)
+    with torch.no_grad():
+        for p in refm.parameters():
+            p.add_(0.02 * torch.randn(p.shape, generator=g))
+            p.copy_(p.to(torch.bfloat16).to(torch.float32))
+    B, T, PAD, IMG = 2, 40, 304, 300
+    grids1 = [[1, 4, 6], [1, 4, 4]]                       # per pair: 24 / 16 patches -> 6 / 4 image tokens
+    grids = grids1 + grids1                               # images * 2 (chosen rows, then rejected rows)
+    pix1 = [torch.randn(t * h * w, 3 * 2 * 14 * 14, generator=g) for t, h, w in grids1]
+    pixel_values = torch.cat(pix1 + pix1, 0)
+    ids = torch.full((2 * B, T), PAD, dtype=torch.long)
+    mask = torch.zeros((2 * B, T), dtype=torch.long)
+    for r, lp in enumerate((0, 5, 3, 0)):
+        ntok = grids[r][1] * grids[r][2] // 4
+        n_txt = T - lp - 3 - ntok
+        row = torch.cat([torch.tensor([1, 302]), torch.full((ntok,), IMG), torch.tensor([303]), torch.randint(3, 299, (n_txt,), generator=g)])
+        ids[r, lp:] = row
+        mask[r, lp:] = 1
+    resp = [11, 8, 6, 12]
+    batch = {'input_ids': ids, 'attention_mask': mask, 'pixel_values': pixel_values, 'image_grid_thw': torch.tensor(grids),
+             'mm_token_type_ids': (ids == IMG).int(), 'meta_info': {'response_lens': resp}}
+    tr = DPOTrainer.__new__(DPOTrainer)
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+    tr.tokenizer = SimpleNamespace(pad_token_id=PAD)
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    tr.model, tr.reference_model = SimpleNamespace(module=policy), SimpleNamespace(module=refm)
+    policy.zero_grad()
+    seq_lp = tr.compute_log_probs(policy, batch)
+    ld = tr.loss(batch)
+    ld['loss'].backward()
+    with torch.no_grad():
+        out_hf = policy(**tr.infer_batch(batch))
+        pos, deltas = policy.model.get_rope_index(ids, batch['mm_token_type_ids'], image_grid_thw=batch['image_grid_thw'], attention_mask=mask)
+        feats = torch.cat(policy.model.get_image_features(pixel_values, batch['image_grid_thw']).pooler_output, 0)
+    out = {'input_ids': ids.numpy(), 'attention_mask': mask.numpy(), 'pixel_values': pixel_values.numpy(), 'image_grid_thw': np.array(grids),
+           'response_lens': np.array(resp), 'pad_token_id': np.array(PAD), 'scale_coeff': np.array(0.1),
+           'policy_logits': out_hf.logits.numpy(), 'seq_log_probs': seq_lp.detach().numpy(), 'position_ids': pos.numpy(),
+           'rope_deltas': deltas.flatten().numpy(), 'image_features': feats.numpy()}
+    for k, v in ld.items():
+        out['loss_' + k] = v.detach().numpy()
+    for n, p in policy.state_dict().items():
+        out['w.' + n] = bf16_bits(p)
+    for n, p in refm.state_dict().items():
+        out['r.' + n] = bf16_bits(p)
+    for n, p in policy.named_parameters():
+        if p.grad is not None and not n.startswith('model.visual.blocks'):
+            out['g.' + n] = p.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'qwen2vl_tiny_dpo.npz'), **out)
+    print('qwen2vl_tiny_dpo.npz loss', float(ld['loss']), 'acc', float(ld['reward_accuracy']), 'n arrays', len(out))
+
+
 def gen_pref():
     """SimPO / ORPO / KTO: the reference's unmodified `loss` overrides (trainers/text_to_text/simpo.py:41-108,
     orpo.py:41-112, kto.py:83-160) on the tiny OPT of opt_tiny_dpo.npz (weights are read back from that fixture, so
@@ -430,6 +510,7 @@ if __name__ == '__main__':
     gen_rl_math()
     gen_llava_dpo()
     gen_opt_dpo()
+    gen_qwen2vl_dpo()
     gen_pref()
     gen_collator()
     gen_grpo()

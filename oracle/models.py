@@ -40,8 +40,12 @@ def rope_tables(T, hd, theta, dtype=torch.float32):
 def apply_rope(x, cos, sin):
     """hf:models/llama/modeling_llama.py:130-160 -- half-split rotate_half.  x: [N, H, T, hd]."""
     half = x.shape[-1] // 2
-    c = torch.cat([cos, cos], -1)[None, None]
-    s = torch.cat([sin, sin], -1)[None, None]
+    if cos.dim() == 3:          # per-row tables [N, T, hd/2] (multimodal RoPE)
+        c = torch.cat([cos, cos], -1)[:, None]
+        s = torch.cat([sin, sin], -1)[:, None]
+    else:
+        c = torch.cat([cos, cos], -1)[None, None]
+        s = torch.cat([sin, sin], -1)[None, None]
     rot = torch.cat([-x[..., half:], x[..., :half]], -1)
     return x * c + rot * s
 
@@ -67,13 +71,13 @@ def linear(x, sd, prefix):
 
 
 # ------------------------------------------------------------------ Llama decoder
-def llama_decoder(sd, cfg, x, key_valid, prefix='model.language_model.'):
+def llama_decoder(sd, cfg, x, key_valid, prefix='model.language_model.', cos_sin=None):
     """hf:models/llama/modeling_llama.py:295-325 (layer), :385-413 (stack).  position_ids = arange(T) for
     every row, i.e. RoPE positions count left-pad tokens (SURVEY.md §8 a')."""
     N, T, h = x.shape
     H, Hkv = cfg['num_heads'], cfg['num_kv_heads']
     hd = cfg['head_dim']
-    cos, sin = rope_tables(T, hd, cfg['rope_theta'], x.dtype)
+    cos, sin = rope_tables(T, hd, cfg['rope_theta'], x.dtype) if cos_sin is None else cos_sin
     for i in range(cfg['num_layers']):
         p = f'{prefix}layers.{i}.'
         r = x
@@ -151,6 +155,120 @@ def llava_hidden(sd, cfg, input_ids, attention_mask, pixel_values):
 def llava_logits(sd, cfg, input_ids, attention_mask, pixel_values):
     """hf:models/llava/modeling_llava.py:359-361 -- lm_head on ALL positions."""
     return F.linear(llava_hidden(sd, cfg, input_ids, attention_mask, pixel_values), sd['lm_head.weight'])
+
+
+# ------------------------------------------------------------------ Qwen2-VL
+def qwen2vl_vision(sd, vcfg, pixel_values, grid_thw, prefix='model.visual.'):
+    """hf:models/qwen2_vl/modeling_qwen2_vl.py:251-291 (patch embed = Conv3d with kernel == stride, i.e. a matmul over the
+    flattened patches; merger), :342-450 (block: LayerNorm, fused qkv, 2-D rotary in fp32, full attention within each
+    temporal frame, quick_gelu MLP), :700-730 (model); hf:vision_utils.py get_vision_position_ids (block-major h/w ids).
+    pixel_values: [n_patches, C*tps*ps*ps]; grid_thw: [[t, h, w], ...].  Returns merged features [n_patches/merge^2, out]."""
+    E, H, m = vcfg['embed_dim'], vcfg['num_heads'], vcfg['spatial_merge_size']
+    hd = E // H
+    w = sd[prefix + 'patch_embed.proj.weight']
+    x = F.linear(pixel_values.to(w.dtype), w.reshape(E, -1))
+    pos = []
+    for t, h, wd in grid_thw:
+        hp, wp = torch.meshgrid(torch.arange(h), torch.arange(wd), indexing='ij')
+        blk = (h // m, m, wd // m, m)
+        hp = hp.reshape(blk).transpose(1, 2).flatten()
+        wp = wp.reshape(blk).transpose(1, 2).flatten()
+        pos.append(torch.stack([hp, wp], -1).repeat(t, 1))
+    pos = torch.cat(pos, 0)
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float) / (hd // 2)))
+    freqs = (pos.unsqueeze(-1) * inv_freq).flatten(1)               # [n, hd/2]
+    emb = torch.cat([freqs, freqs], -1)
+    cos, sin = emb.cos()[:, None].float(), emb.sin()[:, None].float()
+
+    def rot(t):                                                      # apply_rotary_pos_emb_vision: fp32, cast back
+        tf = t.float()
+        half = tf.shape[-1] // 2
+        r = torch.cat([-tf[..., half:], tf[..., :half]], -1)
+        return (tf * cos + r * sin).to(t.dtype)
+
+    segs = [h * wd for t, h, wd in grid_thw for _ in range(t)]
+    n = x.shape[0]
+    for i in range(vcfg['depth']):
+        p = f'{prefix}blocks.{i}.'
+        y = F.layer_norm(x, (E,), sd[p + 'norm1.weight'], sd[p + 'norm1.bias'], 1e-6)
+        q, k, v = linear(y, sd, p + 'attn.qkv').reshape(n, 3, H, hd).permute(1, 0, 2, 3).unbind(0)
+        q, k = rot(q), rot(k)
+        outs, o = [], 0
+        for L in segs:                                               # one attention segment per (image, frame)
+            a = attention(q[o:o + L].transpose(0, 1)[None], k[o:o + L].transpose(0, 1)[None], v[o:o + L].transpose(0, 1)[None],
+                          hd ** -0.5, False)
+            outs.append(a[0].transpose(0, 1).reshape(L, E)); o += L
+        x = x + linear(torch.cat(outs, 0), sd, p + 'attn.proj')
+        y = F.layer_norm(x, (E,), sd[p + 'norm2.weight'], sd[p + 'norm2.bias'], 1e-6)
+        y = linear(y, sd, p + 'mlp.fc1')
+        x = x + linear(y * torch.sigmoid(1.702 * y), sd, p + 'mlp.fc2')
+    y = F.layer_norm(x, (E,), sd[prefix + 'merger.ln_q.weight'], sd[prefix + 'merger.ln_q.bias'], 1e-6).view(-1, E * m * m)
+    return linear(F.gelu(linear(y, sd, prefix + 'merger.mlp.0')), sd, prefix + 'merger.mlp.2')
+
+
+def qwen2vl_rope_index(input_ids, attention_mask, grid_thw, image_token_id, merge):
+    """hf:models/qwen2_vl/modeling_qwen2_vl.py:862-1018 (get_vision_position_ids + get_rope_index) with the token types
+    taken from input_ids == image_token_id (what the processor's mm_token_type_ids encodes).  Integer work: must match
+    HF bit-exactly.  Returns position_ids int64 [3, N, T] (pad positions 0) and the per-row rope deltas."""
+    N, T = input_ids.shape
+    pos = torch.zeros(3, N, T, dtype=torch.int64)
+    grids = iter(grid_thw)
+    deltas = []
+    for b in range(N):
+        keep = attention_mask[b].bool() if attention_mask is not None else torch.ones(T, dtype=torch.bool)
+        types = (input_ids[b][keep] == image_token_id).tolist()
+        cur, chunks, i = 0, [], 0
+        while i < len(types):
+            j = i
+            while j < len(types) and types[j] == types[i]:
+                j += 1
+            if not types[i]:
+                chunks.append(torch.arange(j - i).view(1, -1).expand(3, -1) + cur)
+                cur += j - i
+            else:
+                t, h, w = next(grids)
+                gh, gw = h // merge, w // merge
+                tt, hh, ww = torch.meshgrid(torch.arange(t), torch.arange(gh) + cur, torch.arange(gw) + cur, indexing='ij')
+                v = torch.stack([tt, hh, ww], 0).reshape(3, -1)
+                v[0] += cur
+                chunks.append(v)
+                cur += max(h, w) // merge
+            i = j
+        lp = torch.cat(chunks, 1)
+        pos[:, b, keep] = lp
+        deltas.append(int(lp.max()) + 1 - int(keep.sum()))
+    return pos, torch.tensor(deltas)
+
+
+def qwen2vl_hidden(sd, cfg, input_ids, attention_mask, pixel_values, grid_thw):
+    """hf:models/qwen2_vl/modeling_qwen2_vl.py:1144-1205 (merge image features by masked_scatter, 3-D position ids) and
+    :156-222 (multimodal RoPE: frequency f of the half-dim takes its angle from the t / h / w position according to
+    mrope_section), then the Qwen2 decoder (= the Llama block with q/k/v biases)."""
+    t = cfg['text']
+    x = F.embedding(input_ids, sd['model.language_model.embed_tokens.weight'])
+    if pixel_values is not None:
+        feat = qwen2vl_vision(sd, cfg['vision'], pixel_values, grid_thw)
+        mask = input_ids == cfg['image_token_id']
+        assert int(mask.sum()) == feat.shape[0], 'image token / feature count mismatch'
+        x = x.masked_scatter(mask[..., None].expand_as(x), feat.to(x.dtype))
+        pos, _ = qwen2vl_rope_index(input_ids, attention_mask, grid_thw, cfg['image_token_id'], cfg['vision']['spatial_merge_size'])
+    else:   # text only: HF derives 1-D positions from the mask, identical on the three axes
+        am = attention_mask if attention_mask is not None else torch.ones_like(input_ids)
+        p1 = (am.long().cumsum(-1) - 1).masked_fill(am == 0, 0)
+        pos = p1[None].expand(3, -1, -1)
+    hd = t['head_dim']
+    inv_freq = 1.0 / (t['rope_theta'] ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
+    freqs = pos[..., None].float() * inv_freq                        # [3, N, T, hd/2]
+    sec = t['mrope_section']
+    comp = torch.cat([torch.full((n,), i % 3) for i, n in enumerate(sec)])
+    f = torch.stack([freqs[int(comp[j]), :, :, j] for j in range(hd // 2)], -1)    # [N, T, hd/2]
+    cos, sin = f.cos().to(x.dtype), f.sin().to(x.dtype)
+    key_valid = attention_mask.bool() if attention_mask is not None else None
+    return llama_decoder(sd, t, x, key_valid, cos_sin=(cos, sin))
+
+
+def qwen2vl_logits(sd, cfg, input_ids, attention_mask, pixel_values, grid_thw):
+    return F.linear(qwen2vl_hidden(sd, cfg, input_ids, attention_mask, pixel_values, grid_thw), sd['lm_head.weight'])
 
 
 def llama_logits(sd, cfg, input_ids, attention_mask, prefix='model.'):

@@ -175,3 +175,33 @@ def test_simpo_orpo_kto_oracle_matches_reference_losses():
     logits = om.opt_logits(sd, tiny_opt_cfg(), ids, mask)
     mine = orl.compute_log_probs(logits, ids, [int(r) for r in z['response_lens']], int(z['pad_token_id']))
     np.testing.assert_allclose(mine.numpy(), z['seq_log_probs'], rtol=2e-4, atol=2e-4)
+
+
+def test_qwen2vl_oracle_matches_reference_dpo_fixture():
+    """oracle/models.py::qwen2vl_* (vision tower with 2-D rotary, 3-D rope index, multimodal RoPE decoder) vs the fixture the
+    reference's text_image_to_text DPOTrainer produced on HF Qwen2VLForConditionalGeneration (qwen2vl_tiny_dpo.npz)."""
+    from tests.util import tiny_qwen2vl_cfg
+    z = load_golden('qwen2vl_tiny_dpo.npz')
+    cfg = tiny_qwen2vl_cfg()
+    ids, mask, pix = T(z['input_ids']), T(z['attention_mask']), T(z['pixel_values'])
+    grid = z['image_grid_thw'].tolist()
+    pos, deltas = om.qwen2vl_rope_index(ids, mask, grid, cfg['image_token_id'], 2)
+    assert np.array_equal(pos.numpy(), z['position_ids']) and deltas.tolist() == z['rope_deltas'].tolist()   # integer work: exact
+    sd = {k: v.clone().requires_grad_(True) for k, v in state_dict_from_golden(z, 'w.').items()}
+    rsd = state_dict_from_golden(z, 'r.')
+    feats = om.qwen2vl_vision(sd, cfg['vision'], pix, grid)
+    assert rel_err(feats.detach(), T(z['image_features'])) < 1e-5
+    logits = om.qwen2vl_logits(sd, cfg, ids, mask, pix, grid)
+    valid = mask.bool()
+    assert rel_err(logits.detach()[valid], T(z['policy_logits'])[valid]) < 1e-5
+    resp = [int(r) for r in z['response_lens']]
+    lp = orl.compute_log_probs(logits, ids, resp, int(z['pad_token_id']))
+    np.testing.assert_allclose(lp.detach().numpy(), z['seq_log_probs'], rtol=2e-4, atol=2e-4)
+    with torch.no_grad():
+        rlp = orl.compute_log_probs(om.qwen2vl_logits(rsd, cfg, ids, mask, pix, grid), ids, resp, int(z['pad_token_id']))
+    ld = orl.dpo_loss(lp, rlp, float(z['scale_coeff']))
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < 2e-5
+    ld['loss'].backward()
+    for k in z.files:
+        if k.startswith('g.') and k[2:] in sd:
+            assert rel_err(sd[k[2:]].grad, T(z[k])) < 2e-3, k
