@@ -106,16 +106,21 @@ class LlamaStack:
             n = max(T, self.cfg.get('max_position_embeddings', 0) or T)
             self.cos, self.sin = rope_tables(n, self.cfg['head_dim'], self.cfg['rope_theta'], self.store.device, self.store.dtype)
 
-    def forward(self, x, N, T, start, pos, save, kv_sink=None):
+    def forward(self, x, N, T, start, pos, save, kv_sink=None, tables=None):
+        """tables = (cos, sin) [rows, hd/2]: per-token rope rows (multimodal RoPE), indexed by pos[row]; default = the
+        1-D position tables."""
         c, P = self.cfg, self.store.p
         H, Hkv, hd, eps = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps']
-        self._tables(T)
+        if tables is None:
+            self._tables(T)
+            tables = (self.cos, self.sin)
+        self._rope = tables
         self.saved = []
         qw, kw = H * hd, Hkv * hd
         for li, L in enumerate(self.layers):
             n1, rstd1 = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
             qkv = L['qkv'].fwd(n1)
-            ops.rope_(qkv, 0, H + Hkv, hd, pos, self.cos, self.sin)
+            ops.rope_(qkv, 0, H + Hkv, hd, pos, tables[0], tables[1])
             if kv_sink is not None:
                 kv_sink(li, qkv[:N * T, qw:])  # post-RoPE keys | values of this layer -> KV cache (prefill)
             attn, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
@@ -188,7 +193,7 @@ class LlamaStack:
             ops.attn_bwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], attn, d_attn, lse,
                          d_qkv[:, :qw], d_qkv[:, qw:qw + kw], d_qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
                          hd ** -0.5, start)
-            ops.rope_(d_qkv, 0, H + Hkv, hd, pos, self.cos, self.sin, inverse=True)
+            ops.rope_(d_qkv, 0, H + Hkv, hd, pos, self._rope[0], self._rope[1], inverse=True)
             d_n1 = L['qkv'].dx(d_qkv)
             if tr:
                 L['qkv'].dw(d_qkv, n1)
@@ -431,6 +436,10 @@ class NativeCausalLM:
     def init_training(self):
         self.store.init_training()
 
+    def decode_start_positions(self, valid):
+        """RoPE position of the first generated token of every row (generation.py); HF: number of attended tokens."""
+        return valid
+
     # -- geometry helpers
     def _token_geometry(self, input_ids, attention_mask, position_ids=None):
         N, T = input_ids.shape
@@ -456,27 +465,27 @@ class NativeCausalLM:
 
     # -- the DPO/PPO entry points
     def response_logprobs(self, input_ids, attention_mask, window, pixel_values=None, save=False,
-                          image_features=None, round_bf16=False):
+                          image_features=None, round_bf16=False, **mm):
         """window: dict(row_idx int64[rows_pad], labels int64[rows_pad], inv_map int32[Mp]) built by
         trainers.common.build_window.  Returns flat fp32 log-probs [rows_pad] (pad rows meaningless)."""
-        x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features)
+        x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features, **mm)
         logp = self.head.forward(x, window['row_idx'], window['labels'], save, round_bf16)
         if save:
             self._ctx['window'] = window
         return logp
 
-    def response_scores(self, input_ids, attention_mask, window, pixel_values=None, save=False, image_features=None):
+    def response_scores(self, input_ids, attention_mask, window, pixel_values=None, save=False, image_features=None, **mm):
         """Score-head models: fp32 scores on the window rows (critic values / reward scores)."""
-        x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features)
+        x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features, **mm)
         sc = self.head.forward(x, window['row_idx'], None, save)
         if save:
             self._ctx['window'] = window
         return sc
 
-    def scores(self, input_ids, attention_mask=None, pixel_values=None):
+    def scores(self, input_ids, attention_mask=None, pixel_values=None, **mm):
         """ScoreModelOutput.scores [N, T] (fp32) for every position."""
         N, T = input_ids.shape
-        x = self.forward_stream(input_ids, attention_mask, pixel_values, save=False)
+        x = self.forward_stream(input_ids, attention_mask, pixel_values, save=False, **mm)
         return self.head.scores_all(x)[:N * T].view(N, T)
 
     def backward_from_dlogp(self, dlogp, on_layer_done=None):
@@ -484,15 +493,15 @@ class NativeCausalLM:
         self.backward_stream(dres, on_layer_done)
         self._ctx = None
 
-    def logits(self, input_ids, attention_mask=None, pixel_values=None):
+    def logits(self, input_ids, attention_mask=None, pixel_values=None, **mm):
         """All-position logits [N, T, V] (what HF returns) -- parity tests and PPO/generation callers."""
         N, T = input_ids.shape
-        x = self.forward_stream(input_ids, attention_mask, pixel_values, save=False)
+        x = self.forward_stream(input_ids, attention_mask, pixel_values, save=False, **mm)
         return self.head.logits_all(x)[:N * T].view(N, T, -1)
 
-    def final_hidden(self, input_ids, attention_mask=None, pixel_values=None):
+    def final_hidden(self, input_ids, attention_mask=None, pixel_values=None, **mm):
         N, T = input_ids.shape
-        x = self.forward_stream(input_ids, attention_mask, pixel_values, save=False)
+        x = self.forward_stream(input_ids, attention_mask, pixel_values, save=False, **mm)
         return self.head.hidden_all(x)[:N * T].view(N, T, -1)
 
 
@@ -591,6 +600,295 @@ class NativeLlava(NativeCausalLM):
             d_a1 = self.proj2.dx(dfeat)
             d_f1 = ops.act_bwd(cx['f1'], d_a1, ops.ACT_GELU)
             self.proj1.dw(d_f1, cx['vfeat'])
+
+
+# ====================================================================== Qwen2-VL
+def qwen2vl_rope_index(input_ids, attention_mask, grid_thw, image_token_id: int, merge: int):
+    """hf:models/qwen2_vl/modeling_qwen2_vl.py:862-1018 get_rope_index (+ get_vision_position_ids) on the host: 3-D position
+    ids int32 [3, N, T] (pad positions 0) and the per-row rope deltas (max position + 1 - attended length).  Integer
+    work -- pinned bit-exactly to HF through tests/golden/qwen2vl_tiny_dpo.npz.  Token types come from
+    input_ids == image_token_id (what the processor's mm_token_type_ids encodes)."""
+    import numpy as np
+    ids = input_ids.cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)
+    N, T = ids.shape
+    am = np.ones((N, T), dtype=bool) if attention_mask is None else (
+        attention_mask.cpu().numpy() if isinstance(attention_mask, torch.Tensor) else np.asarray(attention_mask)).astype(bool)
+    pos = np.zeros((3, N, T), dtype=np.int32)
+    deltas = np.zeros(N, dtype=np.int32)
+    gi = 0
+    for b in range(N):
+        keep = np.nonzero(am[b])[0]
+        types = ids[b, keep] == image_token_id
+        out = np.zeros((3, len(keep)), dtype=np.int64)
+        cur, i, n = 0, 0, len(keep)
+        while i < n:
+            j = i
+            while j < n and types[j] == types[i]:
+                j += 1
+            if not types[i]:
+                out[:, i:j] = np.arange(j - i)[None] + cur
+                cur += j - i
+            else:
+                t, h, w = (int(v) for v in grid_thw[gi]); gi += 1
+                gh, gw = h // merge, w // merge
+                if t * gh * gw != j - i:
+                    raise ValueError(f'row {b}: {j - i} image tokens for a {t}x{h}x{w} grid (expected {t * gh * gw})')
+                tt, hh, ww = np.meshgrid(np.arange(t), np.arange(gh) + cur, np.arange(gw) + cur, indexing='ij')
+                out[0, i:j] = tt.reshape(-1) + cur; out[1, i:j] = hh.reshape(-1); out[2, i:j] = ww.reshape(-1)
+                cur += max(h, w) // merge
+            i = j
+        pos[:, b, keep] = out
+        deltas[b] = (out.max() + 1 - n) if n else 0
+    return pos, deltas
+
+
+class Qwen2VLVisionTower:
+    """hf:models/qwen2_vl/modeling_qwen2_vl.py:649-730 Qwen2VisionTransformerPretrainedModel, forward only (frozen):
+    patch embed (Conv3d with kernel == stride = one GEMM over the processor's flattened patches), `depth` pre-LN blocks
+    with 2-D rotary (fp32, :225-236) and full attention inside every (image, frame) segment, then the 2x2 PatchMerger.
+    head_dim 80 (1280 / 16) has no attention kernel: q/k/v heads are produced zero-padded to 128 columns by padding the
+    ROWS of the qkv weight (and the columns of the output projection) once at load time -- the scores and the output are
+    unchanged, the softmax scale stays head_dim**-0.5."""
+
+    def __init__(self, vcfg: dict, store: ParamStore, prefix: str, train_merger: bool):
+        self.cfg, self.store, self.prefix, self.train_merger = vcfg, store, prefix, train_merger
+        E, H = vcfg['embed_dim'], vcfg['num_heads']
+        self.hd = E // H
+        if self.hd > 128 or self.hd % 16:
+            raise NotImplementedError(f'vision head_dim {self.hd}: must be a multiple of 16 and <= 128')
+        self.hdp = self.hd if self.hd in (64, 128) else 128
+        self.K = vcfg['in_channels'] * vcfg['temporal_patch_size'] * vcfg['patch_size'] ** 2
+        self.Kp = _pad64(self.K)
+        F = int(E * vcfg['mlp_ratio'])
+        m2 = vcfg['spatial_merge_size'] ** 2
+        self.patch_w = store.add(prefix + 'patch_embed.proj.weight', (E, self.Kp), False)
+        self.blocks = []
+        for i in range(vcfg['depth']):
+            p = f'{prefix}blocks.{i}.'
+            B = {'n1w': store.add(p + 'norm1.weight', (E,), False), 'n1b': store.add(p + 'norm1.bias', (E,), False),
+                 'n2w': store.add(p + 'norm2.weight', (E,), False), 'n2b': store.add(p + 'norm2.bias', (E,), False),
+                 'qkv_w': store.add(p + 'attn.qkv.weight', (3 * E, E), False), 'qkv_b': store.add(p + 'attn.qkv.bias', (3 * E,), False),
+                 'proj_w': store.add(p + 'attn.proj.weight', (E, E), False), 'proj_b': store.add(p + 'attn.proj.bias', (E,), False),
+                 'fc1': Linear(store, store.add(p + 'mlp.fc1.weight', (F, E), False), store.add(p + 'mlp.fc1.bias', (F,), False)),
+                 'fc2': Linear(store, store.add(p + 'mlp.fc2.weight', (E, F), False), store.add(p + 'mlp.fc2.bias', (E,), False))}
+            self.blocks.append(B)
+        tm = train_merger
+        self.lnq_w = store.add(prefix + 'merger.ln_q.weight', (E,), tm)
+        self.lnq_b = store.add(prefix + 'merger.ln_q.bias', (E,), tm)
+        self.m0 = Linear(store, store.add(prefix + 'merger.mlp.0.weight', (E * m2, E * m2), tm), store.add(prefix + 'merger.mlp.0.bias', (E * m2,), tm))
+        self.m2 = Linear(store, store.add(prefix + 'merger.mlp.2.weight', (vcfg['hidden_size'], E * m2), tm),
+                         store.add(prefix + 'merger.mlp.2.bias', (vcfg['hidden_size'],), tm))
+        self._padded = None
+        self._ctx = None
+
+    def invalidate(self):
+        self._padded = None
+
+    def _attn_weights(self):
+        """Per block (qkv_w, qkv_b, proj_w): the HF tensors when head_dim has a kernel, else head-padded copies."""
+        if self._padded is None:
+            P, E, H, hd, hdp = self.store.p, self.cfg['embed_dim'], self.cfg['num_heads'], self.hd, self.hdp
+            out = []
+            for B in self.blocks:
+                if hd == hdp:
+                    out.append((P[B['qkv_w']], P[B['qkv_b']], P[B['proj_w']]))
+                    continue
+                qw = torch.zeros((3, H, hdp, E), dtype=self.store.dtype, device=self.store.device)
+                qw[:, :, :hd] = P[B['qkv_w']].view(3, H, hd, E)
+                qb = torch.zeros((3, H, hdp), dtype=self.store.dtype, device=self.store.device)
+                qb[:, :, :hd] = P[B['qkv_b']].view(3, H, hd)
+                pw = torch.zeros((E, H, hdp), dtype=self.store.dtype, device=self.store.device)
+                pw[:, :, :hd] = P[B['proj_w']].view(E, H, hd)
+                out.append((qw.view(3 * H * hdp, E), qb.view(-1), pw.view(E, H * hdp)))
+            self._padded = out
+        return self._padded
+
+    def _rotary(self, grid_thw):
+        """hf:vision_utils.py get_vision_position_ids + VisionRotaryEmbedding: fp32 cos/sin rows [n_patches, head_dim/2]
+        (block-major h / w ids of the 2x2 merge groups), and the attention segments [(row0, n_seq, seq_len)]."""
+        import numpy as np
+        m, hd = self.cfg['spatial_merge_size'], self.hd
+        pos, segs, o = [], [], 0
+        for t, h, w in grid_thw:
+            hp, wp = np.meshgrid(np.arange(h), np.arange(w), indexing='ij')
+            blk = (h // m, m, w // m, m)
+            hp = hp.reshape(blk).transpose(0, 2, 1, 3).reshape(-1)
+            wp = wp.reshape(blk).transpose(0, 2, 1, 3).reshape(-1)
+            pos.append(np.tile(np.stack([hp, wp], -1), (t, 1)))
+            segs.append((o, t, h * w)); o += t * h * w
+        pos = torch.from_numpy(np.concatenate(pos, 0)).to(torch.float32)
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float32) / (hd // 2)))
+        freqs = (pos.unsqueeze(-1) * inv_freq).flatten(1)             # [n, hd/2]  (h part | w part)
+        return freqs.cos().contiguous(), freqs.sin().contiguous(), segs, o
+
+    def forward(self, pixel_values, grid_thw, save=False):
+        """pixel_values [n_patches, C*tps*ps*ps] (fp32 / bf16), grid_thw [[t, h, w], ...] host ints -> merged features
+        [n_patches / merge^2 (padded to 64 rows, zero), hidden_size]."""
+        c, P, dev, dt = self.cfg, self.store.p, self.store.device, self.store.dtype
+        grid = [[int(v) for v in g] for g in (grid_thw.tolist() if isinstance(grid_thw, torch.Tensor) else grid_thw)]
+        E, H, hd, hdp = c['embed_dim'], c['num_heads'], self.hd, self.hdp
+        cos, sin, segs, n = self._rotary(grid)
+        if pixel_values.shape[0] != n or pixel_values.shape[1] != self.K:
+            raise ValueError(f'pixel_values {tuple(pixel_values.shape)} does not match image_grid_thw ({n} patches of {self.K})')
+        cos, sin = cos.to(dev), sin.to(dev)
+        pix = torch.zeros((n, self.Kp), dtype=dt, device=dev)
+        pix[:, :self.K] = pixel_values.to(dt)
+        x = ops.gemm(pix, P[self.patch_w])
+        rows = torch.arange(n, dtype=torch.int32, device=dev)
+        W = self._attn_weights()
+        for B, (qkv_w, qkv_b, proj_w) in zip(self.blocks, W):
+            y, _, _ = ops.layernorm_fwd(x, P[B['n1w']], P[B['n1b']], 1e-6, want_stats=False)
+            qkv = ops.gemm(y, qkv_w, bias=qkv_b)
+            ops.rope_(qkv, 0, 2 * H, hd, rows, cos, sin, head_stride=hdp, precise=True)
+            a = torch.empty((n, H * hdp), dtype=dt, device=dev)
+            for o, nseq, L in segs:
+                v = slice(o, o + nseq * L)
+                ops.attn_fwd(qkv[v, :H * hdp], qkv[v, H * hdp:2 * H * hdp], qkv[v, 2 * H * hdp:], nseq, L, H, H, hdp, False, hd ** -0.5,
+                             out=a[v])
+            x = ops.gemm(a, proj_w, bias=P[B['proj_b']], residual=x)
+            y, _, _ = ops.layernorm_fwd(x, P[B['n2w']], P[B['n2b']], 1e-6, want_stats=False)
+            y = B['fc1'].fwd(y, act=ops.ACT_QUICK_GELU)
+            x = B['fc2'].fwd(y, residual=x)
+        m2 = c['spatial_merge_size'] ** 2
+        y, mean, rstd = ops.layernorm_fwd(x, P[self.lnq_w], P[self.lnq_b], 1e-6)
+        nf = n // m2
+        y4 = torch.zeros((_pad64(nf), E * m2), dtype=dt, device=dev)      # pad rows zero: K of the merger dW GEMMs
+        y4[:nf] = y.view(nf, E * m2)
+        f1 = self.m0.fwd(y4)
+        a1 = ops.act_fwd(f1, ops.ACT_GELU)
+        feat = self.m2.fwd(a1)
+        if save:
+            self._ctx = dict(x=x, mean=mean, rstd=rstd, y4=y4, f1=f1, a1=a1, nf=nf)
+        return feat, nf
+
+    def backward_merger(self, dfeat):
+        """Gradients of the PatchMerger (ln_q, mlp.0, mlp.2); the blocks below it are frozen, so dx stops here."""
+        cx, G, P = self._ctx, self.store.g, self.store.p
+        self.m2.dw(dfeat, cx['a1'])
+        d_a1 = self.m2.dx(dfeat)
+        d_f1 = ops.act_bwd(cx['f1'], d_a1, ops.ACT_GELU)
+        self.m0.dw(d_f1, cx['y4'])
+        d_y4 = self.m0.dx(d_f1)
+        E = self.cfg['embed_dim']
+        d_y = d_y4[:cx['nf']].reshape(-1, E).contiguous()
+        ops.layernorm_bwd(d_y, cx['x'], P[self.lnq_w], cx['mean'], cx['rstd'], G.get(self.lnq_w), G.get(self.lnq_b))
+        self._ctx = None
+
+
+class NativeQwen2VL(NativeCausalLM):
+    """hf:models/qwen2_vl/modeling_qwen2_vl.py:1207+ Qwen2VLForConditionalGeneration (align_anything/models/qwen2_vl.py):
+    vision tower -> merged image features scattered over the image-token positions -> Qwen2 decoder (the Llama block with
+    q/k/v biases, GQA) under multimodal RoPE.  The visual blocks are frozen (forward only); the PatchMerger follows
+    `freeze_mm_proj`.  (The reference freezes by the substrings 'vision_tower' / 'multi_modal_projector',
+    models/pretrained_model.py:265-281, which match nothing in `model.visual.*`, so there the whole tower trains.)"""
+
+    kind = 'qwen2vl'
+
+    def __init__(self, cfg, device, trainable=True, freeze_mm_proj=False, freeze_language_model=False,
+                 freeze_vision_tower=True, head='lm', dtype=bf16):
+        super().__init__(cfg, device, trainable, dtype)
+        self.head_kind = head
+        if not freeze_vision_tower and trainable:
+            raise NotImplementedError('training the Qwen2-VL visual blocks is not built (forward only); the merger trains')
+        t = cfg['text']
+        self.hidden_size = t['hidden_size']
+        self.train_lm = trainable and not freeze_language_model
+        self.train_proj = trainable and not freeze_mm_proj
+        st = self.store
+        self.vision = Qwen2VLVisionTower(cfg['vision'], st, 'model.visual.', self.train_proj)
+        self.embed = st.add('model.language_model.embed_tokens.weight', (t['vocab_size'], t['hidden_size']), self.train_lm, f32_grad=True)
+        self.stack = LlamaStack(t, st, 'model.language_model.', self.train_lm)
+        if head == 'lm':
+            lm = st.add('lm_head.weight', (t['vocab_size'], t['hidden_size']), self.train_lm)
+            self.head = LMHead(st, 'rms', self.stack.norm, None, lm, t['rms_eps'], self.train_lm)
+        else:
+            sw = st.add('score_head.weight', (1, t['hidden_size']), trainable, f32_grad=True)
+            self.head = ScoreHead(st, 'rms', self.stack.norm, None, sw, t['rms_eps'], trainable)
+        hd = t['head_dim']
+        self.inv_freq = (1.0 / (t['rope_theta'] ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(self.device)
+        self._deltas = None
+        self.finalize()
+
+    def _padcols(self):
+        return {'model.visual.patch_embed.proj.weight': True}
+
+    def _unpad(self):
+        v = self.cfg['vision']
+        return {'model.visual.patch_embed.proj.weight':
+                (v['embed_dim'], v['in_channels'], v['temporal_patch_size'], v['patch_size'], v['patch_size'])}
+
+    def load_state_dict(self, sd, strict=True):
+        self.vision.invalidate()
+        return super().load_state_dict(sd, strict)
+
+    def vision_features(self, pixel_values, image_grid_thw):
+        return self.vision.forward(pixel_values, image_grid_thw)[0]
+
+    def decode_start_positions(self, valid):
+        return valid + self._deltas.to(valid.dtype) if self._deltas is not None else valid
+
+    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
+                       position_ids=None, kv_sink=None, image_grid_thw=None, position_ids3=None):
+        """position_ids3 (int32 [3, N, T], e.g. precomputed by the input pipeline on the host) avoids the device->host
+        copy of input_ids that computing the 3-D rope index needs."""
+        N, T, Mp, start, _ = self._token_geometry(input_ids, attention_mask, None)
+        P, t = self.store.p, self.cfg['text']
+        ids = input_ids.reshape(-1)
+        if Mp != N * T:
+            ids = torch.cat([ids, torch.zeros(Mp - N * T, dtype=ids.dtype, device=ids.device)])
+        slot = feat = None
+        has_img = pixel_values is not None or image_features is not None
+        if has_img:
+            if image_grid_thw is None:
+                raise ValueError('Qwen2-VL needs image_grid_thw with pixel_values (the processor returns both)')
+            if image_features is not None:
+                feat, nf = image_features, None
+            else:
+                feat, nf = self.vision.forward(pixel_values, image_grid_thw, save=save and self.train_proj)
+            slot, count = ops.image_slot_index(ids, self.cfg['image_token_id'])
+            self._last_image_token_count, self._last_feature_rows = count, nf
+        if position_ids3 is None:
+            if has_img:
+                grid = image_grid_thw.tolist() if isinstance(image_grid_thw, torch.Tensor) else image_grid_thw
+                p3, deltas = qwen2vl_rope_index(input_ids, attention_mask, grid, self.cfg['image_token_id'],
+                                                self.cfg['vision']['spatial_merge_size'])
+                position_ids3 = torch.from_numpy(p3).to(self.device)
+                self._deltas = torch.from_numpy(deltas).to(self.device)
+            else:   # text only: 1-D positions from the mask on all three axes (hf compute_3d_position_ids fallback)
+                am = attention_mask.to(torch.int64) if attention_mask is not None else torch.ones_like(input_ids)
+                p1 = ((torch.cumsum(am, 1) - 1) * am).to(torch.int32)
+                position_ids3 = p1[None].expand(3, -1, -1)
+                self._deltas = None
+        p3 = position_ids3.to(torch.int32).reshape(3, N * T)
+        if Mp != N * T:
+            p3 = torch.cat([p3, torch.zeros((3, Mp - N * T), dtype=torch.int32, device=self.device)], 1)
+        p3 = p3.contiguous()
+        tables = ops.mrope_tables(p3, self.inv_freq, t['mrope_section'], self.dtype)
+        rows = torch.arange(Mp, dtype=torch.int32, device=self.device)
+        x = ops.embed_fwd(ids, P[self.embed], slot, feat)
+        if save:
+            self._ctx = dict(ids=ids, slot=slot, feat_rows=None if feat is None else feat.shape[0], N=N, T=T, start=start, pos=rows)
+        return self.stack.forward(x, N, T, start, rows, save, kv_sink, tables=tables)
+
+    def embed_tokens(self, ids, pos=None):
+        return ops.embed_fwd(ids, self.store.p[self.embed])
+
+    def validate_batch(self):
+        c = int(self._last_image_token_count.item())
+        if self._last_feature_rows is not None and c != self._last_feature_rows:
+            raise ValueError(f'Image features and image tokens do not match: tokens: {c}, features {self._last_feature_rows}')
+
+    def backward_stream(self, dres, on_layer_done=None):
+        cx = self._ctx
+        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done)
+        G = self.store.g
+        want_feat = cx['slot'] is not None and self.train_proj and self.vision._ctx is not None
+        dfeat = torch.zeros((cx['feat_rows'], self.hidden_size), dtype=self.dtype, device=self.device) if want_feat else None
+        if self.train_lm or want_feat:
+            ops.embed_bwd(cx['ids'], dx, self.cfg['text']['vocab_size'], slot=cx['slot'],
+                          dE=G.get(self.embed) if self.train_lm else None, dfeat=dfeat)
+        if want_feat:
+            self.vision.backward_merger(dfeat)
 
 
 # ====================================================================== Llama (text only)
@@ -812,4 +1110,6 @@ def build_model(cfg: dict, device, trainable=True, head='lm', dtype=bf16, **free
         return NativeOPT(cfg, device, trainable, head=head, dtype=dtype)
     if cfg['kind'] == 'llama':
         return NativeLlama(cfg, device, trainable, head=head, dtype=dtype)
+    if cfg['kind'] == 'qwen2vl':
+        return NativeQwen2VL(cfg, device, trainable, head=head, dtype=dtype, **freeze)
     raise ValueError(f"no native model for kind {cfg['kind']!r}")

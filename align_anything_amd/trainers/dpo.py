@@ -120,9 +120,10 @@ class DPOTrainer:
     def _flat_log_probs(self, module, batch, save):
         w = self._window(batch)
         feats = self._features(batch) if (self.share_vision_tower or module is self.policy) else None
+        mm = {k: batch[k] for k in ('image_grid_thw', 'position_ids3') if k in batch}   # Qwen2-VL processor outputs
         return module.response_logprobs(batch['input_ids'], batch.get('attention_mask'), w,
                                         pixel_values=batch.get('pixel_values') if feats is None else None,
-                                        save=save, image_features=feats, round_bf16=self.emulate_bf16_logp)
+                                        save=save, image_features=feats, round_bf16=self.emulate_bf16_logp, **mm)
 
     def compute_log_probs(self, model, batch) -> torch.Tensor:
         """dpo.py:122-142: [2B, max(R)-1] response-window log-probs, right-padded with 0.0 (fp32 here)."""

@@ -231,7 +231,7 @@ def tiny_qwen2vl():
         text_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
                          vocab_size=320, max_position_embeddings=256, rms_norm_eps=1e-6,
                          rope_parameters={'rope_type': 'default', 'rope_theta': 10000.0, 'mrope_section': [8, 12, 12]}),
-        vision_config=dict(depth=2, embed_dim=160, hidden_size=128, num_heads=2, mlp_ratio=2, patch_size=14, temporal_patch_size=2,
+        vision_config=dict(depth=2, embed_dim=320, hidden_size=128, num_heads=4, mlp_ratio=2, patch_size=14, temporal_patch_size=2,
                            spatial_merge_size=2, in_channels=3),      # head_dim 80, like the real tower (1280 / 16)
         image_token_id=300, video_token_id=301, vision_start_token_id=302, vision_end_token_id=303, bos_token_id=1, eos_token_id=2)
     torch.manual_seed(17)

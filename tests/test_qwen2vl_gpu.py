@@ -1,0 +1,91 @@
+"""GPU: native Qwen2-VL (BASELINE configs[2] backbone) against the fixture the reference's text_image_to_text DPOTrainer
+produced on HF Qwen2VLForConditionalGeneration (tests/golden/qwen2vl_tiny_dpo.npz): vision tower with head_dim 80 (zero-
+padded heads), 2-D rotary, 2x2 merger, image-token scatter, 3-D rope index, multimodal RoPE decoder with GQA + biases."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import assert_close, dev, dump
+from tests.util import load_golden, rel_err, state_dict_from_golden, tiny_qwen2vl_cfg
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _batch(z):
+    return {'input_ids': T(z['input_ids']).to(dev()), 'attention_mask': T(z['attention_mask']).to(dev()),
+            'pixel_values': T(z['pixel_values']).to(dev()), 'image_grid_thw': T(z['image_grid_thw']),
+            'meta_info': {'response_lens': [int(x) for x in z['response_lens']]}}
+
+
+def _trainer(z, dtype):
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    cfgs = {'train_cfgs': {'scale_coeff': float(z['scale_coeff']), 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant',
+                           'weight_decay': 0.0, 'compute_dtype': dtype},
+            'model_cfgs': {'pad_token_id': int(z['pad_token_id'])}}
+    wd = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    return DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_qwen2vl_cfg(), policy_state=state_dict_from_golden(z, 'w.', wd),
+                      reference_state=state_dict_from_golden(z, 'r.', wd), device='cuda:0', share_vision_tower=False)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_qwen2vl_dpo_matches_reference_fixture(dtype):
+    z = load_golden('qwen2vl_tiny_dpo.npz')
+    tr = _trainer(z, dtype)
+    b = _batch(z)
+    tight = dtype == 'fp32'
+    feats = tr.policy.vision_features(b['pixel_values'], b['image_grid_thw'])
+    nf = z['image_features'].shape[0]
+    e_feat = rel_err(feats[:nf].float().cpu(), T(z['image_features']))
+    logits = tr.policy.logits(b['input_ids'], b['attention_mask'], b['pixel_values'], image_grid_thw=b['image_grid_thw']).float().cpu()
+    tr.policy.validate_batch()
+    valid = T(z['attention_mask']).bool()
+    e_log = rel_err(logits[valid], T(z['policy_logits'])[valid])
+    rep = [f'{dtype}: vision features rel_err {e_feat:.2e}, logits rel_err {e_log:.2e}']
+    assert e_feat < (2e-5 if tight else 2e-2) and e_log < (2e-5 if tight else 3e-2), rep
+    lp = tr.compute_log_probs(tr.model, b).cpu()
+    assert torch.equal(lp == 0, T(z['seq_log_probs']) == 0)
+    assert (lp - T(z['seq_log_probs'])).abs().max() < (1e-4 if tight else 8e-2)
+    ld = tr.loss(b)
+    rep.append(f"loss native {float(ld['loss']):.6f} reference {float(z['loss_loss']):.6f}")
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < (3e-5 if tight else 2e-2)
+    assert_close(ld['reward_margin'].cpu(), T(z['loss_reward_margin']), rtol=1e-2, atol=(3e-5 if tight else 5e-2), what='margin')
+    tr.model.backward(ld['loss'])
+    torch.cuda.synchronize()
+    worst, n = 0.0, 0
+    for k in z.files:
+        if not k.startswith('g.') or k.startswith('g.model.visual.patch_embed'):
+            continue
+        g = tr.policy.store.grad_view(k[2:])
+        assert g is not None, k                       # language model + merger are trainable
+        want = T(z[k])
+        if float(want.norm()) < 1e-6:
+            assert float(g.float().norm()) < 1e-4, k
+            continue
+        e = rel_err(g.float().cpu().reshape(want.shape), want)
+        worst = max(worst, e); n += 1
+        assert e < (3e-4 if tight else 9e-2), (k, e)
+    rep.append(f'worst gradient rel_err {worst:.2e} over {n} tensors (language model + merger)')
+    dump(f'parity_qwen2vl_{dtype}.txt', '\n'.join(rep) + '\n')
+    assert n > 25
+    info = tr.train_step(b)
+    assert np.isfinite(info['train/loss'])
+
+
+def test_qwen2vl_rope_index_and_text_only_path():
+    from align_anything_amd.modeling import build_model, qwen2vl_rope_index
+    z = load_golden('qwen2vl_tiny_dpo.npz')
+    p3, d = qwen2vl_rope_index(T(z['input_ids']), T(z['attention_mask']), z['image_grid_thw'].tolist(), 300, 2)
+    assert np.array_equal(p3, z['position_ids']) and d.tolist() == z['rope_deltas'].tolist()
+    with pytest.raises(ValueError):
+        qwen2vl_rope_index(T(z['input_ids']), T(z['attention_mask']), [[1, 2, 2]] * 4, 300, 2)     # wrong grid for the token count
+    # text only: equals a plain Qwen2 (1-D RoPE from the mask) -- checked against the oracle
+    from oracle import models as om
+    m = build_model(tiny_qwen2vl_cfg(), 'cuda:0', trainable=False, dtype=torch.float32)
+    sd = state_dict_from_golden(z, 'w.')
+    m.load_state_dict(sd)
+    ids = T(z['input_ids']).clone(); ids[ids == 300] = 7
+    mask = T(z['attention_mask'])
+    got = m.logits(ids.to(dev()), mask.to(dev())).cpu()
+    want = om.qwen2vl_logits(sd, tiny_qwen2vl_cfg(), ids, mask, None, None)
+    assert rel_err(got[mask.bool()], want[mask.bool()]) < 2e-5
