@@ -19,7 +19,7 @@ from . import ops
 @torch.no_grad()
 def generate(model, input_ids, attention_mask, *, max_length=None, max_new_tokens=None, do_sample=True,
              temperature=1.0, top_p=1.0, repetition_penalty=1.0, eos_token_id=None, pad_token_id=0,
-             pixel_values=None, generator=None, sync_every=8, use_graph=False):
+             pixel_values=None, generator=None, sync_every=8, use_graph=False, **mm):
     """Returns sequences [N, T_prompt + n_new] (int64), right-padded with pad_token_id after EOS."""
     if repetition_penalty <= 0.0:
         raise ValueError('repetition_penalty must be > 0')
@@ -46,8 +46,10 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
     def kv_sink(li, kv):  # kv: [N*T, kvw] of layer li
         cache[li].view(N, Tmax, kvw)[:, :T] = kv.view(N, T, kvw)
 
+    # **mm: extra processor outputs of the backbone (Qwen2-VL: image_grid_thw; its prompt positions are the 3-D rope index,
+    # generated tokens continue at max position + 1 on all three axes = 1-D RoPE, hf:models/qwen2_vl/modeling_qwen2_vl.py:1122-1136)
     x = model.forward_stream(input_ids, attention_mask, pixel_values, save=False, position_ids=position_ids,
-                             kv_sink=kv_sink)
+                             kv_sink=kv_sink, **mm)
     last_rows = torch.arange(N, device=dev) * T + (T - 1)
     logits = model.head.logits_rows(ops.embed_fwd(last_rows, x))
 
@@ -60,7 +62,7 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
     # ctypes/torch launches (launch-bound at 7B: ~17 us x 320) collapses to one graph launch)
     st = {
         'logits': logits.clone(), 'unfinished': torch.ones(N, dtype=torch.bool, device=dev),
-        'tslot': torch.full((N,), T, dtype=torch.int64, device=dev), 'pos': valid.to(torch.int32).clone(),
+        'tslot': torch.full((N,), T, dtype=torch.int64, device=dev), 'pos': model.decode_start_positions(valid).to(torch.int32).clone(),
         'length': torch.full((N,), T + 1, dtype=torch.int32, device=dev), 'step': torch.zeros(1, dtype=torch.int64, device=dev),
         'U': torch.rand((max_new_tokens, N), device=dev, generator=generator) if do_sample else None,
     }

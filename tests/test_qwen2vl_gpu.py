@@ -89,3 +89,36 @@ def test_qwen2vl_rope_index_and_text_only_path():
     got = m.logits(ids.to(dev()), mask.to(dev())).cpu()
     want = om.qwen2vl_logits(sd, tiny_qwen2vl_cfg(), ids, mask, None, None)
     assert rel_err(got[mask.bool()], want[mask.bool()]) < 2e-5
+
+
+def test_qwen2vl_generate_greedy_with_image_prefill():
+    """HIP decode after an M-RoPE prefill: generated tokens continue at max(position) + 1 (rope deltas), i.e. what HF's
+    get_rope_index yields when re-run on the extended sequence -- the oracle does exactly that each step."""
+    from align_anything_amd.generation import generate
+    from align_anything_amd.modeling import build_model
+    from oracle import models as om
+    z = load_golden('qwen2vl_tiny_dpo.npz')
+    cfg = tiny_qwen2vl_cfg()
+    m = build_model(cfg, 'cuda:0', trainable=False)
+    m.load_state_dict(state_dict_from_golden(z, 'w.', torch.bfloat16))
+    sd = state_dict_from_golden(z, 'w.')
+    Tn, n_new = 28, 8
+    ids, mask = T(z['input_ids'])[:, :Tn].clone(), T(z['attention_mask'])[:, :Tn].clone()
+    pix, grid = T(z['pixel_values']), z['image_grid_thw'].tolist()
+    seq = generate(m, ids.to(dev()), mask.to(dev()), max_new_tokens=n_new, do_sample=False, pad_token_id=304,
+                   pixel_values=pix.to(dev()), image_grid_thw=grid, sync_every=2).cpu()
+    assert torch.equal(seq[:, :Tn], ids) and seq.shape == (4, Tn + n_new)
+    cur, cm, agree = ids.clone(), mask.clone(), 0
+    for s in range(n_new):
+        lg = om.qwen2vl_logits(sd, cfg, cur, cm, pix, grid)[:, -1]
+        top2 = torch.topk(lg, 2, -1).values
+        nxt = lg.argmax(-1)
+        for r in range(4):
+            if seq[r, Tn + s] == nxt[r]:
+                agree += 1
+            else:   # bf16 decode vs fp32 oracle may flip a near-tie; follow the native token so later steps stay comparable
+                assert float(top2[r, 0] - top2[r, 1]) < 0.08, (s, r, float(top2[r, 0] - top2[r, 1]))
+                nxt[r] = seq[r, Tn + s]
+        cur = torch.cat([cur, nxt[:, None]], 1); cm = torch.cat([cm, torch.ones(4, 1, dtype=cm.dtype)], 1)
+    dump('parity_generate_qwen2vl.txt', f'native {seq.tolist()}\nagree {agree}/{4 * n_new}\n')
+    assert agree >= 4 * n_new - 4
