@@ -323,3 +323,33 @@ extern "C" int aa_sample_top_p(const void* logits, long ld, int rows, int V, flo
     AA_CHECK_LAUNCH("aa_sample_top_p");
     return AA_OK;
 }
+
+// align_anything/trainers/text_image_to_text/ppo.py:56-86 move_padding_left: every row of the generated sequences is rotated
+// right by (L - #non-pad - #leading-pad) so that the padding appended after EOS joins the left padding.  Same integer
+// arithmetic as the reference (a circular shift; pad ids inside the text are NOT compacted) -- bit-exact.
+__global__ __launch_bounds__(256) void move_padding_left_kernel(const int64_t* __restrict__ in, long ldi,
+                                                                int64_t* __restrict__ out, long ldo, int L, int64_t pad) {
+    __shared__ int red[2][4];
+    const int64_t* x = in + (long)blockIdx.x * ldi;
+    int nonpad = 0, first = L;                       // first non-pad index = length of the leading pad run
+    for (int t = threadIdx.x; t < L; t += 256) {
+        if (x[t] != pad) { ++nonpad; first = min(first, t); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nonpad += __shfl_xor(nonpad, o, 64); first = min(first, __shfl_xor(first, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = nonpad; red[1][threadIdx.x >> 6] = first; }
+    __syncthreads();
+    nonpad = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    first = min(min(red[1][0], red[1][1]), min(red[1][2], red[1][3]));
+    const int shift = L - nonpad - first;
+    int64_t* y = out + (long)blockIdx.x * ldo;
+    for (int t = threadIdx.x; t < L; t += 256) y[t] = x[((t - shift) % L + L) % L];
+}
+extern "C" int aa_move_padding_left(const int64_t* in, long ldi, int64_t* out, long ldo, int rows, int L, int64_t pad,
+                                    void* stream) {
+    AA_REQUIRE(rows >= 0 && L > 0 && in != out, "aa_move_padding_left: bad arguments (rows=%d L=%d, in-place not supported)", rows, L);
+    if (rows == 0) return AA_OK;
+    hipLaunchKernelGGL(move_padding_left_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, in, ldi, out, ldo, L, pad);
+    AA_CHECK_LAUNCH("aa_move_padding_left");
+    return AA_OK;
+}

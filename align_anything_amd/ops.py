@@ -520,6 +520,14 @@ def mark_seen_(seen, ids):
     return seen
 
 
+def move_padding_left(seq, pad_token_id):
+    rows, L = seq.shape
+    seq = seq.contiguous()
+    out = torch.empty_like(seq)
+    call('aa_move_padding_left', seq.data_ptr(), seq.stride(0), out.data_ptr(), out.stride(0), rows, L, int(pad_token_id), stream())
+    return out
+
+
 def argmax_rows(logits, seen=None, repetition_penalty=1.0):
     rows, V = logits.shape
     out = torch.empty(rows, dtype=torch.int64, device=logits.device)

@@ -114,6 +114,35 @@ def build_span_window(input_ids: torch.Tensor, start: int):
             'inv_map': torch.from_numpy(inv).to(dev, non_blocking=True), 'labels': labels}
 
 
+def build_tail_window(input_ids: torch.Tensor, response_lens):
+    """Rows of `logits[idx, :-1][-R:]` x `input_ids[idx, 1:][-R:]` (align_anything/trainers/text_image_to_text/ppo.py:233-241,
+    302-305; also `scores[:, :-1][idx][-R:]`): row (n, j), j in [T-1-R_n, T-2], reads hidden position j and is labelled with
+    token j+1 -- R_n entries per sequence, flat, in the layout of build_window.  Pure positional: built on the host."""
+    N, T = input_ids.shape
+    dev = input_ids.device
+    R = np.asarray([int(r) for r in response_lens], dtype=np.int64)
+    if len(R) != N or (R < 1).any() or (R > T - 1).any():
+        raise ValueError(f'response_lens must have {N} entries within [1, {T - 1}]: {R.tolist()}')
+    off = np.concatenate([[0], np.cumsum(R)])
+    rows, rows_pad, L = int(off[-1]), pad64(int(off[-1])), int(R.max())
+    Mp = (N * T + 63) // 64 * 64
+    row_idx = np.zeros(rows_pad, dtype=np.int64)
+    f2p = np.zeros(rows, dtype=np.int64)
+    for n in range(N):
+        j = np.arange(R[n])
+        row_idx[off[n]:off[n + 1]] = n * T + (T - 1 - R[n]) + j
+        f2p[off[n]:off[n + 1]] = n * L + j
+    inv = np.full(Mp, -1, dtype=np.int32)
+    inv[row_idx[:rows]] = np.arange(rows, dtype=np.int32)
+    ridx = torch.from_numpy(row_idx).to(dev, non_blocking=True)
+    labels = torch.zeros(rows_pad, dtype=torch.int64, device=dev)
+    labels[:rows] = input_ids.reshape(-1)[ridx[:rows] + 1]
+    return {'N': N, 'T': T, 'rows': rows, 'rows_pad': rows_pad, 'max_len': L, 'row_idx': ridx,
+            'inv_map': torch.from_numpy(inv).to(dev, non_blocking=True),
+            'seq_off': torch.from_numpy(off.astype(np.int32)).to(dev, non_blocking=True),
+            'flat_to_padded': torch.from_numpy(f2p).to(dev, non_blocking=True), 'labels': labels}
+
+
 def pad_rows(flat_2d: torch.Tensor, rows_pad: int) -> torch.Tensor:
     """[B, W] gradient -> flat fp32 [rows_pad] with zero tail (the pad rows of a window carry no gradient)."""
     out = torch.zeros(rows_pad, dtype=torch.float32, device=flat_2d.device)

@@ -188,6 +188,9 @@ int aa_sample_top_p(const void* logits, long ld, int rows, int V, float temperat
                     const float* uniform, const uint8_t* seen, long ld_seen, float repetition_penalty, int64_t* out,
                     void* stream);
 
+/* trainers/text_image_to_text/ppo.py:56-86 move_padding_left on the generated sequences (circular shift per row, bit-exact) */
+int aa_move_padding_left(const int64_t* in, long ldi, int64_t* out, long ldo, int rows, int L, int64_t pad, void* stream);
+
 /* ---- optimizer (DeepSpeed FusedAdam + gradient_clipping, supervised_trainer.py:245-249) ------ */
 /* *out_accum += sum((g*scale)^2); deterministic (no float atomics): ws = caller-owned scratch of AA_SUMSQ_WS floats, so the
    clip coefficient is bit-identical on every data-parallel rank */

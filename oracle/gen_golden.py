@@ -305,6 +305,98 @@ def gen_qwen2vl_dpo():
     print('qwen2vl_tiny_dpo.npz loss', float(ld['loss']), 'acc', float(ld['reward_accuracy']), 'n arrays', len(out))
 
 
+def gen_qwen2vl_ppo():
+    """BASELINE configs[2]: the reference's unmodified text_image_to_text PPOTrainer.{actor_step (after generate), rollout,
+    rl_step} (trainers/text_image_to_text/ppo.py:174-379) with HF Qwen2-VL as actor / reference and the reference's own
+    AccustomedQwen2VLRewardModel (models/qwen2_vl.py:42-72) as reward model and critic, fp32, CPU.  Only `generate` (fixed
+    sequences), the DeepSpeed engines (plain backward, no optimizer), dist.barrier and -- for transformers 5.x -- the
+    processor-side `mm_token_type_ids` (recomputed from the ids) are stood in."""
+    import align_anything.trainers.text_image_to_text.ppo as ppo_mod
+    from align_anything.models.qwen2_vl import AccustomedQwen2VLRewardModel
+    from align_anything.trainers.text_image_to_text.ppo import PPOTrainer
+    ppo_mod.get_all_reduce_mean = lambda x: x
+    ppo_mod.get_all_reduce_max = lambda x: x
+    ppo_mod.dist = SimpleNamespace(barrier=lambda: None)
+
+    cfg, actor = tiny_qwen2vl()
+    _, refm = tiny_qwen2vl()
+    cfg.hidden_size = cfg.text_config.hidden_size          # models/qwen2_vl.py:48 reads config.hidden_size (pre-5.x layout)
+    g = torch.Generator().manual_seed(31)
+    with torch.no_grad():
+        for p in refm.parameters():
+            p.add_(0.02 * torch.randn(p.shape, generator=g)); p.copy_(p.to(torch.bfloat16).to(torch.float32))
+
+    def score_model(seed):
+        torch.manual_seed(seed)
+        m = AccustomedQwen2VLRewardModel(cfg).eval()
+        m.load_state_dict(actor.state_dict(), strict=False)
+        with torch.no_grad():
+            m.score_head.weight.copy_((torch.randn(1, 128, generator=g) * 0.3).to(torch.bfloat16).float())
+            for p in m.model.language_model.parameters():
+                p.add_(0.01 * torch.randn(p.shape, generator=g)); p.copy_(p.to(torch.bfloat16).to(torch.float32))
+        return m
+    reward, critic = score_model(1), score_model(2)
+
+    PAD, IMG, P, L = 304, 300, 20, 10
+    grids = [[1, 4, 4], [1, 2, 4], [1, 4, 4]]
+    pix = torch.cat([torch.randn(t * h * w, 1176, generator=g) for t, h, w in grids], 0)
+    B = len(grids)
+    prompts = torch.full((B, P), PAD, dtype=torch.long)
+    for r, lp in enumerate((0, 4, 2)):
+        ntok = grids[r][1] * grids[r][2] // 4
+        row = torch.cat([torch.tensor([1, 302]), torch.full((ntok,), IMG), torch.tensor([303]), torch.randint(3, 299, (P - lp - 3 - ntok,), generator=g)])
+        prompts[r, lp:] = row
+    gen = torch.randint(3, 299, (B, L), generator=g)
+    gen[1, 6:] = PAD; gen[1, 5] = 2                        # row 1 stopped at EOS after 6 tokens -> right padding
+    gen[2, 9:] = PAD; gen[2, 8] = 2
+    sequences = torch.cat([prompts, gen], 1)
+
+    class Mod(torch.nn.Module):   # what `engine.module` is: callable like the HF model, with a stubbed generate
+        def __init__(self, m): super().__init__(); self.m = m
+        def forward(self, **kw):
+            kw.pop('use_cache', None)
+            kw['mm_token_type_ids'] = (kw['input_ids'] == IMG).int()
+            return self.m(**kw)
+        def generate(self, **kw): return sequences.clone()
+
+    class Engine:
+        def __init__(self, m): self.module = Mod(m); self.optimizer = SimpleNamespace(param_groups=[{'lr': 0.0}])
+        def __call__(self, **kw): return self.module(**kw)
+        def backward(self, loss): loss.backward()
+        def step(self): pass
+
+    tr = PPOTrainer.__new__(PPOTrainer)
+    tr.actor_model, tr.actor_reference_model, tr.reward_model, tr.reward_critic_model = Engine(actor), Engine(refm), Engine(reward), Engine(critic)
+    tr.tokenizer = tr.reward_tokenizer = SimpleNamespace(pad_token_id=PAD)
+    tr.infer_batch = tr.reward_infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    tr.generation_config = None
+    tr.set_train = lambda mode=True: None
+    tr.kl_coeff, tr.clip_range_ratio, tr.clip_range_score, tr.clip_range_value, tr.gamma, tr.gae_lambda = 0.02, 0.2, 50.0, 5.0, 1.0, 0.95
+    prompt_batch = {'input_ids': prompts, 'attention_mask': (prompts != PAD).long(), 'pixel_values': pix, 'image_grid_thw': torch.tensor(grids)}
+    inf, trn = tr.rollout(prompt_batch)
+    inf, trn = inf[0], trn[0]
+    out = {'prompts': prompts.numpy(), 'generated_sequences': sequences.numpy(), 'pixel_values': pix.numpy(), 'image_grid_thw': np.array(grids),
+           'pad_token_id': np.array(PAD), 'sequences_left': inf['input_ids'].numpy(), 'attention_mask': inf['attention_mask'].numpy().astype(np.int64),
+           'response_lens': np.array(trn['response_lens']), 'log_probs': trn['log_probs'].numpy(), 'ref_log_probs': trn['ref_log_probs'].numpy(),
+           'reward': trn['reward'].numpy(), 'reward_values': trn['reward_values'].numpy(), 'response_mask': trn['response_mask'].numpy()}
+    actor.zero_grad(); critic.zero_grad()
+    info = tr.rl_step(inf, trn)
+    for k, v in info.items():
+        out['info.' + k] = np.array(v)
+    for tag, m in (('a', actor), ('c', critic)):
+        for n, p in m.named_parameters():
+            if p.grad is not None and (n.endswith('layers.1.mlp.down_proj.weight') or n.endswith('layers.0.self_attn.q_proj.weight')
+                                       or n.endswith('language_model.norm.weight') or n == 'score_head.weight' or n.endswith('merger.mlp.2.bias')):
+                out[f'g{tag}.{n}'] = p.grad.numpy().copy()
+    for tag, m in (('a', actor), ('r', refm), ('rm', reward), ('c', critic)):
+        for n, p in m.state_dict().items():
+            if tag in ('rm', 'c') and n.startswith('model.visual.'):
+                continue                                   # reward model / critic share the actor's visual tower (a.model.visual.*)
+            out[f'{tag}.{n}'] = bf16_bits(p)
+    np.savez_compressed(os.path.join(GOLD, 'qwen2vl_tiny_ppo.npz'), **out)
+    print('qwen2vl_tiny_ppo.npz', {k: v for k, v in info.items() if 'loss' in k or 'length' in k}, 'response_lens', trn['response_lens'])
+
+
 def gen_pref():
     """SimPO / ORPO / KTO: the reference's unmodified `loss` overrides (trainers/text_to_text/simpo.py:41-108,
     orpo.py:41-112, kto.py:83-160) on the tiny OPT of opt_tiny_dpo.npz (weights are read back from that fixture, so
@@ -511,6 +603,7 @@ if __name__ == '__main__':
     gen_llava_dpo()
     gen_opt_dpo()
     gen_qwen2vl_dpo()
+    gen_qwen2vl_ppo()
     gen_pref()
     gen_collator()
     gen_grpo()

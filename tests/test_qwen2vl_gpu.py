@@ -122,3 +122,95 @@ def test_qwen2vl_generate_greedy_with_image_prefill():
         cur = torch.cat([cur, nxt[:, None]], 1); cm = torch.cat([cm, torch.ones(4, 1, dtype=cm.dtype)], 1)
     dump('parity_generate_qwen2vl.txt', f'native {seq.tolist()}\nagree {agree}/{4 * n_new}\n')
     assert agree >= 4 * n_new - 4
+
+
+def _ppo_trainer(z, dtype):
+    from align_anything_amd.trainers.ppo_ti2t import PPOTrainerTI2T
+    cfg = tiny_qwen2vl_cfg()
+    cfgs = {'train_cfgs': {'actor_lr': 1e-3, 'critic_lr': 1e-3, 'actor_weight_decay': 0.0, 'critic_weight_decay': 0.0, 'actor_lr_warmup_ratio': 0.0,
+                           'critic_lr_warmup_ratio': 0.0, 'actor_lr_scheduler_type': 'constant', 'critic_lr_scheduler_type': 'constant',
+                           'kl_coeff': 0.02, 'clip_range_ratio': 0.2, 'clip_range_value': 5.0, 'clip_range_score': 50.0, 'gamma': 1.0,
+                           'gae_lambda': 0.95, 'compute_dtype': dtype},
+            'model_cfgs': {'pad_token_id': int(z['pad_token_id']), 'max_new_tokens': 10, 'eos_token_id': 2}}
+    wd = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    vis = {k: v for k, v in state_dict_from_golden(z, 'a.', wd).items() if k.startswith('model.visual.')}
+    score_sd = lambda tag: {**vis, **{k: v for k, v in state_dict_from_golden(z, tag + '.', wd).items() if k != 'lm_head.weight'}}
+    tr = PPOTrainerTI2T(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=state_dict_from_golden(z, 'a.', wd),
+                        reward_state=score_sd('rm'), critic_state=score_sd('c'), device='cuda:0')
+    tr.actor_reference_model.module.load_state_dict(state_dict_from_golden(z, 'r.', wd))
+    return tr
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_qwen2vl_ppo_rollout_and_rl_step_match_reference_fixture(dtype):
+    """The reference's own ti2t PPOTrainer.rollout + rl_step on HF Qwen2-VL (qwen2vl_tiny_ppo.npz) vs the native trainer."""
+    z = load_golden('qwen2vl_tiny_ppo.npz')
+    tr = _ppo_trainer(z, dtype)
+    tight = dtype == 'fp32'
+    d = lambda a: T(a).to(dev())
+    prompt_batch = {'input_ids': d(z['prompts']), 'attention_mask': (d(z['prompts']) != int(z['pad_token_id'])).long(),
+                    'pixel_values': d(z['pixel_values']), 'image_grid_thw': T(z['image_grid_thw'])}
+    inf, trn = tr.rollout(prompt_batch, sequences=d(z['generated_sequences']))
+    # integer work: bit-exact
+    assert torch.equal(inf['input_ids'].cpu(), T(z['sequences_left'])) and torch.equal(inf['attention_mask'].cpu(), T(z['attention_mask']))
+    assert trn['response_lens'] == z['response_lens'].tolist()
+    assert torch.equal(trn['response_mask'].cpu(), T(z['response_mask']))
+    for k in ('log_probs', 'ref_log_probs', 'reward_values', 'reward'):
+        err = (trn[k].float().cpu() - T(z[k])).abs() / (1.0 + T(z[k]).abs())       # bf16 envelope scales with the value
+        assert err.max() < (5e-5 if tight else 1e-1), (k, err.max())
+    # update on the reference's own rollout statistics
+    trn_ref = {k: (d(z[k]) if k != 'response_lens' else z[k].tolist()) for k in ('response_lens', 'log_probs', 'ref_log_probs', 'reward', 'reward_values', 'response_mask')}
+    info = tr.rl_step(inf, trn_ref)
+    rep = []
+    for k in ('train/actor_loss', 'train/reward_critic_loss', 'train/reward', 'train/reward_with_kl_penalty', 'train/reward_advantage',
+              'train/reward_return', 'train/reward_value', 'train/kl_divergence', 'train/mean_generated_length', 'train/max_generated_length'):
+        want = float(z['info.' + k])
+        rep.append(f'{dtype} {k}: native {info[k]:.6f} reference {want:.6f}')
+        assert abs(info[k] - want) < (1e-4 if tight else 6e-2) * max(1.0, abs(want)), rep[-1]
+    for tag, eng in (('ga', tr.actor_model), ('gc', tr.reward_critic_model)):
+        eng.wait_optimizer()
+        torch.cuda.synchronize()
+        for k in z.files:
+            if k.startswith(tag + '.'):
+                g = eng.module.store.grad_view(k[len(tag) + 1:])
+                assert g is not None, k
+                e = rel_err(g.float().cpu().reshape(z[k].shape), T(z[k]))
+                rep.append(f'  {k}: rel_err {e:.2e}')
+                assert e < (5e-4 if tight else 9e-2), (k, e)
+    dump(f'parity_qwen2vl_ppo_{dtype}.txt', '\n'.join(rep) + '\n')
+
+
+def test_qwen2vl_full_ppo_iteration_with_hip_rollout():
+    z = load_golden('qwen2vl_tiny_ppo.npz')
+    tr = _ppo_trainer(z, 'bf16')
+    d = lambda a: T(a).to(dev())
+    prompt_batch = {'input_ids': d(z['prompts']), 'attention_mask': (d(z['prompts']) != int(z['pad_token_id'])).long(),
+                    'pixel_values': d(z['pixel_values']), 'image_grid_thw': T(z['image_grid_thw'])}
+    inf, trn = tr.rollout(prompt_batch, generator=torch.Generator(device='cuda').manual_seed(0))
+    B, P = z['prompts'].shape
+    assert inf['input_ids'].shape[0] == B and P < inf['input_ids'].shape[1] <= P + 10
+    assert all(1 <= r <= 10 for r in trn['response_lens'])
+    pad = int(z['pad_token_id'])
+    for r in range(B):          # all padding on the left, the prompt's own tokens intact
+        row = inf['input_ids'][r]
+        n = int((row != pad).sum())
+        assert bool((row[-n:] != pad).all()) and bool((row[:-n] == pad).all())
+    info = tr.rl_step(inf, trn)
+    assert all(np.isfinite(v) for v in info.values())
+
+
+def test_move_padding_left_matches_reference_arithmetic():
+    from align_anything_amd import ops
+    g = torch.Generator().manual_seed(4)
+    pad = 9
+    x = torch.randint(0, 9, (7, 33), generator=g)
+    for r, (lead, trail) in enumerate(((0, 0), (3, 5), (0, 12), (8, 0), (2, 2), (0, 32), (10, 10))):
+        x[r, :lead] = pad
+        if trail:
+            x[r, 33 - trail:] = pad
+    x[4, 15] = pad                                       # a pad id inside the text: the reference's arithmetic is reproduced as is
+    start = (x == pad).cumsum(1).eq(torch.arange(1, 34)).sum(1)
+    nonpad = (x != pad).sum(1)
+    shifts = 33 - nonpad.unsqueeze(1) - start.unsqueeze(1)
+    want = torch.gather(x, 1, (torch.arange(33).expand(7, 33) - shifts) % 33)
+    assert torch.equal(ops.move_padding_left(x.to(dev()), pad).cpu(), want)
