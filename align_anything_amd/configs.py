@@ -60,6 +60,15 @@ def llava_1_5_7b(num_layers=32, vision_layers=24):
     return llava_cfg(text, vision, image_token_id=32000, pad_token_id=32001)
 
 
+def qwen2_vl_7b(num_layers=28, vision_depth=32):
+    """Qwen2-VL-7B-Instruct geometry (BASELINE.json config 3): ViT 1280 x 32 (16 heads of 80) + Qwen2-7B (28 x 3584, GQA 28/4,
+    ffn 18944, V = 152064), mrope_section [16, 24, 24], theta 1e6."""
+    text = llama_cfg(3584, 18944, num_layers, 28, 4, 152064, rms_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=32768,
+                     attention_bias=True)
+    vision = qwen2vl_vision_cfg(1280, vision_depth, 16, 4, 3584)
+    return qwen2vl_cfg(text, vision, image_token_id=151655, mrope_section=[16, 24, 24], pad_token_id=151643)
+
+
 def opt_125m():
     """facebook/opt-125m geometry (BASELINE.json config 1), dropout forced to 0 for parity."""
     return opt_cfg(768, 3072, 12, 12, 50272, 2048)
