@@ -103,6 +103,7 @@ struct AttnParams {
     float* lse;          // [N, H, T] natural-log LSE of the scaled scores
     float* delta;        // [N, H, T] rowsum(dO * O)
     const int* start;    // [N] first valid key (left padding) or null
+    const int* kvlen;    // [N] number of valid keys (right padding: keys >= kvlen[n] are masked) or null
     long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int N, T, H, Hkv, causal;
     float scale;
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const int q0 = qb * 128, qw = q0 + wave * 32;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
+    const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
     const bf16_t* Qb = p.Q + (long)n * T * p.ldq + h * HD;
     const bf16_t* Kb = p.K + (long)n * T * p.ldk + hk * HD;
     const bf16_t* Vb = p.V + (long)n * T * p.ldv + hk * HD;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                         sacc[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], sacc[qi][kb], 0, 0, 0);
                 }
             // masks only where a mask can bite: diagonal tile, left-pad boundary, ragged end (wave-uniform)
-            const bool need_mask = (p.causal && kv0 + 63 > qw) || kv0 < start || kv0 + 64 > T;
+            const bool need_mask = (p.causal && kv0 + 63 > qw) || kv0 < start || kv0 + 64 > KT;
             bf16x8 pf[2][2];
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi) {
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int kv = kv0 + kb * 16 + g * 4 + r;
-                            const bool ok = kv >= start && kv < T && (!p.causal || kv <= qg);
+                            const bool ok = kv >= start && kv < KT && (!p.causal || kv <= qg);
                             const float s = ok ? sacc[qi][kb][r] * c2 : -INFINITY;
                             sacc[qi][kb][r] = s;
                             mx = fmaxf(mx, s);
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     const int q0 = qb * 128, qw = q0 + wave * 32;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
+    const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
     const bf16_t* Qb = p.Q + (long)n * T * p.ldq + h * HD;
     const bf16_t* dOb = p.dO + (long)n * T * p.lddo + h * HD;
     const bf16_t* Kb = p.K + (long)n * T * p.ldk + hk * HD;
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
                         dpacc[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qi][ks], dpacc[qi][kb], 0, 0, 0);
                     }
                 }
-            const bool need_mask = (p.causal && kv0 + 63 > qw) || kv0 < start || kv0 + 64 > T || qw + 32 > T;
+            const bool need_mask = (p.causal && kv0 + 63 > qw) || kv0 < start || kv0 + 64 > KT || qw + 32 > T;
             bf16x8 dsf[2][2];
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi) {
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
                         float pe = fast_exp2(sacc[qi][kb][r] * c2 - lse2[qi]);
                         if (need_mask) {
                             const int kv = kv0 + kb * 16 + g * 4 + r;
-                            const bool ok = kv >= start && kv < T && (!p.causal || kv <= qg) && qg < T;
+                            const bool ok = kv >= start && kv < KT && (!p.causal || kv <= qg) && qg < T;
                             pe = ok ? pe : 0.f;
                         }
                         sacc[qi][kb][r] = pe * (dpacc[qi][kb][r] - dl[qi]) * p.scale;
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     const int kv0 = (blockIdx.x / HkN) * 64, kvw = kv0 + wave * 16;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
+    const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
     const bf16_t* Kb = p.K + (long)n * T * p.ldk + hk * HD;
     const bf16_t* Vb = p.V + (long)n * T * p.ldv + hk * HD;
     const float c2 = p.scale * LOG2E_F;
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
                     sacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sacc[qb], 0, 0, 0);
                     dpacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dpacc[qb], 0, 0, 0);
                 }
-            const bool need_mask = (p.causal && qt0 < kvw + 15) || kvw < start || kvw + 16 > T || qt0 + 64 > T;
+            const bool need_mask = (p.causal && qt0 < kvw + 15) || kvw < start || kvw + 16 > KT || qt0 + 64 > T;
             bf16x8 pfr[2], dsfr[2];
             f32x4 pv[4], dsv[4];
 #pragma unroll
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
                     float pe = fast_exp2(sacc[qb][r] * c2 - st[ql]);
                     if (need_mask) {
                         const int qg = qt0 + ql;
-                        const bool ok = kvg >= start && kvg < T && qg < T && (!p.causal || kvg <= qg);
+                        const bool ok = kvg >= start && kvg < KT && qg < T && (!p.causal || kvg <= qg);
                         pe = ok ? pe : 0.f;
                     }
                     pv[qb][r] = pe;
@@ -583,14 +587,14 @@ static int set_lds(K kern, int bytes, const char* name) {
 }
 
 extern "C" int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse,
-                           const int* start, long ldq, long ldk, long ldv, long ldo, int N, int T,
+                           const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, int N, int T,
                            int H, int Hkv, int hd, int causal, float scale, void* stream) {
     int rc = check_common("aa_attn_fwd", N, T, H, Hkv, hd);
     if (rc) return rc;
     AA_REQUIRE((ldq | ldk | ldv | ldo) % 8 == 0, "aa_attn_fwd: leading dims must be multiples of 8");
     AttnParams p{};
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O;
-    p.lse = lse; p.start = start; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.lse = lse; p.start = start; p.kvlen = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
     dim3 grid(aa_cdiv(T, 128) * H * N);
     const int lds = 4 * 64 * hd * 2;
@@ -607,7 +611,7 @@ extern "C" int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O,
 
 extern "C" int aa_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
                            const float* lse, float* delta, void* dQ, void* dK, void* dV,
-                           const int* start, long ldq, long ldk, long ldv, long ldo, long lddo,
+                           const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo,
                            long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
                            int causal, float scale, void* stream) {
     int rc = check_common("aa_attn_bwd", N, T, H, Hkv, hd);
@@ -617,7 +621,7 @@ extern "C" int aa_attn_bwd(const void* Q, const void* K, const void* V, const vo
     AttnParams p{};
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O;
     p.dO = (const bf16_t*)dO; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
-    p.lse = const_cast<float*>(lse); p.delta = delta; p.start = start;
+    p.lse = const_cast<float*>(lse); p.delta = delta; p.start = start; p.kvlen = kv_len;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
     hipStream_t st = (hipStream_t)stream;

@@ -12,7 +12,7 @@ namespace {
 struct AttnF32Params {
     const float* Q; const float* K; const float* V; float* O;
     const float* dO; float* dQ; float* dK; float* dV;
-    float* lse; float* delta; const int* start;
+    float* lse; float* delta; const int* start; const int* kvlen;
     long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int N, T, H, Hkv, causal;
     float scale;
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AttnF32Params p
     const int hk = h / (p.H / p.Hkv);
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
+    const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
     const int qi = qb * ROWS + (threadIdx.x >> 2);
     const int part = threadIdx.x & 3;
     const long seq0 = (long)n * T;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AttnF32Params p
             }
             acc = quad_sum(acc) * p.scale;
             const int kj = k0 + j;
-            const bool ok = kj >= start && kj < T && (!p.causal || kj <= qi) && qi < T;
+            const bool ok = kj >= start && kj < KT && (!p.causal || kj <= qi) && qi < T;
             s[j] = ok ? acc : -INFINITY;
             mx = fmaxf(mx, s[j]);
         }
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AttnF32Param
     const int hk = h / (p.H / p.Hkv);
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
+    const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
     const int qi = qb * ROWS + (threadIdx.x >> 2);
     const int part = threadIdx.x & 3;
     const long seq0 = (long)n * T;
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AttnF32Param
             a = quad_sum(a) * p.scale;
             b = quad_sum(b);
             const int kj = k0 + j;
-            const bool ok = kj >= start && kj < T && (!p.causal || kj <= qi) && qi < T && lse != -INFINITY;
+            const bool ok = kj >= start && kj < KT && (!p.causal || kj <= qi) && qi < T && lse != -INFINITY;
             const float pj = ok ? expf(a - lse) : 0.f;
             const float ds = pj * (b - delta) * p.scale;
 #pragma unroll
@@ -196,13 +198,14 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AttnF32Para
     const int group = p.H / p.Hkv;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
+    const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
     const int kj = kb * ROWS + (threadIdx.x >> 2);
     const int part = threadIdx.x & 3;
     const long seq0 = (long)n * T;
     float k[DPL], v[DPL], dk[DPL], dv[DPL];
 #pragma unroll
     for (int d = 0; d < DPL; ++d) { k[d] = 0.f; v[d] = 0.f; dk[d] = 0.f; dv[d] = 0.f; }
-    const bool key_ok = kj < T && kj >= start;
+    const bool key_ok = kj < KT && kj >= start;
     if (kj < T) {
         const float* kr = p.K + (seq0 + kj) * p.ldk + hk * HD + part * DPL;
         const float* vr = p.V + (seq0 + kj) * p.ldv + hk * HD + part * DPL;
@@ -262,14 +265,14 @@ int check_f32(const char* who, int N, int T, int H, int Hkv, int hd) {
 }  // namespace
 
 extern "C" int aa_attn_fwd_f32(const void* Q, const void* K, const void* V, void* O, float* lse, const int* start,
-                               long ldq, long ldk, long ldv, long ldo, int N, int T, int H, int Hkv, int hd,
+                               const int* kv_len, long ldq, long ldk, long ldv, long ldo, int N, int T, int H, int Hkv, int hd,
                                int causal, float scale, void* stream) {
     int rc = check_f32("aa_attn_fwd_f32", N, T, H, Hkv, hd);
     if (rc) return rc;
     AA_REQUIRE((ldq | ldk | ldv | ldo) % 4 == 0, "aa_attn_fwd_f32: leading dims must be multiples of 4");
     if (N == 0) return AA_OK;
     AttnF32Params p{};
-    p.Q = (const float*)Q; p.K = (const float*)K; p.V = (const float*)V; p.O = (float*)O; p.lse = lse; p.start = start;
+    p.Q = (const float*)Q; p.K = (const float*)K; p.V = (const float*)V; p.O = (float*)O; p.lse = lse; p.start = start; p.kvlen = kv_len;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal;
     p.scale = scale;
     const dim3 grid(aa_cdiv(T, ROWS) * H * N);
@@ -281,7 +284,7 @@ extern "C" int aa_attn_fwd_f32(const void* Q, const void* K, const void* V, void
 
 extern "C" int aa_attn_bwd_f32(const void* Q, const void* K, const void* V, const void* O, const void* dO,
                                const float* lse, float* delta, void* dQ, void* dK, void* dV, const int* start,
-                               long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv,
+                               const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv,
                                int N, int T, int H, int Hkv, int hd, int causal, float scale, void* stream) {
     int rc = check_f32("aa_attn_bwd_f32", N, T, H, Hkv, hd);
     if (rc) return rc;
@@ -289,7 +292,7 @@ extern "C" int aa_attn_bwd_f32(const void* Q, const void* K, const void* V, cons
     if (N == 0) return AA_OK;
     AttnF32Params p{};
     p.Q = (const float*)Q; p.K = (const float*)K; p.V = (const float*)V; p.O = (float*)O; p.dO = (const float*)dO;
-    p.dQ = (float*)dQ; p.dK = (float*)dK; p.dV = (float*)dV; p.lse = const_cast<float*>(lse); p.delta = delta; p.start = start;
+    p.dQ = (float*)dQ; p.dK = (float*)dK; p.dV = (float*)dV; p.lse = const_cast<float*>(lse); p.delta = delta; p.start = start; p.kvlen = kv_len;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
     hipStream_t st = (hipStream_t)stream;

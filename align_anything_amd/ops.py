@@ -313,19 +313,19 @@ def f32_to_bf16(x, out=None):
 
 
 # ------------------------------------------------------------------ attention
-def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None):
+def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None, kv_len=None):
     """q/k/v: 2-D views [N*T, >=H*hd] (column slices of the fused qkv buffer are fine)."""
     out = torch.empty((N * T, H * hd), dtype=q.dtype, device=q.device) if out is None else out
     lse = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
-    call('aa_attn_fwd' + _sfx(q, 'attn_fwd'), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(start),
+    call('aa_attn_fwd' + _sfx(q, 'attn_fwd'), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(start), _p(kv_len),
          q.stride(0), k.stride(0), v.stride(0), out.stride(0), N, T, H, Hkv, hd, int(causal), float(scale), stream())
     return out, lse
 
 
-def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start=None):
+def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start=None, kv_len=None):
     delta = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
     call('aa_attn_bwd' + _sfx(q, 'attn_bwd'), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
-         delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(start), q.stride(0), k.stride(0),
+         delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(start), _p(kv_len), q.stride(0), k.stride(0),
          v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), N, T, H, Hkv, hd,
          int(causal), float(scale), stream())
     return dq, dk, dv

@@ -162,12 +162,13 @@ int aa_clip_embed(const void* patch, const void* cls, const void* pos, void* out
                   int h, void* stream);
 int aa_f32_to_bf16(const float* in, void* out, long n, void* stream);
 /* torch SDPA in hf:models/llama/modeling_llama.py:243-281 / clip :289 / opt attention.
- * start[n] = first valid key of left-padded sequence n (or NULL). lse f32[N,H,T]. */
-int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, const int* start,
+ * start[n] = first valid key of left-padded sequence n (or NULL); kv_len[n] = number of valid keys of a right-padded
+ * sequence (keys >= kv_len[n] masked; NULL = T).  lse f32[N,H,T]. */
+int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, const int* start, const int* kv_len,
                 long ldq, long ldk, long ldv, long ldo, int N, int T, int H, int Hkv, int hd, int causal,
                 float scale, void* stream);
 int aa_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
-                const float* lse, float* delta, void* dQ, void* dK, void* dV, const int* start, long ldq,
+                const float* lse, float* delta, void* dQ, void* dK, void* dV, const int* start, const int* kv_len, long ldq,
                 long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, int N, int T,
                 int H, int Hkv, int hd, int causal, float scale, void* stream);
 

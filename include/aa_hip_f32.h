@@ -69,12 +69,12 @@ int aa_patch_im2col_f32(const void* pixels, int pix_dtype, void* out, int n_img,
 int aa_clip_embed_f32(const void* patch, const void* cls, const void* pos, void* out, int n_img, int G2, int h,
                       void* stream);
 /* fp32 twin of aa_attn_fwd */
-int aa_attn_fwd_f32(const void* Q, const void* K, const void* V, void* O, float* lse, const int* start, long ldq,
+int aa_attn_fwd_f32(const void* Q, const void* K, const void* V, void* O, float* lse, const int* start, const int* kv_len, long ldq,
                     long ldk, long ldv, long ldo, int N, int T, int H, int Hkv, int hd, int causal, float scale,
                     void* stream);
 /* fp32 twin of aa_attn_bwd */
 int aa_attn_bwd_f32(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
-                    float* delta, void* dQ, void* dK, void* dV, const int* start, long ldq, long ldk, long ldv,
+                    float* delta, void* dQ, void* dK, void* dV, const int* start, const int* kv_len, long ldq, long ldk, long ldv,
                     long ldo, long lddo, long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
                     int causal, float scale, void* stream);
 

@@ -274,3 +274,40 @@ def test_opt125m_64_step_loss_curve_vs_reference():
     assert np.abs(got[:, keys.index('train/reward_margin')] - gold[:, keys.index('train/reward_margin')]).max() < 2e-2
     assert np.array_equal(got[:, keys.index('train/reward_accuracy')], gold[:, keys.index('train/reward_accuracy')])
     assert np.allclose(got[:, keys.index('train/lr')], gold[:, keys.index('train/lr')], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', [(3, 150, 4, 4, 64, [150, 97, 1]), (2, 64, 2, 2, 128, [33, 64]), (1, 200, 2, 1, 64, [130])])
+def test_attention_right_padding_kv_len(case, dtype):
+    """Encoder attention over right-padded sequences (Whisper / Qwen2-Audio tower): keys >= kv_len[n] are masked
+    (hf:models/qwen2_audio/modeling_qwen2_audio.py:686-712); forward and backward, both element types."""
+    from align_anything_amd import ops
+    N, T, H, Hkv, hd, lens = case
+    dt = torch.float32 if dtype == 'fp32' else torch.bfloat16
+    scale = hd ** -0.5
+    qkv = rnd(N * T, (H + 2 * Hkv) * hd, seed=21).to(dt)
+    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:(H + Hkv) * hd], qkv[:, (H + Hkv) * hd:]
+    do = rnd(N * T, H * hd, seed=22).to(dt)
+    kvl = torch.tensor(lens, dtype=torch.int32, device=dev())
+    idx = torch.arange(T, device=dev())
+    valid = (idx[None, :] < kvl[:, None].long())                                    # [N, T]
+    qf = q.double().view(N, T, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    kf = k.double().view(N, T, Hkv, hd).transpose(1, 2).detach().requires_grad_(True)
+    vf = v.double().view(N, T, Hkv, hd).transpose(1, 2).detach().requires_grad_(True)
+    s = (qf @ kf.repeat_interleave(H // Hkv, 1).transpose(-1, -2)) * scale
+    p = torch.softmax(s.masked_fill(~valid[:, None, None, :], float('-inf')), -1)
+    o_ref = p @ vf.repeat_interleave(H // Hkv, 1)
+    dof = do.double().view(N, T, H, hd).transpose(1, 2) * valid[:, None, :, None]   # no loss gradient reaches pad frames
+    (o_ref * dof).sum().backward()
+    back = lambda t, h: t.transpose(1, 2).reshape(N * T, h * hd)
+    o, lse = ops.attn_fwd(q, k, v, N, T, H, Hkv, hd, False, scale, kv_len=kvl)
+    dqkv = torch.zeros_like(qkv)
+    dq, dk, dv = dqkv[:, :H * hd], dqkv[:, H * hd:(H + Hkv) * hd], dqkv[:, (H + Hkv) * hd:]
+    do_m = (do * valid.reshape(-1, 1).to(dt)).contiguous()
+    ops.attn_bwd(q, k, v, o, do_m, lse, dq, dk, dv, N, T, H, Hkv, hd, False, scale, kv_len=kvl)
+    vm = valid.reshape(-1, 1)
+    tol = 1e-5 if dtype == 'fp32' else 3e-2
+    assert rel_err(o.double() * vm, back(o_ref.detach(), H) * vm) < tol
+    assert rel_err(dq.double() * vm, back(qf.grad, H) * vm) < 3 * tol
+    assert rel_err(dk.double(), back(kf.grad, Hkv)) < 3 * tol and rel_err(dv.double(), back(vf.grad, Hkv)) < 3 * tol
+    assert float((dk.float() * (~vm)).abs().max()) == 0.0 and float((dv.float() * (~vm)).abs().max()) == 0.0   # masked keys get no gradient
