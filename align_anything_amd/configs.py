@@ -47,6 +47,15 @@ def qwen2vl_cfg(text, vision, image_token_id, mrope_section, pad_token_id=None):
     return {'kind': 'qwen2vl', 'text': text, 'vision': vision, 'image_token_id': image_token_id, 'pad_token_id': pad_token_id}
 
 
+def qwen2audio_tower_cfg(d_model, num_layers, num_heads, ffn_dim, num_mel_bins=128, max_source_positions=1500):
+    return {'kind': 'qwen2audio_tower', 'd_model': d_model, 'num_layers': num_layers, 'num_heads': num_heads, 'ffn_dim': ffn_dim,
+            'num_mel_bins': num_mel_bins, 'max_source_positions': max_source_positions}
+
+
+def qwen2audio_cfg(text, audio, audio_token_id, pad_token_id=None):
+    return {'kind': 'qwen2audio', 'text': text, 'audio': audio, 'audio_token_id': audio_token_id, 'pad_token_id': pad_token_id}
+
+
 def opt_cfg(hidden_size, ffn_dim, num_layers, num_heads, vocab_size, max_position_embeddings=2048):
     return {'kind': 'opt', 'hidden_size': hidden_size, 'ffn_dim': ffn_dim, 'num_layers': num_layers,
             'num_heads': num_heads, 'vocab_size': vocab_size,
@@ -112,7 +121,17 @@ def from_hf_config(c) -> dict:
         vision = qwen2vl_vision_cfg(v.embed_dim, v.depth, v.num_heads, v.mlp_ratio, v.hidden_size, v.patch_size,
                                     v.temporal_patch_size, v.spatial_merge_size, v.in_channels)
         return qwen2vl_cfg(text, vision, c.image_token_id, rp['mrope_section'], getattr(c, 'pad_token_id', None))
+    if mt == 'qwen2_audio':   # align_anything/models/qwen2_audio.py -> hf Qwen2AudioForConditionalGeneration
+        t, a = c.text_config, c.audio_config
+        rp = getattr(t, 'rope_parameters', None) or {}
+        theta = rp.get('rope_theta', getattr(t, 'rope_theta', 10000.0))
+        text = llama_cfg(t.hidden_size, t.intermediate_size, t.num_hidden_layers, t.num_attention_heads, t.num_key_value_heads,
+                         t.vocab_size, t.rms_norm_eps, theta, getattr(t, 'head_dim', None), t.max_position_embeddings,
+                         attention_bias=True)
+        audio = qwen2audio_tower_cfg(a.d_model, a.encoder_layers, a.encoder_attention_heads, a.encoder_ffn_dim, a.num_mel_bins,
+                                     a.max_source_positions)
+        return qwen2audio_cfg(text, audio, c.audio_token_id, getattr(c, 'pad_token_id', None))
     if mt == 'opt':
         return opt_cfg(c.hidden_size, c.ffn_dim, c.num_hidden_layers, c.num_attention_heads, c.vocab_size,
                        c.max_position_embeddings)
-    raise ValueError(f'model_type {mt!r} has no native MI355X implementation (llava, llama, qwen2, qwen2_vl, opt are built)')
+    raise ValueError(f'model_type {mt!r} has no native MI355X implementation (llava, llama, qwen2, qwen2_vl, qwen2_audio, opt are built)')

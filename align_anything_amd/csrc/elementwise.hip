@@ -893,6 +893,112 @@ extern "C" int AA_FN(aa_clip_embed)(const void* patch, const void* cls, const vo
     return AA_OK;
 }
 
+// ================================================================== Conv1d (k = 3) as im2col + GEMM, AvgPool1d(2)
+// hf:models/qwen2_audio/modeling_qwen2_audio.py:315-316, 372-373 (Whisper front-end): conv1 = Conv1d(mel, d, 3, padding 1),
+// conv2 = Conv1d(d, d, 3, stride 2, padding 1).  col[(b, t), ci * 3 + k] = x[b, ci, t * stride + k - 1] (0 outside), so
+// the HF weight [co, ci, 3] is used as stored ([co, ci * 3 + k]).  x element (b, ci, tin) lives at b*sb + ci*sc + tin*st:
+// channels-first input_features (sb = C*Tin, sc = Tin, st = 1) or token-major activations (sb = Tin*C, sc = 1, st = C).
+template <typename TIN>
+__global__ __launch_bounds__(256) void conv1d_im2col_kernel(const TIN* __restrict__ x, long sb, long sc, long st,
+                                                            elem_t* __restrict__ col, int B, int C, int Tin, int Tout,
+                                                            int stride) {
+    const long total = (long)B * Tout * C * 3;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % 3);
+        const int ci = (int)((idx / 3) % C);
+        const long row = idx / (3L * C);
+        const int t = (int)(row % Tout);
+        const long b = row / Tout;
+        const int tin = t * stride + k - 1;
+        float v = 0.f;
+        if (tin >= 0 && tin < Tin) {
+            const TIN r = x[b * sb + ci * sc + (long)tin * st];
+            if constexpr (sizeof(TIN) == 2) v = bf2f(r); else v = r;
+        }
+        col[idx] = f2e(v);
+    }
+}
+extern "C" int AA_FN(aa_conv1d_im2col)(const void* x, int x_dtype, long sb, long sc, long st, void* col, int B, int C,
+                                       int Tin, int Tout, int stride, void* stream) {
+    AA_REQUIRE(B >= 0 && C > 0 && Tin > 0 && Tout > 0 && stride > 0 && (Tin + 2 - 3) / stride + 1 == Tout,
+               "aa_conv1d_im2col: Tin=%d stride=%d does not give Tout=%d (k=3, padding=1)", Tin, stride, Tout);
+    if (B == 0) return AA_OK;
+    const long total = (long)B * Tout * C * 3;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (x_dtype == 0)
+        hipLaunchKernelGGL(conv1d_im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, sb, sc, st,
+                           (elem_t*)col, B, C, Tin, Tout, stride);
+    else
+        hipLaunchKernelGGL(conv1d_im2col_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, sb, sc, st,
+                           (elem_t*)col, B, C, Tin, Tout, stride);
+    AA_CHECK_LAUNCH("aa_conv1d_im2col");
+    return AA_OK;
+}
+// backward to a token-major input: dx[(b, tin), ci] = sum_k dcol[(b, t), ci * 3 + k] over t * stride + k - 1 == tin
+__global__ __launch_bounds__(256) void conv1d_col2im_kernel(const elem_t* __restrict__ dcol, elem_t* __restrict__ dx, int B,
+                                                            int C, int Tin, int Tout, int stride) {
+    const long total = (long)B * Tin * C;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ci = (int)(idx % C);
+        const long r = idx / C;
+        const int tin = (int)(r % Tin);
+        const long b = r / Tin;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int num = tin + 1 - k;
+            if (num >= 0 && num % stride == 0) {
+                const int t = num / stride;
+                if (t < Tout) acc += e2f(dcol[((b * Tout + t) * C + ci) * 3 + k]);
+            }
+        }
+        dx[idx] = f2e(acc);
+    }
+}
+extern "C" int AA_FN(aa_conv1d_col2im)(const void* dcol, void* dx, int B, int C, int Tin, int Tout, int stride, void* stream) {
+    AA_REQUIRE(B >= 0 && C > 0 && Tin > 0 && Tout > 0 && stride > 0, "aa_conv1d_col2im: bad shape");
+    if (B == 0) return AA_OK;
+    const long total = (long)B * Tin * C;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(conv1d_col2im_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const elem_t*)dcol, (elem_t*)dx, B, C,
+                       Tin, Tout, stride);
+    AA_CHECK_LAUNCH("aa_conv1d_col2im");
+    return AA_OK;
+}
+// nn.AvgPool1d(2, stride 2) over time of token-major rows (T even): out[j] = (x[2j] + x[2j+1]) / 2 ; backward dx[2j] = dx[2j+1] = dy[j] / 2
+__global__ __launch_bounds__(256) void avgpool2_kernel(const elem_t* __restrict__ x, elem_t* __restrict__ y, long rows_out, int C,
+                                                       int backward) {
+    const int nv = C >> 3;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < rows_out * nv; idx += (long)gridDim.x * 256) {
+        const long r = idx / nv;
+        const int v = (int)(idx % nv);
+        if (!backward) {
+            ev8 a = *reinterpret_cast<const ev8*>(x + (2 * r) * C + v * 8);
+            ev8 b = *reinterpret_cast<const ev8*>(x + (2 * r + 1) * C + v * 8);
+            ev8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2e(0.5f * (e2f(a[j]) + e2f(b[j])));
+            *reinterpret_cast<ev8*>(y + r * C + v * 8) = o;
+        } else {      // x = dy [rows_out, C], y = dx [2 * rows_out, C]
+            ev8 a = *reinterpret_cast<const ev8*>(x + r * C + v * 8);
+            ev8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2e(0.5f * e2f(a[j]));
+            *reinterpret_cast<ev8*>(y + (2 * r) * C + v * 8) = o;
+            *reinterpret_cast<ev8*>(y + (2 * r + 1) * C + v * 8) = o;
+        }
+    }
+}
+extern "C" int AA_FN(aa_avgpool2)(const void* x, void* y, long rows_out, int C, int backward, void* stream) {
+    AA_REQUIRE(rows_out >= 0 && C > 0 && (C & 7) == 0, "aa_avgpool2: C=%d must be a multiple of 8", C);
+    if (rows_out == 0) return AA_OK;
+    const long total = rows_out * (C >> 3);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, (elem_t*)y, rows_out, C, backward);
+    AA_CHECK_LAUNCH("aa_avgpool2");
+    return AA_OK;
+}
+
 // ================================================================== score head  (Linear(h -> 1, bias=False))
 // align_anything/models/opt.py:59-60 / models/llava.py:60: scores = score_head(last_hidden_state).float()
 // out[r] = float(bf16(sum_c x[r,c] * w[c]))   (the bf16 Linear output, upcast)

@@ -299,6 +299,32 @@ def patch_im2col(pixels, patch, Kp, dtype=bf16):
     return out
 
 
+def conv1d_im2col(x, B, C, Tin, stride, channels_first, dtype):
+    """Conv1d(k=3, padding=1) patches: x = [B, C, Tin] features (channels_first) or token-major [B*Tin, C] -> [B*Tout, 3C]."""
+    Tout = (Tin + 2 - 3) // stride + 1
+    col = torch.empty((B * Tout, 3 * C), dtype=dtype, device=x.device)
+    sb, sc, st_ = (C * Tin, Tin, 1) if channels_first else (Tin * C, 1, C)
+    if x.dtype not in (bf16, f32) or not x.is_contiguous():
+        raise RuntimeError(f'conv1d_im2col: contiguous bf16 / fp32 input expected, got {x.dtype}')
+    call('aa_conv1d_im2col' + _sfx(col, 'conv1d_im2col'), x.data_ptr(), 0 if x.dtype == bf16 else 1, sb, sc, st_, col.data_ptr(), B, C, Tin,
+         Tout, int(stride), stream())
+    return col, Tout
+
+
+def conv1d_col2im(dcol, B, C, Tin, Tout, stride):
+    dx = torch.empty((B * Tin, C), dtype=dcol.dtype, device=dcol.device)
+    call('aa_conv1d_col2im' + _sfx(dcol, 'conv1d_col2im'), dcol.data_ptr(), dx.data_ptr(), B, C, Tin, Tout, int(stride), stream())
+    return dx
+
+
+def avgpool2(x, backward=False):
+    rows, C = x.shape
+    rows_out = rows if backward else rows // 2
+    y = torch.empty((2 * rows if backward else rows_out, C), dtype=x.dtype, device=x.device)
+    call('aa_avgpool2' + _sfx(x, 'avgpool2'), x.data_ptr(), y.data_ptr(), rows_out, C, int(backward), stream())
+    return y
+
+
 def clip_embed(patch_emb, cls, pos, n_img, G2):
     h = patch_emb.shape[1]
     out = torch.empty((n_img * (G2 + 1), h), dtype=patch_emb.dtype, device=patch_emb.device)

@@ -155,6 +155,13 @@ int aa_colsum_bf16(const void* in, long ld, long R, int C, float* out, void* str
 int aa_rowdot_fwd(const void* x, const void* w, float* out, long rows, int h, void* stream);
 int aa_rowdot_bwd(const float* dy, const void* x, const void* w, void* dx, float* dw, float* ws, int ws_rows,
                   long rows, int h, void* stream);
+/* Whisper / Qwen2-Audio front-end (hf:models/qwen2_audio/modeling_qwen2_audio.py:315-316, 372-393): Conv1d(k = 3, padding 1,
+ * stride 1 | 2) as im2col + GEMM on the HF weight as stored, its input gradient (col2im), and AvgPool1d(2) forward / backward.
+ * x element (b, ci, tin) at b*sb + ci*sc + tin*st (channels-first features or token-major activations); x_dtype 0 bf16, 1 f32 */
+int aa_conv1d_im2col(const void* x, int x_dtype, long sb, long sc, long st, void* col, int B, int C, int Tin, int Tout,
+                     int stride, void* stream);
+int aa_conv1d_col2im(const void* dcol, void* dx, int B, int C, int Tin, int Tout, int stride, void* stream);
+int aa_avgpool2(const void* x, void* y, long rows_out, int C, int backward, void* stream);
 /* hf:models/clip/modeling_clip.py:138-218 CLIPVisionEmbeddings (patch conv as im2col + GEMM) */
 int aa_patch_im2col(const void* pixels, int pix_dtype, void* out, int n_img, int channels,
                     int image_size, int patch, int Kp, void* stream);

@@ -78,6 +78,14 @@ int aa_attn_bwd_f32(const void* Q, const void* K, const void* V, const void* O, 
                     long ldo, long lddo, long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
                     int causal, float scale, void* stream);
 
+/* fp32 twins: Whisper / Qwen2-Audio front-end (hf:models/qwen2_audio/modeling_qwen2_audio.py:315-316, 372-393): Conv1d(k = 3, padding 1,
+ * stride 1 | 2) as im2col + GEMM on the HF weight as stored, its input gradient (col2im), and AvgPool1d(2) forward / backward.
+ * x element (b, ci, tin) at b*sb + ci*sc + tin*st (channels-first features or token-major activations); x_dtype 0 bf16, 1 f32 */
+int aa_conv1d_im2col_f32(const void* x, int x_dtype, long sb, long sc, long st, void* col, int B, int C, int Tin, int Tout,
+                     int stride, void* stream);
+int aa_conv1d_col2im_f32(const void* dcol, void* dx, int B, int C, int Tin, int Tout, int stride, void* stream);
+int aa_avgpool2_f32(const void* x, void* y, long rows_out, int C, int backward, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

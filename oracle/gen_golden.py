@@ -397,6 +397,86 @@ def gen_qwen2vl_ppo():
     print('qwen2vl_tiny_ppo.npz', {k: v for k, v in info.items() if 'loss' in k or 'length' in k}, 'response_lens', trn['response_lens'])
 
 
+def tiny_qwen2audio():
+    from transformers import Qwen2AudioConfig, Qwen2AudioForConditionalGeneration
+    cfg = Qwen2AudioConfig(
+        audio_config=dict(num_mel_bins=64, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, d_model=128, max_source_positions=32),
+        text_config=dict(model_type='qwen2', hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                         num_key_value_heads=1, vocab_size=320, max_position_embeddings=256, rms_norm_eps=1e-6),
+        audio_token_id=300)
+    torch.manual_seed(19)
+    m = Qwen2AudioForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2 and 'embed_positions' not in n:
+                p.mul_(3.0)
+            p.copy_(p.to(torch.bfloat16).to(torch.float32))
+    return cfg, m.eval()
+
+
+def gen_qwen2audio_dpo():
+    """BASELINE configs[3] backbone: the reference's unmodified text_audio_to_text DPOTrainer.{compute_log_probs, loss}
+    (trainers/text_audio_to_text/dpo.py:86-166) on a tiny random HF Qwen2AudioForConditionalGeneration (align_anything/models/
+    qwen2_audio.py), fp32, CPU, audio tower trainable (configs/train/text_audio_to_text/dpo.yaml:63).  Batch = processor
+    output: mel features padded to 2 * max_source_positions with feature_attention_mask, expanded audio tokens, left padding,
+    the pair's audio repeated for chosen and rejected."""
+    from align_anything.trainers.text_audio_to_text.dpo import DPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+
+    cfg, policy = tiny_qwen2audio()
+    _, refm = tiny_qwen2audio()
+    g = torch.Generator().manual_seed(37)
+    with torch.no_grad():
+        for n, p in refm.named_parameters():
+            if 'embed_positions' in n:
+                continue
+            p.add_(0.02 * torch.randn(p.shape, generator=g)); p.copy_(p.to(torch.bfloat16).to(torch.float32))
+    B, T, PAD, AUD = 2, 48, 304, 300
+    flen1 = [64, 37]                                     # mel frames of the two audios (second one is padded)
+    feats1 = torch.randn(B, 64, 64, generator=g)
+    fmask1 = torch.zeros(B, 64, dtype=torch.long)
+    for b, n in enumerate(flen1):
+        fmask1[b, :n] = 1
+        feats1[b, :, n:] = 0.0
+    feats, fmask = torch.cat([feats1, feats1], 0), torch.cat([fmask1, fmask1], 0)
+    olen = [((n - 1) // 2 + 1 - 2) // 2 + 1 for n in flen1] * 2
+    ids = torch.full((2 * B, T), PAD, dtype=torch.long)
+    mask = torch.zeros((2 * B, T), dtype=torch.long)
+    for r, lp in enumerate((0, 6, 2, 0)):
+        n_txt = T - lp - 2 - olen[r]
+        row = torch.cat([torch.tensor([1]), torch.full((olen[r],), AUD), torch.tensor([2]), torch.randint(3, 299, (n_txt,), generator=g)])
+        ids[r, lp:] = row
+        mask[r, lp:] = 1
+    resp = [12, 9, 7, 13]
+    batch = {'input_ids': ids, 'attention_mask': mask, 'input_features': feats, 'feature_attention_mask': fmask, 'meta_info': {'response_lens': resp}}
+    tr = DPOTrainer.__new__(DPOTrainer)
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+    tr.tokenizer = SimpleNamespace(pad_token_id=PAD)
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    tr.model, tr.reference_model = SimpleNamespace(module=policy), SimpleNamespace(module=refm)
+    policy.zero_grad()
+    seq_lp = tr.compute_log_probs(policy, batch)
+    ld = tr.loss(batch)
+    ld['loss'].backward()
+    with torch.no_grad():
+        logits = policy(**tr.infer_batch(batch)).logits
+    out = {'input_ids': ids.numpy(), 'attention_mask': mask.numpy(), 'input_features': feats.numpy(), 'feature_attention_mask': fmask.numpy(),
+           'response_lens': np.array(resp), 'pad_token_id': np.array(PAD), 'scale_coeff': np.array(0.1), 'policy_logits': logits.numpy(),
+           'seq_log_probs': seq_lp.detach().numpy()}
+    for k, v in ld.items():
+        out['loss_' + k] = v.detach().numpy()
+    for n, p in policy.state_dict().items():
+        out['w.' + n] = bf16_bits(p) if 'embed_positions' not in n else p.numpy()
+    for n, p in refm.state_dict().items():
+        if 'embed_positions' not in n:
+            out['r.' + n] = bf16_bits(p)
+    for n, p in policy.named_parameters():
+        if p.grad is not None:
+            out['g.' + n] = p.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'qwen2audio_tiny_dpo.npz'), **out)
+    print('qwen2audio_tiny_dpo.npz loss', float(ld['loss']), 'acc', float(ld['reward_accuracy']), 'n arrays', len(out))
+
+
 def gen_pref():
     """SimPO / ORPO / KTO: the reference's unmodified `loss` overrides (trainers/text_to_text/simpo.py:41-108,
     orpo.py:41-112, kto.py:83-160) on the tiny OPT of opt_tiny_dpo.npz (weights are read back from that fixture, so
@@ -604,6 +684,7 @@ if __name__ == '__main__':
     gen_opt_dpo()
     gen_qwen2vl_dpo()
     gen_qwen2vl_ppo()
+    gen_qwen2audio_dpo()
     gen_pref()
     gen_collator()
     gen_grpo()

@@ -271,6 +271,57 @@ def qwen2vl_logits(sd, cfg, input_ids, attention_mask, pixel_values, grid_thw):
     return F.linear(qwen2vl_hidden(sd, cfg, input_ids, attention_mask, pixel_values, grid_thw), sd['lm_head.weight'])
 
 
+# ------------------------------------------------------------------ Qwen2-Audio
+def qwen2audio_lengths(feature_lengths):
+    """hf:models/qwen2_audio/modeling_qwen2_audio.py:400-406: frames after conv2 (stride 2) and after AvgPool1d(2)."""
+    a = (feature_lengths - 1) // 2 + 1
+    return a, (a - 2) // 2 + 1
+
+
+def qwen2audio_tower(sd, acfg, input_features, feature_lengths, prefix='model.audio_tower.'):
+    """hf:models/qwen2_audio/modeling_qwen2_audio.py:343-395 Qwen2AudioEncoder: conv1 + GELU, conv2 (stride 2) + GELU, + sinusoidal
+    positions, pre-LN layers (q scaled by head_dim**-0.5, k_proj without bias, keys beyond the audio's length masked), AvgPool1d(2),
+    LayerNorm.  input_features [B, mel, 2 * max_source_positions]; returns [B, max_source_positions / 2, d_model]."""
+    d, H = acfg['d_model'], acfg['num_heads']
+    hd = d // H
+    x = F.gelu(F.conv1d(input_features.to(sd[prefix + 'conv1.weight'].dtype), sd[prefix + 'conv1.weight'], sd[prefix + 'conv1.bias'], padding=1))
+    x = F.gelu(F.conv1d(x, sd[prefix + 'conv2.weight'], sd[prefix + 'conv2.bias'], stride=2, padding=1))
+    x = x.permute(0, 2, 1) + sd[prefix + 'embed_positions.weight']
+    B, T, _ = x.shape
+    alen, _ = qwen2audio_lengths(feature_lengths)
+    key_valid = torch.arange(T)[None, :] < alen[:, None]
+    for i in range(acfg['num_layers']):
+        p = f'{prefix}layers.{i}.'
+        y = F.layer_norm(x, (d,), sd[p + 'self_attn_layer_norm.weight'], sd[p + 'self_attn_layer_norm.bias'], 1e-5)
+        q = (linear(y, sd, p + 'self_attn.q_proj') * hd ** -0.5).view(B, T, H, hd).transpose(1, 2)
+        k = linear(y, sd, p + 'self_attn.k_proj').view(B, T, H, hd).transpose(1, 2)
+        v = linear(y, sd, p + 'self_attn.v_proj').view(B, T, H, hd).transpose(1, 2)
+        a = attention(q, k, v, 1.0, False, key_valid).transpose(1, 2).reshape(B, T, d)
+        x = x + linear(a, sd, p + 'self_attn.out_proj')
+        y = F.layer_norm(x, (d,), sd[p + 'final_layer_norm.weight'], sd[p + 'final_layer_norm.bias'], 1e-5)
+        x = x + linear(F.gelu(linear(y, sd, p + 'fc1')), sd, p + 'fc2')
+    x = F.avg_pool1d(x.permute(0, 2, 1), 2, stride=2).permute(0, 2, 1)
+    return F.layer_norm(x, (d,), sd[prefix + 'layer_norm.weight'], sd[prefix + 'layer_norm.bias'], 1e-5)
+
+
+def qwen2audio_logits(sd, cfg, input_ids, attention_mask, input_features, feature_attention_mask):
+    """hf:models/qwen2_audio/modeling_qwen2_audio.py:674-745 (processor-expanded audio tokens: tower -> Linear projector -> the
+    first `output_length` frames of every audio are masked_scatter'ed over the audio-token positions), then the Qwen2
+    decoder with 1-D RoPE positions arange(T)."""
+    x = F.embedding(input_ids, sd['model.language_model.embed_tokens.weight'])
+    if input_features is not None:
+        flen = feature_attention_mask.sum(-1)
+        feat = linear(qwen2audio_tower(sd, cfg['audio'], input_features, flen), sd, 'model.multi_modal_projector.linear')
+        _, olen = qwen2audio_lengths(flen)
+        keep = torch.arange(feat.shape[1])[None, :] < olen[:, None]
+        feat = feat[keep]
+        mask = input_ids == cfg['audio_token_id']
+        assert int(mask.sum()) == feat.shape[0], 'audio token / feature count mismatch'
+        x = x.masked_scatter(mask[..., None].expand_as(x), feat.to(x.dtype))
+    key_valid = attention_mask.bool() if attention_mask is not None else None
+    return F.linear(llama_decoder(sd, cfg['text'], x, key_valid), sd['lm_head.weight'])
+
+
 def llama_logits(sd, cfg, input_ids, attention_mask, prefix='model.'):
     x = F.embedding(input_ids, sd[prefix + 'embed_tokens.weight'])
     key_valid = attention_mask.bool() if attention_mask is not None else None

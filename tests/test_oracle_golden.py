@@ -205,3 +205,37 @@ def test_qwen2vl_oracle_matches_reference_dpo_fixture():
     for k in z.files:
         if k.startswith('g.') and k[2:] in sd:
             assert rel_err(sd[k[2:]].grad, T(z[k])) < 2e-3, k
+
+
+def test_qwen2audio_oracle_matches_reference_dpo_fixture():
+    """oracle/models.py::qwen2audio_* (Whisper-style tower: conv front-end, masked encoder attention, avg-pool; projector; audio-
+    token scatter; Qwen2 decoder) vs the fixture the reference's text_audio_to_text DPOTrainer produced on HF Qwen2Audio."""
+    from tests.util import tiny_qwen2audio_cfg
+    z = load_golden('qwen2audio_tiny_dpo.npz')
+    cfg = tiny_qwen2audio_cfg()
+    ids, mask = T(z['input_ids']), T(z['attention_mask'])
+    feats, fmask = T(z['input_features']), T(z['feature_attention_mask'])
+    load = lambda pre: {k[len(pre):]: (bits_to_bf16(z[k]).float() if z[k].dtype == np.uint16 else T(z[k])) for k in z.files if k.startswith(pre)}
+    sd = {k: (v.clone().requires_grad_(True) if 'embed_positions' not in k else v) for k, v in load('w.').items()}
+    rsd = load('r.')
+    rsd['model.audio_tower.embed_positions.weight'] = sd['model.audio_tower.embed_positions.weight']
+    logits = om.qwen2audio_logits(sd, cfg, ids, mask, feats, fmask)
+    valid = mask.bool()
+    assert rel_err(logits.detach()[valid], T(z['policy_logits'])[valid]) < 1e-5
+    resp = [int(r) for r in z['response_lens']]
+    lp = orl.compute_log_probs(logits, ids, resp, int(z['pad_token_id']))
+    np.testing.assert_allclose(lp.detach().numpy(), z['seq_log_probs'], rtol=2e-4, atol=2e-4)
+    with torch.no_grad():
+        rlp = orl.compute_log_probs(om.qwen2audio_logits(rsd, cfg, ids, mask, feats, fmask), ids, resp, int(z['pad_token_id']))
+    ld = orl.dpo_loss(lp, rlp, float(z['scale_coeff']))
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < 2e-5
+    ld['loss'].backward()
+    n = 0
+    for k in z.files:
+        if k.startswith('g.') and k[2:] in sd:
+            want = T(z[k])
+            if float(want.norm()) < 1e-7:
+                continue
+            assert rel_err(sd[k[2:]].grad, want) < 2e-3, k
+            n += 1
+    assert n > 50          # audio tower (conv, layers, layer_norm), projector and language model all receive gradients
