@@ -891,6 +891,225 @@ class NativeQwen2VL(NativeCausalLM):
             self.vision.backward_merger(dfeat)
 
 
+# ====================================================================== Qwen2-Audio
+class Qwen2AudioTower:
+    """hf:models/qwen2_audio/modeling_qwen2_audio.py:289-406 Qwen2AudioEncoder (the Whisper encoder + AvgPool1d(2)), forward AND
+    backward -- the reference trains it by default (configs/train/text_audio_to_text/dpo.yaml:63).  Conv1d front-end = im2col +
+    GEMM on the HF weights as stored; q/k/v fused (k_proj has no bias: its slice of the fused bias is held at zero); encoder
+    attention masks the keys beyond each audio's length (`kv_len`); every activation is token-major [rows64(B*T), d]."""
+
+    def __init__(self, acfg: dict, store: ParamStore, prefix: str, trainable: bool):
+        self.cfg, self.store, self.prefix, self.trainable = acfg, store, prefix, trainable
+        d, F, mel, S = acfg['d_model'], acfg['ffn_dim'], acfg['num_mel_bins'], acfg['max_source_positions']
+        self.hd = d // acfg['num_heads']
+        if self.hd not in (64, 128):
+            raise NotImplementedError(f'audio head_dim {self.hd}: attention kernels are built for 64 and 128')
+        if (3 * mel) % 64 or (3 * d) % 64:
+            raise NotImplementedError('conv front-end: 3 * num_mel_bins and 3 * d_model must be multiples of 64')
+        tr = trainable
+        self.conv1 = Linear(store, store.add(prefix + 'conv1.weight', (d, 3 * mel), tr), store.add(prefix + 'conv1.bias', (d,), tr))
+        self.conv2 = Linear(store, store.add(prefix + 'conv2.weight', (d, 3 * d), tr), store.add(prefix + 'conv2.bias', (d,), tr))
+        self.pos = store.add(prefix + 'embed_positions.weight', (S, d), False)
+        self.layers = []
+        for i in range(acfg['num_layers']):
+            p = f'{prefix}layers.{i}.'
+            L = {'ln1w': store.add(p + 'self_attn_layer_norm.weight', (d,), tr), 'ln1b': store.add(p + 'self_attn_layer_norm.bias', (d,), tr)}
+            blk = store.add_fused(p + 'self_attn.qkv_fused', [(p + 'self_attn.q_proj.weight', d, d), (p + 'self_attn.k_proj.weight', d, d),
+                                                              (p + 'self_attn.v_proj.weight', d, d)], tr)
+            bq = store.add(p + 'self_attn.qkv_fused.bias', (3 * d,), tr)
+            del store.alias[bq]
+            store.alias[p + 'self_attn.q_proj.bias'] = (bq, 0, (d,))
+            store.alias[p + 'self_attn.v_proj.bias'] = (bq, 2 * d, (d,))
+            L['qkv'], L['kbias'] = Linear(store, blk, bq), bq
+            L['out'] = Linear(store, store.add(p + 'self_attn.out_proj.weight', (d, d), tr), store.add(p + 'self_attn.out_proj.bias', (d,), tr))
+            L['ln2w'] = store.add(p + 'final_layer_norm.weight', (d,), tr)
+            L['ln2b'] = store.add(p + 'final_layer_norm.bias', (d,), tr)
+            L['fc1'] = Linear(store, store.add(p + 'fc1.weight', (F, d), tr), store.add(p + 'fc1.bias', (F,), tr))
+            L['fc2'] = Linear(store, store.add(p + 'fc2.weight', (d, F), tr), store.add(p + 'fc2.bias', (d,), tr))
+            self.layers.append(L)
+        self.lnp_w = store.add(prefix + 'layer_norm.weight', (d,), tr)
+        self.lnp_b = store.add(prefix + 'layer_norm.bias', (d,), tr)
+        self._ctx = None
+
+    def padcols(self):
+        return {self.prefix + 'conv1.weight': True, self.prefix + 'conv2.weight': True}
+
+    def unpad(self):
+        c = self.cfg
+        return {self.prefix + 'conv1.weight': (c['d_model'], c['num_mel_bins'], 3), self.prefix + 'conv2.weight': (c['d_model'], c['d_model'], 3)}
+
+    def forward(self, input_features, audio_lengths, save=False):
+        """input_features [B, mel, 2 * max_source_positions] (fp32 / bf16); audio_lengths int32 [B] (device) = frames after conv2 that
+        carry audio.  Returns [rows64(B * S / 2), d] (frame j of audio b at row b * S/2 + j)."""
+        c, P, dt = self.cfg, self.store.p, self.store.dtype
+        B, mel, Tin = input_features.shape
+        d, H, hd, S = c['d_model'], c['num_heads'], self.hd, c['max_source_positions']
+        if mel != c['num_mel_bins'] or Tin != 2 * S:
+            raise ValueError(f'Qwen2Audio expects mel features [B, {c["num_mel_bins"]}, {2 * S}], got {tuple(input_features.shape)}')
+        col1, _ = ops.conv1d_im2col(input_features.contiguous(), B, mel, Tin, 1, True, dt)
+        p1 = self.conv1.fwd(col1)
+        a1 = ops.act_fwd(p1, ops.ACT_GELU)
+        col2, _ = ops.conv1d_im2col(a1, B, d, Tin, 2, False, dt)
+        p2 = self.conv2.fwd(col2)
+        a2 = ops.act_fwd(p2, ops.ACT_GELU)
+        M = a2.shape[0]
+        dev = a2.device
+        rows = torch.arange(M, device=dev)
+        x = ops.embed_fwd(rows, a2, pos=(rows % S).to(torch.int32), P=P[self.pos])          # + embed_positions
+        saved = []
+        for L in self.layers:
+            y1, m1, r1 = ops.layernorm_fwd(x, P[L['ln1w']], P[L['ln1b']], 1e-5)
+            qkv = L['qkv'].fwd(y1)
+            attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, S, H, H, hd, False, hd ** -0.5, kv_len=audio_lengths,
+                                     out=torch.zeros_like(x) if M != B * S else None)
+            x_mid = L['out'].fwd(attn, residual=x)
+            y2, m2, r2 = ops.layernorm_fwd(x_mid, P[L['ln2w']], P[L['ln2b']], 1e-5)
+            f1 = L['fc1'].fwd(y2)
+            g1 = ops.act_fwd(f1, ops.ACT_GELU)
+            x_out = L['fc2'].fwd(g1, residual=x_mid)
+            if save:
+                saved.append((x, m1, r1, y1, qkv, attn, lse, x_mid, m2, r2, y2, f1, g1))
+            x = x_out
+        pooled = ops.avgpool2(x, B * S // 2)
+        out, mp, rp = ops.layernorm_fwd(pooled, P[self.lnp_w], P[self.lnp_b], 1e-5)
+        if save:
+            self._ctx = dict(col1=col1, p1=p1, col2=col2, p2=p2, saved=saved, pooled=pooled, mp=mp, rp=rp, B=B, Tin=Tin, M=M,
+                             lens=audio_lengths)
+        return out
+
+    def backward(self, dout):
+        """dout [rows64(B*S/2), d] with zero pad rows; accumulates every tower gradient into store.g."""
+        cx, c, P, G = self._ctx, self.cfg, self.store.p, self.store.g
+        B, Tin, M = cx['B'], cx['Tin'], cx['M']
+        d, H, hd, S = c['d_model'], c['num_heads'], self.hd, c['max_source_positions']
+        d_pooled = ops.layernorm_bwd(dout, cx['pooled'], P[self.lnp_w], cx['mp'], cx['rp'], G.get(self.lnp_w), G.get(self.lnp_b))
+        dres = ops.avgpool2(d_pooled, B * S // 2, backward=True)
+        if dres.shape[0] != M:
+            raise RuntimeError('Qwen2AudioTower.backward: row padding mismatch')
+        for L, sv in zip(reversed(self.layers), reversed(cx['saved'])):
+            x, m1, r1, y1, qkv, attn, lse, x_mid, m2, r2, y2, f1, g1 = sv
+            d_g1 = L['fc2'].dx(dres)
+            L['fc2'].dw(dres, g1)
+            d_f1 = ops.act_bwd(f1, d_g1, ops.ACT_GELU)
+            d_y2 = L['fc1'].dx(d_f1)
+            L['fc1'].dw(d_f1, y2)
+            ops.layernorm_bwd(d_y2, x_mid, P[L['ln2w']], m2, r2, G.get(L['ln2w']), G.get(L['ln2b']), dx=dres, add_to_dx=True)
+            d_attn = L['out'].dx(dres)
+            L['out'].dw(dres, attn)
+            d_qkv = torch.zeros_like(qkv) if M != B * S else torch.empty_like(qkv)
+            ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], attn, d_attn, lse, d_qkv[:, :d], d_qkv[:, d:2 * d], d_qkv[:, 2 * d:],
+                         B, S, H, H, hd, False, hd ** -0.5, kv_len=cx['lens'])
+            d_y1 = L['qkv'].dx(d_qkv)
+            L['qkv'].dw(d_qkv, y1)
+            if L['kbias'] in G:
+                G[L['kbias']][d:2 * d].zero_()            # k_proj has no bias in HF: its slot of the fused bias never moves
+            ops.layernorm_bwd(d_y1, x, P[L['ln1w']], m1, r1, G.get(L['ln1w']), G.get(L['ln1b']), dx=dres, add_to_dx=True)
+        d_p2 = ops.act_bwd(cx['p2'], dres, ops.ACT_GELU)             # embed_positions is frozen: d(a2) = d(x)
+        self.conv2.dw(d_p2, cx['col2'])
+        d_col2 = self.conv2.dx(d_p2)
+        d_a1 = ops.conv1d_col2im(d_col2, B, d, Tin, S, 2)
+        d_p1 = ops.act_bwd(cx['p1'], d_a1, ops.ACT_GELU)
+        self.conv1.dw(d_p1, cx['col1'])
+        self._ctx = None
+
+
+class NativeQwen2Audio(NativeCausalLM):
+    """hf:models/qwen2_audio/modeling_qwen2_audio.py:776+ Qwen2AudioForConditionalGeneration (align_anything/models/
+    qwen2_audio.py): audio tower -> Linear projector -> the first `output_length` frames of every audio scattered over the
+    (processor-expanded) audio-token positions -> Qwen2 decoder with 1-D RoPE.  Freeze flags follow the reference's
+    substrings: audio_tower / multi_modal_projector / language_model (models/pretrained_model.py:265-281)."""
+
+    kind = 'qwen2audio'
+
+    def __init__(self, cfg, device, trainable=True, freeze_mm_proj=False, freeze_language_model=False, freeze_audio_tower=False,
+                 freeze_vision_tower=True, freeze_audio_proj=False, head='lm', dtype=bf16):
+        super().__init__(cfg, device, trainable, dtype)
+        self.head_kind = head
+        t = cfg['text']
+        self.hidden_size = t['hidden_size']
+        self.train_lm = trainable and not freeze_language_model
+        self.train_proj = trainable and not freeze_mm_proj
+        self.train_tower = trainable and not freeze_audio_tower
+        st = self.store
+        self.tower = Qwen2AudioTower(cfg['audio'], st, 'model.audio_tower.', self.train_tower)
+        ad = cfg['audio']['d_model']
+        self.proj = Linear(st, st.add('model.multi_modal_projector.linear.weight', (t['hidden_size'], ad), self.train_proj),
+                           st.add('model.multi_modal_projector.linear.bias', (t['hidden_size'],), self.train_proj))
+        self.embed = st.add('model.language_model.embed_tokens.weight', (t['vocab_size'], t['hidden_size']), self.train_lm, f32_grad=True)
+        self.stack = LlamaStack(t, st, 'model.language_model.', self.train_lm)
+        if head == 'lm':
+            lm = st.add('lm_head.weight', (t['vocab_size'], t['hidden_size']), self.train_lm)
+            self.head = LMHead(st, 'rms', self.stack.norm, None, lm, t['rms_eps'], self.train_lm)
+        else:
+            sw = st.add('score_head.weight', (1, t['hidden_size']), trainable, f32_grad=True)
+            self.head = ScoreHead(st, 'rms', self.stack.norm, None, sw, t['rms_eps'], trainable)
+        self.finalize()
+
+    def _padcols(self):
+        return self.tower.padcols()
+
+    def _unpad(self):
+        return self.tower.unpad()
+
+    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
+                       position_ids=None, kv_sink=None, input_features=None, feature_attention_mask=None):
+        N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask, position_ids)
+        P = self.store.p
+        ids = input_ids.reshape(-1)
+        if Mp != N * T:
+            ids = torch.cat([ids, torch.zeros(Mp - N * T, dtype=ids.dtype, device=ids.device)])
+        slot = feat = None
+        actx = None
+        if input_features is not None:
+            B = input_features.shape[0]
+            flen = feature_attention_mask.sum(-1) if feature_attention_mask is not None else \
+                torch.full((B,), input_features.shape[-1], device=input_features.device)
+            alen = (flen - 1) // 2 + 1                                 # hf _get_feat_extract_output_lengths
+            olen = ((alen - 2) // 2 + 1).tolist()                     # host read: the gather plan has data-dependent size
+            S2 = self.cfg['audio']['max_source_positions'] // 2
+            tower_out = self.tower.forward(input_features, alen.to(device=self.device, dtype=torch.int32), save=save and self.train_tower)
+            proj_all = self.proj.fwd(tower_out)                        # [rows64(B*S/2), h]
+            idx = torch.cat([torch.arange(int(n)) + b * S2 for b, n in enumerate(olen)]).to(self.device)
+            n_feat = idx.numel()
+            if n_feat % 64:
+                idx_p = torch.cat([idx, torch.zeros(_pad64(n_feat) - n_feat, dtype=idx.dtype, device=self.device)])
+            else:
+                idx_p = idx
+            feat = ops.embed_fwd(idx_p, proj_all)                      # row gather of the valid frames (pad rows: copies of row 0)
+            slot, count = ops.image_slot_index(ids, self.cfg['audio_token_id'])
+            self._last_image_token_count, self._last_feature_rows = count, n_feat
+            actx = dict(idx=idx, n_feat=n_feat, tower_out=tower_out, rows_all=proj_all.shape[0])
+        x = ops.embed_fwd(ids, P[self.embed], slot, feat)
+        if save:
+            self._ctx = dict(ids=ids, slot=slot, N=N, T=T, start=start, pos=pos, audio=actx)
+        return self.stack.forward(x, N, T, start, pos, save, kv_sink)
+
+    def embed_tokens(self, ids, pos=None):
+        return ops.embed_fwd(ids, self.store.p[self.embed])
+
+    def validate_batch(self):
+        c = int(self._last_image_token_count.item())
+        if c != self._last_feature_rows:
+            raise ValueError(f'Audio features and audio tokens do not match, tokens: {c}, features: {self._last_feature_rows}')
+
+    def backward_stream(self, dres, on_layer_done=None):
+        cx = self._ctx
+        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done)
+        G, a = self.store.g, cx['audio']
+        want_feat = a is not None and (self.train_proj or self.train_tower)
+        dfeat = torch.zeros((_pad64(a['n_feat']), self.hidden_size), dtype=self.dtype, device=self.device) if want_feat else None
+        if self.train_lm or want_feat:
+            ops.embed_bwd(cx['ids'], dx, self.cfg['text']['vocab_size'], slot=cx['slot'],
+                          dE=G.get(self.embed) if self.train_lm else None, dfeat=dfeat)
+        if want_feat:
+            d_all = torch.zeros((a['rows_all'], self.hidden_size), dtype=self.dtype, device=self.device)
+            d_all.index_copy_(0, a['idx'], dfeat[:a['n_feat']])      # rows of the frames that were scattered; everything else 0
+            if self.train_proj:
+                self.proj.dw(d_all, a['tower_out'])
+            if self.train_tower:
+                self.tower.backward(self.proj.dx(d_all))
+
+
 # ====================================================================== Llama (text only)
 class NativeLlama(NativeCausalLM):
     """hf:models/llama/modeling_llama.py LlamaForCausalLM (MHA or GQA, head_dim 64/128): the text-to-text trainers'
@@ -1112,4 +1331,6 @@ def build_model(cfg: dict, device, trainable=True, head='lm', dtype=bf16, **free
         return NativeLlama(cfg, device, trainable, head=head, dtype=dtype)
     if cfg['kind'] == 'qwen2vl':
         return NativeQwen2VL(cfg, device, trainable, head=head, dtype=dtype, **freeze)
+    if cfg['kind'] == 'qwen2audio':
+        return NativeQwen2Audio(cfg, device, trainable, head=head, dtype=dtype, **freeze)
     raise ValueError(f"no native model for kind {cfg['kind']!r}")

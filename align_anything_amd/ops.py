@@ -299,10 +299,15 @@ def patch_im2col(pixels, patch, Kp, dtype=bf16):
     return out
 
 
+def _rows64(n):
+    return (n + 63) // 64 * 64
+
+
 def conv1d_im2col(x, B, C, Tin, stride, channels_first, dtype):
-    """Conv1d(k=3, padding=1) patches: x = [B, C, Tin] features (channels_first) or token-major [B*Tin, C] -> [B*Tout, 3C]."""
+    """Conv1d(k=3, padding=1) patches: x = [B, C, Tin] features (channels_first) or token-major [>=B*Tin, C] -> [B*Tout, 3C]
+    (rows padded to a multiple of 64 with zeros: they are the contraction dim of the weight-gradient GEMM)."""
     Tout = (Tin + 2 - 3) // stride + 1
-    col = torch.empty((B * Tout, 3 * C), dtype=dtype, device=x.device)
+    col = torch.zeros((_rows64(B * Tout), 3 * C), dtype=dtype, device=x.device)
     sb, sc, st_ = (C * Tin, Tin, 1) if channels_first else (Tin * C, 1, C)
     if x.dtype not in (bf16, f32) or not x.is_contiguous():
         raise RuntimeError(f'conv1d_im2col: contiguous bf16 / fp32 input expected, got {x.dtype}')
@@ -312,15 +317,15 @@ def conv1d_im2col(x, B, C, Tin, stride, channels_first, dtype):
 
 
 def conv1d_col2im(dcol, B, C, Tin, Tout, stride):
-    dx = torch.empty((B * Tin, C), dtype=dcol.dtype, device=dcol.device)
+    dx = torch.zeros((_rows64(B * Tin), C), dtype=dcol.dtype, device=dcol.device)
     call('aa_conv1d_col2im' + _sfx(dcol, 'conv1d_col2im'), dcol.data_ptr(), dx.data_ptr(), B, C, Tin, Tout, int(stride), stream())
     return dx
 
 
-def avgpool2(x, backward=False):
-    rows, C = x.shape
-    rows_out = rows if backward else rows // 2
-    y = torch.empty((2 * rows if backward else rows_out, C), dtype=x.dtype, device=x.device)
+def avgpool2(x, rows_out, backward=False):
+    """forward: x [>= 2*rows_out, C] -> [rows64(rows_out), C]; backward: x = dy [>= rows_out, C] -> dx [rows64(2*rows_out), C]."""
+    C = x.shape[1]
+    y = torch.zeros((_rows64(2 * rows_out if backward else rows_out), C), dtype=x.dtype, device=x.device)
     call('aa_avgpool2' + _sfx(x, 'avgpool2'), x.data_ptr(), y.data_ptr(), rows_out, C, int(backward), stream())
     return y
 

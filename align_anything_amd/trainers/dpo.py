@@ -63,7 +63,11 @@ class DPOTrainer:
     def init_models(self, policy_state=None, reference_state=None) -> None:
         """text_image_to_text/dpo.py:58-83: policy with freeze flags, frozen reference from the same checkpoint."""
         freeze = {}
-        if self.model_cfg['kind'] == 'llava':
+        if self.model_cfg['kind'] == 'qwen2audio':
+            freeze = dict(freeze_mm_proj=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_mm_proj', False)),
+                          freeze_language_model=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_language_model', False)),
+                          freeze_audio_tower=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_audio_tower', False)))
+        if self.model_cfg['kind'] in ('llava', 'qwen2vl'):
             freeze = dict(freeze_mm_proj=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_mm_proj', False)),
                           freeze_language_model=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_language_model', False)),
                           freeze_vision_tower=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_vision_tower', True)))
@@ -120,7 +124,7 @@ class DPOTrainer:
     def _flat_log_probs(self, module, batch, save):
         w = self._window(batch)
         feats = self._features(batch) if (self.share_vision_tower or module is self.policy) else None
-        mm = {k: batch[k] for k in ('image_grid_thw', 'position_ids3') if k in batch}   # Qwen2-VL processor outputs
+        mm = {k: batch[k] for k in ('image_grid_thw', 'position_ids3', 'input_features', 'feature_attention_mask') if k in batch}   # Qwen2-VL / Qwen2-Audio processor outputs
         return module.response_logprobs(batch['input_ids'], batch.get('attention_mask'), w,
                                         pixel_values=batch.get('pixel_values') if feats is None else None,
                                         save=save, image_features=feats, round_bf16=self.emulate_bf16_logp, **mm)

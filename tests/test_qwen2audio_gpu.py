@@ -1,0 +1,109 @@
+"""GPU: native Qwen2-Audio (BASELINE configs[3] backbone) against the fixture the reference's text_audio_to_text DPOTrainer
+produced on HF Qwen2AudioForConditionalGeneration with a TRAINABLE audio tower (tests/golden/qwen2audio_tiny_dpo.npz):
+conv front-end as im2col GEMMs, masked encoder attention, avg-pool, projector, audio-token scatter, Qwen2 decoder --
+forward, loss and every gradient (tower, projector, language model)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import assert_close, dev, dump
+from tests.util import bits_to_bf16, load_golden, rel_err, tiny_qwen2audio_cfg
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _sd(z, pre, dtype):
+    out = {k[len(pre):]: (bits_to_bf16(z[k]).to(dtype) if z[k].dtype == np.uint16 else T(z[k]).to(dtype)) for k in z.files if k.startswith(pre)}
+    out.setdefault('model.audio_tower.embed_positions.weight', T(z['w.model.audio_tower.embed_positions.weight']).to(dtype))
+    return out
+
+
+def _trainer(z, dtype):
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    cfgs = {'train_cfgs': {'scale_coeff': float(z['scale_coeff']), 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant',
+                           'weight_decay': 0.0, 'compute_dtype': dtype},
+            'model_cfgs': {'pad_token_id': int(z['pad_token_id'])}}
+    wd = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    return DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_qwen2audio_cfg(), policy_state=_sd(z, 'w.', wd), reference_state=_sd(z, 'r.', wd),
+                      device='cuda:0')
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_qwen2audio_dpo_matches_reference_fixture(dtype):
+    z = load_golden('qwen2audio_tiny_dpo.npz')
+    tr = _trainer(z, dtype)
+    tight = dtype == 'fp32'
+    b = {'input_ids': T(z['input_ids']).to(dev()), 'attention_mask': T(z['attention_mask']).to(dev()),
+         'input_features': T(z['input_features']).to(dev()), 'feature_attention_mask': T(z['feature_attention_mask']).to(dev()),
+         'meta_info': {'response_lens': [int(x) for x in z['response_lens']]}}
+    logits = tr.policy.logits(b['input_ids'], b['attention_mask'], input_features=b['input_features'],
+                              feature_attention_mask=b['feature_attention_mask']).float().cpu()
+    tr.policy.validate_batch()
+    valid = T(z['attention_mask']).bool()
+    e_log = rel_err(logits[valid], T(z['policy_logits'])[valid])
+    rep = [f'{dtype}: logits rel_err {e_log:.2e}']
+    assert e_log < (2e-5 if tight else 3e-2), rep
+    lp = tr.compute_log_probs(tr.model, b).cpu()
+    assert torch.equal(lp == 0, T(z['seq_log_probs']) == 0)
+    assert (lp - T(z['seq_log_probs'])).abs().max() < (1e-4 if tight else 8e-2)
+    ld = tr.loss(b)
+    rep.append(f"loss native {float(ld['loss']):.6f} reference {float(z['loss_loss']):.6f}")
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < (3e-5 if tight else 2e-2)
+    tr.model.backward(ld['loss'])
+    torch.cuda.synchronize()
+    worst, n, groups = 0.0, 0, set()
+    for k in z.files:
+        if not k.startswith('g.'):
+            continue
+        g = tr.policy.store.grad_view(k[2:])
+        assert g is not None, k
+        want = T(z[k])
+        got = g.float().cpu().reshape(want.shape)
+        if float(want.norm()) < 1e-6:                      # k_proj-style shift-invariant directions etc.
+            assert float(got.norm()) < 1e-4, k
+            continue
+        e = rel_err(got, want)
+        worst = max(worst, e); n += 1; groups.add(k.split('.')[2])
+        assert e < (5e-4 if tight else 9e-2), (k, e)
+    rep.append(f'worst gradient rel_err {worst:.2e} over {n} tensors in {sorted(groups)}')
+    dump(f'parity_qwen2audio_{dtype}.txt', '\n'.join(rep) + '\n')
+    assert {'audio_tower', 'multi_modal_projector', 'language_model'} <= groups and n > 55
+    # the k_proj slot of the fused q/k/v bias must stay exactly zero through an optimizer step
+    info = tr.train_step(b)
+    tr.model.wait_optimizer()
+    torch.cuda.synchronize()
+    d = tiny_qwen2audio_cfg()['audio']['d_model']
+    for L in tr.policy.tower.layers:
+        assert float(tr.policy.store.p[L['kbias']][d:2 * d].float().abs().max()) == 0.0
+    assert np.isfinite(info['train/loss'])
+    sd = tr.policy.state_dict()
+    assert sd['model.audio_tower.conv1.weight'].shape == (128, 64, 3) and 'model.audio_tower.layers.0.self_attn.k_proj.bias' not in sd
+
+
+def test_conv1d_and_avgpool_kernels_vs_torch():
+    from align_anything_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, C, Tin, Co = 3, 64, 50, 128
+    x = torch.randn(B, C, Tin, generator=g)
+    w, bias = torch.randn(Co, C, 3, generator=g) * 0.1, torch.randn(Co, generator=g)
+    for stride in (1, 2):
+        ref = torch.nn.functional.conv1d(x, w, bias, stride=stride, padding=1)              # [B, Co, Tout]
+        col, Tout = ops.conv1d_im2col(x.to(dev()), B, C, Tin, stride, True, torch.float32)
+        out = ops.gemm(col, w.reshape(Co, -1).contiguous().to(dev()), bias=bias.to(dev()))
+        assert rel_err(out[:B * Tout].view(B, Tout, Co).permute(0, 2, 1).cpu(), ref) < 1e-5
+        xt = x.permute(0, 2, 1).reshape(B * Tin, C).contiguous().to(dev())               # token-major input gives the same patches
+        col2, _ = ops.conv1d_im2col(xt, B, C, Tin, stride, False, torch.float32)
+        assert torch.equal(col, col2)
+        xa = x.clone().requires_grad_(True)
+        dy = torch.randn(B, Co, Tout, generator=g)
+        torch.nn.functional.conv1d(xa, w, None, stride=stride, padding=1).backward(dy)
+        dyt = torch.zeros(col.shape[0], Co); dyt[:B * Tout] = dy.permute(0, 2, 1).reshape(B * Tout, Co)
+        dcol = ops.gemm(dyt.to(dev()), w.reshape(Co, -1).contiguous().to(dev()), b_n=True)
+        dx = ops.conv1d_col2im(dcol, B, C, Tin, Tout, stride)
+        assert rel_err(dx[:B * Tin].view(B, Tin, C).permute(0, 2, 1).cpu(), xa.grad) < 1e-5
+    y = torch.randn(2 * 37, 64, generator=g)
+    p = ops.avgpool2(y.to(dev()), 37)
+    assert rel_err(p[:37].cpu(), 0.5 * (y[0::2] + y[1::2])) < 1e-6
+    back = ops.avgpool2(p, 37, backward=True)
+    assert rel_err(back[:74].cpu(), (0.5 * p[:37].cpu()).repeat_interleave(2, 0)) < 1e-6
