@@ -56,6 +56,16 @@ def qwen2audio_cfg(text, audio, audio_token_id, pad_token_id=None):
     return {'kind': 'qwen2audio', 'text': text, 'audio': audio, 'audio_token_id': audio_token_id, 'pad_token_id': pad_token_id}
 
 
+def qwen3moe_cfg(hidden_size, moe_intermediate_size, num_layers, num_heads, num_kv_heads, vocab_size, num_experts, num_experts_per_tok,
+                 head_dim=128, norm_topk_prob=True, rms_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=40960):
+    """Qwen3-MoE text decoder (every layer sparse): q/k RMSNorm per head, no attention bias, `num_experts` SwiGLU experts of
+    width `moe_intermediate_size`, top-`num_experts_per_tok` routing."""
+    return {'kind': 'qwen3moe', 'hidden_size': hidden_size, 'moe_intermediate_size': moe_intermediate_size, 'num_layers': num_layers,
+            'num_heads': num_heads, 'num_kv_heads': num_kv_heads, 'head_dim': head_dim, 'vocab_size': vocab_size,
+            'num_experts': num_experts, 'num_experts_per_tok': num_experts_per_tok, 'norm_topk_prob': bool(norm_topk_prob),
+            'rms_eps': rms_eps, 'rope_theta': rope_theta, 'max_position_embeddings': max_position_embeddings}
+
+
 def opt_cfg(hidden_size, ffn_dim, num_layers, num_heads, vocab_size, max_position_embeddings=2048):
     return {'kind': 'opt', 'hidden_size': hidden_size, 'ffn_dim': ffn_dim, 'num_layers': num_layers,
             'num_heads': num_heads, 'vocab_size': vocab_size,
@@ -131,7 +141,17 @@ def from_hf_config(c) -> dict:
         audio = qwen2audio_tower_cfg(a.d_model, a.encoder_layers, a.encoder_attention_heads, a.encoder_ffn_dim, a.num_mel_bins,
                                      a.max_source_positions)
         return qwen2audio_cfg(text, audio, c.audio_token_id, getattr(c, 'pad_token_id', None))
+    if mt == 'qwen3_moe':   # align_anything/models/qwen3_moe.py -> hf Qwen3MoeForCausalLM
+        rp = getattr(c, 'rope_parameters', None) or {}
+        theta = rp.get('rope_theta', getattr(c, 'rope_theta', 1000000.0))
+        if getattr(c, 'mlp_only_layers', None) or getattr(c, 'decoder_sparse_step', 1) != 1:
+            raise ValueError('qwen3_moe with dense layers (mlp_only_layers / decoder_sparse_step) has no native implementation yet')
+        if getattr(c, 'attention_bias', False):
+            raise ValueError('qwen3_moe with attention_bias has no native implementation yet')
+        return qwen3moe_cfg(c.hidden_size, c.moe_intermediate_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads,
+                            c.vocab_size, c.num_experts, c.num_experts_per_tok, getattr(c, 'head_dim', None) or c.hidden_size // c.num_attention_heads,
+                            c.norm_topk_prob, c.rms_norm_eps, theta, c.max_position_embeddings)
     if mt == 'opt':
         return opt_cfg(c.hidden_size, c.ffn_dim, c.num_hidden_layers, c.num_attention_heads, c.vocab_size,
                        c.max_position_embeddings)
-    raise ValueError(f'model_type {mt!r} has no native MI355X implementation (llava, llama, qwen2, qwen2_vl, qwen2_audio, opt are built)')
+    raise ValueError(f'model_type {mt!r} has no native MI355X implementation (llava, llama, qwen2, qwen2_vl, qwen2_audio, qwen3_moe, opt are built)')

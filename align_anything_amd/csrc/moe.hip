@@ -1,0 +1,209 @@
+// Mixture-of-experts routing and token movement for Qwen3-MoE (hf:models/qwen3_moe/modeling_qwen3_moe.py:210-283):
+//   router:  probs = softmax_fp32(x Wg^T); top-k; optional renormalisation over the k; weights cast to the activation dtype
+//   experts: tokens grouped by expert (64-row aligned segments so a segment can be the contraction dim of a dW GEMM),
+//            per-expert SwiGLU MLP through the ordinary GEMM, weighted combine back to token order.
+// The combine is a GATHER over each token's k expert rows (no atomics: deterministic).  Written against elem_t and
+// compiled twice (bf16 production / fp32 parity mode, moe_f32.hip), like elementwise.hip.
+#include "aa_common.h"
+
+namespace AA_ELEM_NS {
+
+// one wave per token row; E <= 1024.  probs fp32 [rows, E] is kept for the backward.
+__global__ __launch_bounds__(256) void moe_route_kernel(const elem_t* __restrict__ logits, long ld, long rows, int E, int k,
+                                                        int norm, float* __restrict__ probs, int* __restrict__ idx,
+                                                        elem_t* __restrict__ w) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const elem_t* x = logits + row * ld;
+    float mx = -INFINITY;
+    for (int e = lane; e < E; e += 64) mx = fmaxf(mx, e2f(x[e]));
+    mx = wave_max(mx);
+    float z = 0.f;
+    for (int e = lane; e < E; e += 64) z += expf(e2f(x[e]) - mx);
+    z = wave_sum(z);
+    float* pr = probs + row * E;
+    for (int e = lane; e < E; e += 64) pr[e] = expf(e2f(x[e]) - mx) / z;
+    __threadfence_block();     // other lanes of this wave read the probabilities back below
+    // k rounds of wave-wide argmax (ties -> lower index), previous winners excluded
+    float sum = 0.f;
+    float val[8]; int sel[8];
+    for (int j = 0; j < k; ++j) {
+        float best = -1.f; int bi = 0x7fffffff;
+        for (int e = lane; e < E; e += 64) {
+            bool taken = false;
+            for (int q = 0; q < j; ++q) taken |= (sel[q] == e);
+            const float p = taken ? -1.f : pr[e];
+            if (p > best || (p == best && e < bi)) { best = p; bi = e; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        val[j] = best; sel[j] = bi; sum += best;
+    }
+    if (lane == 0) {
+        for (int j = 0; j < k; ++j) {
+            idx[row * k + j] = sel[j];
+            w[row * k + j] = f2e(norm ? val[j] / sum : val[j]);
+        }
+    }
+}
+
+extern "C" int AA_FN(aa_moe_route)(const void* logits, long ld, long rows, int E, int k, int norm_topk, float* probs, int* idx,
+                                   void* weights, void* stream) {
+    AA_REQUIRE(rows >= 0 && E > 0 && k > 0 && k <= 8 && k <= E, "aa_moe_route: bad shape rows=%ld E=%d k=%d (k <= 8)", rows, E, k);
+    if (rows == 0) return AA_OK;
+    hipLaunchKernelGGL(moe_route_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)logits, ld, rows,
+                       E, k, norm_topk, probs, idx, (elem_t*)weights);
+    AA_CHECK_LAUNCH("aa_moe_route");
+    return AA_OK;
+}
+
+// d logits from d weights:  w_j = p_j / s (s = sum of the selected p, or 1 when not normalised);
+//   dp_i = (dw_i - [norm] sum_j dw_j w_j) / s for the selected i, 0 otherwise;  dlogit = p * (dp - sum_i p_i dp_i)
+__global__ __launch_bounds__(256) void moe_route_bwd_kernel(const float* __restrict__ probs, const int* __restrict__ idx,
+                                                            const float* __restrict__ dw, long rows, int E, int k, int norm,
+                                                            elem_t* __restrict__ dlogits, long ld) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* pr = probs + row * E;
+    float s = 1.f, dot_w = 0.f;
+    if (norm) {
+        s = 0.f;
+        for (int j = 0; j < k; ++j) s += pr[idx[row * k + j]];
+        for (int j = 0; j < k; ++j) dot_w += dw[row * k + j] * (pr[idx[row * k + j]] / s);
+    }
+    float pdp = 0.f;       // sum_i p_i dp_i (only selected i contribute)
+    for (int j = 0; j < k; ++j) {
+        const float p = pr[idx[row * k + j]];
+        pdp += p * (dw[row * k + j] - dot_w) / s;
+    }
+    for (int e = lane; e < E; e += 64) {
+        float dp = 0.f;
+        for (int j = 0; j < k; ++j) if (idx[row * k + j] == e) dp = (dw[row * k + j] - dot_w) / s;
+        dlogits[row * ld + e] = f2e(pr[e] * (dp - pdp));
+    }
+}
+extern "C" int AA_FN(aa_moe_route_bwd)(const float* probs, const int* idx, const float* dweights, long rows, int E, int k,
+                                       int norm_topk, void* dlogits, long ld, void* stream) {
+    AA_REQUIRE(rows >= 0 && E > 0 && k > 0 && k <= 8, "aa_moe_route_bwd: bad shape rows=%ld E=%d k=%d", rows, E, k);
+    if (rows == 0) return AA_OK;
+    hipLaunchKernelGGL(moe_route_bwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, probs, idx, dweights, rows, E,
+                       k, norm_topk, (elem_t*)dlogits, ld);
+    AA_CHECK_LAUNCH("aa_moe_route_bwd");
+    return AA_OK;
+}
+
+// Xp[r, :] = src[r] >= 0 ? x[src[r], :] : 0      (expert-major token copy; pad rows of a segment are zero)
+__global__ __launch_bounds__(256) void moe_gather_kernel(const elem_t* __restrict__ x, const int* __restrict__ src,
+                                                         elem_t* __restrict__ out, long rows_out, int h) {
+    const int nv = h >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows_out * nv; i += (long)gridDim.x * 256) {
+        const long r = i / nv;
+        const int v = (int)(i % nv);
+        const int s = src[r];
+        ev8 o;
+        if (s >= 0) o = *reinterpret_cast<const ev8*>(x + (long)s * h + v * 8);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2e(0.f);
+        }
+        *reinterpret_cast<ev8*>(out + r * h + v * 8) = o;
+    }
+}
+extern "C" int AA_FN(aa_moe_gather)(const void* x, const int* src_row, void* out, long rows_out, int h, void* stream) {
+    AA_REQUIRE(h > 0 && (h & 7) == 0, "aa_moe_gather: hidden %d must be a multiple of 8", h);
+    if (rows_out == 0) return AA_OK;
+    const long total = rows_out * (h >> 3);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(moe_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, src_row, (elem_t*)out, rows_out, h);
+    AA_CHECK_LAUNCH("aa_moe_gather");
+    return AA_OK;
+}
+
+// out[t, :] = (residual ? residual[t, :] : 0) + sum_j w[t, j] * Yp[pos[t, j], :]   (w == NULL -> unit weights)
+// hf :244-246: each expert output is multiplied by the (activation-dtype) weight, rounded, then index_add'ed in expert order.
+__global__ __launch_bounds__(256) void moe_combine_kernel(const elem_t* __restrict__ yp, const int* __restrict__ pos,
+                                                          const elem_t* __restrict__ w, const elem_t* __restrict__ residual,
+                                                          elem_t* __restrict__ out, long rows, int k, int h) {
+    const int nv = h >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * nv; i += (long)gridDim.x * 256) {
+        const long t = i / nv;
+        const int v = (int)(i % nv);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // hf index_add's the expert outputs in ascending expert order = ascending row of the expert-major buffer
+        int order[8];
+        for (int j = 0; j < k; ++j) {
+            int q = j;
+            while (q > 0 && pos[t * k + order[q - 1]] > pos[t * k + j]) { order[q] = order[q - 1]; --q; }
+            order[q] = j;
+        }
+        for (int jj = 0; jj < k; ++jj) {
+            const int j = order[jj];
+            const ev8 y = *reinterpret_cast<const ev8*>(yp + (long)pos[t * k + j] * h + v * 8);
+            const float wj = w ? e2f(w[t * k + j]) : 1.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = ernd(acc[q] + ernd(e2f(y[q]) * wj));
+        }
+        ev8 o;
+        if (residual) {
+            const ev8 r = *reinterpret_cast<const ev8*>(residual + t * h + v * 8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = f2e(acc[q] + e2f(r[q]));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = f2e(acc[q]);
+        }
+        *reinterpret_cast<ev8*>(out + t * h + v * 8) = o;
+    }
+}
+extern "C" int AA_FN(aa_moe_combine)(const void* yp, const int* pos, const void* weights, const void* residual, void* out, long rows,
+                                     int k, int h, void* stream) {
+    AA_REQUIRE(h > 0 && (h & 7) == 0 && k > 0 && k <= 8, "aa_moe_combine: hidden %d must be a multiple of 8 (k <= 8)", h);
+    if (rows == 0) return AA_OK;
+    const long total = rows * (h >> 3);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(moe_combine_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const elem_t*)yp, pos, (const elem_t*)weights,
+                       (const elem_t*)residual, (elem_t*)out, rows, k, h);
+    AA_CHECK_LAUNCH("aa_moe_combine");
+    return AA_OK;
+}
+
+// backward of the weighted combine: dYp[pos[t, j], :] = w[t, j] * dout[t, :] ;  dw[t, j] = <dout[t, :], Yp[pos[t, j], :]>
+// one wave per (token, slot); pad rows of dYp must have been zeroed by the caller.
+__global__ __launch_bounds__(256) void moe_combine_bwd_kernel(const elem_t* __restrict__ dout, const elem_t* __restrict__ yp,
+                                                              const int* __restrict__ pos, const elem_t* __restrict__ w,
+                                                              elem_t* __restrict__ dyp, float* __restrict__ dw, long rows, int k,
+                                                              int h) {
+    const int lane = threadIdx.x & 63;
+    const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= rows * k) return;
+    const long t = pair / k;
+    const long r = pos[pair];
+    const float wj = e2f(w[pair]);
+    float dot = 0.f;
+    for (int c = lane * 8; c < h; c += 512) {
+        const ev8 g = *reinterpret_cast<const ev8*>(dout + t * h + c);
+        const ev8 y = *reinterpret_cast<const ev8*>(yp + r * h + c);
+        ev8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { dot += e2f(g[q]) * e2f(y[q]); o[q] = f2e(e2f(g[q]) * wj); }
+        *reinterpret_cast<ev8*>(dyp + r * h + c) = o;
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) dw[pair] = dot;
+}
+extern "C" int AA_FN(aa_moe_combine_bwd)(const void* dout, const void* yp, const int* pos, const void* weights, void* dyp,
+                                         float* dweights, long rows, int k, int h, void* stream) {
+    AA_REQUIRE(h > 0 && (h & 7) == 0 && k > 0, "aa_moe_combine_bwd: hidden %d must be a multiple of 8", h);
+    if (rows == 0) return AA_OK;
+    hipLaunchKernelGGL(moe_combine_bwd_kernel, dim3((int)((rows * k + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)dout,
+                       (const elem_t*)yp, pos, (const elem_t*)weights, (elem_t*)dyp, dweights, rows, k, h);
+    AA_CHECK_LAUNCH("aa_moe_combine_bwd");
+    return AA_OK;
+}
+
+}  // namespace AA_ELEM_NS

@@ -1110,6 +1110,209 @@ class NativeQwen2Audio(NativeCausalLM):
                 self.tower.backward(self.proj.dx(d_all))
 
 
+# ====================================================================== Qwen3-MoE
+def moe_plan(idx: torch.Tensor, E: int):
+    """Expert-major layout of the (token, slot) pairs of a routing decision idx int32 [rows, k]: every expert owns a segment of
+    rows64(count) rows (zero padded, so a segment can be the contraction dim of its weight-gradient GEMM), tokens in token
+    order inside a segment.  Index plumbing on the device; ONE host read (the per-expert counts size the GEMM launches -- a
+    device-side grouped GEMM is the next step)."""
+    rows, k = idx.shape
+    dev = idx.device
+    flat = idx.reshape(-1).to(torch.int64)
+    counts = torch.bincount(flat, minlength=E)
+    cl = [int(c) for c in counts.tolist()]
+    seg = [(_pad64(c)) for c in cl]
+    off = [0]
+    for c in seg:
+        off.append(off[-1] + c)
+    off_dev = torch.tensor(off[:-1], dtype=torch.int64, device=dev)
+    order = torch.argsort(flat, stable=True)
+    sorted_e = flat[order]
+    starts = torch.cumsum(counts, 0) - counts
+    dest = off_dev[sorted_e] + (torch.arange(rows * k, device=dev) - starts[sorted_e])
+    pos = torch.empty(rows * k, dtype=torch.int32, device=dev)
+    pos[order] = dest.to(torch.int32)
+    src = torch.full((max(off[-1], 64),), -1, dtype=torch.int32, device=dev)
+    src[dest] = (order // k).to(torch.int32)
+    return {'pos': pos.view(rows, k), 'src': src, 'segments': [(e, off[e], seg[e]) for e in range(E) if cl[e] > 0],
+            'empty': [e for e in range(E) if cl[e] == 0], 'counts': cl}
+
+
+class Qwen3MoeStack:
+    """hf:models/qwen3_moe/modeling_qwen3_moe.py:305-350 x num_layers: attention with per-head RMSNorm on q and k (:143-166),
+    sparse MoE block (:210-283).  Routing, token movement and combine are HIP kernels (csrc/moe.hip); the experts run through
+    the ordinary GEMM on 64-row-aligned segments of the expert-major buffer."""
+
+    def __init__(self, cfg: dict, store: ParamStore, prefix: str, trainable: bool):
+        self.cfg, self.store, self.prefix, self.trainable = cfg, store, prefix, trainable
+        h, F, E = cfg['hidden_size'], cfg['moe_intermediate_size'], cfg['num_experts']
+        H, Hkv, hd = cfg['num_heads'], cfg['num_kv_heads'], cfg['head_dim']
+        if hd not in (64, 128):
+            raise NotImplementedError(f'head_dim {hd}: attention kernels are built for 64 and 128')
+        tr = trainable
+        self.layers = []
+        for i in range(cfg['num_layers']):
+            p = f'{prefix}layers.{i}.'
+            L = {'ln1': store.add(p + 'input_layernorm.weight', (h,), tr),
+                 'q': Linear(store, store.add(p + 'self_attn.q_proj.weight', (H * hd, h), tr)),
+                 'k': Linear(store, store.add(p + 'self_attn.k_proj.weight', (Hkv * hd, h), tr)),
+                 'v': Linear(store, store.add(p + 'self_attn.v_proj.weight', (Hkv * hd, h), tr)),
+                 'qn': store.add(p + 'self_attn.q_norm.weight', (hd,), tr), 'kn': store.add(p + 'self_attn.k_norm.weight', (hd,), tr),
+                 'o': Linear(store, store.add(p + 'self_attn.o_proj.weight', (h, H * hd), tr)),
+                 'ln2': store.add(p + 'post_attention_layernorm.weight', (h,), tr),
+                 'gate': Linear(store, store.add(p + 'mlp.gate.weight', (E, h), tr)),
+                 'gu': store.add(p + 'mlp.experts.gate_up_proj', (E, 2 * F, h), tr),
+                 'down': store.add(p + 'mlp.experts.down_proj', (E, h, F), tr)}
+            self.layers.append(L)
+        self.norm = store.add(prefix + 'norm.weight', (h,), tr)
+        self.cos = self.sin = None
+        self.saved = []
+
+    def _tables(self, T):
+        if self.cos is None or self.cos.shape[0] < T:
+            n = max(T, self.cfg.get('max_position_embeddings', 0) or T)
+            self.cos, self.sin = rope_tables(n, self.cfg['head_dim'], self.cfg['rope_theta'], self.store.device, self.store.dtype)
+
+    def forward(self, x, N, T, start, pos, save, kv_sink=None):
+        if kv_sink is not None:
+            raise NotImplementedError('Qwen3-MoE decode (KV-cache prefill) is not built yet')
+        c, P = self.cfg, self.store.p
+        H, Hkv, hd, eps, E, k = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps'], c['num_experts'], c['num_experts_per_tok']
+        self._tables(T)
+        self.saved = []
+        Mp = x.shape[0]
+        for L in self.layers:
+            n1, rstd1 = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
+            q, kk, v = L['q'].fwd(n1), L['k'].fwd(n1), L['v'].fwd(n1)
+            qn, rq = ops.rmsnorm_fwd(q.view(Mp * H, hd), P[L['qn']], eps)
+            kn, rk = ops.rmsnorm_fwd(kk.view(Mp * Hkv, hd), P[L['kn']], eps)
+            qn, kn = qn.view(Mp, H * hd), kn.view(Mp, Hkv * hd)
+            ops.rope_(qn, 0, H, hd, pos, self.cos, self.sin)
+            ops.rope_(kn, 0, Hkv, hd, pos, self.cos, self.sin)
+            attn, lse = ops.attn_fwd(qn, kn, v, N, T, H, Hkv, hd, True, hd ** -0.5, start,
+                                     out=None if Mp == N * T else torch.zeros((Mp, H * hd), dtype=x.dtype, device=x.device))
+            x_mid = L['o'].fwd(attn, residual=x)
+            n2, rstd2 = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
+            logits = L['gate'].fwd(n2)
+            probs, idx, w = ops.moe_route(logits, k, c['norm_topk_prob'])
+            plan = moe_plan(idx, E)
+            xp = ops.moe_gather(n2, plan['src'])
+            gu = torch.zeros((xp.shape[0], P[L['gu']].shape[1]), dtype=x.dtype, device=x.device)
+            for e, o, n in plan['segments']:
+                ops.gemm(xp[o:o + n], P[L['gu']][e], out=gu[o:o + n])
+            act = ops.swiglu_fwd(gu)
+            yp = torch.zeros((xp.shape[0], c['hidden_size']), dtype=x.dtype, device=x.device)
+            for e, o, n in plan['segments']:
+                ops.gemm(act[o:o + n], P[L['down']][e], out=yp[o:o + n])
+            x_out = ops.moe_combine(yp, plan['pos'], w, Mp, residual=x_mid)
+            if save:
+                self.saved.append((x, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp))
+            x = x_out
+        return x
+
+    def backward(self, dres, N, T, start, pos, on_layer_done=None):
+        c, P, G = self.cfg, self.store.p, self.store.g
+        H, Hkv, hd, E = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['num_experts']
+        tr, st = self.trainable, self.store
+        Mp = dres.shape[0]
+        acc = lambda g: (g.dtype == torch.float32) or st.accumulate
+        for L, sv in zip(reversed(self.layers), reversed(self.saved)):
+            x, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp = sv
+            sv = None
+            # ---- sparse MoE block
+            dyp, dw = ops.moe_combine_bwd(dres, yp, plan['pos'], w)
+            dact = torch.zeros_like(act)
+            for e, o, n in plan['segments']:
+                ops.gemm(dyp[o:o + n], P[L['down']][e], out=dact[o:o + n], b_n=True)
+                if tr:
+                    g = G[L['down']][e]
+                    ops.gemm(dyp[o:o + n], act[o:o + n], out=g, a_t=True, b_n=True, accumulate=acc(g))
+            dgu = ops.swiglu_bwd(gu, dact)
+            dxp = torch.zeros_like(xp)
+            for e, o, n in plan['segments']:
+                ops.gemm(dgu[o:o + n], P[L['gu']][e], out=dxp[o:o + n], b_n=True)
+                if tr:
+                    g = G[L['gu']][e]
+                    ops.gemm(dgu[o:o + n], xp[o:o + n], out=g, a_t=True, b_n=True, accumulate=acc(g))
+            if tr and not st.accumulate:
+                for e in plan['empty']:                # experts that saw no token this step: their gradient is zero, not stale
+                    G[L['gu']][e].zero_(); G[L['down']][e].zero_()
+            d_n2 = ops.moe_combine(dxp, plan['pos'], None, Mp)
+            dlogits = ops.moe_route_bwd(probs, idx, dw, c['norm_topk_prob'], x.dtype)
+            if E % 64:   # the expert count is the contraction dim here: zero-pad it for small (test-size) routers
+                Ep = _pad64(E)
+                dl = torch.zeros((Mp, Ep), dtype=x.dtype, device=x.device); dl[:, :E] = dlogits
+                wg = torch.zeros((Ep, c['hidden_size']), dtype=x.dtype, device=x.device); wg[:E] = L['gate'].w
+                ops.gemm(dl, wg, out=d_n2, b_n=True, accumulate=True)
+            else:
+                ops.gemm(dlogits, L['gate'].w, out=d_n2, b_n=True, accumulate=True)
+            if tr:
+                L['gate'].dw(dlogits, n2)
+            ops.rmsnorm_bwd(d_n2, x_mid, P[L['ln2']], rstd2, G.get(L['ln2']) if tr else None, dx=dres, add_to_dx=True)
+            # ---- attention
+            d_attn = L['o'].dx(dres)
+            if tr:
+                L['o'].dw(dres, attn)
+            z = lambda t: torch.zeros_like(t) if Mp != N * T else torch.empty_like(t)
+            dqn, dkn, dv = z(qn), z(kn), z(v)
+            ops.attn_bwd(qn, kn, v, attn, d_attn, lse, dqn, dkn, dv, N, T, H, Hkv, hd, True, hd ** -0.5, start)
+            ops.rope_(dqn, 0, H, hd, pos, self.cos, self.sin, inverse=True)
+            ops.rope_(dkn, 0, Hkv, hd, pos, self.cos, self.sin, inverse=True)
+            dq = ops.rmsnorm_bwd(dqn.view(Mp * H, hd), q.view(Mp * H, hd), P[L['qn']], rq, G.get(L['qn']) if tr else None).view(Mp, H * hd)
+            dk = ops.rmsnorm_bwd(dkn.view(Mp * Hkv, hd), kk.view(Mp * Hkv, hd), P[L['kn']], rk, G.get(L['kn']) if tr else None).view(Mp, Hkv * hd)
+            d_n1 = L['q'].dx(dq)
+            ops.gemm(dk, L['k'].w, out=d_n1, b_n=True, accumulate=True)
+            ops.gemm(dv, L['v'].w, out=d_n1, b_n=True, accumulate=True)
+            if tr:
+                L['q'].dw(dq, n1); L['k'].dw(dk, n1); L['v'].dw(dv, n1)
+            ops.rmsnorm_bwd(d_n1, x, P[L['ln1']], rstd1, G.get(L['ln1']) if tr else None, dx=dres, add_to_dx=True)
+            if on_layer_done is not None:
+                on_layer_done(L)
+        self.saved = []
+        return dres
+
+
+class NativeQwen3Moe(NativeCausalLM):
+    """hf:models/qwen3_moe/modeling_qwen3_moe.py:597+ Qwen3MoeForCausalLM (align_anything/models/qwen3_moe.py), text only."""
+
+    kind = 'qwen3moe'
+
+    def __init__(self, cfg, device, trainable=True, head='lm', dtype=bf16):
+        super().__init__(cfg, device, trainable, dtype)
+        self.head_kind = head
+        self.hidden_size = cfg['hidden_size']
+        st = self.store
+        self.embed = st.add('model.embed_tokens.weight', (cfg['vocab_size'], cfg['hidden_size']), trainable, f32_grad=True)
+        self.stack = Qwen3MoeStack(cfg, st, 'model.', trainable)
+        if head == 'lm':
+            lm = st.add('lm_head.weight', (cfg['vocab_size'], cfg['hidden_size']), trainable)
+            self.head = LMHead(st, 'rms', self.stack.norm, None, lm, cfg['rms_eps'], trainable)
+        else:   # models/qwen3_moe.py:36-72 AccustomedQwen3MoeRewardModel
+            sw = st.add('score_head.weight', (1, cfg['hidden_size']), trainable, f32_grad=True)
+            self.head = ScoreHead(st, 'rms', self.stack.norm, None, sw, cfg['rms_eps'], trainable)
+        self.finalize()
+
+    def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
+                       position_ids=None, kv_sink=None):
+        N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask, position_ids)
+        ids = input_ids.reshape(-1)
+        if Mp != N * T:
+            ids = torch.cat([ids, torch.zeros(Mp - N * T, dtype=ids.dtype, device=ids.device)])
+        x = ops.embed_fwd(ids, self.store.p[self.embed])
+        if save:
+            self._ctx = dict(ids=ids, N=N, T=T, start=start, pos=pos)
+        return self.stack.forward(x, N, T, start, pos, save, kv_sink)
+
+    def embed_tokens(self, ids, pos=None):
+        return ops.embed_fwd(ids, self.store.p[self.embed])
+
+    def backward_stream(self, dres, on_layer_done=None):
+        cx = self._ctx
+        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done)
+        if self.trainable:
+            ops.embed_bwd(cx['ids'], dx, self.cfg['vocab_size'], dE=self.store.g.get(self.embed))
+
+
 # ====================================================================== Llama (text only)
 class NativeLlama(NativeCausalLM):
     """hf:models/llama/modeling_llama.py LlamaForCausalLM (MHA or GQA, head_dim 64/128): the text-to-text trainers'
@@ -1333,4 +1536,6 @@ def build_model(cfg: dict, device, trainable=True, head='lm', dtype=bf16, **free
         return NativeQwen2VL(cfg, device, trainable, head=head, dtype=dtype, **freeze)
     if cfg['kind'] == 'qwen2audio':
         return NativeQwen2Audio(cfg, device, trainable, head=head, dtype=dtype, **freeze)
+    if cfg['kind'] == 'qwen3moe':
+        return NativeQwen3Moe(cfg, device, trainable, head=head, dtype=dtype)
     raise ValueError(f"no native model for kind {cfg['kind']!r}")

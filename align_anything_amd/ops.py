@@ -343,6 +343,49 @@ def f32_to_bf16(x, out=None):
     return out
 
 
+# ------------------------------------------------------------------ mixture of experts
+def moe_route(logits, k, norm_topk):
+    rows, E = logits.shape
+    dev = logits.device
+    probs = torch.empty((rows, E), dtype=f32, device=dev)
+    idx = torch.empty((rows, k), dtype=torch.int32, device=dev)
+    w = torch.empty((rows, k), dtype=logits.dtype, device=dev)
+    call('aa_moe_route' + _sfx(logits, 'moe_route'), logits.data_ptr(), logits.stride(0), rows, E, int(k), int(bool(norm_topk)),
+         probs.data_ptr(), idx.data_ptr(), w.data_ptr(), stream())
+    return probs, idx, w
+
+
+def moe_route_bwd(probs, idx, dw, norm_topk, dtype):
+    rows, E = probs.shape
+    dlogits = torch.empty((rows, E), dtype=dtype, device=probs.device)
+    call('aa_moe_route_bwd' + _sfx(dlogits, 'moe_route_bwd'), probs.data_ptr(), idx.data_ptr(), dw.data_ptr(), rows, E, idx.shape[1],
+         int(bool(norm_topk)), dlogits.data_ptr(), dlogits.stride(0), stream())
+    return dlogits
+
+
+def moe_gather(x, src_row):
+    rows_out, h = src_row.numel(), x.shape[1]
+    out = torch.empty((rows_out, h), dtype=x.dtype, device=x.device)
+    call('aa_moe_gather' + _sfx(x, 'moe_gather'), x.data_ptr(), src_row.data_ptr(), out.data_ptr(), rows_out, h, stream())
+    return out
+
+
+def moe_combine(yp, pos, w, rows, residual=None):
+    k, h = pos.shape[1], yp.shape[1]
+    out = torch.empty((rows, h), dtype=yp.dtype, device=yp.device)
+    call('aa_moe_combine' + _sfx(yp, 'moe_combine'), yp.data_ptr(), pos.data_ptr(), _p(w), _p(residual), out.data_ptr(), rows, k, h, stream())
+    return out
+
+
+def moe_combine_bwd(dout, yp, pos, w):
+    rows, k = pos.shape
+    dyp = torch.zeros_like(yp)                       # pad rows of every expert segment carry no gradient
+    dw = torch.empty((rows, k), dtype=f32, device=yp.device)
+    call('aa_moe_combine_bwd' + _sfx(yp, 'moe_combine_bwd'), dout.data_ptr(), yp.data_ptr(), pos.data_ptr(), w.data_ptr(), dyp.data_ptr(),
+         dw.data_ptr(), rows, k, yp.shape[1], stream())
+    return dyp, dw
+
+
 # ------------------------------------------------------------------ attention
 def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None, kv_len=None):
     """q/k/v: 2-D views [N*T, >=H*hd] (column slices of the fused qkv buffer are fine)."""

@@ -162,6 +162,19 @@ int aa_conv1d_im2col(const void* x, int x_dtype, long sb, long sc, long st, void
                      int stride, void* stream);
 int aa_conv1d_col2im(const void* dcol, void* dx, int B, int C, int Tin, int Tout, int stride, void* stream);
 int aa_avgpool2(const void* x, void* y, long rows_out, int C, int backward, void* stream);
+/* Qwen3-MoE sparse block (hf:models/qwen3_moe/modeling_qwen3_moe.py:210-283): router softmax (fp32) + top-k (k <= 8, ties -> lower
+ * expert) + optional renormalisation, weights cast to the activation dtype; its backward from d weights; expert-major token copy
+ * (src_row < 0 -> zero pad row); weighted combine as a gather over each token's k expert rows (ascending expert order, like
+ * hf's index_add; weights NULL = 1; optional residual) and its backward (dYp rows + d weights). */
+int aa_moe_route(const void* logits, long ld, long rows, int E, int k, int norm_topk, float* probs, int* idx, void* weights,
+                 void* stream);
+int aa_moe_route_bwd(const float* probs, const int* idx, const float* dweights, long rows, int E, int k, int norm_topk,
+                     void* dlogits, long ld, void* stream);
+int aa_moe_gather(const void* x, const int* src_row, void* out, long rows_out, int h, void* stream);
+int aa_moe_combine(const void* yp, const int* pos, const void* weights, const void* residual, void* out, long rows, int k, int h,
+                   void* stream);
+int aa_moe_combine_bwd(const void* dout, const void* yp, const int* pos, const void* weights, void* dyp, float* dweights,
+                       long rows, int k, int h, void* stream);
 /* hf:models/clip/modeling_clip.py:138-218 CLIPVisionEmbeddings (patch conv as im2col + GEMM) */
 int aa_patch_im2col(const void* pixels, int pix_dtype, void* out, int n_img, int channels,
                     int image_size, int patch, int Kp, void* stream);

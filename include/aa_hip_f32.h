@@ -86,6 +86,17 @@ int aa_conv1d_im2col_f32(const void* x, int x_dtype, long sb, long sc, long st, 
 int aa_conv1d_col2im_f32(const void* dcol, void* dx, int B, int C, int Tin, int Tout, int stride, void* stream);
 int aa_avgpool2_f32(const void* x, void* y, long rows_out, int C, int backward, void* stream);
 
+/* fp32 twins: Qwen3-MoE sparse block (see aa_hip.h) */
+int aa_moe_route_f32(const void* logits, long ld, long rows, int E, int k, int norm_topk, float* probs, int* idx, void* weights,
+                     void* stream);
+int aa_moe_route_bwd_f32(const float* probs, const int* idx, const float* dweights, long rows, int E, int k, int norm_topk,
+                         void* dlogits, long ld, void* stream);
+int aa_moe_gather_f32(const void* x, const int* src_row, void* out, long rows_out, int h, void* stream);
+int aa_moe_combine_f32(const void* yp, const int* pos, const void* weights, const void* residual, void* out, long rows, int k, int h,
+                       void* stream);
+int aa_moe_combine_bwd_f32(const void* dout, const void* yp, const int* pos, const void* weights, void* dyp, float* dweights,
+                           long rows, int k, int h, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -477,6 +477,70 @@ def gen_qwen2audio_dpo():
     print('qwen2audio_tiny_dpo.npz loss', float(ld['loss']), 'acc', float(ld['reward_accuracy']), 'n arrays', len(out))
 
 
+def tiny_qwen3moe():
+    from transformers import Qwen3MoeConfig, Qwen3MoeForCausalLM
+    cfg = Qwen3MoeConfig(hidden_size=128, intermediate_size=256, moe_intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                         num_key_value_heads=1, head_dim=64, vocab_size=320, num_experts=8, num_experts_per_tok=2, norm_topk_prob=True,
+                         max_position_embeddings=256, rope_parameters={'rope_type': 'default', 'rope_theta': 10000.0}, pad_token_id=1)
+    torch.manual_seed(41)
+    m = Qwen3MoeForCausalLM(cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+            if 'mlp.gate.weight' in n:
+                p.normal_(0, 0.5)                        # spread the router so the top-2 choice is not a near-tie
+            p.copy_(p.to(torch.bfloat16).to(torch.float32))
+    return cfg, m.eval()
+
+
+def gen_qwen3moe_dpo():
+    """BASELINE configs[4] backbone: the reference's unmodified text_to_text DPOTrainer.{compute_log_probs, loss}
+    (trainers/text_to_text/dpo.py:122-203) on a tiny random HF Qwen3MoeForCausalLM (align_anything/models/qwen3_moe.py: 8 experts,
+    top-2, q/k norm, GQA), fp32, CPU; records the routing of the first layer too (integer work)."""
+    from align_anything.trainers.text_to_text.dpo import DPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+    cfg, policy = tiny_qwen3moe()
+    _, refm = tiny_qwen3moe()
+    g = torch.Generator().manual_seed(43)
+    with torch.no_grad():
+        for p in refm.parameters():
+            p.add_(0.02 * torch.randn(p.shape, generator=g)); p.copy_(p.to(torch.bfloat16).to(torch.float32))
+    N, T = 4, 40
+    ids = torch.full((N, T), 1, dtype=torch.long)
+    mask = torch.zeros((N, T), dtype=torch.long)
+    for r, lp in enumerate((0, 6, 2, 0)):
+        ids[r, lp:] = torch.randint(3, 320, (T - lp,), generator=g)
+        mask[r, lp:] = 1
+    resp = [10, 8, 12, 5]
+    batch = {'input_ids': ids, 'attention_mask': mask, 'meta_info': {'response_lens': resp}}
+    tr = DPOTrainer.__new__(DPOTrainer)
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+    tr.tokenizer = SimpleNamespace(pad_token_id=1)
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    tr.model, tr.reference_model = SimpleNamespace(module=policy), SimpleNamespace(module=refm)
+    policy.zero_grad()
+    seq_lp = tr.compute_log_probs(policy, batch)
+    ld = tr.loss(batch)
+    ld['loss'].backward()
+    with torch.no_grad():
+        o = policy(input_ids=ids, attention_mask=mask, output_router_logits=True)
+    out = {'input_ids': ids.numpy(), 'attention_mask': mask.numpy(), 'response_lens': np.array(resp), 'pad_token_id': np.array(1),
+           'scale_coeff': np.array(0.1), 'policy_logits': o.logits.numpy(), 'seq_log_probs': seq_lp.detach().numpy(),
+           'router_logits_l0': o.router_logits[0].numpy()}
+    for k, v in ld.items():
+        out['loss_' + k] = v.detach().numpy()
+    for n, p in policy.state_dict().items():
+        out['w.' + n] = bf16_bits(p)
+    for n, p in refm.state_dict().items():
+        out['r.' + n] = bf16_bits(p)
+    for n, p in policy.named_parameters():
+        if p.grad is not None:
+            out['g.' + n] = p.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'qwen3moe_tiny_dpo.npz'), **out)
+    print('qwen3moe_tiny_dpo.npz loss', float(ld['loss']), 'n arrays', len(out))
+
+
 def gen_pref():
     """SimPO / ORPO / KTO: the reference's unmodified `loss` overrides (trainers/text_to_text/simpo.py:41-108,
     orpo.py:41-112, kto.py:83-160) on the tiny OPT of opt_tiny_dpo.npz (weights are read back from that fixture, so
@@ -685,6 +749,7 @@ if __name__ == '__main__':
     gen_qwen2vl_dpo()
     gen_qwen2vl_ppo()
     gen_qwen2audio_dpo()
+    gen_qwen3moe_dpo()
     gen_pref()
     gen_collator()
     gen_grpo()

@@ -322,6 +322,47 @@ def qwen2audio_logits(sd, cfg, input_ids, attention_mask, input_features, featur
     return F.linear(llama_decoder(sd, cfg['text'], x, key_valid), sd['lm_head.weight'])
 
 
+# ------------------------------------------------------------------ Qwen3-MoE
+def qwen3moe_logits(sd, cfg, input_ids, attention_mask, prefix='model.'):
+    """hf:models/qwen3_moe/modeling_qwen3_moe.py: attention with per-head RMSNorm on q and k before RoPE (:122-190), sparse MoE
+    block (:210-283: fp32 router softmax, top-k, renormalisation, weights cast to the activation dtype, per-expert SwiGLU on the
+    3-D `gate_up_proj` / `down_proj` parameters, index_add combine), 1-D RoPE positions arange(T)."""
+    N, T = input_ids.shape
+    H, Hkv, hd, eps = cfg['num_heads'], cfg['num_kv_heads'], cfg['head_dim'], cfg['rms_eps']
+    E, k = cfg['num_experts'], cfg['num_experts_per_tok']
+    x = F.embedding(input_ids, sd[prefix + 'embed_tokens.weight'])
+    key_valid = attention_mask.bool() if attention_mask is not None else None
+    cos, sin = rope_tables(T, hd, cfg['rope_theta'], x.dtype)
+    for i in range(cfg['num_layers']):
+        p = f'{prefix}layers.{i}.'
+        y = rms_norm(x, sd[p + 'input_layernorm.weight'], eps)
+        q = rms_norm(linear(y, sd, p + 'self_attn.q_proj').view(N, T, H, hd), sd[p + 'self_attn.q_norm.weight'], eps).transpose(1, 2)
+        kk = rms_norm(linear(y, sd, p + 'self_attn.k_proj').view(N, T, Hkv, hd), sd[p + 'self_attn.k_norm.weight'], eps).transpose(1, 2)
+        v = linear(y, sd, p + 'self_attn.v_proj').view(N, T, Hkv, hd).transpose(1, 2)
+        q, kk = apply_rope(q, cos, sin), apply_rope(kk, cos, sin)
+        if Hkv != H:
+            kk = kk.repeat_interleave(H // Hkv, dim=1); v = v.repeat_interleave(H // Hkv, dim=1)
+        a = attention(q, kk, v, hd ** -0.5, True, key_valid).transpose(1, 2).reshape(N, T, H * hd)
+        x = x + linear(a, sd, p + 'self_attn.o_proj')
+        y = rms_norm(x, sd[p + 'post_attention_layernorm.weight'], eps).reshape(N * T, -1)
+        logits = F.linear(y, sd[p + 'mlp.gate.weight'])
+        probs = F.softmax(logits, dim=-1, dtype=torch.float)
+        top_w, top_i = torch.topk(probs, k, dim=-1)
+        if cfg['norm_topk_prob']:
+            top_w = top_w / top_w.sum(-1, keepdim=True)
+        top_w = top_w.to(logits.dtype)
+        out = torch.zeros_like(y)
+        for e in range(E):
+            slot, tok = torch.where((top_i == e).t())
+            if tok.numel() == 0:
+                continue
+            g, u = F.linear(y[tok], sd[p + 'mlp.experts.gate_up_proj'][e]).chunk(2, dim=-1)
+            h_e = F.linear(F.silu(g) * u, sd[p + 'mlp.experts.down_proj'][e]) * top_w[tok, slot, None]
+            out = out.index_add(0, tok, h_e.to(out.dtype))
+        x = x + out.view(N, T, -1)
+    return F.linear(rms_norm(x, sd[prefix + 'norm.weight'], eps), sd['lm_head.weight'])
+
+
 def llama_logits(sd, cfg, input_ids, attention_mask, prefix='model.'):
     x = F.embedding(input_ids, sd[prefix + 'embed_tokens.weight'])
     key_valid = attention_mask.bool() if attention_mask is not None else None

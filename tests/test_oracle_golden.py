@@ -239,3 +239,31 @@ def test_qwen2audio_oracle_matches_reference_dpo_fixture():
             assert rel_err(sd[k[2:]].grad, want) < 2e-3, k
             n += 1
     assert n > 50          # audio tower (conv, layers, layer_norm), projector and language model all receive gradients
+
+
+def test_qwen3moe_oracle_matches_reference_dpo_fixture():
+    """oracle/models.py::qwen3moe_logits (q/k head RMSNorm, fp32 router softmax + top-2 + renormalisation, per-expert SwiGLU,
+    index_add combine) vs the fixture the reference's text_to_text DPOTrainer produced on HF Qwen3MoeForCausalLM."""
+    from tests.util import tiny_qwen3moe_cfg
+    z = load_golden('qwen3moe_tiny_dpo.npz')
+    cfg = tiny_qwen3moe_cfg()
+    ids, mask = T(z['input_ids']), T(z['attention_mask'])
+    sd = {k: v.clone().requires_grad_(True) for k, v in state_dict_from_golden(z, 'w.').items()}
+    rsd = state_dict_from_golden(z, 'r.')
+    logits = om.qwen3moe_logits(sd, cfg, ids, mask)
+    valid = mask.bool()
+    assert rel_err(logits.detach()[valid], T(z['policy_logits'])[valid]) < 1e-5
+    resp = [int(r) for r in z['response_lens']]
+    lp = orl.compute_log_probs(logits, ids, resp, int(z['pad_token_id']))
+    np.testing.assert_allclose(lp.detach().numpy(), z['seq_log_probs'], rtol=2e-4, atol=2e-4)
+    with torch.no_grad():
+        rlp = orl.compute_log_probs(om.qwen3moe_logits(rsd, cfg, ids, mask), ids, resp, int(z['pad_token_id']))
+    ld = orl.dpo_loss(lp, rlp, float(z['scale_coeff']))
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < 2e-5
+    ld['loss'].backward()
+    n = 0
+    for k in z.files:
+        if k.startswith('g.') and k[2:] in sd and float(np.linalg.norm(z[k])) > 1e-7:
+            assert rel_err(sd[k[2:]].grad, T(z[k])) < 2e-3, k
+            n += 1
+    assert n >= 25

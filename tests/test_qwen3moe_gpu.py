@@ -1,0 +1,107 @@
+"""GPU: native Qwen3-MoE (BASELINE configs[4] backbone) against the fixture the reference's text_to_text DPOTrainer produced on HF
+Qwen3MoeForCausalLM (tests/golden/qwen3moe_tiny_dpo.npz: 8 experts, top-2, q/k head RMSNorm, GQA): routing bit-exact, logits,
+loss and every gradient incl. router and per-expert weights."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import assert_close, dev, dump
+from tests.util import load_golden, rel_err, state_dict_from_golden, tiny_qwen3moe_cfg
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def test_moe_kernels_vs_torch():
+    from align_anything_amd import ops
+    from align_anything_amd.modeling import moe_plan
+    g = torch.Generator().manual_seed(2)
+    rows, E, k, h = 100, 16, 4, 64
+    logits = (torch.randn(rows, E, generator=g) * 2).to(dev())
+    for norm in (True, False):
+        probs, idx, w = ops.moe_route(logits, k, norm)
+        p_ref = torch.softmax(logits.double(), -1)
+        tv, ti = torch.topk(p_ref, k, -1)
+        assert torch.equal(idx.long().cpu(), ti.cpu())                                   # integer work: exact
+        wr = tv / tv.sum(-1, keepdim=True) if norm else tv
+        assert rel_err(w.cpu(), wr.cpu()) < 1e-6 and rel_err(probs.cpu(), p_ref.cpu()) < 1e-6
+        # backward of the routing weights w.r.t. the logits
+        lg = logits.double().clone().requires_grad_(True)
+        pr = torch.softmax(lg, -1)
+        sel = torch.gather(pr, 1, ti)
+        ww = sel / sel.sum(-1, keepdim=True) if norm else sel
+        dw = torch.randn(rows, k, generator=g).to(dev())
+        (ww * dw.double()).sum().backward()
+        got = ops.moe_route_bwd(probs, idx, dw, norm, torch.float32)
+        assert rel_err(got.cpu(), lg.grad.cpu()) < 1e-5
+    plan = moe_plan(idx, E)
+    x = torch.randn(rows, h, generator=g).to(dev())
+    xp = ops.moe_gather(x, plan['src'])
+    src = plan['src'].cpu()
+    assert torch.equal(xp.cpu()[src >= 0], x.cpu()[src[src >= 0].long()]) and float(xp.cpu()[src < 0].abs().max()) == 0.0
+    counts = torch.bincount(idx.reshape(-1).long().cpu(), minlength=E).tolist()
+    assert plan['counts'] == counts and all(o % 64 == 0 and n % 64 == 0 for _, o, n in plan['segments'])
+    pos = plan['pos'].long().cpu()
+    assert len(set(pos.reshape(-1).tolist())) == rows * k                                  # a permutation into distinct rows
+    yp = torch.randn(xp.shape[0], h, generator=g).to(dev())
+    res = torch.randn(rows, h, generator=g).to(dev())
+    out = ops.moe_combine(yp, plan['pos'], w, rows, residual=res)
+    ref = res.cpu().double() + (yp.cpu().double()[pos] * w.cpu().double()[..., None]).sum(1)
+    assert rel_err(out.cpu(), ref) < 1e-6
+    dout = torch.randn(rows, h, generator=g).to(dev())
+    dyp, dw = ops.moe_combine_bwd(dout, yp, plan['pos'], w)
+    assert rel_err(dw.cpu(), (dout.cpu().double()[:, None] * yp.cpu().double()[pos]).sum(-1)) < 1e-6
+    want = torch.zeros_like(yp.cpu().double())
+    want[pos.reshape(-1)] = (dout.cpu().double()[:, None] * w.cpu().double()[..., None]).reshape(rows * k, h)
+    assert rel_err(dyp.cpu(), want) < 1e-6
+
+
+def _trainer(z, dtype):
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    cfgs = {'train_cfgs': {'scale_coeff': float(z['scale_coeff']), 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant',
+                           'weight_decay': 0.0, 'compute_dtype': dtype},
+            'model_cfgs': {'pad_token_id': int(z['pad_token_id'])}}
+    wd = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    return DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_qwen3moe_cfg(), policy_state=state_dict_from_golden(z, 'w.', wd),
+                      reference_state=state_dict_from_golden(z, 'r.', wd), device='cuda:0')
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_qwen3moe_dpo_matches_reference_fixture(dtype):
+    z = load_golden('qwen3moe_tiny_dpo.npz')
+    tr = _trainer(z, dtype)
+    tight = dtype == 'fp32'
+    b = {'input_ids': T(z['input_ids']).to(dev()), 'attention_mask': T(z['attention_mask']).to(dev()),
+         'meta_info': {'response_lens': [int(x) for x in z['response_lens']]}}
+    logits = tr.policy.logits(b['input_ids'], b['attention_mask']).float().cpu()
+    valid = T(z['attention_mask']).bool()
+    e_log = rel_err(logits[valid], T(z['policy_logits'])[valid])
+    rep = [f'{dtype}: logits rel_err {e_log:.2e}']
+    assert e_log < (2e-5 if tight else 4e-2), rep
+    lp = tr.compute_log_probs(tr.model, b).cpu()
+    assert torch.equal(lp == 0, T(z['seq_log_probs']) == 0)
+    assert (lp - T(z['seq_log_probs'])).abs().max() < (1e-4 if tight else 1e-1)
+    ld = tr.loss(b)
+    rep.append(f"loss native {float(ld['loss']):.6f} reference {float(z['loss_loss']):.6f}")
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < (3e-5 if tight else 2e-2)
+    tr.model.backward(ld['loss'])
+    torch.cuda.synchronize()
+    worst, n = 0.0, 0
+    for k in z.files:
+        if not k.startswith('g.'):
+            continue
+        g = tr.policy.store.grad_view(k[2:])
+        assert g is not None, k
+        want = T(z[k])
+        got = g.float().cpu().reshape(want.shape)
+        if float(want.norm()) < 1e-6:
+            assert float(got.norm()) < 1e-4, k
+            continue
+        e = rel_err(got, want)
+        worst = max(worst, e); n += 1
+        assert e < (5e-4 if tight else 1.2e-1), (k, e)
+    rep.append(f'worst gradient rel_err {worst:.2e} over {n} tensors (router, experts, q/k norms, attention, embeddings)')
+    dump(f'parity_qwen3moe_{dtype}.txt', '\n'.join(rep) + '\n')
+    assert n >= 25
+    info = tr.train_step(b)
+    assert np.isfinite(info['train/loss'])

@@ -50,3 +50,8 @@ def tiny_qwen2audio_cfg():
     text = configs.llama_cfg(128, 256, 2, 2, 1, 320, rms_eps=1e-6, rope_theta=10000.0, max_position_embeddings=256, attention_bias=True)
     audio = configs.qwen2audio_tower_cfg(128, 2, 2, 256, num_mel_bins=64, max_source_positions=32)
     return configs.qwen2audio_cfg(text, audio, audio_token_id=300, pad_token_id=304)
+
+
+def tiny_qwen3moe_cfg():
+    from align_anything_amd import configs
+    return configs.qwen3moe_cfg(128, 64, 2, 2, 1, 320, 8, 2, head_dim=64, rope_theta=10000.0, max_position_embeddings=256)
