@@ -23,7 +23,12 @@
 // row-contiguous tile: [64 k rows][R cols] bf16; 32-B unit ^= (krow&3) | ((krow>>3)&1)<<2.
 __device__ __forceinline__ int tr_swz(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
-template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE, int ILV>
+// GRP (mixture-of-experts grouped launches, aa_gemm_grouped_bf16):
+//   1: the rows of A / C are an expert-major token buffer whose BM-row tiles each belong to one expert (grp_tile_expert);
+//      that expert's weight matrix B + e * grp_strideB is the other operand (forward NT and dX NN of the expert MLPs)
+//   2: blockIdx.y = expert; the contraction runs over that expert's row segment [grp_off[e], grp_off[e+1]) of A and B
+//      (both row-contiguous, TN) and the result goes to C + e * grp_strideC (the per-expert weight gradients)
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE, int ILV, int GRP = 0>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1)
 void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
@@ -55,6 +60,37 @@ void gemm_kernel(const GemmParams p) {
     const int tn = (wg % per_group) / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
+    const bf16_t* Ap = p.A;
+    const bf16_t* Bp = p.B;
+    void* Cp = p.C;
+    int Kp = p.K;
+    if constexpr (GRP == 1) {
+        const int e = p.grp_tile_expert[tm];
+        if (e < 0) return;                                  // tile beyond the rows in use (uniform per block)
+        Bp += (long)e * p.grp_strideB;
+    } else if constexpr (GRP == 2) {
+        const int e = blockIdx.y;
+        const int r0 = p.grp_off[e], r1 = p.grp_off[e + 1];
+        Ap += (long)r0 * p.lda;
+        Bp += (long)r0 * p.ldb;
+        Kp = r1 - r0;
+        const bool f32o = p.flags & AA_GEMM_OUT_F32;
+        Cp = f32o ? (void*)(reinterpret_cast<float*>(p.C) + (long)e * p.grp_strideC)
+                  : (void*)(reinterpret_cast<bf16_t*>(p.C) + (long)e * p.grp_strideC);
+        if (Kp == 0) {                                      // expert without tokens: its gradient tile is zero
+            if (!(p.flags & AA_GEMM_ACCUM)) {
+                for (int i = threadIdx.x; i < BM * (BN / 4); i += NW * 64) {
+                    const int m = m0 + i / (BN / 4), n = n0 + (i % (BN / 4)) * 4;
+                    if (m < p.M && n < p.N) {
+                        if (f32o) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cp) + (long)m * p.ldc + n) = f32x4{0.f, 0.f, 0.f, 0.f};
+                        else *reinterpret_cast<u16x4*>(reinterpret_cast<bf16_t*>(Cp) + (long)m * p.ldc + n) = u16x4{0, 0, 0, 0};
+                    }
+                }
+            }
+            return;
+        }
+    }
+
     // ---- per-lane DMA source pointers (advance by one K-tile per stage)
     const bf16_t* srcA[A_IT];
     const bf16_t* srcB[B_IT];
@@ -66,7 +102,7 @@ void gemm_kernel(const GemmParams p) {
             const int r = c * 8 + (lane >> 3);
             const int ks = (lane & 7) ^ ((r >> 1) & 7);
             const int gr = min(m0 + r, p.M - 1);
-            srcA[j] = p.A + (long)gr * p.lda + ks * 8;
+            srcA[j] = Ap + (long)gr * p.lda + ks * 8;
         }
         stepA = BK;
     } else {
@@ -81,7 +117,7 @@ void gemm_kernel(const GemmParams p) {
             const int unit = (s >> 1) ^ tr_swz(kr);
             int col = m0 + unit * 16 + (s & 1) * 8;
             col = min(col, p.M - 8);  // M % 8 == 0 enforced on host for transposed operands
-            srcA[j] = p.A + (long)kr * p.lda + col;
+            srcA[j] = Ap + (long)kr * p.lda + col;
         }
         stepA = (long)BK * p.lda;
     }
@@ -92,7 +128,7 @@ void gemm_kernel(const GemmParams p) {
             const int r = c * 8 + (lane >> 3);
             const int ks = (lane & 7) ^ ((r >> 1) & 7);
             const int gr = min(n0 + r, p.N - 1);
-            srcB[j] = p.B + (long)gr * p.ldb + ks * 8;
+            srcB[j] = Bp + (long)gr * p.ldb + ks * 8;
         }
         stepB = BK;
     } else {
@@ -106,7 +142,7 @@ void gemm_kernel(const GemmParams p) {
             const int unit = (s >> 1) ^ tr_swz(kr);
             int col = n0 + unit * 16 + (s & 1) * 8;
             col = min(col, p.N - 8);
-            srcB[j] = p.B + (long)kr * p.ldb + col;
+            srcB[j] = Bp + (long)kr * p.ldb + col;
         }
         stepB = (long)BK * p.ldb;
     }
@@ -186,7 +222,7 @@ void gemm_kernel(const GemmParams p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     };
 
-    const int nt = p.K / BK;
+    const int nt = Kp / BK;
     if constexpr (!PIPE) {
         // simple schedule: one barrier per K-tile, fragment reads interleaved by the compiler
         stage(0);
@@ -356,12 +392,12 @@ void gemm_kernel(const GemmParams p) {
                 for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) + bf2f(r[e]);
             }
             if (out_f32) {
-                float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+                float* c = reinterpret_cast<float*>(Cp) + (long)m * p.ldc + n;
                 f32x4 o = {v[0], v[1], v[2], v[3]};
                 if (accum) { const f32x4 old = *reinterpret_cast<const f32x4*>(c); o += old; }
                 *reinterpret_cast<f32x4*>(c) = o;
             } else {
-                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
+                bf16_t* c = reinterpret_cast<bf16_t*>(Cp) + (long)m * p.ldc + n;
                 if (accum) {
                     const u16x4 old = *reinterpret_cast<const u16x4*>(c);
 #pragma unroll
@@ -466,7 +502,7 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
     if (a_t) AA_REQUIRE(M % 8 == 0, "aa_gemm_bf16: transposed A needs M %% 8 == 0 (got %d)", M);
     if (b_n) AA_REQUIRE(N % 8 == 0, "aa_gemm_bf16: N-contiguous B needs N %% 8 == 0 (got %d)", N);
     if (residual) AA_REQUIRE(ldr % 4 == 0, "aa_gemm_bf16: ldr=%ld must be a multiple of 4", ldr);
-    GemmParams p;
+    GemmParams p{};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
     p.bias = (const bf16_t*)bias; p.residual = (const bf16_t*)residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
@@ -480,6 +516,47 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
     if (a_t && b_n) return launch_layout<true, true>(p, tile, st);
     aa_set_error("aa_gemm_bf16: layout A^T with K-contiguous B is not built (unused by the hot path)");
     return AA_ERR_ARG;
+}
+
+// ---- grouped (mixture-of-experts) GEMM: the 128x256 tile, so expert segments are aligned to AA_MOE_ALIGN = 128 rows
+template <bool A_T, bool B_N, int GRP>
+static int launch_grouped(GemmParams& p, int E, hipStream_t st) {
+    constexpr int BM = 128, BN = 256, WM = 2, WN = 4;
+    p.tiles_m = aa_cdiv(p.M, BM);
+    p.tiles_n = aa_cdiv(p.N, BN);
+    constexpr int lds = 2 * (BM + BN) * BK * 2;
+    auto kern = gemm_kernel<BM, BN, WM, WN, A_T, B_N, true, 0, GRP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { aa_set_error("aa_gemm_grouped_bf16: cannot reserve %d B LDS: %s", lds, hipGetErrorString(e)); return AA_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, GRP == 2 ? E : 1), dim3(WM * WN * 64), lds, st, p);
+    AA_CHECK_LAUNCH("aa_gemm_grouped_bf16");
+    return AA_OK;
+}
+
+extern "C" int aa_gemm_grouped_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc,
+                                    int flags, int mode, const int* tile_expert, const int* seg_off, long stride, int E,
+                                    void* stream) {
+    AA_REQUIRE(mode == 1 || mode == 2, "aa_gemm_grouped_bf16: mode %d (1 = rows grouped, 2 = contraction grouped)", mode);
+    AA_REQUIRE(M > 0 && N > 0 && E > 0 && N % 8 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0,
+               "aa_gemm_grouped_bf16: bad shape M=%d N=%d E=%d", M, N, E);
+    const bool a_t = flags & AA_GEMM_A_T, b_n = flags & AA_GEMM_B_N;
+    GemmParams p{};
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.flags = flags; p.act = AA_ACT_NONE;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 1) {
+        AA_REQUIRE(tile_expert != nullptr && !a_t && K > 0 && K % BK == 0 && M % 128 == 0,
+                   "aa_gemm_grouped_bf16: mode 1 needs tile_expert, A row-major, K %% 64 == 0, M %% 128 == 0 (K=%d M=%d)", K, M);
+        p.grp_tile_expert = tile_expert; p.grp_strideB = stride;
+        return b_n ? launch_grouped<false, true, 1>(p, E, st) : launch_grouped<false, false, 1>(p, E, st);
+    }
+    AA_REQUIRE(seg_off != nullptr && a_t && b_n && M % 8 == 0, "aa_gemm_grouped_bf16: mode 2 needs seg_off and the TN layout");
+    p.grp_off = seg_off; p.grp_strideC = stride;
+    return launch_grouped<true, true, 2>(p, E, st);
 }
 
 // test hook: force a tile config (-1 = heuristic)

@@ -19,6 +19,7 @@ struct GemmF32Params {
     int M, N, K;
     long lda, ldb, ldc, ldr;
     int act, flags;
+    const int* grp_tile_expert; const int* grp_off; long grp_stride;   // grouped (mixture-of-experts) launches, see gemm.hip
 };
 
 // Stage one operand tile (128 x 16) into LDS as [k][r].  `kmajor_global` = the operand's contiguous dimension is
@@ -60,11 +61,20 @@ __device__ __forceinline__ void store_tile(float (*S)[FLD], const f32x4 (&reg)[2
     }
 }
 
-template <bool A_T, bool B_N>
+template <bool A_T, bool B_N, int GRP = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Params p) {
     __shared__ __attribute__((aligned(16))) float As[FBK][FLD];
     __shared__ __attribute__((aligned(16))) float Bs[FBK][FLD];
     const int m0 = blockIdx.y * FBM, n0 = blockIdx.x * FBN;
+    if constexpr (GRP == 1) {          // rows grouped by expert: this 128-row tile uses expert e's B
+        const int e = p.grp_tile_expert[blockIdx.y];
+        if (e < 0) return;
+        p.B += (long)e * p.grp_stride;
+    } else if constexpr (GRP == 2) {   // contraction grouped: expert = blockIdx.z, rows [off[e], off[e+1]) of A and B
+        const int e = blockIdx.z, r0 = p.grp_off[e];
+        p.A += (long)r0 * p.lda; p.B += (long)r0 * p.ldb; p.C += (long)e * p.grp_stride;
+        p.K = p.grp_off[e + 1] - r0;
+    }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
     f32x16_t acc[2][2];
@@ -75,8 +85,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Params p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     f32x4 ra[2], rb[2];
-    load_tile<A_T>(p.A, p.lda, m0, p.M, 0, ra);
-    load_tile<B_N>(p.B, p.ldb, n0, p.N, 0, rb);
+    if (p.K > 0) {                    // (a grouped launch may hand an expert an empty contraction range)
+        load_tile<A_T>(p.A, p.lda, m0, p.M, 0, ra);
+        load_tile<B_N>(p.B, p.ldb, n0, p.N, 0, rb);
+    }
     const int l31 = lane & 31, kh = lane >> 5;
     for (int k0 = 0; k0 < p.K; k0 += FBK) {
         __syncthreads();              // previous tile's fragment reads are done
@@ -125,6 +137,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Params p) {
 
 }  // namespace
 
+extern "C" int aa_gemm_grouped_f32(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc,
+                                   int flags, int mode, const int* tile_expert, const int* seg_off, long stride, int E,
+                                   void* stream) {
+    AA_REQUIRE(mode == 1 || mode == 2, "aa_gemm_grouped_f32: mode %d (1 = rows grouped, 2 = contraction grouped)", mode);
+    AA_REQUIRE(M > 0 && N > 0 && E > 0 && (lda & 3) == 0 && (ldb & 3) == 0, "aa_gemm_grouped_f32: bad shape M=%d N=%d E=%d", M, N, E);
+    const bool a_t = flags & AA_GEMM_A_T, b_n = flags & AA_GEMM_B_N;
+    GemmF32Params p{(const float*)A, (const float*)B, (float*)C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, AA_ACT_NONE, flags,
+                    tile_expert, seg_off, stride};
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 1) {
+        AA_REQUIRE(tile_expert != nullptr && !a_t && K % FBK == 0 && M % FBM == 0, "aa_gemm_grouped_f32: mode 1 needs tile_expert, A row-major, M %% 128 == 0");
+        const dim3 grid(aa_cdiv(N, FBN), M / FBM);
+        if (b_n) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<false, false, 1>), grid, dim3(256), 0, st, p);
+    } else {
+        AA_REQUIRE(seg_off != nullptr && a_t && b_n, "aa_gemm_grouped_f32: mode 2 needs seg_off and the TN layout");
+        hipLaunchKernelGGL((gemm_f32_kernel<true, true, 2>), dim3(aa_cdiv(N, FBN), aa_cdiv(M, FBM), E), dim3(256), 0, st, p);
+    }
+    AA_CHECK_LAUNCH("aa_gemm_grouped_f32");
+    return AA_OK;
+}
+
 extern "C" int aa_gemm_f32(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,
                            long ldc, const void* bias, const void* residual, long ldr, int act, int flags,
                            void* stream) {
@@ -132,7 +166,7 @@ extern "C" int aa_gemm_f32(const void* A, const void* B, void* C, int M, int N, 
     AA_REQUIRE((lda & 3) == 0 && (ldb & 3) == 0, "aa_gemm_f32: lda=%ld / ldb=%ld must be multiples of 4", lda, ldb);
     if (M == 0 || N == 0) return AA_OK;
     GemmF32Params p{(const float*)A, (const float*)B, (float*)C, (const float*)bias, (const float*)residual,
-                    M, N, K, lda, ldb, ldc, ldr, act, flags};
+                    M, N, K, lda, ldb, ldc, ldr, act, flags, nullptr, nullptr, 0};
     const dim3 grid(aa_cdiv(N, FBN), aa_cdiv(M, FBM));
     hipStream_t st = (hipStream_t)stream;
     const bool a_t = flags & AA_GEMM_A_T, b_n = flags & AA_GEMM_B_N;

@@ -206,4 +206,78 @@ extern "C" int AA_FN(aa_moe_combine_bwd)(const void* dout, const void* yp, const
     return AA_OK;
 }
 
+#ifndef AA_ELEM_F32   // integer work: one instantiation
+// Expert-major layout of the (token, slot) pairs, entirely on the device (no host read):
+//   counts[e]; off[e+1] = off[e] + align_up(counts[e], align) (align = 128 = the row tile of the grouped GEMM);
+//   pos[pair] = off[e] + rank of the pair among expert e's pairs in (token, slot) order (stable);
+//   src[row] = token of the pair stored at that row, -1 for pad rows / rows beyond off[E];
+//   tile_expert[t] = expert owning rows [t*align, (t+1)*align), -1 beyond off[E].
+// One workgroup per expert scans all pairs with ballots (E x rows*k reads; E <= 1024), then writes its rows.
+__global__ __launch_bounds__(256) void moe_plan_kernel(const int* __restrict__ idx, long npairs, int k, int E, int align, long cap_rows,
+                                                       int* __restrict__ counts, int* __restrict__ off, int* __restrict__ pos,
+                                                       int* __restrict__ src, int* __restrict__ tile_expert) {
+    __shared__ int wsum[4];
+    __shared__ int base;
+    __shared__ int my_off, my_cnt;
+    const int e = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // every block recomputes all counts (E small) to know its own offset: deterministic, no inter-block sync
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    int mine = 0, before = 0;      // rows of experts < e (aligned), and this expert's count
+    for (int ee = 0; ee <= e; ++ee) {
+        int c = 0;
+        for (long i = threadIdx.x; i < npairs; i += 256) c += (idx[i] == ee) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        __syncthreads();
+        if (lane == 0) wsum[wid] = c;
+        __syncthreads();
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (ee < e) before += (tot + align - 1) / align * align; else mine = tot;
+    }
+    if (threadIdx.x == 0) { my_off = before; my_cnt = mine; counts[e] = mine; off[e] = before; }
+    __syncthreads();
+    const int o0 = my_off;
+    const int seg = (my_cnt + align - 1) / align * align;
+    if (e == E - 1 && threadIdx.x == 0) off[E] = o0 + seg;
+    // stable ranks: scan the pairs in order, 256 at a time
+    for (long b0 = 0; b0 < npairs; b0 += 256) {
+        const long i = b0 + threadIdx.x;
+        const int f = (i < npairs && idx[i] == e) ? 1 : 0;
+        const unsigned long long bal = __ballot(f);
+        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) wsum[wid] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int b = base;
+        if (f) {
+            const int r = o0 + b + woff + prefix;
+            pos[i] = r;
+            src[r] = (int)(i / k);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base = b + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    for (int r = my_cnt + threadIdx.x; r < seg; r += 256) src[o0 + r] = -1;           // pad rows of the segment
+    for (int t = threadIdx.x; t < seg / align; t += 256) tile_expert[o0 / align + t] = e;
+    if (e == E - 1) {                                                                   // everything beyond the last segment
+        for (long r = o0 + seg + threadIdx.x; r < cap_rows; r += 256) src[r] = -1;
+        for (long t = (o0 + seg) / align + threadIdx.x; t < cap_rows / align; t += 256) tile_expert[t] = -1;
+    }
+}
+extern "C" int aa_moe_plan(const int* idx, long rows, int k, int E, int align, long cap_rows, int* counts, int* off, int* pos, int* src,
+                           int* tile_expert, void* stream) {
+    AA_REQUIRE(rows >= 0 && k > 0 && E > 0 && align > 0 && cap_rows % align == 0 && cap_rows >= rows * k + (long)E * (align - 1) / align * align,
+               "aa_moe_plan: cap_rows=%ld too small / unaligned for rows=%ld k=%d E=%d align=%d", cap_rows, rows, k, E, align);
+    hipLaunchKernelGGL(moe_plan_kernel, dim3(E), dim3(256), 0, (hipStream_t)stream, idx, rows * k, k, E, align, cap_rows, counts, off, pos, src,
+                       tile_expert);
+    AA_CHECK_LAUNCH("aa_moe_plan");
+    return AA_OK;
+}
+#endif
+
 }  // namespace AA_ELEM_NS

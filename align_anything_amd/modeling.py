@@ -1111,37 +1111,11 @@ class NativeQwen2Audio(NativeCausalLM):
 
 
 # ====================================================================== Qwen3-MoE
-def moe_plan(idx: torch.Tensor, E: int):
-    """Expert-major layout of the (token, slot) pairs of a routing decision idx int32 [rows, k]: every expert owns a segment of
-    rows64(count) rows (zero padded, so a segment can be the contraction dim of its weight-gradient GEMM), tokens in token
-    order inside a segment.  Index plumbing on the device; ONE host read (the per-expert counts size the GEMM launches -- a
-    device-side grouped GEMM is the next step)."""
-    rows, k = idx.shape
-    dev = idx.device
-    flat = idx.reshape(-1).to(torch.int64)
-    counts = torch.bincount(flat, minlength=E)
-    cl = [int(c) for c in counts.tolist()]
-    seg = [(_pad64(c)) for c in cl]
-    off = [0]
-    for c in seg:
-        off.append(off[-1] + c)
-    off_dev = torch.tensor(off[:-1], dtype=torch.int64, device=dev)
-    order = torch.argsort(flat, stable=True)
-    sorted_e = flat[order]
-    starts = torch.cumsum(counts, 0) - counts
-    dest = off_dev[sorted_e] + (torch.arange(rows * k, device=dev) - starts[sorted_e])
-    pos = torch.empty(rows * k, dtype=torch.int32, device=dev)
-    pos[order] = dest.to(torch.int32)
-    src = torch.full((max(off[-1], 64),), -1, dtype=torch.int32, device=dev)
-    src[dest] = (order // k).to(torch.int32)
-    return {'pos': pos.view(rows, k), 'src': src, 'segments': [(e, off[e], seg[e]) for e in range(E) if cl[e] > 0],
-            'empty': [e for e in range(E) if cl[e] == 0], 'counts': cl}
-
-
 class Qwen3MoeStack:
     """hf:models/qwen3_moe/modeling_qwen3_moe.py:305-350 x num_layers: attention with per-head RMSNorm on q and k (:143-166),
-    sparse MoE block (:210-283).  Routing, token movement and combine are HIP kernels (csrc/moe.hip); the experts run through
-    the ordinary GEMM on 64-row-aligned segments of the expert-major buffer."""
+    sparse MoE block (:210-283).  Routing, the expert-major layout (`aa_moe_plan`), token movement and combine are HIP kernels
+    (csrc/moe.hip); all experts of a layer run in ONE grouped-GEMM launch per matrix (`aa_gemm_grouped_*`: the kernel reads the
+    128-row-tile -> expert table and the segment offsets from device memory), so a layer needs no host read at all."""
 
     def __init__(self, cfg: dict, store: ParamStore, prefix: str, trainable: bool):
         self.cfg, self.store, self.prefix, self.trainable = cfg, store, prefix, trainable
@@ -1195,15 +1169,12 @@ class Qwen3MoeStack:
             n2, rstd2 = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
             logits = L['gate'].fwd(n2)
             probs, idx, w = ops.moe_route(logits, k, c['norm_topk_prob'])
-            plan = moe_plan(idx, E)
-            xp = ops.moe_gather(n2, plan['src'])
-            gu = torch.zeros((xp.shape[0], P[L['gu']].shape[1]), dtype=x.dtype, device=x.device)
-            for e, o, n in plan['segments']:
-                ops.gemm(xp[o:o + n], P[L['gu']][e], out=gu[o:o + n])
+            plan = ops.moe_plan(idx, E)
+            xp = ops.moe_gather(n2, plan['src'])                           # [cap, h], zero pad rows
+            zeros = lambda n: torch.zeros((plan['cap'], n), dtype=x.dtype, device=x.device)
+            gu = ops.gemm_grouped(xp, P[L['gu']], plan, out=zeros(P[L['gu']].shape[1]))
             act = ops.swiglu_fwd(gu)
-            yp = torch.zeros((xp.shape[0], c['hidden_size']), dtype=x.dtype, device=x.device)
-            for e, o, n in plan['segments']:
-                ops.gemm(act[o:o + n], P[L['down']][e], out=yp[o:o + n])
+            yp = ops.gemm_grouped(act, P[L['down']], plan, out=zeros(c['hidden_size']))
             x_out = ops.moe_combine(yp, plan['pos'], w, Mp, residual=x_mid)
             if save:
                 self.saved.append((x, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp))
@@ -1221,22 +1192,13 @@ class Qwen3MoeStack:
             sv = None
             # ---- sparse MoE block
             dyp, dw = ops.moe_combine_bwd(dres, yp, plan['pos'], w)
-            dact = torch.zeros_like(act)
-            for e, o, n in plan['segments']:
-                ops.gemm(dyp[o:o + n], P[L['down']][e], out=dact[o:o + n], b_n=True)
-                if tr:
-                    g = G[L['down']][e]
-                    ops.gemm(dyp[o:o + n], act[o:o + n], out=g, a_t=True, b_n=True, accumulate=acc(g))
+            dact = ops.gemm_grouped(dyp, P[L['down']], plan, out=torch.zeros_like(act), b_n=True)
+            if tr:      # experts that saw no token get an all-zero gradient from the kernel (never a stale one)
+                ops.gemm_grouped_dw(dyp, act, plan, G[L['down']], accumulate=acc(G[L['down']]))
             dgu = ops.swiglu_bwd(gu, dact)
-            dxp = torch.zeros_like(xp)
-            for e, o, n in plan['segments']:
-                ops.gemm(dgu[o:o + n], P[L['gu']][e], out=dxp[o:o + n], b_n=True)
-                if tr:
-                    g = G[L['gu']][e]
-                    ops.gemm(dgu[o:o + n], xp[o:o + n], out=g, a_t=True, b_n=True, accumulate=acc(g))
-            if tr and not st.accumulate:
-                for e in plan['empty']:                # experts that saw no token this step: their gradient is zero, not stale
-                    G[L['gu']][e].zero_(); G[L['down']][e].zero_()
+            dxp = ops.gemm_grouped(dgu, P[L['gu']], plan, out=torch.zeros_like(xp), b_n=True)
+            if tr:
+                ops.gemm_grouped_dw(dgu, xp, plan, G[L['gu']], accumulate=acc(G[L['gu']]))
             d_n2 = ops.moe_combine(dxp, plan['pos'], None, Mp)
             dlogits = ops.moe_route_bwd(probs, idx, dw, c['norm_topk_prob'], x.dtype)
             if E % 64:   # the expert count is the contraction dim here: zero-pad it for small (test-size) routers

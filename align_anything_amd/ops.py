@@ -363,6 +363,50 @@ def moe_route_bwd(probs, idx, dw, norm_topk, dtype):
     return dlogits
 
 
+MOE_ALIGN = 128   # row tile of the grouped GEMM = alignment of the expert segments
+
+
+def moe_plan(idx, E):
+    """Device-side expert-major layout (no host read).  Returns dict(pos [rows,k], src [cap], tile_expert, off [E+1], counts [E], cap)."""
+    rows, k = idx.shape
+    dev = idx.device
+    cap = (rows * k + E * (MOE_ALIGN - 1) + MOE_ALIGN - 1) // MOE_ALIGN * MOE_ALIGN
+    i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+    plan = {'pos': i32(rows * k).view(rows, k), 'src': i32(cap), 'tile_expert': i32(cap // MOE_ALIGN), 'off': i32(E + 1), 'counts': i32(E),
+            'cap': cap, 'E': E}
+    call('aa_moe_plan', idx.data_ptr(), rows, k, E, MOE_ALIGN, cap, plan['counts'].data_ptr(), plan['off'].data_ptr(), plan['pos'].data_ptr(),
+         plan['src'].data_ptr(), plan['tile_expert'].data_ptr(), stream())
+    return plan
+
+
+def gemm_grouped(a, w3, plan, out=None, b_n=False):
+    """Rows grouped by expert: out[cap, N] = a[cap, K] @ op(w3[e]) for every 128-row tile's expert e (w3 = [E, N, K], or [E, K, N] with b_n)."""
+    sfx = _sfx(a, 'gemm_grouped')
+    cap, K = a.shape
+    E = w3.shape[0]
+    N = w3.shape[2] if b_n else w3.shape[1]
+    if (w3.shape[1] if b_n else w3.shape[2]) != K or w3.dtype != a.dtype or not w3.is_contiguous():
+        raise RuntimeError(f'gemm_grouped: weight {tuple(w3.shape)} does not match activations {tuple(a.shape)}')
+    out = torch.empty((cap, N), dtype=a.dtype, device=a.device) if out is None else out
+    call('aa_gemm_grouped' + (sfx or '_bf16'), a.data_ptr(), w3.data_ptr(), out.data_ptr(), cap, N, K, a.stride(0), w3.stride(1), out.stride(0),
+         GEMM_B_N if b_n else 0, 1, plan['tile_expert'].data_ptr(), None, w3.stride(0), E, stream())
+    return out
+
+
+def gemm_grouped_dw(dy, x, plan, out3, accumulate=False):
+    """Per-expert weight gradients in one launch: out3[e] (+)= dy[seg_e]^T @ x[seg_e]   (out3 = [E, N_out, K_in])."""
+    sfx = _sfx(dy, 'gemm_grouped_dw')
+    E, M, N = out3.shape
+    if dy.shape[1] != M or x.shape[1] != N or not out3.is_contiguous():
+        raise RuntimeError('gemm_grouped_dw: shape mismatch')
+    if sfx and out3.dtype != f32:
+        raise RuntimeError('gemm_grouped_dw: fp32 operands need fp32 gradients')
+    flags = GEMM_A_T | GEMM_B_N | (GEMM_OUT_F32 if out3.dtype == f32 and not sfx else 0) | (GEMM_ACCUM if accumulate else 0)
+    call('aa_gemm_grouped' + (sfx or '_bf16'), dy.data_ptr(), x.data_ptr(), out3.data_ptr(), M, N, 0, dy.stride(0), x.stride(0), out3.stride(1),
+         flags, 2, None, plan['off'].data_ptr(), out3.stride(0), E, stream())
+    return out3
+
+
 def moe_gather(x, src_row):
     rows_out, h = src_row.numel(), x.shape[1]
     out = torch.empty((rows_out, h), dtype=x.dtype, device=x.device)

@@ -97,6 +97,10 @@ int aa_moe_combine_f32(const void* yp, const int* pos, const void* weights, cons
 int aa_moe_combine_bwd_f32(const void* dout, const void* yp, const int* pos, const void* weights, void* dyp, float* dweights,
                            long rows, int k, int h, void* stream);
 
+/* fp32 twin of aa_gemm_grouped_bf16 */
+int aa_gemm_grouped_f32(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int flags,
+                        int mode, const int* tile_expert, const int* seg_off, long stride, int E, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

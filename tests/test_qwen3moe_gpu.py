@@ -14,7 +14,6 @@ T = torch.from_numpy
 
 def test_moe_kernels_vs_torch():
     from align_anything_amd import ops
-    from align_anything_amd.modeling import moe_plan
     g = torch.Generator().manual_seed(2)
     rows, E, k, h = 100, 16, 4, 64
     logits = (torch.randn(rows, E, generator=g) * 2).to(dev())
@@ -34,15 +33,53 @@ def test_moe_kernels_vs_torch():
         (ww * dw.double()).sum().backward()
         got = ops.moe_route_bwd(probs, idx, dw, norm, torch.float32)
         assert rel_err(got.cpu(), lg.grad.cpu()) < 1e-5
-    plan = moe_plan(idx, E)
+    # device-side plan (no host read) vs the same layout computed with torch: integer work, exact
+    plan = ops.moe_plan(idx, E)
+    A = ops.MOE_ALIGN
+    flat = idx.reshape(-1).long().cpu()
+    counts = torch.bincount(flat, minlength=E)
+    seg = (counts + A - 1) // A * A
+    off = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(seg, 0)])
+    assert plan['counts'].cpu().tolist() == counts.tolist() and plan['off'].cpu().tolist() == off.tolist()
+    order = torch.argsort(flat, stable=True)
+    starts = torch.cumsum(counts, 0) - counts
+    dest = off[flat[order]] + (torch.arange(rows * k) - starts[flat[order]])
+    want_pos = torch.empty(rows * k, dtype=torch.long); want_pos[order] = dest
+    assert torch.equal(plan['pos'].long().cpu().reshape(-1), want_pos)
+    want_src = torch.full((plan['cap'],), -1, dtype=torch.long); want_src[dest] = order // k
+    assert torch.equal(plan['src'].long().cpu(), want_src)
+    te = torch.full((plan['cap'] // A,), -1, dtype=torch.long)
+    for e in range(E):
+        te[off[e] // A: off[e + 1] // A] = e
+    assert torch.equal(plan['tile_expert'].long().cpu(), te)
     x = torch.randn(rows, h, generator=g).to(dev())
     xp = ops.moe_gather(x, plan['src'])
     src = plan['src'].cpu()
     assert torch.equal(xp.cpu()[src >= 0], x.cpu()[src[src >= 0].long()]) and float(xp.cpu()[src < 0].abs().max()) == 0.0
-    counts = torch.bincount(idx.reshape(-1).long().cpu(), minlength=E).tolist()
-    assert plan['counts'] == counts and all(o % 64 == 0 and n % 64 == 0 for _, o, n in plan['segments'])
     pos = plan['pos'].long().cpu()
-    assert len(set(pos.reshape(-1).tolist())) == rows * k                                  # a permutation into distinct rows
+    # grouped GEMMs (all experts in one launch) vs a per-expert loop in torch
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2)):
+        F_ = 128
+        w3 = (torch.randn(E, F_, h, generator=g) * 0.2).to(dt).to(dev())
+        xq = xp.to(dt)
+        out = ops.gemm_grouped(xq, w3, plan, out=torch.zeros((plan['cap'], F_), dtype=dt, device=dev()))
+        ref = torch.zeros(plan['cap'], F_, dtype=torch.float64)
+        for e in range(E):
+            ref[off[e]:off[e + 1]] = xq[off[e]:off[e + 1]].double().cpu() @ w3[e].double().cpu().t()
+        assert rel_err(out.cpu()[: off[E]], ref[: off[E]]) < tol
+        dy = (torch.randn(plan['cap'], F_, generator=g) * (src >= 0)[:, None]).to(dt).to(dev())
+        dx = ops.gemm_grouped(dy, w3, plan, out=torch.zeros((plan['cap'], h), dtype=dt, device=dev()), b_n=True)
+        refx = torch.zeros(plan['cap'], h, dtype=torch.float64)
+        for e in range(E):
+            refx[off[e]:off[e + 1]] = dy[off[e]:off[e + 1]].double().cpu() @ w3[e].double().cpu()
+        assert rel_err(dx.cpu()[: off[E]], refx[: off[E]]) < tol
+        gw = torch.full((E, F_, h), 7.0, dtype=dt, device=dev())                    # stale values must be overwritten, also for empty experts
+        ops.gemm_grouped_dw(dy, xq, plan, gw)
+        refw = torch.stack([dy[off[e]:off[e + 1]].double().cpu().t() @ xq[off[e]:off[e + 1]].double().cpu() for e in range(E)])
+        assert rel_err(gw.cpu(), refw) < tol
+        for e in range(E):
+            if counts[e] == 0:
+                assert float(gw[e].float().abs().max()) == 0.0
     yp = torch.randn(xp.shape[0], h, generator=g).to(dev())
     res = torch.randn(rows, h, generator=g).to(dev())
     out = ops.moe_combine(yp, plan['pos'], w, rows, residual=res)
