@@ -212,33 +212,33 @@ extern "C" int AA_FN(aa_moe_combine_bwd)(const void* dout, const void* yp, const
 //   pos[pair] = off[e] + rank of the pair among expert e's pairs in (token, slot) order (stable);
 //   src[row] = token of the pair stored at that row, -1 for pad rows / rows beyond off[E];
 //   tile_expert[t] = expert owning rows [t*align, (t+1)*align), -1 beyond off[E].
-// One workgroup per expert scans all pairs with ballots (E x rows*k reads; E <= 1024), then writes its rows.
+// One workgroup per expert counts, then scans all pairs with ballots (E x rows*k reads; E <= 1024) and writes its rows.
+__global__ __launch_bounds__(256) void moe_count_kernel(const int* __restrict__ idx, long npairs, int* __restrict__ counts) {
+    __shared__ int wsum[4];
+    const int e = blockIdx.x;
+    int c = 0;
+    for (long i = threadIdx.x; i < npairs; i += 256) c += (idx[i] == e) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[e] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
 __global__ __launch_bounds__(256) void moe_plan_kernel(const int* __restrict__ idx, long npairs, int k, int E, int align, long cap_rows,
-                                                       int* __restrict__ counts, int* __restrict__ off, int* __restrict__ pos,
+                                                       const int* __restrict__ counts, int* __restrict__ off, int* __restrict__ pos,
                                                        int* __restrict__ src, int* __restrict__ tile_expert) {
     __shared__ int wsum[4];
     __shared__ int base;
-    __shared__ int my_off, my_cnt;
+    __shared__ int my_off;
     const int e = blockIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // every block recomputes all counts (E small) to know its own offset: deterministic, no inter-block sync
-    if (threadIdx.x == 0) base = 0;
-    __syncthreads();
-    int mine = 0, before = 0;      // rows of experts < e (aligned), and this expert's count
-    for (int ee = 0; ee <= e; ++ee) {
-        int c = 0;
-        for (long i = threadIdx.x; i < npairs; i += 256) c += (idx[i] == ee) ? 1 : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        __syncthreads();
-        if (lane == 0) wsum[wid] = c;
-        __syncthreads();
-        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (ee < e) before += (tot + align - 1) / align * align; else mine = tot;
+    if (threadIdx.x == 0) {
+        int before = 0;
+        for (int ee = 0; ee < e; ++ee) before += (counts[ee] + align - 1) / align * align;
+        my_off = before; base = 0; off[e] = before;
     }
-    if (threadIdx.x == 0) { my_off = before; my_cnt = mine; counts[e] = mine; off[e] = before; }
     __syncthreads();
-    const int o0 = my_off;
+    const int o0 = my_off, my_cnt = counts[e];
     const int seg = (my_cnt + align - 1) / align * align;
     if (e == E - 1 && threadIdx.x == 0) off[E] = o0 + seg;
     // stable ranks: scan the pairs in order, 256 at a time
@@ -273,6 +273,7 @@ extern "C" int aa_moe_plan(const int* idx, long rows, int k, int E, int align, l
                            int* tile_expert, void* stream) {
     AA_REQUIRE(rows >= 0 && k > 0 && E > 0 && align > 0 && cap_rows % align == 0 && cap_rows >= rows * k + (long)E * (align - 1) / align * align,
                "aa_moe_plan: cap_rows=%ld too small / unaligned for rows=%ld k=%d E=%d align=%d", cap_rows, rows, k, E, align);
+    hipLaunchKernelGGL(moe_count_kernel, dim3(E), dim3(256), 0, (hipStream_t)stream, idx, rows * k, counts);
     hipLaunchKernelGGL(moe_plan_kernel, dim3(E), dim3(256), 0, (hipStream_t)stream, idx, rows * k, k, E, align, cap_rows, counts, off, pos, src,
                        tile_expert);
     AA_CHECK_LAUNCH("aa_moe_plan");
