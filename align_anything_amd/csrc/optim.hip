@@ -140,6 +140,44 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
     }
 }
 
+// "Thin" variant for running UNDER the GEMMs of the next step (NativeEngine.step launches the optimizer on a side stream while the
+// main stream already runs the reference forward): the 256x256 GEMM tile holds 2 waves x 248 VGPRs per SIMD lane, which leaves
+// 16 of the 512 -- a wave that needs at most 16 VGPRs (and no LDS) can be co-resident with them, so this HBM-bound update
+// overlaps the MFMA-bound GEMMs instead of waiting for a CU to drain.  Two elements per lane, everything else in SGPRs.
+template <typename TG>
+__global__ __launch_bounds__(256)
+void adamw_thin_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v, bf16_t* __restrict__ p16,
+                       const TG* __restrict__ g, uint32_t n, float lr, float b1, float b2, float eps, float wd, float inv_bc1,
+                       float inv_bc2, float gscale, const float* __restrict__ clip_coef) {
+    // buffer addressing: the five base addresses live in SGPR descriptors, each access costs ONE VGPR byte offset
+    // (the host chunks the flat buffer so offsets fit 32 bits); one element per lane.
+    const float gs = gscale * (clip_coef ? *clip_coef : 1.f);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(master, 0, n * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(m, 0, n * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(v, 0, n * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<TG*>(g), 0, n * (uint32_t)sizeof(TG), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r16 = __builtin_amdgcn_make_buffer_rsrc(p16 ? p16 : (bf16_t*)master, 0, p16 ? n * 2u : 0u, 0x00020000);
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
+        const uint32_t o4 = i * 4u;
+        float gg;
+        if constexpr (sizeof(TG) == 2) gg = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rg, i * 2u, 0, 0)) * gs;
+        else gg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, o4, 0, 0)) * gs;
+        const float mm = b1 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, o4, 0, 0)) + (1.f - b1) * gg;
+        const float vv = b2 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, o4, 0, 0)) + (1.f - b2) * gg * gg;
+        float pw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, o4, 0, 0));
+        // hardware sqrt / rcp (1 ulp): keeps the live range under 16 VGPRs; the update is far below bf16 resolution either way
+        pw -= lr * ((mm * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv * inv_bc2) + eps) + wd * pw);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, mm), rm, o4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), rv, o4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, pw), rp, o4, 0, 0);
+        if (p16) __builtin_amdgcn_raw_buffer_store_b16(f2bf(pw), r16, i * 2u, 0, 0);
+    }
+}
+
+static int g_adam_thin = 0;
+extern "C" int aa_adamw_set_thin(int on) { g_adam_thin = on ? 1 : 0; return AA_OK; }
+
 extern "C" int aa_adamw_flat(float* master, float* m, float* v, void* p16, const void* g, int g_dtype,
                              long n, float lr, float beta1, float beta2, float eps, float weight_decay,
                              int step, float gscale, const float* clip_coef, void* stream) {
@@ -151,6 +189,22 @@ extern "C" int aa_adamw_flat(float* master, float* m, float* v, void* p16, const
     const long work = n / 4 / 256 + 1;
     const int grid = (int)(work < 4096 ? work : 4096);
     hipStream_t st = (hipStream_t)stream;
+    if (g_adam_thin) {
+        const long CH = 1L << 28;          // elements per launch: 32-bit offsets inside the kernel
+        for (long o = 0; o < n; o += CH) {
+            const uint32_t cn = (uint32_t)((n - o) < CH ? (n - o) : CH);
+            const int tg = (int)((cn + 255u) / 256u < 16384u ? (cn + 255u) / 256u : 16384u);
+            bf16_t* p16o = p16 ? (bf16_t*)p16 + o : nullptr;
+            if (g_dtype == 0)
+                hipLaunchKernelGGL(adamw_thin_kernel<bf16_t>, dim3(tg), dim3(256), 0, st, master + o, m + o, v + o, p16o, (const bf16_t*)g + o, cn,
+                                   lr, beta1, beta2, eps, weight_decay, 1.f / bc1, 1.f / bc2, gscale, clip_coef);
+            else
+                hipLaunchKernelGGL(adamw_thin_kernel<float>, dim3(tg), dim3(256), 0, st, master + o, m + o, v + o, p16o, (const float*)g + o, cn,
+                                   lr, beta1, beta2, eps, weight_decay, 1.f / bc1, 1.f / bc2, gscale, clip_coef);
+        }
+        AA_CHECK_LAUNCH("aa_adamw_flat");
+        return AA_OK;
+    }
     if (g_dtype == 0)
         hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, master, m, v,
                            (bf16_t*)p16, (const bf16_t*)g, n, lr, beta1, beta2, eps, weight_decay, bc1,

@@ -88,6 +88,9 @@ class NativeEngine:
         self.gas = max(1, int(gradient_accumulation_steps))
         self.micro_steps = 0
         self.async_optimizer = True
+        # optional <= 16-VGPR AdamW kernel that can share CUs with the next step's GEMMs (2 x 248 of the 512 VGPRs per lane are
+        # theirs).  Measured: no gain over the default kernel (4.655 / 4.623 vs 4.642 / 4.644 pairs/s) -> off.
+        self.thin_optimizer = os.environ.get('AA_ADAM_THIN', '0') == '1'
         self._opt_stream = None
         self._opt_done = None
         if trainable:
@@ -214,6 +217,7 @@ class NativeEngine:
                                 self.betas[1], self.eps, wd, self.global_steps, gscale, self._coef)
 
         if self.async_optimizer and self.module.device.type == 'cuda':
+            ops.adamw_set_thin(self.thin_optimizer)
             if self._opt_stream is None:
                 self._opt_stream = torch.cuda.Stream()
             ev = torch.cuda.Event()
@@ -224,6 +228,7 @@ class NativeEngine:
                 self._opt_done = torch.cuda.Event()
                 self._opt_done.record(self._opt_stream)
         else:
+            ops.adamw_set_thin(False)
             launch()
         for pg in self.optimizer.param_groups:
             pg['lr'] = lr

@@ -75,7 +75,12 @@ def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=Fals
     flags = (GEMM_A_T if a_t else 0) | (GEMM_B_N if b_n else 0) | \
             (GEMM_OUT_F32 if out.dtype == torch.float32 else 0) | (GEMM_ACCUM if accumulate else 0)
     ldr = residual.stride(0) if residual is not None else 0
+    global _gemm_seq
     prof = GEMM_PROF
+    if prof is not None:       # sample every GEMM_PROF_STRIDE-th launch: an event pair around EVERY launch serialises kernel
+        _gemm_seq += 1         # boundaries (measured: +2 % step time); a stride coprime to the launches per step stays unbiased
+        if _gemm_seq % GEMM_PROF_STRIDE:
+            prof = None
     if prof is not None:
         e0 = event_record()
     if sfx and out.dtype != f32:
@@ -89,12 +94,28 @@ def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=Fals
 
 # HIP events on the launch stream (bench.py roofline: per-launch GEMM durations over the timed region)
 GEMM_PROF = None
+GEMM_PROF_STRIDE = 1
+_gemm_seq = 0
+
+
+EVENT_POOL: list = []   # pre-created HIP events (bench.py fills it so that creation stays out of the timed region)
+
+
+def event_pool_fill(n: int) -> None:
+    import ctypes
+    for _ in range(max(0, n - len(EVENT_POOL))):
+        ev = ctypes.c_void_p()
+        call('aa_event_create', ctypes.byref(ev))
+        EVENT_POOL.append(ev)
 
 
 def event_record():
     import ctypes
-    ev = ctypes.c_void_p()
-    call('aa_event_create', ctypes.byref(ev))
+    if EVENT_POOL:
+        ev = EVENT_POOL.pop()
+    else:
+        ev = ctypes.c_void_p()
+        call('aa_event_create', ctypes.byref(ev))
     call('aa_event_record', ev, stream())
     return ev
 
@@ -601,6 +622,11 @@ def grad_sumsq_(g, out_accum, scale=1.0, ws=None):
 
 def clip_coef(sumsq, max_norm, coef_out, norm_out=None):
     call('aa_clip_coef', sumsq.data_ptr(), float(max_norm), coef_out.data_ptr(), _p(norm_out), stream())
+
+
+def adamw_set_thin(on: bool) -> None:
+    """<= 16-VGPR update kernel that can be co-resident with the 256x256 GEMM tiles (overlapped optimizer)."""
+    call('aa_adamw_set_thin', int(bool(on)))
 
 
 def adamw_flat_(master, m, v, p16, g, lr, beta1, beta2, eps, wd, step, gscale=1.0, clip=None):

@@ -125,6 +125,7 @@ def main():
     ap.add_argument('--layers', type=int, default=32, help='LLM depth (32 = LLaVA-1.5-7B; anything else is NOT the headline config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-events', action='store_true')
+    ap.add_argument('--gemm-event-stride', type=int, default=1, help='time every k-th GEMM launch with HIP events (1 = all)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -171,8 +172,19 @@ def main():
             dist.barrier()
 
     for i in range(args.warmup):
+        if i == args.warmup - 1 and not args.no_gemm_events:
+            ops.GEMM_PROF = []                      # count the GEMM launches of one step ...
         tr.train_step(batches[i % 2])
     torch.cuda.synchronize()
+    if not args.no_gemm_events:                     # ... and create every event the timed region will record up front
+        per_step = len(ops.GEMM_PROF) if ops.GEMM_PROF else 600
+        ops.GEMM_PROF = None
+        # same-box A/B (tools/gpu_event_ab.sh): events around every launch cost ~0.4 % of the step once they are pre-created;
+        # --gemm-event-stride k samples every k-th launch instead (default 1 = every launch, no sampling bias)
+        ops.GEMM_PROF_STRIDE = args.gemm_event_stride
+        while ops.GEMM_PROF_STRIDE > 1 and per_step % ops.GEMM_PROF_STRIDE == 0:
+            ops.GEMM_PROF_STRIDE += 1
+        ops.event_pool_fill(2 * (per_step * args.steps // ops.GEMM_PROF_STRIDE + 8) + 64)
     barrier()
 
     gemm_events = None if args.no_gemm_events else []
@@ -235,7 +247,7 @@ def main():
                                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                                'traffic': traffic, 'traffic_unit': 'HBM bytes per GEMM launch (PMC, profiles/r01_gemm_traffic.json)',
                                'algorithmic_bytes_per_launch': sum(e[3] for e in gemm_events) / n,
-                               'launches': n, 'avg_launch_ms': tot_ms / n,
+                               'launches': n, 'launch_sampling': f'every {ops.GEMM_PROF_STRIDE}th GEMM launch of the timed steps', 'avg_launch_ms': tot_ms / n,
                                'avg_flops_per_launch': tot_fl / n, 'gemm_share_of_step_time': tot_ms / (dt * 1e3)}
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -231,6 +231,8 @@ int aa_move_padding_left(const int64_t* in, long ldi, int64_t* out, long ldo, in
 #define AA_SUMSQ_WS 2048
 int aa_grad_sumsq(const void* g, int g_dtype, long n, float scale, float* out_accum, float* ws, void* stream);
 int aa_clip_coef(const float* sumsq, float max_norm, float* coef_out, float* norm_out, void* stream);
+/* 1: use the <= 16-VGPR update kernel that can be co-resident with the 256x256 GEMM tiles (overlapped optimizer), 0: default */
+int aa_adamw_set_thin(int on);
 int aa_adamw_flat(float* master, float* m, float* v, void* p16, const void* g, int g_dtype, long n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   float gscale, const float* clip_coef, void* stream);

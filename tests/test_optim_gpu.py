@@ -8,9 +8,12 @@ from tests.gpu_util import assert_close, dev
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('thin', [False, True])
 @pytest.mark.parametrize('gdtype', [torch.bfloat16, torch.float32])
-def test_adamw_flat_five_steps(gdtype):
+def test_adamw_flat_five_steps(gdtype, thin):
+    """thin = the <= 16-VGPR kernel that runs co-resident with the GEMM tiles (hardware sqrt / rcp, same update)."""
     from align_anything_amd import ops
+    ops.adamw_set_thin(thin)
     n = 100003
     gen = torch.Generator().manual_seed(0)
     p0 = torch.randn(n, generator=gen)
@@ -29,5 +32,6 @@ def test_adamw_flat_five_steps(gdtype):
         assert abs(nrm.item() - tot.item()) < 1e-3 * tot.item()
         orl.adamw_step(q, g.float() * c, qm, qv, step, 1e-3, 0.9, 0.95, 1e-8, 0.05)
     torch.cuda.synchronize()
+    ops.adamw_set_thin(False)
     assert_close(master.cpu(), q, rtol=1e-5, atol=2e-6, what='master')
     assert torch.equal(p16, master.to(torch.bfloat16)), 'bf16 shadow must be RNE of the fp32 master'
