@@ -176,11 +176,23 @@ __global__ __launch_bounds__(256) void dpo_loss_kernel(const float* __restrict__
                                                        const int* __restrict__ seq_off, int B,
                                                        float beta, float* __restrict__ out,
                                                        float* __restrict__ per_sample,
-                                                       float* __restrict__ dlogp) {
+                                                       float* __restrict__ dlogp,
+                                                       const uint8_t* __restrict__ keep) {
     __shared__ float red[8];
     __shared__ float sums[2];
     float loss = 0.f, acc = 0.f, rsum = 0.f, bsum = 0.f, wsum = 0.f, msum = 0.f;
+    int kept = B;
+    if (keep) { kept = 0; for (int i = 0; i < B; ++i) kept += keep[i] ? 1 : 0; }
+    const float invk = kept > 0 ? 1.f / (float)kept : 0.f;
     for (int i = 0; i < B; ++i) {
+        if (keep && !keep[i]) {   // trainers/text_audio_to_text/dpo.py:139-140: identical chosen / rejected rows are skipped
+            if (dlogp) {
+                for (int t = seq_off[i] + threadIdx.x; t < seq_off[i + 1]; t += 256) dlogp[t] = 0.f;
+                for (int t = seq_off[i + B] + threadIdx.x; t < seq_off[i + B + 1]; t += 256) dlogp[t] = 0.f;
+            }
+            if (threadIdx.x == 0 && per_sample) per_sample[i] = per_sample[B + i] = per_sample[2 * B + i] = per_sample[3 * B + i] = 0.f;
+            continue;
+        }
         float lr[2];
         for (int h = 0; h < 2; ++h) {
             const int s = i + h * B;
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(256) void dpo_loss_kernel(const float* __restrict__
         // -logsigmoid(z) = softplus(-z), stable form
         const float li = fmaxf(-z, 0.f) + log1pf(expf(-fabsf(z)));
         const float sg = 1.f / (1.f + expf(z));  // sigmoid(-z)
-        const float gb = -beta * sg / (float)B;
+        const float gb = -beta * sg * invk;
         if (dlogp) {
             for (int t = seq_off[i] + threadIdx.x; t < seq_off[i + 1]; t += 256) dlogp[t] = gb;
             for (int t = seq_off[i + B] + threadIdx.x; t < seq_off[i + B + 1]; t += 256) dlogp[t] = -gb;
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(256) void dpo_loss_kernel(const float* __restrict__
         loss += li; acc += (br > wr) ? 1.f : 0.f; rsum += br + wr; bsum += br; wsum += wr; msum += br - wr;
     }
     if (threadIdx.x == 0) {
-        const float inv = 1.f / (float)B;
+        const float inv = invk;
         out[0] = loss * inv; out[1] = acc * inv; out[2] = rsum * inv;
         out[3] = bsum * inv; out[4] = wsum * inv; out[5] = msum * inv;
     }
@@ -216,10 +228,10 @@ __global__ __launch_bounds__(256) void dpo_loss_kernel(const float* __restrict__
 
 extern "C" int aa_dpo_loss_fwd_bwd(const float* pol_logp, const float* ref_logp, const int* seq_off,
                                    int B, float beta, float* out6, float* per_sample4B,
-                                   float* dlogp, void* stream) {
+                                   float* dlogp, const uint8_t* keep, void* stream) {
     AA_REQUIRE(B > 0, "aa_dpo_loss_fwd_bwd: B must be > 0 (got %d)", B);
     hipLaunchKernelGGL(dpo_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pol_logp, ref_logp,
-                       seq_off, B, beta, out6, per_sample4B, dlogp);
+                       seq_off, B, beta, out6, per_sample4B, dlogp, keep);
     AA_CHECK_LAUNCH("aa_dpo_loss_fwd_bwd");
     return AA_OK;
 }

@@ -497,13 +497,13 @@ def window_labels(ids, pad_id, resp_len_i32, row_off_i32, labels_out):
     return labels_out
 
 
-def dpo_loss(pol_logp, ref_logp, seq_off, B, beta, want_grad=True):
+def dpo_loss(pol_logp, ref_logp, seq_off, B, beta, want_grad=True, keep=None):
     dev = pol_logp.device
     out6 = torch.empty(6, dtype=torch.float32, device=dev)
     per = torch.empty((4, B), dtype=torch.float32, device=dev)
     dlogp = torch.zeros_like(pol_logp) if want_grad else None  # pad rows (rows..rows_pad) must be exactly 0
     call('aa_dpo_loss_fwd_bwd', pol_logp.data_ptr(), ref_logp.data_ptr(), seq_off.data_ptr(), int(B), float(beta),
-         out6.data_ptr(), per.data_ptr(), _p(dlogp), stream())
+         out6.data_ptr(), per.data_ptr(), _p(dlogp), _p(keep), stream())
     return out6, per, dlogp
 
 

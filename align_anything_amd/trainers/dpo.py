@@ -26,6 +26,7 @@ from .common import build_window, cfg_get, compute_dtype, flat_to_padded, get_al
 
 class DPOTrainer:
     uses_reference = True     # SimPO / ORPO (trainers/pref.py) never evaluate the reference model
+    skip_identical_pairs = False   # set by __init__ for the audio trainer, whose reference `loss` skips identical pairs
 
     def __init__(self, cfgs, ds_cfgs=None, *, model_cfg: dict | None = None, policy_state=None, reference_state=None,
                  train_dataloader=None, tokenizer=None, device='cuda:0', share_vision_tower=True,
@@ -41,6 +42,9 @@ class DPOTrainer:
         self.global_step = 0
         self.emulate_bf16_logp = emulate_bf16_logp
         self.share_vision_tower = share_vision_tower
+        # trainers/text_audio_to_text/dpo.py:139-140 `continue`s on identical pairs; the text and text+image trainers
+        # (text_to_text/dpo.py:160-176, text_image_to_text/dpo.py:134-153) do not
+        self.skip_identical_pairs = bool(model_cfg and model_cfg.get('kind') == 'qwen2audio')
         self.infer_batch = lambda batch: {k: v for k, v in batch.items() if k != 'meta_info'}
         self.init_check()
         self.init_models(policy_state, reference_state)
@@ -146,11 +150,16 @@ class DPOTrainer:
         ref = self._flat_log_probs(self.reference_model.module, batch, save=False)
         self.model.wait_optimizer()
         pol = self._flat_log_probs(self.model.module, batch, save=True)
-        out6, per, dlogp = ops.dpo_loss(pol, ref, w['seq_off'], B, self.scale_coeff, want_grad=True)
+        keep = None
+        if self.skip_identical_pairs:   # text_audio_to_text/dpo.py:139-140: identical pairs contribute nothing
+            am = batch.get('attention_mask')
+            _, _, _, keep = ops.pair_slice_index(batch['input_ids'], am if am is not None else torch.ones_like(batch['input_ids']), w['seq_off'], B)
+        out6, per, dlogp = ops.dpo_loss(pol, ref, w['seq_off'], B, self.scale_coeff, want_grad=True, keep=keep)
         self.model.set_pending(dlogp)
+        sel = (lambda t: t[keep.bool()]) if keep is not None else (lambda t: t)
         return {
-            'loss': out6[0], 'reward': per[2], 'better_sample_reward': per[0], 'worse_sample_reward': per[1],
-            'reward_accuracy': out6[1], 'reward_margin': per[3], '_means': out6,
+            'loss': out6[0], 'reward': sel(per[2]), 'better_sample_reward': sel(per[0]), 'worse_sample_reward': sel(per[1]),
+            'reward_accuracy': out6[1], 'reward_margin': sel(per[3]), '_means': out6,
         }
 
     def train_step(self, batch) -> dict[str, Any]:

@@ -60,9 +60,11 @@ int aa_window_labels(const int64_t* ids, int N, int T, int64_t pad_id, const int
 /* align_anything/trainers/text_to_text/dpo.py:144-203 DPOTrainer.loss (forward + d loss/d logp).
  * sequences [0,B) better, [B,2B) worse; per-token log-probs flat, sequence s = rows
  * [seq_off[s], seq_off[s+1]).  out6 = loss, reward_accuracy, mean reward, mean better, mean worse,
- * mean margin; per_sample4B = better_reward[B], worse_reward[B], reward[B], margin[B]. */
+ * mean margin; per_sample4B = better_reward[B], worse_reward[B], reward[B], margin[B].
+ * keep (uint8 [B], NULL = all): pairs with keep == 0 are skipped and every mean runs over the kept pairs -- the audio / image
+ * trainers drop pairs whose chosen and rejected rows are identical (trainers/text_audio_to_text/dpo.py:139-140). */
 int aa_dpo_loss_fwd_bwd(const float* pol_logp, const float* ref_logp, const int* seq_off, int B,
-                        float beta, float* out6, float* per_sample4B, float* dlogp, void* stream);
+                        float beta, float* out6, float* per_sample4B, float* dlogp, const uint8_t* keep, void* stream);
 /* trainers/text_to_text/rm.py:97-132 reward-model pairwise loss (+ L2 regularisation) and its gradient */
 int aa_rm_loss_fwd_bwd(const float* end_scores, int B, float regularization, float* out2, float* dscores,
                        void* stream);

@@ -142,3 +142,33 @@ def test_qwen3moe_dpo_matches_reference_fixture(dtype):
     assert n >= 25
     info = tr.train_step(b)
     assert np.isfinite(info['train/loss'])
+
+
+def test_grpo_step_on_qwen3moe_backbone():
+    """BASELINE configs[4] names GRPO on Qwen3-MoE: the native GRPOTrainer (trainers/grpo.py, pinned to the reference's own
+    train_step on OPT) runs unchanged on the MoE backbone -- loss against the oracle on the same sequences / rewards."""
+    from oracle import models as om
+    from oracle import rl_math as orl
+    from align_anything_amd.trainers.grpo import GRPOTrainer
+    z = load_golden('qwen3moe_tiny_dpo.npz')
+    cfg = tiny_qwen3moe_cfg()
+    sd, rsd = state_dict_from_golden(z, 'w.'), state_dict_from_golden(z, 'r.')
+    cfgs = {'train_cfgs': {'actor_lr': 1e-3, 'actor_weight_decay': 0.0, 'actor_lr_warmup_ratio': 0.0, 'actor_lr_scheduler_type': 'constant',
+                           'beta': 0.04, 'num_generations': 3, 'compute_dtype': 'fp32'},
+            'model_cfgs': {'pad_token_id': 1, 'eos_token_id': 2}}
+    tr = GRPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=sd, reference_state=rsd, reward_fn=lambda c: c.sum(1).float(),
+                     device='cuda:0')
+    g = torch.Generator().manual_seed(3)
+    B, G, P, L = 2, 3, 10, 12
+    prompts = torch.randint(3, 320, (B, P), generator=g)
+    seqs = torch.cat([prompts.repeat_interleave(G, 0), torch.randint(3, 320, (B * G, L), generator=g)], 1)
+    seqs[1, P + 5] = 2; seqs[1, P + 6:] = 1
+    rewards = torch.randn(B * G, generator=g)
+    info = tr.train_step({'input_ids': prompts.to(dev()), 'attention_mask': torch.ones_like(prompts).to(dev())},
+                         sequences=seqs.to(dev()), rewards=rewards.to(dev()))
+    am = (seqs != 1).long()
+    lp = orl.gather_log_probabilities(om.qwen3moe_logits(sd, cfg, seqs, am)[:, :-1][:, -L:], seqs[:, -L:])
+    rlp = orl.gather_log_probabilities(om.qwen3moe_logits(rsd, cfg, seqs, am)[:, :-1][:, -L:], seqs[:, -L:])
+    want, _, _ = orl.grpo_loss(lp, rlp, rewards, B, G, seqs[:, P:], 2, 0.04)
+    assert abs(info['train/loss'] - float(want)) < 5e-5, (info['train/loss'], float(want))
+    assert abs(info['train/reward'] - float(rewards.mean())) < 1e-6

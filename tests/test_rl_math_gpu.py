@@ -132,3 +132,26 @@ def test_window_labels_are_bit_exact_including_inner_pad_ids():
         _, want = orl.response_window(ids[n], pad, R, Tn)
         assert torch.equal(lab[off:off + R - 1], want), n
         off += R - 1
+
+
+def test_dpo_loss_keep_mask_skips_identical_pairs():
+    """trainers/text_audio_to_text/dpo.py:139-140: pairs with identical rows are dropped, means run over the kept pairs."""
+    from align_anything_amd import ops
+    g = torch.Generator().manual_seed(8)
+    lens = [5, 9, 3, 7, 9, 4]                                    # 3 pairs; windows of different lengths
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    pol, ref = -torch.rand(int(off[-1]), generator=g) * 3, -torch.rand(int(off[-1]), generator=g) * 3
+    keep = torch.tensor([1, 0, 1], dtype=torch.uint8)
+    out6, per, d = ops.dpo_loss(pol.to(dev()), ref.to(dev()), off.to(dev()), 3, 0.1, keep=keep.to(dev()))
+    seg = lambda t, s: t[int(off[s]):int(off[s + 1])].sum()
+    losses, br, wr = [], [], []
+    pa = pol.clone().requires_grad_(True)
+    for i in (0, 2):
+        blr, wlr = seg(pa, i) - seg(ref, i), seg(pa, i + 3) - seg(ref, i + 3)
+        losses.append(-torch.nn.functional.logsigmoid(0.1 * (blr - wlr))); br.append(0.1 * blr.detach()); wr.append(0.1 * wlr.detach())
+    loss = torch.stack(losses).mean()
+    loss.backward()
+    assert abs(float(out6[0]) - float(loss)) < 1e-6
+    assert_close(per[0].cpu()[keep.bool()], torch.stack(br), rtol=1e-5, atol=1e-6, what='kept better rewards')
+    assert_close(d.cpu(), pa.grad, rtol=1e-5, atol=1e-7, what='dlogp (skipped pair: zero)')
+    assert float(d.cpu()[int(off[1]):int(off[2])].abs().max()) == 0.0 and float(d.cpu()[int(off[4]):int(off[5])].abs().max()) == 0.0
