@@ -39,6 +39,81 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const elem_t* __restri
     }
 }
 
+// h <= 512 (per-head q/k norms of Qwen3: head_dim 128 over rows x heads "rows"): one WAVE per row, 4 rows per workgroup
+__global__ __launch_bounds__(256) void rmsnorm_fwd_small_kernel(const elem_t* __restrict__ x, const elem_t* __restrict__ w,
+                                                                elem_t* __restrict__ y, float* __restrict__ rstd_out, long rows,
+                                                                int h, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nv = h >> 3;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+        ev8 v;
+        float ss = 0.f;
+        if (lane < nv) {
+            v = *reinterpret_cast<const ev8*>(x + row * h + lane * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = e2f(v[j]); ss += f * f; }
+        }
+        ss = wave_sum(ss);
+        const float rstd = rsqrtf(ss / (float)h + eps);
+        if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+        if (lane < nv) {
+            const ev8 wv = *reinterpret_cast<const ev8*>(w + lane * 8);
+            ev8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2e(e2f(wv[j]) * ernd(e2f(v[j]) * rstd));
+            *reinterpret_cast<ev8*>(y + row * h + lane * 8) = o;
+        }
+    }
+}
+// backward for h <= 512: one wave per row; every lane keeps the dw partial of its 8 columns over the rows of its wave
+__global__ __launch_bounds__(256) void rmsnorm_bwd_small_kernel(const elem_t* __restrict__ dy, const elem_t* __restrict__ x,
+                                                                const elem_t* __restrict__ w, const float* __restrict__ rstd_in,
+                                                                elem_t* __restrict__ dx, float* __restrict__ dw_part, long rows, int h,
+                                                                int add_to_dx) {
+    __shared__ float part[4][512];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nv = h >> 3;
+    float dwacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    ev8 wv;
+    if (lane < nv) wv = *reinterpret_cast<const ev8*>(w + lane * 8);
+    for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
+        const float rstd = rstd_in[row];
+        ev8 xv, gv;
+        float dot = 0.f;
+        if (lane < nv) {
+            xv = *reinterpret_cast<const ev8*>(x + row * h + lane * 8);
+            gv = *reinterpret_cast<const ev8*>(dy + row * h + lane * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = e2f(xv[j]) * rstd, g = e2f(gv[j]);
+                dot += g * e2f(wv[j]) * xh;
+                dwacc[j] += g * ernd(xh);
+            }
+        }
+        dot = wave_sum(dot) / (float)h;
+        if (lane < nv) {
+            ev8 o;
+            if (add_to_dx) o = *reinterpret_cast<const ev8*>(dx + row * h + lane * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = e2f(xv[j]) * rstd;
+                float d = rstd * (e2f(gv[j]) * e2f(wv[j]) - xh * dot);
+                if (add_to_dx) d += e2f(o[j]);
+                o[j] = f2e(d);
+            }
+            *reinterpret_cast<ev8*>(dx + row * h + lane * 8) = o;
+        }
+    }
+    if (dw_part) {
+        if (lane < nv)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[wid][lane * 8 + j] = dwacc[j];
+        __syncthreads();
+        for (int c = threadIdx.x; c < h; c += 256)
+            dw_part[(long)blockIdx.x * h + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+    }
+}
+
 // dx = rstd * (dy*w - xhat * mean(dy*w*xhat)),  dw[c] += sum_rows dy*bf16(xhat)
 // dw partials are kept per thread in registers across the block's rows and flushed with fp32 atomics.
 template <int MAXV>  // max 16-byte vectors per thread (h <= 256*8*MAXV)
@@ -134,6 +209,13 @@ extern "C" int AA_FN(aa_rmsnorm_fwd)(const void* x, const void* w, void* y, floa
                               float eps, void* stream) {
     AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0, "aa_rmsnorm_fwd: hidden %d must be a multiple of 8", h);
     if (rows == 0) return AA_OK;
+    if (h <= 512) {
+        const long nb = ((long)rows + 3) / 4;
+        hipLaunchKernelGGL(rmsnorm_fwd_small_kernel, dim3((int)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream,
+                           (const elem_t*)x, (const elem_t*)w, (elem_t*)y, rstd, (long)rows, h, eps);
+        AA_CHECK_LAUNCH("aa_rmsnorm_fwd");
+        return AA_OK;
+    }
     const int grid = rows < 4096 ? rows : 4096;
     hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const elem_t*)x, (const elem_t*)w, (elem_t*)y, rstd, rows, h, eps);
@@ -152,6 +234,16 @@ extern "C" int AA_FN(aa_rmsnorm_bwd)(const void* dy, const void* x, const void* 
     if (dw && grid > ws_rows) grid = ws_rows;
     float* part = dw ? ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
+    if (h <= 512) {
+        long nb = ((long)rows + 3) / 4;
+        int g2 = (int)(nb < 2048 ? nb : 2048);
+        if (dw && g2 > ws_rows) g2 = ws_rows;
+        hipLaunchKernelGGL(rmsnorm_bwd_small_kernel, dim3(g2), dim3(256), 0, st, (const elem_t*)dy, (const elem_t*)x, (const elem_t*)w, rstd,
+                           (elem_t*)dx, part, (long)rows, h, add_to_dx);
+        if (dw) launch_reduce_rows(part, g2, h, dw, st);
+        AA_CHECK_LAUNCH("aa_rmsnorm_bwd");
+        return AA_OK;
+    }
 #define LAUNCH_RMSB(MV)                                                                             \
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const elem_t*)dy,     \
                        (const elem_t*)x, (const elem_t*)w, rstd, (elem_t*)dx, part, rows, h, add_to_dx)

@@ -8,7 +8,7 @@ from tests.gpu_util import assert_close, dev, randn_bf16
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('rows,h', [(37, 128), (300, 4096), (64, 1024), (5, 11008 - 11008 % 8)])
+@pytest.mark.parametrize('rows,h', [(37, 128), (300, 4096), (64, 1024), (5, 11008 - 11008 % 8), (1000, 128), (37, 64), (4099, 512)])
 def test_rmsnorm_fwd_bwd(rows, h):
     from align_anything_amd import ops
     x, w, dy = randn_bf16(rows, h, seed=1), randn_bf16(h, seed=2) * 0.5 + 1, randn_bf16(rows, h, seed=3)
