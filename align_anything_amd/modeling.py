@@ -643,15 +643,16 @@ def qwen2vl_rope_index(input_ids, attention_mask, grid_thw, image_token_id: int,
 
 
 class Qwen2VLVisionTower:
-    """hf:models/qwen2_vl/modeling_qwen2_vl.py:649-730 Qwen2VisionTransformerPretrainedModel, forward only (frozen):
+    """hf:models/qwen2_vl/modeling_qwen2_vl.py:649-730 Qwen2VisionTransformerPretrainedModel, forward and (train_blocks) backward:
     patch embed (Conv3d with kernel == stride = one GEMM over the processor's flattened patches), `depth` pre-LN blocks
     with 2-D rotary (fp32, :225-236) and full attention inside every (image, frame) segment, then the 2x2 PatchMerger.
     head_dim 80 (1280 / 16) has no attention kernel: q/k/v heads are produced zero-padded to 128 columns by padding the
-    ROWS of the qkv weight (and the columns of the output projection) once at load time -- the scores and the output are
-    unchanged, the softmax scale stays head_dim**-0.5."""
+    ROWS of the qkv weight (and the columns of the output projection) -- the scores and the output are unchanged, the softmax
+    scale stays head_dim**-0.5; when the blocks train, the padded copies are rebuilt every forward and the gradients of the
+    padded matrices are copied back into the HF-shaped gradient buffers."""
 
-    def __init__(self, vcfg: dict, store: ParamStore, prefix: str, train_merger: bool):
-        self.cfg, self.store, self.prefix, self.train_merger = vcfg, store, prefix, train_merger
+    def __init__(self, vcfg: dict, store: ParamStore, prefix: str, train_merger: bool, train_blocks: bool = False):
+        self.cfg, self.store, self.prefix, self.train_merger, self.train_blocks = vcfg, store, prefix, train_merger, train_blocks
         E, H = vcfg['embed_dim'], vcfg['num_heads']
         self.hd = E // H
         if self.hd > 128 or self.hd % 16:
@@ -661,16 +662,17 @@ class Qwen2VLVisionTower:
         self.Kp = _pad64(self.K)
         F = int(E * vcfg['mlp_ratio'])
         m2 = vcfg['spatial_merge_size'] ** 2
-        self.patch_w = store.add(prefix + 'patch_embed.proj.weight', (E, self.Kp), False)
+        tb = train_blocks
+        self.patch_w = store.add(prefix + 'patch_embed.proj.weight', (E, self.Kp), tb)
         self.blocks = []
         for i in range(vcfg['depth']):
             p = f'{prefix}blocks.{i}.'
-            B = {'n1w': store.add(p + 'norm1.weight', (E,), False), 'n1b': store.add(p + 'norm1.bias', (E,), False),
-                 'n2w': store.add(p + 'norm2.weight', (E,), False), 'n2b': store.add(p + 'norm2.bias', (E,), False),
-                 'qkv_w': store.add(p + 'attn.qkv.weight', (3 * E, E), False), 'qkv_b': store.add(p + 'attn.qkv.bias', (3 * E,), False),
-                 'proj_w': store.add(p + 'attn.proj.weight', (E, E), False), 'proj_b': store.add(p + 'attn.proj.bias', (E,), False),
-                 'fc1': Linear(store, store.add(p + 'mlp.fc1.weight', (F, E), False), store.add(p + 'mlp.fc1.bias', (F,), False)),
-                 'fc2': Linear(store, store.add(p + 'mlp.fc2.weight', (E, F), False), store.add(p + 'mlp.fc2.bias', (E,), False))}
+            B = {'n1w': store.add(p + 'norm1.weight', (E,), tb), 'n1b': store.add(p + 'norm1.bias', (E,), tb),
+                 'n2w': store.add(p + 'norm2.weight', (E,), tb), 'n2b': store.add(p + 'norm2.bias', (E,), tb),
+                 'qkv_w': store.add(p + 'attn.qkv.weight', (3 * E, E), tb), 'qkv_b': store.add(p + 'attn.qkv.bias', (3 * E,), tb),
+                 'proj_w': store.add(p + 'attn.proj.weight', (E, E), tb), 'proj_b': store.add(p + 'attn.proj.bias', (E,), tb),
+                 'fc1': Linear(store, store.add(p + 'mlp.fc1.weight', (F, E), tb), store.add(p + 'mlp.fc1.bias', (F,), tb)),
+                 'fc2': Linear(store, store.add(p + 'mlp.fc2.weight', (E, F), tb), store.add(p + 'mlp.fc2.bias', (E,), tb))}
             self.blocks.append(B)
         tm = train_merger
         self.lnq_w = store.add(prefix + 'merger.ln_q.weight', (E,), tm)
@@ -731,24 +733,39 @@ class Qwen2VLVisionTower:
         if pixel_values.shape[0] != n or pixel_values.shape[1] != self.K:
             raise ValueError(f'pixel_values {tuple(pixel_values.shape)} does not match image_grid_thw ({n} patches of {self.K})')
         cos, sin = cos.to(dev), sin.to(dev)
-        pix = torch.zeros((n, self.Kp), dtype=dt, device=dev)
-        pix[:, :self.K] = pixel_values.to(dt)
+        keep = save and self.train_blocks
+        npad = _pad64(n) if keep else n                     # training: rows are the contraction dim of the dW GEMMs
+        pix = torch.zeros((npad, self.Kp), dtype=dt, device=dev)
+        pix[:n, :self.K] = pixel_values.to(dt)
         x = ops.gemm(pix, P[self.patch_w])
-        rows = torch.arange(n, dtype=torch.int32, device=dev)
+        rows = torch.arange(npad, dtype=torch.int32, device=dev)
+        if npad != n:
+            cos = torch.cat([cos, torch.ones((npad - n, cos.shape[1]), device=dev)]); sin = torch.cat([sin, torch.zeros((npad - n, sin.shape[1]), device=dev)])
+        if self.train_blocks:
+            self._padded = None                             # the weights moved since the last step
         W = self._attn_weights()
+        saved = []
         for B, (qkv_w, qkv_b, proj_w) in zip(self.blocks, W):
-            y, _, _ = ops.layernorm_fwd(x, P[B['n1w']], P[B['n1b']], 1e-6, want_stats=False)
-            qkv = ops.gemm(y, qkv_w, bias=qkv_b)
+            y1, m1, r1 = ops.layernorm_fwd(x, P[B['n1w']], P[B['n1b']], 1e-6, want_stats=keep)
+            qkv = ops.gemm(y1, qkv_w, bias=qkv_b)
             ops.rope_(qkv, 0, 2 * H, hd, rows, cos, sin, head_stride=hdp, precise=True)
-            a = torch.empty((n, H * hdp), dtype=dt, device=dev)
+            a = torch.zeros((npad, H * hdp), dtype=dt, device=dev) if npad != n else torch.empty((n, H * hdp), dtype=dt, device=dev)
+            lses = []
             for o, nseq, L in segs:
                 v = slice(o, o + nseq * L)
-                ops.attn_fwd(qkv[v, :H * hdp], qkv[v, H * hdp:2 * H * hdp], qkv[v, 2 * H * hdp:], nseq, L, H, H, hdp, False, hd ** -0.5,
-                             out=a[v])
-            x = ops.gemm(a, proj_w, bias=P[B['proj_b']], residual=x)
-            y, _, _ = ops.layernorm_fwd(x, P[B['n2w']], P[B['n2b']], 1e-6, want_stats=False)
-            y = B['fc1'].fwd(y, act=ops.ACT_QUICK_GELU)
-            x = B['fc2'].fwd(y, residual=x)
+                _, lse = ops.attn_fwd(qkv[v, :H * hdp], qkv[v, H * hdp:2 * H * hdp], qkv[v, 2 * H * hdp:], nseq, L, H, H, hdp, False, hd ** -0.5,
+                                      out=a[v])
+                lses.append(lse)
+            x_mid = ops.gemm(a, proj_w, bias=P[B['proj_b']], residual=x)
+            y2, m2_, r2 = ops.layernorm_fwd(x_mid, P[B['n2w']], P[B['n2b']], 1e-6, want_stats=keep)
+            if keep:
+                f1 = B['fc1'].fwd(y2)
+                g1 = ops.act_fwd(f1, ops.ACT_QUICK_GELU)
+                saved.append((x, m1, r1, y1, qkv, a, lses, x_mid, m2_, r2, y2, f1, g1, qkv_w, proj_w))
+            else:
+                g1 = B['fc1'].fwd(y2, act=ops.ACT_QUICK_GELU)
+            x = B['fc2'].fwd(g1, residual=x_mid)
+        x = x[:n] if npad != n else x
         m2 = c['spatial_merge_size'] ** 2
         y, mean, rstd = ops.layernorm_fwd(x, P[self.lnq_w], P[self.lnq_b], 1e-6)
         nf = n // m2
@@ -758,11 +775,12 @@ class Qwen2VLVisionTower:
         a1 = ops.act_fwd(f1, ops.ACT_GELU)
         feat = self.m2.fwd(a1)
         if save:
-            self._ctx = dict(x=x, mean=mean, rstd=rstd, y4=y4, f1=f1, a1=a1, nf=nf)
+            self._ctx = dict(x=x, mean=mean, rstd=rstd, y4=y4, f1=f1, a1=a1, nf=nf, n=n, npad=npad, saved=saved, pix=pix, segs=segs,
+                             cos=cos, sin=sin, rows=rows)
         return feat, nf
 
     def backward_merger(self, dfeat):
-        """Gradients of the PatchMerger (ln_q, mlp.0, mlp.2); the blocks below it are frozen, so dx stops here."""
+        """Gradients of the PatchMerger (ln_q, mlp.0, mlp.2), then of the blocks and the patch embedding when they train."""
         cx, G, P = self._ctx, self.store.g, self.store.p
         self.m2.dw(dfeat, cx['a1'])
         d_a1 = self.m2.dx(dfeat)
@@ -771,16 +789,73 @@ class Qwen2VLVisionTower:
         d_y4 = self.m0.dx(d_f1)
         E = self.cfg['embed_dim']
         d_y = d_y4[:cx['nf']].reshape(-1, E).contiguous()
-        ops.layernorm_bwd(d_y, cx['x'], P[self.lnq_w], cx['mean'], cx['rstd'], G.get(self.lnq_w), G.get(self.lnq_b))
+        d_x = ops.layernorm_bwd(d_y, cx['x'].contiguous(), P[self.lnq_w], cx['mean'], cx['rstd'], G.get(self.lnq_w), G.get(self.lnq_b))
+        if self.train_blocks:
+            self._backward_blocks(d_x)
         self._ctx = None
+
+    def _unpad_grad(self, name, tmp, view_pad, view_real, sel):
+        """Copy the gradient of a head-padded matrix into the HF-shaped gradient buffer (add when accumulating)."""
+        g = self.store.g[name]
+        src = tmp.view(*view_pad)[sel].to(g.dtype)
+        if g.dtype == torch.float32 or self.store.accumulate:
+            g.view(*view_real).add_(src)
+        else:
+            g.view(*view_real).copy_(src)
+
+    def _backward_blocks(self, d_x):
+        cx, c, P, G, st = self._ctx, self.cfg, self.store.p, self.store.g, self.store
+        E, H, hd, hdp, n, npad = c['embed_dim'], c['num_heads'], self.hd, self.hdp, cx['n'], cx['npad']
+        dres = d_x
+        if npad != n:
+            dres = torch.zeros((npad, E), dtype=d_x.dtype, device=d_x.device); dres[:n] = d_x
+        acc = lambda g: (g.dtype == torch.float32) or st.accumulate
+        padded = hd != hdp
+        for B, sv in zip(reversed(self.blocks), reversed(cx['saved'])):
+            x, m1, r1, y1, qkv, a, lses, x_mid, m2_, r2, y2, f1, g1, qkv_w, proj_w = sv
+            d_g1 = B['fc2'].dx(dres)
+            B['fc2'].dw(dres, g1)
+            d_f1 = ops.act_bwd(f1, d_g1, ops.ACT_QUICK_GELU)
+            d_y2 = B['fc1'].dx(d_f1)
+            B['fc1'].dw(d_f1, y2)
+            ops.layernorm_bwd(d_y2, x_mid, P[B['n2w']], m2_, r2, G.get(B['n2w']), G.get(B['n2b']), dx=dres, add_to_dx=True)
+            d_a = ops.gemm(dres, proj_w, b_n=True)
+            ops.colsum_(dres, G[B['proj_b']])
+            if padded:
+                tmp = ops.gemm(dres, a, a_t=True, b_n=True)                                     # [E, H*hdp]
+                self._unpad_grad(B['proj_w'], tmp, (E, H, hdp), (E, H, hd), (slice(None), slice(None), slice(0, hd)))
+            else:
+                g = G[B['proj_w']]
+                ops.gemm(dres, a, out=g, a_t=True, b_n=True, accumulate=acc(g))
+            d_qkv = torch.zeros_like(qkv)
+            for (o, nseq, L), lse in zip(cx['segs'], lses):
+                v = slice(o, o + nseq * L)
+                ops.attn_bwd(qkv[v, :H * hdp], qkv[v, H * hdp:2 * H * hdp], qkv[v, 2 * H * hdp:], a[v], d_a[v], lse,
+                             d_qkv[v, :H * hdp], d_qkv[v, H * hdp:2 * H * hdp], d_qkv[v, 2 * H * hdp:], nseq, L, H, H, hdp, False, hd ** -0.5)
+            ops.rope_(d_qkv, 0, 2 * H, hd, cx['rows'], cx['cos'], cx['sin'], inverse=True, head_stride=hdp, precise=True)
+            d_y1 = ops.gemm(d_qkv, qkv_w, b_n=True)
+            if padded:
+                tmp = ops.gemm(d_qkv, y1, a_t=True, b_n=True)                                   # [3*H*hdp, E]
+                self._unpad_grad(B['qkv_w'], tmp, (3, H, hdp, E), (3, H, hd, E), (slice(None), slice(None), slice(0, hd)))
+                tb = torch.zeros(3 * H * hdp, dtype=torch.float32, device=dres.device)
+                ops.colsum_(d_qkv, tb)
+                G[B['qkv_b']].view(3, H, hd).add_(tb.view(3, H, hdp)[:, :, :hd])
+            else:
+                g = G[B['qkv_w']]
+                ops.gemm(d_qkv, y1, out=g, a_t=True, b_n=True, accumulate=acc(g))
+                ops.colsum_(d_qkv, G[B['qkv_b']])
+            ops.layernorm_bwd(d_y1, x, P[B['n1w']], m1, r1, G.get(B['n1w']), G.get(B['n1b']), dx=dres, add_to_dx=True)
+        g = G[self.patch_w]
+        ops.gemm(dres, cx['pix'], out=g, a_t=True, b_n=True, accumulate=acc(g))
 
 
 class NativeQwen2VL(NativeCausalLM):
     """hf:models/qwen2_vl/modeling_qwen2_vl.py:1207+ Qwen2VLForConditionalGeneration (align_anything/models/qwen2_vl.py):
     vision tower -> merged image features scattered over the image-token positions -> Qwen2 decoder (the Llama block with
-    q/k/v biases, GQA) under multimodal RoPE.  The visual blocks are frozen (forward only); the PatchMerger follows
-    `freeze_mm_proj`.  (The reference freezes by the substrings 'vision_tower' / 'multi_modal_projector',
-    models/pretrained_model.py:265-281, which match nothing in `model.visual.*`, so there the whole tower trains.)"""
+    q/k/v biases, GQA) under multimodal RoPE.  `freeze_vision_tower` (default True here) covers the patch embedding and the
+    visual blocks, the PatchMerger follows `freeze_mm_proj`.  The reference freezes by the substrings 'vision_tower' /
+    'multi_modal_projector' (models/pretrained_model.py:265-281), which match nothing in `model.visual.*`: there the whole
+    tower trains whatever the flags say -- pass freeze_vision_tower=False to reproduce that."""
 
     kind = 'qwen2vl'
 
@@ -788,14 +863,15 @@ class NativeQwen2VL(NativeCausalLM):
                  freeze_vision_tower=True, head='lm', dtype=bf16):
         super().__init__(cfg, device, trainable, dtype)
         self.head_kind = head
-        if not freeze_vision_tower and trainable:
-            raise NotImplementedError('training the Qwen2-VL visual blocks is not built (forward only); the merger trains')
         t = cfg['text']
         self.hidden_size = t['hidden_size']
         self.train_lm = trainable and not freeze_language_model
         self.train_proj = trainable and not freeze_mm_proj
+        self.train_tower = trainable and not freeze_vision_tower
+        if self.train_tower and not self.train_proj:
+            raise NotImplementedError('training the visual blocks with a frozen merger is not built')
         st = self.store
-        self.vision = Qwen2VLVisionTower(cfg['vision'], st, 'model.visual.', self.train_proj)
+        self.vision = Qwen2VLVisionTower(cfg['vision'], st, 'model.visual.', self.train_proj, self.train_tower)
         self.embed = st.add('model.language_model.embed_tokens.weight', (t['vocab_size'], t['hidden_size']), self.train_lm, f32_grad=True)
         self.stack = LlamaStack(t, st, 'model.language_model.', self.train_lm)
         if head == 'lm':

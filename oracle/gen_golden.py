@@ -299,7 +299,7 @@ def gen_qwen2vl_dpo():
     for n, p in refm.state_dict().items():
         out['r.' + n] = bf16_bits(p)
     for n, p in policy.named_parameters():
-        if p.grad is not None and not n.startswith('model.visual.blocks'):
+        if p.grad is not None:
             out['g.' + n] = p.grad.numpy()
     np.savez_compressed(os.path.join(GOLD, 'qwen2vl_tiny_dpo.npz'), **out)
     print('qwen2vl_tiny_dpo.npz loss', float(ld['loss']), 'acc', float(ld['reward_accuracy']), 'n arrays', len(out))
