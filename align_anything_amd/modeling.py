@@ -209,69 +209,125 @@ class ClipVisionTower:
     """hf:models/clip/modeling_clip.py:138-218, :338-351, :605-651.  Runs layers 0..L+feature_layer only (the
     reference computes the last block(s) and post_layernorm and discards them, modeling_llava.py:154-166)."""
 
-    def __init__(self, vcfg: dict, store: ParamStore, prefix: str, feature_layer: int = -2):
-        self.cfg, self.store, self.prefix = vcfg, store, prefix
+    def __init__(self, vcfg: dict, store: ParamStore, prefix: str, feature_layer: int = -2, trainable: bool = False):
+        self.cfg, self.store, self.prefix, self.trainable = vcfg, store, prefix, trainable
         h, F = vcfg['hidden_size'], vcfg['intermediate_size']
         self.K = vcfg['num_channels'] * vcfg['patch_size'] ** 2
         self.Kp = _pad64(self.K)
         self.G2 = (vcfg['image_size'] // vcfg['patch_size']) ** 2
         if h // vcfg['num_heads'] not in (64, 128):
             raise NotImplementedError('CLIP head_dim must be 64 or 128 for the native attention kernel')
+        nl = vcfg['num_layers']
+        self.run_layers = nl + 1 + feature_layer if feature_layer < 0 else feature_layer  # hidden_states index
+        tr = trainable
         e = prefix + 'embeddings.'
-        self.patch_w = store.add(e + 'patch_embedding.weight', (h, self.Kp), False)
-        self.cls = store.add(e + 'class_embedding', (h,), False)
-        self.pos = store.add(e + 'position_embedding.weight', (self.G2 + 1, h), False)
-        self.pre_w = store.add(prefix + 'pre_layrnorm.weight', (h,), False)
-        self.pre_b = store.add(prefix + 'pre_layrnorm.bias', (h,), False)
+        self.patch_w = store.add(e + 'patch_embedding.weight', (h, self.Kp), tr)
+        self.cls = store.add(e + 'class_embedding', (h,), tr)
+        self.pos = store.add(e + 'position_embedding.weight', (self.G2 + 1, h), tr, f32_grad=True)   # accumulated by a column sum
+        self.pre_w = store.add(prefix + 'pre_layrnorm.weight', (h,), tr)
+        self.pre_b = store.add(prefix + 'pre_layrnorm.bias', (h,), tr)
         self.layers = []
         for i in range(vcfg['num_layers']):
             p = f'{prefix}encoder.layers.{i}.'
             L = {}
-            L['ln1w'] = store.add(p + 'layer_norm1.weight', (h,), False)
-            L['ln1b'] = store.add(p + 'layer_norm1.bias', (h,), False)
-            wq = store.add_fused(p + 'self_attn.qkv_fused.weight', [(p + f'self_attn.{n}_proj.weight', h, h) for n in 'qkv'], False)
+            tr = trainable and i < self.run_layers          # blocks past the feature layer get no gradient in HF either
+            L['ln1w'] = store.add(p + 'layer_norm1.weight', (h,), tr)
+            L['ln1b'] = store.add(p + 'layer_norm1.bias', (h,), tr)
+            wq = store.add_fused(p + 'self_attn.qkv_fused.weight', [(p + f'self_attn.{n}_proj.weight', h, h) for n in 'qkv'], tr)
             # biases are 1-D: fuse by registering one [3h] block with three aliases
-            bq = store.add(p + 'self_attn.qkv_fused.bias', (3 * h,), False)
+            bq = store.add(p + 'self_attn.qkv_fused.bias', (3 * h,), tr)
             del store.alias[bq]
             for j, n in enumerate('qkv'):
                 store.alias[p + f'self_attn.{n}_proj.bias'] = (bq, j * h, (h,))
             L['qkv'] = Linear(store, wq, bq)
-            L['out'] = Linear(store, store.add(p + 'self_attn.out_proj.weight', (h, h), False),
-                              store.add(p + 'self_attn.out_proj.bias', (h,), False))
-            L['ln2w'] = store.add(p + 'layer_norm2.weight', (h,), False)
-            L['ln2b'] = store.add(p + 'layer_norm2.bias', (h,), False)
-            L['fc1'] = Linear(store, store.add(p + 'mlp.fc1.weight', (F, h), False), store.add(p + 'mlp.fc1.bias', (F,), False))
-            L['fc2'] = Linear(store, store.add(p + 'mlp.fc2.weight', (h, F), False), store.add(p + 'mlp.fc2.bias', (h,), False))
+            L['out'] = Linear(store, store.add(p + 'self_attn.out_proj.weight', (h, h), tr),
+                              store.add(p + 'self_attn.out_proj.bias', (h,), tr))
+            L['ln2w'] = store.add(p + 'layer_norm2.weight', (h,), tr)
+            L['ln2b'] = store.add(p + 'layer_norm2.bias', (h,), tr)
+            L['fc1'] = Linear(store, store.add(p + 'mlp.fc1.weight', (F, h), tr), store.add(p + 'mlp.fc1.bias', (F,), tr))
+            L['fc2'] = Linear(store, store.add(p + 'mlp.fc2.weight', (h, F), tr), store.add(p + 'mlp.fc2.bias', (h,), tr))
             self.layers.append(L)
         self.post_w = store.add(prefix + 'post_layernorm.weight', (h,), False)
         self.post_b = store.add(prefix + 'post_layernorm.bias', (h,), False)
-        nl = vcfg['num_layers']
-        self.run_layers = nl + 1 + feature_layer if feature_layer < 0 else feature_layer  # hidden_states index
         self._drop_cls_idx = {}
+        self._ctx = None
 
-    def forward(self, pixel_values):
+    def forward(self, pixel_values, save=False):
         """pixel_values [n, 3, S, S] (fp32 or bf16) -> patch features [n * G2, h] (CLS dropped)."""
         c, P = self.cfg, self.store.p
         n = pixel_values.shape[0]
         h, H = c['hidden_size'], c['num_heads']
         hd, eps, T = h // H, c['ln_eps'], self.G2 + 1
+        keep = save and self.trainable
         col = ops.patch_im2col(pixel_values.contiguous(), c['patch_size'], self.Kp, self.store.dtype)
+        if keep and col.shape[0] % 64:      # training: every row count is the contraction dim of a dW GEMM
+            col = torch.cat([col, torch.zeros((_pad64(col.shape[0]) - col.shape[0], self.Kp), dtype=col.dtype, device=col.device)])
         pe = ops.gemm(col, P[self.patch_w])
-        x = ops.clip_embed(pe, P[self.cls], P[self.pos], n, self.G2)
-        x, _, _ = ops.layernorm_fwd(x, P[self.pre_w], P[self.pre_b], eps, want_stats=False)
+        x0 = ops.clip_embed(pe, P[self.cls], P[self.pos], n, self.G2)
+        M = n * T
+        if keep and M % 64:
+            x0 = torch.cat([x0, torch.zeros((_pad64(M) - M, h), dtype=x0.dtype, device=x0.device)])
+        x, mp, rp = ops.layernorm_fwd(x0, P[self.pre_w], P[self.pre_b], eps, want_stats=keep)
+        saved = []
         for L in self.layers[:self.run_layers]:
-            y, _, _ = ops.layernorm_fwd(x, P[L['ln1w']], P[L['ln1b']], eps, want_stats=False)
-            qkv = L['qkv'].fwd(y)
-            a, _ = ops.attn_fwd(qkv[:, :h], qkv[:, h:2 * h], qkv[:, 2 * h:], n, T, H, H, hd, False, hd ** -0.5)
-            x = L['out'].fwd(a, residual=x)
-            y, _, _ = ops.layernorm_fwd(x, P[L['ln2w']], P[L['ln2b']], eps, want_stats=False)
-            y = L['fc1'].fwd(y, act=ops.ACT_QUICK_GELU)
-            x = L['fc2'].fwd(y, residual=x)
+            y1, m1, r1 = ops.layernorm_fwd(x, P[L['ln1w']], P[L['ln1b']], eps, want_stats=keep)
+            qkv = L['qkv'].fwd(y1)
+            a, lse = ops.attn_fwd(qkv[:, :h], qkv[:, h:2 * h], qkv[:, 2 * h:], n, T, H, H, hd, False, hd ** -0.5,
+                                  out=torch.zeros_like(x) if x.shape[0] != M else None)
+            x_mid = L['out'].fwd(a, residual=x)
+            y2, m2, r2 = ops.layernorm_fwd(x_mid, P[L['ln2w']], P[L['ln2b']], eps, want_stats=keep)
+            if keep:
+                f1 = L['fc1'].fwd(y2)
+                g1 = ops.act_fwd(f1, ops.ACT_QUICK_GELU)
+                saved.append((x, m1, r1, y1, qkv, a, lse, x_mid, m2, r2, y2, f1, g1))
+            else:
+                g1 = L['fc1'].fwd(y2, act=ops.ACT_QUICK_GELU)
+            x = L['fc2'].fwd(g1, residual=x_mid)
         idx = self._drop_cls_idx.get(n)
         if idx is None:
             idx = (torch.arange(n * T).view(n, T)[:, 1:]).reshape(-1).to(self.store.device)
             self._drop_cls_idx[n] = idx
+        if keep:
+            self._ctx = dict(n=n, T=T, M=M, rows=x.shape[0], col=col, x0=x0, mp=mp, rp=rp, saved=saved, idx=idx)
         return ops.embed_fwd(idx, x)  # row gather: drop the CLS token of every image
+
+    def backward(self, dfeat):
+        """dfeat [>= n * G2, h]: gradient of the returned patch features.  Accumulates the gradients of the blocks up to the feature
+        layer, pre_layrnorm and the embeddings (patch conv, class token, positions) into store.g."""
+        cx, c, P, G = self._ctx, self.cfg, self.store.p, self.store.g
+        n, T, M, rows = cx['n'], cx['T'], cx['M'], cx['rows']
+        h, H = c['hidden_size'], c['num_heads']
+        hd = h // H
+        dres = torch.zeros((rows, h), dtype=dfeat.dtype, device=dfeat.device)
+        dres.index_copy_(0, cx['idx'], dfeat[:cx['idx'].numel()])          # CLS rows and pad rows get no gradient from the features
+        for L, sv in zip(reversed(self.layers[:self.run_layers]), reversed(cx['saved'])):
+            x, m1, r1, y1, qkv, a, lse, x_mid, m2, r2, y2, f1, g1 = sv
+            d_g1 = L['fc2'].dx(dres)
+            L['fc2'].dw(dres, g1)
+            d_f1 = ops.act_bwd(f1, d_g1, ops.ACT_QUICK_GELU)
+            d_y2 = L['fc1'].dx(d_f1)
+            L['fc1'].dw(d_f1, y2)
+            ops.layernorm_bwd(d_y2, x_mid, P[L['ln2w']], m2, r2, G.get(L['ln2w']), G.get(L['ln2b']), dx=dres, add_to_dx=True)
+            d_a = L['out'].dx(dres)
+            L['out'].dw(dres, a)
+            d_qkv = torch.zeros_like(qkv) if rows != M else torch.empty_like(qkv)
+            ops.attn_bwd(qkv[:, :h], qkv[:, h:2 * h], qkv[:, 2 * h:], a, d_a, lse, d_qkv[:, :h], d_qkv[:, h:2 * h], d_qkv[:, 2 * h:],
+                         n, T, H, H, hd, False, hd ** -0.5)
+            d_y1 = L['qkv'].dx(d_qkv)
+            L['qkv'].dw(d_qkv, y1)
+            ops.layernorm_bwd(d_y1, x, P[L['ln1w']], m1, r1, G.get(L['ln1w']), G.get(L['ln1b']), dx=dres, add_to_dx=True)
+        d_x0 = ops.layernorm_bwd(dres, cx['x0'], P[self.pre_w], cx['mp'], cx['rp'], G.get(self.pre_w), G.get(self.pre_b))
+        # embeddings (modeling_clip.py:190-218): x0[n, 0] = cls + pos[0], x0[n, 1+p] = patch[n, p] + pos[1+p]
+        dpos = G[self.pos]                                                   # fp32 [T, h], accumulated
+        ops.colsum_(d_x0[:M].view(n, T * h), dpos.view(-1))
+        dcls_src = torch.zeros(h, dtype=torch.float32, device=dres.device)
+        cls_rows = torch.arange(n, device=dres.device) * T
+        ops.colsum_(ops.embed_fwd(cls_rows, d_x0), dcls_src)
+        G[self.cls].add_(dcls_src)
+        d_pe = torch.zeros((cx['col'].shape[0], h), dtype=d_x0.dtype, device=dres.device)
+        d_pe[:cx['idx'].numel()] = ops.embed_fwd(cx['idx'], d_x0)
+        Linear(self.store, self.patch_w).dw(d_pe, cx['col'])
+        self._ctx = None
 
 
 # ====================================================================== LM head + log-prob (shared)
@@ -515,15 +571,13 @@ class NativeLlava(NativeCausalLM):
                  freeze_vision_tower=True, head='lm', dtype=bf16):
         super().__init__(cfg, device, trainable, dtype)
         self.head_kind = head
-        if not freeze_vision_tower and trainable:
-            raise NotImplementedError('training the CLIP vision tower is not built (the reference default freezes '
-                                      'it, configs/train/text_image_to_text/dpo.yaml:60)')
         t = cfg['text']
         self.hidden_size = t['hidden_size']
         self.train_lm = trainable and not freeze_language_model
         self.train_proj = trainable and not freeze_mm_proj
+        self.train_tower = trainable and not freeze_vision_tower     # reference default: frozen (configs/train/text_image_to_text/dpo.yaml:60)
         st = self.store
-        self.vision = ClipVisionTower(cfg['vision'], st, 'model.vision_tower.', cfg.get('vision_feature_layer', -2))
+        self.vision = ClipVisionTower(cfg['vision'], st, 'model.vision_tower.', cfg.get('vision_feature_layer', -2), self.train_tower)
         vh = cfg['vision']['hidden_size']
         self.proj1 = Linear(st, st.add('model.multi_modal_projector.linear_1.weight', (t['hidden_size'], vh), self.train_proj),
                             st.add('model.multi_modal_projector.linear_1.bias', (t['hidden_size'],), self.train_proj))
@@ -561,7 +615,7 @@ class NativeLlava(NativeCausalLM):
             ids = torch.cat([ids, torch.zeros(Mp - N * T, dtype=ids.dtype, device=ids.device)])
         slot = feat = f1 = a1 = vfeat = None
         if pixel_values is not None or image_features is not None:
-            vfeat = image_features if image_features is not None else self.vision.forward(pixel_values)
+            vfeat = image_features if image_features is not None else self.vision.forward(pixel_values, save=save)
             n_feat = vfeat.shape[0]
             if n_feat % 64:  # rows are the contraction dim of the projector dW GEMMs (K % 64); pad rows are zero
                 vfeat = torch.cat([vfeat, torch.zeros((_pad64(n_feat) - n_feat, vfeat.shape[1]), dtype=vfeat.dtype, device=vfeat.device)])
@@ -590,16 +644,21 @@ class NativeLlava(NativeCausalLM):
         cx = self._ctx
         dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done)
         G = self.store.g
-        want_feat = cx['slot'] is not None and self.train_proj
+        tower = self.train_tower and self.vision._ctx is not None
+        want_feat = cx['slot'] is not None and (self.train_proj or tower)
         dfeat = torch.zeros((cx['vfeat'].shape[0], self.hidden_size), dtype=self.dtype, device=self.device) if want_feat else None
         if self.train_lm or want_feat:
             ops.embed_bwd(cx['ids'], dx, self.cfg['text']['vocab_size'], slot=cx['slot'],
                           dE=G.get(self.embed) if self.train_lm else None, dfeat=dfeat)
         if want_feat:
-            self.proj2.dw(dfeat, cx['a1'])
+            if self.train_proj:
+                self.proj2.dw(dfeat, cx['a1'])
             d_a1 = self.proj2.dx(dfeat)
             d_f1 = ops.act_bwd(cx['f1'], d_a1, ops.ACT_GELU)
-            self.proj1.dw(d_f1, cx['vfeat'])
+            if self.train_proj:
+                self.proj1.dw(d_f1, cx['vfeat'])
+            if tower:
+                self.vision.backward(self.proj1.dx(d_f1))
 
 
 # ====================================================================== Qwen2-VL

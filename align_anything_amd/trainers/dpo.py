@@ -106,8 +106,8 @@ class DPOTrainer:
         """Frozen CLIP tower once per unique image (collator stacks images*2: rows [0,B) == rows [B,2B),
         datasets/text_image_to_text/preference.py:219-222), shared by policy and reference."""
         pv = batch.get('pixel_values')
-        if pv is None or self.policy.kind != 'llava':
-            return None
+        if pv is None or self.policy.kind != 'llava' or getattr(self.policy, 'train_tower', False):
+            return None      # a training tower is run by the policy itself (its activations are needed) and differs from the reference's
         if '_vision_features' in batch:
             return batch['_vision_features']
         tower = self.policy if self.share_vision_tower else None
