@@ -35,6 +35,7 @@ struct GemmParams {
     long lda, ldb, ldc, ldr;
     int act, flags;
     int tiles_m, tiles_n;
+    int gm;                  // tile-group height of the grouped tile order
     // grouped (mixture-of-experts) launches, aa_gemm_grouped_bf16; null / 0 for ordinary GEMMs
     const int* grp_tile_expert;  // mode 1: expert of every BM-row tile of the expert-major A / C (-1 = unused tile)
     const int* grp_off;          // mode 2: row offsets [E + 1] of the expert segments (the contraction range of expert e)
