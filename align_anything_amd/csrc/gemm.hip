@@ -51,13 +51,23 @@ void gemm_kernel(const GemmParams p) {
         const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int GM = p.gm;   // tile-group height (tiles of one group share B panels in an XCD's L2); default 8, AA_GEMM_GM / aa_gemm_set_group
-    const int per_group = GM * p.tiles_n;
-    const int group = wg / per_group;
-    const int first_m = group * GM;
-    const int gsz = min(p.tiles_m - first_m, GM);
-    const int tm = first_m + (wg % per_group) % gsz;
-    const int tn = (wg % per_group) / gsz;
+    const int GM = p.gm & 0xff;   // tile-group height (tiles of one group share panels in an XCD's L2); see pick_group()
+    int tm, tn;
+    if (!(p.gm & 0x100)) {        // groups of GM tile rows, swept column by column
+        const int per_group = GM * p.tiles_n;
+        const int group = wg / per_group;
+        const int first_m = group * GM;
+        const int gsz = min(p.tiles_m - first_m, GM);
+        tm = first_m + (wg % per_group) % gsz;
+        tn = (wg % per_group) / gsz;
+    } else {                      // groups of GM tile columns, swept row by row
+        const int per_group = GM * p.tiles_m;
+        const int group = wg / per_group;
+        const int first_n = group * GM;
+        const int gsz = min(p.tiles_n - first_n, GM);
+        tn = first_n + (wg % per_group) % gsz;
+        tm = (wg % per_group) / gsz;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const bf16_t* Ap = p.A;
@@ -421,11 +431,14 @@ static int g_ilv = -1;   // 1: interleave ds_reads with MFMAs via sched_group_ba
 // Height (in tiles) of the groups of the L2-aware tile order.  Same-process sweep on the 7B shapes at M = 16384
 // (tools/bench_gemm_gm.py, profiles/r01_gemm_group_height.txt): 4 beats the former 8 by 0-7 % (NN most), 3 is best for NN with a wide
 // N (down-projection dX, +8 %), 16 / 32 lose 3-15 %.
-static int pick_group(bool a_t, bool b_n, int tiles_n) {
+// Second sweep (same file): with few tile columns (N <= 4096) and a long contraction (K >= 8192) grouping tile COLUMNS and
+// sweeping the rows is 3-6.5 % faster (down-projection forward, qkv / gate_up dX and dW); otherwise rows stay grouped.
+static int pick_group(bool a_t, bool b_n, int tiles_n, int K) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("AA_GEMM_GM"); env = e ? atoi(e) : 0; }
     if (g_gm > 0) return g_gm;
     if (env > 0) return env;
+    if (tiles_n <= 16 && K >= 8192) return 0x100 | 4;
     if (!a_t && b_n && tiles_n > 32) return 3;
     return 4;
 }
@@ -434,7 +447,7 @@ template <int BM, int BN, int WM, int WN, bool A_T, bool B_N, bool PIPE, int ILV
 static int launch_cfg2(GemmParams& p, hipStream_t st) {
     p.tiles_m = aa_cdiv(p.M, BM);
     p.tiles_n = aa_cdiv(p.N, BN);
-    p.gm = pick_group(A_T, B_N, p.tiles_n);
+    p.gm = pick_group(A_T, B_N, p.tiles_n, p.K);
     constexpr int lds = 2 * (BM + BN) * BK * 2;
     auto kern = gemm_kernel<BM, BN, WM, WN, A_T, B_N, PIPE, ILV>;
     static bool attr_set = false;
@@ -538,7 +551,7 @@ static int launch_grouped(GemmParams& p, int E, hipStream_t st) {
     constexpr int BM = 128, BN = 256, WM = 2, WN = 4;
     p.tiles_m = aa_cdiv(p.M, BM);
     p.tiles_n = aa_cdiv(p.N, BN);
-    p.gm = pick_group(A_T, B_N, p.tiles_n);
+    p.gm = 4;      // grouped (MoE) launches: rows are expert segments, keep the row-grouped order
     constexpr int lds = 2 * (BM + BN) * BK * 2;
     auto kern = gemm_kernel<BM, BN, WM, WN, A_T, B_N, true, 0, GRP>;
     static bool attr_set = false;
@@ -580,4 +593,4 @@ extern "C" int aa_gemm_set_tile(int tile) { g_force_tile = tile; return AA_OK; }
 extern "C" int aa_gemm_set_interleave(int mode) { g_ilv = mode; return AA_OK; }  // -1 auto, 0 off, 1 phase A, 2 both phases (peeled), 3 split-K ring (gemm_ring.hip)
 extern "C" int aa_gemm_set_mfma32(int on) { g_mfma32 = on ? 1 : 0; return AA_OK; }
 extern "C" int aa_gemm_set_pipeline(int on) { g_pipe = on ? 1 : 0; return AA_OK; }
-extern "C" int aa_gemm_set_group(int gm) { g_gm = gm < 0 ? 0 : gm; return AA_OK; }   // 0 = heuristic
+extern "C" int aa_gemm_set_group(int gm) { g_gm = gm < 0 ? 0 : gm; return AA_OK; }   // 0 = heuristic; +256 = group tile columns instead of rows

@@ -24,7 +24,7 @@ for name, N, K in (('qkv', 12288, 4096), ('o', 4096, 4096), ('gate_up', 22016, 4
         out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
         row = {'name': name, 'layout': layout}
         for rep in range(2):
-            for gm in (1, 2, 3, 4, 6, 8):
+            for gm in (3, 4, 8, 256 + 2, 256 + 4, 256 + 8):
                 call('aa_gemm_set_group', gm)
                 ms = timeit(lambda: ops.gemm(a, b, out=out, a_t=a_t, b_n=b_n))
                 row[f'gm{gm}_{rep}'] = round(2.0 * m * n * k / ms / 1e9)
