@@ -18,8 +18,15 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
                                                                   bf16_t* __restrict__ out, long ldo,
                                                                   const bf16_t* __restrict__ bias,
                                                                   const bf16_t* __restrict__ residual, long ldr,
-                                                                  int M, int N, int K) {
+                                                                  int M, int N, int K,
+                                                                  const int* __restrict__ row_expert, long strideE, int x_div) {
     __shared__ float red[NWAVE][16][17];
+    if (row_expert) {   // mixture-of-experts decode: blockIdx.y = routed row r = (token, choice); its own weight matrix, M = 1
+        const int r = blockIdx.y;
+        W += (long)row_expert[r] * strideE;
+        x += (long)(r / x_div) * ldx;
+        out += (long)r * ldo;
+    }
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16;
@@ -79,12 +86,26 @@ extern "C" int aa_gemm_skinny_bf16(const void* x, const void* W, void* out, int 
     if (wide)
         hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(aa_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
-                           (const bf16_t*)residual, ldr, M, N, K);
+                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1);
     else
         hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3(aa_cdiv(N, 16)), dim3(512), 0, (hipStream_t)stream,
                            (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
-                           (const bf16_t*)residual, ldr, M, N, K);
+                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1);
     AA_CHECK_LAUNCH("aa_gemm_skinny_bf16");
+    return AA_OK;
+}
+
+// Mixture-of-experts decode: out[r, :] = x[r / x_div, :] W3[row_expert[r]]^T for R routed rows (a handful of tokens x top-k):
+// every routed row streams its own expert matrix once (the floor for a row-private weight), no padding to the 128-row
+// tiles of the grouped training GEMM.  hf:models/qwen3_moe/modeling_qwen3_moe.py:210-283 at one token per sequence.
+extern "C" int aa_moe_gemv_bf16(const void* x, const void* W3, void* out, int R, int N, int K, long ldx, long ldw, long ldo,
+                                const int* row_expert, long strideE, int x_div, void* stream) {
+    AA_REQUIRE(R >= 1 && R <= 65535 && N > 0 && K > 0 && K % 32 == 0, "aa_moe_gemv_bf16: R=%d N=%d K=%d (K must be a multiple of 32)", R, N, K);
+    AA_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && strideE % 8 == 0 && x_div >= 1 && row_expert != nullptr, "aa_moe_gemv_bf16: ldx/ldw/strideE must be multiples of 8");
+    hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(aa_cdiv(N, 16), R), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, (const bf16_t*)W3, ldw, (bf16_t*)out, ldo, (const bf16_t*)nullptr,
+                       (const bf16_t*)nullptr, 0, 1, N, K, row_expert, strideE, x_div);
+    AA_CHECK_LAUNCH("aa_moe_gemv_bf16");
     return AA_OK;
 }
 

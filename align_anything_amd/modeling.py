@@ -1282,15 +1282,60 @@ class Qwen3MoeStack:
             n = max(T, self.cfg.get('max_position_embeddings', 0) or T)
             self.cos, self.sin = rope_tables(n, self.cfg['head_dim'], self.cfg['rope_theta'], self.store.device, self.store.dtype)
 
+    def kv_width(self):
+        return 2 * self.cfg['num_kv_heads'] * self.cfg['head_dim']
+
+    def _experts(self, L, n2, x_mid, rows):
+        """Sparse MoE block without saved state (prefill of big batches / decode beyond a handful of rows): the training layout."""
+        c, P = self.cfg, self.store.p
+        logits = L['gate'].fwd(n2) if n2.shape[0] > 16 else ops.linear_small(n2, L['gate'].w)
+        _, idx, w = ops.moe_route(logits, c['num_experts_per_tok'], c['norm_topk_prob'])
+        plan = ops.moe_plan(idx, c['num_experts'])
+        zeros = lambda n: torch.zeros((plan['cap'], n), dtype=n2.dtype, device=n2.device)
+        gu = ops.gemm_grouped(ops.moe_gather(n2, plan['src']), P[L['gu']], plan, out=zeros(P[L['gu']].shape[1]))
+        yp = ops.gemm_grouped(ops.swiglu_fwd(gu), P[L['down']], plan, out=zeros(c['hidden_size']))
+        return ops.moe_combine(yp, plan['pos'], w, rows, residual=x_mid)
+
+    def decode_step(self, x, cache, t, Tmax, pos, start, length):
+        """One new token per sequence against the KV cache (generation.py).  The experts of a handful of rows are streamed once
+        per routed (token, choice) row by `aa_moe_gemv_bf16`; beyond that the 128-row-tile training layout is cheaper (every
+        expert matrix is read once however many rows chose it)."""
+        c, P = self.cfg, self.store.p
+        H, Hkv, hd, eps, E, k = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps'], c['num_experts'], c['num_experts_per_tok']
+        qw, kw = H * hd, Hkv * hd
+        N = x.shape[0]
+        self._tables(Tmax)
+        rows = torch.arange(N, device=x.device)
+        ident = torch.arange(N * k, dtype=torch.int32, device=x.device).view(N, k)
+        for li, L in enumerate(self.layers):
+            n1, _ = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
+            q, kk, v = ops.linear_small(n1, L['q'].w), ops.linear_small(n1, L['k'].w), ops.linear_small(n1, L['v'].w)
+            qn, _ = ops.rmsnorm_fwd(q.view(N * H, hd), P[L['qn']], eps)
+            kn, _ = ops.rmsnorm_fwd(kk.view(N * Hkv, hd), P[L['kn']], eps)
+            qn, kn = qn.view(N, qw), kn.view(N, kw)
+            ops.rope_(qn, 0, H, hd, pos, self.cos, self.sin)
+            ops.rope_(kn, 0, Hkv, hd, pos, self.cos, self.sin)
+            cl = cache[li]
+            cl.view(N, Tmax, 2 * kw).index_put_((rows, t), torch.cat([kn, v], dim=1))
+            attn = ops.attn_decode(qn, cl, cl[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
+            x_mid = ops.linear_small(attn, L['o'].w, residual=x)
+            n2, _ = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
+            if N > 16 or N * k > 2 * E:
+                x = self._experts(L, n2, x_mid, N)
+                continue
+            _, idx, w = ops.moe_route(ops.linear_small(n2, L['gate'].w), k, c['norm_topk_prob'])
+            gu = ops.moe_gemv(n2, P[L['gu']], idx, k)                  # [N*k, 2F]: row (token, choice) x its expert
+            yp = ops.moe_gemv(ops.swiglu_fwd(gu), P[L['down']], idx, 1)
+            x = ops.moe_combine(yp, ident, w, N, residual=x_mid)
+        return x
+
     def forward(self, x, N, T, start, pos, save, kv_sink=None):
-        if kv_sink is not None:
-            raise NotImplementedError('Qwen3-MoE decode (KV-cache prefill) is not built yet')
         c, P = self.cfg, self.store.p
         H, Hkv, hd, eps, E, k = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps'], c['num_experts'], c['num_experts_per_tok']
         self._tables(T)
         self.saved = []
         Mp = x.shape[0]
-        for L in self.layers:
+        for li, L in enumerate(self.layers):
             n1, rstd1 = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
             q, kk, v = L['q'].fwd(n1), L['k'].fwd(n1), L['v'].fwd(n1)
             qn, rq = ops.rmsnorm_fwd(q.view(Mp * H, hd), P[L['qn']], eps)
@@ -1298,6 +1343,8 @@ class Qwen3MoeStack:
             qn, kn = qn.view(Mp, H * hd), kn.view(Mp, Hkv * hd)
             ops.rope_(qn, 0, H, hd, pos, self.cos, self.sin)
             ops.rope_(kn, 0, Hkv, hd, pos, self.cos, self.sin)
+            if kv_sink is not None:     # post-norm, post-RoPE keys | values of this layer -> KV cache (prefill)
+                kv_sink(li, torch.cat([kn[:N * T], v[:N * T]], dim=1))
             attn, lse = ops.attn_fwd(qn, kn, v, N, T, H, Hkv, hd, True, hd ** -0.5, start,
                                      out=None if Mp == N * T else torch.zeros((Mp, H * hd), dtype=x.dtype, device=x.device))
             x_mid = L['o'].fwd(attn, residual=x)

@@ -650,6 +650,18 @@ def linear_small(x, w, bias=None, residual=None, out=None):
     return out
 
 
+def moe_gemv(x, w3, row_expert, x_div):
+    """out[r] = x[r // x_div] @ w3[row_expert[r]]^T: the expert matrices of a few routed rows, streamed once each (decode)."""
+    R = row_expert.numel()
+    E, N, K = w3.shape
+    if x.shape[1] != K or x.dtype != bf16 or w3.dtype != bf16 or not w3.is_contiguous() or row_expert.dtype != torch.int32:
+        raise RuntimeError(f'moe_gemv: x {tuple(x.shape)} {x.dtype} / w3 {tuple(w3.shape)} {w3.dtype} / row_expert {row_expert.dtype}')
+    out = torch.empty((R, N), dtype=bf16, device=x.device)
+    call('aa_moe_gemv_bf16', x.data_ptr(), w3.data_ptr(), out.data_ptr(), R, N, K, x.stride(0), w3.stride(1), out.stride(0),
+         row_expert.data_ptr(), w3.stride(0), int(x_div), stream())
+    return out
+
+
 def attn_decode(q, kcache, vcache, Tmax, start, length, N, H, Hkv, hd, scale):
     out = torch.empty((N, H * hd), dtype=bf16, device=q.device)
     call('aa_attn_decode', q.data_ptr(), q.stride(0), kcache.data_ptr(), vcache.data_ptr(), kcache.stride(0), int(Tmax),

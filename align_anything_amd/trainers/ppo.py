@@ -67,7 +67,10 @@ class PPOTrainer(PPOMath):
     (base/rl_trainer.py:217-272).  The rollout batch (sequences from `generate`) is an input."""
 
     def __init__(self, cfgs, ds_cfgs=None, *, model_cfg, reward_model_cfg=None, actor_state=None, reward_state=None,
-                 critic_state=None, device='cuda:0'):
+                 critic_state=None, device='cuda:0', reward_fn=None):
+        """reward_fn(input_ids, attention_mask) -> [N] scores replaces the learned reward model: the rule / remote reward of
+        trainers/text_to_text/ppo_remote_rm.py:321-347 (decode prompts + responses on the host, score them over HTTP with
+        `remote_rm_client.score`; that string work stays the caller's Python) -- the critic still comes from `reward_model_cfg`."""
         t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
         PPOMath.__init__(self, kl_coeff=float(t('kl_coeff', 0.02)), clip_range_score=float(t('clip_range_score', 50.0)),
                          gamma=float(t('gamma', 1.0)), gae_lambda=float(t('gae_lambda', 0.95)),
@@ -77,13 +80,15 @@ class PPOTrainer(PPOMath):
         dt = compute_dtype(t('compute_dtype', 'bf16'))   # fp32 = parity mode for the update phase (rollouts need bf16)
         actor = build_model(model_cfg, device, trainable=True, dtype=dt)
         ref = build_model(model_cfg, device, trainable=False, dtype=dt)
-        reward = build_model(rcfg, device, trainable=False, head='score', dtype=dt)
+        self.reward_fn = reward_fn
+        reward = build_model(rcfg, device, trainable=False, head='score', dtype=dt) if reward_fn is None else None
         critic = build_model(rcfg, device, trainable=True, head='score', dtype=dt)
         if actor_state is not None:
             actor.load_state_dict(actor_state)
             ref.load_state_dict(actor_state)
-        if reward_state is not None:
+        if reward_state is not None and reward is not None:
             reward.load_state_dict(reward_state)
+        if critic_state is not None or reward_state is not None:
             critic.load_state_dict(critic_state if critic_state is not None else reward_state)
         clip = float(cfg_get(ds_cfgs, 'gradient_clipping', 1.0))
         betas = [float(b) for b in t('actor_betas', t('adam_betas', [0.9, 0.95]))]
@@ -95,7 +100,7 @@ class PPOTrainer(PPOMath):
                                                 max_grad_norm=clip, total_steps=total, warmup_steps=int(float(t('critic_lr_warmup_ratio', 0.03)) * total),
                                                 lr_scheduler_type=t('critic_lr_scheduler_type', 'constant'))
         self.actor_reference_model = NativeEngine(ref, trainable=False)
-        self.reward_model = NativeEngine(reward, trainable=False)
+        self.reward_model = NativeEngine(reward, trainable=False) if reward is not None else None
 
     # ------------------------------------------------------------------ rollout (ppo.py:209-222, 244-289)
     def actor_step(self, prompt_batch, generator=None):
@@ -127,9 +132,15 @@ class PPOTrainer(PPOMath):
         """reward = end score of the reward model (last attended token, models/opt.py:67-89);
         reward_values = critic scores[:, :-1]."""
         N, T = input_ids.shape
-        scores = self.reward_model.module.scores(input_ids, attention_mask)
-        end = (attention_mask.to(torch.int64) * torch.arange(T, device=input_ids.device)[None]).argmax(dim=1)
-        reward = scores[torch.arange(N, device=scores.device), end]
+        if self.reward_fn is not None:     # ppo_remote_rm.py:328-340: whatever the scorer returns, as a 1-D tensor on the device
+            reward = torch.as_tensor(self.reward_fn(input_ids, attention_mask)).detach().to(device=input_ids.device, dtype=torch.float32)
+            reward = reward.reshape(1) if reward.dim() == 0 else reward
+            if reward.shape != (N,):
+                raise ValueError(f'reward_fn returned shape {tuple(reward.shape)}, expected ({N},)')
+        else:
+            scores = self.reward_model.module.scores(input_ids, attention_mask)
+            end = (attention_mask.to(torch.int64) * torch.arange(T, device=input_ids.device)[None]).argmax(dim=1)
+            reward = scores[torch.arange(N, device=scores.device), end]
         self.reward_critic_model.wait_optimizer()
         values = self.reward_critic_model.module.scores(input_ids, attention_mask)[:, :-1]
         return {'reward': reward, 'reward_values': values}

@@ -212,6 +212,10 @@ int aa_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
 /* out[M<=16, N] = x[M,K] W[N,K]^T (+bias) (+residual, HF rounding); K % 32 == 0; HBM-streaming skinny GEMM */
 int aa_gemm_skinny_bf16(const void* x, const void* W, void* out, int M, int N, int K, long ldx, long ldw, long ldo,
                         const void* bias, const void* residual, long ldr, void* stream);
+/* sparse-MoE block at one token per sequence (hf:models/qwen3_moe/modeling_qwen3_moe.py:210-283 during generate):
+ * out[r, :] = x[r / x_div, :] W3[row_expert[r]]^T for R routed rows r = (token, choice); W3 [E, N, K], expert stride strideE */
+int aa_moe_gemv_bf16(const void* x, const void* W3, void* out, int R, int N, int K, long ldx, long ldw, long ldo,
+                     const int* row_expert, long strideE, int x_div, void* stream);
 /* one query per sequence against the token-major KV cache [N, Tmax, Hkv*hd] (row stride ldc); keys [start[n], len[n]) */
 int aa_attn_decode(const void* q, long ldq, const void* Kc, const void* Vc, long ldc, int Tmax, const int* start,
                    const int* len, void* o, long ldo, int N, int H, int Hkv, int hd, float scale, void* stream);

@@ -215,3 +215,31 @@ def test_qwen2_style_text_model_dpo_step_vs_oracle():
               'model.layers.0.mlp.up_proj.weight', 'lm_head.weight'):
         got = tr.policy.store.grad_view(n).float().cpu().reshape(f[n].grad.shape)
         assert rel_err(got, f[n].grad) < 8e-2, (n, rel_err(got, f[n].grad))
+
+
+def test_rule_reward_replaces_the_reward_model():
+    """trainers/text_to_text/ppo_remote_rm.py:321-347: the reward comes from a scorer outside the model (rule / HTTP service); the critic
+    values and the whole update are unchanged.  A scalar return is promoted to 1-D as the reference does (:337-338)."""
+    from align_anything_amd.trainers.ppo import PPOTrainer
+    tr, z, cfg, actor_sd, old_sd, rm_sd, ids, mask, start = _setup()
+    want = tr.reward_model_step(ids.to(dev()), mask.to(dev()))
+    seen = {}
+
+    def rule(i, a):
+        seen['shape'] = tuple(i.shape)
+        return [float(x) for x in (i * a).sum(1) % 7]            # a host-side list, like remote_rm_client.score's return
+
+    tr2 = PPOTrainer(tr.cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, critic_state=rm_sd, device='cuda:0', reward_fn=rule)
+    assert tr2.reward_model is None
+    got = tr2.reward_model_step(ids.to(dev()), mask.to(dev()))
+    assert seen['shape'] == tuple(ids.shape)
+    assert torch.equal(got['reward'].cpu(), ((ids * mask).sum(1) % 7).float())
+    assert torch.equal(got['reward_values'], want['reward_values'])          # same critic weights -> identical values
+    lp, _ = tr2.sequence_log_probs(tr2.actor_model, ids.to(dev()), mask.to(dev()))
+    info = tr2.rl_step({'input_ids': ids.to(dev()), 'attention_mask': mask.to(dev())},
+                       {'prompt_idx': start, 'log_probs': lp, 'ref_log_probs': lp.clone(), 'reward': got['reward'], 'reward_values': got['reward_values']})
+    assert abs(info['train/reward'] - float(got['reward'].mean())) < 1e-6 and info['train/kl_divergence'] == 0.0
+    bad = PPOTrainer(tr.cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, critic_state=rm_sd, device='cuda:0',
+                     reward_fn=lambda i, a: torch.zeros(2))
+    with pytest.raises(ValueError):
+        bad.reward_model_step(ids.to(dev()), mask.to(dev()))
