@@ -93,6 +93,9 @@ class NativeEngine:
         self.thin_optimizer = os.environ.get('AA_ADAM_THIN', '0') == '1'
         self._opt_stream = None
         self._opt_done = None
+        ep = getattr(module, 'ep', None)
+        if ep is not None and ep.size != self.world:
+            raise ValueError(f'expert-parallel degree {ep.size} must equal the data-parallel world size {self.world}')
         if trainable:
             module.init_training()
             dev = module.device
@@ -208,8 +211,15 @@ class NativeEngine:
         def launch():
             self._sumsq.zero_()
             groups = st.trainable_groups()
+            if 'exp' in groups:
+                # expert-parallel shards (expert_parallel.py): every rank owns different experts, whose gradients are already the
+                # sum over all ranks' rows -> never all-reduced; the clip norm needs the sum of the shards' squared norms
+                ops.grad_sumsq_(st.gflat['exp'], self._sumsq, gscale, self._sumsq_ws)
+                if self.world > 1:
+                    dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.reducer.group)
             for g in groups:
-                ops.grad_sumsq_(st.gflat[g], self._sumsq, gscale, self._sumsq_ws)
+                if g != 'exp':
+                    ops.grad_sumsq_(st.gflat[g], self._sumsq, gscale, self._sumsq_ws)
             ops.clip_coef(self._sumsq, self.max_grad_norm if self.max_grad_norm else 0.0, self._coef, self._gnorm)
             for g in groups:
                 wd = 0.0 if g == 'vec' else self.weight_decay
@@ -258,23 +268,31 @@ class NativeEngine:
         return path
 
     def save_checkpoint(self, save_dir, tag=None):
-        """Full training state (fp32 masters + Adam moments + step), the analogue of DeepSpeed's checkpoint."""
+        """Full training state (fp32 masters + Adam moments + step), the analogue of DeepSpeed's checkpoint.  Replicated
+        groups are written by rank 0; an expert-parallel shard ('exp') by the rank that owns it (`..._ep<rank>.pt`)."""
         self.wait_optimizer()
         os.makedirs(save_dir, exist_ok=True)
         st = self.module.store
         rank = dist.get_rank() if dist.is_initialized() else 0
+        tag = tag or 'latest'
+        pick = lambda groups: {k: {g: t.cpu() for g, t in d.items() if g in groups} for k, d in (('master', st.master), ('m', st.m), ('v', st.v))}
         if rank == 0:
-            torch.save({'global_steps': self.global_steps,
-                        'master': {g: t.cpu() for g, t in st.master.items()},
-                        'm': {g: t.cpu() for g, t in st.m.items()},
-                        'v': {g: t.cpu() for g, t in st.v.items()}},
-                       os.path.join(save_dir, f'native_engine_{tag or "latest"}.pt'))
+            torch.save({'global_steps': self.global_steps, **pick([g for g in st.master if g != 'exp'])},
+                       os.path.join(save_dir, f'native_engine_{tag}.pt'))
+        if 'exp' in st.master:
+            torch.save(pick(['exp']), os.path.join(save_dir, f'native_engine_{tag}_ep{rank}.pt'))
 
     def load_checkpoint(self, load_dir, tag=None):
         self.wait_optimizer()
         st = self.module.store
-        ck = torch.load(os.path.join(load_dir, f'native_engine_{tag or "latest"}.pt'), map_location='cpu')
+        tag = tag or 'latest'
+        ck = torch.load(os.path.join(load_dir, f'native_engine_{tag}.pt'), map_location='cpu')
         self.global_steps = ck['global_steps']
+        if 'exp' in st.master:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            shard = torch.load(os.path.join(load_dir, f'native_engine_{tag}_ep{rank}.pt'), map_location='cpu')
+            for k in ('master', 'm', 'v'):
+                ck[k]['exp'] = shard[k]['exp']
         for g in st.master:
             st.master[g].copy_(ck['master'][g])
             st.m[g].copy_(ck['m'][g])

@@ -1252,13 +1252,16 @@ class Qwen3MoeStack:
     (csrc/moe.hip); all experts of a layer run in ONE grouped-GEMM launch per matrix (`aa_gemm_grouped_*`: the kernel reads the
     128-row-tile -> expert table and the segment offsets from device memory), so a layer needs no host read at all."""
 
-    def __init__(self, cfg: dict, store: ParamStore, prefix: str, trainable: bool):
-        self.cfg, self.store, self.prefix, self.trainable = cfg, store, prefix, trainable
+    def __init__(self, cfg: dict, store: ParamStore, prefix: str, trainable: bool, ep=None):
+        """ep: expert_parallel.ExpertParallel -> this rank holds experts [e0, e0 + El) only (expert_parallel.py); None = all."""
+        self.cfg, self.store, self.prefix, self.trainable, self.ep = cfg, store, prefix, trainable, ep
         h, F, E = cfg['hidden_size'], cfg['moe_intermediate_size'], cfg['num_experts']
         H, Hkv, hd = cfg['num_heads'], cfg['num_kv_heads'], cfg['head_dim']
         if hd not in (64, 128):
             raise NotImplementedError(f'head_dim {hd}: attention kernels are built for 64 and 128')
         tr = trainable
+        e0, El = ep.local_experts(E) if ep is not None else (0, E)
+        shard = (e0, E) if ep is not None else None
         self.layers = []
         for i in range(cfg['num_layers']):
             p = f'{prefix}layers.{i}.'
@@ -1270,8 +1273,8 @@ class Qwen3MoeStack:
                  'o': Linear(store, store.add(p + 'self_attn.o_proj.weight', (h, H * hd), tr)),
                  'ln2': store.add(p + 'post_attention_layernorm.weight', (h,), tr),
                  'gate': Linear(store, store.add(p + 'mlp.gate.weight', (E, h), tr)),
-                 'gu': store.add(p + 'mlp.experts.gate_up_proj', (E, 2 * F, h), tr),
-                 'down': store.add(p + 'mlp.experts.down_proj', (E, h, F), tr)}
+                 'gu': store.add(p + 'mlp.experts.gate_up_proj', (El, 2 * F, h), tr, shard=shard),
+                 'down': store.add(p + 'mlp.experts.down_proj', (El, h, F), tr, shard=shard)}
             self.layers.append(L)
         self.norm = store.add(prefix + 'norm.weight', (h,), tr)
         self.cos = self.sin = None
@@ -1288,6 +1291,8 @@ class Qwen3MoeStack:
     def _experts(self, L, n2, x_mid, rows):
         """Sparse MoE block without saved state (prefill of big batches / decode beyond a handful of rows): the training layout."""
         c, P = self.cfg, self.store.p
+        if self.ep is not None:
+            raise NotImplementedError('rollout decode with expert-parallel weights is not built: generate on a replica that holds all experts')
         logits = L['gate'].fwd(n2) if n2.shape[0] > 16 else ops.linear_small(n2, L['gate'].w)
         _, idx, w = ops.moe_route(logits, c['num_experts_per_tok'], c['norm_topk_prob'])
         plan = ops.moe_plan(idx, c['num_experts'])
@@ -1304,6 +1309,8 @@ class Qwen3MoeStack:
         H, Hkv, hd, eps, E, k = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps'], c['num_experts'], c['num_experts_per_tok']
         qw, kw = H * hd, Hkv * hd
         N = x.shape[0]
+        if self.ep is not None:
+            raise NotImplementedError('rollout decode with expert-parallel weights is not built: generate on a replica that holds all experts')
         self._tables(Tmax)
         rows = torch.arange(N, device=x.device)
         ident = torch.arange(N * k, dtype=torch.int32, device=x.device).view(N, k)
@@ -1329,6 +1336,52 @@ class Qwen3MoeStack:
             x = ops.moe_combine(yp, ident, w, N, residual=x_mid)
         return x
 
+    # ---- the experts this rank holds, on rows already in the 128-row-tile expert-major layout `plan`
+    def _local_experts_fwd(self, L, xp, plan):
+        P = self.store.p
+        zeros = lambda n: torch.zeros((plan['cap'], n), dtype=xp.dtype, device=xp.device)
+        gu = ops.gemm_grouped(xp, P[L['gu']], plan, out=zeros(P[L['gu']].shape[1]))
+        act = ops.swiglu_fwd(gu)
+        yp = ops.gemm_grouped(act, P[L['down']], plan, out=zeros(self.cfg['hidden_size']))
+        return gu, act, yp
+
+    def _local_experts_bwd(self, L, dyp, plan, xp, gu, act):
+        """dyp: gradient of the expert outputs in the tile layout (pad rows zero) -> gradient of xp; dW into the store."""
+        P, G, st, tr = self.store.p, self.store.g, self.store, self.trainable
+        acc = lambda g: (g.dtype == torch.float32) or st.accumulate
+        dact = ops.gemm_grouped(dyp, P[L['down']], plan, out=torch.zeros_like(act), b_n=True)
+        if tr:      # experts that saw no token get an all-zero gradient from the kernel (never a stale one)
+            ops.gemm_grouped_dw(dyp, act, plan, G[L['down']], accumulate=acc(G[L['down']]))
+        dgu = ops.swiglu_bwd(gu, dact)
+        dxp = ops.gemm_grouped(dgu, P[L['gu']], plan, out=torch.zeros_like(xp), b_n=True)
+        if tr:
+            ops.gemm_grouped_dw(dgu, xp, plan, G[L['gu']], accumulate=acc(G[L['gu']]))
+        return dxp
+
+    # ---- expert parallelism (expert_parallel.py): rows travel to the ranks that own their experts and back
+    def _ep_experts_fwd(self, L, n2, x_mid, idx, w, Mp):
+        ep, E = self.ep, self.cfg['num_experts']
+        lay = ops.moe_plan(idx, E, align=1)                      # dense expert-major order = send order (experts are rank-contiguous)
+        xs = ops.moe_gather(n2, lay['src'])                      # [Mp*k, h]
+        send, recv, recv_counts = ep.exchange_counts(lay['counts'])
+        xr = ep.exchange_rows(xs, send, recv)                    # rows for my experts, source-rank major
+        plan = ops.moe_plan(ep.local_expert_ids(recv_counts, n2.device), E // ep.size)
+        xp = ops.moe_gather(xr, plan['src'])
+        gu, act, yp = self._local_experts_fwd(L, xp, plan)
+        yr = ops.moe_combine(yp, plan['pos'], None, xr.shape[0])         # tile layout -> arrival order (a copy: k = 1, unit weight)
+        ys = ep.exchange_rows(yr, recv, send)                    # back in my send order
+        x_out = ops.moe_combine(ys, lay['pos'], w, Mp, residual=x_mid)
+        return x_out, {'lay': lay, 'local': plan, 'send': send, 'recv': recv, 'ys': ys}, xp, gu, act, yp
+
+    def _ep_experts_bwd(self, L, dres, ctx, xp, gu, act, w, Mp):
+        ep, lay, plan = self.ep, ctx['lay'], ctx['local']
+        dys, dw = ops.moe_combine_bwd(dres, ctx['ys'], lay['pos'], w)
+        dyr = ep.exchange_rows(dys, ctx['send'], ctx['recv'])
+        dxp = self._local_experts_bwd(L, ops.moe_gather(dyr, plan['src']), plan, xp, gu, act)
+        dxr = ops.moe_combine(dxp, plan['pos'], None, dyr.shape[0])
+        dxs = ep.exchange_rows(dxr, ctx['recv'], ctx['send'])
+        return ops.moe_combine(dxs, lay['pos'], None, Mp), dw
+
     def forward(self, x, N, T, start, pos, save, kv_sink=None):
         c, P = self.cfg, self.store.p
         H, Hkv, hd, eps, E, k = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps'], c['num_experts'], c['num_experts_per_tok']
@@ -1351,13 +1404,13 @@ class Qwen3MoeStack:
             n2, rstd2 = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
             logits = L['gate'].fwd(n2)
             probs, idx, w = ops.moe_route(logits, k, c['norm_topk_prob'])
-            plan = ops.moe_plan(idx, E)
-            xp = ops.moe_gather(n2, plan['src'])                           # [cap, h], zero pad rows
-            zeros = lambda n: torch.zeros((plan['cap'], n), dtype=x.dtype, device=x.device)
-            gu = ops.gemm_grouped(xp, P[L['gu']], plan, out=zeros(P[L['gu']].shape[1]))
-            act = ops.swiglu_fwd(gu)
-            yp = ops.gemm_grouped(act, P[L['down']], plan, out=zeros(c['hidden_size']))
-            x_out = ops.moe_combine(yp, plan['pos'], w, Mp, residual=x_mid)
+            if self.ep is not None:
+                x_out, plan, xp, gu, act, yp = self._ep_experts_fwd(L, n2, x_mid, idx, w, Mp)
+            else:
+                plan = ops.moe_plan(idx, E)
+                xp = ops.moe_gather(n2, plan['src'])                           # [cap, h], zero pad rows
+                gu, act, yp = self._local_experts_fwd(L, xp, plan)
+                x_out = ops.moe_combine(yp, plan['pos'], w, Mp, residual=x_mid)
             if save:
                 self.saved.append((x, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp))
             x = x_out
@@ -1368,20 +1421,15 @@ class Qwen3MoeStack:
         H, Hkv, hd, E = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['num_experts']
         tr, st = self.trainable, self.store
         Mp = dres.shape[0]
-        acc = lambda g: (g.dtype == torch.float32) or st.accumulate
         for L, sv in zip(reversed(self.layers), reversed(self.saved)):
             x, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp = sv
             sv = None
             # ---- sparse MoE block
-            dyp, dw = ops.moe_combine_bwd(dres, yp, plan['pos'], w)
-            dact = ops.gemm_grouped(dyp, P[L['down']], plan, out=torch.zeros_like(act), b_n=True)
-            if tr:      # experts that saw no token get an all-zero gradient from the kernel (never a stale one)
-                ops.gemm_grouped_dw(dyp, act, plan, G[L['down']], accumulate=acc(G[L['down']]))
-            dgu = ops.swiglu_bwd(gu, dact)
-            dxp = ops.gemm_grouped(dgu, P[L['gu']], plan, out=torch.zeros_like(xp), b_n=True)
-            if tr:
-                ops.gemm_grouped_dw(dgu, xp, plan, G[L['gu']], accumulate=acc(G[L['gu']]))
-            d_n2 = ops.moe_combine(dxp, plan['pos'], None, Mp)
+            if 'lay' in plan:
+                d_n2, dw = self._ep_experts_bwd(L, dres, plan, xp, gu, act, w, Mp)
+            else:
+                dyp, dw = ops.moe_combine_bwd(dres, yp, plan['pos'], w)
+                d_n2 = ops.moe_combine(self._local_experts_bwd(L, dyp, plan, xp, gu, act), plan['pos'], None, Mp)
             dlogits = ops.moe_route_bwd(probs, idx, dw, c['norm_topk_prob'], x.dtype)
             if E % 64:   # the expert count is the contraction dim here: zero-pad it for small (test-size) routers
                 Ep = _pad64(E)
@@ -1421,13 +1469,14 @@ class NativeQwen3Moe(NativeCausalLM):
 
     kind = 'qwen3moe'
 
-    def __init__(self, cfg, device, trainable=True, head='lm', dtype=bf16):
+    def __init__(self, cfg, device, trainable=True, head='lm', dtype=bf16, ep=None):
         super().__init__(cfg, device, trainable, dtype)
         self.head_kind = head
         self.hidden_size = cfg['hidden_size']
+        self.ep = ep
         st = self.store
         self.embed = st.add('model.embed_tokens.weight', (cfg['vocab_size'], cfg['hidden_size']), trainable, f32_grad=True)
-        self.stack = Qwen3MoeStack(cfg, st, 'model.', trainable)
+        self.stack = Qwen3MoeStack(cfg, st, 'model.', trainable, ep)
         if head == 'lm':
             lm = st.add('lm_head.weight', (cfg['vocab_size'], cfg['hidden_size']), trainable)
             self.head = LMHead(st, 'rms', self.stack.norm, None, lm, cfg['rms_eps'], trainable)
@@ -1449,6 +1498,15 @@ class NativeQwen3Moe(NativeCausalLM):
 
     def embed_tokens(self, ids, pos=None):
         return ops.embed_fwd(ids, self.store.p[self.embed])
+
+    def state_dict(self):
+        """HF-layout tensors.  With expert parallelism this is a COLLECTIVE call: every rank contributes its expert rows and
+        gets the full [E, ...] tensors back (what save_pretrained writes)."""
+        sd = super().state_dict()
+        if self.ep is not None:
+            for name in self.store.shard:
+                sd[name] = self.ep.all_gather_rows(sd[name])
+        return sd
 
     def backward_stream(self, dres, on_layer_done=None):
         cx = self._ctx
@@ -1681,5 +1739,5 @@ def build_model(cfg: dict, device, trainable=True, head='lm', dtype=bf16, **free
     if cfg['kind'] == 'qwen2audio':
         return NativeQwen2Audio(cfg, device, trainable, head=head, dtype=dtype, **freeze)
     if cfg['kind'] == 'qwen3moe':
-        return NativeQwen3Moe(cfg, device, trainable, head=head, dtype=dtype)
+        return NativeQwen3Moe(cfg, device, trainable, head=head, dtype=dtype, **freeze)      # ep=ExpertParallel(...)
     raise ValueError(f"no native model for kind {cfg['kind']!r}")

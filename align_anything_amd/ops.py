@@ -387,15 +387,17 @@ def moe_route_bwd(probs, idx, dw, norm_topk, dtype):
 MOE_ALIGN = 128   # row tile of the grouped GEMM = alignment of the expert segments
 
 
-def moe_plan(idx, E):
-    """Device-side expert-major layout (no host read).  Returns dict(pos [rows,k], src [cap], tile_expert, off [E+1], counts [E], cap)."""
+def moe_plan(idx, E, align=MOE_ALIGN):
+    """Device-side expert-major layout (no host read).  Returns dict(pos [rows,k], src [cap], tile_expert, off [E+1], counts [E], cap).
+    align = MOE_ALIGN: segments padded to the grouped GEMM's row tile; align = 1: the dense expert-major order (the send buffer
+    of the expert-parallel exchange)."""
     rows, k = idx.shape
     dev = idx.device
-    cap = (rows * k + E * (MOE_ALIGN - 1) + MOE_ALIGN - 1) // MOE_ALIGN * MOE_ALIGN
+    cap = (rows * k + E * (align - 1) + align - 1) // align * align
     i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
-    plan = {'pos': i32(rows * k).view(rows, k), 'src': i32(cap), 'tile_expert': i32(cap // MOE_ALIGN), 'off': i32(E + 1), 'counts': i32(E),
+    plan = {'pos': i32(rows * k).view(rows, k), 'src': i32(cap), 'tile_expert': i32(cap // align), 'off': i32(E + 1), 'counts': i32(E),
             'cap': cap, 'E': E}
-    call('aa_moe_plan', idx.data_ptr(), rows, k, E, MOE_ALIGN, cap, plan['counts'].data_ptr(), plan['off'].data_ptr(), plan['pos'].data_ptr(),
+    call('aa_moe_plan', idx.data_ptr(), rows, k, E, align, cap, plan['counts'].data_ptr(), plan['off'].data_ptr(), plan['pos'].data_ptr(),
          plan['src'].data_ptr(), plan['tile_expert'].data_ptr(), stream())
     return plan
 
@@ -431,6 +433,8 @@ def gemm_grouped_dw(dy, x, plan, out3, accumulate=False):
 def moe_gather(x, src_row):
     rows_out, h = src_row.numel(), x.shape[1]
     out = torch.empty((rows_out, h), dtype=x.dtype, device=x.device)
+    if rows_out == 0:
+        return out
     call('aa_moe_gather' + _sfx(x, 'moe_gather'), x.data_ptr(), src_row.data_ptr(), out.data_ptr(), rows_out, h, stream())
     return out
 
@@ -438,6 +442,8 @@ def moe_gather(x, src_row):
 def moe_combine(yp, pos, w, rows, residual=None):
     k, h = pos.shape[1], yp.shape[1]
     out = torch.empty((rows, h), dtype=yp.dtype, device=yp.device)
+    if rows == 0:
+        return out
     call('aa_moe_combine' + _sfx(yp, 'moe_combine'), yp.data_ptr(), pos.data_ptr(), _p(w), _p(residual), out.data_ptr(), rows, k, h, stream())
     return out
 

@@ -44,12 +44,20 @@ class ParamStore:
         self.p: dict[str, torch.Tensor] = {}
         self.g: dict[str, torch.Tensor] = {}
         self.sizes: dict[str, int] = {}
+        self.shard: dict[str, tuple[int, int]] = {}           # expert-parallel blocks: hf name -> (first row held here, full dim 0)
         self.accumulate = False   # set by NativeEngine during gradient accumulation (bf16 dW GEMMs then add)
 
     # ---- registration
-    def add(self, name, shape, trainable=True, f32_grad=False):
+    def add(self, name, shape, trainable=True, f32_grad=False, shard=None):
+        """shard = (first, full): this rank holds rows [first, first + shape[0]) of a [full, ...] checkpoint tensor (expert
+        parallelism).  Trainable shards live in their own flat group 'exp': its gradients are complete on the owning rank and
+        are never all-reduced (engine.py)."""
         group = 'frozen'
-        if trainable:
+        if shard is not None:
+            self.shard[name] = (int(shard[0]), int(shard[1]))
+        if trainable and shard is not None:
+            group = 'exp'
+        elif trainable:
             if is_no_decay(name):
                 group = 'vec'
             elif f32_grad or len(shape) == 1:
@@ -95,7 +103,7 @@ class ParamStore:
         for g, n in self.sizes.items():
             if g == 'frozen':
                 continue
-            gd = torch.bfloat16 if (g == 'mat' and self.dtype == torch.bfloat16) else torch.float32
+            gd = torch.bfloat16 if (g in ('mat', 'exp') and self.dtype == torch.bfloat16) else torch.float32
             self.gflat[g] = torch.zeros(n, dtype=gd, device=self.device)
             self.master[g] = self.flat[g] if self.dtype == torch.float32 else self.flat[g].to(torch.float32)
             self.m[g] = torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -112,7 +120,7 @@ class ParamStore:
                 t.zero_()
 
     def trainable_groups(self):
-        return [g for g in ('mat', 'emb', 'vec') if g in self.gflat]
+        return [g for g in ('mat', 'exp', 'emb', 'vec') if g in self.gflat]
 
     def num_trainable(self) -> int:
         return sum(s['numel'] for s in self.specs.values() if s['group'] != 'frozen')
@@ -144,6 +152,10 @@ class ParamStore:
                 continue
             src = sd[hf_name]
             dst = self.view(hf_name)
+            if hf_name in self.shard:   # a full checkpoint tensor: keep the rows this rank owns
+                first, full = self.shard[hf_name]
+                if src.shape[0] == full:
+                    src = src[first:first + dst.shape[0]]
             if pad_cols and hf_name in pad_cols:  # zero-padded K (CLIP patch embedding 588 -> 640)
                 src = src.reshape(src.shape[0], -1)
                 dst.zero_()

@@ -75,8 +75,15 @@ class DPOTrainer:
             freeze = dict(freeze_mm_proj=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_mm_proj', False)),
                           freeze_language_model=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_language_model', False)),
                           freeze_vision_tower=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_vision_tower', True)))
+        ref_kw = {}
+        if self.model_cfg['kind'] == 'qwen3moe' and bool(cfg_get(self.cfgs, 'train_cfgs.expert_parallel', False)):
+            # experts split over the data-parallel ranks (expert_parallel.py); the exchange runs on its own communicator so it
+            # never queues behind a gradient bucket.  Policy and reference shard the same way.
+            import torch.distributed as dist
+            from ..expert_parallel import ExpertParallel
+            freeze = ref_kw = dict(ep=ExpertParallel(dist.new_group()))
         self.policy = build_model(self.model_cfg, self.device, trainable=True, dtype=self.dtype, **freeze)
-        self.reference = build_model(self.model_cfg, self.device, trainable=False, dtype=self.dtype) if self.uses_reference else None
+        self.reference = build_model(self.model_cfg, self.device, trainable=False, dtype=self.dtype, **ref_kw) if self.uses_reference else None
         if policy_state is not None:
             self.policy.load_state_dict(policy_state)
             if self.reference is not None:

@@ -1,0 +1,80 @@
+"""CPU, world_size 2, gloo: the token exchange of the expert-parallel MoE block (align_anything_amd/expert_parallel.py) -- counts,
+dispatch to the ranks that own the experts, local expert ids of the arriving rows, and the mirrored return path.  The device
+kernels are replaced by their integer definition (a stable sort by expert = `aa_moe_plan` with align 1) so the bookkeeping of
+the exchange itself is pinned without a GPU; tests/test_ep_gpu.py runs the real block."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from align_anything_amd.expert_parallel import ExpertParallel
+    ep = ExpertParallel(dist.new_group())
+    ok = ep.size == world and ep.rank == rank and ep.host_staged
+    E, k, h = 8, 2, 6
+    e0, El = ep.local_experts(E)
+    ok = ok and (e0, El) == (rank * 4, 4)
+    for trial, M in enumerate((13, 1, 40)):
+        g = torch.Generator().manual_seed(100 * trial + rank)
+        idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(M)])        # [M, k] distinct experts per token
+        if trial == 1 and rank == 0:
+            idx = torch.tensor([[5, 6]])                                                   # rank 0 sends nothing to itself
+        flat = idx.reshape(-1)
+        order = torch.argsort(flat, stable=True)                                           # dense expert-major send order
+        tok, choice = order // k, order % k
+        xs = torch.stack([torch.full_like(tok, rank), tok, choice, flat[order], torch.zeros_like(tok), torch.zeros_like(tok)], 1).float()
+        counts = torch.bincount(flat, minlength=E).to(torch.int32)
+        send, recv, recv_counts = ep.exchange_counts(counts)
+        ok = ok and send == [int(counts[:4].sum()), int(counts[4:].sum())] and sum(send) == M * k
+        xr = ep.exchange_rows(xs, send, recv)
+        ids = ExpertParallel.local_expert_ids(recv_counts, 'cpu').view(-1).long()
+        ok = ok and xr.shape[0] == sum(recv) == ids.numel()
+        ok = ok and bool((xr[:, 3].long() == e0 + ids).all())                              # every row reached the owner of its expert
+        src_rank = torch.repeat_interleave(torch.arange(world), torch.tensor(recv))
+        ok = ok and bool((xr[:, 0].long() == src_rank).all())                              # source-rank major
+        # within one (source, expert) block the sender's token order is kept (stable)
+        key = xr[:, 0] * 1e6 + xr[:, 3] * 1e3 + xr[:, 1]
+        ok = ok and bool((key[1:] >= key[:-1]).all())
+        ys = ep.exchange_rows(xr * 2.0, recv, send)                                        # "expert output" travels back
+        ok = ok and torch.equal(ys, xs * 2.0)
+        # bf16 rows travel as raw words
+        xb = xs.to(torch.bfloat16)
+        ok = ok and torch.equal(ep.exchange_rows(ep.exchange_rows(xb, send, recv), recv, send), xb)
+    full = ep.all_gather_rows(torch.full((El, 3), float(rank)).to(torch.bfloat16))
+    ok = ok and full.shape == (E, 3) and full[:, 0].tolist() == [0.0] * 4 + [1.0] * 4
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_expert_parallel_exchange_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_sharded_blocks_load_their_rows_of_a_full_checkpoint():
+    from align_anything_amd.params import ParamStore
+    st = ParamStore('cpu', torch.float32)
+    st.add('experts.w', (2, 3, 4), trainable=True, shard=(2, 8))
+    st.add('dense.w', (3, 4), trainable=True)
+    st.allocate()
+    assert st.specs['experts.w']['group'] == 'exp' and st.specs['dense.w']['group'] == 'mat'
+    full = torch.arange(8 * 3 * 4, dtype=torch.float32).view(8, 3, 4)
+    st.load_state_dict({'experts.w': full, 'dense.w': torch.ones(3, 4)})
+    assert torch.equal(st.p['experts.w'], full[2:4])
+    st.load_state_dict({'experts.w': full[2:4] + 1, 'dense.w': torch.ones(3, 4)})          # an already sharded tensor loads as is
+    assert torch.equal(st.p['experts.w'], full[2:4] + 1)
+    st.init_training()
+    assert st.trainable_groups() == ['mat', 'exp'] and st.gflat['exp'].numel() >= 24
