@@ -88,6 +88,14 @@ def qwen2_vl_7b(num_layers=28, vision_depth=32):
     return qwen2vl_cfg(text, vision, image_token_id=151655, mrope_section=[16, 24, 24], pad_token_id=151643)
 
 
+def qwen2_audio_7b(num_layers=32, audio_layers=32):
+    """Qwen2-Audio-7B-Instruct geometry (BASELINE.json config 4): Whisper-large-v3 style encoder (1280 x 32, 20 heads of 64, ffn 5120,
+    128 mel bins, 1500 positions -> 750 audio tokens per 30 s) + Qwen-7B decoder (32 x 4096, MHA 32, ffn 11008, V = 156032, q/k/v bias)."""
+    text = llama_cfg(4096, 11008, num_layers, 32, 32, 156032, rms_eps=1e-5, rope_theta=10000.0, max_position_embeddings=8192, attention_bias=True)
+    audio = qwen2audio_tower_cfg(1280, audio_layers, 20, 5120, num_mel_bins=128, max_source_positions=1500)
+    return qwen2audio_cfg(text, audio, audio_token_id=151646, pad_token_id=151643)
+
+
 def opt_125m():
     """facebook/opt-125m geometry (BASELINE.json config 1), dropout forced to 0 for parity."""
     return opt_cfg(768, 3072, 12, 12, 50272, 2048)

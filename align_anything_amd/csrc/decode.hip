@@ -12,15 +12,51 @@
 #define LOG2E_D 1.4426950408889634f
 
 // ------------------------------------------------------------------ skinny GEMM (M <= 16)
-template <int NWAVE>
+// PRO selects what the kernel does to its activation fragments on the way in -- the decode step's element-wise kernels folded
+// into the weight stream they precede (x is a few KB, L2-resident; the VALU work hides under the HBM stream):
+//   0: x as is
+//   1: RMSNorm.  rmsnorm(x)[k] = x[k] * rstd * w[k] with a per-row scalar rstd, so the kernel multiplies bf16(x[k] * w[k]) into the
+//      dot products, accumulates sum(x^2) from the very fragments it loads, and scales the finished dot product by rstd in the
+//      epilogue.  Rounding points differ from hf LlamaRMSNorm (w * bf16(x * rstd)) by bf16 noise; rollout sampling only.
+//   2: SwiGLU.  x = [gate | up] rows of width 2K; the fragment is bf16(bf16(silu(gate)) * up), exactly aa_swiglu_fwd's value.
+template <int PRO>
+__device__ __forceinline__ bf16x8 skinny_x(const bf16_t* __restrict__ xp, const bf16_t* __restrict__ nwp, int k, int K, float& ss) {
+    const u16x8 v = *reinterpret_cast<const u16x8*>(xp + k);
+    if constexpr (PRO == 1) {
+        const u16x8 nw = *reinterpret_cast<const u16x8*>(nwp + k);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f(v[j]);
+            ss += f * f;
+            o[j] = f2bf(f * bf2f(nw[j]));
+        }
+        return __builtin_bit_cast(bf16x8, o);
+    } else if constexpr (PRO == 2) {
+        const u16x8 u = *reinterpret_cast<const u16x8*>(xp + K + k);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gf = bf2f(v[j]);
+            o[j] = f2bf(rbf(gf / (1.f + expf(-gf))) * bf2f(u[j]));
+        }
+        return __builtin_bit_cast(bf16x8, o);
+    } else {
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <int NWAVE, int PRO>
 __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                   const bf16_t* __restrict__ W, long ldw,
                                                                   bf16_t* __restrict__ out, long ldo,
                                                                   const bf16_t* __restrict__ bias,
                                                                   const bf16_t* __restrict__ residual, long ldr,
                                                                   int M, int N, int K,
-                                                                  const int* __restrict__ row_expert, long strideE, int x_div) {
+                                                                  const int* __restrict__ row_expert, long strideE, int x_div,
+                                                                  const bf16_t* __restrict__ norm_w, float eps) {
     __shared__ float red[NWAVE][16][17];
+    __shared__ float ssred[NWAVE][16];
     if (row_expert) {   // mixture-of-experts decode: blockIdx.y = routed row r = (token, choice); its own weight matrix, M = 1
         const int r = blockIdx.y;
         W += (long)row_expert[r] * strideE;
@@ -34,33 +70,43 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     const int mrow = min(l15, M - 1);
     const bf16_t* wp = W + (long)nrow * ldw + g * 8;
     const bf16_t* xp = x + (long)mrow * ldx + g * 8;
+    const bf16_t* nwp = PRO == 1 ? norm_w + g * 8 : nullptr;
+    float ss = 0.f;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     // wave w owns k in [w*kq, (w+1)*kq), kq = K/NWAVE rounded up to 32; 8 MFMA k-steps (256 k) per trip keep
     // 16 x 16-B loads per lane in flight (the weight stream is read exactly once: no LDS round trip)
     const int kq = ((K / NWAVE + 31) / 32) * 32;
     const int k_lo = wave * kq, k_hi = min(K, k_lo + kq);
     int k = k_lo;
-    for (; k + 256 <= k_hi; k += 256) {
-        bf16x8 wf[8], xf[8];
+    // fragments in flight per trip: 8 k-steps (256 k), 4 with the RMSNorm prologue (its raw x, norm weight and product
+    // fragments would otherwise push the kernel past 128 VGPRs and halve the waves that keep the HBM queue full)
+    constexpr int S = PRO == 1 ? 4 : 8;
+    for (; k + S * 32 <= k_hi; k += S * 32) {
+        bf16x8 wf[S], xf[S];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < S; ++s) {
             wf[s] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + k + s * 32));
-            xf[s] = *reinterpret_cast<const bf16x8*>(xp + k + s * 32);
+            xf[s] = skinny_x<PRO>(xp, nwp, k + s * 32, K, ss);
         }
 #pragma unroll
-        for (int s = 0; s < 8; s += 2) {
+        for (int s = 0; s < S; s += 2) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf[s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s + 1], xf[s + 1], acc1, 0, 0, 0);
         }
     }
     for (; k < k_hi; k += 32) {
         const bf16x8 wf = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + k));
-        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + k);
+        const bf16x8 xf = skinny_x<PRO>(xp, nwp, k, K, ss);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc0, 0, 0, 0);
     }
     // D[i = n (4g + r)][j = m (l15)]
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][l15] = acc0[r] + acc1[r];
+    if constexpr (PRO == 1) {      // lane (l15, g) holds row l15's sum of squares over its k-chunks: fold the 4 g groups
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (g == 0) ssred[wave][l15] = ss;
+    }
     __syncthreads();
     // thread t < 256 -> (m = t / 16, n = t % 16)
     const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
@@ -69,10 +115,31 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < NWAVE; ++w) v += red[w][nn][m];
+        if constexpr (PRO == 1) {
+            float q = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) q += ssred[w][m];
+            v *= rsqrtf(q / (float)K + eps);
+        }
         if (bias) v += bf2f(bias[n]);
         if (residual) v = rbf(v) + bf2f(residual[(long)m * ldr + n]);
         out[(long)m * ldo + n] = f2bf(v);
     }
+}
+
+template <int PRO>
+static void launch_skinny(const void* x, const void* W, void* out, int M, int N, int K, long ldx, long ldw, long ldo,
+                          const void* bias, const void* residual, long ldr, const void* norm_w, float eps, hipStream_t st) {
+    // few column strips (N/16 < ~3 per CU): split K over 8 waves so enough loads are in flight per CU
+    const bool wide = (N / 16) >= 768 || K < 2048;
+    if (wide)
+        hipLaunchKernelGGL((gemm_skinny_kernel<4, PRO>), dim3(aa_cdiv(N, 16)), dim3(256), 0, st,
+                           (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
+                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1, (const bf16_t*)norm_w, eps);
+    else
+        hipLaunchKernelGGL((gemm_skinny_kernel<8, PRO>), dim3(aa_cdiv(N, 16)), dim3(512), 0, st,
+                           (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
+                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1, (const bf16_t*)norm_w, eps);
 }
 
 extern "C" int aa_gemm_skinny_bf16(const void* x, const void* W, void* out, int M, int N, int K, long ldx,
@@ -81,17 +148,25 @@ extern "C" int aa_gemm_skinny_bf16(const void* x, const void* W, void* out, int 
     AA_REQUIRE(M >= 1 && M <= 16, "aa_gemm_skinny_bf16: M=%d must be in [1, 16] (use aa_gemm_bf16 beyond)", M);
     AA_REQUIRE(N > 0 && K > 0 && K % 32 == 0, "aa_gemm_skinny_bf16: K=%d must be a multiple of 32", K);
     AA_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0, "aa_gemm_skinny_bf16: ldx/ldw must be multiples of 8");
-    // few column strips (N/16 < ~3 per CU): split K over 8 waves so enough loads are in flight per CU
-    const bool wide = (N / 16) >= 768 || K < 2048;
-    if (wide)
-        hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(aa_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
-                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1);
-    else
-        hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3(aa_cdiv(N, 16)), dim3(512), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
-                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1);
+    launch_skinny<0>(x, W, out, M, N, K, ldx, ldw, ldo, bias, residual, ldr, nullptr, 0.f, (hipStream_t)stream);
     AA_CHECK_LAUNCH("aa_gemm_skinny_bf16");
+    return AA_OK;
+}
+
+// The same weight stream with the preceding element-wise kernel of the decode step folded in (see PRO above):
+// prologue 1 = RMSNorm(x; norm_w, eps) -> out = rmsnorm(x) W^T;  prologue 2 = SwiGLU, x = [gate | up] [M, 2K] -> out = swiglu(x) W^T.
+extern "C" int aa_gemm_skinny_fused_bf16(const void* x, const void* W, void* out, int M, int N, int K, long ldx, long ldw,
+                                         long ldo, const void* bias, const void* residual, long ldr, int prologue,
+                                         const void* norm_w, float eps, void* stream) {
+    AA_REQUIRE(M >= 1 && M <= 16, "aa_gemm_skinny_fused_bf16: M=%d must be in [1, 16]", M);
+    AA_REQUIRE(N > 0 && K > 0 && K % 32 == 0, "aa_gemm_skinny_fused_bf16: K=%d must be a multiple of 32", K);
+    AA_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0, "aa_gemm_skinny_fused_bf16: ldx/ldw must be multiples of 8");
+    AA_REQUIRE(prologue == 1 || prologue == 2, "aa_gemm_skinny_fused_bf16: prologue %d (1 = RMSNorm, 2 = SwiGLU)", prologue);
+    AA_REQUIRE(prologue != 1 || norm_w != nullptr, "aa_gemm_skinny_fused_bf16: the RMSNorm prologue needs norm_w");
+    AA_REQUIRE(prologue != 2 || ldx >= 2L * K, "aa_gemm_skinny_fused_bf16: the SwiGLU prologue reads [gate | up] rows of width 2K = %d", 2 * K);
+    if (prologue == 1) launch_skinny<1>(x, W, out, M, N, K, ldx, ldw, ldo, bias, residual, ldr, norm_w, eps, (hipStream_t)stream);
+    else launch_skinny<2>(x, W, out, M, N, K, ldx, ldw, ldo, bias, residual, ldr, nullptr, 0.f, (hipStream_t)stream);
+    AA_CHECK_LAUNCH("aa_gemm_skinny_fused_bf16");
     return AA_OK;
 }
 
@@ -102,28 +177,83 @@ extern "C" int aa_moe_gemv_bf16(const void* x, const void* W3, void* out, int R,
                                 const int* row_expert, long strideE, int x_div, void* stream) {
     AA_REQUIRE(R >= 1 && R <= 65535 && N > 0 && K > 0 && K % 32 == 0, "aa_moe_gemv_bf16: R=%d N=%d K=%d (K must be a multiple of 32)", R, N, K);
     AA_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && strideE % 8 == 0 && x_div >= 1 && row_expert != nullptr, "aa_moe_gemv_bf16: ldx/ldw/strideE must be multiples of 8");
-    hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(aa_cdiv(N, 16), R), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((gemm_skinny_kernel<4, 0>), dim3(aa_cdiv(N, 16), R), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x, ldx, (const bf16_t*)W3, ldw, (bf16_t*)out, ldo, (const bf16_t*)nullptr,
-                       (const bf16_t*)nullptr, 0, 1, N, K, row_expert, strideE, x_div);
+                       (const bf16_t*)nullptr, 0, 1, N, K, row_expert, strideE, x_div, (const bf16_t*)nullptr, 0.f);
     AA_CHECK_LAUNCH("aa_moe_gemv_bf16");
+    return AA_OK;
+}
+
+// ------------------------------------------------------------------ RoPE + KV-cache write of the new token
+// One pass over the fused [q | k | v] row of every sequence: q heads are rotated in place, k heads are rotated and written to
+// the cache slot of this position, v heads are copied there -- aa_rope_inplace + an index_put, without the round trip.
+// Rounding as aa_rope_inplace (hf apply_rotary_pos_emb in bf16): bf16(bf16(x*cos) + bf16(rotate_half(x)*sin)).
+__global__ __launch_bounds__(256) void decode_rope_cache_kernel(bf16_t* __restrict__ qkv, long ld, int H, int Hkv, int hd,
+                                                                const int* __restrict__ pos, const bf16_t* __restrict__ cos_t,
+                                                                const bf16_t* __restrict__ sin_t, bf16_t* __restrict__ cache,
+                                                                long ldc, int Tmax, const int64_t* __restrict__ slot, int N) {
+    const int half = hd >> 1, vph = half >> 3, heads = H + 2 * Hkv, kw = Hkv * hd;
+    const long total = (long)N * heads * vph;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int v = (int)(idx % vph);
+        const long t = idx / vph;
+        const int head = (int)(t % heads);
+        const int row = (int)(t / heads);
+        bf16_t* base = qkv + (long)row * ld + (long)head * hd + v * 8;
+        const u16x8 x1 = *reinterpret_cast<const u16x8*>(base);
+        const u16x8 x2 = *reinterpret_cast<const u16x8*>(base + half);
+        bf16_t* crow = cache + ((long)row * Tmax + slot[row]) * ldc;
+        if (head >= H + Hkv) {                 // value head: copy
+            bf16_t* dst = crow + kw + (long)(head - H - Hkv) * hd + v * 8;
+            *reinterpret_cast<u16x8*>(dst) = x1;
+            *reinterpret_cast<u16x8*>(dst + half) = x2;
+            continue;
+        }
+        const int p = pos[row];
+        const u16x8 c = *reinterpret_cast<const u16x8*>(cos_t + (long)p * half + v * 8);
+        const u16x8 s = *reinterpret_cast<const u16x8*>(sin_t + (long)p * half + v * 8);
+        u16x8 o1, o2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = bf2f(x1[j]), b = bf2f(x2[j]), cc = bf2f(c[j]), ss = bf2f(s[j]);
+            o1[j] = f2bf(rbf(a * cc) + rbf(-b * ss));
+            o2[j] = f2bf(rbf(b * cc) + rbf(a * ss));
+        }
+        bf16_t* dst = head < H ? base : crow + (long)(head - H) * hd + v * 8;
+        *reinterpret_cast<u16x8*>(dst) = o1;
+        *reinterpret_cast<u16x8*>(dst + half) = o2;
+    }
+}
+extern "C" int aa_decode_rope_cache(void* qkv, long ld, int N, int H, int Hkv, int hd, const int* pos, const void* cos_t,
+                                    const void* sin_t, void* cache, long ldc, int Tmax, const int64_t* slot, void* stream) {
+    AA_REQUIRE(N > 0 && H > 0 && Hkv > 0 && hd >= 16 && (hd & 15) == 0, "aa_decode_rope_cache: N=%d H=%d Hkv=%d head_dim %d (multiple of 16)", N, H, Hkv, hd);
+    AA_REQUIRE((ld & 7) == 0 && (ldc & 7) == 0 && ldc >= 2L * Hkv * hd && Tmax > 0, "aa_decode_rope_cache: ld / ldc must be multiples of 8, ldc >= 2*Hkv*hd");
+    const long total = (long)N * (H + 2 * Hkv) * (hd >> 4);
+    hipLaunchKernelGGL(decode_rope_cache_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, ld, H, Hkv,
+                       hd, pos, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)cache, ldc, Tmax, slot, N);
+    AA_CHECK_LAUNCH("aa_decode_rope_cache");
     return AA_OK;
 }
 
 // ------------------------------------------------------------------ decode attention
 // q [N, H*HD] (one new token per sequence), caches Kc/Vc token-major [N, Tmax, Hkv*HD] (row stride ldc),
 // valid keys of sequence n: [start[n], len[n]).  One workgroup per (head, sequence); HD/8 lanes per key,
-// 64/(HD/8) keys per wave step, 4 waves stride the keys; partial (m, l, acc) merged through LDS.
-template <int HD>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, long ldq,
-                                                          const bf16_t* __restrict__ Kc,
-                                                          const bf16_t* __restrict__ Vc, long ldc, int Tmax,
-                                                          const int* __restrict__ start,
-                                                          const int* __restrict__ len, bf16_t* __restrict__ o,
-                                                          long ldo, int H, int Hkv, float scale) {
+// 64/(HD/8) keys per wave step, NW waves stride the keys two steps at a time (both steps' K and V rows are requested before
+// either is used: the loop is a chain of dependent online-softmax updates, so memory parallelism has to come from the
+// loads); partial (m, l, acc) merged through LDS.  NW = 8 when H*N alone would leave CUs idle and waves scarce
+// (a 4-sequence rollout of a 32-head model is 128 workgroups on 256 CUs), 4 otherwise.
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __restrict__ q, long ldq,
+                                                              const bf16_t* __restrict__ Kc,
+                                                              const bf16_t* __restrict__ Vc, long ldc, int Tmax,
+                                                              const int* __restrict__ start,
+                                                              const int* __restrict__ len, bf16_t* __restrict__ o,
+                                                              long ldo, int H, int Hkv, float scale) {
     constexpr int LPK = HD / 8;        // lanes per key
     constexpr int KPW = 64 / LPK;      // keys per wave step
-    __shared__ float sm_m[4][KPW], sm_l[4][KPW];
-    __shared__ float sm_acc[4][KPW][HD];
+    constexpr int STRIDE = NW * KPW;   // keys per workgroup step
+    __shared__ float sm_m[NW][KPW], sm_l[NW][KPW];
+    __shared__ float sm_acc[NW][KPW][HD];
     const int h = blockIdx.x, n = blockIdx.y, hk = h / (H / Hkv);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPK, kg = lane / LPK;
@@ -137,39 +267,42 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     float m = -INFINITY, l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bf16_t* kb = Kc + (long)n * Tmax * ldc + hk * HD + sub * 8;
     const bf16_t* vb = Vc + (long)n * Tmax * ldc + hk * HD + sub * 8;
-    for (int j0 = s0 + wave * KPW; j0 < s1; j0 += 4 * KPW) {
-        const int j = j0 + kg;
-        const bool ok = j < s1;
-        const int jr = ok ? j : s1 - 1;
-        const u16x8 kk = *reinterpret_cast<const u16x8*>(kb + (long)jr * ldc);
-        const u16x8 vv = *reinterpret_cast<const u16x8*>(vb + (long)jr * ldc);
-        float s = 0.f;
+    for (int j0 = s0 + wave * KPW; j0 < s1; j0 += 2 * STRIDE) {
+        const int ja = j0 + kg, jb = ja + STRIDE;
+        const bool oka = ja < s1, okb = jb < s1;
+        const long ra = oka ? ja : s1 - 1, rb = okb ? jb : s1 - 1;
+        const u16x8 ka = *reinterpret_cast<const u16x8*>(kb + ra * ldc);
+        const u16x8 kb2 = *reinterpret_cast<const u16x8*>(kb + rb * ldc);
+        const u16x8 va = *reinterpret_cast<const u16x8*>(vb + ra * ldc);
+        const u16x8 vb2 = *reinterpret_cast<const u16x8*>(vb + rb * ldc);
+        float sa = 0.f, sb = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += qv[e] * bf2f(kk[e]);
+        for (int e = 0; e < 8; ++e) { sa += qv[e] * bf2f(ka[e]); sb += qv[e] * bf2f(kb2[e]); }
 #pragma unroll
-        for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        s = ok ? s : -INFINITY;
-        const float mn = fmaxf(m, s);
+        for (int off = LPK / 2; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
+        sa = oka ? sa : -INFINITY;
+        sb = okb ? sb : -INFINITY;
+        const float mn = fmaxf(m, fmaxf(sa, sb));
         const float ms = (mn == -INFINITY) ? 0.f : mn;
-        const float alpha = exp2f(m - ms), p = exp2f(s - ms);
+        const float alpha = exp2f(m - ms), pa = exp2f(sa - ms), pb = exp2f(sb - ms);
         m = mn;
-        l = l * alpha + p;
+        l = l * alpha + pa + pb;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = acc[e] * alpha + p * bf2f(vv[e]);
+        for (int e = 0; e < 8; ++e) acc[e] = acc[e] * alpha + pa * bf2f(va[e]) + pb * bf2f(vb2[e]);
     }
     if (sub == 0) { sm_m[wave][kg] = m; sm_l[wave][kg] = l; }
 #pragma unroll
     for (int e = 0; e < 8; ++e) sm_acc[wave][kg][sub * 8 + e] = acc[e];
     __syncthreads();
-    // merge the 4*KPW partial states; thread d < HD owns output dim d
+    // merge the NW*KPW partial states; thread d < HD owns output dim d
     if (threadIdx.x < HD) {
         const int d = threadIdx.x;
         float gm = -INFINITY;
-        for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < NW; ++w)
             for (int c = 0; c < KPW; ++c) gm = fmaxf(gm, sm_m[w][c]);
         float tl = 0.f, ta = 0.f;
         if (gm > -INFINITY) {
-            for (int w = 0; w < 4; ++w)
+            for (int w = 0; w < NW; ++w)
                 for (int c = 0; c < KPW; ++c) {
                     const float f = exp2f(sm_m[w][c] - gm);
                     tl += sm_l[w][c] * f;
@@ -188,12 +321,13 @@ extern "C" int aa_attn_decode(const void* q, long ldq, const void* Kc, const voi
     AA_REQUIRE(len != nullptr, "aa_attn_decode: len (keys per sequence) is required");
     AA_REQUIRE((ldq | ldc | ldo) % 8 == 0, "aa_attn_decode: leading dims must be multiples of 8");
     hipStream_t st = (hipStream_t)stream;
-    if (hd == 128)
-        hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(H, N), dim3(256), 0, st, (const bf16_t*)q, ldq,
-                           (const bf16_t*)Kc, (const bf16_t*)Vc, ldc, Tmax, start, len, (bf16_t*)o, ldo, H, Hkv, scale);
-    else
-        hipLaunchKernelGGL(attn_decode_kernel<64>, dim3(H, N), dim3(256), 0, st, (const bf16_t*)q, ldq,
-                           (const bf16_t*)Kc, (const bf16_t*)Vc, ldc, Tmax, start, len, (bf16_t*)o, ldo, H, Hkv, scale);
+    const bool few = (long)H * N < 512;      // fewer than two workgroups per CU: give each one 8 waves
+#define AA_LAUNCH_ATTN_DECODE(HD_, NW_)                                                                                       \
+    hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_>), dim3(H, N), dim3(NW_ * 64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)Kc, \
+                       (const bf16_t*)Vc, ldc, Tmax, start, len, (bf16_t*)o, ldo, H, Hkv, scale)
+    if (hd == 128) { if (few) AA_LAUNCH_ATTN_DECODE(128, 8); else AA_LAUNCH_ATTN_DECODE(128, 4); }
+    else { if (few) AA_LAUNCH_ATTN_DECODE(64, 8); else AA_LAUNCH_ATTN_DECODE(64, 4); }
+#undef AA_LAUNCH_ATTN_DECODE
     AA_CHECK_LAUNCH("aa_attn_decode");
     return AA_OK;
 }
@@ -265,73 +399,145 @@ extern "C" int aa_argmax_rows(const void* logits, long ld, int rows, int V, cons
 
 // temperature + nucleus (top-p) sampling, HF semantics (TemperatureLogitsWarper, TopPLogitsWarper with
 // min_tokens_to_keep = 1): keep the smallest set of highest-probability tokens whose mass reaches top_p, renormalise,
-// draw with the caller's uniform u[row].  The kept set is found by bisection on the probability threshold (no sort);
-// the draw walks the vocabulary in index order.
-__global__ __launch_bounds__(256) void sample_top_p_kernel(const bf16_t* __restrict__ logits, long ld, int V,
+// draw with the caller's uniform u[row].  The kept set is found by searching the probability threshold (no sort): 10 rounds
+// of an 8-way split (7 candidate thresholds per pass over the row = the 2^-30 resolution of 30 bisections in a third of the
+// passes); the draw walks the vocabulary in index order.
+// One 512-thread workgroup per row; thread t owns the contiguous slice [t*per, (t+1)*per) and re-reads it from L2 with 16-B
+// loads in each of the 13 passes (a register-resident copy spills at 1024 x 40 and at 512 x 80 values -- measured, not kept).
+__device__ __forceinline__ void load_scores8(const bf16_t* __restrict__ x, const uint8_t* __restrict__ seen, int i0, int e, float pen,
+                                             float inv_temp, float (&v)[8]) {
+    if (i0 + 8 <= e && ((reinterpret_cast<uintptr_t>(x + i0) & 15) == 0)) {
+        const u16x8 t = *reinterpret_cast<const u16x8*>(x + i0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bf2f(t[j]);
+        if (seen) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (seen[i0 + j]) v[j] = v[j] < 0.f ? v[j] * pen : v[j] / pen;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= inv_temp;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (i0 + j < e) ? penalised(x, seen, i0 + j, pen) * inv_temp : -INFINITY;
+    }
+}
+
+__global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restrict__ logits, long ld, int V,
                                                            float inv_temp, float top_p,
                                                            const float* __restrict__ u,
                                                            const uint8_t* __restrict__ seen_all, long ld_seen, float pen,
                                                            int64_t* __restrict__ out) {
-    __shared__ float red[8];
-    __shared__ float part[256];
+    constexpr int NT = 512, NW = NT / 64, KS = 7;
+    __shared__ float red[NW];
+    __shared__ float red7[NW][KS];
+    __shared__ float wtot[NW];
+    __shared__ int sel[2];
     const bf16_t* x = logits + (long)blockIdx.x * ld;
     const uint8_t* seen = seen_all ? seen_all + (long)blockIdx.x * ld_seen : nullptr;
+    const int per = (((V + NT - 1) / NT) + 7) & ~7;
+    const int b = min(V, (int)threadIdx.x * per), e = min(V, b + per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- pass 1: maximum of the scores (penalty, temperature applied)
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < V; i += 256) mx = fmaxf(mx, penalised(x, seen, i, pen) * inv_temp);
-    mx = block_max<256>(mx, red);
+#pragma unroll 2
+    for (int i = b; i < e; i += 8) {
+        float v[8];
+        load_scores8(x, seen, i, e, pen, inv_temp, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[j]);
+    }
+    mx = block_max<NT>(mx, red);
+    // ---- pass 2: partition function
     float z = 0.f;
-    for (int i = threadIdx.x; i < V; i += 256) z += expf(penalised(x, seen, i, pen) * inv_temp - mx);
-    z = block_sum<256>(z, red);
+#pragma unroll 2
+    for (int i = b; i < e; i += 8) {
+        float v[8];
+        load_scores8(x, seen, i, e, pen, inv_temp, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z += expf(v[j] - mx);          // exp(-inf) = 0 for the slots beyond e
+    }
+    z = block_sum<NT>(z, red);
     const float invz = 1.f / z;
-    // bisection: largest tau with mass(p >= tau) >= top_p   (p in (0, 1], p_max = 1/z * 1)
-    float lo = 0.f, hi = invz;  // mass(p >= lo) = 1 >= top_p ; hi = p_max
+    // ---- threshold search: largest tau with mass(p >= tau) >= top_p   (p in (0, 1], p_max = 1/z)
+    float lo = 0.f, hi = invz, kept = 1.f;     // mass(p >= 0) = 1 >= top_p
     if (top_p < 1.f) {
-        for (int it = 0; it < 30; ++it) {
-            const float tau = 0.5f * (lo + hi);
-            float ms = 0.f;
-            for (int i = threadIdx.x; i < V; i += 256) {
-                const float p = expf(penalised(x, seen, i, pen) * inv_temp - mx) * invz;
-                ms += (p >= tau) ? p : 0.f;
+        for (int it = 0; it < 10; ++it) {
+            const float step = (hi - lo) * 0.125f;
+            float ms[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) ms[k] = 0.f;
+#pragma unroll 2
+            for (int i = b; i < e; i += 8) {
+                float v[8];
+                load_scores8(x, seen, i, e, pen, inv_temp, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pj = expf(v[j] - mx) * invz;
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) ms[k] += (pj >= lo + step * (float)(k + 1)) ? pj : 0.f;
+                }
             }
-            ms = block_sum<256>(ms, red);
-            if (ms >= top_p) lo = tau; else hi = tau;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) ms[k] = wave_sum(ms[k]);
+            __syncthreads();
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < KS; ++k) red7[wave][k] = ms[k];
+            }
+            __syncthreads();
+            float nlo = lo, nhi = lo + step, nkept = kept;      // no candidate keeps enough mass -> the answer is below the first one
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += red7[w][k];
+                if (t >= top_p) { nlo = lo + step * (float)(k + 1); nhi = (k + 1 < KS) ? lo + step * (float)(k + 2) : hi; nkept = t; }
+            }
+            lo = nlo; hi = nhi; kept = nkept;
         }
     }
     const float tau = lo;
-    float kept = 0.f;
-    for (int i = threadIdx.x; i < V; i += 256) {
-        const float p = expf(penalised(x, seen, i, pen) * inv_temp - mx) * invz;
-        kept += (p >= tau) ? p : 0.f;
-    }
-    kept = block_sum<256>(kept, red);
-    const float target = u[blockIdx.x] * kept;
-    // each thread owns a contiguous slice so the walk is in index order
-    const int per = (V + 255) / 256;
-    const int b = threadIdx.x * per, e = min(V, b + per);
+    // ---- the draw: first index (vocabulary order) whose running kept mass exceeds u * kept
     float mine = 0.f;
-    for (int i = b; i < e; ++i) {
-        const float p = expf(penalised(x, seen, i, pen) * inv_temp - mx) * invz;
-        mine += (p >= tau) ? p : 0.f;
+#pragma unroll 2
+    for (int i = b; i < e; i += 8) {
+        float v[8];
+        load_scores8(x, seen, i, e, pen, inv_temp, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float pj = expf(v[j] - mx) * invz; mine += (pj >= tau) ? pj : 0.f; }
     }
-    part[threadIdx.x] = mine;
+    if (top_p >= 1.f) kept = block_sum<NT>(mine, red);          // (the search did not run: kept = total mass as summed here)
+    const float target = u[blockIdx.x] * kept;
+    float incl = mine;                                           // inclusive scan over the threads: wave level, then wave totals
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (threadIdx.x == 0) { sel[0] = NT; sel[1] = -1; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float c = 0.f; int t = 0;
-        for (; t < 255; ++t) { if (c + part[t] > target) break; c += part[t]; }
-        part[0] = c; red[0] = __int_as_float(t);
-    }
+    if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    const int owner = __float_as_int(red[0]);
-    if (threadIdx.x == owner) {
-        float c = part[0];
+    float base = 0.f;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    incl += base;
+    if (incl > target && mine > 0.f) atomicMin(&sel[0], (int)threadIdx.x);
+    if (mine > 0.f) atomicMax(&sel[1], (int)threadIdx.x);
+    __syncthreads();
+    // u ~ 1 and rounding can leave the total a hair under the target: then the last kept token is drawn
+    const int owner = sel[0] < NT ? sel[0] : sel[1];
+    if ((int)threadIdx.x == owner) {
+        float c = incl - mine;
         int pick = -1, last_kept = -1;
-        for (int i = b; i < e; ++i) {
-            const float p = expf(penalised(x, seen, i, pen) * inv_temp - mx) * invz;
-            if (p >= tau) { last_kept = i; c += p; if (c > target) { pick = i; break; } }
+        for (int i = b; i < e && pick < 0; i += 8) {
+            float v[8];
+            load_scores8(x, seen, i, e, pen, inv_temp, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pj = expf(v[j] - mx) * invz;
+                if (pick < 0 && i + j < e && pj >= tau) { last_kept = i + j; c += pj; if (c > target) pick = i + j; }
+            }
         }
-        if (pick < 0) pick = last_kept >= 0 ? last_kept : (e > b ? b : V - 1);
-        out[blockIdx.x] = pick;
+        out[blockIdx.x] = pick >= 0 ? pick : (last_kept >= 0 ? last_kept : b);
     }
+    if (owner < 0 && threadIdx.x == 0) out[blockIdx.x] = 0;      // unreachable: p_max >= tau always keeps one token
 }
 extern "C" int aa_sample_top_p(const void* logits, long ld, int rows, int V, float temperature, float top_p,
                                const float* uniform, const uint8_t* seen, long ld_seen, float repetition_penalty,
@@ -339,7 +545,7 @@ extern "C" int aa_sample_top_p(const void* logits, long ld, int rows, int V, flo
     AA_REQUIRE(rows > 0 && V > 0, "aa_sample_top_p: bad shape rows=%d V=%d", rows, V);
     AA_REQUIRE(repetition_penalty > 0.f, "aa_sample_top_p: repetition_penalty must be > 0");
     AA_REQUIRE(temperature > 0.f && top_p > 0.f && top_p <= 1.f, "aa_sample_top_p: temperature=%f / top_p=%f out of range", temperature, top_p);
-    hipLaunchKernelGGL(sample_top_p_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
+    hipLaunchKernelGGL(sample_top_p_kernel, dim3(rows), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
                        1.f / temperature, top_p, uniform, seen, ld_seen, repetition_penalty, out);
     AA_CHECK_LAUNCH("aa_sample_top_p");
     return AA_OK;

@@ -146,19 +146,16 @@ class LlamaStack:
         qw, kw = H * hd, Hkv * hd
         N = x.shape[0]
         self._tables(Tmax)
-        rows = torch.arange(N, device=x.device)
         for li, L in enumerate(self.layers):
-            n1, _ = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
-            qkv = ops.linear_small(n1, L['qkv'].w, bias=L['qkv'].b)
-            ops.rope_(qkv, 0, H + Hkv, hd, pos, self.cos, self.sin)
+            # RoPE and the cache write are one pass over the new row (aa_decode_rope_cache); linear_small(norm= / swiglu=) runs the
+            # RMSNorm / SwiGLU kernels itself unless ops.DECODE_FUSED folds them into the weight stream (measured slower, off)
+            qkv = ops.linear_small(x, L['qkv'].w, bias=L['qkv'].b, norm=(P[L['ln1']], eps))
             cl = cache[li]
-            cl.view(N, Tmax, 2 * kw).index_put_((rows, t), qkv[:, qw:])   # t: device int64 [N] (graph-capturable)
+            ops.decode_rope_cache(qkv, H, Hkv, hd, pos, self.cos, self.sin, cl, Tmax, t)   # t: device int64 [N] (graph-capturable)
             attn = ops.attn_decode(qkv[:, :qw], cl, cl[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
             x_mid = ops.linear_small(attn, L['o'].w, residual=x)
-            n2, _ = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
-            gu = ops.linear_small(n2, L['gu'].w)
-            act = ops.swiglu_fwd(gu)
-            x = ops.linear_small(act, L['down'].w, residual=x_mid)
+            gu = ops.linear_small(x_mid, L['gu'].w, norm=(P[L['ln2']], eps))
+            x = ops.linear_small(gu, L['down'].w, residual=x_mid, swiglu=True)
         return x
 
     @staticmethod
@@ -369,6 +366,8 @@ class LMHead:
         """Logits of a handful of rows (decode): norm + skinny lm_head."""
         P = self.store.p
         if self.kind == 'rms':
+            if x_rows.dtype == bf16:
+                return ops.linear_small(x_rows, self._w(), norm=(P[self.norm_w], self.eps))     # norm folded into the lm_head stream
             n, _ = ops.rmsnorm_fwd(x_rows, P[self.norm_w], self.eps)
         else:
             n, _, _ = ops.layernorm_fwd(x_rows, P[self.norm_w], P[self.norm_b], self.eps, want_stats=False)

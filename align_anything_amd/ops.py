@@ -6,6 +6,8 @@ CPU or falls back to torch ops.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .lib import call
@@ -643,17 +645,51 @@ def adamw_flat_(master, m, v, p16, g, lr, beta1, beta2, eps, wd, step, gscale=1.
 
 
 # ------------------------------------------------------------------ decode
-def linear_small(x, w, bias=None, residual=None, out=None):
-    """y = x W^T for a handful of rows (decode): HBM-streaming skinny kernel for M <= 16, tiled GEMM beyond."""
-    M, K = x.shape
+# decode step: fold RMSNorm / SwiGLU into the weight streams that consume them (aa_gemm_skinny_fused_bf16).  Measured SLOWER at 7B
+# (7.0 vs 5.6 ms per position at 4 sequences: the prologue's VALU work and registers cost the stream more than the two saved
+# launches, profiles/r01_bench_decode_7b_v2.json) -> off by default, AA_DECODE_FUSED=1 selects it.
+DECODE_FUSED = os.environ.get('AA_DECODE_FUSED', '0') == '1'
+
+
+def linear_small(x, w, bias=None, residual=None, out=None, norm=None, swiglu=False):
+    """y = x W^T for a handful of rows (decode): HBM-streaming skinny kernel for M <= 16, tiled GEMM beyond.
+    norm = (weight, eps): y = RMSNorm(x) W^T; swiglu: x = [gate | up], y = (silu(gate) * up) W^T -- folded into the weight
+    stream for M <= 16 (aa_gemm_skinny_fused_bf16), the separate kernels beyond."""
+    M = x.shape[0]
     N = w.shape[0]
+    if M > 16 or not DECODE_FUSED:
+        if norm is not None:
+            x = rmsnorm_fwd(x, norm[0], norm[1])[0]
+        if swiglu:
+            x = swiglu_fwd(x)
+        norm, swiglu = None, False
+    K = x.shape[1] // 2 if swiglu else x.shape[1]
     if M > 16:
         return gemm(x, w, out=out, bias=bias, residual=residual)
     out = torch.empty((M, N), dtype=bf16, device=x.device) if out is None else out
     ldr = residual.stride(0) if residual is not None else 0
+    if norm is not None or swiglu:
+        if norm is not None and swiglu:
+            raise RuntimeError('linear_small: one prologue at a time')
+        if w.shape[1] != K:
+            raise RuntimeError(f'linear_small: weight {tuple(w.shape)} does not match K = {K}')
+        call('aa_gemm_skinny_fused_bf16', x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, x.stride(0), w.stride(0), out.stride(0),
+             _p(bias), _p(residual), ldr, 1 if norm is not None else 2, _p(norm[0]) if norm is not None else None,
+             float(norm[1]) if norm is not None else 0.0, stream())
+        return out
     call('aa_gemm_skinny_bf16', x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, x.stride(0), w.stride(0),
          out.stride(0), _p(bias), _p(residual), ldr, stream())
     return out
+
+
+def decode_rope_cache(qkv, H, Hkv, hd, pos, cos_t, sin_t, cache, Tmax, slot):
+    """RoPE on the q / k heads of the new token's fused row + write of (k, v) into cache slot `slot[n]` (int64 [N])."""
+    N = qkv.shape[0]
+    if cos_t.dtype != bf16 or qkv.dtype != bf16 or cache.dtype != bf16 or slot.dtype != torch.int64 or pos.dtype != torch.int32:
+        raise RuntimeError('decode_rope_cache: bf16 activations / tables / cache, int32 pos, int64 slot')
+    call('aa_decode_rope_cache', qkv.data_ptr(), qkv.stride(0), N, int(H), int(Hkv), int(hd), pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(),
+         cache.data_ptr(), cache.stride(0), int(Tmax), slot.data_ptr(), stream())
+    return qkv
 
 
 def moe_gemv(x, w3, row_expert, x_div):

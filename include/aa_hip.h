@@ -212,6 +212,17 @@ int aa_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
 /* out[M<=16, N] = x[M,K] W[N,K]^T (+bias) (+residual, HF rounding); K % 32 == 0; HBM-streaming skinny GEMM */
 int aa_gemm_skinny_bf16(const void* x, const void* W, void* out, int M, int N, int K, long ldx, long ldw, long ldo,
                         const void* bias, const void* residual, long ldr, void* stream);
+/* the same weight stream with the element-wise kernel that precedes it in a decode step folded in:
+ * prologue 1: out = RMSNorm(x; norm_w, eps) W^T (hf LlamaRMSNorm, models/llama/modeling_llama.py:50-68; the per-row rstd is applied
+ *             to the finished dot products, so rounding differs from the unfused chain by bf16 noise -- rollout sampling only);
+ * prologue 2: x = [gate | up] rows [M, 2K], out = (silu(gate) * up) W^T (LlamaMLP :154-158), same values as aa_swiglu_fwd. */
+int aa_gemm_skinny_fused_bf16(const void* x, const void* W, void* out, int M, int N, int K, long ldx, long ldw, long ldo,
+                              const void* bias, const void* residual, long ldr, int prologue, const void* norm_w, float eps,
+                              void* stream);
+/* new token of every sequence: rotate the q heads of the fused [q|k|v] row in place (aa_rope_inplace rounding), rotate the k heads
+ * into cache[(n*Tmax + slot[n]), 0:Hkv*hd] and copy the v heads to [.., Hkv*hd:2*Hkv*hd] (HF DynamicCache.update) */
+int aa_decode_rope_cache(void* qkv, long ld, int N, int H, int Hkv, int hd, const int* pos, const void* cos_t, const void* sin_t,
+                         void* cache, long ldc, int Tmax, const int64_t* slot, void* stream);
 /* sparse-MoE block at one token per sequence (hf:models/qwen3_moe/modeling_qwen3_moe.py:210-283 during generate):
  * out[r, :] = x[r / x_div, :] W3[row_expert[r]]^T for R routed rows r = (token, choice); W3 [E, N, K], expert stride strideE */
 int aa_moe_gemv_bf16(const void* x, const void* W3, void* out, int R, int N, int K, long ldx, long ldw, long ldo,

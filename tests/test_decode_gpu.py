@@ -24,6 +24,55 @@ def test_skinny_gemm(M):
         assert_close(out, ref, rtol=1e-2, atol=2e-2, what='skinny bias+residual')
 
 
+@pytest.mark.parametrize('M', [1, 5, 16])
+def test_skinny_gemm_with_folded_rmsnorm_and_swiglu(M):
+    """aa_gemm_skinny_fused_bf16: the decode step's RMSNorm / SwiGLU ride in the weight stream that consumes them."""
+    from align_anything_amd import ops
+    ops.DECODE_FUSED = True          # the folded variant is off by default (slower at 7B); exercised here
+    try:
+        _check_folded(ops, M)
+    finally:
+        ops.DECODE_FUSED = False
+
+
+def _check_folded(ops, M):
+    for (N, K) in [(64, 128), (320, 640), (12288, 4096), (4096, 11008), (1000, 2048)]:
+        x, w = randn_bf16(M, K, scale=1.5, seed=1), randn_bf16(N, K, scale=0.05, seed=2)
+        nw = (1 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16).to(dev())
+        bias, res = randn_bf16(N, seed=4), randn_bf16(M, N, seed=5)
+        # RMSNorm prologue vs fp64 math of norm -> matmul; the unfused native chain is the second yardstick
+        xn = x.double() * torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-5) * nw.double()
+        ref = xn @ w.double().t()
+        got = ops.linear_small(x, w, norm=(nw, 1e-5))
+        unf = ops.linear_small(ops.rmsnorm_fwd(x, nw, 1e-5)[0], w)
+        tol = 1e-2 * float(ref.abs().mean()) + 1e-3
+        assert_close(got, ref.float(), rtol=1e-2, atol=tol, what=f'rmsnorm->skinny {M}x{N}x{K}')
+        assert float((got.double() - ref).abs().mean()) < 1.5 * float((unf.double() - ref).abs().mean()) + 1e-4      # no worse than the unfused chain
+        got = ops.linear_small(x, w, bias=bias, residual=res, norm=(nw, 1e-5))
+        assert_close(got, (ref.float() + bias.float()).to(torch.bfloat16).float() + res.float(), rtol=1e-2, atol=tol + 2e-2, what='rmsnorm->skinny bias+residual')
+        # SwiGLU prologue: the fragments are exactly aa_swiglu_fwd's values and the accumulation order is the same -> bit-equal
+        gu = randn_bf16(M, 2 * K, seed=6)
+        got = ops.linear_small(gu, w, residual=res, swiglu=True)
+        assert torch.equal(got, ops.linear_small(ops.swiglu_fwd(gu), w, residual=res)), (M, N, K)
+
+
+def test_decode_rope_cache_equals_rope_then_index_put():
+    from align_anything_amd import ops
+    from align_anything_amd.modeling import rope_tables
+    for (N, H, Hkv, hd, Tmax) in [(3, 4, 2, 64, 50), (16, 32, 32, 128, 40), (5, 28, 4, 128, 33)]:
+        kw = Hkv * hd
+        qkv = randn_bf16(N, (H + 2 * Hkv) * hd, seed=1)
+        cos, sin = rope_tables(64, hd, 10000.0, dev(), torch.bfloat16)
+        pos = torch.randint(0, 64, (N,), generator=torch.Generator().manual_seed(2)).to(torch.int32).to(dev())
+        slot = torch.randint(0, Tmax, (N,), generator=torch.Generator().manual_seed(3)).to(dev())
+        a, ca = qkv.clone(), randn_bf16(N * Tmax, 2 * kw, seed=4)
+        b, cb = qkv.clone(), ca.clone()
+        ops.decode_rope_cache(a, H, Hkv, hd, pos, cos, sin, ca, Tmax, slot)
+        ops.rope_(b, 0, H + Hkv, hd, pos, cos, sin)
+        cb.view(N, Tmax, 2 * kw).index_put_((torch.arange(N, device=dev()), slot), b[:, H * hd:])
+        assert torch.equal(a[:, :H * hd], b[:, :H * hd]) and torch.equal(ca, cb), (N, H, Hkv, hd)
+
+
 @pytest.mark.parametrize('hd,H,Hkv', [(128, 4, 4), (64, 4, 2)])
 def test_decode_attention_vs_reference(hd, H, Hkv):
     from align_anything_amd import ops
