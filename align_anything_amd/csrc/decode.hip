@@ -19,6 +19,7 @@
 //      dot products, accumulates sum(x^2) from the very fragments it loads, and scales the finished dot product by rstd in the
 //      epilogue.  Rounding points differ from hf LlamaRMSNorm (w * bf16(x * rstd)) by bf16 noise; rollout sampling only.
 //   2: SwiGLU.  x = [gate | up] rows of width 2K; the fragment is bf16(bf16(silu(gate)) * up), exactly aa_swiglu_fwd's value.
+//   3: x as is, W pre-arranged by aa_swizzle_weights_bf16 so that every fragment load of a wave is 1 KB contiguous (below).
 template <int PRO>
 __device__ __forceinline__ bf16x8 skinny_x(const bf16_t* __restrict__ xp, const bf16_t* __restrict__ nwp, int k, int K, float& ss) {
     const u16x8 v = *reinterpret_cast<const u16x8*>(xp + k);
@@ -46,6 +47,23 @@ __device__ __forceinline__ bf16x8 skinny_x(const bf16_t* __restrict__ xp, const 
     }
 }
 
+// S k-steps of 32: all 2S fragment loads are issued before the first MFMA consumes one
+template <int PRO, int S>
+__device__ __forceinline__ void skinny_trip(const bf16_t* __restrict__ wp, const bf16_t* __restrict__ xp, const bf16_t* __restrict__ nwp,
+                                            int k, int K, float& ss, f32x4& acc0, f32x4& acc1) {
+    bf16x8 wf[S], xf[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        wf[s] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (PRO == 3 ? (long)(k + s * 32) * 16 : (long)(k + s * 32))));
+        xf[s] = skinny_x<PRO>(xp, nwp, k + s * 32, K, ss);
+    }
+#pragma unroll
+    for (int s = 0; s < S; s += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s + 1], xf[s + 1], acc1, 0, 0, 0);
+    }
+}
+
 template <int NWAVE, int PRO>
 __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                   const bf16_t* __restrict__ W, long ldw,
@@ -68,7 +86,8 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     const int n0 = blockIdx.x * 16;
     const int nrow = min(n0 + l15, N - 1);
     const int mrow = min(l15, M - 1);
-    const bf16_t* wp = W + (long)nrow * ldw + g * 8;
+    // PRO 3 = strip-major swizzled weights: [N/16][K/32][lane = n%16 + 16*(k%32/8)][8] -- a wave's fragment load is 1 KB contiguous
+    const bf16_t* wp = PRO == 3 ? W + (long)blockIdx.x * 16 * K + lane * 8 : W + (long)nrow * ldw + g * 8;
     const bf16_t* xp = x + (long)mrow * ldx + g * 8;
     const bf16_t* nwp = PRO == 1 ? norm_w + g * 8 : nullptr;
     float ss = 0.f;
@@ -78,24 +97,14 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     const int kq = ((K / NWAVE + 31) / 32) * 32;
     const int k_lo = wave * kq, k_hi = min(K, k_lo + kq);
     int k = k_lo;
-    // fragments in flight per trip: 8 k-steps (256 k), 4 with the RMSNorm prologue (its raw x, norm weight and product
-    // fragments would otherwise push the kernel past 128 VGPRs and halve the waves that keep the HBM queue full)
+    // fragments in flight per trip: 8 k-steps (256 k); 4 with the RMSNorm prologue (its raw x, norm weight and product
+    // fragments would otherwise push the kernel past 128 VGPRs and halve the waves that keep the HBM queue full).
+    // (16 in flight -- 512 k per trip -- measured no different: 4.19 vs 4.20 ms per position, tools/gpu_skinny_ab.sh.)
     constexpr int S = PRO == 1 ? 4 : 8;
-    for (; k + S * 32 <= k_hi; k += S * 32) {
-        bf16x8 wf[S], xf[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            wf[s] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + k + s * 32));
-            xf[s] = skinny_x<PRO>(xp, nwp, k + s * 32, K, ss);
-        }
-#pragma unroll
-        for (int s = 0; s < S; s += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s + 1], xf[s + 1], acc1, 0, 0, 0);
-        }
-    }
-    for (; k < k_hi; k += 32) {
-        const bf16x8 wf = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + k));
+    for (; k + S * 32 <= k_hi; k += S * 32) skinny_trip<PRO, S>(wp, xp, nwp, k, K, ss, acc0, acc1);
+    for (; k + 64 <= k_hi; k += 64) skinny_trip<PRO, 2>(wp, xp, nwp, k, K, ss, acc0, acc1);
+    if (k < k_hi) {
+        const bf16x8 wf = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (PRO == 3 ? (long)k * 16 : (long)k)));
         const bf16x8 xf = skinny_x<PRO>(xp, nwp, k, K, ss);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc0, 0, 0, 0);
     }
@@ -167,6 +176,42 @@ extern "C" int aa_gemm_skinny_fused_bf16(const void* x, const void* W, void* out
     if (prologue == 1) launch_skinny<1>(x, W, out, M, N, K, ldx, ldw, ldo, bias, residual, ldr, norm_w, eps, (hipStream_t)stream);
     else launch_skinny<2>(x, W, out, M, N, K, ldx, ldw, ldo, bias, residual, ldr, nullptr, 0.f, (hipStream_t)stream);
     AA_CHECK_LAUNCH("aa_gemm_skinny_fused_bf16");
+    return AA_OK;
+}
+
+// Strip-major weight layout for the rollout.  In the row-major [N, K] matrix a wave's MFMA fragment load touches 16 rows x 64 B
+// (half a cache line per row per instruction); measured, that access pattern -- not bytes in flight -- is what holds the strip
+// kernel at 4.5 of 8 TB/s.  Weights do not change during a rollout (hundreds of positions per optimizer step), so `generate`
+// re-arranges them once per call into [N/16 strips][K/32 blocks][lane = n%16 + 16*(k%32/8)][8 elements]: the very order the
+// lanes consume, 1 KB contiguous per wave load.  Same operands, same MFMA order -> bit-identical results to the row-major kernel.
+__global__ __launch_bounds__(256) void swizzle_weights_kernel(const bf16_t* __restrict__ W, long ld, bf16_t* __restrict__ out, int N, int K) {
+    const long kblocks = K >> 5;
+    const long total = (long)((N + 15) >> 4) * kblocks * 64;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int lane = (int)(idx & 63);
+        const long t = idx >> 6;
+        const long kb = t % kblocks, strip = t / kblocks;
+        const long n = strip * 16 + (lane & 15);
+        const long k = kb * 32 + (lane >> 4) * 8;
+        u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (n < N) v = *reinterpret_cast<const u16x8*>(W + n * ld + k);
+        *reinterpret_cast<u16x8*>(out + idx * 8) = v;
+    }
+}
+extern "C" int aa_swizzle_weights_bf16(const void* W, long ld, void* out, int N, int K, void* stream) {
+    AA_REQUIRE(N > 0 && K > 0 && K % 32 == 0 && ld % 8 == 0, "aa_swizzle_weights_bf16: N=%d K=%d ld=%ld (K %% 32 == 0, ld %% 8 == 0)", N, K, ld);
+    const long total = (long)((N + 15) >> 4) * (K >> 5) * 64;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(swizzle_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K);
+    AA_CHECK_LAUNCH("aa_swizzle_weights_bf16");
+    return AA_OK;
+}
+extern "C" int aa_gemm_skinny_swz_bf16(const void* x, const void* Wswz, void* out, int M, int N, int K, long ldx, long ldo,
+                                       const void* bias, const void* residual, long ldr, void* stream) {
+    AA_REQUIRE(M >= 1 && M <= 16, "aa_gemm_skinny_swz_bf16: M=%d must be in [1, 16]", M);
+    AA_REQUIRE(N > 0 && K > 0 && K % 32 == 0 && ldx % 8 == 0, "aa_gemm_skinny_swz_bf16: N=%d K=%d (K %% 32 == 0), ldx %% 8 == 0", N, K);
+    launch_skinny<3>(x, Wswz, out, M, N, K, ldx, K, ldo, bias, residual, ldr, nullptr, 0.f, (hipStream_t)stream);
+    AA_CHECK_LAUNCH("aa_gemm_skinny_swz_bf16");
     return AA_OK;
 }
 

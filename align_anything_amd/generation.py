@@ -51,7 +51,11 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
     x = model.forward_stream(input_ids, attention_mask, pixel_values, save=False, position_ids=position_ids,
                              kv_sink=kv_sink, **mm)
     last_rows = torch.arange(N, device=dev) * T + (T - 1)
-    logits = model.head.logits_rows(ops.embed_fwd(last_rows, x))
+    # the weights are frozen for the whole rollout: stacks that support it hand the strip kernel copies in its own order
+    dw = stack.prepare_decode(N) if hasattr(stack, 'prepare_decode') else None
+    step_kw = {} if dw is None else {'dw': dw}
+    head_w = model.head.prepare_decode(N) if (dw is not None and hasattr(model.head, 'prepare_decode')) else None
+    logits = model.head.logits_rows(ops.embed_fwd(last_rows, x), head_w) if head_w is not None else model.head.logits_rows(ops.embed_fwd(last_rows, x))
 
     out = torch.full((N, Tmax), pad_token_id, dtype=torch.int64, device=dev)
     out[:, :T] = input_ids
@@ -87,8 +91,8 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
             st['unfinished'].logical_and_(nxt != eos)
         emb_pos = (st['pos'] + 2) if is_opt else None        # OPT learned positions carry an offset of 2
         xt = model.embed_tokens(nxt, emb_pos)
-        xt = stack.decode_step(xt, cache, st['tslot'], Tmax, st['pos'], start, st['length'])
-        st['logits'].copy_(model.head.logits_rows(xt))
+        xt = stack.decode_step(xt, cache, st['tslot'], Tmax, st['pos'], start, st['length'], **step_kw)
+        st['logits'].copy_(model.head.logits_rows(xt, head_w) if head_w is not None else model.head.logits_rows(xt))
         st['tslot'].add_(1); st['pos'].add_(1); st['length'].add_(1); st['step'].add_(1)
 
     graph = None

@@ -14,6 +14,8 @@ Memory: nothing is recomputed -- 288 GB HBM holds all saved activations of a 7B 
 """
 from __future__ import annotations
 
+import os
+
 import math
 
 import torch
@@ -138,9 +140,30 @@ class LlamaStack:
     def kv_width(self):
         return 2 * self.cfg['num_kv_heads'] * self.cfg['head_dim']
 
-    def decode_step(self, x, cache, t, Tmax, pos, start, length):
+    def prepare_decode(self, N):
+        """Rollout-only copies of the layer matrices in the strip kernel's own order (ops.SwizzledWeight; +1 x the bf16 weights
+        for the duration of `generate`, the weights being frozen during a rollout).  None beyond 16 sequences (tiled GEMM path)
+        or with AA_DECODE_SWIZZLE=0."""
+        if N > 16 or self.store.dtype != bf16 or os.environ.get('AA_DECODE_SWIZZLE', '1') == '0' or ops.DECODE_FUSED:
+            return None
+        # the storage persists between rollouts (same sizes every time: no allocator churn of a second copy of the model per
+        # `generate`); every call refreshes it from the current weights -- one pass over the matrices, ~5 ms at 7B
+        if getattr(self, '_dw', None) is None:
+            self._dw = [{k: ops.SwizzledWeight(L[k].w) for k in ('qkv', 'o', 'gu', 'down')} for L in self.layers]
+        else:
+            for L, W in zip(self.layers, self._dw):
+                for k, sw in W.items():
+                    sw.update(L[k].w)
+        return self._dw
+
+    def release_decode(self):
+        """Free the rollout-only weight copies."""
+        self._dw = None
+
+    def decode_step(self, x, cache, t, Tmax, pos, start, length, dw=None):
         """One new token per sequence (x [N, h]) against the KV cache (csrc/decode.hip): every GEMM streams its
-        weight once through the skinny kernel.  cache[l]: [N*Tmax, 2*kw] (keys | values), slot t is written here."""
+        weight once through the skinny kernel.  cache[l]: [N*Tmax, 2*kw] (keys | values), slot t is written here.
+        dw: `prepare_decode` result (per-layer swizzled matrices) or None."""
         c, P = self.cfg, self.store.p
         H, Hkv, hd, eps = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps']
         qw, kw = H * hd, Hkv * hd
@@ -149,8 +172,17 @@ class LlamaStack:
         for li, L in enumerate(self.layers):
             # RoPE and the cache write are one pass over the new row (aa_decode_rope_cache); linear_small(norm= / swiglu=) runs the
             # RMSNorm / SwiGLU kernels itself unless ops.DECODE_FUSED folds them into the weight stream (measured slower, off)
-            qkv = ops.linear_small(x, L['qkv'].w, bias=L['qkv'].b, norm=(P[L['ln1']], eps))
             cl = cache[li]
+            if dw is not None:       # strip-major weight copies: the element-wise kernels run on their own
+                W = dw[li]
+                qkv = ops.linear_small(ops.rmsnorm_fwd(x, P[L['ln1']], eps)[0], W['qkv'], bias=L['qkv'].b)
+                ops.decode_rope_cache(qkv, H, Hkv, hd, pos, self.cos, self.sin, cl, Tmax, t)
+                attn = ops.attn_decode(qkv[:, :qw], cl, cl[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
+                x_mid = ops.linear_small(attn, W['o'], residual=x)
+                gu = ops.linear_small(ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)[0], W['gu'])
+                x = ops.linear_small(ops.swiglu_fwd(gu), W['down'], residual=x_mid)
+                continue
+            qkv = ops.linear_small(x, L['qkv'].w, bias=L['qkv'].b, norm=(P[L['ln1']], eps))
             ops.decode_rope_cache(qkv, H, Hkv, hd, pos, self.cos, self.sin, cl, Tmax, t)   # t: device int64 [N] (graph-capturable)
             attn = ops.attn_decode(qkv[:, :qw], cl, cl[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
             x_mid = ops.linear_small(attn, L['o'].w, residual=x)
@@ -362,16 +394,26 @@ class LMHead:
             n, _, _ = ops.layernorm_fwd(x_last, P[self.norm_w], P[self.norm_b], self.eps, want_stats=False)
         return ops.gemm(n, self._w())
 
-    def logits_rows(self, x_rows):
-        """Logits of a handful of rows (decode): norm + skinny lm_head."""
+    def prepare_decode(self, N):
+        """lm_head in the strip kernel's order for the rollout (see LlamaStack.prepare_decode)."""
+        if N > 16 or self.store.dtype != bf16 or os.environ.get('AA_DECODE_SWIZZLE', '1') == '0' or ops.DECODE_FUSED:
+            return None
+        if getattr(self, '_dw', None) is None:
+            self._dw = ops.SwizzledWeight(self._w())
+        else:
+            self._dw.update(self._w())
+        return self._dw
+
+    def logits_rows(self, x_rows, w=None):
+        """Logits of a handful of rows (decode): norm + skinny lm_head (w: `prepare_decode` result or None)."""
         P = self.store.p
         if self.kind == 'rms':
-            if x_rows.dtype == bf16:
-                return ops.linear_small(x_rows, self._w(), norm=(P[self.norm_w], self.eps))     # norm folded into the lm_head stream
+            if x_rows.dtype == bf16 and w is None:
+                return ops.linear_small(x_rows, self._w(), norm=(P[self.norm_w], self.eps))     # (norm folded in with ops.DECODE_FUSED)
             n, _ = ops.rmsnorm_fwd(x_rows, P[self.norm_w], self.eps)
         else:
             n, _, _ = ops.layernorm_fwd(x_rows, P[self.norm_w], P[self.norm_b], self.eps, want_stats=False)
-        return ops.linear_small(n, self._w())
+        return ops.linear_small(n, self._w() if w is None else w)
 
     def hidden_all(self, x_last):
         P = self.store.p

@@ -651,6 +651,28 @@ def adamw_flat_(master, m, v, p16, g, lr, beta1, beta2, eps, wd, step, gscale=1.
 DECODE_FUSED = os.environ.get('AA_DECODE_FUSED', '0') == '1'
 
 
+class SwizzledWeight:
+    """A [N, K] bf16 matrix re-arranged by aa_swizzle_weights_bf16 for the rollout's strip kernel (1 KB contiguous per wave load)."""
+
+    def __init__(self, w):
+        if w.dim() != 2 or w.dtype != bf16 or w.stride(1) != 1 or w.shape[1] % 32:
+            raise RuntimeError(f'SwizzledWeight: expected a row-major bf16 [N, K] matrix with K % 32 == 0, got {tuple(w.shape)} {w.dtype}')
+        self.N, self.K = int(w.shape[0]), int(w.shape[1])
+        self.data = torch.empty(((self.N + 15) // 16) * 16 * self.K, dtype=bf16, device=w.device)
+        self.update(w)
+
+    def update(self, w):
+        """Re-arrange the current values of `w` into the existing storage (the weights moved since the last rollout)."""
+        if tuple(w.shape) != (self.N, self.K) or w.dtype != bf16 or w.stride(1) != 1:
+            raise RuntimeError(f'SwizzledWeight.update: expected bf16 {(self.N, self.K)}, got {tuple(w.shape)} {w.dtype}')
+        call('aa_swizzle_weights_bf16', w.data_ptr(), w.stride(0), self.data.data_ptr(), self.N, self.K, stream())
+        return self
+
+    @property
+    def shape(self):
+        return (self.N, self.K)
+
+
 def linear_small(x, w, bias=None, residual=None, out=None, norm=None, swiglu=False):
     """y = x W^T for a handful of rows (decode): HBM-streaming skinny kernel for M <= 16, tiled GEMM beyond.
     norm = (weight, eps): y = RMSNorm(x) W^T; swiglu: x = [gate | up], y = (silu(gate) * up) W^T -- folded into the weight
@@ -664,6 +686,15 @@ def linear_small(x, w, bias=None, residual=None, out=None, norm=None, swiglu=Fal
             x = swiglu_fwd(x)
         norm, swiglu = None, False
     K = x.shape[1] // 2 if swiglu else x.shape[1]
+    if isinstance(w, SwizzledWeight):
+        if M > 16 or norm is not None or swiglu:
+            raise RuntimeError('linear_small: swizzled weights serve the plain M <= 16 strip kernel only')
+        if w.K != K:
+            raise RuntimeError(f'linear_small: weight {w.shape} does not match K = {K}')
+        out = torch.empty((M, N), dtype=bf16, device=x.device) if out is None else out
+        call('aa_gemm_skinny_swz_bf16', x.data_ptr(), w.data.data_ptr(), out.data_ptr(), M, N, K, x.stride(0), out.stride(0), _p(bias),
+             _p(residual), residual.stride(0) if residual is not None else 0, stream())
+        return out
     if M > 16:
         return gemm(x, w, out=out, bias=bias, residual=residual)
     out = torch.empty((M, N), dtype=bf16, device=x.device) if out is None else out

@@ -219,6 +219,12 @@ int aa_gemm_skinny_bf16(const void* x, const void* W, void* out, int M, int N, i
 int aa_gemm_skinny_fused_bf16(const void* x, const void* W, void* out, int M, int N, int K, long ldx, long ldw, long ldo,
                               const void* bias, const void* residual, long ldr, int prologue, const void* norm_w, float eps,
                               void* stream);
+/* rollout-only weight layout: out[((n/16)*(K/32) + k/32)*512 + ((n%16) + 16*((k%32)/8))*8 + k%8] = W[n, k] (rows beyond N zero; out holds
+ * ceil(N/16)*16*K elements) -- every fragment load of aa_gemm_skinny_swz_bf16 is then 1 KB contiguous.  `generate` builds it once per call
+ * (the weights are frozen for the whole rollout); results are bit-identical to aa_gemm_skinny_bf16 on the row-major matrix. */
+int aa_swizzle_weights_bf16(const void* W, long ld, void* out, int N, int K, void* stream);
+int aa_gemm_skinny_swz_bf16(const void* x, const void* Wswz, void* out, int M, int N, int K, long ldx, long ldo, const void* bias,
+                            const void* residual, long ldr, void* stream);
 /* new token of every sequence: rotate the q heads of the fused [q|k|v] row in place (aa_rope_inplace rounding), rotate the k heads
  * into cache[(n*Tmax + slot[n]), 0:Hkv*hd] and copy the v heads to [.., Hkv*hd:2*Hkv*hd] (HF DynamicCache.update) */
 int aa_decode_rope_cache(void* qkv, long ld, int N, int H, int Hkv, int hd, const int* pos, const void* cos_t, const void* sin_t,

@@ -25,6 +25,25 @@ def test_skinny_gemm(M):
 
 
 @pytest.mark.parametrize('M', [1, 5, 16])
+def test_skinny_gemm_on_strip_major_weights_is_bit_identical(M):
+    """aa_swizzle_weights_bf16 + aa_gemm_skinny_swz_bf16 (the rollout's weight layout): same operands, same MFMA order."""
+    from align_anything_amd import ops
+    for (N, K) in [(64, 128), (320, 640), (1000, 2048), (12288, 4096), (4096, 11008), (32064, 4096)]:
+        x, w = randn_bf16(M, K, seed=1), randn_bf16(N, K, scale=0.1, seed=2)
+        bias, res = randn_bf16(N, seed=3), randn_bf16(M, N, seed=4)
+        sw = ops.SwizzledWeight(w)
+        assert sw.shape == (N, K) and sw.data.numel() == (N + 15) // 16 * 16 * K
+        # the layout itself (integer work): element (n, k) sits at ((n/16)*(K/32) + k/32)*512 + ((n%16) + 16*((k%32)/8))*8 + k%8
+        n_i = torch.tensor([0, 1, 15, 16, N - 1, N // 2]); k_i = torch.tensor([0, 7, 8, 31, 32, K - 1])
+        off = ((n_i // 16) * (K // 32) + k_i // 32) * 512 + ((n_i % 16) + 16 * ((k_i % 32) // 8)) * 8 + k_i % 8
+        assert torch.equal(sw.data.cpu()[off], w.cpu()[n_i, k_i])
+        assert torch.equal(ops.linear_small(x, sw), ops.linear_small(x, w)), (M, N, K)
+        assert torch.equal(ops.linear_small(x, sw, bias=bias, residual=res), ops.linear_small(x, w, bias=bias, residual=res)), (M, N, K)
+    with pytest.raises(RuntimeError):
+        ops.linear_small(randn_bf16(17, 128, seed=1), ops.SwizzledWeight(randn_bf16(64, 128, seed=2)))
+
+
+@pytest.mark.parametrize('M', [1, 5, 16])
 def test_skinny_gemm_with_folded_rmsnorm_and_swiglu(M):
     """aa_gemm_skinny_fused_bf16: the decode step's RMSNorm / SwiGLU ride in the weight stream that consumes them."""
     from align_anything_amd import ops
@@ -209,7 +228,16 @@ def test_generate_greedy_llava_with_image_prefill():
     sd = state_dict_from_golden(z, 'w.')
     ids, mask, pix = T(z['input_ids'])[:, :30].clone(), T(z['attention_mask'])[:, :30].clone(), T(z['pixel_values'])
     fn = lambda i, a: om.llava_logits(sd, cfg, i, a, pix)
-    _check_greedy(m, fn, ids, mask, 8, None, 301, 'llava', pixel_values=pix.to(dev()))
+    import os
+    seq = _check_greedy(m, fn, ids, mask, 8, None, 301, 'llava', pixel_values=pix.to(dev()))
+    # the rollout ran on strip-major weight copies (LlamaStack.prepare_decode); the row-major kernels give the same tokens
+    assert m.stack.prepare_decode(4) is not None
+    os.environ['AA_DECODE_SWIZZLE'] = '0'
+    try:
+        assert m.stack.prepare_decode(4) is None
+        assert torch.equal(_check_greedy(m, fn, ids, mask, 8, None, 301, 'llava_rowmajor', pixel_values=pix.to(dev())), seq)
+    finally:
+        del os.environ['AA_DECODE_SWIZZLE']
 
 
 def test_generate_sampling_runs_and_respects_length_cap():
