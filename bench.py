@@ -241,8 +241,8 @@ def main():
             try:
                 with open(os.path.join(ROOT, 'profiles', 'r01_gemm_traffic.json')) as f:
                     traffic = json.load(f)['gemm_hbm_bytes_per_launch']
-            except Exception:
-                pass
+            except (OSError, KeyError, ValueError):
+                pass              # the profile is not in this checkout: traffic stays null
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel<BM,BN,...> (csrc/gemm.hip), all launches of the timed steps',
                                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                                'traffic': traffic, 'traffic_unit': 'HBM bytes per GEMM launch (PMC, profiles/r01_gemm_traffic.json)',

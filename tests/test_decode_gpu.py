@@ -255,3 +255,23 @@ def test_generate_sampling_runs_and_respects_length_cap():
     g = torch.Generator(device='cuda').manual_seed(0)
     c = generate(m, ids, mask, max_length=32, do_sample=True, temperature=0.8, top_p=0.9, pad_token_id=1, generator=g, repetition_penalty=1.3)
     assert c.shape == (4, 32) and torch.equal(c[:, :20], ids) and not torch.equal(c, a)
+
+
+def test_generate_replaying_a_hipgraph_gives_the_same_tokens():
+    """generate(use_graph=True): one decode position captured once and replayed (state lives in static device buffers)."""
+    from align_anything_amd.generation import generate
+    from align_anything_amd.modeling import build_model
+    for fixture, cfg, pad, pix_key in (('opt_tiny_dpo.npz', tiny_opt_cfg(), 1, None), ('llava_tiny_dpo.npz', tiny_llava_cfg(), 301, 'pixel_values')):
+        z = load_golden(fixture)
+        m = build_model(cfg, 'cuda:0', trainable=False)
+        m.load_state_dict(state_dict_from_golden(z, 'w.', torch.bfloat16))
+        n = 24 if pix_key is None else 30
+        ids, mask = T(z['input_ids'])[:, :n].to(dev()), T(z['attention_mask'])[:, :n].to(dev())
+        kw = dict(max_new_tokens=10, pad_token_id=pad, pixel_values=T(z[pix_key]).to(dev()) if pix_key else None)
+        for sample in (False, True):
+            outs = []
+            for ug in (False, True):
+                g = torch.Generator(device='cuda').manual_seed(7)
+                outs.append(generate(m, ids, mask, do_sample=sample, temperature=0.9, top_p=0.8, generator=g, use_graph=ug, **kw))
+                assert generate.last_used_graph == ug, (fixture, sample, ug)
+            assert torch.equal(outs[0], outs[1]), (fixture, sample)

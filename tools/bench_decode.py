@@ -19,7 +19,7 @@ from align_anything_amd import ops
 quick = os.environ.get('AA_BENCH_DECODE_QUICK') == '1'      # one configuration, default kernels: the run rocprofv3 wraps
 cases = itertools.product(((4, 512, 32),) if os.environ.get("AA_BENCH_DECODE_AB") != "1" else ((4, 512, 64), (16, 512, 64)), (False,)) if quick else itertools.product(((4, 512, 64), (16, 512, 64), (16, 1536, 64)), (False,))
 for (N, Tp, new), fused in cases:
-    ops.DECODE_FUSED = fused; ug = False
+    ops.DECODE_FUSED = fused; ug = os.environ.get('AA_BENCH_DECODE_GRAPH') == '1'
     ids = torch.randint(3, 32000, (N, Tp), device=dev)
     mask = torch.ones_like(ids)
     # every timed call is preceded by an identical untimed one: buffers of the same sizes come back from torch's caching
