@@ -212,3 +212,83 @@ def test_cached_input_pipeline_reproduces_the_reference_collator_batch():
         raise RuntimeError('loader failed')
     with pytest.raises(RuntimeError, match='loader failed'):
         list(DevicePrefetcher(boom(), 'cpu'))
+
+
+def test_span_and_tail_windows_match_the_reference_slicing():
+    """trainers/common.py::build_span_window / build_tail_window are the index plans of
+    `gather_log_probabilities(logits[:, :-1], ids[:, 1:])[:, start:]` (text_to_text/ppo.py:339-356) and of
+    `logits[idx, :-1][-R:]` x `ids[idx, 1:][-R:]` (text_image_to_text/ppo.py:233-241): integer work, exact."""
+    from align_anything_amd.trainers.common import build_span_window, build_tail_window, pad_rows
+    g = torch.Generator().manual_seed(0)
+    N, T, start = 3, 17, 5
+    ids = torch.randint(0, 100, (N, T), generator=g)
+    pos_code = torch.arange(N * T).view(N, T)                       # stands for "hidden state at (n, t)"
+    w = build_span_window(ids, start)
+    assert (w['N'], w['T'], w['W'], w['rows'], w['rows_pad']) == (N, T, T - 1 - start, N * (T - 1 - start), 64)
+    rows = w['rows']
+    assert torch.equal(w['row_idx'][:rows], pos_code[:, :-1][:, start:].reshape(-1))
+    assert torch.equal(w['labels'][:rows], ids[:, 1:][:, start:].reshape(-1))
+    inv = w['inv_map']
+    assert inv.numel() == 64 and int((inv >= 0).sum()) == rows and torch.equal(inv[w['row_idx'][:rows]].long(), torch.arange(rows))
+    with pytest.raises(ValueError):
+        build_span_window(ids, T - 1)
+    R = [4, 1, 16]
+    t = build_tail_window(ids, R)
+    assert t['rows'] == sum(R) and t['max_len'] == 16 and t['seq_off'].tolist() == [0, 4, 5, 21]
+    for n in range(N):
+        a, b = int(t['seq_off'][n]), int(t['seq_off'][n + 1])
+        assert torch.equal(t['row_idx'][a:b], pos_code[n, :-1][-R[n]:])
+        assert torch.equal(t['labels'][a:b], ids[n, 1:][-R[n]:])
+        assert torch.equal(t['flat_to_padded'][a:b], n * 16 + torch.arange(R[n]))
+    for bad in ([4, 1], [0, 1, 2], [4, 1, 17]):
+        with pytest.raises(ValueError):
+            build_tail_window(ids, bad)
+    d = pad_rows(torch.ones(2, 3), 64)
+    assert d.shape == (64,) and float(d.sum()) == 6.0 and float(d[6:].abs().sum()) == 0.0
+
+
+def test_native_qwen2vl_rope_index_reproduces_hf_position_ids():
+    """modeling.qwen2vl_rope_index (the product's host-side get_rope_index) against the position ids / rope deltas HF produced
+    for the reference fixture: integer work, bit-exact; and the oracle's restatement agrees with both."""
+    from align_anything_amd.modeling import qwen2vl_rope_index
+    from oracle import models as om
+    from tests.util import load_golden
+    z = load_golden('qwen2vl_tiny_dpo.npz')
+    ids, am = torch.from_numpy(z['input_ids']), torch.from_numpy(z['attention_mask'])
+    grid = [[int(v) for v in r] for r in z['image_grid_thw']]
+    from tests.util import tiny_qwen2vl_cfg
+    cfg = tiny_qwen2vl_cfg()
+    pos, deltas = qwen2vl_rope_index(ids, am, grid, cfg['image_token_id'], cfg['vision']['spatial_merge_size'])
+    want = z['position_ids']
+    valid = z['attention_mask'].astype(bool)
+    assert pos.shape == want.shape
+    assert (pos[:, valid] == want[:, valid]).all()                      # HF leaves pad positions at 1, the native table at 0: never read
+    assert (deltas.reshape(-1) == z['rope_deltas'].reshape(-1)).all()
+    o_pos, o_del = om.qwen2vl_rope_index(ids, am, grid, cfg['image_token_id'], cfg['vision']['spatial_merge_size'])
+    assert (np.asarray(o_pos)[:, valid] == pos[:, valid]).all() and (np.asarray(o_del).reshape(-1) == deltas.reshape(-1)).all()
+    with pytest.raises(ValueError):
+        qwen2vl_rope_index(ids, am, [[1, 2, 2]] * len(grid), cfg['image_token_id'], cfg['vision']['spatial_merge_size'])
+
+
+def test_from_hf_config_covers_every_native_backbone():
+    """configs.from_hf_config reads what AnyModel.from_pretrained reads from config.json (models/model_registry.py:134-175)."""
+    import transformers as tf
+    from align_anything_amd import configs
+    c = configs.from_hf_config(tf.OPTConfig(hidden_size=64, ffn_dim=128, num_hidden_layers=2, num_attention_heads=2, vocab_size=99, max_position_embeddings=77))
+    assert (c['kind'], c['hidden_size'], c['ffn_dim'], c['num_layers'], c['num_heads'], c['vocab_size'], c['max_position_embeddings']) == ('opt', 64, 128, 2, 2, 99, 77)
+    c = configs.from_hf_config(tf.LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2, vocab_size=321))
+    assert (c['kind'], c['num_kv_heads'], c['head_dim'], c['attention_bias']) == ('llama', 2, 32, False)
+    c = configs.from_hf_config(tf.Qwen2Config(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=321))
+    assert c['kind'] == 'llama' and c['attention_bias'] is True and c['head_dim'] == 64
+    moe = tf.Qwen3MoeConfig(hidden_size=128, moe_intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=320,
+                            num_experts=8, num_experts_per_tok=2, head_dim=64, norm_topk_prob=True)
+    c = configs.from_hf_config(moe)
+    assert (c['kind'], c['num_experts'], c['num_experts_per_tok'], c['moe_intermediate_size'], c['head_dim'], c['norm_topk_prob']) == ('qwen3moe', 8, 2, 64, 64, True)
+    moe.mlp_only_layers = [0]
+    with pytest.raises(ValueError):
+        configs.from_hf_config(moe)
+    with pytest.raises(ValueError):
+        configs.from_hf_config(tf.GPT2Config())
+    # the named 7B geometries carry the published sizes
+    assert configs.qwen2_audio_7b()['audio']['d_model'] == 1280 and configs.qwen2_audio_7b()['text']['vocab_size'] == 156032
+    assert configs.qwen2_vl_7b()['text']['mrope_section'] == [16, 24, 24] and configs.llava_1_5_7b()['text']['vocab_size'] == 32064
