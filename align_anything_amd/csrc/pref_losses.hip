@@ -168,3 +168,25 @@ extern "C" int aa_window_kl(const float* pol_logp, const float* ref_logp, int ro
     AA_CHECK_LAUNCH("aa_window_kl");
     return AA_OK;
 }
+
+// Supervised fine-tuning loss (trainers/text_to_text/sft.py:94-97 -> hf:loss/loss_utils.py ForCausalLMLoss): mean negative
+// log-likelihood over the label positions (labels != -100 after the shift; the host-side window holds exactly those rows).
+// loss = -sum(logp[0:rows]) / rows;  dlogp[r] = -1/rows for the real rows, 0 for the padding rows up to rows_pad.
+__global__ __launch_bounds__(256) void sft_loss_kernel(const float* __restrict__ logp, int rows, int rows_pad,
+                                                       float* __restrict__ loss, float* __restrict__ dlogp) {
+    __shared__ float red[8];
+    float p = 0.f;
+    for (int t = threadIdx.x; t < rows; t += 256) p += logp[t];
+    p = block_sum<256>(p, red);
+    if (threadIdx.x == 0) loss[0] = -p / (float)rows;
+    if (dlogp) {
+        const float g = -1.f / (float)rows;
+        for (int t = threadIdx.x; t < rows_pad; t += 256) dlogp[t] = t < rows ? g : 0.f;
+    }
+}
+extern "C" int aa_sft_loss_fwd_bwd(const float* logp, int rows, int rows_pad, float* loss_out, float* dlogp, void* stream) {
+    AA_REQUIRE(rows > 0 && rows_pad >= rows, "aa_sft_loss_fwd_bwd: rows=%d rows_pad=%d (a batch without label positions has no loss)", rows, rows_pad);
+    hipLaunchKernelGGL(sft_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, rows, rows_pad, loss_out, dlogp);
+    AA_CHECK_LAUNCH("aa_sft_loss_fwd_bwd");
+    return AA_OK;
+}

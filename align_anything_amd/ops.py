@@ -532,6 +532,14 @@ def pair_slice_index(ids, mask, seq_off, B):
     return lo, hi, ln, keep
 
 
+def sft_loss(logp, rows, want_grad=True):
+    """-mean(logp[:rows]) and its gradient w.r.t. the flat window log-probs (pad rows zero)."""
+    loss = torch.empty(1, dtype=torch.float32, device=logp.device)
+    dlogp = torch.empty_like(logp) if want_grad else None
+    call('aa_sft_loss_fwd_bwd', logp.data_ptr(), int(rows), logp.numel(), loss.data_ptr(), _p(dlogp), stream())
+    return loss[0], dlogp
+
+
 def pref_loss(kind, pol_logp, ref_logp, lo, hi, ln, keep, B, beta, p1=0.0, p2=0.0, p3=0.0, want_grad=True):
     dev = pol_logp.device
     out7 = torch.empty(7, dtype=torch.float32, device=dev)

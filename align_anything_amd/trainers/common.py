@@ -143,6 +143,31 @@ def build_tail_window(input_ids: torch.Tensor, response_lens):
             'flat_to_padded': torch.from_numpy(f2p).to(dev, non_blocking=True), 'labels': labels}
 
 
+def build_label_window(labels: torch.Tensor, ignore_index: int = -100, device=None):
+    """Rows of the supervised loss (hf:loss/loss_utils.py ForCausalLMLoss on datasets/text_to_text/supervised.py:96-99 labels):
+    hidden position j of row n predicts labels[n, j + 1]; every (n, j) with j < T - 1 and labels[n, j + 1] != ignore_index is one
+    row, in row-major order.  The labels come from the collator (host tensors): built on the host, like the other plans, and
+    placed on `device` (default: where the labels live -- pass the model's device for host-side labels)."""
+    lab = labels.detach().cpu().numpy()
+    N, T = lab.shape
+    tgt = lab[:, 1:]
+    n_i, j_i = np.nonzero(tgt != ignore_index)
+    rows = int(n_i.size)
+    if rows == 0:
+        raise ValueError('supervised batch without a single label position (all labels == ignore_index)')
+    rows_pad = pad64(rows)
+    Mp = (N * T + 63) // 64 * 64
+    row_idx = np.zeros(rows_pad, dtype=np.int64)
+    row_idx[:rows] = n_i * T + j_i
+    inv = np.full(Mp, -1, dtype=np.int32)
+    inv[row_idx[:rows]] = np.arange(rows, dtype=np.int32)
+    lbl = np.zeros(rows_pad, dtype=np.int64)
+    lbl[:rows] = tgt[n_i, j_i]
+    dev = labels.device if device is None else torch.device(device)
+    return {'N': N, 'T': T, 'rows': rows, 'rows_pad': rows_pad, 'row_idx': torch.from_numpy(row_idx).to(dev, non_blocking=True),
+            'inv_map': torch.from_numpy(inv).to(dev, non_blocking=True), 'labels': torch.from_numpy(lbl).to(dev, non_blocking=True)}
+
+
 def pad_rows(flat_2d: torch.Tensor, rows_pad: int) -> torch.Tensor:
     """[B, W] gradient -> flat fp32 [rows_pad] with zero tail (the pad rows of a window carry no gradient)."""
     out = torch.zeros(rows_pad, dtype=torch.float32, device=flat_2d.device)

@@ -105,6 +105,8 @@ int aa_pref_loss_fwd_bwd(int kind, const float* pol_logp, const float* ref_logp,
                          const int* len, const uint8_t* keep, int B, int total_rows, float scale_coeff, float p1,
                          float p2, float p3, float* out7, float* per_sample4B, float* dlogp, void* stream);
 int aa_window_kl(const float* pol_logp, const float* ref_logp, int rows, float denom, float* out, void* stream);
+/* trainers/text_to_text/sft.py:94-97 (hf ForCausalLMLoss): loss = -mean(logp) over the label rows of the window, dlogp = -1/rows (pad rows 0) */
+int aa_sft_loss_fwd_bwd(const float* logp, int rows, int rows_pad, float* loss_out, float* dlogp, void* stream);
 
 /* ---- transformer blocks (what model(**batch).logits executes, dpo.py:128) -------------------- */
 /* torch nn.Linear / its backward: C[M,N] (+)= op(A) op(B), fp32 accumulate, fused bias/act/residual.

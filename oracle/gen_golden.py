@@ -602,6 +602,43 @@ def gen_pref():
     np.savez_compressed(os.path.join(GOLD, 'opt_tiny_pref.npz'), **out)
 
 
+def gen_sft():
+    """Supervised fine-tuning: the reference's unmodified `SupervisedTrainer.loss` (trainers/text_to_text/sft.py:94-97 -> the HF
+    causal-LM loss of `model(**batch)`) on the tiny OPT of opt_tiny_dpo.npz, with the collator's label convention
+    (datasets/text_to_text/supervised.py:96-99, 154-157: prompt tokens and right padding = -100)."""
+    from transformers import OPTConfig, OPTForCausalLM
+    from align_anything.trainers.text_to_text.sft import SupervisedTrainer
+
+    z = np.load(os.path.join(GOLD, 'opt_tiny_dpo.npz'))
+    bits = lambda a: torch.from_numpy(a.astype(np.int16)).view(torch.bfloat16).float()
+    oc = OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=320,
+                   max_position_embeddings=128, word_embed_proj_dim=128, dropout=0.0, attention_dropout=0.0, pad_token_id=1)
+    policy = OPTForCausalLM(oc).eval()
+    policy.load_state_dict({k[2:]: bits(z[k]) for k in z.files if k.startswith('w.')})
+    g = torch.Generator().manual_seed(41)
+    N, T = 4, 36
+    ids = torch.full((N, T), 1, dtype=torch.long)
+    mask = torch.zeros((N, T), dtype=torch.long)
+    labels = torch.full((N, T), -100, dtype=torch.long)
+    for r, (n_tok, n_prompt) in enumerate(((36, 9), (30, 12), (21, 20), (33, 1))):      # right padding (padding_side='right', sft.py:80)
+        ids[r, :n_tok] = torch.randint(3, 320, (n_tok,), generator=g)
+        mask[r, :n_tok] = 1
+        labels[r, n_prompt:n_tok] = ids[r, n_prompt:n_tok]
+    batch = {'input_ids': ids, 'labels': labels, 'attention_mask': mask}
+    tr = SupervisedTrainer.__new__(SupervisedTrainer)
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    tr.model = policy
+    policy.zero_grad()
+    loss = tr.loss(batch)['loss']
+    loss.backward()
+    out = {'input_ids': ids.numpy(), 'attention_mask': mask.numpy(), 'labels': labels.numpy(), 'pad_token_id': np.array(1), 'loss': loss.detach().numpy()}
+    for n, p in policy.named_parameters():
+        if p.grad is not None:
+            out['g.' + n] = p.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'opt_tiny_sft.npz'), **out)
+    print('opt_tiny_sft.npz loss', float(loss))
+
+
 def gen_collator():
     """The reference's unmodified PreferenceCollator (datasets/text_image_to_text/preference.py:199-263) on synthetic
     samples with the stub processor: the batch the native cached pipeline (align_anything_amd/data.py) must reproduce."""
@@ -751,6 +788,7 @@ if __name__ == '__main__':
     gen_qwen2audio_dpo()
     gen_qwen3moe_dpo()
     gen_pref()
+    gen_sft()
     gen_collator()
     gen_grpo()
     gen_opt125m_curve()

@@ -226,3 +226,11 @@ def kto_loss(seq_logp, ref_seq_logp, input_ids, attention_mask, scale_coeff, sca
 def kto_kl(seq_logp, ref_seq_logp):
     """kto.py:74-81: mean over the padded tensors, clamped at 0."""
     return torch.clamp((seq_logp - ref_seq_logp).mean(), min=0.0)
+
+
+def sft_loss(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """trainers/text_to_text/sft.py:94-97 `outputs.loss` = hf:loss/loss_utils.py ForCausalLMLoss: logits upcast to fp32, labels shifted
+    left by one (the last position predicts nothing), mean cross-entropy over the positions whose label is not `ignore_index`."""
+    logits = logits.float()
+    shift = F.pad(labels, (0, 1), value=ignore_index)[..., 1:]
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), shift.reshape(-1), ignore_index=ignore_index, reduction='mean')

@@ -267,3 +267,27 @@ def test_qwen3moe_oracle_matches_reference_dpo_fixture():
             assert rel_err(sd[k[2:]].grad, T(z[k])) < 2e-3, k
             n += 1
     assert n >= 25
+
+
+def test_sft_oracle_matches_reference_supervised_loss():
+    """oracle.rl_math.sft_loss on the oracle OPT vs the reference's own SupervisedTrainer.loss (tests/golden/opt_tiny_sft.npz), and
+    the native label-window plan = exactly the positions that loss averages over."""
+    import pytest
+    from oracle import models as om
+    from oracle import rl_math as orl
+    from align_anything_amd.trainers.common import build_label_window
+    from tests.util import load_golden, state_dict_from_golden, tiny_opt_cfg
+    z, zw = load_golden('opt_tiny_sft.npz'), load_golden('opt_tiny_dpo.npz')
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ('input_ids', 'attention_mask', 'labels'))
+    sd = state_dict_from_golden(zw, 'w.')
+    logits = om.opt_logits(sd, tiny_opt_cfg(), ids, mask)
+    assert abs(float(orl.sft_loss(logits, labels)) - float(z['loss'])) < 2e-5
+    w = build_label_window(labels)
+    tgt = labels[:, 1:]
+    assert w['rows'] == int((tgt != -100).sum()) and w['rows_pad'] % 64 == 0
+    n_i, j_i = (tgt != -100).nonzero(as_tuple=True)
+    assert torch.equal(w['row_idx'][:w['rows']], n_i * labels.shape[1] + j_i) and torch.equal(w['labels'][:w['rows']], tgt[n_i, j_i])
+    lp = orl.gather_log_probabilities(logits[:, :-1], tgt.clamp(min=0))
+    assert abs(float(-(lp[tgt != -100]).mean()) - float(z['loss'])) < 2e-5      # the window formulation of the same loss
+    with pytest.raises(ValueError):
+        build_label_window(torch.full((2, 5), -100))
