@@ -1,9 +1,10 @@
-"""CPU, world_size 2, gloo: the token exchange of the expert-parallel MoE block (align_anything_amd/expert_parallel.py) -- counts,
+"""CPU, world_size 2 and 4, gloo: the token exchange of the expert-parallel MoE block (align_anything_amd/expert_parallel.py) -- counts,
 dispatch to the ranks that own the experts, local expert ids of the arriving rows, and the mirrored return path.  The device
 kernels are replaced by their integer definition (a stable sort by expert = `aa_moe_plan` with align 1) so the bookkeeping of
 the exchange itself is pinned without a GPU; tests/test_ep_gpu.py runs the real block."""
 import os
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -17,19 +18,19 @@ def _worker(rank, world, port, q):
     ok = ep.size == world and ep.rank == rank and ep.host_staged
     E, k, h = 8, 2, 6
     e0, El = ep.local_experts(E)
-    ok = ok and (e0, El) == (rank * 4, 4)
+    ok = ok and (e0, El) == (rank * (E // world), E // world)
     for trial, M in enumerate((13, 1, 40)):
         g = torch.Generator().manual_seed(100 * trial + rank)
         idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(M)])        # [M, k] distinct experts per token
         if trial == 1 and rank == 0:
-            idx = torch.tensor([[5, 6]])                                                   # rank 0 sends nothing to itself
+            idx = torch.tensor([[E - 3, E - 2]])                                           # rank 0 sends nothing to itself
         flat = idx.reshape(-1)
         order = torch.argsort(flat, stable=True)                                           # dense expert-major send order
         tok, choice = order // k, order % k
         xs = torch.stack([torch.full_like(tok, rank), tok, choice, flat[order], torch.zeros_like(tok), torch.zeros_like(tok)], 1).float()
         counts = torch.bincount(flat, minlength=E).to(torch.int32)
         send, recv, recv_counts = ep.exchange_counts(counts)
-        ok = ok and send == [int(counts[:4].sum()), int(counts[4:].sum())] and sum(send) == M * k
+        ok = ok and send == [int(counts[r * El:(r + 1) * El].sum()) for r in range(world)] and sum(send) == M * k
         xr = ep.exchange_rows(xs, send, recv)
         ids = ExpertParallel.local_expert_ids(recv_counts, 'cpu').view(-1).long()
         ok = ok and xr.shape[0] == sum(recv) == ids.numel()
@@ -45,23 +46,24 @@ def _worker(rank, world, port, q):
         xb = xs.to(torch.bfloat16)
         ok = ok and torch.equal(ep.exchange_rows(ep.exchange_rows(xb, send, recv), recv, send), xb)
     full = ep.all_gather_rows(torch.full((El, 3), float(rank)).to(torch.bfloat16))
-    ok = ok and full.shape == (E, 3) and full[:, 0].tolist() == [0.0] * 4 + [1.0] * 4
+    ok = ok and full.shape == (E, 3) and full[:, 0].tolist() == [float(r) for r in range(world) for _ in range(El)]
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_expert_parallel_exchange_world2():
+@pytest.mark.parametrize('world', [2, 4])
+def test_expert_parallel_exchange(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
 
 
 def test_sharded_blocks_load_their_rows_of_a_full_checkpoint():
