@@ -292,3 +292,52 @@ def test_from_hf_config_covers_every_native_backbone():
     # the named 7B geometries carry the published sizes
     assert configs.qwen2_audio_7b()['audio']['d_model'] == 1280 and configs.qwen2_audio_7b()['text']['vocab_size'] == 156032
     assert configs.qwen2_vl_7b()['text']['mrope_section'] == [16, 24, 24] and configs.llava_1_5_7b()['text']['vocab_size'] == 32064
+
+
+def test_window_plans_on_random_ragged_batches():
+    """300 random batches (left padding of any length, response lengths from 1 to the full row, single-row batches): the native
+    index plans vs the reference's own slicing expressions evaluated literally -- integer work, exact."""
+    from oracle import rl_math as orl
+    from align_anything_amd.trainers import common
+    import align_anything_amd.ops as ops
+    g = torch.Generator().manual_seed(2024)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    orig = ops.window_labels
+    ops.window_labels = lambda *a, **k: None              # the device half of build_window is checked in the gpu suite
+    try:
+        for _ in range(300):
+            N, T, pad = ri(1, 5), ri(2, 40), 1
+            ids = torch.randint(2, 50, (N, T), generator=g)
+            lens = []
+            for n in range(N):
+                lp = ri(0, T - 1)
+                ids[n, :lp] = pad
+                lens.append(ri(1, T - lp))
+            w = common.build_window(ids, lens, pad)
+            code = torch.arange(N * T).view(N, T)
+            off = 0
+            for n, R in enumerate(lens):
+                want = code[n][-R:][:-1]                     # logits[idx][-R:][:-1] reads these hidden positions (dpo.py:131-139)
+                assert torch.equal(w['row_idx'][off:off + R - 1], want)
+                pos, lab = orl.response_window(ids[n], pad, R, T)
+                assert (pos + n * T).tolist() == want.tolist() and lab.tolist() == ids[n][ids[n] != pad][-R:][1:].tolist()
+                off += R - 1
+            assert w['rows'] == off and w['seq_off'].tolist() == [0] + list(np.cumsum([r - 1 for r in lens]))
+            if w['rows']:
+                assert torch.equal(w['inv_map'][w['row_idx'][:off]].long(), torch.arange(off))
+            t = common.build_tail_window(ids, [min(r, T - 1) for r in lens])
+            o2 = 0
+            for n, R in enumerate(min(r, T - 1) for r in lens):
+                assert torch.equal(t['row_idx'][o2:o2 + R], code[n, :-1][-R:]) and torch.equal(t['labels'][o2:o2 + R], ids[n, 1:][-R:])
+                o2 += R
+            if T >= 3:
+                st = ri(0, T - 2)
+                s = common.build_span_window(ids, st)
+                assert torch.equal(s['row_idx'][:s['rows']], code[:, :-1][:, st:].reshape(-1)) and torch.equal(s['labels'][:s['rows']], ids[:, 1:][:, st:].reshape(-1))
+            lab = ids.clone(); lab[ids == pad] = -100; lab[:, :ri(0, T - 1)] = -100
+            if int((lab[:, 1:] != -100).sum()):
+                lw = common.build_label_window(lab)
+                n_i, j_i = (lab[:, 1:] != -100).nonzero(as_tuple=True)
+                assert torch.equal(lw['row_idx'][:lw['rows']], n_i * T + j_i) and torch.equal(lw['labels'][:lw['rows']], lab[:, 1:][n_i, j_i])
+    finally:
+        ops.window_labels = orig
