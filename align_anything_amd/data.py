@@ -10,7 +10,10 @@ work inside the training loop -- and then does a blocking `.to(device)` per tens
   padded to the longest row on `padding_side`, `pixel_values` = images * 2, `meta_info.response_lens`) -- integer work
   that must equal the reference collator's output exactly;
 * `DevicePrefetcher` stages batch k+1 host->HBM on a side HIP stream while step k computes, and pre-builds the response
-  window index plan (`trainers/common.py::build_window`) so the step starts with no host work.
+  window index plan (`trainers/common.py::build_window`) so the step starts with no host work;
+* `SupervisedCollator` / `PromptOnlyCollator` are the SFT and rollout counterparts (datasets/text_to_text/supervised.py:139-162,
+  prompt_only.py:154-175) on already tokenised samples: pinned host tensors of the same contract, for the same prefetcher
+  (which then pre-builds the label window of the supervised loss as well).
 """
 from __future__ import annotations
 
@@ -75,6 +78,47 @@ class CachedPreferenceCollator:
         return batch
 
 
+def _pad(rows, value, side, dtype=torch.int64):
+    T = max(int(r.numel()) for r in rows)
+    out = torch.full((len(rows), T), value, dtype=dtype)
+    for r, row in enumerate(rows):
+        n = int(row.numel())
+        if side == 'left':
+            out[r, T - n:] = row
+        else:
+            out[r, :n] = row
+    return out
+
+
+class SupervisedCollator:
+    """datasets/text_to_text/supervised.py:139-162: input_ids right-padded with pad_token_id, labels right-padded with -100,
+    attention_mask = input_ids != pad_token_id (a bool tensor, as the reference returns).  samples: dicts with 1-D `input_ids` / `labels`."""
+
+    IGNORE_INDEX = -100
+
+    def __init__(self, pad_token_id: int):
+        self.pad_token_id = int(pad_token_id)
+
+    def __call__(self, samples) -> dict:
+        ids = _pad([s['input_ids'] for s in samples], self.pad_token_id, 'right')
+        labels = _pad([s['labels'] for s in samples], self.IGNORE_INDEX, 'right')
+        return {'input_ids': _pin(ids), 'labels': _pin(labels), 'attention_mask': _pin(ids.ne(self.pad_token_id))}
+
+
+class PromptOnlyCollator:
+    """datasets/text_to_text/prompt_only.py:154-175: prompts LEFT-padded with pad_token_id; the mask marks the real tokens of every
+    row (all of them, also a pad id inside the text) -- what `generate` and the PPO rollout consume."""
+
+    def __init__(self, pad_token_id: int):
+        self.pad_token_id = int(pad_token_id)
+
+    def __call__(self, samples) -> dict:
+        rows = [s['input_ids'] for s in samples]
+        ids = _pad(rows, self.pad_token_id, 'left')
+        mask = _pad([torch.ones(int(r.numel()), dtype=torch.bool) for r in rows], False, 'left', dtype=torch.bool)
+        return {'input_ids': _pin(ids), 'attention_mask': _pin(mask)}
+
+
 class DevicePrefetcher:
     """Iterates a host dataloader one batch ahead: the next batch's tensors are copied to the device on a side stream
     (non_blocking from pinned memory) and its window plan is built, while the current step runs.  `pad_token_id` given
@@ -93,11 +137,15 @@ class DevicePrefetcher:
             with torch.cuda.stream(self.stream):
                 for k, v in batch.items():
                     out[k] = v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v
+                if isinstance(batch.get('labels'), torch.Tensor):
+                    out['_labels_host'] = batch['labels']          # the label plan is integer host work: keep the host copy for it
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
             out['_ready'] = ev
         else:
             out = dict(batch)
+            if isinstance(batch.get('labels'), torch.Tensor):
+                out['_labels_host'] = batch['labels']
         return out
 
     def _finish(self, out):
@@ -107,6 +155,9 @@ class DevicePrefetcher:
         if self.pad_token_id is not None and 'meta_info' in out and 'response_lens' in out['meta_info']:
             from .trainers.common import build_window
             out['_window'] = build_window(out['input_ids'], out['meta_info']['response_lens'], self.pad_token_id)
+        if out.get('labels') is not None and out.get('_labels_host') is not None:
+            from .trainers.common import build_label_window
+            out['_window'] = build_label_window(out.pop('_labels_host'), device=self.device)     # supervised loss rows (trainers/sft.py)
         return out
 
     def __iter__(self):

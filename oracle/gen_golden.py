@@ -653,6 +653,21 @@ def gen_collator():
         out[f'{side}_attention_mask'] = batch['attention_mask'].numpy()
         out[f'{side}_pixel_values'] = batch['pixel_values'].numpy()
         out[f'{side}_response_lens'] = np.array(batch['meta_info']['response_lens'])
+    # text_to_text SupervisedCollator / PromptOnlyCollator on ragged tokenised samples (a pad id inside the text included)
+    import align_anything.datasets.text_to_text.prompt_only as po
+    import align_anything.datasets.text_to_text.supervised as sup
+    sup.get_current_device = po.get_current_device = lambda: torch.device('cpu')
+    g = torch.Generator().manual_seed(77)
+    rows = [torch.randint(2, 60, (n,), generator=g) for n in (9, 1, 14, 6)]
+    rows[2][4] = 1                                                   # pad_token_id inside the text
+    labels = [r.clone() for r in rows]
+    for lab, p in zip(labels, (3, 0, 13, 2)):
+        lab[:p] = -100
+    sb = sup.SupervisedCollator(1)([{'input_ids': r, 'labels': l} for r, l in zip(rows, labels)])
+    pb = po.PromptOnlyCollator(1)([{'input_ids': r} for r in rows])
+    out.update({'tok_lens': np.array([len(r) for r in rows]), 'tok_flat': torch.cat(rows).numpy(), 'lab_flat': torch.cat(labels).numpy(),
+                'sft_input_ids': sb['input_ids'].numpy(), 'sft_labels': sb['labels'].numpy(), 'sft_attention_mask': sb['attention_mask'].numpy(),
+                'prompt_input_ids': pb['input_ids'].numpy(), 'prompt_attention_mask': pb['attention_mask'].numpy()})
     np.savez_compressed(os.path.join(GOLD, 'collator.npz'), **out)
     print('collator.npz', {k: v.shape for k, v in out.items()})
 

@@ -357,3 +357,30 @@ def test_every_evidence_file_cited_in_the_docs_exists():
             if not os.path.exists(os.path.join(ROOT, path)):
                 missing.append((doc, path))
     assert not missing, missing
+
+
+def test_supervised_and_prompt_only_collators_reproduce_the_reference_batches():
+    """data.py::SupervisedCollator / PromptOnlyCollator vs the reference's own collators (datasets/text_to_text/supervised.py:139-162,
+    prompt_only.py:154-175; tests/golden/collator.npz): integer work, exact -- incl. the reference's quirk that a pad id INSIDE the text
+    is masked out by the supervised collator (mask = ids != pad) but not by the prompt-only one; and the prefetcher attaches the
+    label-window plan of the supervised loss."""
+    from align_anything_amd.data import DevicePrefetcher, PromptOnlyCollator, SupervisedCollator
+    z = load_golden('collator.npz')
+    lens = [int(n) for n in z['tok_lens']]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    rows = [torch.from_numpy(z['tok_flat'][offs[i]:offs[i + 1]]) for i in range(len(lens))]
+    labs = [torch.from_numpy(z['lab_flat'][offs[i]:offs[i + 1]]) for i in range(len(lens))]
+    sb = SupervisedCollator(1)([{'input_ids': r, 'labels': l} for r, l in zip(rows, labs)])
+    assert sb['attention_mask'].dtype == torch.bool
+    for k in ('input_ids', 'labels', 'attention_mask'):
+        assert torch.equal(sb[k], torch.from_numpy(z['sft_' + k])), k
+    assert not bool(sb['attention_mask'][2, 4]) and int(sb['input_ids'][2, 4]) == 1
+    pb = PromptOnlyCollator(1)([{'input_ids': r} for r in rows])
+    for k in ('input_ids', 'attention_mask'):
+        assert torch.equal(pb[k], torch.from_numpy(z['prompt_' + k])), k
+    T = pb['input_ids'].shape[1]
+    assert bool(pb['attention_mask'][2, T - lens[2] + 4]) and int(pb['input_ids'][2, T - lens[2] + 4]) == 1
+    got = list(DevicePrefetcher([sb], 'cpu'))
+    assert len(got) == 1 and '_labels_host' not in got[0]
+    w = got[0]['_window']
+    assert w['rows'] == int((sb['labels'][:, 1:] != -100).sum()) and torch.equal(got[0]['labels'], sb['labels'])
