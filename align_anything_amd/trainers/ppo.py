@@ -76,6 +76,7 @@ class PPOTrainer(PPOMath):
                          gamma=float(t('gamma', 1.0)), gae_lambda=float(t('gae_lambda', 0.95)),
                          clip_range_ratio=float(t('clip_range_ratio', 0.2)), clip_range_value=float(t('clip_range_value', 5.0)))
         self.cfgs, self.device = cfgs, torch.device(device)
+        self.ptx_coeff = float(t('ptx_coeff', 16.0))        # configs/train/text_to_text/ppo.yaml:71
         rcfg = reward_model_cfg or model_cfg
         dt = compute_dtype(t('compute_dtype', 'bf16'))   # fp32 = parity mode for the update phase (rollouts need bf16)
         actor = build_model(model_cfg, device, trainable=True, dtype=dt)
@@ -152,6 +153,21 @@ class PPOTrainer(PPOMath):
             engine.wait_optimizer()
         lp = engine.module.response_logprobs(input_ids, attention_mask, w, save=save)
         return lp[:w['rows']].view(w['N'], w['W']), w
+
+    # ------------------------------------------------------------------ PTX mix-in (ppo.py:400-408)
+    def ptx_step(self, ptx_batch):
+        """One supervised step on the actor with the pre-training / SFT batch (`input_ids`, `labels`, `attention_mask`):
+        backward of ptx_coeff * (HF causal-LM loss), logged unscaled -- the native form of the supervised loss is trainers/sft.py."""
+        from .common import build_label_window
+        ids = ptx_batch['input_ids']
+        w = ptx_batch.get('_window') or build_label_window(ptx_batch['labels'], device=ids.device)
+        self.actor_model.wait_optimizer()
+        logp = self.actor_model.module.response_logprobs(ids, ptx_batch.get('attention_mask'), w, save=True)
+        ptx_loss, dlogp = ops.sft_loss(logp, w['rows'])
+        self.actor_model.set_pending(dlogp * self.ptx_coeff)
+        self.actor_model.backward(ptx_loss)
+        self.actor_model.step()
+        return {'train/ptx_loss': float(get_all_reduce_mean(ptx_loss.reshape(1).clone()).item())}
 
     # ------------------------------------------------------------------ update (ppo.py:309-398)
     def rl_step(self, inference_batch, training_batch):
