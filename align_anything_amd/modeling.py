@@ -16,8 +16,6 @@ from __future__ import annotations
 
 import os
 
-import math
-
 import torch
 
 from . import ops

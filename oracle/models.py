@@ -14,7 +14,6 @@ backward oracle.
 """
 from __future__ import annotations
 
-import math
 
 import torch
 import torch.nn.functional as F
