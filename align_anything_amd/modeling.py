@@ -1540,6 +1540,27 @@ class NativeQwen3Moe(NativeCausalLM):
     def embed_tokens(self, ids, pos=None):
         return ops.embed_fwd(ids, self.store.p[self.embed])
 
+    def load_state_dict(self, sd, strict=True):
+        """Accepts the fused expert tensors of transformers >= 5 (`mlp.experts.gate_up_proj` [E, 2F, h], `down_proj` [E, h, F]) and
+        the per-expert keys hub checkpoints are written with (`mlp.experts.<e>.{gate,up,down}_proj.weight`), which are merged here
+        exactly as hf:conversion_mapping.py "qwen2_moe" does (experts stacked on dim 0, gate before up).  Expert-parallel ranks
+        merge only the experts they hold."""
+        return super().load_state_dict(self.fuse_expert_keys(sd), strict)
+
+    def fuse_expert_keys(self, sd):
+        if not any('.mlp.experts.0.' in k for k in sd):
+            return sd
+        E = self.cfg['num_experts']
+        e0, n = self.ep.local_experts(E) if self.ep is not None else (0, E)
+        out = {k: v for k, v in sd.items() if '.mlp.experts.' not in k or k.endswith(('experts.gate_up_proj', 'experts.down_proj'))}
+        for i in range(self.cfg['num_layers']):
+            p = f'model.layers.{i}.mlp.experts.'
+            if p + '0.gate_proj.weight' not in sd:
+                continue
+            out[p + 'gate_up_proj'] = torch.stack([torch.cat([sd[f'{p}{e}.gate_proj.weight'], sd[f'{p}{e}.up_proj.weight']], 0) for e in range(e0, e0 + n)])
+            out[p + 'down_proj'] = torch.stack([sd[f'{p}{e}.down_proj.weight'] for e in range(e0, e0 + n)])
+        return out
+
     def state_dict(self):
         """HF-layout tensors.  With expert parallelism this is a COLLECTIVE call: every rank contributes its expert rows and
         gets the full [E, ...] tensors back (what save_pretrained writes)."""

@@ -384,3 +384,30 @@ def test_supervised_and_prompt_only_collators_reproduce_the_reference_batches():
     assert len(got) == 1 and '_labels_host' not in got[0]
     w = got[0]['_window']
     assert w['rows'] == int((sb['labels'][:, 1:] != -100).sum()) and torch.equal(got[0]['labels'], sb['labels'])
+
+
+def test_qwen3moe_loads_hub_style_per_expert_checkpoints():
+    """Hub checkpoints carry `mlp.experts.<e>.{gate,up,down}_proj.weight`; transformers >= 5 merges them on load
+    (hf:conversion_mapping.py "qwen2_moe": stack on dim 0, gate before up).  The native loader does the same merge."""
+    from align_anything_amd.modeling import build_model
+    from tests.util import tiny_qwen3moe_cfg
+    z = load_golden('qwen3moe_tiny_dpo.npz')
+    sd = state_dict_from_golden(z, 'w.', torch.bfloat16)
+    cfg = tiny_qwen3moe_cfg()
+    F = cfg['moe_intermediate_size']
+    hub = {k: v for k, v in sd.items() if '.mlp.experts.' not in k}
+    for i in range(cfg['num_layers']):
+        p = f'model.layers.{i}.mlp.experts.'
+        for e in range(cfg['num_experts']):
+            hub[f'{p}{e}.gate_proj.weight'] = sd[p + 'gate_up_proj'][e, :F].clone()
+            hub[f'{p}{e}.up_proj.weight'] = sd[p + 'gate_up_proj'][e, F:].clone()
+            hub[f'{p}{e}.down_proj.weight'] = sd[p + 'down_proj'][e].clone()
+    a, b = build_model(cfg, 'cpu', trainable=False), build_model(cfg, 'cpu', trainable=False)
+    assert a.load_state_dict(sd) == [] and b.load_state_dict(hub) == []
+    sa, sb = a.state_dict(), b.state_dict()
+    assert set(sa) == set(sb) == set(sd)
+    for k in sd:
+        assert torch.equal(sa[k], sd[k]) and torch.equal(sb[k], sd[k]), k
+    del hub['model.layers.1.mlp.experts.3.up_proj.weight']
+    with pytest.raises(KeyError):
+        build_model(cfg, 'cpu', trainable=False).load_state_dict(hub)
