@@ -200,8 +200,14 @@ class DPOTrainer:
         return {}  # the reference's DPO eval is a stub (dpo.py:310-313)
 
     def save(self, model=None, tag=None, output_dir=None) -> str:
-        """base/supervised_trainer.py:404-450 layout: <output_dir>/slice_<tag|end>/{config.json, pytorch_model.bin}."""
+        """base/supervised_trainer.py:404-450 layout: <output_dir>/slice_<tag|end>/{config.json, tokenizer / processor files,
+        pytorch_model.bin} -- a directory `AnyModel.from_pretrained` loads.  The weights come from the native engine under their HF
+        names; config.json / tokenizer / processor are written when the trainer was handed the HF objects (`self.hf_config`,
+        `self.tokenizer`, `self.processor`: the native path itself only needs the plain-dict geometry)."""
         out = output_dir or cfg_get(self.cfgs, 'logger_cfgs.output_dir', './output')
         d = os.path.join(out, f'slice_{tag or "end"}')
         (model or self.model).save_16bit_model(d, save_filename='pytorch_model.bin')
+        for obj in (getattr(self, 'hf_config', None), self.tokenizer, getattr(self, 'processor', None)):
+            if obj is not None and hasattr(obj, 'save_pretrained'):
+                obj.save_pretrained(d)
         return d

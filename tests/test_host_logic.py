@@ -411,3 +411,45 @@ def test_qwen3moe_loads_hub_style_per_expert_checkpoints():
     del hub['model.layers.1.mlp.experts.3.up_proj.weight']
     with pytest.raises(KeyError):
         build_model(cfg, 'cpu', trainable=False).load_state_dict(hub)
+
+
+def test_native_checkpoints_round_trip_through_hf_from_pretrained(tmp_path):
+    """SURVEY section 8b checkpoint contract: what the native engine saves (`slice_<tag>/pytorch_model.bin` under HF parameter names +
+    the HF config) must load with `from_pretrained` and give back the same weights -- OPT (tied head), Llama (GQA), Qwen3-MoE (fused
+    expert tensors), and through the trainer's own `save()`."""
+    import transformers as tf
+    from align_anything_amd import configs
+    from align_anything_amd.engine import NativeEngine
+    from align_anything_amd.modeling import build_model
+    torch.manual_seed(0)
+    cases = {
+        'opt': (tf.OPTForCausalLM, tf.OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=320,
+                                                max_position_embeddings=128, word_embed_proj_dim=128, dropout=0.0, pad_token_id=1)),
+        'llama': (tf.LlamaForCausalLM, tf.LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                                      num_key_value_heads=1, vocab_size=320, max_position_embeddings=256)),
+        'qwen3_moe': (tf.Qwen3MoeForCausalLM, tf.Qwen3MoeConfig(hidden_size=128, moe_intermediate_size=64, intermediate_size=64, num_hidden_layers=2,
+                                                                num_attention_heads=2, num_key_value_heads=1, vocab_size=320, num_experts=8,
+                                                                num_experts_per_tok=2, head_dim=64, max_position_embeddings=256)),
+    }
+    for name, (cls, hc) in cases.items():
+        hf = cls(hc).eval()
+        sd = {k: v.detach().clone() for k, v in hf.state_dict().items()}
+        m = build_model(configs.from_hf_config(hf.config), 'cpu', trainable=False)
+        assert m.load_state_dict(sd) == [] and set(m.state_dict()) == set(sd), name
+        d = str(tmp_path / name)
+        NativeEngine(m, trainable=False).save_16bit_model(d, 'pytorch_model.bin')
+        hf.config.save_pretrained(d)
+        back = cls.from_pretrained(d, torch_dtype=torch.bfloat16).state_dict()
+        for k, v in sd.items():
+            assert torch.equal(back[k].float(), v.to(torch.bfloat16).float()), (name, k)
+    # the trainer's save(): slice_<tag>/ with config.json next to the weights
+    from align_anything_amd.trainers.sft import SupervisedTrainer
+    cls, hc = cases['opt']
+    hf = cls(hc).eval()
+    tr = SupervisedTrainer({'train_cfgs': {}, 'model_cfgs': {'pad_token_id': 1}, 'logger_cfgs': {'output_dir': str(tmp_path / 'out')}}, None,
+                           model_cfg=configs.from_hf_config(hc), policy_state=hf.state_dict(), device='cpu')
+    tr.hf_config = hc
+    d = tr.save(tag=7)
+    assert d.endswith('slice_7') and os.path.exists(os.path.join(d, 'config.json')) and os.path.exists(os.path.join(d, 'pytorch_model.bin'))
+    back = cls.from_pretrained(d, torch_dtype=torch.bfloat16).state_dict()
+    assert all(torch.equal(back[k].float(), v.to(torch.bfloat16).float()) for k, v in hf.state_dict().items())
