@@ -416,7 +416,7 @@ def test_qwen3moe_loads_hub_style_per_expert_checkpoints():
 def test_native_checkpoints_round_trip_through_hf_from_pretrained(tmp_path):
     """SURVEY section 8b checkpoint contract: what the native engine saves (`slice_<tag>/pytorch_model.bin` under HF parameter names +
     the HF config) must load with `from_pretrained` and give back the same weights -- OPT (tied head), Llama (GQA), Qwen3-MoE (fused
-    expert tensors), and through the trainer's own `save()`."""
+    expert tensors), LLaVA (CLIP patch embedding stored K-padded), Qwen2-VL, Qwen2-Audio, and through the trainer's own `save()`."""
     import transformers as tf
     from align_anything_amd import configs
     from align_anything_amd.engine import NativeEngine
@@ -431,6 +431,22 @@ def test_native_checkpoints_round_trip_through_hf_from_pretrained(tmp_path):
                                                                 num_attention_heads=2, num_key_value_heads=1, vocab_size=320, num_experts=8,
                                                                 num_experts_per_tok=2, head_dim=64, max_position_embeddings=256)),
     }
+    vc = tf.CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, image_size=28, patch_size=14)
+    tc = tf.LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, vocab_size=320,
+                        rms_norm_eps=1e-5, max_position_embeddings=256)
+    cases['llava'] = (tf.LlavaForConditionalGeneration, tf.LlavaConfig(vision_config=vc, text_config=tc, image_token_id=300, image_seq_length=4))
+    cases['qwen2_vl'] = (tf.Qwen2VLForConditionalGeneration, tf.Qwen2VLConfig(      # 80-wide vision heads: stored zero-padded natively, HF-shaped on disk
+        text_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=320,
+                         max_position_embeddings=256, rms_norm_eps=1e-6,
+                         rope_parameters={'rope_type': 'default', 'rope_theta': 10000.0, 'mrope_section': [8, 12, 12]}),
+        vision_config=dict(depth=2, embed_dim=320, hidden_size=128, num_heads=4, mlp_ratio=2, patch_size=14, temporal_patch_size=2,
+                           spatial_merge_size=2, in_channels=3),
+        image_token_id=300, video_token_id=301, vision_start_token_id=302, vision_end_token_id=303, bos_token_id=1, eos_token_id=2))
+    cases['qwen2_audio'] = (tf.Qwen2AudioForConditionalGeneration, tf.Qwen2AudioConfig(
+        audio_config=dict(num_mel_bins=64, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, d_model=128, max_source_positions=32),
+        text_config=dict(model_type='qwen2', hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                         num_key_value_heads=1, vocab_size=320, max_position_embeddings=256, rms_norm_eps=1e-6),
+        audio_token_id=300))
     for name, (cls, hc) in cases.items():
         hf = cls(hc).eval()
         sd = {k: v.detach().clone() for k, v in hf.state_dict().items()}
