@@ -458,6 +458,16 @@ def test_native_checkpoints_round_trip_through_hf_from_pretrained(tmp_path):
         back = cls.from_pretrained(d, torch_dtype=torch.bfloat16).state_dict()
         for k, v in sd.items():
             assert torch.equal(back[k].float(), v.to(torch.bfloat16).float()), (name, k)
+    # safetensors variant (tied lm_head left out of the file, re-tied by HF on load)
+    cls, hc = cases['opt']
+    hf = cls(hc).eval()
+    m = build_model(configs.from_hf_config(hc), 'cpu', trainable=False)
+    m.load_state_dict(hf.state_dict())
+    d = str(tmp_path / 'opt_st')
+    NativeEngine(m, trainable=False).save_16bit_model(d, 'model.safetensors')
+    hc.save_pretrained(d)
+    back = cls.from_pretrained(d, torch_dtype=torch.bfloat16).state_dict()
+    assert all(torch.equal(back[k].float(), v.to(torch.bfloat16).float()) for k, v in hf.state_dict().items())
     # the trainer's save(): slice_<tag>/ with config.json next to the weights
     from align_anything_amd.trainers.sft import SupervisedTrainer
     cls, hc = cases['opt']
