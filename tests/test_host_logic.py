@@ -479,3 +479,39 @@ def test_native_checkpoints_round_trip_through_hf_from_pretrained(tmp_path):
     assert d.endswith('slice_7') and os.path.exists(os.path.join(d, 'config.json')) and os.path.exists(os.path.join(d, 'pytorch_model.bin'))
     back = cls.from_pretrained(d, torch_dtype=torch.bfloat16).state_dict()
     assert all(torch.equal(back[k].float(), v.to(torch.bfloat16).float()) for k, v in hf.state_dict().items())
+
+
+def test_every_ctypes_call_site_matches_its_prototype_arity():
+    """Static guard (no GPU needed): every `call('aa_...', ...)` in the host code passes exactly as many arguments as the header
+    declares for that entry point (names built as 'aa_x' + suffix are matched by their constant prefix, starred arguments skipped)."""
+    import ast
+    import glob
+    from align_anything_amd.lib import HEADER, HEADER_F32, parse_header
+    protos = {**parse_header(HEADER), **parse_header(HEADER_F32)}
+
+    def const_prefix(node):
+        if isinstance(node, ast.Constant) and isinstance(node.value, str):
+            return node.value
+        if isinstance(node, ast.BinOp) and isinstance(node.op, ast.Add):
+            return const_prefix(node.left)
+        if isinstance(node, ast.IfExp):            # 'aa_gemm_f32' if sfx else 'aa_gemm_bf16'
+            return const_prefix(node.body)
+        return None
+
+    checked, bad = 0, []
+    files = glob.glob(os.path.join(ROOT, 'align_anything_amd', '**', '*.py'), recursive=True) + [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')]
+    for f in files:
+        for node in ast.walk(ast.parse(open(f).read())):
+            if not (isinstance(node, ast.Call) and getattr(node.func, 'id', getattr(node.func, 'attr', None)) == 'call' and node.args):
+                continue
+            name = const_prefix(node.args[0])
+            if not name or not name.startswith('aa_') or any(isinstance(a, ast.Starred) for a in node.args):
+                continue
+            cands = [n for n in protos if n == name or n.startswith(name)]
+            assert cands, (os.path.basename(f), node.lineno, name)
+            want = {len(protos[n][1]) for n in cands}
+            checked += 1
+            if len(node.args) - 1 not in want:
+                bad.append((os.path.basename(f), node.lineno, name, len(node.args) - 1, sorted(want)))
+    assert not bad, bad
+    assert checked >= 70
