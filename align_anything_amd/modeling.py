@@ -563,8 +563,9 @@ class NativeCausalLM:
                           image_features=None, round_bf16=False, **mm):
         """window: dict(row_idx int64[rows_pad], labels int64[rows_pad], inv_map int32[Mp]) built by
         trainers.common.build_window.  Returns flat fp32 log-probs [rows_pad] (pad rows meaningless)."""
-        if not (window['row_idx'].is_cuda and window['labels'].is_cuda and window['inv_map'].is_cuda):
-            raise RuntimeError('response_logprobs: the window plan (row_idx / labels / inv_map) must live on the GPU')
+        for k in ('row_idx', 'labels', 'inv_map'):      # a host-side plan handed to the kernels would be a wild device pointer
+            if window[k].device.type != self.device.type:
+                raise RuntimeError(f'response_logprobs: window[{k!r}] lives on {window[k].device}, the model on {self.device}')
         x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features, **mm)
         logp = self.head.forward(x, window['row_idx'], window['labels'], save, round_bf16)
         if save:

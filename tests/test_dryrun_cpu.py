@@ -1,0 +1,229 @@
+"""CPU: host control flow of every trainer with the kernel launches stubbed out.
+
+The product path has no CPU fallback, so nothing here computes: `ops.call` (the single ctypes gateway) is replaced by a recorder,
+the device checks of ops.py are relaxed, and the trainers run on CPU tensors whose contents are whatever `torch.empty` holds.  What
+this pins without a GPU is everything python does between the launches -- constructor wiring, batch / window plumbing, shapes of
+every buffer handed to a kernel, engine bookkeeping (accumulation, schedules, optimizer ordering), metric keys -- for the code
+paths the GPU suite covers AND for the ones written after the round's GPU budget was spent (PPOTrainer.ptx_step).  Numerical
+parity lives in the `-m gpu` tests."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load_golden, state_dict_from_golden, tiny_llava_cfg, tiny_opt_cfg, tiny_qwen3moe_cfg
+
+T = torch.from_numpy
+
+
+@pytest.fixture
+def launches(monkeypatch):
+    from align_anything_amd import ops
+    seen = []
+
+    def sfx(t, name):
+        if t.dtype == torch.bfloat16:
+            return ''
+        if t.dtype == torch.float32:
+            return '_f32'
+        raise RuntimeError(f'{name}: expected bfloat16 or float32 activations, got {t.dtype}')
+
+    monkeypatch.setattr(ops, 'call', lambda name, *a: seen.append(name))
+    monkeypatch.setattr(ops, '_sfx', sfx)
+    monkeypatch.setattr(ops, '_chk', lambda t, dtype, name: None)
+    monkeypatch.setattr(ops, 'stream', lambda: 0)
+    return seen
+
+
+def _cfgs(z=None, **extra):
+    t = {'scale_coeff': 0.1, 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'weight_decay': 0.0}
+    t.update(extra)
+    return {'train_cfgs': t, 'model_cfgs': {'pad_token_id': int(z['pad_token_id']) if z is not None else 1}}
+
+
+def _pref_batch(z, pixels=False):
+    b = {'input_ids': T(z['input_ids']), 'attention_mask': T(z['attention_mask']), 'meta_info': {'response_lens': [int(x) for x in z['response_lens']]}}
+    if pixels:
+        b['pixel_values'] = T(z['pixel_values'])
+    return b
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_dpo_family_steps_launch_the_expected_kernels(launches, dtype):
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    from align_anything_amd.trainers.pref import KTOTrainer, ORPOTrainer, SimPOTrainer
+    z = load_golden('opt_tiny_dpo.npz')
+    wd = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    keys = {'train/loss', 'train/reward', 'train/better_sample_reward', 'train/worse_sample_reward', 'train/reward_accuracy', 'train/reward_margin', 'train/lr'}
+    for cls, loss_kernel in ((DPOTrainer, 'aa_dpo_loss_fwd_bwd'), (SimPOTrainer, 'aa_pref_loss_fwd_bwd'), (ORPOTrainer, 'aa_pref_loss_fwd_bwd'), (KTOTrainer, 'aa_pref_loss_fwd_bwd')):
+        tr = cls(_cfgs(z, compute_dtype=dtype, gradient_accumulation_steps=2), {'gradient_clipping': 1.0}, model_cfg=tiny_opt_cfg(),
+                 policy_state=state_dict_from_golden(z, 'w.', wd), reference_state=state_dict_from_golden(z, 'r.', wd), device='cpu')
+        assert (tr.reference is None) == (cls in (SimPOTrainer, ORPOTrainer))
+        del launches[:]
+        info = tr.train_step(_pref_batch(z))
+        assert keys <= set(info) and loss_kernel in launches
+        assert 'aa_adamw_flat' not in launches and tr.model.global_steps == 0         # accumulation: no optimizer step at the first micro-batch
+        tr.train_step(_pref_batch(z))
+        assert launches.count('aa_adamw_flat') == len(tr.policy.store.trainable_groups()) and tr.model.global_steps == 1
+        assert 'aa_grad_sumsq' in launches and 'aa_clip_coef' in launches
+        gemm = 'aa_gemm_bf16' if dtype == 'bf16' else 'aa_gemm_f32'
+        assert gemm in launches and ('aa_attn_bwd' + ('' if dtype == 'bf16' else '_f32')) in launches
+
+
+def test_llava_and_moe_dpo_steps(launches):
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    z = load_golden('llava_tiny_dpo.npz')
+    tr = DPOTrainer(_cfgs(z), {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                    reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cpu')
+    info = tr.train_step(_pref_batch(z, pixels=True))
+    assert np.isfinite(info['train/lr'])
+    for k in ('aa_patch_im2col', 'aa_clip_embed', 'aa_image_slot_index', 'aa_embed_fwd', 'aa_layernorm_fwd', 'aa_rmsnorm_bwd', 'aa_dpo_loss_fwd_bwd'):
+        assert k in launches, k
+    z = load_golden('qwen3moe_tiny_dpo.npz')
+    del launches[:]
+    tr = DPOTrainer(_cfgs(z), {'gradient_clipping': 1.0}, model_cfg=tiny_qwen3moe_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                    reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cpu')
+    tr.train_step(_pref_batch(z))
+    for k in ('aa_moe_route', 'aa_moe_plan', 'aa_moe_gather', 'aa_gemm_grouped_bf16', 'aa_moe_combine', 'aa_moe_combine_bwd', 'aa_moe_route_bwd'):
+        assert k in launches, k
+
+
+def test_supervised_step_and_prefetched_window(launches):
+    from align_anything_amd.data import DevicePrefetcher
+    from align_anything_amd.trainers.sft import SupervisedTrainer
+    z, zw = load_golden('opt_tiny_sft.npz'), load_golden('opt_tiny_dpo.npz')
+    tr = SupervisedTrainer(_cfgs(zw), {'gradient_clipping': 1.0}, model_cfg=tiny_opt_cfg(), policy_state=state_dict_from_golden(zw, 'w.', torch.bfloat16), device='cpu')
+    b = {'input_ids': T(z['input_ids']), 'attention_mask': T(z['attention_mask']), 'labels': T(z['labels'])}
+    info = tr.train_step(b)
+    assert set(info) == {'train/loss', 'train/lr'} and 'aa_sft_loss_fwd_bwd' in launches and 'aa_adamw_flat' in launches
+    (pb,) = list(DevicePrefetcher([b], 'cpu'))
+    assert pb['_window']['rows'] == int((T(z['labels'])[:, 1:] != -100).sum())
+    tr.train_step(pb)                                      # the pre-built plan is taken as is
+    assert tr.model.global_steps == 2
+
+
+def test_ppo_rollout_update_and_ptx_steps(launches):
+    from align_anything_amd.trainers.ppo import PPOTrainer
+    z = load_golden('opt_tiny_dpo.npz')
+    cfg = tiny_opt_cfg()
+    actor_sd = state_dict_from_golden(z, 'w.', torch.bfloat16)
+    rm_sd = {k: v for k, v in actor_sd.items() if k != 'lm_head.weight'}
+    rm_sd['score_head.weight'] = torch.zeros(1, cfg['hidden_size'], dtype=torch.bfloat16)
+    cfgs = {'train_cfgs': {'actor_lr': 1e-3, 'critic_lr': 1e-3, 'actor_lr_scheduler_type': 'constant', 'critic_lr_scheduler_type': 'constant', 'ptx_coeff': 4.0},
+            'model_cfgs': {'pad_token_id': 1, 'model_max_length': 30, 'temperature': 0.9, 'top_p': 0.8, 'repetition_penalty': 1.2}}
+    tr = PPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, reward_state=rm_sd, device='cpu')
+    assert tr.ptx_coeff == 4.0
+    prompts = T(z['input_ids'])[:, :24]
+    inference, training = tr.rollout({'input_ids': prompts, 'attention_mask': T(z['attention_mask'])[:, :24]})
+    assert inference['input_ids'].shape == (4, 30) and torch.equal(inference['input_ids'][:, :24], prompts)
+    assert training['log_probs'].shape == training['ref_log_probs'].shape == (4, 29) and training['prompt_idx'] == 23
+    for k in ('aa_gemm_skinny_bf16', 'aa_attn_decode', 'aa_sample_top_p', 'aa_mark_seen', 'aa_rowdot_fwd'):
+        assert k in launches, k
+    info = tr.rl_step(inference, training)
+    assert {'train/actor_loss', 'train/reward_critic_loss', 'train/kl_divergence', 'train/actor_lr'} <= set(info)
+    assert tr.actor_model.global_steps == 1 and tr.reward_critic_model.global_steps == 1
+    labels = inference['input_ids'].clone()
+    labels[:, :24] = -100
+    del launches[:]
+    out = tr.ptx_step({'input_ids': inference['input_ids'], 'attention_mask': inference['attention_mask'], 'labels': labels})
+    assert set(out) == {'train/ptx_loss'} and tr.actor_model.global_steps == 2 and tr.reward_critic_model.global_steps == 1
+    assert 'aa_sft_loss_fwd_bwd' in launches and 'aa_adamw_flat' in launches
+    # a rule reward instead of the reward model
+    tr2 = PPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, critic_state=rm_sd, device='cpu', reward_fn=lambda i, a: [1.0] * i.shape[0])
+    assert tr2.reward_model is None and tr2.reward_model_step(prompts, torch.ones_like(prompts))['reward'].tolist() == [1.0] * 4
+
+
+def test_grpo_and_rm_steps(launches):
+    from align_anything_amd.trainers.grpo import GRPOTrainer
+    from align_anything_amd.trainers.rm import RMTrainer
+    z = load_golden('opt_tiny_dpo.npz')
+    cfg = tiny_opt_cfg()
+    sd = state_dict_from_golden(z, 'w.', torch.bfloat16)
+    cfgs = {'train_cfgs': {'actor_lr': 1e-3, 'actor_lr_scheduler_type': 'constant', 'beta': 0.04, 'num_generations': 2},
+            'model_cfgs': {'pad_token_id': 1, 'eos_token_id': 2, 'model_max_length': 28, 'temperature': 1.0, 'top_p': 1.0}}
+    tr = GRPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=sd, reference_state=sd, reward_fn=lambda c: c.sum(1).float(), device='cpu')
+    prompts = T(z['input_ids'])[:2, :20]
+    info = tr.train_step({'input_ids': prompts, 'attention_mask': torch.ones_like(prompts)})
+    assert {'train/loss', 'train/reward'} <= set(info)
+    for k in ('aa_group_advantage', 'aa_completion_mask', 'aa_grpo_loss_fwd_bwd', 'aa_adamw_flat'):
+        assert k in launches, k
+    rm_sd = {k: v for k, v in sd.items() if k != 'lm_head.weight'}
+    rm_sd['score_head.weight'] = torch.zeros(1, cfg['hidden_size'], dtype=torch.bfloat16)
+    rm = RMTrainer(_cfgs(z), {'gradient_clipping': 1.0}, model_cfg=cfg, state=rm_sd, device='cpu')
+    del launches[:]
+    info = rm.train_step(_pref_batch(z))
+    assert 'train/loss' in info and 'aa_rm_loss_fwd_bwd' in launches and 'aa_rowdot_bwd' in launches
+
+
+def test_multimodal_backbones_and_ti2t_ppo_update(launches):
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    from align_anything_amd.trainers.ppo_ti2t import PPOTrainerTI2T
+    from tests.util import bits_to_bf16, tiny_qwen2audio_cfg, tiny_qwen2vl_cfg
+    # Qwen2-VL DPO (vision tower -> merger -> multimodal RoPE tables -> decoder), with the visual blocks training
+    z = load_golden('qwen2vl_tiny_dpo.npz')
+    tr = DPOTrainer(_cfgs(z, freeze_vision_tower=False), {'gradient_clipping': 1.0}, model_cfg=tiny_qwen2vl_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                    reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cpu')
+    b = _pref_batch(z, pixels=True)
+    b['image_grid_thw'] = T(z['image_grid_thw'])
+    info = tr.train_step(b)
+    assert 'train/loss' in info
+    for k in ('aa_mrope_tables', 'aa_rope_inplace', 'aa_attn_bwd', 'aa_adamw_flat'):
+        assert k in launches, k
+    # Qwen2-Audio DPO (conv front-end as im2col GEMMs, trainable tower, identical-pair skipping mask)
+    z = load_golden('qwen2audio_tiny_dpo.npz')
+    sd = lambda pre: {k[len(pre):]: (bits_to_bf16(z[k]) if z[k].dtype == np.uint16 else T(z[k]).to(torch.bfloat16)) for k in z.files if k.startswith(pre)}
+    pol, ref = sd('w.'), sd('r.')
+    ref.setdefault('model.audio_tower.embed_positions.weight', pol['model.audio_tower.embed_positions.weight'])
+    del launches[:]
+    tr = DPOTrainer(_cfgs(z), {'gradient_clipping': 1.0}, model_cfg=tiny_qwen2audio_cfg(), policy_state=pol, reference_state=ref, device='cpu')
+    assert tr.skip_identical_pairs
+    b = _pref_batch(z)
+    b['input_features'], b['feature_attention_mask'] = T(z['input_features']), T(z['feature_attention_mask'])
+    tr.train_step(b)
+    for k in ('aa_conv1d_im2col', 'aa_conv1d_col2im', 'aa_avgpool2', 'aa_attn_fwd'):
+        assert k in launches, k
+    # ti2t PPO update on the reference's own rollout statistics (tail windows, response mask)
+    z = load_golden('qwen2vl_tiny_ppo.npz')
+    cfgs = {'train_cfgs': {'actor_lr': 1e-3, 'critic_lr': 1e-3, 'actor_lr_scheduler_type': 'constant', 'critic_lr_scheduler_type': 'constant'},
+            'model_cfgs': {'pad_token_id': int(z['pad_token_id']), 'max_new_tokens': 10, 'eos_token_id': 2}}
+    wd = torch.bfloat16
+    vis = {k: v for k, v in state_dict_from_golden(z, 'a.', wd).items() if k.startswith('model.visual.')}
+    score_sd = lambda tag: {**vis, **{k: v for k, v in state_dict_from_golden(z, tag + '.', wd).items() if k != 'lm_head.weight'}}
+    tr = PPOTrainerTI2T(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_qwen2vl_cfg(), actor_state=state_dict_from_golden(z, 'a.', wd),
+                        reward_state=score_sd('rm'), critic_state=score_sd('c'), device='cpu')
+    inf = {'input_ids': T(z['sequences_left']), 'attention_mask': T(z['attention_mask']), 'pixel_values': T(z['pixel_values']), 'image_grid_thw': T(z['image_grid_thw'])}
+    trn = {k: (T(z[k]) if k != 'response_lens' else z[k].tolist()) for k in ('response_lens', 'log_probs', 'ref_log_probs', 'reward', 'reward_values', 'response_mask')}
+    del launches[:]
+    info = tr.rl_step(inf, trn)
+    assert {'train/actor_loss', 'train/reward_critic_loss', 'train/mean_generated_length', 'train/max_generated_length'} <= set(info)
+    assert info['train/max_generated_length'] == float(T(z['response_mask']).sum(-1).max())      # host arithmetic on real inputs
+    for k in ('aa_kl_reward', 'aa_gae', 'aa_ppo_actor_loss', 'aa_ppo_critic_loss'):
+        assert k in launches, k
+
+
+def test_rollout_plumbing_on_llama_and_moe_decoders(launches):
+    """generate(): prefill with KV sink, strip-major weight copies (Llama family), per-row expert GEMV (Qwen3-MoE), token bookkeeping."""
+    from align_anything_amd.generation import generate
+    from align_anything_amd.modeling import build_model
+    z = load_golden('llava_tiny_dpo.npz')
+    m = build_model(tiny_llava_cfg(), 'cpu', trainable=False)
+    m.load_state_dict(state_dict_from_golden(z, 'w.', torch.bfloat16))
+    ids, mask = T(z['input_ids'])[:, :30], T(z['attention_mask'])[:, :30]
+    seq = generate(m, ids, mask, max_new_tokens=5, do_sample=False, pad_token_id=301, pixel_values=T(z['pixel_values']))
+    assert seq.shape == (ids.shape[0], 35) and torch.equal(seq[:, :30], ids)
+    assert 'aa_swizzle_weights_bf16' in launches and 'aa_gemm_skinny_swz_bf16' in launches and 'aa_decode_rope_cache' in launches and 'aa_argmax_rows' in launches
+    n_swz = launches.count('aa_swizzle_weights_bf16')
+    generate(m, ids, mask, max_new_tokens=2, do_sample=False, pad_token_id=301, pixel_values=T(z['pixel_values']))
+    assert launches.count('aa_swizzle_weights_bf16') == 2 * n_swz            # refreshed in place every call, same storage
+    assert m.stack._dw is not None
+    m.stack.release_decode()
+    assert m.stack._dw is None
+    z = load_golden('qwen3moe_tiny_dpo.npz')
+    m = build_model(tiny_qwen3moe_cfg(), 'cpu', trainable=False)
+    m.load_state_dict(state_dict_from_golden(z, 'w.', torch.bfloat16))
+    del launches[:]
+    ids, mask = T(z['input_ids'])[:, :20], T(z['attention_mask'])[:, :20]
+    seq = generate(m, ids, mask, max_new_tokens=4, do_sample=True, temperature=0.7, top_p=0.9, pad_token_id=int(z['pad_token_id']))
+    assert seq.shape == (4, 24) and 'aa_moe_gemv_bf16' in launches and 'aa_sample_top_p' in launches
+    del launches[:]
+    generate(m, ids.repeat(5, 1), mask.repeat(5, 1), max_new_tokens=2, do_sample=False, pad_token_id=int(z['pad_token_id']))     # 20 rows: tile layout
+    assert 'aa_gemm_grouped_bf16' in launches and 'aa_moe_gemv_bf16' not in launches
