@@ -280,3 +280,91 @@ def test_two_rank_step_reduces_every_gradient_element_exactly_once():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _ep_worker(rank, world, port, q):
+    """Expert-parallel DPO step, stubbed launches -- except that the two INTEGER kernels whose outputs steer the host (router choice,
+    expert-major plan) are emulated by their definitions, written straight into the (host) buffers the C ABI would have filled."""
+    import ctypes
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from align_anything_amd import ops
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    seen = []
+    ints = lambda ptr, n: np.ctypeslib.as_array((ctypes.c_int * n).from_address(ptr))
+
+    def call(name, *a):
+        seen.append(name)
+        if name.startswith('aa_moe_route') and 'bwd' not in name:          # (logits, ld, rows, E, k, norm, probs, idx, weights, stream)
+            rows, E, k, idx = a[2], a[3], a[4], a[7]
+            g = np.random.default_rng(1000 * rank + len(seen))
+            ints(idx, rows * k)[:] = np.stack([g.permutation(E)[:k] for _ in range(rows)]).reshape(-1)
+        elif name == 'aa_moe_plan':                                         # the plan of csrc/moe.hip, restated (stable sort by expert)
+            idx, rows, k, E, align, cap, counts, off, pos, src, te = a[:11]
+            flat = ints(idx, rows * k).copy()
+            cnt = np.bincount(flat, minlength=E)
+            seg = (cnt + align - 1) // align * align
+            o = np.concatenate([[0], np.cumsum(seg)])
+            ints(counts, E)[:] = cnt
+            ints(off, E + 1)[:] = o
+            order = np.argsort(flat, kind='stable')
+            starts = np.cumsum(cnt) - cnt
+            dest = o[flat[order]] + (np.arange(rows * k) - starts[flat[order]])
+            if rows * k:
+                ints(pos, rows * k)[order] = dest
+            s_arr = ints(src, cap)
+            s_arr[:] = -1
+            s_arr[dest] = order // k
+            t_arr = ints(te, cap // align)
+            t_arr[:] = -1
+            for e in range(E):
+                t_arr[o[e] // align:o[e + 1] // align] = e
+
+    ops.call = call
+    ops._sfx = lambda t, name: '' if t.dtype == torch.bfloat16 else '_f32'
+    ops._chk = lambda t, dtype, name: None
+    ops.stream = lambda: 0
+    z = load_golden('qwen3moe_tiny_dpo.npz')
+    tr = DPOTrainer(_cfgs(z, expert_parallel=True), {'gradient_clipping': 1.0}, model_cfg=tiny_qwen3moe_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                    reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cpu')
+    st = tr.policy.store
+    ok = tr.policy.ep.size == world and st.p['model.layers.0.mlp.experts.gate_up_proj'].shape[0] == 8 // world and 'exp' in st.sizes
+    orig_zero = st.zero_grad
+
+    def zero_then_mark():
+        orig_zero()
+        for g in st.gflat.values():
+            g.fill_(float(rank + 1))
+    st.zero_grad = zero_then_mark
+    rows = [rank, rank + 2]
+    b = {'input_ids': T(z['input_ids'])[rows], 'attention_mask': T(z['attention_mask'])[rows], 'meta_info': {'response_lens': [int(z['response_lens'][r]) for r in rows]}}
+    info = tr.train_step(b)
+    want = float(sum(range(1, world + 1)))
+    for name, g in st.gflat.items():       # replicated groups are summed over the ranks; the expert shard is this rank's own and never reduced
+        ok = ok and bool((g.float() == (float(rank + 1) if name == 'exp' else want)).all())
+    ok = ok and 'train/loss' in info and 'aa_gemm_grouped_bf16' in seen and seen.count('aa_moe_plan') == 2 * 2 * 2      # (dense + local plan) x 2 layers x (policy + reference)
+    sd = tr.policy.state_dict()                                            # collective: expert rows gathered back
+    ok = ok and sd['model.layers.1.mlp.experts.down_proj'].shape[0] == 8
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_expert_parallel_step_host_flow():
+    """World-size-2 gloo run of an expert-parallel Qwen3-MoE DPO step on CPU tensors: the token exchange runs for real (split sizes from
+    the emulated plan), the replicated gradient groups are all-reduced exactly once, the expert shard never is, the clip-norm exchange and the
+    optimizer step go through, `state_dict()` gathers the experts.  The numerics of the same step are pinned on hardware (tests/test_ep_gpu.py)."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
