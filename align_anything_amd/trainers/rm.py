@@ -58,3 +58,35 @@ class RMTrainer:
         self.model.step()
         s = get_all_reduce_mean(ld['_stats'].clone()).tolist()
         return {'train/loss': s[0], 'train/accuracy': s[1], 'train/lr': self.model.optimizer.param_groups[0]['lr']}
+
+    @torch.no_grad()
+    def eval(self, eval_dataloader=None) -> dict:
+        """rm.py eval (the loop before `train_step` in the reference file): end scores of every chosen / rejected pair of the evaluation
+        set, `eval/accuracy` (chosen scored higher; all-reduce mean like the reference), `eval/reward_mean` / `eval/reward_std` over the rewards
+        of all ranks (the reference gathers them on rank 0; here every rank gets the same numbers).  Returns {} without a dataloader."""
+        import torch.distributed as dist
+        dl = eval_dataloader if eval_dataloader is not None else getattr(self, 'eval_dataloader', None)
+        if dl is None:
+            return {}
+        correct, total, rewards = None, 0, []
+        for batch in dl:
+            ids, am = batch['input_ids'], batch['attention_mask']
+            B = ids.shape[0] // 2
+            w, _ = self._end_window(ids, am)
+            self.model.wait_optimizer()
+            s = self.model.module.response_scores(ids, am, w, pixel_values=batch.get('pixel_values'), save=False)[:2 * B]
+            hits = (s[:B] > s[B:]).sum()
+            correct = hits if correct is None else correct + hits
+            total += B
+            rewards.append(s.float())
+        if not rewards:
+            return {}
+        accuracy = get_all_reduce_mean((correct.float() / total).reshape(1))
+        rewards = torch.cat(rewards)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            parts = [torch.empty_like(rewards) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, rewards)
+            rewards = torch.cat(parts)
+        return {'eval/accuracy': float(accuracy.item()), 'eval/reward_mean': float(rewards.mean().item()),
+                'eval/reward_std': float(rewards.std().item())}
+

@@ -152,6 +152,10 @@ def test_grpo_and_rm_steps(launches):
     del launches[:]
     info = rm.train_step(_pref_batch(z))
     assert 'train/loss' in info and 'aa_rm_loss_fwd_bwd' in launches and 'aa_rowdot_bwd' in launches
+    assert rm.eval() == {} and rm.eval([]) == {}
+    del launches[:]
+    ev = rm.eval([_pref_batch(z), _pref_batch(z)])
+    assert set(ev) == {'eval/accuracy', 'eval/reward_mean', 'eval/reward_std'} and launches.count('aa_rowdot_fwd') == 2 and 'aa_adamw_flat' not in launches
 
 
 def test_multimodal_backbones_and_ti2t_ppo_update(launches):
