@@ -117,3 +117,15 @@ class GRPOTrainer:
         self.actor_model.step()
         s = get_all_reduce_mean(torch.stack([loss.reshape(()), rewards.mean()])).tolist()
         return {'train/loss': s[0], 'train/reward': s[1]}
+
+    def train(self, prompt_only_dataloader, generator=None) -> list:
+        """grpo.py train loop without its logging / checkpoint plumbing: one `train_step` (rollout of `num_generations` completions per
+        prompt, rewards, update) per prompt batch and epoch; returns the per-step metrics."""
+        history = []
+        self.global_step = getattr(self, 'global_step', 0)
+        for _ in range(int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))):
+            for batch in prompt_only_dataloader:
+                history.append(self.train_step(batch, generator))
+                self.global_step += 1
+        return history
+

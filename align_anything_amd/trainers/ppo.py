@@ -169,6 +169,43 @@ class PPOTrainer(PPOMath):
         self.actor_model.step()
         return {'train/ptx_loss': float(get_all_reduce_mean(ptx_loss.reshape(1).clone()).item())}
 
+    # ------------------------------------------------------------------ outer loop (ppo.py:410-480)
+    @staticmethod
+    def _rows(batch, lo, hi):
+        return {k: (v[lo:hi] if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+
+    def train(self, prompt_only_dataloader, ptx_dataloader=None, generator=None):
+        """The reference's PPO loop without its logging / checkpoint plumbing: every prompt batch is rolled out in micro-batches of
+        `per_device_train_batch_size` prompts (ppo.py:244-289), then `update_iters` passes of `rl_step` (+ `ptx_step` when a PTX
+        dataloader is given) run over those micro-batches.  Reference quirks kept: PTX batches are cycled to the length of the prompt set
+        (:427-433), split into ONE-row micro-batches (`split_ptx_micro_batches`, :195-207) and zipped with the rollout micro-batches (the
+        shorter list wins).  Returns the per-step metric dicts."""
+        import itertools
+        t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
+        epochs, update_iters = int(t('epochs', 1)), int(t('update_iters', 1))
+        micro = int(t('per_device_train_batch_size', 8))
+        use_ptx = ptx_dataloader is not None
+        self.global_step = getattr(self, 'global_step', 0)
+        history = []
+        for _ in range(epochs):
+            ptx_iter = itertools.cycle(ptx_dataloader) if use_ptx else None
+            for prompt_batch in prompt_only_dataloader:
+                n = prompt_batch['input_ids'].shape[0]
+                rollouts = [self.rollout(self._rows(prompt_batch, i, i + micro), generator) for i in range(0, n, micro)]
+                if use_ptx:
+                    pb = next(ptx_iter)
+                    ptx_batches = [self._rows(pb, i, i + 1) for i in range(pb['input_ids'].shape[0])]
+                else:
+                    ptx_batches = [None] * len(rollouts)
+                for _ in range(update_iters):
+                    for (inference_batch, training_batch), ptx_batch in zip(rollouts, ptx_batches):
+                        info = self.rl_step(inference_batch, training_batch)
+                        if use_ptx:
+                            info.update(self.ptx_step(ptx_batch))
+                        self.global_step += 1
+                        history.append(info)
+        return history
+
     # ------------------------------------------------------------------ update (ppo.py:309-398)
     def rl_step(self, inference_batch, training_batch):
         old_log_probs = training_batch['log_probs'].float()

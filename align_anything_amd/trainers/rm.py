@@ -59,6 +59,19 @@ class RMTrainer:
         s = get_all_reduce_mean(ld['_stats'].clone()).tolist()
         return {'train/loss': s[0], 'train/accuracy': s[1], 'train/lr': self.model.optimizer.param_groups[0]['lr']}
 
+    def train(self, train_dataloader=None) -> list:
+        """rm.py train loop without its logging / checkpoint plumbing: `epochs` passes of `train_step`; returns the per-step metrics."""
+        dl = train_dataloader if train_dataloader is not None else getattr(self, 'train_dataloader', None)
+        if dl is None:
+            raise ValueError('RMTrainer.train needs a dataloader of preference batches')
+        history = []
+        self.global_step = getattr(self, 'global_step', 0)
+        for _ in range(int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))):
+            for batch in dl:
+                history.append(self.train_step(batch))
+                self.global_step += 1
+        return history
+
     @torch.no_grad()
     def eval(self, eval_dataloader=None) -> dict:
         """rm.py eval (the loop before `train_step` in the reference file): end scores of every chosen / rejected pair of the evaluation

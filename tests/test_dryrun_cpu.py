@@ -127,6 +127,15 @@ def test_ppo_rollout_update_and_ptx_steps(launches):
     out = tr.ptx_step({'input_ids': inference['input_ids'], 'attention_mask': inference['attention_mask'], 'labels': labels})
     assert set(out) == {'train/ptx_loss'} and tr.actor_model.global_steps == 2 and tr.reward_critic_model.global_steps == 1
     assert 'aa_sft_loss_fwd_bwd' in launches and 'aa_adamw_flat' in launches
+    # the outer loop: 2 prompt batches x 2 micro-batches x 2 update iterations, PTX batches cycled and split into one-row micro-batches
+    cfgs2 = {'train_cfgs': dict(cfgs['train_cfgs'], per_device_train_batch_size=2, update_iters=2, epochs=1), 'model_cfgs': cfgs['model_cfgs']}
+    tr3 = PPOTrainer(cfgs2, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, reward_state=rm_sd, device='cpu')
+    pbatch = {'input_ids': prompts, 'attention_mask': T(z['attention_mask'])[:, :24]}
+    ptx = {'input_ids': inference['input_ids'], 'attention_mask': inference['attention_mask'], 'labels': labels}
+    hist = tr3.train([pbatch, pbatch], ptx_dataloader=[ptx])
+    assert len(hist) == 8 and tr3.global_step == 8 and all('train/ptx_loss' in h and 'train/actor_loss' in h for h in hist)
+    assert tr3.actor_model.global_steps == 16 and tr3.reward_critic_model.global_steps == 8
+    assert len(tr3.train([pbatch])) == 4 and tr3.actor_model.global_steps == 20          # without PTX
     # a rule reward instead of the reward model
     tr2 = PPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, critic_state=rm_sd, device='cpu', reward_fn=lambda i, a: [1.0] * i.shape[0])
     assert tr2.reward_model is None and tr2.reward_model_step(prompts, torch.ones_like(prompts))['reward'].tolist() == [1.0] * 4
@@ -152,6 +161,8 @@ def test_grpo_and_rm_steps(launches):
     del launches[:]
     info = rm.train_step(_pref_batch(z))
     assert 'train/loss' in info and 'aa_rm_loss_fwd_bwd' in launches and 'aa_rowdot_bwd' in launches
+    assert len(rm.train([_pref_batch(z)] * 3)) == 3 and rm.model.global_steps == 4 and rm.global_step == 3
+    assert len(tr.train([{'input_ids': prompts, 'attention_mask': torch.ones_like(prompts)}] * 2)) == 2 and tr.actor_model.global_steps == 3
     assert rm.eval() == {} and rm.eval([]) == {}
     del launches[:]
     ev = rm.eval([_pref_batch(z), _pref_batch(z)])
