@@ -76,3 +76,25 @@ class KTOTrainer(_SlicedPreferenceTrainer):
     def _params(self):
         return (float(cfg_get(self.cfgs, 'train_cfgs.scale_better', 1.0)), float(cfg_get(self.cfgs, 'train_cfgs.scale_worse', 1.0)),
                 float(self.kl))
+
+    def train(self, kl_dataloader=None):
+        """kto.py:196-240: at the start of every epoch whose first step index is a multiple of `kl_steps`, the KL estimate is refreshed
+        over the unmatched batches (`kl_dataloader`: prompts paired with a neighbour's response, datasets/text_to_text/supervised.py
+        UnmatchedSupervisedDataset) -- each batch overwrites the estimate, the last one stands, as in the reference's loop -- then the
+        ordinary preference steps run."""
+        history = []
+        epochs = int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))
+        kl_steps = max(1, int(cfg_get(self.cfgs, 'train_cfgs.kl_steps', 1)))
+        self.model.train()
+        for _ in range(epochs):
+            if kl_dataloader is not None and self.global_step % kl_steps == 0:
+                for b in kl_dataloader:
+                    self.compute_kl(b)
+            for batch in self.train_dataloader:
+                info = self.train_step(batch)
+                self.global_step += 1
+                info['train/epoch'] = self.global_step / max(1, len(self.train_dataloader))
+                history.append(info)
+            self.model.tput_timer.update_epoch_count()
+        return history
+

@@ -67,6 +67,11 @@ def test_dpo_family_steps_launch_the_expected_kernels(launches, dtype):
         assert 'aa_grad_sumsq' in launches and 'aa_clip_coef' in launches
         gemm = 'aa_gemm_bf16' if dtype == 'bf16' else 'aa_gemm_f32'
         assert gemm in launches and ('aa_attn_bwd' + ('' if dtype == 'bf16' else '_f32')) in launches
+        tr.train_dataloader = [_pref_batch(z)] * 4                 # the inherited epoch loop (accumulation of 2 -> 2 optimizer steps)
+        del launches[:]
+        hist = tr.train([_pref_batch(z)] * 3) if cls is KTOTrainer else tr.train()
+        assert len(hist) == 4 and hist[-1]['train/epoch'] == 1.0 and tr.model.global_steps == 3
+        assert launches.count('aa_window_kl') == (3 if cls is KTOTrainer else 0)
 
 
 def test_llava_and_moe_dpo_steps(launches):
