@@ -105,6 +105,19 @@ class SupervisedCollator:
         return {'input_ids': _pin(ids), 'labels': _pin(labels), 'attention_mask': _pin(ids.ne(self.pad_token_id))}
 
 
+class UnmatchedSupervisedCollator:
+    """datasets/text_to_text/supervised.py:196-219, the batches KTO estimates its KL term on (a prompt paired with a neighbour's response):
+    input_ids right-padded, attention_mask = ids != pad, labels None, meta_info.response_lens from the samples."""
+
+    def __init__(self, pad_token_id: int):
+        self.pad_token_id = int(pad_token_id)
+
+    def __call__(self, samples) -> dict:
+        ids = _pad([s['input_ids'] for s in samples], self.pad_token_id, 'right')
+        return {'input_ids': _pin(ids), 'labels': None, 'attention_mask': _pin(ids.ne(self.pad_token_id)),
+                'meta_info': {'response_lens': [int(s['response_lens']) for s in samples]}}
+
+
 class PromptOnlyCollator:
     """datasets/text_to_text/prompt_only.py:154-175: prompts LEFT-padded with pad_token_id; the mask marks the real tokens of every
     row (all of them, also a pad id inside the text) -- what `generate` and the PPO rollout consume."""

@@ -665,9 +665,12 @@ def gen_collator():
         lab[:p] = -100
     sb = sup.SupervisedCollator(1)([{'input_ids': r, 'labels': l} for r, l in zip(rows, labels)])
     pb = po.PromptOnlyCollator(1)([{'input_ids': r} for r in rows])
+    ub = sup.UnmatchedSupervisedCollator(1)([{'input_ids': r, 'response_lens': n} for r, n in zip(rows, (4, 1, 9, 2))])
     out.update({'tok_lens': np.array([len(r) for r in rows]), 'tok_flat': torch.cat(rows).numpy(), 'lab_flat': torch.cat(labels).numpy(),
                 'sft_input_ids': sb['input_ids'].numpy(), 'sft_labels': sb['labels'].numpy(), 'sft_attention_mask': sb['attention_mask'].numpy(),
-                'prompt_input_ids': pb['input_ids'].numpy(), 'prompt_attention_mask': pb['attention_mask'].numpy()})
+                'prompt_input_ids': pb['input_ids'].numpy(), 'prompt_attention_mask': pb['attention_mask'].numpy(),
+                'unmatched_input_ids': ub['input_ids'].numpy(), 'unmatched_attention_mask': ub['attention_mask'].numpy(),
+                'unmatched_response_lens': np.array(ub['meta_info']['response_lens']), 'unmatched_labels_is_none': np.array(ub['labels'] is None)})
     np.savez_compressed(os.path.join(GOLD, 'collator.npz'), **out)
     print('collator.npz', {k: v.shape for k, v in out.items()})
 

@@ -380,6 +380,10 @@ def test_supervised_and_prompt_only_collators_reproduce_the_reference_batches():
         assert torch.equal(pb[k], torch.from_numpy(z['prompt_' + k])), k
     T = pb['input_ids'].shape[1]
     assert bool(pb['attention_mask'][2, T - lens[2] + 4]) and int(pb['input_ids'][2, T - lens[2] + 4]) == 1
+    from align_anything_amd.data import UnmatchedSupervisedCollator
+    ub = UnmatchedSupervisedCollator(1)([{'input_ids': r, 'response_lens': n} for r, n in zip(rows, (4, 1, 9, 2))])        # KTO's KL batches
+    assert torch.equal(ub['input_ids'], torch.from_numpy(z['unmatched_input_ids'])) and torch.equal(ub['attention_mask'], torch.from_numpy(z['unmatched_attention_mask']))
+    assert ub['meta_info']['response_lens'] == z['unmatched_response_lens'].tolist() and ub['labels'] is None and bool(z['unmatched_labels_is_none'])
     got = list(DevicePrefetcher([sb], 'cpu'))
     assert len(got) == 1 and '_labels_host' not in got[0]
     w = got[0]['_window']
