@@ -32,11 +32,15 @@ class TokenizedPreferenceCache:
     better_response_lens, worse_response_lens; preference.py:132-160).  processor(text=..., images=..., return_tensors='pt')
     is called once per conversation, without padding."""
 
-    def __init__(self, samples, processor, has_images: bool = True):
+    def __init__(self, samples, processor, has_images: bool = True, processor_kwargs: dict | None = None):
+        """processor_kwargs: extra arguments of the per-conversation call, to mirror the collator being replaced -- the text-to-text
+        PreferenceCollator tokenises with `add_special_tokens=False` (datasets/text_to_text/preference.py:186-193), the text+image one
+        with the processor's defaults (datasets/text_image_to_text/preference.py:232-239)."""
         self.items = []
+        extra = dict(processor_kwargs or {})
         for s in samples:
             img = s.get('image') if has_images else None
-            kw = {'images': img} if img is not None else {}
+            kw = dict(extra, images=img) if img is not None else dict(extra)
             b = processor(text=s['better_conversation'], return_tensors='pt', **kw)
             w = processor(text=s['worse_conversation'], return_tensors='pt', **kw)
             item = {'better_ids': _pin(b['input_ids'][0].to(torch.int64).contiguous()),

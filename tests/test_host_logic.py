@@ -519,3 +519,24 @@ def test_every_ctypes_call_site_matches_its_prototype_arity():
                 bad.append((os.path.basename(f), node.lineno, name, len(node.args) - 1, sorted(want)))
     assert not bad, bad
     assert checked >= 70
+
+
+def test_preference_cache_forwards_tokenizer_arguments_of_the_text_collator():
+    """The text-to-text PreferenceCollator tokenises with add_special_tokens=False (datasets/text_to_text/preference.py:186-193): the cache
+    must be able to make the same call, or every cached row would carry an extra BOS."""
+    from align_anything_amd.data import CachedPreferenceCollator, TokenizedPreferenceCache
+
+    class Tok:
+        pad_token_id = 0
+
+        def __call__(self, text, return_tensors='pt', add_special_tokens=True, **kw):
+            ids = [1] * bool(add_special_tokens) + [10 + (ord(c) % 7) for c in text]
+            return {'input_ids': torch.tensor([ids])}
+
+    samples = [{'better_conversation': 'abcd', 'worse_conversation': 'xy', 'better_response_lens': 2, 'worse_response_lens': 1}]
+    with_bos = TokenizedPreferenceCache(samples, Tok(), has_images=False)
+    plain = TokenizedPreferenceCache(samples, Tok(), has_images=False, processor_kwargs={'add_special_tokens': False})
+    assert with_bos[0]['better_ids'].tolist()[0] == 1 and len(with_bos[0]['better_ids']) == 5
+    assert plain[0]['better_ids'].tolist() == [10 + (ord(c) % 7) for c in 'abcd'] and len(plain[0]['worse_ids']) == 2
+    b = CachedPreferenceCollator(0, 'right')([plain[0]])
+    assert b['input_ids'].shape == (2, 4) and b['attention_mask'].tolist() == [[1, 1, 1, 1], [1, 1, 0, 0]] and b['meta_info']['response_lens'] == [2, 1]
