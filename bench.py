@@ -240,12 +240,13 @@ def main():
             traffic = None
             try:
                 with open(os.path.join(ROOT, 'profiles', 'r01_gemm_traffic.json')) as f:
-                    traffic = json.load(f)['gemm_hbm_bytes_per_launch']
+                    tj = json.load(f)
+                    traffic = tj.get('gemm_hbm_bytes_per_launch_full_depth_mix', tj['gemm_hbm_bytes_per_launch'])     # re-weighted to the 32-layer launch mix
             except (OSError, KeyError, ValueError):
                 pass              # the profile is not in this checkout: traffic stays null
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel<BM,BN,...> (csrc/gemm.hip), all launches of the timed steps',
                                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                               'traffic': traffic, 'traffic_unit': 'HBM bytes per GEMM launch (PMC, profiles/r01_gemm_traffic.json)',
+                               'traffic': traffic, 'traffic_unit': 'HBM bytes per GEMM launch (PMC passes of tools/gpu_traffic.sh re-weighted to this workload\'s launch mix, profiles/r01_gemm_traffic.json)',
                                'algorithmic_bytes_per_launch': sum(e[3] for e in gemm_events) / n,
                                'launches': n, 'launch_sampling': f'every {ops.GEMM_PROF_STRIDE}th GEMM launch of the timed steps', 'avg_launch_ms': tot_ms / n,
                                'avg_flops_per_launch': tot_fl / n, 'gemm_share_of_step_time': tot_ms / (dt * 1e3)}
