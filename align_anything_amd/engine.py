@@ -76,6 +76,8 @@ class NativeEngine:
         self.trainable = trainable
         self.base_lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(float(b) for b in betas), eps, weight_decay
         self.max_grad_norm = max_grad_norm
+        # total_steps None = not known yet (the RL / RM trainers learn it from the dataloader handed to train()): a decaying
+        # schedule then refuses to step instead of silently decaying to 0 after the first update
         self.total_steps, self.warmup_steps, self.sched = total_steps, warmup_steps, lr_scheduler_type
         self.global_steps = 0
         self.reducer = GradReducer(group)
@@ -120,8 +122,31 @@ class NativeEngine:
     def __call__(self, *a, **k):
         raise RuntimeError('NativeEngine is not callable: use trainer.compute_log_probs(engine.module, batch)')
 
+    def set_schedule(self, total_steps: int, warmup_ratio: float | None = None, gradient_accumulation_steps: int | None = None):
+        """Length of the LR schedule in OPTIMIZER updates (what the reference hands to transformers.get_scheduler,
+        base/rl_trainer.py:190-197, base/supervised_trainer.py:236-257) and, optionally, the accumulation depth.  May be called
+        until the first update; the trainers' train() use it once the dataloader length is known."""
+        if self.global_steps:
+            raise RuntimeError('set_schedule() after the first optimizer update')
+        if gradient_accumulation_steps is not None:
+            if self.micro_steps % self.gas:
+                raise RuntimeError('set_schedule(): cannot change the accumulation depth inside an accumulation window')
+            self.gas = max(1, int(gradient_accumulation_steps))
+            self.micro_steps = 0
+        self.total_steps = max(1, int(total_steps))
+        if warmup_ratio is not None:
+            self.warmup_steps = int(self.total_steps * float(warmup_ratio))
+        for pg in self.optimizer.param_groups:
+            pg['lr'] = self._lr_at(0)
+
     def _lr_at(self, step):
         if self.sched == 'cosine':
+            if self.total_steps is None:
+                if step == 0:
+                    return 0.0 if self.warmup_steps else self.base_lr
+                raise RuntimeError("lr_scheduler_type 'cosine' needs the number of optimizer updates: run the trainer's train() (it "
+                                   "derives it from the dataloader like the reference), call engine.set_schedule(total), or set "
+                                   "train_cfgs.total_training_steps")
             return cosine_with_warmup(step, self.base_lr, self.warmup_steps, self.total_steps)
         if self.sched == 'constant':
             return self.base_lr

@@ -69,6 +69,8 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
         'tslot': torch.full((N,), T, dtype=torch.int64, device=dev), 'pos': model.decode_start_positions(valid).to(torch.int32).clone(),
         'length': torch.full((N,), T + 1, dtype=torch.int32, device=dev), 'step': torch.zeros(1, dtype=torch.int64, device=dev),
         'U': torch.rand((max_new_tokens, N), device=dev, generator=generator) if do_sample else None,
+        # number of steps that still produced a token for at least one row = the columns HF's stopping criteria keep
+        'nact': torch.zeros(1, dtype=torch.int64, device=dev),
     }
     padv = torch.full((N,), pad_token_id, dtype=torch.int64, device=dev)
     seen = None
@@ -82,6 +84,7 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
 
     def one_step():
         """select token from st['logits'], record it, run one decode pass, leave next logits in st['logits']."""
+        st['nact'].add_(st['unfinished'].any().to(torch.int64))
         nxt = select(st['logits'], st['U'].index_select(0, st['step'])[0] if do_sample else None)
         nxt = torch.where(st['unfinished'], nxt, padv)
         out.scatter_(1, st['tslot'][:, None], nxt[:, None])
@@ -97,28 +100,33 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
 
     graph = None
     if use_graph and max_new_tokens > 4:
+        # everything the warm-up step mutates is restored afterwards: the decode state, the output and the repetition-penalty
+        # marks (`seen`), so a token the warm-up happened to sample is not penalised for the whole rollout
+        snap = {k: v.clone() for k, v in st.items() if v is not None and k != 'U'}
+        out_snap = out.clone()
+        seen_snap = seen.clone() if seen is not None else None
+
+        def restore():
+            for k, v in snap.items():
+                st[k].copy_(v)
+            out.copy_(out_snap)
+            if seen is not None:
+                seen.copy_(seen_snap)
+
         try:
-            snap = {k: v.clone() for k, v in st.items() if v is not None and k != 'U'}
-            out_snap = out.clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 one_step()                                      # warm-up on a side stream (allocator, lazy inits)
             torch.cuda.current_stream().wait_stream(side)
-            for k, v in snap.items():
-                st[k].copy_(v)
-            out.copy_(out_snap)
+            restore()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 one_step()
-            for k, v in snap.items():                           # capture does not execute: state is still pristine,
-                st[k].copy_(v)                                  # but make that explicit
-            out.copy_(out_snap)
+            restore()                                           # capture does not execute: state is still pristine, but make that explicit
         except Exception:                                       # capture unsupported -> eager launches
             graph = None
-            for k, v in snap.items():
-                st[k].copy_(v)
-            out.copy_(out_snap)
+            restore()
 
     generate.last_used_graph = graph is not None
     n_new = 0
@@ -127,6 +135,7 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
     for step in range(max_new_tokens):
         if step + 1 == max_new_tokens:
             # final token: selection only
+            st['nact'].add_(st['unfinished'].any().to(torch.int64))
             nxt = select(st['logits'], st['U'][step] if do_sample else None)
             nxt = torch.where(st['unfinished'], nxt, padv)
             out[:, T + step] = nxt
@@ -141,7 +150,8 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
             break
     seq = out[:, :T + n_new]
     if eos_token_id is not None:
-        # drop trailing columns that are pad for every row (rows that finished before the last sync point)
-        keep = int((seq != pad_token_id).any(dim=0).nonzero().max().item()) + 1 if bool((seq != pad_token_id).any()) else T
-        seq = seq[:, :max(keep, T)]
+        # HF stops at the step in which the last unfinished row emitted its EOS: keep exactly the columns of steps that still had
+        # an unfinished row when they started (steps run past that point between two sync checks only wrote pad).  Counting steps,
+        # not non-pad columns, keeps a final EOS column when pad_token_id == eos_token_id.
+        seq = seq[:, :T + min(n_new, int(st['nact'].item()))]
     return seq

@@ -87,12 +87,17 @@ def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=Fals
         e0 = event_record()
     if sfx and out.dtype != f32:
         raise RuntimeError('gemm: fp32 operands need an fp32 output')
+    FLOPS['gemm'] += 2.0 * M * N * K
     call('aa_gemm_f32' if sfx else 'aa_gemm_bf16', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0),
          b.stride(0), out.stride(0), _p(bias), _p(residual), ldr, int(act), flags, stream())
     if prof is not None:
         prof.append((e0, event_record(), 2.0 * M * N * K, float(a.element_size()) * (M * K + N * K) + out.element_size() * M * N))
     return out
 
+
+# executed-work counters (bench.py: MFMA fraction on the FLOPs the step really executes): 2*M*N*K per GEMM launch,
+# 4*T*T*hd per (row, head) of attention forward (halved when causal), 2.5x that for its backward
+FLOPS = {'gemm': 0.0, 'attn': 0.0}
 
 # HIP events on the launch stream (bench.py roofline: per-launch GEMM durations over the timed region)
 GEMM_PROF = None
@@ -464,6 +469,7 @@ def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None, kv_
     """q/k/v: 2-D views [N*T, >=H*hd] (column slices of the fused qkv buffer are fine)."""
     out = torch.empty((N * T, H * hd), dtype=q.dtype, device=q.device) if out is None else out
     lse = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
+    FLOPS['attn'] += 4.0 * N * H * T * T * hd * (0.5 if causal else 1.0)
     call('aa_attn_fwd' + _sfx(q, 'attn_fwd'), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(start), _p(kv_len),
          q.stride(0), k.stride(0), v.stride(0), out.stride(0), N, T, H, Hkv, hd, int(causal), float(scale), stream())
     return out, lse
@@ -471,6 +477,7 @@ def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None, kv_
 
 def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start=None, kv_len=None):
     delta = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
+    FLOPS['attn'] += 10.0 * N * H * T * T * hd * (0.5 if causal else 1.0)
     call('aa_attn_bwd' + _sfx(q, 'attn_bwd'), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
          delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(start), _p(kv_len), q.stride(0), k.stride(0),
          v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), N, T, H, Hkv, hd,

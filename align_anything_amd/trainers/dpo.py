@@ -92,15 +92,17 @@ class DPOTrainer:
     def init_engines(self) -> None:
         """base/supervised_trainer.py:234-271 + dpo.py:114-120, with the native engine in DeepSpeed's place."""
         t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
-        steps_per_epoch = len(self.train_dataloader) if self.train_dataloader is not None and hasattr(self.train_dataloader, '__len__') else 1
         gas = int(t('gradient_accumulation_steps', 1))
-        total = int(t('epochs', 1)) * ((steps_per_epoch + gas - 1) // gas)
-        total = int(t('total_training_steps', total))
+        total = None         # unknown: a cosine schedule refuses to step (engine._lr_at) instead of decaying to 0 after one update
+        if self.train_dataloader is not None and hasattr(self.train_dataloader, '__len__'):
+            total = int(t('epochs', 1)) * ((len(self.train_dataloader) + gas - 1) // gas)      # supervised_trainer.py:236-239
+        total = t('total_training_steps', total)
+        total = int(total) if total is not None else None
         betas = [float(b) for b in t('adam_betas', [0.9, 0.95])]
         self.model = NativeEngine(self.policy, lr=float(t('learning_rate', 1e-6)), betas=betas,
                                   eps=float(t('adam_epsilon', 1e-8)), weight_decay=float(t('weight_decay', 0.0)),
                                   max_grad_norm=float(cfg_get(self.ds_train_cfgs, 'gradient_clipping', 1.0)),
-                                  total_steps=total, warmup_steps=int(float(t('lr_warmup_ratio', 0.03)) * total),
+                                  total_steps=total, warmup_steps=int(float(t('lr_warmup_ratio', 0.03)) * (total or 0)),
                                   lr_scheduler_type=t('lr_scheduler_type', 'cosine'), trainable=True,
                                   gradient_accumulation_steps=gas)
         self.reference_model = NativeEngine(self.reference, trainable=False) if self.reference is not None else None
@@ -186,6 +188,9 @@ class DPOTrainer:
         """dpo.py:239-308 without the per-step torch_gc() (a ZeRO-3 memory work-around)."""
         history = []
         epochs = int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))
+        if self.model.total_steps is None and not self.model.global_steps and hasattr(self.train_dataloader, '__len__'):   # dataloader attached after __init__
+            self.model.set_schedule(epochs * ((len(self.train_dataloader) + self.model.gas - 1) // self.model.gas),
+                                    float(cfg_get(self.cfgs, 'train_cfgs.lr_warmup_ratio', 0.03)))
         self.model.train()
         for epoch in range(epochs):
             for batch in self.train_dataloader:

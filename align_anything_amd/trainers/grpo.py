@@ -37,12 +37,16 @@ class GRPOTrainer:
             actor.load_state_dict(actor_state)
         if reference_state is not None or actor_state is not None:
             ref.load_state_dict(reference_state if reference_state is not None else actor_state)
-        total = int(t('total_training_steps', 1))
+        # grpo.py:153-181: the schedule length comes from the prompt dataloader that train() receives; until then it is unknown
+        # (an explicit train_cfgs.total_training_steps wins) and a cosine engine refuses to step rather than decay to 0
+        self.gas = int(cfg_get(ds_cfgs, 'gradient_accumulation_steps', t('gradient_accumulation_steps', 1)))
+        total = t('total_training_steps', None)
+        total = None if total is None else max(1, int(total) // self.gas)
         self.actor_model = NativeEngine(
             actor, lr=float(t('actor_lr', 1e-6)), betas=[float(b) for b in t('adam_betas', [0.9, 0.95])],
             weight_decay=float(t('actor_weight_decay', 0.01)), max_grad_norm=float(cfg_get(ds_cfgs, 'gradient_clipping', 1.0)),
-            total_steps=total, warmup_steps=int(float(t('actor_lr_warmup_ratio', 0.03)) * total),
-            lr_scheduler_type=t('actor_lr_scheduler_type', 'cosine'))
+            total_steps=total, warmup_steps=int(float(t('actor_lr_warmup_ratio', 0.03)) * (total or 0)),
+            lr_scheduler_type=t('actor_lr_scheduler_type', 'cosine'), gradient_accumulation_steps=self.gas)
         self.actor_reference_model = NativeEngine(ref, trainable=False)
         self.reward_model = None
         if reward_fn is None:
@@ -123,6 +127,11 @@ class GRPOTrainer:
         prompt, rewards, update) per prompt batch and epoch; returns the per-step metrics."""
         history = []
         self.global_step = getattr(self, 'global_step', 0)
+        t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
+        if self.actor_model.total_steps is None and not self.actor_model.global_steps and hasattr(prompt_only_dataloader, '__len__'):
+            total = (len(prompt_only_dataloader) * int(t('epochs', 1)) * int(t('update_iters', 1)) * int(t('per_device_prompt_batch_size', 1))
+                     // max(1, int(t('per_device_train_batch_size', 1))))            # grpo.py:157-163
+            self.actor_model.set_schedule(max(1, total // self.gas), float(t('actor_lr_warmup_ratio', 0.03)))
         for _ in range(int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))):
             for batch in prompt_only_dataloader:
                 history.append(self.train_step(batch, generator))

@@ -67,7 +67,7 @@ class PPOTrainer(PPOMath):
     (base/rl_trainer.py:217-272).  The rollout batch (sequences from `generate`) is an input."""
 
     def __init__(self, cfgs, ds_cfgs=None, *, model_cfg, reward_model_cfg=None, actor_state=None, reward_state=None,
-                 critic_state=None, device='cuda:0', reward_fn=None):
+                 critic_state=None, device='cuda:0', reward_fn=None, use_ptx=None):
         """reward_fn(input_ids, attention_mask) -> [N] scores replaces the learned reward model: the rule / remote reward of
         trainers/text_to_text/ppo_remote_rm.py:321-347 (decode prompts + responses on the host, score them over HTTP with
         `remote_rm_client.score`; that string work stays the caller's Python) -- the critic still comes from `reward_model_cfg`."""
@@ -93,13 +93,22 @@ class PPOTrainer(PPOMath):
             critic.load_state_dict(critic_state if critic_state is not None else reward_state)
         clip = float(cfg_get(ds_cfgs, 'gradient_clipping', 1.0))
         betas = [float(b) for b in t('actor_betas', t('adam_betas', [0.9, 0.95]))]
-        total = int(t('total_training_steps', 1))
+        # base/rl_trainer.py:217-260: the schedule length comes from the prompt dataloader, which train() receives -> the engines start
+        # with an unknown total (explicit train_cfgs.total_training_steps = number of MICRO steps wins) and train() fills it in.
+        # With a PTX dataset the actor accumulates over (rl_step, ptx_step) pairs: its accumulation depth and micro-step total double
+        # (:231-234), so both losses are scaled by 1 / (2 gas) and land in ONE optimizer update.
+        self.use_ptx = bool(cfg_get(cfgs, 'data_cfgs.ptx_datasets', None)) if use_ptx is None else bool(use_ptx)
+        self.gas = int(cfg_get(ds_cfgs, 'gradient_accumulation_steps', t('gradient_accumulation_steps', 1)))
+        total = t('total_training_steps', None)
+        a_gas = self.gas * (2 if self.use_ptx else 1)
+        a_total = None if total is None else max(1, int(total) * (2 if self.use_ptx else 1) // a_gas)
+        c_total = None if total is None else max(1, int(total) // self.gas)
         self.actor_model = NativeEngine(actor, lr=float(t('actor_lr', 1e-5)), betas=betas, weight_decay=float(t('actor_weight_decay', 0.01)),
-                                        max_grad_norm=clip, total_steps=total, warmup_steps=int(float(t('actor_lr_warmup_ratio', 0.03)) * total),
-                                        lr_scheduler_type=t('actor_lr_scheduler_type', 'cosine'))
+                                        max_grad_norm=clip, total_steps=a_total, warmup_steps=int(float(t('actor_lr_warmup_ratio', 0.03)) * (a_total or 0)),
+                                        lr_scheduler_type=t('actor_lr_scheduler_type', 'cosine'), gradient_accumulation_steps=a_gas)
         self.reward_critic_model = NativeEngine(critic, lr=float(t('critic_lr', 5e-6)), betas=betas, weight_decay=float(t('critic_weight_decay', 0.0)),
-                                                max_grad_norm=clip, total_steps=total, warmup_steps=int(float(t('critic_lr_warmup_ratio', 0.03)) * total),
-                                                lr_scheduler_type=t('critic_lr_scheduler_type', 'constant'))
+                                                max_grad_norm=clip, total_steps=c_total, warmup_steps=int(float(t('critic_lr_warmup_ratio', 0.03)) * (c_total or 0)),
+                                                lr_scheduler_type=t('critic_lr_scheduler_type', 'constant'), gradient_accumulation_steps=self.gas)
         self.actor_reference_model = NativeEngine(ref, trainable=False)
         self.reward_model = NativeEngine(reward, trainable=False) if reward is not None else None
 
@@ -156,8 +165,10 @@ class PPOTrainer(PPOMath):
 
     # ------------------------------------------------------------------ PTX mix-in (ppo.py:400-408)
     def ptx_step(self, ptx_batch):
-        """One supervised step on the actor with the pre-training / SFT batch (`input_ids`, `labels`, `attention_mask`):
-        backward of ptx_coeff * (HF causal-LM loss), logged unscaled -- the native form of the supervised loss is trainers/sft.py."""
+        """One supervised micro-step on the actor with the pre-training / SFT batch (`input_ids`, `labels`, `attention_mask`):
+        backward of ptx_coeff * (HF causal-LM loss), logged unscaled -- the native form of the supervised loss is trainers/sft.py.
+        With `use_ptx` the actor engine accumulates over 2 x gas micro-steps (base/rl_trainer.py:231-234), so the preceding
+        rl_step's `step()` was a no-op and the `step()` here applies the sum of both gradients as one update."""
         from .common import build_label_window
         ids = ptx_batch['input_ids']
         w = ptx_batch.get('_window') or build_label_window(ptx_batch['labels'], device=ids.device)
@@ -170,6 +181,33 @@ class PPOTrainer(PPOMath):
         return {'train/ptx_loss': float(get_all_reduce_mean(ptx_loss.reshape(1).clone()).item())}
 
     # ------------------------------------------------------------------ outer loop (ppo.py:410-480)
+    def _rollout_micro_batch(self, per_device_train_batch_size: int) -> int:
+        """Rows per rollout micro-batch (ppo.py:244-289 splits the prompt batch); 0 = roll out the whole prompt batch at once."""
+        return per_device_train_batch_size
+
+    def _set_schedules(self, prompt_only_dataloader, use_ptx: bool) -> None:
+        """base/rl_trainer.py:217-260: total micro-steps = len(prompt dataloader) x epochs x update_iters x per_device_train_batch_size
+        x per_device_prompt_batch_size; the schedulers run over total // gas updates; with PTX the actor's gas and total double."""
+        t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
+        a, c = self.actor_model, self.reward_critic_model
+        if use_ptx != self.use_ptx:
+            if a.global_steps:
+                raise RuntimeError('PTX dataloader presence changed after the first actor update')
+            self.use_ptx = use_ptx
+        a_gas = self.gas * (2 if use_ptx else 1)
+        explicit = t('total_training_steps', None)
+        if explicit is None and not hasattr(prompt_only_dataloader, '__len__'):
+            if a.gas != a_gas and not a.global_steps and a.micro_steps % a.gas == 0:
+                a.gas, a.micro_steps = a_gas, 0
+            return           # unsized iterable and no explicit total: a cosine engine will refuse to step (engine._lr_at)
+        if a.global_steps or c.global_steps:
+            return           # a resumed / second train() call keeps the schedule it started with
+        total = int(explicit) if explicit is not None else (
+            len(prompt_only_dataloader) * int(t('epochs', 1)) * int(t('update_iters', 1)) * int(t('per_device_train_batch_size', 8))
+            * int(t('per_device_prompt_batch_size', 1)))
+        a.set_schedule(max(1, total * (2 if use_ptx else 1) // a_gas), float(t('actor_lr_warmup_ratio', 0.03)), a_gas)
+        c.set_schedule(max(1, total // self.gas), float(t('critic_lr_warmup_ratio', 0.03)), self.gas)
+
     @staticmethod
     def _rows(batch, lo, hi):
         return {k: (v[lo:hi] if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
@@ -183,15 +221,17 @@ class PPOTrainer(PPOMath):
         import itertools
         t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
         epochs, update_iters = int(t('epochs', 1)), int(t('update_iters', 1))
-        micro = int(t('per_device_train_batch_size', 8))
+        micro = self._rollout_micro_batch(int(t('per_device_train_batch_size', 8)))
         use_ptx = ptx_dataloader is not None
+        self._set_schedules(prompt_only_dataloader, use_ptx)
         self.global_step = getattr(self, 'global_step', 0)
         history = []
         for _ in range(epochs):
             ptx_iter = itertools.cycle(ptx_dataloader) if use_ptx else None
             for prompt_batch in prompt_only_dataloader:
                 n = prompt_batch['input_ids'].shape[0]
-                rollouts = [self.rollout(self._rows(prompt_batch, i, i + micro), generator) for i in range(0, n, micro)]
+                step = micro or n
+                rollouts = [self.rollout(self._rows(prompt_batch, i, i + step), generator) for i in range(0, n, step)]
                 if use_ptx:
                     pb = next(ptx_iter)
                     ptx_batches = [self._rows(pb, i, i + 1) for i in range(pb['input_ids'].shape[0])]

@@ -21,6 +21,12 @@ class PPOTrainerTI2T(PPOTrainer):
     def _mm(batch):
         return {k: batch[k] for k in MM_KEYS if k in batch and batch[k] is not None}
 
+    def _rollout_micro_batch(self, per_device_train_batch_size: int) -> int:
+        """text_image_to_text/ppo.py:206-269 rolls out the WHOLE prompt batch in one go (no micro-batch split): the processor's
+        `pixel_values` are [sum of patches, C] with `image_grid_thw` describing all images, so row-slicing them would corrupt the
+        tower input."""
+        return 0
+
     def _pad_id(self):
         from .common import cfg_get
         return int(cfg_get(self.cfgs, 'model_cfgs.pad_token_id', 0))

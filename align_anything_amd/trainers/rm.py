@@ -19,11 +19,14 @@ class RMTrainer:
         module = build_model(model_cfg, device, trainable=True, head='score', dtype=compute_dtype(t('compute_dtype', 'bf16')))
         if state is not None:
             module.load_state_dict(state)
-        total = int(t('total_training_steps', 1))
+        # base/supervised_trainer.py:236-257: epochs x ceil(len(dataloader) / gas) updates -- known once train() has the dataloader
+        self.gas = int(t('gradient_accumulation_steps', cfg_get(ds_cfgs, 'gradient_accumulation_steps', 1)))
+        total = t('total_training_steps', None)
+        total = None if total is None else int(total)
         self.model = NativeEngine(module, lr=float(t('learning_rate', 2e-5)), betas=[float(b) for b in t('adam_betas', [0.9, 0.95])],
                                   weight_decay=float(t('weight_decay', 0.1)), max_grad_norm=float(cfg_get(ds_cfgs, 'gradient_clipping', 1.0)),
-                                  total_steps=total, warmup_steps=int(float(t('lr_warmup_ratio', 0.03)) * total),
-                                  lr_scheduler_type=t('lr_scheduler_type', 'cosine'))
+                                  total_steps=total, warmup_steps=int(float(t('lr_warmup_ratio', 0.03)) * (total or 0)),
+                                  lr_scheduler_type=t('lr_scheduler_type', 'cosine'), gradient_accumulation_steps=self.gas)
 
     def _end_window(self, input_ids, attention_mask):
         """One row per sequence: the last attended position (device-side index math, no host sync)."""
@@ -66,6 +69,9 @@ class RMTrainer:
             raise ValueError('RMTrainer.train needs a dataloader of preference batches')
         history = []
         self.global_step = getattr(self, 'global_step', 0)
+        if self.model.total_steps is None and not self.model.global_steps and hasattr(dl, '__len__'):
+            self.model.set_schedule(int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1)) * ((len(dl) + self.gas - 1) // self.gas),
+                                    float(cfg_get(self.cfgs, 'train_cfgs.lr_warmup_ratio', 0.03)))
         for _ in range(int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))):
             for batch in dl:
                 history.append(self.train_step(batch))

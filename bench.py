@@ -1,35 +1,39 @@
 """bench.py -- DPO-step throughput of the MI355X-native hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W            (N=1 default)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W            (N=1 default; N>1 spawns its own N ranks)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (also accepted)
 
 A "step" is one full DPO optimizer step on one synthetic micro-batch per GPU, exactly what
-DPOTrainer.train_step does (align_anything/trainers/text_to_text/dpo.py:205-237): policy forward on the 2B
-chosen/rejected rows + reference forward + fused log-prob/DPO loss + policy backward + (N>1) bucketed RCCL
-gradient all-reduce overlapped with backward + global-norm clip + AdamW.  Workload = BASELINE.json configs[1]:
-LLaVA-1.5-7B geometry (CLIP-L/14-336 + Llama 32x4096, V=32064), bf16, T=2048 = BOS + 576 image tokens + text,
-response R=512, random-init weights, synthetic ids/pixels (no network).  Nothing is skipped or cached inside
-the timed region; inputs are resident in HBM before it starts.
+DPOTrainer.train_step does (align_anything/trainers/text_to_text/dpo.py:205-237): reference forward + policy
+forward on the 2B chosen/rejected rows (CLIP tower included) + fused log-prob/DPO loss + policy backward +
+(N>1) bucketed RCCL gradient all-reduce overlapped with backward + global-norm clip + AdamW.  Workload =
+BASELINE.json configs[1]: LLaVA-1.5-7B geometry (CLIP-L/14-336 + Llama 32x4096, V=32064), bf16, T=2048 =
+BOS + 576 image tokens + text, response R=512, random-init weights, synthetic ids/pixels (no network).
+
+Every step gets its OWN freshly generated batch (ids + pixels resident in HBM before the timed region starts, as the
+boundary hands over device tensors): the CLIP tower, the response-window plan and every kernel of the step run inside
+the timed region for every step -- nothing is cached across steps, and the loss stays at its random-data level.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the bf16 MFMA GEMM, measured with
-HIP events around every GEMM launch of the timed steps) and `cpu_baseline` (the CPU oracle port, bounded sample).
+HIP events around every GEMM launch of the timed steps), `step_mfma` (whole-step MFMA fraction on the FLOPs the step
+EXECUTES, with SURVEY.md's algorithmic figure beside it) and `cpu_baseline` (the CPU oracle port, bounded sample).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_PROFILES = ('r02_gemm_traffic.json', 'r01_gemm_traffic.json')   # newest first (tools/pmc_traffic.sh writes them)
 
 
 def flops_per_pair(cfg, T, R, n_img_tok, vision_passes=4):
@@ -52,6 +56,7 @@ def flops_per_pair(cfg, T, R, n_img_tok, vision_passes=4):
 def make_batch(cfg, B, T, R, device, seed):
     """PreferenceCollator layout (datasets/text_image_to_text/preference.py:215-263): rows [0,B) chosen,
     [B,2B) rejected, one image per pair shared by both rows, no padding (fixed (image_patches, seq_len))."""
+    import torch
     g = torch.Generator(device='cpu').manual_seed(seed)
     n_img = (cfg['vision']['image_size'] // cfg['vision']['patch_size']) ** 2
     N = 2 * B
@@ -71,6 +76,7 @@ def make_batch(cfg, B, T, R, device, seed):
 def random_init_(model, seed, std=0.02):
     """Random-init weights of the named architecture (no checkpoints offline): N(0, std) matrices and
     embeddings, norm weights 1, biases 0 -- directly on the device."""
+    import torch
     g = torch.Generator(device=model.device).manual_seed(seed)
     st = model.store
     for name, s in st.specs.items():
@@ -85,11 +91,15 @@ def random_init_(model, seed, std=0.02):
         st.p['model.vision_tower.embeddings.patch_embedding.weight'][:, 588:].zero_()
 
 
-def cpu_baseline(cfg, T, seconds_budget=30.0):
-    """The CPU oracle (port of the reference path) on a bounded sample: ONE Llama decoder layer of the 7B
-    geometry, forward + backward over the 2 rows of one pair at T=2048 in fp32, extrapolated linearly to
-    the per-pair cost (32 layers; policy fwd+bwd = 3 forward units, reference fwd = 1: x 4/3).  lm_head,
-    vision tower and optimizer are NOT included, so this flatters the CPU."""
+def cpu_baseline(cfg, T, reps=2):
+    """The CPU oracle (fp32 torch-CPU port of the reference path, oracle/models.py) on a bounded sample: ONE Llama decoder
+    layer of the 7B geometry, forward + backward over the 2 rows of one pair at T=2048, one untimed warm-up (thread pool,
+    allocator) then `reps` timed repetitions (median), extrapolated linearly to the per-pair cost (32 layers; policy
+    fwd+bwd = 3 forward units, reference fwd = 1: x 4/3).  lm_head, vision tower and optimizer are NOT included, which
+    flatters the CPU.  kind = "port": SURVEY.md §8(d) asks for the reference's own DPOTrainer.loss on HF modules, but
+    /root/reference (and a DeepSpeed install) do not exist on the GPU box, so the restatement the parity tests pin to the
+    reference's fixtures is what can be timed there."""
+    import torch
     from oracle import models as om
     t = dict(cfg['text'])
     t['num_layers'] = 1
@@ -103,15 +113,46 @@ def cpu_baseline(cfg, T, seconds_budget=30.0):
         sd[p + f'layers.0.{n}.weight'] = (torch.randn(shape) * 0.02).requires_grad_(True)
     x = torch.randn(2, T, h) * 0.1
     cores = torch.get_num_threads()
-    t0 = time.time()
-    out = om.llama_decoder(sd, t, x, None)
-    out.float().pow(2).mean().backward()
-    dt = time.time() - t0
+
+    def once():
+        for v in sd.values():
+            v.grad = None
+        t0 = time.time()
+        out = om.llama_decoder(sd, t, x, None)
+        out.float().pow(2).mean().backward()
+        return time.time() - t0
+
+    warm = once()
+    times = sorted(once() for _ in range(max(1, reps)))
+    dt = times[len(times) // 2]
     per_pair = dt * cfg['text']['num_layers'] * 4.0 / 3.0
     return {'value': 1.0 / per_pair, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle/models.py llama_decoder, 1 of {cfg["text"]["num_layers"]} layers, fwd+bwd fp32, 2x{T} tokens: '
-                      f'{dt:.1f} s; extrapolated x{cfg["text"]["num_layers"]} layers x4/3 (policy fwd+bwd + ref fwd); '
-                      'lm_head/vision/optimizer excluded'}
+            'sample': f'oracle/models.py llama_decoder, 1 of {cfg["text"]["num_layers"]} layers, fwd+bwd fp32, 2x{T} tokens: warm-up '
+                      f'{warm:.1f} s, then {len(times)} timed reps {[round(x, 2) for x in times]} s (median used); extrapolated '
+                      f'x{cfg["text"]["num_layers"]} layers x4/3 (policy fwd+bwd + ref fwd); lm_head/vision/optimizer excluded',
+            'why_port': 'the reference (HF + DeepSpeed trainer under /root/reference) is not present on the GPU box; the oracle '
+                        'port is pinned to reference-generated fixtures by tests/test_oracle_golden.py'}
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(argv, n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU
+    (the reference launches the same way through `deepspeed --master_port ... --module`, scripts/llava/llava_dpo.sh:35-46)."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    if os.environ.get('AA_BENCH_DRYRUN_LAUNCH') == '1':     # tests: show the command, do not run it
+        print(json.dumps({'self_launch': cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('MASTER_ADDR', '127.0.0.1')
+    print(f'[bench] spawning {n} ranks: {" ".join(cmd)}', file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -128,6 +169,12 @@ def main():
     ap.add_argument('--gemm-event-stride', type=int, default=1, help='time every k-th GEMM launch with HIP events (1 = all)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -139,6 +186,9 @@ def main():
     backend = os.environ.get('AA_BENCH_BACKEND', 'nccl')
     if one_device:
         local = 0
+    if not one_device and local >= torch.cuda.device_count():
+        raise SystemExit(f'rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible '
+                         '(AA_BENCH_ONE_DEVICE=1 AA_BENCH_BACKEND=gloo runs the functional check on one device)')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
@@ -147,6 +197,11 @@ def main():
             dist.init_process_group('nccl', device_id=device)      # nccl == RCCL on ROCm
         else:
             dist.init_process_group(backend)
+        # per-rank confirmation of what the collectives run on (stderr; stdout carries the one JSON line)
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)
+        print(f'[bench] rank {rank}/{world} device {torch.cuda.get_device_name(local)} #{local} backend={dist.get_backend()} '
+              f'world_seen_by_collective={int(probe.item())}', file=sys.stderr, flush=True)
 
     from align_anything_amd import configs, ops
     from align_anything_amd.trainers.dpo import DPOTrainer
@@ -164,7 +219,9 @@ def main():
     tr.reference.load_state_dict(tr.policy.state_dict())
     for g in tr.policy.store.master:
         tr.policy.store.master[g].copy_(tr.policy.store.flat[g])
-    batches = [make_batch(cfg, B, T, R, device, seed=1234 + rank * 1000 + i) for i in range(2)]
+    # one fresh batch per step (warm-up and timed), all resident in HBM before the clock starts
+    n_b = args.warmup + args.steps
+    batches = [make_batch(cfg, B, T, R, device, seed=1234 + rank * 100003 + i) for i in range(n_b)]
     torch.cuda.synchronize()
 
     def barrier():
@@ -174,12 +231,12 @@ def main():
     for i in range(args.warmup):
         if i == args.warmup - 1 and not args.no_gemm_events:
             ops.GEMM_PROF = []                      # count the GEMM launches of one step ...
-        tr.train_step(batches[i % 2])
+        tr.train_step(batches[i])
     torch.cuda.synchronize()
     if not args.no_gemm_events:                     # ... and create every event the timed region will record up front
         per_step = len(ops.GEMM_PROF) if ops.GEMM_PROF else 600
         ops.GEMM_PROF = None
-        # same-box A/B (tools/gpu_event_ab.sh): events around every launch cost ~0.4 % of the step once they are pre-created;
+        # same-box A/B (profiles/README.md): events around every launch cost ~0.4 % of the step once they are pre-created;
         # --gemm-event-stride k samples every k-th launch instead (default 1 = every launch, no sampling bias)
         ops.GEMM_PROF_STRIDE = args.gemm_event_stride
         while ops.GEMM_PROF_STRIDE > 1 and per_step % ops.GEMM_PROF_STRIDE == 0:
@@ -189,17 +246,18 @@ def main():
 
     gemm_events = None if args.no_gemm_events else []
     ops.GEMM_PROF = gemm_events
+    ops.FLOPS['gemm'] = ops.FLOPS['attn'] = 0.0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    last = None
     losses = []
     for i in range(args.steps):
-        last = tr.train_step(batches[i % 2])
+        last = tr.train_step(batches[args.warmup + i])
         losses.append(round(last['train/loss'], 5))
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     ops.GEMM_PROF = None
+    executed = dict(ops.FLOPS)
 
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -211,21 +269,32 @@ def main():
         fl_pair, _ = flops_per_pair(cfg, T, R, n_img)
         pairs = B * world * args.steps
         value = pairs / dt
-        step_tflops = fl_pair * B / (dt / args.steps) / 1e12   # per GPU
+        step_s = dt / args.steps
+        alg_tflops = fl_pair * B / step_s / 1e12   # per GPU
+        exe_pair = (executed['gemm'] + executed['attn']) / (B * args.steps)
+        exe_tflops = exe_pair * B / step_s / 1e12
         out = {
             'metric': 'preference-pairs/sec (DPO step, LLaVA-1.5-7B geometry, seq=2048), whole job',
             'value': value, 'unit': 'pairs/s', 'per_gpu': value / world, 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'warmup': args.warmup, 'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: LLaVA-1.5-7B DPO, bf16, 336px/576 patches, seq_len={T}, response={R}, '
-                                   f'{B} pairs/GPU/step, policy+ref fwd, bwd, clip, AdamW' + ('' if args.layers == 32 else f' [REDUCED DEPTH {args.layers}]')
+                                   f'{B} pairs/GPU/step, CLIP tower + policy+ref fwd, bwd, clip, AdamW; a fresh batch every step'
+                                   + ('' if args.layers == 32 else f' [REDUCED DEPTH {args.layers}]')
                                    + (' [FUNCTIONAL CHECK: ranks share one device, gloo]' if one_device or backend != 'nccl' else ''),
                        'global_batch_pairs': B * world, 'seq_len': T, 'parallelism': f'dp{world}',
+                       'shapes': {'hidden': cfg['text']['hidden_size'], 'heads': cfg['text']['num_heads'], 'head_dim': cfg['text']['head_dim'],
+                                  'ffn': cfg['text']['intermediate_size'], 'vocab': cfg['text']['vocab_size'], 'layers': args.layers,
+                                  'tokens_per_gpu_step': 2 * B * T, 'image_tokens': n_img},
                        'trainable_params': tr.policy.store.num_trainable(), 'losses_timed_steps': losses},
-            'step_mfma': {'algorithmic_tflop_per_pair': fl_pair / 1e12, 'achieved_tflops_per_gpu': step_tflops,
-                          'frac_of_dense_bf16_peak': step_tflops / PEAK_BF16_TFLOPS,
-                          'note': 'SURVEY.md §8(d) accounting (lm_head over all T, 4 vision passes); executed work is smaller: '
-                                  'lm_head only on response rows, vision tower once per image'},
+            'step_mfma': {'executed_tflop_per_pair': exe_pair / 1e12, 'achieved_tflops_per_gpu': exe_tflops,
+                          'frac_of_dense_bf16_peak': exe_tflops / PEAK_BF16_TFLOPS,
+                          'executed_split': {'gemm_tflop_per_pair': executed['gemm'] / (B * args.steps) / 1e12,
+                                             'attention_tflop_per_pair': executed['attn'] / (B * args.steps) / 1e12},
+                          'algorithmic_tflop_per_pair': fl_pair / 1e12, 'algorithmic_frac_of_dense_bf16_peak': alg_tflops / PEAK_BF16_TFLOPS,
+                          'note': 'headline = FLOPs counted at the launches of the timed steps (2MNK per GEMM, causal attention at half, '
+                                  'backward 2.5x forward); algorithmic = SURVEY.md §8(d) accounting (lm_head over all T, 4 vision passes), '
+                                  'larger because lm_head runs on the response rows only and the frozen tower once per image'},
         }
         if gemm_events:
             tot_ms, tot_fl = 0.0, 0.0
@@ -234,19 +303,23 @@ def main():
                 tot_fl += fl
             n = len(gemm_events)
             ach = tot_fl / tot_ms / 1e9
-            # HBM bytes per GEMM launch from the PMC counters: rocprofv3 cannot run inside this process, so the
-            # number is the one measured by the separate --pmc passes of tools/gpu_traffic.sh (FETCH_SIZE doubled
-            # per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is), committed under profiles/
-            traffic = None
-            try:
-                with open(os.path.join(ROOT, 'profiles', 'r01_gemm_traffic.json')) as f:
-                    tj = json.load(f)
-                    traffic = tj.get('gemm_hbm_bytes_per_launch_full_depth_mix', tj['gemm_hbm_bytes_per_launch'])     # re-weighted to the 32-layer launch mix
-            except (OSError, KeyError, ValueError):
-                pass              # the profile is not in this checkout: traffic stays null
+            # HBM bytes per GEMM launch from the PMC counters: rocprofv3 cannot run inside this process, so the number comes
+            # from the separate --pmc passes of THIS command (tools/pmc_traffic.sh: FETCH_SIZE doubled per the gfx950 note of
+            # MI355X_MICROARCH.md, WRITE_SIZE as is, separate passes), committed under profiles/
+            traffic, src = None, None
+            for name in TRAFFIC_PROFILES:
+                try:
+                    with open(os.path.join(ROOT, 'profiles', name)) as f:
+                        tj = json.load(f)
+                    traffic = tj.get('gemm_hbm_bytes_per_launch_full_depth_mix', tj.get('gemm_hbm_bytes_per_launch'))
+                    src = name
+                    if traffic is not None:
+                        break
+                except (OSError, ValueError):
+                    continue          # the profile is not in this checkout: traffic stays null
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel<BM,BN,...> (csrc/gemm.hip), all launches of the timed steps',
                                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                               'traffic': traffic, 'traffic_unit': 'HBM bytes per GEMM launch (PMC passes of tools/gpu_traffic.sh re-weighted to this workload\'s launch mix, profiles/r01_gemm_traffic.json)',
+                               'traffic': traffic, 'traffic_unit': f'HBM bytes per GEMM launch (rocprofv3 --pmc passes of this command, profiles/{src})',
                                'algorithmic_bytes_per_launch': sum(e[3] for e in gemm_events) / n,
                                'launches': n, 'launch_sampling': f'every {ops.GEMM_PROF_STRIDE}th GEMM launch of the timed steps', 'avg_launch_ms': tot_ms / n,
                                'avg_flops_per_launch': tot_fl / n, 'gemm_share_of_step_time': tot_ms / (dt * 1e3)}

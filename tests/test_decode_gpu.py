@@ -214,6 +214,15 @@ def test_generate_greedy_opt_and_eos_padding():
     seq2 = _check_greedy(m, fn, ids, mask, 12, eos, 1, 'opt_eos')
     first = (seq2[0, 24:] == eos).nonzero()[0].item()
     assert (seq2[0, 24 + first + 1:] == 1).all()
+    # pad_token_id == eos_token_id (Llama / Qwen tokenizers): HF stops after the step in which the last row emitted EOS and KEEPS
+    # that column -- the length is counted in steps, not inferred from non-pad columns
+    from align_anything_amd.generation import generate
+    one = generate(m, ids[:1].to(dev()), mask[:1].to(dev()), max_new_tokens=12, do_sample=False, eos_token_id=eos, pad_token_id=eos,
+                   sync_every=1).cpu()
+    assert one.shape == (1, 24 + first + 1) and int(one[0, -1]) == eos and torch.equal(one[0], seq2[0, :24 + first + 1])
+    late = generate(m, ids[:1].to(dev()), mask[:1].to(dev()), max_new_tokens=12, do_sample=False, eos_token_id=eos, pad_token_id=eos,
+                    sync_every=5).cpu()          # the loop notices late; the trim is the same
+    assert torch.equal(late, one)
     # repetition penalty (hf RepetitionPenaltyLogitsProcessor): a strong penalty forbids repeats and changes the path
     seq3 = _check_greedy(m, fn, ids, mask, 12, None, 1, 'opt_reppen', penalty=4.0)
     assert not torch.equal(seq3, seq)

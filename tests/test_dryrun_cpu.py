@@ -139,8 +139,26 @@ def test_ppo_rollout_update_and_ptx_steps(launches):
     ptx = {'input_ids': inference['input_ids'], 'attention_mask': inference['attention_mask'], 'labels': labels}
     hist = tr3.train([pbatch, pbatch], ptx_dataloader=[ptx])
     assert len(hist) == 8 and tr3.global_step == 8 and all('train/ptx_loss' in h and 'train/actor_loss' in h for h in hist)
-    assert tr3.actor_model.global_steps == 16 and tr3.reward_critic_model.global_steps == 8
-    assert len(tr3.train([pbatch])) == 4 and tr3.actor_model.global_steps == 20          # without PTX
+    # base/rl_trainer.py:231-234: with PTX the actor accumulates over the (rl_step, ptx_step) pair -> ONE update per pair
+    assert tr3.actor_model.gas == 2 and tr3.actor_model.global_steps == 8 and tr3.reward_critic_model.global_steps == 8
+    assert tr3.actor_model.micro_steps == 16
+    with pytest.raises(RuntimeError):
+        tr3.train([pbatch])                                # dropping the PTX set mid-run would change the accumulation depth
+    tr4 = PPOTrainer(cfgs2, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, reward_state=rm_sd, device='cpu')
+    assert len(tr4.train([pbatch])) == 4 and tr4.actor_model.gas == 1 and tr4.actor_model.global_steps == 4          # without PTX
+    # the default schedulers (cosine actor, constant critic) get their length from the prompt dataloader like the reference:
+    # 2 prompt batches x 1 epoch x 2 update_iters x per_device_train_batch_size 2 x per_device_prompt_batch_size 1 = 8 micro steps
+    cfgs3 = {'train_cfgs': {k: v for k, v in cfgs2['train_cfgs'].items() if not k.endswith('scheduler_type')}, 'model_cfgs': cfgs['model_cfgs']}
+    cfgs3['train_cfgs'].update(actor_lr_warmup_ratio=0.0, critic_lr_warmup_ratio=0.0)
+    tr5 = PPOTrainer(cfgs3, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, reward_state=rm_sd, device='cpu')
+    assert tr5.actor_model.sched == 'cosine' and tr5.actor_model.total_steps is None
+    with pytest.raises(RuntimeError, match='cosine'):
+        tr5.rl_step(inference, training)                   # no schedule length known: refuse instead of decaying to 0
+    tr5 = PPOTrainer(cfgs3, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, reward_state=rm_sd, device='cpu')
+    hist = tr5.train([pbatch, pbatch])
+    assert tr5.actor_model.total_steps == 8 and tr5.reward_critic_model.total_steps == 8
+    lrs = [h['train/actor_lr'] for h in hist]
+    assert len(lrs) == 8 and all(a > b for a, b in zip(lrs, lrs[1:])) and lrs[1] > 0.5e-3 and lrs[-1] == 0.0, lrs
     # a rule reward instead of the reward model
     tr2 = PPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, critic_state=rm_sd, device='cpu', reward_fn=lambda i, a: [1.0] * i.shape[0])
     assert tr2.reward_model is None and tr2.reward_model_step(prompts, torch.ones_like(prompts))['reward'].tolist() == [1.0] * 4
