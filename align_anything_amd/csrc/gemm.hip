@@ -467,7 +467,9 @@ static int launch_cfg2(GemmParams& p, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, bool A_T, bool B_N>
 static int launch_cfg(GemmParams& p, hipStream_t st) {
-    if constexpr (BM == 256 && BN == 256) {
+    if constexpr (BM == 256 && BN == 256 && WM * WN == 4) {
+        return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 1>(p, st);     // one-wave-per-SIMD tile: the phase-A interleave only
+    } else if constexpr (BM == 256 && BN == 256) {
         // schedule variants exist for the hot 256x256 tile only (A/B data: profiles/r01_gemm_*_ab.json):
         //   g_ilv = -1 (auto): NN -> fully interleaved peeled loop (2), NT / TN -> phase-A interleave (1)
         if (!g_pipe) return launch_cfg2<BM, BN, WM, WN, A_T, B_N, false, 0>(p, st);
@@ -488,6 +490,7 @@ static int launch_layout(GemmParams& p, int tile, hipStream_t st) {
         case 1: return launch_cfg<128, 128, 2, 2, A_T, B_N>(p, st);
         case 2: return launch_cfg<256, 128, 4, 2, A_T, B_N>(p, st);
         case 3: return launch_cfg<128, 256, 2, 4, A_T, B_N>(p, st);
+        case 4: return launch_cfg<256, 256, 2, 2, A_T, B_N>(p, st);   // 4 waves x (128 x 128): one wave per SIMD, 1/3 fewer LDS bytes per flop
         default: aa_set_error("aa_gemm_bf16: unknown tile config %d", tile); return AA_ERR_ARG;
     }
 }

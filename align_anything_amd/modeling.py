@@ -572,12 +572,18 @@ class NativeCausalLM:
             self._ctx['window'] = window
         return logp
 
-    def response_scores(self, input_ids, attention_mask, window, pixel_values=None, save=False, image_features=None, **mm):
-        """Score-head models: fp32 scores on the window rows (critic values / reward scores)."""
+    def response_scores(self, input_ids, attention_mask, window, pixel_values=None, save=False, image_features=None,
+                        all_scores=False, **mm):
+        """Score-head models: fp32 scores on the window rows (critic values / reward scores).  all_scores=True additionally
+        returns ScoreModelOutput.scores [N, T] of the same forward (no gradient flows through it): what the reference's
+        RMTrainer.loss reports as higher_rewards / lower_rewards (trainers/text_to_text/rm.py:110-130)."""
         x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features, **mm)
         sc = self.head.forward(x, window['row_idx'], None, save)
         if save:
             self._ctx['window'] = window
+        if all_scores:
+            N, T = input_ids.shape
+            return sc, self.head.scores_all(x)[:N * T].view(N, T)
         return sc
 
     def scores(self, input_ids, attention_mask=None, pixel_values=None, **mm):

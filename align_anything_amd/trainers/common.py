@@ -79,6 +79,21 @@ def get_all_reduce_max(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+END_AT_LAST_POSITION_KINDS = ('llava', 'qwen2vl')
+
+
+def end_index(kind: str, attention_mask: torch.Tensor) -> torch.Tensor:
+    """Position whose score is the reward model's `end_scores`, per backbone as the reference's score models define it:
+    the LAST ATTENDED token for OPT / Llama / Qwen2-Audio / Qwen3-MoE (models/opt.py:67, llama.py:71, qwen2_audio.py:80,
+    qwen3_moe.py:71: `attention_mask[i].nonzero()[-1]`), but position -1 REGARDLESS of the mask for the vision-language reward
+    models (models/llava.py:64-68, qwen2_vl.py:61-64: `last_hidden_state[:, -1]`).  The two agree on left-padded PPO
+    experience; they differ on the right-padded batches of reward-model training (trainers/text_to_text/rm.py:81)."""
+    N, T = attention_mask.shape
+    if kind in END_AT_LAST_POSITION_KINDS:
+        return torch.full((N,), T - 1, dtype=torch.int64, device=attention_mask.device)
+    return (attention_mask.to(torch.int64) * torch.arange(1, T + 1, device=attention_mask.device)[None]).argmax(dim=1)
+
+
 def cfg_get(cfgs, path: str, default=None):
     """Read `a.b.c` from a namedtuple / namespace / dict config (missing -> default), mirroring the reference's
     dict_to_namedtuple objects whose missing attributes read as None (utils/tools.py:87-93)."""

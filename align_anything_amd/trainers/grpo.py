@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import build_span_window, cfg_get, compute_dtype, get_all_reduce_mean, pad_rows
+from .common import build_span_window, cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad_rows
 
 
 class GRPOTrainer:
@@ -81,7 +81,7 @@ class GRPOTrainer:
         am = keep.to(torch.int64)
         T = ids.shape[1]
         scores = self.reward_model.module.scores(ids, am)
-        end = (am * torch.arange(T, device=ids.device)[None]).argmax(dim=1)
+        end = end_index(self.reward_model.module.kind, am)
         return scores[torch.arange(ids.shape[0], device=ids.device), end].float()
 
     # ------------------------------------------------------------------ grpo.py:199-210

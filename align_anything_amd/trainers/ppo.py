@@ -58,7 +58,7 @@ def gather_log_probabilities(logits: torch.Tensor, labels: torch.Tensor) -> torc
 
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import build_span_window, cfg_get, compute_dtype, get_all_reduce_max, get_all_reduce_mean, pad_rows
+from .common import build_span_window, cfg_get, compute_dtype, end_index, get_all_reduce_max, get_all_reduce_mean, pad_rows
 
 
 class PPOTrainer(PPOMath):
@@ -113,11 +113,14 @@ class PPOTrainer(PPOMath):
         self.reward_model = NativeEngine(reward, trainable=False) if reward is not None else None
 
     # ------------------------------------------------------------------ rollout (ppo.py:209-222, 244-289)
-    def actor_step(self, prompt_batch, generator=None):
-        """`self.actor_model.module.generate(**batch, generation_config=..., do_sample=True)` natively."""
+    def actor_step(self, prompt_batch, generator=None, sequences=None):
+        """`self.actor_model.module.generate(**batch, generation_config=..., do_sample=True)` natively (ppo.py:209-222).
+        `sequences` injects already generated rows (tests against the reference's fixture, external samplers)."""
         from ..generation import generate
         m = lambda k, d: cfg_get(self.cfgs, 'model_cfgs.' + k, d)
         pad = m('pad_token_id', 0)
+        if sequences is not None:
+            return {'input_ids': sequences, 'attention_mask': sequences.ne(pad)}
         self.actor_model.wait_optimizer()
         seq = generate(self.actor_model.module, prompt_batch['input_ids'], prompt_batch['attention_mask'],
                        max_length=int(m('model_max_length', 2048)), do_sample=True, temperature=float(m('temperature', 1.0)),
@@ -126,9 +129,9 @@ class PPOTrainer(PPOMath):
                        pixel_values=prompt_batch.get('pixel_values'), generator=generator)
         return {'input_ids': seq, 'attention_mask': seq.ne(pad)}
 
-    def rollout(self, prompt_only_batch, generator=None):
+    def rollout(self, prompt_only_batch, generator=None, sequences=None):
         """One micro-batch of experience: generate, score, log-probs of actor and reference (all no-grad)."""
-        actor_batch = self.actor_step(prompt_only_batch, generator)
+        actor_batch = self.actor_step(prompt_only_batch, generator, sequences)
         ids, am = actor_batch['input_ids'], actor_batch['attention_mask'].to(torch.int64)
         scored = self.reward_model_step(ids, am)
         log_probs, _ = self.sequence_log_probs(self.actor_model, ids, am, 0)
@@ -149,7 +152,7 @@ class PPOTrainer(PPOMath):
                 raise ValueError(f'reward_fn returned shape {tuple(reward.shape)}, expected ({N},)')
         else:
             scores = self.reward_model.module.scores(input_ids, attention_mask)
-            end = (attention_mask.to(torch.int64) * torch.arange(T, device=input_ids.device)[None]).argmax(dim=1)
+            end = end_index(self.reward_model.module.kind, attention_mask)
             reward = scores[torch.arange(N, device=scores.device), end]
         self.reward_critic_model.wait_optimizer()
         values = self.reward_critic_model.module.scores(input_ids, attention_mask)[:, :-1]

@@ -1,6 +1,7 @@
 """Native reward-model trainer step (align_anything/trainers/text_to_text/rm.py:97-147): score-head model forward,
 pairwise -logsigmoid(r+ - r-) + L2 regularisation on the end scores, backward, step.  Batches are RIGHT padded
-(rm.py:81); the end score is the score at the last attended token (models/opt.py:67-89)."""
+(rm.py:81); the end score is the score at the last attended token for the text backbones (models/opt.py:67-89) and at
+position -1 for the vision-language reward models (models/llava.py:64-68, qwen2_vl.py:61-64) -- common.end_index."""
 from __future__ import annotations
 
 import torch
@@ -8,7 +9,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import cfg_get, compute_dtype, get_all_reduce_mean, pad64
+from .common import cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad64
 
 
 class RMTrainer:
@@ -29,10 +30,10 @@ class RMTrainer:
                                   lr_scheduler_type=t('lr_scheduler_type', 'cosine'), gradient_accumulation_steps=self.gas)
 
     def _end_window(self, input_ids, attention_mask):
-        """One row per sequence: the last attended position (device-side index math, no host sync)."""
+        """One row per sequence: the backbone's end position (device-side index math, no host sync)."""
         N, T = input_ids.shape
         dev = input_ids.device
-        end = (attention_mask.to(torch.int64) * torch.arange(1, T + 1, device=dev)[None]).argmax(dim=1)
+        end = end_index(self.model.module.kind, attention_mask)
         rows_pad = pad64(N)
         row_idx = torch.zeros(rows_pad, dtype=torch.int64, device=dev)
         row_idx[:N] = torch.arange(N, device=dev) * T + end
@@ -47,13 +48,16 @@ class RMTrainer:
         B = ids.shape[0] // 2
         w, end = self._end_window(ids, am)
         self.model.wait_optimizer()
-        end_scores = self.model.module.response_scores(ids, am, w, pixel_values=batch.get('pixel_values'), save=True)
+        mm = {k: batch[k] for k in ('image_grid_thw', 'position_ids3', 'input_features', 'feature_attention_mask') if k in batch}
+        end_scores, scores = self.model.module.response_scores(ids, am, w, pixel_values=batch.get('pixel_values'), save=True,
+                                                               all_scores=True, **mm)
         out2, d = ops.rm_loss(end_scores[:2 * B].contiguous(), B, self.regularization)
         dpad = torch.zeros(w['rows_pad'], dtype=torch.float32, device=ids.device)
         dpad[:2 * B] = d
         self.model.set_pending(dpad)
+        # the six outputs of rm.py:125-132 (+ the fused [loss, accuracy] pair the step all-reduces once)
         return {'loss': out2[0], 'accuracy': out2[1], 'higher_end_reward': end_scores[:B], 'lower_end_reward': end_scores[B:2 * B],
-                '_stats': out2}
+                'higher_rewards': scores[:B], 'lower_rewards': scores[B:2 * B], '_stats': out2}
 
     def train_step(self, batch):
         ld = self.loss(batch)

@@ -740,6 +740,157 @@ def gen_grpo():
     print('grpo_tiny.npz loss', out['train/loss'], 'reward', out['train/reward'])
 
 
+def _tiny_opt_pair(seed_w=5, score_seed=17):
+    """Tiny HF OPT actor and the reference's own AccustomedOPTRewardModel (models/opt.py:31-97) sharing its backbone weights."""
+    from transformers import OPTConfig, OPTForCausalLM
+    from align_anything.models.opt import AccustomedOPTRewardModel
+    oc = OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=320,
+                   max_position_embeddings=128, word_embed_proj_dim=128, dropout=0.0, attention_dropout=0.0, pad_token_id=1)
+    torch.manual_seed(seed_w)
+    actor = OPTForCausalLM(oc).eval()
+    with torch.no_grad():
+        for p in actor.parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+            p.copy_(p.to(torch.bfloat16).to(torch.float32))
+        actor.model.decoder.embed_tokens.weight[1].zero_()
+
+    def score_model(seed, jitter):
+        g = torch.Generator().manual_seed(seed)
+        torch.manual_seed(seed)
+        m = AccustomedOPTRewardModel(oc).eval()
+        m.model.load_state_dict(actor.model.state_dict())
+        with torch.no_grad():
+            for q in m.model.parameters():
+                q.add_(jitter * torch.randn(q.shape, generator=g)); q.copy_(q.to(torch.bfloat16).to(torch.float32))
+            m.score_head.weight.copy_((torch.randn(1, 128, generator=g) * 0.3).to(torch.bfloat16).float())
+        return m
+    return oc, actor, score_model
+
+
+def gen_opt_rm():
+    """The reference's unmodified RMTrainer.loss (trainers/text_to_text/rm.py:97-132) on its own AccustomedOPTRewardModel
+    (models/opt.py:31-97): all six outputs (loss, higher/lower_end_reward [B], higher/lower_rewards [B, L], accuracy) and
+    gradients, on a RIGHT-padded preference batch (rm.py:81 padding_side='right') with and without regularisation."""
+    from align_anything.trainers.text_to_text.rm import RMTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+    oc, actor, score_model = _tiny_opt_pair()
+    rm = score_model(23, 0.02)
+    g = torch.Generator().manual_seed(41)
+    B, T = 3, 36
+    ids = torch.full((2 * B, T), 1, dtype=torch.long)
+    mask = torch.zeros((2 * B, T), dtype=torch.long)
+    for r, n_tok in enumerate((36, 30, 21, 33, 36, 17)):                 # right padding: tokens first, pad id 1 after
+        ids[r, :n_tok] = torch.randint(3, 320, (n_tok,), generator=g)
+        mask[r, :n_tok] = 1
+    ids[3:, :10] = ids[:3, :10]                                          # shared prompt prefix
+    batch = {'input_ids': ids, 'attention_mask': mask, 'meta_info': {}}
+    out = {'input_ids': ids.numpy(), 'attention_mask': mask.numpy(), 'pad_token_id': np.array(1)}
+    for tag, reg in (('reg', 0.01), ('noreg', 0.0)):
+        tr = RMTrainer.__new__(RMTrainer)
+        tr.cfgs = dict_to_namedtuple({'train_cfgs': {'regularization': reg}})
+        tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+        tr.model = rm                                                    # `self.model(**infer_batch)`: the engine is callable like the module
+        rm.zero_grad()
+        ld = tr.loss(batch)
+        ld['loss'].backward()
+        for k, v in ld.items():
+            out[f'{tag}_{k}'] = v.detach().numpy()
+        out[f'{tag}_regularization'] = np.array(reg)
+        for n, q in rm.named_parameters():
+            if n == 'score_head.weight' or n.endswith('layers.1.fc1.weight') or n.endswith('layers.0.self_attn.q_proj.weight') \
+                    or n.endswith('final_layer_norm.weight') or n.endswith('embed_tokens.weight'):
+                out[f'{tag}_g.{n}'] = q.grad.numpy().copy()
+        print('opt_tiny_rm', tag, 'loss', float(ld['loss']), 'acc', float(ld['accuracy']))
+    for n, q in rm.state_dict().items():
+        out['w.' + n] = bf16_bits(q)
+    np.savez_compressed(os.path.join(GOLD, 'opt_tiny_rm.npz'), **out)
+
+
+def gen_opt_ppo():
+    """The reference's unmodified text_to_text PPOTrainer.rollout (trainers/text_to_text/ppo.py:244-289, incl. actor_step
+    :209-222 after `generate` and reward_model_step :224-242) and rl_step (:309-398) with HF OPT as actor / reference and the
+    reference's AccustomedOPTRewardModel as reward model and critic, fp32, CPU.  Stood in: `generate` (fixed sequences per
+    micro-batch), the DeepSpeed engines (plain backward, no optimizer step), dist.barrier / all-reduce (world 1)."""
+    import align_anything.trainers.text_to_text.ppo as ppo_mod
+    from align_anything.trainers.text_to_text.ppo import PPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+    ppo_mod.get_all_reduce_mean = lambda x: x
+    ppo_mod.get_all_reduce_max = lambda x: x
+    ppo_mod.dist = SimpleNamespace(barrier=lambda: None)
+    oc, actor, score_model = _tiny_opt_pair()
+    from transformers import OPTForCausalLM
+    refm = OPTForCausalLM(oc).eval()
+    g = torch.Generator().manual_seed(43)
+    with torch.no_grad():
+        for p, q in zip(refm.parameters(), actor.parameters()):
+            p.copy_((q + 0.02 * torch.randn(q.shape, generator=g)).to(torch.bfloat16).to(torch.float32))
+    reward, critic = score_model(1, 0.01), score_model(2, 0.01)
+
+    PAD, EOS, P, L, N, MICRO = 1, 2, 14, 12, 4, 2
+    prompts = torch.full((N, P), PAD, dtype=torch.long)
+    for r, lp in enumerate((0, 3, 5, 0)):                               # LEFT-padded prompts (prompt_only.py collator)
+        prompts[r, lp:] = torch.randint(3, 320, (P - lp,), generator=g)
+    gen = torch.randint(3, 320, (N, L), generator=g)
+    gen[1, 7] = EOS; gen[1, 8:] = PAD                                   # rows that stopped early: EOS then right padding
+    gen[2, 3] = EOS; gen[2, 4:] = PAD
+    gen[3, L - 1] = EOS
+    sequences = torch.cat([prompts, gen], 1)
+
+    class Mod(torch.nn.Module):      # `engine.module`: callable like the HF model, with a stubbed generate
+        def __init__(self, m): super().__init__(); self.m = m; self.calls = 0
+        def forward(self, **kw):
+            kw.pop('use_cache', None)
+            return self.m(**kw)
+        def generate(self, **kw):
+            ids = kw['input_ids']
+            rows = [int((prompts == ids[i]).all(1).nonzero()[0]) for i in range(ids.shape[0])]
+            return sequences[rows].clone()
+
+    class Engine:
+        def __init__(self, m): self.module = Mod(m); self.optimizer = SimpleNamespace(param_groups=[{'lr': 0.0}]); self.device = 'cpu'
+        def __call__(self, **kw): return self.module(**kw)
+        def backward(self, loss): loss.backward()
+        def step(self): pass
+
+    tr = PPOTrainer.__new__(PPOTrainer)
+    tr.actor_model, tr.actor_reference_model, tr.reward_model, tr.reward_critic_model = Engine(actor), Engine(refm), Engine(reward), Engine(critic)
+    tr.tokenizer = tr.reward_tokenizer = SimpleNamespace(pad_token_id=PAD)
+    tr.infer_batch = tr.reward_infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    tr.generation_config = None
+    tr.set_train = lambda mode=True: None
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'per_device_train_batch_size': MICRO}})
+    tr.kl_coeff, tr.clip_range_ratio, tr.clip_range_score, tr.clip_range_value, tr.gamma, tr.gae_lambda = 0.02, 0.2, 50.0, 5.0, 1.0, 0.95
+    prompt_batch = {'input_ids': prompts, 'attention_mask': (prompts != PAD).long()}
+    inf, trn = tr.rollout(prompt_batch)
+    assert len(inf) == N // MICRO
+    out = {'prompts': prompts.numpy(), 'sequences': sequences.numpy(), 'pad_token_id': np.array(PAD), 'eos_token_id': np.array(EOS),
+           'micro': np.array(MICRO), 'kl_coeff': np.array(0.02), 'clip_range_ratio': np.array(0.2), 'clip_range_score': np.array(50.0),
+           'clip_range_value': np.array(5.0), 'gamma': np.array(1.0), 'gae_lambda': np.array(0.95)}
+    for i, (ib, tb) in enumerate(zip(inf, trn)):
+        out[f'mb{i}.input_ids'] = ib['input_ids'].numpy()
+        out[f'mb{i}.attention_mask'] = ib['attention_mask'].numpy().astype(np.int64)
+        out[f'mb{i}.prompt_idx'] = np.array(tb['prompt_idx'])
+        for k in ('log_probs', 'ref_log_probs', 'reward', 'reward_values'):
+            out[f'mb{i}.{k}'] = tb[k].numpy()
+    # rl_step on micro-batch 0 (gradients recorded), then on micro-batch 1 with the SAME weights (no optimizer in the stand-in)
+    for i in range(len(inf)):
+        actor.zero_grad(); critic.zero_grad()
+        info = tr.rl_step(inf[i], trn[i])
+        for k, v in info.items():
+            out[f'mb{i}.info.{k}'] = np.array(v)
+        for tag, m in (('a', actor), ('c', critic)):
+            for n, q in m.named_parameters():
+                if q.grad is not None and (n.endswith('layers.1.fc1.weight') or n.endswith('layers.0.self_attn.q_proj.weight')
+                                           or n.endswith('final_layer_norm.weight') or n == 'score_head.weight' or n.endswith('layers.1.fc2.bias')):
+                    out[f'mb{i}.g{tag}.{n}'] = q.grad.numpy().copy()
+        print('opt_tiny_ppo micro-batch', i, {k: round(float(v), 6) for k, v in info.items() if 'loss' in k or 'length' in k or 'kl' in k})
+    for tag, m in (('a', actor), ('r', refm), ('rm', reward), ('c', critic)):
+        for n, q in m.state_dict().items():
+            out[f'{tag}.{n}'] = bf16_bits(q)
+    np.savez_compressed(os.path.join(GOLD, 'opt_tiny_ppo.npz'), **out)
+
+
 def gen_opt125m_curve(threads=8, alt_threads=3):
     """The 'loss curves matching reference to 1e-4' target of BASELINE.json: drive the reference's unmodified
     DPOTrainer.train_step (trainers/text_to_text/dpo.py:205-237) for 64 steps, fp32, on config 1, with the DeepSpeed
@@ -798,6 +949,10 @@ def gen_opt125m_curve(threads=8, alt_threads=3):
 if __name__ == '__main__':
     _shim.install()
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1:                       # regenerate only the named fixtures: python -m oracle.gen_golden gen_opt_rm gen_opt_ppo
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     gen_rl_math()
     gen_llava_dpo()
     gen_opt_dpo()
@@ -809,4 +964,6 @@ if __name__ == '__main__':
     gen_sft()
     gen_collator()
     gen_grpo()
+    gen_opt_rm()
+    gen_opt_ppo()
     gen_opt125m_curve()

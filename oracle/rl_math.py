@@ -234,3 +234,15 @@ def sft_loss(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -10
     logits = logits.float()
     shift = F.pad(labels, (0, 1), value=ignore_index)[..., 1:]
     return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), shift.reshape(-1), ignore_index=ignore_index, reduction='mean')
+
+
+def rm_loss(scores: torch.Tensor, end_scores: torch.Tensor, regularization: float) -> dict:
+    """align_anything/trainers/text_to_text/rm.py:97-132 -- scores [2B, L, 1] and end_scores [2B, 1] of the score model
+    (rows [0, B) = better, [B, 2B) = worse): pairwise -logsigmoid, optional L2 on the end rewards, all six outputs."""
+    higher_rewards, lower_rewards = scores.squeeze(dim=-1).chunk(chunks=2, dim=0)
+    higher_end, lower_end = end_scores.squeeze(dim=-1).chunk(chunks=2, dim=0)
+    loss = -F.logsigmoid(higher_end - lower_end).mean()
+    if regularization > 0.0:
+        loss = loss + regularization * torch.stack([lower_end, higher_end]).square().mean()
+    return {'loss': loss, 'higher_end_reward': higher_end, 'lower_end_reward': lower_end, 'higher_rewards': higher_rewards,
+            'lower_rewards': lower_rewards, 'accuracy': (higher_end > lower_end).float().mean()}

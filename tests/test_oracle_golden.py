@@ -291,3 +291,86 @@ def test_sft_oracle_matches_reference_supervised_loss():
     assert abs(float(-(lp[tgt != -100]).mean()) - float(z['loss'])) < 2e-5      # the window formulation of the same loss
     with pytest.raises(ValueError):
         build_label_window(torch.full((2, 5), -100))
+
+
+def test_rm_oracle_matches_reference_rm_trainer_loss():
+    """oracle.rl_math.rm_loss on the oracle OPT score model vs the reference's own RMTrainer.loss on its AccustomedOPTRewardModel
+    (tests/golden/opt_tiny_rm.npz: right-padded batch, all six outputs, gradients), with and without regularisation."""
+    from tests.util import tiny_opt_cfg
+    z = load_golden('opt_tiny_rm.npz')
+    cfg = tiny_opt_cfg()
+    ids, mask = T(z['input_ids']), T(z['attention_mask'])
+    for tag in ('reg', 'noreg'):
+        sd = {k: v.clone().requires_grad_(True) for k, v in state_dict_from_golden(z, 'w.').items()}
+        hid = om.opt_logits({k: v for k, v in sd.items() if k != 'score_head.weight'}, cfg, ids, mask, return_hidden=True)
+        scores, end = om.score_from_hidden(hid, sd['score_head.weight'], mask, end_at_last_position=False)
+        ld = orl.rm_loss(scores, end[:, None] if end.dim() == 1 else end, float(z[f'{tag}_regularization']))
+        for k in ('loss', 'higher_end_reward', 'lower_end_reward', 'accuracy'):
+            np.testing.assert_allclose(ld[k].detach().numpy(), z[f'{tag}_{k}'], rtol=2e-5, atol=2e-5, err_msg=k)
+        valid = mask.bool()
+        for k, rows in (('higher_rewards', slice(0, 3)), ('lower_rewards', slice(3, 6))):     # pad positions hold don't-care values
+            np.testing.assert_allclose(ld[k].detach()[valid[rows]].numpy(), z[f'{tag}_{k}'][valid[rows].numpy()], rtol=2e-4, atol=2e-4, err_msg=k)
+        ld['loss'].backward()
+        n = 0
+        for k in z.files:
+            if k.startswith(f'{tag}_g.'):
+                assert rel_err(sd[k[len(tag) + 3:]].grad, T(z[k])) < 2e-3, k
+                n += 1
+        assert n >= 5
+
+
+def test_ppo_oracle_matches_reference_t2t_rollout_and_rl_step():
+    """The oracle composition the PPO GPU tests use (oracle OPT logits / scores + oracle.rl_math) vs the reference's own
+    text_to_text PPOTrainer.rollout and rl_step (tests/golden/opt_tiny_ppo.npz), micro-batch by micro-batch."""
+    from tests.util import tiny_opt_cfg
+    z = load_golden('opt_tiny_ppo.npz')
+    cfg = tiny_opt_cfg()
+    P = z['prompts'].shape[1]
+    micro = int(z['micro'])
+    a = {k: v.clone().requires_grad_(True) for k, v in state_dict_from_golden(z, 'a.').items()}
+    r = state_dict_from_golden(z, 'r.')
+    rm, c = state_dict_from_golden(z, 'rm.'), {k: v.clone().requires_grad_(True) for k, v in state_dict_from_golden(z, 'c.').items()}
+    body = lambda sd: {k: v for k, v in sd.items() if k != 'score_head.weight'}
+    for i in range(z['sequences'].shape[0] // micro):
+        ids, mask = T(z[f'mb{i}.input_ids']), T(z[f'mb{i}.attention_mask'])
+        assert np.array_equal(z[f'mb{i}.input_ids'], z['sequences'][i * micro:(i + 1) * micro]) and int(z[f'mb{i}.prompt_idx']) == P - 1
+        assert torch.equal(mask.bool(), ids != int(z['pad_token_id']))
+        with torch.no_grad():
+            lp = orl.gather_log_probabilities(om.opt_logits({k: v.detach() for k, v in a.items()}, cfg, ids, mask)[:, :-1], ids[:, 1:])
+            rlp = orl.gather_log_probabilities(om.opt_logits(r, cfg, ids, mask)[:, :-1], ids[:, 1:])
+            _, reward = om.score_from_hidden(om.opt_logits(body(rm), cfg, ids, mask, return_hidden=True), rm['score_head.weight'], mask, False)
+            vals, _ = om.score_from_hidden(om.opt_logits(body({k: v.detach() for k, v in c.items()}), cfg, ids, mask, return_hidden=True),
+                                           c['score_head.weight'].detach(), mask, False)
+        sm = mask[:, 1:].bool()
+        # position j predicts token j+1: compared where BOTH are attended (the last left-pad position is inside sequence_mask,
+        # but its query row is fully masked and holds don't-care values; PPO never reads it: prompt_idx lies beyond the padding)
+        both = (sm & mask[:, :-1].bool()).numpy()
+        np.testing.assert_allclose(lp.numpy()[both], z[f'mb{i}.log_probs'][both], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(rlp.numpy()[both], z[f'mb{i}.ref_log_probs'][both], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(reward.reshape(-1).numpy(), z[f'mb{i}.reward'], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(vals.squeeze(-1)[:, :-1].numpy()[both], z[f'mb{i}.reward_values'][both], rtol=2e-4, atol=2e-4)
+        # rl_step on the FIXTURE's rollout statistics
+        old_lp, ref_lp, rew, old_v = (T(z[f'mb{i}.{k}']) for k in ('log_probs', 'ref_log_probs', 'reward', 'reward_values'))
+        start = P - 1
+        old_rewards = orl.add_kl_divergence_regularization(rew, old_lp, ref_lp, sm, float(z['kl_coeff']), float(z['clip_range_score']))
+        adv, ret = orl.get_advantages_and_returns(old_v, old_rewards, sm, start, float(z['gamma']), float(z['gae_lambda']))
+        for sd in (a, c):
+            for v in sd.values():
+                v.grad = None
+        new_lp = orl.gather_log_probabilities(om.opt_logits(a, cfg, ids, mask)[:, :-1], ids[:, 1:])
+        a_loss = orl.actor_loss_fn(new_lp[:, start:], old_lp[:, start:], adv, sm[:, start:], float(z['clip_range_ratio']))
+        nv, _ = om.score_from_hidden(om.opt_logits(body(c), cfg, ids, mask, return_hidden=True), c['score_head.weight'], mask, False)
+        c_loss = orl.critic_loss_fn(nv.squeeze(-1)[:, :-1][:, start:], old_v[:, start:], ret, sm[:, start:], float(z['clip_range_value']))
+        assert abs(float(a_loss) - float(z[f'mb{i}.info.train/actor_loss'])) < 2e-5
+        assert abs(float(c_loss) - float(z[f'mb{i}.info.train/reward_critic_loss'])) < 2e-4
+        m = sm[:, start:].float()
+        assert abs(float((old_rewards[:, start:] * m).sum(-1).mean()) - float(z[f'mb{i}.info.train/reward_with_kl_penalty'])) < 2e-5
+        assert abs(float(((old_lp - ref_lp)[:, start:] * m).sum(-1).mean()) - float(z[f'mb{i}.info.train/kl_divergence'])) < 2e-5
+        a_loss.backward(); c_loss.backward()
+        n = 0
+        for k in z.files:
+            for tag, sd in ((f'mb{i}.ga.', a), (f'mb{i}.gc.', c)):
+                if k.startswith(tag):
+                    assert rel_err(sd[k[len(tag):]].grad, T(z[k])) < 2e-3, k
+                    n += 1
+        assert n >= 8

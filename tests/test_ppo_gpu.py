@@ -243,3 +243,129 @@ def test_rule_reward_replaces_the_reward_model():
                      reward_fn=lambda i, a: torch.zeros(2))
     with pytest.raises(ValueError):
         bad.reward_model_step(ids.to(dev()), mask.to(dev()))
+
+
+# ====================================================================== pinned to the REFERENCE's own trainers (tests/golden/opt_tiny_rm.npz,
+# opt_tiny_ppo.npz: oracle/gen_golden.py::gen_opt_rm / gen_opt_ppo drive the unmodified RMTrainer.loss and PPOTrainer.rollout / rl_step)
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_rm_trainer_loss_matches_reference_fixture(dtype):
+    """All six outputs of the reference's RMTrainer.loss (trainers/text_to_text/rm.py:97-132) on its AccustomedOPTRewardModel,
+    right-padded batch, with and without regularisation; gradients of the backward it would run."""
+    from align_anything_amd.trainers.rm import RMTrainer
+    z = load_golden('opt_tiny_rm.npz')
+    ids, mask = T(z['input_ids']).to(dev()), T(z['attention_mask']).to(dev())
+    f32 = dtype == 'fp32'
+    rep = []
+    for tag in ('reg', 'noreg'):
+        sd = state_dict_from_golden(z, 'w.', torch.float32 if f32 else torch.bfloat16)
+        tr = RMTrainer({'train_cfgs': {'regularization': float(z[f'{tag}_regularization']), 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0,
+                                       'lr_scheduler_type': 'constant', 'weight_decay': 0.0, 'compute_dtype': dtype}},
+                       {'gradient_clipping': 1.0}, model_cfg=tiny_opt_cfg(), state=sd, device='cuda:0')
+        ld = tr.loss({'input_ids': ids, 'attention_mask': mask})
+        assert set(ld) >= {'loss', 'higher_end_reward', 'lower_end_reward', 'higher_rewards', 'lower_rewards', 'accuracy'}
+        tol = dict(rtol=1e-4, atol=1e-4) if f32 else dict(rtol=3e-2, atol=3e-2)
+        for k in ('higher_end_reward', 'lower_end_reward'):
+            assert_close(ld[k].cpu(), T(z[f'{tag}_{k}']), what=f'{tag} {k}', **tol)
+        valid = T(z['attention_mask']).bool()
+        for k, rows in (('higher_rewards', slice(0, 3)), ('lower_rewards', slice(3, 6))):
+            assert ld[k].shape == (3, ids.shape[1])
+            assert_close(ld[k].cpu()[valid[rows]], T(z[f'{tag}_{k}'])[valid[rows]], what=f'{tag} {k}', **tol)
+        assert abs(float(ld['loss']) - float(z[f'{tag}_loss'])) < (2e-5 if f32 else 2e-2), (float(ld['loss']), float(z[f'{tag}_loss']))
+        assert float(ld['accuracy']) == float(z[f'{tag}_accuracy'])
+        tr.model.backward(ld['loss'])
+        torch.cuda.synchronize()
+        worst = 0.0
+        for k in z.files:
+            if k.startswith(f'{tag}_g.'):
+                name = k[len(tag) + 3:]
+                got = tr.model.module.store.grad_view(name).float().cpu().reshape(z[k].shape)
+                worst = max(worst, rel_err(got, T(z[k])))
+        rep.append(f'{dtype} {tag}: loss {float(ld["loss"]):.6f} vs reference {float(z[f"{tag}_loss"]):.6f}, worst gradient rel-err {worst:.2e}')
+        assert worst < (2e-5 if f32 else 8e-2), rep
+    dump(f'parity_rm_reference_{dtype}.txt', '\n'.join(rep) + '\n')
+
+
+def test_vlm_reward_models_take_the_score_at_the_last_position():
+    """models/llava.py:64-68 / qwen2_vl.py:61-64: end_scores = score of position -1 whatever the mask says; OPT / Llama take the
+    last ATTENDED token (models/opt.py:67).  On a right-padded RM batch the two differ, and the RM trainer must follow the backbone."""
+    from align_anything_amd.trainers.common import end_index
+    from align_anything_amd.trainers.rm import RMTrainer
+    from tests.util import tiny_llava_cfg
+    mask = torch.ones(4, 40, dtype=torch.long)
+    mask[1, 30:] = 0
+    mask[3, 12:] = 0
+    assert end_index('opt', mask).tolist() == [39, 29, 39, 11] and end_index('qwen3moe', mask).tolist() == [39, 29, 39, 11]
+    assert end_index('llava', mask).tolist() == [39] * 4 and end_index('qwen2vl', mask).tolist() == [39] * 4
+    z = load_golden('llava_tiny_dpo.npz')
+    sd = {k: v for k, v in state_dict_from_golden(z, 'w.', torch.bfloat16).items() if k != 'lm_head.weight'}
+    g = torch.Generator().manual_seed(5)
+    sd['score_head.weight'] = (torch.randn(1, 128, generator=g) * 0.3).to(torch.bfloat16)
+    tr = RMTrainer({'train_cfgs': {'regularization': 0.0, 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant'}},
+                   {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), state=sd, device='cuda:0')
+    ids, am = T(z['input_ids']).clone(), T(z['attention_mask']).clone()
+    am[1, -6:] = 0                                                                # right padding on one row (ids stay: the tower needs its image tokens)
+    b = {'input_ids': ids.to(dev()), 'attention_mask': am.to(dev()), 'pixel_values': T(z['pixel_values']).to(dev())}
+    ld = tr.loss(b)
+    scores = torch.cat([ld['higher_rewards'], ld['lower_rewards']])
+    end = torch.cat([ld['higher_end_reward'], ld['lower_end_reward']])
+    assert_close(end.cpu(), scores[:, -1].cpu(), rtol=0, atol=1e-6, what='VLM end score = score at position -1')
+    tr.model.backward(ld['loss'])
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.model.module.store.grad_view('score_head.weight').float()).all()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_t2t_ppo_rollout_and_rl_step_match_reference_fixture(dtype):
+    """The reference's own text_to_text PPOTrainer.rollout (fixed `generate` output) and rl_step, micro-batch by micro-batch:
+    log-probs / reference log-probs / end reward / critic values of the rollout, then the 12 metrics and the gradients of rl_step."""
+    from align_anything_amd.trainers.ppo import PPOTrainer
+    z = load_golden('opt_tiny_ppo.npz')
+    f32 = dtype == 'fp32'
+    wd = torch.float32 if f32 else torch.bfloat16
+    a_sd, r_sd = state_dict_from_golden(z, 'a.', wd), state_dict_from_golden(z, 'r.', wd)
+    rm_sd, c_sd = state_dict_from_golden(z, 'rm.', wd), state_dict_from_golden(z, 'c.', wd)
+    cfgs = {'train_cfgs': {'actor_lr': 1e-3, 'critic_lr': 1e-3, 'actor_weight_decay': 0.0, 'critic_weight_decay': 0.0, 'actor_lr_warmup_ratio': 0.0,
+                           'critic_lr_warmup_ratio': 0.0, 'actor_lr_scheduler_type': 'constant', 'critic_lr_scheduler_type': 'constant',
+                           'kl_coeff': float(z['kl_coeff']), 'clip_range_ratio': float(z['clip_range_ratio']), 'clip_range_value': float(z['clip_range_value']),
+                           'clip_range_score': float(z['clip_range_score']), 'gamma': float(z['gamma']), 'gae_lambda': float(z['gae_lambda']),
+                           'per_device_train_batch_size': int(z['micro']), 'compute_dtype': dtype},
+            'model_cfgs': {'pad_token_id': int(z['pad_token_id']), 'eos_token_id': int(z['eos_token_id'])}}
+    micro, P = int(z['micro']), z['prompts'].shape[1]
+    rep = []
+    for i in range(z['sequences'].shape[0] // micro):
+        # a fresh trainer per micro-batch: the fixture's stand-in engines never stepped, so every rl_step starts from the same weights
+        tr = PPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_opt_cfg(), actor_state=a_sd, reward_state=rm_sd, critic_state=c_sd, device='cuda:0')
+        tr.actor_reference_model.module.load_state_dict(r_sd)
+        rows = slice(i * micro, (i + 1) * micro)
+        prompts = T(z['prompts'])[rows].to(dev())
+        pb = {'input_ids': prompts, 'attention_mask': prompts.ne(int(z['pad_token_id'])).long()}
+        inf, trn = tr.rollout(pb, sequences=T(z['sequences'])[rows].to(dev()))
+        assert torch.equal(inf['input_ids'].cpu(), T(z[f'mb{i}.input_ids'])) and trn['prompt_idx'] == int(z[f'mb{i}.prompt_idx']) == P - 1
+        assert torch.equal(inf['attention_mask'].cpu(), T(z[f'mb{i}.attention_mask']))
+        am = T(z[f'mb{i}.attention_mask'])
+        both = (am[:, 1:] & am[:, :-1]).bool()
+        tol = dict(rtol=1e-4, atol=2e-4) if f32 else dict(rtol=3e-2, atol=6e-2)
+        for k in ('log_probs', 'ref_log_probs', 'reward_values'):
+            assert_close(trn[k].cpu()[both], T(z[f'mb{i}.{k}'])[both], what=f'mb{i} {k}', **tol)
+        assert_close(trn['reward'].cpu(), T(z[f'mb{i}.reward']), what=f'mb{i} reward', **tol)
+        # rl_step on the FIXTURE's experience (the reference's numbers in, its metrics and gradients out)
+        tb = {k: T(z[f'mb{i}.{k}']).to(dev()) for k in ('log_probs', 'ref_log_probs', 'reward', 'reward_values')}
+        tb['prompt_idx'] = P - 1
+        info = tr.rl_step(inf, tb)
+        lim = 2e-5 if f32 else 3e-2
+        for k in ('train/actor_loss', 'train/reward_critic_loss', 'train/reward', 'train/reward_with_kl_penalty', 'train/reward_advantage',
+                  'train/reward_return', 'train/reward_value', 'train/kl_divergence', 'train/mean_generated_length', 'train/max_generated_length'):
+            want = float(z[f'mb{i}.info.{k}'])
+            assert abs(info[k] - want) < lim * max(1.0, abs(want)), (i, k, info[k], want)
+            rep.append(f'{dtype} mb{i} {k}: native {info[k]:.6f} reference {want:.6f}')
+        worst = 0.0
+        for eng, tag in ((tr.actor_model, f'mb{i}.ga.'), (tr.reward_critic_model, f'mb{i}.gc.')):
+            eng.wait_optimizer()
+            torch.cuda.synchronize()
+            for k in z.files:
+                if k.startswith(tag):
+                    got = eng.module.store.grad_view(k[len(tag):]).float().cpu().reshape(z[k].shape)
+                    worst = max(worst, rel_err(got, T(z[k])))
+        rep.append(f'{dtype} mb{i} worst gradient rel-err {worst:.2e}')
+        assert worst < (3e-5 if f32 else 8e-2), rep
+    dump(f'parity_ppo_t2t_reference_{dtype}.txt', '\n'.join(rep) + '\n')
