@@ -406,3 +406,68 @@ def test_two_rank_expert_parallel_step_host_flow():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+@pytest.mark.skipif(not __import__('os').path.isdir('/root/reference/align_anything'),
+                    reason='the reference checkout exists only in the build container (never on the GPU box)')
+def test_integration_level_b_stub_runs_the_reference_train_step(launches, monkeypatch):
+    """INTEGRATION.md section 3, executed: the three overrides a maintainer adds to the REFERENCE's own DPOTrainer
+    (init_models / init_engines / compute_log_probs+loss) -- then the reference's UNMODIFIED train_step
+    (align_anything/trainers/text_to_text/dpo.py:205-237) drives the native engines: loss dict keys, engine.backward(loss),
+    engine.step(), optimizer.param_groups[0]['lr'].  Kernel launches are recorded, not executed (CPU)."""
+    from oracle import _shim
+    _shim.install()
+    import align_anything.trainers.text_to_text.dpo as ref_dpo
+    from transformers import OPTConfig, OPTForCausalLM
+    from align_anything_amd import configs
+    from align_anything_amd.engine import NativeEngine
+    from align_anything_amd.trainers.dpo import DPOTrainer as NativeDPO
+
+    z = load_golden('opt_tiny_dpo.npz')
+    oc = OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=320, max_position_embeddings=128,
+                   word_embed_proj_dim=128, dropout=0.0, attention_dropout=0.0, pad_token_id=1)
+    hf = OPTForCausalLM(oc)
+
+    def hf_load(self):                                     # stands in for load_pretrained_models (no checkpoint / network here)
+        self.model, self.tokenizer, self.processor = hf, type('Tok', (), {'pad_token_id': 1})(), None
+        self.reference_model = hf
+    monkeypatch.setattr(ref_dpo.DPOTrainer, 'init_models', hf_load)
+    monkeypatch.setattr(ref_dpo, 'get_all_reduce_mean', lambda t: t)            # world size 1, no process group
+
+    class DPOTrainer(ref_dpo.DPOTrainer):                  # === the stub of INTEGRATION.md section 3, verbatim ===
+        def init_models(self):
+            super().init_models()                          # HF load: tokenizer/processor + checkpoint tensors
+            cfg = configs.from_hf_config(self.model.config)
+            sd = self.model.state_dict()
+            self.native = NativeDPO(self.cfgs, self.ds_train_cfgs, model_cfg=cfg, policy_state=sd, reference_state=sd,
+                                    tokenizer=self.tokenizer, train_dataloader=self.train_dataloader, device='cpu')
+            del self.model, self.reference_model           # the HF modules are not used on the hot path
+
+        def init_engines(self):
+            self.model, self.reference_model = self.native.model, self.native.reference_model
+
+        compute_log_probs = lambda self, model, batch: self.native.compute_log_probs(model, batch)
+        loss = lambda self, batch: self.native.loss(batch)
+
+    tr = DPOTrainer.__new__(DPOTrainer)                    # the reference __init__ wants yaml / datasets / deepspeed configs
+    tr.cfgs, tr.ds_train_cfgs = _cfgs(z), {'gradient_clipping': 1.0}
+    batch = _pref_batch(z)
+    tr.train_dataloader = [batch, batch]
+    tr.init_models()
+    tr.init_engines()
+    assert isinstance(tr.model, NativeEngine) and isinstance(tr.reference_model, NativeEngine) and not hasattr(tr, 'native_model')
+    del launches[:]
+    info = ref_dpo.DPOTrainer.train_step(tr, batch)        # the reference's own method body
+    assert set(info) == {'train/loss', 'train/reward', 'train/better_sample_reward', 'train/worse_sample_reward',
+                         'train/reward_accuracy', 'train/reward_margin', 'train/lr'}
+    assert info['train/lr'] == 1e-3 and tr.model.global_steps == 1
+    for k in ('aa_gemm_bf16', 'aa_attn_fwd', 'aa_logprob_gather_fwd', 'aa_dpo_loss_fwd_bwd', 'aa_attn_bwd', 'aa_grad_sumsq', 'aa_adamw_flat'):
+        assert k in launches, k
+    lp = ref_dpo.DPOTrainer.compute_log_probs is not DPOTrainer.compute_log_probs and tr.compute_log_probs(tr.model, batch)
+    assert lp.shape == (4, max(int(r) for r in z['response_lens']) - 1)
+    # the reference's checkpoint call on the engine (supervised_trainer.py:404-450) works on the native engine too
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        tr.model.save_16bit_model(d, save_filename='pytorch_model.bin')
+        sd = torch.load(d + '/pytorch_model.bin')
+        assert set(sd) >= set(hf.state_dict()) - {'lm_head.weight'}
