@@ -539,6 +539,12 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
     p.act = act; p.flags = flags;
     const int tile = pick_tile(M, N);
     hipStream_t st = (hipStream_t)stream;
+    if (tile == 5) {   // one-wave-per-SIMD 256x256 tile with accumulator-file MFMAs (gemm4.hip)
+        p.tiles_m = aa_cdiv(p.M, 256);
+        p.tiles_n = aa_cdiv(p.N, 256);
+        p.gm = pick_group(a_t, b_n, p.tiles_n, p.K);
+        return aa_gemm4_dispatch(p, a_t, b_n, st);
+    }
     if (g_mfma32 && tile == 0 && !(a_t && !b_n)) return aa_gemm32_dispatch(p, a_t, b_n, st);
     if (g_ilv == 3 && g_pipe && tile == 0 && !(a_t && !b_n) && K >= 4 * BK) return aa_gemm_ring_dispatch(p, a_t, b_n, st);
     if (!a_t && !b_n) return launch_layout<false, false>(p, tile, st);

@@ -84,5 +84,7 @@ __device__ __forceinline__ void gemm_store4(const GemmParams& p, int m, int n, f
 
 // split-K-ring 256x256 kernel (gemm_ring.hip)
 int aa_gemm_ring_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
+// one-wave-per-SIMD 256x256 kernel, accumulators in the accumulator file (gemm4.hip)
+int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
 // 32x32x16-MFMA 256x256 kernel (gemm32.hip)
 int aa_gemm32_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);

@@ -15,10 +15,11 @@ def _ref(a, b, a_t, b_n):
     return A @ B
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 32])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 32])
 @pytest.mark.parametrize('layout', ['nt', 'nn', 'tn'])
 def test_gemm_layouts_and_tiles(tile, layout):
-    """tile 0-3: 16x16x32-MFMA tile configs; 32: the 32x32x16-MFMA 256x256 kernel (gemm32.hip)."""
+    """tile 0-3: 16x16x32-MFMA tile configs; 4: the 4-wave instantiation of the same template; 5: the one-wave-per-SIMD kernel
+    with accumulator-file MFMAs (gemm4.hip); 32: the 32x32x16-MFMA 256x256 kernel (gemm32.hip)."""
     from align_anything_amd import ops
     ops.gemm_set_mfma32(tile == 32)
     ops.gemm_set_tile(0 if tile == 32 else tile)
