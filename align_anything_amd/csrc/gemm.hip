@@ -504,6 +504,8 @@ static int pick_tile(int M, int N) {
         g_force_tile = e ? atoi(e) : -1;
     }
     if (g_force_tile >= 0) return g_force_tile;
+    static int g4 = -1;      // AA_GEMM_G4=0 keeps the 8-wave kernel for the 256x256 tile (A/B runs)
+    if (g4 < 0) { const char* e = getenv("AA_GEMM_G4"); g4 = e ? atoi(e) : 1; }
     struct Cfg { int bm, bn, slots; float eff; };
     // slots = concurrently resident tiles on the chip; eff = relative per-flop efficiency of the config
     const Cfg cfgs[4] = {{256, 256, 256, 1.00f}, {128, 128, 512, 0.72f}, {256, 128, 256, 0.86f}, {128, 256, 256, 0.86f}};
@@ -516,6 +518,9 @@ static int pick_tile(int M, int N) {
         const float t = rounds * per;
         if (t < best_t) { best_t = t; best = c; }
     }
+    // the 256x256 tile runs on the one-wave-per-SIMD kernel (gemm4.hip): +1..17 % on every hot 7B shape and layout
+    // (profiles/r02_gemm_lab_g4.json); the 8-wave kernel stays reachable as tile 0
+    if (best == 0 && g4) return 5;
     return best;
 }
 

@@ -35,17 +35,29 @@ __device__ __forceinline__ int tr_swz4(int krow) { return (krow & 3) | (((krow >
 #define AA_MFMA_ACC(ACC, BF, AF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(BF), "v"(AF))
 
 
-// one LDS-DMA piece: K < 8 = A chunk K, else B chunk K - 8 (see G4_DMA_RAW in the kernel)
-#define G4_DMA_RAW_(OFF, LDSW, IMM, SRC)                                                                      \
-    asm volatile("s_add_i32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3" ::"v"(OFF), "s"(LDSW), "i"(IMM), "s"(SRC) : "memory")
+// One LDS-DMA piece: K < 8 = A chunk K, else B chunk K - 8.  M0 (the LDS destination) is a running pointer: G4_M0_SET points it at
+// this wave's first A chunk of the target buffer well ahead of piece 0, and every piece advances it for the NEXT one right after its
+// request (4 KB to the wave's next chunk; from the last A chunk to the first B chunk; nothing after the last piece) -- the one
+// wait state the M0 write needs before a DMA reads it is then covered by the MFMA in between, no s_nop in the stream.  saddr form:
+// wave-uniform 64-bit base + per-lane 32-bit byte offset.
+#define G4_M0_SET(LDSW) asm volatile("s_mov_b32 m0, %0" ::"s"(LDSW) : "memory")
 template <int K>
-__device__ __forceinline__ void G4_DMA_PIECE(const unsigned (&offA)[A_IT], const unsigned (&offB)[B_IT], int ldsw_c, const char* srcA,
-                                             const char* srcB) {
-    if constexpr (K < A_IT) { G4_DMA_RAW_(offA[K], ldsw_c, K * NW * 1024, srcA); }
-    else { G4_DMA_RAW_(offB[K - A_IT], ldsw_c, 65536 + (K - A_IT) * NW * 1024, srcB); }
+__device__ __forceinline__ void G4_DMA_PIECE(const unsigned (&offA)[A_IT], const unsigned (&offB)[B_IT], const char* srcA, const char* srcB) {
+    if constexpr (K < A_IT - 1) {
+        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(offA[K]), "s"(srcA), "i"(NW * 1024) : "memory");
+    } else if constexpr (K == A_IT - 1) {
+        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(offA[K]), "s"(srcA), "i"(65536 - (A_IT - 1) * NW * 1024) : "memory");
+    } else if constexpr (K < A_IT + B_IT - 1) {
+        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(offB[K - A_IT]), "s"(srcB), "i"(NW * 1024) : "memory");
+    } else {
+        asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(offB[K - A_IT]), "s"(srcB) : "memory");
+    }
 }
 
-template <bool A_T, bool B_N>
+// PLAIN: bf16 C = A * B with no bias / activation / residual / accumulate and M, N multiples of the tile (every forward, dX and
+// dW GEMM of the 7B decoder stack): the epilogue is straight-line 16-byte stores, and -- its own instantiation -- shares no
+// registers with the general epilogue, whose 256-value fan-out would otherwise make the compiler spill accumulators
+template <bool A_T, bool B_N, bool PLAIN>
 __global__ __launch_bounds__(NW * 64, 1)
 void gemm4_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -140,7 +152,7 @@ void gemm4_kernel(const GemmParams p) {
     const int ldsw = lds0 + wave * 1024;                                    // this wave's first DMA chunk
     // DMA piece k (0..7 = A chunks, 8..15 = B chunks of this wave) of the K-tile whose operand pointers are (srcA, srcB) into
     // buffer offset `cb` (0 / 32768).  asm: saddr form (uniform 64-bit base + per-lane 32-bit offset), M0 = LDS destination.
-#define G4_DMA(K) G4_DMA_PIECE<K>(offA, offB, ldsw_c, srcA, srcB)
+#define G4_DMA(K) G4_DMA_PIECE<K>(offA, offB, srcA, srcB)
 
     // ---- per-lane LDS read addresses (same swizzled images as gemm.hip)
     const int l15 = lane & 15, g = lane >> 4;
@@ -176,7 +188,7 @@ void gemm4_kernel(const GemmParams p) {
 #define G4_RDT(DST, VADDR, IMM) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(VADDR), "i"(IMM))
 #define G4_WAIT_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N))
 #define G4_PIN __builtin_amdgcn_sched_barrier(0)
-#define G4_SYNC asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define G4_SYNC asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_mov_b32 m0, %0" ::"s"(ldsw_c) : "memory")
 #define G4_JOIN(LO, HI) __builtin_shufflevector(LO, HI, 0, 1, 2, 3, 4, 5, 6, 7)
 
     const int nt = p.K / BK;
@@ -184,11 +196,12 @@ void gemm4_kernel(const GemmParams p) {
     {
         const char* srcA = baseA;
         const char* srcB = baseB;
-        const int ldsw_c = ldsw;
+        G4_M0_SET(ldsw);
+        asm volatile("s_nop 0");
         G4_DMA(0); G4_DMA(1); G4_DMA(2); G4_DMA(3); G4_DMA(4); G4_DMA(5); G4_DMA(6); G4_DMA(7);
         G4_DMA(8); G4_DMA(9); G4_DMA(10); G4_DMA(11); G4_DMA(12); G4_DMA(13); G4_DMA(14); G4_DMA(15);
     }
-    G4_SYNC;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     {
         // same order as the in-loop reads (b0..b7, a0..a7): the phase-A wait counts rely on it
 #pragma unroll
@@ -204,7 +217,8 @@ void gemm4_kernel(const GemmParams p) {
         const int t1 = min(1, nt - 1);
         const char* srcA = baseA + (long)t1 * stepA;
         const char* srcB = baseB + (long)t1 * stepB;
-        const int ldsw_c = ldsw + 32768;
+        G4_M0_SET(ldsw + 32768);
+        asm volatile("s_nop 0");
         G4_DMA(0); G4_DMA(1); G4_DMA(2); G4_DMA(3); G4_DMA(4); G4_DMA(5); G4_DMA(6); G4_DMA(7);
         G4_DMA(8); G4_DMA(9); G4_DMA(10); G4_DMA(11); G4_DMA(12); G4_DMA(13); G4_DMA(14); G4_DMA(15);
     }
@@ -246,25 +260,30 @@ void gemm4_kernel(const GemmParams p) {
                  :: "memory");
 
     // ---- epilogue: lane owns C[m][n..n+3], m = .. + l15, n = .. + g*4
-    // fast path (every forward / dX / dW GEMM of the decoder stack without bias: bf16 out, no bias / activation / residual /
-    // accumulate, tile fully inside C): straight-line convert + 8-byte stores
-    const bool plain = p.flags == (p.flags & (AA_GEMM_A_T | AA_GEMM_B_N)) && !p.bias && !p.residual && p.act == AA_ACT_NONE &&
-                       m0 + BM <= p.M && n0 + BN <= p.N;
-    if (plain) {
-        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)(m0 + wm * TM + l15) * p.ldc + n0 + wn * TNW + g * 4;
+    if constexpr (PLAIN) {
+        // 16-byte stores: lanes g and g^1 (16 lanes apart) exchange halves with v_permlane16_swap, so that a lane ends up with 8
+        // consecutive columns of ONE fragment (even g: fragment j, odd g: fragment j+1) -- half the store instructions of the
+        // 4-columns-per-lane layout the MFMA leaves (the tile's store tail is issue-bound)
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)(m0 + wm * TM + l15) * p.ldc + n0 + wn * TNW + (g & 1) * 16 + (g >> 1) * 8;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                u16x4 o;
+            for (int j = 0; j < FN; j += 2) {
+                unsigned w[2][2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[i][j][e]);
-                *reinterpret_cast<u16x4*>(crow + (long)i * 16 * p.ldc + j * 16) = o;
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        w[f][h] = (unsigned)f2bf(acc[i][j + f][2 * h]) | ((unsigned)f2bf(acc[i][j + f][2 * h + 1]) << 16);
+                const u32x2 lo = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+                const u32x2 hi = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+                *reinterpret_cast<u32x4*>(crow + (long)i * 16 * p.ldc + j * 16) = u32x4{lo[0], hi[0], lo[1], hi[1]};
             }
             __builtin_amdgcn_sched_barrier(0);      // one accumulator row at a time: no 256-register fan-out of the reads
         }
-        return;
-    }
+    } else {
     // general path (gemm_store4: the rounding points of gemm.hip)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -278,12 +297,13 @@ void gemm4_kernel(const GemmParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    }
 }
 
-template <bool A_T, bool B_N>
+template <bool A_T, bool B_N, bool PLAIN>
 int launch4(GemmParams& p, hipStream_t st) {
     constexpr int lds = 2 * STAGE;
-    auto kern = gemm4_kernel<A_T, B_N>;
+    auto kern = gemm4_kernel<A_T, B_N, PLAIN>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -298,13 +318,20 @@ int launch4(GemmParams& p, hipStream_t st) {
     return AA_OK;
 }
 
+template <bool PLAIN>
+int launch4_layout(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
+    if (!a_t && !b_n) return launch4<false, false, PLAIN>(p, st);
+    if (!a_t && b_n) return launch4<false, true, PLAIN>(p, st);
+    if (a_t && b_n) return launch4<true, true, PLAIN>(p, st);
+    aa_set_error("aa_gemm_bf16: layout A^T with K-contiguous B is not built (unused by the hot path)");
+    return AA_ERR_ARG;
+}
+
 }  // namespace
 
 // p.tiles_m / tiles_n / gm are set by the caller (gemm.hip)
 int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
-    if (!a_t && !b_n) return launch4<false, false>(p, st);
-    if (!a_t && b_n) return launch4<false, true>(p, st);
-    if (a_t && b_n) return launch4<true, true>(p, st);
-    aa_set_error("aa_gemm_bf16: layout A^T with K-contiguous B is not built (unused by the hot path)");
-    return AA_ERR_ARG;
+    const bool plain = p.flags == (p.flags & (AA_GEMM_A_T | AA_GEMM_B_N)) && !p.bias && !p.residual && p.act == AA_ACT_NONE &&
+                       p.M % BM == 0 && p.N % BN == 0 && (p.ldc & 7) == 0;
+    return plain ? launch4_layout<true>(p, a_t, b_n, st) : launch4_layout<false>(p, a_t, b_n, st);
 }

@@ -42,11 +42,14 @@ def test_gemm_layouts_and_tiles(tile, layout):
         ops.gemm_set_mfma32(False)
 
 
-@pytest.mark.parametrize('mfma32', [False, True])
+@pytest.mark.parametrize('mfma32', [False, True, 'g4'])
 def test_gemm_epilogues_match_hf_rounding_points(mfma32):
+    """'g4' = the general epilogue of the one-wave-per-SIMD kernel (gemm4.hip; its plain bf16 epilogue is what the layout test runs)."""
     from align_anything_amd import ops
+    g4 = mfma32 == 'g4'
+    mfma32 = mfma32 is True
     ops.gemm_set_mfma32(mfma32)
-    ops.gemm_set_tile(0 if mfma32 else -1)
+    ops.gemm_set_tile(5 if g4 else (0 if mfma32 else -1))
     M, N, K = 384, 512, 256
     a, w = randn_bf16(M, K, seed=3), randn_bf16(N, K, scale=0.1, seed=4)
     bias, res = randn_bf16(N, seed=5), randn_bf16(M, N, seed=6)

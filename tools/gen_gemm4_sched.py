@@ -20,10 +20,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), 'align_anything_amd', 'csrc')
 
 
-def fillers(n_reads, n_dma):
-    """Proportional merge of reads and DMA pieces over the first 48 slots: slot -> filler tag ('R', k) / ('D', d)."""
+def fillers(n_reads, n_dma, variant=0):
+    """Proportional merge of reads and DMA pieces over the first 48 slots: slot -> filler tag ('R', k) / ('D', d).
+    variant 1: the DMA pieces take slots 0..15 (the request of K-tile t+2 gets the longest possible flight time), the reads follow."""
     total = n_reads + n_dma
     assert total <= 48
+    if variant == 1 and n_dma:
+        slots = {d: ('D', d) for d in range(n_dma)}
+        for r in range(n_reads):
+            slots[n_dma + r * (48 - n_dma) // n_reads] = ('R', r)
+        assert len(slots) == total
+        return slots
     seq = []
     r = d = 0
     for f in range(total):          # Bresenham-style interleave: keep reads / dma in proportion
@@ -40,7 +47,7 @@ def fillers(n_reads, n_dma):
     return slots
 
 
-def gen(a_t, b_n):
+def gen(a_t, b_n, variant=0):
     rA, rB = (2 if a_t else 1), (2 if b_n else 1)
     # flattened read list of one fragment set: (operand, fragment index, half)
     reads = [('b', j, h) for j in range(8) for h in range(rB)] + [('a', i, h) for i in range(8) for h in range(rA)]
@@ -73,25 +80,30 @@ def gen(a_t, b_n):
             # F0 fragments a[i] (and every b for i == 0) must have landed: reads issued after a[i] in the previous phase C + the new
             # reads issued so far in this phase may still be outstanding
             pend = (n - first_read_after_a[i]) + issued_new
-            w(f'G4_WAIT_LGKM({min(pend, 15)});')
+            if variant not in (3, 4):
+                w(f'G4_WAIT_LGKM({min(pend, 15)});')
         w(mfma(0, i, j))
         if s in fa:
-            w(read_stmt(1, fa[s][1], 1, 'cur'))
+            if variant not in (3, 4):
+                w(read_stmt(1, fa[s][1], 1, 'cur'))
             issued_new += 1
         w('G4_PIN;')
     assert issued_new == n
     w('G4_SYNC;')
     # ---------------- phase C: MFMA(F1) (complete: waited at the barrier), reads F0 from buffer cur^1 (k-step 0), DMA into buffer cur
-    fc = fillers(n, 16)
+    fc = fillers(n, 16, variant)
     for s in range(64):
         i, j = s // 8, s % 8
         w(mfma(1, i, j))
         if s in fc:
             kind, k = fc[s]
-            w(read_stmt(0, k, 0, 'nxt') if kind == 'R' else f'G4_DMA({k});')
+            if kind == 'R' and variant not in (3, 4):
+                w(read_stmt(0, k, 0, 'nxt'))
+            if kind == 'D' and variant not in (2, 4):
+                w(f'G4_DMA({k});')
         w('G4_PIN;')
     name = ('t' if a_t else 'n') + ('n' if b_n else 't')
-    path = os.path.join(OUT, f'gemm4_sched_{name}.inc')
+    path = os.path.join(OUT, f'gemm4_sched_{name}' + (f'_v{variant}' if variant else '') + '.inc')
     hdr = (f'// GENERATED by tools/gen_gemm4_sched.py -- do not edit.  K-tile schedule of gemm4_kernel<{str(a_t).lower()}, {str(b_n).lower()}>:\n'
            f'// {n} LDS reads per fragment set ({rA} per A fragment, {rB} per B fragment), 16 DMA pieces per K-tile, at most one filler per MFMA slot.\n')
     with open(path, 'w') as f:
@@ -100,5 +112,9 @@ def gen(a_t, b_n):
 
 
 if __name__ == '__main__':
-    for a_t, b_n in ((False, False), (False, True), (True, True)):
-        print(*gen(a_t, b_n))
+    import sys
+    # variant 0 is the build; `python tools/gen_gemm4_sched.py 1` (DMA pieces first: measured 7-10 % slower) and 2 / 3 / 4 (ablations
+    # without DMA / without LDS reads / without both: timing only) write gemm4_sched_*_v<N>.inc for experiments
+    for variant in [int(a) for a in sys.argv[1:]] or [0]:
+        for a_t, b_n in ((False, False), (False, True), (True, True)):
+            print(*gen(a_t, b_n, variant))
