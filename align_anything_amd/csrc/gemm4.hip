@@ -41,6 +41,29 @@ __device__ __forceinline__ int tr_swz4(int krow) { return (krow & 3) | (((krow >
 // wait state the M0 write needs before a DMA reads it is then covered by the MFMA in between, no s_nop in the stream.  saddr form:
 // wave-uniform 64-bit base + per-lane 32-bit byte offset.
 #define G4_M0_SET(LDSW) asm volatile("s_mov_b32 m0, %0" ::"s"(LDSW) : "memory")
+// PLAIN kernels (no edge clamping): the lanes' source pattern is the same for every piece of an operand up to a uniform row
+// stride (K-contiguous image) or alternates between two patterns with the piece's parity (row-contiguous image, whose swizzle takes
+// bit 3 of the k-row), so ONE or TWO offset VGPRs per operand serve all 8 pieces: buffer_load ... lds with the piece's byte offset in
+// the scalar offset operand.  `srd` = buffer descriptor of the operand at the K-tile being requested (base advanced by SALU).
+typedef __attribute__((ext_vector_type(4))) int g4_srd_t;
+__device__ __forceinline__ g4_srd_t g4_make_srd(const char* base) {
+    const unsigned long long a = (unsigned long long)base;
+    return g4_srd_t{(int)(unsigned)a, (int)(unsigned)(a >> 32), 0x7fffffff, 0x00020000};     // stride 0, raw 32-bit format
+}
+template <int K, bool A_T, bool B_N>
+__device__ __forceinline__ void G4_DMA_PIECE_BUF(unsigned vA0, unsigned vA1, unsigned vB0, unsigned vB1, int pieceA, int pieceB,
+                                                 g4_srd_t srdA, g4_srd_t srdB) {
+    constexpr int j = K < A_IT ? K : K - A_IT;
+    constexpr int adv = K == A_IT - 1 ? 65536 - (A_IT - 1) * NW * 1024 : NW * 1024;
+    const unsigned v = K < A_IT ? ((A_T && (j & 1)) ? vA1 : vA0) : ((B_N && (j & 1)) ? vB1 : vB0);
+    const int so = j * (K < A_IT ? pieceA : pieceB);
+    if constexpr (K < A_IT + B_IT - 1) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, %3" ::"v"(v), "s"(K < A_IT ? srdA : srdB), "s"(so), "i"(adv) : "memory");
+    } else {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(v), "s"(srdB), "s"(so) : "memory");
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void G4_DMA_PIECE(const unsigned (&offA)[A_IT], const unsigned (&offB)[B_IT], const char* srcA, const char* srcB) {
     if constexpr (K < A_IT - 1) {
@@ -57,39 +80,48 @@ __device__ __forceinline__ void G4_DMA_PIECE(const unsigned (&offA)[A_IT], const
 // PLAIN: bf16 C = A * B with no bias / activation / residual / accumulate and M, N multiples of the tile (every forward, dX and
 // dW GEMM of the 7B decoder stack): the epilogue is straight-line 16-byte stores, and -- its own instantiation -- shares no
 // registers with the general epilogue, whose 256-value fan-out would otherwise make the compiler spill accumulators
-template <bool A_T, bool B_N, bool PLAIN>
+// PERSIST (PLAIN only, K >= 2 K-tiles): at most one workgroup per CU walks the tile list with stride gridDim.x and treats its
+// tiles as ONE stream of K-tiles -- the requests of the next tile's first two K-tiles ride in the last two iterations of the current
+// tile, so the epilogue's stores overlap their flight and no tile after the first pays a prologue (or a workgroup launch).
+template <bool A_T, bool B_N, int EPI, bool PERSIST>
 __global__ __launch_bounds__(NW * 64, 1)
 void gemm4_kernel(const GemmParams p) {
+    constexpr bool PLAIN = EPI != 0;       // EPI: 0 = general epilogue, 1 = plain bf16 store, 2 = plain + residual add (o / down projections)
+    static_assert(PLAIN || !PERSIST, "the persistent walk relies on tile-independent DMA lane offsets (no edge clamping)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // ---- XCD-aware bijective remap, then grouped tile order (identical to gemm_kernel)
+    // ---- XCD-aware bijective remap, then grouped tile order (identical to gemm_kernel); `bid` = position in dispatch order
     const int nwg = p.tiles_m * p.tiles_n;
-    int wg;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int GM = p.gm & 0xff;
-    int tm, tn;
-    if (!(p.gm & 0x100)) {
-        const int per_group = GM * p.tiles_n;
-        const int group = wg / per_group;
-        const int first_m = group * GM;
-        const int gsz = min(p.tiles_m - first_m, GM);
-        tm = first_m + (wg % per_group) % gsz;
-        tn = (wg % per_group) / gsz;
-    } else {
-        const int per_group = GM * p.tiles_m;
-        const int group = wg / per_group;
-        const int first_n = group * GM;
-        const int gsz = min(p.tiles_n - first_n, GM);
-        tn = first_n + (wg % per_group) % gsz;
-        tm = (wg % per_group) / gsz;
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
+    auto map_tile = [&](int bid, int& m0_, int& n0_) {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int GM = p.gm & 0xff;
+        int tm, tn;
+        if (!(p.gm & 0x100)) {
+            const int per_group = GM * p.tiles_n;
+            const int group = wg / per_group;
+            const int first_m = group * GM;
+            const int gsz = min(p.tiles_m - first_m, GM);
+            tm = first_m + (wg % per_group) % gsz;
+            tn = (wg % per_group) / gsz;
+        } else {
+            const int per_group = GM * p.tiles_m;
+            const int group = wg / per_group;
+            const int first_n = group * GM;
+            const int gsz = min(p.tiles_n - first_n, GM);
+            tn = first_n + (wg % per_group) % gsz;
+            tm = (wg % per_group) / gsz;
+        }
+        m0_ = tm * BM;
+        n0_ = tn * BN;
+    };
+    int m0, n0;
+    map_tile(blockIdx.x, m0, n0);
+    auto tile_base_a = [&](int m0_) { return reinterpret_cast<const char*>(A_T ? p.A + m0_ : p.A + (long)m0_ * p.lda); };
+    auto tile_base_b = [&](int n0_) { return reinterpret_cast<const char*>(B_N ? p.B + n0_ : p.B + (long)n0_ * p.ldb); };
 
     // ---- DMA sources: uniform base (advanced per K-tile) + per-lane byte offset inside the tile's row / column block
     const char* baseA;
@@ -97,7 +129,7 @@ void gemm4_kernel(const GemmParams p) {
     unsigned offA[A_IT], offB[B_IT];
     long stepA, stepB;
     if constexpr (!A_T) {
-        baseA = reinterpret_cast<const char*>(p.A + (long)m0 * p.lda);
+        baseA = tile_base_a(m0);
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
             const int c = wave + j * NW;
@@ -109,7 +141,7 @@ void gemm4_kernel(const GemmParams p) {
         stepA = BK * 2;
     } else {
         constexpr int RPI = 1024 / (BM * 2), SPR = BM * 2 / 16;
-        baseA = reinterpret_cast<const char*>(p.A + m0);
+        baseA = tile_base_a(m0);
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
             const int c = wave + j * NW;
@@ -122,7 +154,7 @@ void gemm4_kernel(const GemmParams p) {
         stepA = (long)BK * p.lda * 2;
     }
     if constexpr (!B_N) {
-        baseB = reinterpret_cast<const char*>(p.B + (long)n0 * p.ldb);
+        baseB = tile_base_b(n0);
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
             const int c = wave + j * NW;
@@ -134,7 +166,7 @@ void gemm4_kernel(const GemmParams p) {
         stepB = BK * 2;
     } else {
         constexpr int RPI = 1024 / (BN * 2), SPR = BN * 2 / 16;
-        baseB = reinterpret_cast<const char*>(p.B + n0);
+        baseB = tile_base_b(n0);
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
             const int c = wave + j * NW;
@@ -152,7 +184,16 @@ void gemm4_kernel(const GemmParams p) {
     const int ldsw = lds0 + wave * 1024;                                    // this wave's first DMA chunk
     // DMA piece k (0..7 = A chunks, 8..15 = B chunks of this wave) of the K-tile whose operand pointers are (srcA, srcB) into
     // buffer offset `cb` (0 / 32768).  asm: saddr form (uniform 64-bit base + per-lane 32-bit offset), M0 = LDS destination.
-#define G4_DMA(K) G4_DMA_PIECE<K>(offA, offB, srcA, srcB)
+    // PLAIN: per-operand lane patterns (even / odd piece) and the uniform byte distance between consecutive pieces of this wave
+    const unsigned vA0 = offA[0], vA1 = A_T ? offA[1] - (unsigned)(NW * (1024 / (BM * 2)) * p.lda * 2) : 0u;
+    const unsigned vB0 = offB[0], vB1 = B_N ? offB[1] - (unsigned)(NW * (1024 / (BN * 2)) * p.ldb * 2) : 0u;
+    const int pieceA = (A_T ? NW * (1024 / (BM * 2)) : NW * 8) * (int)p.lda * 2;       // rows (k-rows) per piece step x row bytes
+    const int pieceB = (B_N ? NW * (1024 / (BN * 2)) : NW * 8) * (int)p.ldb * 2;
+#define G4_DMA(K)                                                                                                   \
+    do {                                                                                                            \
+        if constexpr (PLAIN) G4_DMA_PIECE_BUF<K, A_T, B_N>(vA0, vA1, vB0, vB1, pieceA, pieceB, g4_make_srd(srcA), g4_make_srd(srcB)); \
+        else G4_DMA_PIECE<K>(offA, offB, srcA, srcB);                                                               \
+    } while (0)
 
     // ---- per-lane LDS read addresses (same swizzled images as gemm.hip)
     const int l15 = lane & 15, g = lane >> 4;
@@ -222,88 +263,143 @@ void gemm4_kernel(const GemmParams p) {
         G4_DMA(0); G4_DMA(1); G4_DMA(2); G4_DMA(3); G4_DMA(4); G4_DMA(5); G4_DMA(6); G4_DMA(7);
         G4_DMA(8); G4_DMA(9); G4_DMA(10); G4_DMA(11); G4_DMA(12); G4_DMA(13); G4_DMA(14); G4_DMA(15);
     }
-    // ---- main loop: one K-tile per iteration, branch-free (the K-tile index of the request is clamped: the last two
-    // iterations re-request the last tile into a buffer nobody reads any more)
-    for (int t = 0; t < nt; ++t) {
-        const int cbc = (t & 1) * 32768, cbn = cbc ^ 32768;                  // buffer offsets: current / next K-tile
-        const int t2 = min(t + 2, nt - 1);
-        const char* srcA = baseA + (long)t2 * stepA;
-        const char* srcB = baseB + (long)t2 * stepB;
-        const int ldsw_c = ldsw + cbc;
-        [[maybe_unused]] const int vak1_cur = vak[1] + cbc, vbk1_cur = vbk[1] + cbc, vak0_nxt = vak[0] + cbn, vbk0_nxt = vbk[0] + cbn;
-        if constexpr (!A_T && !B_N) {
+    // ---- tile walk (one tile unless PERSIST).  `u` counts the K-tiles of the whole walk: buffer parity = u & 1.
+    int u = 0;
+    for (int bid = blockIdx.x;;) {
+        const int bid_next = bid + (int)gridDim.x;
+        const bool has_next = PERSIST && bid_next < nwg;
+        // operands of the tile after this one (PERSIST): its first two K-tiles are requested by this tile's last two iterations
+        const char* nextA = baseA;
+        const char* nextB = baseB;
+        int m0n = m0, n0n = n0;
+        if (has_next) {
+            map_tile(bid_next, m0n, n0n);
+            nextA = tile_base_a(m0n);
+            nextB = tile_base_b(n0n);
+        }
+        // ---- K loop: one K-tile per iteration, branch-free.  The request two K-tiles ahead wraps into the next tile; without one it
+        // is clamped to the last K-tile (re-requested into a buffer nobody reads any more).
+        for (int t = 0; t < nt; ++t, ++u) {
+            const int cbc = (u & 1) * 32768, cbn = cbc ^ 32768;                  // buffer offsets: current / next K-tile
+            const bool wrap = has_next && t + 2 >= nt;
+            const int t2 = wrap ? t + 2 - nt : min(t + 2, nt - 1);
+            const char* srcA = (wrap ? nextA : baseA) + (long)t2 * stepA;
+            const char* srcB = (wrap ? nextB : baseB) + (long)t2 * stepB;
+            const int ldsw_c = ldsw + cbc;
+            [[maybe_unused]] const int vak1_cur = vak[1] + cbc, vbk1_cur = vbk[1] + cbc, vak0_nxt = vak[0] + cbn, vbk0_nxt = vbk[0] + cbn;
+            if constexpr (!A_T && !B_N) {
 #define G4_FRAG_A(S, I) a##S[I]
 #define G4_FRAG_B(S, J) b##S[J]
 #include "gemm4_sched_nt.inc"
 #undef G4_FRAG_A
 #undef G4_FRAG_B
-        } else if constexpr (!A_T && B_N) {
+            } else if constexpr (!A_T && B_N) {
 #define G4_FRAG_A(S, I) a##S[I]
 #define G4_FRAG_B(S, J) G4_JOIN(b##S##h[J][0], b##S##h[J][1])
 #include "gemm4_sched_nn.inc"
 #undef G4_FRAG_A
 #undef G4_FRAG_B
-        } else {
+            } else {
 #define G4_FRAG_A(S, I) G4_JOIN(a##S##h[I][0], a##S##h[I][1])
 #define G4_FRAG_B(S, J) G4_JOIN(b##S##h[J][0], b##S##h[J][1])
 #include "gemm4_sched_tn.inc"
 #undef G4_FRAG_A
 #undef G4_FRAG_B
+            }
         }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped re-requests of the last K-tile
-    // the last MFMAs are still in the matrix pipe: the compiler does not know the asm statements wrote the accumulators late
-    // (nothing may read the last row's accumulators above this statement: they are its operands)
-    asm volatile("s_nop 15\n\ts_nop 15"
-                 : "+a"(acc[FM - 1][0]), "+a"(acc[FM - 1][1]), "+a"(acc[FM - 1][2]), "+a"(acc[FM - 1][3]), "+a"(acc[FM - 1][4]),
-                   "+a"(acc[FM - 1][5]), "+a"(acc[FM - 1][6]), "+a"(acc[FM - 1][7])
-                 :: "memory");
+        if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped re-requests of the last K-tile
+        // PERSIST: the next tile's first fragment set was read (asm, not tracked by the compiler) during the last phase; let it land
+        // before compiler-scheduled code runs, so that whatever the register allocator does with those registers here is safe
+        if constexpr (PERSIST) G4_WAIT_LGKM(0);
+        // the last MFMAs are still in the matrix pipe: the compiler does not know the asm statements wrote the accumulators late
+        // (nothing may read the last row's accumulators above this statement: they are its operands)
+        asm volatile("s_nop 15\n\ts_nop 15"
+                     : "+a"(acc[FM - 1][0]), "+a"(acc[FM - 1][1]), "+a"(acc[FM - 1][2]), "+a"(acc[FM - 1][3]), "+a"(acc[FM - 1][4]),
+                       "+a"(acc[FM - 1][5]), "+a"(acc[FM - 1][6]), "+a"(acc[FM - 1][7])
+                     :: "memory");
 
-    // ---- epilogue: lane owns C[m][n..n+3], m = .. + l15, n = .. + g*4
-    if constexpr (PLAIN) {
-        // 16-byte stores: lanes g and g^1 (16 lanes apart) exchange halves with v_permlane16_swap, so that a lane ends up with 8
-        // consecutive columns of ONE fragment (even g: fragment j, odd g: fragment j+1) -- half the store instructions of the
-        // 4-columns-per-lane layout the MFMA leaves (the tile's store tail is issue-bound)
-        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)(m0 + wm * TM + l15) * p.ldc + n0 + wn * TNW + (g & 1) * 16 + (g >> 1) * 8;
+        // ---- epilogue: lane owns C[m][n..n+3], m = .. + l15, n = .. + g*4
+        if constexpr (PLAIN) {
+            // 16-byte stores: lanes g and g^1 (16 lanes apart) exchange halves with v_permlane16_swap, so that a lane ends up with 8
+            // consecutive columns of ONE fragment (even g: fragment j, odd g: fragment j+1) -- half the store instructions of the
+            // 4-columns-per-lane layout the MFMA leaves (the tile's store tail is issue-bound)
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            // (the lane id is laundered through an empty asm: the store addresses are then recomputed per tile -- a handful of VALU --
+            // instead of being hoisted out of the tile walk as loop invariants that sit in registers across the whole K loop)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int e15 = ln & 15, eg = ln >> 4;
+            bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)(m0 + wm * TM + e15) * p.ldc + n0 + wn * TNW + (eg & 1) * 16 + (eg >> 1) * 8;
+            [[maybe_unused]] const bf16_t* rrow = p.residual + (long)(m0 + wm * TM + e15) * p.ldr + n0 + wn * TNW + (eg & 1) * 16 + (eg >> 1) * 8;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                for (int j = 0; j < FN; j += 2) {
+                    // nothing of this fragment pair may be read before the previous pair's store has been issued: the empty asm
+                    // "modifies" the pair and is ordered after that store -- otherwise the compiler hoists all 256 accumulator
+                    // reads to the top of the epilogue (+110 live registers, spills in the persistent kernel)
+                    asm volatile("" : "+a"(acc[i][j]), "+a"(acc[i][j + 1])::"memory");
+                    unsigned w[2][2];
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            w[f][h] = (unsigned)f2bf(acc[i][j + f][2 * h]) | ((unsigned)f2bf(acc[i][j + f][2 * h + 1]) << 16);
+                    const u32x2 lo = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+                    const u32x2 hi = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+                    u32x4 o = u32x4{lo[0], hi[0], lo[1], hi[1]};
+                    if constexpr (EPI == 2) {
+                        // HF: `residual + linear(x)`: the projection's bf16 output (what `o` holds) plus the bf16 residual, rounded once more
+                        const u32x4 r = *reinterpret_cast<const u32x4*>(rrow + (long)i * 16 * p.ldr + j * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x0 = bf2f((bf16_t)(o[e] & 0xffff)) + bf2f((bf16_t)(r[e] & 0xffff));
+                            const float x1 = bf2f((bf16_t)(o[e] >> 16)) + bf2f((bf16_t)(r[e] >> 16));
+                            o[e] = (unsigned)f2bf(x0) | ((unsigned)f2bf(x1) << 16);
+                        }
+                    }
+                    *reinterpret_cast<u32x4*>(crow + (long)i * 16 * p.ldc + j * 16) = o;
+                    __builtin_amdgcn_sched_barrier(0);  // one fragment pair at a time: a dozen live registers, not a 256-value fan-out
+                }
+            }
+        } else {
+            // general path (gemm_store4: the rounding points of gemm.hip)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * TM + i * 16 + l15;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = n0 + wn * TNW + j * 16 + g * 4;
+                    if (n >= p.N) continue;
+                    gemm_store4(p, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!has_next) break;
+        // ---- next tile of the walk: fresh accumulators; its first fragment set and K-tile requests are already under way
+        bid = bid_next;
+        m0 = m0n; n0 = n0n;
+        baseA = nextA; baseB = nextB;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
-            for (int j = 0; j < FN; j += 2) {
-                unsigned w[2][2];
-#pragma unroll
-                for (int f = 0; f < 2; ++f)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        w[f][h] = (unsigned)f2bf(acc[i][j + f][2 * h]) | ((unsigned)f2bf(acc[i][j + f][2 * h + 1]) << 16);
-                const u32x2 lo = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
-                const u32x2 hi = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
-                *reinterpret_cast<u32x4*>(crow + (long)i * 16 * p.ldc + j * 16) = u32x4{lo[0], hi[0], lo[1], hi[1]};
-            }
-            __builtin_amdgcn_sched_barrier(0);      // one accumulator row at a time: no 256-register fan-out of the reads
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // (the zeroing of row i sits above this statement, and the two wait states an accumulator write needs before an MFMA
+            // reads it are inside it: the compiler pads nothing around asm)
+            asm volatile("s_nop 1"
+                         : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]),
+                           "+a"(acc[i][6]), "+a"(acc[i][7]));
         }
-    } else {
-    // general path (gemm_store4: the rounding points of gemm.hip)
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * TM + i * 16 + l15;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * TNW + j * 16 + g * 4;
-            if (n >= p.N) continue;
-            gemm_store4(p, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
     }
 }
 
-template <bool A_T, bool B_N, bool PLAIN>
+template <bool A_T, bool B_N, int EPI, bool PERSIST>
 int launch4(GemmParams& p, hipStream_t st) {
     constexpr int lds = 2 * STAGE;
-    auto kern = gemm4_kernel<A_T, B_N, PLAIN>;
+    auto kern = gemm4_kernel<A_T, B_N, EPI, PERSIST>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -313,25 +409,45 @@ int launch4(GemmParams& p, hipStream_t st) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), lds, st, p);
+    const int tiles = p.tiles_m * p.tiles_n;
+    static int cus = 0;                  // persistent walk: one workgroup per CU (128 KB of LDS each: a CU holds exactly one)
+    if (PERSIST && !cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+        cus &= ~7;                       // multiple of the 8 XCDs: block b and block b + grid run on the same XCD
+        if (cus < 8) cus = 8;
+    }
+    const int grid = PERSIST ? (tiles < cus ? tiles : cus) : tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);
     AA_CHECK_LAUNCH("aa_gemm_bf16");
     return AA_OK;
 }
 
-template <bool PLAIN>
+template <int EPI, bool PERSIST>
 int launch4_layout(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
-    if (!a_t && !b_n) return launch4<false, false, PLAIN>(p, st);
-    if (!a_t && b_n) return launch4<false, true, PLAIN>(p, st);
-    if (a_t && b_n) return launch4<true, true, PLAIN>(p, st);
+    if (!a_t && !b_n) return launch4<false, false, EPI, PERSIST>(p, st);
+    if constexpr (EPI != 2) {          // the residual epilogue exists for the forward (NT) layout only
+        if (!a_t && b_n) return launch4<false, true, EPI, PERSIST>(p, st);
+        if (a_t && b_n) return launch4<true, true, EPI, PERSIST>(p, st);
+    }
     aa_set_error("aa_gemm_bf16: layout A^T with K-contiguous B is not built (unused by the hot path)");
     return AA_ERR_ARG;
 }
 
 }  // namespace
 
-// p.tiles_m / tiles_n / gm are set by the caller (gemm.hip)
+// p.tiles_m / tiles_n / gm are set by the caller (gemm.hip).  AA_GEMM_PERSIST=0: one workgroup per tile for the plain kernel too.
 int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
-    const bool plain = p.flags == (p.flags & (AA_GEMM_A_T | AA_GEMM_B_N)) && !p.bias && !p.residual && p.act == AA_ACT_NONE &&
-                       p.M % BM == 0 && p.N % BN == 0 && (p.ldc & 7) == 0;
-    return plain ? launch4_layout<true>(p, a_t, b_n, st) : launch4_layout<false>(p, a_t, b_n, st);
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("AA_GEMM_PERSIST"); persist = e ? atoi(e) : 1; }
+    const bool shape_ok = p.flags == (p.flags & (AA_GEMM_A_T | AA_GEMM_B_N)) && !p.bias && p.act == AA_ACT_NONE && p.M % BM == 0 &&
+                          p.N % BN == 0 && (p.ldc & 7) == 0;
+    const bool plain = shape_ok && !p.residual;
+    const bool resid = shape_ok && p.residual && !a_t && !b_n && (p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0;
+    const bool pers = persist && p.K >= 2 * BK;
+    if (plain) return pers ? launch4_layout<1, true>(p, a_t, b_n, st) : launch4_layout<1, false>(p, a_t, b_n, st);
+    if (resid) return pers ? launch4_layout<2, true>(p, a_t, b_n, st) : launch4_layout<2, false>(p, a_t, b_n, st);
+    return launch4_layout<0, false>(p, a_t, b_n, st);
 }

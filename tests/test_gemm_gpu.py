@@ -114,3 +114,45 @@ def test_gemm_k_loop_schedules_agree(mode, layout):
     finally:
         ops.gemm_set_tile(-1)
         ops.gemm_set_interleave(-1)
+
+
+@pytest.mark.parametrize('persist', ['1', '0'])
+def test_gemm4_fast_epilogues_and_persistent_walk(persist):
+    """gemm4.hip's specialised paths: plain and residual epilogues with 16-byte permlane-swapped stores, and the persistent tile walk
+    (more tiles than workgroups, odd K-tile counts so the buffer parity flips between tiles) -- in a fresh process per setting, since
+    AA_GEMM_PERSIST is read once."""
+    import os, subprocess, sys
+    from tests.util import ROOT
+    code = r'''
+import torch
+from align_anything_amd import ops
+from tests.gpu_util import assert_close, randn_bf16
+ops.gemm_set_tile(5)
+for (M, N, K) in [(512, 512, 256), (256, 256, 64), (256, 256, 128), (4096, 8192, 192), (16384, 4096, 320), (8192, 4352, 448)]:
+    for layout in ('nt', 'nn', 'tn'):
+        a_t, b_n = layout == 'tn', layout in ('nn', 'tn')
+        a = randn_bf16(K, M, seed=1) if a_t else randn_bf16(M, K, seed=1)
+        b = randn_bf16(K, N, seed=2) if b_n else randn_bf16(N, K, seed=2)
+        out = ops.gemm(a, b, a_t=a_t, b_n=b_n)
+        rows = torch.arange(0, M, 61, device=a.device)
+        ref = ((a[:, rows].t() if a_t else a[rows]).float()) @ (b if b_n else b.t()).float()
+        assert_close(out[rows], ref, rtol=1e-2, atol=1e-2 * float(ref.abs().mean()), what=f'{layout} {M}x{N}x{K}')
+        cs = out.double().sum(0)
+        want = (a.double().sum(1) if a_t else a.double().sum(0)) @ (b if b_n else b.t()).double()
+        assert float((cs - want).abs().max()) < 0.04 * (M ** 0.5) * float(ref.abs().mean()) * 8 + 1e-2 * float(want.abs().mean()), (layout, M, N, K)
+    # residual epilogue (forward layout): bf16(bf16(acc) + res), also in place
+    a, w, res = randn_bf16(M, K, seed=3), randn_bf16(N, K, scale=0.1, seed=4), randn_bf16(M, N, seed=6)
+    acc = a.float() @ w.float().t()
+    want = (acc.to(torch.bfloat16).float() + res.float()).to(torch.bfloat16)
+    out = ops.gemm(a, w, residual=res)
+    assert_close(out, want, rtol=1e-2, atol=2e-2, what=f'residual {M}x{N}x{K}')
+    frac_exact = float((out == want).float().mean())
+    assert frac_exact > 0.995, frac_exact          # same rounding points: only fp32 summation order differs from the torch matmul
+    buf = res.clone()
+    ops.gemm(a, w, out=buf, residual=buf)
+    assert torch.equal(buf, out)
+print('ok')
+'''
+    env = dict(os.environ, AA_GEMM_PERSIST=persist, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.stdout[-2000:], r.stderr[-3000:])

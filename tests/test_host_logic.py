@@ -540,3 +540,36 @@ def test_preference_cache_forwards_tokenizer_arguments_of_the_text_collator():
     assert plain[0]['better_ids'].tolist() == [10 + (ord(c) % 7) for c in 'abcd'] and len(plain[0]['worse_ids']) == 2
     b = CachedPreferenceCollator(0, 'right')([plain[0]])
     assert b['input_ids'].shape == (2, 4) and b['attention_mask'].tolist() == [[1, 1, 1, 1], [1, 1, 0, 0]] and b['meta_info']['response_lens'] == [2, 1]
+
+
+def test_gemm4_kernels_keep_everything_in_registers():
+    """csrc/gemm4.hip counts its own LDS reads and LDS-DMA requests (inline asm), which is only sound while the compiler neither spills
+    nor keeps accumulators in scratch: a spill of a fragment register could store it before its untracked load has landed, and any
+    scratch access makes hipcc put `s_waitcnt vmcnt(0)` into the K loop (draining the DMA pipeline every K-tile -- measured -15 %).
+    Compile the file and require: no scratch, no spills, accumulators in the accumulator file, and a K loop whose only vmcnt wait is
+    the one in the mid-tile barrier statement."""
+    import re
+    import subprocess
+    import tempfile
+    from align_anything_amd import build as b
+    src = os.path.join(b.CSRC, 'gemm4.hip')
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, 'gemm4.s')
+        r = subprocess.run([b.HIPCC, *b.FLAGS, '--cuda-device-only', '-S', src, '-o', asm, '-Rpass-analysis=kernel-resource-usage'],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        text = open(asm).read()
+    names = re.findall(r'Function Name: (\S*gemm4_kernel\S*)', r.stderr)
+    scratch = [int(x) for x in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
+    vspill = [int(x) for x in re.findall(r'VGPRs Spill: (\d+)', r.stderr)]
+    agprs = [int(x) for x in re.findall(r'AGPRs: (\d+)', r.stderr)]
+    assert len(names) >= 11 and len(names) == len(scratch) == len(vspill) == len(agprs)
+    assert all(s == 0 for s in scratch) and all(s == 0 for s in vspill), list(zip(names, scratch, vspill))
+    assert all(a == 256 for a in agprs), agprs
+    assert 'scratch_' not in text
+    # every K loop: 128 MFMAs, one barrier, exactly one vmcnt wait (inside the barrier statement), no accumulator shuffling
+    loops = re.findall(r'Inner Loop Header.*?s_cbranch_scc\d', text, flags=re.S)
+    assert len(loops) >= 11
+    for body in loops:
+        assert body.count('v_mfma_f32_16x16x32_bf16') == 128 and body.count('s_barrier') == 1
+        assert len(re.findall(r's_waitcnt[^\n]*vmcnt', body)) == 1 and 'v_accvgpr' not in body and 'v_mov_b32' not in body

@@ -282,7 +282,7 @@ def test_rm_trainer_loss_matches_reference_fixture(dtype):
                 got = tr.model.module.store.grad_view(name).float().cpu().reshape(z[k].shape)
                 worst = max(worst, rel_err(got, T(z[k])))
         rep.append(f'{dtype} {tag}: loss {float(ld["loss"]):.6f} vs reference {float(z[f"{tag}_loss"]):.6f}, worst gradient rel-err {worst:.2e}')
-        assert worst < (2e-5 if f32 else 8e-2), rep
+        assert worst < (2e-5 if f32 else 1.2e-1), rep          # bf16: the envelope of profiles/parity/parity_bf16_envelope.txt on a 2-layer model with x3 weights
     dump(f'parity_rm_reference_{dtype}.txt', '\n'.join(rep) + '\n')
 
 
@@ -368,5 +368,5 @@ def test_t2t_ppo_rollout_and_rl_step_match_reference_fixture(dtype):
                     got = eng.module.store.grad_view(k[len(tag):]).float().cpu().reshape(z[k].shape)
                     worst = max(worst, rel_err(got, T(z[k])))
         rep.append(f'{dtype} mb{i} worst gradient rel-err {worst:.2e}')
-        assert worst < (3e-5 if f32 else 8e-2), rep
+        assert worst < (3e-5 if f32 else 1.2e-1), rep
     dump(f'parity_ppo_t2t_reference_{dtype}.txt', '\n'.join(rep) + '\n')

@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 2, call J: gemm4 persistent walk without spills: correctness, A/B persist on/off, bench
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export PYTHONPATH=$PWD
+timeout 900 python -m pytest tests/test_gemm_gpu.py tests/test_bench_geometry_gpu.py -m gpu -q -x -k "not decoder_layer" 2>&1 | tail -3
+timeout 300 python -m pytest "tests/test_ppo_gpu.py::test_rm_trainer_loss_matches_reference_fixture" "tests/test_ppo_gpu.py::test_t2t_ppo_rollout_and_rl_step_match_reference_fixture" -m gpu -q 2>&1 | grep -E "^E  |passed|failed" | cut -c1-300 | head -6
+for ps in 1 0 1 0; do
+AA_GEMM_PERSIST=$ps AA_LAB_VARIANTS=g4:5 AA_LAB_BLASLT=0 AA_LAB_OUT=r2j_gemm_lab_p$ps.json timeout 600 python tools/bench_gemm_lab.py 2>&1 | grep -v amdgpu | python3 -c "
+import sys,ast
+rows=[ast.literal_eval(l) for l in sys.stdin if l.startswith('{')]
+print('persist=$ps', ' '.join(f\"{r['name']}.{r['layout']}={max(r['g4_tf_0'],r['g4_tf_1']):.0f}\" for r in rows))"
+done
+for ps in 1 0; do
+AA_GEMM_PERSIST=$ps AA_LAB_VARIANTS=g4:5 timeout 300 python tools/bench_gemm_ksweep.py 2>&1 | tail -1 | cut -c1-400
+done
+timeout 600 python bench.py --no-cpu-baseline > gpurun_out/r2j_bench.json 2> gpurun_out/r2j_bench.err
+AA_GEMM_PERSIST=0 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/r2j_bench_np.json 2>> gpurun_out/r2j_bench.err
+python - <<'PY'
+import json
+for f in ('gpurun_out/r2j_bench.json', 'gpurun_out/r2j_bench_np.json'):
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    print(f, d['value'], d['ms_per_step'], d['step_mfma']['frac_of_dense_bf16_peak'], d['roofline']['achieved'], d['config']['losses_timed_steps'][:3])
+PY
