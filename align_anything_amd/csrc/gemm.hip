@@ -601,6 +601,84 @@ extern "C" int aa_gemm_grouped_bf16(const void* A, const void* B, void* C, int M
     return launch_grouped<true, true, 2>(p, E, st);
 }
 
+// ---- GEMMs with the element-wise neighbour of the HF graph folded into the epilogue (gemm4.hip); each entry point runs the fused
+// kernel when the shape qualifies and the unfused pair of kernels otherwise, with identical rounding points (bit-identical results)
+extern "C" int aa_rope_inplace(void* buf, long ld, int col0, int nheads, int hd, const int* pos, const void* cos_t, const void* sin_t,
+                               long rows, int inverse, int head_stride, int precise, void* stream);
+extern "C" int aa_swiglu_fwd(const void* gate_up, void* out, long M, int F, void* stream);
+extern "C" int aa_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, long M, int F, void* stream);
+
+static int g_fuse = -1;      // AA_GEMM_FUSE=0: always the unfused kernels (A/B runs, parity tests)
+static bool fuse_enabled() {
+    if (g_fuse < 0) { const char* e = getenv("AA_GEMM_FUSE"); g_fuse = e ? atoi(e) : 1; }
+    return g_fuse != 0 && g_force_tile != 0;
+}
+extern "C" int aa_gemm_set_fuse(int on) { g_fuse = on ? 1 : 0; return AA_OK; }
+
+// hf:models/llama/modeling_llama.py:228-246 q/k/v projections + apply_rotary_pos_emb (:130-160): C[M, N] = A W^T with the rotary
+// embedding applied to the heads in columns [0, rope_cols) (q and k of the fused [q|k|v] weight); pos[M], cos / sin [max_pos, hd/2] bf16
+extern "C" int aa_gemm_qkv_rope_bf16(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
+                                     const int* pos, const void* cos_t, const void* sin_t, int rope_cols, int hd, void* stream) {
+    AA_REQUIRE(hd > 0 && rope_cols % hd == 0 && rope_cols <= N, "aa_gemm_qkv_rope_bf16: rope_cols %d must be whole heads of %d within N=%d", rope_cols, hd, N);
+    if (fuse_enabled() && hd == 128) {
+        GemmParams p{};
+        p.A = (const bf16_t*)A; p.B = (const bf16_t*)W; p.C = C;
+        p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc;
+        p.gm = pick_group(false, false, aa_cdiv(N, 256), K);
+        p.fuse = AA_FUSE_ROPE; p.rope_pos = pos; p.rope_cos = (const bf16_t*)cos_t; p.rope_sin = (const bf16_t*)sin_t; p.rope_cols = rope_cols;
+        if ((lda & 7) == 0 && (ldw & 7) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0) {
+            const int rc = aa_gemm4_fused(p, (hipStream_t)stream);
+            if (rc != 1) return rc;
+        }
+    }
+    const int rc = aa_gemm_bf16(A, W, C, M, N, K, lda, ldw, ldc, nullptr, nullptr, 0, AA_ACT_NONE, 0, stream);
+    if (rc != AA_OK || rope_cols == 0) return rc;
+    return aa_rope_inplace(C, ldc, 0, rope_cols / hd, hd, pos, cos_t, sin_t, M, 0, 0, 0, stream);
+}
+
+// hf:models/llama/modeling_llama.py:163-176 LlamaMLP: GU[M, 2F] = A [Wg; Wu]^T (saved for the backward) and ACT[M, F] = silu(gate) * up
+extern "C" int aa_gemm_glu_fwd_bf16(const void* A, const void* Wgu, void* GU, void* ACT, int M, int F, int K, long lda, long ldw,
+                                    long ldgu, long ldact, void* stream) {
+    AA_REQUIRE(F > 0 && (F & 7) == 0, "aa_gemm_glu_fwd_bf16: ffn %d must be a multiple of 8", F);
+    if (fuse_enabled()) {
+        GemmParams p{};
+        p.A = (const bf16_t*)A; p.B = (const bf16_t*)Wgu; p.C = GU;
+        p.M = M; p.N = 2 * F; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldgu;
+        p.gm = pick_group(false, false, aa_cdiv(2 * F, 256), K);
+        p.fuse = AA_FUSE_GLU_FWD; p.aux = ACT; p.ldaux = ldact; p.glu_f = F;
+        if ((lda & 7) == 0 && (ldw & 7) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)Wgu & 15) == 0 && ((uintptr_t)GU & 15) == 0) {
+            const int rc = aa_gemm4_fused(p, (hipStream_t)stream);
+            if (rc != 1) return rc;
+        }
+    }
+    const int rc = aa_gemm_bf16(A, Wgu, GU, M, 2 * F, K, lda, ldw, ldgu, nullptr, nullptr, 0, AA_ACT_NONE, 0, stream);
+    if (rc != AA_OK) return rc;
+    AA_REQUIRE(ldgu == 2L * F && ldact == F, "aa_gemm_glu_fwd_bf16: the unfused path needs dense [M, 2F] / [M, F] buffers");
+    return aa_swiglu_fwd(GU, ACT, M, F, stream);
+}
+
+// backward of the same block: dGU[M, 2F] = swiglu'(GU) (.) (dY[M, h] W_down[h, F]); the fused kernel never stores d_act, the unfused
+// path needs `dact_ws` [M, F]
+extern "C" int aa_gemm_glu_bwd_bf16(const void* dY, const void* Wdown, const void* GU, void* dGU, void* dact_ws, int M, int F, int K,
+                                    long ldy, long ldw, long ldgu, long lddgu, void* stream) {
+    AA_REQUIRE(F > 0 && (F & 7) == 0, "aa_gemm_glu_bwd_bf16: ffn %d must be a multiple of 8", F);
+    if (fuse_enabled()) {
+        GemmParams p{};
+        p.A = (const bf16_t*)dY; p.B = (const bf16_t*)Wdown; p.C = nullptr;
+        p.M = M; p.N = F; p.K = K; p.lda = ldy; p.ldb = ldw; p.ldc = 8; p.flags = AA_GEMM_B_N;
+        p.gm = pick_group(false, true, aa_cdiv(F, 256), K);
+        p.fuse = AA_FUSE_GLU_BWD; p.aux = dGU; p.ldaux = lddgu; p.aux_in = (const bf16_t*)GU; p.ldaux_in = ldgu; p.glu_f = F;
+        if ((ldy & 7) == 0 && (ldw & 7) == 0 && ((uintptr_t)dY & 15) == 0 && ((uintptr_t)Wdown & 15) == 0) {
+            const int rc = aa_gemm4_fused(p, (hipStream_t)stream);
+            if (rc != 1) return rc;
+        }
+    }
+    AA_REQUIRE(dact_ws != nullptr && ldgu == 2L * F && lddgu == 2L * F, "aa_gemm_glu_bwd_bf16: the unfused path needs a d_act workspace and dense [M, 2F] buffers");
+    const int rc = aa_gemm_bf16(dY, Wdown, dact_ws, M, F, K, ldy, ldw, F, nullptr, nullptr, 0, AA_ACT_NONE, AA_GEMM_B_N, stream);
+    if (rc != AA_OK) return rc;
+    return aa_swiglu_bwd(GU, dact_ws, dGU, M, F, stream);
+}
+
 // test hook: force a tile config (-1 = heuristic)
 extern "C" int aa_gemm_set_tile(int tile) { g_force_tile = tile; return AA_OK; }
 // test/bench hook: 1 = software-pipelined K loop (default), 0 = simple one-barrier schedule

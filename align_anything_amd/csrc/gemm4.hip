@@ -51,12 +51,12 @@ __device__ __forceinline__ g4_srd_t g4_make_srd(const char* base) {
     return g4_srd_t{(int)(unsigned)a, (int)(unsigned)(a >> 32), 0x7fffffff, 0x00020000};     // stride 0, raw 32-bit format
 }
 template <int K, bool A_T, bool B_N>
-__device__ __forceinline__ void G4_DMA_PIECE_BUF(unsigned vA0, unsigned vA1, unsigned vB0, unsigned vB1, int pieceA, int pieceB,
-                                                 g4_srd_t srdA, g4_srd_t srdB) {
+__device__ __forceinline__ void G4_DMA_PIECE_BUF(unsigned vA0, unsigned vA1, unsigned vB0, unsigned vB1, const int (&soA)[A_IT],
+                                                 const int (&soB)[B_IT], g4_srd_t srdA, g4_srd_t srdB) {
     constexpr int j = K < A_IT ? K : K - A_IT;
     constexpr int adv = K == A_IT - 1 ? 65536 - (A_IT - 1) * NW * 1024 : NW * 1024;
     const unsigned v = K < A_IT ? ((A_T && (j & 1)) ? vA1 : vA0) : ((B_N && (j & 1)) ? vB1 : vB0);
-    const int so = j * (K < A_IT ? pieceA : pieceB);
+    const int so = K < A_IT ? soA[j] : soB[j];
     if constexpr (K < A_IT + B_IT - 1) {
         asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, %3" ::"v"(v), "s"(K < A_IT ? srdA : srdB), "s"(so), "i"(adv) : "memory");
     } else {
@@ -86,7 +86,11 @@ __device__ __forceinline__ void G4_DMA_PIECE(const unsigned (&offA)[A_IT], const
 template <bool A_T, bool B_N, int EPI, bool PERSIST>
 __global__ __launch_bounds__(NW * 64, 1)
 void gemm4_kernel(const GemmParams p) {
-    constexpr bool PLAIN = EPI != 0;       // EPI: 0 = general epilogue, 1 = plain bf16 store, 2 = plain + residual add (o / down projections)
+    // EPI: 0 = general epilogue; 1 = plain bf16 store; 2 = + residual add (o / down projections); 3 = rotary embedding on the q / k
+    // heads of a fused qkv projection (head_dim 128 = one wave's columns); 4 = SwiGLU forward (tile = 128 gate + the matching 128 up
+    // columns, writes [gate | up] and silu(gate) * up); 5 = SwiGLU backward on the down-projection's dX (writes d[gate | up] only)
+    constexpr bool PLAIN = EPI != 0;
+    constexpr bool GLU_FWD = EPI == 4;
     static_assert(PLAIN || !PERSIST, "the persistent walk relies on tile-independent DMA lane offsets (no edge clamping)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -121,7 +125,10 @@ void gemm4_kernel(const GemmParams p) {
     int m0, n0;
     map_tile(blockIdx.x, m0, n0);
     auto tile_base_a = [&](int m0_) { return reinterpret_cast<const char*>(A_T ? p.A + m0_ : p.A + (long)m0_ * p.lda); };
-    auto tile_base_b = [&](int n0_) { return reinterpret_cast<const char*>(B_N ? p.B + n0_ : p.B + (long)n0_ * p.ldb); };
+    auto tile_base_b = [&](int n0_) {
+        if constexpr (GLU_FWD) return reinterpret_cast<const char*>(p.B + (long)(n0_ >> 1) * p.ldb);
+        return reinterpret_cast<const char*>(B_N ? p.B + n0_ : p.B + (long)n0_ * p.ldb);
+    };
 
     // ---- DMA sources: uniform base (advanced per K-tile) + per-lane byte offset inside the tile's row / column block
     const char* baseA;
@@ -189,9 +196,25 @@ void gemm4_kernel(const GemmParams p) {
     const unsigned vB0 = offB[0], vB1 = B_N ? offB[1] - (unsigned)(NW * (1024 / (BN * 2)) * p.ldb * 2) : 0u;
     const int pieceA = (A_T ? NW * (1024 / (BM * 2)) : NW * 8) * (int)p.lda * 2;       // rows (k-rows) per piece step x row bytes
     const int pieceB = (B_N ? NW * (1024 / (BN * 2)) : NW * 8) * (int)p.ldb * 2;
+    // scalar byte offset of piece j relative to piece 0.  GLU_FWD: the B tile's 256 rows are, per N-wave, 64 gate rows followed by
+    // the 64 up rows of the same output columns (F rows further down the fused [gate; up] weight), so that one lane ends up with the
+    // gate and the up value of a column: piece j (tile rows 8 wave + 32 j ..) starts at a remapped weight row
+    int soA[A_IT], soB[B_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) soA[j] = j * pieceA;
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        if constexpr (GLU_FWD) {
+            const int r0 = 8 * wave + 32 * j, wq = r0 >> 7, q = r0 & 127;
+            const int row = q < 64 ? wq * 64 + q : p.glu_f + wq * 64 + (q - 64);
+            soB[j] = (row - 8 * wave) * (int)p.ldb * 2;
+        } else {
+            soB[j] = j * pieceB;
+        }
+    }
 #define G4_DMA(K)                                                                                                   \
     do {                                                                                                            \
-        if constexpr (PLAIN) G4_DMA_PIECE_BUF<K, A_T, B_N>(vA0, vA1, vB0, vB1, pieceA, pieceB, g4_make_srd(srcA), g4_make_srd(srcB)); \
+        if constexpr (PLAIN) G4_DMA_PIECE_BUF<K, A_T, B_N>(vA0, vA1, vB0, vB1, soA, soB, g4_make_srd(srcA), g4_make_srd(srcB)); \
         else G4_DMA_PIECE<K>(offA, offB, srcA, srcB);                                                               \
     } while (0)
 
@@ -330,37 +353,124 @@ void gemm4_kernel(const GemmParams p) {
             int ln = lane;
             asm volatile("" : "+v"(ln));
             const int e15 = ln & 15, eg = ln >> 4;
-            bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)(m0 + wm * TM + e15) * p.ldc + n0 + wn * TNW + (eg & 1) * 16 + (eg >> 1) * 8;
-            [[maybe_unused]] const bf16_t* rrow = p.residual + (long)(m0 + wm * TM + e15) * p.ldr + n0 + wn * TNW + (eg & 1) * 16 + (eg >> 1) * 8;
+            const long erow = m0 + wm * TM + e15;                           // + 16 i
+            const int ecol = (eg & 1) * 16 + (eg >> 1) * 8;                 // + 16 j: first of this lane's 8 columns inside the wave's 128
+            // packed bf16 of the fragment pair (j, j+1), redistributed so that this lane holds 8 consecutive columns of fragment j + (g & 1)
+            auto pack_pair = [&](int i, int j) -> u32x4 {
+                asm volatile("" : "+a"(acc[i][j]), "+a"(acc[i][j + 1])::"memory");
+                unsigned w[2][2];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
+                for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int j = 0; j < FN; j += 2) {
-                    // nothing of this fragment pair may be read before the previous pair's store has been issued: the empty asm
-                    // "modifies" the pair and is ordered after that store -- otherwise the compiler hoists all 256 accumulator
-                    // reads to the top of the epilogue (+110 live registers, spills in the persistent kernel)
-                    asm volatile("" : "+a"(acc[i][j]), "+a"(acc[i][j + 1])::"memory");
-                    unsigned w[2][2];
+                    for (int h = 0; h < 2; ++h)
+                        w[f][h] = (unsigned)f2bf(acc[i][j + f][2 * h]) | ((unsigned)f2bf(acc[i][j + f][2 * h + 1]) << 16);
+                const u32x2 lo = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+                const u32x2 hi = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+                return u32x4{lo[0], hi[0], lo[1], hi[1]};
+            };
+            auto lo16 = [](unsigned x) { return bf2f((bf16_t)(x & 0xffff)); };
+            auto hi16 = [](unsigned x) { return bf2f((bf16_t)(x >> 16)); };
+            auto pk = [](float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); };
+            if constexpr (EPI == 1 || EPI == 2) {
+                bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + erow * p.ldc + n0 + wn * TNW + ecol;
+                [[maybe_unused]] const bf16_t* rrow = p.residual + erow * p.ldr + n0 + wn * TNW + ecol;
 #pragma unroll
-                    for (int f = 0; f < 2; ++f)
+                for (int i = 0; i < FM; ++i) {
 #pragma unroll
-                        for (int h = 0; h < 2; ++h)
-                            w[f][h] = (unsigned)f2bf(acc[i][j + f][2 * h]) | ((unsigned)f2bf(acc[i][j + f][2 * h + 1]) << 16);
-                    const u32x2 lo = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
-                    const u32x2 hi = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
-                    u32x4 o = u32x4{lo[0], hi[0], lo[1], hi[1]};
-                    if constexpr (EPI == 2) {
-                        // HF: `residual + linear(x)`: the projection's bf16 output (what `o` holds) plus the bf16 residual, rounded once more
-                        const u32x4 r = *reinterpret_cast<const u32x4*>(rrow + (long)i * 16 * p.ldr + j * 16);
+                    for (int j = 0; j < FN; j += 2) {
+                        u32x4 o = pack_pair(i, j);
+                        if constexpr (EPI == 2) {
+                            // HF: `residual + linear(x)`: the projection's bf16 output (what `o` holds) plus the bf16 residual, rounded once more
+                            const u32x4 r = *reinterpret_cast<const u32x4*>(rrow + (long)i * 16 * p.ldr + j * 16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = pk(lo16(o[e]) + lo16(r[e]), hi16(o[e]) + hi16(r[e]));
+                        }
+                        *reinterpret_cast<u32x4*>(crow + (long)i * 16 * p.ldc + j * 16) = o;
+                        __builtin_amdgcn_sched_barrier(0);  // one fragment pair at a time: a dozen live registers, not a 256-value fan-out
+                    }
+                }
+            } else if constexpr (EPI == 3) {
+                // rotary embedding (hf:models/llama/modeling_llama.py:130-160 on the bf16 projection output, rounding points of
+                // aa_rope_inplace): the wave's 128 columns are one head; fragments j < 4 hold d < 64, fragment j + 4 holds d + 64
+                const int colw = n0 + wn * TNW;
+                const bool rot = colw < p.rope_cols;                        // q / k head (v heads are stored as they are)
+                bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + erow * p.ldc + colw + ecol;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const long tb = (long)p.rope_pos[erow + i * 16] * 64 + ecol;
+#pragma unroll
+                    for (int j = 0; j < FN / 2; j += 2) {
+                        u32x4 x1 = pack_pair(i, j), x2 = pack_pair(i, j + 4);
+                        if (rot) {
+                            const u32x4 c = *reinterpret_cast<const u32x4*>(p.rope_cos + tb + j * 16);
+                            const u32x4 sn = *reinterpret_cast<const u32x4*>(p.rope_sin + tb + j * 16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float a0 = lo16(x1[e]), a1 = hi16(x1[e]), b0 = lo16(x2[e]), b1 = hi16(x2[e]);
+                                const float c0 = lo16(c[e]), c1 = hi16(c[e]), s0 = lo16(sn[e]), s1 = hi16(sn[e]);
+                                x1[e] = pk(rbf(a0 * c0) + rbf(-b0 * s0), rbf(a1 * c1) + rbf(-b1 * s1));
+                                x2[e] = pk(rbf(b0 * c0) + rbf(a0 * s0), rbf(b1 * c1) + rbf(a1 * s1));
+                            }
+                        }
+                        *reinterpret_cast<u32x4*>(crow + (long)i * 16 * p.ldc + j * 16) = x1;
+                        *reinterpret_cast<u32x4*>(crow + (long)i * 16 * p.ldc + j * 16 + 64) = x2;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else if constexpr (EPI == 4) {
+                // SwiGLU forward (hf LlamaMLP: act_fn(gate_proj(x)) * up_proj(x), every factor bf16; rounding points of aa_swiglu_fwd):
+                // fragments j < 4 = gate columns, j + 4 = the up values of the same columns
+                const int gcol = (n0 >> 1) + wn * 64 + ecol;
+                bf16_t* gu = reinterpret_cast<bf16_t*>(p.C) + erow * p.ldc + gcol;
+                bf16_t* act = reinterpret_cast<bf16_t*>(p.aux) + erow * p.ldaux + gcol;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < FN / 2; j += 2) {
+                        const u32x4 gt = pack_pair(i, j), up = pack_pair(i, j + 4);
+                        u32x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float x0 = bf2f((bf16_t)(o[e] & 0xffff)) + bf2f((bf16_t)(r[e] & 0xffff));
-                            const float x1 = bf2f((bf16_t)(o[e] >> 16)) + bf2f((bf16_t)(r[e] >> 16));
-                            o[e] = (unsigned)f2bf(x0) | ((unsigned)f2bf(x1) << 16);
+                            const float g0 = lo16(gt[e]), g1 = hi16(gt[e]);
+                            o[e] = pk(rbf(g0 / (1.f + expf(-g0))) * lo16(up[e]), rbf(g1 / (1.f + expf(-g1))) * hi16(up[e]));
                         }
+                        *reinterpret_cast<u32x4*>(gu + (long)i * 16 * p.ldc + j * 16) = gt;
+                        *reinterpret_cast<u32x4*>(gu + (long)i * 16 * p.ldc + j * 16 + p.glu_f) = up;
+                        *reinterpret_cast<u32x4*>(act + (long)i * 16 * p.ldaux + j * 16) = o;
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    *reinterpret_cast<u32x4*>(crow + (long)i * 16 * p.ldc + j * 16) = o;
-                    __builtin_amdgcn_sched_barrier(0);  // one fragment pair at a time: a dozen live registers, not a 256-value fan-out
+                }
+            } else {
+                // SwiGLU backward (EPI 5): this tile of d_act = dY W_down (bf16-rounded like the stored tensor it replaces) with the saved
+                // [gate | up] -> d[gate | up] (aa_swiglu_bwd arithmetic); d_act itself is never written
+                const int col = n0 + wn * TNW + ecol;
+                const bf16_t* gu = p.aux_in + erow * p.ldaux_in + col;
+                bf16_t* dgu = reinterpret_cast<bf16_t*>(p.aux) + erow * p.ldaux + col;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < FN; j += 2) {
+                        const u32x4 d = pack_pair(i, j);
+                        const u32x4 gt = *reinterpret_cast<const u32x4*>(gu + (long)i * 16 * p.ldaux_in + j * 16);
+                        const u32x4 up = *reinterpret_cast<const u32x4*>(gu + (long)i * 16 * p.ldaux_in + j * 16 + p.glu_f);
+                        u32x4 og, ou;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float r[2][2];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const float gf = h ? hi16(gt[e]) : lo16(gt[e]), uf = h ? hi16(up[e]) : lo16(up[e]), df = h ? hi16(d[e]) : lo16(d[e]);
+                                const float sg = 1.f / (1.f + expf(-gf));
+                                r[0][h] = df * uf * sg * (1.f + gf * (1.f - sg));
+                                r[1][h] = df * gf * sg;
+                            }
+                            og[e] = pk(r[0][0], r[0][1]);
+                            ou[e] = pk(r[1][0], r[1][1]);
+                        }
+                        *reinterpret_cast<u32x4*>(dgu + (long)i * 16 * p.ldaux + j * 16) = og;
+                        *reinterpret_cast<u32x4*>(dgu + (long)i * 16 * p.ldaux + j * 16 + p.glu_f) = ou;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         } else {
@@ -427,27 +537,59 @@ int launch4(GemmParams& p, hipStream_t st) {
 
 template <int EPI, bool PERSIST>
 int launch4_layout(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
-    if (!a_t && !b_n) return launch4<false, false, EPI, PERSIST>(p, st);
-    if constexpr (EPI != 2) {          // the residual epilogue exists for the forward (NT) layout only
-        if (!a_t && b_n) return launch4<false, true, EPI, PERSIST>(p, st);
-        if (a_t && b_n) return launch4<true, true, EPI, PERSIST>(p, st);
+    if constexpr (EPI == 5) {          // SwiGLU backward rides on the dX (NN) GEMM of the down projection
+        return launch4<false, true, EPI, PERSIST>(p, st);
+    } else {
+        if (!a_t && !b_n) return launch4<false, false, EPI, PERSIST>(p, st);
+        if constexpr (EPI <= 1) {      // the residual / rotary / SwiGLU-forward epilogues exist for the forward (NT) layout only
+            if (!a_t && b_n) return launch4<false, true, EPI, PERSIST>(p, st);
+            if (a_t && b_n) return launch4<true, true, EPI, PERSIST>(p, st);
+        }
+        aa_set_error("aa_gemm_bf16: layout not built for this epilogue (A^T with K-contiguous B is unused by the hot path)");
+        return AA_ERR_ARG;
     }
-    aa_set_error("aa_gemm_bf16: layout A^T with K-contiguous B is not built (unused by the hot path)");
-    return AA_ERR_ARG;
+}
+
+int g4_persist() {
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("AA_GEMM_PERSIST"); persist = e ? atoi(e) : 1; }
+    return persist;
 }
 
 }  // namespace
 
-// p.tiles_m / tiles_n / gm are set by the caller (gemm.hip).  AA_GEMM_PERSIST=0: one workgroup per tile for the plain kernel too.
+// p.tiles_m / tiles_n / gm are set by the caller (gemm.hip).  AA_GEMM_PERSIST=0: one workgroup per tile for the plain kernels too.
 int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
-    static int persist = -1;
-    if (persist < 0) { const char* e = getenv("AA_GEMM_PERSIST"); persist = e ? atoi(e) : 1; }
     const bool shape_ok = p.flags == (p.flags & (AA_GEMM_A_T | AA_GEMM_B_N)) && !p.bias && p.act == AA_ACT_NONE && p.M % BM == 0 &&
                           p.N % BN == 0 && (p.ldc & 7) == 0;
     const bool plain = shape_ok && !p.residual;
     const bool resid = shape_ok && p.residual && !a_t && !b_n && (p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0;
-    const bool pers = persist && p.K >= 2 * BK;
+    const bool pers = g4_persist() && p.K >= 2 * BK;
     if (plain) return pers ? launch4_layout<1, true>(p, a_t, b_n, st) : launch4_layout<1, false>(p, a_t, b_n, st);
     if (resid) return pers ? launch4_layout<2, true>(p, a_t, b_n, st) : launch4_layout<2, false>(p, a_t, b_n, st);
     return launch4_layout<0, false>(p, a_t, b_n, st);
+}
+
+// Fused epilogues (p.fuse = AA_FUSE_*).  Returns 1 when the shape does not qualify (the caller then runs the unfused pair of kernels):
+// M, N multiples of the 256 tile, 16-byte aligned rows everywhere, and per mode: ROPE head_dim 128 with rope_cols a multiple of 128;
+// GLU_FWD F a multiple of 128 (N = 2F); GLU_BWD N = F.
+int aa_gemm4_fused(GemmParams& p, hipStream_t st) {
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if (p.M % BM || p.N % BN || p.K % BK || p.K < BK || (p.ldc & 7) || p.bias || p.residual || p.act != AA_ACT_NONE) return 1;
+    p.tiles_m = p.M / BM;
+    p.tiles_n = p.N / BN;
+    const bool pers = g4_persist() && p.K >= 2 * BK;
+    if (p.fuse == AA_FUSE_ROPE) {
+        if (!p.rope_pos || !al16(p.rope_cos) || !al16(p.rope_sin) || p.rope_cols % 128 || p.rope_cols < 0 || p.rope_cols > p.N) return 1;
+        return pers ? launch4_layout<3, true>(p, false, false, st) : launch4_layout<3, false>(p, false, false, st);
+    }
+    if (p.fuse == AA_FUSE_GLU_FWD) {
+        if (p.glu_f % 128 || p.N != 2 * p.glu_f || !p.aux || !al16(p.aux) || (p.ldaux & 7) || (p.glu_f & 7)) return 1;
+        return pers ? launch4_layout<4, true>(p, false, false, st) : launch4_layout<4, false>(p, false, false, st);
+    }
+    if (p.fuse == AA_FUSE_GLU_BWD) {
+        if (p.N != p.glu_f || !p.aux || !p.aux_in || !al16(p.aux) || !al16(p.aux_in) || (p.ldaux & 7) || (p.ldaux_in & 7) || (p.glu_f & 7)) return 1;
+        return pers ? launch4_layout<5, true>(p, false, true, st) : launch4_layout<5, false>(p, false, true, st);
+    }
+    return 1;
 }

@@ -40,7 +40,21 @@ struct GemmParams {
     const int* grp_tile_expert;  // mode 1: expert of every BM-row tile of the expert-major A / C (-1 = unused tile)
     const int* grp_off;          // mode 2: row offsets [E + 1] of the expert segments (the contraction range of expert e)
     long grp_strideB, grp_strideC;  // elements between consecutive experts' B (mode 1) / C (mode 2) matrices
+    // fused epilogues of the one-wave-per-SIMD kernel (gemm4.hip), selected by `fuse`; 0 / null for ordinary GEMMs
+    int fuse;                    // AA_FUSE_*
+    const int* rope_pos;         // ROPE: position of every row of C
+    const bf16_t* rope_cos;      //       [max_pos, 64] tables (head_dim 128)
+    const bf16_t* rope_sin;
+    int rope_cols;               //       columns [0, rope_cols) hold rotary heads (q and k of a fused [q|k|v] projection)
+    void* aux;                   // GLU_FWD: act [M, F] output;  GLU_BWD: d[gate|up] [M, 2F] output (C is not written)
+    const bf16_t* aux_in;        // GLU_BWD: the saved [gate|up] [M, 2F]
+    long ldaux, ldaux_in;
+    int glu_f;                   // GLU_*: F (C / B of GLU_FWD have 2F columns / rows: gate block then up block)
 };
+#define AA_FUSE_NONE 0
+#define AA_FUSE_ROPE 1       // C = rope(A W^T) on the q / k heads of a fused qkv projection (hf apply_rotary_pos_emb, bf16 rounding points)
+#define AA_FUSE_GLU_FWD 2    // C = [gate | up] = A [Wg; Wu]^T and aux = silu(gate) * up (LlamaMLP), one tile owning both halves of its columns
+#define AA_FUSE_GLU_BWD 3    // aux = d[gate | up] from d_act = A W (never stored) and the saved [gate | up]
 
 constexpr int BK = 64;
 
@@ -86,5 +100,7 @@ __device__ __forceinline__ void gemm_store4(const GemmParams& p, int m, int n, f
 int aa_gemm_ring_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
 // one-wave-per-SIMD 256x256 kernel, accumulators in the accumulator file (gemm4.hip)
 int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
+// fused-epilogue launches of the same kernel (p.fuse); 1 = shape does not qualify, run the unfused kernels
+int aa_gemm4_fused(GemmParams& p, hipStream_t st);
 // 32x32x16-MFMA 256x256 kernel (gemm32.hip)
 int aa_gemm32_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);

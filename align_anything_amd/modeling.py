@@ -119,16 +119,24 @@ class LlamaStack:
         qw, kw = H * hd, Hkv * hd
         for li, L in enumerate(self.layers):
             n1, rstd1 = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
-            qkv = L['qkv'].fwd(n1)
-            ops.rope_(qkv, 0, H + Hkv, hd, pos, tables[0], tables[1])
+            if x.dtype == bf16 and L['qkv'].b is None:
+                # projection + rotary embedding in one launch (epilogue of the GEMM; falls back to the two kernels inside the library
+                # when the shape does not qualify -- bit-identical either way)
+                qkv = ops.gemm_qkv_rope(n1, L['qkv'].w, pos, tables[0], tables[1], H + Hkv, hd)
+            else:
+                qkv = L['qkv'].fwd(n1)
+                ops.rope_(qkv, 0, H + Hkv, hd, pos, tables[0], tables[1])
             if kv_sink is not None:
                 kv_sink(li, qkv[:N * T, qw:])  # post-RoPE keys | values of this layer -> KV cache (prefill)
             attn, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
                                      hd ** -0.5, start, out=self._attn_out(x, N * T, H * hd))
             x_mid = L['o'].fwd(attn, residual=x)
             n2, rstd2 = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
-            gu = L['gu'].fwd(n2)
-            act = ops.swiglu_fwd(gu)
+            if x.dtype == bf16:
+                gu, act = ops.gemm_glu_fwd(n2, L['gu'].w, c['intermediate_size'])     # [gate|up] and silu(gate)*up from one GEMM launch
+            else:
+                gu = L['gu'].fwd(n2)
+                act = ops.swiglu_fwd(gu)
             x_out = L['down'].fwd(act, residual=x_mid)
             if save:
                 self.saved.append((x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act))
@@ -204,10 +212,12 @@ class LlamaStack:
             x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act = sv
             sv = None
             # ---- MLP
-            d_act = L['down'].dx(dres)
+            if dres.dtype == bf16:
+                d_gu = ops.gemm_glu_bwd(dres, L['down'].w, gu, c['intermediate_size'])   # dX GEMM of the down projection with the SwiGLU backward as epilogue
+            else:
+                d_gu = ops.swiglu_bwd(gu, L['down'].dx(dres))
             if tr:
                 L['down'].dw(dres, act)
-            d_gu = ops.swiglu_bwd(gu, d_act)
             d_n2 = L['gu'].dx(d_gu)
             if tr:
                 L['gu'].dw(d_gu, n2)

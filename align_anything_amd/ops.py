@@ -99,6 +99,82 @@ def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=Fals
 # 4*T*T*hd per (row, head) of attention forward (halved when causal), 2.5x that for its backward
 FLOPS = {'gemm': 0.0, 'attn': 0.0}
 
+def gemm_qkv_rope(x, w, pos, cos_t, sin_t, rope_heads, hd, out=None):
+    """qkv = x @ w^T with the rotary embedding applied to the first `rope_heads` heads (q and k of the fused [q|k|v] weight): the
+    projection GEMM with HF's apply_rotary_pos_emb in its epilogue (aa_gemm_qkv_rope_bf16; unfused pair of kernels when the shape does
+    not qualify -- bit-identical either way)."""
+    _chk(x, bf16, 'gemm_qkv_rope.x'); _chk(w, bf16, 'gemm_qkv_rope.w')
+    _row_major(x, 'gemm_qkv_rope.x'); _row_major(w, 'gemm_qkv_rope.w')
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=bf16, device=x.device) if out is None else out
+    FLOPS['gemm'] += 2.0 * M * N * K
+    prof = _prof_begin()
+    call('aa_gemm_qkv_rope_bf16', x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, x.stride(0), w.stride(0), out.stride(0),
+         pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), int(rope_heads) * hd, hd, stream())
+    _prof_end(prof, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N))
+    return out
+
+
+def gemm_glu_fwd(x, w_gu, F):
+    """LlamaMLP front half in one launch: returns (gate_up [M, 2F], act [M, F] = silu(gate) * up)."""
+    _chk(x, bf16, 'gemm_glu_fwd.x'); _chk(w_gu, bf16, 'gemm_glu_fwd.w')
+    _row_major(x, 'gemm_glu_fwd.x'); _row_major(w_gu, 'gemm_glu_fwd.w')
+    M, K = x.shape
+    gu = torch.empty((M, 2 * F), dtype=bf16, device=x.device)
+    act = torch.empty((M, F), dtype=bf16, device=x.device)
+    FLOPS['gemm'] += 4.0 * M * F * K
+    prof = _prof_begin()
+    call('aa_gemm_glu_fwd_bf16', x.data_ptr(), w_gu.data_ptr(), gu.data_ptr(), act.data_ptr(), M, F, K, x.stride(0), w_gu.stride(0),
+         gu.stride(0), act.stride(0), stream())
+    _prof_end(prof, 4.0 * M * F * K, 2.0 * (M * K + 2 * F * K + 3 * M * F))
+    return gu, act
+
+
+def gemm_glu_bwd(dy, w_down, gu, F):
+    """d[gate|up] [M, 2F] of the block above from dy [M, h] (gradient of the down projection's output) and w_down [h, F]."""
+    _chk(dy, bf16, 'gemm_glu_bwd.dy'); _chk(w_down, bf16, 'gemm_glu_bwd.w'); _chk(gu, bf16, 'gemm_glu_bwd.gu')
+    _row_major(dy, 'gemm_glu_bwd.dy'); _row_major(w_down, 'gemm_glu_bwd.w'); _row_major(gu, 'gemm_glu_bwd.gu')
+    M, K = dy.shape
+    dgu = torch.empty_like(gu)
+    fused = fuse_enabled() and M % 256 == 0 and F % 256 == 0 and K % 64 == 0
+    ws = None if fused else torch.empty((M, F), dtype=bf16, device=dy.device)
+    FLOPS['gemm'] += 2.0 * M * F * K
+    prof = _prof_begin()
+    call('aa_gemm_glu_bwd_bf16', dy.data_ptr(), w_down.data_ptr(), gu.data_ptr(), dgu.data_ptr(), _p(ws), M, F, K, dy.stride(0),
+         w_down.stride(0), gu.stride(0), dgu.stride(0), stream())
+    _prof_end(prof, 2.0 * M * F * K, 2.0 * (M * K + F * K + 4 * M * F))
+    return dgu
+
+
+_FUSE = os.environ.get('AA_GEMM_FUSE', '1') != '0'
+
+
+def fuse_enabled() -> bool:
+    return _FUSE
+
+
+def gemm_set_fuse(on: bool) -> None:
+    global _FUSE
+    _FUSE = bool(on)
+    call('aa_gemm_set_fuse', int(bool(on)))
+
+
+def _prof_begin():
+    global _gemm_seq
+    prof = GEMM_PROF
+    if prof is not None:
+        _gemm_seq += 1
+        if _gemm_seq % GEMM_PROF_STRIDE:
+            prof = None
+    return (prof, event_record()) if prof is not None else None
+
+
+def _prof_end(tok, flops, nbytes):
+    if tok is not None:
+        tok[0].append((tok[1], event_record(), flops, nbytes))
+
+
 # HIP events on the launch stream (bench.py roofline: per-launch GEMM durations over the timed region)
 GEMM_PROF = None
 GEMM_PROF_STRIDE = 1

@@ -140,6 +140,22 @@ int aa_rope_inplace(void* buf, long ld, int col0, int nheads, int hd, const int*
  * ids pos3 [3, rows]; frequency f uses component 0 / 1 / 2 for f < sec0 / < sec0 + sec1 / else */
 int aa_mrope_tables(const int* pos3, long rows, const float* inv_freq, int half, int sec0, int sec1, void* cos_t,
                     void* sin_t, void* stream);
+/* GEMMs with the element-wise neighbour of the HF graph folded into the epilogue of the one-wave-per-SIMD kernel (csrc/gemm4.hip).
+ * Each runs fused when the shape qualifies (M and N multiples of 256, K of 64, 16-byte aligned rows; rotary: head_dim 128) and as the
+ * unfused pair of kernels otherwise -- same rounding points, bit-identical results (tests/test_gemm_gpu.py).
+ *  - aa_gemm_qkv_rope_bf16: hf:models/llama/modeling_llama.py:228-246 (q/k/v projections of the fused [q|k|v] weight) +
+ *    apply_rotary_pos_emb :130-160 on the heads in columns [0, rope_cols); pos[M] int32, cos_t / sin_t [max_pos, hd/2] bf16
+ *  - aa_gemm_glu_fwd_bf16: LlamaMLP :163-176: GU[M, 2F] = A [Wgate; Wup]^T (kept for the backward), ACT[M, F] = silu(gate) * up
+ *  - aa_gemm_glu_bwd_bf16: its backward: dGU[M, 2F] from d_act = dY[M, K] Wdown[K, F] (never stored when fused; the unfused path
+ *    needs the [M, F] workspace dact_ws) and the saved GU
+ *  - aa_gemm_set_fuse(0): always the unfused kernels (A/B and parity runs; env AA_GEMM_FUSE=0 does the same) */
+int aa_gemm_qkv_rope_bf16(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc, const int* pos,
+                          const void* cos_t, const void* sin_t, int rope_cols, int hd, void* stream);
+int aa_gemm_glu_fwd_bf16(const void* A, const void* Wgu, void* GU, void* ACT, int M, int F, int K, long lda, long ldw, long ldgu,
+                         long ldact, void* stream);
+int aa_gemm_glu_bwd_bf16(const void* dY, const void* Wdown, const void* GU, void* dGU, void* dact_ws, int M, int F, int K, long ldy,
+                         long ldw, long ldgu, long lddgu, void* stream);
+int aa_gemm_set_fuse(int on);
 /* hf:models/llama/modeling_llama.py:163-176 LlamaMLP gate: silu(gate)*up on [M, 2F] -> [M, F] */
 int aa_swiglu_fwd(const void* gate_up, void* out, long M, int F, void* stream);
 int aa_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, long M, int F, void* stream);

@@ -156,3 +156,57 @@ print('ok')
     env = dict(os.environ, AA_GEMM_PERSIST=persist, PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, '-c', code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_fused_epilogues_are_bit_identical_to_the_unfused_kernels():
+    """aa_gemm_qkv_rope_bf16 / aa_gemm_glu_fwd_bf16 / aa_gemm_glu_bwd_bf16: the GEMM with HF's rotary embedding / SwiGLU forward /
+    SwiGLU backward in its epilogue (gemm4.hip) against the same entry point with fusion switched off (GEMM kernel + aa_rope_inplace /
+    aa_swiglu_fwd / aa_swiglu_bwd): same rounding points, so EVERY bit must agree; shapes that do not qualify take the unfused path."""
+    from align_anything_amd import ops
+    from align_anything_amd.modeling import rope_tables
+    g = torch.Generator(device='cpu').manual_seed(5)
+    try:
+        for (M, K, H, Hkv) in [(512, 256, 4, 2), (256, 64, 2, 2), (1024, 448, 3, 1), (320, 128, 2, 1)]:       # last: M % 256 != 0 -> unfused inside
+            hd = 128
+            N = (H + 2 * Hkv) * hd
+            x, w = randn_bf16(M, K, seed=1), randn_bf16(N, K, scale=0.2, seed=2)
+            pos = torch.randint(0, 300, (M,), generator=g).to(torch.int32).to(dev())
+            cos_t, sin_t = rope_tables(320, hd, 10000.0, dev())
+            outs = []
+            for fuse in (True, False):
+                ops.gemm_set_fuse(fuse)
+                outs.append(ops.gemm_qkv_rope(x, w, pos, cos_t, sin_t, H + Hkv, hd))
+            assert torch.equal(outs[0], outs[1]), ('rope', M, K, H, Hkv, float((outs[0].float() - outs[1].float()).abs().max()))
+            # and against the definition: rotate_half form on the bf16 projection
+            ops.gemm_set_fuse(True)
+            y = (x.float() @ w.float().t()).to(torch.bfloat16)
+            qk = y[:, :(H + Hkv) * hd].float().view(M, H + Hkv, hd)
+            c = torch.cat([cos_t[pos.long()], cos_t[pos.long()]], -1).float()[:, None]
+            s_ = torch.cat([sin_t[pos.long()], sin_t[pos.long()]], -1).float()[:, None]
+            rot = torch.cat([-qk[..., hd // 2:], qk[..., :hd // 2]], -1)
+            ref = (qk * c).to(torch.bfloat16).float() + (rot * s_).to(torch.bfloat16).float()
+            assert_close(outs[0][:, :(H + Hkv) * hd].float().view(M, H + Hkv, hd), ref, rtol=1.6e-2, atol=2e-2, what='rope vs definition')
+            assert_close(outs[0][:, (H + Hkv) * hd:], y[:, (H + Hkv) * hd:], rtol=1e-2, atol=2e-2, what='v heads untouched')
+        for (M, K, F) in [(512, 256, 384), (256, 128, 128), (768, 320, 1408), (320, 128, 256)]:
+            x, w = randn_bf16(M, K, seed=3), randn_bf16(2 * F, K, scale=0.2, seed=4)
+            res = []
+            for fuse in (True, False):
+                ops.gemm_set_fuse(fuse)
+                res.append(ops.gemm_glu_fwd(x, w, F))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), ('glu fwd', M, K, F)
+            gu = (x.float() @ w.float().t()).to(torch.bfloat16)
+            assert_close(res[0][0], gu, rtol=1e-2, atol=2e-2, what='gate|up')
+            want = (torch.nn.functional.silu(gu[:, :F].float()).to(torch.bfloat16).float() * gu[:, F:].float())
+            assert_close(res[0][1], want, rtol=1.6e-2, atol=2e-2, what='silu(gate)*up')
+        for (M, K, F) in [(512, 256, 512), (256, 64, 256), (1024, 192, 768), (320, 128, 256), (512, 128, 384)]:
+            dy, wd = randn_bf16(M, K, seed=6), randn_bf16(K, F, scale=0.2, seed=7)
+            gu = randn_bf16(M, 2 * F, seed=8)
+            res = []
+            for fuse in (True, False):
+                ops.gemm_set_fuse(fuse)
+                res.append(ops.gemm_glu_bwd(dy, wd, gu, F))
+            assert torch.equal(res[0], res[1]), ('glu bwd', M, K, F, float((res[0].float() - res[1].float()).abs().max()))
+            dact = (dy.float() @ wd.float()).to(torch.bfloat16)
+            assert_close(res[0], ops.swiglu_bwd(gu, dact), rtol=1.6e-2, atol=2e-2, what='glu bwd vs unfused pieces')
+    finally:
+        ops.gemm_set_fuse(True)
