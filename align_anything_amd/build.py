@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libaa_hip.so')
-SOURCES = ['runtime.hip', 'rl_math.hip', 'pref_losses.hip', 'elementwise.hip', 'elementwise_f32.hip', 'optim.hip', 'gemm.hip', 'gemm4.hip', 'gemm32.hip', 'gemm_ring.hip', 'attention.hip', 'decode.hip',
+SOURCES = ['runtime.hip', 'comm.hip', 'rl_math.hip', 'pref_losses.hip', 'elementwise.hip', 'elementwise_f32.hip', 'optim.hip', 'gemm.hip', 'gemm4.hip', 'gemm32.hip', 'gemm_ring.hip', 'attention.hip', 'decode.hip',
            'gemm_f32.hip', 'attention_f32.hip', 'moe.hip', 'moe_f32.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wno-unused-result']
@@ -44,7 +44,7 @@ def build(verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(_compile, srcs))
     if any(_newer(o, LIB) for o in objs):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB]
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-ldl', '-o', LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')

@@ -371,7 +371,9 @@ void gemm4_kernel(const GemmParams p) {
             auto lo16 = [](unsigned x) { return bf2f((bf16_t)(x & 0xffff)); };
             auto hi16 = [](unsigned x) { return bf2f((bf16_t)(x >> 16)); };
             auto pk = [](float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); };
-            if constexpr (EPI == 1 || EPI == 2) {
+            if (EPI == 1 && (p.grp_strideC & 1)) {
+                // ABLATION (AA_GEMM_ABLATE=1, timing only): no conversion, no stores -- what does the epilogue cost?
+            } else if constexpr (EPI == 1 || EPI == 2) {
                 bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + erow * p.ldc + n0 + wn * TNW + ecol;
                 [[maybe_unused]] const bf16_t* rrow = p.residual + erow * p.ldr + n0 + wn * TNW + ecol;
 #pragma unroll
@@ -565,6 +567,7 @@ int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
     const bool plain = shape_ok && !p.residual;
     const bool resid = shape_ok && p.residual && !a_t && !b_n && (p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0;
     const bool pers = g4_persist() && p.K >= 2 * BK;
+    { static long abl = -1; if (abl < 0) { const char* e = getenv("AA_GEMM_ABLATE"); abl = e ? atol(e) : 0; } p.grp_strideC = abl; }   // timing experiments only
     if (plain) return pers ? launch4_layout<1, true>(p, a_t, b_n, st) : launch4_layout<1, false>(p, a_t, b_n, st);
     if (resid) return pers ? launch4_layout<2, true>(p, a_t, b_n, st) : launch4_layout<2, false>(p, a_t, b_n, st);
     return launch4_layout<0, false>(p, a_t, b_n, st);

@@ -226,6 +226,20 @@ int aa_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
                 long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, int N, int T,
                 int H, int Hkv, int hd, int causal, float scale, void* stream);
 
+/* ---- data-parallel exchange for non-Python hosts (csrc/comm.hip; the Python host side uses torch.distributed for the same three
+ * operations).  RCCL is bound at run time (dlopen librccl.so); one communicator per process = per GPU.
+ * reference: DeepSpeed's gradient all-reduce behind engine.backward / step (trainers/text_to_text/dpo.py:212-213) and
+ * utils/multi_process.py:74-89 get_all_reduce_mean / get_all_reduce_max on the logged scalars. */
+int aa_comm_unique_id(void* id128);                               /* rank 0: the 128-byte id to hand to the other ranks */
+int aa_comm_init(const void* id128, int rank, int world);         /* after hipSetDevice(local rank) */
+int aa_comm_world(int* rank, int* world);
+int aa_comm_destroy(void);
+/* SUM all-reduce in place of one slice of a flat gradient buffer (dtype 0 = bf16, 1 = fp32) on `stream` (a side stream overlaps it
+ * with the backward of the layers below); 1/world is folded into aa_grad_sumsq / aa_adamw_flat */
+int aa_grad_allreduce_bucket(void* grads, long count, int dtype, void* stream);
+int aa_metrics_allreduce(float* vals, int n, int op /* 0 mean, 1 max */, void* stream);
+int aa_broadcast(void* buf, long bytes, int root, void* stream);
+
 /* ---- autoregressive decode (replaces HF generate in the PPO rollout, trainers/text_to_text/ppo.py:209-222) ---- */
 /* out[M<=16, N] = x[M,K] W[N,K]^T (+bias) (+residual, HF rounding); K % 32 == 0; HBM-streaming skinny GEMM */
 int aa_gemm_skinny_bf16(const void* x, const void* W, void* out, int M, int N, int K, long ldx, long ldw, long ldo,

@@ -37,3 +37,40 @@ def test_two_rank_dp_step_equals_single_rank_full_batch(tmp_path):
         # Adam's first step moves every weight by ~lr = 1e-3; a sign flip of a near-zero gradient component costs 2e-3
         assert (a - f).abs().max().item() <= 2.1e-3, (g, (a - f).abs().max().item())
         assert ((a - f).abs() < 1e-4).float().mean().item() > 0.97, g
+
+
+def test_c_abi_collectives_bind_rccl_and_run_on_one_rank():
+    """csrc/comm.hip: aa_comm_unique_id / aa_comm_init / aa_grad_allreduce_bucket / aa_metrics_allreduce / aa_broadcast bind librccl at
+    run time and work as a 1-rank communicator on the test box's one GPU (the N-rank behaviour is RCCL's; what is pinned here is that
+    the symbols resolve, the communicator comes up on the current device and the calls are stream-ordered and leave a 1-rank job's data
+    untouched)."""
+    import ctypes
+    from align_anything_amd.lib import LIB, AAHipError, call
+    dll = LIB.load()
+    uid = (ctypes.c_char * 128)()
+    call('aa_comm_unique_id', ctypes.cast(uid, ctypes.c_void_p))
+    assert any(b != b'\x00' for b in uid)
+    torch.cuda.set_device(0)
+    call('aa_comm_init', ctypes.cast(uid, ctypes.c_void_p), 0, 1)
+    try:
+        with pytest.raises(AAHipError):
+            call('aa_comm_init', ctypes.cast(uid, ctypes.c_void_p), 0, 1)       # one communicator per process
+        r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+        call('aa_comm_world', ctypes.byref(r), ctypes.byref(w))
+        assert (r.value, w.value) == (0, 1)
+        st = torch.cuda.current_stream().cuda_stream
+        g16 = torch.randn(1 << 20, device='cuda').to(torch.bfloat16)
+        g32 = torch.randn(4097, device='cuda')
+        m = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0, 6.0], device='cuda')
+        keep = (g16.clone(), g32.clone(), m.clone())
+        call('aa_grad_allreduce_bucket', g16.data_ptr(), g16.numel(), 0, st)
+        call('aa_grad_allreduce_bucket', g32.data_ptr(), g32.numel(), 1, st)
+        call('aa_metrics_allreduce', m.data_ptr(), m.numel(), 0, st)
+        call('aa_metrics_allreduce', m.data_ptr(), m.numel(), 1, st)
+        call('aa_broadcast', g32.data_ptr(), g32.numel() * 4, 0, st)
+        torch.cuda.synchronize()
+        assert torch.equal(g16, keep[0]) and torch.equal(g32, keep[1]) and torch.equal(m, keep[2])
+        with pytest.raises(AAHipError):
+            call('aa_grad_allreduce_bucket', g16.data_ptr(), g16.numel(), 7, st)
+    finally:
+        call('aa_comm_destroy')

@@ -17,8 +17,10 @@ REPORT = []
 
 def ulps(got_bf16, want_f32, row_dim=-1):
     want = want_f32.float()
+    # scale: the element, the RMS of its row, or (rows that are entirely ~0, e.g. masked query rows) the RMS of the whole tensor
     scale = torch.maximum(want.abs(), want.pow(2).mean(row_dim, keepdim=True).sqrt().expand_as(want))
-    return ((got_bf16.float() - want).abs() / (scale * ULP + 1e-30))
+    scale = torch.maximum(scale, want.pow(2).mean().sqrt() * 1e-2)
+    return ((got_bf16.float() - want).abs() / (scale * ULP))
 
 
 def check(name, got, want, max_ulp, frac_within2=0.99):
