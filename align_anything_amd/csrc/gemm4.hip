@@ -554,7 +554,9 @@ int launch4_layout(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
 
 int g4_persist() {
     static int persist = -1;
-    if (persist < 0) { const char* e = getenv("AA_GEMM_PERSIST"); persist = e ? atoi(e) : 1; }
+    // default off: the walk measured +-1 % against one workgroup per tile on every hot shape and on the whole step (804.96 vs 804.98 ms,
+    // profiles/r02_gemm_vs_hipblaslt_pmc.txt) -- the per-tile cost it removes (launch, prologue) is not where the tile's fixed ~8 us go
+    if (persist < 0) { const char* e = getenv("AA_GEMM_PERSIST"); persist = e ? atoi(e) : 0; }
     return persist;
 }
 

@@ -11,13 +11,14 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
             if r['Counter_Name'] == c:
                 agg[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
     for k, v in agg.items():
-        if any(s in k for s in ('gemm_kernel', 'attn_', 'adamw_kernel')):
+        if any(s in k for s in ('gemm_kernel', 'gemm4_kernel', 'attn_', 'adamw_kernel')):
             per[k][c] = sum(v) / len(v); per[k]['launches'] = len(v)
-g = {k: v for k, v in per.items() if 'gemm_kernel' in k and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v}
+g = {k: v for k, v in per.items() if ('gemm_kernel' in k or 'gemm4_kernel' in k) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v}
 n = sum(v['launches'] for v in g.values())
 fetch = sum(v['FETCH_SIZE'] * v['launches'] for v in g.values()) / n
 write = sum(v['WRITE_SIZE'] * v['launches'] for v in g.values()) / n
-json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_traffic.sh), bench.py --layers 4 --pairs-per-gpu 4; '
+import os
+json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, ' + os.environ.get('AA_TRAFFIC_CMD', 'tools/gpu_traffic.sh: bench.py --layers 4 --pairs-per-gpu 4') + '); '
                    'FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section', 'gemm_launches': n, 'gemm_fetch_KiB_avg_raw': fetch,
            'gemm_write_KiB_avg': write, 'gemm_hbm_bytes_per_launch': (2 * fetch + write) * 1024, 'per_kernel': per}, open(out, 'w'), indent=1)
 print('gemm launches', n, 'HBM bytes per launch', (2 * fetch + write) * 1024)
