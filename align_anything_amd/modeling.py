@@ -388,8 +388,12 @@ class LMHead:
             mean = None
         else:
             n, mean, rstd = ops.layernorm_fwd(sel, P[self.norm_w], P[self.norm_b], self.eps)
-        logits = ops.gemm(n, self._w())
-        logp, lse = ops.logprob_gather_fwd(logits, labels, round_bf16)
+        if ops.lmhead_fused():      # lm_head inside the log-prob pass: no [rows, V] buffer, backward recomputes the chunks
+            logp, lse = ops.lmhead_logprob_fwd(n, self._w(), labels, round_bf16)
+            logits = None
+        else:
+            logits = ops.gemm(n, self._w())
+            logp, lse = ops.logprob_gather_fwd(logits, labels, round_bf16)
         self.saved = (sel, mean, rstd, n, logits, lse, labels) if save else None
         return logp
 
@@ -433,13 +437,19 @@ class LMHead:
         """dlogp f32[rows_pad] -> gradient of the residual stream [Mp, h] (rows outside the windows are 0)."""
         sel, mean, rstd, n, logits, lse, labels = self.saved
         P, G = self.store.p, self.store.g
-        ops.logprob_gather_bwd(logits, labels, lse, dlogp, out=logits)  # in place: logits -> dlogits
-        d_n = ops.gemm(logits, self._w(), b_n=True)
+        gw = None
         if self.trainable:
             gw = G.get(self.lm_w)
             if gw is None:
                 gw = self.store.grad_view(self.lm_w)
-            ops.gemm(logits, n, out=gw, a_t=True, b_n=True, accumulate=(gw.dtype == torch.float32) or self.store.accumulate)
+        acc = gw is not None and ((gw.dtype == torch.float32) or self.store.accumulate)
+        if logits is None:
+            d_n = ops.lmhead_logprob_bwd(n, self._w(), labels, lse, dlogp, dw=gw, accumulate=acc)
+        else:
+            ops.logprob_gather_bwd(logits, labels, lse, dlogp, out=logits)  # in place: logits -> dlogits
+            d_n = ops.gemm(logits, self._w(), b_n=True)
+            if gw is not None:
+                ops.gemm(logits, n, out=gw, a_t=True, b_n=True, accumulate=acc)
         tr = self.trainable
         if self.kind == 'rms':
             d_sel = ops.rmsnorm_bwd(d_n, sel, P[self.norm_w], rstd, G.get(self.norm_w) if tr else None)

@@ -581,6 +581,56 @@ def logprob_gather_bwd(logits, labels, lse, dlogp, out=None):
     return out
 
 
+LMHEAD_CHUNK = int(os.environ.get('AA_LMHEAD_CHUNK', '8192'))     # vocabulary columns per pass of the fused lm_head x log-prob
+
+
+def lmhead_fused() -> bool:
+    """AA_LMHEAD_FUSED=0 keeps the unfused pair (lm_head GEMM into a [rows, V] buffer, then aa_logprob_gather_*) for A/B and parity runs."""
+    return os.environ.get('AA_LMHEAD_FUSED', '1') != '0'
+
+
+def _lmhead_ws_bytes(rows, chunk, h, dt, backward) -> int:
+    import ctypes
+    nb = ctypes.c_long(0)
+    call('aa_lmhead_logprob_ws_bytes', rows, chunk, h, dt, backward, ctypes.byref(nb))
+    return int(nb.value)
+
+
+def lmhead_logprob_fwd(hidden, w, labels, round_bf16=False, chunk=None):
+    """log_softmax(hidden @ w^T).gather(labels) per row without the [rows, V] logits buffer (aa_lmhead_logprob_fwd): the vocabulary is
+    walked `chunk` columns at a time through a [rows, chunk] scratch.  Bit-identical to gemm + logprob_gather_fwd."""
+    _chk(w, hidden.dtype, 'lmhead_logprob_fwd.w'); _row_major(hidden, 'lmhead_logprob_fwd.hidden'); _row_major(w, 'lmhead_logprob_fwd.w')
+    rows, h = hidden.shape
+    V = w.shape[0]
+    chunk = int(chunk or LMHEAD_CHUNK)
+    dt = 0 if hidden.dtype == bf16 else 1
+    nb = _lmhead_ws_bytes(rows, chunk, h, dt, 0)
+    ws = torch.empty(nb, dtype=torch.uint8, device=hidden.device)
+    logp = torch.empty(rows, dtype=torch.float32, device=hidden.device)
+    lse = torch.empty(rows, dtype=torch.float32, device=hidden.device)
+    FLOPS['gemm'] += 2.0 * rows * V * h
+    call('aa_lmhead_logprob_fwd', hidden.data_ptr(), hidden.stride(0), w.data_ptr(), w.stride(0), labels.data_ptr(), logp.data_ptr(),
+         lse.data_ptr(), ws.data_ptr(), nb, rows, V, h, chunk, dt, int(round_bf16), stream())
+    return logp, lse
+
+
+def lmhead_logprob_bwd(hidden, w, labels, lse, dlogp, dw=None, accumulate=False, chunk=None):
+    """Backward of lmhead_logprob_fwd: recomputes each chunk of logits, returns d_hidden [rows, h]; `dw` [V, h] (bf16 or fp32) receives
+    (accumulate: is added) the lm_head weight gradient."""
+    rows, h = hidden.shape
+    V = w.shape[0]
+    chunk = int(chunk or LMHEAD_CHUNK)
+    dt = 0 if hidden.dtype == bf16 else 1
+    nb = _lmhead_ws_bytes(rows, chunk, h, dt, 1)
+    ws = torch.empty(nb, dtype=torch.uint8, device=hidden.device)
+    d_hidden = torch.empty_like(hidden)
+    FLOPS['gemm'] += 2.0 * rows * V * h * (3 if dw is not None else 2)
+    call('aa_lmhead_logprob_bwd', hidden.data_ptr(), hidden.stride(0), w.data_ptr(), w.stride(0), labels.data_ptr(), lse.data_ptr(),
+         dlogp.data_ptr(), d_hidden.data_ptr(), d_hidden.stride(0), _p(dw), dw.stride(0) if dw is not None else 0,
+         int(dw is not None and dw.dtype == torch.float32), int(accumulate), ws.data_ptr(), nb, rows, V, h, chunk, dt, stream())
+    return d_hidden
+
+
 def window_labels(ids, pad_id, resp_len_i32, row_off_i32, labels_out):
     N, T = ids.shape
     call('aa_window_labels', ids.data_ptr(), N, T, int(pad_id), resp_len_i32.data_ptr(), row_off_i32.data_ptr(),

@@ -317,7 +317,8 @@ def main():
                         break
                 except (OSError, ValueError):
                     continue          # the profile is not in this checkout: traffic stays null
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel<BM,BN,...> (csrc/gemm.hip), all launches of the timed steps',
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm4_kernel<A_T,B_N,EPI,PERSIST> (csrc/gemm4.hip: one wave per SIMD, 128x128 per wave) + the few '
+                                                          'gemm_kernel launches of the small / ragged shapes (csrc/gemm.hip): all GEMM launches of the timed steps',
                                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                                'traffic': traffic, 'traffic_unit': f'HBM bytes per GEMM launch (rocprofv3 --pmc passes of this command, profiles/{src})',
                                'algorithmic_bytes_per_launch': sum(e[3] for e in gemm_events) / n,

@@ -53,6 +53,17 @@ int aa_logprob_gather_fwd(const void* logits, long ld, const int64_t* labels, fl
 int aa_logprob_gather_bwd(const void* logits, long ld, const int64_t* labels, const float* lse,
                           const float* dlogp, void* dlogits, long ldd, int rows, int V, int dtype,
                           void* stream);
+/* The same log-prob with the lm_head inside and no [rows, V] logits buffer (utils/tools.py:402-413 applied to `model(**batch).logits`,
+ * trainers/text_to_text/dpo.py:128-138): the vocabulary is walked `chunk` columns (a multiple of 2048) at a time through the caller's scratch
+ * `ws` (size from aa_lmhead_logprob_ws_bytes).  hidden [rows, h] is the final-norm output, W [V, h] the lm_head weight, dtype 0 = bf16 / 1 = fp32.
+ * Forward is bit-identical to aa_gemm_* + aa_logprob_gather_fwd; backward recomputes every chunk, accumulates d_hidden in fp32 across chunks
+ * and writes (dw_accumulate: adds) dW [V, h] (bf16, or fp32 when dw_f32) unless dW is NULL. */
+int aa_lmhead_logprob_ws_bytes(int rows, int chunk, int h, int dtype, int backward, long* bytes_out);
+int aa_lmhead_logprob_fwd(const void* hidden, long ldh, const void* W, long ldw, const int64_t* labels, float* logp, float* lse,
+                          void* ws, long ws_bytes, int rows, int V, int h, int chunk, int dtype, int round_bf16, void* stream);
+int aa_lmhead_logprob_bwd(const void* hidden, long ldh, const void* W, long ldw, const int64_t* labels, const float* lse,
+                          const float* dlogp, void* d_hidden, long lddh, void* dW, long lddw, int dw_f32, int dw_accumulate,
+                          void* ws, long ws_bytes, int rows, int V, int h, int chunk, int dtype, void* stream);
 /* align_anything/trainers/text_to_text/dpo.py:131-137: labels = strip_pad(ids[n])[-R_n:][1:], written at
  * labels[row_off[n] .. row_off[n] + R_n - 1); bit-exact integer path. ids int64[N,T]. */
 int aa_window_labels(const int64_t* ids, int N, int T, int64_t pad_id, const int* resp_len,

@@ -2,7 +2,7 @@
 FETCH_SIZE is doubled per the gfx950 note of MI355X_MICROARCH.md (HBM section), WRITE_SIZE is used as is."""
 import collections, csv, glob, json, re, sys
 root, out = sys.argv[1], sys.argv[2]
-short = lambda n: re.sub(r'\(.*$', '', n).replace('void ', '')
+short = lambda n: re.sub(r'\(.*$', '', n.replace('(anonymous namespace)::', '')).replace('void ', '')
 per = collections.defaultdict(dict)
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     agg = collections.defaultdict(list)
