@@ -18,6 +18,7 @@ SOURCES = ['runtime.hip', 'comm.hip', 'rl_math.hip', 'lmhead.hip', 'pref_losses.
            'gemm_f32.hip', 'attention_f32.hip', 'moe.hip', 'moe_f32.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wno-unused-result']
+FLAGS += os.environ.get('AA_HIPCC_EXTRA', '').split()      # experiment builds only (e.g. -DAA_G4_TIMING, tools/gemm4_timing.py)
 
 
 def _newer(a: str, b: str) -> bool:

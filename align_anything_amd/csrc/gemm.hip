@@ -542,8 +542,9 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
     p.bias = (const bf16_t*)bias; p.residual = (const bf16_t*)residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.act = act; p.flags = flags;
-    const int tile = pick_tile(M, N);
+    int tile = pick_tile(M, N);
     hipStream_t st = (hipStream_t)stream;
+    if (tile == 5 && !aa_gemm4_supports(K)) tile = 0;      // K not a multiple of 128: the 8-wave kernel of the same tile
     if (tile == 5) {   // one-wave-per-SIMD 256x256 tile with accumulator-file MFMAs (gemm4.hip)
         p.tiles_m = aa_cdiv(p.M, 256);
         p.tiles_n = aa_cdiv(p.N, 256);

@@ -99,6 +99,7 @@ __device__ __forceinline__ void gemm_store4(const GemmParams& p, int m, int n, f
 // split-K-ring 256x256 kernel (gemm_ring.hip)
 int aa_gemm_ring_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
 // one-wave-per-SIMD 256x256 kernel, accumulators in the accumulator file (gemm4.hip)
+bool aa_gemm4_supports(int K);      // the 4-slot ring walks K in trips of 128
 int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
 // fused-epilogue launches of the same kernel (p.fuse); 1 = shape does not qualify, run the unfused kernels
 int aa_gemm4_fused(GemmParams& p, hipStream_t st);

@@ -10,7 +10,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libaa_hip.so')
+LIB_PATH = os.environ.get('AA_HIP_LIB') or os.path.join(HERE, 'libaa_hip.so')     # AA_HIP_LIB: another build of the SAME ABI (same-box A/B runs)
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'aa_hip.h')
 HEADER_F32 = os.path.join(os.path.dirname(HERE), 'include', 'aa_hip_f32.h')   # fp32 parity-mode twins
 

@@ -137,7 +137,7 @@ def gemm_glu_bwd(dy, w_down, gu, F):
     _row_major(dy, 'gemm_glu_bwd.dy'); _row_major(w_down, 'gemm_glu_bwd.w'); _row_major(gu, 'gemm_glu_bwd.gu')
     M, K = dy.shape
     dgu = torch.empty_like(gu)
-    fused = fuse_enabled() and M % 256 == 0 and F % 256 == 0 and K % 64 == 0
+    fused = fuse_enabled() and M % 256 == 0 and F % 256 == 0 and K % 128 == 0      # aa_gemm4_fused's conditions; otherwise the unfused pair needs d_act
     ws = None if fused else torch.empty((M, F), dtype=bf16, device=dy.device)
     FLOPS['gemm'] += 2.0 * M * F * K
     prof = _prof_begin()

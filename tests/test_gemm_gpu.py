@@ -116,46 +116,38 @@ def test_gemm_k_loop_schedules_agree(mode, layout):
         ops.gemm_set_interleave(-1)
 
 
-@pytest.mark.parametrize('persist', ['1', '0'])
-def test_gemm4_fast_epilogues_and_persistent_walk(persist):
-    """gemm4.hip's specialised paths: plain and residual epilogues with 16-byte permlane-swapped stores, and the persistent tile walk
-    (more tiles than workgroups, odd K-tile counts so the buffer parity flips between tiles) -- in a fresh process per setting, since
-    AA_GEMM_PERSIST is read once."""
-    import os, subprocess, sys
-    from tests.util import ROOT
-    code = r'''
-import torch
-from align_anything_amd import ops
-from tests.gpu_util import assert_close, randn_bf16
-ops.gemm_set_tile(5)
-for (M, N, K) in [(512, 512, 256), (256, 256, 64), (256, 256, 128), (4096, 8192, 192), (16384, 4096, 320), (8192, 4352, 448)]:
-    for layout in ('nt', 'nn', 'tn'):
-        a_t, b_n = layout == 'tn', layout in ('nn', 'tn')
-        a = randn_bf16(K, M, seed=1) if a_t else randn_bf16(M, K, seed=1)
-        b = randn_bf16(K, N, seed=2) if b_n else randn_bf16(N, K, seed=2)
-        out = ops.gemm(a, b, a_t=a_t, b_n=b_n)
-        rows = torch.arange(0, M, 61, device=a.device)
-        ref = ((a[:, rows].t() if a_t else a[rows]).float()) @ (b if b_n else b.t()).float()
-        assert_close(out[rows], ref, rtol=1e-2, atol=1e-2 * float(ref.abs().mean()), what=f'{layout} {M}x{N}x{K}')
-        cs = out.double().sum(0)
-        want = (a.double().sum(1) if a_t else a.double().sum(0)) @ (b if b_n else b.t()).double()
-        assert float((cs - want).abs().max()) < 0.04 * (M ** 0.5) * float(ref.abs().mean()) * 8 + 1e-2 * float(want.abs().mean()), (layout, M, N, K)
-    # residual epilogue (forward layout): bf16(bf16(acc) + res), also in place
-    a, w, res = randn_bf16(M, K, seed=3), randn_bf16(N, K, scale=0.1, seed=4), randn_bf16(M, N, seed=6)
-    acc = a.float() @ w.float().t()
-    want = (acc.to(torch.bfloat16).float() + res.float()).to(torch.bfloat16)
-    out = ops.gemm(a, w, residual=res)
-    assert_close(out, want, rtol=1e-2, atol=2e-2, what=f'residual {M}x{N}x{K}')
-    frac_exact = float((out == want).float().mean())
-    assert frac_exact > 0.995, frac_exact          # same rounding points: only fp32 summation order differs from the torch matmul
-    buf = res.clone()
-    ops.gemm(a, w, out=buf, residual=buf)
-    assert torch.equal(buf, out)
-print('ok')
-'''
-    env = dict(os.environ, AA_GEMM_PERSIST=persist, PYTHONPATH=ROOT)
-    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.stdout[-2000:], r.stderr[-3000:])
+def test_gemm4_ring_pipeline_and_fast_epilogues():
+    """gemm4.hip's specialised paths: the 4-slot LDS ring over short and long contractions (1, 2, 3, 5, 7 trips of four stages; more tiles
+    than CUs), plain and residual epilogues with 16-byte permlane-swapped stores; K = 192 is not a multiple of the ring's trip and takes
+    the 8-wave kernel of the same tile."""
+    from align_anything_amd import ops
+    ops.gemm_set_tile(5)
+    try:
+        for (M, N, K) in [(512, 512, 256), (256, 256, 128), (256, 256, 384), (4096, 8192, 640), (16384, 4096, 384), (8192, 4352, 896), (512, 768, 192)]:
+            for layout in ('nt', 'nn', 'tn'):
+                a_t, b_n = layout == 'tn', layout in ('nn', 'tn')
+                a = randn_bf16(K, M, seed=1) if a_t else randn_bf16(M, K, seed=1)
+                b = randn_bf16(K, N, seed=2) if b_n else randn_bf16(N, K, seed=2)
+                out = ops.gemm(a, b, a_t=a_t, b_n=b_n)
+                rows = torch.arange(0, M, 61, device=a.device)
+                ref = ((a[:, rows].t() if a_t else a[rows]).float()) @ (b if b_n else b.t()).float()
+                assert_close(out[rows], ref, rtol=1e-2, atol=1e-2 * float(ref.abs().mean()), what=f'{layout} {M}x{N}x{K}')
+                cs = out.double().sum(0)
+                want = (a.double().sum(1) if a_t else a.double().sum(0)) @ (b if b_n else b.t()).double()
+                assert float((cs - want).abs().max()) < 0.04 * (M ** 0.5) * float(ref.abs().mean()) * 8 + 1e-2 * float(want.abs().mean()), (layout, M, N, K)
+            # residual epilogue (forward layout): bf16(bf16(acc) + res), also in place
+            a, w, res = randn_bf16(M, K, seed=3), randn_bf16(N, K, scale=0.1, seed=4), randn_bf16(M, N, seed=6)
+            acc = a.float() @ w.float().t()
+            want = (acc.to(torch.bfloat16).float() + res.float()).to(torch.bfloat16)
+            out = ops.gemm(a, w, residual=res)
+            assert_close(out, want, rtol=1e-2, atol=7e-2, what=f'residual {M}x{N}x{K}')     # one bf16 ulp of the accumulator where acc + res cancels
+            frac_exact = float((out == want).float().mean())
+            assert frac_exact > 0.995, frac_exact          # same rounding points: only fp32 summation order differs from the torch matmul
+            buf = res.clone()
+            ops.gemm(a, w, out=buf, residual=buf)
+            assert torch.equal(buf, out)
+    finally:
+        ops.gemm_set_tile(-1)
 
 
 def test_fused_epilogues_are_bit_identical_to_the_unfused_kernels():
@@ -166,7 +158,7 @@ def test_fused_epilogues_are_bit_identical_to_the_unfused_kernels():
     from align_anything_amd.modeling import rope_tables
     g = torch.Generator(device='cpu').manual_seed(5)
     try:
-        for (M, K, H, Hkv) in [(512, 256, 4, 2), (256, 64, 2, 2), (1024, 448, 3, 1), (320, 128, 2, 1)]:       # last: M % 256 != 0 -> unfused inside
+        for (M, K, H, Hkv) in [(512, 256, 4, 2), (256, 128, 2, 2), (1024, 640, 3, 1), (256, 64, 2, 2), (320, 128, 2, 1)]:       # last two: K % 128 / M % 256 != 0 -> unfused inside
             hd = 128
             N = (H + 2 * Hkv) * hd
             x, w = randn_bf16(M, K, seed=1), randn_bf16(N, K, scale=0.2, seed=2)
@@ -185,9 +177,9 @@ def test_fused_epilogues_are_bit_identical_to_the_unfused_kernels():
             s_ = torch.cat([sin_t[pos.long()], sin_t[pos.long()]], -1).float()[:, None]
             rot = torch.cat([-qk[..., hd // 2:], qk[..., :hd // 2]], -1)
             ref = (qk * c).to(torch.bfloat16).float() + (rot * s_).to(torch.bfloat16).float()
-            assert_close(outs[0][:, :(H + Hkv) * hd].float().view(M, H + Hkv, hd), ref, rtol=1.6e-2, atol=2e-2, what='rope vs definition')
+            assert_close(outs[0][:, :(H + Hkv) * hd].float().view(M, H + Hkv, hd), ref, rtol=1.6e-2, atol=7e-2, what='rope vs definition')       # one bf16 ulp of the projection where the two terms cancel
             assert_close(outs[0][:, (H + Hkv) * hd:], y[:, (H + Hkv) * hd:], rtol=1e-2, atol=2e-2, what='v heads untouched')
-        for (M, K, F) in [(512, 256, 384), (256, 128, 128), (768, 320, 1408), (320, 128, 256)]:
+        for (M, K, F) in [(512, 256, 384), (256, 128, 128), (768, 384, 1408), (768, 320, 1408), (320, 128, 256)]:
             x, w = randn_bf16(M, K, seed=3), randn_bf16(2 * F, K, scale=0.2, seed=4)
             res = []
             for fuse in (True, False):
@@ -198,7 +190,7 @@ def test_fused_epilogues_are_bit_identical_to_the_unfused_kernels():
             assert_close(res[0][0], gu, rtol=1e-2, atol=2e-2, what='gate|up')
             want = (torch.nn.functional.silu(gu[:, :F].float()).to(torch.bfloat16).float() * gu[:, F:].float())
             assert_close(res[0][1], want, rtol=1.6e-2, atol=2e-2, what='silu(gate)*up')
-        for (M, K, F) in [(512, 256, 512), (256, 64, 256), (1024, 192, 768), (320, 128, 256), (512, 128, 384)]:
+        for (M, K, F) in [(512, 256, 512), (256, 64, 256), (1024, 192, 768), (1024, 384, 768), (320, 128, 256), (512, 128, 384)]:
             dy, wd = randn_bf16(M, K, seed=6), randn_bf16(K, F, scale=0.2, seed=7)
             gu = randn_bf16(M, 2 * F, seed=8)
             res = []

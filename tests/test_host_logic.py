@@ -545,9 +545,9 @@ def test_preference_cache_forwards_tokenizer_arguments_of_the_text_collator():
 def test_gemm4_kernels_keep_everything_in_registers():
     """csrc/gemm4.hip counts its own LDS reads and LDS-DMA requests (inline asm), which is only sound while the compiler neither spills
     nor keeps accumulators in scratch: a spill of a fragment register could store it before its untracked load has landed, and any
-    scratch access makes hipcc put `s_waitcnt vmcnt(0)` into the K loop (draining the DMA pipeline every K-tile -- measured -15 %).
-    Compile the file and require: no scratch, no spills, accumulators in the accumulator file, and a K loop whose only vmcnt wait is
-    the one in the mid-tile barrier statement."""
+    scratch access makes hipcc put `s_waitcnt vmcnt(0)` into the K loop (draining the DMA ring every step -- measured -15 %).
+    Compile the file and require: no scratch, no spills, accumulators in the accumulator file, and a K loop whose only vmcnt waits are
+    the counted ones of the begin-of-step statements."""
     import re
     import subprocess
     import tempfile
@@ -559,30 +559,32 @@ def test_gemm4_kernels_keep_everything_in_registers():
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
         text = open(asm).read()
-    names = re.findall(r'Function Name: (\S*gemm4_kernel\S*)', r.stderr)
+    names = re.findall(r'Function Name: (\S*gemm4(?:nt)?_kernel\S*)', r.stderr)
     scratch = [int(x) for x in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
     vspill = [int(x) for x in re.findall(r'VGPRs Spill: (\d+)', r.stderr)]
     agprs = [int(x) for x in re.findall(r'AGPRs: (\d+)', r.stderr)]
-    assert len(names) >= 11 and len(names) == len(scratch) == len(vspill) == len(agprs)
+    assert len(names) >= 10 and len(names) == len(scratch) == len(vspill) == len(agprs)
     assert all(s == 0 for s in scratch) and all(s == 0 for s in vspill), list(zip(names, scratch, vspill))
     assert all(a == 256 for a in agprs), agprs
     assert 'scratch_' not in text
-    # between the first and the last MFMA of a kernel (the K loop, and in the persistent kernels the epilogue between two tiles) every
-    # vmcnt wait must be one of OURS, i.e. sit inside an inline-asm block; the only waits the compiler may add there are the ones for
-    # the residual / saved-activation loads of an epilogue, which come with lgkmcnt-free `s_waitcnt vmcnt(N)` right before their use
-    kernels = re.findall(r'^(_ZN\S*gemm4_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end', text, flags=re.S | re.M)
-    assert len(kernels) >= 11
+    # between the first and the last MFMA of a kernel (= the K loop: four ring steps per trip) every vmcnt wait must be one of OURS, i.e.
+    # sit inside an inline-asm block
+    kernels = re.findall(r'^(_ZN\S*gemm4(?:nt)?_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end', text, flags=re.S | re.M)
+    assert len(kernels) >= 10
     for name, body in kernels:
         lines = body.split('\n')
         idx = [i for i, ln in enumerate(lines) if 'v_mfma_f32_16x16x32_bf16' in ln]
-        assert len(idx) >= 128, name
-        epi_loads = ('Li2E' in name) or ('Li5E' in name) or ('Li3E' in name)      # epilogues that load (residual, [gate|up], rope tables)
-        in_asm, compiler_waits = False, 0
+        assert len(idx) == 256, (name, len(idx))
+        in_asm, compiler_waits, ours = False, 0, 0
         for ln in lines[idx[0]:idx[-1]]:
             if 'ASMSTART' in ln:
                 in_asm = True
             elif 'ASMEND' in ln:
                 in_asm = False
-            elif not in_asm and 's_waitcnt' in ln and 'vmcnt' in ln:
-                compiler_waits += 1
-        assert compiler_waits == 0 or (epi_loads and 'Lb1EEEv' in name), (name, compiler_waits)
+            elif 's_waitcnt' in ln and 'vmcnt' in ln:
+                if in_asm:
+                    ours += 1
+                else:
+                    compiler_waits += 1
+        assert compiler_waits == 0, (name, compiler_waits)
+        assert ours == 3, (name, ours)          # steps 1..3 of the trip (step 0's begin sits above the first MFMA)
