@@ -185,19 +185,41 @@ class DPOTrainer:
         }
 
     def train(self) -> list[dict[str, Any]]:
-        """dpo.py:239-308 without the per-step torch_gc() (a ZeRO-3 memory work-around)."""
+        """dpo.py:239-308 without the per-step torch_gc() (a ZeRO-3 memory work-around): resumes at
+        `self.global_step` (remaining epochs, the first `global_step % len(dataloader)` batches of the first one skipped,
+        dpo.py:256-270), saves `slice_<global_step>` every epochs * len(dataloader) // logger_cfgs.save_total_limit steps
+        (dpo.py:285-293) and evaluates on the reference's `eval_strategy` schedule when `data_cfgs.eval_datasets` is set."""
         history = []
         epochs = int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))
-        if self.model.total_steps is None and not self.model.global_steps and hasattr(self.train_dataloader, '__len__'):   # dataloader attached after __init__
-            self.model.set_schedule(epochs * ((len(self.train_dataloader) + self.model.gas - 1) // self.model.gas),
+        n_batches = len(self.train_dataloader) if hasattr(self.train_dataloader, '__len__') else None
+        if self.model.total_steps is None and not self.model.global_steps and n_batches is not None:   # dataloader attached after __init__
+            self.model.set_schedule(epochs * ((n_batches + self.model.gas - 1) // self.model.gas),
                                     float(cfg_get(self.cfgs, 'train_cfgs.lr_warmup_ratio', 0.03)))
-        self.model.train()
-        for epoch in range(epochs):
-            for batch in self.train_dataloader:
+        per_epoch = max(1, n_batches or 1)
+        remain_epoch = epochs - self.global_step // per_epoch if n_batches is not None else epochs
+        start_batch_idx = self.global_step % per_epoch if n_batches is not None else 0
+        limit = cfg_get(self.cfgs, 'logger_cfgs.save_total_limit', None)
+        save_interval = (epochs * per_epoch // int(limit)) if (limit and n_batches is not None) else 0
+        evals = bool(cfg_get(self.cfgs, 'data_cfgs.eval_datasets', None))
+        strategy = cfg_get(self.cfgs, 'train_cfgs.eval_strategy', 'epoch')
+        eval_interval = int(cfg_get(self.cfgs, 'train_cfgs.eval_interval', 0) or 0)
+        if evals:
+            history.append({'eval/step': 0, **self.eval()})
+        for epoch in range(int(remain_epoch)):
+            self.model.train()
+            for batch_idx, batch in enumerate(self.train_dataloader):
+                if epoch == 0 and batch_idx < start_batch_idx:
+                    continue
                 info = self.train_step(batch)
                 self.global_step += 1
-                info['train/epoch'] = self.global_step / max(1, len(self.train_dataloader))
+                info['train/epoch'] = self.global_step / per_epoch
                 history.append(info)
+                if save_interval > 0 and self.global_step % save_interval == 0:
+                    self.save(tag=self.global_step)
+                if evals and strategy == 'steps' and eval_interval > 0 and self.global_step % eval_interval == 0:
+                    history.append({'eval/step': self.global_step, **self.eval()})
+            if evals and strategy == 'epoch':
+                history.append({'eval/step': self.global_step, **self.eval()})
             self.model.tput_timer.update_epoch_count()
         return history
 

@@ -461,8 +461,10 @@ def test_integration_level_b_stub_runs_the_reference_train_step(launches, monkey
     assert set(info) == {'train/loss', 'train/reward', 'train/better_sample_reward', 'train/worse_sample_reward',
                          'train/reward_accuracy', 'train/reward_margin', 'train/lr'}
     assert info['train/lr'] == 1e-3 and tr.model.global_steps == 1
-    for k in ('aa_gemm_bf16', 'aa_attn_fwd', 'aa_logprob_gather_fwd', 'aa_dpo_loss_fwd_bwd', 'aa_attn_bwd', 'aa_grad_sumsq', 'aa_adamw_flat'):
+    for k in ('aa_gemm_bf16', 'aa_attn_fwd', 'aa_dpo_loss_fwd_bwd', 'aa_attn_bwd', 'aa_grad_sumsq', 'aa_adamw_flat'):
         assert k in launches, k
+    # log-probs: the fused lm_head x log-prob walk (default) or the unfused GEMM + gather pair (AA_LMHEAD_FUSED=0)
+    assert 'aa_lmhead_logprob_fwd' in launches or 'aa_logprob_gather_fwd' in launches
     lp = ref_dpo.DPOTrainer.compute_log_probs is not DPOTrainer.compute_log_probs and tr.compute_log_probs(tr.model, batch)
     assert lp.shape == (4, max(int(r) for r in z['response_lens']) - 1)
     # the reference's checkpoint call on the engine (supervised_trainer.py:404-450) works on the native engine too
@@ -471,3 +473,24 @@ def test_integration_level_b_stub_runs_the_reference_train_step(launches, monkey
         tr.model.save_16bit_model(d, save_filename='pytorch_model.bin')
         sd = torch.load(d + '/pytorch_model.bin')
         assert set(sd) >= set(hf.state_dict()) - {'lm_head.weight'}
+
+
+def test_train_resumes_mid_epoch_and_saves_on_the_reference_schedule(launches, tmp_path):
+    """dpo.py:256-270 (remaining epochs, the first `global_step % len(dataloader)` batches skipped) and dpo.py:285-293
+    (`slice_<global_step>` every epochs * len(dataloader) // save_total_limit steps)."""
+    import os
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    z = load_golden('opt_tiny_dpo.npz')
+    cfgs = _cfgs(z, epochs=2)
+    cfgs['logger_cfgs'] = {'output_dir': str(tmp_path), 'save_total_limit': 3}
+    tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_opt_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                    reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cpu')
+    tr.train_dataloader = [_pref_batch(z)] * 3
+    tr.global_step = 4                                     # a checkpoint taken after step 4 of 6: one batch of epoch 2 is already consumed
+    hist = tr.train()
+    assert len(hist) == 2 and tr.global_step == 6 and hist[-1]['train/epoch'] == 2.0
+    # save interval = 2 * 3 // 3 = 2 -> only step 6 falls in the resumed part
+    assert sorted(os.listdir(tmp_path)) == ['slice_6'] and os.path.exists(tmp_path / 'slice_6' / 'pytorch_model.bin')
+    tr.global_step = 0
+    hist = tr.train()
+    assert len(hist) == 6 and sorted(os.listdir(tmp_path)) == ['slice_2', 'slice_4', 'slice_6']
