@@ -16,44 +16,86 @@
 //                                permuted consistently on the V side via ds_read_b64_tr_b16)
 // K/V (fwd, dQ) and Q/dO (dK/dV) tiles are streamed HBM->LDS by global_load_lds DMA, double buffered,
 // with a 32-byte-unit XOR swizzle that is conflict-free for both ds_read_b128 and the transpose read.
+//
+// Scheduling notes (round 2, from the device assembly): hipcc treats the transpose-read builtin as a reader of ANY LDS byte,
+// so it put `s_waitcnt vmcnt(0)` -- a full drain of the next tile's DMA -- in front of the first transpose read of every tile,
+// i.e. the prefetch only overlapped half a tile.  The transpose reads are therefore issued as inline asm (TrPipe: groups of
+// fragments one group ahead of the MFMAs that consume them, own lgkmcnt wait tied to the fragment registers), which the
+// compiler does not order against the DMA; the tile's own data is complete since the barrier that ended the previous tile.
+// Mask handling is a template parameter of the tile body (two instantiations, chosen per tile by a wave-uniform branch) instead
+// of a branch per score, and the dK/dV kernel's per-row statistics arrive by DMA as well instead of through registers.
 #include "aa_common.h"
+
+#include <type_traits>
+#include <utility>
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_p;
 
 #define LOG2E_F 1.4426950408889634f
+#ifndef TR_NBUF
+#define TR_NBUF 4      // transposed-read groups per wave: TR_NBUF - 1 in flight ahead of the MFMAs (2 reads -> 2 MFMAs per group)
+#endif
+#ifndef AA_ATTN_XCD_LOCAL
+#define AA_ATTN_XCD_LOCAL 1   // 0 (lab builds): kv heads fastest, the round-1 order
+#endif
+#ifndef AA_ATTN_XCD_LOCAL_FWD
+#define AA_ATTN_XCD_LOCAL_FWD 0   // measured: the forward is 5 % SLOWER with the XCD-local order (load balance), the two backward kernels 2 % faster
+#endif
+#ifndef AA_ATTN_PK
+#define AA_ATTN_PK 0
+#endif
+#ifndef TR_NBUF_KV
+#define TR_NBUF_KV 4   // the same for the dK/dV kernel (4 reads -> 2 MFMAs per group)
+#endif
 #define LN2_F 0.6931471805599453f
 
 template <int HD> __device__ __forceinline__ int unit_swz(int row) {
     if constexpr (HD == 128) return row & 7; else return (row >> 1) & 3;
 }
 
-// DMA a [ROWS][HD] bf16 tile (rows row0.. of one sequence/head, clamped to max_row-1) into LDS.
-// The per-lane (row-in-tile, column) pairs depend only on the lane: computed once (DmaLane), so a tile
-// issue costs one min + one 64-bit mad per 1-KiB piece.
+// DMA a [ROWS][HD] bf16 tile (rows row0.. of one sequence/head) into LDS, 1 KiB per wave-instruction.  A lane's (row in tile,
+// column) pair depends only on the lane, so its byte offset from the tile's first row is computed ONCE per tensor (DmaOff) and a
+// piece is issued as `global_load_lds_dwordx4 voff, s[tile base]` with M0 = its LDS chunk: no vector arithmetic per piece (the
+// 64-bit per-lane addresses cost 6 VALU a piece, two of them quarter-rate integer multiplies: 53 of the ~300 VALU instructions
+// of a forward tile).  Tiles that reach past the sequence's last row (ragged T) take the clamped per-lane path.
 template <int HD, int ROWS, int NW>
 struct DmaLane {
     static constexpr int ROW_B = HD * 2, RPI = 1024 / ROW_B, SPR = ROW_B / 16;
     static constexpr int IT = (ROWS / RPI) / NW;
     static_assert(IT >= 1, "tile too small");
-    int r[IT], col[IT], chunk[IT];
-    __device__ __forceinline__ void init(int wave, int lane) {
-#pragma unroll
-        for (int j = 0; j < IT; ++j) {
-            const int c = wave + j * NW;
-            r[j] = c * RPI + lane / SPR;
-            const int s = lane % SPR;
-            col[j] = (((s >> 1) ^ unit_swz<HD>(r[j])) << 4) + (s & 1) * 8;
-            chunk[j] = c * 1024;
-        }
+    struct Off { int v[IT]; };
+    int wave, lane;
+    __device__ __forceinline__ void init(int wave_, int lane_) { wave = wave_; lane = lane_; }
+    __device__ __forceinline__ int row_of(int j) const { return (wave + j * NW) * RPI + lane / SPR; }
+    __device__ __forceinline__ int col_of(int j) const {
+        const int s = lane % SPR;
+        return (((s >> 1) ^ unit_swz<HD>(row_of(j))) << 4) + (s & 1) * 8;
     }
-    __device__ __forceinline__ void issue(const bf16_t* gbase, long ld, int row0, int max_row, char* lds) const {
+    // lane-constant byte offsets of this lane's IT pieces inside a tile of a tensor with leading dimension ld (elements)
+    __device__ __forceinline__ Off offsets(long ld) const {
+        Off o;
 #pragma unroll
-        for (int j = 0; j < IT; ++j) {
-            const int gr = min(row0 + r[j], max_row - 1);
-            const bf16_t* src = gbase + (long)gr * ld + col[j];
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + chunk[j]), 16, 0, 0);
+        for (int j = 0; j < IT; ++j) o.v[j] = (row_of(j) * (int)ld + col_of(j)) * 2;
+        return o;
+    }
+    // lds: LDS byte address of the tile (wave-uniform)
+    __device__ __forceinline__ void issue(const bf16_t* gbase, long ld, const Off& off, int row0, int max_row, int lds) const {
+        if (row0 + ROWS <= max_row) {
+            const bf16_t* tile = gbase + (long)row0 * ld;          // wave-uniform: lives in an SGPR pair
+#pragma unroll
+            for (int j = 0; j < IT; ++j)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                             :: "s"(lds + (wave + j * NW) * 1024), "v"(off.v[j]), "s"(tile) : "memory");
+        } else {
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const int gr = min(row0 + row_of(j), max_row - 1);
+                const bf16_t* src = gbase + (long)gr * ld + col_of(j);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                             :: "s"(lds + (wave + j * NW) * 1024), "v"(src) : "memory");
+            }
         }
     }
 };
@@ -81,6 +123,90 @@ __device__ __forceinline__ bf16x8 lds_tr_pair(const char* tile, int a16, int b16
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// ---- compile-time loops (inline-asm immediates must be constant expressions)
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// ---- transpose reads as inline asm
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+template <int IMM>
+__device__ __forceinline__ i32x2 at_rdt(int vaddr) {
+    i32x2 d;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(vaddr), "i"(IMM));
+    return d;
+}
+#define AT_PIN __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ bf16x8 at_join(const i32x2& lo, const i32x2& hi) {
+    const i32x4 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// wait for every outstanding LDS read of this wave; the fragments pass through the statement so no consumer can be moved above it
+__device__ __forceinline__ void at_wait(i32x2& a, i32x2& b, i32x2& c, i32x2& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+template <int NR> struct TrBuf { i32x2 f[NR]; };
+// counted form: returns once at most LEFT LDS operations of this wave are outstanding (LDS returns in order, so everything
+// issued before the youngest LEFT reads has landed); b's registers pass through so their consumers stay below
+template <int LEFT>
+__device__ __forceinline__ void at_wait_buf(TrBuf<4>& b) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b.f[0]), "+v"(b.f[1]), "+v"(b.f[2]), "+v"(b.f[3]) : "i"(LEFT));
+}
+template <int LEFT>
+__device__ __forceinline__ void at_wait_buf(TrBuf<8>& b) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(b.f[0]), "+v"(b.f[1]), "+v"(b.f[2]), "+v"(b.f[3]), "+v"(b.f[4]), "+v"(b.f[5]), "+v"(b.f[6]), "+v"(b.f[7])
+                 : "i"(LEFT));
+}
+template <int LEFT>
+__device__ __forceinline__ void at_wait_buf(TrBuf<2>& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b.f[0]), "+v"(b.f[1]) : "i"(LEFT));
+}
+// Lane part of a transpose-read address inside a [64][HD] tile: row 4g + (l15 >> 2) (further multiples of 16 rows and the tile's
+// offset go into the instruction's immediate), 8-byte slot l15 & 3, and the row's swizzle already XORed into the 32-byte-unit bits
+// (5.. of the byte offset, zero in every other term), so that d block db is reached with one more XOR:
+//     address(db, rows16) = (tile + tr_lane_base) ^ (db << 5)  + rows16 * 16 * HD * 2        -- the bytes lds_tr() addresses
+template <int HD>
+__device__ __forceinline__ int tr_lane_base(int g, int l15) {
+    const int row = 4 * g + (l15 >> 2);
+    return row * (HD * 2) + (unit_swz<HD>(row) << 5) + (l15 & 3) * 8;
+}
+// Streams every transposed fragment of one or two (NT) [64][HD] tiles to `consume(S, D, frag0[, frag1])`: S = 32-row half (the
+// contraction slots 32S .. 32S+31 of the tile), D = 16-wide d block, frag = the bf16x8 MFMA operand lds_tr_pair() would return.
+// The reads are inline asm, NBUF - 1 groups (one (S, D) pair = 2 NT reads) ahead of their consumers; OFF0 / OFF1 = byte offsets
+// of the tiles from `base` (= LDS address of the stage + tr_lane_base).
+template <int HD, int NT, int OFF0, int OFF1, int NBUF, typename F>
+__device__ __forceinline__ void tr_stream(const int base, F&& consume) {
+    constexpr int ROWB = HD * 2, DB = HD / 16, NG = 2 * DB, NR = 2 * NT;
+    static_assert(NR * (NBUF - 2) <= 15 && NBUF >= 2 && NBUF - 1 <= NG, "lgkmcnt is a 4-bit counter");
+    TrBuf<NR> tb[NBUF];
+    auto issue = [&](auto gi) {
+        constexpr int G = decltype(gi)::value, S = G / DB, D = G % DB;
+        const int a = base ^ (D << 5);
+        TrBuf<NR>& b = tb[G % NBUF];
+        b.f[0] = at_rdt<OFF0 + S * 32 * ROWB>(a);
+        b.f[1] = at_rdt<OFF0 + (S * 32 + 16) * ROWB>(a);
+        if constexpr (NT == 2) {
+            b.f[2] = at_rdt<OFF1 + S * 32 * ROWB>(a);
+            b.f[3] = at_rdt<OFF1 + (S * 32 + 16) * ROWB>(a);
+        }
+    };
+    static_for<NBUF - 1>(issue);
+    static_for<NG>([&](auto gi) {
+        constexpr int G = decltype(gi)::value, S = G / DB, D = G % DB;
+        constexpr int LEFT = (NBUF - 2 < NG - 1 - G ? NBUF - 2 : NG - 1 - G) * NR;   // reads of younger groups that may stay in flight
+        TrBuf<NR>& b = tb[G % NBUF];
+        at_wait_buf<LEFT>(b);
+        if constexpr (G + NBUF - 1 < NG) issue(std::integral_constant<int, G + NBUF - 1>{});
+        if constexpr (NT == 2)
+            consume(std::integral_constant<int, S>{}, std::integral_constant<int, D>{}, at_join(b.f[0], b.f[1]), at_join(b.f[2], b.f[3]));
+        else
+            consume(std::integral_constant<int, S>{}, std::integral_constant<int, D>{}, at_join(b.f[0], b.f[1]));
+    });
+}
+
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x4& a, const f32x4& b) {
@@ -92,6 +218,27 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x4& a, const f32x4& b) {
     const bf16x4 lo = __builtin_shufflevector(p0, p1, 0, 1, 2, 3);
     const bf16x4 hi = __builtin_shufflevector(p2, p3, 0, 1, 2, 3);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// Reductions over the four 16-lane rows of a wave (the lanes that share l15): v_permlane16_swap / v_permlane32_swap exchange
+// rows (halves) between two registers, so with both operands = v the two results hold the row pair's members in every lane and
+// one max / add finishes the step -- 2 VALU per step instead of __shfl_xor's index arithmetic + ds_bpermute round trip
+// (~7 VALU and an LDS wait per step).  Row step first, half step second: the association of the sums __shfl_xor(16), (32) gave.
+__device__ __forceinline__ float row4_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    float m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    return m;
+}
+__device__ __forceinline__ float row4_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    // the adds are asm as well: written in C++, hipcc (ROCm 7.2) emitted r[0] + r[0] for a swap of a value with itself
+    float m;
+    asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    return m;
 }
 // v_exp_f32 without the denormal-range fix-up of exp2f(): arguments here are <= 0 and results that would be
 // denormal contribute nothing to a softmax sum
@@ -109,9 +256,39 @@ struct AttnParams {
     float scale;
 };
 
+// ------------------------------------------------------------------ workgroup -> (sequence, head, block)
+// Block b runs on XCD b % 8 and every XCD has its own 4 MB L2.  All blocks that stream the SAME K/V (forward, dQ: the query
+// blocks of the query heads sharing one kv head) or the same Q/dO (dK/dV: the key blocks of one kv head) are therefore given to
+// ONE XCD, back to back in its dispatch sequence (b / 8), so that they run at the same time and the head's rows are fetched from
+// HBM once and served to the others by that L2; with heads fastest (round 1) the 64 blocks resident on an XCD belonged to 64
+// different heads and every one of them streamed its K/V from memory alone: the PMC counters showed 2.3 GB of L2-miss reads per
+// forward launch for 0.4 GB of operands, i.e. the kernels were bound by HBM/MALL bandwidth, not by the MFMAs.  Heaviest blocks of
+// a head first (causal); heads are dealt to the XCDs round-robin, which needs Hkv * N % 8 == 0 -- otherwise kv heads fastest.
+// Measured (profiles/r02_attention_lab.txt): L2-miss reads drop 5-6x (forward 2.3 GB -> 0.4 GB per launch) but the kernels are
+// NOT bound by that traffic -- the backward pair gains 2 %, the forward loses 5 % to the coarser load balance -- so the
+// forward keeps kv heads fastest and only the backward kernels use the XCD-local order (less HBM power next to the GEMMs).
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void q_block_of(const AttnParams& p, int nqb, int& n, int& h, int& hk, int& qb) {
+    const int HkN = p.Hkv * p.N, group = p.H / p.Hkv, per = nqb * group;
+    const int b = blockIdx.x;
+    int hkn, r;
+    if (XCD_LOCAL && AA_ATTN_XCD_LOCAL && (HkN & 7) == 0) { hkn = (b & 7) + 8 * ((b >> 3) / per); r = (b >> 3) % per; }
+    else                { hkn = b % HkN; r = b / HkN; }
+    n = hkn / p.Hkv; hk = hkn % p.Hkv;
+    h = hk * group + r % group;
+    qb = nqb - 1 - r / group;
+}
+__device__ __forceinline__ void kv_block_of(const AttnParams& p, int nkvb, int& n, int& hk, int& kvb) {
+    const int HkN = p.Hkv * p.N;
+    const int b = blockIdx.x;
+    int hkn;
+    if (AA_ATTN_XCD_LOCAL && (HkN & 7) == 0) { hkn = (b & 7) + 8 * ((b >> 3) / nkvb); kvb = (b >> 3) % nkvb; }
+    else                { hkn = b % HkN; kvb = b / HkN; }
+    n = hkn / p.Hkv; hk = hkn % p.Hkv;
+}
+
 // ================================================================== forward
-// 1-D grid, heaviest (latest) query blocks first and heads fastest, so the 8 XCDs (block b -> XCD b % 8) get
-// equal causal work and short blocks fill the tail.  256 threads: wave w owns queries q0 + 32w .. +31.
+// 1-D grid (q_block_of).  256 threads: wave w owns queries q0 + 32w .. +31.
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KS = HD / 32, DB = HD / 16;
@@ -119,11 +296,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int HN = p.H * p.N;
     const int nqb = (p.T + 127) / 128;
-    const int hn = blockIdx.x % HN;
-    const int qb = nqb - 1 - blockIdx.x / HN;
-    const int n = hn / p.H, h = hn % p.H, hk = h / (p.H / p.Hkv);
+    int n, h, hk, qb;
+    q_block_of<AA_ATTN_XCD_LOCAL_FWD>(p, nqb, n, h, hk, qb);
     const int q0 = qb * 128, qw = q0 + wave * 32;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
@@ -134,6 +309,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const float c2 = p.scale * LOG2E_F;
     DmaLane<HD, 64, 4> dma;
     dma.init(wave, lane);
+    const auto koff = dma.offsets(p.ldk), voff = dma.offsets(p.ldv);
+    const int lds0 = (int)(uintptr_t)smem;                   // LDS byte address of the dynamic segment
+    const int trl = tr_lane_base<HD>(g, l15);                // lane part of the transposed-read addresses
 
     // Q fragments (B operand of S^T): lane -> query l15, d = ks*32 + g*8 ..+7
     bf16x8 qf[2][KS];
@@ -155,8 +333,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const int kv_end = p.causal ? min(T, q0 + 128) : T;
     const int ntile = (kv_end - kv_begin + 63) / 64;
     if (ntile > 0) {
-        dma.issue(Kb, p.ldk, kv_begin, T, smem);
-        dma.issue(Vb, p.ldv, kv_begin, T, smem + TILE_B);
+        dma.issue(Kb, p.ldk, koff, kv_begin, T, lds0);
+        dma.issue(Vb, p.ldv, voff, kv_begin, T, lds0 + TILE_B);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -164,8 +342,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         const int cur = t & 1;
         const int kv0 = kv_begin + t * 64;
         if (t + 1 < ntile) {
-            dma.issue(Kb, p.ldk, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B);
-            dma.issue(Vb, p.ldv, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B + TILE_B);
+            dma.issue(Kb, p.ldk, koff, kv0 + 64, T, lds0 + (cur ^ 1) * 2 * TILE_B);
+            dma.issue(Vb, p.ldv, voff, kv0 + 64, T, lds0 + (cur ^ 1) * 2 * TILE_B + TILE_B);
         }
         const char* kt = smem + cur * 2 * TILE_B;
         const char* vt = kt + TILE_B;
@@ -214,13 +392,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                             mx = fmaxf(mx, s);
                         }
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = row4_max(mx);
                 const float mn = fmaxf(m2[qi], mx);
                 const float ms = (mn == -INFINITY) ? 0.f : mn;
                 const float alpha = fast_exp2(m2[qi] - ms);
                 m2[qi] = mn;
                 float ps = 0.f;
+#if AA_ATTN_PK
+                // packed form (lab): the 16 subtractions and the 16 additions as 8 + 8 v_pk_add_f32; the row sum becomes
+                // (even lanes' sum) + (odd lanes' sum), i.e. a different association than the sequential sum below
+                {
+                    const f32x2 ms2 = {ms, ms};
+                    f32x2 acc2 = {0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const f32x2 x = f32x2{sacc[qi][kb][2 * hh], sacc[qi][kb][2 * hh + 1]} - ms2;
+                            const f32x2 e = {fast_exp2(x[0]), fast_exp2(x[1])};
+                            sacc[qi][kb][2 * hh] = e[0];
+                            sacc[qi][kb][2 * hh + 1] = e[1];
+                            acc2 += e;
+                        }
+                    ps = acc2[0] + acc2[1];
+                }
+#else
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -229,6 +425,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                         sacc[qi][kb][r] = pe;
                         ps += pe;
                     }
+#endif
                 lsum[qi] = lsum[qi] * alpha + ps;
                 // exact skip of the O rescale while the running max is unchanged for the whole wave
                 if (!__all(alpha == 1.f)) {
@@ -238,15 +435,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 pf[qi][0] = pack_bf16x8(sacc[qi][0], sacc[qi][1]);
                 pf[qi][1] = pack_bf16x8(sacc[qi][2], sacc[qi][3]);
             }
+            // O^T += V^T P^T: the transposed V fragments come by inline asm (tr_stream), a few groups ahead of their MFMAs
+            tr_stream<HD, 1, TILE_B, 0, TR_NBUF>(lds0 + cur * 2 * TILE_B + trl, [&](auto si, auto di, const bf16x8 vf) {
+                constexpr int S = decltype(si)::value, D = decltype(di)::value;
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const bf16x8 vf = lds_tr_pair<HD>(vt, s * 32, s * 32 + 16, db, g, l15);
-#pragma unroll
-                    for (int qi = 0; qi < 2; ++qi)
-                        oacc[qi][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qi][s], oacc[qi][db], 0, 0, 0);
-                }
+                for (int qi = 0; qi < 2; ++qi)
+                    oacc[qi][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qi][S], oacc[qi][D], 0, 0, 0);
+            });
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -254,9 +449,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     // epilogue: O[q][16db + 4g + r] = oacc / l
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
-        float l = lsum[qi];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        const float l = row4_sum(lsum[qi]);
         const int qg = qw + qi * 16 + l15;
         if (qg >= T) continue;
         const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -306,11 +499,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int HN = p.H * p.N;
     const int nqb = (p.T + 127) / 128;
-    const int hn = blockIdx.x % HN;
-    const int qb = nqb - 1 - blockIdx.x / HN;
-    const int n = hn / p.H, h = hn % p.H, hk = h / (p.H / p.Hkv);
+    int n, h, hk, qb;
+    q_block_of<true>(p, nqb, n, h, hk, qb);
     const int q0 = qb * 128, qw = q0 + wave * 32;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
@@ -322,6 +513,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     const float c2 = p.scale * LOG2E_F;
     DmaLane<HD, 64, 4> dma;
     dma.init(wave, lane);
+    const auto koff = dma.offsets(p.ldk), voff = dma.offsets(p.ldv);
+    const int lds0 = (int)(uintptr_t)smem;
+    const int trl = tr_lane_base<HD>(g, l15);
 
     bf16x8 qf[2][KS], dof[2][KS];
     float lse2[2], dl[2];
@@ -346,8 +540,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     const int kv_end = p.causal ? min(T, q0 + 128) : T;
     const int ntile = (kv_end - kv_begin + 63) / 64;
     if (ntile > 0) {
-        dma.issue(Kb, p.ldk, kv_begin, T, smem);
-        dma.issue(Vb, p.ldv, kv_begin, T, smem + TILE_B);
+        dma.issue(Kb, p.ldk, koff, kv_begin, T, lds0);
+        dma.issue(Vb, p.ldv, voff, kv_begin, T, lds0 + TILE_B);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -355,62 +549,74 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
         const int cur = t & 1;
         const int kv0 = kv_begin + t * 64;
         if (t + 1 < ntile) {
-            dma.issue(Kb, p.ldk, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B);
-            dma.issue(Vb, p.ldv, kv0 + 64, T, smem + (cur ^ 1) * 2 * TILE_B + TILE_B);
+            dma.issue(Kb, p.ldk, koff, kv0 + 64, T, lds0 + (cur ^ 1) * 2 * TILE_B);
+            dma.issue(Vb, p.ldv, voff, kv0 + 64, T, lds0 + (cur ^ 1) * 2 * TILE_B + TILE_B);
         }
         const char* kt = smem + cur * 2 * TILE_B;
         const char* vt = kt + TILE_B;
         const bool wave_active = !(p.causal && kv0 > qw + 31) && (qw < T);
         if (wave_active) {
-            f32x4 sacc[2][4], dpacc[2][4];
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    sacc[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    dpacc[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 kf = lds_frag<HD>(kt, kb * 16 + l15, ks * 4 + g);
-                    const bf16x8 vf = lds_frag<HD>(vt, kb * 16 + l15, ks * 4 + g);
-#pragma unroll
-                    for (int qi = 0; qi < 2; ++qi) {
-                        sacc[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], sacc[qi][kb], 0, 0, 0);
-                        dpacc[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qi][ks], dpacc[qi][kb], 0, 0, 0);
-                    }
-                }
             const bool need_mask = (p.causal && kv0 + 63 > qw) || kv0 < start || kv0 + 64 > KT || qw + 32 > T;
             bf16x8 dsf[2][2];
+            // S, dP and dS = P * (dP - delta) * scale, one 32-key half of the tile at a time: only 2 x 2 score blocks per operand
+            // are live at once (the register file holds dQ, Q and dO fragments as well).  The masked instantiation runs only on
+            // the diagonal / padding / ragged tiles.
+            auto half = [&](auto hi, auto masked) {
+                constexpr int S = decltype(hi)::value;
+                f32x4 sacc[2][2], dpacc[2][2];
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                const int qg = qw + qi * 16 + l15;
+                for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float pe = fast_exp2(sacc[qi][kb][r] * c2 - lse2[qi]);
-                        if (need_mask) {
-                            const int kv = kv0 + kb * 16 + g * 4 + r;
-                            const bool ok = kv >= start && kv < KT && (!p.causal || kv <= qg) && qg < T;
-                            pe = ok ? pe : 0.f;
-                        }
-                        sacc[qi][kb][r] = pe * (dpacc[qi][kb][r] - dl[qi]) * p.scale;
+                    for (int kk = 0; kk < 2; ++kk) {
+                        sacc[qi][kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        dpacc[qi][kk] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                dsf[qi][0] = pack_bf16x8(sacc[qi][0], sacc[qi][1]);
-                dsf[qi][1] = pack_bf16x8(sacc[qi][2], sacc[qi][3]);
-            }
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+                for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const bf16x8 ktf = lds_tr_pair<HD>(kt, s * 32, s * 32 + 16, db, g, l15);
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const bf16x8 kf = lds_frag<HD>(kt, (2 * S + kk) * 16 + l15, ks * 4 + g);
+                        const bf16x8 vf = lds_frag<HD>(vt, (2 * S + kk) * 16 + l15, ks * 4 + g);
 #pragma unroll
-                    for (int qi = 0; qi < 2; ++qi)
-                        dqacc[qi][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qi][s], dqacc[qi][db], 0, 0, 0);
+                        for (int qi = 0; qi < 2; ++qi) {
+                            sacc[qi][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], sacc[qi][kk], 0, 0, 0);
+                            dpacc[qi][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qi][ks], dpacc[qi][kk], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) {
+                    const int qg = qw + qi * 16 + l15;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float pe = fast_exp2(sacc[qi][kk][r] * c2 - lse2[qi]);
+                            if constexpr (decltype(masked)::value) {
+                                const int kv = kv0 + (2 * S + kk) * 16 + g * 4 + r;
+                                const bool ok = kv >= start && kv < KT && (!p.causal || kv <= qg) && qg < T;
+                                pe = ok ? pe : 0.f;
+                            }
+                            sacc[qi][kk][r] = pe * (dpacc[qi][kk][r] - dl[qi]) * p.scale;
+                        }
+                    dsf[qi][S] = pack_bf16x8(sacc[qi][0], sacc[qi][1]);
                 }
+            };
+            if (need_mask) {
+                half(std::integral_constant<int, 0>{}, std::true_type{});
+                AT_PIN;
+                half(std::integral_constant<int, 1>{}, std::true_type{});
+            } else {
+                half(std::integral_constant<int, 0>{}, std::false_type{});
+                AT_PIN;
+                half(std::integral_constant<int, 1>{}, std::false_type{});
+            }
+            // dQ^T += K^T dS^T: transposed K fragments by inline asm (see the forward's PV step)
+            tr_stream<HD, 1, 0, 0, TR_NBUF>(lds0 + cur * 2 * TILE_B + trl, [&](auto si, auto di, const bf16x8 ktf) {
+                constexpr int S = decltype(si)::value, D = decltype(di)::value;
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi)
+                    dqacc[qi][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qi][S], dqacc[qi][D], 0, 0, 0);
+            });
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -431,9 +637,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 }
 
 // ================================================================== backward: dK, dV
-// 1-D grid: kv block = blockIdx / (Hkv*N) ascending (block 0 sees every query tile under a causal mask: heaviest
-// first), kv heads fastest.  Wave w owns keys kv0 + 16w .. +15 and loops over 64-query tiles (and over the
-// H/Hkv query heads sharing this kv head).
+// 1-D grid (kv_block_of): the key blocks of a kv head ascending (block 0 sees every query tile under a causal mask: heaviest
+// first).  Wave w owns keys kv0 + 16w .. +15 and loops over 64-query tiles (and over the H/Hkv query heads sharing this kv head).
 //   S[q][kv] = Q K^T, dP[q][kv] = dO V^T          (lane: kv = lane&15, q = 16qb + 4g + r)
 //   dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]
 template <int HD>
@@ -444,11 +649,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     float* stat = reinterpret_cast<float*>(smem + 4 * TILE_B);
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int HkN = p.Hkv * p.N;
-    const int hn = blockIdx.x % HkN;
-    const int n = hn / p.Hkv, hk = hn % p.Hkv;
     const int group = p.H / p.Hkv;
-    const int kv0 = (blockIdx.x / HkN) * 64, kvw = kv0 + wave * 16;
+    int n, hk, kvb;
+    kv_block_of(p, (p.T + 63) / 64, n, hk, kvb);
+    const int kv0 = kvb * 64, kvw = kv0 + wave * 16;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
     const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
@@ -458,6 +662,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     const int kvg = kvw + l15;
     DmaLane<HD, 64, 4> dma;
     dma.init(wave, lane);
+    const auto qoff = dma.offsets(p.ldq), dooff = dma.offsets(p.lddo);
+    const int lds0 = (int)(uintptr_t)smem;
+    const int trl = tr_lane_base<HD>(g, l15);
 
     bf16x8 kf[KS], vf[KS];
     {
@@ -477,18 +684,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     const int total = ntq * group;  // iteration = (head in group, q tile)
     const bool kv_valid_block = kv0 + 63 >= start;  // some key of this block can be attended
 
+    // The tile's 64 LSE and 64 delta values travel by DMA as well (wave 0 / wave 1, one dword per lane): a register round trip
+    // would put `s_waitcnt vmcnt(0)` -- the whole prefetch -- in front of the ds_write at the top of every iteration.
     auto issue = [&](int it, int buf) {
         const int hh = hk * group + it / ntq;
         const int qt0 = q_begin + (it % ntq) * 64;
         const bf16_t* Qb = p.Q + (long)n * T * p.ldq + hh * HD;
         const bf16_t* dOb = p.dO + (long)n * T * p.lddo + hh * HD;
-        dma.issue(Qb, p.ldq, qt0, T, smem + buf * 2 * TILE_B);
-        dma.issue(dOb, p.lddo, qt0, T, smem + buf * 2 * TILE_B + TILE_B);
-        if (threadIdx.x < 128) {
-            const int i = threadIdx.x & 63;
-            const int qr = min(qt0 + i, T - 1);
-            const long idx = ((long)n * p.H + hh) * T + qr;
-            stat[buf * 128 + threadIdx.x] = (threadIdx.x < 64) ? p.lse[idx] * LOG2E_F : p.delta[idx];
+        dma.issue(Qb, p.ldq, qoff, qt0, T, lds0 + buf * 2 * TILE_B);
+        dma.issue(dOb, p.lddo, dooff, qt0, T, lds0 + buf * 2 * TILE_B + TILE_B);
+        if (wave < 2) {
+            const long idx = ((long)n * p.H + hh) * T + min(qt0 + lane, T - 1);
+            const float* src = (wave == 0 ? p.lse : p.delta) + idx;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+                         :: "s"(lds0 + 4 * TILE_B + buf * 512 + wave * 256), "v"(src) : "memory");
         }
     };
 
@@ -518,32 +727,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
                 }
             const bool need_mask = (p.causal && qt0 < kvw + 15) || kvw < start || kvw + 16 > KT || qt0 + 64 > T;
             bf16x8 pfr[2], dsfr[2];
-            f32x4 pv[4], dsv[4];
+            // P and dS of the 64 x 16 block; the rows' statistics come as 16-byte LDS reads (q = 16 qb + 4 g + r)
+            auto softmax_bwd = [&](auto masked) {
+                f32x4 pv[4], dsv[4];
 #pragma unroll
-            for (int qb = 0; qb < 4; ++qb)
+                for (int qb = 0; qb < 4; ++qb) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(st + qb * 16 + g * 4);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(st + 64 + qb * 16 + g * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ql = qb * 16 + g * 4 + r;
-                    float pe = fast_exp2(sacc[qb][r] * c2 - st[ql]);
-                    if (need_mask) {
-                        const int qg = qt0 + ql;
-                        const bool ok = kvg >= start && kvg < KT && qg < T && (!p.causal || kvg <= qg);
-                        pe = ok ? pe : 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        float l2;       // lse * log2(e) rounded on its own (as when it was pre-scaled into LDS), never contracted into the fma below
+                        asm("v_mul_f32 %0, %1, %2" : "=v"(l2) : "v"(l4[r]), "v"(LOG2E_F));
+                        float pe = fast_exp2(sacc[qb][r] * c2 - l2);
+                        if constexpr (decltype(masked)::value) {
+                            const int qg = qt0 + qb * 16 + g * 4 + r;
+                            const bool ok = kvg >= start && kvg < KT && qg < T && (!p.causal || kvg <= qg);
+                            pe = ok ? pe : 0.f;
+                        }
+                        pv[qb][r] = pe;
+                        dsv[qb][r] = pe * (dpacc[qb][r] - d4[r]) * p.scale;
                     }
-                    pv[qb][r] = pe;
-                    dsv[qb][r] = pe * (dpacc[qb][r] - st[64 + ql]) * p.scale;
                 }
-            pfr[0] = pack_bf16x8(pv[0], pv[1]); pfr[1] = pack_bf16x8(pv[2], pv[3]);
-            dsfr[0] = pack_bf16x8(dsv[0], dsv[1]); dsfr[1] = pack_bf16x8(dsv[2], dsv[3]);
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const bf16x8 dot_f = lds_tr_pair<HD>(dot, s * 32, s * 32 + 16, db, g, l15);
-                    const bf16x8 qt_f = lds_tr_pair<HD>(qt, s * 32, s * 32 + 16, db, g, l15);
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr[s], dvacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsfr[s], dkacc[db], 0, 0, 0);
-                }
+                pfr[0] = pack_bf16x8(pv[0], pv[1]); pfr[1] = pack_bf16x8(pv[2], pv[3]);
+                dsfr[0] = pack_bf16x8(dsv[0], dsv[1]); dsfr[1] = pack_bf16x8(dsv[2], dsv[3]);
+            };
+            if (need_mask) softmax_bwd(std::true_type{}); else softmax_bwd(std::false_type{});
+            // dV^T += dO^T P, dK^T += Q^T dS: the transposed Q / dO fragments by inline asm (tr_stream)
+            tr_stream<HD, 2, 0, TILE_B, TR_NBUF_KV>(lds0 + cur * 2 * TILE_B + trl, [&](auto si, auto di, const bf16x8 qt_f, const bf16x8 dot_f) {
+                constexpr int S = decltype(si)::value, D = decltype(di)::value;
+                dvacc[D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr[S], dvacc[D], 0, 0, 0);
+                dkacc[D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsfr[S], dkacc[D], 0, 0, 0);
+            });
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -168,7 +168,8 @@ static long ws_bytes_for(int rows, int chunk, int h, int dtype, int backward) {
     const long el = dtype == 0 ? 2 : 4;
     long b = (long)rows * chunk * el;
     b = (b + 255) / 256 * 256;
-    b += backward ? (long)rows * h * 4 : (long)rows * 256 * 8 + (long)rows * 4;
+    // backward: fp32 d_hidden accumulator + a zero-padded copy of the last (V mod K-granule) weight rows (ragged vocabularies)
+    b += backward ? (long)rows * h * 4 + 64L * h * 4 : (long)rows * 256 * 8 + (long)rows * 4;
     return b;
 }
 extern "C" int aa_lmhead_logprob_ws_bytes(int rows, int chunk, int h, int dtype, int backward, long* bytes_out) {
@@ -219,7 +220,7 @@ extern "C" int aa_lmhead_logprob_bwd(const void* hidden, long ldh, const void* W
     AA_REQUIRE(dtype == 0 || dtype == 1, "aa_lmhead_logprob_bwd: dtype must be 0 (bf16) or 1 (f32)");
     AA_REQUIRE(rows >= 0 && V > 0 && h > 0 && ldh >= h && ldw >= h && lddh >= h, "aa_lmhead_logprob_bwd: bad shape rows=%d V=%d h=%d", rows, V, h);
     AA_REQUIRE(chunk > 0 && chunk % 2048 == 0, "aa_lmhead_logprob_bwd: chunk=%d must be a positive multiple of 2048", chunk);
-    AA_REQUIRE(V % 64 == 0 && h % 4 == 0, "aa_lmhead_logprob_bwd: V=%d must be a multiple of 64 (it is the contraction of d_hidden) and h=%d of 4", V, h);
+    AA_REQUIRE(V % 4 == 0 && h % 4 == 0, "aa_lmhead_logprob_bwd: V=%d and h=%d must be multiples of 4", V, h);
     AA_REQUIRE(dtype == 0 || !dW || dw_f32, "aa_lmhead_logprob_bwd: fp32 operands need an fp32 dW");
     AA_REQUIRE(ws && ws_bytes >= ws_bytes_for(rows, chunk, h, dtype, 1),
                "aa_lmhead_logprob_bwd: scratch too small (%ld bytes, need %ld)", ws_bytes, ws_bytes_for(rows, chunk, h, dtype, 1));
@@ -228,6 +229,8 @@ extern "C" int aa_lmhead_logprob_bwd(const void* hidden, long ldh, const void* W
     const long el = dtype == 0 ? 2 : 4;
     const long chunk_bytes = ((long)rows * chunk * el + 255) / 256 * 256;
     float* dh32 = (float*)((char*)ws + chunk_bytes);
+    char* wtail = (char*)ws + chunk_bytes + (long)rows * h * 4;      // [KG, h] zero-padded tail rows of W
+    const int KG = dtype == 0 ? 64 : 16;                              // contraction granule of aa_gemm_bf16 / aa_gemm_f32
     if (hipMemsetAsync(dh32, 0, (size_t)rows * h * 4, st) != hipSuccess) {
         aa_set_error("aa_lmhead_logprob_bwd: hipMemsetAsync failed");
         return AA_ERR_LAUNCH;
@@ -244,8 +247,28 @@ extern "C" int aa_lmhead_logprob_bwd(const void* hidden, long ldh, const void* W
             hipLaunchKernelGGL(lmhead_dlogits_chunk_kernel<float>, dim3(rows), dim3(256), 0, st, (float*)ws, (long)chunk, labels,
                                lse, dlogp, c0, vc);
         AA_CHECK_LAUNCH("aa_lmhead_logprob_bwd");
-        rc = gemm_any(dtype, ws, Wc, dh32, rows, h, vc, chunk, ldw, h, AA_GEMM_B_N | AA_GEMM_OUT_F32 | AA_GEMM_ACCUM, stream);
-        if (rc != AA_OK) return rc;
+        // d_hidden += dlogits_chunk @ W_chunk: contraction over the chunk's vocabulary columns.  A ragged vocabulary (OPT: 50272 =
+        // 64 x 785 + 32) leaves a last piece shorter than the GEMM's K granule: it runs as one granule against a zero-padded copy
+        // of those weight rows, with the dlogits columns past the vocabulary zeroed in the scratch chunk.
+        const int tail = vc % KG, vc_main = vc - tail;
+        if (vc_main) {
+            rc = gemm_any(dtype, ws, Wc, dh32, rows, h, vc_main, chunk, ldw, h, AA_GEMM_B_N | AA_GEMM_OUT_F32 | AA_GEMM_ACCUM, stream);
+            if (rc != AA_OK) return rc;
+        }
+        if (tail) {
+            hipError_t e = hipMemset2DAsync((char*)ws + (long)vc * el, (size_t)chunk * el, 0, (size_t)(KG - tail) * el, rows, st);
+            if (e == hipSuccess) e = hipMemsetAsync(wtail, 0, (size_t)KG * h * el, st);
+            if (e == hipSuccess)
+                e = hipMemcpy2DAsync(wtail, (size_t)h * el, Wc + (long)vc_main * ldw * el, (size_t)ldw * el, (size_t)h * el, tail,
+                                     hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) {
+                aa_set_error("aa_lmhead_logprob_bwd: staging the ragged vocabulary tail failed: %s", hipGetErrorString(e));
+                return AA_ERR_LAUNCH;
+            }
+            rc = gemm_any(dtype, (char*)ws + (long)vc_main * el, wtail, dh32, rows, h, KG, chunk, h, h,
+                          AA_GEMM_B_N | AA_GEMM_OUT_F32 | AA_GEMM_ACCUM, stream);
+            if (rc != AA_OK) return rc;
+        }
         if (dW) {
             const long del = dw_f32 ? 4 : 2;
             rc = gemm_any(dtype, ws, hidden, (char*)dW + (long)c0 * lddw * del, vc, h, rows, chunk, ldh, lddw,

@@ -44,6 +44,10 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.handles = []
         self.comm_stream = None
+        # AA_COMM_PROF=1 (bench.py --comm-prof): HIP events on the communication stream around every bucket, so a run on real xGMI
+        # reports how long each all-reduce took from "bucket ready" to "reduced" next to the backward it overlaps with
+        self.prof = os.environ.get('AA_COMM_PROF', '0') == '1'
+        self.records = []          # (bytes, ready event, done event) per bucket since the last report()
 
     def reduce_async(self, flat_slice: torch.Tensor):
         if self.world == 1 or flat_slice.numel() == 0:
@@ -51,11 +55,16 @@ class GradReducer:
         if flat_slice.is_cuda:
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream()
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.prof)
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 h = dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.prof:
+                    h.wait()       # stream-side join only: the communication stream (not the host) waits for the collective
+                    done = torch.cuda.Event(enable_timing=True)
+                    done.record(self.comm_stream)
+                    self.records.append((flat_slice.numel() * flat_slice.element_size(), ev, done))
             self.handles.append(h)
         else:
             self.handles.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -66,6 +75,23 @@ class GradReducer:
         self.handles = []
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def report(self) -> dict:
+        """Profiling mode: per-bucket milliseconds from "gradient slice ready" to "all-reduce finished" (queueing behind earlier
+        buckets included) and the bus bandwidth a ring all-reduce of that size implies; clears the records.  Synchronises."""
+        if not self.records:
+            return {'buckets': 0}
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for _, a, b in self.records]
+        nbytes = [n for n, _, _ in self.records]
+        span = self.records[0][1].elapsed_time(self.records[-1][2])
+        out = {'buckets': len(ms), 'bytes_total': int(sum(nbytes)), 'bucket_ms_sum': sum(ms), 'bucket_ms_max': max(ms),
+               'first_ready_to_last_done_ms': span,
+               # ring all-reduce moves 2 (w-1)/w of the message over every link
+               'busbw_GBps_over_span': 2.0 * (self.world - 1) / self.world * sum(nbytes) / max(span, 1e-6) / 1e6,
+               'largest_bucket': {'bytes': int(max(nbytes)), 'ms': ms[nbytes.index(max(nbytes))]}}
+        self.records = []
+        return out
 
 
 class NativeEngine:
@@ -197,7 +223,12 @@ class NativeEngine:
                 done.add(rng)
 
         hook = on_layer_done if (self.world > 1 and boundary) else None
+        if self.reducer.prof and self.module.device.type == 'cuda':
+            self._bwd_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._bwd_ev[0].record()
         self.module.backward_from_dlogp(self._pending, hook)
+        if self.reducer.prof and self.module.device.type == 'cuda':
+            self._bwd_ev[1].record()
         self._pending = None
         st.accumulate = False
         self.micro_steps += 1
@@ -273,6 +304,36 @@ class NativeEngine:
         if self._opt_done is not None:
             torch.cuda.current_stream().wait_event(self._opt_done)
             self._opt_done = None
+
+    def comm_report(self) -> dict:
+        """AA_COMM_PROF=1: the last backward's duration next to the gradient buckets it overlapped with (GradReducer.report)."""
+        rep = self.reducer.report()
+        ev = getattr(self, '_bwd_ev', None)
+        if ev is not None:
+            torch.cuda.synchronize()
+            rep['backward_ms'] = ev[0].elapsed_time(ev[1])
+        return rep
+
+    def replica_checksum(self) -> torch.Tensor:
+        """Order-sensitive 64-bit checksum of every replicated weight group (bf16 / fp32 bit patterns as integers), one int64 per
+        group: pure data parallelism keeps the replicas bit-identical (same all-reduced gradients, deterministic clip norm and
+        AdamW), so all ranks must agree on it after any number of steps.  Expert-parallel shards ('exp') differ by design."""
+        self.wait_optimizer()
+        st = self.module.store
+        sums = []
+        for g in sorted(st.flat):
+            if g == 'exp':
+                continue
+            t = st.flat[g].view(-1)
+            t = t.view(torch.int16 if t.element_size() == 2 else torch.int32)
+            acc = torch.zeros((), dtype=torch.int64, device=t.device)
+            CH = 1 << 24                                   # bounded temporaries: 3 x 128 MB per chunk
+            w = (torch.arange(CH, device=t.device, dtype=torch.int64) % 8191) + 1
+            for lo in range(0, t.numel(), CH):
+                v = t[lo:lo + CH].to(torch.int64)
+                acc += (v * w[:v.numel()]).sum() * (1 + (lo // CH) % 127)
+            sums.append(acc)
+        return torch.stack(sums)
 
     def grad_norm(self) -> float:
         self.wait_optimizer()

@@ -167,6 +167,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-events', action='store_true')
     ap.add_argument('--gemm-event-stride', type=int, default=1, help='time every k-th GEMM launch with HIP events (1 = all)')
+    ap.add_argument('--comm-prof', action='store_true',
+                    help='N>1: after the timed region run ONE extra untimed step with HIP events around every gradient bucket '
+                         '(all-reduce time vs the backward it overlaps with) and add it to the JSON line as "comm"')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -264,6 +267,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
+    # N>1, outside the timed region: (1) the replicas must still be bit-identical after warmup + steps optimizer updates (pure DP:
+    # identical all-reduced gradients, deterministic clip norm and AdamW); (2) optionally one extra step with events on the
+    # communication stream, to put numbers on the bucket / backward overlap the first time this runs on real xGMI
+    multi = None
+    if world > 1:
+        mine = tr.model.replica_checksum()
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        same = all(bool(torch.equal(c, allc[0])) for c in allc)
+        multi = {'backend': dist.get_backend(), 'world': world, 'replicas_bit_identical_after_steps': same,
+                 'optimizer_updates_checked': tr.model.global_steps}
+        if not same:
+            print(f'[bench] rank {rank}: REPLICAS DIVERGED: {[c.tolist() for c in allc]}', file=sys.stderr, flush=True)
+        if args.comm_prof:
+            tr.model.reducer.prof = True
+            tr.train_step(make_batch(cfg, B, T, R, device, seed=99 + rank))
+            multi['comm'] = tr.model.comm_report()
+            tr.model.reducer.prof = False
+
     if rank == 0:
         n_img = (cfg['vision']['image_size'] // cfg['vision']['patch_size']) ** 2
         fl_pair, _ = flops_per_pair(cfg, T, R, n_img)
@@ -324,6 +346,8 @@ def main():
                                'algorithmic_bytes_per_launch': sum(e[3] for e in gemm_events) / n,
                                'launches': n, 'launch_sampling': f'every {ops.GEMM_PROF_STRIDE}th GEMM launch of the timed steps', 'avg_launch_ms': tot_ms / n,
                                'avg_flops_per_launch': tot_fl / n, 'gemm_share_of_step_time': tot_ms / (dt * 1e3)}
+        if multi is not None:
+            out['multi_gpu'] = multi
         if not args.no_cpu_baseline and world == 1:
             try:
                 out['cpu_baseline'] = cpu_baseline(cfg, T)

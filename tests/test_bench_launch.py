@@ -33,7 +33,7 @@ def test_bench_two_ranks_functional_on_one_device():
     """`python bench.py --gpus 2` end to end (self-launch -> 2 ranks -> gradient buckets all-reduced -> one JSON line),
     reduced depth / length so it takes seconds; both ranks share cuda:0 and talk over gloo: a functional check only."""
     r = _run(['--gpus', '2', '--steps', '2', '--warmup', '1', '--layers', '1', '--seq-len', '1024', '--response-len', '128',
-              '--pairs-per-gpu', '1', '--no-cpu-baseline'], {'AA_BENCH_ONE_DEVICE': '1', 'AA_BENCH_BACKEND': 'gloo'}, 900)
+              '--pairs-per-gpu', '1', '--no-cpu-baseline', '--comm-prof'], {'AA_BENCH_ONE_DEVICE': '1', 'AA_BENCH_BACKEND': 'gloo'}, 900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(line) == 1, r.stdout[-2000:]
@@ -41,3 +41,7 @@ def test_bench_two_ranks_functional_on_one_device():
     assert out['n_gpus'] == 2 and out['config']['global_batch_pairs'] == 2 and out['config']['parallelism'] == 'dp2'
     assert out['value'] > 0 and all(abs(x - 0.6931) < 0.05 for x in out['config']['losses_timed_steps'])
     assert 'rank 0/2' in r.stderr and 'rank 1/2' in r.stderr and 'world_seen_by_collective=2' in r.stderr
+    # the replicas saw different batches, exchanged gradient buckets and must still hold bit-identical weights
+    mg = out['multi_gpu']
+    assert mg['world'] == 2 and mg['replicas_bit_identical_after_steps'] is True and mg['optimizer_updates_checked'] == 3
+    assert mg['comm']['buckets'] >= 2 and mg['comm']['bytes_total'] > 0 and mg['comm']['backward_ms'] > 0

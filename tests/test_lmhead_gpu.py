@@ -124,3 +124,32 @@ def test_policy_step_same_with_and_without_the_logits_buffer(monkeypatch):
         for k, g1 in out['1'][1].items():
             g0 = out['0'][1][k]
             assert_close(g1, g0, rtol=2e-2, atol=2e-2 * float(g0.abs().max()) + 1e-8, what=f'{fixture} {k}')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('rows,V,h,chunk', [(64, 50272, 768, 8192), (64, 2048 + 40, 128, 2048)])
+def test_ragged_vocabulary_backward(dtype, rows, V, h, chunk):
+    """OPT's vocabulary (50272 = 64 x 785 + 32) is not a multiple of the GEMM's contraction granule: the last piece of
+    d_hidden = dlogits @ W runs against a zero-padded copy of the tail rows.  Checked against plain fp32 torch math on the
+    same operands (tolerance: bf16 rounding of the logits / dlogits, 1e-5 relative for the fp32 twin)."""
+    from align_anything_amd import ops
+    hidden, w, labels = _case(rows, V, h, dtype, seed=V)
+    dlogp = torch.randn(rows, generator=torch.Generator().manual_seed(7)).to(dev())
+    lp, lse = ops.lmhead_logprob_fwd(hidden, w, labels, chunk=chunk)
+    gdt = torch.float32
+    dw = torch.zeros(V, h, dtype=gdt, device=dev())
+    dh = ops.lmhead_logprob_bwd(hidden, w, labels, lse, dlogp, dw=dw, chunk=chunk)
+    H, W = hidden.float(), w.float()
+    logits = H @ W.t()
+    if dtype == torch.bfloat16:
+        logits = logits.bfloat16().float()           # the kernels round the logits chunk to bf16 like the reference's bf16 lm_head
+    ref_lp = torch.log_softmax(logits, -1).gather(1, labels[:, None])[:, 0]
+    dlog = -torch.softmax(logits, -1) * dlogp[:, None]
+    dlog[torch.arange(rows), labels] += dlogp
+    if dtype == torch.bfloat16:
+        dlog = dlog.bfloat16().float()
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    assert_close(lp, ref_lp, rtol=tol, atol=tol, what='logp')
+    ref_dh, ref_dw = dlog @ W, dlog.t() @ H
+    assert_close(dh.float(), ref_dh, rtol=tol, atol=tol * float(ref_dh.abs().max()), what='d_hidden (ragged V)')
+    assert_close(dw, ref_dw, rtol=tol, atol=tol * float(ref_dw.abs().max()), what='dW (ragged V)')
