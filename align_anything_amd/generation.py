@@ -31,10 +31,24 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
         if max_length is None:
             raise ValueError('give max_length (GenerationConfig.max_length) or max_new_tokens')
         max_new_tokens = max_length - T
+    stack = model.stack
+    # Expert-parallel weights (expert_parallel.py): every decode position is a token exchange between ALL ranks, so the ranks must
+    # execute the same number of passes whatever their prompts and EOS positions are -- what `synced_gpus=True` does for the
+    # reference's ZeRO-3 rollouts (text_to_text/ppo.py:209-222).  The pass count is the maximum over the ranks; a rank whose own
+    # budget (max_length - its prompt length) is used up, or whose rows have all finished, keeps stepping on pad tokens, and the
+    # loop ends early only when NO rank has an unfinished row.
+    ep = getattr(stack, 'ep', None)
+    own_new = max_new_tokens
+    if ep is not None and ep.size > 1:
+        import torch.distributed as dist
+        cnt = torch.tensor([max(max_new_tokens, 0)], dtype=torch.int64, device=dev if not ep.host_staged else 'cpu')
+        dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=ep.group)
+        max_new_tokens = int(cnt.item())
+    else:
+        ep = None
     if max_new_tokens <= 0:
         return input_ids
     Tmax = T + max_new_tokens
-    stack = model.stack
     kvw = stack.kv_width()
     cache = [torch.zeros((N * Tmax, kvw), dtype=torch.bfloat16, device=dev) for _ in stack.layers]
 
@@ -99,7 +113,7 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
         st['tslot'].add_(1); st['pos'].add_(1); st['length'].add_(1); st['step'].add_(1)
 
     graph = None
-    if use_graph and max_new_tokens > 4:
+    if use_graph and max_new_tokens > 4 and ep is None:      # collectives cannot be captured: expert-parallel rollouts launch eagerly
         # everything the warm-up step mutates is restored afterwards: the decode state, the output and the repetition-penalty
         # marks (`seen`), so a token the warm-up happened to sample is not penalised for the whole rollout
         snap = {k: v.clone() for k, v in st.items() if v is not None and k != 'U'}
@@ -135,19 +149,32 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
     for step in range(max_new_tokens):
         if step + 1 == max_new_tokens:
             # final token: selection only
+            if ep is not None and step >= own_new:
+                st['unfinished'].zero_()
             st['nact'].add_(st['unfinished'].any().to(torch.int64))
             nxt = select(st['logits'], st['U'][step] if do_sample else None)
             nxt = torch.where(st['unfinished'], nxt, padv)
             out[:, T + step] = nxt
             n_new = step + 1
             break
+        if ep is not None and step >= own_new:
+            st['unfinished'].zero_()                            # this rank's own length cap: its rows only pad from here on
         if graph is not None:
             graph.replay()
         else:
             one_step()
         n_new = step + 1
-        if eos >= 0 and (step % sync_every == sync_every - 1) and not bool(st['unfinished'].any()):
-            break
+        if eos >= 0 and (step % sync_every == sync_every - 1):
+            if ep is None:
+                if not bool(st['unfinished'].any()):
+                    break
+            else:                                               # stop only when every rank is done (same decision on every rank)
+                flag = st['unfinished'].any().to(torch.int32).reshape(1)
+                flag = flag.cpu() if ep.host_staged else flag
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ep.group)
+                if int(flag.item()) == 0:
+                    break
+    n_new = min(n_new, max(own_new, 0))
     seq = out[:, :T + n_new]
     if eos_token_id is not None:
         # HF stops at the step in which the last unfinished row emitted its EOS: keep exactly the columns of steps that still had

@@ -1359,10 +1359,13 @@ class Qwen3MoeStack:
     def _experts(self, L, n2, x_mid, rows):
         """Sparse MoE block without saved state (prefill of big batches / decode beyond a handful of rows): the training layout."""
         c, P = self.cfg, self.store.p
-        if self.ep is not None:
-            raise NotImplementedError('rollout decode with expert-parallel weights is not built: generate on a replica that holds all experts')
         logits = L['gate'].fwd(n2) if n2.shape[0] > 16 else ops.linear_small(n2, L['gate'].w)
         _, idx, w = ops.moe_route(logits, c['num_experts_per_tok'], c['norm_topk_prob'])
+        if self.ep is not None:
+            # expert-parallel weights: the routed rows travel to the ranks that own their experts and back, exactly as in the
+            # training forward (one exchange per block; during a rollout that is one per decode position, with every rank
+            # stepping in lockstep -- generation.py keeps the ranks' step counts equal)
+            return self._ep_experts_fwd(L, n2, x_mid, idx, w, rows)[0]
         plan = ops.moe_plan(idx, c['num_experts'])
         zeros = lambda n: torch.zeros((plan['cap'], n), dtype=n2.dtype, device=n2.device)
         gu = ops.gemm_grouped(ops.moe_gather(n2, plan['src']), P[L['gu']], plan, out=zeros(P[L['gu']].shape[1]))
@@ -1377,8 +1380,6 @@ class Qwen3MoeStack:
         H, Hkv, hd, eps, E, k = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps'], c['num_experts'], c['num_experts_per_tok']
         qw, kw = H * hd, Hkv * hd
         N = x.shape[0]
-        if self.ep is not None:
-            raise NotImplementedError('rollout decode with expert-parallel weights is not built: generate on a replica that holds all experts')
         self._tables(Tmax)
         rows = torch.arange(N, device=x.device)
         ident = torch.arange(N * k, dtype=torch.int32, device=x.device).view(N, k)
@@ -1395,7 +1396,7 @@ class Qwen3MoeStack:
             attn = ops.attn_decode(qn, cl, cl[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
             x_mid = ops.linear_small(attn, L['o'].w, residual=x)
             n2, _ = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
-            if N > 16 or N * k > 2 * E:
+            if self.ep is not None or N > 16 or N * k > 2 * E:      # expert-parallel: the experts are not all here, rows travel
                 x = self._experts(L, n2, x_mid, N)
                 continue
             _, idx, w = ops.moe_route(ops.linear_small(n2, L['gate'].w), k, c['norm_topk_prob'])

@@ -200,3 +200,15 @@ def compute_dtype(name):
     if str(name).lower() not in table:
         raise ValueError(f'compute dtype {name!r} not supported (bf16, fp32)')
     return table[str(name).lower()]
+
+
+def expert_parallel_kwargs(cfgs, *model_cfgs) -> dict:
+    """`train_cfgs.expert_parallel: true` on a sparse-MoE backbone: the experts are split over the data-parallel ranks
+    (expert_parallel.py).  Returns the `build_model` keyword for every model of the trainer -- ONE ExpertParallel on a communicator of
+    its own (the token exchange never queues behind a gradient bucket), shared by the trainer's models, which run one after the other in
+    the same order on every rank -- or {} when the flag is off / the backbones are dense."""
+    if not bool(cfg_get(cfgs, 'train_cfgs.expert_parallel', False)) or not any(c is not None and c.get('kind') == 'qwen3moe' for c in model_cfgs):
+        return {}
+    import torch.distributed as dist
+    from ..expert_parallel import ExpertParallel
+    return {'ep': ExpertParallel(dist.new_group())}

@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import build_span_window, cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad_rows
+from .common import build_span_window, cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad_rows, expert_parallel_kwargs
 
 
 class GRPOTrainer:
@@ -31,8 +31,12 @@ class GRPOTrainer:
         self.eos_token_id = int(cfg_get(cfgs, 'model_cfgs.eos_token_id', 2))
         self.reward_fn = reward_fn
         dt = compute_dtype(t('compute_dtype', 'bf16'))   # fp32 = parity mode (sequences / rewards must then be injected)
-        actor = build_model(model_cfg, device, trainable=True, dtype=dt)
-        ref = build_model(model_cfg, device, trainable=False, dtype=dt)
+        # train_cfgs.expert_parallel (Qwen3-MoE, BASELINE configs[4]): actor, reference and reward model hold 1/world of the experts;
+        # the rollout then exchanges tokens per decode position with every rank stepping in lockstep (generation.py)
+        epk = expert_parallel_kwargs(cfgs, model_cfg)
+        rpk = epk if (reward_model_cfg or model_cfg).get('kind') == 'qwen3moe' else {}
+        actor = build_model(model_cfg, device, trainable=True, dtype=dt, **epk)
+        ref = build_model(model_cfg, device, trainable=False, dtype=dt, **epk)
         if actor_state is not None:
             actor.load_state_dict(actor_state)
         if reference_state is not None or actor_state is not None:
@@ -50,7 +54,7 @@ class GRPOTrainer:
         self.actor_reference_model = NativeEngine(ref, trainable=False)
         self.reward_model = None
         if reward_fn is None:
-            reward = build_model(reward_model_cfg or model_cfg, device, trainable=False, head='score', dtype=dt)
+            reward = build_model(reward_model_cfg or model_cfg, device, trainable=False, head='score', dtype=dt, **rpk)
             if reward_state is not None:
                 reward.load_state_dict(reward_state)
             self.reward_model = NativeEngine(reward, trainable=False)

@@ -58,7 +58,8 @@ def gather_log_probabilities(logits: torch.Tensor, labels: torch.Tensor) -> torc
 
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import build_span_window, cfg_get, compute_dtype, end_index, get_all_reduce_max, get_all_reduce_mean, pad_rows
+from .common import (build_span_window, cfg_get, compute_dtype, end_index, expert_parallel_kwargs, get_all_reduce_max,
+                     get_all_reduce_mean, pad_rows)
 
 
 class PPOTrainer(PPOMath):
@@ -79,11 +80,13 @@ class PPOTrainer(PPOMath):
         self.ptx_coeff = float(t('ptx_coeff', 16.0))        # configs/train/text_to_text/ppo.yaml:71
         rcfg = reward_model_cfg or model_cfg
         dt = compute_dtype(t('compute_dtype', 'bf16'))   # fp32 = parity mode for the update phase (rollouts need bf16)
-        actor = build_model(model_cfg, device, trainable=True, dtype=dt)
-        ref = build_model(model_cfg, device, trainable=False, dtype=dt)
+        epk = expert_parallel_kwargs(cfgs, model_cfg)            # train_cfgs.expert_parallel on a Qwen3-MoE actor (see trainers/grpo.py)
+        actor = build_model(model_cfg, device, trainable=True, dtype=dt, **epk)
+        ref = build_model(model_cfg, device, trainable=False, dtype=dt, **epk)
         self.reward_fn = reward_fn
-        reward = build_model(rcfg, device, trainable=False, head='score', dtype=dt) if reward_fn is None else None
-        critic = build_model(rcfg, device, trainable=True, head='score', dtype=dt)
+        rpk = epk if rcfg.get('kind') == 'qwen3moe' else {}
+        reward = build_model(rcfg, device, trainable=False, head='score', dtype=dt, **rpk) if reward_fn is None else None
+        critic = build_model(rcfg, device, trainable=True, head='score', dtype=dt, **rpk)
         if actor_state is not None:
             actor.load_state_dict(actor_state)
             ref.load_state_dict(actor_state)

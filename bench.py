@@ -15,7 +15,7 @@ boundary hands over device tensors): the CLIP tower, the response-window plan an
 the timed region for every step -- nothing is cached across steps, and the loss stays at its random-data level.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the bf16 MFMA GEMM, measured with
-HIP events around every GEMM launch of the timed steps), `step_mfma` (whole-step MFMA fraction on the FLOPs the step
+HIP event pairs around a 1-in-11 sample of the GEMM launches of the timed steps), `step_mfma` (whole-step MFMA fraction on the FLOPs the step
 EXECUTES, with SURVEY.md's algorithmic figure beside it) and `cpu_baseline` (the CPU oracle port, bounded sample).
 """
 from __future__ import annotations
@@ -166,7 +166,11 @@ def main():
     ap.add_argument('--layers', type=int, default=32, help='LLM depth (32 = LLaVA-1.5-7B; anything else is NOT the headline config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-events', action='store_true')
-    ap.add_argument('--gemm-event-stride', type=int, default=1, help='time every k-th GEMM launch with HIP events (1 = all)')
+    ap.add_argument('--gemm-event-stride', type=int, default=11,
+                    help='time every k-th GEMM launch of the timed steps with a HIP event pair (1 = all).  An event pair isolates its launch from '
+                         'its neighbours (no tail / head overlap with the next kernel): around EVERY launch that costs the one-wave-per-SIMD '
+                         'GEMMs 6.5 %% of the step (806 vs 754 ms, same box), so the default samples every 11th launch -- made coprime to the '
+                         'launches per step, hence unbiased over the shapes -- which costs < 1 %%')
     ap.add_argument('--comm-prof', action='store_true',
                     help='N>1: after the timed region run ONE extra untimed step with HIP events around every gradient bucket '
                          '(all-reduce time vs the backward it overlaps with) and add it to the JSON line as "comm"')
@@ -239,10 +243,11 @@ def main():
     if not args.no_gemm_events:                     # ... and create every event the timed region will record up front
         per_step = len(ops.GEMM_PROF) if ops.GEMM_PROF else 600
         ops.GEMM_PROF = None
-        # same-box A/B (profiles/README.md): events around every launch cost ~0.4 % of the step once they are pre-created;
-        # --gemm-event-stride k samples every k-th launch instead (default 1 = every launch, no sampling bias)
-        ops.GEMM_PROF_STRIDE = args.gemm_event_stride
-        while ops.GEMM_PROF_STRIDE > 1 and per_step % ops.GEMM_PROF_STRIDE == 0:
+        # --gemm-event-stride k: every k-th launch carries an event pair (see the flag's help); k is bumped until it shares no factor
+        # with the number of GEMM launches per step, so successive steps sample different launches and every shape gets its share
+        import math
+        ops.GEMM_PROF_STRIDE = max(1, args.gemm_event_stride)
+        while ops.GEMM_PROF_STRIDE > 1 and math.gcd(per_step, ops.GEMM_PROF_STRIDE) != 1:
             ops.GEMM_PROF_STRIDE += 1
         ops.event_pool_fill(2 * (per_step * args.steps // ops.GEMM_PROF_STRIDE + 8) + 64)
     barrier()

@@ -45,6 +45,44 @@ def run(z, dtype, rank):
     return {'info': info, 'grads': grads, 'state': sd, 'grad_norm': gn}
 
 
+def rollout(z, rank):
+    """Greedy rollout with expert-parallel weights (token exchange per decode position, ranks in lockstep) == the same rollout on a
+    replica holding all experts.  The ranks get prompts of DIFFERENT lengths under one max_length (so their own step budgets differ)
+    and, in the second run, an EOS that ends rank-local rows early: the pass count must still agree on every rank."""
+    from align_anything_amd.expert_parallel import ExpertParallel
+    from align_anything_amd.generation import generate
+    from align_anything_amd.modeling import build_model
+    cfg = tiny_qwen3moe_cfg()
+    sd = state_dict_from_golden(z, 'w.', torch.bfloat16)
+    ep_model = build_model(cfg, 'cuda:0', trainable=False, ep=ExpertParallel(dist.new_group()))
+    ep_model.load_state_dict(sd)
+    full = build_model(cfg, 'cuda:0', trainable=False)
+    full.load_state_dict(sd)
+    L = 10 if rank == 0 else 14
+    ids = torch.from_numpy(z['input_ids'])[[rank, rank + 2], :L].clone().cuda()
+    am = torch.ones_like(ids)
+    am[1, :2] = 0                                            # a left-padded row
+    ids[1, :2] = int(z['pad_token_id'])
+    kw = dict(max_length=24, do_sample=False, pad_token_id=int(z['pad_token_id']))
+    rep = {}
+    want = generate(full, ids, am, eos_token_id=None, **kw)
+    got = generate(ep_model, ids, am, eos_token_id=None, **kw)
+    rep['no_eos'] = (tuple(got.shape), tuple(want.shape), bool(torch.equal(got, want)))
+    eos = int(want[0, L + 2])                                # ends row 0 at its third new token (other rows: whenever they emit it)
+    want = generate(full, ids, am, eos_token_id=eos, sync_every=2, **kw)
+    got = generate(ep_model, ids, am, eos_token_id=eos, sync_every=2, **kw)
+    rep['eos'] = (tuple(got.shape), tuple(want.shape), bool(torch.equal(got, want)))
+    # the trainers' flag: a GRPO trainer with train_cfgs.expert_parallel builds sharded actor / reference / reward models and rolls out
+    from align_anything_amd.trainers.grpo import GRPOTrainer
+    cfgs = {'train_cfgs': {'expert_parallel': True, 'num_generations': 2, 'actor_lr_scheduler_type': 'constant'},
+            'model_cfgs': {'pad_token_id': int(z['pad_token_id']), 'eos_token_id': eos, 'model_max_length': 20}}
+    tr = GRPOTrainer(cfgs, {}, model_cfg=cfg, actor_state=sd, reward_fn=lambda completions: torch.zeros(completions.shape[0]), device='cuda:0')
+    assert tr.actor_model.module.ep is not None and tr.actor_reference_model.module.ep is not None
+    seqs = tr.generate_completions({'input_ids': ids, 'attention_mask': am}, generator=torch.Generator(device='cuda').manual_seed(5 + rank))
+    rep['grpo_rollout_rows'] = int(seqs.shape[0])
+    return rep
+
+
 def main():
     out = sys.argv[1]
     rank = int(os.environ['RANK'])
@@ -52,11 +90,14 @@ def main():
     dist.init_process_group('gloo')
     z = load_golden('qwen3moe_tiny_dpo.npz')
     res = {dt: run(z, dt, rank) for dt in ('fp32', 'bf16')}
+    rolls = [None, None]
+    dist.all_gather_object(rolls, rollout(z, rank))
     sums = [None, None]
     dist.all_gather_object(sums, {dt: (r['grad_norm'], float(r['state']['model.norm.weight'].double().sum()),
                                        float(r['state']['model.layers.1.mlp.experts.down_proj'].double().sum())) for dt, r in res.items()})
     if rank == 0:
         assert sums[0] == sums[1], f'ranks disagree on clip norm / replicated weights after the step: {sums}'
+        res['rollout'] = rolls
         torch.save(res, out)
     dist.barrier()
     dist.destroy_process_group()

@@ -385,6 +385,20 @@ def _ep_worker(rank, world, port, q):
     ok = ok and 'train/loss' in info and 'aa_gemm_grouped_bf16' in seen and seen.count('aa_moe_plan') == 2 * 2 * 2      # (dense + local plan) x 2 layers x (policy + reference)
     sd = tr.policy.state_dict()                                            # collective: expert rows gathered back
     ok = ok and sd['model.layers.1.mlp.experts.down_proj'].shape[0] == 8
+    # rollout on the sharded weights: one token exchange per decode position, so the ranks must run the SAME number of passes although
+    # their prompts (hence their own budgets under one max_length) differ: 24 - 10 = 14 new tokens on rank 0, 24 - 16 = 8 on rank 1
+    from align_anything_amd.generation import generate
+    L = 10 if rank == 0 else 16
+    ids, mask = T(z['input_ids'])[rows, :L], T(z['attention_mask'])[rows, :L]
+    del seen[:]
+    seq = generate(tr.policy, ids, mask, max_length=24, do_sample=False, pad_token_id=int(z['pad_token_id']))
+    passes = seen.count('aa_attn_decode')
+    ok = ok and seq.shape == (2, 24) and passes == 13 * 2                  # 14 positions -> 13 decode passes x 2 layers, on BOTH ranks
+    del seen[:]
+    generate(tr.policy, ids, mask, max_length=24, do_sample=False, eos_token_id=7, sync_every=2, pad_token_id=int(z['pad_token_id']))
+    both = [None] * world
+    dist.all_gather_object(both, seen.count('aa_attn_decode'))              # whatever the (garbage) tokens did, the ranks stopped together
+    ok = ok and len(set(both)) == 1
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

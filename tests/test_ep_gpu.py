@@ -71,4 +71,11 @@ def test_two_rank_expert_parallel_step_equals_single_rank(tmp_path):
                 assert (d < 1e-4).float().mean().item() > 0.97, (name, (d < 1e-4).float().mean().item())
         rep.append(f'{dtype}: loss ep {e["info"]["train/loss"]:.6f} single {info["train/loss"]:.6f}; clip norm ep {e["grad_norm"]:.6f} single {gnorm:.6f}; '
                    f'worst gradient rel_err {worst:.2e} over {n} tensors ({n_exp} expert tensors)')
+    # rollout under expert parallelism (generation.py: lockstep passes, token exchange per position) == the all-experts rollout
+    for r, roll in enumerate(ep['rollout']):
+        for key in ('no_eos', 'eos'):
+            got_shape, want_shape, same = roll[key]
+            assert same and got_shape == want_shape, (r, key, roll)
+        assert roll['grpo_rollout_rows'] == 4
+        rep.append(f'rank {r}: expert-parallel greedy rollout == all-experts rollout, shapes {roll["no_eos"][0]} / with EOS {roll["eos"][0]}')
     dump('parity_expert_parallel.txt', '\n'.join(rep) + '\n')

@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export PYTHONPATH=$PWD
 R=$PWD
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee gpurun_out/art_tests.log
+timeout 1500 python -m pytest tests -m gpu -q --no-header > gpurun_out/art_tests_full.log 2>&1; grep -E "passed|failed|error" gpurun_out/art_tests_full.log | tail -3 | tee gpurun_out/art_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 900 python bench.py > gpurun_out/art_bench.json 2> gpurun_out/art_bench.err
 tail -c 1500 gpurun_out/art_bench.json

@@ -11,9 +11,9 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
             if r['Counter_Name'] == c:
                 agg[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
     for k, v in agg.items():
-        if any(s in k for s in ('gemm_kernel', 'gemm4_kernel', 'attn_', 'adamw_kernel')):
+        if any(s in k for s in ('gemm_kernel', 'gemm4_kernel', 'gemm4nt_kernel', 'attn_', 'adamw_kernel')):
             per[k][c] = sum(v) / len(v); per[k]['launches'] = len(v)
-g = {k: v for k, v in per.items() if ('gemm_kernel' in k or 'gemm4_kernel' in k) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v}
+g = {k: v for k, v in per.items() if ('gemm_kernel' in k or 'gemm4_kernel' in k or 'gemm4nt_kernel' in k) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v}
 n = sum(v['launches'] for v in g.values())
 fetch = sum(v['FETCH_SIZE'] * v['launches'] for v in g.values()) / n
 write = sum(v['WRITE_SIZE'] * v['launches'] for v in g.values()) / n
