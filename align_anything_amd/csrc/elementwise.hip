@@ -136,38 +136,39 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const elem_t* __restri
         const elem_t* xr = x + row * h;
         const elem_t* gr = dy + row * h;
         float dot = 0.f;
+        // the row's x / dy / (residual) vectors stay in registers between the reduction pass and the output pass: the second pass
+        // re-read them through L2 before (same arithmetic, same order -> same bits)
+        ev8 xk[MAXV], gk[MAXV], ok[MAXV];
+        elem_t* dxr = dx + row * h;
 #pragma unroll
         for (int a = 0; a < MAXV; ++a) {
             const int i = threadIdx.x + a * 256;
             if (i < nv) {
-                ev8 xv = *reinterpret_cast<const ev8*>(xr + i * 8);
-                ev8 gv = *reinterpret_cast<const ev8*>(gr + i * 8);
-                ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
+                xk[a] = *reinterpret_cast<const ev8*>(xr + i * 8);
+                gk[a] = *reinterpret_cast<const ev8*>(gr + i * 8);
+                if (add_to_dx) ok[a] = *reinterpret_cast<const ev8*>(dxr + i * 8);
+                const ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float xh = e2f(xv[j]) * rstd;
-                    const float g = e2f(gv[j]);
+                    const float xh = e2f(xk[a][j]) * rstd;
+                    const float g = e2f(gk[a][j]);
                     dot += g * e2f(wv[j]) * xh;
                     dwacc[a][j] += g * ernd(xh);
                 }
             }
         }
         dot = block_sum<256>(dot, red) / (float)h;
-        elem_t* dxr = dx + row * h;
 #pragma unroll
         for (int a = 0; a < MAXV; ++a) {
             const int i = threadIdx.x + a * 256;
             if (i < nv) {
-                ev8 xv = *reinterpret_cast<const ev8*>(xr + i * 8);
-                ev8 gv = *reinterpret_cast<const ev8*>(gr + i * 8);
-                ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
+                const ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
                 ev8 o;
-                if (add_to_dx) o = *reinterpret_cast<const ev8*>(dxr + i * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float xh = e2f(xv[j]) * rstd;
-                    float d = rstd * (e2f(gv[j]) * e2f(wv[j]) - xh * dot);
-                    if (add_to_dx) d += e2f(o[j]);
+                    const float xh = e2f(xk[a][j]) * rstd;
+                    float d = rstd * (e2f(gk[a][j]) * e2f(wv[j]) - xh * dot);
+                    if (add_to_dx) d += e2f(ok[a][j]);
                     o[j] = f2e(d);
                 }
                 *reinterpret_cast<ev8*>(dxr + i * 8) = o;

@@ -330,6 +330,14 @@ def main():
                 tot_fl += fl
             n = len(gemm_events)
             ach = tot_fl / tot_ms / 1e9
+            # the same sample split by launch kind (a kind = equal FLOPs and equal algorithmic bytes: one GEMM shape / epilogue of the step)
+            kinds = {}
+            for ev0, ev1, fl, by in gemm_events:
+                k = kinds.setdefault((fl, by), [0, 0.0])
+                k[0] += 1
+                k[1] += ops.event_elapsed_ms(ev0, ev1)
+            by_kind = [{'tflop': round(fl / 1e12, 4), 'algorithmic_MB': round(by / 1e6, 1), 'sampled_launches': c, 'avg_ms': round(ms / c, 4),
+                        'tflops': round(fl / (ms / c) / 1e9, 1)} for (fl, by), (c, ms) in sorted(kinds.items(), key=lambda kv: -kv[1][1])][:12]
             # HBM bytes per GEMM launch from the PMC counters: rocprofv3 cannot run inside this process, so the number comes
             # from the separate --pmc passes of THIS command (tools/pmc_traffic.sh: FETCH_SIZE doubled per the gfx950 note of
             # MI355X_MICROARCH.md, WRITE_SIZE as is, separate passes), committed under profiles/
@@ -338,19 +346,35 @@ def main():
                 try:
                     with open(os.path.join(ROOT, 'profiles', name)) as f:
                         tj = json.load(f)
-                    traffic = tj.get('gemm_hbm_bytes_per_launch_full_depth_mix', tj.get('gemm_hbm_bytes_per_launch'))
+                    traffic = tj.get('gemm4_hbm_bytes_per_launch', tj.get('gemm_hbm_bytes_per_launch_full_depth_mix', tj.get('gemm_hbm_bytes_per_launch')))
                     src = name
                     if traffic is not None:
                         break
                 except (OSError, ValueError):
                     continue          # the profile is not in this checkout: traffic stays null
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm4_kernel<A_T,B_N,EPI,PERSIST> (csrc/gemm4.hip: one wave per SIMD, 128x128 per wave) + the few '
-                                                          'gemm_kernel launches of the small / ragged shapes (csrc/gemm.hip): all GEMM launches of the timed steps',
+            # dominant kernel = the gemm4 kernels: every launch of >= 0.25 TFLOP (all decoder / lm_head shapes of the step; they are 99.8 % of
+            # the GEMM FLOPs).  The small launches (CLIP tower, projector: gemm_kernel of csrc/gemm.hip) are reported beside it -- they run at
+            # the start of the step, partly beside the previous step's asynchronous AdamW on the other stream, so their event-pair times
+            # include waiting for CUs and would otherwise shift the dominant kernel's figure by the luck of the sample.
+            big = [(ops.event_elapsed_ms(e0, e1), fl, by) for e0, e1, fl, by in gemm_events if fl >= 0.25e12]
+            if big:
+                all_ach, all_n, all_ms = ach, n, tot_ms
+                tot_ms, tot_fl, n = sum(b[0] for b in big), sum(b[1] for b in big), len(big)
+                ach = tot_fl / tot_ms / 1e9
+                gemm_events = [(None, None, fl, by) for _, fl, by in big]
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm4_kernel<A_T,B_N,EPI> / gemm4nt_kernel<EPI> (csrc/gemm4.hip: one wave per SIMD, 128x128 per wave): '
+                                                          'every sampled GEMM launch of >= 0.25 TFLOP in the timed steps',
                                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                                'traffic': traffic, 'traffic_unit': f'HBM bytes per GEMM launch (rocprofv3 --pmc passes of this command, profiles/{src})',
                                'algorithmic_bytes_per_launch': sum(e[3] for e in gemm_events) / n,
                                'launches': n, 'launch_sampling': f'every {ops.GEMM_PROF_STRIDE}th GEMM launch of the timed steps', 'avg_launch_ms': tot_ms / n,
-                               'avg_flops_per_launch': tot_fl / n, 'gemm_share_of_step_time': tot_ms / (dt * 1e3)}
+                               'avg_flops_per_launch': tot_fl / n,
+                               'gemm_share_of_step_time': tot_ms * ops.GEMM_PROF_STRIDE / (dt * 1e3),     # sample scaled to all launches
+                               'by_kind_top12': by_kind}
+            if big:
+                out['roofline']['all_gemm_launches_sampled'] = {'achieved': all_ach, 'launches': all_n, 'avg_launch_ms': all_ms / all_n,
+                                                                'note': 'incl. the small CLIP-tower / projector GEMMs (see the comment in bench.py)'}
+                out['roofline']['gemm_share_of_step_time'] = all_ms * ops.GEMM_PROF_STRIDE / (dt * 1e3)
         if multi is not None:
             out['multi_gpu'] = multi
         if not args.no_cpu_baseline and world == 1:

@@ -19,7 +19,7 @@ x = (torch.randn(M, K, generator=g) * 0.5).to(bf).to(dev)
 w_down = (torch.randn(K, F, generator=g) * 0.02).to(bf).to(dev)
 w_gu = (torch.randn(2 * F, K, generator=g) * 0.02).to(bf).to(dev)
 GU_B = M * 2 * F * 2
-arena = torch.empty(3 * GU_B + (64 << 20), dtype=torch.uint8, device=dev)
+arena = torch.empty((7 << 30), dtype=torch.uint8, device=dev)
 base = (arena.data_ptr() + (2 << 20) - 1) // (2 << 20) * (2 << 20) - arena.data_ptr()      # 2 MB-aligned start
 
 
@@ -45,22 +45,30 @@ def timed(fn, reps=8):
 gu = view(base, M, 2 * F)
 gu.copy_((torch.randn(M, 2 * F, generator=g) * 0.5).to(bf))
 res = {'bwd': {}, 'fwd': {}}
-deltas = [0, 256, 512, 1024, 2048, 4096, 8192, 65536, (1 << 20), (1 << 20) + 4096, (2 << 20), (2 << 20) + 2048, (16 << 20) + 512]
-for d in deltas:
-    off = base + (GU_B + (2 << 20) - 1) // (2 << 20) * (2 << 20) + d
+R2M = (GU_B + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+# byte distances dgu - gu: just past the operand, then "round" distances (powers of two and sums of two of them), where a
+# channel / set hash that ignores the high address bits would make the two streams of a tile collide
+dists = [R2M, 0x40000000, 0x100000000] if os.environ.get('AA_PROBE_SHORT') else \
+        [R2M, R2M + 4096, 0x2C000000, 0x30000000, 0x38000000, 0x40000000, 0x40000000 + 4096, 0x50000000, 0x60000000, 0x80000000,
+         0x80000000 + (1 << 21), 0xC0000000, 0x100000000, 0x100000000 + 0x2B200000, 0x140000000]
+for d in dists:
+    off = base + d
     dgu = view(off, M, 2 * F)
 
     def bwd():
         ops.call('aa_gemm_glu_bwd_bf16', dy.data_ptr(), w_down.data_ptr(), gu.data_ptr(), dgu.data_ptr(), None, M, F, K, dy.stride(0),
                  w_down.stride(0), gu.stride(0), dgu.stride(0), ops.stream())
     res['bwd'][d] = timed(bwd)
-    act = view(off, M, F)
-
-    def fwd():
-        ops.call('aa_gemm_glu_fwd_bf16', x.data_ptr(), w_gu.data_ptr(), gu.data_ptr(), act.data_ptr(), M, F, K, x.stride(0), w_gu.stride(0),
-                 gu.stride(0), act.stride(0), ops.stream())
-    res['fwd'][d] = timed(fwd)
-    print(f'distance (2 MB-rounded operand size) + {d:9d} B: glu_bwd {res["bwd"][d]:7.1f} us   glu_fwd {res["fwd"][d]:7.1f} us', flush=True)
+    print(f'dgu - gu = {d:#13x}: glu_bwd {res["bwd"][d]:7.1f} us', flush=True)
+# does it depend on where dy / w_down lie instead?  (fresh copies at different allocator positions)
+for i in range(0 if os.environ.get('AA_PROBE_SHORT') else 4):
+    pad = torch.empty(((i + 1) * 97 << 20) + i * 4096, dtype=torch.uint8, device=dev)
+    dy2, w2 = dy.clone(), w_down.clone()
+    dgu = view(base + R2M, M, 2 * F)
+    t = timed(lambda: ops.call('aa_gemm_glu_bwd_bf16', dy2.data_ptr(), w2.data_ptr(), gu.data_ptr(), dgu.data_ptr(), None, M, F, K, dy2.stride(0),
+                               w2.stride(0), gu.stride(0), dgu.stride(0), ops.stream()))
+    print(f'dy at {dy2.data_ptr():#x} w_down at {w2.data_ptr():#x}: glu_bwd {t:7.1f} us', flush=True)
+    del pad
 # the allocator's own placement, as the trainer gets it
 gu2 = torch.empty((M, 2 * F), dtype=bf, device=dev); gu2.copy_(gu)
 dgu2 = torch.empty_like(gu2)

@@ -17,8 +17,14 @@ g = {k: v for k, v in per.items() if ('gemm_kernel' in k or 'gemm4_kernel' in k 
 n = sum(v['launches'] for v in g.values())
 fetch = sum(v['FETCH_SIZE'] * v['launches'] for v in g.values()) / n
 write = sum(v['WRITE_SIZE'] * v['launches'] for v in g.values()) / n
+# the dominant kernel of bench.py's roofline: the gemm4 kernels with a fused / plain epilogue of the big shapes (template EPI >= 1; EPI 0 is the
+# general path the small shapes take)
+g4 = {k: v for k, v in g.items() if 'gemm4' in k and not re.search(r', 0>$|<0>$', k)}
+n4 = max(1, sum(v['launches'] for v in g4.values()))
+fetch4 = sum(v['FETCH_SIZE'] * v['launches'] for v in g4.values()) / n4
+write4 = sum(v['WRITE_SIZE'] * v['launches'] for v in g4.values()) / n4
 import os
-json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, ' + os.environ.get('AA_TRAFFIC_CMD', 'tools/gpu_traffic.sh: bench.py --layers 4 --pairs-per-gpu 4') + '); '
+json.dump({'gemm4_launches': n4, 'gemm4_hbm_bytes_per_launch': (2 * fetch4 + write4) * 1024, 'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, ' + os.environ.get('AA_TRAFFIC_CMD', 'tools/gpu_traffic.sh: bench.py --layers 4 --pairs-per-gpu 4') + '); '
                    'FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section', 'gemm_launches': n, 'gemm_fetch_KiB_avg_raw': fetch,
            'gemm_write_KiB_avg': write, 'gemm_hbm_bytes_per_launch': (2 * fetch + write) * 1024, 'per_kernel': per}, open(out, 'w'), indent=1)
-print('gemm launches', n, 'HBM bytes per launch', (2 * fetch + write) * 1024)
+print('gemm launches', n, 'HBM bytes per launch', (2 * fetch + write) * 1024, '| gemm4 (big shapes)', n4, (2 * fetch4 + write4) * 1024)
