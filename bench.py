@@ -171,6 +171,10 @@ def main():
                          'its neighbours (no tail / head overlap with the next kernel): around EVERY launch that costs the one-wave-per-SIMD '
                          'GEMMs 6.5 %% of the step (806 vs 754 ms, same box), so the default samples every 11th launch -- made coprime to the '
                          'launches per step, hence unbiased over the shapes -- which costs < 1 %%')
+    ap.add_argument('--measure-traffic', action='store_true',
+                    help='N=1: before the timed run, collect roofline.traffic for THIS box and build by running tools/pmc_traffic.sh (two '
+                         'rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1` at full depth, ~3 min) instead of reading the committed '
+                         'profiles/r02_gemm_traffic.json; needs rocprofv3 on PATH')
     ap.add_argument('--comm-prof', action='store_true',
                     help='N>1: after the timed region run ONE extra untimed step with HIP events around every gradient bucket '
                          '(all-reduce time vs the backward it overlaps with) and add it to the JSON line as "comm"')
@@ -178,6 +182,16 @@ def main():
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+    live_traffic = None
+    if args.measure_traffic and args.gpus == 1 and os.environ.get('AA_BENCH_IN_PMC') != '1':
+        env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, AA_BENCH_IN_PMC='1')
+        r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'pmc_traffic.sh')], env=env, capture_output=True, text=True)
+        try:
+            with open(os.path.join(ROOT, 'gpurun_out', 'gemm_traffic.json')) as f:
+                live_traffic = json.load(f)
+            live_traffic['_source'] = 'measured by this invocation (tools/pmc_traffic.sh)'
+        except (OSError, ValueError):
+            print(f'[bench] --measure-traffic failed (rc={r.returncode}): {r.stderr[-500:]}', file=sys.stderr, flush=True)
 
     import torch
     import torch.distributed as dist
@@ -342,7 +356,10 @@ def main():
             # from the separate --pmc passes of THIS command (tools/pmc_traffic.sh: FETCH_SIZE doubled per the gfx950 note of
             # MI355X_MICROARCH.md, WRITE_SIZE as is, separate passes), committed under profiles/
             traffic, src = None, None
-            for name in TRAFFIC_PROFILES:
+            if live_traffic is not None:
+                traffic = live_traffic.get('gemm4_hbm_bytes_per_launch', live_traffic.get('gemm_hbm_bytes_per_launch'))
+                src = 'gpurun_out/gemm_traffic.json, ' + live_traffic['_source']
+            for name in (TRAFFIC_PROFILES if traffic is None else ()):
                 try:
                     with open(os.path.join(ROOT, 'profiles', name)) as f:
                         tj = json.load(f)
@@ -365,7 +382,7 @@ def main():
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm4_kernel<A_T,B_N,EPI> / gemm4nt_kernel<EPI> (csrc/gemm4.hip: one wave per SIMD, 128x128 per wave): '
                                                           'every sampled GEMM launch of >= 0.25 TFLOP in the timed steps',
                                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                               'traffic': traffic, 'traffic_unit': f'HBM bytes per GEMM launch (rocprofv3 --pmc passes of this command, profiles/{src})',
+                               'traffic': traffic, 'traffic_unit': f'HBM bytes per gemm4 launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes of this command: {src if live_traffic is not None else "profiles/" + str(src)})',
                                'algorithmic_bytes_per_launch': sum(e[3] for e in gemm_events) / n,
                                'launches': n, 'launch_sampling': f'every {ops.GEMM_PROF_STRIDE}th GEMM launch of the timed steps', 'avg_launch_ms': tot_ms / n,
                                'avg_flops_per_launch': tot_fl / n,
