@@ -28,7 +28,7 @@ def _newer(a: str, b: str) -> bool:
 def _compile(src: str) -> str:
     s = os.path.join(CSRC, src)
     o = os.path.join(OBJ, src.replace('.hip', '.o'))
-    hdrs = [os.path.join(CSRC, h) for h in ('aa_common.h', 'gemm_params.h')]
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(('.h', '.inc'))]      # every header / generated include (gemm4_*.inc)
     if src.endswith('_f32.hip') and os.path.exists(os.path.join(CSRC, src.replace('_f32.hip', '.hip'))):
         hdrs.append(os.path.join(CSRC, src.replace('_f32.hip', '.hip')))   # twin instantiation includes the bf16 source
     if _newer(s, o) or any(_newer(h, o) for h in hdrs if os.path.exists(h)):
