@@ -147,6 +147,14 @@ __device__ __forceinline__ bf16x8 at_join(const i32x2& lo, const i32x2& hi) {
 __device__ __forceinline__ void at_wait(i32x2& a, i32x2& b, i32x2& c, i32x2& d) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+// "this register value is needed HERE": makes hipcc put the wait for a prologue load in front of the tile loop.  Left to itself it waits
+// at the first use INSIDE the loop -- `s_waitcnt vmcnt(3..0)` in every iteration, which (the counter being shared) drains the DMA
+// prefetch of the next tile a quarter into the current one.
+__device__ __forceinline__ void landed(const bf16x8& v) {
+    const i32x4 t = __builtin_bit_cast(i32x4, v);
+    asm volatile("" ::"v"(t));
+}
+__device__ __forceinline__ void landed(float v) { asm volatile("" ::"v"(v)); }
 template <int NR> struct TrBuf { i32x2 f[NR]; };
 // counted form: returns once at most LEFT LDS operations of this wave are outstanding (LDS returns in order, so everything
 // issued before the youngest LEFT reads has landed); b's registers pass through so their consumers stay below
@@ -337,6 +345,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         dma.issue(Vb, p.ldv, voff, kv_begin, T, lds0 + TILE_B);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) landed(qf[qi][ks]);
     __syncthreads();
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
@@ -544,6 +556,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
         dma.issue(Vb, p.ldv, voff, kv_begin, T, lds0 + TILE_B);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { landed(qf[qi][ks]); landed(dof[qi][ks]); }
+        landed(lse2[qi]); landed(dl[qi]);
+    }
     __syncthreads();
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
@@ -703,6 +721,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
 
     if (total > 0 && kv_valid_block) issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { landed(kf[ks]); landed(vf[ks]); }
     __syncthreads();
     for (int it = 0; it < total && kv_valid_block; ++it) {
         const int cur = it & 1;

@@ -588,3 +588,99 @@ def test_gemm4_kernels_keep_everything_in_registers():
                     compiler_waits += 1
         assert compiler_waits == 0, (name, compiler_waits)
         assert ours == 3, (name, ours)          # steps 1..3 of the trip (step 0's begin sits above the first MFMA)
+
+
+def test_attention_kernels_keep_fragments_in_registers_and_the_prefetch_in_flight():
+    """csrc/attention.hip issues its transpose reads and DMA pieces as inline asm (the compiler neither tracks their completion nor orders
+    them against each other).  That is only sound -- and only fast -- while (1) nothing spills: a spilled fragment register would be stored
+    before its untracked read has landed; (2) the tile loops contain no compiler-made `s_waitcnt vmcnt` except the one glued to the
+    end-of-tile barrier: the round-1 build had a full drain of the NEXT tile's DMA in the middle of every tile."""
+    import subprocess
+    import tempfile
+    from align_anything_amd import build as b
+    src = os.path.join(b.CSRC, 'attention.hip')
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, 'attention.s')
+        r = subprocess.run([b.HIPCC, *b.FLAGS, '--cuda-device-only', '-S', src, '-o', asm, '-Rpass-analysis=kernel-resource-usage'],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        text = open(asm).read()
+    names = re.findall(r'Function Name: (\S*attn_(?:fwd|bwd_dq|bwd_dkv)_kernel\S*)', r.stderr)
+    blocks = re.split(r'Function Name: ', r.stderr)[1:]
+    checked = 0
+    for blk in blocks:
+        if not re.match(r'\S*attn_(?:fwd|bwd_dq|bwd_dkv)_kernel', blk):
+            continue
+        assert int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', blk).group(1)) == 0, blk[:200]
+        assert int(re.search(r'VGPRs Spill: (\d+)', blk).group(1)) == 0, blk[:200]
+        checked += 1
+    assert checked == 6 and len(names) == 6                 # forward, dQ, dK/dV x head_dim 64 / 128
+    assert 'scratch_' not in text
+    kernels = re.findall(r'^(_Z\d+attn_(?:fwd|bwd_dq|bwd_dkv)_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end', text, flags=re.S | re.M)
+    assert len(kernels) == 6
+    for name, body in kernels:
+        lines = [ln for ln in body.split('\n') if ln.strip() and not ln.strip().startswith(';') or 'ASM' in ln]
+        mf = [i for i, ln in enumerate(lines) if 'v_mfma_f32_16x16x32_bf16' in ln]
+        assert mf, name
+        in_asm, stray = False, []
+        for i in range(mf[0], mf[-1]):
+            ln = lines[i]
+            if 'ASMSTART' in ln:
+                in_asm = True
+            elif 'ASMEND' in ln:
+                in_asm = False
+            elif 's_waitcnt' in ln and 'vmcnt' in ln and not in_asm:
+                if not any('s_barrier' in x for x in lines[i + 1:i + 3]):
+                    stray.append(ln.strip())
+        assert not stray, (name, stray)
+        assert sum('ds_read_b64_tr_b16' in ln for ln in lines) > 0 and not any('ds_bpermute' in ln for ln in lines), name
+
+
+def test_attention_block_orders_are_bijections_and_the_transpose_addresses_match():
+    """Integer restatements of two pieces of csrc/attention.hip whose errors would be silent on most shapes: (1) q_block_of / kv_block_of
+    (block index -> (sequence, head, block); XCD-local when Hkv * N % 8 == 0) must visit every (n, h, block) exactly once, all blocks of
+    one kv head on ONE XCD and back to back in its dispatch sequence; (2) tr_lane_base + the XOR with (db << 5) + the row immediate must
+    address the same bytes as the swizzled tile layout the DMA writes (unit_swz), for both head sizes."""
+    def q_block_of(b, N, H, Hkv, nqb, xcd_local):
+        HkN, group = Hkv * N, H // Hkv
+        per = nqb * group
+        if xcd_local and HkN % 8 == 0:
+            hkn, r = (b & 7) + 8 * ((b >> 3) // per), (b >> 3) % per
+        else:
+            hkn, r = b % HkN, b // HkN
+        n, hk = hkn // Hkv, hkn % Hkv
+        return n, hk * group + r % group, hk, nqb - 1 - r // group
+
+    def kv_block_of(b, N, Hkv, nkvb):
+        HkN = Hkv * N
+        if HkN % 8 == 0:
+            hkn, kvb = (b & 7) + 8 * ((b >> 3) // nkvb), (b >> 3) % nkvb
+        else:
+            hkn, kvb = b % HkN, b // HkN
+        return hkn // Hkv, hkn % Hkv, kvb
+
+    for N, H, Hkv, T in ((8, 32, 32, 2048), (2, 8, 2, 1000), (3, 20, 20, 750), (4, 16, 16, 577), (8, 28, 4, 2048), (1, 32, 8, 130)):
+        nqb, nkvb = (T + 127) // 128, (T + 63) // 64
+        for local in (True, False):
+            seen = [q_block_of(b, N, H, Hkv, nqb, local) for b in range(nqb * H * N)]
+            assert len(set((n, h, qb) for n, h, _, qb in seen)) == nqb * H * N and all(hk == h // (H // Hkv) for _, h, hk, _ in seen)
+            if local and (Hkv * N) % 8 == 0:
+                for b, (n, h, hk, qb) in enumerate(seen):            # one kv head = one XCD, a contiguous stretch of its sequence
+                    assert (n * Hkv + hk) % 8 == b % 8
+        seen = [kv_block_of(b, N, Hkv, nkvb) for b in range(nkvb * Hkv * N)]
+        assert len(set(seen)) == nkvb * Hkv * N
+        if (Hkv * N) % 8 == 0:
+            assert all((n * Hkv + hk) % 8 == b % 8 for b, (n, hk, _) in enumerate(seen))
+    for HD in (64, 128):
+        ROWB, DB = HD * 2, HD // 16
+        swz = (lambda row: row & 7) if HD == 128 else (lambda row: (row >> 1) & 3)
+        for lane in range(64):
+            l15, g = lane & 15, lane >> 4
+            row = 4 * g + (l15 >> 2)
+            base = row * ROWB + (swz(row) << 5) + (l15 & 3) * 8                      # tr_lane_base
+            for db in range(DB):
+                for rows16 in range(4):
+                    got = (base ^ (db << 5)) + rows16 * 16 * ROWB                    # tr_stream: XOR, then the immediate
+                    r = rows16 * 16 + row
+                    want = r * ROWB + ((db ^ swz(r)) << 5) + (l15 & 3) * 8           # lds_tr(): row r, unit db ^ swizzle(r), slot
+                    assert got == want, (HD, lane, db, rows16)
