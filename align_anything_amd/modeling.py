@@ -117,6 +117,10 @@ class LlamaStack:
         self._rope = tables
         self.saved = []
         qw, kw = H * hd, Hkv * hd
+        # keys at or beyond kv_len[n] are masked for every query (RIGHT padding inside the sequence, as HF's padding mask does).  Unset on
+        # the DPO / PPO paths: their right-padded rows are never read at a masked position.  Set by the caller (attribute `kv_len`) for the one
+        # consumer that is: the vision-language reward models' end score at position -1 (models/llava.py:64-68) on a right-padded batch.
+        kv_len = self._kv_len_saved = getattr(self, 'kv_len', None)
         for li, L in enumerate(self.layers):
             n1, rstd1 = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
             if x.dtype == bf16 and L['qkv'].b is None:
@@ -129,7 +133,7 @@ class LlamaStack:
             if kv_sink is not None:
                 kv_sink(li, qkv[:N * T, qw:])  # post-RoPE keys | values of this layer -> KV cache (prefill)
             attn, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
-                                     hd ** -0.5, start, out=self._attn_out(x, N * T, H * hd))
+                                     hd ** -0.5, start, out=self._attn_out(x, N * T, H * hd), kv_len=kv_len)
             x_mid = L['o'].fwd(attn, residual=x)
             n2, rstd2 = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
             if x.dtype == bf16:
@@ -229,7 +233,7 @@ class LlamaStack:
             d_qkv = torch.zeros_like(qkv) if qkv.shape[0] != N * T else torch.empty_like(qkv)
             ops.attn_bwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], attn, d_attn, lse,
                          d_qkv[:, :qw], d_qkv[:, qw:qw + kw], d_qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
-                         hd ** -0.5, start)
+                         hd ** -0.5, start, kv_len=getattr(self, '_kv_len_saved', None))
             ops.rope_(d_qkv, 0, H + Hkv, hd, pos, self._rope[0], self._rope[1], inverse=True)
             d_n1 = L['qkv'].dx(d_qkv)
             if tr:
@@ -675,8 +679,10 @@ class NativeLlava(NativeCausalLM):
         return self.vision.forward(pixel_values)
 
     def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
-                       position_ids=None, kv_sink=None):
+                       position_ids=None, kv_sink=None, kv_len=None):
+        """kv_len (int32 [N], optional): keys at or beyond it are masked in the decoder (right padding; see LlamaStack.forward)."""
         N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask, position_ids)
+        self.stack.kv_len = kv_len
         P = self.store.p
         ids = input_ids.reshape(-1)
         if Mp != N * T:

@@ -49,6 +49,11 @@ class RMTrainer:
         w, end = self._end_window(ids, am)
         self.model.wait_optimizer()
         mm = {k: batch[k] for k in ('image_grid_thw', 'position_ids3', 'input_features', 'feature_attention_mask') if k in batch}
+        if self.model.module.kind == 'llava':
+            # the end score of this backbone is read at position -1 even when that position is padding (models/llava.py:64-68), so what
+            # a masked query row sees matters: HF hides the right-padded keys from it -> one past the last attended key, per row
+            T = ids.shape[1]
+            mm['kv_len'] = (am.to(torch.int32) * torch.arange(1, T + 1, dtype=torch.int32, device=ids.device)).amax(dim=1).to(torch.int32)
         end_scores, scores = self.model.module.response_scores(ids, am, w, pixel_values=batch.get('pixel_values'), save=True,
                                                                all_scores=True, **mm)
         out2, d = ops.rm_loss(end_scores[:2 * B].contiguous(), B, self.regularization)
@@ -97,7 +102,10 @@ class RMTrainer:
             B = ids.shape[0] // 2
             w, _ = self._end_window(ids, am)
             self.model.wait_optimizer()
-            s = self.model.module.response_scores(ids, am, w, pixel_values=batch.get('pixel_values'), save=False)[:2 * B]
+            mm = {}
+            if self.model.module.kind == 'llava':      # as in loss(): right-padded keys are hidden from the row at position -1
+                mm['kv_len'] = (am.to(torch.int32) * torch.arange(1, ids.shape[1] + 1, dtype=torch.int32, device=ids.device)).amax(dim=1).to(torch.int32)
+            s = self.model.module.response_scores(ids, am, w, pixel_values=batch.get('pixel_values'), save=False, **mm)[:2 * B]
             hits = (s[:B] > s[B:]).sum()
             correct = hits if correct is None else correct + hits
             total += B

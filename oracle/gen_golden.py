@@ -807,6 +807,58 @@ def gen_opt_rm():
     np.savez_compressed(os.path.join(GOLD, 'opt_tiny_rm.npz'), **out)
 
 
+def gen_llava_rm():
+    """The reference's text+image reward-model trainer (trainers/text_image_to_text/rm.py: RMTrainer.loss is the text trainer's,
+    trainers/text_to_text/rm.py:97-132) on its own AccustomedLlavaRewardModel (models/llava.py:29-76: end score = the score at position -1
+    whatever the attention mask says), fp32, CPU: six outputs + gradients on (a) the left-padded batch the ti2t collator builds and (b) the
+    same batch with one row's mask cut short on the RIGHT, where position -1 is no longer the last attended token."""
+    from align_anything.models.llava import AccustomedLlavaRewardModel
+    from align_anything.trainers.text_image_to_text.rm import RMTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+    from transformers import LlavaPreTrainedModel
+    from align_anything.models.llava import AccustomedLlavaModel
+    cfg, lm = tiny_llava()
+    # the reference's constructor reads `self.model.language_model.lm_head.in_features` (models/llava.py:41), an attribute path the installed
+    # transformers (5.x: lm_head sits on the outer model) no longer has; the constructor's three statements are therefore restated with the
+    # width taken from the config -- SURVEY.md section 8(c) -- and everything that computes (the reference's forward, :47-76) runs unmodified
+    rm = AccustomedLlavaRewardModel.__new__(AccustomedLlavaRewardModel)
+    LlavaPreTrainedModel.__init__(rm, cfg)
+    setattr(rm, rm.base_model_prefix, AccustomedLlavaModel(cfg))
+    rm.score_head = torch.nn.Linear(cfg.text_config.hidden_size, 1, bias=False)
+    rm = rm.eval()
+    with torch.no_grad():
+        missing = rm.model.load_state_dict(lm.state_dict(), strict=False)
+        assert not missing.unexpected_keys, missing
+        g = torch.Generator().manual_seed(29)
+        rm.score_head.weight.copy_((torch.randn(1, 128, generator=g) * 0.3).to(torch.bfloat16).float())
+    gb = torch.Generator().manual_seed(43)
+    batch = make_llava_batch(gb)
+    out = {'input_ids': batch['input_ids'].numpy(), 'pixel_values': batch['pixel_values'].numpy(), 'pad_token_id': np.array(301)}
+    for tag, cut in (('left', None), ('rightcut', (1, 6))):
+        am = batch['attention_mask'].clone()
+        if cut is not None:
+            am[cut[0], -cut[1]:] = 0
+        out[f'{tag}_attention_mask'] = am.numpy()
+        tr = RMTrainer.__new__(RMTrainer)
+        tr.cfgs = dict_to_namedtuple({'train_cfgs': {'regularization': 0.01}})
+        tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+        tr.model = rm
+        rm.zero_grad()
+        ld = tr.loss({'input_ids': batch['input_ids'], 'attention_mask': am, 'pixel_values': batch['pixel_values'], 'meta_info': {}})
+        ld['loss'].backward()
+        for k, v in ld.items():
+            out[f'{tag}_{k}'] = v.detach().numpy()
+        for n, q in rm.named_parameters():
+            if q.grad is not None and (n == 'score_head.weight' or n.endswith('layers.1.mlp.down_proj.weight') or n.endswith('layers.0.self_attn.q_proj.weight')
+                                       or n.endswith('language_model.norm.weight') or n.endswith('multi_modal_projector.linear_2.weight')):
+                out[f'{tag}_g.{n}'] = q.grad.numpy().copy()
+        print('llava_tiny_rm', tag, 'loss', float(ld['loss']), 'acc', float(ld['accuracy']), 'grads', sum(k.startswith(tag + '_g.') for k in out))
+    out['regularization'] = np.array(0.01)
+    for n, q in rm.state_dict().items():
+        out['w.' + n] = bf16_bits(q)
+    np.savez_compressed(os.path.join(GOLD, 'llava_tiny_rm.npz'), **out)
+
+
 def gen_opt_ppo():
     """The reference's unmodified text_to_text PPOTrainer.rollout (trainers/text_to_text/ppo.py:244-289, incl. actor_step
     :209-222 after `generate` and reward_model_step :224-242) and rl_step (:309-398) with HF OPT as actor / reference and the
@@ -965,5 +1017,6 @@ if __name__ == '__main__':
     gen_collator()
     gen_grpo()
     gen_opt_rm()
+    gen_llava_rm()
     gen_opt_ppo()
     gen_opt125m_curve()

@@ -374,3 +374,48 @@ def test_ppo_oracle_matches_reference_t2t_rollout_and_rl_step():
                     assert rel_err(sd[k[len(tag):]].grad, T(z[k])) < 2e-3, k
                     n += 1
         assert n >= 8
+
+
+def _llava_rm_state(z, dtype=torch.float32):
+    """The reference reward model nests the HF model one level deeper (`model.model.*`, `model.lm_head`); the oracle / native
+    loaders take the HF names plus `score_head.weight`."""
+    sd = {}
+    for k, v in state_dict_from_golden(z, 'w.', dtype).items():
+        if k == 'score_head.weight':
+            sd[k] = v
+        elif k.startswith('model.') and k != 'model.lm_head.weight':
+            sd[k[len('model.'):]] = v
+    return sd
+
+
+def test_llava_rm_oracle_matches_reference_ti2t_rm_trainer_loss():
+    """The reference's text+image RMTrainer.loss on its AccustomedLlavaRewardModel (tests/golden/llava_tiny_rm.npz, fp32 CPU): the oracle's
+    LLaVA hidden states + score_from_hidden(end at position -1, models/llava.py:64-68) + rm_loss reproduce all six outputs and the
+    gradients, on the left-padded batch AND with one row's mask cut on the right (where position -1 is not the last attended token)."""
+    from tests.util import tiny_llava_cfg
+    z = load_golden('llava_tiny_rm.npz')
+    cfg = tiny_llava_cfg()
+    ids, pix = T(z['input_ids']), T(z['pixel_values'])
+    for tag in ('left', 'rightcut'):
+        mask = T(z[f'{tag}_attention_mask'])
+        sd = {k: v.clone().requires_grad_(True) for k, v in _llava_rm_state(z).items()}
+        hid = om.llava_hidden({k: v for k, v in sd.items() if k != 'score_head.weight'}, cfg, ids, mask, pix)
+        scores, end = om.score_from_hidden(hid, sd['score_head.weight'], mask, end_at_last_position=True)
+        ld = orl.rm_loss(scores, end, float(z['regularization']))
+        for k in ('loss', 'higher_end_reward', 'lower_end_reward', 'accuracy'):
+            np.testing.assert_allclose(ld[k].detach().numpy(), z[f'{tag}_{k}'], rtol=2e-5, atol=2e-5, err_msg=f'{tag} {k}')
+        valid = mask.bool()
+        B = ids.shape[0] // 2
+        for k, rows in (('higher_rewards', slice(0, B)), ('lower_rewards', slice(B, 2 * B))):
+            np.testing.assert_allclose(ld[k].detach()[valid[rows]].numpy(), z[f'{tag}_{k}'][valid[rows].numpy()], rtol=2e-4, atol=2e-4, err_msg=k)
+        ld['loss'].backward()
+        n = 0
+        for k in z.files:
+            if k.startswith(f'{tag}_g.'):
+                name = k[len(tag) + 3:]
+                name = name if name == 'score_head.weight' else name[len('model.'):]
+                assert rel_err(sd[name].grad, T(z[k])) < 2e-3, (tag, k, rel_err(sd[name].grad, T(z[k])))
+                n += 1
+        assert n == 6
+    # the cut changes the result: the two variants are different problems, not one tested twice
+    assert abs(float(z['left_loss']) - float(z['rightcut_loss'])) > 1e-3
