@@ -399,6 +399,22 @@ def _ep_worker(rank, world, port, q):
     both = [None] * world
     dist.all_gather_object(both, seen.count('aa_attn_decode'))              # whatever the (garbage) tokens did, the ranks stopped together
     ok = ok and len(set(both)) == 1
+    # the RL trainers' flag: a PPO trainer with train_cfgs.expert_parallel shards actor / reference / reward / critic (one communicator),
+    # rolls out in lockstep and takes one rl_step (actor + critic updates; expert shards never all-reduced)
+    from align_anything_amd.trainers.ppo import PPOTrainer
+    wsd = state_dict_from_golden(z, 'w.', torch.bfloat16)
+    rsd = {k: v for k, v in wsd.items() if k != 'lm_head.weight'}
+    rsd['score_head.weight'] = torch.zeros(1, tiny_qwen3moe_cfg()['hidden_size'], dtype=torch.bfloat16)
+    pcfgs = {'train_cfgs': {'expert_parallel': True, 'actor_lr': 1e-3, 'critic_lr': 1e-3, 'actor_lr_scheduler_type': 'constant',
+                            'critic_lr_scheduler_type': 'constant'},
+             'model_cfgs': {'pad_token_id': int(z['pad_token_id']), 'model_max_length': 24}}
+    ptr = PPOTrainer(pcfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_qwen3moe_cfg(), actor_state=wsd, reward_state=rsd, device='cpu')
+    eps = [m.module.ep for m in (ptr.actor_model, ptr.actor_reference_model, ptr.reward_model, ptr.reward_critic_model)]
+    ok = ok and all(e is not None and e.size == world for e in eps) and len({id(e) for e in eps}) == 1
+    inference, training = ptr.rollout({'input_ids': ids, 'attention_mask': mask})
+    ok = ok and inference['input_ids'].shape == (2, 24)
+    info = ptr.rl_step(inference, training)
+    ok = ok and 'train/actor_loss' in info and ptr.actor_model.global_steps == 1 and ptr.reward_critic_model.global_steps == 1
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
