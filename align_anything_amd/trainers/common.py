@@ -212,3 +212,27 @@ def expert_parallel_kwargs(cfgs, *model_cfgs) -> dict:
     import torch.distributed as dist
     from ..expert_parallel import ExpertParallel
     return {'ep': ExpertParallel(dist.new_group())}
+
+
+def save_slice(trainer, engine, tag=None, output_dir=None) -> str:
+    """base/supervised_trainer.py:404-450 layout: <output_dir>/slice_<tag|end>/{config.json, tokenizer / processor files,
+    pytorch_model.bin} -- a directory `AnyModel.from_pretrained` loads.  The weights come from the native engine under their HF names;
+    config.json / tokenizer / processor are written when the trainer was handed the HF objects (`hf_config`, `tokenizer`, `processor`
+    attributes: the native path itself only needs the plain-dict geometry)."""
+    import os
+    out = output_dir or cfg_get(trainer.cfgs, 'logger_cfgs.output_dir', './output')
+    d = os.path.join(out, f'slice_{tag or "end"}')
+    engine.save_16bit_model(d, save_filename='pytorch_model.bin')
+    for obj in (getattr(trainer, 'hf_config', None), getattr(trainer, 'tokenizer', None), getattr(trainer, 'processor', None)):
+        if obj is not None and hasattr(obj, 'save_pretrained'):
+            obj.save_pretrained(d)
+    return d
+
+
+def save_interval(cfgs, total_steps) -> int:
+    """`total // logger_cfgs.save_total_limit` of the reference's loops (dpo.py:285-293, rm.py:307-314, ppo.py:462-468, grpo.py:368-375);
+    0 = no periodic saves (no limit configured, or the total is unknown)."""
+    limit = cfg_get(cfgs, 'logger_cfgs.save_total_limit', None)
+    if not limit or not total_steps:
+        return 0
+    return max(1, int(total_steps) // int(limit))

@@ -21,7 +21,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import build_window, cfg_get, compute_dtype, flat_to_padded, get_all_reduce_mean
+from .common import build_window, cfg_get, compute_dtype, flat_to_padded, get_all_reduce_mean, save_slice
 
 
 class DPOTrainer:
@@ -227,14 +227,5 @@ class DPOTrainer:
         return {}  # the reference's DPO eval is a stub (dpo.py:310-313)
 
     def save(self, model=None, tag=None, output_dir=None) -> str:
-        """base/supervised_trainer.py:404-450 layout: <output_dir>/slice_<tag|end>/{config.json, tokenizer / processor files,
-        pytorch_model.bin} -- a directory `AnyModel.from_pretrained` loads.  The weights come from the native engine under their HF
-        names; config.json / tokenizer / processor are written when the trainer was handed the HF objects (`self.hf_config`,
-        `self.tokenizer`, `self.processor`: the native path itself only needs the plain-dict geometry)."""
-        out = output_dir or cfg_get(self.cfgs, 'logger_cfgs.output_dir', './output')
-        d = os.path.join(out, f'slice_{tag or "end"}')
-        (model or self.model).save_16bit_model(d, save_filename='pytorch_model.bin')
-        for obj in (getattr(self, 'hf_config', None), self.tokenizer, getattr(self, 'processor', None)):
-            if obj is not None and hasattr(obj, 'save_pretrained'):
-                obj.save_pretrained(d)
-        return d
+        """base/supervised_trainer.py:404-450: <output_dir>/slice_<tag|end>/ in the layout `from_pretrained` loads (common.save_slice)."""
+        return save_slice(self, model or self.model, tag, output_dir)

@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import build_span_window, cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad_rows, expert_parallel_kwargs
+from .common import build_span_window, cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad_rows, expert_parallel_kwargs, save_interval, save_slice
 
 
 class GRPOTrainer:
@@ -127,18 +127,34 @@ class GRPOTrainer:
         return {'train/loss': s[0], 'train/reward': s[1]}
 
     def train(self, prompt_only_dataloader, generator=None) -> list:
-        """grpo.py train loop without its logging / checkpoint plumbing: one `train_step` (rollout of `num_generations` completions per
-        prompt, rewards, update) per prompt batch and epoch; returns the per-step metrics."""
+        """grpo.py:330-386 without its logging: one `train_step` (rollout of `num_generations` completions per prompt, rewards, update) per
+        prompt batch and epoch; resumes at `self.global_step` (:347-357), saves `slice_<global_step>` every epochs * len(dataloader) //
+        logger_cfgs.save_total_limit steps (:368-375) and -- when `logger_cfgs.output_dir` is configured -- the final model (:386; the reference
+        always writes it, the native loop does not create ./output on its own).  Returns the per-step metrics."""
         history = []
         self.global_step = getattr(self, 'global_step', 0)
         t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
-        if self.actor_model.total_steps is None and not self.actor_model.global_steps and hasattr(prompt_only_dataloader, '__len__'):
-            total = (len(prompt_only_dataloader) * int(t('epochs', 1)) * int(t('update_iters', 1)) * int(t('per_device_prompt_batch_size', 1))
+        epochs = int(t('epochs', 1))
+        n = len(prompt_only_dataloader) if hasattr(prompt_only_dataloader, '__len__') else None
+        if self.actor_model.total_steps is None and not self.actor_model.global_steps and n is not None:
+            total = (n * epochs * int(t('update_iters', 1)) * int(t('per_device_prompt_batch_size', 1))
                      // max(1, int(t('per_device_train_batch_size', 1))))            # grpo.py:157-163
             self.actor_model.set_schedule(max(1, total // self.gas), float(t('actor_lr_warmup_ratio', 0.03)))
-        for _ in range(int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))):
-            for batch in prompt_only_dataloader:
+        remain = epochs - self.global_step // n if n else epochs
+        skip = self.global_step % n if n else 0
+        every = save_interval(self.cfgs, epochs * n if n else None)
+        for epoch in range(int(remain)):
+            for i, batch in enumerate(prompt_only_dataloader):
+                if epoch == 0 and i < skip:
+                    continue
                 history.append(self.train_step(batch, generator))
                 self.global_step += 1
+                if every and self.global_step % every == 0:
+                    self.save(tag=self.global_step)
+        if cfg_get(self.cfgs, 'logger_cfgs.output_dir', None):
+            self.save()
         return history
 
+    def save(self, model=None, tag=None, output_dir=None) -> str:
+        """base/rl_trainer.py save_transformers: the ACTOR in the layout `from_pretrained` loads (common.save_slice)."""
+        return save_slice(self, model or self.actor_model, tag, output_dir)

@@ -59,7 +59,7 @@ def gather_log_probabilities(logits: torch.Tensor, labels: torch.Tensor) -> torc
 from ..engine import NativeEngine
 from ..modeling import build_model
 from .common import (build_span_window, cfg_get, compute_dtype, end_index, expert_parallel_kwargs, get_all_reduce_max,
-                     get_all_reduce_mean, pad_rows)
+                     get_all_reduce_mean, pad_rows, save_interval, save_slice)
 
 
 class PPOTrainer(PPOMath):
@@ -232,6 +232,10 @@ class PPOTrainer(PPOMath):
         self._set_schedules(prompt_only_dataloader, use_ptx)
         self.global_step = getattr(self, 'global_step', 0)
         history = []
+        # ppo.py:462-468: slice_<global_step> every total_update_steps // save_total_limit steps (rl_trainer.py:217-227: total_update_steps =
+        # len(prompt dataloader) x epochs x update_iters x per_device_train_batch_size x per_device_prompt_batch_size)
+        every = save_interval(self.cfgs, len(prompt_only_dataloader) * epochs * update_iters * int(t('per_device_train_batch_size', 8))
+                              * int(t('per_device_prompt_batch_size', 1)) if hasattr(prompt_only_dataloader, '__len__') else None)
         for _ in range(epochs):
             ptx_iter = itertools.cycle(ptx_dataloader) if use_ptx else None
             for prompt_batch in prompt_only_dataloader:
@@ -250,7 +254,13 @@ class PPOTrainer(PPOMath):
                             info.update(self.ptx_step(ptx_batch))
                         self.global_step += 1
                         history.append(info)
+                        if every and self.global_step % every == 0:
+                            self.save(tag=self.global_step)
         return history
+
+    def save(self, model=None, tag=None, output_dir=None) -> str:
+        """ppo.py:549-555 / base/rl_trainer.py save_transformers: the ACTOR in the layout `from_pretrained` loads (common.save_slice)."""
+        return save_slice(self, model or self.actor_model, tag, output_dir)
 
     # ------------------------------------------------------------------ update (ppo.py:309-398)
     def rl_step(self, inference_batch, training_batch):

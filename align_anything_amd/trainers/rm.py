@@ -9,7 +9,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad64
+from .common import cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad64, save_interval, save_slice
 
 
 class RMTrainer:
@@ -72,20 +72,34 @@ class RMTrainer:
         return {'train/loss': s[0], 'train/accuracy': s[1], 'train/lr': self.model.optimizer.param_groups[0]['lr']}
 
     def train(self, train_dataloader=None) -> list:
-        """rm.py train loop without its logging / checkpoint plumbing: `epochs` passes of `train_step`; returns the per-step metrics."""
+        """rm.py:265-330 without its logging: `epochs` passes of `train_step`; resumes at `self.global_step` (remaining epochs, the first
+        `global_step % len(dataloader)` batches of the resumed epoch skipped, :276-292) and saves `slice_<global_step>` every
+        epochs * len(dataloader) // logger_cfgs.save_total_limit steps (:307-314).  Returns the per-step metrics."""
         dl = train_dataloader if train_dataloader is not None else getattr(self, 'train_dataloader', None)
         if dl is None:
             raise ValueError('RMTrainer.train needs a dataloader of preference batches')
         history = []
         self.global_step = getattr(self, 'global_step', 0)
-        if self.model.total_steps is None and not self.model.global_steps and hasattr(dl, '__len__'):
-            self.model.set_schedule(int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1)) * ((len(dl) + self.gas - 1) // self.gas),
-                                    float(cfg_get(self.cfgs, 'train_cfgs.lr_warmup_ratio', 0.03)))
-        for _ in range(int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))):
-            for batch in dl:
+        epochs = int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))
+        n = len(dl) if hasattr(dl, '__len__') else None
+        if self.model.total_steps is None and not self.model.global_steps and n is not None:
+            self.model.set_schedule(epochs * ((n + self.gas - 1) // self.gas), float(cfg_get(self.cfgs, 'train_cfgs.lr_warmup_ratio', 0.03)))
+        remain = epochs - self.global_step // n if n else epochs
+        skip = self.global_step % n if n else 0
+        every = save_interval(self.cfgs, epochs * n if n else None)
+        for epoch in range(int(remain)):
+            for i, batch in enumerate(dl):
+                if epoch == 0 and i < skip:
+                    continue
                 history.append(self.train_step(batch))
                 self.global_step += 1
+                if every and self.global_step % every == 0:
+                    self.save(tag=self.global_step)
         return history
+
+    def save(self, model=None, tag=None, output_dir=None) -> str:
+        """base/supervised_trainer.py:404-450 (common.save_slice): the score model in the layout `from_pretrained` loads."""
+        return save_slice(self, model or self.model, tag, output_dir)
 
     @torch.no_grad()
     def eval(self, eval_dataloader=None) -> dict:

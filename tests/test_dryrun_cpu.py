@@ -524,3 +524,47 @@ def test_train_resumes_mid_epoch_and_saves_on_the_reference_schedule(launches, t
     tr.global_step = 0
     hist = tr.train()
     assert len(hist) == 6 and sorted(os.listdir(tmp_path)) == ['slice_2', 'slice_4', 'slice_6']
+
+
+def test_rm_grpo_ppo_loops_resume_and_save_on_the_reference_schedules(launches, tmp_path):
+    """rm.py:276-314 (resume + slice every epochs * len // save_total_limit), grpo.py:347-386 (the same + the final save of the actor),
+    ppo.py:462-468 (slice every total_update_steps // save_total_limit) -- the sibling loops of dpo.py:256-293."""
+    import os
+    from align_anything_amd.trainers.grpo import GRPOTrainer
+    from align_anything_amd.trainers.ppo import PPOTrainer
+    from align_anything_amd.trainers.rm import RMTrainer
+    z = load_golden('opt_tiny_dpo.npz')
+    cfg = tiny_opt_cfg()
+    sd = state_dict_from_golden(z, 'w.', torch.bfloat16)
+    rm_sd = {k: v for k, v in sd.items() if k != 'lm_head.weight'}
+    rm_sd['score_head.weight'] = torch.zeros(1, cfg['hidden_size'], dtype=torch.bfloat16)
+    # ---- RM: 2 epochs x 3 batches, limit 3 -> every 2 steps; resumed after step 4 (one batch of epoch 2 consumed)
+    c = _cfgs(z, epochs=2)
+    c['logger_cfgs'] = {'output_dir': str(tmp_path / 'rm'), 'save_total_limit': 3}
+    rm = RMTrainer(c, {'gradient_clipping': 1.0}, model_cfg=cfg, state=rm_sd, device='cpu')
+    rm.global_step = 4
+    assert len(rm.train([_pref_batch(z)] * 3)) == 2 and rm.global_step == 6
+    assert sorted(os.listdir(tmp_path / 'rm')) == ['slice_6'] and os.path.exists(tmp_path / 'rm' / 'slice_6' / 'pytorch_model.bin')
+    saved = torch.load(tmp_path / 'rm' / 'slice_6' / 'pytorch_model.bin')
+    assert 'score_head.weight' in saved and 'lm_head.weight' not in saved
+    # ---- GRPO: 1 epoch x 4 prompt batches, limit 2 -> slices at 2 and 4, and the final actor (output_dir is configured)
+    prompts = T(z['input_ids'])[:2, :20]
+    pb = {'input_ids': prompts, 'attention_mask': torch.ones_like(prompts)}
+    gc = {'train_cfgs': {'actor_lr': 1e-3, 'actor_lr_scheduler_type': 'constant', 'num_generations': 2},
+          'model_cfgs': {'pad_token_id': 1, 'eos_token_id': 2, 'model_max_length': 24},
+          'logger_cfgs': {'output_dir': str(tmp_path / 'grpo'), 'save_total_limit': 2}}
+    g = GRPOTrainer(gc, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=sd, reference_state=sd, reward_fn=lambda x: x.sum(1).float(), device='cpu')
+    assert len(g.train([pb] * 4)) == 4
+    assert sorted(os.listdir(tmp_path / 'grpo')) == ['slice_2', 'slice_4', 'slice_end']
+    assert 'lm_head.weight' in torch.load(tmp_path / 'grpo' / 'slice_end' / 'pytorch_model.bin') or cfg['kind'] == 'opt'
+    g.global_step = 3                                     # resumed: only the last prompt batch is left
+    assert len(g.train([pb] * 4)) == 1 and g.global_step == 4
+    # ---- PPO: 2 prompt batches x 2 micro-batches x 1 update iteration = total_update_steps 2 * 1 * 1 * 2 * 1 = 4, limit 2 -> slices at 2 and 4
+    pc = {'train_cfgs': {'actor_lr': 1e-3, 'critic_lr': 1e-3, 'actor_lr_scheduler_type': 'constant', 'critic_lr_scheduler_type': 'constant',
+                         'per_device_train_batch_size': 2, 'update_iters': 1, 'epochs': 1},
+          'model_cfgs': {'pad_token_id': 1, 'model_max_length': 28},
+          'logger_cfgs': {'output_dir': str(tmp_path / 'ppo'), 'save_total_limit': 2}}
+    p = PPOTrainer(pc, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=sd, reward_state=rm_sd, device='cpu')
+    four = {'input_ids': T(z['input_ids'])[:, :24], 'attention_mask': T(z['attention_mask'])[:, :24]}
+    assert len(p.train([four, four])) == 4 and p.global_step == 4
+    assert sorted(os.listdir(tmp_path / 'ppo')) == ['slice_2', 'slice_4']
