@@ -341,10 +341,17 @@ class NativeEngine:
 
     # ---- checkpoints (HF layout, supervised_trainer.py:404-450)
     def save_16bit_model(self, save_dir, save_filename='pytorch_model.bin'):
+        """Rank 0 writes (the replicas are identical; DeepSpeed's save_16bit_model writes from rank 0 as well).  Every rank may call it --
+        with expert-parallel weights every rank MUST: `state_dict()` gathers the expert shards, a collective."""
         self.wait_optimizer()
-        os.makedirs(save_dir, exist_ok=True)
-        sd = {k: v.cpu() for k, v in self.module.state_dict().items()}
         path = os.path.join(save_dir, save_filename)
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        if rank != 0 and getattr(self.module, 'ep', None) is None:
+            return path
+        sd = {k: v.cpu() for k, v in self.module.state_dict().items()}
+        if rank != 0:
+            return path
+        os.makedirs(save_dir, exist_ok=True)
         if save_filename.endswith('.safetensors'):
             from safetensors.torch import save_file
             save_file({k: v.contiguous() for k, v in sd.items() if k != 'lm_head.weight' or self.module.kind != 'opt'},

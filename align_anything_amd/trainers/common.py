@@ -222,10 +222,12 @@ def save_slice(trainer, engine, tag=None, output_dir=None) -> str:
     import os
     out = output_dir or cfg_get(trainer.cfgs, 'logger_cfgs.output_dir', './output')
     d = os.path.join(out, f'slice_{tag or "end"}')
-    engine.save_16bit_model(d, save_filename='pytorch_model.bin')
-    for obj in (getattr(trainer, 'hf_config', None), getattr(trainer, 'tokenizer', None), getattr(trainer, 'processor', None)):
-        if obj is not None and hasattr(obj, 'save_pretrained'):
-            obj.save_pretrained(d)
+    engine.save_16bit_model(d, save_filename='pytorch_model.bin')          # every rank calls it (expert shards are gathered), rank 0 writes
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0:
+        for obj in (getattr(trainer, 'hf_config', None), getattr(trainer, 'tokenizer', None), getattr(trainer, 'processor', None)):
+            if obj is not None and hasattr(obj, 'save_pretrained'):
+                obj.save_pretrained(d)
     return d
 
 

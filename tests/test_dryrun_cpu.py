@@ -298,6 +298,12 @@ def _dp_worker(rank, world, port, q):
     for g in st.gflat.values():
         ok = ok and bool((g.float() == want).all())
     ok = ok and 'train/loss' in info and tr.model.global_steps == 1 and 'aa_adamw_flat' in seen
+    # checkpoints: every rank calls save(), rank 0 alone writes (replicas are identical)
+    import tempfile
+    d = tempfile.mkdtemp(prefix=f'aa_dp_save_r{rank}_')
+    tr.save(tag=1, output_dir=d)
+    wrote = os.path.exists(os.path.join(d, 'slice_1', 'pytorch_model.bin'))
+    ok = ok and wrote == (rank == 0)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
