@@ -659,25 +659,121 @@ extern "C" int aa_gemm_glu_fwd_bf16(const void* A, const void* Wgu, void* GU, vo
 }
 
 // backward of the same block: dGU[M, 2F] = swiglu'(GU) (.) (dY[M, h] W_down[h, F]); the fused kernel never stores d_act, the unfused
-// path needs `dact_ws` [M, F]
-extern "C" int aa_gemm_glu_bwd_bf16(const void* dY, const void* Wdown, const void* GU, void* dGU, void* dact_ws, int M, int F, int K,
-                                    long ldy, long ldw, long ldgu, long lddgu, void* stream) {
-    AA_REQUIRE(F > 0 && (F & 7) == 0, "aa_gemm_glu_bwd_bf16: ffn %d must be a multiple of 8", F);
-    if (fuse_enabled()) {
+// path needs `dact_ws` [M, F].
+//
+// Which of the two runs is a per-shape PLAN.  The fused epilogue moves 4 x M x F x 2 B from inside a one-workgroup-per-CU GEMM tile
+// (its loads are dependent round trips the MFMA work of no other tile can hide), the unfused pair streams d_act once more but from a
+// full-chip element-wise kernel.  On most MI355X boxes the two are within 5 % of each other; on boxes with a longer memory round trip the
+// fused kernel was measured at 2.2-2.3 ms against 1.03 + 0.36 ms for the pair (BENCH_r02, profiles/r02_glu_bwd_latency.txt).  A box cannot
+// be told apart from inside a kernel, so the caller measures: aa_gemm_glu_bwd_probe() times both variants on the caller's own buffers
+// (both produce bit-identical dGU, tests/test_gemm_gpu.py) and records the faster one for that (M, F, K); aa_gemm_glu_bwd_bf16 follows
+// the record, and fuses when there is none.
+static bool glu_bwd_fusable(const void* dY, const void* Wdown, int M, int F, int K, long ldy, long ldw, long ldgu, long lddgu,
+                            const void* GU, const void* dGU) {
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    return fuse_enabled() && M % 256 == 0 && F % 256 == 0 && aa_gemm4_supports(K) && (ldy & 7) == 0 && (ldw & 7) == 0 && (ldgu & 7) == 0 &&
+           (lddgu & 7) == 0 && (F & 7) == 0 && al16(dY) && al16(Wdown) && al16(GU) && al16(dGU);
+}
+
+namespace {
+struct GluPlan { int M, F, K, fused; };
+constexpr int GLU_PLANS = 16;
+GluPlan g_glu_plans[GLU_PLANS];
+int g_glu_nplans = 0;
+int g_glu_mode = -1;                 // AA_GLU_BWD: -1 = follow the per-shape record (default), 0 = always unfused, 1 = always fused
+bool g_glu_mode_read = false;
+int glu_mode() {
+    if (!g_glu_mode_read) { const char* e = getenv("AA_GLU_BWD"); if (e) g_glu_mode = atoi(e); g_glu_mode_read = true; }
+    return g_glu_mode;
+}
+int glu_plan_lookup(int M, int F, int K) {
+    for (int i = 0; i < g_glu_nplans; ++i)
+        if (g_glu_plans[i].M == M && g_glu_plans[i].F == F && g_glu_plans[i].K == K) return g_glu_plans[i].fused;
+    return -1;
+}
+void glu_plan_store(int M, int F, int K, int fused) {
+    for (int i = 0; i < g_glu_nplans; ++i)
+        if (g_glu_plans[i].M == M && g_glu_plans[i].F == F && g_glu_plans[i].K == K) { g_glu_plans[i].fused = fused; return; }
+    const int slot = g_glu_nplans < GLU_PLANS ? g_glu_nplans++ : 0;
+    g_glu_plans[slot] = GluPlan{M, F, K, fused};
+}
+int glu_bwd_run(bool fused, const void* dY, const void* Wdown, const void* GU, void* dGU, void* dact_ws, int M, int F, int K, long ldy,
+                long ldw, long ldgu, long lddgu, void* stream) {
+    if (fused) {
         GemmParams p{};
         p.A = (const bf16_t*)dY; p.B = (const bf16_t*)Wdown; p.C = nullptr;
         p.M = M; p.N = F; p.K = K; p.lda = ldy; p.ldb = ldw; p.ldc = 8; p.flags = AA_GEMM_B_N;
         p.gm = pick_group(false, true, aa_cdiv(F, 256), K);
         p.fuse = AA_FUSE_GLU_BWD; p.aux = dGU; p.ldaux = lddgu; p.aux_in = (const bf16_t*)GU; p.ldaux_in = ldgu; p.glu_f = F;
-        if ((ldy & 7) == 0 && (ldw & 7) == 0 && ((uintptr_t)dY & 15) == 0 && ((uintptr_t)Wdown & 15) == 0) {
-            const int rc = aa_gemm4_fused(p, (hipStream_t)stream);
-            if (rc != 1) return rc;
-        }
+        const int rc = aa_gemm4_fused(p, (hipStream_t)stream);
+        if (rc != 1) return rc;
     }
     AA_REQUIRE(dact_ws != nullptr && ldgu == 2L * F && lddgu == 2L * F, "aa_gemm_glu_bwd_bf16: the unfused path needs a d_act workspace and dense [M, 2F] buffers");
     const int rc = aa_gemm_bf16(dY, Wdown, dact_ws, M, F, K, ldy, ldw, F, nullptr, nullptr, 0, AA_ACT_NONE, AA_GEMM_B_N, stream);
     if (rc != AA_OK) return rc;
     return aa_swiglu_bwd(GU, dact_ws, dGU, M, F, stream);
+}
+}  // namespace
+
+// *plan = 1: the fused kernel will run for these arguments, 0 = the unfused pair (the caller must pass a d_act workspace), 2 = fusable but no
+// record yet for (M, F, K): fused unless aa_gemm_glu_bwd_probe decides otherwise.  The single source of truth for "is dact_ws needed".
+static int glu_bwd_plan(const void* dY, const void* Wdown, const void* GU, const void* dGU, int M, int F, int K, long ldy, long ldw,
+                        long ldgu, long lddgu) {
+    if (!glu_bwd_fusable(dY, Wdown, M, F, K, ldy, ldw, ldgu, lddgu, GU, dGU) || glu_mode() == 0) return 0;
+    if (glu_mode() == 1) return 1;
+    const int rec = glu_plan_lookup(M, F, K);
+    return rec < 0 ? 2 : rec;
+}
+extern "C" int aa_gemm_glu_bwd_plan(const void* dY, const void* Wdown, const void* GU, const void* dGU, int M, int F, int K, long ldy,
+                                    long ldw, long ldgu, long lddgu, int* plan) {
+    AA_REQUIRE(plan != nullptr, "aa_gemm_glu_bwd_plan: plan is null");
+    *plan = glu_bwd_plan(dY, Wdown, GU, dGU, M, F, K, ldy, ldw, ldgu, lddgu);
+    return AA_OK;
+}
+
+extern "C" int aa_gemm_glu_bwd_set_mode(int mode) { g_glu_mode = mode; g_glu_mode_read = true; return AA_OK; }
+extern "C" int aa_gemm_glu_bwd_forget(void) { g_glu_nplans = 0; return AA_OK; }
+
+// Times `reps` launches of each variant on the caller's buffers (after one untimed launch each) with HIP events on `stream`, records the
+// faster one for (M, F, K) and leaves dGU computed.  Synchronises the stream: call it once per shape, outside any timed region.
+extern "C" int aa_gemm_glu_bwd_probe(const void* dY, const void* Wdown, const void* GU, void* dGU, void* dact_ws, int M, int F, int K,
+                                     long ldy, long ldw, long ldgu, long lddgu, int reps, float* ms_fused, float* ms_unfused, void* stream) {
+    AA_REQUIRE(dact_ws != nullptr && reps > 0, "aa_gemm_glu_bwd_probe: needs a d_act workspace and reps > 0");
+    if (!glu_bwd_fusable(dY, Wdown, M, F, K, ldy, ldw, ldgu, lddgu, GU, dGU)) {
+        if (ms_fused) *ms_fused = -1.f;
+        if (ms_unfused) *ms_unfused = -1.f;
+        return glu_bwd_run(false, dY, Wdown, GU, dGU, dact_ws, M, F, K, ldy, ldw, ldgu, lddgu, stream);
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { aa_set_error("aa_gemm_glu_bwd_probe: hipEventCreate failed"); return AA_ERR_LAUNCH; }
+    float ms[2] = {0.f, 0.f};
+    int rc = AA_OK;
+    for (int variant = 0; variant < 2 && rc == AA_OK; ++variant) {
+        const bool fused = variant == 0;
+        rc = glu_bwd_run(fused, dY, Wdown, GU, dGU, dact_ws, M, F, K, ldy, ldw, ldgu, lddgu, stream);
+        (void)hipEventRecord(e0, (hipStream_t)stream);
+        for (int r = 0; r < reps && rc == AA_OK; ++r) rc = glu_bwd_run(fused, dY, Wdown, GU, dGU, dact_ws, M, F, K, ldy, ldw, ldgu, lddgu, stream);
+        (void)hipEventRecord(e1, (hipStream_t)stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms[variant], e0, e1) != hipSuccess) {
+            aa_set_error("aa_gemm_glu_bwd_probe: event timing failed");
+            rc = AA_ERR_LAUNCH;
+        }
+        ms[variant] /= (float)reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != AA_OK) return rc;
+    if (ms_fused) *ms_fused = ms[0];
+    if (ms_unfused) *ms_unfused = ms[1];
+    glu_plan_store(M, F, K, ms[0] <= ms[1] ? 1 : 0);
+    return AA_OK;
+}
+
+extern "C" int aa_gemm_glu_bwd_bf16(const void* dY, const void* Wdown, const void* GU, void* dGU, void* dact_ws, int M, int F, int K,
+                                    long ldy, long ldw, long ldgu, long lddgu, void* stream) {
+    AA_REQUIRE(F > 0 && (F & 7) == 0, "aa_gemm_glu_bwd_bf16: ffn %d must be a multiple of 8", F);
+    const bool fused = glu_bwd_plan(dY, Wdown, GU, dGU, M, F, K, ldy, ldw, ldgu, lddgu) != 0;
+    return glu_bwd_run(fused, dY, Wdown, GU, dGU, dact_ws, M, F, K, ldy, ldw, ldgu, lddgu, stream);
 }
 
 // test hook: force a tile config (-1 = heuristic)

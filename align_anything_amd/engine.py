@@ -256,13 +256,14 @@ class NativeEngine:
         st = self.module.store
         if self.micro_steps % self.gas != 0:
             return  # not at a gradient-accumulation boundary (DeepSpeedEngine.step semantics)
+        # HF schedulers are stepped AFTER optimizer.step(): update k (1-based) uses lr(k-1); the value the
+        # trainer logs as train/lr after the step is lr(k).  Computed BEFORE any state changes: a schedule that cannot be evaluated
+        # yet (cosine / linear without total_steps) raises here and leaves the engine un-stepped, so set_schedule() can still be called
+        lr_used = self._lr_at(self.global_steps)
+        lr = self._lr_at(self.global_steps + 1)
         self.reducer.wait()
         self.global_steps += 1
         gscale = 1.0 / self.world
-        # HF schedulers are stepped AFTER optimizer.step(): update k (1-based) uses lr(k-1); the value the
-        # trainer logs as train/lr after the step is lr(k)
-        lr_used = self._lr_at(self.global_steps - 1)
-        lr = self._lr_at(self.global_steps)
 
         def launch():
             self._sumsq.zero_()

@@ -1037,10 +1037,12 @@ class NativeQwen2VL(NativeCausalLM):
         return valid + self._deltas.to(valid.dtype) if self._deltas is not None else valid
 
     def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
-                       position_ids=None, kv_sink=None, image_grid_thw=None, position_ids3=None):
+                       position_ids=None, kv_sink=None, image_grid_thw=None, position_ids3=None, kv_len=None):
         """position_ids3 (int32 [3, N, T], e.g. precomputed by the input pipeline on the host) avoids the device->host
-        copy of input_ids that computing the 3-D rope index needs."""
+        copy of input_ids that computing the 3-D rope index needs.  kv_len (int32 [N], optional): keys at or beyond it are masked
+        in the decoder (right padding, as for NativeLlava: the reward model reads position -1, models/qwen2_vl.py:61-64)."""
         N, T, Mp, start, _ = self._token_geometry(input_ids, attention_mask, None)
+        self.stack.kv_len = kv_len
         P, t = self.store.p, self.cfg['text']
         ids = input_ids.reshape(-1)
         if Mp != N * T:

@@ -6,6 +6,7 @@ CPU or falls back to torch ops.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -131,18 +132,41 @@ def gemm_glu_fwd(x, w_gu, F):
     return gu, act
 
 
+_GLU_WS = {}          # (device, M, F) -> d_act workspace of the unfused SwiGLU-backward pair (allocated only when that plan is chosen)
+GLU_BWD_PROBE = os.environ.get('AA_GLU_BWD_PROBE', '1') != '0'
+GLU_BWD_PROBE_LOG = []   # (M, F, K, ms_fused, ms_unfused) of every probe this process ran (bench.py reports it)
+
+
+def _glu_ws(M, F, device):
+    key = (str(device), M, F)
+    ws = _GLU_WS.get(key)
+    if ws is None:
+        ws = _GLU_WS[key] = torch.empty((M, F), dtype=bf16, device=device)
+    return ws
+
+
 def gemm_glu_bwd(dy, w_down, gu, F):
-    """d[gate|up] [M, 2F] of the block above from dy [M, h] (gradient of the down projection's output) and w_down [h, F]."""
+    """d[gate|up] [M, 2F] of the block above from dy [M, h] (gradient of the down projection's output) and w_down [h, F].  The C side
+    owns the decision between the fused epilogue and the unfused GEMM + aa_swiglu_bwd pair (aa_gemm_glu_bwd_plan); the first time a
+    fusable shape is seen both are timed on the live buffers (aa_gemm_glu_bwd_probe: same bits either way) and the faster one is kept
+    for the process -- the fused epilogue is 1.6 x slower than the pair on boxes with a long memory round trip."""
     _chk(dy, bf16, 'gemm_glu_bwd.dy'); _chk(w_down, bf16, 'gemm_glu_bwd.w'); _chk(gu, bf16, 'gemm_glu_bwd.gu')
     _row_major(dy, 'gemm_glu_bwd.dy'); _row_major(w_down, 'gemm_glu_bwd.w'); _row_major(gu, 'gemm_glu_bwd.gu')
     M, K = dy.shape
     dgu = torch.empty_like(gu)
-    fused = fuse_enabled() and M % 256 == 0 and F % 256 == 0 and K % 128 == 0      # aa_gemm4_fused's conditions; otherwise the unfused pair needs d_act
-    ws = None if fused else torch.empty((M, F), dtype=bf16, device=dy.device)
+    plan = ctypes.c_int(-1)
+    args = (dy.data_ptr(), w_down.data_ptr(), gu.data_ptr(), dgu.data_ptr())
+    dims = (M, F, K, dy.stride(0), w_down.stride(0), gu.stride(0), dgu.stride(0))
+    call('aa_gemm_glu_bwd_plan', *args, *dims, ctypes.addressof(plan))
     FLOPS['gemm'] += 2.0 * M * F * K
+    if plan.value == 2 and GLU_BWD_PROBE:
+        t = (ctypes.c_float * 2)()
+        call('aa_gemm_glu_bwd_probe', *args, _glu_ws(M, F, dy.device).data_ptr(), *dims, 3, ctypes.addressof(t), ctypes.addressof(t) + 4, stream())
+        GLU_BWD_PROBE_LOG.append((M, F, K, float(t[0]), float(t[1])))
+        return dgu
+    ws = _glu_ws(M, F, dy.device) if plan.value == 0 else None
     prof = _prof_begin()
-    call('aa_gemm_glu_bwd_bf16', dy.data_ptr(), w_down.data_ptr(), gu.data_ptr(), dgu.data_ptr(), _p(ws), M, F, K, dy.stride(0),
-         w_down.stride(0), gu.stride(0), dgu.stride(0), stream())
+    call('aa_gemm_glu_bwd_bf16', *args, _p(ws), *dims, stream())
     _prof_end(prof, 2.0 * M * F * K, 2.0 * (M * K + F * K + 4 * M * F))
     return dgu
 

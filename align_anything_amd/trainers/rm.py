@@ -9,7 +9,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad64, save_interval, save_slice
+from .common import END_AT_LAST_POSITION_KINDS, cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad64, save_interval, save_slice
 
 
 class RMTrainer:
@@ -43,17 +43,23 @@ class RMTrainer:
         return {'N': N, 'T': T, 'rows': N, 'rows_pad': rows_pad, 'row_idx': row_idx, 'inv_map': inv,
                 'labels': torch.zeros(rows_pad, dtype=torch.int64, device=dev)}, end
 
+    def _mm(self, batch):
+        """The multimodal keys of a batch for `response_scores`, the same for loss() and eval().  The vision-language reward models read
+        the end score at position -1 even when that position is padding (models/llava.py:64-68, qwen2_vl.py:61-64), so what a masked
+        query row sees matters: HF hides the right-padded keys from it -> kv_len = one past the last attended key, per row."""
+        ids, am = batch['input_ids'], batch['attention_mask']
+        mm = {k: batch[k] for k in ('image_grid_thw', 'position_ids3', 'input_features', 'feature_attention_mask') if k in batch}
+        if self.model.module.kind in END_AT_LAST_POSITION_KINDS:
+            T = ids.shape[1]
+            mm['kv_len'] = (am.to(torch.int32) * torch.arange(1, T + 1, dtype=torch.int32, device=ids.device)).amax(dim=1).to(torch.int32)
+        return mm
+
     def loss(self, batch):
         ids, am = batch['input_ids'], batch['attention_mask']
         B = ids.shape[0] // 2
         w, end = self._end_window(ids, am)
         self.model.wait_optimizer()
-        mm = {k: batch[k] for k in ('image_grid_thw', 'position_ids3', 'input_features', 'feature_attention_mask') if k in batch}
-        if self.model.module.kind == 'llava':
-            # the end score of this backbone is read at position -1 even when that position is padding (models/llava.py:64-68), so what
-            # a masked query row sees matters: HF hides the right-padded keys from it -> one past the last attended key, per row
-            T = ids.shape[1]
-            mm['kv_len'] = (am.to(torch.int32) * torch.arange(1, T + 1, dtype=torch.int32, device=ids.device)).amax(dim=1).to(torch.int32)
+        mm = self._mm(batch)
         end_scores, scores = self.model.module.response_scores(ids, am, w, pixel_values=batch.get('pixel_values'), save=True,
                                                                all_scores=True, **mm)
         out2, d = ops.rm_loss(end_scores[:2 * B].contiguous(), B, self.regularization)
@@ -116,9 +122,7 @@ class RMTrainer:
             B = ids.shape[0] // 2
             w, _ = self._end_window(ids, am)
             self.model.wait_optimizer()
-            mm = {}
-            if self.model.module.kind == 'llava':      # as in loss(): right-padded keys are hidden from the row at position -1
-                mm['kv_len'] = (am.to(torch.int32) * torch.arange(1, ids.shape[1] + 1, dtype=torch.int32, device=ids.device)).amax(dim=1).to(torch.int32)
+            mm = self._mm(batch)
             s = self.model.module.response_scores(ids, am, w, pixel_values=batch.get('pixel_values'), save=False, **mm)[:2 * B]
             hits = (s[:B] > s[B:]).sum()
             correct = hits if correct is None else correct + hits

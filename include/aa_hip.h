@@ -152,13 +152,19 @@ int aa_rope_inplace(void* buf, long ld, int col0, int nheads, int hd, const int*
 int aa_mrope_tables(const int* pos3, long rows, const float* inv_freq, int half, int sec0, int sec1, void* cos_t,
                     void* sin_t, void* stream);
 /* GEMMs with the element-wise neighbour of the HF graph folded into the epilogue of the one-wave-per-SIMD kernel (csrc/gemm4.hip).
- * Each runs fused when the shape qualifies (M and N multiples of 256, K of 64, 16-byte aligned rows; rotary: head_dim 128) and as the
+ * Each runs fused when the shape qualifies (M and N multiples of 256, K of 128, 16-byte aligned rows; rotary: head_dim 128) and as the
  * unfused pair of kernels otherwise -- same rounding points, bit-identical results (tests/test_gemm_gpu.py).
  *  - aa_gemm_qkv_rope_bf16: hf:models/llama/modeling_llama.py:228-246 (q/k/v projections of the fused [q|k|v] weight) +
  *    apply_rotary_pos_emb :130-160 on the heads in columns [0, rope_cols); pos[M] int32, cos_t / sin_t [max_pos, hd/2] bf16
  *  - aa_gemm_glu_fwd_bf16: LlamaMLP :163-176: GU[M, 2F] = A [Wgate; Wup]^T (kept for the backward), ACT[M, F] = silu(gate) * up
  *  - aa_gemm_glu_bwd_bf16: its backward: dGU[M, 2F] from d_act = dY[M, K] Wdown[K, F] (never stored when fused; the unfused path
  *    needs the [M, F] workspace dact_ws) and the saved GU
+ *    needs the [M, F] workspace dact_ws) and the saved GU.  Which of the two runs is a per-(M, F, K) plan: aa_gemm_glu_bwd_plan
+ *    writes *plan = 1 (fused), 0 (unfused pair: dact_ws required) or 2 (fusable, not yet measured: fused); aa_gemm_glu_bwd_probe times both
+ *    variants on the caller's buffers (`reps` launches each, HIP events on `stream`, synchronises it), records the faster one for the
+ *    shape and leaves dGU computed -- boxes with a longer memory round trip run the fused epilogue 1.6 x slower than the pair
+ *    (profiles/r02_glu_bwd_latency.txt), which no kernel can see from the inside; aa_gemm_glu_bwd_set_mode(-1 / 0 / 1) = follow the
+ *    record / always unfused / always fused (env AA_GLU_BWD), aa_gemm_glu_bwd_forget() drops the records
  *  - aa_gemm_set_fuse(0): always the unfused kernels (A/B and parity runs; env AA_GEMM_FUSE=0 does the same) */
 int aa_gemm_qkv_rope_bf16(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc, const int* pos,
                           const void* cos_t, const void* sin_t, int rope_cols, int hd, void* stream);
@@ -166,6 +172,12 @@ int aa_gemm_glu_fwd_bf16(const void* A, const void* Wgu, void* GU, void* ACT, in
                          long ldact, void* stream);
 int aa_gemm_glu_bwd_bf16(const void* dY, const void* Wdown, const void* GU, void* dGU, void* dact_ws, int M, int F, int K, long ldy,
                          long ldw, long ldgu, long lddgu, void* stream);
+int aa_gemm_glu_bwd_plan(const void* dY, const void* Wdown, const void* GU, const void* dGU, int M, int F, int K, long ldy, long ldw,
+                         long ldgu, long lddgu, int* plan);
+int aa_gemm_glu_bwd_probe(const void* dY, const void* Wdown, const void* GU, void* dGU, void* dact_ws, int M, int F, int K, long ldy,
+                          long ldw, long ldgu, long lddgu, int reps, float* ms_fused, float* ms_unfused, void* stream);
+int aa_gemm_glu_bwd_set_mode(int mode);
+int aa_gemm_glu_bwd_forget(void);
 int aa_gemm_set_fuse(int on);
 /* hf:models/llama/modeling_llama.py:163-176 LlamaMLP gate: silu(gate)*up on [M, 2F] -> [M, F] */
 int aa_swiglu_fwd(const void* gate_up, void* out, long M, int F, void* stream);

@@ -859,6 +859,65 @@ def gen_llava_rm():
     np.savez_compressed(os.path.join(GOLD, 'llava_tiny_rm.npz'), **out)
 
 
+def gen_qwen2vl_rm():
+    """The reference's text+image reward-model trainer (trainers/text_image_to_text/rm.py -> text_to_text/rm.py:97-132) on its own
+    AccustomedQwen2VLRewardModel (models/qwen2_vl.py:42-72: end score = the score at position -1 whatever the attention mask says), fp32,
+    CPU, on a RIGHT-padded batch (rm.py:81 `padding_side='right'`): chosen / rejected rows of different lengths, so position -1 of the
+    shorter rows is padding and HF hides the padded keys from it.  Six outputs + gradients.  Stood in: `mm_token_type_ids` (recomputed
+    from the ids, transformers 5.x) and `config.hidden_size` (pre-5.x layout, models/qwen2_vl.py:48)."""
+    from align_anything.models.qwen2_vl import AccustomedQwen2VLRewardModel
+    from align_anything.trainers.text_image_to_text.rm import RMTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+    cfg, lm = tiny_qwen2vl()
+    cfg.hidden_size = cfg.text_config.hidden_size
+    torch.manual_seed(3)
+    rm = AccustomedQwen2VLRewardModel(cfg).eval()
+    g = torch.Generator().manual_seed(37)
+    with torch.no_grad():
+        rm.load_state_dict(lm.state_dict(), strict=False)
+        rm.score_head.weight.copy_((torch.randn(1, 128, generator=g) * 0.3).to(torch.bfloat16).float())
+    B, T, PAD, IMG = 2, 40, 304, 300
+    grids1 = [[1, 4, 6], [1, 4, 4]]
+    grids = grids1 + grids1
+    pix1 = [torch.randn(t * h * w, 3 * 2 * 14 * 14, generator=g) for t, h, w in grids1]
+    pixel_values = torch.cat(pix1 + pix1, 0)
+    ids = torch.full((2 * B, T), PAD, dtype=torch.long)
+    mask = torch.zeros((2 * B, T), dtype=torch.long)
+    for r, rp in enumerate((0, 7, 5, 0)):                 # right padding: row 0 / 3 are full, rows 1 / 2 end early
+        ntok = grids[r][1] * grids[r][2] // 4
+        n_txt = T - rp - 3 - ntok
+        row = torch.cat([torch.tensor([1, 302]), torch.full((ntok,), IMG), torch.tensor([303]), torch.randint(3, 299, (n_txt,), generator=g)])
+        ids[r, :T - rp] = row
+        mask[r, :T - rp] = 1
+
+    class Mod(torch.nn.Module):
+        def __init__(self, m): super().__init__(); self.m = m
+        def forward(self, **kw):
+            kw['mm_token_type_ids'] = (kw['input_ids'] == IMG).int()
+            return self.m(**kw)
+    tr = RMTrainer.__new__(RMTrainer)
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'regularization': 0.01}})
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    tr.model = Mod(rm)
+    rm.zero_grad()
+    batch = {'input_ids': ids, 'attention_mask': mask, 'pixel_values': pixel_values, 'image_grid_thw': torch.tensor(grids), 'meta_info': {}}
+    ld = tr.loss(batch)
+    ld['loss'].backward()
+    out = {'input_ids': ids.numpy(), 'attention_mask': mask.numpy(), 'pixel_values': pixel_values.numpy(), 'image_grid_thw': np.array(grids),
+           'pad_token_id': np.array(PAD), 'regularization': np.array(0.01)}
+    for k, v in ld.items():
+        out[k] = v.detach().numpy()
+    for n, q in rm.named_parameters():
+        if q.grad is not None and (n == 'score_head.weight' or n.endswith('layers.1.mlp.down_proj.weight') or n.endswith('layers.0.self_attn.q_proj.weight')
+                                   or n.endswith('layers.0.self_attn.k_proj.bias') or n.endswith('language_model.norm.weight') or n.endswith('merger.mlp.2.bias')):
+            out['g.' + n] = q.grad.numpy().copy()
+    for n, q in rm.state_dict().items():
+        out['w.' + n] = bf16_bits(q)
+    np.savez_compressed(os.path.join(GOLD, 'qwen2vl_tiny_rm.npz'), **out)
+    print('qwen2vl_tiny_rm loss', float(ld['loss']), 'acc', float(ld['accuracy']), 'end', ld['higher_end_reward'].tolist(), ld['lower_end_reward'].tolist(),
+          'grads', sum(k.startswith('g.') for k in out))
+
+
 def gen_opt_ppo():
     """The reference's unmodified text_to_text PPOTrainer.rollout (trainers/text_to_text/ppo.py:244-289, incl. actor_step
     :209-222 after `generate` and reward_model_step :224-242) and rl_step (:309-398) with HF OPT as actor / reference and the
@@ -1018,5 +1077,6 @@ if __name__ == '__main__':
     gen_grpo()
     gen_opt_rm()
     gen_llava_rm()
+    gen_qwen2vl_rm()
     gen_opt_ppo()
     gen_opt125m_curve()

@@ -419,3 +419,33 @@ def test_llava_rm_oracle_matches_reference_ti2t_rm_trainer_loss():
         assert n == 6
     # the cut changes the result: the two variants are different problems, not one tested twice
     assert abs(float(z['left_loss']) - float(z['rightcut_loss'])) > 1e-3
+
+
+def test_qwen2vl_rm_oracle_matches_reference_ti2t_rm_trainer_loss():
+    """The reference's text+image RMTrainer.loss on its AccustomedQwen2VLRewardModel (tests/golden/qwen2vl_tiny_rm.npz, fp32 CPU) on a
+    RIGHT-padded batch: the end score is read at position -1 (models/qwen2_vl.py:61-64), a padding position for the shorter rows, whose
+    query must not see the padded keys.  The oracle's Qwen2-VL hidden states + score_from_hidden + rm_loss reproduce the six outputs and
+    the gradients."""
+    from tests.util import tiny_qwen2vl_cfg
+    z = load_golden('qwen2vl_tiny_rm.npz')
+    cfg = tiny_qwen2vl_cfg()
+    ids, mask, pix = T(z['input_ids']), T(z['attention_mask']), T(z['pixel_values'])
+    grid = z['image_grid_thw'].tolist()
+    assert (mask[:, -1] == 0).any() and (mask[:, 0] == 1).all()                      # right padding, some rows end early
+    sd = {k: v.clone().requires_grad_(True) for k, v in state_dict_from_golden(z, 'w.').items() if k != 'lm_head.weight'}
+    hid = om.qwen2vl_hidden({k: v for k, v in sd.items() if k != 'score_head.weight'}, cfg, ids, mask, pix, grid)
+    scores, end = om.score_from_hidden(hid, sd['score_head.weight'], mask, end_at_last_position=True)
+    ld = orl.rm_loss(scores, end, float(z['regularization']))
+    for k in ('loss', 'higher_end_reward', 'lower_end_reward', 'accuracy'):
+        np.testing.assert_allclose(ld[k].detach().numpy(), z[k], rtol=2e-5, atol=2e-5, err_msg=k)
+    valid = mask.bool()
+    B = ids.shape[0] // 2
+    for k, rows in (('higher_rewards', slice(0, B)), ('lower_rewards', slice(B, 2 * B))):
+        np.testing.assert_allclose(ld[k].detach()[valid[rows]].numpy(), z[k][valid[rows].numpy()], rtol=2e-4, atol=2e-4, err_msg=k)
+    ld['loss'].backward()
+    n = 0
+    for k in z.files:
+        if k.startswith('g.'):
+            assert rel_err(sd[k[2:]].grad, T(z[k])) < 2e-3, (k, rel_err(sd[k[2:]].grad, T(z[k])))
+            n += 1
+    assert n == 6

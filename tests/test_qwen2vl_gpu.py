@@ -221,3 +221,48 @@ def test_move_padding_left_matches_reference_arithmetic():
     shifts = 33 - nonpad.unsqueeze(1) - start.unsqueeze(1)
     want = torch.gather(x, 1, (torch.arange(33).expand(7, 33) - shifts) % 33)
     assert torch.equal(ops.move_padding_left(x.to(dev()), pad).cpu(), want)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_qwen2vl_rm_trainer_loss_matches_reference_fixture_right_padded(dtype):
+    """The reference's ti2t RMTrainer.loss on its AccustomedQwen2VLRewardModel (models/qwen2_vl.py:42-72) on a RIGHT-padded batch
+    (tests/golden/qwen2vl_tiny_rm.npz): the end score is the score at position -1, padding for the shorter row of a pair, whose query
+    must not see the padded keys (kv_len in the decoder, as for LLaVA) -- ADVICE r2.  Six outputs + gradients; eval() takes the same
+    multimodal keys as loss()."""
+    from align_anything_amd.trainers.rm import RMTrainer
+    z = load_golden('qwen2vl_tiny_rm.npz')
+    f32 = dtype == 'fp32'
+    wd = torch.float32 if f32 else torch.bfloat16
+    sd = {k: v for k, v in state_dict_from_golden(z, 'w.', wd).items() if k != 'lm_head.weight'}
+    tr = RMTrainer({'train_cfgs': {'regularization': float(z['regularization']), 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0,
+                                   'lr_scheduler_type': 'constant', 'weight_decay': 0.0, 'compute_dtype': dtype}},
+                   {'gradient_clipping': 1.0}, model_cfg=tiny_qwen2vl_cfg(), state=sd, device='cuda:0')
+    b = {'input_ids': T(z['input_ids']).to(dev()), 'attention_mask': T(z['attention_mask']).to(dev()),
+         'pixel_values': T(z['pixel_values']).to(dev()), 'image_grid_thw': T(z['image_grid_thw'])}
+    B = b['input_ids'].shape[0] // 2
+    ev = tr.eval([b])                                  # same multimodal keys (image_grid_thw, kv_len) as loss()
+    assert ev['eval/accuracy'] == float(z['accuracy'])
+    ld = tr.loss(b)
+    rms = float(T(z['higher_rewards']).pow(2).mean().sqrt())
+    tol = dict(rtol=1e-4, atol=1e-4) if f32 else dict(rtol=3e-2, atol=6e-2 * max(1.0, rms))
+    for k in ('higher_end_reward', 'lower_end_reward'):
+        assert_close(ld[k].cpu(), T(z[k]), what=k, **tol)
+    valid = T(z['attention_mask']).bool()
+    for k, rows in (('higher_rewards', slice(0, B)), ('lower_rewards', slice(B, 2 * B))):
+        assert_close(ld[k].cpu()[valid[rows]], T(z[k])[valid[rows]], what=k, **tol)
+    assert abs(float(ld['loss']) - float(z['loss'])) < (3e-5 if f32 else 1e-1), (float(ld['loss']), float(z['loss']))
+    assert float(ld['accuracy']) == float(z['accuracy'])
+    tr.model.backward(ld['loss'])
+    torch.cuda.synchronize()
+    worst, n = 0.0, 0
+    for k in z.files:
+        if k.startswith('g.'):
+            g = tr.model.module.store.grad_view(k[2:])
+            if g is None:
+                assert 'visual' in k, k
+                continue
+            worst = max(worst, rel_err(g.float().cpu().reshape(z[k].shape), T(z[k])))
+            n += 1
+    assert n >= 5 and worst < (3e-5 if f32 else 1.2e-1), (n, worst)
+    dump(f'parity_qwen2vl_rm_reference_{dtype}.txt',
+         f'{dtype} right-padded: loss {float(ld["loss"]):.6f} vs reference {float(z["loss"]):.6f}, worst gradient rel-err {worst:.2e} over {n} tensors\n')
