@@ -1,0 +1,492 @@
+// bf16 MFMA GEMM: the one-wave-per-SIMD kernel of gemm4.hip on v_mfma_f32_32x32x16_bf16.
+//
+// Same contract, tile (256 x 256, 4 waves as 2 x 2, 128 x 128 per wave), accumulator-file MFMAs, four-slot LDS ring of 32-deep DMA stages
+// (NT: 3 A + 2 B buffers of 64-deep tiles), wave-uniform DMA bases and generated hand-placed schedule as gemm4.hip; what changes is the
+// MFMA shape and everything that follows from its fragment geometry:
+//   * a wave's 128 x 128 = 4 x 4 accumulator tiles of 32 x 32 (16 registers each, 256 in the accumulator file); one 32-deep ring step =
+//     2 k16 sub-steps x 16 = 32 MFMAs of 32 cycles instead of 64 of 16 (measured back-to-back issue of the 16x16x32 shape: ~17): half
+//     the MFMA issues and half the operand-register reads per flop (the step is power-limited), the instruction ceiling of the shape is
+//     2382-2495 TFLOP/s against 2075 (MI355X_MICROARCH.md), and each MFMA gap has ~8 issue slots of which <= 5 hide a filler -- the
+//     DMA issue cost profiles/r02_gemm4_phase_clocks.txt measured in the 16-cycle gaps has room here.
+//   * operand fragment: lane l holds row / column (l & 31) and the 8 consecutive k at 16 k16 + 8 (l >> 5).  LDS bytes and the number
+//     of LDS reads per step are those of gemm4 (the wave tile is the same).
+//   * LDS images.  K-contiguous 64-byte-row stage (NN's A): 16-byte unit u of row r at u ^ ((r >> 2) & 3) -- ds_read_b128 is served in
+//     16-lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (per half wave), which for a 32-row fragment are rows with four distinct
+//     (r >> 2) & 3, i.e. four distinct units of the four-row bank line (gemm4's u ^ 2 bit3(r) serves its 16-row fragments).  128-byte-row
+//     tiles of the NT kernel: gemm4's u ^ ((r >> 1) & 7) is conflict-free for 32 rows as it is.  Row-contiguous stage ([k][256]): 32-byte
+//     column blocks XOR-swizzled with 2 (k & 3) | bit3(k): one ds_read_b64_tr_b16 pass (32 lanes) covers 4 k-rows x 2 adjacent blocks,
+//     which that swizzle sends to 8 distinct blocks of the 8-block bank line.
+//   * D = B-fragment x A-fragment (operands swapped): lane l owns C[m = .. + (l & 31)][n = .. + 8 q + 4 (l >> 5) + 0..3], q = 0..3; the
+//     plain epilogue pairs lanes l / l + 32 with v_permlane32_swap so that a lane stores 8 consecutive columns (16 bytes).
+// Selected with aa_gemm_set_mfma32(1) / AA_GEMM_MFMA32=1 (A/B against gemm4 on the same box: tools/bench_gemm_lab.py).
+#include "aa_common.h"
+
+#include <type_traits>
+
+#include "gemm_params.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, NW = 4, WN = 2, TM = 128, TNW = 128, FM = 4, FN = 4, KK = 2;   // 32-row fragments, 2 k16 sub-steps / stage
+constexpr int SK = 32;                                        // contraction depth of one ring stage
+constexpr int NSLOT = 4, SLOT = 32768, PART = 16384;          // LDS ring: slot = [A part | B part]
+constexpr int NP = PART / 1024 / NW;                          // DMA pieces (1 KB) per operand per stage per wave
+
+__device__ __forceinline__ int tr_swz5(int krow) { return ((krow & 3) << 1) | ((krow >> 3) & 1); }
+
+#define AA_MFMA32_ACC(ACC, BF, AF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(BF), "v"(AF))
+#define G5_M0_SET(LDSW) asm volatile("s_mov_b32 m0, %0" ::"s"(LDSW) : "memory")
+
+typedef __attribute__((ext_vector_type(4))) int g5_srd_t;
+__device__ __forceinline__ g5_srd_t g5_make_srd(const char* base) {
+    const unsigned long long a = (unsigned long long)base;
+    return g5_srd_t{(int)(unsigned)a, (int)(unsigned)(a >> 32), 0x7fffffff, 0x00020000};     // stride 0, raw 32-bit format
+}
+// One LDS-DMA piece of a stage (gemm4.hip G4_DMA_PIECE_BUF): J < NP = A piece J, else B piece J - NP; M0 is a running LDS pointer.
+template <int J, bool A_T, bool B_N>
+__device__ __forceinline__ void G5_DMA_PIECE_BUF(unsigned vA0, unsigned vA1, unsigned vB0, unsigned vB1, const int (&soA)[NP],
+                                                 const int (&soB)[NP], g5_srd_t srdA, g5_srd_t srdB) {
+    constexpr int j = J < NP ? J : J - NP;
+    const unsigned v = J < NP ? ((A_T && (j & 1)) ? vA1 : vA0) : ((B_N && (j & 1)) ? vB1 : vB0);
+    const int so = J < NP ? soA[j] : soB[j];
+    if constexpr (J < 2 * NP - 1) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, %3" ::"v"(v), "s"(J < NP ? srdA : srdB), "s"(so), "i"(NW * 1024) : "memory");
+    } else {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(v), "s"(srdB), "s"(so) : "memory");
+    }
+}
+template <int J>
+__device__ __forceinline__ void G5_DMA_PIECE(const unsigned (&offA)[NP], const unsigned (&offB)[NP], const char* srcA, const char* srcB) {
+    if constexpr (J < NP) {
+        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(offA[J]), "s"(srcA), "i"(NW * 1024) : "memory");
+    } else if constexpr (J < 2 * NP - 1) {
+        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(offB[J - NP]), "s"(srcB), "i"(NW * 1024) : "memory");
+    } else {
+        asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(offB[J - NP]), "s"(srcB) : "memory");
+    }
+}
+
+// XCD-aware bijective remap of the dispatch position, then grouped tile order (identical to gemm_kernel / gemm4)
+__device__ __forceinline__ void g5_map_tile(const GemmParams& p, int& m0, int& n0) {
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GM = p.gm & 0xff;
+    int tm, tn;
+    if (!(p.gm & 0x100)) {
+        const int per_group = GM * p.tiles_n;
+        const int group = wg / per_group;
+        const int first_m = group * GM;
+        const int gsz = min(p.tiles_m - first_m, GM);
+        tm = first_m + (wg % per_group) % gsz;
+        tn = (wg % per_group) / gsz;
+    } else {
+        const int per_group = GM * p.tiles_m;
+        const int group = wg / per_group;
+        const int first_n = group * GM;
+        const int gsz = min(p.tiles_n - first_n, GM);
+        tn = first_n + (wg % per_group) % gsz;
+        tm = (wg % per_group) / gsz;
+    }
+    m0 = tm * BM;
+    n0 = tn * BN;
+}
+
+#define G5_MFMA(ACC, BF, AF) AA_MFMA32_ACC(ACC, BF, AF)
+#define G5_RDK(DST, VADDR, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(VADDR), "i"(IMM))
+#define G5_RDT(DST, VADDR, IMM) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(VADDR), "i"(IMM))
+#define G5_PIN __builtin_amdgcn_sched_barrier(0)
+#define G5_JOIN(LO, HI) __builtin_shufflevector(LO, HI, 0, 1, 2, 3, 4, 5, 6, 7)
+// the last MFMAs are still in the matrix pipe when the loop ends (16 passes): the compiler does not know the asm statements wrote the
+// accumulators late; nothing may read the last row's accumulators above this statement (they are its operands)
+#define G5_DRAIN_MFMA()                                                                                                        \
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"                                                   \
+                 : "+a"(acc[FM - 1][0]), "+a"(acc[FM - 1][1]), "+a"(acc[FM - 1][2]), "+a"(acc[FM - 1][3])::"memory")
+
+// EPI: 0 = general epilogue; 1 = plain bf16 store; 2 = + residual add.  (The rotary / SwiGLU epilogues of gemm4.hip are not built for
+// this MFMA shape: aa_gemm4_fused keeps them on gemm4's kernels.)
+template <bool A_T, bool B_N, int EPI>
+__global__ __launch_bounds__(NW * 64, 1)
+void gemm5_kernel(const GemmParams p) {
+    constexpr bool PLAIN = EPI != 0;
+    static_assert(A_T || B_N, "both operands K-contiguous: gemm5nt_kernel");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    int m0, n0;
+    g5_map_tile(p, m0, n0);
+
+    // ---- DMA sources (gemm4.hip): K-contiguous operand: piece c = wave + 4 j covers tile rows 16 c .. 16 c + 15, lane -> row lane >> 2,
+    // stored unit lane & 3 holds k-unit (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3).  Row-contiguous operand: piece c
+    // covers k-rows 2 c, 2 c + 1, 32-byte column block b of k-row k stored at block b ^ tr_swz5(k).
+    const char* baseA = reinterpret_cast<const char*>(A_T ? p.A + m0 : p.A + (long)m0 * p.lda);
+    const char* baseB = reinterpret_cast<const char*>(B_N ? p.B + n0 : p.B + (long)n0 * p.ldb);
+    unsigned offA[NP], offB[NP];
+    long stepA, stepB;
+    const int kcu = (lane & 3) ^ ((lane >> 4) & 3);
+    if constexpr (!A_T) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int r = (wave + j * NW) * 16 + (lane >> 2);
+            const int gr = min(m0 + r, p.M - 1) - m0;
+            offA[j] = (unsigned)((gr * p.lda + kcu * 8) * 2);
+        }
+        stepA = SK * 2;
+    } else {
+        constexpr int RPI = 1024 / (BM * 2), SPR = BM * 2 / 16;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = wave + j * NW;
+            const int kr = c * RPI + lane / SPR;
+            const int s = lane % SPR;
+            const int unit = (s >> 1) ^ tr_swz5(kr);
+            const int col = min(m0 + unit * 16 + (s & 1) * 8, p.M - 8) - m0;
+            offA[j] = (unsigned)((kr * p.lda + col) * 2);
+        }
+        stepA = (long)SK * p.lda * 2;
+    }
+    if constexpr (!B_N) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int r = (wave + j * NW) * 16 + (lane >> 2);
+            const int gr = min(n0 + r, p.N - 1) - n0;
+            offB[j] = (unsigned)((gr * p.ldb + kcu * 8) * 2);
+        }
+        stepB = SK * 2;
+    } else {
+        constexpr int RPI = 1024 / (BN * 2), SPR = BN * 2 / 16;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = wave + j * NW;
+            const int kr = c * RPI + lane / SPR;
+            const int s = lane % SPR;
+            const int unit = (s >> 1) ^ tr_swz5(kr);
+            const int col = min(n0 + unit * 16 + (s & 1) * 8, p.N - 8) - n0;
+            offB[j] = (unsigned)((kr * p.ldb + col) * 2);
+        }
+        stepB = (long)SK * p.ldb * 2;
+    }
+
+    // ---- LDS ring: slot sg at sg * 32 KB = [A part 16 KB | B part 16 KB]
+    const int lds0 = (int)(uintptr_t)smem;
+    const int ldsw = lds0 + wave * 1024;
+    const int pieceA = (A_T ? NW * (1024 / (BM * 2)) : NW * 16) * (int)p.lda * 2;
+    const int pieceB = (B_N ? NW * (1024 / (BN * 2)) : NW * 16) * (int)p.ldb * 2;
+    // row-contiguous operand: piece j is k-rows 2 (wave + 4 j) + (lane >> 5): k & 3 is the lane's, bit 3 of k is j & 1 -> two lane patterns
+    const unsigned vA0 = offA[0], vA1 = A_T ? offA[1] - (unsigned)pieceA : 0u;
+    const unsigned vB0 = offB[0], vB1 = B_N ? offB[1] - (unsigned)pieceB : 0u;
+    int soA[NP], soB[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { soA[j] = j * pieceA; soB[j] = j * pieceB; }
+#define G5_DMA(J)                                                                                                   \
+    do {                                                                                                            \
+        if constexpr (PLAIN) G5_DMA_PIECE_BUF<J, A_T, B_N>(vA0, vA1, vB0, vB1, soA, soB, g5_make_srd(srcA), g5_make_srd(srcB)); \
+        else G5_DMA_PIECE<J>(offA, offB, srcA, srcB);                                                               \
+    } while (0)
+#define G5_DMA_STAGE() do { G5_DMA(0); G5_DMA(1); G5_DMA(2); G5_DMA(3); G5_DMA(4); G5_DMA(5); G5_DMA(6); G5_DMA(7); } while (0)
+    static_assert(NP == 4, "G5_DMA_STAGE and the generated schedule issue 8 pieces per stage");
+
+    // ---- per-lane LDS read addresses.  K-contiguous image: one base per k16 sub-step (the unit XOR is not additive), fragment i = rows
+    // 32 i .. of the wave's 128 = 2 KB further (immediate).  Row-contiguous image: one base per fragment (the block XOR is not additive),
+    // k16 sub-step = 16 k-rows = 8 KB, second transpose read = 4 k-rows = 2 KB further (immediates).  L / H = slots 0-1 / 2-3.
+    const int l31 = lane & 31, hi = lane >> 5, l15 = lane & 15, ch = (lane >> 4) & 1;
+    [[maybe_unused]] int vakL[KK], vakH[KK], vbkL[KK], vbkH[KK], taL[FM], taH[FM], tbL[FN], tbH[FN];
+    {
+        const int f = (l31 >> 2) & 3;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int offK = l31 * 64 + (((2 * kk + hi) ^ f) << 4);
+            vakL[kk] = lds0 + offK + wm * TM * 64;
+            vbkL[kk] = lds0 + PART + offK + wn * TNW * 64;
+            vakH[kk] = vakL[kk] + 2 * SLOT;
+            vbkH[kk] = vbkL[kk] + 2 * SLOT;
+        }
+        const int swz = ((l15 >> 2) << 1) | hi;                         // tr_swz5(k-row): k & 3 = l15 >> 2, bit3(k) = hi
+        const int lanepart = (8 * hi + (l15 >> 2)) * (BM * 2) + (l15 & 3) * 8;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            taL[i] = lds0 + lanepart + (wm * 8 + ((2 * i + ch) ^ swz)) * 32;
+            tbL[i] = lds0 + PART + lanepart + (wn * 8 + ((2 * i + ch) ^ swz)) * 32;
+            taH[i] = taL[i] + 2 * SLOT;
+            tbH[i] = tbL[i] + 2 * SLOT;
+        }
+    }
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment sets [k16][fragment]: whole 128-bit fragments for K-contiguous images, two 64-bit halves for transposed reads
+    bf16x8 a0[KK][FM], b0[KK][FN], a1[KK][FM], b1[KK][FN];
+    bf16x4 a0h[KK][FM][2], b0h[KK][FN][2], a1h[KK][FM][2], b1h[KK][FN][2];
+
+#define G5_SYNC(SG) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier\n\ts_mov_b32 m0, %0" ::"s"(ldsw + (SG) * SLOT) : "memory")
+#define G5_STEP_BEGIN(SG)                                                   \
+    do {                                                                    \
+        const int q_ = min(s0 + (SG) + NSLOT, nsteps - 1);                  \
+        srcA = baseA + (long)q_ * stepA;                                    \
+        srcB = baseB + (long)q_ * stepB;                                    \
+        G5_SYNC(SG);                                                        \
+    } while (0)
+
+    const int nsteps = p.K / SK;                                            // a multiple of 4 (dispatch)
+    const char* srcA;
+    const char* srcB;
+    // ---- prologue: stages 0..3 -> slots 0..3, wait for stage 0, first fragment set
+#pragma unroll
+    for (int sg = 0; sg < NSLOT; ++sg) {
+        srcA = baseA + (long)sg * stepA;
+        srcB = baseB + (long)sg * stepB;
+        G5_M0_SET(ldsw + sg * SLOT);
+        asm volatile("s_nop 0");
+        G5_DMA_STAGE();
+    }
+    asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+    {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (!B_N) { G5_RDK(b0[kk][j], vbkL[kk], j * 2048); }
+                else { G5_RDT(b0h[kk][j][0], tbL[j], kk * 8192); G5_RDT(b0h[kk][j][1], tbL[j], kk * 8192 + 2048); }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if constexpr (!A_T) { G5_RDK(a0[kk][i], vakL[kk], i * 2048); }
+                else { G5_RDT(a0h[kk][i][0], taL[i], kk * 8192); G5_RDT(a0h[kk][i][1], taL[i], kk * 8192 + 2048); }
+            }
+        }
+    }
+    // ---- K loop: four ring steps per trip, branch-free
+    for (int s0 = 0; s0 < nsteps; s0 += NSLOT) {
+        if constexpr (!A_T && B_N) {
+#define G5_FRAG_A(S, K2, I) a##S[K2][I]
+#define G5_FRAG_B(S, K2, J) G5_JOIN(b##S##h[K2][J][0], b##S##h[K2][J][1])
+#include "gemm5_sched_nn.inc"
+#undef G5_FRAG_A
+#undef G5_FRAG_B
+        } else {
+#define G5_FRAG_A(S, K2, I) G5_JOIN(a##S##h[K2][I][0], a##S##h[K2][I][1])
+#define G5_FRAG_B(S, K2, J) G5_JOIN(b##S##h[K2][J][0], b##S##h[K2][J][1])
+#include "gemm5_sched_tn.inc"
+#undef G5_FRAG_A
+#undef G5_FRAG_B
+        }
+    }
+    // the clamped re-requests of the last stage and the (unused) fragment reads of the last step
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    G5_DRAIN_MFMA();
+    {
+#include "gemm5_epilogue.inc"
+    }
+}
+
+
+// ================================================================================================================================
+// NT layout (both operands K-contiguous: every forward GEMM): 64-deep tiles, THREE A buffers + two B buffers as gemm4nt_kernel.
+// LDS image of a tile: row r = 128 bytes at r * 128, 16-byte unit u stored at u ^ ((r >> 1) & 7).
+constexpr int NP8 = 32768 / 1024 / NW;
+constexpr int NT_B0 = 3 * 32768, NT_LDS = 5 * 32768;
+
+template <int J>
+__device__ __forceinline__ void G5NT_DMA_PIECE_BUF(unsigned v, const int (&so)[NP8], g5_srd_t srd) {
+    if constexpr (J < NP8 - 1) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, %3" ::"v"(v), "s"(srd), "s"(so[J]), "i"(NW * 1024) : "memory");
+    } else {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(v), "s"(srd), "s"(so[J]) : "memory");
+    }
+}
+template <int J>
+__device__ __forceinline__ void G5NT_DMA_PIECE(unsigned v, const char* src) {
+    if constexpr (J < NP8 - 1) {
+        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(v), "s"(src), "i"(NW * 1024) : "memory");
+    } else {
+        asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(v), "s"(src) : "memory");
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NW * 64, 1)
+void gemm5nt_kernel(const GemmParams p) {
+    constexpr bool PLAIN = EPI != 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int m0, n0;
+    g5_map_tile(p, m0, n0);
+
+    // ---- DMA sources.  Piece c = wave + 4 j covers tile rows 8 c .. 8 c + 7; lane -> row lane >> 3, stored unit lane & 7 holds
+    // k-unit (lane & 7) ^ ((row >> 1) & 7) of the tile's 64 k
+    const char* baseA = reinterpret_cast<const char*>(p.A + (long)m0 * p.lda);
+    const char* baseB = reinterpret_cast<const char*>(p.B + (long)n0 * p.ldb);
+    unsigned offA[NP8], offB[NP8];
+    {
+        const int rr = wave * 8 + (lane >> 3);
+        const int ks = (lane & 7) ^ ((rr >> 1) & 7);
+#pragma unroll
+        for (int j = 0; j < NP8; ++j) {
+            const int r = rr + j * NW * 8;
+            offA[j] = (unsigned)(((min(m0 + r, p.M - 1) - m0) * p.lda + ks * 8) * 2);
+            offB[j] = (unsigned)(((min(n0 + r, p.N - 1) - n0) * p.ldb + ks * 8) * 2);
+        }
+    }
+    const int lds0 = (int)(uintptr_t)smem;
+    const int ldsw = lds0 + wave * 1024;
+    const int pieceA = NW * 8 * (int)p.lda * 2, pieceB = NW * 8 * (int)p.ldb * 2;
+    int soA[NP8], soB[NP8];
+#pragma unroll
+    for (int j = 0; j < NP8; ++j) { soA[j] = j * pieceA; soB[j] = j * pieceB; }
+#define G5NT_DMA_A(J)                                                                \
+    do {                                                                             \
+        if constexpr (PLAIN) G5NT_DMA_PIECE_BUF<J>(offA[0], soA, g5_make_srd(srcA)); \
+        else G5NT_DMA_PIECE<J>(offA[J], srcA);                                       \
+    } while (0)
+#define G5NT_DMA_B(J)                                                                \
+    do {                                                                             \
+        if constexpr (PLAIN) G5NT_DMA_PIECE_BUF<J>(offB[0], soB, g5_make_srd(srcB)); \
+        else G5NT_DMA_PIECE<J>(offB[J], srcB);                                       \
+    } while (0)
+#define G5NT_GROUP_A() do { G5NT_DMA_A(0); G5NT_DMA_A(1); G5NT_DMA_A(2); G5NT_DMA_A(3); G5NT_DMA_A(4); G5NT_DMA_A(5); G5NT_DMA_A(6); G5NT_DMA_A(7); } while (0)
+#define G5NT_GROUP_B() do { G5NT_DMA_B(0); G5NT_DMA_B(1); G5NT_DMA_B(2); G5NT_DMA_B(3); G5NT_DMA_B(4); G5NT_DMA_B(5); G5NT_DMA_B(6); G5NT_DMA_B(7); } while (0)
+    static_assert(NP8 == 8, "request groups are written out for 8 pieces");
+
+    // ---- LDS: A tile t in buffer t % 3, B tile u at 96 KB + (u & 1) * 32 KB; fragment i = 32 rows = 4 KB further (immediate).  A read
+    // base per (32-deep half of the tile, k16 sub-step): unit 4 half + 2 k16 + (lane >> 5), XOR-swizzled with the row.
+    const int l31 = lane & 31, hi = lane >> 5;
+    int vak[2][KK], vbk[2][KK], vakc[2][KK];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int offK = l31 * 128 + (((hf * 4 + 2 * kk + hi) ^ ((l31 >> 1) & 7)) << 4);
+            vak[hf][kk] = lds0 + offK + wm * TM * 128;
+            vbk[hf][kk] = lds0 + NT_B0 + offK + wn * TNW * 128;
+            vakc[hf][kk] = vak[hf][kk];
+        }
+    }
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bf16x8 a0[KK][FM], b0[KK][FN], a1[KK][FM], b1[KK][FN];
+
+#define G5NT_SYNC(VM, DST) asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier\n\ts_mov_b32 m0, %0" ::"s"(DST) : "memory")
+    const int nsteps = p.K / SK;                               // a multiple of 4 (dispatch)
+    const int last = nsteps / 2 - 1;                           // last 64-deep tile
+#define G5NT_STEP_BEGIN(SG)                                                                     \
+    do {                                                                                        \
+        if constexpr (((SG) & 1) == 0) {                                                        \
+            srcA = baseA + (long)min((s0 + (SG)) / 2 + 2, last) * 128;                          \
+            G5NT_SYNC(16, ldsw + a_wr);                                                         \
+            a_wr = a_wr == 65536 ? 0 : a_wr + 32768;                                            \
+        } else {                                                                                \
+            srcB = baseB + (long)min((s0 + (SG)) / 2 + 2, last) * 128;                          \
+            a_rd = a_rd == 65536 ? 0 : a_rd + 32768;                                            \
+            vakc[0][0] = vak[0][0] + a_rd;                                                      \
+            vakc[0][1] = vak[0][1] + a_rd;                                                      \
+            vakc[1][0] = vak[1][0] + a_rd;                                                      \
+            vakc[1][1] = vak[1][1] + a_rd;                                                      \
+            G5NT_SYNC(8, ldsw + NT_B0 + ((SG) >> 1) * 32768);                                   \
+        }                                                                                       \
+    } while (0)
+
+    const char* srcA;
+    const char* srcB;
+    int a_wr = 65536, a_rd = 0;
+    // ---- prologue: A tile 0, B tile 0, A tile 1, B tile 1; the first two have landed -> first fragment set
+    srcA = baseA;
+    G5_M0_SET(ldsw); asm volatile("s_nop 0");
+    G5NT_GROUP_A();
+    srcB = baseB;
+    G5_M0_SET(ldsw + NT_B0); asm volatile("s_nop 0");
+    G5NT_GROUP_B();
+    srcA = baseA + 128;
+    G5_M0_SET(ldsw + 32768); asm volatile("s_nop 0");
+    G5NT_GROUP_A();
+    srcB = baseB + 128;
+    G5_M0_SET(ldsw + NT_B0 + 32768); asm volatile("s_nop 0");
+    G5NT_GROUP_B();
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    {
+        // stage 0 = lower halves of A tile 0 and B tile 0
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) G5_RDK(b0[kk][j], vbk[0][kk], j * 4096);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) G5_RDK(a0[kk][i], vakc[0][kk], i * 4096);
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += 4) {
+#define G5_FRAG_A(S, K2, I) a##S[K2][I]
+#define G5_FRAG_B(S, K2, J) b##S[K2][J]
+#include "gemm5_sched_nt.inc"
+#undef G5_FRAG_A
+#undef G5_FRAG_B
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    G5_DRAIN_MFMA();
+    {
+#include "gemm5_epilogue.inc"
+    }
+}
+
+template <bool A_T, bool B_N, int EPI>
+int launch5(GemmParams& p, hipStream_t st) {
+    constexpr int lds = (!A_T && !B_N) ? NT_LDS : NSLOT * SLOT;
+    void (*kern)(const GemmParams);
+    if constexpr (!A_T && !B_N) kern = gemm5nt_kernel<EPI>;
+    else kern = gemm5_kernel<A_T, B_N, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            aa_set_error("aa_gemm_bf16 (32x32x16 one-wave tile): cannot reserve %d B LDS: %s", lds, hipGetErrorString(e));
+            return AA_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), lds, st, p);
+    AA_CHECK_LAUNCH("aa_gemm_bf16");
+    return AA_OK;
+}
+
+template <int EPI>
+int launch5_layout(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
+    if (!a_t && !b_n) return launch5<false, false, EPI>(p, st);
+    if constexpr (EPI <= 1) {          // the residual epilogue exists for the forward (NT) layout only
+        if (!a_t && b_n) return launch5<false, true, EPI>(p, st);
+        if (a_t && b_n) return launch5<true, true, EPI>(p, st);
+    }
+    aa_set_error("aa_gemm_bf16: layout not built for this epilogue (A^T with K-contiguous B is unused by the hot path)");
+    return AA_ERR_ARG;
+}
+
+}  // namespace
+
+// p.tiles_m / tiles_n / gm are set by the caller (gemm.hip), which has checked aa_gemm4_supports(p.K) (same K granule: 128).
+int aa_gemm5_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
+    const bool shape_ok = p.flags == (p.flags & (AA_GEMM_A_T | AA_GEMM_B_N)) && !p.bias && p.act == AA_ACT_NONE && p.M % BM == 0 &&
+                          p.N % BN == 0 && (p.ldc & 7) == 0;
+    const bool plain = shape_ok && !p.residual;
+    const bool resid = shape_ok && p.residual && !a_t && !b_n && (p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0;
+    if (plain) return launch5_layout<1>(p, a_t, b_n, st);
+    if (resid) return launch5_layout<2>(p, a_t, b_n, st);
+    return launch5_layout<0>(p, a_t, b_n, st);
+}

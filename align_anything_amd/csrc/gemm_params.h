@@ -1,4 +1,4 @@
-// Shared between gemm.hip (16x16x32 MFMA kernels) and gemm32.hip (32x32x16 MFMA kernel).
+// Shared between gemm.hip (8-wave 16x16x32 MFMA kernels), gemm4.hip (one wave per SIMD, 16x16x32) and gemm5.hip (one wave per SIMD, 32x32x16).
 #pragma once
 #include "aa_common.h"
 
@@ -96,12 +96,10 @@ __device__ __forceinline__ void gemm_store4(const GemmParams& p, int m, int n, f
     }
 }
 
-// split-K-ring 256x256 kernel (gemm_ring.hip)
-int aa_gemm_ring_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
 // one-wave-per-SIMD 256x256 kernel, accumulators in the accumulator file (gemm4.hip)
 bool aa_gemm4_supports(int K);      // the 4-slot ring walks K in trips of 128
 int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
 // fused-epilogue launches of the same kernel (p.fuse); 1 = shape does not qualify, run the unfused kernels
 int aa_gemm4_fused(GemmParams& p, hipStream_t st);
-// 32x32x16-MFMA 256x256 kernel (gemm32.hip)
-int aa_gemm32_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
+// the same one-wave-per-SIMD kernel on v_mfma_f32_32x32x16_bf16 (gemm5.hip; plain / residual / general epilogues)
+int aa_gemm5_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);

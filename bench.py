@@ -16,7 +16,9 @@ the timed region for every step -- nothing is cached across steps, and the loss 
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the bf16 MFMA GEMM, measured with
 HIP event pairs around a 1-in-11 sample of the GEMM launches of the timed steps), `step_mfma` (whole-step MFMA fraction on the FLOPs the step
-EXECUTES, with SURVEY.md's algorithmic figure beside it) and `cpu_baseline` (the CPU oracle port, bounded sample).
+EXECUTES, with SURVEY.md's algorithmic figure beside it) `cpu_baseline` (the CPU oracle port, bounded sample, live; + the committed figure of the reference's own trainer timed in the build
+container), `per_batch` (the same step at 1 and 2 pairs per GPU) and `glu_bwd_plan` (the per-box choice between the fused and the
+unfused SwiGLU-backward, csrc/gemm.hip).
 """
 from __future__ import annotations
 
@@ -171,10 +173,12 @@ def main():
                          'its neighbours (no tail / head overlap with the next kernel): around EVERY launch that costs the one-wave-per-SIMD '
                          'GEMMs 6.5 %% of the step (806 vs 754 ms, same box), so the default samples every 11th launch -- made coprime to the '
                          'launches per step, hence unbiased over the shapes -- which costs < 1 %%')
-    ap.add_argument('--measure-traffic', action='store_true',
-                    help='N=1: before the timed run, collect roofline.traffic for THIS box and build by running tools/pmc_traffic.sh (two '
-                         'rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1` at full depth, ~3 min) instead of reading the committed '
-                         'profiles/r02_gemm_traffic.json; needs rocprofv3 on PATH')
+    ap.add_argument('--traffic', choices=('auto', 'measure', 'committed'), default=os.environ.get('AA_BENCH_TRAFFIC', 'auto'),
+                    help='where roofline.traffic comes from.  measure: before the timed run, tools/pmc_traffic.sh collects it for THIS box and build '
+                         '(two rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1` at full depth, ~3 min); committed: read profiles/r02_gemm_traffic.json; '
+                         'auto (default): measure at N=1 when rocprofv3 is on PATH, else committed.  roofline.traffic_source says which one the line carries')
+    ap.add_argument('--measure-traffic', action='store_true', help='same as --traffic measure (kept for the round-2 command lines)')
+    ap.add_argument('--no-per-batch', action='store_true', help='skip the B=1 / B=2 pairs-per-GPU datapoints measured after the timed region (N=1 only)')
     ap.add_argument('--comm-prof', action='store_true',
                     help='N>1: after the timed region run ONE extra untimed step with HIP events around every gradient bucket '
                          '(all-reduce time vs the backward it overlaps with) and add it to the JSON line as "comm"')
@@ -183,15 +187,27 @@ def main():
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     live_traffic = None
-    if args.measure_traffic and args.gpus == 1 and os.environ.get('AA_BENCH_IN_PMC') != '1':
+    in_pmc_child = os.environ.get('AA_BENCH_IN_PMC') == '1'      # this process IS one of the rocprofv3 --pmc passes: no extras
+    import shutil
+    want_measure = args.measure_traffic or args.traffic == 'measure' or (args.traffic == 'auto' and shutil.which('rocprofv3') is not None)
+    if want_measure and args.gpus == 1 and args.layers == 32 and not in_pmc_child:
         env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, AA_BENCH_IN_PMC='1')
-        r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'pmc_traffic.sh')], env=env, capture_output=True, text=True)
         try:
+            os.remove(os.path.join(ROOT, 'gpurun_out', 'gemm_traffic.json'))
+        except OSError:
+            pass
+        t_pmc = time.time()
+        try:
+            r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'pmc_traffic.sh')], env=env, capture_output=True, text=True,
+                               timeout=float(os.environ.get('AA_BENCH_TRAFFIC_TIMEOUT', 900)))
             with open(os.path.join(ROOT, 'gpurun_out', 'gemm_traffic.json')) as f:
                 live_traffic = json.load(f)
-            live_traffic['_source'] = 'measured by this invocation (tools/pmc_traffic.sh)'
-        except (OSError, ValueError):
-            print(f'[bench] --measure-traffic failed (rc={r.returncode}): {r.stderr[-500:]}', file=sys.stderr, flush=True)
+            if not live_traffic.get('gemm4_launches'):
+                raise ValueError('no gemm4 launches in the counter files')
+            live_traffic['_source'] = f'measured by this invocation (tools/pmc_traffic.sh, {time.time() - t_pmc:.0f} s before the timed run)'
+        except (OSError, ValueError, subprocess.TimeoutExpired) as ex:
+            live_traffic = None
+            print(f'[bench] in-run traffic measurement failed ({ex!r}); falling back to the committed profile', file=sys.stderr, flush=True)
 
     import torch
     import torch.distributed as dist
@@ -231,7 +247,7 @@ def main():
     B, T, R = args.pairs_per_gpu, args.seq_len, args.response_len
     cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-6, 'lr_warmup_ratio': 0.03, 'weight_decay': 0.0,
                            'adam_betas': [0.9, 0.95], 'lr_scheduler_type': 'cosine',
-                           'total_training_steps': args.steps + args.warmup, 'freeze_mm_proj': False,
+                           'total_training_steps': args.steps + args.warmup + 16, 'freeze_mm_proj': False,
                            'freeze_language_model': False, 'freeze_vision_tower': True},
             'model_cfgs': {'pad_token_id': cfg['pad_token_id']}}
     tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, device=device)
@@ -305,6 +321,26 @@ def main():
             multi['comm'] = tr.model.comm_report()
             tr.model.reducer.prof = False
 
+    # N=1, outside the timed region: the same step at 1 and 2 pairs per GPU (the reference's yaml default is
+    # per_device_train_batch_size 1, configs/train/text_image_to_text/dpo.yaml:30; SURVEY section 8(d) allows B in {1, 2, 4})
+    per_batch = None
+    if world == 1 and not args.no_per_batch and not in_pmc_child:
+        per_batch = {}
+        ops.GEMM_PROF = None
+        for b2 in (1, 2):
+            if b2 == B:
+                continue
+            bb = [make_batch(cfg, b2, T, R, device, seed=777 + 10 * b2 + i) for i in range(4)]
+            tr.train_step(bb[0])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(1, 4):
+                tr.train_step(bb[i])
+            torch.cuda.synchronize()
+            d1 = (time.perf_counter() - t1) / 3
+            per_batch[f'B{b2}'] = {'pairs_per_gpu_step': b2, 'value': b2 / d1, 'unit': 'pairs/s', 'ms_per_step': d1 * 1e3, 'steps': 3, 'warmup': 1}
+            del bb
+
     if rank == 0:
         n_img = (cfg['vision']['image_size'] // cfg['vision']['patch_size']) ** 2
         fl_pair, _ = flops_per_pair(cfg, T, R, n_img)
@@ -328,6 +364,8 @@ def main():
                                   'ffn': cfg['text']['intermediate_size'], 'vocab': cfg['text']['vocab_size'], 'layers': args.layers,
                                   'tokens_per_gpu_step': 2 * B * T, 'image_tokens': n_img},
                        'trainable_params': tr.policy.store.num_trainable(), 'losses_timed_steps': losses},
+            'n1_equivalent': {'value': value / world, 'unit': 'pairs/s per GPU', 'ms_per_step': step_s * 1e3,
+                              'note': 'weak scaling: every GPU runs the N=1 workload; compare with the N=1 line directly'},
             'step_mfma': {'executed_tflop_per_pair': exe_pair / 1e12, 'achieved_tflops_per_gpu': exe_tflops,
                           'frac_of_dense_bf16_peak': exe_tflops / PEAK_BF16_TFLOPS,
                           'executed_split': {'gemm_tflop_per_pair': executed['gemm'] / (B * args.steps) / 1e12,
@@ -382,7 +420,9 @@ def main():
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm4_kernel<A_T,B_N,EPI> / gemm4nt_kernel<EPI> (csrc/gemm4.hip: one wave per SIMD, 128x128 per wave): '
                                                           'every sampled GEMM launch of >= 0.25 TFLOP in the timed steps',
                                'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                               'traffic': traffic, 'traffic_unit': f'HBM bytes per gemm4 launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes of this command: {src if live_traffic is not None else "profiles/" + str(src)})',
+                               'traffic': traffic, 'traffic_source': ('measured_in_this_invocation' if live_traffic is not None else
+                                                                      (f'committed:profiles/{src}' if traffic is not None else None)),
+                               'traffic_unit': f'HBM bytes per gemm4 launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes of this command: {src if live_traffic is not None else "profiles/" + str(src)})',
                                'algorithmic_bytes_per_launch': sum(e[3] for e in gemm_events) / n,
                                'launches': n, 'launch_sampling': f'every {ops.GEMM_PROF_STRIDE}th GEMM launch of the timed steps', 'avg_launch_ms': tot_ms / n,
                                'avg_flops_per_launch': tot_fl / n,
@@ -392,6 +432,17 @@ def main():
                 out['roofline']['all_gemm_launches_sampled'] = {'achieved': all_ach, 'launches': all_n, 'avg_launch_ms': all_ms / all_n,
                                                                 'note': 'incl. the small CLIP-tower / projector GEMMs (see the comment in bench.py)'}
                 out['roofline']['gemm_share_of_step_time'] = all_ms * ops.GEMM_PROF_STRIDE / (dt * 1e3)
+        if per_batch:
+            per_batch[f'B{B}'] = {'pairs_per_gpu_step': B, 'value': value / world, 'unit': 'pairs/s', 'ms_per_step': step_s * 1e3, 'steps': args.steps,
+                                  'warmup': args.warmup, 'headline': True}
+            per_batch['note'] = (f'headline = {B} pairs/GPU/step: one optimizer step over {B} pairs is what the reference reaches with per_device_train_batch_size 1 x '
+                                 f'gradient_accumulation_steps {B} (configs/train/text_image_to_text/dpo.yaml:30,34) -- same update, and activations for {B} pairs fit '
+                                 'the 288 GB of one MI355X without recomputation, so the native step does them in one pass (longer GEMM M = fewer partial tile '
+                                 'rounds, one AdamW per 4 pairs).  B1 / B2 = the same step at the yaml default micro-batch and at 2, measured after the timed region.')
+            out['per_batch'] = per_batch
+        if ops.GLU_BWD_PROBE_LOG:
+            out['glu_bwd_plan'] = [{'M': m, 'F': f, 'K': k, 'fused_ms': round(a, 4), 'unfused_ms': round(b, 4), 'chosen': 'fused' if a <= b else 'unfused'}
+                                   for m, f, k, a, b in ops.GLU_BWD_PROBE_LOG]
         if multi is not None:
             out['multi_gpu'] = multi
         if not args.no_cpu_baseline and world == 1:
@@ -399,6 +450,15 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(cfg, T)
             except Exception as ex:  # the bench line must still be printed
                 out['cpu_baseline'] = {'error': repr(ex)}
+            # kind "reference": the reference's OWN DPOTrainer.loss + backward + AdamW on HF modules, timed in the build container (the
+            # reference is not on the GPU box) by tools/cpu_reference_baseline.py and committed; carried beside the live port figure
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'cpu_reference_L2.json')) as f:
+                    ref = json.load(f)
+                out['cpu_baseline']['reference'] = {k: ref[k] for k in ('kind', 'value', 'unit', 'cores', 'cpu', 'where', 'dtype', 'what', 'sample', 'script') if k in ref}
+                out['cpu_baseline']['reference']['source'] = 'committed:profiles/cpu_reference_L2.json (not measured on this box)'
+            except (OSError, ValueError):
+                pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -45,6 +45,12 @@ def _rand(rows, cols, seed, scale=1.0):
 
 @pytest.mark.parametrize('case', HOT_GEMMS, ids=[c[0] for c in HOT_GEMMS])
 def test_hot_gemm_shapes_of_the_benchmarked_step(case):
+    check_gemm_case(case)
+
+
+def check_gemm_case(case):
+    """One production GEMM launch (name, layout, M, N, K) against an fp32 matmul on a row sample that touches every tile row, plus the
+    whole-output column-sum identity.  Shared with tests/test_secondary_geometry_gpu.py (the 7B shapes of configs[2]-[4])."""
     from align_anything_amd import ops
     name, layout, M, N, K = case
     a_t, b_n = layout == 'tn', layout in ('nn', 'tn')

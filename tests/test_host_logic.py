@@ -542,39 +542,34 @@ def test_preference_cache_forwards_tokenizer_arguments_of_the_text_collator():
     assert b['input_ids'].shape == (2, 4) and b['attention_mask'].tolist() == [[1, 1, 1, 1], [1, 1, 0, 0]] and b['meta_info']['response_lens'] == [2, 1]
 
 
-def test_gemm4_kernels_keep_everything_in_registers():
-    """csrc/gemm4.hip counts its own LDS reads and LDS-DMA requests (inline asm), which is only sound while the compiler neither spills
-    nor keeps accumulators in scratch: a spill of a fragment register could store it before its untracked load has landed, and any
-    scratch access makes hipcc put `s_waitcnt vmcnt(0)` into the K loop (draining the DMA ring every step -- measured -15 %).
-    Compile the file and require: no scratch, no spills, accumulators in the accumulator file, and a K loop whose only vmcnt waits are
-    the counted ones of the begin-of-step statements."""
+def _check_ring_gemm_isa(src_name, kernel_re, mfma, mfma_per_trip, min_kernels):
     import re
     import subprocess
     import tempfile
     from align_anything_amd import build as b
-    src = os.path.join(b.CSRC, 'gemm4.hip')
+    src = os.path.join(b.CSRC, src_name)
     with tempfile.TemporaryDirectory() as d:
-        asm = os.path.join(d, 'gemm4.s')
+        asm = os.path.join(d, 'k.s')
         r = subprocess.run([b.HIPCC, *b.FLAGS, '--cuda-device-only', '-S', src, '-o', asm, '-Rpass-analysis=kernel-resource-usage'],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
         text = open(asm).read()
-    names = re.findall(r'Function Name: (\S*gemm4(?:nt)?_kernel\S*)', r.stderr)
+    names = re.findall(r'Function Name: (\S*' + kernel_re + r'\S*)', r.stderr)
     scratch = [int(x) for x in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
     vspill = [int(x) for x in re.findall(r'VGPRs Spill: (\d+)', r.stderr)]
     agprs = [int(x) for x in re.findall(r'AGPRs: (\d+)', r.stderr)]
-    assert len(names) >= 10 and len(names) == len(scratch) == len(vspill) == len(agprs)
+    assert len(names) >= min_kernels and len(names) == len(scratch) == len(vspill) == len(agprs)
     assert all(s == 0 for s in scratch) and all(s == 0 for s in vspill), list(zip(names, scratch, vspill))
     assert all(a == 256 for a in agprs), agprs
     assert 'scratch_' not in text
     # between the first and the last MFMA of a kernel (= the K loop: four ring steps per trip) every vmcnt wait must be one of OURS, i.e.
     # sit inside an inline-asm block
-    kernels = re.findall(r'^(_ZN\S*gemm4(?:nt)?_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end', text, flags=re.S | re.M)
-    assert len(kernels) >= 10
+    kernels = re.findall(r'^(_ZN\S*' + kernel_re + r'\S*):[^\n]*\n(.*?)\n\.Lfunc_end', text, flags=re.S | re.M)
+    assert len(kernels) >= min_kernels
     for name, body in kernels:
         lines = body.split('\n')
-        idx = [i for i, ln in enumerate(lines) if 'v_mfma_f32_16x16x32_bf16' in ln]
-        assert len(idx) == 256, (name, len(idx))
+        idx = [i for i, ln in enumerate(lines) if mfma in ln]
+        assert len(idx) == mfma_per_trip, (name, len(idx))
         in_asm, compiler_waits, ours = False, 0, 0
         for ln in lines[idx[0]:idx[-1]]:
             if 'ASMSTART' in ln:
@@ -586,8 +581,25 @@ def test_gemm4_kernels_keep_everything_in_registers():
                     ours += 1
                 else:
                     compiler_waits += 1
+            elif not in_asm and ('v_mov_b32' in ln or 'v_accvgpr' in ln):
+                compiler_waits += 1000      # a register copy in the loop = the compiler is shuttling fragments / accumulators
         assert compiler_waits == 0, (name, compiler_waits)
         assert ours == 3, (name, ours)          # steps 1..3 of the trip (step 0's begin sits above the first MFMA)
+
+
+def test_gemm4_kernels_keep_everything_in_registers():
+    """csrc/gemm4.hip counts its own LDS reads and LDS-DMA requests (inline asm), which is only sound while the compiler neither spills
+    nor keeps accumulators in scratch: a spill of a fragment register could store it before its untracked load has landed, and any
+    scratch access makes hipcc put `s_waitcnt vmcnt(0)` into the K loop (draining the DMA ring every step -- measured -15 %).
+    Compile the file and require: no scratch, no spills, accumulators in the accumulator file, and a K loop whose only vmcnt waits are
+    the counted ones of the begin-of-step statements."""
+    _check_ring_gemm_isa('gemm4.hip', r'gemm4(?:nt)?_kernel', 'v_mfma_f32_16x16x32_bf16', 256, 10)
+
+
+def test_gemm5_kernels_keep_everything_in_registers():
+    """The same static guarantees for the 32x32x16 variant (csrc/gemm5.hip): 4 ring steps x 32 MFMAs per trip, 256 accumulator
+    registers, no spills / scratch / register copies in the K loop, only the counted vmcnt waits."""
+    _check_ring_gemm_isa('gemm5.hip', r'gemm5(?:nt)?_kernel', 'v_mfma_f32_32x32x16_bf16', 128, 7)
 
 
 def test_attention_kernels_keep_fragments_in_registers_and_the_prefetch_in_flight():

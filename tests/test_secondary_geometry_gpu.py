@@ -1,0 +1,416 @@
+"""GPU: parity at the 7B GEOMETRIES OF BASELINE configs[2]-[4] -- the shapes `tools/bench_qwen2vl.py`,
+`bench_qwen2audio.py`, `bench_qwen3moe.py` and `bench_ppo.py` time, which the reference-fixture tests only cover at h <= 128:
+
+* Qwen2-VL-7B (models/qwen2_vl.py:31-74 -> hf Qwen2VLForConditionalGeneration): every hot GEMM shape of the decoder (h = 3584,
+  ffn = 18944, qkv = 4608 = (28 + 2 x 4) x 128, V = 152064) in its layout at 8192 and 16384 tokens; GQA attention at N = 4, H = 28,
+  Hkv = 4, hd = 128, T = 2048 with left padding against the fp32 softmax reference; ONE full-width decoder layer + final norm +
+  lm_head + log-prob gather + DPO loss + backward through the trainer against the CPU oracle (oracle/models.py::qwen2vl_logits).
+* Qwen3-30B-A3B (models/qwen3_moe.py:28-60): ONE full-width sparse block (h = 2048, 128 experts, top-8, expert width 768, per-head
+  q/k RMSNorm, GQA 32/4) forward + backward incl. router and expert gradients: fp32 twin vs the oracle, bf16 vs the twin.
+* Qwen2-Audio (models/qwen2_audio.py:36-110): the Whisper front-end at 128 mel x 3000 frames (conv1 / conv2 as im2col GEMMs, GELU,
+  sinusoidal positions) + one 1280-wide encoder layer with a right-padded clip + AvgPool + LayerNorm, forward and backward against
+  oracle/models.py::qwen2audio_tower.
+* LLaVA-1.5-7B (configs[1]): the full-width layer of tests/test_bench_geometry_gpu.py through the FP32 TWIN kernels (gemm_f32 /
+  attention_f32 / lmhead f32 at h = 4096, T = 2048, V = 32064 -- the kernels that carry the 1e-4 loss-curve claim), twin vs oracle
+  <= 1e-4, and the bf16 production kernels against the twin on identical bf16-valued weights with the ONE scalar that dominates the
+  bf16 gradient deviation (beta * sigmoid(-margin)) factored out.
+"""
+import gc
+import math
+
+import pytest
+import torch
+
+from tests.gpu_util import assert_close, dev, dump
+from tests.test_attention_gpu import ref_attention
+from tests.test_bench_geometry_gpu import _rand, check_gemm_case
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+HQ, FQ, VQ, QKVQ = 3584, 18944, 152064, (28 + 2 * 4) * 128
+TOK2, TOK4, RESP2 = 8192, 16384, 2048          # 2 / 4 pairs x 2 rows x 2048 tokens; response rows of 2 pairs padded to 64
+
+QWEN2VL_GEMMS = [
+    ('qkv.fwd', 'nt', TOK2, QKVQ, HQ), ('o.fwd', 'nt', TOK2, HQ, HQ), ('gate_up.fwd', 'nt', TOK2, 2 * FQ, HQ), ('down.fwd', 'nt', TOK2, HQ, FQ),
+    ('qkv.dx', 'nn', TOK2, HQ, QKVQ), ('o.dx', 'nn', TOK2, HQ, HQ), ('gate_up.dx', 'nn', TOK2, HQ, 2 * FQ), ('down.dx', 'nn', TOK2, FQ, HQ),
+    ('qkv.dw', 'tn', QKVQ, HQ, TOK2), ('o.dw', 'tn', HQ, HQ, TOK2), ('gate_up.dw', 'tn', 2 * FQ, HQ, TOK2), ('down.dw', 'tn', HQ, FQ, TOK2),
+    ('lm_head.fwd', 'nt', RESP2, VQ, HQ), ('lm_head.dx', 'nn', RESP2, HQ, VQ), ('lm_head.dw', 'tn', VQ, HQ, RESP2),
+    ('gate_up.fwd.16k', 'nt', TOK4, 2 * FQ, HQ), ('down.dx.16k', 'nn', TOK4, FQ, HQ), ('qkv.dw.16k', 'tn', QKVQ, HQ, TOK4),
+    ('down.fwd.16k', 'nt', TOK4, HQ, FQ),
+]
+
+
+def _free():
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('case', QWEN2VL_GEMMS, ids=[c[0] for c in QWEN2VL_GEMMS])
+def test_qwen2vl_7b_hot_gemm_shapes(case):
+    check_gemm_case(case)
+    _free()
+
+
+def test_qwen2vl_7b_fused_epilogue_gemms_match_the_unfused_pair():
+    """RoPE on the (28 + 8) x 128 qkv projection, SwiGLU forward / backward at ffn = 18944: the fused gemm4 epilogues at the Qwen2-VL
+    widths are bit-identical to the unfused kernels (both plans of aa_gemm_glu_bwd_bf16)."""
+    from align_anything_amd import ops
+    from align_anything_amd.modeling import rope_tables
+    M = 2048
+    x = _rand(M, HQ, 1)
+    try:
+        wqkv = _rand(QKVQ, HQ, 2, 0.03)
+        pos = (torch.arange(M, device=dev()) % 2048).to(torch.int32)
+        cos_t, sin_t = rope_tables(2048, 128, 1000000.0, dev(), torch.bfloat16)
+        ops.gemm_set_fuse(True)
+        fused = ops.gemm_qkv_rope(x, wqkv, pos, cos_t, sin_t, 28 + 4, 128)
+        ops.gemm_set_fuse(False)
+        plain = ops.gemm_qkv_rope(x, wqkv, pos, cos_t, sin_t, 28 + 4, 128)
+        assert torch.equal(fused, plain), 'qkv + RoPE epilogue'
+        wgu, wdown = _rand(2 * FQ, HQ, 3, 0.03), _rand(HQ, FQ, 4, 0.03)
+        ops.gemm_set_fuse(True)
+        gu_f, act_f = ops.gemm_glu_fwd(x, wgu, FQ)
+        ops.gemm_set_fuse(False)
+        gu_p, act_p = ops.gemm_glu_fwd(x, wgu, FQ)
+        assert torch.equal(gu_f, gu_p) and torch.equal(act_f, act_p), 'gate_up + SwiGLU epilogue'
+        dy = _rand(M, HQ, 5)
+        ops.gemm_set_fuse(True)
+        outs = []
+        for mode in (1, 0):
+            ops.call('aa_gemm_glu_bwd_set_mode', mode)
+            outs.append(ops.gemm_glu_bwd(dy, wdown, gu_f, FQ))
+        assert torch.equal(outs[0], outs[1]), 'SwiGLU-backward epilogue vs GEMM + aa_swiglu_bwd'
+    finally:
+        ops.gemm_set_fuse(True)
+        ops.call('aa_gemm_glu_bwd_set_mode', -1)
+    _free()
+
+
+def test_gqa_attention_at_the_qwen2vl_7b_geometry():
+    """N = 4 rows (2 pairs), H = 28, Hkv = 4 (7 query heads per key head), hd = 128, T = 2048, causal; rows 1 / 3 left padded.
+    Two whole key-head groups (all 7 query heads of kv heads 0 and 3) against the fp32 softmax reference, so dK / dV carry the sum
+    over the group."""
+    from align_anything_amd import ops
+    N, T, H, Hkv, hd = 4, 2048, 28, 4, 128
+    rep_h = H // Hkv
+    scale = hd ** -0.5
+    qkv = _rand(N * T, (H + 2 * Hkv) * hd, 21, 0.7)
+    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:(H + Hkv) * hd], qkv[:, (H + Hkv) * hd:]
+    do = _rand(N * T, H * hd, 22)
+    start = torch.tensor([0, 411, 0, 64], dtype=torch.int32, device=dev())
+    idx = torch.arange(T, device=dev())
+    valid = (idx[None, :] >= start[:, None].long()).reshape(N * T)
+    do = do * valid[:, None].to(do.dtype)
+    o, lse = ops.attn_fwd(q, k, v, N, T, H, Hkv, hd, True, scale, start)
+    dqkv = torch.empty_like(qkv)
+    dq, dk, dv = dqkv[:, :H * hd], dqkv[:, H * hd:(H + Hkv) * hd], dqkv[:, (H + Hkv) * hd:]
+    ops.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, True, scale, start)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all() and torch.isfinite(dqkv.float()).all()
+    vm = valid[:, None].float()
+    assert float((o.float() * (1 - vm)).abs().max()) == 0.0, 'pad query rows must be exactly 0'
+    rep = []
+    for kvh in (0, 3):
+        qs, ks = slice(kvh * rep_h * hd, (kvh + 1) * rep_h * hd), slice(kvh * hd, (kvh + 1) * hd)
+        ro, rdq, rdk, rdv, _ = ref_attention(q[:, qs], k[:, ks], v[:, ks], do[:, qs], N, T, rep_h, 1, hd, True, scale, start)
+        assert_close(o[:, qs].float() * vm, ro * vm, rtol=2e-2, atol=2e-2, what=f'O kv head {kvh}')
+        for nm, got, want in (('dQ', dq[:, qs].float() * vm, rdq * vm), ('dK', dk[:, ks], rdk), ('dV', dv[:, ks], rdv)):
+            assert_close(got, want, rtol=3e-2, atol=2e-2 * max(float(want.abs().max()), 1e-3), what=f'{nm} kv head {kvh}')
+            rep.append(f'kv head {kvh} {nm} rel_err {rel_err(got.float(), want):.5f}')
+        rep.append(f'kv head {kvh} O rel_err {rel_err(o[:, qs].float() * vm, ro * vm):.5f}')
+        del ro, rdq, rdk, rdv
+        _free()
+    dump('parity_attention_gqa28x4_T2048.txt', '\n'.join(rep) + '\n')
+
+
+# ---------------------------------------------------------------------------------------------------------------- full-width layers
+def _dpo_cfgs(pad_id, dtype, beta=0.1):
+    return {'train_cfgs': {'scale_coeff': beta, 'learning_rate': 1e-6, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant',
+                           'compute_dtype': dtype}, 'model_cfgs': {'pad_token_id': pad_id}}
+
+
+def _pair_batch(V, Tn, R, pad_id, seed, left_pad=100):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    ids = torch.randint(3, V, (2, Tn), generator=g)
+    am = torch.ones(2, Tn, dtype=torch.long)
+    ids[1, :left_pad] = pad_id
+    am[1, :left_pad] = 0
+    ids[1, :Tn - R] = torch.where(am[1, :Tn - R].bool(), ids[0, :Tn - R], ids[1, :Tn - R])
+    return ids, am, [R, R - 37]
+
+
+def _native_layer_step(cfg, sd, sd_ref, ids, am, lens, pad_id, dtype, **trainer_kw):
+    """One DPO loss + backward of the native trainer; returns (logp, loss dict on the host, {name: grad fp32 cpu})."""
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    wd = torch.float32 if dtype == 'fp32' else torch.bfloat16
+    tr = DPOTrainer(_dpo_cfgs(pad_id, dtype), {'gradient_clipping': 1.0}, model_cfg=cfg, policy_state={k: v.to(wd) for k, v in sd.items()},
+                    reference_state={k: v.to(wd) for k, v in sd_ref.items()}, device='cuda:0', **trainer_kw)
+    batch = {'input_ids': ids.to(dev()), 'attention_mask': am.to(dev()), 'meta_info': {'response_lens': lens}}
+    lp = tr.compute_log_probs(tr.model, batch).cpu()
+    ld = tr.loss(batch)
+    tr.model.backward(ld['loss'])
+    torch.cuda.synchronize()
+    out = {k: (float(v) if v.numel() == 1 else v.float().cpu()) for k, v in ld.items() if isinstance(v, torch.Tensor)}
+    st = tr.policy.store
+    grads = {}
+    for k in sd:
+        g = st.grad_view(k)
+        if g is not None:
+            grads[k] = g.float().cpu().reshape(sd[k].shape)
+    del tr, batch
+    _free()
+    return lp, out, grads
+
+
+def _oracle_step(logits_fn, sd, sd_ref, ids, am, lens, pad_id, beta=0.1):
+    from oracle import rl_math as orl
+    osd = {k: v.float().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    with torch.no_grad():
+        ref_lp = orl.compute_log_probs(logits_fn({k: v.float() for k, v in sd_ref.items()}), ids, lens, pad_id)
+    want_lp = orl.compute_log_probs(logits_fn(osd), ids, lens, pad_id)
+    want = orl.dpo_loss(want_lp, ref_lp, beta)
+    want['loss'].backward()
+    return want_lp.detach(), {k: float(v) for k, v in want.items() if v.numel() == 1}, {k: v.grad for k, v in osd.items() if v.grad is not None}
+
+
+def _scaled_fit(got, want):
+    """Least-squares scale alpha of `got` on `want` and the relative residual after removing it."""
+    a = float((got.double() * want.double()).sum() / want.double().pow(2).sum().clamp_min(1e-300))
+    res = float((got.double() - a * want.double()).norm() / (abs(a) * want.double().norm()).clamp_min(1e-300))
+    return a, res
+
+
+def _rand_state(shapes, vec_names, seed, std=0.02):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    sd = {k: (torch.randn(s, generator=g) * std).to(torch.bfloat16) for k, s in shapes.items()}
+    for k, n in vec_names.items():
+        sd[k] = (1.0 + 0.1 * torch.randn(n, generator=g)).to(torch.bfloat16)
+    return sd, g
+
+
+def _perturbed(sd, g, eps=0.002):
+    return {k: (v.float() + eps * torch.randn(v.shape, generator=g)).to(torch.bfloat16) if v.dim() >= 2 else v.clone() for k, v in sd.items()}
+
+
+def test_llava_7b_layer_fp32_twin_vs_oracle_and_bf16_vs_twin():
+    """VERDICT r2 item 1(d) / weak #1.  The 1e-4 loss-curve claim of north_star rests on the fp32 twin kernels; here they run at
+    configs[1]'s benchmarked geometry (h = 4096, ffn 11008, V = 32064, T = 2048) and are held to the oracle at 1e-4 (loss: north_star's tolerance; the
+    fp32 ulp of a 511-token log-prob sum of about -5000 is 5e-4, times beta = 0.1) / 3e-4 (every gradient; measured values in the dump).  The bf16 production kernels are then compared with the TWIN on identical bf16-valued weights.  Their gradient
+    deviation is dominated by one scalar, s = beta * sigmoid(-margin) (every gradient of a one-pair DPO loss is linear in it), which
+    bf16 noise in the summed log-probs moves by a percent or two; with alpha = the least-squares scale of the bf16 gradient on the
+    twin's, the test asserts (i) alpha == s_bf16 / s_twin for EVERY tensor to 1 % (a tensor-specific scale bug cannot hide),
+    (ii) the residual after removing alpha stays under 2.5 % (rounding noise of one layer), (iii) per-token log-probs within 3e-2."""
+    from align_anything_amd import configs
+    from oracle import models as om
+    h, F, V, Tn, R, pad_id, beta = 4096, 11008, 32064, 2048, 512, 0, 0.1
+    cfg = configs.llama_cfg(h, F, 1, 32, 32, V, rms_eps=1e-5, max_position_embeddings=4096)
+    p = 'model.layers.0.'
+    shapes = {'model.embed_tokens.weight': (V, h), p + 'self_attn.q_proj.weight': (h, h), p + 'self_attn.k_proj.weight': (h, h),
+              p + 'self_attn.v_proj.weight': (h, h), p + 'self_attn.o_proj.weight': (h, h), p + 'mlp.gate_proj.weight': (F, h),
+              p + 'mlp.up_proj.weight': (F, h), p + 'mlp.down_proj.weight': (h, F), 'lm_head.weight': (V, h)}
+    sd, g = _rand_state(shapes, {p + 'input_layernorm.weight': h, p + 'post_attention_layernorm.weight': h, 'model.norm.weight': h}, 7)
+    sd_ref = _perturbed(sd, g)
+    ids, am, lens = _pair_batch(V, Tn, R, pad_id, 8)
+    lp32, ld32, g32 = _native_layer_step(cfg, sd, sd_ref, ids, am, lens, pad_id, 'fp32')
+    lp16, ld16, g16 = _native_layer_step(cfg, sd, sd_ref, ids, am, lens, pad_id, 'bf16')
+    want_lp, want, gw = _oracle_step(lambda s: om.llama_logits(s, cfg, ids, am), sd, sd_ref, ids, am, lens, pad_id, beta)
+    rep = [f'loss: fp32 twin {ld32["loss"]:.7f}  oracle {want["loss"]:.7f}  bf16 {ld16["loss"]:.7f}']
+    # ---- twin vs oracle
+    assert torch.equal(lp32 == 0, want_lp == 0)
+    e_lp = float((lp32 - want_lp).abs().max())
+    rep.append(f'fp32 twin vs oracle: max |d logp| {e_lp:.2e}, |d loss| {abs(ld32["loss"] - want["loss"]):.2e}')
+    worst32 = 0.0
+    for k, v in gw.items():
+        e = rel_err(g32[k], v)
+        worst32 = max(worst32, e)
+        rep.append(f'  twin grad {k}: rel_err {e:.2e}')
+    assert e_lp < 2e-4 and abs(ld32['loss'] - want['loss']) < 1e-4 and worst32 < 3e-4, rep
+    # ---- bf16 vs twin
+    s16, s32 = beta / (1 + math.exp(ld16['reward_margin'])), beta / (1 + math.exp(ld32['reward_margin']))
+    ratio = s16 / s32
+    rep.append(f'bf16 vs twin: margin {ld16["reward_margin"]:.5f} vs {ld32["reward_margin"]:.5f} -> scalar ratio s_bf16 / s_twin = {ratio:.5f}')
+    e_lp16 = float((lp16 - lp32).abs().max())
+    rep.append(f'  per-token log-probs: max |bf16 - twin| {e_lp16:.3e}')
+    worst_a, worst_r = 0.0, 0.0
+    for k, v in g32.items():
+        a, res = _scaled_fit(g16[k], v)
+        worst_a, worst_r = max(worst_a, abs(a / ratio - 1)), max(worst_r, res)
+        rep.append(f'  bf16 grad {k}: alpha {a:.5f} (alpha / ratio - 1 = {a / ratio - 1:+.2e}), residual {res:.2e}, unscaled rel_err {rel_err(g16[k], v):.2e}')
+    dump('parity_layer_h4096_T2048_twin.txt', '\n'.join(rep) + f'\nworst twin-vs-oracle grad rel_err {worst32:.2e}; bf16-vs-twin worst |alpha/ratio-1| {worst_a:.2e}, worst residual {worst_r:.2e}\n')
+    assert e_lp16 < 5e-2 and worst_a < 1e-2 and worst_r < 2.5e-2, rep
+
+
+def test_qwen2vl_7b_full_width_decoder_layer_matches_oracle():
+    """One Qwen2-VL-7B decoder layer (h = 3584, GQA 28 / 4 x 128 with q/k/v biases, ffn 18944, V = 152064, multimodal RoPE with
+    mrope_section [16, 24, 24], theta 1e6) at T = 2048, one text-only pair with a left-padded row: fp32 twin vs the CPU oracle
+    (1e-4 / 3e-4), bf16 vs the twin with the DPO scalar factored out (as for LLaVA above)."""
+    from align_anything_amd import configs
+    from oracle import models as om
+    cfg = configs.qwen2_vl_7b(num_layers=1, vision_depth=1)
+    t = cfg['text']
+    h, F, V, Tn, R, pad_id, beta = t['hidden_size'], t['intermediate_size'], t['vocab_size'], 2048, 512, cfg['pad_token_id'], 0.1
+    kvw = t['num_kv_heads'] * t['head_dim']
+    p = 'model.language_model.layers.0.'
+    shapes = {'model.language_model.embed_tokens.weight': (V, h), p + 'self_attn.q_proj.weight': (h, h), p + 'self_attn.k_proj.weight': (kvw, h),
+              p + 'self_attn.v_proj.weight': (kvw, h), p + 'self_attn.o_proj.weight': (h, h), p + 'mlp.gate_proj.weight': (F, h),
+              p + 'mlp.up_proj.weight': (F, h), p + 'mlp.down_proj.weight': (h, F), 'lm_head.weight': (V, h)}
+    sd, g = _rand_state(shapes, {p + 'input_layernorm.weight': h, p + 'post_attention_layernorm.weight': h, 'model.language_model.norm.weight': h}, 17)
+    for nm, n in (('q', h), ('k', kvw), ('v', kvw)):
+        sd[p + f'self_attn.{nm}_proj.bias'] = (0.1 * torch.randn(n, generator=g)).to(torch.bfloat16)
+    sd_ref = _perturbed(sd, g)
+    ids, am, lens = _pair_batch(V - 1000, Tn, R, pad_id, 18, left_pad=77)
+    # the vision tower is not on this path (text-only rows): its weights stay at their zero init (strict=False inside the trainer is
+    # not available, so the missing visual tensors are filled from a freshly built model's own state)
+    from align_anything_amd.modeling import build_model
+    probe = build_model(cfg, 'cuda:0', trainable=False)
+    full = {k: v.cpu() for k, v in probe.state_dict().items()}
+    del probe
+    _free()
+    sd_full = {**{k: v for k, v in full.items() if k not in sd}, **sd}
+    sd_ref_full = {**{k: v for k, v in full.items() if k not in sd_ref}, **sd_ref}
+    lp32, ld32, g32 = _native_layer_step(cfg, sd_full, sd_ref_full, ids, am, lens, pad_id, 'fp32', share_vision_tower=False)
+    lp16, ld16, g16 = _native_layer_step(cfg, sd_full, sd_ref_full, ids, am, lens, pad_id, 'bf16', share_vision_tower=False)
+    want_lp, want, gw = _oracle_step(lambda s: om.qwen2vl_logits(s, cfg, ids, am, None, None), sd, sd_ref, ids, am, lens, pad_id, beta)
+    rep = [f'loss: fp32 twin {ld32["loss"]:.7f}  oracle {want["loss"]:.7f}  bf16 {ld16["loss"]:.7f}']
+    assert torch.equal(lp32 == 0, want_lp == 0)
+    e_lp = float((lp32 - want_lp).abs().max())
+    worst32 = 0.0
+    for k, v in gw.items():
+        e = rel_err(g32[k], v)
+        worst32 = max(worst32, e)
+        rep.append(f'  twin grad {k}: rel_err {e:.2e}')
+    rep.append(f'fp32 twin vs oracle: max |d logp| {e_lp:.2e}, |d loss| {abs(ld32["loss"] - want["loss"]):.2e}, worst grad rel_err {worst32:.2e}')
+    assert e_lp < 2e-4 and abs(ld32['loss'] - want['loss']) < 1e-4 and worst32 < 3e-4, rep
+    s16, s32 = beta / (1 + math.exp(ld16['reward_margin'])), beta / (1 + math.exp(ld32['reward_margin']))
+    ratio = s16 / s32
+    e_lp16 = float((lp16 - lp32).abs().max())
+    worst_a, worst_r = 0.0, 0.0
+    for k, v in gw.items():
+        a, res = _scaled_fit(g16[k], g32[k])
+        worst_a, worst_r = max(worst_a, abs(a / ratio - 1)), max(worst_r, res)
+        rep.append(f'  bf16 grad {k}: alpha / ratio - 1 = {a / ratio - 1:+.2e}, residual {res:.2e}')
+    rep.append(f'bf16 vs twin: scalar ratio {ratio:.5f}, max |d logp| {e_lp16:.3e}, worst |alpha/ratio-1| {worst_a:.2e}, worst residual {worst_r:.2e}')
+    dump('parity_qwen2vl7b_layer_T2048.txt', '\n'.join(rep) + '\n')
+    assert e_lp16 < 5e-2 and worst_a < 1e-2 and worst_r < 2.5e-2, rep
+
+
+def test_qwen3moe_30b_full_width_sparse_block_matches_oracle():
+    """One Qwen3-30B-A3B layer at full width (h = 2048, 32 / 4 heads x 128 with per-head q/k RMSNorm, 128 experts of width 768, top-8,
+    renormalised; V = 151936) at T = 1024, one pair: the fp32 twin (exact-fp32 grouped GEMMs, moe_f32.hip) against the CPU oracle --
+    loss, log-probs and EVERY gradient incl. the router (`mlp.gate.weight`) and the 3-D expert tensors; the bf16 production kernels
+    (grouped bf16 GEMM over 128 experts x 8 choices) against the twin with the DPO scalar factored out.  Routing is a top-8 of 128 on
+    bf16 activations: a token whose 8th / 9th probabilities tie within bf16 noise may pick another expert than the twin, which moves
+    single rows of the expert gradients, so their residual bound is wider (and reported)."""
+    from align_anything_amd import configs
+    from oracle import models as om
+    h, Fm, E, k, V, Tn, R, pad_id, beta = 2048, 768, 128, 8, 151936, 1024, 256, 0, 0.1
+    cfg = configs.qwen3moe_cfg(h, Fm, 1, 32, 4, V, E, k)
+    p = 'model.layers.0.'
+    shapes = {'model.embed_tokens.weight': (V, h), p + 'self_attn.q_proj.weight': (32 * 128, h), p + 'self_attn.k_proj.weight': (4 * 128, h),
+              p + 'self_attn.v_proj.weight': (4 * 128, h), p + 'self_attn.o_proj.weight': (h, 32 * 128), p + 'mlp.gate.weight': (E, h),
+              p + 'mlp.experts.gate_up_proj': (E, 2 * Fm, h), p + 'mlp.experts.down_proj': (E, h, Fm), 'lm_head.weight': (V, h)}
+    sd, g = _rand_state(shapes, {p + 'input_layernorm.weight': h, p + 'post_attention_layernorm.weight': h, 'model.norm.weight': h,
+                                 p + 'self_attn.q_norm.weight': 128, p + 'self_attn.k_norm.weight': 128}, 27)
+    sd[p + 'mlp.gate.weight'] = (torch.randn(E, h, generator=g) * 0.05).to(torch.bfloat16)       # a router that spreads its top-8
+    sd_ref = _perturbed(sd, g)
+    ids, am, lens = _pair_batch(V, Tn, R, pad_id, 28, left_pad=50)
+    lp32, ld32, g32 = _native_layer_step(cfg, sd, sd_ref, ids, am, lens, pad_id, 'fp32')
+    lp16, ld16, g16 = _native_layer_step(cfg, sd, sd_ref, ids, am, lens, pad_id, 'bf16')
+    want_lp, want, gw = _oracle_step(lambda s: om.qwen3moe_logits(s, cfg, ids, am), sd, sd_ref, ids, am, lens, pad_id, beta)
+    rep = [f'loss: fp32 twin {ld32["loss"]:.7f}  oracle {want["loss"]:.7f}  bf16 {ld16["loss"]:.7f}']
+    assert torch.equal(lp32 == 0, want_lp == 0)
+    e_lp = float((lp32 - want_lp).abs().max())
+    worst32 = 0.0
+    for kk, v in gw.items():
+        e = rel_err(g32[kk], v)
+        worst32 = max(worst32, e)
+        rep.append(f'  twin grad {kk}: rel_err {e:.2e} |want| {float(v.norm()):.3e}')
+    rep.append(f'fp32 twin vs oracle: max |d logp| {e_lp:.2e}, |d loss| {abs(ld32["loss"] - want["loss"]):.2e}, worst grad rel_err {worst32:.2e}')
+    assert p + 'mlp.gate.weight' in gw and p + 'mlp.experts.gate_up_proj' in gw
+    assert e_lp < 2e-4 and abs(ld32['loss'] - want['loss']) < 1e-4 and worst32 < 3e-4, rep
+    s16, s32 = beta / (1 + math.exp(ld16['reward_margin'])), beta / (1 + math.exp(ld32['reward_margin']))
+    ratio = s16 / s32
+    e_lp16 = float((lp16 - lp32).abs().max())
+    worst_a, worst_r, worst_r_exp = 0.0, 0.0, 0.0
+    for kk, v in gw.items():
+        a, res = _scaled_fit(g16[kk], g32[kk])
+        rep.append(f'  bf16 grad {kk}: alpha / ratio - 1 = {a / ratio - 1:+.2e}, residual {res:.2e}')
+        worst_a = max(worst_a, abs(a / ratio - 1))
+        if 'experts' in kk or 'mlp.gate' in kk:
+            worst_r_exp = max(worst_r_exp, res)
+        else:
+            worst_r = max(worst_r, res)
+    rep.append(f'bf16 vs twin: scalar ratio {ratio:.5f}, max |d logp| {e_lp16:.3e}, worst |alpha/ratio-1| {worst_a:.2e}, worst residual dense {worst_r:.2e} / router+experts {worst_r_exp:.2e}')
+    dump('parity_qwen3moe30b_layer_T1024.txt', '\n'.join(rep) + '\n')
+    assert e_lp16 < 5e-2 and worst_a < 2e-2 and worst_r < 3e-2 and worst_r_exp < 1.5e-1, rep
+
+
+def test_whisper_front_end_and_encoder_layer_at_128_mel_3000_frames():
+    """Qwen2-Audio tower at the real input size (models/qwen2_audio.py:36-110 -> hf Qwen2AudioEncoder): 128 mel x 3000 frames ->
+    conv1 (k 3) + GELU -> conv2 (k 3, stride 2) + GELU -> + 1500 sinusoidal positions -> one 1280-wide pre-LN encoder layer (20 heads
+    of 64, ffn 5120; clip 1 is right-padded: keys beyond its length are masked) -> AvgPool1d(2) -> LayerNorm = [750, 1280] per clip;
+    forward and every tower gradient against oracle/models.py::qwen2audio_tower, fp32 twin at 1e-4 and bf16 inside the envelope."""
+    from align_anything_amd import configs
+    from align_anything_amd.modeling import build_model
+    from oracle import models as om
+    acfg = configs.qwen2audio_tower_cfg(1280, 1, 20, 5120, num_mel_bins=128, max_source_positions=1500)
+    text = configs.llama_cfg(128, 256, 1, 2, 1, 320, rms_eps=1e-6, max_position_embeddings=256, attention_bias=True)
+    cfg = configs.qwen2audio_cfg(text, acfg, audio_token_id=300, pad_token_id=304)
+    g = torch.Generator(device='cpu').manual_seed(31)
+    B, S = 2, 1500
+    feats = torch.randn(B, 128, 2 * S, generator=g)
+    flen = torch.tensor([3000, 2001])
+    feats[1, :, 2001:] = 0.0
+    alen, olen = om.qwen2audio_lengths(flen)
+    dout = torch.randn(B, S // 2, 1280, generator=g) * (torch.arange(S // 2)[None, :, None] < olen[:, None, None])
+    rep = []
+    sd = None
+    for dtype, wd in (('fp32', torch.float32), ('bf16', torch.bfloat16)):
+        m = build_model(cfg, 'cuda:0', trainable=True, dtype=wd)
+        if sd is None:
+            gg = torch.Generator(device='cpu').manual_seed(32)
+            sd = {}
+            for k, v in m.state_dict().items():
+                if 'embed_positions' in k:
+                    sd[k] = v.float().cpu()
+                elif v.dim() >= 2:
+                    sd[k] = (torch.randn(v.shape, generator=gg) * 0.03).to(torch.bfloat16).float()
+                else:
+                    sd[k] = ((1.0 if 'norm.weight' in k else 0.0) + 0.05 * torch.randn(v.shape, generator=gg)).to(torch.bfloat16).float()
+            # the real sinusoids (hf WhisperEncoder / Qwen2AudioEncoder embed_positions)
+            half = 640
+            inc = math.log(10000.0) / (half - 1)
+            ang = torch.arange(S)[:, None].float() * torch.exp(-inc * torch.arange(half).float())[None]
+            sd['model.audio_tower.embed_positions.weight'] = torch.cat([ang.sin(), ang.cos()], 1)
+        m.load_state_dict(sd)
+        m.init_training()
+        m.store.zero_grad()
+        out = m.tower.forward(feats.to(dev()).to(wd), alen.to(torch.int32).to(dev()), save=True)
+        rows = out.shape[0]
+        dpad = torch.zeros((rows, 1280), dtype=wd, device=dev())
+        dpad[:B * (S // 2)] = dout.reshape(-1, 1280).to(wd).to(dev())
+        m.tower.backward(dpad)
+        torch.cuda.synchronize()
+        got = out[:B * (S // 2)].float().cpu().view(B, S // 2, 1280)
+        if dtype == 'fp32':
+            osd = {k: v.clone().requires_grad_('embed_positions' not in k) for k, v in sd.items() if k.startswith('model.audio_tower.')}
+            want = om.qwen2audio_tower(osd, acfg, feats, flen)
+            (want * dout).sum().backward()
+            want = want.detach()
+        keep = (torch.arange(S // 2)[None, :] < olen[:, None])
+        e_out = rel_err(got[keep], want[keep])
+        worst, n = 0.0, 0
+        for k, v in osd.items():
+            if v.grad is None or float(v.grad.norm()) < 1e-9:
+                continue
+            gv = m.store.grad_view(k)
+            assert gv is not None, k
+            e = rel_err(gv.float().cpu().reshape(v.grad.shape), v.grad)
+            worst, n = max(worst, e), n + 1
+            rep.append(f'  {dtype} grad {k}: rel_err {e:.2e}')
+        rep.append(f'{dtype}: tower output rel_err {e_out:.2e}, worst gradient rel_err {worst:.2e} over {n} tensors')
+        assert n >= 18 and e_out < (1e-4 if dtype == 'fp32' else 2e-2) and worst < (2e-4 if dtype == 'fp32' else 6e-2), rep
+        del m
+        _free()
+    dump('parity_whisper_front_end_128x3000.txt', '\n'.join(rep) + '\n')
