@@ -423,7 +423,7 @@ void gemm_kernel(const GemmParams p) {
 }
 
 static int g_mfma32 = -1; // 1: the one-wave-per-SIMD 256x256 tile runs on v_mfma_f32_32x32x16_bf16 (gemm5.hip) instead of 16x16x32 (gemm4.hip); -1 = env AA_GEMM_MFMA32
-static bool mfma32_on() {
+bool aa_gemm_mfma32_on() {
     if (g_mfma32 < 0) { const char* e = getenv("AA_GEMM_MFMA32"); g_mfma32 = e ? (atoi(e) != 0) : 0; }
     return g_mfma32 != 0;
 }
@@ -553,7 +553,7 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
         p.tiles_m = aa_cdiv(p.M, 256);
         p.tiles_n = aa_cdiv(p.N, 256);
         p.gm = pick_group(a_t, b_n, p.tiles_n, p.K);
-        if (mfma32_on() && !(a_t && !b_n)) return aa_gemm5_dispatch(p, a_t, b_n, st);
+        if (aa_gemm_mfma32_on() && !(a_t && !b_n)) return aa_gemm5_dispatch(p, a_t, b_n, st);
         return aa_gemm4_dispatch(p, a_t, b_n, st);
     }
     if (!a_t && !b_n) return launch_layout<false, false>(p, tile, st);

@@ -104,8 +104,8 @@ __device__ __forceinline__ void g5_map_tile(const GemmParams& p, int& m0, int& n
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"                                                   \
                  : "+a"(acc[FM - 1][0]), "+a"(acc[FM - 1][1]), "+a"(acc[FM - 1][2]), "+a"(acc[FM - 1][3])::"memory")
 
-// EPI: 0 = general epilogue; 1 = plain bf16 store; 2 = + residual add.  (The rotary / SwiGLU epilogues of gemm4.hip are not built for
-// this MFMA shape: aa_gemm4_fused keeps them on gemm4's kernels.)
+// EPI (as gemm4.hip): 0 = general epilogue; 1 = plain bf16 store; 2 = + residual add; 3 = rotary embedding on the q / k heads of a fused qkv
+// projection; 4 = SwiGLU forward (tile = 128 gate + the matching 128 up columns); 5 = SwiGLU backward on the down-projection's dX
 template <bool A_T, bool B_N, int EPI>
 __global__ __launch_bounds__(NW * 64, 1)
 void gemm5_kernel(const GemmParams p) {
@@ -319,6 +319,7 @@ template <int EPI>
 __global__ __launch_bounds__(NW * 64, 1)
 void gemm5nt_kernel(const GemmParams p) {
     constexpr bool PLAIN = EPI != 0;
+    constexpr bool GLU_FWD = EPI == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -329,7 +330,9 @@ void gemm5nt_kernel(const GemmParams p) {
     // ---- DMA sources.  Piece c = wave + 4 j covers tile rows 8 c .. 8 c + 7; lane -> row lane >> 3, stored unit lane & 7 holds
     // k-unit (lane & 7) ^ ((row >> 1) & 7) of the tile's 64 k
     const char* baseA = reinterpret_cast<const char*>(p.A + (long)m0 * p.lda);
-    const char* baseB = reinterpret_cast<const char*>(p.B + (long)n0 * p.ldb);
+    const char* baseB;
+    if constexpr (GLU_FWD) baseB = reinterpret_cast<const char*>(p.B + (long)(n0 >> 1) * p.ldb);
+    else baseB = reinterpret_cast<const char*>(p.B + (long)n0 * p.ldb);
     unsigned offA[NP8], offB[NP8];
     {
         const int rr = wave * 8 + (lane >> 3);
@@ -346,7 +349,16 @@ void gemm5nt_kernel(const GemmParams p) {
     const int pieceA = NW * 8 * (int)p.lda * 2, pieceB = NW * 8 * (int)p.ldb * 2;
     int soA[NP8], soB[NP8];
 #pragma unroll
-    for (int j = 0; j < NP8; ++j) { soA[j] = j * pieceA; soB[j] = j * pieceB; }
+    for (int j = 0; j < NP8; ++j) {
+        soA[j] = j * pieceA;
+        if constexpr (GLU_FWD) {       // B tile rows: per N-wave 64 gate rows then the 64 up rows of the same columns (F rows further down)
+            const int r0 = 8 * wave + 32 * j, wq = r0 >> 7, q = r0 & 127;
+            const int row = q < 64 ? wq * 64 + q : p.glu_f + wq * 64 + (q - 64);
+            soB[j] = (row - 8 * wave) * (int)p.ldb * 2;
+        } else {
+            soB[j] = j * pieceB;
+        }
+    }
 #define G5NT_DMA_A(J)                                                                \
     do {                                                                             \
         if constexpr (PLAIN) G5NT_DMA_PIECE_BUF<J>(offA[0], soA, g5_make_srd(srcA)); \
@@ -469,13 +481,17 @@ int launch5(GemmParams& p, hipStream_t st) {
 
 template <int EPI>
 int launch5_layout(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
-    if (!a_t && !b_n) return launch5<false, false, EPI>(p, st);
-    if constexpr (EPI <= 1) {          // the residual epilogue exists for the forward (NT) layout only
-        if (!a_t && b_n) return launch5<false, true, EPI>(p, st);
-        if (a_t && b_n) return launch5<true, true, EPI>(p, st);
+    if constexpr (EPI == 5) {          // SwiGLU backward rides on the dX (NN) GEMM of the down projection
+        return launch5<false, true, EPI>(p, st);
+    } else {
+        if (!a_t && !b_n) return launch5<false, false, EPI>(p, st);
+        if constexpr (EPI <= 1) {      // the residual / rotary / SwiGLU-forward epilogues exist for the forward (NT) layout only
+            if (!a_t && b_n) return launch5<false, true, EPI>(p, st);
+            if (a_t && b_n) return launch5<true, true, EPI>(p, st);
+        }
+        aa_set_error("aa_gemm_bf16: layout not built for this epilogue (A^T with K-contiguous B is unused by the hot path)");
+        return AA_ERR_ARG;
     }
-    aa_set_error("aa_gemm_bf16: layout not built for this epilogue (A^T with K-contiguous B is unused by the hot path)");
-    return AA_ERR_ARG;
 }
 
 }  // namespace
@@ -489,4 +505,12 @@ int aa_gemm5_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
     if (plain) return launch5_layout<1>(p, a_t, b_n, st);
     if (resid) return launch5_layout<2>(p, a_t, b_n, st);
     return launch5_layout<0>(p, a_t, b_n, st);
+}
+
+// Fused epilogues on the 32x32x16 kernels; the caller (aa_gemm4_fused) has validated the shape and set tiles_m / tiles_n.
+int aa_gemm5_fused(GemmParams& p, hipStream_t st) {
+    if (p.fuse == AA_FUSE_ROPE) return launch5_layout<3>(p, false, false, st);
+    if (p.fuse == AA_FUSE_GLU_FWD) return launch5_layout<4>(p, false, false, st);
+    if (p.fuse == AA_FUSE_GLU_BWD) return launch5_layout<5>(p, false, true, st);
+    return 1;
 }

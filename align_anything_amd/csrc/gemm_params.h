@@ -103,3 +103,5 @@ int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
 int aa_gemm4_fused(GemmParams& p, hipStream_t st);
 // the same one-wave-per-SIMD kernel on v_mfma_f32_32x32x16_bf16 (gemm5.hip; plain / residual / general epilogues)
 int aa_gemm5_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
+int aa_gemm5_fused(GemmParams& p, hipStream_t st);       // fused epilogues (p.fuse) after aa_gemm4_fused's shape checks
+bool aa_gemm_mfma32_on();                                // aa_gemm_set_mfma32 / AA_GEMM_MFMA32

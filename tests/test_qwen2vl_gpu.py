@@ -266,3 +266,23 @@ def test_qwen2vl_rm_trainer_loss_matches_reference_fixture_right_padded(dtype):
     assert n >= 5 and worst < (3e-5 if f32 else 1.2e-1), (n, worst)
     dump(f'parity_qwen2vl_rm_reference_{dtype}.txt',
          f'{dtype} right-padded: loss {float(ld["loss"]):.6f} vs reference {float(z["loss"]):.6f}, worst gradient rel-err {worst:.2e} over {n} tensors\n')
+
+
+def test_ppo_four_engines_and_decode_copies_coexist_at_full_width_reduced_depth():
+    """tools/bench_ppo.py (BASELINE configs[2] on one GPU) at Qwen2-VL-7B WIDTH (h = 3584, GQA 28 / 4, ffn 18944, V = 152064, ViT 1280 x 16
+    heads of 80) but 2 decoder layers / 2 ViT blocks: actor, reference, reward model and critic are resident together with the actor's
+    strip-major decode copies, a sampled HIP rollout of 16 tokens feeds rl_step, both updates produce finite losses.  The full-depth
+    run is a profiles/ artifact (r03_bench_ppo_qwen2vl7b.json); this keeps its code path under test."""
+    import math
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import bench_ppo
+    out = bench_ppo.bench(prompts=2, new_tokens=16, iters=1, layers=2, vision_depth=2)
+    m = out['memory']
+    assert m['decode_copies_resident_during_update'] and m['peak_allocated_GiB'] > m['resident_after_build_GiB'] > 20.0
+    assert m['actor_trainable_params'] > 1.5e9 and m['critic_trainable_params'] > 1.0e9
+    for r in out['iterations']:
+        assert r['response_lens'] == [16, 16] and math.isfinite(r['actor_loss']) and math.isfinite(r['critic_loss'])
+    assert out['decode_ms_per_position'] > 0 and out['split_ms']['prefill_of_generate'] > 0
+    torch.cuda.empty_cache()

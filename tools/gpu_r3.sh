@@ -38,6 +38,14 @@ PY
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r03_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03_prof -o p -- python $R/bench.py --steps 3 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > $R/gpurun_out/r03_bench_under_rocprof.json 2> $R/gpurun_out/r03_prof.err )
       f=$(find gpurun_out/r03_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r03_dpo7b_kernel_stats.csv && head -25 "$f"
       find gpurun_out/r03_prof -name "*kernel_trace.csv" -delete ;;
+    power)       # gemm4 vs gemm5 under sustained load: TFLOP/s, shader clock, package power
+      timeout 300 python tools/gemm_power_ab.py > gpurun_out/r03_gemm_power_ab.log 2>&1; tail -13 gpurun_out/r03_gemm_power_ab.log ;;
+    tests_fix)   # the tests changed after the first hardware run
+      timeout 1200 python -m pytest tests/test_secondary_geometry_gpu.py tests/test_qwen2vl_gpu.py -m gpu -q --maxfail=40 -p no:cacheprovider -k "twin or sparse_block or four_engines or rm_trainer" > gpurun_out/r03_pytest_fix.log 2>&1; tail -8 gpurun_out/r03_pytest_fix.log ;;
+    secondary)   # the other backbones' DPO steps and the decode micro-bench on this round's kernels
+      timeout 400 python tools/bench_qwen2vl.py > gpurun_out/r03_bench_qwen2vl_7b_dpo.json 2> gpurun_out/r03_bench_qwen2vl.err; tail -c 400 gpurun_out/r03_bench_qwen2vl_7b_dpo.json
+      timeout 400 python tools/bench_qwen2audio.py > gpurun_out/r03_bench_qwen2audio_7b_dpo.json 2> gpurun_out/r03_bench_qwen2audio.err; tail -c 400 gpurun_out/r03_bench_qwen2audio_7b_dpo.json
+      timeout 400 python tools/bench_qwen3moe.py > gpurun_out/r03_bench_qwen3moe_12layers_dpo.json 2> gpurun_out/r03_bench_qwen3moe.err; tail -c 400 gpurun_out/r03_bench_qwen3moe_12layers_dpo.json ;;
     ppo)
       timeout 1500 python tools/bench_ppo.py > gpurun_out/r03_bench_ppo.json 2> gpurun_out/r03_bench_ppo.err; tail -c 2500 gpurun_out/r03_bench_ppo.json; tail -5 gpurun_out/r03_bench_ppo.err ;;
     *) echo "unknown stage $stage" ;;
