@@ -346,7 +346,7 @@ class NativeEngine:
         with expert-parallel weights every rank MUST: `state_dict()` gathers the expert shards, a collective."""
         self.wait_optimizer()
         path = os.path.join(save_dir, save_filename)
-        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        rank = dist.get_rank(self.reducer.group) if (dist.is_available() and dist.is_initialized()) else 0     # the writer is rank 0 of THIS engine's group
         if rank != 0 and getattr(self.module, 'ep', None) is None:
             return path
         sd = {k: v.cpu() for k, v in self.module.state_dict().items()}
@@ -367,7 +367,7 @@ class NativeEngine:
         self.wait_optimizer()
         os.makedirs(save_dir, exist_ok=True)
         st = self.module.store
-        rank = dist.get_rank() if dist.is_initialized() else 0
+        rank = dist.get_rank(self.reducer.group) if dist.is_initialized() else 0
         tag = tag or 'latest'
         pick = lambda groups: {k: {g: t.cpu() for g, t in d.items() if g in groups} for k, d in (('master', st.master), ('m', st.m), ('v', st.v))}
         if rank == 0:
@@ -383,7 +383,7 @@ class NativeEngine:
         ck = torch.load(os.path.join(load_dir, f'native_engine_{tag}.pt'), map_location='cpu')
         self.global_steps = ck['global_steps']
         if 'exp' in st.master:
-            rank = dist.get_rank() if dist.is_initialized() else 0
+            rank = dist.get_rank(self.reducer.group) if dist.is_initialized() else 0
             shard = torch.load(os.path.join(load_dir, f'native_engine_{tag}_ep{rank}.pt'), map_location='cpu')
             for k in ('master', 'm', 'v'):
                 ck[k]['exp'] = shard[k]['exp']

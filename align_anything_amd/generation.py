@@ -41,9 +41,15 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
     own_new = max_new_tokens
     if ep is not None and ep.size > 1:
         import torch.distributed as dist
-        cnt = torch.tensor([max(max_new_tokens, 0)], dtype=torch.int64, device=dev if not ep.host_staged else 'cpu')
+        # one exchange decides for ALL ranks: [max, -min] of the ranks' own budgets.  A rank whose prompts already fill the length cap
+        # would return its prompts unchanged (zero generated columns) and fail in the caller's window plan while the other ranks sit
+        # in the token exchange of their first decode position -- so everybody raises, together, before any exchange
+        cnt = torch.tensor([max(max_new_tokens, 0), -max_new_tokens], dtype=torch.int64, device=dev if not ep.host_staged else 'cpu')
         dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=ep.group)
-        max_new_tokens = int(cnt.item())
+        max_new_tokens, min_new = int(cnt[0].item()), -int(cnt[1].item())
+        if min_new <= 0:
+            raise ValueError(f'generate (expert-parallel): a rank has no room for new tokens (smallest budget {min_new}, this rank {own_new}): '
+                             'prompt length >= max_length on that rank; every rank raises so that nobody waits in a collective')
     else:
         ep = None
     if max_new_tokens <= 0:

@@ -405,6 +405,14 @@ def _ep_worker(rank, world, port, q):
     both = [None] * world
     dist.all_gather_object(both, seen.count('aa_attn_decode'))              # whatever the (garbage) tokens did, the ranks stopped together
     ok = ok and len(set(both)) == 1
+    # a rank with no room for new tokens (prompt length == max_length) must not leave the others in the exchange: EVERY rank raises
+    L2 = 10 if rank == 0 else 24
+    try:
+        generate(tr.policy, T(z['input_ids'])[rows, :L2], T(z['attention_mask'])[rows, :L2], max_length=24, do_sample=False, pad_token_id=int(z['pad_token_id']))
+        raised = False
+    except ValueError:
+        raised = True
+    ok = ok and raised
     # the RL trainers' flag: a PPO trainer with train_cfgs.expert_parallel shards actor / reference / reward / critic (one communicator),
     # rolls out in lockstep and takes one rl_step (actor + critic updates; expert shards never all-reduced)
     from align_anything_amd.trainers.ppo import PPOTrainer
