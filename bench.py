@@ -179,6 +179,10 @@ def main():
                          'auto (default): measure at N=1 when rocprofv3 is on PATH, else committed.  roofline.traffic_source says which one the line carries')
     ap.add_argument('--measure-traffic', action='store_true', help='same as --traffic measure (kept for the round-2 command lines)')
     ap.add_argument('--no-per-batch', action='store_true', help='skip the B=1 / B=2 pairs-per-GPU datapoints measured after the timed region (N=1 only)')
+    ap.add_argument('--rccl-channels', type=int, default=int(os.environ.get('AA_RCCL_CHANNELS', 0)),
+                    help='N>1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS; one channel = one workgroup = one CU taken from the GEMMs while a '
+                         'gradient bucket is in flight -- a gemm4 workgroup holds all 512 registers of its CU\'s SIMDs, so RCCL and GEMM tiles never share '
+                         'a CU; DESIGN.md section 6 has the expected cost).  0 = RCCL\'s default')
     ap.add_argument('--comm-prof', action='store_true',
                     help='N>1: after the timed region run ONE extra untimed step with HIP events around every gradient bucket '
                          '(all-reduce time vs the backward it overlaps with) and add it to the JSON line as "comm"')
@@ -230,6 +234,9 @@ def main():
     device = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.rccl_channels > 0:
+            os.environ['NCCL_MAX_NCHANNELS'] = str(args.rccl_channels)
+            os.environ['NCCL_MIN_NCHANNELS'] = str(min(args.rccl_channels, int(os.environ.get('NCCL_MIN_NCHANNELS', args.rccl_channels))))
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)      # nccl == RCCL on ROCm
         else:
@@ -311,7 +318,7 @@ def main():
         allc = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allc, mine)
         same = all(bool(torch.equal(c, allc[0])) for c in allc)
-        multi = {'backend': dist.get_backend(), 'world': world, 'replicas_bit_identical_after_steps': same,
+        multi = {'backend': dist.get_backend(), 'world': world, 'rccl_max_nchannels': os.environ.get('NCCL_MAX_NCHANNELS'), 'replicas_bit_identical_after_steps': same,
                  'optimizer_updates_checked': tr.model.global_steps}
         if not same:
             print(f'[bench] rank {rank}: REPLICAS DIVERGED: {[c.tolist() for c in allc]}', file=sys.stderr, flush=True)

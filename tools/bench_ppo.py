@@ -79,6 +79,8 @@ def main():
 def bench(prompts=1, new_tokens=512, iters=2, layers=28, vision_depth=32, device='cuda:0'):
     dev = torch.device(device)
     cfg = configs.qwen2_vl_7b(layers, vision_depth)
+    torch.cuda.set_device(dev)
+    torch.zeros(1, device=dev)                                    # create the context before the memory statistics are touched
     torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
     tr = build_trainer(cfg, new_tokens, total_steps=iters + 2, device=dev)

@@ -46,6 +46,10 @@ PY
       timeout 400 python tools/bench_qwen2vl.py > gpurun_out/r03_bench_qwen2vl_7b_dpo.json 2> gpurun_out/r03_bench_qwen2vl.err; tail -c 400 gpurun_out/r03_bench_qwen2vl_7b_dpo.json
       timeout 400 python tools/bench_qwen2audio.py > gpurun_out/r03_bench_qwen2audio_7b_dpo.json 2> gpurun_out/r03_bench_qwen2audio.err; tail -c 400 gpurun_out/r03_bench_qwen2audio_7b_dpo.json
       timeout 400 python tools/bench_qwen3moe.py > gpurun_out/r03_bench_qwen3moe_12layers_dpo.json 2> gpurun_out/r03_bench_qwen3moe.err; tail -c 400 gpurun_out/r03_bench_qwen3moe_12layers_dpo.json ;;
+    ppo_smoke)
+      timeout 600 python -m pytest tests/test_qwen2vl_gpu.py -m gpu -q -p no:cacheprovider -k four_engines > gpurun_out/r03_pytest_ppo_smoke.log 2>&1; tail -5 gpurun_out/r03_pytest_ppo_smoke.log ;;
+    ppo4)
+      timeout 900 python tools/bench_ppo.py --prompts 4 > gpurun_out/r03_bench_ppo_4prompts.json 2> gpurun_out/r03_bench_ppo4.err; tail -c 1500 gpurun_out/r03_bench_ppo_4prompts.json; tail -5 gpurun_out/r03_bench_ppo4.err ;;
     ppo)
       timeout 1500 python tools/bench_ppo.py > gpurun_out/r03_bench_ppo.json 2> gpurun_out/r03_bench_ppo.err; tail -c 2500 gpurun_out/r03_bench_ppo.json; tail -5 gpurun_out/r03_bench_ppo.err ;;
     *) echo "unknown stage $stage" ;;
