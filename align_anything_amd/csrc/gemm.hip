@@ -422,11 +422,6 @@ void gemm_kernel(const GemmParams p) {
     }
 }
 
-static int g_mfma32 = -1; // 1: the one-wave-per-SIMD 256x256 tile runs on v_mfma_f32_32x32x16_bf16 (gemm5.hip) instead of 16x16x32 (gemm4.hip); -1 = env AA_GEMM_MFMA32
-bool aa_gemm_mfma32_on() {
-    if (g_mfma32 < 0) { const char* e = getenv("AA_GEMM_MFMA32"); g_mfma32 = e ? (atoi(e) != 0) : 0; }
-    return g_mfma32 != 0;
-}
 static int g_pipe = 1;  // 1: software-pipelined K loop (default), 0: simple schedule
 static int g_gm = 0;    // tile-group height of the grouped tile order; 0 = heuristic (AA_GEMM_GM / aa_gemm_set_group override)
 
@@ -553,7 +548,6 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
         p.tiles_m = aa_cdiv(p.M, 256);
         p.tiles_n = aa_cdiv(p.N, 256);
         p.gm = pick_group(a_t, b_n, p.tiles_n, p.K);
-        if (aa_gemm_mfma32_on() && !(a_t && !b_n)) return aa_gemm5_dispatch(p, a_t, b_n, st);
         return aa_gemm4_dispatch(p, a_t, b_n, st);
     }
     if (!a_t && !b_n) return launch_layout<false, false>(p, tile, st);
@@ -783,6 +777,5 @@ extern "C" int aa_gemm_glu_bwd_bf16(const void* dY, const void* Wdown, const voi
 extern "C" int aa_gemm_set_tile(int tile) { g_force_tile = tile; return AA_OK; }
 // test/bench hook: 1 = software-pipelined K loop (default), 0 = simple one-barrier schedule
 extern "C" int aa_gemm_set_interleave(int mode) { g_ilv = mode; return AA_OK; }  // -1 auto, 0 off, 1 phase A, 2 both phases (peeled)
-extern "C" int aa_gemm_set_mfma32(int on) { g_mfma32 = on < 0 ? -1 : (on ? 1 : 0); return AA_OK; }
 extern "C" int aa_gemm_set_pipeline(int on) { g_pipe = on ? 1 : 0; return AA_OK; }
 extern "C" int aa_gemm_set_group(int gm) { g_gm = gm < 0 ? 0 : gm; return AA_OK; }   // 0 = heuristic; +256 = group tile columns instead of rows

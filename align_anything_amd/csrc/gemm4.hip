@@ -631,18 +631,17 @@ int aa_gemm4_fused(GemmParams& p, hipStream_t st) {
     if (p.M % BM || p.N % BN || !aa_gemm4_supports(p.K) || (p.ldc & 7) || p.bias || p.residual || p.act != AA_ACT_NONE) return 1;
     p.tiles_m = p.M / BM;
     p.tiles_n = p.N / BN;
-    const bool m32 = aa_gemm_mfma32_on();      // the same epilogues on the 32x32x16 kernels (gemm5.hip)
     if (p.fuse == AA_FUSE_ROPE) {
         if (!p.rope_pos || !al16(p.rope_cos) || !al16(p.rope_sin) || p.rope_cols % 128 || p.rope_cols < 0 || p.rope_cols > p.N) return 1;
-        return m32 ? aa_gemm5_fused(p, st) : launch4_layout<3>(p, false, false, st);
+        return launch4_layout<3>(p, false, false, st);
     }
     if (p.fuse == AA_FUSE_GLU_FWD) {
         if (p.glu_f % 128 || p.N != 2 * p.glu_f || !p.aux || !al16(p.aux) || (p.ldaux & 7) || (p.glu_f & 7)) return 1;
-        return m32 ? aa_gemm5_fused(p, st) : launch4_layout<4>(p, false, false, st);
+        return launch4_layout<4>(p, false, false, st);
     }
     if (p.fuse == AA_FUSE_GLU_BWD) {
         if (p.N != p.glu_f || !p.aux || !p.aux_in || !al16(p.aux) || !al16(p.aux_in) || (p.ldaux & 7) || (p.ldaux_in & 7) || (p.glu_f & 7)) return 1;
-        return m32 ? aa_gemm5_fused(p, st) : launch4_layout<5>(p, false, true, st);
+        return launch4_layout<5>(p, false, true, st);
     }
     return 1;
 }

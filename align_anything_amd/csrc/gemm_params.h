@@ -1,4 +1,4 @@
-// Shared between gemm.hip (8-wave 16x16x32 MFMA kernels), gemm4.hip (one wave per SIMD, 16x16x32) and gemm5.hip (one wave per SIMD, 32x32x16).
+// Shared between gemm.hip (8-wave 16x16x32 MFMA kernels) and gemm4.hip (one wave per SIMD, 16x16x32; its 32x32x16 sibling is a recorded negative: tools/lab/gemm5).
 #pragma once
 #include "aa_common.h"
 
@@ -101,7 +101,3 @@ bool aa_gemm4_supports(int K);      // the 4-slot ring walks K in trips of 128
 int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
 // fused-epilogue launches of the same kernel (p.fuse); 1 = shape does not qualify, run the unfused kernels
 int aa_gemm4_fused(GemmParams& p, hipStream_t st);
-// the same one-wave-per-SIMD kernel on v_mfma_f32_32x32x16_bf16 (gemm5.hip; plain / residual / general epilogues)
-int aa_gemm5_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
-int aa_gemm5_fused(GemmParams& p, hipStream_t st);       // fused epilogues (p.fuse) after aa_gemm4_fused's shape checks
-bool aa_gemm_mfma32_on();                                // aa_gemm_set_mfma32 / AA_GEMM_MFMA32

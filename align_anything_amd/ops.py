@@ -242,10 +242,6 @@ def gemm_set_interleave(mode: int) -> None:
     call('aa_gemm_set_interleave', int(mode))
 
 
-def gemm_set_mfma32(on: bool) -> None:
-    call('aa_gemm_set_mfma32', int(bool(on)))
-
-
 def gemm_set_pipeline(on: bool) -> None:
     call('aa_gemm_set_pipeline', int(bool(on)))
 

@@ -596,12 +596,6 @@ def test_gemm4_kernels_keep_everything_in_registers():
     _check_ring_gemm_isa('gemm4.hip', r'gemm4(?:nt)?_kernel', 'v_mfma_f32_16x16x32_bf16', 256, 10)
 
 
-def test_gemm5_kernels_keep_everything_in_registers():
-    """The same static guarantees for the 32x32x16 variant (csrc/gemm5.hip): 4 ring steps x 32 MFMAs per trip, 256 accumulator
-    registers, no spills / scratch / register copies in the K loop, only the counted vmcnt waits."""
-    _check_ring_gemm_isa('gemm5.hip', r'gemm5(?:nt)?_kernel', 'v_mfma_f32_32x32x16_bf16', 128, 7)
-
-
 def test_attention_kernels_keep_fragments_in_registers_and_the_prefetch_in_flight():
     """csrc/attention.hip issues its transpose reads and DMA pieces as inline asm (the compiler neither tracks their completion nor orders
     them against each other).  That is only sound -- and only fast -- while (1) nothing spills: a spilled fragment register would be stored

@@ -43,13 +43,11 @@ def test_gemm_bf16_is_the_rounded_fp32_twin(layout):
             a = randn_bf16(K, M, seed=1) if a_t else randn_bf16(M, K, seed=1)
             b = randn_bf16(K, N, seed=2) if b_n else randn_bf16(N, K, seed=2)
             want = ops.gemm(a.float(), b.float(), a_t=a_t, b_n=b_n, out_f32=True)
-            for tile in (0, 5, 1, 32):                    # 32 = the one-wave-per-SIMD kernel on v_mfma_f32_32x32x16_bf16 (gemm5.hip)
-                ops.gemm_set_tile(5 if tile == 32 else tile)
-                ops.gemm_set_mfma32(tile == 32)
+            for tile in (0, 5, 1):
+                ops.gemm_set_tile(tile)
                 check(f'gemm {layout} tile{tile} {M}x{N}x{K}', ops.gemm(a, b, a_t=a_t, b_n=b_n), want, max_ulp=1.01, frac_within2=1.0)
     finally:
         ops.gemm_set_tile(-1)
-        ops.gemm_set_mfma32(False)
 
 
 def test_block_kernels_bf16_vs_fp32_twin():

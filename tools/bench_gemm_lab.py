@@ -1,7 +1,7 @@
 """Same-process A/B of GEMM kernel variants on the 12 hot 7B shapes at M = 16384 tokens (random bf16 operands), with
 torch.matmul (hipBLASLt) on the same tensors as a yardstick only.  Variants: env AA_LAB_VARIANTS = comma list of
-`name:tile[:ilv[:mfma32]]` (tile = aa_gemm_set_tile id, ilv = aa_gemm_set_interleave mode, mfma32 = 1: the one-wave-per-SIMD tile 5 on
-v_mfma_f32_32x32x16_bf16, csrc/gemm5.hip).  Writes gpurun_out/gemm_lab.json."""
+`name:tile[:ilv]` (tile = aa_gemm_set_tile id, ilv = aa_gemm_set_interleave mode; a fourth field selected the 32x32x16 kernel of tools/lab/gemm5
+while it was wired in, commit adb854f).  Writes gpurun_out/gemm_lab.json."""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from align_anything_amd import ops
@@ -17,9 +17,9 @@ def timeit(fn, iters=12, warm=2):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 variants = []
-for v in os.environ.get('AA_LAB_VARIANTS', 'g4:5,g5:5:-1:1').split(','):
+for v in os.environ.get('AA_LAB_VARIANTS', 'g8:0,g4:5').split(','):
     parts = v.split(':')
-    variants.append((parts[0], int(parts[1]), int(parts[2]) if len(parts) > 2 else -1, int(parts[3]) if len(parts) > 3 else 0))
+    variants.append((parts[0], int(parts[1]), int(parts[2]) if len(parts) > 2 else -1))
 shapes = [('qkv', 12288, 4096), ('o', 4096, 4096), ('gate_up', 22016, 4096), ('down', 4096, 11008)]
 only = os.environ.get('AA_LAB_LAYOUTS', 'nt,nn,tn').split(',')
 res = []
@@ -37,13 +37,13 @@ for name, N, K in shapes:
         rows = torch.arange(0, m, 97, device=dev)[:256]
         ref = ((a[:, rows].t() if a_t else a[rows]).float()) @ (b if b_n else b.t()).float()
         for rep in range(2):
-            for vn, tile, ilv, m32 in variants:
-                ops.gemm_set_tile(tile); ops.gemm_set_interleave(ilv); ops.gemm_set_mfma32(bool(m32))
+            for vn, tile, ilv in variants:
+                ops.gemm_set_tile(tile); ops.gemm_set_interleave(ilv)
                 ms = timeit(lambda: ops.gemm(a, b, out=out, a_t=a_t, b_n=b_n))
                 row[f'{vn}_tf_{rep}'] = round(fl / ms / 1e9, 1)
                 if rep == 0:
                     row[f'{vn}_relerr'] = round((out[rows].float() - ref).abs().max().item() / ref.abs().max().item(), 5)
-        ops.gemm_set_tile(-1); ops.gemm_set_interleave(-1); ops.gemm_set_mfma32(False)
+        ops.gemm_set_tile(-1); ops.gemm_set_interleave(-1)
         if os.environ.get('AA_LAB_BLASLT', '1') == '1':
             A = a.t() if a_t else a; B = b if b_n else b.t()
             ms = timeit(lambda: torch.matmul(A, B, out=out))
