@@ -64,7 +64,20 @@ __device__ __forceinline__ void skinny_trip(const bf16_t* __restrict__ wp, const
     }
 }
 
-template <int NWAVE, int PRO>
+// EPI: what the strip's 16 finished columns turn into (strip-major weights only, whose row ORDER inside a strip is free):
+//   0: out[m, n0 + 0..15]  (+ bias, + residual)
+//   1: SwiGLU.  The strip holds gate columns 8 s .. 8 s + 7 and the up values of the SAME columns (aa_swizzle_weights_perm_bf16 mode 1 of
+//      the fused [gate; up] weight), so the thread that owns (m, c) has both and writes act[m, 8 s + c] = bf16(bf16(silu(bf16 gate)) *
+//      bf16 up): aa_swiglu_fwd's value bit for bit, without the [M, 2F] round trip and without that kernel's launch.
+//   2: rotary embedding + KV-cache write of the new token (head_dim 128).  The strip holds d = 8 s' .. + 7 and d + 64 of one head of the
+//      fused [q | k | v] projection (mode 2), i.e. both members of every rotation pair: q heads are rotated and written to out[m, head *
+//      128 + d], k heads rotated and written to the cache slot of this position, v heads copied there -- aa_decode_rope_cache's
+//      arithmetic (bf16(bf16(x cos) + bf16(rotate_half(x) sin)) on the bf16-rounded projection) without its launch.
+struct SkinnyEpi {
+    const int* pos; const bf16_t* cos_t; const bf16_t* sin_t; bf16_t* cache; long ldc; int Tmax; const int64_t* slot; int H, Hkv;
+};
+
+template <int NWAVE, int PRO, int EPI>
 __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                   const bf16_t* __restrict__ W, long ldw,
                                                                   bf16_t* __restrict__ out, long ldo,
@@ -72,7 +85,7 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
                                                                   const bf16_t* __restrict__ residual, long ldr,
                                                                   int M, int N, int K,
                                                                   const int* __restrict__ row_expert, long strideE, int x_div,
-                                                                  const bf16_t* __restrict__ norm_w, float eps) {
+                                                                  const bf16_t* __restrict__ norm_w, float eps, const SkinnyEpi epi) {
     __shared__ float red[NWAVE][16][17];
     __shared__ float ssred[NWAVE][16];
     if (row_expert) {   // mixture-of-experts decode: blockIdx.y = routed row r = (token, choice); its own weight matrix, M = 1
@@ -117,6 +130,38 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
         if (g == 0) ssred[wave][l15] = ss;
     }
     __syncthreads();
+    if constexpr (EPI != 0) {
+        // thread t < 128 -> (m = t / 8, c = t % 8): columns c and c + 8 of the strip are a (gate, up) / (d, d + 64) pair
+        const int m = threadIdx.x >> 3, c = threadIdx.x & 7;
+        if (threadIdx.x < 128 && m < M) {
+            float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) { v1 += red[w][c][m]; v2 += red[w][c + 8][m]; }
+            if constexpr (EPI == 1) {
+                const float gf = rbf(v1), uf = rbf(v2);
+                out[(long)m * ldo + blockIdx.x * 8 + c] = f2bf(rbf(gf / (1.f + expf(-gf))) * uf);
+            } else {
+                const int head = blockIdx.x >> 3, d = (blockIdx.x & 7) * 8 + c;          // head_dim 128: 8 strips per head
+                const int col = head * 128 + d;
+                if (bias) { v1 += bf2f(bias[col]); v2 += bf2f(bias[col + 64]); }
+                const float a = rbf(v1), b = rbf(v2);
+                bf16_t* crow = epi.cache + ((long)m * epi.Tmax + epi.slot[m]) * epi.ldc;
+                if (head >= epi.H + epi.Hkv) {                                            // value head: copy into the cache
+                    bf16_t* dst = crow + (long)epi.Hkv * 128 + (long)(head - epi.H - epi.Hkv) * 128 + d;
+                    dst[0] = f2bf(a);
+                    dst[64] = f2bf(b);
+                } else {
+                    const long tb = (long)epi.pos[m] * 64 + d;
+                    const float cc = bf2f(epi.cos_t[tb]), ss = bf2f(epi.sin_t[tb]);
+                    const bf16_t o1 = f2bf(rbf(a * cc) + rbf(-b * ss)), o2 = f2bf(rbf(b * cc) + rbf(a * ss));
+                    bf16_t* dst = head < epi.H ? out + (long)m * ldo + col : crow + (long)(head - epi.H) * 128 + d;
+                    dst[0] = o1;
+                    dst[64] = o2;
+                }
+            }
+        }
+        return;
+    }
     // thread t < 256 -> (m = t / 16, n = t % 16)
     const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
     const int n = n0 + nn;
@@ -136,19 +181,20 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     }
 }
 
-template <int PRO>
+template <int PRO, int EPI = 0>
 static void launch_skinny(const void* x, const void* W, void* out, int M, int N, int K, long ldx, long ldw, long ldo,
-                          const void* bias, const void* residual, long ldr, const void* norm_w, float eps, hipStream_t st) {
+                          const void* bias, const void* residual, long ldr, const void* norm_w, float eps, hipStream_t st,
+                          const SkinnyEpi epi = SkinnyEpi{}) {
     // few column strips (N/16 < ~3 per CU): split K over 8 waves so enough loads are in flight per CU
     const bool wide = (N / 16) >= 768 || K < 2048;
     if (wide)
-        hipLaunchKernelGGL((gemm_skinny_kernel<4, PRO>), dim3(aa_cdiv(N, 16)), dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_skinny_kernel<4, PRO, EPI>), dim3(aa_cdiv(N, 16)), dim3(256), 0, st,
                            (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
-                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1, (const bf16_t*)norm_w, eps);
+                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1, (const bf16_t*)norm_w, eps, epi);
     else
-        hipLaunchKernelGGL((gemm_skinny_kernel<8, PRO>), dim3(aa_cdiv(N, 16)), dim3(512), 0, st,
+        hipLaunchKernelGGL((gemm_skinny_kernel<8, PRO, EPI>), dim3(aa_cdiv(N, 16)), dim3(512), 0, st,
                            (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
-                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1, (const bf16_t*)norm_w, eps);
+                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1, (const bf16_t*)norm_w, eps, epi);
 }
 
 extern "C" int aa_gemm_skinny_bf16(const void* x, const void* W, void* out, int M, int N, int K, long ldx,
@@ -184,14 +230,20 @@ extern "C" int aa_gemm_skinny_fused_bf16(const void* x, const void* W, void* out
 // kernel at 4.5 of 8 TB/s.  Weights do not change during a rollout (hundreds of positions per optimizer step), so `generate`
 // re-arranges them once per call into [N/16 strips][K/32 blocks][lane = n%16 + 16*(k%32/8)][8 elements]: the very order the
 // lanes consume, 1 KB contiguous per wave load.  Same operands, same MFMA order -> bit-identical results to the row-major kernel.
-__global__ __launch_bounds__(256) void swizzle_weights_kernel(const bf16_t* __restrict__ W, long ld, bf16_t* __restrict__ out, int N, int K) {
+// mode: 0 = strip s holds rows 16 s .. 16 s + 15; 1 = rows of a fused [gate; up] weight (N = 2 F): strip s = gate rows 8 s .. + 7 then the up
+// rows F + 8 s .. + 7 (EPI 1 of the strip kernel); 2 = head_dim-128 heads: strip 8 h + s' = rows 128 h + 8 s' .. + 7 then the rows 64 further
+// (the rotation partners, EPI 2)
+__global__ __launch_bounds__(256) void swizzle_weights_kernel(const bf16_t* __restrict__ W, long ld, bf16_t* __restrict__ out, int N, int K, int mode) {
     const long kblocks = K >> 5;
     const long total = (long)((N + 15) >> 4) * kblocks * 64;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int lane = (int)(idx & 63);
         const long t = idx >> 6;
         const long kb = t % kblocks, strip = t / kblocks;
-        const long n = strip * 16 + (lane & 15);
+        const int c = lane & 15;
+        long n = strip * 16 + c;
+        if (mode == 1) n = (c < 8 ? 0 : (long)(N >> 1)) + strip * 8 + (c & 7);
+        else if (mode == 2) n = (strip >> 3) * 128 + (strip & 7) * 8 + (c & 7) + (c < 8 ? 0 : 64);
         const long k = kb * 32 + (lane >> 4) * 8;
         u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (n < N) v = *reinterpret_cast<const u16x8*>(W + n * ld + k);
@@ -202,8 +254,20 @@ extern "C" int aa_swizzle_weights_bf16(const void* W, long ld, void* out, int N,
     AA_REQUIRE(N > 0 && K > 0 && K % 32 == 0 && ld % 8 == 0, "aa_swizzle_weights_bf16: N=%d K=%d ld=%ld (K %% 32 == 0, ld %% 8 == 0)", N, K, ld);
     const long total = (long)((N + 15) >> 4) * (K >> 5) * 64;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(swizzle_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K);
+    hipLaunchKernelGGL(swizzle_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K, 0);
     AA_CHECK_LAUNCH("aa_swizzle_weights_bf16");
+    return AA_OK;
+}
+// The same re-arrangement with the rows of a strip permuted for a fused epilogue of the strip kernel: mode 1 = [gate; up] weight of a SwiGLU
+// MLP (N = 2 F, F a multiple of 8) for aa_gemm_skinny_swz_glu_bf16, mode 2 = fused [q | k | v] projection with head_dim 128 (N a multiple of
+// 128) for aa_gemm_skinny_swz_rope_cache_bf16.
+extern "C" int aa_swizzle_weights_perm_bf16(const void* W, long ld, void* out, int N, int K, int mode, void* stream) {
+    AA_REQUIRE(N > 0 && K > 0 && K % 32 == 0 && ld % 8 == 0, "aa_swizzle_weights_perm_bf16: N=%d K=%d ld=%ld (K %% 32 == 0, ld %% 8 == 0)", N, K, ld);
+    AA_REQUIRE((mode == 1 && N % 16 == 0) || (mode == 2 && N % 128 == 0), "aa_swizzle_weights_perm_bf16: mode %d needs N=%d a multiple of %d", mode, N, mode == 1 ? 16 : 128);
+    const long total = (long)(N >> 4) * (K >> 5) * 64;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(swizzle_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K, mode);
+    AA_CHECK_LAUNCH("aa_swizzle_weights_perm_bf16");
     return AA_OK;
 }
 extern "C" int aa_gemm_skinny_swz_bf16(const void* x, const void* Wswz, void* out, int M, int N, int K, long ldx, long ldo,
@@ -215,6 +279,30 @@ extern "C" int aa_gemm_skinny_swz_bf16(const void* x, const void* Wswz, void* ou
     return AA_OK;
 }
 
+// hf LlamaMLP front half of a decode position in one launch: act[M, F] = silu(x Wg^T) * (x Wu^T) from the mode-1 strip-major copy of the
+// fused [gate; up] weight -- bit-identical to aa_gemm_skinny_swz_bf16 followed by aa_swiglu_fwd.
+extern "C" int aa_gemm_skinny_swz_glu_bf16(const void* x, const void* Wswz, void* act, int M, int F, int K, long ldx, long ldo, void* stream) {
+    AA_REQUIRE(M >= 1 && M <= 16, "aa_gemm_skinny_swz_glu_bf16: M=%d must be in [1, 16]", M);
+    AA_REQUIRE(F > 0 && F % 8 == 0 && K > 0 && K % 32 == 0 && ldx % 8 == 0, "aa_gemm_skinny_swz_glu_bf16: F=%d (multiple of 8) K=%d (multiple of 32)", F, K);
+    launch_skinny<3, 1>(x, Wswz, act, M, 2 * F, K, ldx, K, ldo, nullptr, nullptr, 0, nullptr, 0.f, (hipStream_t)stream);
+    AA_CHECK_LAUNCH("aa_gemm_skinny_swz_glu_bf16");
+    return AA_OK;
+}
+// q/k/v projection of a decode position with aa_decode_rope_cache in its epilogue (head_dim 128): q[M, H * 128] rotated, k rotated into and v
+// copied into cache slot `slot[m]` of sequence m (cache rows [M * Tmax, ldc] = keys | values), from the mode-2 strip-major copy of the
+// fused weight; bias = the fused [q | k | v] bias or null.  Bit-identical to aa_gemm_skinny_swz_bf16 + aa_decode_rope_cache.
+extern "C" int aa_gemm_skinny_swz_rope_cache_bf16(const void* x, const void* Wswz, void* q_out, int M, int H, int Hkv, int K, long ldx, long ldq,
+                                                  const void* bias, const int* pos, const void* cos_t, const void* sin_t, void* cache, long ldc,
+                                                  int Tmax, const int64_t* slot, void* stream) {
+    AA_REQUIRE(M >= 1 && M <= 16, "aa_gemm_skinny_swz_rope_cache_bf16: M=%d must be in [1, 16]", M);
+    AA_REQUIRE(H > 0 && Hkv > 0 && K > 0 && K % 32 == 0 && ldx % 8 == 0, "aa_gemm_skinny_swz_rope_cache_bf16: H=%d Hkv=%d K=%d (multiple of 32)", H, Hkv, K);
+    AA_REQUIRE(ldc >= 2L * Hkv * 128 && Tmax > 0 && ldq >= (long)H * 128, "aa_gemm_skinny_swz_rope_cache_bf16: ldc >= 2 * Hkv * 128, ldq >= H * 128");
+    SkinnyEpi e{pos, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)cache, ldc, Tmax, slot, H, Hkv};
+    launch_skinny<3, 2>(x, Wswz, q_out, M, (H + 2 * Hkv) * 128, K, ldx, K, ldq, bias, nullptr, 0, nullptr, 0.f, (hipStream_t)stream, e);
+    AA_CHECK_LAUNCH("aa_gemm_skinny_swz_rope_cache_bf16");
+    return AA_OK;
+}
+
 // Mixture-of-experts decode: out[r, :] = x[r / x_div, :] W3[row_expert[r]]^T for R routed rows (a handful of tokens x top-k):
 // every routed row streams its own expert matrix once (the floor for a row-private weight), no padding to the 128-row
 // tiles of the grouped training GEMM.  hf:models/qwen3_moe/modeling_qwen3_moe.py:210-283 at one token per sequence.
@@ -222,9 +310,9 @@ extern "C" int aa_moe_gemv_bf16(const void* x, const void* W3, void* out, int R,
                                 const int* row_expert, long strideE, int x_div, void* stream) {
     AA_REQUIRE(R >= 1 && R <= 65535 && N > 0 && K > 0 && K % 32 == 0, "aa_moe_gemv_bf16: R=%d N=%d K=%d (K must be a multiple of 32)", R, N, K);
     AA_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && strideE % 8 == 0 && x_div >= 1 && row_expert != nullptr, "aa_moe_gemv_bf16: ldx/ldw/strideE must be multiples of 8");
-    hipLaunchKernelGGL((gemm_skinny_kernel<4, 0>), dim3(aa_cdiv(N, 16), R), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((gemm_skinny_kernel<4, 0, 0>), dim3(aa_cdiv(N, 16), R), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x, ldx, (const bf16_t*)W3, ldw, (bf16_t*)out, ldo, (const bf16_t*)nullptr,
-                       (const bf16_t*)nullptr, 0, 1, N, K, row_expert, strideE, x_div, (const bf16_t*)nullptr, 0.f);
+                       (const bf16_t*)nullptr, 0, 1, N, K, row_expert, strideE, x_div, (const bf16_t*)nullptr, 0.f, SkinnyEpi{});
     AA_CHECK_LAUNCH("aa_moe_gemv_bf16");
     return AA_OK;
 }

@@ -158,8 +158,14 @@ class LlamaStack:
             return None
         # the storage persists between rollouts (same sizes every time: no allocator churn of a second copy of the model per
         # `generate`); every call refreshes it from the current weights -- one pass over the matrices, ~5 ms at 7B
+        # AA_DECODE_EPI=0: plain copies + the separate SwiGLU / RoPE+cache kernels (A/B and bit-identity tests); default: the copies of gate_up
+        # and (head_dim 128) qkv are row-permuted inside their strips so the strip kernel finishes those two kernels in its epilogue
+        epi = os.environ.get('AA_DECODE_EPI', '1') != '0'
+        modes = {'qkv': 'rope128' if (epi and self.cfg['head_dim'] == 128) else 'plain', 'o': 'plain', 'gu': 'glu' if epi else 'plain', 'down': 'plain'}
+        if getattr(self, '_dw', None) is not None and any(W[k].mode != modes[k] for W in self._dw[:1] for k in modes):
+            self._dw = None
         if getattr(self, '_dw', None) is None:
-            self._dw = [{k: ops.SwizzledWeight(L[k].w) for k in ('qkv', 'o', 'gu', 'down')} for L in self.layers]
+            self._dw = [{k: ops.SwizzledWeight(L[k].w, modes[k]) for k in ('qkv', 'o', 'gu', 'down')} for L in self.layers]
         else:
             for L, W in zip(self.layers, self._dw):
                 for k, sw in W.items():
@@ -185,12 +191,18 @@ class LlamaStack:
             cl = cache[li]
             if dw is not None:       # strip-major weight copies: the element-wise kernels run on their own
                 W = dw[li]
-                qkv = ops.linear_small(ops.rmsnorm_fwd(x, P[L['ln1']], eps)[0], W['qkv'], bias=L['qkv'].b)
-                ops.decode_rope_cache(qkv, H, Hkv, hd, pos, self.cos, self.sin, cl, Tmax, t)
-                attn = ops.attn_decode(qkv[:, :qw], cl, cl[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
+                n1 = ops.rmsnorm_fwd(x, P[L['ln1']], eps)[0]
+                if W['qkv'].mode == 'rope128':      # q/k/v GEMV + RoPE + cache write in one launch
+                    q = ops.gemm_skinny_rope_cache(n1, W['qkv'], L['qkv'].b, H, Hkv, pos, self.cos, self.sin, cl, Tmax, t)
+                else:
+                    qkv = ops.linear_small(n1, W['qkv'], bias=L['qkv'].b)
+                    ops.decode_rope_cache(qkv, H, Hkv, hd, pos, self.cos, self.sin, cl, Tmax, t)
+                    q = qkv[:, :qw]
+                attn = ops.attn_decode(q, cl, cl[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
                 x_mid = ops.linear_small(attn, W['o'], residual=x)
-                gu = ops.linear_small(ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)[0], W['gu'])
-                x = ops.linear_small(ops.swiglu_fwd(gu), W['down'], residual=x_mid)
+                n2 = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)[0]
+                act = ops.gemm_skinny_glu(n2, W['gu']) if W['gu'].mode == 'glu' else ops.swiglu_fwd(ops.linear_small(n2, W['gu']))
+                x = ops.linear_small(act, W['down'], residual=x_mid)
                 continue
             qkv = ops.linear_small(x, L['qkv'].w, bias=L['qkv'].b, norm=(P[L['ln1']], eps))
             ops.decode_rope_cache(qkv, H, Hkv, hd, pos, self.cos, self.sin, cl, Tmax, t)   # t: device int64 [N] (graph-capturable)

@@ -813,12 +813,17 @@ DECODE_FUSED = os.environ.get('AA_DECODE_FUSED', '0') == '1'
 
 
 class SwizzledWeight:
-    """A [N, K] bf16 matrix re-arranged by aa_swizzle_weights_bf16 for the rollout's strip kernel (1 KB contiguous per wave load)."""
+    """A [N, K] bf16 matrix re-arranged by aa_swizzle_weights_bf16 for the rollout's strip kernel (1 KB contiguous per wave load).
+    mode 'glu' / 'rope128' additionally permutes the rows inside every strip so that the strip kernel can finish the element-wise kernel
+    that follows the projection in its epilogue (aa_swizzle_weights_perm_bf16: [gate; up] pairs / rotation pairs of head_dim-128 heads)."""
+    MODES = {'plain': 0, 'glu': 1, 'rope128': 2}
 
-    def __init__(self, w):
+    def __init__(self, w, mode='plain'):
         if w.dim() != 2 or w.dtype != bf16 or w.stride(1) != 1 or w.shape[1] % 32:
             raise RuntimeError(f'SwizzledWeight: expected a row-major bf16 [N, K] matrix with K % 32 == 0, got {tuple(w.shape)} {w.dtype}')
-        self.N, self.K = int(w.shape[0]), int(w.shape[1])
+        self.N, self.K, self.mode = int(w.shape[0]), int(w.shape[1]), mode
+        if (mode == 'glu' and self.N % 16) or (mode == 'rope128' and self.N % 128) or mode not in self.MODES:
+            raise RuntimeError(f'SwizzledWeight: mode {mode!r} does not fit N = {self.N}')
         self.data = torch.empty(((self.N + 15) // 16) * 16 * self.K, dtype=bf16, device=w.device)
         self.update(w)
 
@@ -826,12 +831,40 @@ class SwizzledWeight:
         """Re-arrange the current values of `w` into the existing storage (the weights moved since the last rollout)."""
         if tuple(w.shape) != (self.N, self.K) or w.dtype != bf16 or w.stride(1) != 1:
             raise RuntimeError(f'SwizzledWeight.update: expected bf16 {(self.N, self.K)}, got {tuple(w.shape)} {w.dtype}')
-        call('aa_swizzle_weights_bf16', w.data_ptr(), w.stride(0), self.data.data_ptr(), self.N, self.K, stream())
+        if self.mode == 'plain':
+            call('aa_swizzle_weights_bf16', w.data_ptr(), w.stride(0), self.data.data_ptr(), self.N, self.K, stream())
+        else:
+            call('aa_swizzle_weights_perm_bf16', w.data_ptr(), w.stride(0), self.data.data_ptr(), self.N, self.K, self.MODES[self.mode], stream())
         return self
 
     @property
     def shape(self):
         return (self.N, self.K)
+
+
+def gemm_skinny_glu(x, w):
+    """act [M, F] = silu(x Wg^T) * (x Wu^T) of a decode position from the 'glu' strip-major copy of the fused [gate; up] weight: the GEMV and
+    aa_swiglu_fwd in one launch (bit-identical to the pair)."""
+    if not isinstance(w, SwizzledWeight) or w.mode != 'glu' or x.shape[0] > 16 or x.shape[1] != w.K or x.dtype != bf16:
+        raise RuntimeError('gemm_skinny_glu: needs a SwizzledWeight(mode="glu"), M <= 16 bf16 rows of width K')
+    M, F = x.shape[0], w.N // 2
+    act = torch.empty((M, F), dtype=bf16, device=x.device)
+    call('aa_gemm_skinny_swz_glu_bf16', x.data_ptr(), w.data.data_ptr(), act.data_ptr(), M, F, w.K, x.stride(0), act.stride(0), stream())
+    return act
+
+
+def gemm_skinny_rope_cache(x, w, bias, H, Hkv, pos, cos_t, sin_t, cache, Tmax, slot):
+    """q [M, H * 128] (rotated) of a decode position; the rotated k heads and the v heads go straight into cache slot `slot[m]`: the q/k/v GEMV
+    and aa_decode_rope_cache in one launch, from the 'rope128' strip-major copy of the fused projection (bit-identical to the pair)."""
+    if not isinstance(w, SwizzledWeight) or w.mode != 'rope128' or x.shape[0] > 16 or x.shape[1] != w.K or w.N != (H + 2 * Hkv) * 128:
+        raise RuntimeError('gemm_skinny_rope_cache: needs a SwizzledWeight(mode="rope128") of (H + 2 Hkv) * 128 rows, M <= 16 rows of width K')
+    if cos_t.dtype != bf16 or x.dtype != bf16 or cache.dtype != bf16 or slot.dtype != torch.int64 or pos.dtype != torch.int32:
+        raise RuntimeError('gemm_skinny_rope_cache: bf16 activations / tables / cache, int32 pos, int64 slot')
+    M = x.shape[0]
+    q = torch.empty((M, H * 128), dtype=bf16, device=x.device)
+    call('aa_gemm_skinny_swz_rope_cache_bf16', x.data_ptr(), w.data.data_ptr(), q.data_ptr(), M, int(H), int(Hkv), w.K, x.stride(0), q.stride(0), _p(bias),
+         pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), cache.data_ptr(), cache.stride(0), int(Tmax), slot.data_ptr(), stream())
+    return q
 
 
 def linear_small(x, w, bias=None, residual=None, out=None, norm=None, swiglu=False):
@@ -848,8 +881,8 @@ def linear_small(x, w, bias=None, residual=None, out=None, norm=None, swiglu=Fal
         norm, swiglu = None, False
     K = x.shape[1] // 2 if swiglu else x.shape[1]
     if isinstance(w, SwizzledWeight):
-        if M > 16 or norm is not None or swiglu:
-            raise RuntimeError('linear_small: swizzled weights serve the plain M <= 16 strip kernel only')
+        if M > 16 or norm is not None or swiglu or w.mode != 'plain':
+            raise RuntimeError('linear_small: plain swizzled weights serve the M <= 16 strip kernel only (glu / rope128 copies have their own entry points)')
         if w.K != K:
             raise RuntimeError(f'linear_small: weight {w.shape} does not match K = {K}')
         out = torch.empty((M, N), dtype=bf16, device=x.device) if out is None else out

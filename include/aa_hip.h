@@ -279,6 +279,17 @@ int aa_gemm_skinny_fused_bf16(const void* x, const void* W, void* out, int M, in
 int aa_swizzle_weights_bf16(const void* W, long ld, void* out, int N, int K, void* stream);
 int aa_gemm_skinny_swz_bf16(const void* x, const void* Wswz, void* out, int M, int N, int K, long ldx, long ldo, const void* bias,
                             const void* residual, long ldr, void* stream);
+/* The strip kernel with the element-wise kernel that FOLLOWS it in a decode position folded into its epilogue -- possible because the row order
+ * inside a strip of the rollout-only weight copy is free (aa_swizzle_weights_perm_bf16): mode 1 puts gate column c and the up value of the same
+ * column into one strip of the fused [gate; up] weight (aa_gemm_skinny_swz_glu_bf16 = GEMV + aa_swiglu_fwd, hf LlamaMLP :163-176), mode 2 both
+ * members d / d + 64 of every rotation pair of a head_dim-128 head of the fused [q | k | v] weight (aa_gemm_skinny_swz_rope_cache_bf16 = GEMV +
+ * aa_decode_rope_cache: q rotated into q_out, k rotated into / v copied into the KV-cache slot of the position).  Bit-identical to the unfused
+ * pairs (tests/test_decode_gpu.py); two launches and two small round trips less per layer and position. */
+int aa_swizzle_weights_perm_bf16(const void* W, long ld, void* out, int N, int K, int mode, void* stream);
+int aa_gemm_skinny_swz_glu_bf16(const void* x, const void* Wswz, void* act, int M, int F, int K, long ldx, long ldo, void* stream);
+int aa_gemm_skinny_swz_rope_cache_bf16(const void* x, const void* Wswz, void* q_out, int M, int H, int Hkv, int K, long ldx, long ldq,
+                                       const void* bias, const int* pos, const void* cos_t, const void* sin_t, void* cache, long ldc, int Tmax,
+                                       const int64_t* slot, void* stream);
 /* new token of every sequence: rotate the q heads of the fused [q|k|v] row in place (aa_rope_inplace rounding), rotate the k heads
  * into cache[(n*Tmax + slot[n]), 0:Hkv*hd] and copy the v heads to [.., Hkv*hd:2*Hkv*hd] (HF DynamicCache.update) */
 int aa_decode_rope_cache(void* qkv, long ld, int N, int H, int Hkv, int hd, const int* pos, const void* cos_t, const void* sin_t,

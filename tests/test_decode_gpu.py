@@ -284,3 +284,60 @@ def test_generate_replaying_a_hipgraph_gives_the_same_tokens():
                 outs.append(generate(m, ids, mask, do_sample=sample, temperature=0.9, top_p=0.8, generator=g, use_graph=ug, **kw))
                 assert generate.last_used_graph == ug, (fixture, sample, ug)
             assert torch.equal(outs[0], outs[1]), (fixture, sample)
+
+
+@pytest.mark.parametrize('M', [1, 4, 16])
+def test_strip_kernel_fused_epilogues_are_bit_identical_to_the_kernel_pairs(M):
+    """Round 3: the rollout's strip kernel finishes the element-wise kernel that follows the projection in its epilogue, made possible by
+    permuting the rows inside every strip of the rollout-only weight copy (aa_swizzle_weights_perm_bf16):
+      * [gate; up] weight, mode 'glu': aa_gemm_skinny_swz_glu_bf16 == aa_gemm_skinny_swz_bf16 + aa_swiglu_fwd (hf LlamaMLP :163-176);
+      * fused [q | k | v] weight with head_dim 128, mode 'rope128': aa_gemm_skinny_swz_rope_cache_bf16 == GEMV (+ bias) + aa_decode_rope_cache
+        (q rotated, k rotated into / v copied into the KV-cache slot of the position) -- with and without the Qwen2 q/k/v bias, MHA and GQA.
+    Same operands, same MFMA order, same rounding points -> every bit."""
+    from align_anything_amd import ops
+    from align_anything_amd.modeling import rope_tables
+    for (F, K) in [(64, 128), (11008, 4096), (18944, 3584)]:
+        x, wgu = randn_bf16(M, K, seed=1), randn_bf16(2 * F, K, scale=0.05, seed=2)
+        want = ops.swiglu_fwd(ops.linear_small(x, ops.SwizzledWeight(wgu)))
+        got = ops.gemm_skinny_glu(x, ops.SwizzledWeight(wgu, 'glu'))
+        assert got.shape == (M, F) and torch.equal(got, want), (M, F, K, float((got.float() - want.float()).abs().max()))
+    for (H, Hkv, K, with_bias, Tmax) in [(4, 4, 256, False, 9), (32, 32, 4096, False, 40), (28, 4, 3584, True, 33)]:
+        hd, kw = 128, Hkv * 128
+        x, w = randn_bf16(M, K, seed=3), randn_bf16((H + 2 * Hkv) * hd, K, scale=0.05, seed=4)
+        bias = randn_bf16((H + 2 * Hkv) * hd, seed=5) if with_bias else None
+        cos, sin = rope_tables(64, hd, 1000000.0, dev(), torch.bfloat16)
+        pos = torch.randint(0, 64, (M,), generator=torch.Generator().manual_seed(6)).to(torch.int32).to(dev())
+        slot = torch.randint(0, Tmax, (M,), generator=torch.Generator().manual_seed(7)).to(dev())
+        ca = randn_bf16(M * Tmax, 2 * kw, seed=8)
+        cb = ca.clone()
+        qkv = ops.linear_small(x, ops.SwizzledWeight(w), bias=bias)
+        ops.decode_rope_cache(qkv, H, Hkv, hd, pos, cos, sin, ca, Tmax, slot)
+        q = ops.gemm_skinny_rope_cache(x, ops.SwizzledWeight(w, 'rope128'), bias, H, Hkv, pos, cos, sin, cb, Tmax, slot)
+        assert torch.equal(q, qkv[:, :H * hd]), (M, H, Hkv, 'q')
+        assert torch.equal(ca, cb), (M, H, Hkv, 'cache')
+
+
+def test_generate_with_and_without_the_fused_decode_epilogues_gives_the_same_tokens(monkeypatch):
+    """The whole rollout with the epilogue fusions on (default) and off (AA_DECODE_EPI=0): identical sequences, greedy and sampled, on a Llama-family
+    stack with head_dim 128 (q/k/v bias, GQA) -- the path tools/bench_ppo.py times."""
+    from align_anything_amd import configs
+    from align_anything_amd.generation import generate
+    from align_anything_amd.modeling import build_model
+    from bench import random_init_
+    text = configs.llama_cfg(512, 1024, 2, 4, 2, 1000, rms_eps=1e-6, rope_theta=1000000.0, head_dim=128, max_position_embeddings=256, attention_bias=True)
+    m = build_model(text, 'cuda:0', trainable=False)
+    random_init_(m, seed=3, std=0.05)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(3, 1000, (3, 20), generator=g).to(dev())
+    mask = torch.ones_like(ids)
+    mask[1, :4] = 0
+    outs = []
+    for epi in ('1', '0'):
+        monkeypatch.setenv('AA_DECODE_EPI', epi)
+        greedy = generate(m, ids, mask, max_new_tokens=12, do_sample=False, pad_token_id=0)
+        sampled = generate(m, ids, mask, max_new_tokens=12, do_sample=True, temperature=0.8, top_p=0.9, pad_token_id=0,
+                           generator=torch.Generator(device=dev()).manual_seed(5))
+        modes = {k: v.mode for k, v in m.stack._dw[0].items()}
+        assert modes == ({'qkv': 'rope128', 'o': 'plain', 'gu': 'glu', 'down': 'plain'} if epi == '1' else dict.fromkeys(('qkv', 'o', 'gu', 'down'), 'plain'))
+        outs.append((greedy.cpu(), sampled.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
