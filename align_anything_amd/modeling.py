@@ -1577,8 +1577,6 @@ class Qwen3MoeStack:
             if tr:
                 L['q'].dw(dq, n1); L['k'].dw(dk, n1); L['v'].dw(dv, n1)
             ops.rmsnorm_bwd(d_n1, x, P[L['ln1']], rstd1, G.get(L['ln1']) if tr else None, dx=dres, add_to_dx=True)
-            if side is not None:
-                main.wait_stream(side)             # every weight gradient of the layer is complete before its bucket is reduced / the next layer reuses buffers
             if on_layer_done is not None:
                 on_layer_done(L)
         self.saved = []
