@@ -224,26 +224,6 @@ class LlamaStack:
         H, Hkv, hd = c['num_heads'], c['num_kv_heads'], c['head_dim']
         qw, kw = H * hd, Hkv * hd
         tr = self.trainable
-        # AA_DW_STREAM=1 (experiment, off): the two MLP weight-gradient GEMMs whose tile counts leave a ragged last round (down dW 688 tiles =
-        # 2.7 rounds of 256, gate_up dW 1376 = 5.4) run on a side stream beside the dX GEMMs that follow, so their tails are filled by the
-        # other kernel's tiles instead of idling ~10 % of a round.  Nothing downstream in the layer reads a weight gradient; `dres` is updated
-        # in place by the RMSNorm backward, so the down dW (which reads it) is joined before that.
-        side = None
-        if tr and dres.is_cuda and os.environ.get('AA_DW_STREAM', '0') == '1':
-            if getattr(self, '_dw_stream', None) is None:
-                self._dw_stream = torch.cuda.Stream()
-            side = self._dw_stream
-        main = torch.cuda.current_stream() if side is not None else None
-
-        def dw_on_side(lin, dy, xin):
-            ev = torch.cuda.Event()
-            ev.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                lin.dw(dy, xin)
-            dy.record_stream(side)
-            xin.record_stream(side)
-
         for L, sv in zip(reversed(self.layers), reversed(self.saved)):
             x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act = sv
             sv = None
@@ -253,18 +233,10 @@ class LlamaStack:
             else:
                 d_gu = ops.swiglu_bwd(gu, L['down'].dx(dres))
             if tr:
-                if side is not None:
-                    dw_on_side(L['down'], dres, act)
-                else:
-                    L['down'].dw(dres, act)
+                L['down'].dw(dres, act)
             d_n2 = L['gu'].dx(d_gu)
-            if side is not None:
-                main.wait_stream(side)             # the down dW has read dres
             if tr:
-                if side is not None:
-                    dw_on_side(L['gu'], d_gu, n2)
-                else:
-                    L['gu'].dw(d_gu, n2)
+                L['gu'].dw(d_gu, n2)
             ops.rmsnorm_bwd(d_n2, x_mid, P[L['ln2']], rstd2, G.get(L['ln2']) if tr else None, dx=dres, add_to_dx=True)
             # ---- attention
             d_attn = L['o'].dx(dres)
@@ -279,8 +251,6 @@ class LlamaStack:
             if tr:
                 L['qkv'].dw(d_qkv, n1)
             ops.rmsnorm_bwd(d_n1, x, P[L['ln1']], rstd1, G.get(L['ln1']) if tr else None, dx=dres, add_to_dx=True)
-            if side is not None:
-                main.wait_stream(side)             # every weight gradient of the layer is complete before its bucket is reduced / the next layer reuses buffers
             if on_layer_done is not None:
                 on_layer_done(L)
         self.saved = []

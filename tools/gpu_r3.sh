@@ -34,11 +34,6 @@ for stage in "$@"; do
       AA_DECODE_EPI=0 timeout 600 python tools/bench_ppo.py > gpurun_out/r03_bench_ppo_epi0.json 2> gpurun_out/r03_bench_ppo_epi0.err; python -c "import json; d=json.load(open('gpurun_out/r03_bench_ppo_epi0.json')); print('EPI=0', d['iteration_ms'], d['decode_ms_per_position'], d['split_ms'])"
       timeout 600 python tools/bench_ppo.py > gpurun_out/r03_bench_ppo_epi1.json 2> gpurun_out/r03_bench_ppo_epi1.err; python -c "import json; d=json.load(open('gpurun_out/r03_bench_ppo_epi1.json')); print('EPI=1', d['iteration_ms'], d['decode_ms_per_position'], d['split_ms'])"
       timeout 600 python tools/bench_decode.py > gpurun_out/r03_bench_decode_7b.json 2> gpurun_out/r03_bench_decode.err; tail -c 1200 gpurun_out/r03_bench_decode_7b.json ;;
-    dw_ab)       # weight-gradient GEMMs of the MLP on a side stream (AA_DW_STREAM=1) vs in order, same box, twice each
-      for rep in 1 2; do for v in 0 1; do
-        AA_DW_STREAM=$v timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r03_bench_dw$v.json 2> gpurun_out/r03_bench_dw$v.err
-        python -c "import json; d=json.load(open('gpurun_out/r03_bench_dw$v.json')); print('AA_DW_STREAM=$v rep $rep', round(d['ms_per_step'],2), round(d['value'],4), d['config']['losses_timed_steps'][:3])"
-      done; done ;;
     ppo_prof)    # kernel trace of one PPO iteration (decode kernel split at the Qwen2-VL-7B geometry)
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r03_ppo_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03_ppo_prof -o p -- python $R/tools/bench_ppo.py --iters 1 --new-tokens 256 > $R/gpurun_out/r03_bench_ppo_under_rocprof.json 2> $R/gpurun_out/r03_ppo_prof.err )
       f=$(find gpurun_out/r03_ppo_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r03_ppo_kernel_stats.csv && head -22 "$f" | cut -c1-260
