@@ -416,3 +416,74 @@ def test_whisper_front_end_and_encoder_layer_at_128_mel_3000_frames():
         del m
         _free()
     dump('parity_whisper_front_end_128x3000.txt', '\n'.join(rep) + '\n')
+
+
+def test_full_depth_llava_7b_bf16_step_vs_fp32_twin():
+    """VERDICT r2 weak #1, last sentence: "with 32 layers the sum-logp noise grows; nobody has measured the bf16 loss deviation of the full-depth
+    model against anything".  The WHOLE benchmarked model (CLIP-L tower + projector + 32 x 4096-wide layers + lm_head, configs[1]) runs one
+    DPO pair at T = 2048 (576 image tokens, response 512) through the bf16 production kernels and through the fp32 twin kernels on identical
+    bf16-valued weights (the twin holds 6.76 B trainable fp32 parameters + fp32 gradients + reference + fp32 activations: ~170 GB, one device).
+    Reported: loss, reward margin, summed log-probs, per-token log-probs; gradients of six tensors spread over the depth with the DPO scalar
+    factored out (see the one-layer test above).  Bounds are set from the first hardware run with ~2 x headroom."""
+    import math
+    from align_anything_amd import configs
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    from bench import make_batch
+    cfg = configs.llava_1_5_7b()
+    beta, T_, R = 0.1, 2048, 512
+    picks = ['model.language_model.layers.0.self_attn.q_proj.weight', 'model.language_model.layers.0.mlp.down_proj.weight',
+             'model.language_model.layers.15.mlp.gate_proj.weight', 'model.language_model.layers.31.self_attn.o_proj.weight',
+             'model.language_model.layers.31.mlp.down_proj.weight', 'lm_head.weight', 'model.language_model.norm.weight',
+             'model.multi_modal_projector.linear_2.weight']
+    res = {}
+    for dtype in ('fp32', 'bf16'):
+        tr = DPOTrainer(_dpo_cfgs(cfg['pad_token_id'], dtype, beta), {'gradient_clipping': 1.0}, model_cfg=cfg, device='cuda:0')
+        for mod, seed, eps in ((tr.policy, 42, 0.0), (tr.reference, 42, 0.002)):
+            g = torch.Generator(device=dev()).manual_seed(seed)
+            g2 = torch.Generator(device=dev()).manual_seed(seed + 1)
+            st = mod.store
+            for name, sp in st.specs.items():                    # the same bf16-valued numbers whatever the model's dtype
+                p_ = st.p[name]
+                if len(sp['shape']) >= 2:
+                    v = torch.empty(p_.shape, dtype=torch.float32, device=dev()).normal_(0.0, 0.02, generator=g)
+                    if eps:
+                        v += eps * torch.empty(p_.shape, dtype=torch.float32, device=dev()).normal_(0.0, 1.0, generator=g2)
+                    p_.copy_(v.to(torch.bfloat16))
+                    del v
+                elif 'norm' in name and name.endswith('weight'):
+                    p_.fill_(1.0)
+                else:
+                    p_.zero_()
+            if 'model.vision_tower.embeddings.patch_embedding.weight' in st.p:
+                st.p['model.vision_tower.embeddings.patch_embedding.weight'][:, 588:].zero_()
+            if hasattr(mod, 'vision') and hasattr(mod.vision, 'invalidate'):
+                mod.vision.invalidate()
+        for gname in tr.policy.store.master:
+            if tr.policy.store.master[gname] is not tr.policy.store.flat[gname]:
+                tr.policy.store.master[gname].copy_(tr.policy.store.flat[gname])
+        batch = make_batch(cfg, 1, T_, R, dev(), seed=77)
+        lp = tr.compute_log_probs(tr.model, batch).cpu()
+        ld = tr.loss(batch)
+        tr.model.backward(ld['loss'])
+        torch.cuda.synchronize()
+        grads = {k: tr.policy.store.grad_view(k).float().cpu() for k in picks}
+        res[dtype] = (lp, float(ld['loss']), float(ld['reward_margin']), grads)
+        del tr, batch, ld
+        _free()
+    (lp32, l32, m32, g32), (lp16, l16, m16, g16) = res['fp32'], res['bf16']
+    s16, s32 = beta / (1 + math.exp(m16)), beta / (1 + math.exp(m32))
+    ratio = s16 / s32
+    e_lp = float(((lp16 - lp32).abs() / (5e-2 + 2e-2 * lp32.abs())).max())
+    rep = [f'full depth (32 layers + CLIP tower), one pair, T = 2048: loss bf16 {l16:.6f} vs fp32 twin {l32:.6f} (|d| {abs(l16 - l32):.2e}); reward margin {m16:.5f} vs {m32:.5f}',
+           f'summed response log-probs: chosen {float(lp16[0].sum()):.3f} vs {float(lp32[0].sum()):.3f}, rejected {float(lp16[1].sum()):.3f} vs {float(lp32[1].sum()):.3f}; '
+           f'per-token max |d| {float((lp16 - lp32).abs().max()):.3e} ({e_lp:.2f} of the bound 5e-2 + 2e-2 |logp|), rms {float((lp16 - lp32).pow(2).mean().sqrt()):.3e}',
+           f'DPO scalar ratio s_bf16 / s_twin = {ratio:.5f}']
+    worst_a, worst_r = 0.0, 0.0
+    for k in picks:
+        a, resid = _scaled_fit(g16[k], g32[k])
+        worst_a, worst_r = max(worst_a, abs(a / ratio - 1)), max(worst_r, resid)
+        rep.append(f'  grad {k}: alpha / ratio - 1 = {a / ratio - 1:+.2e}, residual {resid:.2e}, unscaled rel_err {rel_err(g16[k], g32[k]):.2e}')
+    rep.append(f'worst |alpha / ratio - 1| {worst_a:.2e}, worst residual {worst_r:.2e}')
+    dump('parity_full_depth_llava7b_bf16_vs_twin.txt', '\n'.join(rep) + '\n')
+    assert torch.equal(lp16 == 0, lp32 == 0)
+    assert abs(l16 - l32) < 1e-1 and e_lp < 2.0 and worst_a < 5e-2 and worst_r < 2.5e-1, rep
