@@ -422,10 +422,8 @@ void gemm_kernel(const GemmParams p) {
     }
 }
 
-static int g_pipe = 1;  // 1: software-pipelined K loop (default), 0: simple schedule
 static int g_gm = 0;    // tile-group height of the grouped tile order; 0 = heuristic (AA_GEMM_GM / aa_gemm_set_group override)
 
-static int g_ilv = -1;   // 1: interleave ds_reads with MFMAs via sched_group_barrier (256x256 tile only)
 
 // Height (in tiles) of the groups of the L2-aware tile order.  Same-process sweep on the 7B shapes at M = 16384
 // (tools/bench_gemm_gm.py, profiles/r01_gemm_group_height.txt): 4 beats the former 8 by 0-7 % (NN most), 3 is best for NN with a wide
@@ -469,14 +467,10 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
     if constexpr (BM == 256 && BN == 256 && WM * WN == 4) {
         return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 1>(p, st);     // one-wave-per-SIMD tile: the phase-A interleave only
     } else if constexpr (BM == 256 && BN == 256) {
-        // schedule variants exist for the hot 256x256 tile only (A/B data: profiles/r01_gemm_*_ab.json):
-        //   g_ilv = -1 (auto): NN -> fully interleaved peeled loop (2), NT / TN -> phase-A interleave (1)
-        if (!g_pipe) return launch_cfg2<BM, BN, WM, WN, A_T, B_N, false, 0>(p, st);
-        int mode = g_ilv;
-        if (mode < 0) mode = (!A_T && B_N) ? 2 : 1;
-        if (mode == 2) return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 2>(p, st);
-        if (mode == 1) return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 1>(p, st);
-        return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 0>(p, st);
+        // the schedule each layout measured best with (profiles/r01_gemm_*_ab.json): NN = fully interleaved peeled loop (2), NT / TN = phase-A
+        // interleave (1).  The other schedules (simple pipeline, no interleave) were A/B variants of rounds 1-2 and are no longer instantiated.
+        if constexpr (!A_T && B_N) return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 2>(p, st);
+        else return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 1>(p, st);
     } else {
         return launch_cfg2<BM, BN, WM, WN, A_T, B_N, true, 0>(p, st);
     }
@@ -489,7 +483,6 @@ static int launch_layout(GemmParams& p, int tile, hipStream_t st) {
         case 1: return launch_cfg<128, 128, 2, 2, A_T, B_N>(p, st);
         case 2: return launch_cfg<256, 128, 4, 2, A_T, B_N>(p, st);
         case 3: return launch_cfg<128, 256, 2, 4, A_T, B_N>(p, st);
-        case 4: return launch_cfg<256, 256, 2, 2, A_T, B_N>(p, st);   // 4 waves x (128 x 128): one wave per SIMD, 1/3 fewer LDS bytes per flop
         default: aa_set_error("aa_gemm_bf16: unknown tile config %d", tile); return AA_ERR_ARG;
     }
 }
@@ -776,6 +769,4 @@ extern "C" int aa_gemm_glu_bwd_bf16(const void* dY, const void* Wdown, const voi
 // test hook: force a tile config (-1 = heuristic)
 extern "C" int aa_gemm_set_tile(int tile) { g_force_tile = tile; return AA_OK; }
 // test/bench hook: 1 = software-pipelined K loop (default), 0 = simple one-barrier schedule
-extern "C" int aa_gemm_set_interleave(int mode) { g_ilv = mode; return AA_OK; }  // -1 auto, 0 off, 1 phase A, 2 both phases (peeled)
-extern "C" int aa_gemm_set_pipeline(int on) { g_pipe = on ? 1 : 0; return AA_OK; }
 extern "C" int aa_gemm_set_group(int gm) { g_gm = gm < 0 ? 0 : gm; return AA_OK; }   // 0 = heuristic; +256 = group tile columns instead of rows

@@ -238,14 +238,6 @@ def gemm_set_tile(tile: int) -> None:
     call('aa_gemm_set_tile', int(tile))
 
 
-def gemm_set_interleave(mode: int) -> None:
-    call('aa_gemm_set_interleave', int(mode))
-
-
-def gemm_set_pipeline(on: bool) -> None:
-    call('aa_gemm_set_pipeline', int(bool(on)))
-
-
 # ------------------------------------------------------------------ norms
 NORM_WS_ROWS = 512
 _ws_cache: dict = {}

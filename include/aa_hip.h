@@ -126,8 +126,6 @@ int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, lon
                  long ldc, const void* bias, const void* residual, long ldr, int act, int flags,
                  void* stream);
 int aa_gemm_set_tile(int tile);
-int aa_gemm_set_pipeline(int on);
-int aa_gemm_set_interleave(int on);
 int aa_gemm_set_group(int gm);   /* tile-group height of the L2-aware tile order (0 = heuristic: 4, or 3 for NN with wide N) */
 /* hf:models/llama/modeling_llama.py:62-67 LlamaRMSNorm */
 int aa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int h, float eps,

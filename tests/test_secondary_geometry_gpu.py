@@ -424,7 +424,10 @@ def test_full_depth_llava_7b_bf16_step_vs_fp32_twin():
     DPO pair at T = 2048 (576 image tokens, response 512) through the bf16 production kernels and through the fp32 twin kernels on identical
     bf16-valued weights (the twin holds 6.76 B trainable fp32 parameters + fp32 gradients + reference + fp32 activations: ~170 GB, one device).
     Reported: loss, reward margin, summed log-probs, per-token log-probs; gradients of six tensors spread over the depth with the DPO scalar
-    factored out (see the one-layer test above).  Bounds are set from the first hardware run with ~2 x headroom."""
+    factored out (see the one-layer test above).  First hardware run: summed log-probs -5725.07 / -5719.97 (bf16) vs -5725.32 / -5718.99 (twin), i.e. off by
+    0.25 / 0.98 nat of 5.7e3 (per-token rms 0.042) -> margin -1.889 vs -1.782, loss 2.030 vs 1.938; every gradient's scale = the DPO scalar ratio to 1e-3, residual
+    1.6-5.1 % (rounding noise accumulated over 32 layers).  For scale: the reference's own bf16 path sums the bf16 log-probs IN bf16 (ulp of 5.7e3 = 32).  Bounds = ~2 x
+    the measured values."""
     import math
     from align_anything_amd import configs
     from align_anything_amd.trainers.dpo import DPOTrainer
@@ -486,4 +489,4 @@ def test_full_depth_llava_7b_bf16_step_vs_fp32_twin():
     rep.append(f'worst |alpha / ratio - 1| {worst_a:.2e}, worst residual {worst_r:.2e}')
     dump('parity_full_depth_llava7b_bf16_vs_twin.txt', '\n'.join(rep) + '\n')
     assert torch.equal(lp16 == 0, lp32 == 0)
-    assert abs(l16 - l32) < 1e-1 and e_lp < 2.0 and worst_a < 5e-2 and worst_r < 2.5e-1, rep
+    assert abs(l16 - l32) < 2e-1 and e_lp < 1.3 and worst_a < 5e-3 and worst_r < 1e-1, rep

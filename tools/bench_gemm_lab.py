@@ -1,6 +1,6 @@
 """Same-process A/B of GEMM kernel variants on the 12 hot 7B shapes at M = 16384 tokens (random bf16 operands), with
 torch.matmul (hipBLASLt) on the same tensors as a yardstick only.  Variants: env AA_LAB_VARIANTS = comma list of
-`name:tile[:ilv]` (tile = aa_gemm_set_tile id, ilv = aa_gemm_set_interleave mode; a fourth field selected the 32x32x16 kernel of tools/lab/gemm5
+`name:tile` (tile = aa_gemm_set_tile id; further fields once selected the K-loop schedule variants of rounds 1-2 and the 32x32x16 kernel of tools/lab/gemm5
 while it was wired in, commit adb854f).  Writes gpurun_out/gemm_lab.json."""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,12 +38,12 @@ for name, N, K in shapes:
         ref = ((a[:, rows].t() if a_t else a[rows]).float()) @ (b if b_n else b.t()).float()
         for rep in range(2):
             for vn, tile, ilv in variants:
-                ops.gemm_set_tile(tile); ops.gemm_set_interleave(ilv)
+                ops.gemm_set_tile(tile)
                 ms = timeit(lambda: ops.gemm(a, b, out=out, a_t=a_t, b_n=b_n))
                 row[f'{vn}_tf_{rep}'] = round(fl / ms / 1e9, 1)
                 if rep == 0:
                     row[f'{vn}_relerr'] = round((out[rows].float() - ref).abs().max().item() / ref.abs().max().item(), 5)
-        ops.gemm_set_tile(-1); ops.gemm_set_interleave(-1)
+        ops.gemm_set_tile(-1)
         if os.environ.get('AA_LAB_BLASLT', '1') == '1':
             A = a.t() if a_t else a; B = b if b_n else b.t()
             ms = timeit(lambda: torch.matmul(A, B, out=out))
