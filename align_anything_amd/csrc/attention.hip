@@ -50,6 +50,30 @@ typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_p;
 #define TR_NBUF_KV 4   // the same for the dK/dV kernel (4 reads -> 2 MFMAs per group)
 #endif
 #define LN2_F 0.6931471805599453f
+// Wave priority inside a tile (round 3, same-box A/B in profiles/r03_attention_lab.txt; outputs bit-identical): a forward wave raises its priority for the
+// softmax (VALU) segment between the two MFMA clusters, so the SIMD's other wave -- mid-way through ITS MFMA cluster -- cannot starve the exps and
+// the wave gets back to feeding the matrix pipe sooner: forward 402 -> 382 us (-4.8 %) at level 3 (-3 % at level 1; around the MFMA clusters instead
+// -3.4 %).  The backward kernels do not gain from either placement (+1 %): off there.
+#ifndef AA_ATTN_SETPRIO
+#define AA_ATTN_SETPRIO 2     // forward: 0 = off, 1 = s_setprio around the MFMA clusters of a tile, 2 = around the softmax VALU (default)
+#endif
+#ifndef AA_ATTN_SETPRIO_BWD
+#define AA_ATTN_SETPRIO_BWD 0 // the same for the dQ and dK/dV kernels
+#endif
+#ifndef AA_ATTN_PRIO_LEVEL
+#define AA_ATTN_PRIO_LEVEL 3
+#endif
+#define AT_STR2(X) #X
+#define AT_STR(X) AT_STR2(X)
+#define AT_SETPRIO_ON() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_setprio " AT_STR(AA_ATTN_PRIO_LEVEL) ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define AT_SETPRIO_OFF() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_setprio 0" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define AT_PRIO(MODE, WHICH, ON) do { if constexpr ((MODE) == (WHICH)) { if constexpr (ON) AT_SETPRIO_ON(); else AT_SETPRIO_OFF(); } } while (0)
+// forward
+#define AT_PRIO_MFMA(X) AT_PRIO(AA_ATTN_SETPRIO, 1, X)
+#define AT_PRIO_VALU(X) AT_PRIO(AA_ATTN_SETPRIO, 2, X)
+// backward kernels
+#define AT_PRIO_MFMA_B(X) AT_PRIO(AA_ATTN_SETPRIO_BWD, 1, X)
+#define AT_PRIO_VALU_B(X) AT_PRIO(AA_ATTN_SETPRIO_BWD, 2, X)
 
 template <int HD> __device__ __forceinline__ int unit_swz(int row) {
     if constexpr (HD == 128) return row & 7; else return (row >> 1) & 3;
@@ -367,6 +391,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) sacc[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            AT_PRIO_MFMA(1);
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -376,6 +401,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                     for (int qi = 0; qi < 2; ++qi)
                         sacc[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], sacc[qi][kb], 0, 0, 0);
                 }
+            AT_PRIO_MFMA(0);
+            AT_PRIO_VALU(1);
             // masks only where a mask can bite: diagonal tile, left-pad boundary, ragged end (wave-uniform)
             const bool need_mask = (p.causal && kv0 + 63 > qw) || kv0 < start || kv0 + 64 > KT;
             bf16x8 pf[2][2];
@@ -448,12 +475,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 pf[qi][1] = pack_bf16x8(sacc[qi][2], sacc[qi][3]);
             }
             // O^T += V^T P^T: the transposed V fragments come by inline asm (tr_stream), a few groups ahead of their MFMAs
+            AT_PRIO_VALU(0);
+            AT_PRIO_MFMA(1);
             tr_stream<HD, 1, TILE_B, 0, TR_NBUF>(lds0 + cur * 2 * TILE_B + trl, [&](auto si, auto di, const bf16x8 vf) {
                 constexpr int S = decltype(si)::value, D = decltype(di)::value;
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi)
                     oacc[qi][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qi][S], oacc[qi][D], 0, 0, 0);
             });
+            AT_PRIO_MFMA(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -629,12 +659,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
                 half(std::integral_constant<int, 1>{}, std::false_type{});
             }
             // dQ^T += K^T dS^T: transposed K fragments by inline asm (see the forward's PV step)
+            AT_PRIO_MFMA_B(1);
             tr_stream<HD, 1, 0, 0, TR_NBUF>(lds0 + cur * 2 * TILE_B + trl, [&](auto si, auto di, const bf16x8 ktf) {
                 constexpr int S = decltype(si)::value, D = decltype(di)::value;
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi)
                     dqacc[qi][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qi][S], dqacc[qi][D], 0, 0, 0);
             });
+            AT_PRIO_MFMA_B(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -736,6 +768,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
             f32x4 sacc[4], dpacc[4];
 #pragma unroll
             for (int qb = 0; qb < 4; ++qb) { sacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f}; dpacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            AT_PRIO_MFMA_B(1);
 #pragma unroll
             for (int qb = 0; qb < 4; ++qb)
 #pragma unroll
@@ -745,6 +778,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
                     sacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sacc[qb], 0, 0, 0);
                     dpacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dpacc[qb], 0, 0, 0);
                 }
+            AT_PRIO_MFMA_B(0);
+            AT_PRIO_VALU_B(1);
             const bool need_mask = (p.causal && qt0 < kvw + 15) || kvw < start || kvw + 16 > KT || qt0 + 64 > T;
             bf16x8 pfr[2], dsfr[2];
             // P and dS of the 64 x 16 block; the rows' statistics come as 16-byte LDS reads (q = 16 qb + 4 g + r)
@@ -773,11 +808,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
             };
             if (need_mask) softmax_bwd(std::true_type{}); else softmax_bwd(std::false_type{});
             // dV^T += dO^T P, dK^T += Q^T dS: the transposed Q / dO fragments by inline asm (tr_stream)
+            AT_PRIO_VALU_B(0);
+            AT_PRIO_MFMA_B(1);
             tr_stream<HD, 2, 0, TILE_B, TR_NBUF_KV>(lds0 + cur * 2 * TILE_B + trl, [&](auto si, auto di, const bf16x8 qt_f, const bf16x8 dot_f) {
                 constexpr int S = decltype(si)::value, D = decltype(di)::value;
                 dvacc[D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr[S], dvacc[D], 0, 0, 0);
                 dkacc[D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsfr[S], dkacc[D], 0, 0, 0);
             });
+            AT_PRIO_MFMA_B(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
