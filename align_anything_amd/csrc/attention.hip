@@ -631,6 +631,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
                             dpacc[qi][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qi][ks], dpacc[qi][kk], 0, 0, 0);
                         }
                     }
+                AT_PRIO_VALU_B(1);
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi) {
                     const int qg = qw + qi * 16 + l15;
@@ -648,6 +649,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
                         }
                     dsf[qi][S] = pack_bf16x8(sacc[qi][0], sacc[qi][1]);
                 }
+                AT_PRIO_VALU_B(0);
             };
             if (need_mask) {
                 half(std::integral_constant<int, 0>{}, std::true_type{});
