@@ -115,6 +115,7 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     // (16 in flight -- 512 k per trip -- measured no different: 4.19 vs 4.20 ms per position, tools/gpu_skinny_ab.sh.)
     constexpr int S = PRO == 1 ? 4 : 8;
     for (; k + S * 32 <= k_hi; k += S * 32) skinny_trip<PRO, S>(wp, xp, nwp, k, K, ss, acc0, acc1);
+    if constexpr (S > 4) { for (; k + 128 <= k_hi; k += 128) skinny_trip<PRO, 4>(wp, xp, nwp, k, K, ss, acc0, acc1); }   // a 16-wave strip's 224-k share: 4 + 2 + 1 steps
     for (; k + 64 <= k_hi; k += 64) skinny_trip<PRO, 2>(wp, xp, nwp, k, K, ss, acc0, acc1);
     if (k < k_hi) {
         const bf16x8 wf = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (PRO == 3 ? (long)k * 16 : (long)k)));
@@ -187,6 +188,14 @@ static void launch_skinny(const void* x, const void* W, void* out, int M, int N,
                           const SkinnyEpi epi = SkinnyEpi{}) {
     // few column strips (N/16 < ~3 per CU): split K over 8 waves so enough loads are in flight per CU
     const bool wide = (N / 16) >= 768 || K < 2048;
+    // narrow AND deep (the o / down / qkv projections of a 7B decoder: 224-288 strips on 256 CUs, K >= 3584): 16 waves per strip -- the launch is
+    // bound by its fixed costs, and twice the waves halve each wave's share of the stream (same-box PPO A/B: 3.181 -> 3.118 ms per position)
+    if (!wide && K >= 3584) {
+        hipLaunchKernelGGL((gemm_skinny_kernel<16, PRO, EPI>), dim3(aa_cdiv(N, 16)), dim3(1024), 0, st,
+                           (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
+                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1, (const bf16_t*)norm_w, eps, epi);
+        return;
+    }
     if (wide)
         hipLaunchKernelGGL((gemm_skinny_kernel<4, PRO, EPI>), dim3(aa_cdiv(N, 16)), dim3(256), 0, st,
                            (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,

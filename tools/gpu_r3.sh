@@ -38,6 +38,11 @@ for stage in "$@"; do
       timeout 900 python -m pytest tests/test_secondary_geometry_gpu.py -m gpu -q -p no:cacheprovider -k full_depth > gpurun_out/r03_pytest_full_depth.log 2>&1; tail -12 gpurun_out/r03_pytest_full_depth.log; cat gpurun_out/parity_full_depth_llava7b_bf16_vs_twin.txt ;;
     attn_lab)    # same-box A/B of attention builds (tools/build_attn_variant.sh): libaa_hip.so = production, _prio1 / _prio2 = s_setprio variants
       AA_ATTN_LIBS=${AA_ATTN_LIBS:-libaa_hip.so,libaa_hip_prio1.so,libaa_hip_prio2.so,libaa_hip.so} AA_LAB_OUT=r03_attention_lab.json timeout 600 python tools/attn_lab.py > gpurun_out/r03_attention_lab.txt 2>&1; cat gpurun_out/r03_attention_lab.txt ;;
+    decode_lab)  # PPO iteration per library in AA_DECODE_LIBS (strip-kernel lab builds), same box
+      for lib in ${AA_DECODE_LIBS:-libaa_hip.so}; do
+        AA_HIP_LIB=$R/align_anything_amd/$lib timeout 600 python tools/bench_ppo.py --iters 2 > gpurun_out/r03_ppo_$lib.json 2> gpurun_out/r03_ppo_$lib.err
+        python -c "import json,sys; d=json.load(open('gpurun_out/r03_ppo_$lib.json')); print('$lib', 'decode ms/pos', round(d['decode_ms_per_position'],4), 'iteration', round(d['iteration_ms'],1))" || tail -3 gpurun_out/r03_ppo_$lib.err
+      done ;;
     ppo_prof)    # kernel trace of one PPO iteration (decode kernel split at the Qwen2-VL-7B geometry)
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r03_ppo_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03_ppo_prof -o p -- python $R/tools/bench_ppo.py --iters 1 --new-tokens 256 > $R/gpurun_out/r03_bench_ppo_under_rocprof.json 2> $R/gpurun_out/r03_ppo_prof.err )
       f=$(find gpurun_out/r03_ppo_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r03_ppo_kernel_stats.csv && head -22 "$f" | cut -c1-260
