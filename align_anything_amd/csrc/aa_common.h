@@ -28,6 +28,17 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 // round a float through bf16 (emulates a bf16 intermediate of the HF graph)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
+// sigmoid(x) of the bf16 PRODUCTION kernels (SwiGLU forward / backward: element-wise kernels, the gemm4 epilogues, the decode strip kernel): the
+// hardware's v_exp_f32 and v_rcp_f32 (1 ulp each) instead of OCML's expf (range reduction, ~15 instructions) and an IEEE division (~10): every
+// caller rounds the result to bf16 (2^-9), four orders of magnitude coarser.  Inside a one-workgroup-per-CU GEMM tile the precise form was ~60
+// VALU instructions per output element of the SwiGLU epilogues -- 5-8 % of the whole gate_up GEMM, 17 % of the down-projection dX GEMM.
+// The fp32 parity-mode instantiations (elementwise_f32.hip) keep expf and the division: aa_sigmoid<true>.
+template <bool PRECISE>
+__device__ __forceinline__ float aa_sigmoid(float x) {
+    if constexpr (PRECISE) return 1.f / (1.f + expf(-x));
+    else return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
 // ---------------------------------------------------------------- element type of the block kernels
 // elementwise.hip is written against elem_t / ev8 / ev4 / e2f / f2e / ernd and compiled twice: as is (bf16
 // activations, HF rounding points kept: the production path) and through elementwise_f32.hip with AA_ELEM_F32
@@ -44,6 +55,7 @@ __device__ __forceinline__ float ernd(float x) { return x; }
 #define AA_FN(name) name##_f32
 #define AA_FN2(name, name_f32) name_f32
 #define AA_ELEM_NS aa_elem_f32
+#define AA_ELEM_PRECISE true
 #else
 typedef bf16_t elem_t;
 typedef u16x8 ev8;
@@ -54,6 +66,7 @@ __device__ __forceinline__ float ernd(float x) { return rbf(x); }
 #define AA_FN(name) name
 #define AA_FN2(name, name_f32) name
 #define AA_ELEM_NS aa_elem_bf16
+#define AA_ELEM_PRECISE false
 #endif
 
 __device__ __forceinline__ float wave_sum(float v) {

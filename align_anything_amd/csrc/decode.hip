@@ -39,7 +39,7 @@ __device__ __forceinline__ bf16x8 skinny_x(const bf16_t* __restrict__ xp, const 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float gf = bf2f(v[j]);
-            o[j] = f2bf(rbf(gf / (1.f + expf(-gf))) * bf2f(u[j]));
+            o[j] = f2bf(rbf(gf * aa_sigmoid<false>(gf)) * bf2f(u[j]));
         }
         return __builtin_bit_cast(bf16x8, o);
     } else {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
             for (int w = 0; w < NWAVE; ++w) { v1 += red[w][c][m]; v2 += red[w][c + 8][m]; }
             if constexpr (EPI == 1) {
                 const float gf = rbf(v1), uf = rbf(v2);
-                out[(long)m * ldo + blockIdx.x * 8 + c] = f2bf(rbf(gf / (1.f + expf(-gf))) * uf);
+                out[(long)m * ldo + blockIdx.x * 8 + c] = f2bf(rbf(gf * aa_sigmoid<false>(gf)) * uf);
             } else {
                 const int head = blockIdx.x >> 3, d = (blockIdx.x & 7) * 8 + c;          // head_dim 128: 8 strips per head
                 const int col = head * 128 + d;

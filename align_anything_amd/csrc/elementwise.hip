@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const elem_t* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float gf = e2f(g[j]);
-            o[j] = f2e(ernd(gf / (1.f + expf(-gf))) * e2f(u[j]));
+            o[j] = f2e(ernd(gf * aa_sigmoid<AA_ELEM_PRECISE>(gf)) * e2f(u[j]));
         }
         *reinterpret_cast<ev8*>(out + row * F + v * 8) = o;
     }
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const elem_t* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float gf = e2f(g[j]), uf = e2f(u[j]), df = e2f(d[j]);
-            const float s = 1.f / (1.f + expf(-gf));
+            const float s = aa_sigmoid<AA_ELEM_PRECISE>(gf);
             og[j] = f2e(df * uf * s * (1.f + gf * (1.f - s)));
             ou[j] = f2e(df * gf * s);
         }

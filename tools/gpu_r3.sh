@@ -43,6 +43,13 @@ for stage in "$@"; do
         AA_HIP_LIB=$R/align_anything_amd/$lib timeout 600 python tools/bench_ppo.py --iters 2 > gpurun_out/r03_ppo_$lib.json 2> gpurun_out/r03_ppo_$lib.err
         python -c "import json,sys; d=json.load(open('gpurun_out/r03_ppo_$lib.json')); print('$lib', 'decode ms/pos', round(d['decode_ms_per_position'],4), 'iteration', round(d['iteration_ms'],1))" || tail -3 gpurun_out/r03_ppo_$lib.err
       done ;;
+    bench_ab)    # the headline step per library in AA_BENCH_LIBS (same box, alternating, twice)
+      for rep in 1 2; do for lib in ${AA_BENCH_LIBS:-libaa_hip.so}; do
+        AA_HIP_LIB=$R/align_anything_amd/$lib timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r03_bench_ab_$lib.json 2> gpurun_out/r03_bench_ab_$lib.err
+        python -c "import json; d=json.load(open('gpurun_out/r03_bench_ab_$lib.json')); k=[x for x in d['roofline']['by_kind_top12'] if x['tflop'] in (2.9549, 1.4775)]; print('$lib rep $rep', round(d['ms_per_step'],2), round(d['value'],4), d.get('glu_bwd_plan',[{}])[0], [(x['algorithmic_MB'], x['avg_ms']) for x in k])" || tail -3 gpurun_out/r03_bench_ab_$lib.err
+      done; done ;;
+    unit_tests)  # kernel-level suites after an arithmetic change
+      timeout 900 python -m pytest tests/test_gemm_gpu.py tests/test_elementwise_gpu.py tests/test_twin_gpu.py tests/test_decode_gpu.py tests/test_model_gpu.py tests/test_bench_geometry_gpu.py -m gpu -q -p no:cacheprovider > gpurun_out/r03_pytest_unit.log 2>&1; tail -6 gpurun_out/r03_pytest_unit.log ;;
     ppo_prof)    # kernel trace of one PPO iteration (decode kernel split at the Qwen2-VL-7B geometry)
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r03_ppo_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03_ppo_prof -o p -- python $R/tools/bench_ppo.py --iters 1 --new-tokens 256 > $R/gpurun_out/r03_bench_ppo_under_rocprof.json 2> $R/gpurun_out/r03_ppo_prof.err )
       f=$(find gpurun_out/r03_ppo_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r03_ppo_kernel_stats.csv && head -22 "$f" | cut -c1-260
