@@ -251,6 +251,43 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x4& a, const f32x4& b) {
     const bf16x4 hi = __builtin_shufflevector(p2, p3, 0, 1, 2, 3);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// Epilogue store of a wave's [16 rows (lane & 15)][16 DB columns] fp32 block (lane holds columns 16 db + 4 (lane >> 4) + 0..3 of its row) as bf16 with
+// 16-BYTE stores: lanes g and g ^ 1 exchange halves with v_permlane16_swap (the gemm4 epilogue's trick), so a lane ends up with 8 consecutive columns
+// of one 16-column block -- half the store instructions of the 4-columns-per-lane form (the store tail of a workgroup is issue-bound), one packed
+// convert per dword.  Every lane must call it (the swaps are wave-wide); `ok` masks the store only.
+// Same-box A/B (profiles/r03_attention_lab.txt, run 6): the backward pair gains 2.2 % (1211 -> 1185 us), the FORWARD kernel loses 6 % (388 -> 413 us) with
+// the wide form -- it sits at its register limit -- so WIDE is a template parameter: dQ and dK/dV use it, the forward keeps the 8-byte stores.
+template <int DB, bool WIDE>
+__device__ __forceinline__ void at_store_rows(bf16_t* row, const f32x4 (&acc)[DB], float scale, bool ok, int g) {
+    if constexpr (WIDE) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+    auto pk2 = [](float a, float b) -> unsigned {
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    };
+    const int ecol = (g & 1) * 16 + (g >> 1) * 8;
+#pragma unroll
+    for (int db = 0; db < DB; db += 2) {
+        unsigned w[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) w[f][h] = pk2(acc[db + f][2 * h] * scale, acc[db + f][2 * h + 1] * scale);
+        const auto lo = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+        if (ok) *reinterpret_cast<u32x4_*>(row + db * 16 + ecol) = u32x4_{lo[0], hi[0], lo[1], hi[1]};
+    }
+    } else {
+    if (!ok) return;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+        u16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[db][r] * scale);
+        *reinterpret_cast<u16x4*>(row + db * 16 + g * 4) = o;
+    }
+    }
+}
+
 // Reductions over the four 16-lane rows of a wave (the lanes that share l15): v_permlane16_swap / v_permlane32_swap exchange
 // rows (halves) between two registers, so with both operands = v the two results hold the row pair's members in every lane and
 // one max / add finishes the step -- 2 VALU per step instead of __shfl_xor's index arithmetic + ds_bpermute round trip
@@ -493,16 +530,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     for (int qi = 0; qi < 2; ++qi) {
         const float l = row4_sum(lsum[qi]);
         const int qg = qw + qi * 16 + l15;
-        if (qg >= T) continue;
         const float inv = l > 0.f ? 1.f / l : 0.f;
-        bf16_t* orow = p.O + ((long)n * T + qg) * p.ldo + h * HD;
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            u16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf(oacc[qi][db][r] * inv);
-            *reinterpret_cast<u16x4*>(orow + db * 16 + g * 4) = o;
-        }
+        at_store_rows<DB, false>(p.O + ((long)n * T + min(qg, T - 1)) * p.ldo + h * HD, oacc[qi], inv, qg < T, g);
+        if (qg >= T) continue;
         if (g == 0 && p.lse)
             p.lse[((long)n * p.H + h) * T + qg] = l > 0.f ? (m2[qi] + log2f(l)) * LN2_F : -INFINITY;
     }
@@ -676,15 +706,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         const int qg = qw + qi * 16 + l15;
-        if (qg >= T) continue;
-        bf16_t* row = p.dQ + ((long)n * T + qg) * p.lddq + h * HD;
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            u16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf(dqacc[qi][db][r]);
-            *reinterpret_cast<u16x4*>(row + db * 16 + g * 4) = o;
-        }
+        at_store_rows<DB, true>(p.dQ + ((long)n * T + min(qg, T - 1)) * p.lddq + h * HD, dqacc[qi], 1.f, qg < T, g);
     }
 }
 
@@ -822,18 +844,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (kvg < T) {
-        bf16_t* krow = p.dK + ((long)n * T + kvg) * p.lddk + hk * HD;
-        bf16_t* vrow = p.dV + ((long)n * T + kvg) * p.lddv + hk * HD;
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            u16x4 a, b;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { a[r] = f2bf(dkacc[db][r]); b[r] = f2bf(dvacc[db][r]); }
-            *reinterpret_cast<u16x4*>(krow + db * 16 + g * 4) = a;
-            *reinterpret_cast<u16x4*>(vrow + db * 16 + g * 4) = b;
-        }
-    }
+    at_store_rows<DB, true>(p.dK + ((long)n * T + min(kvg, T - 1)) * p.lddk + hk * HD, dkacc, 1.f, kvg < T, g);
+    at_store_rows<DB, true>(p.dV + ((long)n * T + min(kvg, T - 1)) * p.lddv + hk * HD, dvacc, 1.f, kvg < T, g);
 }
 
 // ================================================================== C ABI
