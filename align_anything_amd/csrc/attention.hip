@@ -288,6 +288,47 @@ __device__ __forceinline__ void at_store_rows(bf16_t* row, const f32x4 (&acc)[DB
     }
 }
 
+// at_store_rows<DB, true> with aa_rope_inplace(inverse = 1) applied on the way out (backward of hf apply_rotary_pos_emb on the bf16 gradient, the rounding
+// points of elementwise.hip::rope_kernel: o1 = bf16(bf16(a c) + bf16(b s)), o2 = bf16(bf16(b c) + bf16(-a s)) on the bf16-ROUNDED dQ / dK values): the lane
+// that owns 8 columns d .. d + 7 of block pair (db, db + 1) also owns their partners d + HD / 2 in blocks (db + DB / 2, ...), so the rotation is
+// register-local; `tab` = byte-free offset rope_pos[row] * (HD / 2) into the cos / sin tables.  Removes the separate rope launch over d[q | k].
+template <int DB>
+__device__ __forceinline__ void at_store_rows_rope(bf16_t* row, const f32x4 (&acc)[DB], bool ok, int g, const bf16_t* cos_t, const bf16_t* sin_t, long tab) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+    auto pk2 = [](float a, float b) -> unsigned { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2)); };
+    auto lo16 = [](unsigned x) { return __builtin_bit_cast(float, x << 16); };
+    auto hi16 = [](unsigned x) { return __builtin_bit_cast(float, x & 0xffff0000u); };
+    auto r16 = [](float x) { return bf2f(f2bf(x)); };
+    const int ecol = (g & 1) * 16 + (g >> 1) * 8;
+    auto packed = [&](int db) -> u32x4_ {
+        unsigned w[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) w[f][h] = pk2(acc[db + f][2 * h], acc[db + f][2 * h + 1]);
+        const auto lo = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+        return u32x4_{lo[0], hi[0], lo[1], hi[1]};
+    };
+#pragma unroll
+    for (int db = 0; db < DB / 2; db += 2) {
+        u32x4_ x1 = packed(db), x2 = packed(db + DB / 2);
+        if (ok) {
+            const u32x4_ c = *reinterpret_cast<const u32x4_*>(cos_t + tab + db * 16 + ecol);
+            const u32x4_ sn = *reinterpret_cast<const u32x4_*>(sin_t + tab + db * 16 + ecol);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = lo16(x1[e]), a1 = hi16(x1[e]), b0 = lo16(x2[e]), b1 = hi16(x2[e]);
+                const float c0 = lo16(c[e]), c1 = hi16(c[e]), s0 = lo16(sn[e]), s1 = hi16(sn[e]);
+                x1[e] = pk2(r16(a0 * c0) + r16(b0 * s0), r16(a1 * c1) + r16(b1 * s1));
+                x2[e] = pk2(r16(b0 * c0) + r16(-a0 * s0), r16(b1 * c1) + r16(-a1 * s1));
+            }
+            *reinterpret_cast<u32x4_*>(row + db * 16 + ecol) = x1;
+            *reinterpret_cast<u32x4_*>(row + (db + DB / 2) * 16 + ecol) = x2;
+        }
+    }
+}
+
 // Reductions over the four 16-lane rows of a wave (the lanes that share l15): v_permlane16_swap / v_permlane32_swap exchange
 // rows (halves) between two registers, so with both operands = v the two results hold the row pair's members in every lane and
 // one max / add finishes the step -- 2 VALU per step instead of __shfl_xor's index arithmetic + ds_bpermute round trip
@@ -323,6 +364,9 @@ struct AttnParams {
     long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int N, T, H, Hkv, causal;
     float scale;
+    // backward only: the transpose rotary rotation of dQ / dK in the kernels' epilogues (aa_attn_bwd_rope): position of token row r = rope_pos[r],
+    // cos / sin tables [., HD / 2] bf16; null = plain dQ / dK (aa_attn_bwd)
+    const int* rope_pos; const bf16_t* rope_cos; const bf16_t* rope_sin;
 };
 
 // ------------------------------------------------------------------ workgroup -> (sequence, head, block)
@@ -706,7 +750,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         const int qg = qw + qi * 16 + l15;
-        at_store_rows<DB, true>(p.dQ + ((long)n * T + min(qg, T - 1)) * p.lddq + h * HD, dqacc[qi], 1.f, qg < T, g);
+        const long qrow = (long)n * T + min(qg, T - 1);
+        if (p.rope_pos) at_store_rows_rope<DB>(p.dQ + qrow * p.lddq + h * HD, dqacc[qi], qg < T, g, p.rope_cos, p.rope_sin, (long)p.rope_pos[qrow] * (HD / 2));
+        else at_store_rows<DB, true>(p.dQ + qrow * p.lddq + h * HD, dqacc[qi], 1.f, qg < T, g);
     }
 }
 
@@ -844,7 +890,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    at_store_rows<DB, true>(p.dK + ((long)n * T + min(kvg, T - 1)) * p.lddk + hk * HD, dkacc, 1.f, kvg < T, g);
+    const long krow_i = (long)n * T + min(kvg, T - 1);
+    if (p.rope_pos) at_store_rows_rope<DB>(p.dK + krow_i * p.lddk + hk * HD, dkacc, kvg < T, g, p.rope_cos, p.rope_sin, (long)p.rope_pos[krow_i] * (HD / 2));
+    else at_store_rows<DB, true>(p.dK + krow_i * p.lddk + hk * HD, dkacc, 1.f, kvg < T, g);
     at_store_rows<DB, true>(p.dV + ((long)n * T + min(kvg, T - 1)) * p.lddv + hk * HD, dvacc, 1.f, kvg < T, g);
 }
 
@@ -895,11 +943,11 @@ extern "C" int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O,
     return AA_OK;
 }
 
-extern "C" int aa_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
-                           const float* lse, float* delta, void* dQ, void* dK, void* dV,
-                           const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo,
-                           long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
-                           int causal, float scale, void* stream) {
+static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                         const float* lse, float* delta, void* dQ, void* dK, void* dV,
+                         const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo,
+                         long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
+                         int causal, float scale, const int* rope_pos, const void* rope_cos, const void* rope_sin, void* stream) {
     int rc = check_common("aa_attn_bwd", N, T, H, Hkv, hd);
     if (rc) return rc;
     AA_REQUIRE((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) % 8 == 0,
@@ -910,6 +958,7 @@ extern "C" int aa_attn_bwd(const void* Q, const void* K, const void* V, const vo
     p.lse = const_cast<float*>(lse); p.delta = delta; p.start = start; p.kvlen = kv_len;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
+    p.rope_pos = rope_pos; p.rope_cos = (const bf16_t*)rope_cos; p.rope_sin = (const bf16_t*)rope_sin;
     hipStream_t st = (hipStream_t)stream;
     const long groups = (long)N * T * H;
     const int lds = 4 * 64 * hd * 2;
@@ -929,4 +978,24 @@ extern "C" int aa_attn_bwd(const void* Q, const void* K, const void* V, const vo
     }
     AA_CHECK_LAUNCH("aa_attn_bwd");
     return AA_OK;
+}
+extern "C" int aa_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                           const float* lse, float* delta, void* dQ, void* dK, void* dV,
+                           const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo,
+                           long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
+                           int causal, float scale, void* stream) {
+    return attn_bwd_impl(Q, K, V, O, dO, lse, delta, dQ, dK, dV, start, kv_len, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, N, T, H, Hkv, hd, causal, scale,
+                         nullptr, nullptr, nullptr, stream);
+}
+// aa_attn_bwd followed by aa_rope_inplace(inverse = 1) on dQ and dK (the backward of the rotary embedding the forward applied to q / k), in the kernels'
+// epilogues: pos[N * T] = rotary position of every token row, cos_t / sin_t [., hd / 2] bf16.  Bit-identical to the two-kernel form.
+extern "C" int aa_attn_bwd_rope(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                                const float* lse, float* delta, void* dQ, void* dK, void* dV,
+                                const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo,
+                                long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
+                                int causal, float scale, const int* pos, const void* cos_t, const void* sin_t, void* stream) {
+    AA_REQUIRE(pos != nullptr && cos_t != nullptr && sin_t != nullptr, "aa_attn_bwd_rope: pos / cos_t / sin_t are required");
+    AA_REQUIRE(((uintptr_t)cos_t & 15) == 0 && ((uintptr_t)sin_t & 15) == 0, "aa_attn_bwd_rope: tables must be 16-byte aligned");
+    return attn_bwd_impl(Q, K, V, O, dO, lse, delta, dQ, dK, dV, start, kv_len, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, N, T, H, Hkv, hd, causal, scale,
+                         pos, cos_t, sin_t, stream);
 }

@@ -243,10 +243,13 @@ class LlamaStack:
             if tr:
                 L['o'].dw(dres, attn)
             d_qkv = torch.zeros_like(qkv) if qkv.shape[0] != N * T else torch.empty_like(qkv)
+            fuse_rope = d_qkv.dtype == bf16 and ops.attn_rope_fused()      # the rotary backward rides in the dQ / dK epilogues (bit-identical)
             ops.attn_bwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], attn, d_attn, lse,
                          d_qkv[:, :qw], d_qkv[:, qw:qw + kw], d_qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
-                         hd ** -0.5, start, kv_len=getattr(self, '_kv_len_saved', None))
-            ops.rope_(d_qkv, 0, H + Hkv, hd, pos, self._rope[0], self._rope[1], inverse=True)
+                         hd ** -0.5, start, kv_len=getattr(self, '_kv_len_saved', None),
+                         rope=(pos, self._rope[0], self._rope[1]) if fuse_rope else None)
+            if not fuse_rope:
+                ops.rope_(d_qkv, 0, H + Hkv, hd, pos, self._rope[0], self._rope[1], inverse=True)
             d_n1 = L['qkv'].dx(d_qkv)
             if tr:
                 L['qkv'].dw(d_qkv, n1)
@@ -1536,9 +1539,12 @@ class Qwen3MoeStack:
                 L['o'].dw(dres, attn)
             z = lambda t: torch.zeros_like(t) if Mp != N * T else torch.empty_like(t)
             dqn, dkn, dv = z(qn), z(kn), z(v)
-            ops.attn_bwd(qn, kn, v, attn, d_attn, lse, dqn, dkn, dv, N, T, H, Hkv, hd, True, hd ** -0.5, start)
-            ops.rope_(dqn, 0, H, hd, pos, self.cos, self.sin, inverse=True)
-            ops.rope_(dkn, 0, Hkv, hd, pos, self.cos, self.sin, inverse=True)
+            fuse_rope = dqn.dtype == bf16 and ops.attn_rope_fused()         # as LlamaStack.backward
+            ops.attn_bwd(qn, kn, v, attn, d_attn, lse, dqn, dkn, dv, N, T, H, Hkv, hd, True, hd ** -0.5, start,
+                         rope=(pos, self.cos, self.sin) if fuse_rope else None)
+            if not fuse_rope:
+                ops.rope_(dqn, 0, H, hd, pos, self.cos, self.sin, inverse=True)
+                ops.rope_(dkn, 0, Hkv, hd, pos, self.cos, self.sin, inverse=True)
             dq = ops.rmsnorm_bwd(dqn.view(Mp * H, hd), q.view(Mp * H, hd), P[L['qn']], rq, G.get(L['qn']) if tr else None).view(Mp, H * hd)
             dk = ops.rmsnorm_bwd(dkn.view(Mp * Hkv, hd), kk.view(Mp * Hkv, hd), P[L['kn']], rk, G.get(L['kn']) if tr else None).view(Mp, Hkv * hd)
             d_n1 = L['q'].dx(dq)

@@ -178,6 +178,15 @@ def fuse_enabled() -> bool:
     return _FUSE
 
 
+_ATTN_ROPE = os.environ.get('AA_ATTN_ROPE', '1') != '0'
+
+
+def attn_rope_fused() -> bool:
+    """bf16 backward: the rotary backward of dQ / dK inside the attention backward kernels (aa_attn_bwd_rope) instead of its own launch;
+    AA_ATTN_ROPE=0 keeps the two launches (same bits -- tests/test_attention_gpu.py -- the switch exists for same-box timing)."""
+    return _FUSE and _ATTN_ROPE
+
+
 def gemm_set_fuse(on: bool) -> None:
     global _FUSE
     _FUSE = bool(on)
@@ -563,13 +572,21 @@ def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None, kv_
     return out, lse
 
 
-def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start=None, kv_len=None):
+def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start=None, kv_len=None, rope=None):
+    """rope = (pos int32 [rows], cos_t, sin_t bf16 [., hd / 2]): dq and dk leave the kernels already rotated back (the backward of the rotary embedding
+    of the forward, `rope_(..., inverse=True)`), bf16 only -- bit-identical to the separate launch."""
     delta = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
     FLOPS['attn'] += 10.0 * N * H * T * T * hd * (0.5 if causal else 1.0)
-    call('aa_attn_bwd' + _sfx(q, 'attn_bwd'), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
-         delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(start), _p(kv_len), q.stride(0), k.stride(0),
-         v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), N, T, H, Hkv, hd,
-         int(causal), float(scale), stream())
+    args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+            delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(start), _p(kv_len), q.stride(0), k.stride(0),
+            v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), N, T, H, Hkv, hd, int(causal), float(scale))
+    if rope is not None:
+        pos, cos_t, sin_t = rope
+        if q.dtype != bf16 or cos_t.dtype != bf16 or pos.dtype != torch.int32 or pos.numel() < N * T:
+            raise RuntimeError('attn_bwd(rope=): bf16 activations and tables, int32 positions for every token row')
+        call('aa_attn_bwd_rope', *args, pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), stream())
+    else:
+        call('aa_attn_bwd' + _sfx(q, 'attn_bwd'), *args, stream())
     return dq, dk, dv
 
 

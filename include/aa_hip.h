@@ -245,6 +245,14 @@ int aa_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
                 const float* lse, float* delta, void* dQ, void* dK, void* dV, const int* start, const int* kv_len, long ldq,
                 long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, int N, int T,
                 int H, int Hkv, int hd, int causal, float scale, void* stream);
+/* aa_attn_bwd + the backward of the rotary embedding (aa_rope_inplace with inverse = 1 on dQ and dK; hf apply_rotary_pos_emb, modeling_llama.py:130-160) in the
+ * epilogues of the dQ and dK/dV kernels: pos[N * T] int32 rotary position of every token row, cos_t / sin_t [., hd / 2] bf16 (the tables of the forward).
+ * Bit-identical to the two launches; saves a pass over d[q | k]. */
+int aa_attn_bwd_rope(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                     const float* lse, float* delta, void* dQ, void* dK, void* dV,
+                     const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo,
+                     long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
+                     int causal, float scale, const int* pos, const void* cos_t, const void* sin_t, void* stream);
 
 /* ---- data-parallel exchange for non-Python hosts (csrc/comm.hip; the Python host side uses torch.distributed for the same three
  * operations).  RCCL is bound at run time (dlopen librccl.so); one communicator per process = per GPU.

@@ -84,3 +84,39 @@ def test_attention_forward_backward(case):
     ref_lse = torch.logsumexp(s.masked_fill(m, float('-inf')), -1)
     ok = torch.isfinite(ref_lse)
     assert_close(lse[ok], ref_lse[ok], rtol=1e-3, atol=2e-2, what='lse')
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_attention_backward_rope_epilogue_is_bit_identical(case):
+    """aa_attn_bwd_rope (the rotary backward inside the dQ and dK/dV epilogues) == aa_attn_bwd followed by aa_rope_inplace(inverse=1) on
+    dQ and dK, bit for bit: same bf16 rounding of dQ / dK before the rotation, same rounding points inside it (elementwise.hip::rope_kernel);
+    dV untouched.  Positions are arbitrary per row (padding-left rows restart at 0 in the trainers)."""
+    from align_anything_amd import ops
+    N, T, H, Hkv, hd, causal, starts = case
+    scale = hd ** -0.5
+    qkv = randn_bf16(N * T, (H + 2 * Hkv) * hd, seed=21)
+    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:(H + Hkv) * hd], qkv[:, (H + Hkv) * hd:]
+    do = randn_bf16(N * T, H * hd, seed=22)
+    start = torch.tensor(starts, dtype=torch.int32, device=dev()) if starts is not None else None
+    o, lse = ops.attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start)
+    g = torch.Generator().manual_seed(5)
+    pos = torch.randint(0, 4096, (N * T,), generator=g).to(torch.int32).to(dev())
+    ang = torch.arange(4096, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(0, hd, 2, dtype=torch.float32) / hd))[None, :]
+    cos_t, sin_t = ang.cos().to(torch.bfloat16).to(dev()), ang.sin().to(torch.bfloat16).to(dev())
+
+    def run(fused):
+        d = torch.zeros_like(qkv)
+        dq, dk, dv = d[:, :H * hd], d[:, H * hd:(H + Hkv) * hd], d[:, (H + Hkv) * hd:]
+        ops.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start, rope=(pos, cos_t, sin_t) if fused else None)
+        if not fused:
+            ops.rope_(d, 0, H + Hkv, hd, pos, cos_t, sin_t, inverse=True)
+        torch.cuda.synchronize()
+        return d
+
+    two, one = run(False), run(True)
+    assert torch.isfinite(one.float()).all()
+    assert float(one.float().abs().max()) > 0
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16)), f'{case}: max |d| {float((one.float() - two.float()).abs().max())}'
+    with pytest.raises(RuntimeError):
+        ops.attn_bwd(q, k, v, o, do, lse, one[:, :H * hd], one[:, H * hd:(H + Hkv) * hd], one[:, (H + Hkv) * hd:], N, T, H, Hkv, hd, causal, scale, start,
+                     rope=(pos.long(), cos_t, sin_t))

@@ -58,6 +58,12 @@ for stage in "$@"; do
       timeout 900 python tools/bench_ppo.py --prompts 4 > gpurun_out/r03_bench_ppo_4prompts.json 2> gpurun_out/r03_bench_ppo4.err; tail -c 1500 gpurun_out/r03_bench_ppo_4prompts.json; tail -5 gpurun_out/r03_bench_ppo4.err ;;
     ppo)
       timeout 1500 python tools/bench_ppo.py > gpurun_out/r03_bench_ppo.json 2> gpurun_out/r03_bench_ppo.err; tail -c 2500 gpurun_out/r03_bench_ppo.json; tail -5 gpurun_out/r03_bench_ppo.err ;;
+    rope_ab)     # attention backward with the rotary backward in its epilogues (aa_attn_bwd_rope) vs the separate launch: bit-identity tests, then the headline step both ways, same box
+      timeout 600 python -m pytest tests/test_attention_gpu.py tests/test_model_gpu.py tests/test_qwen3moe_gpu.py tests/test_twin_gpu.py -m gpu -q -p no:cacheprovider > gpurun_out/r03_pytest_rope.log 2>&1; tail -6 gpurun_out/r03_pytest_rope.log
+      for rep in 1 2; do for v in 0 1; do
+        AA_ATTN_ROPE=$v timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r03_bench_rope$v.json 2> gpurun_out/r03_bench_rope$v.err
+        python -c "import json; d=json.load(open('gpurun_out/r03_bench_rope$v.json')); print('AA_ATTN_ROPE=$v rep $rep', round(d['ms_per_step'],2), round(d['value'],4))" || tail -3 gpurun_out/r03_bench_rope$v.err
+      done; done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
