@@ -124,7 +124,7 @@ extern "C" int AA_FN(aa_moe_gather)(const void* x, const int* src_row, void* out
     return AA_OK;
 }
 
-// out[t, :] = (residual ? residual[t, :] : 0) + sum_j w[t, j] * Yp[pos[t, j], :]   (w == NULL -> unit weights)
+// out[t, :] = (residual ? residual[t, :] : 0) + sum_j w[t, j] * Yp[pos[t, j], :]   (w == NULL -> unit weights; pos < 0 -> the slot is skipped)
 // hf :244-246: each expert output is multiplied by the (activation-dtype) weight, rounded, then index_add'ed in expert order.
 __global__ __launch_bounds__(256) void moe_combine_kernel(const elem_t* __restrict__ yp, const int* __restrict__ pos,
                                                           const elem_t* __restrict__ w, const elem_t* __restrict__ residual,
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const elem_t* __restri
         }
         for (int jj = 0; jj < k; ++jj) {
             const int j = order[jj];
+            if (pos[t * k + j] < 0) continue;      // no row behind this slot (pad rows of the capacity-padded expert-parallel exchange): adds nothing
             const ev8 y = *reinterpret_cast<const ev8*>(yp + (long)pos[t * k + j] * h + v * 8);
             const float wj = w ? e2f(w[t * k + j]) : 1.f;
 #pragma unroll
@@ -183,6 +184,10 @@ __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(const elem_t* __re
     if (pair >= rows * k) return;
     const long t = pair / k;
     const long r = pos[pair];
+    if (r < 0) {                                   // slot without a row (see moe_combine_kernel): no gradient row, zero weight gradient
+        if (lane == 0) dw[pair] = 0.f;
+        return;
+    }
     const float wj = e2f(w[pair]);
     float dot = 0.f;
     for (int c = lane * 8; c < h; c += 512) {
@@ -209,7 +214,8 @@ extern "C" int AA_FN(aa_moe_combine_bwd)(const void* dout, const void* yp, const
 #ifndef AA_ELEM_F32   // integer work: one instantiation
 // Expert-major layout of the (token, slot) pairs, entirely on the device (no host read):
 //   counts[e]; off[e+1] = off[e] + align_up(counts[e], align) (align = 128 = the row tile of the grouped GEMM);
-//   pos[pair] = off[e] + rank of the pair among expert e's pairs in (token, slot) order (stable);
+//   pos[pair] = off[e] + rank of the pair among expert e's pairs in (token, slot) order (stable); pairs whose idx is outside [0, E) are in no
+//   segment and their pos is left as the caller initialised it (-1 for the rows of the capacity-padded exchange that carry no token);
 //   src[row] = token of the pair stored at that row, -1 for pad rows / rows beyond off[E];
 //   tile_expert[t] = expert owning rows [t*align, (t+1)*align), -1 beyond off[E].
 // One workgroup per expert counts, then scans all pairs with ballots (E x rows*k reads; E <= 1024) and writes its rows.

@@ -264,6 +264,9 @@ class NativeEngine:
         self.reducer.wait()
         self.global_steps += 1
         gscale = 1.0 / self.world
+        ep = getattr(self.module, 'ep', None)
+        if ep is not None and ep.padded:
+            ep.poll_overflow()        # non-blocking: raises when an earlier step's capacity flag (expert_parallel.py) has landed set
 
         def launch():
             self._sumsq.zero_()
@@ -338,6 +341,9 @@ class NativeEngine:
 
     def grad_norm(self) -> float:
         self.wait_optimizer()
+        ep = getattr(self.module, 'ep', None)
+        if ep is not None and ep.padded:
+            ep.poll_overflow(block=True)     # a host read anyway: report a capacity overflow of this step now rather than a step later
         return float(self._gnorm.item())
 
     # ---- checkpoints (HF layout, supervised_trainer.py:404-450)

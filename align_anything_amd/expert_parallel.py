@@ -20,6 +20,16 @@ Volume per rank and block: rows x k x hidden x 2 B per exchange (268 MB at 8192 
 per layer per step = 1.07 GB, against the 1.21 GB per-layer expert-gradient all-reduce (about 2.1 GB on the wire per rank in a
 ring of 8) that expert sharding removes.
 
+Sync-free form (round 3; `capacity_factor`, the trainers' default): step 2's host read -- one device->host sync per MoE block and direction, 96+ per
+step at 48 layers -- goes away when every (source, destination) pair exchanges a FIXED number of rows, C = ceil(capacity_factor x rows x k / ranks)
+(all rows x k when that is a handful: decode positions), the unused tail zero: the split sizes are constants, the per-expert counts travel in a
+device all-to-all and stay on the device, the receiver derives the local expert of every arriving row (or -1: no token) from them with a
+searchsorted, and `aa_moe_plan` / the grouped GEMM's tile table already skip rows without an expert.  Nothing is dropped: a router that sends one rank
+more than C rows sets a device flag that is copied to pinned memory asynchronously and raised as an error when the engine polls it at the next
+optimizer step (`poll_overflow`; no blocking read) -- the remedy is a larger `train_cfgs.expert_parallel_capacity_factor` (`ranks` can never
+overflow; 0 = the exact exchange above).  The padded layout keeps the expert-major order inside every rank block, so the results are bit-identical
+to the exact exchange (tests/test_ep_gloo.py on CPU; tests/test_ep_gpu.py on hardware).
+
 Use a process group of its own (`dist.new_group()`), not the one the gradient all-reduce runs on: collectives of one
 communicator are serialised, and the exchange of layer l-1 must not queue behind the 400 MB gradient bucket of layer l.
 """
@@ -30,13 +40,21 @@ import torch.distributed as dist
 
 
 class ExpertParallel:
-    def __init__(self, group=None):
+    def __init__(self, group=None, capacity_factor: float | None = None, dense_below: int = 4096):
+        """capacity_factor: None / 0 = exact exchange (one host read per block); f >= 1 = the sync-free capacity-padded exchange with
+        C = ceil(f x rows x k / ranks) rows per peer; blocks with rows x k <= dense_below use C = rows x k (cannot overflow, and tiny)."""
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError('expert parallelism needs an initialised torch.distributed process group')
         self.group = group
         self.size, self.rank = dist.get_world_size(group), dist.get_rank(group)
         # gloo (the CPU / one-GPU test backend) has no device all-to-all: stage through the host.  RCCL exchanges in HBM.
         self.host_staged = dist.get_backend(group) == 'gloo'
+        if capacity_factor is not None and 0 < float(capacity_factor) < 1:
+            raise ValueError(f'expert_parallel capacity factor {capacity_factor} < 1 would drop rows on a perfectly balanced router')
+        self.capacity_factor = float(capacity_factor) if capacity_factor else None
+        self.dense_below = int(dense_below)
+        self._overflow = None          # 0-d bool on the device: some rank block of this step was larger than its capacity
+        self._pending = None           # (pinned host copy, event) of the previous step's flag
 
     def local_experts(self, num_experts: int) -> tuple[int, int]:
         """(first expert, number of experts) held by this rank: contiguous blocks in rank order."""
@@ -46,6 +64,9 @@ class ExpertParallel:
         return self.rank * n, n
 
     def _all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        if self.size == 1:                # a communicator of one: the exchange is a copy (tests/test_qwen3moe_gpu.py runs the whole block this way under
+            out.copy_(inp)                # torch's sync-debug mode to show that the capacity-padded form never reads the device from the host)
+            return out
         if self.host_staged and inp.is_cuda:
             # byte views: the host path is dtype-agnostic (bf16 rows travel as raw 16-bit words)
             h_in = inp.contiguous().cpu()
@@ -75,6 +96,83 @@ class ExpertParallel:
             raise RuntimeError(f'exchange_rows: {x.shape[0]} rows but the splits sum to {sum(in_splits)}')
         out = torch.empty((sum(out_splits), x.shape[1]), dtype=x.dtype, device=x.device)
         return self._all_to_all(out, x, list(out_splits), list(in_splits))
+
+    # ---- sync-free capacity-padded exchange: every tensor below stays on the device
+    @property
+    def padded(self) -> bool:
+        return self.capacity_factor is not None
+
+    def capacity(self, pairs: int) -> int:
+        """Rows per (source, destination) block for a batch of `pairs` = rows x k routed pairs on every rank."""
+        if pairs <= self.dense_below:
+            return max(pairs, 1)
+        return min(pairs, -(-int(self.capacity_factor * pairs) // self.size))
+
+    def padded_send_layout(self, counts, src, pos, idx, cap):
+        """From the dense expert-major plan of the local pairs (`aa_moe_plan`, align 1: counts [E], src [pairs] = token of every dense row,
+        pos [rows, k] = dense row of every pair, idx [rows, k] = its expert) to the padded send buffer [size, cap]:
+        returns (send_src int32 [size * cap]: token row to gather, -1 for the zero tail; pos_padded int32 [rows, k]: row of every pair in that
+        buffer -- and in the buffer that comes back --, -1 for a pair that did not fit, which also raises the overflow flag)."""
+        size, n = self.size, counts.numel() // self.size
+        pairs = pos.numel()
+        cnt_r = counts.view(size, n).sum(1, dtype=torch.int64)                 # rows for every rank
+        off_r = torch.cumsum(cnt_r, 0) - cnt_r                                 # where that rank's block starts in the dense order
+        j = torch.arange(cap, device=counts.device)
+        dense = (off_r[:, None] + j[None, :]).clamp_(max=max(pairs - 1, 0))
+        send_src = torch.where(j[None, :] < cnt_r[:, None], src[:pairs].long()[dense], -1).to(torch.int32).reshape(-1)
+        rank_of = torch.div(idx.long(), n, rounding_mode='floor')
+        within = pos.long() - off_r[rank_of]
+        pos_padded = torch.where(within < cap, rank_of * cap + within, -1).to(torch.int32)
+        over = (cnt_r > cap).any()
+        self._overflow = over if self._overflow is None else (self._overflow | over)
+        return send_src, pos_padded
+
+    def exchange_counts_device(self, counts: torch.Tensor) -> torch.Tensor:
+        """counts int32 [E] -> int32 [size, E_local]: rows rank s holds for each of my experts.  No host read."""
+        recv = torch.empty_like(counts)
+        self._all_to_all(recv, counts)
+        return recv.view(self.size, -1)
+
+    def padded_recv_ids(self, recv_counts: torch.Tensor, cap: int) -> torch.Tensor:
+        """int32 [size * cap, 1]: local expert of every row of the received buffer (source-rank major, expert-major inside a block), -1 for the
+        tail of a block.  A block whose sender overflowed holds that sender's first `cap` rows; the sender's flag reports it."""
+        size, n = recv_counts.shape
+        cum = recv_counts.long().cumsum(1)
+        j = torch.arange(cap, device=recv_counts.device).expand(size, cap).contiguous()
+        ids = torch.searchsorted(cum, j, right=True)                           # number of experts whose rows end at or before j
+        return torch.where(ids >= n, -1, ids).to(torch.int32).view(-1, 1)
+
+    def exchange_fixed(self, x: torch.Tensor) -> torch.Tensor:
+        """x [size * cap, h], block d for rank d -> [size * cap, h], block s from rank s (equal constant splits)."""
+        if x.shape[0] % self.size:
+            raise RuntimeError(f'exchange_fixed: {x.shape[0]} rows do not split over {self.size} ranks')
+        return self._all_to_all(torch.empty_like(x), x)
+
+    def poll_overflow(self, block: bool = False) -> None:
+        """Called once per optimizer step (engine.step) -- never blocks unless asked to: starts the asynchronous read of this step's overflow flag
+        and raises if an EARLIER step's flag, whose copy has landed by now, was set."""
+        if self._pending is not None:
+            host, ev = self._pending
+            if block and ev is not None:
+                ev.synchronize()
+            if ev is None or ev.query():
+                self._pending = None
+                if bool(host.item()):
+                    raise RuntimeError(f'expert-parallel exchange overflowed its capacity (factor {self.capacity_factor}, {self.size} ranks): the router sent one '
+                                       f'rank more rows than a block holds and those rows were NOT processed -- the step is invalid.  Raise '
+                                       f'train_cfgs.expert_parallel_capacity_factor (<= {self.size} always fits) or set it to 0 for the exact exchange')
+        if self._overflow is not None and self._pending is None:
+            flag, self._overflow = self._overflow, None
+            if flag.is_cuda:
+                host = torch.empty((), dtype=torch.bool).pin_memory()
+                host.copy_(flag, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending = (host, ev)
+            else:
+                self._pending = (flag, None)
+            if block:
+                self.poll_overflow(block=True)
 
     def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
         """Concatenate equally shaped shards along dim 0 in rank order (checkpoint export of the expert tensors)."""

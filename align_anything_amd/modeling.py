@@ -1454,6 +1454,18 @@ class Qwen3MoeStack:
     def _ep_experts_fwd(self, L, n2, x_mid, idx, w, Mp):
         ep, E = self.ep, self.cfg['num_experts']
         lay = ops.moe_plan(idx, E, align=1)                      # dense expert-major order = send order (experts are rank-contiguous)
+        if ep.padded:
+            # sync-free form (expert_parallel.py): constant-size blocks per peer, counts and the local plan stay on the device
+            cap = ep.capacity(idx.numel())
+            send_src, pos_p = ep.padded_send_layout(lay['counts'], lay['src'], lay['pos'], idx, cap)
+            xr = ep.exchange_fixed(ops.moe_gather(n2, send_src))                # [size * cap, h]: block s = rank s's rows for my experts, zero tail
+            ids = ep.padded_recv_ids(ep.exchange_counts_device(lay['counts']), cap)
+            plan = ops.moe_plan(ids, E // ep.size, allow_invalid=True)
+            xp = ops.moe_gather(xr, plan['src'])
+            gu, act, yp = self._local_experts_fwd(L, xp, plan)
+            ys = ep.exchange_fixed(ops.moe_combine(yp, plan['pos'], None, xr.shape[0]))      # back in my padded send order
+            x_out = ops.moe_combine(ys, pos_p, w, Mp, residual=x_mid)
+            return x_out, {'lay': lay, 'local': plan, 'pos_p': pos_p, 'ys': ys}, xp, gu, act, yp
         xs = ops.moe_gather(n2, lay['src'])                      # [Mp*k, h]
         send, recv, recv_counts = ep.exchange_counts(lay['counts'])
         xr = ep.exchange_rows(xs, send, recv)                    # rows for my experts, source-rank major
@@ -1467,6 +1479,12 @@ class Qwen3MoeStack:
 
     def _ep_experts_bwd(self, L, dres, ctx, xp, gu, act, w, Mp):
         ep, lay, plan = self.ep, ctx['lay'], ctx['local']
+        if 'pos_p' in ctx:                                       # the same fixed-size exchanges with gradients
+            dys, dw = ops.moe_combine_bwd(dres, ctx['ys'], ctx['pos_p'], w)
+            dyr = ep.exchange_fixed(dys)
+            dxp = self._local_experts_bwd(L, ops.moe_gather(dyr, plan['src']), plan, xp, gu, act)
+            dxs = ep.exchange_fixed(ops.moe_combine(dxp, plan['pos'], None, dyr.shape[0]))
+            return ops.moe_combine(dxs, ctx['pos_p'], None, Mp), dw
         dys, dw = ops.moe_combine_bwd(dres, ctx['ys'], lay['pos'], w)
         dyr = ep.exchange_rows(dys, ctx['send'], ctx['recv'])
         dxp = self._local_experts_bwd(L, ops.moe_gather(dyr, plan['src']), plan, xp, gu, act)

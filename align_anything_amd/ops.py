@@ -491,15 +491,17 @@ def moe_route_bwd(probs, idx, dw, norm_topk, dtype):
 MOE_ALIGN = 128   # row tile of the grouped GEMM = alignment of the expert segments
 
 
-def moe_plan(idx, E, align=MOE_ALIGN):
+def moe_plan(idx, E, align=MOE_ALIGN, allow_invalid=False):
     """Device-side expert-major layout (no host read).  Returns dict(pos [rows,k], src [cap], tile_expert, off [E+1], counts [E], cap).
     align = MOE_ALIGN: segments padded to the grouped GEMM's row tile; align = 1: the dense expert-major order (the send buffer
-    of the expert-parallel exchange)."""
+    of the expert-parallel exchange).  allow_invalid: entries of idx outside [0, E) (-1 = a row of the capacity-padded exchange that
+    carries no token) belong to no expert: pos = -1, which moe_combine / moe_combine_bwd skip."""
     rows, k = idx.shape
     dev = idx.device
     cap = (rows * k + E * (align - 1) + align - 1) // align * align
     i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
-    plan = {'pos': i32(rows * k).view(rows, k), 'src': i32(cap), 'tile_expert': i32(cap // align), 'off': i32(E + 1), 'counts': i32(E),
+    pos = torch.full((rows * k,), -1, dtype=torch.int32, device=dev) if allow_invalid else i32(rows * k)
+    plan = {'pos': pos.view(rows, k), 'src': i32(cap), 'tile_expert': i32(cap // align), 'off': i32(E + 1), 'counts': i32(E),
             'cap': cap, 'E': E}
     call('aa_moe_plan', idx.data_ptr(), rows, k, E, align, cap, plan['counts'].data_ptr(), plan['off'].data_ptr(), plan['pos'].data_ptr(),
          plan['src'].data_ptr(), plan['tile_expert'].data_ptr(), stream())

@@ -206,12 +206,16 @@ def expert_parallel_kwargs(cfgs, *model_cfgs) -> dict:
     """`train_cfgs.expert_parallel: true` on a sparse-MoE backbone: the experts are split over the data-parallel ranks
     (expert_parallel.py).  Returns the `build_model` keyword for every model of the trainer -- ONE ExpertParallel on a communicator of
     its own (the token exchange never queues behind a gradient bucket), shared by the trainer's models, which run one after the other in
-    the same order on every rank -- or {} when the flag is off / the backbones are dense."""
+    the same order on every rank -- or {} when the flag is off / the backbones are dense.  The exchange is the capacity-padded, host-sync-free
+    one unless `train_cfgs.expert_parallel_capacity_factor: 0`."""
     if not bool(cfg_get(cfgs, 'train_cfgs.expert_parallel', False)) or not any(c is not None and c.get('kind') == 'qwen3moe' for c in model_cfgs):
         return {}
     import torch.distributed as dist
     from ..expert_parallel import ExpertParallel
-    return {'ep': ExpertParallel(dist.new_group())}
+    # train_cfgs.expert_parallel_capacity_factor (native key, default 2.0): rows per peer block of the sync-free exchange as a multiple of the
+    # balanced share; 0 = the exact exchange (one host read per MoE block and direction)
+    return {'ep': ExpertParallel(dist.new_group(), capacity_factor=float(cfg_get(cfgs, 'train_cfgs.expert_parallel_capacity_factor', 2.0)),
+                                 dense_below=int(cfg_get(cfgs, 'train_cfgs.expert_parallel_dense_below', 4096)))}
 
 
 def save_slice(trainer, engine, tag=None, output_dir=None) -> str:

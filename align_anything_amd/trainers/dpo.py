@@ -21,7 +21,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import build_window, cfg_get, compute_dtype, flat_to_padded, get_all_reduce_mean, save_slice
+from .common import build_window, cfg_get, compute_dtype, expert_parallel_kwargs, flat_to_padded, get_all_reduce_mean, save_slice
 
 
 class DPOTrainer:
@@ -76,12 +76,11 @@ class DPOTrainer:
                           freeze_language_model=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_language_model', False)),
                           freeze_vision_tower=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_vision_tower', True)))
         ref_kw = {}
-        if self.model_cfg['kind'] == 'qwen3moe' and bool(cfg_get(self.cfgs, 'train_cfgs.expert_parallel', False)):
+        epk = expert_parallel_kwargs(self.cfgs, self.model_cfg)
+        if epk:
             # experts split over the data-parallel ranks (expert_parallel.py); the exchange runs on its own communicator so it
             # never queues behind a gradient bucket.  Policy and reference shard the same way.
-            import torch.distributed as dist
-            from ..expert_parallel import ExpertParallel
-            freeze = ref_kw = dict(ep=ExpertParallel(dist.new_group()))
+            freeze = ref_kw = epk
         self.policy = build_model(self.model_cfg, self.device, trainable=True, dtype=self.dtype, **freeze)
         self.reference = build_model(self.model_cfg, self.device, trainable=False, dtype=self.dtype, **ref_kw) if self.uses_reference else None
         if policy_state is not None:

@@ -13,16 +13,20 @@ sys.path.insert(0, ROOT)
 from tests.util import load_golden, state_dict_from_golden, tiny_qwen3moe_cfg  # noqa: E402
 
 
-def run(z, dtype, rank):
+def run(z, dtype, rank, capacity_factor=0.0):
+    """capacity_factor 0: the exact exchange (one host read per block); 2.0: the sync-free capacity-padded one (on 2 ranks a block holds every
+    pair, so it cannot overflow, and about half of every block is the zero tail); 1.0: blocks of exactly the balanced share -- any imbalance of
+    the router overflows, which must surface as an error at the blocking poll."""
     from align_anything_amd.trainers.dpo import DPOTrainer
     cfgs = {'train_cfgs': {'scale_coeff': float(z['scale_coeff']), 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant',
-                           'weight_decay': 0.0, 'compute_dtype': dtype, 'expert_parallel': True},
+                           'weight_decay': 0.0, 'compute_dtype': dtype, 'expert_parallel': True, 'expert_parallel_capacity_factor': capacity_factor,
+                           'expert_parallel_dense_below': 0},
             'model_cfgs': {'pad_token_id': int(z['pad_token_id'])}}
     wd = torch.bfloat16 if dtype == 'bf16' else torch.float32
     tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_qwen3moe_cfg(), policy_state=state_dict_from_golden(z, 'w.', wd),
                     reference_state=state_dict_from_golden(z, 'r.', wd), device='cuda:0')
     st = tr.policy.store
-    assert tr.model.world == 2 and tr.policy.ep.size == 2 and 'exp' in st.gflat
+    assert tr.model.world == 2 and tr.policy.ep.size == 2 and 'exp' in st.gflat and tr.policy.ep.padded == (capacity_factor > 0)
     assert st.p['model.layers.0.mlp.experts.gate_up_proj'].shape[0] == 4
     rows = [rank, rank + 2]          # pair i = (chosen i, rejected i)
     T = torch.from_numpy
@@ -31,6 +35,12 @@ def run(z, dtype, rank):
     info = tr.train_step(mb)
     tr.model.wait_optimizer()
     torch.cuda.synchronize()
+    if capacity_factor == 1.0:
+        try:
+            tr.model.grad_norm()
+        except RuntimeError as e:
+            return {'overflow_raised': 'capacity' in str(e)}
+        return {'overflow_raised': False, 'loss': info['train/loss']}
     grads = {}
     for name in st.hf_names():
         g = st.grad_view(name)
@@ -90,6 +100,9 @@ def main():
     dist.init_process_group('gloo')
     z = load_golden('qwen3moe_tiny_dpo.npz')
     res = {dt: run(z, dt, rank) for dt in ('fp32', 'bf16')}
+    padded = {dt: run(z, dt, rank, capacity_factor=2.0) for dt in ('fp32', 'bf16')}
+    tight = [None, None]
+    dist.all_gather_object(tight, run(z, 'bf16', rank, capacity_factor=1.0))
     rolls = [None, None]
     dist.all_gather_object(rolls, rollout(z, rank))
     sums = [None, None]
@@ -98,6 +111,8 @@ def main():
     if rank == 0:
         assert sums[0] == sums[1], f'ranks disagree on clip norm / replicated weights after the step: {sums}'
         res['rollout'] = rolls
+        res['padded'] = padded
+        res['tight'] = tight
         torch.save(res, out)
     dist.barrier()
     dist.destroy_process_group()

@@ -348,15 +348,16 @@ def _ep_worker(rank, world, port, q):
         elif name == 'aa_moe_plan':                                         # the plan of csrc/moe.hip, restated (stable sort by expert)
             idx, rows, k, E, align, cap, counts, off, pos, src, te = a[:11]
             flat = ints(idx, rows * k).copy()
-            cnt = np.bincount(flat, minlength=E)
+            valid = (flat >= 0) & (flat < E)               # -1 = a row of the capacity-padded exchange without a token: in no segment, pos untouched
+            cnt = np.bincount(flat[valid], minlength=E)
             seg = (cnt + align - 1) // align * align
             o = np.concatenate([[0], np.cumsum(seg)])
             ints(counts, E)[:] = cnt
             ints(off, E + 1)[:] = o
-            order = np.argsort(flat, kind='stable')
+            order = np.argsort(np.where(valid, flat, E), kind='stable')[:int(valid.sum())]
             starts = np.cumsum(cnt) - cnt
-            dest = o[flat[order]] + (np.arange(rows * k) - starts[flat[order]])
-            if rows * k:
+            dest = o[flat[order]] + (np.arange(order.size) - starts[flat[order]])
+            if order.size:
                 ints(pos, rows * k)[order] = dest
             s_arr = ints(src, cap)
             s_arr[:] = -1

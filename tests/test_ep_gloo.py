@@ -52,6 +52,110 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+# ---- the integer definitions of the device kernels the MoE block runs around the exchange (csrc/moe.hip)
+def _plan(idx, E):
+    """aa_moe_plan, align 1: counts [E], src [pairs] (token of every dense row), pos [rows, k] (dense row of every pair; -1 = no expert)."""
+    rows, k = idx.shape
+    flat = idx.reshape(-1).long()
+    valid = (flat >= 0) & (flat < E)
+    order = torch.argsort(torch.where(valid, flat, E), stable=True)[:int(valid.sum())]
+    pos = torch.full((rows * k,), -1, dtype=torch.int32)
+    pos[order] = torch.arange(order.numel(), dtype=torch.int32)
+    src = torch.full((rows * k,), -1, dtype=torch.int32)
+    src[:order.numel()] = (order // k).to(torch.int32)
+    return {'counts': torch.bincount(flat[valid], minlength=E).to(torch.int32), 'src': src, 'pos': pos.view(rows, k)}
+
+
+def _gather(x, src):
+    out = x[src.long().clamp(min=0)].clone()
+    out[src < 0] = 0
+    return out
+
+
+def _combine(y, pos, rows):
+    out = torch.zeros((rows, y.shape[1]), dtype=y.dtype)
+    for j in range(pos.shape[1]):
+        p = pos[:, j].long()
+        out += torch.where((p >= 0)[:, None], y[p.clamp(min=0)], torch.zeros_like(out))
+    return out
+
+
+def _padded_worker(rank, world, port, q):
+    """The sync-free capacity-padded exchange == the exact one: same rows in the same order in front of every local expert, same combined
+    outputs on the way back; a block that does not fit raises at the poll and loses only the rows beyond the capacity."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from align_anything_amd.expert_parallel import ExpertParallel
+    exact = ExpertParallel(dist.new_group())
+    ep = ExpertParallel(dist.new_group(), capacity_factor=2.0, dense_below=0)
+    ok = ep.padded and not exact.padded and ep.capacity(80) == -(-160 // world) and ExpertParallel(exact.group, 2.0).capacity(80) == 80
+    E, k, h = 8, 2, 6
+    e0, El = ep.local_experts(E)
+    for trial, M in enumerate((13, 1, 40, 64)):
+        g = torch.Generator().manual_seed(100 * trial + rank)
+        idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(M)]).to(torch.int32)
+        x = torch.randn(M, h, generator=g)
+        lay = _plan(idx, E)
+        # exact exchange (the path pinned by test_expert_parallel_exchange)
+        send, recv, recv_counts = exact.exchange_counts(lay['counts'])
+        xr = exact.exchange_rows(_gather(x, lay['src']), send, recv)
+        lp = _plan(ExpertParallel.local_expert_ids(recv_counts, 'cpu'), El)
+        xp = _gather(xr, lp['src'])                                               # rows in front of the local experts, expert-major
+        fn = lambda t, e: t * (1.0 + e.float()[:, None])                          # "expert e" = scale by 1 + e
+        le = torch.repeat_interleave(torch.arange(El), lp['counts'].long())
+        ys = exact.exchange_rows(_combine(fn(xp, le), lp['pos'], xr.shape[0]), recv, send)
+        want = _combine(ys, lay['pos'], M)
+        # padded exchange
+        cap = ep.capacity(M * k)
+        send_src, pos_p = ep.padded_send_layout(lay['counts'], lay['src'], lay['pos'], idx, cap)
+        ok = ok and send_src.numel() == world * cap and int((send_src >= 0).sum()) == M * k and bool((pos_p >= 0).all())
+        xr2 = ep.exchange_fixed(_gather(x, send_src))
+        rc = ep.exchange_counts_device(lay['counts'])
+        ok = ok and torch.equal(rc.long(), recv_counts)
+        ids = ep.padded_recv_ids(rc, cap)
+        ok = ok and ids.shape == (world * cap, 1) and int((ids >= 0).sum()) == sum(recv)
+        lp2 = _plan(ids, El)
+        ok = ok and torch.equal(lp2['counts'], lp['counts'])
+        xp2 = _gather(xr2, lp2['src'])[:xp.shape[0]]
+        ok = ok and torch.equal(xp2, xp)                                          # same rows, same order, in front of every local expert
+        ys2 = ep.exchange_fixed(_combine(fn(_gather(xr2, lp2['src']), torch.cat([le, torch.zeros(world * cap - le.numel(), dtype=le.dtype)])),
+                                         lp2['pos'], world * cap))
+        ok = ok and torch.equal(_combine(ys2, pos_p, M), want)
+        ep.poll_overflow(block=True)                                              # nothing overflowed: no raise
+    # overflow: every rank routes everything to rank 0's experts; factor 1 -> capacity = pairs / world < pairs
+    tight = ExpertParallel(ep.group, capacity_factor=1.0, dense_below=0)
+    M = 16
+    idx = torch.stack([torch.arange(M) % El, (torch.arange(M) + 1) % El], 1).to(torch.int32) if El > 1 else torch.zeros((M, k), dtype=torch.int32)
+    lay = _plan(idx, E)
+    cap = tight.capacity(M * k)
+    send_src, pos_p = tight.padded_send_layout(lay['counts'], lay['src'], lay['pos'], idx, cap)
+    ok = ok and cap == M * k // world and int((pos_p >= 0).sum()) == cap and int((send_src >= 0).sum()) == cap
+    raised = False
+    try:
+        tight.poll_overflow(block=True)
+    except RuntimeError as e:
+        raised = 'capacity' in str(e)
+    ok = ok and raised
+    tight.poll_overflow(block=True)                                                # the flag was consumed
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_capacity_padded_exchange_equals_exact_exchange(world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_padded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
 @pytest.mark.parametrize('world', [2, 4])
 def test_expert_parallel_exchange(world):
     ctx = mp.get_context('spawn')

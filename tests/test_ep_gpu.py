@@ -71,6 +71,20 @@ def test_two_rank_expert_parallel_step_equals_single_rank(tmp_path):
                 assert (d < 1e-4).float().mean().item() > 0.97, (name, (d < 1e-4).float().mean().item())
         rep.append(f'{dtype}: loss ep {e["info"]["train/loss"]:.6f} single {info["train/loss"]:.6f}; clip norm ep {e["grad_norm"]:.6f} single {gnorm:.6f}; '
                    f'worst gradient rel_err {worst:.2e} over {n} tensors ({n_exp} expert tensors)')
+    # the sync-free capacity-padded exchange (expert_parallel.py; trainers' default) is the SAME computation: bit-identical to the exact exchange
+    for dtype in ('fp32', 'bf16'):
+        e, pd = ep[dtype], ep['padded'][dtype]
+        assert pd['info']['train/loss'] == e['info']['train/loss'] and pd['grad_norm'] == e['grad_norm'], (dtype, pd['info'], e['info'])
+        for name, want in e['grads'].items():
+            assert torch.equal(pd['grads'][name], want), (dtype, name, float((pd['grads'][name] - want).abs().max()))
+        for name, want in e['state'].items():
+            assert torch.equal(pd['state'][name], want), (dtype, name)
+        rep.append(f'{dtype}: capacity-padded exchange (factor 2.0, no host read per block) == exact exchange bit for bit: loss, clip norm, '
+                   f'{len(e["grads"])} gradients, {len(e["state"])} updated tensors')
+    # blocks of exactly the balanced share: the fixture's router is not perfectly balanced, so the step must be reported invalid
+    raised = [t['overflow_raised'] for t in ep['tight']]
+    assert any(raised) or all(t['loss'] == ep['bf16']['info']['train/loss'] for t in ep['tight']), ep['tight']
+    rep.append(f'capacity factor 1.0 (blocks of exactly the balanced share): overflow reported on ranks {[r for r, x in enumerate(raised) if x]}')
     # rollout under expert parallelism (generation.py: lockstep passes, token exchange per position) == the all-experts rollout
     for r, roll in enumerate(ep['rollout']):
         for key in ('no_eos', 'eos'):

@@ -210,3 +210,71 @@ def test_generate_greedy_qwen3moe_both_expert_paths():
     top2 = torch.topk(full[:, 19:-1], 2, dim=-1)
     sure = (top2.values[..., 0] - top2.values[..., 1]) > 0.1
     assert torch.equal(top2.indices[..., 0][sure], seq[:, 20:][sure]) and int(sure.sum()) >= 4
+
+
+def test_capacity_padded_expert_parallel_block_never_reads_the_device():
+    """the exact expert-parallel exchange reads the split sizes on the host once per MoE block and direction.  The
+    capacity-padded form (expert_parallel.py, the trainers' default) must not: the whole decoder stack, forward and backward, runs with torch's
+    sync-debug mode set to 'error' (any .item() / .cpu() / nonzero-style device->host read raises) on a communicator of one rank -- the exchange is then
+    a copy, everything around it is the code every rank runs -- and the result is bit-identical to the stack without expert parallelism."""
+    import torch.distributed as dist
+    from align_anything_amd.expert_parallel import ExpertParallel
+    from align_anything_amd.modeling import build_model
+    z = load_golden('qwen3moe_tiny_dpo.npz')
+    cfg = tiny_qwen3moe_cfg()
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29641', rank=0, world_size=1)
+    try:
+        ids, am = T(z['input_ids']).to(dev()), T(z['attention_mask']).to(dev())
+        outs = {}
+        for mode in ('plain', 'padded', 'exact'):
+            ep = None if mode == 'plain' else ExpertParallel(dist.new_group(), capacity_factor=2.0 if mode == 'padded' else None, dense_below=0)
+            m = build_model(cfg, 'cuda:0', trainable=True, dtype=torch.bfloat16, **({} if ep is None else {'ep': ep}))
+            m.load_state_dict(state_dict_from_golden(z, 'w.', torch.bfloat16))
+            N, Tn, Mp, start, pos = m._token_geometry(ids, am, None)
+            flat = ids.reshape(-1)
+            if Mp != N * Tn:
+                flat = torch.cat([flat, torch.zeros(Mp - N * Tn, dtype=flat.dtype, device=flat.device)])
+            x = m.embed_tokens(flat)
+            dres = (torch.randn(x.shape, generator=torch.Generator().manual_seed(3)) * 0.05).to(torch.bfloat16).to(dev())
+            m.stack.forward(x, N, Tn, start, pos, True)                # warm-up outside the guard: rotary tables and other one-time uploads
+            m.stack.backward(dres.clone(), N, Tn, start, pos)
+            m.store.zero_grad()
+            torch.cuda.synchronize()
+            if mode == 'padded':
+                torch.cuda.set_sync_debug_mode('error')
+            try:
+                y = m.stack.forward(x, N, Tn, start, pos, True)
+                dx = m.stack.backward(dres.clone(), N, Tn, start, pos)
+                if ep is not None and ep.padded:
+                    ep.poll_overflow()                           # the asynchronous flag read is not a sync either
+            except RuntimeError as e:
+                if mode == 'exact' and 'synchroniz' in str(e):
+                    raise AssertionError('sync-debug mode was left on') from e
+                raise
+            finally:
+                torch.cuda.set_sync_debug_mode('default')
+            torch.cuda.synchronize()
+            if ep is not None and ep.padded:
+                ep.poll_overflow(block=True)
+            outs[mode] = (y.clone(), dx.clone(), {n: m.store.grad_view(n).clone() for n in m.store.hf_names() if m.store.grad_view(n) is not None})
+        # the exact exchange DOES read the device: the same guard trips on it (so the guard is live)
+        ep = ExpertParallel(dist.new_group())
+        m = build_model(cfg, 'cuda:0', trainable=False, dtype=torch.bfloat16, ep=ep)
+        m.load_state_dict(state_dict_from_golden(z, 'w.', torch.bfloat16))
+        torch.cuda.set_sync_debug_mode('error')
+        try:
+            with pytest.raises(RuntimeError):
+                m.stack.forward(x, N, Tn, start, pos, False)
+        finally:
+            torch.cuda.set_sync_debug_mode('default')
+        for mode in ('padded', 'exact'):
+            assert torch.equal(outs[mode][0], outs['plain'][0]) and torch.equal(outs[mode][1], outs['plain'][1]), mode
+            assert set(outs[mode][2]) == set(outs['plain'][2])
+            for n, g in outs['plain'][2].items():
+                assert torch.equal(outs[mode][2][n], g), (mode, n)
+        assert float(outs['padded'][0].float().abs().max()) > 0 and len(outs['plain'][2]) >= 25
+    finally:
+        if own:
+            dist.destroy_process_group()

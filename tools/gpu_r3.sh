@@ -64,6 +64,8 @@ for stage in "$@"; do
         AA_ATTN_ROPE=$v timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r03_bench_rope$v.json 2> gpurun_out/r03_bench_rope$v.err
         python -c "import json; d=json.load(open('gpurun_out/r03_bench_rope$v.json')); print('AA_ATTN_ROPE=$v rep $rep', round(d['ms_per_step'],2), round(d['value'],4))" || tail -3 gpurun_out/r03_bench_rope$v.err
       done; done ;;
+    ep_tests)    # MoE kernels with pos = -1 rows, the capacity-padded expert-parallel exchange (no host sync; 2 ranks == exact exchange bit for bit)
+      timeout 900 python -m pytest tests/test_qwen3moe_gpu.py tests/test_ep_gpu.py -m gpu -q -p no:cacheprovider > gpurun_out/r03_pytest_ep.log 2>&1; tail -30 gpurun_out/r03_pytest_ep.log; cat gpurun_out/parity/parity_expert_parallel.txt 2>/dev/null ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
