@@ -232,6 +232,7 @@ def test_capacity_padded_expert_parallel_block_never_reads_the_device():
             ep = None if mode == 'plain' else ExpertParallel(dist.new_group(), capacity_factor=2.0 if mode == 'padded' else None, dense_below=0)
             m = build_model(cfg, 'cuda:0', trainable=True, dtype=torch.bfloat16, **({} if ep is None else {'ep': ep}))
             m.load_state_dict(state_dict_from_golden(z, 'w.', torch.bfloat16))
+            m.store.init_training()
             N, Tn, Mp, start, pos = m._token_geometry(ids, am, None)
             flat = ids.reshape(-1)
             if Mp != N * Tn:
@@ -273,7 +274,10 @@ def test_capacity_padded_expert_parallel_block_never_reads_the_device():
             assert torch.equal(outs[mode][0], outs['plain'][0]) and torch.equal(outs[mode][1], outs['plain'][1]), mode
             assert set(outs[mode][2]) == set(outs['plain'][2])
             for n, g in outs['plain'][2].items():
-                assert torch.equal(outs[mode][2][n], g), (mode, n)
+                got = outs[mode][2][n]
+                # GEMM-made (bf16) gradients incl. every expert / router tensor: bit for bit; fp32 vector gradients (norm weights, embedding rows) are
+                # summed with atomics and differ in the last bit between two runs of the SAME path
+                assert torch.equal(got, g) or (g.dtype == torch.float32 and 'experts' not in n and rel_err(got.float(), g.float()) < 1e-5), (mode, n)
         assert float(outs['padded'][0].float().abs().max()) > 0 and len(outs['plain'][2]) >= 25
     finally:
         if own:
