@@ -126,6 +126,10 @@ extern "C" int AA_FN(aa_moe_gather)(const void* x, const int* src_row, void* out
 
 // out[t, :] = (residual ? residual[t, :] : 0) + sum_j w[t, j] * Yp[pos[t, j], :]   (w == NULL -> unit weights; pos < 0 -> the slot is skipped)
 // hf :244-246: each expert output is multiplied by the (activation-dtype) weight, rounded, then index_add'ed in expert order.
+// Round 3: every slot's row is requested before the first one is used (the rows are 4 KB apart in HBM; the round-1 form loaded and accumulated slot by
+// slot, one dependent round trip each: 2.4 TB/s at k = 8), and the ascending-row order comes from each slot's RANK among the token's positions (k <= 8
+// compares per slot, no indexed private array).  Same arithmetic, same order: bit-identical.
+template <int KMAX>
 __global__ __launch_bounds__(256) void moe_combine_kernel(const elem_t* __restrict__ yp, const int* __restrict__ pos,
                                                           const elem_t* __restrict__ w, const elem_t* __restrict__ residual,
                                                           elem_t* __restrict__ out, long rows, int k, int h) {
@@ -133,21 +137,36 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const elem_t* __restri
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * nv; i += (long)gridDim.x * 256) {
         const long t = i / nv;
         const int v = (int)(i % nv);
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        // hf index_add's the expert outputs in ascending expert order = ascending row of the expert-major buffer
-        int order[8];
-        for (int j = 0; j < k; ++j) {
-            int q = j;
-            while (q > 0 && pos[t * k + order[q - 1]] > pos[t * k + j]) { order[q] = order[q - 1]; --q; }
-            order[q] = j;
-        }
-        for (int jj = 0; jj < k; ++jj) {
-            const int j = order[jj];
-            if (pos[t * k + j] < 0) continue;      // no row behind this slot (pad rows of the capacity-padded expert-parallel exchange): adds nothing
-            const ev8 y = *reinterpret_cast<const ev8*>(yp + (long)pos[t * k + j] * h + v * 8);
-            const float wj = w ? e2f(w[t * k + j]) : 1.f;
+        int pj[KMAX];
+        float wj[KMAX];
+        ev8 y[KMAX];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = ernd(acc[q] + ernd(e2f(y[q]) * wj));
+        for (int j = 0; j < KMAX; ++j) {
+            pj[j] = j < k ? pos[t * k + j] : -1;                   // < 0: no row behind this slot (pad rows of the capacity-padded exchange): adds nothing
+            wj[j] = (j < k && w) ? e2f(w[t * k + j]) : 1.f;
+        }
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            if (pj[j] >= 0) y[j] = *reinterpret_cast<const ev8*>(yp + (long)pj[j] * h + v * 8);
+        // hf index_add's the expert outputs in ascending expert order = ascending row of the expert-major buffer
+        int rk[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            int r = 0;
+#pragma unroll
+            for (int q = 0; q < KMAX; ++q) r += (pj[q] >= 0 && pj[q] < pj[j]) ? 1 : 0;      // a token's rows are distinct
+            rk[j] = pj[j] >= 0 ? r : -1;
+        }
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < KMAX; ++r) {
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                if (rk[j] == r) {                                  // uniform over the lanes that share the token
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] = ernd(acc[q] + ernd(e2f(y[j][q]) * wj[j]));
+                }
+            }
         }
         ev8 o;
         if (residual) {
@@ -167,8 +186,10 @@ extern "C" int AA_FN(aa_moe_combine)(const void* yp, const int* pos, const void*
     if (rows == 0) return AA_OK;
     const long total = rows * (h >> 3);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(moe_combine_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const elem_t*)yp, pos, (const elem_t*)weights,
-                       (const elem_t*)residual, (elem_t*)out, rows, k, h);
+#define AA_COMBINE(KM) hipLaunchKernelGGL(moe_combine_kernel<KM>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const elem_t*)yp, pos, \
+                                         (const elem_t*)weights, (const elem_t*)residual, (elem_t*)out, rows, k, h)
+    if (k == 1) AA_COMBINE(1); else if (k == 2) AA_COMBINE(2); else if (k <= 4) AA_COMBINE(4); else AA_COMBINE(8);
+#undef AA_COMBINE
     AA_CHECK_LAUNCH("aa_moe_combine");
     return AA_OK;
 }
@@ -219,11 +240,18 @@ extern "C" int AA_FN(aa_moe_combine_bwd)(const void* dout, const void* yp, const
 //   src[row] = token of the pair stored at that row, -1 for pad rows / rows beyond off[E];
 //   tile_expert[t] = expert owning rows [t*align, (t+1)*align), -1 beyond off[E].
 // One workgroup per expert counts, then scans all pairs with ballots (E x rows*k reads; E <= 1024) and writes its rows.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 __global__ __launch_bounds__(256) void moe_count_kernel(const int* __restrict__ idx, long npairs, int* __restrict__ counts) {
     __shared__ int wsum[4];
     const int e = blockIdx.x;
     int c = 0;
-    for (long i = threadIdx.x; i < npairs; i += 256) c += (idx[i] == e) ? 1 : 0;
+    const long nv = npairs >> 2;                                     // 16-byte loads (idx comes from the allocator: 16-byte aligned)
+    const i32x4* v4 = reinterpret_cast<const i32x4*>(idx);
+    for (long i = threadIdx.x; i < nv; i += 256) {
+        const i32x4 q = v4[i];
+        c += (q[0] == e) + (q[1] == e) + (q[2] == e) + (q[3] == e);
+    }
+    for (long i = (nv << 2) + threadIdx.x; i < npairs; i += 256) c += (idx[i] == e) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -233,40 +261,65 @@ __global__ __launch_bounds__(256) void moe_count_kernel(const int* __restrict__ 
 __global__ __launch_bounds__(256) void moe_plan_kernel(const int* __restrict__ idx, long npairs, int k, int E, int align, long cap_rows,
                                                        const int* __restrict__ counts, int* __restrict__ off, int* __restrict__ pos,
                                                        int* __restrict__ src, int* __restrict__ tile_expert) {
-    __shared__ int wsum[4];
-    __shared__ int base;
+    __shared__ int wsum[2][4];
     __shared__ int my_off;
     const int e = blockIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
         int before = 0;
         for (int ee = 0; ee < e; ++ee) before += (counts[ee] + align - 1) / align * align;
-        my_off = before; base = 0; off[e] = before;
+        my_off = before; off[e] = before;
     }
     __syncthreads();
     const int o0 = my_off, my_cnt = counts[e];
     const int seg = (my_cnt + align - 1) / align * align;
     if (e == E - 1 && threadIdx.x == 0) off[E] = o0 + seg;
-    // stable ranks: scan the pairs in order, 256 at a time
-    for (long b0 = 0; b0 < npairs; b0 += 256) {
-        const long i = b0 + threadIdx.x;
-        const int f = (i < npairs && idx[i] == e) ? 1 : 0;
-        const unsigned long long bal = __ballot(f);
-        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
-        __syncthreads();
-        if (lane == 0) wsum[wid] = __popcll(bal);
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wid; ++w) woff += wsum[w];
-        const int b = base;
-        if (f) {
-            const int r = o0 + b + woff + prefix;
-            pos[i] = r;
-            src[r] = (int)(i / k);
+    // stable ranks: scan the pairs in order, 256 threads x VPT consecutive pairs at a time (round 3: was 256 pairs and four barriers per trip --
+    // 140 us per plan at 65 k pairs x 128 experts; one barrier per 4096 pairs now).  A thread's matches form a bit mask; the block-wide exclusive
+    // prefix of the match counts (wave scan + the four wave totals, double-buffered so one barrier per trip is enough) places them.
+    constexpr int VPT = 16;
+    int base = 0;                                                   // matches in earlier trips (every thread keeps the same value)
+    int trip = 0;
+    for (long b0 = 0; b0 < npairs; b0 += 256 * VPT, ++trip) {
+        const long i0 = b0 + (long)threadIdx.x * VPT;
+        unsigned m = 0;
+        if (i0 + VPT <= npairs) {
+            const i32x4* v4 = reinterpret_cast<const i32x4*>(idx + i0);
+#pragma unroll
+            for (int q = 0; q < VPT / 4; ++q) {
+                const i32x4 x = v4[q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m |= (x[j] == e ? 1u : 0u) << (4 * q + j);
+            }
+        } else {
+            for (int j = 0; j < VPT; ++j)
+                if (i0 + j < npairs && idx[i0 + j] == e) m |= 1u << j;
         }
+        const int c = __popc(m);
+        int inc = c;                                                // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[trip & 1][wid] = inc;
         __syncthreads();
-        if (threadIdx.x == 0) base = b + wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int sw = wsum[trip & 1][w];
+            woff += w < wid ? sw : 0;
+            tot += sw;
+        }
+        int r = o0 + base + woff + inc - c;
+        while (m) {
+            const int j = __ffs(m) - 1;
+            m &= m - 1;
+            pos[i0 + j] = r;
+            src[r] = (int)((i0 + j) / k);
+            ++r;
+        }
+        base += tot;
     }
     for (int r = my_cnt + threadIdx.x; r < seg; r += 256) src[o0 + r] = -1;           // pad rows of the segment
     for (int t = threadIdx.x; t < seg / align; t += 256) tile_expert[o0 / align + t] = e;
@@ -277,6 +330,7 @@ __global__ __launch_bounds__(256) void moe_plan_kernel(const int* __restrict__ i
 }
 extern "C" int aa_moe_plan(const int* idx, long rows, int k, int E, int align, long cap_rows, int* counts, int* off, int* pos, int* src,
                            int* tile_expert, void* stream) {
+    AA_REQUIRE(((uintptr_t)idx & 15) == 0, "aa_moe_plan: idx must be 16-byte aligned");
     AA_REQUIRE(rows >= 0 && k > 0 && E > 0 && align > 0 && cap_rows % align == 0 && cap_rows >= rows * k + (long)E * (align - 1) / align * align,
                "aa_moe_plan: cap_rows=%ld too small / unaligned for rows=%ld k=%d E=%d align=%d", cap_rows, rows, k, E, align);
     hipLaunchKernelGGL(moe_count_kernel, dim3(E), dim3(256), 0, (hipStream_t)stream, idx, rows * k, counts);

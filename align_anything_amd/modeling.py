@@ -1390,9 +1390,8 @@ class Qwen3MoeStack:
             # stepping in lockstep -- generation.py keeps the ranks' step counts equal)
             return self._ep_experts_fwd(L, n2, x_mid, idx, w, rows)[0]
         plan = ops.moe_plan(idx, c['num_experts'])
-        zeros = lambda n: torch.zeros((plan['cap'], n), dtype=n2.dtype, device=n2.device)
-        gu = ops.gemm_grouped(ops.moe_gather(n2, plan['src']), P[L['gu']], plan, out=zeros(P[L['gu']].shape[1]))
-        yp = ops.gemm_grouped(ops.swiglu_fwd(gu), P[L['down']], plan, out=zeros(c['hidden_size']))
+        gu = ops.gemm_grouped(ops.moe_gather(n2, plan['src']), P[L['gu']], plan)
+        yp = ops.gemm_grouped(ops.swiglu_fwd(gu), P[L['down']], plan)
         return ops.moe_combine(yp, plan['pos'], w, rows, residual=x_mid)
 
     def decode_step(self, x, cache, t, Tmax, pos, start, length):
@@ -1431,21 +1430,20 @@ class Qwen3MoeStack:
     # ---- the experts this rank holds, on rows already in the 128-row-tile expert-major layout `plan`
     def _local_experts_fwd(self, L, xp, plan):
         P = self.store.p
-        zeros = lambda n: torch.zeros((plan['cap'], n), dtype=xp.dtype, device=xp.device)
-        gu = ops.gemm_grouped(xp, P[L['gu']], plan, out=zeros(P[L['gu']].shape[1]))
+        gu = ops.gemm_grouped(xp, P[L['gu']], plan)                # every tile is written (zeros where a tile has no expert): ops.grouped_out
         act = ops.swiglu_fwd(gu)
-        yp = ops.gemm_grouped(act, P[L['down']], plan, out=zeros(self.cfg['hidden_size']))
+        yp = ops.gemm_grouped(act, P[L['down']], plan)
         return gu, act, yp
 
     def _local_experts_bwd(self, L, dyp, plan, xp, gu, act):
         """dyp: gradient of the expert outputs in the tile layout (pad rows zero) -> gradient of xp; dW into the store."""
         P, G, st, tr = self.store.p, self.store.g, self.store, self.trainable
         acc = lambda g: (g.dtype == torch.float32) or st.accumulate
-        dact = ops.gemm_grouped(dyp, P[L['down']], plan, out=torch.zeros_like(act), b_n=True)
+        dact = ops.gemm_grouped(dyp, P[L['down']], plan, b_n=True)
         if tr:      # experts that saw no token get an all-zero gradient from the kernel (never a stale one)
             ops.gemm_grouped_dw(dyp, act, plan, G[L['down']], accumulate=acc(G[L['down']]))
         dgu = ops.swiglu_bwd(gu, dact)
-        dxp = ops.gemm_grouped(dgu, P[L['gu']], plan, out=torch.zeros_like(xp), b_n=True)
+        dxp = ops.gemm_grouped(dgu, P[L['gu']], plan, b_n=True)
         if tr:
             ops.gemm_grouped_dw(dgu, xp, plan, G[L['gu']], accumulate=acc(G[L['gu']]))
         return dxp

@@ -508,6 +508,12 @@ def moe_plan(idx, E, align=MOE_ALIGN, allow_invalid=False):
     return plan
 
 
+def grouped_out(rows, n, like):
+    """Output buffer of a grouped GEMM over the padded expert-major layout: the bf16 kernel writes every tile (zeros where a tile has no expert), so no
+    memset; the fp32 twin kernel skips those tiles and gets a zeroed buffer."""
+    return (torch.empty if like.dtype == bf16 else torch.zeros)((rows, n), dtype=like.dtype, device=like.device)
+
+
 def gemm_grouped(a, w3, plan, out=None, b_n=False):
     """Rows grouped by expert: out[cap, N] = a[cap, K] @ op(w3[e]) for every 128-row tile's expert e (w3 = [E, N, K], or [E, K, N] with b_n)."""
     sfx = _sfx(a, 'gemm_grouped')
@@ -516,7 +522,7 @@ def gemm_grouped(a, w3, plan, out=None, b_n=False):
     N = w3.shape[2] if b_n else w3.shape[1]
     if (w3.shape[1] if b_n else w3.shape[2]) != K or w3.dtype != a.dtype or not w3.is_contiguous():
         raise RuntimeError(f'gemm_grouped: weight {tuple(w3.shape)} does not match activations {tuple(a.shape)}')
-    out = torch.empty((cap, N), dtype=a.dtype, device=a.device) if out is None else out
+    out = grouped_out(cap, N, a) if out is None else out
     call('aa_gemm_grouped' + (sfx or '_bf16'), a.data_ptr(), w3.data_ptr(), out.data_ptr(), cap, N, K, a.stride(0), w3.stride(1), out.stride(0),
          GEMM_B_N if b_n else 0, 1, plan['tile_expert'].data_ptr(), None, w3.stride(0), E, stream())
     return out

@@ -93,6 +93,66 @@ def test_moe_kernels_vs_torch():
     assert rel_err(dyp.cpu(), want) < 1e-6
 
 
+def test_moe_plan_and_combine_at_scale():
+    """Round-3 kernels: the plan scans 4096 pairs per trip (16 per thread, one barrier) -- full trips, the ragged last trip, pairs without an expert
+    (-1, the zero tail of the capacity-padded exchange) and empty experts, against the stable sort that defines it; the combine requests all k rows
+    before it adds them in ascending-row order -- bit-exact against the rounding sequence written out in torch, incl. slots without a row."""
+    from align_anything_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for rows, E, k, invalid in ((3000, 128, 8, False), (1029, 24, 2, True), (4096, 8, 1, True), (512, 128, 8, False)):
+        idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(rows)]).to(torch.int32)
+        idx[idx == 5] = 6 if E > 8 else 5                                      # expert 5 empty (E > 8)
+        if invalid:
+            idx[torch.rand(rows, k, generator=g) < 0.3] = -1
+        plan = ops.moe_plan(idx.to(dev()), E, allow_invalid=invalid)
+        A = ops.MOE_ALIGN
+        flat = idx.reshape(-1).long()
+        valid = flat >= 0
+        counts = torch.bincount(flat[valid], minlength=E)
+        seg = (counts + A - 1) // A * A
+        off = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(seg, 0)])
+        assert plan['counts'].cpu().tolist() == counts.tolist() and plan['off'].cpu().tolist() == off.tolist()
+        order = torch.argsort(torch.where(valid, flat, E), stable=True)[:int(valid.sum())]
+        starts = torch.cumsum(counts, 0) - counts
+        dest = off[flat[order]] + (torch.arange(order.numel()) - starts[flat[order]])
+        want_pos = torch.full((rows * k,), -1, dtype=torch.long); want_pos[order] = dest
+        assert torch.equal(plan['pos'].long().cpu().reshape(-1), want_pos), (rows, E, k)
+        want_src = torch.full((plan['cap'],), -1, dtype=torch.long); want_src[dest] = order // k
+        assert torch.equal(plan['src'].long().cpu(), want_src), (rows, E, k)
+        # bf16 combine: acc = bf16(acc + bf16(y w)) over the slots in ascending row order, then bf16(acc + residual)
+        h = 64
+        yp = torch.randn(plan['cap'], h, generator=g).to(torch.bfloat16)
+        w = torch.rand(rows, k, generator=g).to(torch.bfloat16)
+        res = torch.randn(rows, h, generator=g).to(torch.bfloat16)
+        pos = want_pos.view(rows, k)
+        key = torch.where(pos >= 0, pos, torch.full_like(pos, 1 << 40))
+        srt = torch.argsort(key, dim=1)
+        acc = torch.zeros(rows, h)
+        rb = lambda t: t.to(torch.bfloat16).float()
+        for jj in range(k):
+            j = srt[:, jj]
+            pj = pos[torch.arange(rows), j]
+            term = rb(yp.float()[pj.clamp(min=0)] * w.float()[torch.arange(rows), j][:, None])
+            acc = torch.where((pj >= 0)[:, None], rb(acc + term), acc)
+        for use_w, use_res in ((True, True), (False, False)):
+            got = ops.moe_combine(yp.to(dev()), plan['pos'], w.to(dev()) if use_w else None, rows, residual=res.to(dev()) if use_res else None)
+            if use_w:
+                want = (acc + res.float()).to(torch.bfloat16)
+                assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16)), (rows, E, k, float((got.cpu().float() - want.float()).abs().max()))
+            elif k == 1:
+                want = torch.where((pos >= 0), yp.float()[pos.clamp(min=0).view(-1)], torch.zeros(rows, h)).to(torch.bfloat16)
+                assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16))
+        # grouped GEMM without a memset: tiles that belong to no expert come out as zeros, never as stale memory
+        F_ = 256
+        w3 = (torch.randn(E, F_, h, generator=g) * 0.2).to(torch.bfloat16).to(dev())
+        xp = ops.moe_gather(torch.randn(rows, h, generator=g).to(torch.bfloat16).to(dev()), plan['src'])
+        stale = torch.full((plan['cap'], F_), 7.0, dtype=torch.bfloat16, device=dev())
+        out = ops.gemm_grouped(xp, w3, plan, out=stale)
+        assert float(out[int(off[E]):].float().abs().max()) == 0.0 if int(off[E]) < plan['cap'] else True
+        srcs = plan['src'].cpu()
+        assert float(out.cpu()[srcs < 0].float().abs().max()) == 0.0
+
+
 def _trainer(z, dtype):
     from align_anything_amd.trainers.dpo import DPOTrainer
     cfgs = {'train_cfgs': {'scale_coeff': float(z['scale_coeff']), 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant',

@@ -66,6 +66,12 @@ for stage in "$@"; do
       done; done ;;
     ep_tests)    # MoE kernels with pos = -1 rows, the capacity-padded expert-parallel exchange (no host sync; 2 ranks == exact exchange bit for bit)
       timeout 900 python -m pytest tests/test_qwen3moe_gpu.py tests/test_ep_gpu.py -m gpu -q -p no:cacheprovider > gpurun_out/r03_pytest_ep.log 2>&1; tail -30 gpurun_out/r03_pytest_ep.log; cat gpurun_out/parity/parity_expert_parallel.txt 2>/dev/null ;;
+    moe_prof)    # kernel split of the Qwen3-30B-A3B-geometry DPO step (12 layers)
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r03_moe_prof && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03_moe_prof -o p -- python $R/tools/bench_qwen3moe.py --steps 3 --warmup 1 > $R/gpurun_out/r03_bench_qwen3moe_under_rocprof.json 2> $R/gpurun_out/r03_moe_prof.err )
+      f=$(find gpurun_out/r03_moe_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r03_qwen3moe_kernel_stats.csv && head -40 "$f" | cut -c1-200
+      find gpurun_out/r03_moe_prof -name "*kernel_trace.csv" -delete; tail -3 gpurun_out/r03_moe_prof.err ;;
+    moe_bench)   # the 12-layer Qwen3-30B-A3B-geometry DPO step
+      timeout 600 python tools/bench_qwen3moe.py --steps 4 --warmup 2 > gpurun_out/r03_bench_qwen3moe.json 2> gpurun_out/r03_bench_qwen3moe.err; cat gpurun_out/r03_bench_qwen3moe.json; tail -3 gpurun_out/r03_bench_qwen3moe.err ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
