@@ -3,7 +3,7 @@ torch.matmul (hipBLASLt) on the same tensors as a yardstick only.  Variants: env
 `name:tile` (tile = aa_gemm_set_tile id; further fields once selected the K-loop schedule variants of rounds 1-2 and the 32x32x16 kernel of tools/lab/gemm5
 while it was wired in, commit adb854f).  Writes gpurun_out/gemm_lab.json."""
 import json, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from align_anything_amd import ops
 dev = torch.device('cuda:0')
 TOK = int(os.environ.get('AA_LAB_TOKENS', 16384))

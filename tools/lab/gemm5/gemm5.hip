@@ -18,7 +18,7 @@
 //     which that swizzle sends to 8 distinct blocks of the 8-block bank line.
 //   * D = B-fragment x A-fragment (operands swapped): lane l owns C[m = .. + (l & 31)][n = .. + 8 q + 4 (l >> 5) + 0..3], q = 0..3; the
 //     plain epilogue pairs lanes l / l + 32 with v_permlane32_swap so that a lane stores 8 consecutive columns (16 bytes).
-// Selected with aa_gemm_set_mfma32(1) / AA_GEMM_MFMA32=1 (A/B against gemm4 on the same box: tools/bench_gemm_lab.py).
+// Selected with aa_gemm_set_mfma32(1) / AA_GEMM_MFMA32=1 (A/B against gemm4 on the same box: tools/lab/bench_gemm_lab.py).
 #include "aa_common.h"
 
 #include <type_traits>
