@@ -562,14 +562,16 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
 }
 
 // ---- grouped (mixture-of-experts) GEMM: the 128x256 tile, so expert segments are aligned to AA_MOE_ALIGN = 128 rows
-template <bool A_T, bool B_N, int GRP>
+// BM = 128 for the row-grouped modes (the expert segments are 128-row aligned); the per-expert weight gradients (mode 2) tile the OUTPUT [N_out, K_in] and may
+// take the 256 x 256 tile (half the LDS traffic and half the epilogues per flop of their short, segment-long contraction): AA_MOE_DW_TILE, A/B in DESIGN section 5
+template <bool A_T, bool B_N, int GRP, int BM = 128, int ILV = 0>
 static int launch_grouped(GemmParams& p, int E, hipStream_t st) {
-    constexpr int BM = 128, BN = 256, WM = 2, WN = 4;
+    constexpr int BN = 256, WM = 2, WN = 4;
     p.tiles_m = aa_cdiv(p.M, BM);
     p.tiles_n = aa_cdiv(p.N, BN);
     p.gm = 4;      // grouped (MoE) launches: rows are expert segments, keep the row-grouped order
     constexpr int lds = 2 * (BM + BN) * BK * 2;
-    auto kern = gemm_kernel<BM, BN, WM, WN, A_T, B_N, true, 0, GRP>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, A_T, B_N, true, ILV, GRP>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -600,6 +602,9 @@ extern "C" int aa_gemm_grouped_bf16(const void* A, const void* B, void* C, int M
     }
     AA_REQUIRE(seg_off != nullptr && a_t && b_n && M % 8 == 0, "aa_gemm_grouped_bf16: mode 2 needs seg_off and the TN layout");
     p.grp_off = seg_off; p.grp_strideC = stride;
+    static int dw_tile = -1;
+    if (dw_tile < 0) { const char* e = getenv("AA_MOE_DW_TILE"); dw_tile = e ? atoi(e) : 256; }      // same-box A/B, 12-layer Qwen3-30B-A3B-geometry step: 157.1 / 157.4 ms vs 159.9 / 160.7 ms at 128
+    if (dw_tile == 256) return launch_grouped<true, true, 2, 256, 1>(p, E, st);
     return launch_grouped<true, true, 2>(p, E, st);
 }
 
