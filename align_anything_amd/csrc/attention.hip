@@ -401,18 +401,23 @@ __device__ __forceinline__ void kv_block_of(const AttnParams& p, int nkvb, int& 
 }
 
 // ================================================================== forward
-// 1-D grid (q_block_of).  256 threads: wave w owns queries q0 + 32w .. +31.
+// 1-D grid (q_block_of).  256 threads: wave w owns queries q0 + 16 QI w .. + 16 QI - 1 (QI blocks of 16 query rows; AA_ATTN_QI, lab: 4 = 64 rows per wave,
+// one workgroup of 256 query rows per CU, one wave per SIMD -- half the LDS fragment bytes and half the tile steps per query row; row results do not depend on QI)
+#ifndef AA_ATTN_QI
+#define AA_ATTN_QI 2
+#endif
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, AA_ATTN_QI == 2 ? 2 : 1) void attn_fwd_kernel(const AttnParams p) {
+    constexpr int QI = AA_ATTN_QI, QROWS = 64 * QI;
     constexpr int KS = HD / 32, DB = HD / 16;
     constexpr int TILE_B = 64 * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nqb = (p.T + 127) / 128;
+    const int nqb = (p.T + QROWS - 1) / QROWS;
     int n, h, hk, qb;
     q_block_of<AA_ATTN_XCD_LOCAL_FWD>(p, nqb, n, h, hk, qb);
-    const int q0 = qb * 128, qw = q0 + wave * 32;
+    const int q0 = qb * QROWS, qw = q0 + wave * 16 * QI;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
     const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
@@ -427,23 +432,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const int trl = tr_lane_base<HD>(g, l15);                // lane part of the transposed-read addresses
 
     // Q fragments (B operand of S^T): lane -> query l15, d = ks*32 + g*8 ..+7
-    bf16x8 qf[2][KS];
+    bf16x8 qf[QI][KS];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
+    for (int qi = 0; qi < QI; ++qi) {
         const int qr = min(qw + qi * 16 + l15, T - 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             qf[qi][ks] = *reinterpret_cast<const bf16x8*>(Qb + (long)qr * p.ldq + ks * 32 + g * 8);
     }
-    f32x4 oacc[2][DB];
+    f32x4 oacc[QI][DB];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
+    for (int qi = 0; qi < QI; ++qi)
 #pragma unroll
         for (int db = 0; db < DB; ++db) oacc[qi][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m2[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+    float m2[QI], lsum[QI];
+#pragma unroll
+    for (int qi = 0; qi < QI; ++qi) { m2[qi] = -INFINITY; lsum[qi] = 0.f; }
 
     const int kv_begin = (start / 64) * 64;
-    const int kv_end = p.causal ? min(T, q0 + 128) : T;
+    const int kv_end = p.causal ? min(T, q0 + QROWS) : T;
     const int ntile = (kv_end - kv_begin + 63) / 64;
     if (ntile > 0) {
         dma.issue(Kb, p.ldk, koff, kv_begin, T, lds0);
@@ -451,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
+    for (int qi = 0; qi < QI; ++qi)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) landed(qf[qi][ks]);
     __syncthreads();
@@ -465,11 +472,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         const char* kt = smem + cur * 2 * TILE_B;
         const char* vt = kt + TILE_B;
         // wave-uniform skip: every key of this tile is after every query of this wave (causal)
-        const bool wave_active = !(p.causal && kv0 > qw + 31) && (qw < T);
+        const bool wave_active = !(p.causal && kv0 > qw + 16 * QI - 1) && (qw < T);
         if (wave_active) {
-            f32x4 sacc[2][4];
+            f32x4 sacc[QI][4];
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi)
+            for (int qi = 0; qi < QI; ++qi)
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) sacc[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
             AT_PRIO_MFMA(1);
@@ -479,16 +486,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 for (int ks = 0; ks < KS; ++ks) {
                     const bf16x8 kf = lds_frag<HD>(kt, kb * 16 + l15, ks * 4 + g);
 #pragma unroll
-                    for (int qi = 0; qi < 2; ++qi)
+                    for (int qi = 0; qi < QI; ++qi)
                         sacc[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], sacc[qi][kb], 0, 0, 0);
                 }
             AT_PRIO_MFMA(0);
             AT_PRIO_VALU(1);
             // masks only where a mask can bite: diagonal tile, left-pad boundary, ragged end (wave-uniform)
             const bool need_mask = (p.causal && kv0 + 63 > qw) || kv0 < start || kv0 + 64 > KT;
-            bf16x8 pf[2][2];
+            bf16x8 pf[QI][2];
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
+            for (int qi = 0; qi < QI; ++qi) {
                 float mx = -INFINITY;
                 if (need_mask) {
                     const int qg = qw + qi * 16 + l15;
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             tr_stream<HD, 1, TILE_B, 0, TR_NBUF>(lds0 + cur * 2 * TILE_B + trl, [&](auto si, auto di, const bf16x8 vf) {
                 constexpr int S = decltype(si)::value, D = decltype(di)::value;
 #pragma unroll
-                for (int qi = 0; qi < 2; ++qi)
+                for (int qi = 0; qi < QI; ++qi)
                     oacc[qi][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qi][S], oacc[qi][D], 0, 0, 0);
             });
             AT_PRIO_MFMA(0);
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     }
     // epilogue: O[q][16db + 4g + r] = oacc / l
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
+    for (int qi = 0; qi < QI; ++qi) {
         const float l = row4_sum(lsum[qi]);
         const int qg = qw + qi * 16 + l15;
         const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -930,7 +937,7 @@ extern "C" int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O,
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O;
     p.lse = lse; p.start = start; p.kvlen = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
-    dim3 grid(aa_cdiv(T, 128) * H * N);
+    dim3 grid(aa_cdiv(T, 64 * AA_ATTN_QI) * H * N);
     const int lds = 4 * 64 * hd * 2;
     if (hd == 128) {
         if ((rc = set_lds(attn_fwd_kernel<128>, lds, "aa_attn_fwd"))) return rc;
