@@ -903,6 +903,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     at_store_rows<DB, true>(p.dV + ((long)n * T + min(kvg, T - 1)) * p.lddv + hk * HD, dvacc, 1.f, kvg < T, g);
 }
 
+#include "attn128.inc"
+
 // ================================================================== C ABI
 static int check_common(const char* fn, int N, int T, int H, int Hkv, int hd) {
     if (!(N > 0 && T > 0 && H > 0 && Hkv > 0 && H % Hkv == 0)) {
@@ -927,6 +929,20 @@ static int set_lds(K kern, int bytes, const char* name) {
     return AA_OK;
 }
 
+// head_dim 128 runs on the one-wave-per-SIMD 32x32x16 kernels of attn128.inc; AA_ATTN128=0 / aa_attn_set_impl(0) keeps the 16x16x32 kernels above
+// (same-box A/B, bisecting; both stay tested).  Bit 0: forward, bit 1: backward.
+static int g_attn_impl = -1;
+static int attn_impl() {
+    if (g_attn_impl < 0) { const char* e = getenv("AA_ATTN128"); g_attn_impl = e ? atoi(e) : 3; }
+    return g_attn_impl;
+}
+extern "C" int aa_attn_set_impl(int impl) {
+    AA_REQUIRE(impl >= 0 && impl <= 3, "aa_attn_set_impl: %d (bit 0 = forward, bit 1 = backward on the 32x32x16 kernels)", impl);
+    g_attn_impl = impl;
+    return AA_OK;
+}
+static bool attn128_enabled() { return (attn_impl() & 1) != 0; }
+
 extern "C" int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse,
                            const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, int N, int T,
                            int H, int Hkv, int hd, int causal, float scale, void* stream) {
@@ -939,7 +955,10 @@ extern "C" int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O,
     p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
     dim3 grid(aa_cdiv(T, 64 * AA_ATTN_QI) * H * N);
     const int lds = 4 * 64 * hd * 2;
-    if (hd == 128) {
+    if (hd == 128 && attn128_enabled()) {
+        if ((rc = set_lds(a128::attn128_fwd_kernel<128>, a128::LDS_FWD, "aa_attn_fwd"))) return rc;
+        hipLaunchKernelGGL(a128::attn128_fwd_kernel<128>, dim3(aa_cdiv(T, 256) * H * N), dim3(256), a128::LDS_FWD, (hipStream_t)stream, p);
+    } else if (hd == 128) {
         if ((rc = set_lds(attn_fwd_kernel<128>, lds, "aa_attn_fwd"))) return rc;
         hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, p);
     } else {

@@ -39,78 +39,115 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const elem_t* __restri
     }
 }
 
-// h <= 512 (per-head q/k norms of Qwen3: head_dim 128 over rows x heads "rows"): one WAVE per row, 4 rows per workgroup
+// h <= 512 (per-head q / k norms of Qwen3: head_dim 128 over tokens x heads "rows").  LPR = lanes per row (the power of two >= h / 8): a wave holds 64 / LPR rows
+// at once and every group walks TWO rows per iteration, so all 64 lanes load 16 bytes and a wave keeps 2 KB in flight (round 3's one-wave-per-row form had 16
+// of 64 lanes active and one 256-byte load in flight per wave at head_dim 128: 391 us for 270 MB = latency-bound at 0.7 TB/s).  The row sum
+// is the same butterfly over the row's lanes as before (the idle lanes contributed zeros), so results are bit-identical.
+template <int LPR>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_small_kernel(const elem_t* __restrict__ x, const elem_t* __restrict__ w,
                                                                 elem_t* __restrict__ y, float* __restrict__ rstd_out, long rows,
                                                                 int h, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int nv = h >> 3;
-    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
-        ev8 v;
-        float ss = 0.f;
-        if (lane < nv) {
-            v = *reinterpret_cast<const ev8*>(x + row * h + lane * 8);
+    constexpr int GPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const bool act = sub < (h >> 3);
+    ev8 wv;
+    if (act) wv = *reinterpret_cast<const ev8*>(w + sub * 8);
+    for (long row0 = (long)blockIdx.x * (2 * GPB) + grp; row0 < rows; row0 += (long)gridDim.x * (2 * GPB)) {
+        ev8 v[2];
+        float ss[2] = {0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = e2f(v[j]); ss += f * f; }
+        for (int u = 0; u < 2; ++u) {
+            const long row = row0 + u * GPB;
+            if (act && row < rows) {
+                v[u] = *reinterpret_cast<const ev8*>(x + row * h + sub * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = e2f(v[u][j]); ss[u] += f * f; }
+            }
         }
-        ss = wave_sum(ss);
-        const float rstd = rsqrtf(ss / (float)h + eps);
-        if (lane == 0 && rstd_out) rstd_out[row] = rstd;
-        if (lane < nv) {
-            const ev8 wv = *reinterpret_cast<const ev8*>(w + lane * 8);
-            ev8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2e(e2f(wv[j]) * ernd(e2f(v[j]) * rstd));
-            *reinterpret_cast<ev8*>(y + row * h + lane * 8) = o;
+        for (int o = LPR / 2; o > 0; o >>= 1) { ss[0] += __shfl_xor(ss[0], o, 64); ss[1] += __shfl_xor(ss[1], o, 64); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long row = row0 + u * GPB;
+            if (row >= rows) continue;
+            const float rstd = rsqrtf(ss[u] / (float)h + eps);
+            if (sub == 0 && rstd_out) rstd_out[row] = rstd;
+            if (act) {
+                ev8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = f2e(e2f(wv[j]) * ernd(e2f(v[u][j]) * rstd));
+                *reinterpret_cast<ev8*>(y + row * h + sub * 8) = o;
+            }
         }
     }
 }
-// backward for h <= 512: one wave per row; every lane keeps the dw partial of its 8 columns over the rows of its wave
+// backward for h <= 512, same row -> lane mapping; every lane keeps the dw partial of its 8 columns over the rows of its group, the groups of a block meet in LDS
+template <int LPR>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_small_kernel(const elem_t* __restrict__ dy, const elem_t* __restrict__ x,
                                                                 const elem_t* __restrict__ w, const float* __restrict__ rstd_in,
                                                                 elem_t* __restrict__ dx, float* __restrict__ dw_part, long rows, int h,
                                                                 int add_to_dx) {
-    __shared__ float part[4][512];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int nv = h >> 3;
+    constexpr int GPB = 256 / LPR;
+    __shared__ float part[GPB][LPR * 8];
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const bool act = sub < (h >> 3);
     float dwacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     ev8 wv;
-    if (lane < nv) wv = *reinterpret_cast<const ev8*>(w + lane * 8);
-    for (long row = (long)blockIdx.x * 4 + wid; row < rows; row += (long)gridDim.x * 4) {
-        const float rstd = rstd_in[row];
-        ev8 xv, gv;
-        float dot = 0.f;
-        if (lane < nv) {
-            xv = *reinterpret_cast<const ev8*>(x + row * h + lane * 8);
-            gv = *reinterpret_cast<const ev8*>(dy + row * h + lane * 8);
+    if (act) wv = *reinterpret_cast<const ev8*>(w + sub * 8);
+    for (long row0 = (long)blockIdx.x * (2 * GPB) + grp; row0 < rows; row0 += (long)gridDim.x * (2 * GPB)) {
+        ev8 xv[2], gv[2], ov[2];
+        float dot[2] = {0.f, 0.f}, rs[2] = {0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = e2f(xv[j]) * rstd, g = e2f(gv[j]);
-                dot += g * e2f(wv[j]) * xh;
-                dwacc[j] += g * ernd(xh);
+        for (int u = 0; u < 2; ++u) {
+            const long row = row0 + u * GPB;
+            if (act && row < rows) {
+                rs[u] = rstd_in[row];
+                xv[u] = *reinterpret_cast<const ev8*>(x + row * h + sub * 8);
+                gv[u] = *reinterpret_cast<const ev8*>(dy + row * h + sub * 8);
+                if (add_to_dx) ov[u] = *reinterpret_cast<const ev8*>(dx + row * h + sub * 8);
             }
         }
-        dot = wave_sum(dot) / (float)h;
-        if (lane < nv) {
-            ev8 o;
-            if (add_to_dx) o = *reinterpret_cast<const ev8*>(dx + row * h + lane * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = e2f(xv[j]) * rstd;
-                float d = rstd * (e2f(gv[j]) * e2f(wv[j]) - xh * dot);
-                if (add_to_dx) d += e2f(o[j]);
-                o[j] = f2e(d);
+        for (int u = 0; u < 2; ++u) {
+            const long row = row0 + u * GPB;
+            if (act && row < rows) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = e2f(xv[u][j]) * rs[u], g = e2f(gv[u][j]);
+                    dot[u] += g * e2f(wv[j]) * xh;
+                    dwacc[j] += g * ernd(xh);
+                }
             }
-            *reinterpret_cast<ev8*>(dx + row * h + lane * 8) = o;
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) { dot[0] += __shfl_xor(dot[0], o, 64); dot[1] += __shfl_xor(dot[1], o, 64); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long row = row0 + u * GPB;
+            if (act && row < rows) {
+                const float dm = dot[u] / (float)h;
+                ev8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = e2f(xv[u][j]) * rs[u];
+                    float d = rs[u] * (e2f(gv[u][j]) * e2f(wv[j]) - xh * dm);
+                    if (add_to_dx) d += e2f(ov[u][j]);
+                    o[j] = f2e(d);
+                }
+                *reinterpret_cast<ev8*>(dx + row * h + sub * 8) = o;
+            }
         }
     }
     if (dw_part) {
-        if (lane < nv)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) part[wid][lane * 8 + j] = dwacc[j];
+        for (int j = 0; j < 8; ++j) part[grp][sub * 8 + j] = act ? dwacc[j] : 0.f;
         __syncthreads();
-        for (int c = threadIdx.x; c < h; c += 256)
-            dw_part[(long)blockIdx.x * h + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+        for (int c = threadIdx.x; c < h; c += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < GPB; ++g) t += part[g][c];
+            dw_part[(long)blockIdx.x * h + c] = t;
+        }
     }
 }
 
@@ -211,9 +248,15 @@ extern "C" int AA_FN(aa_rmsnorm_fwd)(const void* x, const void* w, void* y, floa
     AA_REQUIRE(rows >= 0 && h > 0 && (h & 7) == 0, "aa_rmsnorm_fwd: hidden %d must be a multiple of 8", h);
     if (rows == 0) return AA_OK;
     if (h <= 512) {
-        const long nb = ((long)rows + 3) / 4;
-        hipLaunchKernelGGL(rmsnorm_fwd_small_kernel, dim3((int)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream,
-                           (const elem_t*)x, (const elem_t*)w, (elem_t*)y, rstd, (long)rows, h, eps);
+        hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_RMSF_SMALL(LPR)                                                                                                      \
+    do {                                                                                                                            \
+        const long nb = ((long)rows + 2 * (256 / LPR) - 1) / (2 * (256 / LPR));                                                     \
+        hipLaunchKernelGGL(rmsnorm_fwd_small_kernel<LPR>, dim3((int)(nb < 16384 ? nb : 16384)), dim3(256), 0, st, (const elem_t*)x, \
+                           (const elem_t*)w, (elem_t*)y, rstd, (long)rows, h, eps);                                                 \
+    } while (0)
+        if (h <= 64) LAUNCH_RMSF_SMALL(8); else if (h <= 128) LAUNCH_RMSF_SMALL(16); else if (h <= 256) LAUNCH_RMSF_SMALL(32); else LAUNCH_RMSF_SMALL(64);
+#undef LAUNCH_RMSF_SMALL
         AA_CHECK_LAUNCH("aa_rmsnorm_fwd");
         return AA_OK;
     }
@@ -236,11 +279,17 @@ extern "C" int AA_FN(aa_rmsnorm_bwd)(const void* dy, const void* x, const void* 
     float* part = dw ? ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (h <= 512) {
-        long nb = ((long)rows + 3) / 4;
-        int g2 = (int)(nb < 2048 ? nb : 2048);
-        if (dw && g2 > ws_rows) g2 = ws_rows;
-        hipLaunchKernelGGL(rmsnorm_bwd_small_kernel, dim3(g2), dim3(256), 0, st, (const elem_t*)dy, (const elem_t*)x, (const elem_t*)w, rstd,
-                           (elem_t*)dx, part, (long)rows, h, add_to_dx);
+        int g2 = 0;
+#define LAUNCH_RMSB_SMALL(LPR)                                                                                                          \
+    do {                                                                                                                                \
+        const long nb = ((long)rows + 2 * (256 / LPR) - 1) / (2 * (256 / LPR));                                                         \
+        g2 = (int)(nb < 2048 ? nb : 2048);                                                                                              \
+        if (dw && g2 > ws_rows) g2 = ws_rows;                                                                                           \
+        hipLaunchKernelGGL(rmsnorm_bwd_small_kernel<LPR>, dim3(g2), dim3(256), 0, st, (const elem_t*)dy, (const elem_t*)x, (const elem_t*)w, rstd, \
+                           (elem_t*)dx, part, (long)rows, h, add_to_dx);                                                                \
+    } while (0)
+        if (h <= 64) LAUNCH_RMSB_SMALL(8); else if (h <= 128) LAUNCH_RMSB_SMALL(16); else if (h <= 256) LAUNCH_RMSB_SMALL(32); else LAUNCH_RMSB_SMALL(64);
+#undef LAUNCH_RMSB_SMALL
         if (dw) launch_reduce_rows(part, g2, h, dw, st);
         AA_CHECK_LAUNCH("aa_rmsnorm_bwd");
         return AA_OK;

@@ -195,14 +195,25 @@ extern "C" int AA_FN(aa_moe_combine)(const void* yp, const int* pos, const void*
 }
 
 // backward of the weighted combine: dYp[pos[t, j], :] = w[t, j] * dout[t, :] ;  dw[t, j] = <dout[t, :], Yp[pos[t, j], :]>
-// one wave per (token, slot); pad rows of dYp must have been zeroed by the caller.
+// one wave per (token, slot).  Rows of dYp that no pair writes (the pad rows of the expert segments) carry no gradient: with `src_row` (the plan's row ->
+// token table, -1 = pad) the launch has one more wave per layout row that zeroes those itself -- round 3 had a torch memset of the WHOLE [cap, h] buffer in
+// front of every call (at::native::FillFunctor<bf16> in the product path); with src_row == null the caller must have zeroed them.
 __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(const elem_t* __restrict__ dout, const elem_t* __restrict__ yp,
                                                               const int* __restrict__ pos, const elem_t* __restrict__ w,
                                                               elem_t* __restrict__ dyp, float* __restrict__ dw, long rows, int k,
-                                                              int h) {
+                                                              int h, const int* __restrict__ src_row, long cap_rows) {
     const int lane = threadIdx.x & 63;
     const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pair >= rows * k) return;
+    if (pair >= rows * k) {
+        const long r = pair - rows * k;
+        if (src_row != nullptr && r < cap_rows && src_row[r] < 0) {
+            ev8 z;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) z[q] = f2e(0.f);
+            for (int c = lane * 8; c < h; c += 512) *reinterpret_cast<ev8*>(dyp + r * h + c) = z;
+        }
+        return;
+    }
     const long t = pair / k;
     const long r = pos[pair];
     if (r < 0) {                                   // slot without a row (see moe_combine_kernel): no gradient row, zero weight gradient
@@ -223,11 +234,13 @@ __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(const elem_t* __re
     if (lane == 0) dw[pair] = dot;
 }
 extern "C" int AA_FN(aa_moe_combine_bwd)(const void* dout, const void* yp, const int* pos, const void* weights, void* dyp,
-                                         float* dweights, long rows, int k, int h, void* stream) {
+                                         float* dweights, long rows, int k, int h, const int* src_row, long cap_rows, void* stream) {
     AA_REQUIRE(h > 0 && (h & 7) == 0 && k > 0, "aa_moe_combine_bwd: hidden %d must be a multiple of 8", h);
-    if (rows == 0) return AA_OK;
-    hipLaunchKernelGGL(moe_combine_bwd_kernel, dim3((int)((rows * k + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)dout,
-                       (const elem_t*)yp, pos, (const elem_t*)weights, (elem_t*)dyp, dweights, rows, k, h);
+    AA_REQUIRE(src_row == nullptr || cap_rows >= 0, "aa_moe_combine_bwd: cap_rows %ld", cap_rows);
+    const long waves = rows * k + (src_row ? cap_rows : 0);
+    if (waves == 0) return AA_OK;
+    hipLaunchKernelGGL(moe_combine_bwd_kernel, dim3((int)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)dout,
+                       (const elem_t*)yp, pos, (const elem_t*)weights, (elem_t*)dyp, dweights, rows, k, h, src_row, cap_rows);
     AA_CHECK_LAUNCH("aa_moe_combine_bwd");
     return AA_OK;
 }

@@ -1536,7 +1536,7 @@ class Qwen3MoeStack:
             if 'lay' in plan:
                 d_n2, dw = self._ep_experts_bwd(L, dres, plan, xp, gu, act, w, Mp)
             else:
-                dyp, dw = ops.moe_combine_bwd(dres, yp, plan['pos'], w)
+                dyp, dw = ops.moe_combine_bwd(dres, yp, plan['pos'], w, src=plan['src'])
                 d_n2 = ops.moe_combine(self._local_experts_bwd(L, dyp, plan, xp, gu, act), plan['pos'], None, Mp)
             dlogits = ops.moe_route_bwd(probs, idx, dw, c['norm_topk_prob'], x.dtype)
             if E % 64:   # the expert count is the contraction dim here: zero-pad it for small (test-size) routers

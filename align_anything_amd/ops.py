@@ -560,12 +560,15 @@ def moe_combine(yp, pos, w, rows, residual=None):
     return out
 
 
-def moe_combine_bwd(dout, yp, pos, w):
+def moe_combine_bwd(dout, yp, pos, w, src=None):
+    """src = the plan's row -> token table (-1 = pad row): the kernel zeroes the pad rows of dyp itself; without it the whole buffer is memset first."""
     rows, k = pos.shape
-    dyp = torch.zeros_like(yp)                       # pad rows of every expert segment carry no gradient
+    dyp = torch.empty_like(yp) if src is not None else torch.zeros_like(yp)      # pad rows of every expert segment carry no gradient
     dw = torch.empty((rows, k), dtype=f32, device=yp.device)
+    if src is not None and src.numel() != yp.shape[0]:
+        raise RuntimeError(f'moe_combine_bwd: src has {src.numel()} rows, the layout {yp.shape[0]}')
     call('aa_moe_combine_bwd' + _sfx(yp, 'moe_combine_bwd'), dout.data_ptr(), yp.data_ptr(), pos.data_ptr(), w.data_ptr(), dyp.data_ptr(),
-         dw.data_ptr(), rows, k, yp.shape[1], stream())
+         dw.data_ptr(), rows, k, yp.shape[1], _p(src), yp.shape[0], stream())
     return dyp, dw
 
 

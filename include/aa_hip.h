@@ -119,6 +119,10 @@ int aa_window_kl(const float* pol_logp, const float* ref_logp, int rows, float d
 /* trainers/text_to_text/sft.py:94-97 (hf ForCausalLMLoss): loss = -mean(logp) over the label rows of the window, dlogp = -1/rows (pad rows 0) */
 int aa_sft_loss_fwd_bwd(const float* logp, int rows, int rows_pad, float* loss_out, float* dlogp, void* stream);
 
+/* head_dim-128 attention implementation: bit 0 = forward, bit 1 = backward on the one-wave-per-SIMD v_mfma_f32_32x32x16_bf16 kernels (csrc/attn128.inc;
+ * default 3, env AA_ATTN128), 0 = the 16x16x32 kernels every other head_dim uses.  Process-wide; for same-box A/B runs and tests of both paths. */
+int aa_attn_set_impl(int impl);
+
 /* ---- transformer blocks (what model(**batch).logits executes, dpo.py:128) -------------------- */
 /* torch nn.Linear / its backward: C[M,N] (+)= op(A) op(B), fp32 accumulate, fused bias/act/residual.
  * K % 64 == 0 (zero-pad), N % 4 == 0. */
@@ -214,8 +218,10 @@ int aa_moe_route_bwd(const float* probs, const int* idx, const float* dweights, 
 int aa_moe_gather(const void* x, const int* src_row, void* out, long rows_out, int h, void* stream);
 int aa_moe_combine(const void* yp, const int* pos, const void* weights, const void* residual, void* out, long rows, int k, int h,
                    void* stream);
+/* dyp rows no (token, slot) pair maps to carry no gradient: src_row (aa_moe_plan's row -> token table, -1 = pad) + cap_rows make the launch zero them;
+ * src_row == NULL: the caller has zeroed dyp. */
 int aa_moe_combine_bwd(const void* dout, const void* yp, const int* pos, const void* weights, void* dyp, float* dweights,
-                       long rows, int k, int h, void* stream);
+                       long rows, int k, int h, const int* src_row, long cap_rows, void* stream);
 /* Expert-major layout of a routing decision, computed on the device (no host read): counts[E], segment offsets off[E+1] aligned to
  * `align` rows (128 = the row tile of aa_gemm_grouped_*), pos[rows*k] (row of every (token, slot) pair, stable in token order),
  * src[cap_rows] (token of every row, -1 = pad) and tile_expert[cap_rows / align] (-1 beyond the rows in use).

@@ -95,7 +95,7 @@ int aa_moe_gather_f32(const void* x, const int* src_row, void* out, long rows_ou
 int aa_moe_combine_f32(const void* yp, const int* pos, const void* weights, const void* residual, void* out, long rows, int k, int h,
                        void* stream);
 int aa_moe_combine_bwd_f32(const void* dout, const void* yp, const int* pos, const void* weights, void* dyp, float* dweights,
-                           long rows, int k, int h, void* stream);
+                           long rows, int k, int h, const int* src_row, long cap_rows, void* stream);
 
 /* fp32 twin of aa_gemm_grouped_bf16 */
 int aa_gemm_grouped_f32(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int flags,

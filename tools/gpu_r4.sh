@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round-4 GPU driver: `gpurun -- bash tools/gpu_r4.sh <stage> [<stage> ...]`; every stage writes under gpurun_out/ (merged back).
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export PYTHONPATH=$PWD
+R=$PWD
+for stage in "$@"; do
+  echo "=== stage $stage  $(date +%T)"
+  case $stage in
+    attn_check)      # attn128 kernels vs the fp32 reference and the 16x16x32 kernels, timings on the bench block
+      timeout 400 python tools/attn128_check.py $ATTN_ARGS > gpurun_out/r04_attn128_check.txt 2>&1; tail -30 gpurun_out/r04_attn128_check.txt ;;
+    attn_variants)   # the same check per lab library in AA_ATTN_LIBS (numerics only unless ATTN_VAR_ARGS says otherwise)
+      for lib in ${AA_ATTN_LIBS:-libaa_hip_thr0.so}; do
+        echo "--- $lib"; AA_HIP_LIB=$R/align_anything_amd/$lib timeout 300 python tools/attn128_check.py ${ATTN_VAR_ARGS:---no-time} --out r04_attn128_$lib.json > gpurun_out/r04_attn128_$lib.txt 2>&1; tail -14 gpurun_out/r04_attn128_$lib.txt | cut -c1-400
+      done ;;
+    attn_pmc)
+      bash tools/attn128_pmc.sh $ATTN_ARGS 2>&1 | tail -60 ;;
+    attn_tests)      # the existing attention / model suites on the new kernels
+      timeout 600 python -m pytest tests/test_attention_gpu.py tests/test_bench_geometry_gpu.py tests/test_model_gpu.py tests/test_twin_gpu.py -m gpu -q -p no:cacheprovider > gpurun_out/r04_pytest_attn.log 2>&1; tail -8 gpurun_out/r04_pytest_attn.log ;;
+    moe_tests)
+      timeout 600 python -m pytest tests/test_elementwise_gpu.py tests/test_qwen3moe_gpu.py -m gpu -q -p no:cacheprovider > gpurun_out/r04_pytest_moe.log 2>&1; tail -8 gpurun_out/r04_pytest_moe.log ;;
+    moe_bench)
+      timeout 400 python tools/bench_qwen3moe.py --steps 4 --warmup 2 > gpurun_out/r04_bench_qwen3moe.json 2> gpurun_out/r04_bench_qwen3moe.err; cat gpurun_out/r04_bench_qwen3moe.json | cut -c1-1500; tail -3 gpurun_out/r04_bench_qwen3moe.err ;;
+    moe_prof)
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r04_moe_prof && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_moe_prof -o p -- python $R/tools/bench_qwen3moe.py --steps 3 --warmup 1 > $R/gpurun_out/r04_bench_qwen3moe_under_rocprof.json 2> $R/gpurun_out/r04_moe_prof.err )
+      f=$(find gpurun_out/r04_moe_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r04_qwen3moe_kernel_stats.csv && head -30 "$f" | cut -c1-200
+      find gpurun_out/r04_moe_prof -name "*kernel_trace.csv" -delete; tail -3 gpurun_out/r04_moe_prof.err ;;
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/r04_pytest.log 2>&1; tail -15 gpurun_out/r04_pytest.log ;;
+    bench)
+      timeout 1500 python bench.py --steps 8 --warmup 2 > gpurun_out/r04_bench.json 2> gpurun_out/r04_bench.err; tail -c 1500 gpurun_out/r04_bench.json; tail -5 gpurun_out/r04_bench.err ;;
+    bench_quick)     # headline step without the PMC passes / CPU leg / batch sweep
+      timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r04_bench_quick.json 2> gpurun_out/r04_bench_quick.err; python -c "import json; d=json.load(open('gpurun_out/r04_bench_quick.json')); print('ms/step', d['ms_per_step'], 'pairs/s', d['value'], 'gemm frac', d['roofline']['frac'])" || tail -5 gpurun_out/r04_bench_quick.err ;;
+    bench_ab)        # headline step with AA_ATTN128 = 0 / 3, alternating, same box
+      for rep in 1 2; do for v in 0 3; do
+        AA_ATTN128=$v timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r04_bench_attn$v.json 2> gpurun_out/r04_bench_attn$v.err
+        python -c "import json; d=json.load(open('gpurun_out/r04_bench_attn$v.json')); print('AA_ATTN128=$v rep $rep', round(d['ms_per_step'],2), round(d['value'],4))" || tail -3 gpurun_out/r04_bench_attn$v.err
+      done; done ;;
+    prof)
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r04_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_prof -o p -- python $R/bench.py --steps 3 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > $R/gpurun_out/r04_bench_under_rocprof.json 2> $R/gpurun_out/r04_prof.err )
+      f=$(find gpurun_out/r04_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r04_dpo7b_kernel_stats.csv && head -25 "$f" | cut -c1-220
+      find gpurun_out/r04_prof -name "*kernel_trace.csv" -delete ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
+echo "=== done $(date +%T)"
