@@ -615,17 +615,18 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
 
 // ================================================================== backward: dQ
 // same structure / block order as forward; dQ^T[d][q] += K^T[d][kv] * dS^T[kv][q]
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
+// NW waves of 32 query rows share one K / V tile stream (4 shipped; 8 was measured, see attn_bwd_impl).
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParams p) {
     constexpr int KS = HD / 32, DB = HD / 16;
-    constexpr int TILE_B = 64 * HD * 2;
+    constexpr int TILE_B = 64 * HD * 2, QROWS = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nqb = (p.T + 127) / 128;
+    const int nqb = (p.T + QROWS - 1) / QROWS;
     int n, h, hk, qb;
     q_block_of<true>(p, nqb, n, h, hk, qb);
-    const int q0 = qb * 128, qw = q0 + wave * 32;
+    const int q0 = qb * QROWS, qw = q0 + wave * 32;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
     const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     const bf16_t* Kb = p.K + (long)n * T * p.ldk + hk * HD;
     const bf16_t* Vb = p.V + (long)n * T * p.ldv + hk * HD;
     const float c2 = p.scale * LOG2E_F;
-    DmaLane<HD, 64, 4> dma;
+    DmaLane<HD, 64, NW> dma;
     dma.init(wave, lane);
     const auto koff = dma.offsets(p.ldk), voff = dma.offsets(p.ldv);
     const int lds0 = (int)(uintptr_t)smem;
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
         for (int db = 0; db < DB; ++db) dqacc[qi][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int kv_begin = (start / 64) * 64;
-    const int kv_end = p.causal ? min(T, q0 + 128) : T;
+    const int kv_end = p.causal ? min(T, q0 + QROWS) : T;
     const int ntile = (kv_end - kv_begin + 63) / 64;
     if (ntile > 0) {
         dma.issue(Kb, p.ldk, koff, kv_begin, T, lds0);
@@ -768,18 +769,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 // first).  Wave w owns keys kv0 + 16w .. +15 and loops over 64-query tiles (and over the H/Hkv query heads sharing this kv head).
 //   S[q][kv] = Q K^T, dP[q][kv] = dO V^T          (lane: kv = lane&15, q = 16qb + 4g + r)
 //   dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
+// NW waves of 16 keys share one Q / dO tile stream.
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
     constexpr int KS = HD / 32, DB = HD / 16;
-    constexpr int TILE_B = 64 * HD * 2;
+    constexpr int TILE_B = 64 * HD * 2, KVB = 16 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q tile | dO tile] + [2][64 lse | 64 delta]
     float* stat = reinterpret_cast<float*>(smem + 4 * TILE_B);
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int group = p.H / p.Hkv;
     int n, hk, kvb;
-    kv_block_of(p, (p.T + 63) / 64, n, hk, kvb);
-    const int kv0 = kvb * 64, kvw = kv0 + wave * 16;
+    kv_block_of(p, (p.T + KVB - 1) / KVB, n, hk, kvb);
+    const int kv0 = kvb * KVB, kvw = kv0 + wave * 16;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
     const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     const bf16_t* Vb = p.V + (long)n * T * p.ldv + hk * HD;
     const float c2 = p.scale * LOG2E_F;
     const int kvg = kvw + l15;
-    DmaLane<HD, 64, 4> dma;
+    DmaLane<HD, 64, NW> dma;
     dma.init(wave, lane);
     const auto qoff = dma.offsets(p.ldq), dooff = dma.offsets(p.lddo);
     const int lds0 = (int)(uintptr_t)smem;
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     const int q_begin = p.causal ? (kv0 / 64) * 64 : 0;
     const int ntq = (T - q_begin + 63) / 64;
     const int total = ntq * group;  // iteration = (head in group, q tile)
-    const bool kv_valid_block = kv0 + 63 >= start;  // some key of this block can be attended
+    const bool kv_valid_block = kv0 + KVB - 1 >= start;  // some key of this block can be attended
 
     // The tile's 64 LSE and 64 delta values travel by DMA as well (wave 0 / wave 1, one dword per lane): a register round trip
     // would put `s_waitcnt vmcnt(0)` -- the whole prefetch -- in front of the ds_write at the top of every iteration.
@@ -988,19 +990,22 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
     hipStream_t st = (hipStream_t)stream;
     const long groups = (long)N * T * H;
     const int lds = 4 * 64 * hd * 2;
-    const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
     if (hd == 128) {
+        // NW = 8 (one 8-wave workgroup per CU sharing the tile stream) measured 1356 us on the bench block against ~1200-1340 for two independent 4-wave
+        // workgroups per CU: what it saves in LDS-DMA pieces it loses in overlap across the per-tile barrier (profiles/r04_attn128_anatomy.txt, section 6)
+        const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(aa_cdiv(groups * 16, 256)), dim3(256), 0, st, p);
-        if ((rc = set_lds(attn_bwd_dq_kernel<128>, lds, "aa_attn_bwd"))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), lds, st, p);
-        if ((rc = set_lds(attn_bwd_dkv_kernel<128>, lds + 1024, "aa_attn_bwd"))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gkv, dim3(256), lds + 1024, st, p);
+        if ((rc = set_lds(attn_bwd_dq_kernel<128, 4>, lds, "aa_attn_bwd"))) return rc;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 4>), gq, dim3(256), lds, st, p);
+        if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4>, lds + 1024, "aa_attn_bwd"))) return rc;
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4>), gkv, dim3(256), lds + 1024, st, p);
     } else {
+        const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
         hipLaunchKernelGGL(attn_delta_kernel<64>, dim3(aa_cdiv(groups * 8, 256)), dim3(256), 0, st, p);
-        if ((rc = set_lds(attn_bwd_dq_kernel<64>, lds, "aa_attn_bwd"))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), lds, st, p);
-        if ((rc = set_lds(attn_bwd_dkv_kernel<64>, lds + 1024, "aa_attn_bwd"))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gkv, dim3(256), lds + 1024, st, p);
+        if ((rc = set_lds(attn_bwd_dq_kernel<64, 4>, lds, "aa_attn_bwd"))) return rc;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 4>), gq, dim3(256), lds, st, p);
+        if ((rc = set_lds(attn_bwd_dkv_kernel<64, 4>, lds + 1024, "aa_attn_bwd"))) return rc;
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 4>), gkv, dim3(256), lds + 1024, st, p);
     }
     AA_CHECK_LAUNCH("aa_attn_bwd");
     return AA_OK;
