@@ -24,6 +24,17 @@ for stage in "$@"; do
     moe_prof)
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r04_moe_prof && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_moe_prof -o p -- python $R/tools/bench_qwen3moe.py --steps 3 --warmup 1 > $R/gpurun_out/r04_bench_qwen3moe_under_rocprof.json 2> $R/gpurun_out/r04_moe_prof.err )
       f=$(find gpurun_out/r04_moe_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r04_qwen3moe_kernel_stats.csv && head -30 "$f" | cut -c1-200
+      t=$(find gpurun_out/r04_moe_prof -name "*kernel_trace.csv" | head -1)
+      [ -n "$t" ] && python3 - "$t" <<'PY' > gpurun_out/r04_moe_trace_summary.txt
+import csv, sys, collections
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    d[r['Kernel_Name'].split('(')[0][-60:]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:25]:
+    s = sorted(v)
+    print(f'{k:62s} n {len(v):4d} total {sum(v) / 1e3:8.2f} ms  p10 {s[len(s) // 10]:9.1f}  p50 {s[len(s) // 2]:9.1f}  p90 {s[(9 * len(s)) // 10]:9.1f}  max {s[-1]:10.1f} us')
+PY
+      cat gpurun_out/r04_moe_trace_summary.txt | cut -c1-200
       find gpurun_out/r04_moe_prof -name "*kernel_trace.csv" -delete; tail -3 gpurun_out/r04_moe_prof.err ;;
     tests)
       timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/r04_pytest.log 2>&1; tail -15 gpurun_out/r04_pytest.log ;;
