@@ -586,7 +586,7 @@ static int launch_grouped(GemmParams& p, int E, hipStream_t st) {
 extern "C" int aa_gemm_grouped_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc,
                                     int flags, int mode, const int* tile_expert, const int* seg_off, long stride, int E,
                                     void* stream) {
-    AA_REQUIRE(mode == 1 || mode == 2, "aa_gemm_grouped_bf16: mode %d (1 = rows grouped, 2 = contraction grouped)", mode);
+    AA_REQUIRE(mode >= 1 && mode <= 3, "aa_gemm_grouped_bf16: mode %d (1 = rows grouped, 2 = contraction grouped, 3 = rows grouped in 256-aligned segments)", mode);
     AA_REQUIRE(M > 0 && N > 0 && E > 0 && N % 8 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0,
                "aa_gemm_grouped_bf16: bad shape M=%d N=%d E=%d", M, N, E);
     const bool a_t = flags & AA_GEMM_A_T, b_n = flags & AA_GEMM_B_N;
@@ -594,10 +594,19 @@ extern "C" int aa_gemm_grouped_bf16(const void* A, const void* B, void* C, int M
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.flags = flags; p.act = AA_ACT_NONE;
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 1) {
+    if (mode == 1 || mode == 3) {
         AA_REQUIRE(tile_expert != nullptr && !a_t && K > 0 && K % BK == 0 && M % 128 == 0,
                    "aa_gemm_grouped_bf16: mode 1 needs tile_expert, A row-major, K %% 64 == 0, M %% 128 == 0 (K=%d M=%d)", K, M);
         p.grp_tile_expert = tile_expert; p.grp_strideB = stride;
+        // segments aligned to 256 rows (ops.MOE_ALIGN) run on gemm4's 256 x 256 one-wave-per-SIMD tile when the shape fits it: 742 / 660 / 683 TFLOP/s on the routed rows
+        // of the Qwen3-30B-A3B layer (gate_up, down, down dX) against 563 / 463 / 502 for the 128 x 256 8-wave kernel below (profiles/r04_moe_gemm4_grouped.txt).
+        // AA_MOE_GEMM4=0 keeps the 8-wave kernel (same-box A/B).  Mode 3 is the caller's promise that no 256-row tile straddles two experts.
+        static int g4 = -1;
+        if (g4 < 0) { const char* e = getenv("AA_MOE_GEMM4"); g4 = e ? atoi(e) : 1; }
+        if (g4 && mode == 3 && M % 256 == 0) {
+            const int rc = aa_gemm4_grouped(p, b_n, st);
+            if (rc != 1) return rc;
+        }
         return b_n ? launch_grouped<false, true, 1>(p, E, st) : launch_grouped<false, false, 1>(p, E, st);
     }
     AA_REQUIRE(seg_off != nullptr && a_t && b_n && M % 8 == 0, "aa_gemm_grouped_bf16: mode 2 needs seg_off and the TN layout");

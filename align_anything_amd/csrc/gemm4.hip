@@ -82,6 +82,16 @@ __device__ __forceinline__ void G4_DMA_PIECE(const unsigned (&offA)[NP], const u
     }
 }
 
+// GRP (mixture-of-experts rows, gemm.hip GRP 1 on this tile): expert segments aligned to BM = 256 rows (aa_moe_plan align = 256; its tile table has one
+// entry per 128 rows, both halves of a tile agree); a tile without an expert is zero-filled
+__device__ __forceinline__ void g4_zero_tile(const GemmParams& p, int m0, int n0) {
+    bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+    for (int i = threadIdx.x; i < BM * (BN / 8); i += NW * 64) {
+        const int r = i / (BN / 8), c = (i % (BN / 8)) * 8;
+        *reinterpret_cast<f32x4*>(C + (long)(m0 + r) * p.ldc + n0 + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // XCD-aware bijective remap of the dispatch position, then grouped tile order (identical to gemm_kernel)
 __device__ __forceinline__ void g4_map_tile(const GemmParams& p, int& m0, int& n0) {
     const int nwg = p.tiles_m * p.tiles_n;
@@ -128,7 +138,7 @@ __device__ unsigned long long g4_timing[8 * 16384];
 // PLAIN (EPI != 0): bf16 C = A * B with no bias / activation / accumulate and M, N multiples of the tile (every forward, dX and
 // dW GEMM of the 7B decoder stack): the epilogue is straight-line 16-byte stores, and -- its own instantiation -- shares no
 // registers with the general epilogue, whose 256-value fan-out would otherwise make the compiler spill accumulators.
-template <bool A_T, bool B_N, int EPI>
+template <bool A_T, bool B_N, int EPI, bool GRP = false>
 __global__ __launch_bounds__(NW * 64, 1)
 void gemm4_kernel(const GemmParams p) {
     // EPI: 0 = general epilogue; 1 = plain bf16 store; 2 = + residual add (o / down projections); 3 = rotary embedding on the q / k
@@ -153,6 +163,11 @@ void gemm4_kernel(const GemmParams p) {
     const char* baseB;
     if constexpr (GLU_FWD) baseB = reinterpret_cast<const char*>(p.B + (long)(n0 >> 1) * p.ldb);
     else baseB = reinterpret_cast<const char*>(B_N ? p.B + n0 : p.B + (long)n0 * p.ldb);
+    if constexpr (GRP) {              // this tile's expert (aa_moe_plan's table, one entry per 128 rows; uniform per workgroup -> scalar load) selects the weight matrix
+        const int e = p.grp_tile_expert[m0 / 128];
+        if (e < 0) { g4_zero_tile(p, m0, n0); return; }
+        baseB += (long)e * p.grp_strideB * 2;
+    }
     unsigned offA[NP], offB[NP];
     long stepA, stepB;
     const int kcu = (lane & 3) ^ (((lane >> 5) & 1) << 1);
@@ -392,7 +407,7 @@ __device__ __forceinline__ void G4NT_DMA_PIECE(unsigned v, const char* src) {
     }
 }
 
-template <int EPI>
+template <int EPI, bool GRP = false>
 __global__ __launch_bounds__(NW * 64, 1)
 void gemm4nt_kernel(const GemmParams p) {
     constexpr bool PLAIN = EPI != 0;
@@ -411,6 +426,11 @@ void gemm4nt_kernel(const GemmParams p) {
     const char* baseB;
     if constexpr (GLU_FWD) baseB = reinterpret_cast<const char*>(p.B + (long)(n0 >> 1) * p.ldb);
     else baseB = reinterpret_cast<const char*>(p.B + (long)n0 * p.ldb);
+    if constexpr (GRP) {
+        const int e = p.grp_tile_expert[m0 / 128];
+        if (e < 0) { g4_zero_tile(p, m0, n0); return; }
+        baseB += (long)e * p.grp_strideB * 2;
+    }
     unsigned offA[NP8], offB[NP8];
     {
         const int rr = wave * 8 + (lane >> 3);                 // row of piece 0; piece j is 32 rows further: (row >> 1) & 7 unchanged
@@ -581,6 +601,27 @@ int launch4(GemmParams& p, hipStream_t st) {
     return AA_OK;
 }
 
+// mixture-of-experts rows on the plain epilogue: forward (NT) and dX (NN)
+template <bool B_N>
+int launch4_grouped(GemmParams& p, hipStream_t st) {
+    constexpr int lds = !B_N ? NT_LDS : NSLOT * SLOT;
+    void (*kern)(const GemmParams);
+    if constexpr (!B_N) kern = gemm4nt_kernel<1, true>;
+    else kern = gemm4_kernel<false, true, 1, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            aa_set_error("aa_gemm_grouped_bf16 (4-wave tile): cannot reserve %d B LDS: %s", lds, hipGetErrorString(e));
+            return AA_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), lds, st, p);
+    AA_CHECK_LAUNCH("aa_gemm_grouped_bf16");
+    return AA_OK;
+}
+
 template <int EPI>
 int launch4_layout(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
     if constexpr (EPI == 5) {          // SwiGLU backward rides on the dX (NN) GEMM of the down projection
@@ -621,6 +662,18 @@ int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st) {
     if (plain) return launch4_layout<1>(p, a_t, b_n, st);
     if (resid) return launch4_layout<2>(p, a_t, b_n, st);
     return launch4_layout<0>(p, a_t, b_n, st);
+}
+
+// Grouped (mixture-of-experts) rows: C[cap, N] = A[cap, K] op(B[e]) with e = p.grp_tile_expert[row / 256], expert segments aligned to 256 rows (the caller's
+// promise: aa_moe_plan with align 256).  Returns 1 when the shape does not fit the tile (the caller then runs the 128 x 256 8-wave kernel).
+int aa_gemm4_grouped(GemmParams& p, bool b_n, hipStream_t st) {
+    if (p.M % BM || p.N % BN || !aa_gemm4_supports(p.K) || (p.ldc & 7) || ((uintptr_t)p.C & 15) || p.bias || p.residual || p.act != AA_ACT_NONE ||
+        (p.flags & ~(AA_GEMM_B_N)) != 0 || !p.grp_tile_expert)
+        return 1;
+    p.tiles_m = p.M / BM;
+    p.tiles_n = p.N / BN;
+    p.gm = 4;
+    return b_n ? launch4_grouped<true>(p, st) : launch4_grouped<false>(p, st);
 }
 
 // Fused epilogues (p.fuse = AA_FUSE_*).  Returns 1 when the shape does not qualify (the caller then runs the unfused pair of kernels):

@@ -140,13 +140,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Params p) {
 extern "C" int aa_gemm_grouped_f32(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc,
                                    int flags, int mode, const int* tile_expert, const int* seg_off, long stride, int E,
                                    void* stream) {
-    AA_REQUIRE(mode == 1 || mode == 2, "aa_gemm_grouped_f32: mode %d (1 = rows grouped, 2 = contraction grouped)", mode);
+    AA_REQUIRE(mode >= 1 && mode <= 3, "aa_gemm_grouped_f32: mode %d (1 = rows grouped, 2 = contraction grouped, 3 = rows grouped in 256-aligned segments)", mode);
     AA_REQUIRE(M > 0 && N > 0 && E > 0 && (lda & 3) == 0 && (ldb & 3) == 0, "aa_gemm_grouped_f32: bad shape M=%d N=%d E=%d", M, N, E);
     const bool a_t = flags & AA_GEMM_A_T, b_n = flags & AA_GEMM_B_N;
     GemmF32Params p{(const float*)A, (const float*)B, (float*)C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, AA_ACT_NONE, flags,
                     tile_expert, seg_off, stride};
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 1) {
+    if (mode == 1 || mode == 3) {
         AA_REQUIRE(tile_expert != nullptr && !a_t && K % FBK == 0 && M % FBM == 0, "aa_gemm_grouped_f32: mode 1 needs tile_expert, A row-major, M %% 128 == 0");
         const dim3 grid(aa_cdiv(N, FBN), M / FBM);
         if (b_n) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1>), grid, dim3(256), 0, st, p);

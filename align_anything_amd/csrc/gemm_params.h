@@ -101,3 +101,4 @@ bool aa_gemm4_supports(int K);      // the 4-slot ring walks K in trips of 128
 int aa_gemm4_dispatch(GemmParams& p, bool a_t, bool b_n, hipStream_t st);
 // fused-epilogue launches of the same kernel (p.fuse); 1 = shape does not qualify, run the unfused kernels
 int aa_gemm4_fused(GemmParams& p, hipStream_t st);
+int aa_gemm4_grouped(GemmParams& p, bool b_n, hipStream_t st);   // MoE rows on the 256 x 256 one-wave-per-SIMD tile (segments aligned to 256 rows); 1 = shape does not fit

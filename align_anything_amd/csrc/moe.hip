@@ -251,7 +251,7 @@ extern "C" int AA_FN(aa_moe_combine_bwd)(const void* dout, const void* yp, const
 //   pos[pair] = off[e] + rank of the pair among expert e's pairs in (token, slot) order (stable); pairs whose idx is outside [0, E) are in no
 //   segment and their pos is left as the caller initialised it (-1 for the rows of the capacity-padded exchange that carry no token);
 //   src[row] = token of the pair stored at that row, -1 for pad rows / rows beyond off[E];
-//   tile_expert[t] = expert owning rows [t*align, (t+1)*align), -1 beyond off[E].
+//   tile_expert[t] = expert owning rows [t*tg, (t+1)*tg), -1 beyond off[E]; tg = 128 when align is a multiple of 128 (256: the gemm4 tile), else align.
 // One workgroup per expert counts, then scans all pairs with ballots (E x rows*k reads; E <= 1024) and writes its rows.
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 __global__ __launch_bounds__(256) void moe_count_kernel(const int* __restrict__ idx, long npairs, int* __restrict__ counts) {
@@ -335,10 +335,11 @@ __global__ __launch_bounds__(256) void moe_plan_kernel(const int* __restrict__ i
         base += tot;
     }
     for (int r = my_cnt + threadIdx.x; r < seg; r += 256) src[o0 + r] = -1;           // pad rows of the segment
-    for (int t = threadIdx.x; t < seg / align; t += 256) tile_expert[o0 / align + t] = e;
+    const int tg = (align % 128 == 0) ? 128 : align;     // rows per table entry: 128 for every alignment the grouped GEMMs take (their tiles are 128 or 256 rows)
+    for (int t = threadIdx.x; t < seg / tg; t += 256) tile_expert[o0 / tg + t] = e;
     if (e == E - 1) {                                                                   // everything beyond the last segment
         for (long r = o0 + seg + threadIdx.x; r < cap_rows; r += 256) src[r] = -1;
-        for (long t = (o0 + seg) / align + threadIdx.x; t < cap_rows / align; t += 256) tile_expert[t] = -1;
+        for (long t = (o0 + seg) / tg + threadIdx.x; t < cap_rows / tg; t += 256) tile_expert[t] = -1;
     }
 }
 extern "C" int aa_moe_plan(const int* idx, long rows, int k, int E, int align, long cap_rows, int* counts, int* off, int* pos, int* src,

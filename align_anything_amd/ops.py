@@ -488,7 +488,10 @@ def moe_route_bwd(probs, idx, dw, norm_topk, dtype):
     return dlogits
 
 
-MOE_ALIGN = 128   # row tile of the grouped GEMM = alignment of the expert segments
+# alignment of the expert segments = the largest row tile of the grouped GEMMs: 256 (the row-grouped launches run on gemm4's 256-row tile, csrc/gemm4.hip GRP;
+# 25 % pad rows at 512 rows per expert against 12.5 % at 128, and still 6.5 % faster per step); AA_MOE_GEMM4=0: 128, the 8-wave kernel's tile (same-box A/B)
+MOE_ALIGN = 128 if os.environ.get('AA_MOE_GEMM4', '1') == '0' else 256
+MOE_TILE_ROWS = 128     # rows per entry of the plan's tile table, whatever the alignment
 
 
 def moe_plan(idx, E, align=MOE_ALIGN, allow_invalid=False):
@@ -501,8 +504,8 @@ def moe_plan(idx, E, align=MOE_ALIGN, allow_invalid=False):
     cap = (rows * k + E * (align - 1) + align - 1) // align * align
     i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
     pos = torch.full((rows * k,), -1, dtype=torch.int32, device=dev) if allow_invalid else i32(rows * k)
-    plan = {'pos': pos.view(rows, k), 'src': i32(cap), 'tile_expert': i32(cap // align), 'off': i32(E + 1), 'counts': i32(E),
-            'cap': cap, 'E': E}
+    plan = {'pos': pos.view(rows, k), 'src': i32(cap), 'tile_expert': i32(cap // (MOE_TILE_ROWS if align % MOE_TILE_ROWS == 0 else align)), 'off': i32(E + 1), 'counts': i32(E),
+            'cap': cap, 'E': E, 'align': align}
     call('aa_moe_plan', idx.data_ptr(), rows, k, E, align, cap, plan['counts'].data_ptr(), plan['off'].data_ptr(), plan['pos'].data_ptr(),
          plan['src'].data_ptr(), plan['tile_expert'].data_ptr(), stream())
     return plan
@@ -524,7 +527,7 @@ def gemm_grouped(a, w3, plan, out=None, b_n=False):
         raise RuntimeError(f'gemm_grouped: weight {tuple(w3.shape)} does not match activations {tuple(a.shape)}')
     out = grouped_out(cap, N, a) if out is None else out
     call('aa_gemm_grouped' + (sfx or '_bf16'), a.data_ptr(), w3.data_ptr(), out.data_ptr(), cap, N, K, a.stride(0), w3.stride(1), out.stride(0),
-         GEMM_B_N if b_n else 0, 1, plan['tile_expert'].data_ptr(), None, w3.stride(0), E, stream())
+         GEMM_B_N if b_n else 0, 3 if plan.get('align', 1) % 256 == 0 else 1, plan['tile_expert'].data_ptr(), None, w3.stride(0), E, stream())
     return out
 
 

@@ -223,14 +223,18 @@ int aa_moe_combine(const void* yp, const int* pos, const void* weights, const vo
 int aa_moe_combine_bwd(const void* dout, const void* yp, const int* pos, const void* weights, void* dyp, float* dweights,
                        long rows, int k, int h, const int* src_row, long cap_rows, void* stream);
 /* Expert-major layout of a routing decision, computed on the device (no host read): counts[E], segment offsets off[E+1] aligned to
- * `align` rows (128 = the row tile of aa_gemm_grouped_*), pos[rows*k] (row of every (token, slot) pair, stable in token order),
- * src[cap_rows] (token of every row, -1 = pad) and tile_expert[cap_rows / align] (-1 beyond the rows in use).
+ * `align` rows (128 or 256: the row tiles of aa_gemm_grouped_*), pos[rows*k] (row of every (token, slot) pair, stable in token order),
+ * src[cap_rows] (token of every row, -1 = pad) and tile_expert[cap_rows / tg] (-1 beyond the rows in use; tg = 128 rows per entry when align is a
+ * multiple of 128, else align).
  * cap_rows >= rows*k + E*(align-1) rounded to `align`: an upper bound known without looking at the routing. */
 int aa_moe_plan(const int* idx, long rows, int k, int E, int align, long cap_rows, int* counts, int* off, int* pos, int* src,
                 int* tile_expert, void* stream);
 /* Grouped GEMM over the expert-major buffer, all experts in ONE launch, sizes read from the device tables of aa_moe_plan:
  *   mode 1: C[M, N] = A[M, K] * op(B_e) where the 128-row tile t of A / C uses expert tile_expert[t]'s matrix B + e * stride
- *           (AA_GEMM_B_N selects the [K][N] layout: forward NT and input-gradient NN of the expert MLPs); tiles with -1 exit;
+ *           (AA_GEMM_B_N selects the [K][N] layout: forward NT and input-gradient NN of the expert MLPs); tiles with -1 exit (are zero-filled on
+ *           the 256-row tile);
+ *   mode 3: mode 1 with the promise that the segments are aligned to 256 rows (aa_moe_plan align 256): runs on the 256 x 256 one-wave-per-SIMD tile
+ *           when M % 256 == 0, N % 256 == 0 and K % 128 == 0 (env AA_MOE_GEMM4=0: never), otherwise like mode 1;
  *   mode 2: C_e[M, N] (+)= A[r0:r1, :M]^T * B[r0:r1, :N] with [r0, r1) = seg_off[e], seg_off[e+1] and C_e = C + e * stride
  *           (TN: the per-expert weight gradients; an expert without tokens gets zeros). */
 int aa_gemm_grouped_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int flags,

@@ -362,10 +362,11 @@ def _ep_worker(rank, world, port, q):
             s_arr = ints(src, cap)
             s_arr[:] = -1
             s_arr[dest] = order // k
-            t_arr = ints(te, cap // align)
+            tg = 128 if align % 128 == 0 else align       # rows per table entry (csrc/moe.hip)
+            t_arr = ints(te, cap // tg)
             t_arr[:] = -1
             for e in range(E):
-                t_arr[o[e] // align:o[e + 1] // align] = e
+                t_arr[o[e] // tg:o[e + 1] // tg] = e
 
     ops.call = call
     ops._sfx = lambda t, name: '' if t.dtype == torch.bfloat16 else '_f32'

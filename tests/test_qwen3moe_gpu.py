@@ -48,9 +48,10 @@ def test_moe_kernels_vs_torch():
     assert torch.equal(plan['pos'].long().cpu().reshape(-1), want_pos)
     want_src = torch.full((plan['cap'],), -1, dtype=torch.long); want_src[dest] = order // k
     assert torch.equal(plan['src'].long().cpu(), want_src)
-    te = torch.full((plan['cap'] // A,), -1, dtype=torch.long)
+    TG = ops.MOE_TILE_ROWS                       # the tile table has one entry per 128 rows, whatever the segment alignment
+    te = torch.full((plan['cap'] // TG,), -1, dtype=torch.long)
     for e in range(E):
-        te[off[e] // A: off[e + 1] // A] = e
+        te[off[e] // TG: off[e + 1] // TG] = e
     assert torch.equal(plan['tile_expert'].long().cpu(), te)
     x = torch.randn(rows, h, generator=g).to(dev())
     xp = ops.moe_gather(x, plan['src'])
