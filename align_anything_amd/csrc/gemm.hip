@@ -691,26 +691,41 @@ static bool glu_bwd_fusable(const void* dY, const void* Wdown, int M, int F, int
 }
 
 namespace {
-struct GluPlan { int M, F, K, fused; };
-constexpr int GLU_PLANS = 16;
+// Records are keyed on (F, K, bucket of M): the winner is a property of the box's memory round trip and of the layer geometry, not of the exact row
+// count, and variable sequence lengths make M take many values -- one record per power-of-two bucket of M / 256 keeps re-probes (8 GEMM launches +
+// stream syncs each) bounded; 64 slots, least-recently-used eviction.
+struct GluPlan { int mb, F, K, fused; unsigned long stamp; };
+constexpr int GLU_PLANS = 64;
 GluPlan g_glu_plans[GLU_PLANS];
 int g_glu_nplans = 0;
+unsigned long g_glu_clock = 0;
 int g_glu_mode = -1;                 // AA_GLU_BWD: -1 = follow the per-shape record (default), 0 = always unfused, 1 = always fused
 bool g_glu_mode_read = false;
 int glu_mode() {
     if (!g_glu_mode_read) { const char* e = getenv("AA_GLU_BWD"); if (e) g_glu_mode = atoi(e); g_glu_mode_read = true; }
     return g_glu_mode;
 }
+int glu_m_bucket(int M) {            // 0: M <= 256, 1: <= 512, 2: <= 1024, ...
+    int b = 0;
+    for (long cap = 256; cap < M; cap <<= 1) ++b;
+    return b;
+}
 int glu_plan_lookup(int M, int F, int K) {
+    const int mb = glu_m_bucket(M);
     for (int i = 0; i < g_glu_nplans; ++i)
-        if (g_glu_plans[i].M == M && g_glu_plans[i].F == F && g_glu_plans[i].K == K) return g_glu_plans[i].fused;
+        if (g_glu_plans[i].mb == mb && g_glu_plans[i].F == F && g_glu_plans[i].K == K) { g_glu_plans[i].stamp = ++g_glu_clock; return g_glu_plans[i].fused; }
     return -1;
 }
 void glu_plan_store(int M, int F, int K, int fused) {
+    const int mb = glu_m_bucket(M);
+    int slot = -1;
     for (int i = 0; i < g_glu_nplans; ++i)
-        if (g_glu_plans[i].M == M && g_glu_plans[i].F == F && g_glu_plans[i].K == K) { g_glu_plans[i].fused = fused; return; }
-    const int slot = g_glu_nplans < GLU_PLANS ? g_glu_nplans++ : 0;
-    g_glu_plans[slot] = GluPlan{M, F, K, fused};
+        if (g_glu_plans[i].mb == mb && g_glu_plans[i].F == F && g_glu_plans[i].K == K) slot = i;
+    if (slot < 0) {
+        if (g_glu_nplans < GLU_PLANS) slot = g_glu_nplans++;
+        else { slot = 0; for (int i = 1; i < GLU_PLANS; ++i) if (g_glu_plans[i].stamp < g_glu_plans[slot].stamp) slot = i; }
+    }
+    g_glu_plans[slot] = GluPlan{mb, F, K, fused, ++g_glu_clock};
 }
 int glu_bwd_run(bool fused, const void* dY, const void* Wdown, const void* GU, void* dGU, void* dact_ws, int M, int F, int K, long ldy,
                 long ldw, long ldgu, long lddgu, void* stream) {

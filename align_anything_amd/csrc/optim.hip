@@ -68,8 +68,16 @@ extern "C" int aa_grad_sumsq(const void* g, int g_dtype, long n, float scale, fl
 }
 
 // clip_coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)) ; norm_out = sqrt(sumsq)  (device-side, no host sync)
+// sumsq == -inf is the "skip this update" sentinel (the expert-parallel capacity overflow, all-reduced into the buffer by the engine:
+// expert_parallel.py): coef = norm = -1, and the AdamW kernels below return without touching weights or moments on a negative coefficient.
+// A squared norm can be +inf or NaN (diverged gradients: those propagate as before) but never negative.
 __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm,
                                  float* __restrict__ coef, float* __restrict__ norm_out) {
+    if (*sumsq == -INFINITY) {
+        if (norm_out) *norm_out = -1.f;
+        *coef = -1.f;
+        return;
+    }
     const float nrm = sqrtf(*sumsq);
     if (norm_out) *norm_out = nrm;
     float c = 1.f;
@@ -97,6 +105,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
                                                     float bc1, float bc2, float gscale,
                                                     const float* __restrict__ clip_coef) {
     const float gs = gscale * (clip_coef ? *clip_coef : 1.f);
+    if (gs < 0.f) return;          // clip_coef_kernel's skip sentinel: this step's update is dropped on every rank
     const float inv_bc1 = 1.f / bc1, inv_bc2 = 1.f / bc2;
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -152,6 +161,7 @@ void adamw_thin_kernel(float* __restrict__ master, float* __restrict__ m, float*
     // buffer addressing: the five base addresses live in SGPR descriptors, each access costs ONE VGPR byte offset
     // (the host chunks the flat buffer so offsets fit 32 bits); one element per lane.
     const float gs = gscale * (clip_coef ? *clip_coef : 1.f);
+    if (gs < 0.f) return;          // skip sentinel (see clip_coef_kernel)
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(master, 0, n * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(m, 0, n * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(v, 0, n * 4u, 0x00020000);

@@ -265,18 +265,26 @@ class NativeEngine:
         self.global_steps += 1
         gscale = 1.0 / self.world
         ep = getattr(self.module, 'ep', None)
-        if ep is not None and ep.padded:
-            ep.poll_overflow()        # non-blocking: raises when an earlier step's capacity flag (expert_parallel.py) has landed set
+        watch = ep is not None and ep.padded
+        if watch:
+            ep.poll_overflow()        # non-blocking: raises (on every rank, in the same step) when an earlier step's shared capacity flag has landed set
 
         def launch():
             self._sumsq.zero_()
             groups = st.trainable_groups()
-            if 'exp' in groups:
+            if 'exp' in groups or watch:
                 # expert-parallel shards (expert_parallel.py): every rank owns different experts, whose gradients are already the
-                # sum over all ranks' rows -> never all-reduced; the clip norm needs the sum of the shards' squared norms
-                ops.grad_sumsq_(st.gflat['exp'], self._sumsq, gscale, self._sumsq_ws)
+                # sum over all ranks' rows -> never all-reduced; the clip norm needs the sum of the shards' squared norms.  The same
+                # all-reduce carries the capacity-overflow flag of the sync-free exchange (-inf survives the SUM): every rank then skips
+                # this update on the device (csrc/optim.hip: coefficient -1) and raises at its next poll -- together.
+                if 'exp' in groups:
+                    ops.grad_sumsq_(st.gflat['exp'], self._sumsq, gscale, self._sumsq_ws)
+                if watch:
+                    self._sumsq.add_(ep.overflow_sentinel(self._sumsq.device))
                 if self.world > 1:
                     dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.reducer.group)
+                if watch:
+                    ep.watch_shared(self._sumsq)
             for g in groups:
                 if g != 'exp':
                     ops.grad_sumsq_(st.gflat[g], self._sumsq, gscale, self._sumsq_ws)
@@ -344,13 +352,21 @@ class NativeEngine:
         ep = getattr(self.module, 'ep', None)
         if ep is not None and ep.padded:
             ep.poll_overflow(block=True)     # a host read anyway: report a capacity overflow of this step now rather than a step later
-        return float(self._gnorm.item())
+        return float(self._gnorm.item())     # -1 would be the skipped-update sentinel, which the poll above has already raised on
+
+    def _poll_ep_blocking(self):
+        """Before anything is written: a capacity overflow of the sync-free expert exchange (identical flag on every rank) raises here, so a
+        checkpoint is never taken of a run that is about to abort."""
+        ep = getattr(self.module, 'ep', None)
+        if ep is not None and ep.padded:
+            ep.poll_overflow(block=True)
 
     # ---- checkpoints (HF layout, supervised_trainer.py:404-450)
     def save_16bit_model(self, save_dir, save_filename='pytorch_model.bin'):
         """Rank 0 writes (the replicas are identical; DeepSpeed's save_16bit_model writes from rank 0 as well).  Every rank may call it --
         with expert-parallel weights every rank MUST: `state_dict()` gathers the expert shards, a collective."""
         self.wait_optimizer()
+        self._poll_ep_blocking()
         path = os.path.join(save_dir, save_filename)
         rank = dist.get_rank(self.reducer.group) if (dist.is_available() and dist.is_initialized()) else 0     # the writer is rank 0 of THIS engine's group
         if rank != 0 and getattr(self.module, 'ep', None) is None:
@@ -371,6 +387,7 @@ class NativeEngine:
         """Full training state (fp32 masters + Adam moments + step), the analogue of DeepSpeed's checkpoint.  Replicated
         groups are written by rank 0; an expert-parallel shard ('exp') by the rank that owns it (`..._ep<rank>.pt`)."""
         self.wait_optimizer()
+        self._poll_ep_blocking()
         os.makedirs(save_dir, exist_ok=True)
         st = self.module.store
         rank = dist.get_rank(self.reducer.group) if dist.is_initialized() else 0

@@ -24,16 +24,27 @@ Sync-free form (round 3; `capacity_factor`, the trainers' default): step 2's hos
 step at 48 layers -- goes away when every (source, destination) pair exchanges a FIXED number of rows, C = ceil(capacity_factor x rows x k / ranks)
 (all rows x k when that is a handful: decode positions), the unused tail zero: the split sizes are constants, the per-expert counts travel in a
 device all-to-all and stay on the device, the receiver derives the local expert of every arriving row (or -1: no token) from them with a
-searchsorted, and `aa_moe_plan` / the grouped GEMM's tile table already skip rows without an expert.  Nothing is dropped: a router that sends one rank
-more than C rows sets a device flag that is copied to pinned memory asynchronously and raised as an error when the engine polls it at the next
-optimizer step (`poll_overflow`; no blocking read) -- the remedy is a larger `train_cfgs.expert_parallel_capacity_factor` (`ranks` can never
-overflow; 0 = the exact exchange above).  The padded layout keeps the expert-major order inside every rank block, so the results are bit-identical
-to the exact exchange (tests/test_ep_gloo.py on CPU; tests/test_ep_gpu.py on hardware).
+searchsorted, and `aa_moe_plan` / the grouped GEMM's tile table already skip rows without an expert.
+
+`rows x k` is the MAXIMUM over the ranks (`shared_pairs`): data-parallel ranks pad to their own batch's longest row and rollouts have different prompt
+lengths, but the equal-split all-to-all needs ONE block size on every rank.  The ranks agree on it once per forward / per rollout with a host-side
+all-reduce of one integer on a gloo side group (`pass_scope`; no device read, ~0.1 ms) -- a rank with fewer rows simply has a longer zero tail.
+
+Overflow: a router that sends one rank more than C rows loses the rows beyond C for that pass (they come back as zeros) and sets a device flag.  The
+engine folds the flag into the squared-gradient-norm buffer it all-reduces anyway (`overflow_sentinel`: -inf survives the SUM), so EVERY rank sees it in
+the same step: the clip kernel turns it into the coefficient -1, on which the AdamW kernels return without touching weights or moments (the step is
+skipped on the device, csrc/optim.hip), and every rank raises together at its next poll / `grad_norm()` / checkpoint save -- nobody is left waiting in a
+collective, and no invalid gradient reaches the weights.  The remedy is a larger `train_cfgs.expert_parallel_capacity_factor` (`ranks` can never
+overflow; 0 = the exact exchange above).  Without an engine (rollout only) `poll_overflow` reports the local flag.  The padded layout keeps the
+expert-major order inside every rank block, so the results are bit-identical to the exact exchange (tests/test_ep_gloo.py on CPU; tests/test_ep_gpu.py
+on hardware).
 
 Use a process group of its own (`dist.new_group()`), not the one the gradient all-reduce runs on: collectives of one
 communicator are serialised, and the exchange of layer l-1 must not queue behind the 400 MB gradient bucket of layer l.
 """
 from __future__ import annotations
+
+import contextlib
 
 import torch
 import torch.distributed as dist
@@ -55,6 +66,12 @@ class ExpertParallel:
         self.dense_below = int(dense_below)
         self._overflow = None          # 0-d bool on the device: some rank block of this step was larger than its capacity
         self._pending = None           # (pinned host copy, event) of the previous step's flag
+        # host integers (block sizes) are agreed on a gloo group: an RCCL all-reduce would need a device tensor and a blocking read.
+        # Collective over the members of `group` (like the constructor's caller `dist.new_group()`); only the padded exchange needs it.
+        self.host_group = group
+        if self.padded and self.size > 1 and not self.host_staged:
+            self.host_group = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD), backend='gloo')
+        self._scope = None             # (local pairs, agreed pairs) inside a pass_scope
 
     def local_experts(self, num_experts: int) -> tuple[int, int]:
         """(first expert, number of experts) held by this rank: contiguous blocks in rank order."""
@@ -102,8 +119,31 @@ class ExpertParallel:
     def padded(self) -> bool:
         return self.capacity_factor is not None
 
+    def shared_pairs(self, pairs: int) -> int:
+        """max over the ranks of `pairs` (this rank's rows x k of the current pass): the value `capacity` must be derived from, because the
+        equal-split all-to-all needs the same block size everywhere while the ranks' padded batch shapes differ.  One host-side all-reduce of
+        an integer (gloo side group) -- once per forward / rollout inside a `pass_scope`, else per call.  Every rank must call it in step."""
+        if self.size == 1:
+            return int(pairs)
+        if self._scope is not None and self._scope[0] == int(pairs):
+            return self._scope[1]
+        t = torch.tensor([int(pairs)], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.host_group)
+        return int(t[0])
+
+    @contextlib.contextmanager
+    def pass_scope(self, pairs: int):
+        """All MoE blocks of one forward (or all decode positions of one rollout) exchange the same number of pairs: agree once."""
+        prev = self._scope
+        self._scope = (int(pairs), self.shared_pairs(pairs)) if self.padded else None
+        try:
+            yield
+        finally:
+            self._scope = prev
+
     def capacity(self, pairs: int) -> int:
-        """Rows per (source, destination) block for a batch of `pairs` = rows x k routed pairs on every rank."""
+        """Rows per (source, destination) block for a batch of `pairs` = rows x k routed pairs -- the SAME number on every rank
+        (`shared_pairs` of the local counts; modeling.Qwen3MoeStack._ep_experts_fwd)."""
         if pairs <= self.dense_below:
             return max(pairs, 1)
         return min(pairs, -(-int(self.capacity_factor * pairs) // self.size))
@@ -148,9 +188,36 @@ class ExpertParallel:
             raise RuntimeError(f'exchange_fixed: {x.shape[0]} rows do not split over {self.size} ranks')
         return self._all_to_all(torch.empty_like(x), x)
 
+    def overflow_sentinel(self, device) -> torch.Tensor:
+        """0-d float32 for the engine's squared-norm buffer: -inf when a block of this step overflowed on THIS rank, else 0; consumes the local
+        flag.  Added before the buffer's SUM all-reduce, the -inf reaches every rank (engine.NativeEngine.step)."""
+        flag, self._overflow = self._overflow, None
+        if flag is None:
+            return torch.zeros((), dtype=torch.float32, device=device)
+        return torch.where(flag.to(device), float('-inf'), 0.0).to(torch.float32)
+
+    def watch_shared(self, sumsq: torch.Tensor) -> None:
+        """After the all-reduce: start the asynchronous host copy of "some rank overflowed" (identical on every rank) for `poll_overflow`."""
+        flag = (sumsq.reshape(-1)[0] == float('-inf'))
+        self._overflow = flag if self._overflow is None else (self._overflow | flag)
+        if self._pending is None:
+            self._start_copy()
+
+    def _start_copy(self):
+        flag, self._overflow = self._overflow, None
+        if flag.is_cuda:
+            host = torch.empty((), dtype=torch.bool).pin_memory()
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (host, ev)
+        else:
+            self._pending = (flag, None)
+
     def poll_overflow(self, block: bool = False) -> None:
-        """Called once per optimizer step (engine.step) -- never blocks unless asked to: starts the asynchronous read of this step's overflow flag
-        and raises if an EARLIER step's flag, whose copy has landed by now, was set."""
+        """Never blocks unless asked to: raises if a flag whose host copy has landed was set, then starts the asynchronous read of the flag
+        accumulated since.  With an engine the flag is the shared one (`watch_shared`: same value, same step on every rank, and the optimizer
+        update of that step was skipped on the device); without one (rollouts) it is this rank's own."""
         if self._pending is not None:
             host, ev = self._pending
             if block and ev is not None:
@@ -159,18 +226,11 @@ class ExpertParallel:
                 self._pending = None
                 if bool(host.item()):
                     raise RuntimeError(f'expert-parallel exchange overflowed its capacity (factor {self.capacity_factor}, {self.size} ranks): the router sent one '
-                                       f'rank more rows than a block holds and those rows were NOT processed -- the step is invalid.  Raise '
+                                       f'rank more rows than a block holds and those rows were NOT processed -- the step is invalid (its optimizer update was '
+                                       f'skipped on the device).  Raise '
                                        f'train_cfgs.expert_parallel_capacity_factor (<= {self.size} always fits) or set it to 0 for the exact exchange')
         if self._overflow is not None and self._pending is None:
-            flag, self._overflow = self._overflow, None
-            if flag.is_cuda:
-                host = torch.empty((), dtype=torch.bool).pin_memory()
-                host.copy_(flag, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                self._pending = (host, ev)
-            else:
-                self._pending = (flag, None)
+            self._start_copy()
             if block:
                 self.poll_overflow(block=True)
 

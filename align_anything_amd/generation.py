@@ -152,34 +152,38 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
     n_new = 0
     # the last selected token needs no decode pass, but running it keeps the loop a single replayed graph;
     # the cache has Tmax slots, so the final pass writes slot Tmax-1 at most
-    for step in range(max_new_tokens):
-        if step + 1 == max_new_tokens:
-            # final token: selection only
+    # expert-parallel decode positions all exchange N x k pairs: the ranks (whose N may differ) agree on the block size once per rollout
+    import contextlib
+    scope = ep.pass_scope(N * stack.cfg['num_experts_per_tok']) if (ep is not None and ep.padded) else contextlib.nullcontext()
+    with scope:
+        for step in range(max_new_tokens):
+            if step + 1 == max_new_tokens:
+                # final token: selection only
+                if ep is not None and step >= own_new:
+                    st['unfinished'].zero_()
+                st['nact'].add_(st['unfinished'].any().to(torch.int64))
+                nxt = select(st['logits'], st['U'][step] if do_sample else None)
+                nxt = torch.where(st['unfinished'], nxt, padv)
+                out[:, T + step] = nxt
+                n_new = step + 1
+                break
             if ep is not None and step >= own_new:
-                st['unfinished'].zero_()
-            st['nact'].add_(st['unfinished'].any().to(torch.int64))
-            nxt = select(st['logits'], st['U'][step] if do_sample else None)
-            nxt = torch.where(st['unfinished'], nxt, padv)
-            out[:, T + step] = nxt
+                st['unfinished'].zero_()                            # this rank's own length cap: its rows only pad from here on
+            if graph is not None:
+                graph.replay()
+            else:
+                one_step()
             n_new = step + 1
-            break
-        if ep is not None and step >= own_new:
-            st['unfinished'].zero_()                            # this rank's own length cap: its rows only pad from here on
-        if graph is not None:
-            graph.replay()
-        else:
-            one_step()
-        n_new = step + 1
-        if eos >= 0 and (step % sync_every == sync_every - 1):
-            if ep is None:
-                if not bool(st['unfinished'].any()):
-                    break
-            else:                                               # stop only when every rank is done (same decision on every rank)
-                flag = st['unfinished'].any().to(torch.int32).reshape(1)
-                flag = flag.cpu() if ep.host_staged else flag
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ep.group)
-                if int(flag.item()) == 0:
-                    break
+            if eos >= 0 and (step % sync_every == sync_every - 1):
+                if ep is None:
+                    if not bool(st['unfinished'].any()):
+                        break
+                else:                                               # stop only when every rank is done (same decision on every rank)
+                    flag = st['unfinished'].any().to(torch.int32).reshape(1)
+                    flag = flag.cpu() if ep.host_staged else flag
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ep.group)
+                    if int(flag.item()) == 0:
+                        break
     n_new = min(n_new, max(own_new, 0))
     seq = out[:, :T + n_new]
     if eos_token_id is not None:

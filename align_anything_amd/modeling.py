@@ -161,7 +161,9 @@ class LlamaStack:
         # AA_DECODE_EPI=0: plain copies + the separate SwiGLU / RoPE+cache kernels (A/B and bit-identity tests); default: the copies of gate_up
         # and (head_dim 128) qkv are row-permuted inside their strips so the strip kernel finishes those two kernels in its epilogue
         epi = os.environ.get('AA_DECODE_EPI', '1') != '0'
-        modes = {'qkv': 'rope128' if (epi and self.cfg['head_dim'] == 128) else 'plain', 'o': 'plain', 'gu': 'glu' if epi else 'plain', 'down': 'plain'}
+        # a shape the permuted copies do not fit (ffn not a multiple of 8) falls back to the plain strip copy + the separate kernel, it does not raise
+        modes = {'qkv': 'rope128' if (epi and self.cfg['head_dim'] == 128) else 'plain', 'o': 'plain',
+                 'gu': 'glu' if (epi and (2 * self.cfg['intermediate_size']) % 16 == 0) else 'plain', 'down': 'plain'}
         if getattr(self, '_dw', None) is not None and any(W[k].mode != modes[k] for W in self._dw[:1] for k in modes):
             self._dw = None
         if getattr(self, '_dw', None) is None:
@@ -1454,7 +1456,7 @@ class Qwen3MoeStack:
         lay = ops.moe_plan(idx, E, align=1)                      # dense expert-major order = send order (experts are rank-contiguous)
         if ep.padded:
             # sync-free form (expert_parallel.py): constant-size blocks per peer, counts and the local plan stay on the device
-            cap = ep.capacity(idx.numel())
+            cap = ep.capacity(ep.shared_pairs(idx.numel()))     # the same block size on every rank, whatever their padded batch shapes
             send_src, pos_p = ep.padded_send_layout(lay['counts'], lay['src'], lay['pos'], idx, cap)
             xr = ep.exchange_fixed(ops.moe_gather(n2, send_src))                # [size * cap, h]: block s = rank s's rows for my experts, zero tail
             ids = ep.padded_recv_ids(ep.exchange_counts_device(lay['counts']), cap)
@@ -1496,6 +1498,10 @@ class Qwen3MoeStack:
         self._tables(T)
         self.saved = []
         Mp = x.shape[0]
+        if self.ep is not None and self.ep.padded and self.ep._scope is None:
+            # every MoE block of this forward exchanges Mp x k pairs: the ranks agree on the block size once (expert_parallel.pass_scope)
+            with self.ep.pass_scope(Mp * k):
+                return self.forward(x, N, T, start, pos, save, kv_sink)
         for li, L in enumerate(self.layers):
             n1, rstd1 = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
             q, kk, v = L['q'].fwd(n1), L['k'].fwd(n1), L['v'].fwd(n1)

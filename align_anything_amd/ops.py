@@ -132,17 +132,23 @@ def gemm_glu_fwd(x, w_gu, F):
     return gu, act
 
 
-_GLU_WS = {}          # (device, M, F) -> d_act workspace of the unfused SwiGLU-backward pair (allocated only when that plan is chosen)
+# d_act workspace of the unfused SwiGLU-backward pair: ONE grow-only flat buffer per device, sized to the largest M x F seen (variable sequence
+# lengths give M many values; a buffer per shape would grow without bound -- ADVICE r3).  A buffer that only ever served probes whose winner was the
+# fused kernel is dropped again.
+_GLU_WS = {}          # device -> flat bf16 buffer
+_GLU_WS_KEEP = set()  # devices on which the unfused plan has actually run
 GLU_BWD_PROBE = os.environ.get('AA_GLU_BWD_PROBE', '1') != '0'
 GLU_BWD_PROBE_LOG = []   # (M, F, K, ms_fused, ms_unfused) of every probe this process ran (bench.py reports it)
 
 
-def _glu_ws(M, F, device):
-    key = (str(device), M, F)
+def _glu_ws(M, F, device, keep=True):
+    key = str(device)
     ws = _GLU_WS.get(key)
-    if ws is None:
-        ws = _GLU_WS[key] = torch.empty((M, F), dtype=bf16, device=device)
-    return ws
+    if ws is None or ws.numel() < M * F:
+        ws = _GLU_WS[key] = torch.empty(M * F, dtype=bf16, device=device)
+    if keep:
+        _GLU_WS_KEEP.add(key)
+    return ws[:M * F].view(M, F)
 
 
 def gemm_glu_bwd(dy, w_down, gu, F):
@@ -161,8 +167,10 @@ def gemm_glu_bwd(dy, w_down, gu, F):
     FLOPS['gemm'] += 2.0 * M * F * K
     if plan.value == 2 and GLU_BWD_PROBE:
         t = (ctypes.c_float * 2)()
-        call('aa_gemm_glu_bwd_probe', *args, _glu_ws(M, F, dy.device).data_ptr(), *dims, 3, ctypes.addressof(t), ctypes.addressof(t) + 4, stream())
+        call('aa_gemm_glu_bwd_probe', *args, _glu_ws(M, F, dy.device, keep=False).data_ptr(), *dims, 3, ctypes.addressof(t), ctypes.addressof(t) + 4, stream())
         GLU_BWD_PROBE_LOG.append((M, F, K, float(t[0]), float(t[1])))
+        if float(t[0]) <= float(t[1]) and str(dy.device) not in _GLU_WS_KEEP:
+            _GLU_WS.pop(str(dy.device), None)       # the fused kernel won (the probe synchronised the stream): nothing needs the workspace
         return dgu
     ws = _glu_ws(M, F, dy.device) if plan.value == 0 else None
     prof = _prof_begin()

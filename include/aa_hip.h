@@ -335,6 +335,8 @@ int aa_move_padding_left(const int64_t* in, long ldi, int64_t* out, long ldo, in
    clip coefficient is bit-identical on every data-parallel rank */
 #define AA_SUMSQ_WS 2048
 int aa_grad_sumsq(const void* g, int g_dtype, long n, float scale, float* out_accum, float* ws, void* stream);
+/* coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)), norm = sqrt(sumsq).  *sumsq == -inf is the "skip this update" sentinel (the all-reduced
+   capacity-overflow flag of the expert-parallel exchange): coef = norm = -1, and aa_adamw_flat returns without writing on a negative coefficient */
 int aa_clip_coef(const float* sumsq, float max_norm, float* coef_out, float* norm_out, void* stream);
 /* 1: use the <= 16-VGPR update kernel that can be co-resident with the 256x256 GEMM tiles (overlapped optimizer), 0: default */
 int aa_adamw_set_thin(int on);

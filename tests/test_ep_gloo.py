@@ -95,7 +95,9 @@ def _padded_worker(rank, world, port, q):
     ok = ep.padded and not exact.padded and ep.capacity(80) == -(-int(factor * 80) // world) and ExpertParallel(exact.group, 2.0).capacity(80) == 80
     E, k, h = 8, 2, 6
     e0, El = ep.local_experts(E)
-    for trial, M in enumerate((13, 1, 40, 64)):
+    # the last two trials give every rank a DIFFERENT number of rows (data-parallel ranks pad to their own batch maximum, rollouts have their own
+    # prompt lengths): the block size must come from the agreed maximum (local M made the equal-split all-to-all abort / corrupt)
+    for trial, M in enumerate((13, 1, 40, 64, 9 + 11 * rank, 64 * (1 + (world - 1 - rank) % 3))):
         g = torch.Generator().manual_seed(100 * trial + rank)
         idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(M)]).to(torch.int32)
         x = torch.randn(M, h, generator=g)
@@ -110,7 +112,13 @@ def _padded_worker(rank, world, port, q):
         ys = exact.exchange_rows(_combine(fn(xp, le), lp['pos'], xr.shape[0]), recv, send)
         want = _combine(ys, lay['pos'], M)
         # padded exchange
-        cap = ep.capacity(M * k)
+        shared = ep.shared_pairs(M * k)
+        mx = torch.tensor([M * k]); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        ok = ok and shared == int(mx)
+        with ep.pass_scope(M * k):                                                # inside a scope the agreement is made once ...
+            ok = ok and ep._scope == (M * k, shared) and ep.shared_pairs(M * k) == shared
+        ok = ok and ep._scope is None
+        cap = ep.capacity(shared)
         send_src, pos_p = ep.padded_send_layout(lay['counts'], lay['src'], lay['pos'], idx, cap)
         ok = ok and send_src.numel() == world * cap and int((send_src >= 0).sum()) == M * k and bool((pos_p >= 0).all())
         xr2 = ep.exchange_fixed(_gather(x, send_src))
@@ -141,6 +149,26 @@ def _padded_worker(rank, world, port, q):
         raised = 'capacity' in str(e)
     ok = ok and raised
     tight.poll_overflow(block=True)                                                # the flag was consumed
+    # with an engine the flag is SHARED: only the last rank overflows, the -inf sentinel rides the squared-norm all-reduce (engine.step) and every
+    # rank raises in the same step -- nobody is left in a collective
+    if rank == world - 1:
+        tight.padded_send_layout(lay['counts'], lay['src'], lay['pos'], idx, cap)
+    sumsq = torch.full((1,), 3.0 + rank)
+    sumsq += tight.overflow_sentinel('cpu')
+    ok = ok and tight._overflow is None and (bool(torch.isinf(sumsq)) == (rank == world - 1))
+    dist.all_reduce(sumsq)
+    tight.watch_shared(sumsq)
+    raised = False
+    try:
+        tight.poll_overflow(block=True)
+    except RuntimeError as e:
+        raised = 'skipped' in str(e)
+    ok = ok and raised and float(sumsq) == float('-inf')
+    sumsq = torch.full((1,), 3.0) + tight.overflow_sentinel('cpu')                 # a clean step: finite norm, nothing pending, no raise
+    dist.all_reduce(sumsq)
+    tight.watch_shared(sumsq)
+    tight.poll_overflow(block=True)
+    ok = ok and bool(torch.isfinite(sumsq))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -35,3 +35,29 @@ def test_adamw_flat_five_steps(gdtype, thin):
     ops.adamw_set_thin(False)
     assert_close(master.cpu(), q, rtol=1e-5, atol=2e-6, what='master')
     assert torch.equal(p16, master.to(torch.bfloat16)), 'bf16 shadow must be RNE of the fp32 master'
+
+
+@pytest.mark.parametrize('thin', [False, True])
+def test_skip_sentinel_leaves_weights_and_moments_untouched(thin):
+    """sumsq == -inf (the all-reduced capacity-overflow flag of the sync-free expert exchange, expert_parallel.py) -> coefficient and
+    norm -1 -> the AdamW kernels return without writing: the invalid step never reaches weights or optimizer state."""
+    from align_anything_amd import ops
+    ops.adamw_set_thin(thin)
+    n = 70001
+    gen = torch.Generator().manual_seed(1)
+    master = torch.randn(n, generator=gen).to(dev()); m = torch.randn(n, generator=gen).to(dev()); v = torch.rand(n, generator=gen).to(dev())
+    p16 = master.to(torch.bfloat16)
+    keep = [t.clone() for t in (master, m, v, p16)]
+    g = torch.randn(n, generator=gen).to(torch.bfloat16).to(dev())
+    sumsq = torch.full((1,), float('-inf'), device=dev()); coef = torch.zeros(1, device=dev()); nrm = torch.zeros(1, device=dev())
+    ops.clip_coef(sumsq, 1.0, coef, nrm)
+    ops.adamw_flat_(master, m, v, p16, g, 1e-3, 0.9, 0.95, 1e-8, 0.05, 3, gscale=0.5, clip=coef)
+    torch.cuda.synchronize()
+    ops.adamw_set_thin(False)
+    assert coef.item() == -1.0 and nrm.item() == -1.0
+    for a, b in zip((master, m, v, p16), keep):
+        assert torch.equal(a, b)
+    # +inf (diverged gradients) is NOT the sentinel: coefficient 0, the update runs as before
+    sumsq.fill_(float('inf'))
+    ops.clip_coef(sumsq, 1.0, coef, nrm)
+    assert coef.item() == 0.0 and nrm.item() == float('inf')
