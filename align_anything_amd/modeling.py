@@ -1628,13 +1628,19 @@ class NativeQwen3Moe(NativeCausalLM):
             return sd
         E = self.cfg['num_experts']
         e0, n = self.ep.local_experts(E) if self.ep is not None else (0, E)
-        out = {k: v for k, v in sd.items() if '.mlp.experts.' not in k or k.endswith(('experts.gate_up_proj', 'experts.down_proj'))}
+        keep = lambda k: '.mlp.experts.' not in k or k.endswith(('experts.gate_up_proj', 'experts.down_proj'))
+        gu = lambda p: (lambda: torch.stack([torch.cat([sd[f'{p}{e}.gate_proj.weight'], sd[f'{p}{e}.up_proj.weight']], 0) for e in range(e0, e0 + n)]))
+        dn = lambda p: (lambda: torch.stack([sd[f'{p}{e}.down_proj.weight'] for e in range(e0, e0 + n)]))
+        thunks = {}
         for i in range(self.cfg['num_layers']):
             p = f'model.layers.{i}.mlp.experts.'
-            if p + '0.gate_proj.weight' not in sd:
-                continue
-            out[p + 'gate_up_proj'] = torch.stack([torch.cat([sd[f'{p}{e}.gate_proj.weight'], sd[f'{p}{e}.up_proj.weight']], 0) for e in range(e0, e0 + n)])
-            out[p + 'down_proj'] = torch.stack([sd[f'{p}{e}.down_proj.weight'] for e in range(e0, e0 + n)])
+            if p + '0.gate_proj.weight' in sd:
+                thunks[p + 'gate_up_proj'], thunks[p + 'down_proj'] = gu(p), dn(p)
+        if not isinstance(sd, dict):      # a lazy checkpoint (checkpoint.LazyCheckpoint): one layer's experts are merged when the store asks for them
+            from .checkpoint import Derived
+            return Derived(sd, lambda k: not keep(k), thunks)
+        out = {k: v for k, v in sd.items() if keep(k)}
+        out.update({k: f() for k, f in thunks.items()})
         return out
 
     def state_dict(self):
@@ -1820,8 +1826,9 @@ class NativeOPT(NativeCausalLM):
         self.finalize()
 
     def load_state_dict(self, sd, strict=True):
-        sd = dict(sd)
-        sd.pop('lm_head.weight', None)  # tied
+        if isinstance(sd, dict):
+            sd = dict(sd)
+            sd.pop('lm_head.weight', None)  # tied (the store has no alias of that name: a lazy checkpoint's copy is simply never read)
         return super().load_state_dict(sd, strict)
 
     def state_dict(self):

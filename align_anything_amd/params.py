@@ -171,6 +171,35 @@ class ParamStore:
                 self.master[g].copy_(self.flat[g])
         return missing
 
+    def opt_state_views(self, hf_name):
+        """(master, m, v) fp32 views of one HF-named tensor inside the flat optimizer buffers, or None when it is frozen."""
+        block, off, shape = self.alias[hf_name]
+        s = self.specs[block]
+        if s['group'] not in self.m:
+            return None
+        out = []
+        for flat in (self.master[s['group']], self.m[s['group']], self.v[s['group']]):
+            t = flat[s['offset']:s['offset'] + s['numel']].view(s['shape'])
+            out.append(t[off:off + shape[0]] if tuple(t.shape) != tuple(shape) else t)
+        return tuple(out)
+
+    def load_opt_state(self, m: dict, v: dict, strict=True):
+        """Adam moments by HF name (a torch.optim.AdamW / DeepSpeed state re-keyed by parameter name) into the flat fp32 buffers: resuming
+        from a foreign optimizer state, and the teacher-forced parity test (tests/test_f32_gpu.py).  After `init_training()`."""
+        missing = []
+        for hf_name in self.alias:
+            views = self.opt_state_views(hf_name)
+            if views is None:
+                continue
+            if hf_name not in m or hf_name not in v:
+                missing.append(hf_name)
+                continue
+            views[1].copy_(m[hf_name].to(torch.float32).reshape(views[1].shape))
+            views[2].copy_(v[hf_name].to(torch.float32).reshape(views[2].shape))
+        if strict and missing:
+            raise RuntimeError(f'missing optimizer state for: {missing[:8]}{"..." if len(missing) > 8 else ""}')
+        return missing
+
     def state_dict(self, unpad: dict | None = None) -> dict:
         out = {}
         for hf_name in self.alias:

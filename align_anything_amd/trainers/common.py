@@ -242,3 +242,70 @@ def save_interval(cfgs, total_steps) -> int:
     if not limit or not total_steps:
         return 0
     return max(1, int(total_steps) // int(limit))
+
+
+def resolve_pretrained(cfgs, device, *, trainable, head='lm', dtype=None, path_key='model_cfgs.model_name_or_path', build_kwargs=None,
+                       with_tokenizer=True):
+    """The reference trainers load their own models from `model_cfgs.model_name_or_path` (text_to_text/dpo.py:83-100,
+    text_image_to_text/dpo.py:58-83 -> models/pretrained_model.py:160-312); the native ones do the same through checkpoint.load_pretrained
+    (config.json -> native geometry, sharded safetensors / .bin streamed into the flat device buffers, tokenizer / processor, pad-token
+    resize).  Returns (model, tokenizer, processor, hf_config)."""
+    from ..checkpoint import load_pretrained
+    path = cfg_get(cfgs, path_key, None)
+    if not path:
+        raise ValueError(f'{path_key} is not set and no model_cfg / state was handed to the trainer')
+    return load_pretrained(path, device, trainable=trainable, head=head, dtype=dtype or compute_dtype(cfg_get(cfgs, 'train_cfgs.compute_dtype', 'bf16')),
+                           model_max_length=int(cfg_get(cfgs, 'model_cfgs.model_max_length', 512)), padding_side='left',
+                           build_kwargs=build_kwargs, with_tokenizer=with_tokenizer)
+
+
+def get_dataloaders(trainer, train_dtype_name: str, eval_dtype_name: str | None = None, modality: str | None = None):
+    """`SupervisedTrainerBase.get_dataloaders` (base/supervised_trainer.py:79-232) for the native trainers' `init_datasets()`.
+
+    The dataset / template plugin surface stays the reference's own (`@register_template` formatters, the Dataset
+    constructor signature, `get_collator()`): the classes are imported from the installed `align_anything` package and called exactly as the
+    reference does -- ChatTemplate(formatter, template), Dataset(path, template, tokenizer, processor, name, size, split, data_files,
+    optional_args), DataLoader(collate_fn=dataset.get_collator(), sampler=DistributedSampler(shuffle=True), batch_size=per_device_*) --
+    and the loader is wrapped in the device prefetcher (data.DevicePrefetcher: next batch host -> HBM on a side stream, window plan prebuilt).
+    Single-process runs use a DistributedSampler of one replica (the order a world-1 reference run sees).  Returns (train, eval) loaders;
+    None where `data_cfgs.{train,eval}_datasets` is unset."""
+    import importlib
+    import torch.distributed as dist
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from ..data import DevicePrefetcher
+    cfgs = trainer.cfgs
+    d = lambda k, default=None: cfg_get(cfgs, 'data_cfgs.' + k, default)
+    if not d('train_datasets') and not d('eval_datasets'):
+        return None, None
+    if modality is None:
+        modality = 'text_image_to_text' if getattr(trainer, 'processor', None) is not None else 'text_to_text'
+    try:
+        ds_mod = importlib.import_module(f'align_anything.datasets.{modality}')
+        from align_anything.configs.template import ChatTemplate
+    except ImportError as e:
+        raise RuntimeError('init_datasets(): data_cfgs names datasets, which are built by the reference\'s own dataset / template plugins '
+                           f'(align_anything.datasets.{modality}, align_anything.configs.template) -- that package is not importable here ({e}); '
+                           'install it, or hand the trainer a `train_dataloader=` of collated batches') from e
+    tokenizer, processor = getattr(trainer, 'tokenizer', None), getattr(trainer, 'processor', None)
+    formatter = processor if processor else tokenizer
+    custom = getattr(getattr(trainer, 'hf_model_hooks', None), 'apply_chat_template', None)
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+
+    def build(prefix, dtype_name, batch_key):
+        paths = d(prefix + '_datasets')
+        if not paths:
+            return None
+        if not isinstance(paths, str):
+            raise NotImplementedError('data_cfgs.*_datasets as a list (ConcatDataset of several templates, supervised_trainer.py:110-160) is not wired natively yet')
+        template = ChatTemplate(formatter, d(prefix + '_template'), custom)
+        setattr(trainer, prefix + '_template', template)
+        ds = getattr(ds_mod, dtype_name)(path=paths, template=template, tokenizer=tokenizer, processor=processor, name=d(prefix + '_name'),
+                                         size=d(prefix + '_size'), split=d(prefix + '_split'), data_files=d(prefix + '_data_files'),
+                                         optional_args=d(prefix + '_optional_args', []))
+        loader = DataLoader(ds, collate_fn=ds.get_collator(), sampler=DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True),
+                            batch_size=int(cfg_get(cfgs, 'train_cfgs.' + batch_key, 1)))
+        return DevicePrefetcher(loader, trainer.device, getattr(trainer, 'pad_token_id', None))
+
+    return build('train', train_dtype_name, 'per_device_train_batch_size'), build('eval', eval_dtype_name or train_dtype_name, 'per_device_eval_batch_size')

@@ -38,7 +38,7 @@ class DPOTrainer:
         self.device = torch.device(device)
         self.model_cfg = model_cfg
         self.train_dataloader, self.eval_dataloader = train_dataloader, None
-        self.tokenizer = tokenizer
+        self.tokenizer, self.processor, self.hf_config = tokenizer, None, None
         self.global_step = 0
         self.emulate_bf16_logp = emulate_bf16_logp
         self.share_vision_tower = share_vision_tower
@@ -46,15 +46,19 @@ class DPOTrainer:
         # (text_to_text/dpo.py:160-176, text_image_to_text/dpo.py:134-153) do not
         self.skip_identical_pairs = bool(model_cfg and model_cfg.get('kind') == 'qwen2audio')
         self.infer_batch = lambda batch: {k: v for k, v in batch.items() if k != 'meta_info'}
-        self.init_check()
+        # the reference's constructor order (text_to_text/dpo.py:59-77): init_check, init_models, init_datasets, init_engines, init_logger.
+        # `DPOTrainer(cfgs, ds_cfgs)` alone works like the reference's: the models come from model_cfgs.model_name_or_path, the
+        # dataloaders from data_cfgs; the keyword arguments inject pre-built pieces instead (tests, bench.py, INTEGRATION.md level B)
         self.init_models(policy_state, reference_state)
+        self.init_check()
+        self.init_datasets()
         self.init_engines()
         self.init_logger()
 
     # ------------------------------------------------------------------ init_*
     def init_check(self) -> None:
         if self.model_cfg is None:
-            raise ValueError('model_cfg (align_anything_amd.configs dict) is required')
+            raise ValueError('model_cfg (align_anything_amd.configs dict) or model_cfgs.model_name_or_path is required')
         self.scale_coeff = float(cfg_get(self.cfgs, 'train_cfgs.scale_coeff', 0.1))
         self.pad_token_id = cfg_get(self.cfgs, 'model_cfgs.pad_token_id', None)
         if self.pad_token_id is None:
@@ -65,7 +69,18 @@ class DPOTrainer:
             raise ValueError('pad_token_id is required (tokenizer.pad_token_id or model_cfgs.pad_token_id)')
 
     def init_models(self, policy_state=None, reference_state=None) -> None:
-        """text_image_to_text/dpo.py:58-83: policy with freeze flags, frozen reference from the same checkpoint."""
+        """text_image_to_text/dpo.py:58-83: policy with freeze flags, frozen reference from the same checkpoint.  Without a `model_cfg` the
+        geometry, the weights of both models, the tokenizer and the processor come from `model_cfgs.model_name_or_path`
+        (checkpoint.load_pretrained = the reference's load_pretrained_models, models/pretrained_model.py:160-312)."""
+        from_path = self.model_cfg is None
+        if from_path:
+            from transformers import AutoConfig
+            from .. import configs
+            path = cfg_get(self.cfgs, 'model_cfgs.model_name_or_path', None)
+            if not path:
+                raise ValueError('model_cfg (align_anything_amd.configs dict) or model_cfgs.model_name_or_path is required')
+            self.model_cfg = configs.from_hf_config(AutoConfig.from_pretrained(path, trust_remote_code=True))     # kind -> freeze flags below
+            self.skip_identical_pairs = self.model_cfg.get('kind') == 'qwen2audio'
         freeze = {}
         if self.model_cfg['kind'] == 'qwen2audio':
             freeze = dict(freeze_mm_proj=bool(cfg_get(self.cfgs, 'train_cfgs.freeze_mm_proj', False)),
@@ -81,12 +96,28 @@ class DPOTrainer:
             # experts split over the data-parallel ranks (expert_parallel.py); the exchange runs on its own communicator so it
             # never queues behind a gradient bucket.  Policy and reference shard the same way.
             freeze = ref_kw = epk
+        if from_path:
+            from .common import resolve_pretrained
+            self.policy, tok, self.processor, self.hf_config = resolve_pretrained(self.cfgs, self.device, trainable=True, dtype=self.dtype, build_kwargs=freeze)
+            self.tokenizer = self.tokenizer or tok
+            self.model_cfg = self.policy.cfg          # after the pad-token resize (vocab + 1 when the tokenizer had no pad token)
+            self.reference = (resolve_pretrained(self.cfgs, self.device, trainable=False, dtype=self.dtype, build_kwargs=ref_kw)[0]
+                              if self.uses_reference else None)
+            return
         self.policy = build_model(self.model_cfg, self.device, trainable=True, dtype=self.dtype, **freeze)
         self.reference = build_model(self.model_cfg, self.device, trainable=False, dtype=self.dtype, **ref_kw) if self.uses_reference else None
         if policy_state is not None:
             self.policy.load_state_dict(policy_state)
             if self.reference is not None:
                 self.reference.load_state_dict(reference_state if reference_state is not None else policy_state)
+
+    def init_datasets(self) -> None:
+        """text_to_text/dpo.py:109-113 `get_dataloaders(PreferenceDataset, PreferenceDataset)`: built from data_cfgs through the reference's own
+        dataset / template plugins (common.get_dataloaders) unless a dataloader was handed in or data_cfgs names no dataset."""
+        if self.train_dataloader is not None:
+            return
+        from .common import get_dataloaders
+        self.train_dataloader, self.eval_dataloader = get_dataloaders(self, 'PreferenceDataset', 'PreferenceDataset')
 
     def init_engines(self) -> None:
         """base/supervised_trainer.py:234-271 + dpo.py:114-120, with the native engine in DeepSpeed's place."""

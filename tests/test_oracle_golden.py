@@ -449,3 +449,31 @@ def test_qwen2vl_rm_oracle_matches_reference_ti2t_rm_trainer_loss():
             assert rel_err(sd[k[2:]].grad, T(z[k])) < 2e-3, (k, rel_err(sd[k[2:]].grad, T(z[k])))
             n += 1
     assert n == 6
+
+
+def test_teacher_reproduces_the_reference_first_steps_without_the_reference():
+    """oracle/teacher.py (the per-step function the GPU test teacher-forces the native fp32 path against) was pinned to the reference's own
+    64 steps in the build container (oracle/gen_golden.py::gen_opt125m_teacher: stored maxima below).  Re-checked here without the reference:
+    from the regenerated init, the teacher's first steps give the reference's stored losses, gradient norms, learning rates and weight
+    fingerprints (the trajectories are still common there)."""
+    from oracle.synthetic import opt125m_config1
+    from oracle.teacher import Teacher, fingerprint
+    from align_anything_amd import configs
+    z = load_golden('opt125m_teacher.npz')
+    dev_keys = [str(k) for k in z['dev_keys']]
+    worst = dict(zip(dev_keys, z['teacher_dev'].max(0)))
+    # teacher-forced on the reference's own weights and AdamW state, all 64 steps (HF arithmetic): loss identical, update within an fp32 quantum
+    assert z['ref'].shape[0] == 64 and worst['abs_loss'] < 2e-6 and worst['rel_grad_norm'] < 2e-4 and worst['max_abs_weight'] <= 2.05e-6
+    assert worst['rel_update_l2_worst_signal_tensor'] < 5e-2 and worst['abs_loss_oracle_port'] < 5e-5 and worst['abs_lr'] < 1e-15
+    oc, policy, refm, batches = opt125m_config1(num_pairs=2)
+    sd = {k: v.detach().clone() for k, v in policy.state_dict().items()}
+    teacher = Teacher(configs.from_hf_config(oc), refm.state_dict(), oc.pad_token_id, 64, hf_config=oc)
+    index = {str(n): torch.from_numpy(i) for n, i in zip(z['fp_names'], z['fp_index'])}
+    assert torch.equal(fingerprint(sd, index), torch.from_numpy(z['fingerprint'][0]))
+    w, m, v = sd, Teacher.zeros_like(sd), Teacher.zeros_like(sd)
+    for k in range(2):
+        info, w, m, v = teacher.step(w, m, v, k, batches[k])
+        assert abs(info['train/loss'] - float(z['ref'][k, 0])) < 2e-6, (k, info['train/loss'], float(z['ref'][k, 0]))
+        assert abs(info['grad_norm'] - float(z['ref'][k, 1])) < 2e-4 * float(z['ref'][k, 1])
+        assert abs(info['train/lr'] - float(z['ref'][k, 2])) < 1e-15
+        assert float((fingerprint(w, index) - torch.from_numpy(z['fingerprint'][k + 1])).abs().max()) <= 2.5e-7
