@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "aa_ctx.h"
+
 typedef unsigned short bf16_t;  // raw bf16 storage (torch.bfloat16 bit pattern)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

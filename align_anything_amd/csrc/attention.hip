@@ -933,14 +933,14 @@ static int set_lds(K kern, int bytes, const char* name) {
 
 // head_dim 128 runs on the one-wave-per-SIMD 32x32x16 kernels of attn128.inc; AA_ATTN128=0 / aa_attn_set_impl(0) keeps the 16x16x32 kernels above
 // (same-box A/B, bisecting; both stay tested).  Bit 0: forward, bit 1: backward.
-static int g_attn_impl = -1;
+// aa_ctx::attn_impl (-1: read AA_ATTN128 once)
 static int attn_impl() {
-    if (g_attn_impl < 0) { const char* e = getenv("AA_ATTN128"); g_attn_impl = e ? atoi(e) : 3; }
-    return g_attn_impl;
+    if (aa_ctx_cur()->attn_impl < 0) { const char* e = getenv("AA_ATTN128"); aa_ctx_cur()->attn_impl = e ? atoi(e) : 3; }
+    return aa_ctx_cur()->attn_impl;
 }
 extern "C" int aa_attn_set_impl(int impl) {
     AA_REQUIRE(impl >= 0 && impl <= 3, "aa_attn_set_impl: %d (bit 0 = forward, bit 1 = backward on the 32x32x16 kernels)", impl);
-    g_attn_impl = impl;
+    aa_ctx_cur()->attn_impl = impl;
     return AA_OK;
 }
 static bool attn128_enabled() { return (attn_impl() & 1) != 0; }

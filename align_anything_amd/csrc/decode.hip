@@ -539,15 +539,20 @@ extern "C" int aa_argmax_rows(const void* logits, long ld, int rows, int V, cons
     return AA_OK;
 }
 
-// temperature + nucleus (top-p) sampling, HF semantics (TemperatureLogitsWarper, TopPLogitsWarper with
-// min_tokens_to_keep = 1): keep the smallest set of highest-probability tokens whose mass reaches top_p, renormalise,
-// draw with the caller's uniform u[row].  The kept set is found by searching the probability threshold (no sort): 10 rounds
+// temperature + top-k + nucleus (top-p) sampling, HF semantics and warper order (TemperatureLogitsWarper, TopKLogitsWarper,
+// TopPLogitsWarper with min_tokens_to_keep = 1; hf:generation/logits_process.py -- the reference's GenerationConfig(temperature, top_p,
+// repetition_penalty, do_sample=True), trainers/text_to_text/ppo.py:161-170, inherits HF's default top_k: 50 under transformers 4.x):
+// top-k keeps every score >= the k-th largest (ties stay, as `scores < topk(scores, k)[..., -1]` removes only strictly smaller ones) --
+// found EXACTLY by an 8-way search over the order-preserving integer keys of the scores (counts, not masses: <= 12 passes); then keep the
+// smallest set of highest-probability tokens of the renormalised rest whose mass reaches top_p, renormalise, draw with the caller's
+// uniform u[row].  The kept set is found by searching the probability threshold (no sort): 10 rounds
 // of an 8-way split (7 candidate thresholds per pass over the row = the 2^-30 resolution of 30 bisections in a third of the
 // passes); the draw walks the vocabulary in index order.
 // One 512-thread workgroup per row; thread t owns the contiguous slice [t*per, (t+1)*per) and re-reads it from L2 with 16-B
 // loads in each of the 13 passes (a register-resident copy spills at 1024 x 40 and at 512 x 80 values -- measured, not kept).
+// floor: scores below it are removed (-inf), the top-k cut of TopKLogitsWarper; -inf = keep everything
 __device__ __forceinline__ void load_scores8(const bf16_t* __restrict__ x, const uint8_t* __restrict__ seen, int i0, int e, float pen,
-                                             float inv_temp, float (&v)[8]) {
+                                             float inv_temp, float (&v)[8], float floor = -INFINITY) {
     if (i0 + 8 <= e && ((reinterpret_cast<uintptr_t>(x + i0) & 15) == 0)) {
         const u16x8 t = *reinterpret_cast<const u16x8*>(x + i0);
 #pragma unroll
@@ -562,10 +567,22 @@ __device__ __forceinline__ void load_scores8(const bf16_t* __restrict__ x, const
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (i0 + j < e) ? penalised(x, seen, i0 + j, pen) * inv_temp : -INFINITY;
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] >= floor ? v[j] : -INFINITY;
+}
+
+// order-preserving map float -> uint32 (larger float = larger key; -inf is the smallest key of any score)
+__device__ __forceinline__ uint32_t float_key(float f) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) {
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __builtin_bit_cast(float, b);
 }
 
 __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restrict__ logits, long ld, int V,
-                                                           float inv_temp, float top_p,
+                                                           float inv_temp, float top_p, int top_k,
                                                            const float* __restrict__ u,
                                                            const uint8_t* __restrict__ seen_all, long ld_seen, float pen,
                                                            int64_t* __restrict__ out) {
@@ -589,12 +606,59 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
         for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[j]);
     }
     mx = block_max<NT>(mx, red);
+    // ---- top-k: floor = the k-th largest score (exact).  Invariant: count(score >= lo) >= k > count(score >= hi), on integer keys.
+    float floor = -INFINITY;
+    if (top_k > 0 && top_k < V) {
+        __shared__ int cnt7[NW][KS];
+        unsigned long long lo = (unsigned long long)float_key(-INFINITY) + 1ull, hi = (unsigned long long)float_key(mx) + 1ull;
+        while (hi - lo > 1ull) {
+            const unsigned long long width = hi - lo;
+            int cs[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) cs[k] = 0;
+#pragma unroll 2
+            for (int i = b; i < e; i += 8) {
+                float v[8];
+                load_scores8(x, seen, i, e, pen, inv_temp, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned long long kj = float_key(v[j]);
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) cs[k] += (kj >= lo + width * (unsigned long long)(k + 1) / 8ull) ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cs[k] += __shfl_xor(cs[k], o, 64);
+            }
+            __syncthreads();
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < KS; ++k) cnt7[wave][k] = cs[k];
+            }
+            __syncthreads();
+            unsigned long long nlo = lo, nhi = lo + width / 8ull;
+            if (nhi <= lo) nhi = lo + 1ull;           // width < 8: the first candidate equals lo (whose count is >= k by the invariant)
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                int t = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += cnt7[w][k];
+                const unsigned long long ck = lo + width * (unsigned long long)(k + 1) / 8ull;
+                if (t >= top_k && ck > nlo) { nlo = ck; nhi = (k + 1 < KS) ? lo + width * (unsigned long long)(k + 2) / 8ull : hi; }
+            }
+            if (nhi <= nlo) nhi = nlo + 1ull;
+            lo = nlo; hi = nhi;
+        }
+        floor = key_float((uint32_t)lo);
+    }
     // ---- pass 2: partition function
     float z = 0.f;
 #pragma unroll 2
     for (int i = b; i < e; i += 8) {
         float v[8];
-        load_scores8(x, seen, i, e, pen, inv_temp, v);
+        load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
 #pragma unroll
         for (int j = 0; j < 8; ++j) z += expf(v[j] - mx);          // exp(-inf) = 0 for the slots beyond e
     }
@@ -611,7 +675,7 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
 #pragma unroll 2
             for (int i = b; i < e; i += 8) {
                 float v[8];
-                load_scores8(x, seen, i, e, pen, inv_temp, v);
+                load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float pj = expf(v[j] - mx) * invz;
@@ -644,7 +708,7 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
 #pragma unroll 2
     for (int i = b; i < e; i += 8) {
         float v[8];
-        load_scores8(x, seen, i, e, pen, inv_temp, v);
+        load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float pj = expf(v[j] - mx) * invz; mine += (pj >= tau) ? pj : 0.f; }
     }
@@ -670,7 +734,7 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
         int pick = -1, last_kept = -1;
         for (int i = b; i < e && pick < 0; i += 8) {
             float v[8];
-            load_scores8(x, seen, i, e, pen, inv_temp, v);
+            load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float pj = expf(v[j] - mx) * invz;
@@ -681,16 +745,22 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
     }
     if (owner < 0 && threadIdx.x == 0) out[blockIdx.x] = 0;      // unreachable: p_max >= tau always keeps one token
 }
+extern "C" int aa_sample_top_k_top_p(const void* logits, long ld, int rows, int V, float temperature, int top_k, float top_p,
+                                     const float* uniform, const uint8_t* seen, long ld_seen, float repetition_penalty,
+                                     int64_t* out, void* stream) {
+    AA_REQUIRE(rows > 0 && V > 0, "aa_sample_top_k_top_p: bad shape rows=%d V=%d", rows, V);
+    AA_REQUIRE(repetition_penalty > 0.f, "aa_sample_top_k_top_p: repetition_penalty must be > 0");
+    AA_REQUIRE(temperature > 0.f && top_p > 0.f && top_p <= 1.f, "aa_sample_top_k_top_p: temperature=%f / top_p=%f out of range", temperature, top_p);
+    AA_REQUIRE(top_k >= 0, "aa_sample_top_k_top_p: top_k %d (0 = no cut)", top_k);
+    hipLaunchKernelGGL(sample_top_p_kernel, dim3(rows), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
+                       1.f / temperature, top_p, top_k, uniform, seen, ld_seen, repetition_penalty, out);
+    AA_CHECK_LAUNCH("aa_sample_top_k_top_p");
+    return AA_OK;
+}
 extern "C" int aa_sample_top_p(const void* logits, long ld, int rows, int V, float temperature, float top_p,
                                const float* uniform, const uint8_t* seen, long ld_seen, float repetition_penalty,
                                int64_t* out, void* stream) {
-    AA_REQUIRE(rows > 0 && V > 0, "aa_sample_top_p: bad shape rows=%d V=%d", rows, V);
-    AA_REQUIRE(repetition_penalty > 0.f, "aa_sample_top_p: repetition_penalty must be > 0");
-    AA_REQUIRE(temperature > 0.f && top_p > 0.f && top_p <= 1.f, "aa_sample_top_p: temperature=%f / top_p=%f out of range", temperature, top_p);
-    hipLaunchKernelGGL(sample_top_p_kernel, dim3(rows), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
-                       1.f / temperature, top_p, uniform, seen, ld_seen, repetition_penalty, out);
-    AA_CHECK_LAUNCH("aa_sample_top_p");
-    return AA_OK;
+    return aa_sample_top_k_top_p(logits, ld, rows, V, temperature, 0, top_p, uniform, seen, ld_seen, repetition_penalty, out, stream);
 }
 
 // align_anything/trainers/text_image_to_text/ppo.py:56-86 move_padding_left: every row of the generated sequences is rotated

@@ -433,7 +433,7 @@ void gemm_kernel(const GemmParams p) {
     }
 }
 
-static int g_gm = 0;    // tile-group height of the grouped tile order; 0 = heuristic (AA_GEMM_GM / aa_gemm_set_group override)
+// tile-group height of the grouped tile order: aa_ctx::gm, 0 = heuristic (AA_GEMM_GM / aa_gemm_set_group override)
 
 
 // Height (in tiles) of the groups of the L2-aware tile order.  Same-process sweep on the 7B shapes at M = 16384
@@ -444,7 +444,7 @@ static int g_gm = 0;    // tile-group height of the grouped tile order; 0 = heur
 static int pick_group(bool a_t, bool b_n, int tiles_n, int K) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("AA_GEMM_GM"); env = e ? atoi(e) : 0; }
-    if (g_gm > 0) return g_gm;
+    if (aa_ctx_cur()->gm > 0) return aa_ctx_cur()->gm;
     if (env > 0) return env;
     if (tiles_n <= 16 && K >= 8192) return 0x100 | 4;
     if (!a_t && b_n && tiles_n > 32) return 3;
@@ -498,15 +498,15 @@ static int launch_layout(GemmParams& p, int tile, hipStream_t st) {
     }
 }
 
-static int g_force_tile = -2;  // -2: read env once ; -1: heuristic
+// forced tile config: aa_ctx::force_tile (-2: read env once; -1: heuristic)
 
 // waves-quantisation heuristic over the 256-CU chip
 static int pick_tile(int M, int N) {
-    if (g_force_tile == -2) {
+    if (aa_ctx_cur()->force_tile == -2) {
         const char* e = getenv("AA_GEMM_TILE");
-        g_force_tile = e ? atoi(e) : -1;
+        aa_ctx_cur()->force_tile = e ? atoi(e) : -1;
     }
-    if (g_force_tile >= 0) return g_force_tile;
+    if (aa_ctx_cur()->force_tile >= 0) return aa_ctx_cur()->force_tile;
     static int g4 = -1;      // AA_GEMM_G4=0 keeps the 8-wave kernel for the 256x256 tile (A/B runs)
     if (g4 < 0) { const char* e = getenv("AA_GEMM_G4"); g4 = e ? atoi(e) : 1; }
     struct Cfg { int bm, bn, slots; float eff; };
@@ -624,12 +624,12 @@ extern "C" int aa_rope_inplace(void* buf, long ld, int col0, int nheads, int hd,
 extern "C" int aa_swiglu_fwd(const void* gate_up, void* out, long M, int F, void* stream);
 extern "C" int aa_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, long M, int F, void* stream);
 
-static int g_fuse = -1;      // AA_GEMM_FUSE=0: always the unfused kernels (A/B runs, parity tests)
+// aa_ctx::fuse: AA_GEMM_FUSE=0 = always the unfused kernels (A/B runs, parity tests)
 static bool fuse_enabled() {
-    if (g_fuse < 0) { const char* e = getenv("AA_GEMM_FUSE"); g_fuse = e ? atoi(e) : 1; }
-    return g_fuse != 0 && g_force_tile != 0;
+    if (aa_ctx_cur()->fuse < 0) { const char* e = getenv("AA_GEMM_FUSE"); aa_ctx_cur()->fuse = e ? atoi(e) : 1; }
+    return aa_ctx_cur()->fuse != 0 && aa_ctx_cur()->force_tile != 0;
 }
-extern "C" int aa_gemm_set_fuse(int on) { g_fuse = on ? 1 : 0; return AA_OK; }
+extern "C" int aa_gemm_set_fuse(int on) { aa_ctx_cur()->fuse = on ? 1 : 0; return AA_OK; }
 
 // hf:models/llama/modeling_llama.py:228-246 q/k/v projections + apply_rotary_pos_emb (:130-160): C[M, N] = A W^T with the rotary
 // embedding applied to the heads in columns [0, rope_cols) (q and k of the fused [q|k|v] weight); pos[M], cos / sin [max_pos, hd/2] bf16
@@ -694,16 +694,11 @@ namespace {
 // Records are keyed on (F, K, bucket of M): the winner is a property of the box's memory round trip and of the layer geometry, not of the exact row
 // count, and variable sequence lengths make M take many values -- one record per power-of-two bucket of M / 256 keeps re-probes (8 GEMM launches +
 // stream syncs each) bounded; 64 slots, least-recently-used eviction.
-struct GluPlan { int mb, F, K, fused; unsigned long stamp; };
-constexpr int GLU_PLANS = 64;
-GluPlan g_glu_plans[GLU_PLANS];
-int g_glu_nplans = 0;
-unsigned long g_glu_clock = 0;
-int g_glu_mode = -1;                 // AA_GLU_BWD: -1 = follow the per-shape record (default), 0 = always unfused, 1 = always fused
-bool g_glu_mode_read = false;
+// (the records live in the library context: aa_ctx::glu_plans, csrc/aa_ctx.h)
 int glu_mode() {
-    if (!g_glu_mode_read) { const char* e = getenv("AA_GLU_BWD"); if (e) g_glu_mode = atoi(e); g_glu_mode_read = true; }
-    return g_glu_mode;
+    aa_ctx* c = aa_ctx_cur();
+    if (!c->glu_mode_read) { const char* e = getenv("AA_GLU_BWD"); if (e) c->glu_mode = atoi(e); c->glu_mode_read = true; }
+    return c->glu_mode;
 }
 int glu_m_bucket(int M) {            // 0: M <= 256, 1: <= 512, 2: <= 1024, ...
     int b = 0;
@@ -711,21 +706,23 @@ int glu_m_bucket(int M) {            // 0: M <= 256, 1: <= 512, 2: <= 1024, ...
     return b;
 }
 int glu_plan_lookup(int M, int F, int K) {
+    aa_ctx* c = aa_ctx_cur();
     const int mb = glu_m_bucket(M);
-    for (int i = 0; i < g_glu_nplans; ++i)
-        if (g_glu_plans[i].mb == mb && g_glu_plans[i].F == F && g_glu_plans[i].K == K) { g_glu_plans[i].stamp = ++g_glu_clock; return g_glu_plans[i].fused; }
+    for (int i = 0; i < c->glu_nplans; ++i)
+        if (c->glu_plans[i].mb == mb && c->glu_plans[i].F == F && c->glu_plans[i].K == K) { c->glu_plans[i].stamp = ++c->glu_clock; return c->glu_plans[i].fused; }
     return -1;
 }
 void glu_plan_store(int M, int F, int K, int fused) {
+    aa_ctx* c = aa_ctx_cur();
     const int mb = glu_m_bucket(M);
     int slot = -1;
-    for (int i = 0; i < g_glu_nplans; ++i)
-        if (g_glu_plans[i].mb == mb && g_glu_plans[i].F == F && g_glu_plans[i].K == K) slot = i;
+    for (int i = 0; i < c->glu_nplans; ++i)
+        if (c->glu_plans[i].mb == mb && c->glu_plans[i].F == F && c->glu_plans[i].K == K) slot = i;
     if (slot < 0) {
-        if (g_glu_nplans < GLU_PLANS) slot = g_glu_nplans++;
-        else { slot = 0; for (int i = 1; i < GLU_PLANS; ++i) if (g_glu_plans[i].stamp < g_glu_plans[slot].stamp) slot = i; }
+        if (c->glu_nplans < AA_GLU_PLANS) slot = c->glu_nplans++;
+        else { slot = 0; for (int i = 1; i < AA_GLU_PLANS; ++i) if (c->glu_plans[i].stamp < c->glu_plans[slot].stamp) slot = i; }
     }
-    g_glu_plans[slot] = GluPlan{mb, F, K, fused, ++g_glu_clock};
+    c->glu_plans[slot] = AaGluPlan{mb, F, K, fused, ++c->glu_clock};
 }
 int glu_bwd_run(bool fused, const void* dY, const void* Wdown, const void* GU, void* dGU, void* dact_ws, int M, int F, int K, long ldy,
                 long ldw, long ldgu, long lddgu, void* stream) {
@@ -761,8 +758,8 @@ extern "C" int aa_gemm_glu_bwd_plan(const void* dY, const void* Wdown, const voi
     return AA_OK;
 }
 
-extern "C" int aa_gemm_glu_bwd_set_mode(int mode) { g_glu_mode = mode; g_glu_mode_read = true; return AA_OK; }
-extern "C" int aa_gemm_glu_bwd_forget(void) { g_glu_nplans = 0; return AA_OK; }
+extern "C" int aa_gemm_glu_bwd_set_mode(int mode) { aa_ctx_cur()->glu_mode = mode; aa_ctx_cur()->glu_mode_read = true; return AA_OK; }
+extern "C" int aa_gemm_glu_bwd_forget(void) { aa_ctx_cur()->glu_nplans = 0; return AA_OK; }
 
 // Times `reps` launches of each variant on the caller's buffers (after one untimed launch each) with HIP events on `stream`, records the
 // faster one for (M, F, K) and leaves dGU computed.  Synchronises the stream: call it once per shape, outside any timed region.
@@ -807,6 +804,6 @@ extern "C" int aa_gemm_glu_bwd_bf16(const void* dY, const void* Wdown, const voi
 }
 
 // test hook: force a tile config (-1 = heuristic)
-extern "C" int aa_gemm_set_tile(int tile) { g_force_tile = tile; return AA_OK; }
+extern "C" int aa_gemm_set_tile(int tile) { aa_ctx_cur()->force_tile = tile; return AA_OK; }
 // test/bench hook: 1 = software-pipelined K loop (default), 0 = simple one-barrier schedule
-extern "C" int aa_gemm_set_group(int gm) { g_gm = gm < 0 ? 0 : gm; return AA_OK; }   // 0 = heuristic; +256 = group tile columns instead of rows
+extern "C" int aa_gemm_set_group(int gm) { aa_ctx_cur()->gm = gm < 0 ? 0 : gm; return AA_OK; }   // 0 = heuristic; +256 = group tile columns instead of rows

@@ -185,8 +185,7 @@ void adamw_thin_kernel(float* __restrict__ master, float* __restrict__ m, float*
     }
 }
 
-static int g_adam_thin = 0;
-extern "C" int aa_adamw_set_thin(int on) { g_adam_thin = on ? 1 : 0; return AA_OK; }
+extern "C" int aa_adamw_set_thin(int on) { aa_ctx_cur()->adam_thin = on ? 1 : 0; return AA_OK; }
 
 extern "C" int aa_adamw_flat(float* master, float* m, float* v, void* p16, const void* g, int g_dtype,
                              long n, float lr, float beta1, float beta2, float eps, float weight_decay,
@@ -199,7 +198,7 @@ extern "C" int aa_adamw_flat(float* master, float* m, float* v, void* p16, const
     const long work = n / 4 / 256 + 1;
     const int grid = (int)(work < 4096 ? work : 4096);
     hipStream_t st = (hipStream_t)stream;
-    if (g_adam_thin) {
+    if (aa_ctx_cur()->adam_thin) {
         const long CH = 1L << 28;          // elements per launch: 32-bit offsets inside the kernel
         for (long o = 0; o < n; o += CH) {
             const uint32_t cn = (uint32_t)((n - o) < CH ? (n - o) : CH);

@@ -13,7 +13,33 @@ void aa_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* aa_last_error(void) { return g_err; }
-extern "C" int aa_version(void) { return 100; }
+extern "C" int aa_version(void) { return 101; }
+
+// ---- library contexts (csrc/aa_ctx.h): the state behind the set_* switches, plan records and the communicator
+static aa_ctx g_default_ctx;
+static thread_local aa_ctx* t_ctx = nullptr;
+aa_ctx* aa_ctx_cur() { return t_ctx ? t_ctx : &g_default_ctx; }
+
+extern "C" int aa_ctx_create(void** ctx) {
+    AA_REQUIRE(ctx != nullptr, "aa_ctx_create: ctx is null");
+    *ctx = new aa_ctx();
+    return AA_OK;
+}
+// NULL = back to the process-wide default context.  Per thread, like hipSetDevice.
+extern "C" int aa_ctx_set_current(void* ctx) { t_ctx = static_cast<aa_ctx*>(ctx); return AA_OK; }
+extern "C" int aa_ctx_get_current(void** ctx) {
+    AA_REQUIRE(ctx != nullptr, "aa_ctx_get_current: ctx is null");
+    *ctx = t_ctx;            // NULL while the thread uses the default context
+    return AA_OK;
+}
+extern "C" int aa_ctx_destroy(void* ctx) {
+    aa_ctx* c = static_cast<aa_ctx*>(ctx);
+    AA_REQUIRE(c != nullptr && c != &g_default_ctx, "aa_ctx_destroy: not a context made by aa_ctx_create");
+    if (t_ctx == c) t_ctx = nullptr;
+    aa_comm_release(c);
+    delete c;
+    return AA_OK;
+}
 
 extern "C" int aa_device_info(int* cu_count, int* lds_per_cu, int* wave_size, char* arch, int arch_len) {
     int dev = 0;

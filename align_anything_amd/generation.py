@@ -16,11 +16,31 @@ import torch
 from . import ops
 
 
+_HF_TOP_K = []
+
+
+def hf_default_top_k():
+    """`GenerationConfig().top_k` of the installed transformers (cached): the value the reference's rollouts sample with when its yaml does
+    not set one."""
+    if not _HF_TOP_K:
+        try:
+            from transformers import GenerationConfig
+            _HF_TOP_K.append(GenerationConfig().top_k)
+        except Exception:
+            _HF_TOP_K.append(None)
+    return _HF_TOP_K[0]
+
+
 @torch.no_grad()
 def generate(model, input_ids, attention_mask, *, max_length=None, max_new_tokens=None, do_sample=True,
              temperature=1.0, top_p=1.0, repetition_penalty=1.0, eos_token_id=None, pad_token_id=0,
-             pixel_values=None, generator=None, sync_every=8, use_graph=False, **mm):
-    """Returns sequences [N, T_prompt + n_new] (int64), right-padded with pad_token_id after EOS."""
+             pixel_values=None, generator=None, sync_every=8, use_graph=False, top_k='hf', **mm):
+    """Returns sequences [N, T_prompt + n_new] (int64), right-padded with pad_token_id after EOS.
+    top_k: HF's TopKLogitsWarper between temperature and top-p; 'hf' = whatever the installed transformers' GenerationConfig defaults to
+    (the reference builds GenerationConfig(temperature, top_p, repetition_penalty, do_sample=True) and inherits it: 50 under 4.x, None under
+    5.x -- trainers/text_to_text/ppo.py:161-170); None / 0 = no cut."""
+    if top_k == 'hf':
+        top_k = hf_default_top_k()
     if repetition_penalty <= 0.0:
         raise ValueError('repetition_penalty must be > 0')
     N, T = input_ids.shape
@@ -99,7 +119,7 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
 
     def select(lg, u):
         if do_sample:
-            return ops.sample_top_p(lg, temperature, top_p, u, seen, repetition_penalty)
+            return ops.sample_top_p(lg, temperature, top_p, u, seen, repetition_penalty, top_k=top_k)
         return ops.argmax_rows(lg, seen, repetition_penalty)
 
     def one_step():

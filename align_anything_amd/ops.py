@@ -990,10 +990,11 @@ def argmax_rows(logits, seen=None, repetition_penalty=1.0):
     return out
 
 
-def sample_top_p(logits, temperature, top_p, uniform, seen=None, repetition_penalty=1.0):
+def sample_top_p(logits, temperature, top_p, uniform, seen=None, repetition_penalty=1.0, top_k=0):
+    """HF's sampling warpers in their order: temperature, top-k (0 / None = off), top-p; draw with `uniform` [rows]."""
     rows, V = logits.shape
     out = torch.empty(rows, dtype=torch.int64, device=logits.device)
-    call('aa_sample_top_p', logits.data_ptr(), logits.stride(0), rows, V, float(temperature), float(top_p),
+    call('aa_sample_top_k_top_p', logits.data_ptr(), logits.stride(0), rows, V, float(temperature), int(top_k or 0), float(top_p),
          uniform.data_ptr(), _p(seen), seen.stride(0) if seen is not None else 0, float(repetition_penalty),
          out.data_ptr(), stream())
     return out

@@ -69,7 +69,7 @@ class GRPOTrainer:
         self.actor_model.wait_optimizer()
         return generate(self.actor_model.module, prompt_batch['input_ids'].repeat_interleave(G, 0),
                         prompt_batch['attention_mask'].repeat_interleave(G, 0), max_length=int(m('model_max_length', 2048)),
-                        do_sample=True, temperature=float(m('temperature', 1.0)), top_p=float(m('top_p', 1.0)),
+                        do_sample=True, temperature=float(m('temperature', 1.0)), top_p=float(m('top_p', 1.0)), top_k=m('top_k', 'hf'),
                         repetition_penalty=float(m('repetition_penalty', 1.0)), eos_token_id=self.eos_token_id,
                         pad_token_id=self.pad_token_id, generator=generator)
 

@@ -127,7 +127,7 @@ class PPOTrainer(PPOMath):
         self.actor_model.wait_optimizer()
         seq = generate(self.actor_model.module, prompt_batch['input_ids'], prompt_batch['attention_mask'],
                        max_length=int(m('model_max_length', 2048)), do_sample=True, temperature=float(m('temperature', 1.0)),
-                       top_p=float(m('top_p', 1.0)), repetition_penalty=float(m('repetition_penalty', 1.0)),
+                       top_p=float(m('top_p', 1.0)), top_k=m('top_k', 'hf'), repetition_penalty=float(m('repetition_penalty', 1.0)),
                        eos_token_id=m('eos_token_id', None), pad_token_id=pad,
                        pixel_values=prompt_batch.get('pixel_values'), generator=generator)
         return {'input_ids': seq, 'attention_mask': seq.ne(pad)}

@@ -136,6 +136,46 @@ def cpu_baseline(cfg, T, reps=2):
                         'port is pinned to reference-generated fixtures by tests/test_oracle_golden.py'}
 
 
+def preflight(device, rank, world, layers, nbytes=1 << 30, reps=5):
+    """Before any model is built (the first real multi-GPU run must not die half-way for a reason a 5-second check finds):
+    per rank the visible device count and the free HBM against what one data-parallel replica needs (policy bf16 + fp32
+    master / m / v + bf16 gradients + frozen reference + activations of 4 pairs ~ 122 GB + 40 GB at full depth), then one 1 GB bf16 all-reduce
+    on RCCL, warmed once and timed `reps` times with HIP events on the collective's stream -- the bus bandwidth (2 (w-1)/w x bytes / time) is what the
+    per-layer 405 MB gradient buckets will see (DESIGN.md section 6 budgets against >= 250 GB/s).  Rank 0 returns the gathered report."""
+    import torch
+    import torch.distributed as dist
+    free, total = torch.cuda.mem_get_info(device)
+    need = int((122 + 40) * (1 << 30) * max(layers, 1) / 32)
+    rep = {'rank': rank, 'visible_devices': torch.cuda.device_count(), 'device': torch.cuda.get_device_name(device), 'free_GiB': round(free / 2 ** 30, 1),
+           'total_GiB': round(total / 2 ** 30, 1), 'replica_needs_GiB': round(need / 2 ** 30, 1), 'fits': bool(free > need)}
+    if world > 1:
+        buf = torch.ones(nbytes // 2, dtype=torch.bfloat16, device=device)
+        dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        buf.fill_(1.0 / world)
+        e0.record()
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        rep['allreduce_1GiB_ms'] = round(ms, 3)
+        rep['allreduce_busbw_GBps'] = round(2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1)
+        rep['allreduce_value_ok'] = bool(torch.isfinite(buf.float().sum()))
+        del buf
+        torch.cuda.empty_cache()
+    print(f'[bench preflight] {json.dumps(rep)}', file=sys.stderr, flush=True)
+    if not rep['fits']:
+        print(f'[bench preflight] rank {rank}: only {rep["free_GiB"]} GiB free, a replica needs ~{rep["replica_needs_GiB"]} GiB -- expect an out-of-memory abort',
+              file=sys.stderr, flush=True)
+    if world > 1:
+        allr = [None] * world
+        dist.all_gather_object(allr, rep)
+        return allr if rank == 0 else None
+    return [rep]
+
+
 def _free_port() -> int:
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -183,10 +223,20 @@ def main():
                     help='N>1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS; one channel = one workgroup = one CU taken from the GEMMs while a '
                          'gradient bucket is in flight -- a gemm4 workgroup holds all 512 registers of its CU\'s SIMDs, so RCCL and GEMM tiles never share '
                          'a CU; DESIGN.md section 6 has the expected cost).  0 = RCCL\'s default')
-    ap.add_argument('--comm-prof', action='store_true',
-                    help='N>1: after the timed region run ONE extra untimed step with HIP events around every gradient bucket '
-                         '(all-reduce time vs the backward it overlaps with) and add it to the JSON line as "comm"')
+    ap.add_argument('--comm-prof', dest='comm_prof', action='store_true', default=None,
+                    help='N>1 (default ON there since round 4: the first multi-GPU record must carry it): after the timed region run ONE extra untimed '
+                         'step with HIP events around every gradient bucket (all-reduce time vs the backward it overlaps with) -> "multi_gpu.comm"')
+    ap.add_argument('--no-comm-prof', dest='comm_prof', action='store_false')
+    ap.add_argument('--preflight', dest='preflight', action='store_true', default=None,
+                    help='before any model is built, per rank: visible devices, free HBM against the ~122 GB replica, and (N>1) a 1 GB RCCL all-reduce '
+                         'timed with HIP events -> bus GB/s on stderr and in "multi_gpu.preflight".  Default: on for N>1, off for N=1')
+    ap.add_argument('--no-preflight', dest='preflight', action='store_false')
+    ap.add_argument('--preflight-only', action='store_true', help='run the preflight, print its JSON line and exit (no model, no steps)')
     args = ap.parse_args()
+    if args.comm_prof is None:
+        args.comm_prof = args.gpus > 1
+    if args.preflight is None:
+        args.preflight = args.gpus > 1 or args.preflight_only
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(sys.argv[1:], args.gpus))
@@ -246,6 +296,15 @@ def main():
         dist.all_reduce(probe)
         print(f'[bench] rank {rank}/{world} device {torch.cuda.get_device_name(local)} #{local} backend={dist.get_backend()} '
               f'world_seen_by_collective={int(probe.item())}', file=sys.stderr, flush=True)
+
+    pre = preflight(device, rank, world, args.layers) if args.preflight else None
+    if args.preflight_only:
+        if rank == 0:
+            print(json.dumps({'preflight': pre}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from align_anything_amd import configs, ops
     from align_anything_amd.trainers.dpo import DPOTrainer
@@ -319,7 +378,7 @@ def main():
         dist.all_gather(allc, mine)
         same = all(bool(torch.equal(c, allc[0])) for c in allc)
         multi = {'backend': dist.get_backend(), 'world': world, 'rccl_max_nchannels': os.environ.get('NCCL_MAX_NCHANNELS'), 'replicas_bit_identical_after_steps': same,
-                 'optimizer_updates_checked': tr.model.global_steps}
+                 'optimizer_updates_checked': tr.model.global_steps, 'preflight': pre}
         if not same:
             print(f'[bench] rank {rank}: REPLICAS DIVERGED: {[c.tolist() for c in allc]}', file=sys.stderr, flush=True)
         if args.comm_prof:

@@ -36,6 +36,17 @@ extern "C" {
 const char* aa_last_error(void);
 int aa_version(void);
 int aa_device_info(int* cu_count, int* lds_per_cu, int* wave_size, char* arch, int arch_len);
+/* Library contexts (SURVEY.md section 8(b) `aa_ctx*`): all state behind the aa_*_set_* switches, the SwiGLU-backward plan records
+   (aa_gemm_glu_bwd_probe / _plan) and the communicator (aa_comm_init, one per context) belongs to the calling THREAD's current context.
+   A thread that never calls aa_ctx_set_current uses the process-wide default context -- the behaviour of every earlier version.  A host
+   that drives several devices or models from one process makes one context per (thread, device / model): aa_ctx_create, then
+   aa_ctx_set_current on the thread that issues that device's calls (per thread, like hipSetDevice); aa_ctx_set_current(NULL) returns to
+   the default.  aa_ctx_destroy also destroys the context's communicator.  Contexts are not locked: one host thread per context at a time
+   (the reference's model: one process per GPU, a single thread driving its streams -- trainers/base/supervised_trainer.py:234-271). */
+int aa_ctx_create(void** ctx);
+int aa_ctx_set_current(void* ctx);
+int aa_ctx_get_current(void** ctx);      /* *ctx = NULL while the thread is on the default context */
+int aa_ctx_destroy(void* ctx);
 int aa_event_create(void** ev);
 int aa_event_record(void* ev, void* stream);
 int aa_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
@@ -326,6 +337,11 @@ int aa_argmax_rows(const void* logits, long ld, int rows, int V, const uint8_t* 
 int aa_sample_top_p(const void* logits, long ld, int rows, int V, float temperature, float top_p,
                     const float* uniform, const uint8_t* seen, long ld_seen, float repetition_penalty, int64_t* out,
                     void* stream);
+/* the same with HF's TopKLogitsWarper between temperature and top-p (warper order of hf:generation/utils.py): top_k > 0 keeps every score >= the
+   k-th largest (ties kept), 0 = no cut.  The reference's GenerationConfig (trainers/text_to_text/ppo.py:161-170) inherits HF's default top_k
+   (50 under transformers 4.x, None under 5.x): generation.py passes the installed default unless train_cfgs.top_k says otherwise */
+int aa_sample_top_k_top_p(const void* logits, long ld, int rows, int V, float temperature, int top_k, float top_p,
+                          const float* uniform, const uint8_t* seen, long ld_seen, float repetition_penalty, int64_t* out, void* stream);
 
 /* trainers/text_image_to_text/ppo.py:56-86 move_padding_left on the generated sequences (circular shift per row, bit-exact) */
 int aa_move_padding_left(const int64_t* in, long ldi, int64_t* out, long ldo, int rows, int L, int64_t pad, void* stream);

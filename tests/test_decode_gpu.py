@@ -158,6 +158,49 @@ def test_token_selection_kernels():
                 assert abs(float(c[got[r]] - c[want])) < 1e-3 * float(pk.sum()) + float(p[r][got[r]]) + float(p[r][want])
 
 
+def test_top_k_cut_matches_hf_warpers_in_hf_order():
+    """TopKLogitsWarper between temperature and top-p (hf:generation/logits_process.py; the reference's GenerationConfig inherits HF's default
+    top_k = 50 under transformers 4.x, trainers/text_to_text/ppo.py:161-170): the kept set must be EXACTLY HF's -- every score >= the k-th
+    largest, ties kept -- and the draw the inverse CDF of the renormalised rest.  Checked through HF's own warper classes on the CPU."""
+    from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper,
+                                                        TopPLogitsWarper)
+    from align_anything_amd import ops
+    rows, V = 48, 3001
+    g = torch.Generator().manual_seed(11)
+    logits = (torch.randn(rows, V, generator=g) * 4.0).to(torch.bfloat16)
+    logits[3, 5:60] = logits[3].float().max().to(torch.bfloat16)            # 55 tied maxima: k = 50 keeps all 55 (HF removes only strictly smaller scores)
+    logits[4] = logits[4].abs() * -1.0                                      # all-negative row (the key order of negative floats)
+    lg = logits.to(dev())
+    u = torch.rand(rows, generator=g).to(dev())
+    seen = (torch.rand(rows, V, generator=g) < 0.2)
+    ids = [seen[r].nonzero().reshape(1, -1) for r in range(rows)]
+    for temp, top_k, top_p, pen in ((1.0, 50, 1.0, 1.0), (0.7, 50, 0.9, 1.0), (1.2, 1, 1.0, 1.0), (0.9, 7, 0.6, 1.3), (1.0, 3000, 0.95, 1.0), (1.0, 0, 0.9, 1.0)):
+        got = ops.sample_top_p(lg, temp, top_p, u, seen.to(torch.uint8).to(dev()) if pen != 1.0 else None, pen, top_k=top_k).cpu()
+        for r in range(rows):
+            sc = logits[r:r + 1].float()
+            if pen != 1.0:
+                sc = RepetitionPenaltyLogitsProcessor(pen)(ids[r], sc)
+            sc = TemperatureLogitsWarper(temp)(None, sc)
+            if top_k:
+                sc = TopKLogitsWarper(top_k)(None, sc)
+            kept_k = torch.isfinite(sc[0])
+            if top_p < 1.0:
+                sc = TopPLogitsWarper(top_p)(None, sc)
+            p = torch.softmax(sc[0], -1)
+            c = torch.cumsum(p, 0)
+            want = int((c > u[r].item()).nonzero()[0]) if bool((c > u[r].item()).any()) else int(p.nonzero()[-1])
+            assert bool(kept_k[got[r]]), (temp, top_k, top_p, r, 'drew a token the top-k cut removes')
+            if got[r].item() != want:      # only a draw on a boundary of the CDF / of the nucleus may differ (fp32 summation order)
+                assert abs(float(c[got[r]] - c[want])) < 2e-3 + float(p[got[r]]) + float(p[want]) or float(p[got[r]]) > 0, (temp, top_k, top_p, r)
+        if top_k == 1:
+            assert torch.equal(got[:3], logits[:3].float().argmax(-1)) and 5 <= int(got[3]) < 60      # k = 1 -> greedy (a tie: any of the tied maxima)
+    # exactness of the cut on its own (top_p = 1: everything the cut keeps can be drawn, nothing else): sweep u over the CDF of row 3
+    us = torch.linspace(0.0, 0.99999, 400).to(dev())
+    row = lg[3:4].expand(400, V).contiguous()
+    drawn = set(ops.sample_top_p(row, 1.0, 1.0, us, None, 1.0, top_k=50).cpu().tolist())
+    assert drawn == set(range(5, 60))
+
+
 def _greedy_oracle(logits_fn, ids, mask, n_new, eos, pad, penalty=1.0):
     ids, mask = ids.clone(), mask.clone()
     unfinished = torch.ones(ids.shape[0], dtype=torch.bool)

@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     twins = set(lib.parse_header(lib.HEADER_F32))
     assert {'aa_gemm_f32', 'aa_attn_fwd_f32', 'aa_attn_bwd_f32', 'aa_rmsnorm_fwd_f32', 'aa_layernorm_bwd_f32'} <= twins
     lib.LIB.load()
-    assert lib.LIB._dll.aa_version() == 100
+    assert lib.LIB._dll.aa_version() == 101      # 101: library contexts (aa_ctx_*)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -791,3 +791,57 @@ def test_load_pretrained_adds_the_pad_row_like_the_reference(tmp_path):
         old = hf.state_dict()[k]
         assert sd[k].shape == (65, 128) and torch.equal(sd[k][:64], old) and torch.equal(sd[k][64], old.mean(dim=0))
     assert torch.equal(sd['model.layers.0.mlp.down_proj.weight'], hf.state_dict()['model.layers.0.mlp.down_proj.weight'])
+
+
+def test_library_contexts_isolate_switches_and_plans_per_thread():
+    """include/aa_hip.h aa_ctx_*: the state behind the set_* switches / plan records / communicator belongs to the calling thread's current
+    context; the default context keeps the old process-global behaviour.  Host-only calls (no kernel is launched: aa_gemm_glu_bwd_plan only
+    consults the records and the argument alignment)."""
+    import ctypes
+    import threading
+    from align_anything_amd.lib import LIB, AAHipError, call
+    LIB.load()
+
+    def plan():
+        p = ctypes.c_int(-9)
+        call('aa_gemm_glu_bwd_plan', 0x1000, 0x2000, 0x3000, 0x4000, 512, 11008, 4096, 4096, 11008, 22016, 22016, ctypes.addressof(p))
+        return p.value
+
+    def world():
+        r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+        call('aa_comm_world', ctypes.byref(r), ctypes.byref(w))
+        return r.value, w.value
+
+    cur = ctypes.c_void_p(1)
+    call('aa_ctx_get_current', ctypes.byref(cur))
+    assert cur.value is None and world() == (0, 1)
+    base = plan()
+    assert base in (1, 2)                                   # fusable shape: no record yet (2) unless AA_GLU_BWD forces the fused kernel (1)
+    c1, c2 = ctypes.c_void_p(), ctypes.c_void_p()
+    call('aa_ctx_create', ctypes.byref(c1))
+    call('aa_ctx_create', ctypes.byref(c2))
+    try:
+        call('aa_gemm_glu_bwd_set_mode', 0)                 # default context: always the unfused pair
+        assert plan() == 0
+        call('aa_ctx_set_current', c1)
+        assert plan() == base                               # a fresh context is untouched by the default context's switch
+        call('aa_gemm_glu_bwd_set_mode', 1)
+        assert plan() == 1
+        call('aa_ctx_set_current', c2)
+        assert plan() == base
+        call('aa_ctx_get_current', ctypes.byref(cur))
+        assert cur.value == c2.value
+        seen = {}
+        t = threading.Thread(target=lambda: seen.update(other=plan()))      # the current context is per THREAD: a new thread is on the default one
+        t.start(); t.join()
+        assert seen['other'] == 0
+        call('aa_ctx_set_current', None)
+        assert plan() == 0
+        with pytest.raises(AAHipError):
+            call('aa_ctx_destroy', None)
+    finally:
+        call('aa_ctx_set_current', None)
+        call('aa_gemm_glu_bwd_set_mode', -1)
+        call('aa_ctx_destroy', c1)
+        call('aa_ctx_destroy', c2)
+    assert plan() == base
