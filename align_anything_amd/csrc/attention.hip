@@ -769,11 +769,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
 // first).  Wave w owns keys kv0 + 16w .. +15 and loops over 64-query tiles (and over the H/Hkv query heads sharing this kv head).
 //   S[q][kv] = Q K^T, dP[q][kv] = dO V^T          (lane: kv = lane&15, q = 16qb + 4g + r)
 //   dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]
-// NW waves of 16 keys share one Q / dO tile stream.
-template <int HD, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
+// NW waves of 16 KJ keys share one Q / dO tile stream.  KJ = key blocks (of 16) per wave: every Q / dO fragment read from LDS (row form for S / dP,
+// transposed for dV / dK) feeds KJ MFMAs.  KJ = 1 (two 4-wave workgroups per CU): a 1-KiB fragment per 16-cycle MFMA = 256 B/clk wanted of the CU's 128
+// -> the LDS pipe caps the kernel at 50 % of the matrix peak (profiles/r04_attn128_anatomy.txt, section 6).  KJ = 2 (one workgroup per CU, one wave per SIMD
+// with the whole register file: K / V operands 64 + accumulators 128 + scores 64 + packed P / dS 32 registers): half the LDS bytes per MFMA.
+template <int HD, int NW, int KJ = 1>
+__global__ __launch_bounds__(64 * NW, KJ == 1 ? 2 : 1) void attn_bwd_dkv_kernel(const AttnParams p) {
     constexpr int KS = HD / 32, DB = HD / 16;
-    constexpr int TILE_B = 64 * HD * 2, KVB = 16 * NW;
+    constexpr int TILE_B = 64 * HD * 2, KVB = 16 * NW * KJ, KW = 16 * KJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q tile | dO tile] + [2][64 lse | 64 delta]
     float* stat = reinterpret_cast<float*>(smem + 4 * TILE_B);
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
@@ -781,32 +784,35 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnPara
     const int group = p.H / p.Hkv;
     int n, hk, kvb;
     kv_block_of(p, (p.T + KVB - 1) / KVB, n, hk, kvb);
-    const int kv0 = kvb * KVB, kvw = kv0 + wave * 16;
+    const int kv0 = kvb * KVB, kvw = kv0 + wave * KW;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
     const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
     const bf16_t* Kb = p.K + (long)n * T * p.ldk + hk * HD;
     const bf16_t* Vb = p.V + (long)n * T * p.ldv + hk * HD;
     const float c2 = p.scale * LOG2E_F;
-    const int kvg = kvw + l15;
+    const int kvg = kvw + l15;            // key of block j: kvg + 16 j
     DmaLane<HD, 64, NW> dma;
     dma.init(wave, lane);
     const auto qoff = dma.offsets(p.ldq), dooff = dma.offsets(p.lddo);
     const int lds0 = (int)(uintptr_t)smem;
     const int trl = tr_lane_base<HD>(g, l15);
 
-    bf16x8 kf[KS], vf[KS];
-    {
-        const int kr = min(kvg, T - 1);
+    bf16x8 kf[KJ][KS], vf[KJ][KS];
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+        const int kr = min(kvg + 16 * j, T - 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = *reinterpret_cast<const bf16x8*>(Kb + (long)kr * p.ldk + ks * 32 + g * 8);
-            vf[ks] = *reinterpret_cast<const bf16x8*>(Vb + (long)kr * p.ldv + ks * 32 + g * 8);
+            kf[j][ks] = *reinterpret_cast<const bf16x8*>(Kb + (long)kr * p.ldk + ks * 32 + g * 8);
+            vf[j][ks] = *reinterpret_cast<const bf16x8*>(Vb + (long)kr * p.ldv + ks * 32 + g * 8);
         }
     }
-    f32x4 dkacc[DB], dvacc[DB];
+    f32x4 dkacc[KJ][DB], dvacc[KJ][DB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db) { dkacc[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int j = 0; j < KJ; ++j)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) { dkacc[j][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[j][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const int q_begin = p.causal ? (kv0 / 64) * 64 : 0;
     const int ntq = (T - q_begin + 63) / 64;
@@ -833,7 +839,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnPara
     if (total > 0 && kv_valid_block) issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) { landed(kf[ks]); landed(vf[ks]); }
+    for (int j = 0; j < KJ; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { landed(kf[j][ks]); landed(vf[j][ks]); }
     __syncthreads();
     for (int it = 0; it < total && kv_valid_block; ++it) {
         const int cur = it & 1;
@@ -844,9 +852,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnPara
         const float* st = stat + cur * 128;
         const bool wave_active = kvw < T && !(p.causal && kvw > qt0 + 63);
         if (wave_active) {
-            f32x4 sacc[4], dpacc[4];
+            f32x4 sacc[KJ][4], dpacc[KJ][4];
 #pragma unroll
-            for (int qb = 0; qb < 4; ++qb) { sacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f}; dpacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int j = 0; j < KJ; ++j)
+#pragma unroll
+                for (int qb = 0; qb < 4; ++qb) { sacc[j][qb] = f32x4{0.f, 0.f, 0.f, 0.f}; dpacc[j][qb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             AT_PRIO_MFMA_B(1);
 #pragma unroll
             for (int qb = 0; qb < 4; ++qb)
@@ -854,16 +864,22 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnPara
                 for (int ks = 0; ks < KS; ++ks) {
                     const bf16x8 qa = lds_frag<HD>(qt, qb * 16 + l15, ks * 4 + g);
                     const bf16x8 da = lds_frag<HD>(dot, qb * 16 + l15, ks * 4 + g);
-                    sacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sacc[qb], 0, 0, 0);
-                    dpacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dpacc[qb], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j) {
+                        sacc[j][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[j][ks], sacc[j][qb], 0, 0, 0);
+                        dpacc[j][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[j][ks], dpacc[j][qb], 0, 0, 0);
+                    }
                 }
             AT_PRIO_MFMA_B(0);
             AT_PRIO_VALU_B(1);
-            const bool need_mask = (p.causal && qt0 < kvw + 15) || kvw < start || kvw + 16 > KT || qt0 + 64 > T;
-            bf16x8 pfr[2], dsfr[2];
+            const bool need_mask = (p.causal && qt0 < kvw + KW - 1) || kvw < start || kvw + KW > KT || qt0 + 64 > T;
+            bf16x8 pfr[KJ][2], dsfr[KJ][2];
             // P and dS of the 64 x 16 block; the rows' statistics come as 16-byte LDS reads (q = 16 qb + 4 g + r)
             auto softmax_bwd = [&](auto masked) {
+#pragma unroll
+              for (int j = 0; j < KJ; ++j) {
                 f32x4 pv[4], dsv[4];
+                const int kvj = kvg + 16 * j;
 #pragma unroll
                 for (int qb = 0; qb < 4; ++qb) {
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(st + qb * 16 + g * 4);
@@ -872,18 +888,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnPara
                     for (int r = 0; r < 4; ++r) {
                         float l2;       // lse * log2(e) rounded on its own (as when it was pre-scaled into LDS), never contracted into the fma below
                         asm("v_mul_f32 %0, %1, %2" : "=v"(l2) : "v"(l4[r]), "v"(LOG2E_F));
-                        float pe = fast_exp2(sacc[qb][r] * c2 - l2);
+                        float pe = fast_exp2(sacc[j][qb][r] * c2 - l2);
                         if constexpr (decltype(masked)::value) {
                             const int qg = qt0 + qb * 16 + g * 4 + r;
-                            const bool ok = kvg >= start && kvg < KT && qg < T && (!p.causal || kvg <= qg);
+                            const bool ok = kvj >= start && kvj < KT && qg < T && (!p.causal || kvj <= qg);
                             pe = ok ? pe : 0.f;
                         }
                         pv[qb][r] = pe;
-                        dsv[qb][r] = pe * (dpacc[qb][r] - d4[r]) * p.scale;
+                        dsv[qb][r] = pe * (dpacc[j][qb][r] - d4[r]) * p.scale;
                     }
                 }
-                pfr[0] = pack_bf16x8(pv[0], pv[1]); pfr[1] = pack_bf16x8(pv[2], pv[3]);
-                dsfr[0] = pack_bf16x8(dsv[0], dsv[1]); dsfr[1] = pack_bf16x8(dsv[2], dsv[3]);
+                pfr[j][0] = pack_bf16x8(pv[0], pv[1]); pfr[j][1] = pack_bf16x8(pv[2], pv[3]);
+                dsfr[j][0] = pack_bf16x8(dsv[0], dsv[1]); dsfr[j][1] = pack_bf16x8(dsv[2], dsv[3]);
+              }
             };
             if (need_mask) softmax_bwd(std::true_type{}); else softmax_bwd(std::false_type{});
             // dV^T += dO^T P, dK^T += Q^T dS: the transposed Q / dO fragments by inline asm (tr_stream)
@@ -891,18 +908,25 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnPara
             AT_PRIO_MFMA_B(1);
             tr_stream<HD, 2, 0, TILE_B, TR_NBUF_KV>(lds0 + cur * 2 * TILE_B + trl, [&](auto si, auto di, const bf16x8 qt_f, const bf16x8 dot_f) {
                 constexpr int S = decltype(si)::value, D = decltype(di)::value;
-                dvacc[D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr[S], dvacc[D], 0, 0, 0);
-                dkacc[D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsfr[S], dkacc[D], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    dvacc[j][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr[j][S], dvacc[j][D], 0, 0, 0);
+                    dkacc[j][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsfr[j][S], dkacc[j][D], 0, 0, 0);
+                }
             });
             AT_PRIO_MFMA_B(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    const long krow_i = (long)n * T + min(kvg, T - 1);
-    if (p.rope_pos) at_store_rows_rope<DB>(p.dK + krow_i * p.lddk + hk * HD, dkacc, kvg < T, g, p.rope_cos, p.rope_sin, (long)p.rope_pos[krow_i] * (HD / 2));
-    else at_store_rows<DB, true>(p.dK + krow_i * p.lddk + hk * HD, dkacc, 1.f, kvg < T, g);
-    at_store_rows<DB, true>(p.dV + ((long)n * T + min(kvg, T - 1)) * p.lddv + hk * HD, dvacc, 1.f, kvg < T, g);
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+        const int kvj = kvg + 16 * j;
+        const long krow_i = (long)n * T + min(kvj, T - 1);
+        if (p.rope_pos) at_store_rows_rope<DB>(p.dK + krow_i * p.lddk + hk * HD, dkacc[j], kvj < T, g, p.rope_cos, p.rope_sin, (long)p.rope_pos[krow_i] * (HD / 2));
+        else at_store_rows<DB, true>(p.dK + krow_i * p.lddk + hk * HD, dkacc[j], 1.f, kvj < T, g);
+        at_store_rows<DB, true>(p.dV + krow_i * p.lddv + hk * HD, dvacc[j], 1.f, kvj < T, g);
+    }
 }
 
 #include "attn128.inc"
@@ -939,7 +963,7 @@ static int attn_impl() {
     return aa_ctx_cur()->attn_impl;
 }
 extern "C" int aa_attn_set_impl(int impl) {
-    AA_REQUIRE(impl >= 0 && impl <= 3, "aa_attn_set_impl: %d (bit 0 = forward, bit 1 = backward on the 32x32x16 kernels)", impl);
+    AA_REQUIRE(impl >= 0 && impl <= 7, "aa_attn_set_impl: %d (bit 0 = 32x32x16 forward, bit 2 = dK / dV kernel with 32 keys per wave)", impl);
     aa_ctx_cur()->attn_impl = impl;
     return AA_OK;
 }
@@ -993,12 +1017,17 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
     if (hd == 128) {
         // NW = 8 (one 8-wave workgroup per CU sharing the tile stream) measured 1356 us on the bench block against ~1200-1340 for two independent 4-wave
         // workgroups per CU: what it saves in LDS-DMA pieces it loses in overlap across the per-tile barrier (profiles/r04_attn128_anatomy.txt, section 6)
-        const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
+        const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N), gkv2(aa_cdiv(T, 128) * Hkv * N);
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(aa_cdiv(groups * 16, 256)), dim3(256), 0, st, p);
         if ((rc = set_lds(attn_bwd_dq_kernel<128, 4>, lds, "aa_attn_bwd"))) return rc;
         hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 4>), gq, dim3(256), lds, st, p);
-        if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4>, lds + 1024, "aa_attn_bwd"))) return rc;
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4>), gkv, dim3(256), lds + 1024, st, p);
+        if (attn_impl() & 4) {     // AA_ATTN128 bit 2: dK/dV with 32 keys per wave (KJ = 2), one workgroup of 128 keys per CU
+            if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4, 2>, lds + 1024, "aa_attn_bwd"))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4, 2>), gkv2, dim3(256), lds + 1024, st, p);
+        } else {
+            if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4>, lds + 1024, "aa_attn_bwd"))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4>), gkv, dim3(256), lds + 1024, st, p);
+        }
     } else {
         const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
         hipLaunchKernelGGL(attn_delta_kernel<64>, dim3(aa_cdiv(groups * 8, 256)), dim3(256), 0, st, p);

@@ -620,10 +620,10 @@ def test_attention_kernels_keep_fragments_in_registers_and_the_prefetch_in_fligh
         assert int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', blk).group(1)) == 0, blk[:200]
         assert int(re.search(r'VGPRs Spill: (\d+)', blk).group(1)) == 0, blk[:200]
         checked += 1
-    assert checked == 6 and len(names) == 6                 # forward, dQ, dK/dV x head_dim 64 / 128
+    assert checked == 7 and len(names) == 7                 # forward, dQ, dK/dV x head_dim 64 / 128 + the 32-keys-per-wave dK/dV (head_dim 128)
     assert 'scratch_' not in text
     kernels = re.findall(r'^(_Z\d+attn_(?:fwd|bwd_dq|bwd_dkv)_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end', text, flags=re.S | re.M)
-    assert len(kernels) == 6
+    assert len(kernels) == 7
     for name, body in kernels:
         lines = [ln for ln in body.split('\n') if ln.strip() and not ln.strip().startswith(';') or 'ASM' in ln]
         mf = [i for i, ln in enumerate(lines) if 'v_mfma_f32_16x16x32_bf16' in ln]

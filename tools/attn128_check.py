@@ -55,6 +55,7 @@ def main():
     ap.add_argument('--bwd', action='store_true')
     ap.add_argument('--no-time', action='store_true')
     ap.add_argument('--impl', type=int, default=3, help='aa_attn_set_impl value of the kernels under test')
+    ap.add_argument('--base', type=int, default=0, help='aa_attn_set_impl value of the kernels compared against (0 = the 16x16x32 kernels; 3 + --impl 7: the dK/dV variants)')
     ap.add_argument('--only', default='', help='comma list of case names')
     ap.add_argument('--out', default='attn128_check.json')
     a = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
         sc = hd ** -0.5
         c = {'case': name, 'shape': [N, T, H, Hkv], 'causal': causal}
         outs = {}
-        for impl in (0, a.impl):
+        for impl in (a.base, a.impl):
             LIB.call('aa_attn_set_impl', impl)
             o, lse = ops.attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, sc, start=st, kv_len=kl)
             d = {'o': o, 'lse': lse}
@@ -102,7 +103,10 @@ def main():
                 d.update(dq=dq, dk=dk, dv=dv)
             torch.cuda.synchronize()
             outs[impl] = d
-        new, old = outs[a.impl], outs[0]
+        new, old = outs[a.impl], outs[a.base]
+        if a.bwd:
+            for t_ in ('dq', 'dk', 'dv'):
+                c['%s_bit_identical_to_base' % t_] = bool(torch.equal(new[t_], old[t_]))
         small = N * H * T * T <= 8 * 32 * 2048 * 2048
         if small:
             r = ref(q, k, v, do, N, T, H, Hkv, hd, causal, sc, st, kl, a.bwd)
@@ -128,7 +132,7 @@ def main():
             c['ok'] = c['rel_o_vs_old'] < 6e-3
         if timed and not a.no_time:
             fl = 4.0 * N * H * T * T * hd * (0.5 if causal else 1.0)
-            for impl in (0, a.impl, 0, a.impl):
+            for impl in (a.base, a.impl, a.base, a.impl):
                 LIB.call('aa_attn_set_impl', impl)
                 o = outs[impl]['o']
                 fns = [('fwd', 1.0, lambda: ops.attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, sc, start=st, kv_len=kl, out=o))]

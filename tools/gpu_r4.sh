@@ -9,6 +9,10 @@ for stage in "$@"; do
   case $stage in
     attn_check)      # attn128 kernels vs the fp32 reference and the 16x16x32 kernels, timings on the bench block
       timeout 400 python tools/attn128_check.py $ATTN_ARGS > gpurun_out/r04_attn128_check.txt 2>&1; tail -30 gpurun_out/r04_attn128_check.txt ;;
+    new_tests)       # this session's new / touched GPU tests
+      timeout 1200 python -m pytest tests/test_optim_gpu.py tests/test_decode_gpu.py tests/test_gemm_gpu.py tests/test_f32_gpu.py tests/test_ep_gpu.py tests/test_qwen3moe_gpu.py tests/test_attention_gpu.py -m gpu -q -p no:cacheprovider --durations=8 > gpurun_out/r04_pytest_new.log 2>&1; tail -25 gpurun_out/r04_pytest_new.log ;;
+    attn_bwd)        # dK/dV with 32 keys per wave (AA_ATTN128 bit 2) against the shipped backward: bit identity + timing
+      timeout 500 python tools/attn128_check.py --bwd --base 3 --impl 7 --out r04_attn_bwd_kj2.json $ATTN_ARGS > gpurun_out/r04_attn_bwd_kj2.txt 2>&1; cut -c1-900 gpurun_out/r04_attn_bwd_kj2.txt | tail -16 ;;
     attn_variants)   # the same check per lab library in AA_ATTN_LIBS (numerics only unless ATTN_VAR_ARGS says otherwise)
       for lib in ${AA_ATTN_LIBS:-libaa_hip_thr0.so}; do
         echo "--- $lib"; AA_HIP_LIB=$R/align_anything_amd/$lib timeout 300 python tools/attn128_check.py ${ATTN_VAR_ARGS:---no-time} --out r04_attn128_$lib.json > gpurun_out/r04_attn128_$lib.txt 2>&1; tail -14 gpurun_out/r04_attn128_$lib.txt | cut -c1-400
