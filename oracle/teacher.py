@@ -43,17 +43,25 @@ def cosine_lr(step: int, base_lr: float, warmup: int, total: int) -> float:
 
 class Teacher:
     def __init__(self, cfg: dict, ref_sd: dict, pad_token_id: int, total_steps: int, *, beta=0.1, lr=1e-6, betas=(0.9, 0.95), eps=1e-8,
-                 weight_decay=0.05, warmup_ratio=0.03, max_grad_norm=1.0, hf_config=None):
+                 weight_decay=0.05, warmup_ratio=0.03, max_grad_norm=1.0, hf_config=None, device=None):
         """hf_config (an OPTConfig): evaluate the model with HuggingFace's own OPTForCausalLM (`torch.func.functional_call` on the given
         weights) -- the arithmetic the reference itself executes (models/opt.py:28 subclasses it) -- instead of the
         oracle's port (oracle/models.py::opt_logits, whose fp32 operation order differs: ~2e-5 on the loss at identical weights)."""
-        self.cfg, self.ref_sd, self.pad = cfg, {k: v.detach() for k, v in ref_sd.items()}, pad_token_id
+        # device ('cuda:0' in the GPU test): the SAME code -- HF modules, torch autograd, torch ops -- executed by torch on the GPU in fp32 (eager
+        # attention), 60 x faster than the host cores of the GPU box; every tensor handed to step() must then live there.  The CPU form is the one
+        # pinned bit for bit to the reference; the GPU test ties the two together at a few steps.
+        self.device = torch.device(device) if device is not None else torch.device('cpu')
+        self.cfg, self.ref_sd, self.pad = cfg, {k: v.detach().to(self.device) for k, v in ref_sd.items()}, pad_token_id
         self.total, self.warmup = int(total_steps), int(warmup_ratio * total_steps)
         self.beta, self.lr, self.betas, self.eps, self.wd, self.max_norm = beta, lr, betas, eps, weight_decay, max_grad_norm
         self.hf = None
         if hf_config is not None:
+            import copy
             from transformers import OPTForCausalLM
-            self.hf = OPTForCausalLM(hf_config).eval()
+            hc = copy.deepcopy(hf_config)
+            if self.device.type != 'cpu':
+                hc._attn_implementation = 'eager'          # plain matmul / softmax in fp32 (no dependence on which fused SDPA kernels the build has)
+            self.hf = OPTForCausalLM(hc).eval().to(self.device)
 
     def logits(self, sd, ids, am):
         if self.hf is None:
@@ -79,7 +87,7 @@ class Teacher:
         leaf = {n: w[n].detach().clone().requires_grad_(True) for n in names}
         sd = dict(leaf)
         sd['lm_head.weight'] = leaf['model.decoder.embed_tokens.weight']
-        ids, am, lens = batch['input_ids'], batch['attention_mask'], batch['meta_info']['response_lens']
+        ids, am, lens = batch['input_ids'].to(self.device), batch['attention_mask'].to(self.device), batch['meta_info']['response_lens']
         logits = self.logits(sd, ids, am)
         lp = orl.compute_log_probs(logits, ids, lens, self.pad)
         with torch.no_grad():

@@ -198,7 +198,7 @@ def test_top_k_cut_matches_hf_warpers_in_hf_order():
     us = torch.linspace(0.0, 0.99999, 400).to(dev())
     row = lg[3:4].expand(400, V).contiguous()
     drawn = set(ops.sample_top_p(row, 1.0, 1.0, us, None, 1.0, top_k=50).cpu().tolist())
-    assert drawn == set(range(5, 60))
+    assert drawn == set((logits[3].float() == logits[3].float().max()).nonzero().reshape(-1).tolist()) and len(drawn) >= 55      # every tied maximum (the 55 set above + the original one), nothing else
 
 
 def _greedy_oracle(logits_fn, ids, mask, n_new, eos, pad, penalty=1.0):

@@ -278,10 +278,15 @@ def test_opt125m_64_step_loss_curve_vs_reference():
 
 def test_opt125m_teacher_forced_all_64_steps():
     """BASELINE.json 'loss curves matching reference to 1e-4', made well posed at EVERY step of configs[0]: step k of
-    the native fp32 path starts from the teacher's weights and Adam moments of step k (oracle/teacher.py, pinned to the reference's own 64
-    steps in the build container: tests/golden/opt125m_teacher.npz) and must reproduce the teacher's loss_k, gradient norm and parameter
-    update.  No trajectory divergence enters: both sides evaluate the same function at the same point.  Reference: trainers/text_to_text/
-    dpo.py:205-237 (train_step), supervised_trainer.py:234-257 (optimizer / schedule)."""
+    the native fp32 path starts from the teacher's weights and Adam moments of step k and must reproduce the teacher's loss_k, gradient norm and
+    parameter update.  No trajectory divergence enters: both sides evaluate the same function at the same point.  Reference:
+    trainers/text_to_text/dpo.py:205-237 (train_step), supervised_trainer.py:234-257 (optimizer / schedule).
+
+    Chain of evidence: (1) oracle/teacher.py on the CPU == the UNMODIFIED reference trainer, bit for bit, teacher-forced on the reference's own
+    states at all 64 steps (build container; tests/golden/opt125m_teacher.npz, re-checked by tests/test_oracle_golden.py); (2) the same teacher
+    code executed by torch on the GPU (HF modules, fp32, eager attention) drives the 64 steps here -- the host cores of the GPU box need 3.7 s per
+    teacher step, the GPU 0.05 s -- and is tied to the CPU teacher at steps 0 / 21 / 42 / 63 on the same states; (3) the native HIP path against
+    that teacher at every step."""
     from oracle.synthetic import opt125m_config1
     from oracle.teacher import Teacher, fingerprint
     from align_anything_amd import configs
@@ -291,19 +296,31 @@ def test_opt125m_teacher_forced_all_64_steps():
     steps = len(batches)
     cfg = configs.from_hf_config(oc)
     sd0 = {k: v.detach().clone() for k, v in policy.state_dict().items()}
-    # HF's own OPTForCausalLM arithmetic (what the reference executes): on the reference's states this teacher reproduces the reference's loss bit for bit
-    teacher = Teacher(cfg, refm.state_dict(), oc.pad_token_id, steps, hf_config=oc)
+    teacher = Teacher(cfg, refm.state_dict(), oc.pad_token_id, steps, hf_config=oc, device=dev())
+    cpu_teacher = Teacher(cfg, refm.state_dict(), oc.pad_token_id, steps, hf_config=oc)
     cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-6, 'lr_warmup_ratio': 0.03, 'lr_scheduler_type': 'cosine', 'weight_decay': 0.05,
                            'adam_betas': [0.9, 0.95], 'total_training_steps': steps, 'compute_dtype': 'fp32'},
             'model_cfgs': {'pad_token_id': oc.pad_token_id}}
     tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, policy_state=sd0, reference_state=refm.state_dict(), device='cuda:0')
     eng, store = tr.model, tr.policy.store
     names = Teacher.names(sd0)
-    index = {str(n): torch.from_numpy(i) for n, i in zip(z['fp_names'], z['fp_index'])}
-    w, m, v = sd0, Teacher.zeros_like(sd0), Teacher.zeros_like(sd0)
-    lines, worst = [], {'loss': 0.0, 'gnorm': 0.0, 'upd': 0.0, 'frac': 0.0, 'maxd': 0.0, 'ref_loss': 0.0, 'fp': 0.0}
+    index = {str(n): torch.from_numpy(i).to(dev()) for n, i in zip(z['fp_names'], z['fp_index'])}
+    w = {k: v.to(dev()) for k, v in sd0.items()}
+    m, v = Teacher.zeros_like(w), Teacher.zeros_like(w)
+    keys = ('loss', 'gnorm', 'upd_mat', 'upd_all', 'frac', 'maxd', 'ref_loss', 'fp', 'cpu_loss', 'cpu_upd')
+    lines, worst = [], dict.fromkeys(keys, 0.0)
+    worst_name = ''
     for k, b in enumerate(batches):
         ti, w2, m2, v2 = teacher.step(w, m, v, k, b)
+        if k in (0, 21, 42, steps - 1):     # the CPU teacher (== the reference, bit for bit) on the same state: loss and update of the GPU teacher
+            tc, wc, _, _ = cpu_teacher.step({n: t.cpu() for n, t in w.items()}, {n: t.cpu() for n, t in m.items()}, {n: t.cpu() for n, t in v.items()}, k, b)
+            worst['cpu_loss'] = max(worst['cpu_loss'], abs(tc['train/loss'] - ti['train/loss']))
+            for n in names:
+                if n.endswith(Teacher.NOISE_ONLY) or w[n].dim() != 2 or 'layer_norm' in n:
+                    continue
+                du = (wc[n] - w[n].cpu()).double()
+                worst['cpu_upd'] = max(worst['cpu_upd'], float(((w2[n].cpu() - w[n].cpu()).double() - du).norm() / du.norm().clamp_min(1e-30)))
+            lines.append(f'step {k:2d} CPU teacher loss {tc["train/loss"]:.7f} (reference run: {float(z["ref"][k, 0]):.7f} on ITS trajectory) vs GPU teacher {ti["train/loss"]:.7f}')
         # ---- teacher forcing: the native step starts from the teacher's state of step k
         eng.wait_optimizer()
         store.load_state_dict(w)
@@ -315,11 +332,13 @@ def test_opt125m_teacher_forced_all_64_steps():
         e_gn = abs(gn - ti['grad_norm']) / ti['grad_norm']
         assert abs(info['train/lr'] - ti['train/lr']) <= 1e-12 * max(1.0, ti['train/lr'])
         # ---- the update of step k, element by element on the device.  An fp32 weight of magnitude |w| moves in quanta of ulp(|w|) (1.9e-9 at
-        # 0.02, 1.2e-7 at a LayerNorm weight of 1.0) against a step of ~lr = 1e-6, so "same update" means: within a few quanta, except for the
-        # rare element whose Adam direction is ill-conditioned (|g| at the noise level: m/sqrt(v) flips) -- bounded by 2 lr whatever happens
-        upd_w, frac_w, maxd = 0.0, 0.0, 0.0
+        # 0.02, 1.2e-7 at a LayerNorm weight of 1.0) against a step of <= lr = 1e-6, so "same update" means: within a few quanta, except for the
+        # rare element whose Adam direction is ill-conditioned (|g| at the noise level: m/sqrt(v) flips) -- bounded by 2 lr whatever happens.
+        # The relative L2 error of the update is asserted on the matrices (quantum << step); for LayerNorm weights and biases the quantum is
+        # a tenth of the step and more, so that figure is reported only and the element-wise bound is the test.
+        upd_mat, upd_all, frac_w, maxd = 0.0, 0.0, 0.0, 0.0
         for n in names:
-            before, want, got = w[n].to(dev()), w2[n].to(dev()), store.view(n)
+            before, want, got = w[n], w2[n], store.view(n)
             d = (got - want).abs()
             quant = 4.0 * torch.finfo(torch.float32).eps * want.abs() + 2e-2 * ti['lr_used']
             maxd = max(maxd, float(d.max()) / max(ti['lr_used'], 1e-30))
@@ -327,24 +346,33 @@ def test_opt125m_teacher_forced_all_64_steps():
                 continue
             frac_w = max(frac_w, float((d > quant).float().mean()))
             du = (want - before).double()
-            upd_w = max(upd_w, float(((got - before).double() - du).norm() / du.norm().clamp_min(1e-30)))
+            e = float(((got - before).double() - du).norm() / du.norm().clamp_min(1e-30))
+            if e > upd_all:
+                upd_all = e
+                if e > worst['upd_all']:
+                    worst_name = f'{n} at step {k}'
+            if want.dim() == 2 and 'layer_norm' not in n:
+                upd_mat = max(upd_mat, e)
         ref_dev = abs(ti['train/loss'] - float(z['ref'][k, 0]))
-        lines.append(f'step {k:2d} loss native {info["train/loss"]:.7f} teacher {ti["train/loss"]:.7f} |diff| {e_loss:.1e}  gnorm rel {e_gn:.1e}  worst tensor: update rel-L2 '
-                     f'{upd_w:.1e}, elements off by > 4 ulp + 2% lr: {frac_w:.1e}, max |dw| / lr {maxd:.2f}   (free-running teacher vs reference curve {ref_dev:.1e})')
-        for key, val in (('loss', e_loss), ('gnorm', e_gn), ('upd', upd_w), ('frac', frac_w), ('maxd', maxd), ('ref_loss', ref_dev)):
+        lines.append(f'step {k:2d} loss native {info["train/loss"]:.7f} teacher {ti["train/loss"]:.7f} |diff| {e_loss:.1e}  gnorm rel {e_gn:.1e}  update rel-L2: matrices '
+                     f'{upd_mat:.1e}, any tensor {upd_all:.1e}; elements off by > 4 ulp + 2% lr: {frac_w:.1e}, max |dw| / lr {maxd:.2f}   (free-running teacher vs reference curve {ref_dev:.1e})')
+        for key, val in (('loss', e_loss), ('gnorm', e_gn), ('upd_mat', upd_mat), ('upd_all', upd_all), ('frac', frac_w), ('maxd', maxd), ('ref_loss', ref_dev)):
             worst[key] = max(worst[key], val)
         w, m, v = w2, m2, v2
-        worst['fp'] = max(worst['fp'], float((fingerprint(w, index) - torch.from_numpy(z['fingerprint'][k + 1])).abs().max()))
-    lines.append(f'max over {steps} teacher-forced steps: |loss diff| {worst["loss"]:.2e} (target 1e-4), grad-norm rel {worst["gnorm"]:.2e}, update rel-L2 (worst tensor) '
-                 f'{worst["upd"]:.2e}, fraction of elements beyond 4 ulp + 2 % lr {worst["frac"]:.2e}, max |dw| / lr {worst["maxd"]:.2f}')
-    lines.append(f'teacher pinned to the reference in the build container (teacher-forced on the reference\'s own states, all {steps} steps): max |loss| '
-                 f'{z["teacher_dev"][:, 0].max():.2e}, rel grad-norm {z["teacher_dev"][:, 1].max():.2e}, rel update {z["teacher_dev"][:, 2].max():.2e}')
-    lines.append(f'free-running teacher on this box vs the committed reference run: max |loss| {worst["ref_loss"]:.2e}, max |weight fingerprint diff| {worst["fp"]:.2e}')
+        worst['fp'] = max(worst['fp'], float((fingerprint(w, index).cpu() - torch.from_numpy(z['fingerprint'][k + 1])).abs().max()))
+    lines.append(f'max over {steps} teacher-forced steps: |loss diff| {worst["loss"]:.2e} (target 1e-4), grad-norm rel {worst["gnorm"]:.2e}, update rel-L2 matrices '
+                 f'{worst["upd_mat"]:.2e} / any tensor {worst["upd_all"]:.2e} ({worst_name}), fraction of elements beyond 4 ulp + 2 % lr {worst["frac"]:.2e}, max |dw| / lr {worst["maxd"]:.2f}')
+    lines.append(f'GPU teacher vs CPU teacher on the same states (steps 0 / 21 / 42 / {steps - 1}): max |loss| {worst["cpu_loss"]:.2e}, max update rel-L2 (matrices) {worst["cpu_upd"]:.2e}')
+    lines.append(f'CPU teacher pinned to the reference in the build container (teacher-forced on the reference\'s own states, all {steps} steps): max |loss| '
+                 f'{z["teacher_dev"][:, 0].max():.2e}, rel grad-norm {z["teacher_dev"][:, 1].max():.2e}, rel update {z["teacher_dev"][:, 2].max():.2e}; the oracle\'s own model '
+                 f'port on the same states: max |loss| {z["teacher_dev"][:, 4].max():.2e}')
+    lines.append(f'free-running GPU teacher vs the committed reference run: max |loss| {worst["ref_loss"]:.2e}, max |weight fingerprint diff| {worst["fp"]:.2e}')
     dump('parity_fp32_opt125m_teacher_forced.txt', '\n'.join(lines) + '\n')
+    assert worst['cpu_loss'] < 2e-5 and worst['cpu_upd'] < 2e-2, worst
     assert worst['loss'] < 1e-4, worst
     assert worst['gnorm'] < 1e-3, worst
     assert worst['maxd'] <= 2.05, worst                       # no element moves further from the teacher than a flipped Adam direction can take it
-    assert worst['frac'] < 2e-2 and worst['upd'] < 0.15, worst
+    assert worst['frac'] < 2e-2 and worst['upd_mat'] < 5e-2, worst
     assert worst['ref_loss'] < 2e-3 and worst['fp'] < 64 * 2e-6, worst
 
 
