@@ -50,6 +50,15 @@ typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_p;
 #define TR_NBUF_KV 4   // the same for the dK/dV kernel (4 reads -> 2 MFMAs per group)
 #endif
 #define LN2_F 0.6931471805599453f
+// Lab builds of the backward kernels (tools/build_attn_variant.sh ... -DAA_BWD_LAB=<mask>; TIMING ONLY, results are wrong): bit 0 no softmax VALU,
+// bit 1 no in-loop DMA (stale tiles), bit 2 no S / dP MFMAs, bit 3 no dV / dK (dQ) MFMAs, bit 4 no per-tile wait + barrier.  0 = the shipped kernels
+// (every switch is `if constexpr`: the default build's ISA does not change).  AA_BWD_LAB_ONLY: 1 = launch only the dQ kernel, 2 = only dK/dV.
+#ifndef AA_BWD_LAB
+#define AA_BWD_LAB 0
+#endif
+#ifndef AA_BWD_LAB_ONLY
+#define AA_BWD_LAB_ONLY 0
+#endif
 // Wave priority inside a tile (round 3, same-box A/B in profiles/r03_attention_lab.txt; outputs bit-identical): a forward wave raises its priority for the
 // softmax (VALU) segment between the two MFMA clusters, so the SIMD's other wave -- mid-way through ITS MFMA cluster -- cannot starve the exps and
 // the wave gets back to feeding the matrix pipe sooner: forward 402 -> 382 us (-4.8 %) at level 3 (-3 % at level 1; around the MFMA clusters instead
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
         const int kv0 = kv_begin + t * 64;
-        if (t + 1 < ntile) {
+        if (t + 1 < ntile && !(AA_BWD_LAB & 2)) {
             dma.issue(Kb, p.ldk, koff, kv0 + 64, T, lds0 + (cur ^ 1) * 2 * TILE_B);
             dma.issue(Vb, p.ldv, voff, kv0 + 64, T, lds0 + (cur ^ 1) * 2 * TILE_B + TILE_B);
         }
@@ -709,6 +718,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
                         const bf16x8 vf = lds_frag<HD>(vt, (2 * S + kk) * 16 + l15, ks * 4 + g);
 #pragma unroll
                         for (int qi = 0; qi < 2; ++qi) {
+                            if constexpr (AA_BWD_LAB & 4) { landed(kf); landed(vf); continue; }
                             sacc[qi][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], sacc[qi][kk], 0, 0, 0);
                             dpacc[qi][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qi][ks], dpacc[qi][kk], 0, 0, 0);
                         }
@@ -721,6 +731,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
                     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
+                            if constexpr (AA_BWD_LAB & 1) { sacc[qi][kk][r] += dpacc[qi][kk][r]; continue; }
                             float pe = fast_exp2(sacc[qi][kk][r] * c2 - lse2[qi]);
                             if constexpr (decltype(masked)::value) {
                                 const int kv = kv0 + (2 * S + kk) * 16 + g * 4 + r;
@@ -747,13 +758,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
             tr_stream<HD, 1, 0, 0, TR_NBUF>(lds0 + cur * 2 * TILE_B + trl, [&](auto si, auto di, const bf16x8 ktf) {
                 constexpr int S = decltype(si)::value, D = decltype(di)::value;
 #pragma unroll
-                for (int qi = 0; qi < 2; ++qi)
+                for (int qi = 0; qi < 2; ++qi) {
+                    if constexpr (AA_BWD_LAB & 8) { landed(ktf); landed(dsf[qi][S]); continue; }
                     dqacc[qi][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qi][S], dqacc[qi][D], 0, 0, 0);
+                }
             });
             AT_PRIO_MFMA_B(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (!(AA_BWD_LAB & 16)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
@@ -845,7 +860,7 @@ __global__ __launch_bounds__(64 * NW, KJ == 1 ? 2 : 1) void attn_bwd_dkv_kernel(
     __syncthreads();
     for (int it = 0; it < total && kv_valid_block; ++it) {
         const int cur = it & 1;
-        if (it + 1 < total) issue(it + 1, cur ^ 1);
+        if (it + 1 < total && !(AA_BWD_LAB & 2)) issue(it + 1, cur ^ 1);
         const int qt0 = q_begin + (it % ntq) * 64;
         const char* qt = smem + cur * 2 * TILE_B;
         const char* dot = qt + TILE_B;
@@ -866,6 +881,7 @@ __global__ __launch_bounds__(64 * NW, KJ == 1 ? 2 : 1) void attn_bwd_dkv_kernel(
                     const bf16x8 da = lds_frag<HD>(dot, qb * 16 + l15, ks * 4 + g);
 #pragma unroll
                     for (int j = 0; j < KJ; ++j) {
+                        if constexpr (AA_BWD_LAB & 4) { landed(qa); landed(da); continue; }
                         sacc[j][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[j][ks], sacc[j][qb], 0, 0, 0);
                         dpacc[j][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[j][ks], dpacc[j][qb], 0, 0, 0);
                     }
@@ -886,6 +902,7 @@ __global__ __launch_bounds__(64 * NW, KJ == 1 ? 2 : 1) void attn_bwd_dkv_kernel(
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(st + 64 + qb * 16 + g * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        if constexpr (AA_BWD_LAB & 1) { pv[qb][r] = sacc[j][qb][r] + l4[r]; dsv[qb][r] = dpacc[j][qb][r] + d4[r]; continue; }
                         float l2;       // lse * log2(e) rounded on its own (as when it was pre-scaled into LDS), never contracted into the fma below
                         asm("v_mul_f32 %0, %1, %2" : "=v"(l2) : "v"(l4[r]), "v"(LOG2E_F));
                         float pe = fast_exp2(sacc[j][qb][r] * c2 - l2);
@@ -910,14 +927,17 @@ __global__ __launch_bounds__(64 * NW, KJ == 1 ? 2 : 1) void attn_bwd_dkv_kernel(
                 constexpr int S = decltype(si)::value, D = decltype(di)::value;
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
+                    if constexpr (AA_BWD_LAB & 8) { landed(dot_f); landed(qt_f); landed(pfr[j][S]); landed(dsfr[j][S]); continue; }
                     dvacc[j][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr[j][S], dvacc[j][D], 0, 0, 0);
                     dkacc[j][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsfr[j][S], dkacc[j][D], 0, 0, 0);
                 }
             });
             AT_PRIO_MFMA_B(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (!(AA_BWD_LAB & 16)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int j = 0; j < KJ; ++j) {
@@ -1020,7 +1040,8 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
         const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N), gkv2(aa_cdiv(T, 128) * Hkv * N);
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(aa_cdiv(groups * 16, 256)), dim3(256), 0, st, p);
         if ((rc = set_lds(attn_bwd_dq_kernel<128, 4>, lds, "aa_attn_bwd"))) return rc;
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 4>), gq, dim3(256), lds, st, p);
+        if (AA_BWD_LAB_ONLY != 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 4>), gq, dim3(256), lds, st, p);
+        if (AA_BWD_LAB_ONLY == 1) { AA_CHECK_LAUNCH("aa_attn_bwd"); return AA_OK; }
         if (attn_impl() & 4) {     // AA_ATTN128 bit 2: dK/dV with 32 keys per wave (KJ = 2), one workgroup of 128 keys per CU
             if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4, 2>, lds + 1024, "aa_attn_bwd"))) return rc;
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4, 2>), gkv2, dim3(256), lds + 1024, st, p);

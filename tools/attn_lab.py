@@ -68,6 +68,9 @@ def child():
     if os.environ.get('AA_LAB_ONLY') == 'bench':        # under rocprofv3: only the timed block, so the per-kernel averages are its own
         case(8, 2048, 32, 32, 128, True, time_it=True)
         return
+    if os.environ.get('AA_LAB_CASES') == 'bench':       # timing-only lab builds (AA_BWD_LAB): the bench block alone
+        print('ATTNLAB ' + json.dumps({'bench': case(8, 2048, 32, 32, 128, True, time_it=True)}), flush=True)
+        return
     res = {
         'bench': case(8, 2048, 32, 32, 128, True, time_it=True),
         'leftpad': case(8, 2048, 32, 32, 128, True, start=[0, 700, 0, 0, 1531, 0, 0, 64], seed=1),
@@ -97,7 +100,7 @@ def parent():
         if base is None:
             base = res
         same = {c: (res[c]['fwd'] == base[c]['fwd'], res[c]['bwd'] == base[c]['bwd']) for c in res}
-        b = res['bench']; c = res['clip']
+        b = res['bench']; c = res.get('clip', {'fwd_us': 0.0, 'bwd_us': 0.0})
         print(f"{lib:24s} bench fwd {b['fwd_us']:7.1f} us {b['fwd_tflops']:6.1f} TF | bwd {b['bwd_us']:7.1f} us {b['bwd_tflops']:6.1f} TF | clip fwd {c['fwd_us']:6.1f} bwd {c['bwd_us']:6.1f} us"
               f" | identical to {libs[0]}: " + ' '.join(f"{k}={'ok' if all(v) else 'DIFF' + str(v)}" for k, v in same.items())
               + ('' if all(res[k]['finite'] for k in res) else ' NON-FINITE'), flush=True)
