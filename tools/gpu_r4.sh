@@ -12,7 +12,12 @@ for stage in "$@"; do
     new_tests)       # this session's new / touched GPU tests
       timeout 1200 python -m pytest tests/test_optim_gpu.py tests/test_decode_gpu.py tests/test_gemm_gpu.py tests/test_f32_gpu.py tests/test_ep_gpu.py tests/test_qwen3moe_gpu.py tests/test_attention_gpu.py -m gpu -q -p no:cacheprovider --durations=8 > gpurun_out/r04_pytest_new.log 2>&1; tail -25 gpurun_out/r04_pytest_new.log ;;
     attn_bwd)        # dK/dV with 32 keys per wave (AA_ATTN128 bit 2) against the shipped backward: bit identity + timing
-      timeout 500 python tools/attn128_check.py --bwd --base 3 --impl 7 --out r04_attn_bwd_kj2.json $ATTN_ARGS > gpurun_out/r04_attn_bwd_kj2.txt 2>&1; cut -c1-900 gpurun_out/r04_attn_bwd_kj2.txt | tail -16 ;;
+      timeout 500 python tools/attn128_check.py --bwd --base ${ATTN_BASE:-1} --impl ${ATTN_IMPL:-3} --out r04_attn_bwd_x.json $ATTN_ARGS > gpurun_out/r04_attn_bwd_x.txt 2>&1; python3 - <<'PY'
+import json
+for c in json.load(open('gpurun_out/r04_attn_bwd_x.json')):
+    print(c['case'], 'ok' if c['ok'] else 'MISMATCH', {k: v for k, v in c.items() if 'identical' in k or k.endswith('_us') or k.startswith('rel_d')})
+PY
+      tail -1 gpurun_out/r04_attn_bwd_x.txt ;;
     bwd_lab)         # timing-only lab builds of the backward kernels (tools/build_bwd_lab.sh): where the tile time goes
       AA_LAB_CASES=bench AA_LAB_OUT=r04_attn_bwd_lab.json AA_ATTN_LIBS=$(cd align_anything_amd && ls libaa_hip_lab_*.so | sort | tr '\n' ',' | sed 's/,$//') timeout 900 python tools/attn_lab.py 2>&1 | cut -c1-140 | tee gpurun_out/r04_attn_bwd_lab.txt ;;
     attn_variants)   # the same check per lab library in AA_ATTN_LIBS (numerics only unless ATTN_VAR_ARGS says otherwise)
