@@ -50,9 +50,10 @@ typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_p;
 #define TR_NBUF_KV 4   // the same for the dK/dV kernel (4 reads -> 2 MFMAs per group)
 #endif
 #define LN2_F 0.6931471805599453f
-// Lab builds of the backward kernels (tools/build_attn_variant.sh ... -DAA_BWD_LAB=<mask>; TIMING ONLY, results are wrong): bit 0 no softmax VALU,
+// Lab builds of the backward kernels (tools/build_bwd_lab.sh: -DAA_BWD_LAB=<mask>; TIMING ONLY, results are wrong): bit 0 no softmax VALU,
 // bit 1 no in-loop DMA (stale tiles), bit 2 no S / dP MFMAs, bit 3 no dV / dK (dQ) MFMAs, bit 4 no per-tile wait + barrier.  0 = the shipped kernels
 // (every switch is `if constexpr`: the default build's ISA does not change).  AA_BWD_LAB_ONLY: 1 = launch only the dQ kernel, 2 = only dK/dV.
+// What they measured: profiles/r04_attn_bwd_anatomy.txt.
 #ifndef AA_BWD_LAB
 #define AA_BWD_LAB 0
 #endif
@@ -784,193 +785,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
 // first).  Wave w owns keys kv0 + 16w .. +15 and loops over 64-query tiles (and over the H/Hkv query heads sharing this kv head).
 //   S[q][kv] = Q K^T, dP[q][kv] = dO V^T          (lane: kv = lane&15, q = 16qb + 4g + r)
 //   dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]
-// NW waves of 16 KJ keys share one Q / dO tile stream.  KJ = key blocks (of 16) per wave: every Q / dO fragment read from LDS (row form for S / dP,
-// transposed for dV / dK) feeds KJ MFMAs.  KJ = 1 (two 4-wave workgroups per CU): a 1-KiB fragment per 16-cycle MFMA = 256 B/clk wanted of the CU's 128
-// -> the LDS pipe caps the kernel at 50 % of the matrix peak (profiles/r04_attn128_anatomy.txt, section 6).  KJ = 2 (one workgroup per CU, one wave per SIMD
-// with the whole register file: K / V operands 64 + accumulators 128 + scores 64 + packed P / dS 32 registers): half the LDS bytes per MFMA.
-template <int HD, int NW, int KJ = 1>
-__global__ __launch_bounds__(64 * NW, KJ == 1 ? 2 : 1) void attn_bwd_dkv_kernel(const AttnParams p) {
+// NW waves of 16 keys share one Q / dO tile stream.
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
     constexpr int KS = HD / 32, DB = HD / 16;
-    constexpr int TILE_B = 64 * HD * 2, KVB = 16 * NW * KJ, KW = 16 * KJ;
+    constexpr int TILE_B = 64 * HD * 2, KVB = 16 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q tile | dO tile] + [2][64 lse | 64 delta]
     float* stat = reinterpret_cast<float*>(smem + 4 * TILE_B);
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int group = p.H / p.Hkv;
-    int n, hk, kvb;
-    kv_block_of(p, (p.T + KVB - 1) / KVB, n, hk, kvb);
-    const int kv0 = kvb * KVB, kvw = kv0 + wave * KW;
-    const int T = p.T;
-    const int start = p.start ? p.start[n] : 0;
-    const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
-    const bf16_t* Kb = p.K + (long)n * T * p.ldk + hk * HD;
-    const bf16_t* Vb = p.V + (long)n * T * p.ldv + hk * HD;
-    const float c2 = p.scale * LOG2E_F;
-    const int kvg = kvw + l15;            // key of block j: kvg + 16 j
-    DmaLane<HD, 64, NW> dma;
-    dma.init(wave, lane);
-    const auto qoff = dma.offsets(p.ldq), dooff = dma.offsets(p.lddo);
-    const int lds0 = (int)(uintptr_t)smem;
-    const int trl = tr_lane_base<HD>(g, l15);
-
-    bf16x8 kf[KJ][KS], vf[KJ][KS];
-#pragma unroll
-    for (int j = 0; j < KJ; ++j) {
-        const int kr = min(kvg + 16 * j, T - 1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            kf[j][ks] = *reinterpret_cast<const bf16x8*>(Kb + (long)kr * p.ldk + ks * 32 + g * 8);
-            vf[j][ks] = *reinterpret_cast<const bf16x8*>(Vb + (long)kr * p.ldv + ks * 32 + g * 8);
-        }
-    }
-    f32x4 dkacc[KJ][DB], dvacc[KJ][DB];
-#pragma unroll
-    for (int j = 0; j < KJ; ++j)
-#pragma unroll
-        for (int db = 0; db < DB; ++db) { dkacc[j][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[j][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-    const int q_begin = p.causal ? (kv0 / 64) * 64 : 0;
-    const int ntq = (T - q_begin + 63) / 64;
-    const int total = ntq * group;  // iteration = (head in group, q tile)
-    const bool kv_valid_block = kv0 + KVB - 1 >= start;  // some key of this block can be attended
-
-    // The tile's 64 LSE and 64 delta values travel by DMA as well (wave 0 / wave 1, one dword per lane): a register round trip
-    // would put `s_waitcnt vmcnt(0)` -- the whole prefetch -- in front of the ds_write at the top of every iteration.
-    auto issue = [&](int it, int buf) {
-        const int hh = hk * group + it / ntq;
-        const int qt0 = q_begin + (it % ntq) * 64;
-        const bf16_t* Qb = p.Q + (long)n * T * p.ldq + hh * HD;
-        const bf16_t* dOb = p.dO + (long)n * T * p.lddo + hh * HD;
-        dma.issue(Qb, p.ldq, qoff, qt0, T, lds0 + buf * 2 * TILE_B);
-        dma.issue(dOb, p.lddo, dooff, qt0, T, lds0 + buf * 2 * TILE_B + TILE_B);
-        if (wave < 2) {
-            const long idx = ((long)n * p.H + hh) * T + min(qt0 + lane, T - 1);
-            const float* src = (wave == 0 ? p.lse : p.delta) + idx;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
-                         :: "s"(lds0 + 4 * TILE_B + buf * 512 + wave * 256), "v"(src) : "memory");
-        }
-    };
-
-    if (total > 0 && kv_valid_block) issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < KJ; ++j)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { landed(kf[j][ks]); landed(vf[j][ks]); }
-    __syncthreads();
-    for (int it = 0; it < total && kv_valid_block; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < total && !(AA_BWD_LAB & 2)) issue(it + 1, cur ^ 1);
-        const int qt0 = q_begin + (it % ntq) * 64;
-        const char* qt = smem + cur * 2 * TILE_B;
-        const char* dot = qt + TILE_B;
-        const float* st = stat + cur * 128;
-        const bool wave_active = kvw < T && !(p.causal && kvw > qt0 + 63);
-        if (wave_active) {
-            f32x4 sacc[KJ][4], dpacc[KJ][4];
-#pragma unroll
-            for (int j = 0; j < KJ; ++j)
-#pragma unroll
-                for (int qb = 0; qb < 4; ++qb) { sacc[j][qb] = f32x4{0.f, 0.f, 0.f, 0.f}; dpacc[j][qb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            AT_PRIO_MFMA_B(1);
-#pragma unroll
-            for (int qb = 0; qb < 4; ++qb)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 qa = lds_frag<HD>(qt, qb * 16 + l15, ks * 4 + g);
-                    const bf16x8 da = lds_frag<HD>(dot, qb * 16 + l15, ks * 4 + g);
-#pragma unroll
-                    for (int j = 0; j < KJ; ++j) {
-                        if constexpr (AA_BWD_LAB & 4) { landed(qa); landed(da); continue; }
-                        sacc[j][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[j][ks], sacc[j][qb], 0, 0, 0);
-                        dpacc[j][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[j][ks], dpacc[j][qb], 0, 0, 0);
-                    }
-                }
-            AT_PRIO_MFMA_B(0);
-            AT_PRIO_VALU_B(1);
-            const bool need_mask = (p.causal && qt0 < kvw + KW - 1) || kvw < start || kvw + KW > KT || qt0 + 64 > T;
-            bf16x8 pfr[KJ][2], dsfr[KJ][2];
-            // P and dS of the 64 x 16 block; the rows' statistics come as 16-byte LDS reads (q = 16 qb + 4 g + r)
-            auto softmax_bwd = [&](auto masked) {
-#pragma unroll
-              for (int j = 0; j < KJ; ++j) {
-                f32x4 pv[4], dsv[4];
-                const int kvj = kvg + 16 * j;
-#pragma unroll
-                for (int qb = 0; qb < 4; ++qb) {
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(st + qb * 16 + g * 4);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(st + 64 + qb * 16 + g * 4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if constexpr (AA_BWD_LAB & 1) { pv[qb][r] = sacc[j][qb][r] + l4[r]; dsv[qb][r] = dpacc[j][qb][r] + d4[r]; continue; }
-                        float l2;       // lse * log2(e) rounded on its own (as when it was pre-scaled into LDS), never contracted into the fma below
-                        asm("v_mul_f32 %0, %1, %2" : "=v"(l2) : "v"(l4[r]), "v"(LOG2E_F));
-                        float pe = fast_exp2(sacc[j][qb][r] * c2 - l2);
-                        if constexpr (decltype(masked)::value) {
-                            const int qg = qt0 + qb * 16 + g * 4 + r;
-                            const bool ok = kvj >= start && kvj < KT && qg < T && (!p.causal || kvj <= qg);
-                            pe = ok ? pe : 0.f;
-                        }
-                        pv[qb][r] = pe;
-                        dsv[qb][r] = pe * (dpacc[j][qb][r] - d4[r]) * p.scale;
-                    }
-                }
-                pfr[j][0] = pack_bf16x8(pv[0], pv[1]); pfr[j][1] = pack_bf16x8(pv[2], pv[3]);
-                dsfr[j][0] = pack_bf16x8(dsv[0], dsv[1]); dsfr[j][1] = pack_bf16x8(dsv[2], dsv[3]);
-              }
-            };
-            if (need_mask) softmax_bwd(std::true_type{}); else softmax_bwd(std::false_type{});
-            // dV^T += dO^T P, dK^T += Q^T dS: the transposed Q / dO fragments by inline asm (tr_stream)
-            AT_PRIO_VALU_B(0);
-            AT_PRIO_MFMA_B(1);
-            tr_stream<HD, 2, 0, TILE_B, TR_NBUF_KV>(lds0 + cur * 2 * TILE_B + trl, [&](auto si, auto di, const bf16x8 qt_f, const bf16x8 dot_f) {
-                constexpr int S = decltype(si)::value, D = decltype(di)::value;
-#pragma unroll
-                for (int j = 0; j < KJ; ++j) {
-                    if constexpr (AA_BWD_LAB & 8) { landed(dot_f); landed(qt_f); landed(pfr[j][S]); landed(dsfr[j][S]); continue; }
-                    dvacc[j][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr[j][S], dvacc[j][D], 0, 0, 0);
-                    dkacc[j][D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsfr[j][S], dkacc[j][D], 0, 0, 0);
-                }
-            });
-            AT_PRIO_MFMA_B(0);
-        }
-        if constexpr (!(AA_BWD_LAB & 16)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < KJ; ++j) {
-        const int kvj = kvg + 16 * j;
-        const long krow_i = (long)n * T + min(kvj, T - 1);
-        if (p.rope_pos) at_store_rows_rope<DB>(p.dK + krow_i * p.lddk + hk * HD, dkacc[j], kvj < T, g, p.rope_cos, p.rope_sin, (long)p.rope_pos[krow_i] * (HD / 2));
-        else at_store_rows<DB, true>(p.dK + krow_i * p.lddk + hk * HD, dkacc[j], 1.f, kvj < T, g);
-        at_store_rows<DB, true>(p.dV + krow_i * p.lddv + hk * HD, dvacc[j], 1.f, kvj < T, g);
-    }
-}
-
-// ================================================================== backward: dK, dV with the transposed reads shared inside the workgroup
-// Lab anatomy of the kernel above (profiles/r04_attn_bwd_anatomy.txt): with every MFMA removed it still runs at 83 % of its time, with everything BUT
-// the MFMAs and the LDS fragment reads removed at 81 % -- the tile time is the LDS fragment reads, 2/3 of them `ds_read_b64_tr_b16` (the 8-byte read
-// reaches its rate only from ~4 waves per SIMD, MI355X_MICROARCH.md LDS table).  And those reads are 4 x redundant: every wave of a workgroup reads
-// the WHOLE transposed Q / dO tile for its own 16 keys.  Here a wave reads only the transposed fragments of ITS head-dim slice (d blocks wt and
-// wt + 4 of 8) and accumulates dK^T / dV^T of that slice for all 64 keys of its 4-wave team; the packed P / dS fragments (MFMA B operands, 1 KiB each)
-// travel between the team's waves through LDS as lane-linear images (written by ds_write_b128, read back by the same lane number: no layout math, no
-// bank conflicts).  Per wave and 64-query tile: 16 transposed reads instead of 64, plus 4 fragment writes, 16 16-byte reads and one more barrier; the
-// same 64 MFMAs in the same accumulation order per output element (bit-identical results).  Two teams (8 waves, 128 keys) share one Q / dO tile
-// stream: one workgroup per CU, 64 KiB of stages + 32 KiB of exchange.  The rotation partner d + 64 of a wave's d block lives in the same lane, so the
-// rotary backward of dK stays in the epilogue (8-byte stores).
-template <int HD>
-__global__ __launch_bounds__(512, 1) void attn_bwd_dkv_x_kernel(const AttnParams p) {
-    static_assert(HD == 128, "the head-dim slices pair d with d + 64");
-    constexpr int NW = 8, KS = HD / 32, ROWB = HD * 2;
-    constexpr int TILE_B = 64 * HD * 2, KVB = 16 * NW;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q tile | dO tile] + [2][64 lse | 64 delta] + [8 waves][P0 P1 dS0 dS1][64 lanes x 16 B]
-    float* stat = reinterpret_cast<float*>(smem + 4 * TILE_B);
-    char* xch = smem + 4 * TILE_B + 1024;
-    const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int team = wave >> 2, wt = wave & 3;
     const int group = p.H / p.Hkv;
     int n, hk, kvb;
     kv_block_of(p, (p.T + KVB - 1) / KVB, n, hk, kvb);
@@ -997,17 +820,17 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_x_kernel(const AttnParams
             vf[ks] = *reinterpret_cast<const bf16x8*>(Vb + (long)kr * p.ldv + ks * 32 + g * 8);
         }
     }
-    f32x4 dkacc[4][2], dvacc[4][2];      // [key block j of my team: keys kv0 + 64 team + 16 j ..][d block wt + 4 i]
+    f32x4 dkacc[DB], dvacc[DB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { dkacc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int db = 0; db < DB; ++db) { dkacc[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const int q_begin = p.causal ? (kv0 / 64) * 64 : 0;
     const int ntq = (T - q_begin + 63) / 64;
     const int total = ntq * group;  // iteration = (head in group, q tile)
     const bool kv_valid_block = kv0 + KVB - 1 >= start;  // some key of this block can be attended
 
+    // The tile's 64 LSE and 64 delta values travel by DMA as well (wave 0 / wave 1, one dword per lane): a register round trip
+    // would put `s_waitcnt vmcnt(0)` -- the whole prefetch -- in front of the ds_write at the top of every iteration.
     auto issue = [&](int it, int buf) {
         const int hh = hk * group + it / ntq;
         const int qt0 = q_begin + (it % ntq) * 64;
@@ -1030,28 +853,32 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_x_kernel(const AttnParams
     __syncthreads();
     for (int it = 0; it < total && kv_valid_block; ++it) {
         const int cur = it & 1;
-        if (it + 1 < total) issue(it + 1, cur ^ 1);
+        if (it + 1 < total && !(AA_BWD_LAB & 2)) issue(it + 1, cur ^ 1);
         const int qt0 = q_begin + (it % ntq) * 64;
         const char* qt = smem + cur * 2 * TILE_B;
         const char* dot = qt + TILE_B;
         const float* st = stat + cur * 128;
-        // a key block contributes to this query tile iff it has a key below T and (causal) not all of its keys lie above the tile's last query
-        auto block_active = [&](int w) { const int k0 = kv0 + 16 * w; return k0 < T && !(p.causal && k0 > qt0 + 63); };
-        if (block_active(wave)) {
+        const bool wave_active = kvw < T && !(p.causal && kvw > qt0 + 63);
+        if (wave_active) {
             f32x4 sacc[4], dpacc[4];
 #pragma unroll
             for (int qb = 0; qb < 4; ++qb) { sacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f}; dpacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            AT_PRIO_MFMA_B(1);
 #pragma unroll
             for (int qb = 0; qb < 4; ++qb)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const bf16x8 qa = lds_frag<HD>(qt, qb * 16 + l15, ks * 4 + g);
                     const bf16x8 da = lds_frag<HD>(dot, qb * 16 + l15, ks * 4 + g);
+                    if constexpr (AA_BWD_LAB & 4) { landed(qa); landed(da); continue; }
                     sacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sacc[qb], 0, 0, 0);
                     dpacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dpacc[qb], 0, 0, 0);
                 }
+            AT_PRIO_MFMA_B(0);
+            AT_PRIO_VALU_B(1);
             const bool need_mask = (p.causal && qt0 < kvw + 15) || kvw < start || kvw + 16 > KT || qt0 + 64 > T;
             bf16x8 pfr[2], dsfr[2];
+            // P and dS of the 64 x 16 block; the rows' statistics come as 16-byte LDS reads (q = 16 qb + 4 g + r)
             auto softmax_bwd = [&](auto masked) {
                 f32x4 pv[4], dsv[4];
 #pragma unroll
@@ -1060,7 +887,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_x_kernel(const AttnParams
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(st + 64 + qb * 16 + g * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float l2;       // lse * log2(e) rounded on its own, never contracted into the fma below (as in attn_bwd_dkv_kernel)
+                        if constexpr (AA_BWD_LAB & 1) { pv[qb][r] = sacc[qb][r] + l4[r]; dsv[qb][r] = dpacc[qb][r] + d4[r]; continue; }
+                        float l2;       // lse * log2(e) rounded on its own (as when it was pre-scaled into LDS), never contracted into the fma below
                         asm("v_mul_f32 %0, %1, %2" : "=v"(l2) : "v"(l4[r]), "v"(LOG2E_F));
                         float pe = fast_exp2(sacc[qb][r] * c2 - l2);
                         if constexpr (decltype(masked)::value) {
@@ -1076,80 +904,26 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_x_kernel(const AttnParams
                 dsfr[0] = pack_bf16x8(dsv[0], dsv[1]); dsfr[1] = pack_bf16x8(dsv[2], dsv[3]);
             };
             if (need_mask) softmax_bwd(std::true_type{}); else softmax_bwd(std::false_type{});
-            // the fragments as lane-linear 1-KiB images: what lane l writes, lane l of the reading wave gets back
-            bf16x8* mine = reinterpret_cast<bf16x8*>(xch + wave * 4096) + lane;
-            mine[0] = pfr[0]; mine[64] = pfr[1]; mine[128] = dsfr[0]; mine[192] = dsfr[1];
-        }
-        __syncthreads();
-        // dV^T += dO^T P, dK^T += Q^T dS on my head-dim slice, for every active key block of my team
-        bool act[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) act[j] = block_active(team * 4 + j);
-        if (act[0] || act[1] || act[2] || act[3]) {
-            const int tb = lds0 + cur * 2 * TILE_B + trl;
-            static_for<2>([&](auto si) {
-                constexpr int S = decltype(si)::value;
-                i32x2 t[2][4];        // [d block i][dO^T rows 32 S, +16 | Q^T rows 32 S, +16]
-                static_for<2>([&](auto ii) {
-                    constexpr int I = decltype(ii)::value;
-                    const int a = tb ^ ((wt + 4 * I) << 5);
-                    t[I][0] = at_rdt<TILE_B + S * 32 * ROWB>(a);
-                    t[I][1] = at_rdt<TILE_B + (S * 32 + 16) * ROWB>(a);
-                    t[I][2] = at_rdt<S * 32 * ROWB>(a);
-                    t[I][3] = at_rdt<(S * 32 + 16) * ROWB>(a);
-                });
-                bf16x8 pj[4], dsj[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bf16x8* src = reinterpret_cast<const bf16x8*>(xch + (team * 4 + j) * 4096) + lane;
-                    if (act[j]) { pj[j] = src[S * 64]; dsj[j] = src[128 + S * 64]; }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]));
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const bf16x8 dot_f = at_join(t[i][0], t[i][1]), qt_f = at_join(t[i][2], t[i][3]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (act[j]) {
-                            dvacc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pj[j], dvacc[j][i], 0, 0, 0);
-                            dkacc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsj[j], dkacc[j][i], 0, 0, 0);
-                        }
-                }
+            // dV^T += dO^T P, dK^T += Q^T dS: the transposed Q / dO fragments by inline asm (tr_stream)
+            AT_PRIO_VALU_B(0);
+            AT_PRIO_MFMA_B(1);
+            tr_stream<HD, 2, 0, TILE_B, TR_NBUF_KV>(lds0 + cur * 2 * TILE_B + trl, [&](auto si, auto di, const bf16x8 qt_f, const bf16x8 dot_f) {
+                constexpr int S = decltype(si)::value, D = decltype(di)::value;
+                if constexpr (AA_BWD_LAB & 8) { landed(dot_f); landed(qt_f); landed(pfr[S]); landed(dsfr[S]); return; }
+                dvacc[D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr[S], dvacc[D], 0, 0, 0);
+                dkacc[D] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsfr[S], dkacc[D], 0, 0, 0);
             });
+            AT_PRIO_MFMA_B(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    // epilogue: lane (l15, g) holds, for key kv0 + 64 team + 16 j + l15, the columns 16 wt + 4 g + r and 64 + 16 wt + 4 g + r
-    auto r16 = [](float x) { return bf2f(f2bf(x)); };
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int kvj = kv0 + 64 * team + 16 * j + l15;
-        if (kvj >= T) continue;
-        const long krow = (long)n * T + kvj;
-        const int dc = 16 * wt + 4 * g;
-        u16x4 k1, k2, v1, v2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v1[r] = f2bf(dvacc[j][0][r]); v2[r] = f2bf(dvacc[j][1][r]); }
-        if (p.rope_pos) {     // aa_rope_inplace(inverse = 1) on the bf16-rounded gradient, the rounding points of at_store_rows_rope
-            const long tab = (long)p.rope_pos[krow] * (HD / 2) + dc;
-            const u16x4 c4 = *reinterpret_cast<const u16x4*>(p.rope_cos + tab), s4 = *reinterpret_cast<const u16x4*>(p.rope_sin + tab);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = r16(dkacc[j][0][r]), b = r16(dkacc[j][1][r]), c = bf2f(c4[r]), sn = bf2f(s4[r]);
-                k1[r] = f2bf(r16(a * c) + r16(b * sn));
-                k2[r] = f2bf(r16(b * c) + r16(-a * sn));
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { k1[r] = f2bf(dkacc[j][0][r]); k2[r] = f2bf(dkacc[j][1][r]); }
+        if constexpr (!(AA_BWD_LAB & 16)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        bf16_t* dkr = p.dK + krow * p.lddk + hk * HD + dc;
-        bf16_t* dvr = p.dV + krow * p.lddv + hk * HD + dc;
-        *reinterpret_cast<u16x4*>(dkr) = k1; *reinterpret_cast<u16x4*>(dkr + 64) = k2;
-        *reinterpret_cast<u16x4*>(dvr) = v1; *reinterpret_cast<u16x4*>(dvr + 64) = v2;
     }
+    const long krow_i = (long)n * T + min(kvg, T - 1);
+    if (p.rope_pos) at_store_rows_rope<DB>(p.dK + krow_i * p.lddk + hk * HD, dkacc, kvg < T, g, p.rope_cos, p.rope_sin, (long)p.rope_pos[krow_i] * (HD / 2));
+    else at_store_rows<DB, true>(p.dK + krow_i * p.lddk + hk * HD, dkacc, 1.f, kvg < T, g);
+    at_store_rows<DB, true>(p.dV + ((long)n * T + min(kvg, T - 1)) * p.lddv + hk * HD, dvacc, 1.f, kvg < T, g);
 }
 
 #include "attn128.inc"
@@ -1179,14 +953,14 @@ static int set_lds(K kern, int bytes, const char* name) {
 }
 
 // head_dim 128 runs on the one-wave-per-SIMD 32x32x16 kernels of attn128.inc; AA_ATTN128=0 / aa_attn_set_impl(0) keeps the 16x16x32 kernels above
-// (same-box A/B, bisecting; both stay tested).  Bit 0: forward (attn128.inc), bit 1: the dK/dV kernel that shares the transposed reads (attn_bwd_dkv_x_kernel).
+// (same-box A/B, bisecting; both stay tested).  Bit 0: forward, bit 1: backward.
 // aa_ctx::attn_impl (-1: read AA_ATTN128 once)
 static int attn_impl() {
     if (aa_ctx_cur()->attn_impl < 0) { const char* e = getenv("AA_ATTN128"); aa_ctx_cur()->attn_impl = e ? atoi(e) : 3; }
     return aa_ctx_cur()->attn_impl;
 }
 extern "C" int aa_attn_set_impl(int impl) {
-    AA_REQUIRE(impl >= 0 && impl <= 7, "aa_attn_set_impl: %d (bit 0 = 32x32x16 forward, bit 1 = dK / dV with shared transposed reads, bit 2 = lab: 32 keys per wave)", impl);
+    AA_REQUIRE(impl >= 0 && impl <= 3, "aa_attn_set_impl: %d (bit 0 = forward, bit 1 = backward on the 32x32x16 kernels)", impl);
     aa_ctx_cur()->attn_impl = impl;
     return AA_OK;
 }
@@ -1240,21 +1014,13 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
     if (hd == 128) {
         // NW = 8 (one 8-wave workgroup per CU sharing the tile stream) measured 1356 us on the bench block against ~1200-1340 for two independent 4-wave
         // workgroups per CU: what it saves in LDS-DMA pieces it loses in overlap across the per-tile barrier (profiles/r04_attn128_anatomy.txt, section 6)
-        const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N), gkv2(aa_cdiv(T, 128) * Hkv * N);
+        const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(aa_cdiv(groups * 16, 256)), dim3(256), 0, st, p);
         if ((rc = set_lds(attn_bwd_dq_kernel<128, 4>, lds, "aa_attn_bwd"))) return rc;
         if (AA_BWD_LAB_ONLY != 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 4>), gq, dim3(256), lds, st, p);
         if (AA_BWD_LAB_ONLY == 1) { AA_CHECK_LAUNCH("aa_attn_bwd"); return AA_OK; }
-        if (attn_impl() & 2) {     // AA_ATTN128 bit 1: dK/dV with the transposed reads shared inside the workgroup (8 waves, 128 keys)
-            if ((rc = set_lds(attn_bwd_dkv_x_kernel<128>, lds + 1024 + 32768, "aa_attn_bwd"))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dkv_x_kernel<128>), gkv2, dim3(512), lds + 1024 + 32768, st, p);
-        } else if (attn_impl() & 4) {     // bit 2 (lab): 32 keys per wave (KJ = 2), one 4-wave workgroup of 128 keys per CU -- measured 1.5 x slower
-            if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4, 2>, lds + 1024, "aa_attn_bwd"))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4, 2>), gkv2, dim3(256), lds + 1024, st, p);
-        } else {
-            if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4>, lds + 1024, "aa_attn_bwd"))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4>), gkv, dim3(256), lds + 1024, st, p);
-        }
+        if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4>, lds + 1024, "aa_attn_bwd"))) return rc;
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4>), gkv, dim3(256), lds + 1024, st, p);
     } else {
         const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
         hipLaunchKernelGGL(attn_delta_kernel<64>, dim3(aa_cdiv(groups * 8, 256)), dim3(256), 0, st, p);

@@ -611,19 +611,19 @@ def test_attention_kernels_keep_fragments_in_registers_and_the_prefetch_in_fligh
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
         text = open(asm).read()
-    names = re.findall(r'Function Name: (\S*attn_(?:fwd|bwd_dq|bwd_dkv|bwd_dkv_x)_kernel\S*)', r.stderr)
+    names = re.findall(r'Function Name: (\S*attn_(?:fwd|bwd_dq|bwd_dkv)_kernel\S*)', r.stderr)
     blocks = re.split(r'Function Name: ', r.stderr)[1:]
     checked = 0
     for blk in blocks:
-        if not re.match(r'\S*attn_(?:fwd|bwd_dq|bwd_dkv|bwd_dkv_x)_kernel', blk):
+        if not re.match(r'\S*attn_(?:fwd|bwd_dq|bwd_dkv)_kernel', blk):
             continue
         assert int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', blk).group(1)) == 0, blk[:200]
         assert int(re.search(r'VGPRs Spill: (\d+)', blk).group(1)) == 0, blk[:200]
         checked += 1
-    assert checked == 8 and len(names) == 8                 # forward, dQ, dK/dV x head_dim 64 / 128 + (head_dim 128) the shared-transposed-read dK/dV and the lab 32-keys-per-wave one
+    assert checked == 6 and len(names) == 6                 # forward, dQ, dK/dV x head_dim 64 / 128
     assert 'scratch_' not in text
-    kernels = re.findall(r'^(_Z\d+attn_(?:fwd|bwd_dq|bwd_dkv|bwd_dkv_x)_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end', text, flags=re.S | re.M)
-    assert len(kernels) == 8
+    kernels = re.findall(r'^(_Z\d+attn_(?:fwd|bwd_dq|bwd_dkv)_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end', text, flags=re.S | re.M)
+    assert len(kernels) == 6
     for name, body in kernels:
         lines = [ln for ln in body.split('\n') if ln.strip() and not ln.strip().startswith(';') or 'ASM' in ln]
         mf = [i for i, ln in enumerate(lines) if 'v_mfma_f32_16x16x32_bf16' in ln]

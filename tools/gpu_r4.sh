@@ -11,7 +11,7 @@ for stage in "$@"; do
       timeout 400 python tools/attn128_check.py $ATTN_ARGS > gpurun_out/r04_attn128_check.txt 2>&1; tail -30 gpurun_out/r04_attn128_check.txt ;;
     new_tests)       # this session's new / touched GPU tests
       timeout 1200 python -m pytest tests/test_optim_gpu.py tests/test_decode_gpu.py tests/test_gemm_gpu.py tests/test_f32_gpu.py tests/test_ep_gpu.py tests/test_qwen3moe_gpu.py tests/test_attention_gpu.py -m gpu -q -p no:cacheprovider --durations=8 > gpurun_out/r04_pytest_new.log 2>&1; tail -25 gpurun_out/r04_pytest_new.log ;;
-    attn_bwd)        # dK/dV with 32 keys per wave (AA_ATTN128 bit 2) against the shipped backward: bit identity + timing
+    attn_bwd)        # backward variants selected by aa_attn_set_impl (ATTN_BASE / ATTN_IMPL) against each other: bit identity + timing
       timeout 500 python tools/attn128_check.py --bwd --base ${ATTN_BASE:-1} --impl ${ATTN_IMPL:-3} --out r04_attn_bwd_x.json $ATTN_ARGS > gpurun_out/r04_attn_bwd_x.txt 2>&1; python3 - <<'PY'
 import json
 for c in json.load(open('gpurun_out/r04_attn_bwd_x.json')):
