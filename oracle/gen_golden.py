@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import _shim  # noqa: E402
-from oracle.synthetic import StubProcessor, opt125m_config1, preference_samples  # noqa: E402
+from oracle.synthetic import StubProcessor, llava7b_width, opt125m_config1, preference_samples  # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
@@ -1002,6 +1002,51 @@ def gen_opt_ppo():
     np.savez_compressed(os.path.join(GOLD, 'opt_tiny_ppo.npz'), **out)
 
 
+def gen_llava7b_width():
+    """A full-WIDTH parity point that is not HIP-vs-HIP: the reference's unmodified text+image DPOTrainer
+    (trainers/text_image_to_text/dpo.py:85-166: compute_log_probs, loss) + backward on oracle.synthetic.llava7b_width -- CLIP-L/14-336, projector and
+    4 Llama layers at the 7B geometry, one pair, fp32, CPU.  Stored: the six loss outputs, both log-prob tensors, per-parameter gradient norms and
+    a leading block of every gradient, per-tensor weight checksums (the weights themselves are regenerated from the seed on the GPU box)."""
+    import time
+    from align_anything.trainers.text_image_to_text.dpo import DPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+    t0 = time.time()
+    cfg, policy, refm, batch = llava7b_width()
+    print(f'models built ({time.time() - t0:.0f}s)', flush=True)
+    tr = DPOTrainer.__new__(DPOTrainer)
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+    tr.tokenizer = SimpleNamespace(pad_token_id=32001)
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    tr.model = SimpleNamespace(module=policy)
+    tr.reference_model = SimpleNamespace(module=refm)
+    for n, p in policy.named_parameters():
+        p.requires_grad_('vision_tower' not in n)          # the reference freezes the tower by default (freeze_vision_tower: True, dpo.yaml)
+    policy.zero_grad()
+    seq_lp = tr.compute_log_probs(policy, batch).detach()
+    ref_lp = tr.compute_log_probs(refm, batch).detach()
+    ld = tr.loss(batch)
+    ld['loss'].backward()
+    print(f'reference loss {float(ld["loss"]):.6f} margin {ld["reward_margin"].tolist()} ({time.time() - t0:.0f}s)', flush=True)
+    out = {'input_ids': batch['input_ids'].numpy(), 'attention_mask': batch['attention_mask'].numpy(), 'response_lens': np.array(batch['meta_info']['response_lens']),
+           'pixel_checksum': np.array(float(batch['pixel_values'].double().sum())), 'seq_log_probs': seq_lp.numpy(), 'ref_seq_log_probs': ref_lp.numpy(),
+           'scale_coeff': np.array(0.1), 'num_layers': np.array(cfg.text_config.num_hidden_layers)}
+    for k, v in ld.items():
+        out['loss_' + k] = v.detach().numpy()
+    names, wsum, rsum, gnorm = [], [], [], []
+    rparams = dict(refm.named_parameters())
+    for n, p in policy.named_parameters():
+        names.append(n); wsum.append(float(p.double().sum())); rsum.append(float(rparams[n].double().sum()))
+        if p.grad is None:
+            gnorm.append(-1.0)
+            continue
+        gnorm.append(float(p.grad.double().norm()))
+        g2 = p.grad.reshape(p.grad.shape[0], -1)
+        out['gblk.' + n] = g2[:32, :32].contiguous().numpy()
+    out.update(names=np.array(names), weight_checksum=np.array(wsum), ref_weight_checksum=np.array(rsum), grad_norm=np.array(gnorm))
+    np.savez_compressed(os.path.join(GOLD, 'llava7b_width_dpo.npz'), **out)
+    print('llava7b_width_dpo.npz', len(out), 'arrays; total grad norm', float(np.sqrt(sum(g * g for g in gnorm if g >= 0))), f'({time.time() - t0:.0f}s)')
+
+
 def _opt125m_reference_trainer(nthreads):
     """The reference's unmodified DPOTrainer (trainers/text_to_text/dpo.py) on config 1 with the DeepSpeed engine replaced by
     torch.optim.AdamW over the reference's own parameter groups + clip_grad_norm_(1.0) + HF cosine schedule (see gen_opt125m_curve).
@@ -1149,3 +1194,4 @@ if __name__ == '__main__':
     gen_opt_ppo()
     gen_opt125m_curve()
     gen_opt125m_teacher()
+    gen_llava7b_width()

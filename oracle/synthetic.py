@@ -87,3 +87,48 @@ def preference_samples(n=5, seed=3):
         out.append({'better_conversation': prompt + ' ' + pick(nb) + ' </s>', 'worse_conversation': prompt + ' ' + pick(nw) + ' </s>',
                     'image': 100 + i, 'better_response_lens': nb + 1, 'worse_response_lens': nw + 1})
     return out
+
+
+def llava7b_width(num_layers=4, T=640, R=48, left_pad=(0, 23), seed=42):
+    """One preference pair at the FULL WIDTH of BASELINE.json configs[1] (LLaVA-1.5-7B: CLIP-L/14-336 tower of 24 x 1024, projector, Llama
+    layers of 4096 / 11008 / 32 heads x 128, vocabulary 32064) but `num_layers` decoder layers, so that the UNMODIFIED reference trainer runs
+    it in fp32 on the build container's CPU in minutes (a full-width parity point that is not HIP-vs-HIP).  HF init from
+    torch.manual_seed(seed), every weight rounded to a bf16-representable value (the bf16 path and the fp32 twin then load identical numbers),
+    reference model = policy + N(0, 2e-3) on the decoder / projector matrices.  Sequence: BOS + 576 image tokens + text, the rejected row left-padded;
+    R response tokens.  Returns (LlavaConfig, policy, reference, batch).  Pure HF + torch CPU RNG: regenerated on the GPU box, the 9 GB of weights
+    are not committed (per-tensor checksums are)."""
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig, LlavaForConditionalGeneration
+    vc = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336, patch_size=14,
+                          projection_dim=768)
+    tc = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=num_layers, num_attention_heads=32, num_key_value_heads=32,
+                     vocab_size=32064, rms_norm_eps=1e-5, max_position_embeddings=4096)
+    cfg = LlavaConfig(vision_config=vc, text_config=tc, image_token_id=32000, image_seq_length=576, pad_token_id=32001)
+    torch.manual_seed(seed)
+    policy = LlavaForConditionalGeneration(cfg).eval()
+    with torch.no_grad():
+        for p in policy.parameters():
+            p.copy_(p.to(torch.bfloat16).to(torch.float32))
+    torch.manual_seed(seed)
+    refm = LlavaForConditionalGeneration(cfg).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for (n, p), q in zip(refm.named_parameters(), policy.parameters()):
+            if p.dim() >= 2 and 'vision_tower' not in n:
+                p.copy_((q + 2e-3 * torch.randn(q.shape, generator=g)).to(torch.bfloat16).to(torch.float32))
+            else:
+                p.copy_(q)
+    gb = torch.Generator().manual_seed(seed + 2)
+    N = 2
+    ids = torch.full((N, T), 32001, dtype=torch.long)
+    mask = torch.zeros((N, T), dtype=torch.long)
+    prompt = torch.randint(3, 31999, (T - 577 - R,), generator=gb)
+    for r in range(N):
+        lp = left_pad[r]
+        resp = torch.randint(3, 31999, (R - lp,), generator=gb)
+        row = torch.cat([torch.tensor([1]), torch.full((576,), 32000), prompt, resp])
+        ids[r, lp:] = row
+        mask[r, lp:] = 1
+    pix = torch.randn(1, 3, 336, 336, generator=gb)
+    batch = {'input_ids': ids, 'attention_mask': mask, 'pixel_values': torch.cat([pix, pix], 0),
+             'meta_info': {'response_lens': [R - lp for lp in left_pad]}}
+    return cfg, policy, refm, batch

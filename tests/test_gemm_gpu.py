@@ -19,7 +19,7 @@ def _ref(a, b, a_t, b_n):
 @pytest.mark.parametrize('layout', ['nt', 'nn', 'tn'])
 def test_gemm_layouts_and_tiles(tile, layout):
     """tile 0-3: 16x16x32-MFMA tile configs of the 8-wave kernel; 5: the one-wave-per-SIMD kernel
-    with accumulator-file MFMAs (gemm4.hip).  (Its 32x32x16-MFMA sibling passed these tests in round 3 and lost the A/B: tools/lab/gemm5.)"""
+    with accumulator-file MFMAs (gemm4.hip).  (Its 32x32x16-MFMA sibling passed these tests in round 3 and lost the A/B: profiles/r03_gemm5_mfma32_negative.txt; source in git history, commit b2c2a50.)"""
     from align_anything_amd import ops
     ops.gemm_set_tile(tile)
     try:

@@ -9,7 +9,7 @@ for stage in "$@"; do
   case $stage in
     tests)       # the whole -m gpu suite (parity reports land in gpurun_out/parity)
       timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/r03_pytest.log 2>&1; tail -15 gpurun_out/r03_pytest.log ;;
-    tests_new)   # only this round's new / changed tests (the gemm4-vs-gemm5 lab / PMC / power stages went to tools/lab/gemm5 with the kernel)
+    tests_new)   # only this round's new / changed tests (the gemm4-vs-gemm5 lab / PMC / power stages were removed with the kernel: git history, commit b2c2a50)
       timeout 1200 python -m pytest tests/test_gemm_gpu.py tests/test_twin_gpu.py tests/test_secondary_geometry_gpu.py tests/test_qwen2vl_gpu.py tests/test_bench_geometry_gpu.py -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/r03_pytest_new.log 2>&1; tail -25 gpurun_out/r03_pytest_new.log ;;
     bench)       # the headline line exactly as the driver runs it (in-run PMC traffic when rocprofv3 is there)
       timeout 1500 python bench.py --steps 8 --warmup 2 > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err; tail -c 1500 gpurun_out/r03_bench.json; tail -5 gpurun_out/r03_bench.err ;;

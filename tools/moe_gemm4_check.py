@@ -1,14 +1,14 @@
-"""Check + time the row-grouped MoE GEMMs on the gemm4 tile (tools/lab/moe_gemm4_grouped.patch; AA_MOE_GEMM4=1 -> ops.MOE_ALIGN = 256, aa_gemm4_grouped) against the
+"""Check + time the row-grouped MoE GEMMs on the gemm4 tile (csrc/gemm4.hip GRP, shipped in round 4; AA_MOE_GEMM4=1 -> ops.MOE_ALIGN = 256, aa_gemm4_grouped) against the
 128 x 256 8-wave kernel (AA_MOE_GEMM4=0) at the Qwen3-30B-A3B layer geometry: 8192 tokens x top-8 of 128 experts, h = 2048, F = 768.
 
-    python tools/lab/moe_gemm4_check.py            parent: one child per setting, prints both JSON lines
+    python tools/moe_gemm4_check.py            parent: one child per setting, prints both JSON lines
 """
 import json
 import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
