@@ -1011,7 +1011,11 @@ def gen_llava7b_width():
     from align_anything.trainers.text_image_to_text.dpo import DPOTrainer
     from align_anything.utils.tools import dict_to_namedtuple
     t0 = time.time()
-    cfg, policy, refm, batch = llava7b_width()
+    from transformers import LlavaForConditionalGeneration
+    cfg, sd, ref_sd, batch = llava7b_width()
+    policy, refm = LlavaForConditionalGeneration(cfg).eval(), LlavaForConditionalGeneration(cfg).eval()
+    assert policy.load_state_dict(sd, strict=True) and refm.load_state_dict(ref_sd, strict=True)
+    del sd, ref_sd
     print(f'models built ({time.time() - t0:.0f}s)', flush=True)
     tr = DPOTrainer.__new__(DPOTrainer)
     tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})

@@ -89,34 +89,41 @@ def preference_samples(n=5, seed=3):
     return out
 
 
-def llava7b_width(num_layers=4, T=640, R=48, left_pad=(0, 23), seed=42):
-    """One preference pair at the FULL WIDTH of BASELINE.json configs[1] (LLaVA-1.5-7B: CLIP-L/14-336 tower of 24 x 1024, projector, Llama
-    layers of 4096 / 11008 / 32 heads x 128, vocabulary 32064) but `num_layers` decoder layers, so that the UNMODIFIED reference trainer runs
-    it in fp32 on the build container's CPU in minutes (a full-width parity point that is not HIP-vs-HIP).  HF init from
-    torch.manual_seed(seed), every weight rounded to a bf16-representable value (the bf16 path and the fp32 twin then load identical numbers),
-    reference model = policy + N(0, 2e-3) on the decoder / projector matrices.  Sequence: BOS + 576 image tokens + text, the rejected row left-padded;
-    R response tokens.  Returns (LlavaConfig, policy, reference, batch).  Pure HF + torch CPU RNG: regenerated on the GPU box, the 9 GB of weights
-    are not committed (per-tensor checksums are)."""
-    from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig, LlavaForConditionalGeneration
+def llava7b_width_config(num_layers=4):
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig
     vc = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336, patch_size=14,
                           projection_dim=768)
     tc = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=num_layers, num_attention_heads=32, num_key_value_heads=32,
                      vocab_size=32064, rms_norm_eps=1e-5, max_position_embeddings=4096)
-    cfg = LlavaConfig(vision_config=vc, text_config=tc, image_token_id=32000, image_seq_length=576, pad_token_id=32001)
-    torch.manual_seed(seed)
-    policy = LlavaForConditionalGeneration(cfg).eval()
-    with torch.no_grad():
-        for p in policy.parameters():
-            p.copy_(p.to(torch.bfloat16).to(torch.float32))
-    torch.manual_seed(seed)
-    refm = LlavaForConditionalGeneration(cfg).eval()
-    g = torch.Generator().manual_seed(seed + 1)
-    with torch.no_grad():
-        for (n, p), q in zip(refm.named_parameters(), policy.parameters()):
-            if p.dim() >= 2 and 'vision_tower' not in n:
-                p.copy_((q + 2e-3 * torch.randn(q.shape, generator=g)).to(torch.bfloat16).to(torch.float32))
-            else:
-                p.copy_(q)
+    return LlavaConfig(vision_config=vc, text_config=tc, image_token_id=32000, image_seq_length=576, pad_token_id=32001)
+
+
+def llava7b_width(num_layers=4, T=640, R=48, left_pad=(0, 23), seed=42):
+    """One preference pair at the FULL WIDTH of BASELINE.json configs[1] (LLaVA-1.5-7B: CLIP-L/14-336 tower of 24 x 1024, projector, Llama
+    layers of 4096 / 11008 / 32 heads x 128, vocabulary 32064) but `num_layers` decoder layers, so that the UNMODIFIED reference trainer runs
+    it in fp32 on the build container's CPU in minutes (a full-width parity point that is not HIP-vs-HIP).
+
+    Weights: every tensor of the HF state dict is drawn from its OWN generator, seeded by (seed, crc32 of the parameter name) -- independent of the
+    order in which any transformers version initialises its modules, and 10 x faster than an HF init: matrices, embeddings and biases N(0, 0.02),
+    norm weights 1 + N(0, 0.1), all rounded to bf16-representable values (the bf16 path and the fp32 twin then load identical numbers);
+    reference model = policy + N(0, 2e-3) on the decoder / projector matrices.  Sequence: BOS + 576 image tokens + text, the rejected row
+    left-padded; R response tokens.  Returns (LlavaConfig, policy state dict, reference state dict, batch).  Pure torch CPU RNG + the HF config
+    classes: regenerated on the GPU box, the 9 GB of weights are not committed (per-tensor checksums are)."""
+    import zlib
+    from transformers import LlavaForConditionalGeneration
+    cfg = llava7b_width_config(num_layers)
+    with torch.device('meta'):
+        skel = LlavaForConditionalGeneration(cfg)
+    sd, ref_sd = {}, {}
+    for n, p in skel.named_parameters():
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(n.encode())) % (1 << 62))
+        norm = p.dim() == 1 and ('norm' in n or 'layrnorm' in n) and n.endswith('weight')
+        w = torch.randn(tuple(p.shape), generator=g) * (0.1 if norm else 0.02) + (1.0 if norm else 0.0)
+        sd[n] = w.to(torch.bfloat16).to(torch.float32)
+        if p.dim() >= 2 and 'vision_tower' not in n:
+            ref_sd[n] = (sd[n] + 2e-3 * torch.randn(tuple(p.shape), generator=g)).to(torch.bfloat16).to(torch.float32)
+        else:
+            ref_sd[n] = sd[n]
     gb = torch.Generator().manual_seed(seed + 2)
     N = 2
     ids = torch.full((N, T), 32001, dtype=torch.long)
@@ -131,4 +138,4 @@ def llava7b_width(num_layers=4, T=640, R=48, left_pad=(0, 23), seed=42):
     pix = torch.randn(1, 3, 336, 336, generator=gb)
     batch = {'input_ids': ids, 'attention_mask': mask, 'pixel_values': torch.cat([pix, pix], 0),
              'meta_info': {'response_lens': [R - lp for lp in left_pad]}}
-    return cfg, policy, refm, batch
+    return cfg, sd, ref_sd, batch

@@ -74,3 +74,30 @@ def test_c_abi_collectives_bind_rccl_and_run_on_one_rank():
             call('aa_grad_allreduce_bucket', g16.data_ptr(), g16.numel(), 7, st)
     finally:
         call('aa_comm_destroy')
+
+
+def test_c_abi_collectives_two_ranks_on_one_device(tmp_path):
+    """drive aa_comm_init / aa_grad_allreduce_bucket / aa_metrics_allreduce / aa_broadcast with WORLD 2 on the test box's
+    one GPU (two processes, both on cuda:0).  RCCL either brings the communicator up -- then sums, means, maxima and the broadcast are checked
+    on both ranks -- or refuses two ranks on one device (NCCL's "duplicate GPU" rule); which of the two happened on this box is written to
+    gpurun_out/comm_two_ranks_one_device.txt.  What may never happen is a hang or a wrong value: both workers run under a timeout."""
+    from tests.gpu_util import dump
+    idfile = str(tmp_path / 'rccl_uid.bin')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', NCCL_DEBUG='WARN')
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'comm_worker.py'), str(r), idfile], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p_ in procs:
+        try:
+            o, e = p_.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            o, e = p_.communicate()
+            o += '\nCOMM_TIMEOUT'
+        outs.append((p_.returncode, o, e))
+    lines = [ln for _, o, _ in outs for ln in o.splitlines() if ln.startswith('COMM_')]
+    dump('comm_two_ranks_one_device.txt', '\n'.join(lines) + '\n' + '\n'.join(e[-1500:] for _, _, e in outs))
+    assert len(lines) == 2 and not any(ln.startswith(('COMM_WRONG', 'COMM_TIMEOUT')) for ln in lines), (lines, [e[-800:] for _, _, e in outs])
+    ok = [ln.startswith('COMM_OK') for ln in lines]
+    assert all(ok) or not any(ok), lines          # both ranks up and correct, or RCCL refused the duplicate device on both
