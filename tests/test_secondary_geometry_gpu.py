@@ -521,6 +521,7 @@ def test_llava7b_width_pair_vs_the_reference_trainer():
     for dtype in ('fp32', 'bf16'):
         tr = DPOTrainer(_dpo_cfgs(cfg['pad_token_id'], dtype, float(z['scale_coeff'])), {'gradient_clipping': 1.0}, model_cfg=cfg, policy_state=sd,
                         reference_state=ref_sd, device='cuda:0')
+        b['pixel_values'] = batch['pixel_values'].to(dev()).to(torch.float32 if dtype == 'fp32' else torch.bfloat16)   # the collator hands pixels in the model dtype
         lp = tr.compute_log_probs(tr.model, b).cpu()
         rlp = tr.compute_log_probs(tr.reference_model, b).cpu()
         assert torch.equal(lp == 0, want_lp == 0), 'response-window layout differs from the reference'
