@@ -98,7 +98,8 @@ def test_c_abi_collectives_two_ranks_on_one_device(tmp_path):
         outs.append((p_.returncode, o, e))
     lines = []
     for rc, o, e in outs:
-        mine = [ln for ln in o.splitlines() if ln.startswith('COMM_')]
+        import re
+        mine = re.findall(r'COMM_(?:OK|REFUSED|WRONG|TIMEOUT)[^\n]*', o)      # RCCL's own warnings share the stream: the marker may sit mid-line
         # a worker that dies inside librccl without reaching a print (RCCL aborting on the duplicate device) counts as a refusal, with its exit code
         lines.append(mine[0] if mine else f'COMM_REFUSED process ended with rc {rc} before reporting: {(e.strip().splitlines() or ["(no stderr)"])[-1][:300]}')
     dump('comm_two_ranks_one_device.txt', '\n'.join(lines) + '\n\n' + '\n'.join(f'--- rank {i} rc {rc}\n{o[-1500:]}\n{e[-3000:]}' for i, (rc, o, e) in enumerate(outs)))

@@ -514,14 +514,14 @@ def test_llava7b_width_pair_vs_the_reference_trainer():
         assert abs(float(ref_sd[n].double().sum()) - float(rc)) <= 1e-9 * max(1.0, abs(float(rc))), n
     assert np.array_equal(batch['input_ids'].numpy(), z['input_ids']) and abs(float(batch['pixel_values'].double().sum()) - float(z['pixel_checksum'])) < 1e-6
     cfg = configs.from_hf_config(hc)
-    b = {'input_ids': batch['input_ids'].to(dev()), 'attention_mask': batch['attention_mask'].to(dev()), 'pixel_values': batch['pixel_values'].to(dev()),
-         'meta_info': batch['meta_info']}
     want_lp, want_ref = torch.from_numpy(z['seq_log_probs']), torch.from_numpy(z['ref_seq_log_probs'])
     rep = [f'reference trainer (fp32, CPU): loss {float(z["loss_loss"]):.6f} margin {z["loss_reward_margin"].tolist()} summed log-probs {want_lp.sum(1).tolist()}']
     for dtype in ('fp32', 'bf16'):
         tr = DPOTrainer(_dpo_cfgs(cfg['pad_token_id'], dtype, float(z['scale_coeff'])), {'gradient_clipping': 1.0}, model_cfg=cfg, policy_state=sd,
                         reference_state=ref_sd, device='cuda:0')
-        b['pixel_values'] = batch['pixel_values'].to(dev()).to(torch.float32 if dtype == 'fp32' else torch.bfloat16)   # the collator hands pixels in the model dtype
+        # a fresh batch per run (the trainer caches the tower output and the window plan inside it); the collator hands pixels in the model dtype
+        b = {'input_ids': batch['input_ids'].to(dev()), 'attention_mask': batch['attention_mask'].to(dev()), 'meta_info': batch['meta_info'],
+             'pixel_values': batch['pixel_values'].to(dev()).to(torch.float32 if dtype == 'fp32' else torch.bfloat16)}
         lp = tr.compute_log_probs(tr.model, b).cpu()
         rlp = tr.compute_log_probs(tr.reference_model, b).cpu()
         assert torch.equal(lp == 0, want_lp == 0), 'response-window layout differs from the reference'
