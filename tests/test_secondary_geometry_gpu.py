@@ -500,9 +500,9 @@ def test_llava7b_width_pair_vs_the_reference_trainer():
     loss, then backward) on oracle.synthetic.llava7b_width in the build container (fp32, CPU): the CLIP-L/14-336 tower, the projector and 4 Llama
     layers of 4096 / 11008 / 32 x 128 with the 32064-row lm_head, one left-padded pair, 576 image tokens.  The weights are regenerated here from the
     seed (per-tensor checksums are checked first) and run through (a) the fp32 twin kernels and (b) the bf16 production kernels.  Stated bounds:
-    fp32: loss / log-probs 2e-4 abs, gradient norms 1e-3 rel, gradient blocks 2e-3 rel; bf16: summed log-probs within 0.5 nat per row (~1e-3 of
-    their magnitude), loss 0.05, gradient norms of the matrices 8e-2 rel -- the one-layer bf16 test above explains those through the rounding of
-    bf16 activations."""
+    fp32: loss / log-probs 2e-4 abs, gradient norms 1e-3 rel, gradient blocks 2e-3 rel (first hardware run: 3.0e-6 / 1.6e-5 / 3.1e-6 / 1.4e-5); bf16:
+    loss 1e-2, summed log-probs 0.3 nat per row (of -510 / -271), gradient norms of the matrices 2e-2 rel, their leading blocks 0.15 (first run:
+    3.3e-3 / 0.093 / 5.7e-3 / 4.9e-2 -- the rounding of bf16 activations, as in the one-layer test above)."""
     from oracle.synthetic import llava7b_width
     from align_anything_amd import configs
     from align_anything_amd.trainers.dpo import DPOTrainer
@@ -553,7 +553,7 @@ def test_llava7b_width_pair_vs_the_reference_trainer():
         if dtype == 'fp32':
             assert e_loss < 2e-4 and e_lp < 2e-4 and e_ref < 2e-4 and worst_norm < 1e-3 and worst_blk < 2e-3, rep[-1]
         else:
-            assert e_loss < 5e-2 and e_sum < 0.5 and worst_norm < 8e-2, rep[-1]
+            assert e_loss < 1e-2 and e_sum < 0.3 and worst_norm < 2e-2 and worst_blk < 0.15, rep[-1]     # ~3 x the first hardware run: 3.3e-3 / 0.093 / 5.7e-3 / 4.9e-2
         assert n_g >= 30
         del tr
         _free()
