@@ -67,6 +67,52 @@ extern "C" int aa_grad_sumsq(const void* g, int g_dtype, long n, float scale, fl
     return AA_OK;
 }
 
+// Reduce step of the DIRECT gradient exchange (engine.GradReducer mode 'direct': all-to-all of the w chunks over the w - 1 point-to-point xGMI links,
+// this sum, all-gather): out[i] = sum over r of in[r][i] for i < c, the w chunks summed in rank order in fp32 and rounded ONCE to the gradient dtype --
+// every rank computes its own chunk the same way, so after the all-gather the replicas hold identical bits (and a bf16 bucket is rounded once instead
+// of w - 1 times along a ring).  HBM-bound: (w + 1) x c elements.  SURVEY.md section 8(e): "7-link-parallel reduce-scatter / all-gather".
+template <typename T>
+__global__ __launch_bounds__(256) void chunk_sum_kernel(const T* __restrict__ in, T* __restrict__ out, long c, int w) {
+    const long c8 = c >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < c8; i += (long)gridDim.x * 256) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int r = 0; r < w; ++r) {
+            if constexpr (sizeof(T) == 2) {
+                const u16x8 v = *reinterpret_cast<const u16x8*>(in + (long)r * c + i * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(in + (long)r * c + i * 8), b = *reinterpret_cast<const f32x4*>(in + (long)r * c + i * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[e] += a[e]; acc[4 + e] += b[e]; }
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            u16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e]);
+            *reinterpret_cast<u16x8*>(out + i * 8) = o;
+        } else {
+            *reinterpret_cast<f32x4*>(out + i * 8) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f32x4*>(out + i * 8 + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+        }
+    }
+}
+extern "C" int aa_chunk_sum(const void* in, void* out, int dtype, long chunk, int world, void* stream) {
+    AA_REQUIRE(dtype == 0 || dtype == 1, "aa_chunk_sum: dtype must be 0 (bf16) or 1 (f32)");
+    AA_REQUIRE(world >= 1 && chunk >= 0 && chunk % 8 == 0, "aa_chunk_sum: world %d, chunk %ld (a multiple of 8 elements)", world, chunk);
+    AA_REQUIRE((((uintptr_t)in | (uintptr_t)out) & 15) == 0, "aa_chunk_sum: buffers must be 16-byte aligned");
+    if (chunk == 0) return AA_OK;
+    const long work = chunk / 8 / 256 + 1;
+    const int grid = (int)(work < 4096 ? work : 4096);
+    if (dtype == 0) hipLaunchKernelGGL(chunk_sum_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, chunk, world);
+    else hipLaunchKernelGGL(chunk_sum_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, chunk, world);
+    AA_CHECK_LAUNCH("aa_chunk_sum");
+    return AA_OK;
+}
+
 // clip_coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)) ; norm_out = sqrt(sumsq)  (device-side, no host sync)
 // sumsq == -inf is the "skip this update" sentinel (the expert-parallel capacity overflow, all-reduced into the buffer by the engine:
 // expert_parallel.py): coef = norm = -1, and the AdamW kernels below return without touching weights or moments on a negative coefficient.

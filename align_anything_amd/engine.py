@@ -36,10 +36,22 @@ def cosine_with_warmup(step: int, base_lr: float, warmup: int, total: int) -> fl
 
 
 class GradReducer:
-    """Bucketed SUM all-reduce of flat gradient slices on a side stream (backend-agnostic: RCCL on GPU,
-    gloo in the CPU tests).  The 1/world scaling is folded into the optimizer kernels (gscale)."""
+    """Bucketed SUM reduction of flat gradient slices on a side stream (backend-agnostic: RCCL on GPU, gloo in the CPU tests).  The 1/world scaling
+    is folded into the optimizer kernels (gscale).
 
-    def __init__(self, group=None):
+    Two exchange forms; `AA_DP_REDUCE` = ring | direct | auto (default):
+      ring    one `all_reduce` per bucket: whatever schedule RCCL builds over the xGMI links.
+      direct  xGMI is a full mesh of point-to-point links (7 per GPU on an 8-GPU node), so a bucket of n elements is exchanged as
+              all-to-all (rank r receives chunk r of every peer: n / w elements over each link, all links at once) -> sum of the w chunks in fp32,
+              rank order, one rounding (csrc/optim.hip aa_chunk_sum) -> all-gather of the reduced chunks (again n / w per link, all links at once).
+              Same bytes per rank as a ring (2 (w - 1) / w x n) but no multi-hop dependency chain, and a bf16 bucket is rounded once, not w - 1
+              times.  Replicas stay bit-identical: every chunk is summed by exactly one rank and broadcast.
+      auto    the first bucket of a run times both forms on a 64 MiB scratch buffer (HIP events on the communication stream, max over the ranks so
+              that all ranks decide alike), checks that they agree to the gradient dtype's rounding, and keeps the faster one -- no 8-GPU node was
+              available while this was written, so the choice is measured where it runs instead of guessed (bench.py reports it as
+              multi_gpu.reduce_mode)."""
+
+    def __init__(self, group=None, mode=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.handles = []
@@ -48,6 +60,85 @@ class GradReducer:
         # reports how long each all-reduce took from "bucket ready" to "reduced" next to the backward it overlaps with
         self.prof = os.environ.get('AA_COMM_PROF', '0') == '1'
         self.records = []          # (bytes, ready event, done event) per bucket since the last report()
+        self.mode = (mode or os.environ.get('AA_DP_REDUCE', 'auto')).lower()
+        if self.mode not in ('ring', 'direct', 'auto'):
+            raise ValueError(f'AA_DP_REDUCE / mode must be ring, direct or auto, got {self.mode!r}')
+        self.autotune_report = None
+        self._ws = {}              # dtype -> (receive buffer [n], reduced chunk [n / w]) of the direct form, grow-only
+
+    # ---- the two exchange forms (called with the communication stream current on a GPU)
+    def _direct(self, flat: torch.Tensor):
+        w, n = self.world, flat.numel()
+        if n % (8 * w) or flat.data_ptr() % 16:
+            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)      # a ragged slice (never the engine's 64-element-aligned buckets)
+        c = n // w
+        recv, mine = self._ws.get(flat.dtype, (None, None))
+        if recv is None or recv.numel() < n:
+            recv = torch.empty(n, dtype=flat.dtype, device=flat.device)
+            mine = torch.empty(-(-n // w), dtype=flat.dtype, device=flat.device)
+            self._ws[flat.dtype] = (recv, mine)
+        recv, mine = recv[:n], mine[:c]
+        if flat.is_cuda:
+            dist.all_to_all_single(recv, flat, group=self.group)
+            ops.chunk_sum(recv, mine, w)
+            dist.all_gather_into_tensor(flat, mine, group=self.group)
+        else:       # gloo / CPU tensors (tests of the plumbing): bytes travel as uint8 (gloo moves no bf16), the same rank-ordered fp32 sum in torch
+            dist.all_to_all_single(recv.view(torch.uint8), flat.view(torch.uint8), group=self.group)
+            mine.copy_(recv.view(w, c).float().sum(0).to(flat.dtype))
+            parts = [torch.empty_like(mine).view(torch.uint8) for _ in range(w)]
+            dist.all_gather(parts, mine.view(torch.uint8), group=self.group)
+            flat.view(torch.uint8).copy_(torch.cat(parts))
+
+    def _exchange(self, flat: torch.Tensor):
+        if self.mode == 'auto':
+            self._autotune(flat)
+        if self.mode == 'direct':
+            self._direct(flat)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _autotune(self, like: torch.Tensor, nbytes: int = 64 << 20, reps: int = 3):
+        """Collective (every rank reaches it at its first bucket).  Leaves self.mode = 'ring' or 'direct'."""
+        import time
+        w = self.world
+        n = max(8 * w, (nbytes // like.element_size()) // (8 * w) * (8 * w))
+        g = torch.Generator(device='cpu').manual_seed(1234 + dist.get_rank(self.group))
+        src = (torch.randn(n, generator=g) * 1e-3).to(like.dtype).to(like.device)
+        times, outs = {}, {}
+        for mode in ('ring', 'direct'):
+            buf = src.clone()
+            run = (lambda b: self._direct(b)) if mode == 'direct' else (lambda b: dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group))
+            try:
+                run(buf)                                   # warm-up (communicator setup, workspaces) and the value check below
+                outs[mode] = buf.clone()
+                if like.is_cuda:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        run(buf)
+                    e1.record()
+                    e1.synchronize()
+                    ms = e0.elapsed_time(e1) / reps
+                else:
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        run(buf)
+                    ms = (time.perf_counter() - t0) * 1e3 / reps
+            except RuntimeError as ex:                   # a backend without one of the collectives: the other form is used
+                ms, outs[mode] = float('inf'), None
+                self.autotune_report = {'error_' + mode: repr(ex)[:200]}
+            t = torch.tensor([ms if ms != float('inf') else 1e30], dtype=torch.float64, device=like.device if like.is_cuda else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            times[mode] = float(t.item())
+        # same sums up to the rounding of the gradient dtype (a ring rounds its partial sums): compared in the L2 norm, element-wise cancellation aside
+        agree = outs['ring'] is not None and outs['direct'] is not None and float((outs['ring'].double() - outs['direct'].double()).norm()) <= \
+            (2.0 ** -6 if like.dtype == torch.bfloat16 else 1e-5) * float(outs['direct'].double().norm()) + 1e-30
+        ok = torch.tensor([1.0 if agree else 0.0], device=like.device if like.is_cuda else 'cpu')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        self.mode = 'direct' if (bool(ok.item()) and times['direct'] < times['ring']) else 'ring'
+        bus = lambda ms: 2.0 * (w - 1) / w * n * like.element_size() / max(ms, 1e-9) / 1e6
+        self.autotune_report = {**(self.autotune_report or {}), 'chosen': self.mode, 'bytes': n * like.element_size(), 'ring_ms': times['ring'], 'direct_ms': times['direct'],
+                                'ring_busbw_GBps': bus(times['ring']), 'direct_busbw_GBps': bus(times['direct']), 'forms_agree': bool(ok.item())}
 
     def reduce_async(self, flat_slice: torch.Tensor):
         if self.world == 1 or flat_slice.numel() == 0:
@@ -59,15 +150,13 @@ class GradReducer:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                h = dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._exchange(flat_slice)               # stream-ordered on the communication stream; wait() joins the stream
                 if self.prof:
-                    h.wait()       # stream-side join only: the communication stream (not the host) waits for the collective
                     done = torch.cuda.Event(enable_timing=True)
                     done.record(self.comm_stream)
                     self.records.append((flat_slice.numel() * flat_slice.element_size(), ev, done))
-            self.handles.append(h)
         else:
-            self.handles.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._exchange(flat_slice)
 
     def wait(self):
         for h in self.handles:

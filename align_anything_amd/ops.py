@@ -820,6 +820,12 @@ def grad_sumsq_(g, out_accum, scale=1.0, ws=None):
     call('aa_grad_sumsq', g.data_ptr(), dt, g.numel(), float(scale), out_accum.data_ptr(), ws.data_ptr(), stream())
 
 
+def chunk_sum(recv, out, world):
+    """out[c] = sum over the `world` chunks of recv[world * c] (fp32 accumulation, rank order): reduce step of the direct gradient exchange."""
+    dt = 0 if recv.dtype == bf16 else 1
+    call('aa_chunk_sum', recv.data_ptr(), out.data_ptr(), dt, out.numel(), int(world), stream())
+
+
 def clip_coef(sumsq, max_norm, coef_out, norm_out=None):
     call('aa_clip_coef', sumsq.data_ptr(), float(max_norm), coef_out.data_ptr(), _p(norm_out), stream())
 

@@ -378,7 +378,10 @@ def main():
         dist.all_gather(allc, mine)
         same = all(bool(torch.equal(c, allc[0])) for c in allc)
         multi = {'backend': dist.get_backend(), 'world': world, 'rccl_max_nchannels': os.environ.get('NCCL_MAX_NCHANNELS'), 'replicas_bit_identical_after_steps': same,
-                 'optimizer_updates_checked': tr.model.global_steps, 'preflight': pre}
+                 'optimizer_updates_checked': tr.model.global_steps, 'preflight': pre,
+                 # which form of the gradient exchange ran (engine.GradReducer: RCCL's all-reduce or all-to-all + sum + all-gather over the direct links) and the
+                 # in-run measurement that chose it
+                 'reduce_mode': tr.model.reducer.mode, 'reduce_autotune': tr.model.reducer.autotune_report}
         if not same:
             print(f'[bench] rank {rank}: REPLICAS DIVERGED: {[c.tolist() for c in allc]}', file=sys.stderr, flush=True)
         if args.comm_prof:

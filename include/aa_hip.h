@@ -351,6 +351,10 @@ int aa_move_padding_left(const int64_t* in, long ldi, int64_t* out, long ldo, in
    clip coefficient is bit-identical on every data-parallel rank */
 #define AA_SUMSQ_WS 2048
 int aa_grad_sumsq(const void* g, int g_dtype, long n, float scale, float* out_accum, float* ws, void* stream);
+/* out[i] = sum_r in[r * chunk + i] (i < chunk; fp32 accumulation in rank order, one rounding to dtype 0 = bf16 / 1 = f32): the reduce step between the
+   all-to-all and the all-gather of the direct (w - 1 link) gradient exchange, engine.GradReducer mode 'direct' -- DeepSpeed's gradient reduction behind
+   engine.backward / engine.step (trainers/text_to_text/dpo.py:212-213), SURVEY.md section 8(e).  chunk % 8 == 0, 16-byte aligned buffers */
+int aa_chunk_sum(const void* in, void* out, int dtype, long chunk, int world, void* stream);
 /* coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)), norm = sqrt(sumsq).  *sumsq == -inf is the "skip this update" sentinel (the all-reduced
    capacity-overflow flag of the expert-parallel exchange): coef = norm = -1, and aa_adamw_flat returns without writing on a negative coefficient */
 int aa_clip_coef(const float* sumsq, float max_norm, float* coef_out, float* norm_out, void* stream);

@@ -102,3 +102,59 @@ def test_bf16_bucket_allreduce_world8_is_within_bf16_ulps_of_the_fp32_sum():
     _, mx, rms, norm_rel, flips, cos = res[0]
     print(f'bf16 all-reduce, world 8: max {mx:.2f} ulp, rms {rms:.2f} ulp, |norm ratio - 1| {norm_rel:.2e}, sign flips {100 * flips:.3f} %, cos {cos:.7f}')
     assert mx <= 4.0 and rms <= 1.5 and norm_rel < 1e-3 and flips < 5e-3 and cos > 0.99999, res[0]
+
+
+def _worker_direct(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from align_anything_amd.engine import GradReducer
+    ok = True
+    for dtype in (torch.float32, torch.bfloat16):
+        n = 64 * world * 37
+        g = torch.Generator().manual_seed(7 + rank)
+        mine = (torch.randn(n, generator=g) * 1e-3).to(dtype)
+        parts = [torch.zeros(n, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(parts, mine.float())
+        exact = sum(p.double() for p in parts)
+        mag = sum(p.double().abs() for p in parts)                                  # elements whose ranks cancel keep the rounding of their partial sums
+        red = GradReducer(mode='direct')
+        flat = mine.clone()
+        for lo, hi in ((64 * world * 30, n), (64 * world * 11, 64 * world * 30), (0, 64 * world * 11)):      # buckets in the engine's order
+            red.reduce_async(flat[lo:hi])
+        red.wait()
+        # one rounding of the fp32 sum (rank order): exact in fp32 up to summation order, half an ulp in bf16
+        tol = 2.0 ** -22 * world if dtype == torch.float32 else 2.0 ** -7.5
+        ok = ok and bool(((flat.double() - exact).abs() <= tol * mag + 1e-12).all())
+        allf = [torch.zeros(n, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(allf, flat.float())
+        ok = ok and all(torch.equal(a, allf[0]) for a in allf)                     # replicas hold identical bits
+        ragged = mine[:100].clone()                                                 # a slice the chunking does not fit falls back to all_reduce
+        red.reduce_async(ragged); red.wait()
+        ok = ok and bool(((ragged.double() - exact[:100]).abs() <= 2.0 ** -6 * mag[:100] + 1e-9).all())
+    auto = GradReducer(mode='auto')
+    buf = torch.full((64 * world * 4,), float(rank + 1))
+    auto.reduce_async(buf); auto.wait()
+    rep = auto.autotune_report
+    ok = ok and auto.mode in ('ring', 'direct') and rep['chosen'] == auto.mode and rep['forms_agree'] and bool((buf == world * (world + 1) / 2).all())
+    modes = [None] * world
+    dist.all_gather_object(modes, auto.mode)
+    ok = ok and len(set(modes)) == 1                                               # every rank took the same decision
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_direct_gradient_exchange_equals_the_sum_and_keeps_replicas_identical(world):
+    """engine.GradReducer mode 'direct' (all-to-all + rank-ordered fp32 sum + all-gather over the point-to-point links) and the
+    in-run choice between it and RCCL's all-reduce ('auto'): every bucket equals the exact sum to one rounding, all ranks hold the same bits, a
+    ragged slice falls back to all_reduce, and all ranks choose the same form."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33100 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_worker_direct, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(r, True) for r in range(world)]
