@@ -61,3 +61,21 @@ def test_skip_sentinel_leaves_weights_and_moments_untouched(thin):
     sumsq.fill_(float('inf'))
     ops.clip_coef(sumsq, 1.0, coef, nrm)
     assert coef.item() == 0.0 and nrm.item() == float('inf')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('world', [2, 8])
+def test_chunk_sum_is_the_rank_ordered_fp32_sum_rounded_once(dtype, world):
+    """aa_chunk_sum (reduce step of the direct gradient exchange, engine.GradReducer): out = sum_r in[r] accumulated in fp32 in rank order and rounded
+    once to the gradient dtype -- bit-exact against the same sum in torch."""
+    from align_anything_amd import ops
+    c = 8 * 12345
+    g = torch.Generator().manual_seed(3)
+    recv = (torch.randn(world * c, generator=g) * 1e-3).to(dtype).to(dev())
+    out = torch.empty(c, dtype=dtype, device=dev())
+    ops.chunk_sum(recv, out, world)
+    acc = torch.zeros(c, dtype=torch.float32, device=dev())
+    for r in range(world):
+        acc = acc + recv[r * c:(r + 1) * c].float()
+    torch.cuda.synchronize()
+    assert torch.equal(out, acc.to(dtype))

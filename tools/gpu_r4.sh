@@ -58,6 +58,12 @@ PY
         AA_ATTN128=$v timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r04_bench_attn$v.json 2> gpurun_out/r04_bench_attn$v.err
         python -c "import json; d=json.load(open('gpurun_out/r04_bench_attn$v.json')); print('AA_ATTN128=$v rep $rep', round(d['ms_per_step'],2), round(d['value'],4))" || tail -3 gpurun_out/r04_bench_attn$v.err
       done; done ;;
+    secondary)       # the secondary configs at 2 and 4 pairs per step + the MoE step
+      for b in 2 4; do
+        timeout 400 python tools/bench_qwen2vl.py --pairs $b --steps 3 --warmup 1 > gpurun_out/r04_bench_qwen2vl_b$b.json 2> gpurun_out/r04_bench_qwen2vl_b$b.err; cut -c1-400 gpurun_out/r04_bench_qwen2vl_b$b.json; tail -2 gpurun_out/r04_bench_qwen2vl_b$b.err
+        timeout 400 python tools/bench_qwen2audio.py --pairs $b --steps 3 --warmup 1 > gpurun_out/r04_bench_qwen2audio_b$b.json 2> gpurun_out/r04_bench_qwen2audio_b$b.err; cut -c1-400 gpurun_out/r04_bench_qwen2audio_b$b.json; tail -2 gpurun_out/r04_bench_qwen2audio_b$b.err
+      done
+      timeout 400 python tools/bench_qwen3moe.py --steps 4 --warmup 2 > gpurun_out/r04_bench_qwen3moe_final.json 2> gpurun_out/r04_bench_qwen3moe_final.err; cut -c1-600 gpurun_out/r04_bench_qwen3moe_final.json ;;
     prof)
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r04_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_prof -o p -- python $R/bench.py --steps 3 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > $R/gpurun_out/r04_bench_under_rocprof.json 2> $R/gpurun_out/r04_prof.err )
       f=$(find gpurun_out/r04_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r04_dpo7b_kernel_stats.csv && head -25 "$f" | cut -c1-220
