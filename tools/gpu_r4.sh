@@ -64,6 +64,10 @@ PY
         timeout 400 python tools/bench_qwen2audio.py --pairs $b --steps 3 --warmup 1 > gpurun_out/r04_bench_qwen2audio_b$b.json 2> gpurun_out/r04_bench_qwen2audio_b$b.err; cut -c1-400 gpurun_out/r04_bench_qwen2audio_b$b.json; tail -2 gpurun_out/r04_bench_qwen2audio_b$b.err
       done
       timeout 400 python tools/bench_qwen3moe.py --steps 4 --warmup 2 > gpurun_out/r04_bench_qwen3moe_final.json 2> gpurun_out/r04_bench_qwen3moe_final.err; cut -c1-600 gpurun_out/r04_bench_qwen3moe_final.json ;;
+    prof_old_fwd)    # the same profile with the 16x16x32 forward (AA_ATTN128=0): in-step kernel averages of both forwards on one box
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r04_prof0 && AA_ATTN128=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_prof0 -o p -- python $R/bench.py --steps 3 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > $R/gpurun_out/r04_bench_under_rocprof_attn0.json 2> $R/gpurun_out/r04_prof0.err )
+      f=$(find gpurun_out/r04_prof0 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r04_dpo7b_kernel_stats_attn0.csv && grep -i "attn" "$f" | cut -c1-160
+      find gpurun_out/r04_prof0 -name "*kernel_trace.csv" -delete ;;
     prof)
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r04_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_prof -o p -- python $R/bench.py --steps 3 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > $R/gpurun_out/r04_bench_under_rocprof.json 2> $R/gpurun_out/r04_prof.err )
       f=$(find gpurun_out/r04_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r04_dpo7b_kernel_stats.csv && head -25 "$f" | cut -c1-220
