@@ -68,6 +68,16 @@ PY
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r04_prof0 && AA_ATTN128=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_prof0 -o p -- python $R/bench.py --steps 3 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > $R/gpurun_out/r04_bench_under_rocprof_attn0.json 2> $R/gpurun_out/r04_prof0.err )
       f=$(find gpurun_out/r04_prof0 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r04_dpo7b_kernel_stats_attn0.csv && grep -i "attn" "$f" | cut -c1-160
       find gpurun_out/r04_prof0 -name "*kernel_trace.csv" -delete ;;
+    fwd_xl)          # in-step A/B of the head_dim-128 forward's block order (kv heads fastest vs XCD-local, lab library libaa_hip_xl1.so): step time + kernel average under rocprofv3
+      for rep in 1 2; do for lib in libaa_hip.so libaa_hip_xl1.so; do
+        AA_HIP_LIB=$R/align_anything_amd/$lib timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r04_bench_$lib.json 2> gpurun_out/r04_bench_$lib.err
+        python -c "import json; d=json.load(open('gpurun_out/r04_bench_$lib.json')); print('$lib rep $rep', round(d['ms_per_step'],2), round(d['value'],4))" || tail -3 gpurun_out/r04_bench_$lib.err
+      done; done
+      for lib in libaa_hip.so libaa_hip_xl1.so; do
+        ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r04_prof_$lib && AA_HIP_LIB=$R/align_anything_amd/$lib timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_prof_$lib -o p -- python $R/bench.py --steps 3 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > /dev/null 2> $R/gpurun_out/r04_prof_$lib.err )
+        f=$(find gpurun_out/r04_prof_$lib -name "*kernel_stats.csv" | head -1); echo "--- $lib"; [ -n "$f" ] && grep -i "attn128" "$f" | cut -c1-140
+        find gpurun_out/r04_prof_$lib -name "*kernel_trace.csv" -delete
+      done ;;
     prof)
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r04_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_prof -o p -- python $R/bench.py --steps 3 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > $R/gpurun_out/r04_bench_under_rocprof.json 2> $R/gpurun_out/r04_prof.err )
       f=$(find gpurun_out/r04_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r04_dpo7b_kernel_stats.csv && head -25 "$f" | cut -c1-220
