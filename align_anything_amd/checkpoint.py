@@ -226,5 +226,12 @@ def load_pretrained(path, device, *, trainable=True, head='lm', dtype=torch.bflo
     bad = [m for m in missing if not m.startswith('score_head')]
     if bad:
         raise RuntimeError(f'{path}: checkpoint lacks {len(bad)} tensors of the native {cfg["kind"]} model, e.g. {bad[:4]}')
+    for name in missing:          # a fresh score head: nn.Linear's default initialisation, as AutoModelForScore gives it (models/reward_model.py)
+        w = model.store.view(name)
+        bound = 1.0 / max(1, w.shape[-1]) ** 0.5
+        w.copy_(((torch.rand(tuple(w.shape)) * 2.0 - 1.0) * bound).to(w.dtype))
+        for g in model.store.master:
+            if model.store.master[g] is not model.store.flat[g]:
+                model.store.master[g].copy_(model.store.flat[g])
     sd.close()
     return model, tokenizer, processor, hf_config

@@ -259,25 +259,30 @@ def resolve_pretrained(cfgs, device, *, trainable, head='lm', dtype=None, path_k
                            build_kwargs=build_kwargs, with_tokenizer=with_tokenizer)
 
 
-def get_dataloaders(trainer, train_dtype_name: str, eval_dtype_name: str | None = None, modality: str | None = None):
-    """`SupervisedTrainerBase.get_dataloaders` (base/supervised_trainer.py:79-232) for the native trainers' `init_datasets()`.
+def get_dataloaders(trainer, train_dtype_name: str, eval_dtype_name: str | None = None, modality: str | None = None, ptx_dtype_name: str | None = None,
+                    rl: bool = False):
+    """`SupervisedTrainerBase.get_dataloaders` (base/supervised_trainer.py:79-232) and, with rl=True, `RLTrainerBase.get_dataloaders`
+    (base/rl_trainer.py:78-172) for the native trainers' `init_datasets()`.
 
     The dataset / template plugin surface stays the reference's own (`@register_template` formatters, the Dataset
     constructor signature, `get_collator()`): the classes are imported from the installed `align_anything` package and called exactly as the
     reference does -- ChatTemplate(formatter, template), Dataset(path, template, tokenizer, processor, name, size, split, data_files,
-    optional_args), DataLoader(collate_fn=dataset.get_collator(), sampler=DistributedSampler(shuffle=True), batch_size=per_device_*) --
-    and the loader is wrapped in the device prefetcher (data.DevicePrefetcher: next batch host -> HBM on a side stream, window plan prebuilt).
-    Single-process runs use a DistributedSampler of one replica (the order a world-1 reference run sees).  Returns (train, eval) loaders;
-    None where `data_cfgs.{train,eval}_datasets` is unset."""
+    optional_args), DataLoader(collate_fn=dataset.get_collator(), sampler=DistributedSampler(shuffle=True), batch_size=...) -- and the loader is
+    wrapped in the device prefetcher (data.DevicePrefetcher: next batch host -> HBM on a side stream, window plan prebuilt).  Batch sizes as in the
+    reference: supervised train / eval = per_device_train / eval_batch_size; RL prompts = per_device_prompt_batch_size, RL eval and PTX =
+    per_device_train_batch_size.  `data_cfgs.*_datasets` as a LIST (several datasets, one template each) becomes a ConcatDataset with the first
+    dataset's collator (supervised_trainer.py:110-160).  Single-process runs use a DistributedSampler of one replica (the order a world-1
+    reference run sees).  Returns (train, eval) loaders, or (train, eval, ptx) with ptx_dtype_name; None where data_cfgs names no dataset."""
     import importlib
     import torch.distributed as dist
-    from torch.utils.data import DataLoader
+    from torch.utils.data import ConcatDataset, DataLoader
     from torch.utils.data.distributed import DistributedSampler
     from ..data import DevicePrefetcher
     cfgs = trainer.cfgs
     d = lambda k, default=None: cfg_get(cfgs, 'data_cfgs.' + k, default)
-    if not d('train_datasets') and not d('eval_datasets'):
-        return None, None
+    want = ('train', 'eval') + (('ptx',) if ptx_dtype_name else ())
+    if not any(d(p + '_datasets') for p in want):
+        return (None,) * len(want)
     if modality is None:
         modality = 'text_image_to_text' if getattr(trainer, 'processor', None) is not None else 'text_to_text'
     try:
@@ -286,26 +291,36 @@ def get_dataloaders(trainer, train_dtype_name: str, eval_dtype_name: str | None 
     except ImportError as e:
         raise RuntimeError('init_datasets(): data_cfgs names datasets, which are built by the reference\'s own dataset / template plugins '
                            f'(align_anything.datasets.{modality}, align_anything.configs.template) -- that package is not importable here ({e}); '
-                           'install it, or hand the trainer a `train_dataloader=` of collated batches') from e
+                           'install it, or hand the trainer dataloaders of collated batches') from e
     tokenizer, processor = getattr(trainer, 'tokenizer', None), getattr(trainer, 'processor', None)
     formatter = processor if processor else tokenizer
     custom = getattr(getattr(trainer, 'hf_model_hooks', None), 'apply_chat_template', None)
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
+    pick = lambda v, i: (v[i] if isinstance(v, (list, tuple)) and v else (None if isinstance(v, (list, tuple)) else v))
 
     def build(prefix, dtype_name, batch_key):
         paths = d(prefix + '_datasets')
         if not paths:
             return None
-        if not isinstance(paths, str):
-            raise NotImplementedError('data_cfgs.*_datasets as a list (ConcatDataset of several templates, supervised_trainer.py:110-160) is not wired natively yet')
-        template = ChatTemplate(formatter, d(prefix + '_template'), custom)
-        setattr(trainer, prefix + '_template', template)
-        ds = getattr(ds_mod, dtype_name)(path=paths, template=template, tokenizer=tokenizer, processor=processor, name=d(prefix + '_name'),
-                                         size=d(prefix + '_size'), split=d(prefix + '_split'), data_files=d(prefix + '_data_files'),
-                                         optional_args=d(prefix + '_optional_args', []))
-        loader = DataLoader(ds, collate_fn=ds.get_collator(), sampler=DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True),
+        cls = getattr(ds_mod, dtype_name)
+        many = not isinstance(paths, str)
+        templates, sets = [], []
+        for i, path in enumerate(list(paths) if many else [paths]):
+            tname = pick(d(prefix + '_template'), i) if many else d(prefix + '_template')
+            template = ChatTemplate(formatter, tname, None if many else custom)
+            templates.append(template)
+            f = (lambda k: pick(d(prefix + '_' + k), i)) if many else (lambda k: d(prefix + '_' + k))
+            sets.append(cls(path=path, template=template, tokenizer=tokenizer, processor=processor, name=f('name'), size=f('size'), split=f('split'),
+                            data_files=f('data_files'), optional_args=(f('optional_args') or []) if many else d(prefix + '_optional_args', [])))
+        setattr(trainer, prefix + '_template', templates if many else templates[0])
+        ds = ConcatDataset(sets) if many else sets[0]
+        loader = DataLoader(ds, collate_fn=sets[0].get_collator(), sampler=DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True),
                             batch_size=int(cfg_get(cfgs, 'train_cfgs.' + batch_key, 1)))
         return DevicePrefetcher(loader, trainer.device, getattr(trainer, 'pad_token_id', None))
 
-    return build('train', train_dtype_name, 'per_device_train_batch_size'), build('eval', eval_dtype_name or train_dtype_name, 'per_device_eval_batch_size')
+    out = [build('train', train_dtype_name, 'per_device_prompt_batch_size' if rl else 'per_device_train_batch_size'),
+           build('eval', eval_dtype_name or train_dtype_name, 'per_device_train_batch_size' if rl else 'per_device_eval_batch_size')]
+    if ptx_dtype_name:
+        out.append(build('ptx', ptx_dtype_name, 'per_device_train_batch_size'))
+    return tuple(out)

@@ -27,6 +27,7 @@ from .common import build_window, cfg_get, compute_dtype, expert_parallel_kwargs
 class DPOTrainer:
     uses_reference = True     # SimPO / ORPO (trainers/pref.py) never evaluate the reference model
     skip_identical_pairs = False   # set by __init__ for the audio trainer, whose reference `loss` skips identical pairs
+    dataset_types = ('PreferenceDataset', 'PreferenceDataset')      # (train, eval) classes of align_anything.datasets.<modality> (dpo.py:109-113)
 
     def __init__(self, cfgs, ds_cfgs=None, *, model_cfg: dict | None = None, policy_state=None, reference_state=None,
                  train_dataloader=None, tokenizer=None, device='cuda:0', share_vision_tower=True,
@@ -117,7 +118,7 @@ class DPOTrainer:
         if self.train_dataloader is not None:
             return
         from .common import get_dataloaders
-        self.train_dataloader, self.eval_dataloader = get_dataloaders(self, 'PreferenceDataset', 'PreferenceDataset')
+        self.train_dataloader, self.eval_dataloader = get_dataloaders(self, *self.dataset_types)
 
     def init_engines(self) -> None:
         """base/supervised_trainer.py:234-271 + dpo.py:114-120, with the native engine in DeepSpeed's place."""

@@ -21,10 +21,23 @@ class GRPOTrainer:
     The reference re-tokenises completions for the reward model (`batch_retokenize`); here actor and reward model
     share one tokenizer, so the masked completion ids are scored directly (`reward_fn` overrides that)."""
 
-    def __init__(self, cfgs, ds_cfgs=None, *, model_cfg, reward_model_cfg=None, actor_state=None, reference_state=None,
+    def __init__(self, cfgs, ds_cfgs=None, *, model_cfg=None, reward_model_cfg=None, actor_state=None, reference_state=None,
                  reward_state=None, reward_fn=None, device='cuda:0'):
         t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
         self.cfgs, self.device = cfgs, torch.device(device)
+        self.tokenizer = self.processor = self.hf_config = None
+        self.prompt_only_dataloader = self.eval_dataloader = None
+        from_paths = model_cfg is None
+        if from_paths:
+            # `GRPOTrainer(cfgs, ds_cfgs)` alone, as the reference's constructor (text_to_text/grpo.py:55-75): actor / reference from
+            # model_cfgs.actor_model_name_or_path, reward model from reward_model_name_or_path (grpo.py:84-133), prompts from data_cfgs (:135-139)
+            from transformers import AutoConfig
+            from .. import configs as _configs
+            ap_, rp_ = cfg_get(cfgs, 'model_cfgs.actor_model_name_or_path', None), cfg_get(cfgs, 'model_cfgs.reward_model_name_or_path', None)
+            if not ap_ or (reward_fn is None and not rp_):
+                raise ValueError('GRPOTrainer: model_cfg, or model_cfgs.actor_model_name_or_path (+ reward_model_name_or_path or a reward_fn), is required')
+            model_cfg = _configs.from_hf_config(AutoConfig.from_pretrained(ap_, trust_remote_code=True))
+            reward_model_cfg = _configs.from_hf_config(AutoConfig.from_pretrained(rp_, trust_remote_code=True)) if rp_ else None
         self.beta = float(t('beta', 0.04))                       # grpo.py:67 default
         self.num_generations = int(t('num_generations', 4))      # grpo.py:66
         self.pad_token_id = int(cfg_get(cfgs, 'model_cfgs.pad_token_id', 0))
@@ -35,12 +48,22 @@ class GRPOTrainer:
         # the rollout then exchanges tokens per decode position with every rank stepping in lockstep (generation.py)
         epk = expert_parallel_kwargs(cfgs, model_cfg)
         rpk = epk if (reward_model_cfg or model_cfg).get('kind') == 'qwen3moe' else {}
-        actor = build_model(model_cfg, device, trainable=True, dtype=dt, **epk)
-        ref = build_model(model_cfg, device, trainable=False, dtype=dt, **epk)
-        if actor_state is not None:
-            actor.load_state_dict(actor_state)
-        if reference_state is not None or actor_state is not None:
-            ref.load_state_dict(reference_state if reference_state is not None else actor_state)
+        if from_paths:
+            from ..checkpoint import load_pretrained
+            mml = int(cfg_get(cfgs, 'model_cfgs.model_max_length', 512))
+            actor, self.tokenizer, self.processor, self.hf_config = load_pretrained(ap_, device, trainable=True, dtype=dt, model_max_length=mml, padding_side='left',
+                                                                                    build_kwargs=epk)
+            ref = load_pretrained(ap_, device, trainable=False, dtype=dt, model_max_length=mml, padding_side='left', build_kwargs=epk)[0]
+            if cfg_get(cfgs, 'model_cfgs.pad_token_id', None) is None and self.tokenizer is not None:
+                self.pad_token_id = int(self.tokenizer.pad_token_id)
+                self.eos_token_id = int(self.tokenizer.eos_token_id) if self.tokenizer.eos_token_id is not None else self.eos_token_id
+        else:
+            actor = build_model(model_cfg, device, trainable=True, dtype=dt, **epk)
+            ref = build_model(model_cfg, device, trainable=False, dtype=dt, **epk)
+            if actor_state is not None:
+                actor.load_state_dict(actor_state)
+            if reference_state is not None or actor_state is not None:
+                ref.load_state_dict(reference_state if reference_state is not None else actor_state)
         # grpo.py:153-181: the schedule length comes from the prompt dataloader that train() receives; until then it is unknown
         # (an explicit train_cfgs.total_training_steps wins) and a cosine engine refuses to step rather than decay to 0
         self.gas = int(cfg_get(ds_cfgs, 'gradient_accumulation_steps', t('gradient_accumulation_steps', 1)))
@@ -54,10 +77,20 @@ class GRPOTrainer:
         self.actor_reference_model = NativeEngine(ref, trainable=False)
         self.reward_model = None
         if reward_fn is None:
-            reward = build_model(reward_model_cfg or model_cfg, device, trainable=False, head='score', dtype=dt, **rpk)
-            if reward_state is not None:
-                reward.load_state_dict(reward_state)
+            if from_paths:
+                reward = load_pretrained(rp_, device, trainable=False, head='score', dtype=dt, model_max_length=mml, padding_side='right', build_kwargs=rpk)[0]
+            else:
+                reward = build_model(reward_model_cfg or model_cfg, device, trainable=False, head='score', dtype=dt, **rpk)
+                if reward_state is not None:
+                    reward.load_state_dict(reward_state)
             self.reward_model = NativeEngine(reward, trainable=False)
+        if from_paths:
+            self.init_datasets()
+
+    def init_datasets(self) -> None:
+        """grpo.py:135-139 `get_dataloaders(PromptOnlyDataset, PromptOnlyDataset, None)` through the reference's own dataset / template plugins."""
+        from .common import get_dataloaders
+        self.prompt_only_dataloader, self.eval_dataloader = get_dataloaders(self, 'PromptOnlyDataset', 'PromptOnlyDataset', rl=True)
 
     # ------------------------------------------------------------------ grpo.py:212-227
     def generate_completions(self, prompt_batch, generator=None):
@@ -126,11 +159,15 @@ class GRPOTrainer:
         s = get_all_reduce_mean(torch.stack([loss.reshape(()), rewards.mean()])).tolist()
         return {'train/loss': s[0], 'train/reward': s[1]}
 
-    def train(self, prompt_only_dataloader, generator=None) -> list:
+    def train(self, prompt_only_dataloader=None, generator=None) -> list:
         """grpo.py:330-386 without its logging: one `train_step` (rollout of `num_generations` completions per prompt, rewards, update) per
         prompt batch and epoch; resumes at `self.global_step` (:347-357), saves `slice_<global_step>` every epochs * len(dataloader) //
         logger_cfgs.save_total_limit steps (:368-375) and -- when `logger_cfgs.output_dir` is configured -- the final model (:386; the reference
         always writes it, the native loop does not create ./output on its own).  Returns the per-step metrics."""
+        if prompt_only_dataloader is None:      # the loader init_datasets() built from data_cfgs (the cfgs-only constructor)
+            prompt_only_dataloader = getattr(self, 'prompt_only_dataloader', None)
+            if prompt_only_dataloader is None:
+                raise ValueError('GRPOTrainer.train needs a prompt dataloader (argument, or data_cfgs.train_datasets with the cfgs-only constructor)')
         history = []
         self.global_step = getattr(self, 'global_step', 0)
         t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)

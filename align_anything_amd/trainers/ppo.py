@@ -67,7 +67,7 @@ class PPOTrainer(PPOMath):
     `reward_model_step` (:224-242) and `rl_step` (:309-398) on four DeepSpeedEngine-shaped native engines
     (base/rl_trainer.py:217-272).  The rollout batch (sequences from `generate`) is an input."""
 
-    def __init__(self, cfgs, ds_cfgs=None, *, model_cfg, reward_model_cfg=None, actor_state=None, reward_state=None,
+    def __init__(self, cfgs, ds_cfgs=None, *, model_cfg=None, reward_model_cfg=None, actor_state=None, reward_state=None,
                  critic_state=None, device='cuda:0', reward_fn=None, use_ptx=None):
         """reward_fn(input_ids, attention_mask) -> [N] scores replaces the learned reward model: the rule / remote reward of
         trainers/text_to_text/ppo_remote_rm.py:321-347 (decode prompts + responses on the host, score them over HTTP with
@@ -78,15 +78,47 @@ class PPOTrainer(PPOMath):
                          clip_range_ratio=float(t('clip_range_ratio', 0.2)), clip_range_value=float(t('clip_range_value', 5.0)))
         self.cfgs, self.device = cfgs, torch.device(device)
         self.ptx_coeff = float(t('ptx_coeff', 16.0))        # configs/train/text_to_text/ppo.yaml:71
-        rcfg = reward_model_cfg or model_cfg
         dt = compute_dtype(t('compute_dtype', 'bf16'))   # fp32 = parity mode for the update phase (rollouts need bf16)
+        self.tokenizer = self.processor = self.hf_config = None
+        self.prompt_only_dataloader = self.eval_dataloader = self.ptx_dataloader = None
+        from_paths = model_cfg is None
+        if from_paths:
+            # `PPOTrainer(cfgs, ds_cfgs)` alone, as the reference's constructor (text_to_text/ppo.py:62-91): geometry of the four models from the
+            # config.json under model_cfgs.{actor,reward,reward_critic}_model_name_or_path (ppo.py:93-147); the weights are streamed in below
+            from transformers import AutoConfig
+            from .. import configs as _configs
+            m_ = lambda k: cfg_get(cfgs, 'model_cfgs.' + k, None)
+            if not m_('actor_model_name_or_path'):
+                raise ValueError('PPOTrainer: model_cfg or model_cfgs.actor_model_name_or_path is required')
+            self._paths = {'actor': m_('actor_model_name_or_path'), 'reward': m_('reward_model_name_or_path'),
+                           'critic': m_('reward_critic_model_name_or_path') or m_('reward_model_name_or_path')}
+            if reward_fn is None and not self._paths['reward']:
+                raise ValueError('PPOTrainer: model_cfgs.reward_model_name_or_path (or a reward_fn) is required')
+            model_cfg = _configs.from_hf_config(AutoConfig.from_pretrained(self._paths['actor'], trust_remote_code=True))
+            rp = self._paths['critic'] or self._paths['actor']
+            reward_model_cfg = _configs.from_hf_config(AutoConfig.from_pretrained(rp, trust_remote_code=True))
+        rcfg = reward_model_cfg or model_cfg
         epk = expert_parallel_kwargs(cfgs, model_cfg)            # train_cfgs.expert_parallel on a Qwen3-MoE actor (see trainers/grpo.py)
-        actor = build_model(model_cfg, device, trainable=True, dtype=dt, **epk)
-        ref = build_model(model_cfg, device, trainable=False, dtype=dt, **epk)
         self.reward_fn = reward_fn
         rpk = epk if rcfg.get('kind') == 'qwen3moe' else {}
-        reward = build_model(rcfg, device, trainable=False, head='score', dtype=dt, **rpk) if reward_fn is None else None
-        critic = build_model(rcfg, device, trainable=True, head='score', dtype=dt, **rpk)
+        if from_paths:
+            from ..checkpoint import load_pretrained
+            mml = int(cfg_get(cfgs, 'model_cfgs.model_max_length', 512))
+            actor, self.tokenizer, self.processor, self.hf_config = load_pretrained(self._paths['actor'], device, trainable=True, dtype=dt, model_max_length=mml,
+                                                                                    padding_side='left', build_kwargs=epk)
+            ref = load_pretrained(self._paths['actor'], device, trainable=False, dtype=dt, model_max_length=mml, padding_side='left', build_kwargs=epk)[0]
+            reward = None
+            if reward_fn is None:
+                reward, self.reward_tokenizer, _, _ = load_pretrained(self._paths['reward'], device, trainable=False, head='score', dtype=dt, model_max_length=mml,
+                                                                      padding_side='right', build_kwargs=rpk)
+            critic, self.reward_critic_tokenizer, _, _ = load_pretrained(self._paths['critic'] or self._paths['actor'], device, trainable=True, head='score', dtype=dt,
+                                                                         model_max_length=mml, padding_side='left', build_kwargs=rpk)
+            model_cfg, rcfg = actor.cfg, critic.cfg
+        else:
+            actor = build_model(model_cfg, device, trainable=True, dtype=dt, **epk)
+            ref = build_model(model_cfg, device, trainable=False, dtype=dt, **epk)
+            reward = build_model(rcfg, device, trainable=False, head='score', dtype=dt, **rpk) if reward_fn is None else None
+            critic = build_model(rcfg, device, trainable=True, head='score', dtype=dt, **rpk)
         if actor_state is not None:
             actor.load_state_dict(actor_state)
             ref.load_state_dict(actor_state)
@@ -114,6 +146,16 @@ class PPOTrainer(PPOMath):
                                                 lr_scheduler_type=t('critic_lr_scheduler_type', 'constant'), gradient_accumulation_steps=self.gas)
         self.actor_reference_model = NativeEngine(ref, trainable=False)
         self.reward_model = NativeEngine(reward, trainable=False) if reward is not None else None
+        if from_paths:
+            self.init_datasets()
+
+    def init_datasets(self) -> None:
+        """ppo.py:149-154 `get_dataloaders(PromptOnlyDataset, PromptOnlyDataset, SupervisedDataset)` through the reference's own dataset / template
+        plugins (common.get_dataloaders, RL batch sizes); `train()` falls back to these loaders when called without arguments."""
+        from .common import get_dataloaders
+        self.pad_token_id = cfg_get(self.cfgs, 'model_cfgs.pad_token_id', getattr(self.tokenizer, 'pad_token_id', None))
+        self.prompt_only_dataloader, self.eval_dataloader, self.ptx_dataloader = get_dataloaders(self, 'PromptOnlyDataset', 'PromptOnlyDataset',
+                                                                                                 ptx_dtype_name='SupervisedDataset', rl=True)
 
     # ------------------------------------------------------------------ rollout (ppo.py:209-222, 244-289)
     def actor_step(self, prompt_batch, generator=None, sequences=None):
@@ -218,7 +260,7 @@ class PPOTrainer(PPOMath):
     def _rows(batch, lo, hi):
         return {k: (v[lo:hi] if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
 
-    def train(self, prompt_only_dataloader, ptx_dataloader=None, generator=None):
+    def train(self, prompt_only_dataloader=None, ptx_dataloader=None, generator=None):
         """The reference's PPO loop without its logging / checkpoint plumbing: every prompt batch is rolled out in micro-batches of
         `per_device_train_batch_size` prompts (ppo.py:244-289), then `update_iters` passes of `rl_step` (+ `ptx_step` when a PTX
         dataloader is given) run over those micro-batches.  Reference quirks kept: PTX batches are cycled to the length of the prompt set
@@ -226,6 +268,11 @@ class PPOTrainer(PPOMath):
         shorter list wins).  Returns the per-step metric dicts."""
         import itertools
         t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
+        if prompt_only_dataloader is None:      # the loaders init_datasets() built from data_cfgs (the cfgs-only constructor)
+            prompt_only_dataloader = getattr(self, 'prompt_only_dataloader', None)
+            ptx_dataloader = ptx_dataloader if ptx_dataloader is not None else getattr(self, 'ptx_dataloader', None)
+            if prompt_only_dataloader is None:
+                raise ValueError('PPOTrainer.train needs a prompt dataloader (argument, or data_cfgs.train_datasets with the cfgs-only constructor)')
         epochs, update_iters = int(t('epochs', 1)), int(t('update_iters', 1))
         micro = self._rollout_micro_batch(int(t('per_device_train_batch_size', 8)))
         use_ptx = ptx_dataloader is not None

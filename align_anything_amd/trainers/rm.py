@@ -13,13 +13,32 @@ from .common import END_AT_LAST_POSITION_KINDS, cfg_get, compute_dtype, end_inde
 
 
 class RMTrainer:
-    def __init__(self, cfgs, ds_cfgs=None, *, model_cfg, state=None, device='cuda:0'):
+    def __init__(self, cfgs, ds_cfgs=None, *, model_cfg=None, state=None, device='cuda:0', train_dataloader=None):
+        """`RMTrainer(cfgs, ds_cfgs)` alone follows the reference's constructor (text_to_text/rm.py:52-72): the score model, tokenizer and
+        processor come from `model_cfgs.model_name_or_path` (rm.py:76-85: `is_reward_model=True`, right padding; a language-model checkpoint
+        without a score head starts with the native initialisation of it) and the dataloaders from `data_cfgs` (rm.py:87-91); the keyword
+        arguments inject pre-built pieces instead."""
         t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
         self.cfgs, self.device = cfgs, torch.device(device)
         self.regularization = float(t('regularization', 0.001))
-        module = build_model(model_cfg, device, trainable=True, head='score', dtype=compute_dtype(t('compute_dtype', 'bf16')))
-        if state is not None:
-            module.load_state_dict(state)
+        self.tokenizer = self.processor = self.hf_config = None
+        self.train_dataloader, self.eval_dataloader = train_dataloader, None
+        if model_cfg is None:
+            from ..checkpoint import load_pretrained
+            path = cfg_get(cfgs, 'model_cfgs.model_name_or_path', None)
+            if not path:
+                raise ValueError('RMTrainer: model_cfg or model_cfgs.model_name_or_path is required')
+            module, self.tokenizer, self.processor, self.hf_config = load_pretrained(
+                path, device, trainable=True, head='score', dtype=compute_dtype(t('compute_dtype', 'bf16')),
+                model_max_length=int(cfg_get(cfgs, 'model_cfgs.model_max_length', 512)), padding_side='right')
+            self.pad_token_id = getattr(self.tokenizer, 'pad_token_id', None)
+            if self.train_dataloader is None:
+                from .common import get_dataloaders
+                self.train_dataloader, self.eval_dataloader = get_dataloaders(self, 'PreferenceDataset', 'PreferenceDataset')
+        else:
+            module = build_model(model_cfg, device, trainable=True, head='score', dtype=compute_dtype(t('compute_dtype', 'bf16')))
+            if state is not None:
+                module.load_state_dict(state)
         # base/supervised_trainer.py:236-257: epochs x ceil(len(dataloader) / gas) updates -- known once train() has the dataloader
         self.gas = int(t('gradient_accumulation_steps', cfg_get(ds_cfgs, 'gradient_accumulation_steps', 1)))
         total = t('total_training_steps', None)

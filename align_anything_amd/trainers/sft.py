@@ -17,6 +17,7 @@ from .dpo import DPOTrainer
 
 class SupervisedTrainer(DPOTrainer):
     uses_reference = False
+    dataset_types = ('SupervisedDataset', 'SupervisedDataset')          # sft.py:85-89
 
     def loss(self, sft_batch) -> dict[str, torch.Tensor]:
         w = sft_batch.get('_window') or build_label_window(sft_batch['labels'], device=sft_batch['input_ids'].device)
