@@ -43,10 +43,16 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const elem_t* __restri
 // at once and every group walks TWO rows per iteration, so all 64 lanes load 16 bytes and a wave keeps 2 KB in flight (round 3's one-wave-per-row form had 16
 // of 64 lanes active and one 256-byte load in flight per wave at head_dim 128: 391 us for 270 MB = latency-bound at 0.7 TB/s).  The row sum
 // is the same butterfly over the row's lanes as before (the idle lanes contributed zeros), so results are bit-identical.
-template <int LPR>
+// ROPE (h == 8 LPR, Qwen3's per-head q / k norm followed by the rotary embedding, hf:models/qwen3_moe/modeling_qwen3_moe.py q_norm -> apply_rotary_pos_emb):
+// the normalised row is rotated before it is stored -- element d pairs with d + h / 2, which lives LPR / 2 lanes away in the same lane group, so the partner
+// arrives by one cross-lane read per element; rounding points exactly those of rmsnorm followed by aa_rope_inplace (bit-identical to the pair), one launch
+// and one pass over q / k instead of two.  Row r belongs to token r / heads; pos[token] indexes the [., h / 2] tables.
+template <int LPR, bool ROPE = false>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_small_kernel(const elem_t* __restrict__ x, const elem_t* __restrict__ w,
                                                                 elem_t* __restrict__ y, float* __restrict__ rstd_out, long rows,
-                                                                int h, float eps) {
+                                                                int h, float eps, const int* __restrict__ pos = nullptr,
+                                                                const elem_t* __restrict__ cos_t = nullptr, const elem_t* __restrict__ sin_t = nullptr,
+                                                                int heads = 1, long ldx = 0) {
     constexpr int GPB = 256 / LPR;
     const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     const bool act = sub < (h >> 3);
@@ -59,7 +65,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_small_kernel(const elem_t* __
         for (int u = 0; u < 2; ++u) {
             const long row = row0 + u * GPB;
             if (act && row < rows) {
-                v[u] = *reinterpret_cast<const ev8*>(x + row * h + sub * 8);
+                // ROPE form: x may be a column slice of a wider buffer (the fused q | k | v projection): token row / heads starts at x + token * ldx
+                const elem_t* xr = ROPE ? x + (row / heads) * ldx + (row % heads) * h : x + row * h;
+                v[u] = *reinterpret_cast<const ev8*>(xr + sub * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = e2f(v[u][j]); ss[u] += f * f; }
             }
@@ -76,6 +84,19 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_small_kernel(const elem_t* __
                 ev8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = f2e(e2f(wv[j]) * ernd(e2f(v[u][j]) * rstd));
+                if constexpr (ROPE) {       // every lane of the group is active here (h == 8 LPR) and both rows of a pair of groups exist or not together
+                    const int half_l = LPR / 2, cs = (sub % half_l) * 8;
+                    const long tab = (long)pos[row / heads] * (h >> 1) + cs;
+                    const ev8 c = *reinterpret_cast<const ev8*>(cos_t + tab), sn = *reinterpret_cast<const ev8*>(sin_t + tab);
+                    const bool lower = sub < half_l;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float mine = e2f(o[j]), other = __shfl_xor(mine, half_l, 64);
+                        const float cc = e2f(c[j]), ss = e2f(sn[j]);
+                        // lower half: o1 = rnd(a c) + rnd(-b s) with a = mine, b = other; upper half: o2 = rnd(b c) + rnd(a s) with b = mine, a = other
+                        o[j] = lower ? f2e(ernd(mine * cc) + ernd(-other * ss)) : f2e(ernd(mine * cc) + ernd(other * ss));
+                    }
+                }
                 *reinterpret_cast<ev8*>(y + row * h + sub * 8) = o;
             }
         }
@@ -86,7 +107,9 @@ template <int LPR>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_small_kernel(const elem_t* __restrict__ dy, const elem_t* __restrict__ x,
                                                                 const elem_t* __restrict__ w, const float* __restrict__ rstd_in,
                                                                 elem_t* __restrict__ dx, float* __restrict__ dw_part, long rows, int h,
-                                                                int add_to_dx) {
+                                                                int add_to_dx, int heads = 0, long ldx = 0, long lddx = 0) {
+    // heads > 0: x and dx are column slices of wider buffers (the fused q | k | v projection output and its gradient): row r = (token r / heads, head
+    // r % heads) lives at token * ld + head * h; dy stays dense
     constexpr int GPB = 256 / LPR;
     __shared__ float part[GPB][LPR * 8];
     const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
@@ -102,9 +125,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_small_kernel(const elem_t* __
             const long row = row0 + u * GPB;
             if (act && row < rows) {
                 rs[u] = rstd_in[row];
-                xv[u] = *reinterpret_cast<const ev8*>(x + row * h + sub * 8);
+                const long xo = heads > 0 ? (row / heads) * ldx + (row % heads) * h : row * h;
+                const long dxo = heads > 0 ? (row / heads) * lddx + (row % heads) * h : row * h;
+                xv[u] = *reinterpret_cast<const ev8*>(x + xo + sub * 8);
                 gv[u] = *reinterpret_cast<const ev8*>(dy + row * h + sub * 8);
-                if (add_to_dx) ov[u] = *reinterpret_cast<const ev8*>(dx + row * h + sub * 8);
+                if (add_to_dx) ov[u] = *reinterpret_cast<const ev8*>(dx + dxo + sub * 8);
             }
         }
 #pragma unroll
@@ -134,7 +159,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_small_kernel(const elem_t* __
                     if (add_to_dx) d += e2f(ov[u][j]);
                     o[j] = f2e(d);
                 }
-                *reinterpret_cast<ev8*>(dx + row * h + sub * 8) = o;
+                const long dxo = heads > 0 ? (row / heads) * lddx + (row % heads) * h : row * h;
+                *reinterpret_cast<ev8*>(dx + dxo + sub * 8) = o;
             }
         }
     }
@@ -264,6 +290,54 @@ extern "C" int AA_FN(aa_rmsnorm_fwd)(const void* x, const void* w, void* y, floa
     hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const elem_t*)x, (const elem_t*)w, (elem_t*)y, rstd, rows, h, eps);
     AA_CHECK_LAUNCH("aa_rmsnorm_fwd");
+    return AA_OK;
+}
+
+// y = rope(rmsnorm(x)) on [rows = tokens x heads, hd] rows (Qwen3 q_norm / k_norm + apply_rotary_pos_emb in one pass); hd in {64, 128, 256, 512}
+// ldx: elements between the first head of consecutive tokens in x (heads * hd when x is dense; larger when x is a column slice of the fused q | k | v
+// projection output); y is dense [rows, hd]
+extern "C" int AA_FN(aa_rmsnorm_rope_fwd)(const void* x, long ldx, const void* w, void* y, float* rstd, long rows, int hd, float eps, const int* pos,
+                                          const void* cos_t, const void* sin_t, int heads, void* stream) {
+    AA_REQUIRE(hd == 64 || hd == 128 || hd == 256 || hd == 512, "aa_rmsnorm_rope_fwd: head_dim %d (64, 128, 256 or 512)", hd);
+    AA_REQUIRE(heads > 0 && rows % heads == 0 && pos && cos_t && sin_t, "aa_rmsnorm_rope_fwd: rows %ld must be tokens x heads (%d), tables required", rows, heads);
+    AA_REQUIRE(ldx >= (long)heads * hd && (ldx & 7) == 0, "aa_rmsnorm_rope_fwd: ldx %ld must be >= heads * head_dim and a multiple of 8", ldx);
+    if (rows == 0) return AA_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_RMSR(LPR)                                                                                                                       \
+    do {                                                                                                                                       \
+        const long nb = (rows + 2 * (256 / LPR) - 1) / (2 * (256 / LPR));                                                                      \
+        hipLaunchKernelGGL((rmsnorm_fwd_small_kernel<LPR, true>), dim3((int)(nb < 16384 ? nb : 16384)), dim3(256), 0, st, (const elem_t*)x,    \
+                           (const elem_t*)w, (elem_t*)y, rstd, rows, hd, eps, pos, (const elem_t*)cos_t, (const elem_t*)sin_t, heads, ldx);    \
+    } while (0)
+    if (hd == 64) LAUNCH_RMSR(8); else if (hd == 128) LAUNCH_RMSR(16); else if (hd == 256) LAUNCH_RMSR(32); else LAUNCH_RMSR(64);
+#undef LAUNCH_RMSR
+    AA_CHECK_LAUNCH("aa_rmsnorm_rope_fwd");
+    return AA_OK;
+}
+
+// backward of the per-head norm with x and dx as column slices of the fused q | k | v buffers (see aa_rmsnorm_rope_fwd): dy dense [rows, hd]
+extern "C" int AA_FN(aa_rmsnorm_heads_bwd)(const void* dy, const void* x, long ldx, const void* w, const float* rstd, void* dx, long lddx, float* dw, float* ws,
+                                           int ws_rows, long rows, int hd, int heads, void* stream) {
+    AA_REQUIRE(hd == 64 || hd == 128 || hd == 256 || hd == 512, "aa_rmsnorm_heads_bwd: head_dim %d (64, 128, 256 or 512)", hd);
+    AA_REQUIRE(heads > 0 && rows % heads == 0 && ldx >= (long)heads * hd && lddx >= (long)heads * hd && ((ldx | lddx) & 7) == 0,
+               "aa_rmsnorm_heads_bwd: rows %ld = tokens x heads (%d); ldx %ld / lddx %ld >= heads * head_dim, multiples of 8", rows, heads, ldx, lddx);
+    AA_REQUIRE(dw == nullptr || (ws != nullptr && ws_rows > 0), "aa_rmsnorm_heads_bwd: dw needs a [ws_rows, hd] fp32 workspace");
+    if (rows == 0) return AA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = dw ? ws : nullptr;
+    int g2 = 0;
+#define LAUNCH_RMSHB(LPR)                                                                                                                 \
+    do {                                                                                                                                  \
+        const long nb = (rows + 2 * (256 / LPR) - 1) / (2 * (256 / LPR));                                                                 \
+        g2 = (int)(nb < 2048 ? nb : 2048);                                                                                                \
+        if (dw && g2 > ws_rows) g2 = ws_rows;                                                                                             \
+        hipLaunchKernelGGL(rmsnorm_bwd_small_kernel<LPR>, dim3(g2), dim3(256), 0, st, (const elem_t*)dy, (const elem_t*)x, (const elem_t*)w, rstd, \
+                           (elem_t*)dx, part, rows, hd, 0, heads, ldx, lddx);                                                             \
+    } while (0)
+    if (hd == 64) LAUNCH_RMSHB(8); else if (hd == 128) LAUNCH_RMSHB(16); else if (hd == 256) LAUNCH_RMSHB(32); else LAUNCH_RMSHB(64);
+#undef LAUNCH_RMSHB
+    if (dw) launch_reduce_rows(part, g2, hd, dw, st);
+    AA_CHECK_LAUNCH("aa_rmsnorm_heads_bwd");
     return AA_OK;
 }
 

@@ -276,7 +276,7 @@ class NativeEngine:
             return out
         for L in stack.layers:
             names = [v.wname for v in L.values() if hasattr(v, 'wname')]
-            specs = [st.specs[n] for n in names if st.specs[n]['group'] == 'mat']
+            specs = [st.specs[n] for n in names if n in st.specs and st.specs[n]['group'] == 'mat']      # aliases of a fused block (q / k / v views) are not blocks
             if specs:
                 lo = min(s['offset'] for s in specs)
                 hi = max(s['offset'] + s['numel'] for s in specs)

@@ -1359,9 +1359,11 @@ class Qwen3MoeStack:
         for i in range(cfg['num_layers']):
             p = f'{prefix}layers.{i}.'
             L = {'ln1': store.add(p + 'input_layernorm.weight', (h,), tr),
-                 'q': Linear(store, store.add(p + 'self_attn.q_proj.weight', (H * hd, h), tr)),
-                 'k': Linear(store, store.add(p + 'self_attn.k_proj.weight', (Hkv * hd, h), tr)),
-                 'v': Linear(store, store.add(p + 'self_attn.v_proj.weight', (Hkv * hd, h), tr)),
+                 # q | k | v stored as ONE block: one forward GEMM, one dX and one dW GEMM per layer on the big-tile kernel instead of three launches each on the
+                 # small-tile one (15 ms of the 150 ms 12-layer step, profiles/r04_qwen3moe_kernel_stats.csv); the HF names stay aliases of its row ranges
+                 'qkv': Linear(store, store.add_fused(p + 'self_attn.qkv_fused', [(p + 'self_attn.q_proj.weight', H * hd, h), (p + 'self_attn.k_proj.weight', Hkv * hd, h),
+                                                                                 (p + 'self_attn.v_proj.weight', Hkv * hd, h)], tr)),
+                 'q': Linear(store, p + 'self_attn.q_proj.weight'), 'k': Linear(store, p + 'self_attn.k_proj.weight'), 'v': Linear(store, p + 'self_attn.v_proj.weight'),
                  'qn': store.add(p + 'self_attn.q_norm.weight', (hd,), tr), 'kn': store.add(p + 'self_attn.k_norm.weight', (hd,), tr),
                  'o': Linear(store, store.add(p + 'self_attn.o_proj.weight', (h, H * hd), tr)),
                  'ln2': store.add(p + 'post_attention_layernorm.weight', (h,), tr),
@@ -1504,12 +1506,13 @@ class Qwen3MoeStack:
                 return self.forward(x, N, T, start, pos, save, kv_sink)
         for li, L in enumerate(self.layers):
             n1, rstd1 = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
-            q, kk, v = L['q'].fwd(n1), L['k'].fwd(n1), L['v'].fwd(n1)
-            qn, rq = ops.rmsnorm_fwd(q.view(Mp * H, hd), P[L['qn']], eps)
-            kn, rk = ops.rmsnorm_fwd(kk.view(Mp * Hkv, hd), P[L['kn']], eps)
+            # one projection GEMM; q / k / v are column slices of its output.  The per-head norm + rotary embedding read their slice in place and
+            # write dense rotated q / k (aa_rmsnorm_rope_fwd: one pass each, same bits as aa_rmsnorm_fwd + aa_rope_inplace); attention reads v in place
+            qkv = L['qkv'].fwd(n1)
+            q, kk, v = qkv[:, :H * hd], qkv[:, H * hd:(H + Hkv) * hd], qkv[:, (H + Hkv) * hd:]
+            qn, rq = ops.rmsnorm_rope_fwd(q, P[L['qn']], eps, pos, self.cos, self.sin, H, hd=hd)
+            kn, rk = ops.rmsnorm_rope_fwd(kk, P[L['kn']], eps, pos, self.cos, self.sin, Hkv, hd=hd)
             qn, kn = qn.view(Mp, H * hd), kn.view(Mp, Hkv * hd)
-            ops.rope_(qn, 0, H, hd, pos, self.cos, self.sin)
-            ops.rope_(kn, 0, Hkv, hd, pos, self.cos, self.sin)
             if kv_sink is not None:     # post-norm, post-RoPE keys | values of this layer -> KV cache (prefill)
                 kv_sink(li, torch.cat([kn[:N * T], v[:N * T]], dim=1))
             attn, lse = ops.attn_fwd(qn, kn, v, N, T, H, Hkv, hd, True, hd ** -0.5, start,
@@ -1560,20 +1563,21 @@ class Qwen3MoeStack:
             if tr:
                 L['o'].dw(dres, attn)
             z = lambda t: torch.zeros_like(t) if Mp != N * T else torch.empty_like(t)
-            dqn, dkn, dv = z(qn), z(kn), z(v)
+            dqn, dkn = z(qn), z(kn)
+            # the gradient of the fused projection output: attention writes dV into its slice, the per-head norm backward dq / dk into theirs
+            d_qkv = torch.zeros((Mp, (H + 2 * Hkv) * hd), dtype=qn.dtype, device=qn.device) if Mp != N * T else torch.empty((Mp, (H + 2 * Hkv) * hd), dtype=qn.dtype, device=qn.device)
+            dv = d_qkv[:, (H + Hkv) * hd:]
             fuse_rope = dqn.dtype == bf16 and ops.attn_rope_fused()         # as LlamaStack.backward
             ops.attn_bwd(qn, kn, v, attn, d_attn, lse, dqn, dkn, dv, N, T, H, Hkv, hd, True, hd ** -0.5, start,
                          rope=(pos, self.cos, self.sin) if fuse_rope else None)
             if not fuse_rope:
                 ops.rope_(dqn, 0, H, hd, pos, self.cos, self.sin, inverse=True)
                 ops.rope_(dkn, 0, Hkv, hd, pos, self.cos, self.sin, inverse=True)
-            dq = ops.rmsnorm_bwd(dqn.view(Mp * H, hd), q.view(Mp * H, hd), P[L['qn']], rq, G.get(L['qn']) if tr else None).view(Mp, H * hd)
-            dk = ops.rmsnorm_bwd(dkn.view(Mp * Hkv, hd), kk.view(Mp * Hkv, hd), P[L['kn']], rk, G.get(L['kn']) if tr else None).view(Mp, Hkv * hd)
-            d_n1 = L['q'].dx(dq)
-            ops.gemm(dk, L['k'].w, out=d_n1, b_n=True, accumulate=True)
-            ops.gemm(dv, L['v'].w, out=d_n1, b_n=True, accumulate=True)
+            ops.rmsnorm_heads_bwd(dqn.view(Mp * H, hd), q, P[L['qn']], rq, G.get(L['qn']) if tr else None, d_qkv[:, :H * hd], H, hd)
+            ops.rmsnorm_heads_bwd(dkn.view(Mp * Hkv, hd), kk, P[L['kn']], rk, G.get(L['kn']) if tr else None, d_qkv[:, H * hd:(H + Hkv) * hd], Hkv, hd)
+            d_n1 = L['qkv'].dx(d_qkv)
             if tr:
-                L['q'].dw(dq, n1); L['k'].dw(dk, n1); L['v'].dw(dv, n1)
+                L['qkv'].dw(d_qkv, n1)
             ops.rmsnorm_bwd(d_n1, x, P[L['ln1']], rstd1, G.get(L['ln1']) if tr else None, dx=dres, add_to_dx=True)
             if on_layer_done is not None:
                 on_layer_done(L)

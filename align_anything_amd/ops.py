@@ -278,6 +278,38 @@ def rmsnorm_fwd(x, w, eps, out=None, rstd=None):
     return out, rstd
 
 
+def rmsnorm_rope_fwd(x, w, eps, pos, cos_t, sin_t, heads, hd=None):
+    """rope(rmsnorm(x)) per head in one pass (Qwen3 q_norm / k_norm + rotary embedding); bit-identical to rmsnorm_fwd + rope_.
+    x: [tokens * heads, hd] dense, or -- with hd given -- [tokens, heads * hd] as a COLUMN SLICE of a wider row-major buffer (the fused q | k | v
+    projection output; x.stride(0) = its width).  Returns (y [tokens * heads, hd] dense, rstd [tokens * heads])."""
+    if hd is None:
+        rows, hd = x.shape
+        ldx = heads * hd
+    else:
+        if x.stride(1) != 1 or x.shape[1] != heads * hd:
+            raise RuntimeError(f'rmsnorm_rope_fwd: expected a [tokens, {heads * hd}] column slice, got {tuple(x.shape)} strides {x.stride()}')
+        rows, ldx = x.shape[0] * heads, x.stride(0)
+    if cos_t.dtype != x.dtype:
+        raise RuntimeError(f'rmsnorm_rope_fwd: tables are {cos_t.dtype}, activations {x.dtype}')
+    out = torch.empty((rows, hd), dtype=x.dtype, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call('aa_rmsnorm_rope_fwd' + _sfx(x, 'rmsnorm_rope_fwd'), x.data_ptr(), int(ldx), w.data_ptr(), out.data_ptr(), rstd.data_ptr(), rows, hd, float(eps), pos.data_ptr(),
+         cos_t.data_ptr(), sin_t.data_ptr(), int(heads), stream())
+    return out, rstd
+
+
+def rmsnorm_heads_bwd(dy, x, w, rstd, dw, dx, heads, hd):
+    """Backward of the per-head norm with x [tokens, heads * hd] (the saved projection output) and dx as column slices of the fused q | k | v buffers;
+    dy [tokens * heads, hd] dense.  dx is written (not accumulated)."""
+    rows = x.shape[0] * heads
+    if x.stride(1) != 1 or dx.stride(1) != 1 or tuple(dx.shape) != tuple(x.shape):
+        raise RuntimeError('rmsnorm_heads_bwd: x / dx must be [tokens, heads * hd] column slices')
+    ws = _norm_ws(x.device, hd, 1) if dw is not None else None
+    call('aa_rmsnorm_heads_bwd' + _sfx(x, 'rmsnorm_heads_bwd'), dy.data_ptr(), x.data_ptr(), x.stride(0), w.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dx.stride(0),
+         _p(dw), _p(ws), NORM_WS_ROWS, rows, hd, int(heads), stream())
+    return dx
+
+
 def rmsnorm_bwd(dy, x, w, rstd, dw, dx=None, add_to_dx=False):
     rows, h = x.shape
     dx = torch.empty_like(x) if dx is None else dx

@@ -145,6 +145,15 @@ int aa_gemm_set_group(int gm);   /* tile-group height of the L2-aware tile order
 /* hf:models/llama/modeling_llama.py:62-67 LlamaRMSNorm */
 int aa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int h, float eps,
                    void* stream);
+/* y = rope(rmsnorm(x)) over rows = tokens x heads of width hd: Qwen3's per-head q_norm / k_norm followed by apply_rotary_pos_emb
+   (hf:models/qwen3_moe/modeling_qwen3_moe.py attention forward, reached from align_anything/models/qwen3_moe.py:28-60) in ONE pass; pos[token] indexes the
+   [., hd / 2] cos / sin tables; x may be a column slice of the fused q | k | v projection output (ldx = elements per token); bit-identical to aa_rmsnorm_fwd
+   followed by aa_rope_inplace */
+int aa_rmsnorm_rope_fwd(const void* x, long ldx, const void* w, void* y, float* rstd, long rows, int hd, float eps, const int* pos, const void* cos_t,
+                        const void* sin_t, int heads, void* stream);
+/* backward of the per-head norm when x (the saved projection output) and dx are column slices of the fused q | k | v buffers: row = (token, head) at token * ld + head * hd; dy dense; dw [hd] fp32 accumulated through ws [ws_rows, hd] */
+int aa_rmsnorm_heads_bwd(const void* dy, const void* x, long ldx, const void* w, const float* rstd, void* dx, long lddx, float* dw, float* ws, int ws_rows,
+                         long rows, int hd, int heads, void* stream);
 /* dw (fp32 [h], accumulated) needs ws = fp32 [ws_rows, h] scratch (per-workgroup partial rows) */
 int aa_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, float* dw,
                    float* ws, int ws_rows, int rows, int h, int add_to_dx, void* stream);

@@ -21,6 +21,12 @@ int aa_gemm_f32(const void* A, const void* B, void* C, int M, int N, int K, long
 /* fp32 twin of aa_rmsnorm_fwd */
 int aa_rmsnorm_fwd_f32(const void* x, const void* w, void* y, float* rstd, int rows, int h, float eps,
                        void* stream);
+/* fp32 twin of aa_rmsnorm_rope_fwd */
+int aa_rmsnorm_rope_fwd_f32(const void* x, long ldx, const void* w, void* y, float* rstd, long rows, int hd, float eps, const int* pos, const void* cos_t,
+                        const void* sin_t, int heads, void* stream);
+/* fp32 twin of aa_rmsnorm_heads_bwd */
+int aa_rmsnorm_heads_bwd_f32(const void* dy, const void* x, long ldx, const void* w, const float* rstd, void* dx, long lddx, float* dw, float* ws, int ws_rows,
+                         long rows, int hd, int heads, void* stream);
 /* fp32 twin of aa_rmsnorm_bwd */
 int aa_rmsnorm_bwd_f32(const void* dy, const void* x, const void* w, const float* rstd, void* dx, float* dw,
                        float* ws, int ws_rows, int rows, int h, int add_to_dx, void* stream);

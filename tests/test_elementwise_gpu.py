@@ -161,3 +161,53 @@ def test_transpose_colsum_im2col_clip_embed():
     emb = ops.clip_embed(pe, cls, pos, n_img, 4)
     ref2 = torch.cat([cls.float().expand(n_img, 1, hdim), pe.float().view(n_img, 4, hdim)], 1) + pos.float()[None]
     assert_close(emb.view(n_img, 5, hdim), ref2, rtol=1e-2, atol=1e-2, what='clip embed')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('hd,heads,tokens', [(128, 32, 200), (128, 4, 777), (64, 6, 130)])
+def test_rmsnorm_rope_fused_is_bit_identical_to_the_pair(hd, heads, tokens, dtype):
+    """aa_rmsnorm_rope_fwd (Qwen3's per-head q_norm / k_norm + apply_rotary_pos_emb in one pass) == aa_rmsnorm_fwd followed by aa_rope_inplace, bit for bit,
+    in both element types; ragged row counts (the last block's partial row pairs)."""
+    from align_anything_amd import ops
+    from align_anything_amd.modeling import rope_tables
+    g = torch.Generator().manual_seed(hd + heads)
+    x = (torch.randn(tokens * heads, hd, generator=g) * 2.0).to(dtype).to(dev())
+    w = (1.0 + 0.1 * torch.randn(hd, generator=g)).to(dtype).to(dev())
+    pos = torch.randint(0, 300, (tokens,), generator=g).to(torch.int32).to(dev())
+    cos, sin = rope_tables(300, hd, 10000.0, dev(), dtype)
+    y0, r0 = ops.rmsnorm_fwd(x, w, 1e-6)
+    y0 = y0.view(tokens, heads * hd).clone()
+    ops.rope_(y0, 0, heads, hd, pos, cos, sin)
+    y1, r1 = ops.rmsnorm_rope_fwd(x, w, 1e-6, pos, cos, sin, heads)
+    torch.cuda.synchronize()
+    assert torch.equal(r0, r1) and torch.equal(y0.view(-1, hd), y1)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_per_head_norm_on_column_slices_of_the_fused_projection(dtype):
+    """The Qwen3-MoE stack projects q | k | v with ONE GEMM; the per-head norm (+ rotary embedding) reads its column slice of that output in place and its
+    backward writes dq / dk into their slices of the fused gradient (aa_rmsnorm_rope_fwd with ldx, aa_rmsnorm_heads_bwd): same bits as the dense kernels on
+    contiguous copies, nothing written outside the slice."""
+    from align_anything_amd import ops
+    from align_anything_amd.modeling import rope_tables
+    tokens, H, Hkv, hd = 333, 8, 2, 128
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(tokens, (H + 2 * Hkv) * hd, generator=g) * 1.5).to(dtype).to(dev())
+    pos = torch.randint(0, 200, (tokens,), generator=g).to(torch.int32).to(dev())
+    cos, sin = rope_tables(200, hd, 10000.0, dev(), dtype)
+    for heads, lo in ((H, 0), (Hkv, H * hd)):
+        w = (1.0 + 0.1 * torch.randn(hd, generator=g)).to(dtype).to(dev())
+        sl = qkv[:, lo:lo + heads * hd]
+        dense = sl.contiguous().view(tokens * heads, hd)
+        y0, r0 = ops.rmsnorm_rope_fwd(dense, w, 1e-6, pos, cos, sin, heads)
+        y1, r1 = ops.rmsnorm_rope_fwd(sl, w, 1e-6, pos, cos, sin, heads, hd=hd)
+        assert torch.equal(y0, y1) and torch.equal(r0, r1)
+        dy = (torch.randn(tokens * heads, hd, generator=g) * 0.3).to(dtype).to(dev())
+        dw0 = torch.zeros(hd, dtype=torch.float32, device=dev()); dw1 = torch.zeros_like(dw0)
+        dx0 = ops.rmsnorm_bwd(dy, dense, w, r0, dw0)
+        d_qkv = torch.full_like(qkv, 7.0)
+        ops.rmsnorm_heads_bwd(dy, sl, w, r1, dw1, d_qkv[:, lo:lo + heads * hd], heads, hd)
+        torch.cuda.synchronize()
+        assert torch.equal(d_qkv[:, lo:lo + heads * hd].contiguous().view(-1, hd), dx0) and torch.equal(dw0, dw1)
+        keep = torch.ones(qkv.shape[1], dtype=torch.bool); keep[lo:lo + heads * hd] = False
+        assert bool((d_qkv[:, keep.to(dev())] == 7.0).all())
