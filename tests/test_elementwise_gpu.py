@@ -167,7 +167,7 @@ def test_transpose_colsum_im2col_clip_embed():
 @pytest.mark.parametrize('hd,heads,tokens', [(128, 32, 200), (128, 4, 777), (64, 6, 130)])
 def test_rmsnorm_rope_fused_is_bit_identical_to_the_pair(hd, heads, tokens, dtype):
     """aa_rmsnorm_rope_fwd (Qwen3's per-head q_norm / k_norm + apply_rotary_pos_emb in one pass) == aa_rmsnorm_fwd followed by aa_rope_inplace, bit for bit,
-    in both element types; ragged row counts (the last block's partial row pairs)."""
+    in bf16 (fp32 twin: to fma-contraction rounding); ragged row counts (the last block's partial row pairs)."""
     from align_anything_amd import ops
     from align_anything_amd.modeling import rope_tables
     g = torch.Generator().manual_seed(hd + heads)
@@ -180,7 +180,11 @@ def test_rmsnorm_rope_fused_is_bit_identical_to_the_pair(hd, heads, tokens, dtyp
     ops.rope_(y0, 0, heads, hd, pos, cos, sin)
     y1, r1 = ops.rmsnorm_rope_fwd(x, w, 1e-6, pos, cos, sin, heads)
     torch.cuda.synchronize()
-    assert torch.equal(r0, r1) and torch.equal(y0.view(-1, hd), y1)
+    assert torch.equal(r0, r1)
+    if dtype == torch.bfloat16:
+        assert torch.equal(y0.view(-1, hd), y1)
+    else:       # the fp32 twin has no rounding points between the multiplies and the add: the compiler's fma contraction may differ between the two kernels
+        assert torch.allclose(y0.view(-1, hd), y1, rtol=2e-6, atol=2e-6)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
@@ -208,6 +212,6 @@ def test_per_head_norm_on_column_slices_of_the_fused_projection(dtype):
         d_qkv = torch.full_like(qkv, 7.0)
         ops.rmsnorm_heads_bwd(dy, sl, w, r1, dw1, d_qkv[:, lo:lo + heads * hd], heads, hd)
         torch.cuda.synchronize()
-        assert torch.equal(d_qkv[:, lo:lo + heads * hd].contiguous().view(-1, hd), dx0) and torch.equal(dw0, dw1)
+        assert torch.equal(d_qkv[:, lo:lo + heads * hd].contiguous().view(-1, hd), dx0) and torch.allclose(dw0, dw1, rtol=1e-5, atol=1e-5)      # dw: fp32 atomics across blocks
         keep = torch.ones(qkv.shape[1], dtype=torch.bool); keep[lo:lo + heads * hd] = False
         assert bool((d_qkv[:, keep.to(dev())] == 7.0).all())
