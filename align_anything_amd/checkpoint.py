@@ -132,6 +132,7 @@ class Derived(Mapping):
     def __init__(self, base, drop, thunks):
         self.base, self.thunks = base, dict(thunks)
         self._names = [k for k in base if not drop(k)] + list(self.thunks)
+        self._set = set(self._names)
 
     def __getitem__(self, name):
         t = self.thunks.get(name)
@@ -144,7 +145,7 @@ class Derived(Mapping):
         return len(self._names)
 
     def __contains__(self, name):
-        return name in self.thunks or name in self._names
+        return name in self._set
 
 
 class _WithNewRows(Mapping):

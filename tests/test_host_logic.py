@@ -412,6 +412,26 @@ def test_qwen3moe_loads_hub_style_per_expert_checkpoints():
     assert set(sa) == set(sb) == set(sd)
     for k in sd:
         assert torch.equal(sa[k], sd[k]) and torch.equal(sb[k], sd[k]), k
+    # the same hub-style tensors through the lazy checkpoint reader (two safetensors shards + index): the per-expert keys of one layer are merged only when
+    # the store asks for that layer's fused block (checkpoint.Derived), nothing else is materialised
+    import json
+    import tempfile
+    import safetensors.torch as st
+    from align_anything_amd.checkpoint import Derived, LazyCheckpoint
+    with tempfile.TemporaryDirectory() as d:
+        names = sorted(hub)
+        halves = {'model-00001-of-00002.safetensors': names[: len(names) // 2], 'model-00002-of-00002.safetensors': names[len(names) // 2:]}
+        for fn, ks in halves.items():
+            st.save_file({k: hub[k].contiguous() for k in ks}, os.path.join(d, fn), metadata={'format': 'pt'})
+        with open(os.path.join(d, 'model.safetensors.index.json'), 'w') as f:
+            json.dump({'metadata': {}, 'weight_map': {k: fn for fn, ks in halves.items() for k in ks}}, f)
+        lazy = LazyCheckpoint(d, 'qwen3moe')
+        c = build_model(cfg, 'cpu', trainable=False)
+        fused = c.fuse_expert_keys(lazy)
+        assert isinstance(fused, Derived) and 'model.layers.0.mlp.experts.gate_up_proj' in fused and 'model.layers.0.mlp.experts.0.gate_proj.weight' not in fused
+        assert c.load_state_dict(lazy) == []
+        sc = c.state_dict()
+        assert all(torch.equal(sc[k], sd[k]) for k in sd)
     del hub['model.layers.1.mlp.experts.3.up_proj.weight']
     with pytest.raises(KeyError):
         build_model(cfg, 'cpu', trainable=False).load_state_dict(hub)
