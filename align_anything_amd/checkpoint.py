@@ -36,7 +36,8 @@ _RENAMES = {
     'llava': [(r'^language_model\.lm_head', 'lm_head'), (r'^language_model\.model', 'model.language_model'),
               (r'^vision_tower', 'model.vision_tower'), (r'^multi_modal_projector', 'model.multi_modal_projector'),
               (r'^model\.vision_tower\.vision_model\.', 'model.vision_tower.')],
-    'qwen2audio': [(r'^language_model\.lm_head', 'lm_head'), (r'^language_model\.model', 'model.language_model'),
+    # (transformers 5.x `save_pretrained` reverses TWO of its renames for this model and writes `language_model.model.model.<...>`: accepted as well)
+    'qwen2audio': [(r'^language_model\.lm_head', 'lm_head'), (r'^language_model\.model\.model\.', 'model.language_model.'), (r'^language_model\.model', 'model.language_model'),
                    (r'^audio_tower', 'model.audio_tower'), (r'^multi_modal_projector', 'model.multi_modal_projector')],
     'qwen2vl': [(r'^visual', 'model.visual'), (r'^model(?!\.(language_model|visual))', 'model.language_model')],
     'opt': [(r'^decoder\.', 'model.decoder.')],

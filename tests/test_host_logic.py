@@ -865,3 +865,56 @@ def test_library_contexts_isolate_switches_and_plans_per_thread():
         call('aa_ctx_destroy', c1)
         call('aa_ctx_destroy', c2)
     assert plan() == base
+
+
+def test_checkpoint_reader_key_layouts_of_the_other_backbones(tmp_path):
+    """checkpoint.normalize_key for Qwen2-VL and Qwen2-Audio: the transformers-4.x hub layout (`visual...` / `model.layers...`, `language_model.model...` /
+    `audio_tower...`) and the >= 5 layout both load into the native stores bit-exactly (hf:conversion_mapping.py "Qwen2VLForConditionalGeneration", "qwen2_audio")."""
+    import safetensors.torch as st
+    import transformers as tf
+    from align_anything_amd import configs
+    from align_anything_amd.checkpoint import LazyCheckpoint, normalize_key
+    from align_anything_amd.modeling import build_model
+    torch.manual_seed(1)
+    qvl = tf.Qwen2VLForConditionalGeneration(tf.Qwen2VLConfig(
+        text_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=320,
+                         max_position_embeddings=256, rms_norm_eps=1e-6, rope_parameters={'rope_type': 'default', 'rope_theta': 10000.0, 'mrope_section': [8, 12, 12]}),
+        vision_config=dict(depth=2, embed_dim=320, hidden_size=128, num_heads=4, mlp_ratio=2, patch_size=14, temporal_patch_size=2, spatial_merge_size=2, in_channels=3),
+        image_token_id=300, video_token_id=301, vision_start_token_id=302, vision_end_token_id=303, bos_token_id=1, eos_token_id=2)).eval()
+    qa = tf.Qwen2AudioForConditionalGeneration(tf.Qwen2AudioConfig(
+        audio_config=dict(num_mel_bins=64, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, d_model=128, max_source_positions=32),
+        text_config=dict(model_type='qwen2', hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=320,
+                         max_position_embeddings=256, rms_norm_eps=1e-6), audio_token_id=300)).eval()
+
+    def old_qvl(k):      # what transformers 4.x wrote
+        if k.startswith('model.visual.'):
+            return k[len('model.'):]
+        if k.startswith('model.language_model.'):
+            return 'model.' + k[len('model.language_model.'):]
+        return k
+
+    def old_qa(k):
+        if k.startswith('model.language_model.'):
+            return 'language_model.model.' + k[len('model.language_model.'):]
+        if k == 'lm_head.weight':
+            return 'language_model.lm_head.weight'
+        if k.startswith('model.audio_tower.') or k.startswith('model.multi_modal_projector.'):
+            return k[len('model.'):]
+        return k
+
+    for kind, hf, old in (('qwen2vl', qvl, old_qvl), ('qwen2audio', qa, old_qa)):
+        want = {k: v.detach().clone() for k, v in hf.state_dict().items()}
+        d5 = str(tmp_path / (kind + '_v5'))
+        hf.save_pretrained(d5, max_shard_size='300KB')
+        d4 = tmp_path / (kind + '_v4')
+        d4.mkdir()
+        legacy = {old(k): v.contiguous() for k, v in want.items()}
+        assert len(legacy) == len(want) and all(normalize_key(kind, old(k)) == k for k in want), kind
+        assert any(old(k) != k for k in want)
+        st.save_file(legacy, str(d4 / 'model.safetensors'), metadata={'format': 'pt'})
+        for d in (d5, str(d4)):
+            m = build_model(configs.from_hf_config(hf.config), 'cpu', trainable=False, dtype=torch.float32)
+            lazy = LazyCheckpoint(d, kind)
+            assert m.load_state_dict(lazy) == [], (kind, d)
+            got = m.state_dict()
+            assert set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want), (kind, d)
