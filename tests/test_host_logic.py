@@ -918,3 +918,32 @@ def test_checkpoint_reader_key_layouts_of_the_other_backbones(tmp_path):
             assert m.load_state_dict(lazy) == [], (kind, d)
             got = m.state_dict()
             assert set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want), (kind, d)
+
+
+def test_checkpoint_reader_loads_what_save_pretrained_writes_for_every_backbone(tmp_path):
+    """Whatever key layout the installed transformers WRITES (it reverses some of its load-time renames on save -- Qwen2-VL and Qwen2-Audio come out in their 4.x
+    layouts, Qwen3-MoE's experts fused or per expert depending on the version) must come back bit-exactly through LazyCheckpoint + the model's loader."""
+    import transformers as tf
+    from align_anything_amd import configs
+    from align_anything_amd.checkpoint import LazyCheckpoint
+    from align_anything_amd.modeling import build_model
+    torch.manual_seed(2)
+    cases = {
+        'opt': tf.OPTForCausalLM(tf.OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=320, max_position_embeddings=128,
+                                              word_embed_proj_dim=128, dropout=0.0, pad_token_id=1)),
+        'llama': tf.LlamaForCausalLM(tf.LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=320,
+                                                    max_position_embeddings=256)),
+        'qwen3moe': tf.Qwen3MoeForCausalLM(tf.Qwen3MoeConfig(hidden_size=128, moe_intermediate_size=64, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                                                             num_key_value_heads=1, vocab_size=320, num_experts=8, num_experts_per_tok=2, head_dim=64, max_position_embeddings=256)),
+        'llava': _tiny_llava_hf(),
+    }
+    for kind, hf in cases.items():
+        hf = hf.eval()
+        want = {k: v.detach().clone() for k, v in hf.state_dict().items()}
+        d = str(tmp_path / kind)
+        hf.save_pretrained(d, max_shard_size='150KB')
+        m = build_model(configs.from_hf_config(hf.config), 'cpu', trainable=False, dtype=torch.float32)
+        assert m.kind == kind
+        assert m.load_state_dict(LazyCheckpoint(d, kind)) == [], kind
+        got = m.state_dict()
+        assert set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want), kind
