@@ -157,20 +157,28 @@ class PPOTrainer(PPOMath):
         self.prompt_only_dataloader, self.eval_dataloader, self.ptx_dataloader = get_dataloaders(self, 'PromptOnlyDataset', 'PromptOnlyDataset',
                                                                                                  ptx_dtype_name='SupervisedDataset', rl=True)
 
+    def _token_id(self, key, default):
+        """pad / eos id of the rollouts: model_cfgs.<key> when configured, else the tokenizer's (the cfgs-only constructor loaded it: the reference
+        takes both from the tokenizer, ppo.py:161-170), else `default`."""
+        v = cfg_get(self.cfgs, 'model_cfgs.' + key, None)
+        if v is None:
+            v = getattr(getattr(self, 'tokenizer', None), key, None)
+        return default if v is None else int(v)
+
     # ------------------------------------------------------------------ rollout (ppo.py:209-222, 244-289)
     def actor_step(self, prompt_batch, generator=None, sequences=None):
         """`self.actor_model.module.generate(**batch, generation_config=..., do_sample=True)` natively (ppo.py:209-222).
         `sequences` injects already generated rows (tests against the reference's fixture, external samplers)."""
         from ..generation import generate
         m = lambda k, d: cfg_get(self.cfgs, 'model_cfgs.' + k, d)
-        pad = m('pad_token_id', 0)
+        pad = self._token_id('pad_token_id', 0)
         if sequences is not None:
             return {'input_ids': sequences, 'attention_mask': sequences.ne(pad)}
         self.actor_model.wait_optimizer()
         seq = generate(self.actor_model.module, prompt_batch['input_ids'], prompt_batch['attention_mask'],
                        max_length=int(m('model_max_length', 2048)), do_sample=True, temperature=float(m('temperature', 1.0)),
                        top_p=float(m('top_p', 1.0)), top_k=m('top_k', 'hf'), repetition_penalty=float(m('repetition_penalty', 1.0)),
-                       eos_token_id=m('eos_token_id', None), pad_token_id=pad,
+                       eos_token_id=self._token_id('eos_token_id', None), pad_token_id=pad,
                        pixel_values=prompt_batch.get('pixel_values'), generator=generator)
         return {'input_ids': seq, 'attention_mask': seq.ne(pad)}
 

@@ -28,8 +28,7 @@ class PPOTrainerTI2T(PPOTrainer):
         return 0
 
     def _pad_id(self):
-        from .common import cfg_get
-        return int(cfg_get(self.cfgs, 'model_cfgs.pad_token_id', 0))
+        return self._token_id('pad_token_id', 0)
 
     # ------------------------------------------------------------------ ppo.py:174-205
     def finish_sequences(self, prompt_batch, sequences):
@@ -53,7 +52,7 @@ class PPOTrainerTI2T(PPOTrainer):
         seq = generate(self.actor_model.module, prompt_batch['input_ids'], prompt_batch['attention_mask'],
                        max_new_tokens=int(m('max_new_tokens', 512)), do_sample=True, temperature=float(m('temperature', 1.0)),
                        top_p=float(m('top_p', 1.0)), top_k=m('top_k', 'hf'), repetition_penalty=float(m('repetition_penalty', 1.0)),
-                       eos_token_id=m('eos_token_id', None), pad_token_id=self._pad_id(), pixel_values=pv, generator=generator, **mm)
+                       eos_token_id=self._token_id('eos_token_id', None), pad_token_id=self._pad_id(), pixel_values=pv, generator=generator, **mm)
         return self.finish_sequences(prompt_batch, seq)
 
     # ------------------------------------------------------------------ ppo.py:206-269
