@@ -57,6 +57,12 @@ typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_p;
 #ifndef AA_BWD_LAB
 #define AA_BWD_LAB 0
 #endif
+// delta = rowsum(dO * O): 1 = computed by the dQ kernel's prologue from the dO fragments it holds anyway (+ one read of its O rows) and written for the dK/dV
+// kernel that follows on the stream -- same partial sums in the same association as attn_delta_kernel (bit-identical), one launch and one pass over dO less
+// per backward; 0 = the separate kernel (same-box A/B)
+#ifndef AA_ATTN_DELTA_IN_DQ
+#define AA_ATTN_DELTA_IN_DQ 1
+#endif
 #ifndef AA_BWD_LAB_ONLY
 #define AA_BWD_LAB_ONLY 0
 #endif
@@ -357,6 +363,16 @@ __device__ __forceinline__ float row4_sum(float v) {
     float m;
     asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
     r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    return m;
+}
+// the same with the half step FIRST: the association of __shfl_xor(32) followed by __shfl_xor(16), which is what attn_delta_kernel's butterfly does to the four
+// 8-column slots a row's four lanes hold (the dQ kernel's in-prologue delta must reproduce that kernel's bits)
+__device__ __forceinline__ float row4_sum_half_first(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    float m;
+    asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
     asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
     return m;
 }
@@ -662,7 +678,28 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
             dof[qi][ks] = *reinterpret_cast<const bf16x8*>(dOb + (long)qr * p.lddo + ks * 32 + g * 8);
         }
         lse2[qi] = p.lse[((long)n * p.H + h) * T + qr] * LOG2E_F;
-        dl[qi] = p.delta[((long)n * p.H + h) * T + qr];
+        if constexpr (AA_ATTN_DELTA_IN_DQ) {
+            // attn_delta_kernel's arithmetic: 8 products per 8-column slot `sub` = 4 ks + g, then the butterfly over the slots (xor 8, 4 inside the lane; xor 2, 1 =
+            // lanes 32 and 16 apart)
+            const bf16_t* Ob = p.O + (long)n * T * p.ldo + h * HD;
+            float sp[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u16x8 ov = *reinterpret_cast<const u16x8*>(Ob + (long)qr * p.ldo + ks * 32 + g * 8);
+                const u16x8 dv = __builtin_bit_cast(u16x8, dof[qi][ks]);
+                float sacc_ = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sacc_ += bf2f(dv[j]) * bf2f(ov[j]);
+                sp[ks] = sacc_;
+            }
+            float dsum;
+            if constexpr (KS == 4) dsum = (sp[0] + sp[2]) + (sp[1] + sp[3]); else dsum = sp[0] + sp[1];
+            dsum = row4_sum_half_first(dsum);
+            dl[qi] = dsum;
+            if (g == 0 && qw + qi * 16 + l15 < T) p.delta[((long)n * p.H + h) * T + qr] = dsum;
+        } else {
+            dl[qi] = p.delta[((long)n * p.H + h) * T + qr];
+        }
     }
     f32x4 dqacc[2][DB];
 #pragma unroll
@@ -1015,7 +1052,7 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
         // NW = 8 (one 8-wave workgroup per CU sharing the tile stream) measured 1356 us on the bench block against ~1200-1340 for two independent 4-wave
         // workgroups per CU: what it saves in LDS-DMA pieces it loses in overlap across the per-tile barrier (profiles/r04_attn128_anatomy.txt, section 6)
         const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
-        hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(aa_cdiv(groups * 16, 256)), dim3(256), 0, st, p);
+        if (!AA_ATTN_DELTA_IN_DQ || AA_BWD_LAB_ONLY == 2) hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(aa_cdiv(groups * 16, 256)), dim3(256), 0, st, p);
         if ((rc = set_lds(attn_bwd_dq_kernel<128, 4>, lds, "aa_attn_bwd"))) return rc;
         if (AA_BWD_LAB_ONLY != 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 4>), gq, dim3(256), lds, st, p);
         if (AA_BWD_LAB_ONLY == 1) { AA_CHECK_LAUNCH("aa_attn_bwd"); return AA_OK; }
@@ -1023,7 +1060,7 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4>), gkv, dim3(256), lds + 1024, st, p);
     } else {
         const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
-        hipLaunchKernelGGL(attn_delta_kernel<64>, dim3(aa_cdiv(groups * 8, 256)), dim3(256), 0, st, p);
+        if (!AA_ATTN_DELTA_IN_DQ) hipLaunchKernelGGL(attn_delta_kernel<64>, dim3(aa_cdiv(groups * 8, 256)), dim3(256), 0, st, p);
         if ((rc = set_lds(attn_bwd_dq_kernel<64, 4>, lds, "aa_attn_bwd"))) return rc;
         hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 4>), gq, dim3(256), lds, st, p);
         if ((rc = set_lds(attn_bwd_dkv_kernel<64, 4>, lds + 1024, "aa_attn_bwd"))) return rc;
