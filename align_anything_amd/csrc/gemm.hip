@@ -501,7 +501,7 @@ static int launch_layout(GemmParams& p, int tile, hipStream_t st) {
 // forced tile config: aa_ctx::force_tile (-2: read env once; -1: heuristic)
 
 // waves-quantisation heuristic over the 256-CU chip
-static int pick_tile(int M, int N) {
+static int pick_tile(int M, int N, int K) {
     if (aa_ctx_cur()->force_tile == -2) {
         const char* e = getenv("AA_GEMM_TILE");
         aa_ctx_cur()->force_tile = e ? atoi(e) : -1;
@@ -512,12 +512,19 @@ static int pick_tile(int M, int N) {
     struct Cfg { int bm, bn, slots; float eff; };
     // slots = concurrently resident tiles on the chip; eff = relative per-flop efficiency of the config
     const Cfg cfgs[4] = {{256, 256, 256, 1.00f}, {128, 128, 512, 0.72f}, {256, 128, 256, 0.86f}, {128, 256, 256, 0.86f}};
+    // Short contractions (K < 2048: the CLIP / ViT / Whisper towers, OPT-125m): a 256 x 256 tile spends its time in the pipeline fill and in the epilogue of
+    // 65536 outputs, not in its 16 k-steps -- the tower's fc1 (M 2308, N 4096, K 1024, bias + quick-GELU) ran 292 us on the one-wave-per-SIMD kernel and
+    // 137 us on the 8-wave 256 x 256 one against 59 us on 256 x 128 although that needs two rounds (tools/bench_clip_gemms.py, profiles/r04_clip_gemms.json):
+    // 5.3 ms of the DPO step.  The model below therefore halves the 256 x 256 tile's efficiency there.  AA_GEMM_SMALLK=0: the round-3 choice (A/B).
+    static int smallk = -1;
+    if (smallk < 0) { const char* e = getenv("AA_GEMM_SMALLK"); smallk = e ? atoi(e) : 1; }
     int best = 1; float best_t = 1e30f;
     for (int c = 0; c < 4; ++c) {
         const long tiles = (long)aa_cdiv(M, cfgs[c].bm) * aa_cdiv(N, cfgs[c].bn);
         const long rounds = (tiles + cfgs[c].slots - 1) / cfgs[c].slots;
         // time ~ rounds * (tile flops / (eff * per-slot rate)); per-slot rate halves when 2 tiles share a CU
-        const float per = (float)cfgs[c].bm * cfgs[c].bn / cfgs[c].eff * (cfgs[c].slots / 256.f);
+        const float eff = (c == 0 && smallk && K < 2048) ? cfgs[c].eff * 0.45f : cfgs[c].eff;
+        const float per = (float)cfgs[c].bm * cfgs[c].bn / eff * (cfgs[c].slots / 256.f);
         const float t = rounds * per;
         if (t < best_t) { best_t = t; best = c; }
     }
@@ -545,7 +552,7 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
     p.bias = (const bf16_t*)bias; p.residual = (const bf16_t*)residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.act = act; p.flags = flags;
-    int tile = pick_tile(M, N);
+    int tile = pick_tile(M, N, K);
     hipStream_t st = (hipStream_t)stream;
     if (tile == 5 && !aa_gemm4_supports(K)) tile = 0;      // K not a multiple of 128: the 8-wave kernel of the same tile
     if (tile == 5) {   // one-wave-per-SIMD 256x256 tile with accumulator-file MFMAs (gemm4.hip)
