@@ -18,7 +18,7 @@ work inside the training loop -- and then does a blocking `.to(device)` per tens
 from __future__ import annotations
 
 import threading
-from queue import Queue
+from queue import Empty, Full, Queue
 
 import torch
 
@@ -136,6 +136,12 @@ class PromptOnlyCollator:
         return {'input_ids': _pin(ids), 'attention_mask': _pin(mask)}
 
 
+# Host-side fetches (dataset __getitem__ + collator: tokenizer and image-processor calls) of ALL prefetchers are serialised: a mid-epoch `eval()`
+# iterates the evaluation loader while the training loader's producer is a batch ahead, and both datasets hold the same fast tokenizer, which
+# is not re-entrant ("Already borrowed").  The reference loads single-threaded (num_workers = 0), so nothing is lost against it.
+_HOST_FETCH = threading.Lock()
+
+
 class DevicePrefetcher:
     """Iterates a host dataloader one batch ahead: the next batch's tensors are copied to the device on a side stream
     (non_blocking from pinned memory) and its window plan is built, while the current step runs.  `pad_token_id` given
@@ -177,25 +183,66 @@ class DevicePrefetcher:
             out['_window'] = build_label_window(out.pop('_labels_host'), device=self.device)     # supervised loss rows (trainers/sft.py)
         return out
 
+    def _retire(self):
+        """Stop the producer of an iterator that was abandoned before its end (`next(iter(loader))`, a `break`, an exception in the step):
+        it would otherwise sit in `q.put` forever holding `depth` staged batches, or -- worse -- keep running the dataset's tokenizer next
+        to the producer of the NEXT iterator (a fast tokenizer is not re-entrant: "Already borrowed")."""
+        prev = getattr(self, '_live', None)
+        if prev is None:
+            return
+        cancel, q, t = prev
+        cancel.set()
+        while t.is_alive():
+            try:
+                q.get(timeout=0.05)         # unblock a producer waiting on a full queue
+            except Empty:
+                pass
+        self._live = None
+
     def __iter__(self):
+        self._retire()
         q: Queue = Queue(maxsize=self.depth)
         stop = object()
+        cancel = threading.Event()
+
+        def put(item) -> bool:
+            while not cancel.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except Full:
+                    continue
+            return False
 
         def producer():
             try:
-                for b in self.loader:
-                    q.put(self._stage(b))
+                it = iter(self.loader)
+                while True:
+                    with _HOST_FETCH:        # one prefetcher inside a dataset at a time: the train and the eval loader share ONE tokenizer
+                        try:
+                            b = next(it)
+                        except StopIteration:
+                            break
+                    if not put(self._stage(b)):
+                        return
             except BaseException as ex:   # surface loader errors in the consumer
-                q.put(ex)
-            q.put(stop)
+                put(ex)
+            put(stop)
 
         t = threading.Thread(target=producer, daemon=True)
+        self._live = (cancel, q, t)
         t.start()
-        while True:
-            item = q.get()
-            if item is stop:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            yield self._finish(item)
-        t.join()
+        try:
+            while True:
+                item = q.get()
+                if item is stop:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield self._finish(item)
+            t.join()
+            if getattr(self, '_live', None) is not None and self._live[2] is t:
+                self._live = None
+        finally:
+            if getattr(self, '_live', None) is not None and self._live[2] is t:
+                self._retire()

@@ -244,6 +244,48 @@ def save_interval(cfgs, total_steps) -> int:
     return max(1, int(total_steps) // int(limit))
 
 
+def eval_due(cfgs, when: str, global_step: int = 0) -> bool:
+    """When the reference's training loops call `self.eval()` (text_to_text/rm.py:274-325, ppo.py:422-485, grpo.py:345-384): only with
+    `data_cfgs.eval_datasets` set; 'begin' = before the first step; 'steps' = `train_cfgs.eval_strategy == 'steps'` and global_step a multiple of
+    `train_cfgs.eval_interval`; 'epoch' = `eval_strategy == 'epoch'` at an epoch's end (PPO; the RM loop evaluates after EVERY epoch whatever the
+    strategy -- its caller passes when='always')."""
+    if not cfg_get(cfgs, 'data_cfgs.eval_datasets', None):
+        return False
+    if when in ('begin', 'always'):
+        return True
+    strategy = cfg_get(cfgs, 'train_cfgs.eval_strategy', 'epoch')
+    if when == 'steps':
+        every = int(cfg_get(cfgs, 'train_cfgs.eval_interval', 0) or 0)
+        return strategy == 'steps' and every > 0 and global_step % every == 0
+    return when == 'epoch' and strategy == 'epoch'
+
+
+@torch.no_grad()
+def rl_eval(trainer, eval_dataloader=None) -> dict:
+    """`RLTrainerBase.eval` (base/rl_trainer.py:289-329): sample a completion for every prompt of the evaluation set with the ACTOR and decode
+    prompt / completion pairs (the reference prints the first five as a table and returns nothing; here they are returned).  Sampling goes
+    through the trainer's own `actor_step` -- the native `generate` with the rollout's settings -- where the reference calls
+    `generate(max_length=model_max_length, do_sample=True)` with the model's default generation config.  {} without an evaluation dataloader."""
+    dl = eval_dataloader if eval_dataloader is not None else getattr(trainer, 'eval_dataloader', None)
+    if dl is None:
+        return {}
+    tok = getattr(trainer, 'tokenizer', None)
+    prompts, generateds = [], []
+    for batch in dl:
+        out = trainer.actor_step(batch)
+        seq = (out[0] if isinstance(out, tuple) else out)['input_ids']
+        if tok is None:                                  # no tokenizer (model_cfg + state constructors): token ids
+            P = batch['input_ids'].shape[1]
+            prompts.extend(batch['input_ids'].tolist())
+            generateds.extend(seq[:, P:].tolist() if seq.shape[1] >= P else seq.tolist())
+            continue
+        prompt = tok.batch_decode(batch['input_ids'], skip_special_tokens=True)
+        text = tok.batch_decode(seq, skip_special_tokens=True)
+        prompts.extend(prompt)
+        generateds.extend(t[len(prompt[i]):] for i, t in enumerate(text))
+    return {'eval/prompts': prompts, 'eval/generated': generateds}
+
+
 def resolve_pretrained(cfgs, device, *, trainable, head='lm', dtype=None, path_key='model_cfgs.model_name_or_path', build_kwargs=None,
                        with_tokenizer=True):
     """The reference trainers load their own models from `model_cfgs.model_name_or_path` (text_to_text/dpo.py:83-100,

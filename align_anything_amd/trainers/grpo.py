@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import build_span_window, cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad_rows, expert_parallel_kwargs, save_interval, save_slice
+from .common import build_span_window, cfg_get, eval_due, rl_eval, compute_dtype, end_index, get_all_reduce_mean, pad_rows, expert_parallel_kwargs, save_interval, save_slice
 
 
 class GRPOTrainer:
@@ -180,6 +180,9 @@ class GRPOTrainer:
         remain = epochs - self.global_step // n if n else epochs
         skip = self.global_step % n if n else 0
         every = save_interval(self.cfgs, epochs * n if n else None)
+        self.eval_history = getattr(self, 'eval_history', [])
+        if eval_due(self.cfgs, 'begin'):                                          # grpo.py:345-346
+            self.eval_history.append((self.global_step, self.eval()))
         for epoch in range(int(remain)):
             for i, batch in enumerate(prompt_only_dataloader):
                 if epoch == 0 and i < skip:
@@ -188,9 +191,26 @@ class GRPOTrainer:
                 self.global_step += 1
                 if every and self.global_step % every == 0:
                     self.save(tag=self.global_step)
+                if eval_due(self.cfgs, 'steps', self.global_step):                # grpo.py:378-384
+                    self.eval_history.append((self.global_step, self.eval()))
         if cfg_get(self.cfgs, 'logger_cfgs.output_dir', None):
             self.save()
         return history
+
+    def actor_step(self, prompt_batch, generator=None):
+        """One sampled completion per prompt (the evaluation loop's `generate`, base/rl_trainer.py:302-309)."""
+        from ..generation import generate
+        m = lambda k, d: cfg_get(self.cfgs, 'model_cfgs.' + k, d)
+        self.actor_model.wait_optimizer()
+        seq = generate(self.actor_model.module, prompt_batch['input_ids'], prompt_batch['attention_mask'], max_length=int(m('model_max_length', 2048)),
+                       do_sample=True, temperature=float(m('temperature', 1.0)), top_p=float(m('top_p', 1.0)), top_k=m('top_k', 'hf'),
+                       repetition_penalty=float(m('repetition_penalty', 1.0)), eos_token_id=self.eos_token_id, pad_token_id=self.pad_token_id,
+                       generator=generator)
+        return {'input_ids': seq, 'attention_mask': seq.ne(self.pad_token_id)}
+
+    def eval(self, eval_dataloader=None) -> dict:
+        """base/rl_trainer.py:289-329 (common.rl_eval): actor completions for the evaluation prompts."""
+        return rl_eval(self, eval_dataloader)
 
     def save(self, model=None, tag=None, output_dir=None) -> str:
         """base/rl_trainer.py save_transformers: the ACTOR in the layout `from_pretrained` loads (common.save_slice)."""

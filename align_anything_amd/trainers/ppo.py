@@ -58,7 +58,7 @@ def gather_log_probabilities(logits: torch.Tensor, labels: torch.Tensor) -> torc
 
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import (build_span_window, cfg_get, compute_dtype, end_index, expert_parallel_kwargs, get_all_reduce_max,
+from .common import (build_span_window, cfg_get, eval_due, rl_eval, compute_dtype, end_index, expert_parallel_kwargs, get_all_reduce_max,
                      get_all_reduce_mean, pad_rows, save_interval, save_slice)
 
 
@@ -291,6 +291,9 @@ class PPOTrainer(PPOMath):
         # len(prompt dataloader) x epochs x update_iters x per_device_train_batch_size x per_device_prompt_batch_size)
         every = save_interval(self.cfgs, len(prompt_only_dataloader) * epochs * update_iters * int(t('per_device_train_batch_size', 8))
                               * int(t('per_device_prompt_batch_size', 1)) if hasattr(prompt_only_dataloader, '__len__') else None)
+        self.eval_history = getattr(self, 'eval_history', [])
+        if eval_due(self.cfgs, 'begin'):                                                  # ppo.py:422-424
+            self.eval_history.append((self.global_step, self.eval()))
         for _ in range(epochs):
             ptx_iter = itertools.cycle(ptx_dataloader) if use_ptx else None
             for prompt_batch in prompt_only_dataloader:
@@ -311,7 +314,15 @@ class PPOTrainer(PPOMath):
                         history.append(info)
                         if every and self.global_step % every == 0:
                             self.save(tag=self.global_step)
+                        if eval_due(self.cfgs, 'steps', self.global_step):                # ppo.py:471-479
+                            self.eval_history.append((self.global_step, self.eval()))
+            if eval_due(self.cfgs, 'epoch'):                                              # ppo.py:481-485
+                self.eval_history.append((self.global_step, self.eval()))
         return history
+
+    def eval(self, eval_dataloader=None) -> dict:
+        """base/rl_trainer.py:289-329 (common.rl_eval): actor completions for the evaluation prompts."""
+        return rl_eval(self, eval_dataloader)
 
     def save(self, model=None, tag=None, output_dir=None) -> str:
         """ppo.py:549-555 / base/rl_trainer.py save_transformers: the ACTOR in the layout `from_pretrained` loads (common.save_slice)."""

@@ -9,7 +9,7 @@ import torch
 from .. import ops
 from ..engine import NativeEngine
 from ..modeling import build_model
-from .common import END_AT_LAST_POSITION_KINDS, cfg_get, compute_dtype, end_index, get_all_reduce_mean, pad64, save_interval, save_slice
+from .common import END_AT_LAST_POSITION_KINDS, cfg_get, eval_due, compute_dtype, end_index, get_all_reduce_mean, pad64, save_interval, save_slice
 
 
 class RMTrainer:
@@ -99,7 +99,9 @@ class RMTrainer:
     def train(self, train_dataloader=None) -> list:
         """rm.py:265-330 without its logging: `epochs` passes of `train_step`; resumes at `self.global_step` (remaining epochs, the first
         `global_step % len(dataloader)` batches of the resumed epoch skipped, :276-292) and saves `slice_<global_step>` every
-        epochs * len(dataloader) // logger_cfgs.save_total_limit steps (:307-314).  Returns the per-step metrics."""
+        epochs * len(dataloader) // logger_cfgs.save_total_limit steps (:307-314); with `data_cfgs.eval_datasets` it evaluates before the first step, every
+        `eval_interval` steps under eval_strategy 'steps' and after every epoch (:274-325; results in `self.eval_history` as (global_step, dict)).
+        Returns the per-step metrics."""
         dl = train_dataloader if train_dataloader is not None else getattr(self, 'train_dataloader', None)
         if dl is None:
             raise ValueError('RMTrainer.train needs a dataloader of preference batches')
@@ -112,6 +114,9 @@ class RMTrainer:
         remain = epochs - self.global_step // n if n else epochs
         skip = self.global_step % n if n else 0
         every = save_interval(self.cfgs, epochs * n if n else None)
+        self.eval_history = getattr(self, 'eval_history', [])
+        if eval_due(self.cfgs, 'begin'):                                  # rm.py:274-275
+            self.eval_history.append((0, self.eval()))
         for epoch in range(int(remain)):
             for i, batch in enumerate(dl):
                 if epoch == 0 and i < skip:
@@ -120,6 +125,10 @@ class RMTrainer:
                 self.global_step += 1
                 if every and self.global_step % every == 0:
                     self.save(tag=self.global_step)
+                if eval_due(self.cfgs, 'steps', self.global_step):        # rm.py:316-322
+                    self.eval_history.append((self.global_step, self.eval()))
+            if eval_due(self.cfgs, 'always'):                             # rm.py:324-325: after every epoch
+                self.eval_history.append((self.global_step, self.eval()))
         return history
 
     def save(self, model=None, tag=None, output_dir=None) -> str:

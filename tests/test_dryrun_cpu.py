@@ -677,7 +677,15 @@ def test_rm_ppo_grpo_sft_trainers_build_themselves_from_cfgs(launches, tmp_path)
     assert head.shape == (1, 128) and float(head.float().abs().max()) > 0 and float(head.float().abs().max()) <= 128 ** -0.5 + 1e-3
     assert torch.equal(rm.model.module.state_dict()['model.decoder.layers.0.fc1.weight'].float(), hf.state_dict()['model.decoder.layers.0.fc1.weight'].to(torch.bfloat16).float())
     hist = rm.train()
-    assert len(hist) == 4 and rm.model.global_steps == 4
+    assert len(hist) == 4 and rm.model.global_steps == 4 and rm.eval_history == []
+    # with data_cfgs.eval_datasets the loop evaluates before the first step, every eval_interval steps and after the epoch (rm.py:274-325)
+    rm2 = RMTrainer({'train_cfgs': {'per_device_train_batch_size': 8, 'per_device_eval_batch_size': 4, 'epochs': 1, 'lr_scheduler_type': 'constant', 'eval_strategy': 'steps',
+                                    'eval_interval': 2}, 'model_cfgs': {'model_name_or_path': d},
+                     'data_cfgs': data(train_datasets=pref, train_template='PKUSafeRLHF', eval_datasets=pref, eval_template='PKUSafeRLHF', eval_size=None, eval_split=None,
+                                       eval_name=None, eval_data_files=None, eval_optional_args=[])}, {'gradient_clipping': 1.0}, device='cpu')
+    assert len(rm2.eval_dataloader) == 8
+    rm2.train()
+    assert [s for s, _ in rm2.eval_history] == [0, 2, 4, 4] and set(rm2.eval_history[0][1]) == {'eval/accuracy', 'eval/reward_mean', 'eval/reward_std'}
     # ---- SFT: SupervisedDataset through the same constructor
     sft = SupervisedTrainer({'train_cfgs': {'per_device_train_batch_size': 16, 'epochs': 1, 'lr_scheduler_type': 'constant'}, 'model_cfgs': {'model_name_or_path': d},
                              'data_cfgs': data(train_datasets=sup, train_template='Alpaca')}, {'gradient_clipping': 1.0}, device='cpu')
@@ -703,3 +711,68 @@ def test_rm_ppo_grpo_sft_trainers_build_themselves_from_cfgs(launches, tmp_path)
     assert gr.pad_token_id == 3 and gr.eos_token_id == 1 and len(gr.prompt_only_dataloader) == 2 and gr.reward_model is not None
     with pytest.raises(ValueError):
         GRPOTrainer({'train_cfgs': {}, 'model_cfgs': {}}, None, device='cpu')
+
+
+def test_text_image_trainers_build_themselves_from_cfgs(launches, tmp_path):
+    """The headline's OWN modality through the cfgs-only constructors: `DPOTrainer(cfgs, ds_cfgs)` on a LLaVA checkpoint directory (model + a real
+    LlavaProcessor, tests/util.tiny_llava_checkpoint) with `data_cfgs.train_template = 'AA_TI2T'` builds the reference's text_image_to_text
+    PreferenceDataset / PreferenceCollator (datasets/text_image_to_text/preference.py:77-263) over a local parquet dataset with an Image column:
+    batches carry `pixel_values` (the same image for the chosen and the rejected row), the processor expands `<image>` to the tower's 4 image
+    tokens, and `train()` runs the epoch through the tower, the projector and the decoder.  `PPOTrainerTI2T(cfgs, ds_cfgs)` builds actor /
+    reference / reward / critic from the same directory, prompts through the reference's text_image_to_text PromptOnlyDataset, rolls out with
+    the native `generate`, and evaluates on `data_cfgs.eval_datasets` on the reference's schedule (ppo.py:422-485)."""
+    import os
+    if not os.path.isdir('/root/reference/align_anything'):
+        pytest.skip('the reference package (dataset / template plugins) is only present in the build container')
+    from oracle import _shim
+    _shim.install()
+    from tests.util import ti2t_parquet_dataset, tiny_llava_checkpoint
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    from align_anything_amd.trainers.ppo_ti2t import PPOTrainerTI2T
+    d = str(tmp_path / 'llava')
+    hf, _ = tiny_llava_checkpoint(d)
+    data_dir = ti2t_parquet_dataset(str(tmp_path / 'data'))
+    data = lambda **kw: dict({'train_datasets': data_dir, 'train_template': 'AA_TI2T', 'train_size': None, 'train_split': 'train', 'train_name': None,
+                              'train_data_files': None, 'train_optional_args': [], 'eval_datasets': None, 'ptx_datasets': None}, **kw)
+    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'weight_decay': 0.0,
+                           'per_device_train_batch_size': 4, 'epochs': 1},
+            'model_cfgs': {'model_name_or_path': d, 'model_max_length': 256}, 'data_cfgs': data()}
+    tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, device='cpu')
+    assert tr.model_cfg['kind'] == 'llava' and type(tr.processor).__name__ == 'LlavaProcessor' and len(tr.train_dataloader) == 3
+    assert type(tr.train_dataloader.loader.dataset).__module__ == 'align_anything.datasets.text_image_to_text.preference'
+    sd = tr.policy.state_dict()
+    hsd = hf.state_dict()
+    for tail in ('encoder.layers.1.mlp.fc1.weight', 'multi_modal_projector.linear_2.bias', 'language_model.layers.1.mlp.down_proj.weight', 'lm_head.weight'):
+        mine, theirs = [k for k in sd if k.endswith(tail)], [k for k in hsd if k.endswith(tail)]          # key prefixes differ between HF versions
+        assert len(mine) == 1 and len(theirs) == 1 and torch.equal(sd[mine[0]].float(), hsd[theirs[0]].to(torch.bfloat16).float()), tail
+    b = next(iter(tr.train_dataloader))        # an abandoned iterator: the prefetcher retires its producer before train() starts another
+    assert b['input_ids'].shape[0] == 8 and b['pixel_values'].shape == (8, 3, 28, 28) and torch.equal(b['pixel_values'][:4], b['pixel_values'][4:])
+    assert bool(((b['input_ids'] == 4).sum(1) == 4).all()) and bool((b['input_ids'][:, -1] == 1).all()) and '_window' in b
+    assert len(b['meta_info']['response_lens']) == 8
+    del launches[:]
+    hist = tr.train()
+    assert len(hist) == 3 and tr.model.global_steps == 3
+    for k in ('aa_patch_im2col', 'aa_clip_embed', 'aa_image_slot_index', 'aa_dpo_loss_fwd_bwd', 'aa_adamw_flat'):
+        assert k in launches, k
+    # ---- PPO, text + image: four models from the directory, prompts and evaluation prompts from data_cfgs
+    pc = {'train_cfgs': {'per_device_prompt_batch_size': 4, 'per_device_train_batch_size': 4, 'epochs': 1, 'update_iters': 1, 'actor_lr_scheduler_type': 'constant',
+                         'critic_lr_scheduler_type': 'constant', 'eval_strategy': 'steps', 'eval_interval': 2},
+          'model_cfgs': {'actor_model_name_or_path': d, 'reward_model_name_or_path': d, 'reward_critic_model_name_or_path': d, 'model_max_length': 128,
+                         'max_new_tokens': 6, 'temperature': 1.0, 'top_p': 1.0},
+          'data_cfgs': data(eval_datasets=data_dir, eval_template='AA_TI2T', eval_size=4, eval_split='train', eval_name=None, eval_data_files=None,
+                            eval_optional_args=[])}
+    ppo = PPOTrainerTI2T(pc, {'gradient_clipping': 1.0}, device='cpu')
+    assert type(ppo.prompt_only_dataloader.loader.dataset).__module__ == 'align_anything.datasets.text_image_to_text.prompt_only'
+    assert len(ppo.prompt_only_dataloader) == 3 and len(ppo.eval_dataloader) == 1 and ppo.reward_critic_model.module.kind == 'llava'
+    pb = next(iter(ppo.prompt_only_dataloader))
+    assert pb['pixel_values'].shape == (4, 3, 28, 28) and bool((pb['attention_mask'][:, -1] == 1).all())
+    del launches[:]
+    decode = ppo.tokenizer.batch_decode          # the sampler is stubbed out here: "sampled" ids are whatever torch.empty held
+    ppo.tokenizer.batch_decode = lambda ids, **kw: decode(ids.clamp(0, 319), **kw)
+    hist = ppo.train()
+    assert len(hist) == 3 and 'train/reward_critic_loss' in hist[-1] and ppo.actor_model.global_steps == 3
+    # evaluated before the first step and at step 2 (eval_strategy 'steps', interval 2): prompt / completion texts of the 4 evaluation prompts
+    assert [s for s, _ in ppo.eval_history] == [0, 2]
+    ev = ppo.eval_history[-1][1]
+    assert len(ev['eval/prompts']) == 4 and len(ev['eval/generated']) == 4 and all(isinstance(x, str) for x in ev['eval/generated'])
+    assert 'aa_attn_decode' in launches and 'aa_ppo_actor_loss' in launches

@@ -947,3 +947,43 @@ def test_checkpoint_reader_loads_what_save_pretrained_writes_for_every_backbone(
         assert m.load_state_dict(LazyCheckpoint(d, kind)) == [], kind
         got = m.state_dict()
         assert set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want), kind
+
+
+def test_device_prefetcher_retires_the_producer_of_an_abandoned_iterator():
+    """`next(iter(loader))`, a `break` or an exception in the step leave a prefetch iterator unfinished: its producer thread must stop (it would hold
+    `depth` staged batches forever, and run the dataset -- a non-re-entrant fast tokenizer -- next to the producer of the following iterator)."""
+    import threading
+    import time
+    from align_anything_amd.data import DevicePrefetcher
+    active, peak, lock = [0], [0], threading.Lock()
+
+    class Loader:
+        def __len__(self):
+            return 50
+
+        def __iter__(self):
+            for i in range(50):
+                with lock:
+                    active[0] += 1
+                    peak[0] = max(peak[0], active[0])
+                time.sleep(0.002)
+                with lock:
+                    active[0] -= 1
+                yield {'input_ids': torch.full((2, 3), i)}
+
+    pf = DevicePrefetcher(Loader(), 'cpu', depth=2)
+    before = threading.active_count()
+    first = next(iter(pf))
+    assert int(first['input_ids'][0, 0]) == 0
+    for i, b in enumerate(pf):
+        if i == 3:
+            break
+    got = [int(b['input_ids'][0, 0]) for b in pf]
+    assert got == list(range(50)) and peak[0] == 1            # never two producers inside the dataset at once
+    with pytest.raises(ZeroDivisionError):
+        for b in pf:
+            1 / 0
+    deadline = time.time() + 5
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.01)
+    assert threading.active_count() == before

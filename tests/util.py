@@ -55,3 +55,49 @@ def tiny_qwen2audio_cfg():
 def tiny_qwen3moe_cfg():
     from align_anything_amd import configs
     return configs.qwen3moe_cfg(128, 64, 2, 2, 1, 320, 8, 2, head_dim=64, rope_theta=10000.0, max_position_embeddings=256)
+
+
+def tiny_llava_checkpoint(path: str, seed: int = 0):
+    """A LLaVA checkpoint directory as `save_pretrained` writes it, built offline: HF LlavaForConditionalGeneration (CLIP tower 3 x 128 on 28 x 28 /
+    14 images -> 4 image tokens, Llama 2 x 128) with random weights, plus a REAL `LlavaProcessor` (PIL CLIP image processor, word-level fast
+    tokenizer with `<image>` / `<pad>` tokens, a chat template that renders {'type': 'image'} parts as `<image>`).  Returns (hf model, processor)."""
+    import transformers as tf
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    vocab = {w: i for i, w in enumerate(['<s>', '</s>', '<unk>', '<pad>', '<image>'] + [f'w{i}' for i in range(315)])}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token='<unk>'))
+    tk.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    fast = tf.PreTrainedTokenizerFast(tokenizer_object=tk, bos_token='<s>', eos_token='</s>', unk_token='<unk>', pad_token='<pad>')
+    fast.add_special_tokens({'additional_special_tokens': ['<image>']})
+    from transformers.models.clip.image_processing_pil_clip import CLIPImageProcessorPil
+    ip = CLIPImageProcessorPil(size={'shortest_edge': 28}, crop_size={'height': 28, 'width': 28})
+    template = ("{% for m in messages %}{{ m['role'] }} : {% for c in m['content'] %}{% if c['type']=='image' %}<image> {% else %}{{ c['text'] }}{% endif %}"
+                "{% endfor %} {% if m['role']=='assistant' %}</s> {% endif %}{% endfor %}{% if add_generation_prompt %}assistant :{% endif %}")
+    processor = tf.LlavaProcessor(image_processor=ip, tokenizer=fast, patch_size=14, vision_feature_select_strategy='default',
+                                  num_additional_image_tokens=1, chat_template=template)
+    vc = tf.CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, image_size=28, patch_size=14, projection_dim=64)
+    tc = tf.LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, vocab_size=320,
+                        rms_norm_eps=1e-5, max_position_embeddings=256)
+    cfg = tf.LlavaConfig(vision_config=vc, text_config=tc, image_token_id=4, image_seq_length=4, pad_token_id=3)
+    torch.manual_seed(seed)
+    hf = tf.LlavaForConditionalGeneration(cfg).eval()
+    hf.save_pretrained(path)
+    processor.save_pretrained(path)
+    return hf, processor
+
+
+def ti2t_parquet_dataset(path: str, n: int = 12, seed: int = 0) -> str:
+    """A local dataset directory `datasets.load_dataset(path)` reads, in the raw layout the reference's `AA_TI2T` template formats
+    (configs/format_dataset.py:465-560): question, image (an Image feature -> PIL), response_1, response_2, overall_response."""
+    import os
+    import datasets
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    words = lambda k: ' '.join(f'w{int(i)}' for i in rng.randint(0, 300, k))
+    ds = datasets.Dataset.from_dict({
+        'question': [words(rng.randint(2, 7)) for _ in range(n)],
+        'image': [Image.fromarray((rng.rand(30 + i, 40, 3) * 255).astype('uint8')) for i in range(n)],
+        'response_1': [words(rng.randint(1, 9)) for _ in range(n)], 'response_2': [words(rng.randint(1, 9)) for _ in range(n)],
+        'overall_response': [1 + i % 2 for i in range(n)]}).cast_column('image', datasets.Image())
+    os.makedirs(path, exist_ok=True)
+    ds.to_parquet(os.path.join(path, 'train.parquet'))
+    return path
