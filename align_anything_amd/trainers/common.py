@@ -301,6 +301,23 @@ def resolve_pretrained(cfgs, device, *, trainable, head='lm', dtype=None, path_k
                            build_kwargs=build_kwargs, with_tokenizer=with_tokenizer)
 
 
+def infer_modality(trainer) -> str:
+    """Which `align_anything.datasets.<modality>` package a trainer's batches come from.  The reference fixes it per trainer MODULE
+    (trainers/text_image_to_text/dpo.py imports datasets.text_image_to_text, trainers/text_audio_to_text/dpo.py datasets.text_audio_to_text, ...);
+    the native trainers are one class per algorithm, so: an explicit `trainer.modality` or `data_cfgs.modality` wins, else the policy's backbone
+    decides -- Qwen2-Audio -> text_audio_to_text, any other model loaded with a processor -> text_image_to_text, else text_to_text."""
+    explicit = getattr(trainer, 'modality', None) or cfg_get(trainer.cfgs, 'data_cfgs.modality', None)
+    if explicit:
+        return str(explicit)
+    kind = (getattr(trainer, 'model_cfg', None) or {}).get('kind')
+    if kind is None:
+        for name in ('actor_model', 'model'):
+            kind = getattr(getattr(getattr(trainer, name, None), 'module', None), 'kind', None) or kind
+    if kind == 'qwen2audio':
+        return 'text_audio_to_text'
+    return 'text_image_to_text' if getattr(trainer, 'processor', None) is not None else 'text_to_text'
+
+
 def get_dataloaders(trainer, train_dtype_name: str, eval_dtype_name: str | None = None, modality: str | None = None, ptx_dtype_name: str | None = None,
                     rl: bool = False):
     """`SupervisedTrainerBase.get_dataloaders` (base/supervised_trainer.py:79-232) and, with rl=True, `RLTrainerBase.get_dataloaders`
@@ -326,7 +343,7 @@ def get_dataloaders(trainer, train_dtype_name: str, eval_dtype_name: str | None 
     if not any(d(p + '_datasets') for p in want):
         return (None,) * len(want)
     if modality is None:
-        modality = 'text_image_to_text' if getattr(trainer, 'processor', None) is not None else 'text_to_text'
+        modality = infer_modality(trainer)
     try:
         ds_mod = importlib.import_module(f'align_anything.datasets.{modality}')
         from align_anything.configs.template import ChatTemplate
