@@ -172,6 +172,27 @@ def test_full_ppo_iteration_rollout_then_update():
     assert abs(info['train/kl_divergence']) < 1e-4
 
 
+def test_rl_eval_samples_completions_and_follows_the_reference_schedule():
+    """`RLTrainerBase.eval` (base/rl_trainer.py:289-329, common.rl_eval) on the native `generate`: every evaluation prompt gets a sampled
+    completion (token ids here: this constructor carries no tokenizer), the evaluation loader is a DevicePrefetcher whose first iterator is
+    abandoned (its producer must retire), and `train()` evaluates before the first step and every `eval_interval` steps (ppo.py:422-479)."""
+    from align_anything_amd.data import DevicePrefetcher
+    tr, z, cfg, actor_sd, old_sd, rm_sd, ids, mask, start = _setup()
+    tr.cfgs = {'model_cfgs': {'model_max_length': 30, 'temperature': 1.0, 'top_p': 0.95, 'pad_token_id': 1, 'eos_token_id': 2},
+               'data_cfgs': {'eval_datasets': 'handed over as a loader'},
+               'train_cfgs': dict(tr.cfgs['train_cfgs'], eval_strategy='steps', eval_interval=2, per_device_train_batch_size=3, epochs=1, update_iters=1)}
+    batches = [{'input_ids': ids[:, k:k + 20].contiguous(), 'attention_mask': torch.ones(3, 20, dtype=torch.long)} for k in (0, 10, 20)]
+    tr.eval_dataloader = DevicePrefetcher(batches[:2], 'cuda:0')
+    first = next(iter(tr.eval_dataloader))
+    assert first['input_ids'].is_cuda and torch.equal(first['input_ids'].cpu(), batches[0]['input_ids'])
+    ev = tr.eval()
+    assert len(ev['eval/prompts']) == 6 and len(ev['eval/generated']) == 6
+    assert ev['eval/prompts'][3] == batches[1]['input_ids'][0].tolist()
+    assert all(1 <= len(g) <= 10 and all(0 <= t < 320 for t in g) for g in ev['eval/generated'])
+    hist = tr.train(DevicePrefetcher(batches, 'cuda:0'), generator=torch.Generator(device='cuda').manual_seed(5))
+    assert len(hist) == 3 and [s for s, _ in tr.eval_history] == [0, 2] and all(v == v for v in hist[-1].values())
+
+
 def test_qwen2_style_text_model_dpo_step_vs_oracle():
     """Llama block with q/k/v biases and GQA (Qwen2 family, from_hf_config 'qwen2'): DPO loss and gradients
     (incl. the fused bias gradient) against the oracle."""
