@@ -20,6 +20,12 @@
 //      epilogue.  Rounding points differ from hf LlamaRMSNorm (w * bf16(x * rstd)) by bf16 noise; rollout sampling only.
 //   2: SwiGLU.  x = [gate | up] rows of width 2K; the fragment is bf16(bf16(silu(gate)) * up), exactly aa_swiglu_fwd's value.
 //   3: x as is, W pre-arranged by aa_swizzle_weights_bf16 so that every fragment load of a wave is 1 KB contiguous (below).
+//   4: RMSNorm on strip-major weights whose COLUMNS were multiplied by the norm weight when the copy was made (aa_swizzle_weights_scaled_bf16;
+//      the weights are frozen during a rollout): rmsnorm(x) W^T = rstd * (x (W diag(w))^T), so the prologue only accumulates sum(x^2) from the
+//      fragments it feeds to the MFMA unchanged (no norm-weight loads, no extra registers: 8 k-steps stay in flight) and the epilogue scales the
+//      finished dot product by rstd.  Removes the RMSNorm launch in front of the q/k/v, gate/up and lm_head projections: 57 of the 211 launches
+//      of a Qwen2-VL-7B decode position, ~4.8 us each whatever their size (profiles/r04_decode_trace_summary.txt).  Rounding: bf16(W w) in
+//      place of w * bf16(x rstd) -- bf16 noise on the logits, rollout sampling only (AA_DECODE_NORM_FOLD=0 restores the separate kernel).
 template <int PRO>
 __device__ __forceinline__ bf16x8 skinny_x(const bf16_t* __restrict__ xp, const bf16_t* __restrict__ nwp, int k, int K, float& ss) {
     const u16x8 v = *reinterpret_cast<const u16x8*>(xp + k);
@@ -42,6 +48,13 @@ __device__ __forceinline__ bf16x8 skinny_x(const bf16_t* __restrict__ xp, const 
             o[j] = f2bf(rbf(gf * aa_sigmoid<false>(gf)) * bf2f(u[j]));
         }
         return __builtin_bit_cast(bf16x8, o);
+    } else if constexpr (PRO == 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f(v[j]);
+            ss += f * f;
+        }
+        return __builtin_bit_cast(bf16x8, v);
     } else {
         return __builtin_bit_cast(bf16x8, v);
     }
@@ -54,7 +67,7 @@ __device__ __forceinline__ void skinny_trip(const bf16_t* __restrict__ wp, const
     bf16x8 wf[S], xf[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        wf[s] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (PRO == 3 ? (long)(k + s * 32) * 16 : (long)(k + s * 32))));
+        wf[s] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + ((PRO == 3 || PRO == 4) ? (long)(k + s * 32) * 16 : (long)(k + s * 32))));
         xf[s] = skinny_x<PRO>(xp, nwp, k + s * 32, K, ss);
     }
 #pragma unroll
@@ -100,7 +113,8 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     const int nrow = min(n0 + l15, N - 1);
     const int mrow = min(l15, M - 1);
     // PRO 3 = strip-major swizzled weights: [N/16][K/32][lane = n%16 + 16*(k%32/8)][8] -- a wave's fragment load is 1 KB contiguous
-    const bf16_t* wp = PRO == 3 ? W + (long)blockIdx.x * 16 * K + lane * 8 : W + (long)nrow * ldw + g * 8;
+    constexpr bool SWZ = PRO == 3 || PRO == 4, NORM = PRO == 1 || PRO == 4;
+    const bf16_t* wp = SWZ ? W + (long)blockIdx.x * 16 * K + lane * 8 : W + (long)nrow * ldw + g * 8;
     const bf16_t* xp = x + (long)mrow * ldx + g * 8;
     const bf16_t* nwp = PRO == 1 ? norm_w + g * 8 : nullptr;
     float ss = 0.f;
@@ -118,14 +132,14 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     if constexpr (S > 4) { for (; k + 128 <= k_hi; k += 128) skinny_trip<PRO, 4>(wp, xp, nwp, k, K, ss, acc0, acc1); }   // a 16-wave strip's 224-k share: 4 + 2 + 1 steps
     for (; k + 64 <= k_hi; k += 64) skinny_trip<PRO, 2>(wp, xp, nwp, k, K, ss, acc0, acc1);
     if (k < k_hi) {
-        const bf16x8 wf = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (PRO == 3 ? (long)k * 16 : (long)k)));
+        const bf16x8 wf = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (SWZ ? (long)k * 16 : (long)k)));
         const bf16x8 xf = skinny_x<PRO>(xp, nwp, k, K, ss);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc0, 0, 0, 0);
     }
     // D[i = n (4g + r)][j = m (l15)]
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][l15] = acc0[r] + acc1[r];
-    if constexpr (PRO == 1) {      // lane (l15, g) holds row l15's sum of squares over its k-chunks: fold the 4 g groups
+    if constexpr (NORM) {          // lane (l15, g) holds row l15's sum of squares over its k-chunks: fold the 4 g groups
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
         if (g == 0) ssred[wave][l15] = ss;
@@ -138,6 +152,13 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
             float v1 = 0.f, v2 = 0.f;
 #pragma unroll
             for (int w = 0; w < NWAVE; ++w) { v1 += red[w][c][m]; v2 += red[w][c + 8][m]; }
+            if constexpr (NORM) {
+                float q = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWAVE; ++w) q += ssred[w][m];
+                const float rs = rsqrtf(q / (float)K + eps);
+                v1 *= rs; v2 *= rs;
+            }
             if constexpr (EPI == 1) {
                 const float gf = rbf(v1), uf = rbf(v2);
                 out[(long)m * ldo + blockIdx.x * 8 + c] = f2bf(rbf(gf * aa_sigmoid<false>(gf)) * uf);
@@ -170,7 +191,7 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < NWAVE; ++w) v += red[w][nn][m];
-        if constexpr (PRO == 1) {
+        if constexpr (NORM) {
             float q = 0.f;
 #pragma unroll
             for (int w = 0; w < NWAVE; ++w) q += ssred[w][m];
@@ -242,7 +263,8 @@ extern "C" int aa_gemm_skinny_fused_bf16(const void* x, const void* W, void* out
 // mode: 0 = strip s holds rows 16 s .. 16 s + 15; 1 = rows of a fused [gate; up] weight (N = 2 F): strip s = gate rows 8 s .. + 7 then the up
 // rows F + 8 s .. + 7 (EPI 1 of the strip kernel); 2 = head_dim-128 heads: strip 8 h + s' = rows 128 h + 8 s' .. + 7 then the rows 64 further
 // (the rotation partners, EPI 2)
-__global__ __launch_bounds__(256) void swizzle_weights_kernel(const bf16_t* __restrict__ W, long ld, bf16_t* __restrict__ out, int N, int K, int mode) {
+__global__ __launch_bounds__(256) void swizzle_weights_kernel(const bf16_t* __restrict__ W, long ld, bf16_t* __restrict__ out, int N, int K, int mode,
+                                                              const bf16_t* __restrict__ kscale) {
     const long kblocks = K >> 5;
     const long total = (long)((N + 15) >> 4) * kblocks * 64;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -256,6 +278,11 @@ __global__ __launch_bounds__(256) void swizzle_weights_kernel(const bf16_t* __re
         const long k = kb * 32 + (lane >> 4) * 8;
         u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (n < N) v = *reinterpret_cast<const u16x8*>(W + n * ld + k);
+        if (kscale != nullptr) {       // column scaling (PRO 4 of the strip kernel): W[n, k] * w_norm[k], one rounding
+            const u16x8 sc = *reinterpret_cast<const u16x8*>(kscale + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * bf2f(sc[j]));
+        }
         *reinterpret_cast<u16x8*>(out + idx * 8) = v;
     }
 }
@@ -263,7 +290,7 @@ extern "C" int aa_swizzle_weights_bf16(const void* W, long ld, void* out, int N,
     AA_REQUIRE(N > 0 && K > 0 && K % 32 == 0 && ld % 8 == 0, "aa_swizzle_weights_bf16: N=%d K=%d ld=%ld (K %% 32 == 0, ld %% 8 == 0)", N, K, ld);
     const long total = (long)((N + 15) >> 4) * (K >> 5) * 64;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(swizzle_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K, 0);
+    hipLaunchKernelGGL(swizzle_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K, 0, (const bf16_t*)nullptr);
     AA_CHECK_LAUNCH("aa_swizzle_weights_bf16");
     return AA_OK;
 }
@@ -275,7 +302,7 @@ extern "C" int aa_swizzle_weights_perm_bf16(const void* W, long ld, void* out, i
     AA_REQUIRE((mode == 1 && N % 16 == 0) || (mode == 2 && N % 128 == 0), "aa_swizzle_weights_perm_bf16: mode %d needs N=%d a multiple of %d", mode, N, mode == 1 ? 16 : 128);
     const long total = (long)(N >> 4) * (K >> 5) * 64;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(swizzle_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K, mode);
+    hipLaunchKernelGGL(swizzle_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K, mode, (const bf16_t*)nullptr);
     AA_CHECK_LAUNCH("aa_swizzle_weights_perm_bf16");
     return AA_OK;
 }
@@ -309,6 +336,46 @@ extern "C" int aa_gemm_skinny_swz_rope_cache_bf16(const void* x, const void* Wsw
     SkinnyEpi e{pos, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)cache, ldc, Tmax, slot, H, Hkv};
     launch_skinny<3, 2>(x, Wswz, q_out, M, (H + 2 * Hkv) * 128, K, ldx, K, ldq, bias, nullptr, 0, nullptr, 0.f, (hipStream_t)stream, e);
     AA_CHECK_LAUNCH("aa_gemm_skinny_swz_rope_cache_bf16");
+    return AA_OK;
+}
+
+// ---- RMSNorm folded into the strip kernel (PRO 4).  aa_swizzle_weights_scaled_bf16 makes the strip-major copy (mode 0 / 1 / 2 as above) of
+// W diag(kscale), kscale = the weight [K] of the RMSNorm in front of the projection; the three entry points below are their namesakes without
+// `_norm` applied to the UN-normalised residual stream x: out = rmsnorm(x; kscale, eps) W^T (+ bias, + residual / SwiGLU / rotary + cache write),
+// hf LlamaRMSNorm + the projection of hf LlamaDecoderLayer (hf:models/llama/modeling_llama.py:62-67) up to bf16 rounding of W kscale.
+extern "C" int aa_swizzle_weights_scaled_bf16(const void* W, long ld, void* out, int N, int K, int mode, const void* kscale, void* stream) {
+    AA_REQUIRE(N > 0 && K > 0 && K % 32 == 0 && ld % 8 == 0 && kscale != nullptr, "aa_swizzle_weights_scaled_bf16: N=%d K=%d ld=%ld (K %% 32 == 0, ld %% 8 == 0), kscale required", N, K, ld);
+    AA_REQUIRE(mode == 0 || (mode == 1 && N % 16 == 0) || (mode == 2 && N % 128 == 0), "aa_swizzle_weights_scaled_bf16: mode %d does not fit N=%d", mode, N);
+    const long total = (long)((N + 15) >> 4) * (K >> 5) * 64;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(swizzle_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K, mode, (const bf16_t*)kscale);
+    AA_CHECK_LAUNCH("aa_swizzle_weights_scaled_bf16");
+    return AA_OK;
+}
+extern "C" int aa_gemm_skinny_swz_norm_bf16(const void* x, const void* Wswz, void* out, int M, int N, int K, long ldx, long ldo,
+                                            const void* bias, const void* residual, long ldr, float eps, void* stream) {
+    AA_REQUIRE(M >= 1 && M <= 16, "aa_gemm_skinny_swz_norm_bf16: M=%d must be in [1, 16]", M);
+    AA_REQUIRE(N > 0 && K > 0 && K % 32 == 0 && ldx % 8 == 0, "aa_gemm_skinny_swz_norm_bf16: N=%d K=%d (K %% 32 == 0), ldx %% 8 == 0", N, K);
+    launch_skinny<4>(x, Wswz, out, M, N, K, ldx, K, ldo, bias, residual, ldr, nullptr, eps, (hipStream_t)stream);
+    AA_CHECK_LAUNCH("aa_gemm_skinny_swz_norm_bf16");
+    return AA_OK;
+}
+extern "C" int aa_gemm_skinny_swz_norm_glu_bf16(const void* x, const void* Wswz, void* act, int M, int F, int K, long ldx, long ldo, float eps, void* stream) {
+    AA_REQUIRE(M >= 1 && M <= 16, "aa_gemm_skinny_swz_norm_glu_bf16: M=%d must be in [1, 16]", M);
+    AA_REQUIRE(F > 0 && F % 8 == 0 && K > 0 && K % 32 == 0 && ldx % 8 == 0, "aa_gemm_skinny_swz_norm_glu_bf16: F=%d (multiple of 8) K=%d (multiple of 32)", F, K);
+    launch_skinny<4, 1>(x, Wswz, act, M, 2 * F, K, ldx, K, ldo, nullptr, nullptr, 0, nullptr, eps, (hipStream_t)stream);
+    AA_CHECK_LAUNCH("aa_gemm_skinny_swz_norm_glu_bf16");
+    return AA_OK;
+}
+extern "C" int aa_gemm_skinny_swz_norm_rope_cache_bf16(const void* x, const void* Wswz, void* q_out, int M, int H, int Hkv, int K, long ldx, long ldq,
+                                                       const void* bias, const int* pos, const void* cos_t, const void* sin_t, void* cache, long ldc,
+                                                       int Tmax, const int64_t* slot, float eps, void* stream) {
+    AA_REQUIRE(M >= 1 && M <= 16, "aa_gemm_skinny_swz_norm_rope_cache_bf16: M=%d must be in [1, 16]", M);
+    AA_REQUIRE(H > 0 && Hkv > 0 && K > 0 && K % 32 == 0 && ldx % 8 == 0, "aa_gemm_skinny_swz_norm_rope_cache_bf16: H=%d Hkv=%d K=%d (multiple of 32)", H, Hkv, K);
+    AA_REQUIRE(ldc >= 2L * Hkv * 128 && Tmax > 0 && ldq >= (long)H * 128, "aa_gemm_skinny_swz_norm_rope_cache_bf16: ldc >= 2 * Hkv * 128, ldq >= H * 128");
+    SkinnyEpi e{pos, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)cache, ldc, Tmax, slot, H, Hkv};
+    launch_skinny<4, 2>(x, Wswz, q_out, M, (H + 2 * Hkv) * 128, K, ldx, K, ldq, bias, nullptr, 0, nullptr, eps, (hipStream_t)stream, e);
+    AA_CHECK_LAUNCH("aa_gemm_skinny_swz_norm_rope_cache_bf16");
     return AA_OK;
 }
 

@@ -164,10 +164,16 @@ class LlamaStack:
         # a shape the permuted copies do not fit (ffn not a multiple of 8) falls back to the plain strip copy + the separate kernel, it does not raise
         modes = {'qkv': 'rope128' if (epi and self.cfg['head_dim'] == 128) else 'plain', 'o': 'plain',
                  'gu': 'glu' if (epi and (2 * self.cfg['intermediate_size']) % 16 == 0) else 'plain', 'down': 'plain'}
-        if getattr(self, '_dw', None) is not None and any(W[k].mode != modes[k] for W in self._dw[:1] for k in modes):
+        # AA_DECODE_NORM_FOLD (default on): the copies of the two projections that follow an RMSNorm are made of W diag(norm weight) and the strip
+        # kernel finishes the norm itself (csrc/decode.hip PRO 4): two launches less per layer and position; 0 = the separate norm kernel
+        fold = os.environ.get('AA_DECODE_NORM_FOLD', '1') != '0'
+        P = self.store.p
+        scale = (lambda L, k: P[L['ln1']] if k == 'qkv' else (P[L['ln2']] if k == 'gu' else None)) if fold else (lambda L, k: None)
+        if getattr(self, '_dw', None) is not None and any(W[k].mode != modes[k] or W[k].folded != (scale(L, k) is not None)
+                                                          for L, W in zip(self.layers[:1], self._dw[:1]) for k in modes):
             self._dw = None
         if getattr(self, '_dw', None) is None:
-            self._dw = [{k: ops.SwizzledWeight(L[k].w, modes[k]) for k in ('qkv', 'o', 'gu', 'down')} for L in self.layers]
+            self._dw = [{k: ops.SwizzledWeight(L[k].w, modes[k], kscale=scale(L, k)) for k in ('qkv', 'o', 'gu', 'down')} for L in self.layers]
         else:
             for L, W in zip(self.layers, self._dw):
                 for k, sw in W.items():
@@ -193,17 +199,20 @@ class LlamaStack:
             cl = cache[li]
             if dw is not None:       # strip-major weight copies: the element-wise kernels run on their own
                 W = dw[li]
-                n1 = ops.rmsnorm_fwd(x, P[L['ln1']], eps)[0]
-                if W['qkv'].mode == 'rope128':      # q/k/v GEMV + RoPE + cache write in one launch
-                    q = ops.gemm_skinny_rope_cache(n1, W['qkv'], L['qkv'].b, H, Hkv, pos, self.cos, self.sin, cl, Tmax, t)
+                # folded copies (W diag(norm weight)) take the residual stream itself and finish the RMSNorm in the strip kernel
+                f1 = eps if W['qkv'].folded else None
+                n1 = x if W['qkv'].folded else ops.rmsnorm_fwd(x, P[L['ln1']], eps)[0]
+                if W['qkv'].mode == 'rope128':      # (norm +) q/k/v GEMV + RoPE + cache write in one launch
+                    q = ops.gemm_skinny_rope_cache(n1, W['qkv'], L['qkv'].b, H, Hkv, pos, self.cos, self.sin, cl, Tmax, t, eps=f1)
                 else:
-                    qkv = ops.linear_small(n1, W['qkv'], bias=L['qkv'].b)
+                    qkv = ops.linear_small(n1, W['qkv'], bias=L['qkv'].b, fold_eps=f1)
                     ops.decode_rope_cache(qkv, H, Hkv, hd, pos, self.cos, self.sin, cl, Tmax, t)
                     q = qkv[:, :qw]
                 attn = ops.attn_decode(q, cl, cl[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
                 x_mid = ops.linear_small(attn, W['o'], residual=x)
-                n2 = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)[0]
-                act = ops.gemm_skinny_glu(n2, W['gu']) if W['gu'].mode == 'glu' else ops.swiglu_fwd(ops.linear_small(n2, W['gu']))
+                f2 = eps if W['gu'].folded else None
+                n2 = x_mid if W['gu'].folded else ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)[0]
+                act = ops.gemm_skinny_glu(n2, W['gu'], eps=f2) if W['gu'].mode == 'glu' else ops.swiglu_fwd(ops.linear_small(n2, W['gu'], fold_eps=f2))
                 x = ops.linear_small(act, W['down'], residual=x_mid)
                 continue
             qkv = ops.linear_small(x, L['qkv'].w, bias=L['qkv'].b, norm=(P[L['ln1']], eps))
@@ -431,8 +440,11 @@ class LMHead:
         """lm_head in the strip kernel's order for the rollout (see LlamaStack.prepare_decode)."""
         if N > 16 or self.store.dtype != bf16 or os.environ.get('AA_DECODE_SWIZZLE', '1') == '0' or ops.DECODE_FUSED:
             return None
+        fold = self.kind == 'rms' and os.environ.get('AA_DECODE_NORM_FOLD', '1') != '0'      # the final RMSNorm folded into the lm_head copy
+        if getattr(self, '_dw', None) is not None and self._dw.folded != fold:
+            self._dw = None
         if getattr(self, '_dw', None) is None:
-            self._dw = ops.SwizzledWeight(self._w())
+            self._dw = ops.SwizzledWeight(self._w(), kscale=self.store.p[self.norm_w] if fold else None)
         else:
             self._dw.update(self._w())
         return self._dw
@@ -440,6 +452,8 @@ class LMHead:
     def logits_rows(self, x_rows, w=None):
         """Logits of a handful of rows (decode): norm + skinny lm_head (w: `prepare_decode` result or None)."""
         P = self.store.p
+        if w is not None and getattr(w, 'folded', False):
+            return ops.linear_small(x_rows, w, fold_eps=self.eps)
         if self.kind == 'rms':
             if x_rows.dtype == bf16 and w is None:
                 return ops.linear_small(x_rows, self._w(), norm=(P[self.norm_w], self.eps))     # (norm folded in with ops.DECODE_FUSED)

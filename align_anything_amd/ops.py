@@ -887,20 +887,31 @@ class SwizzledWeight:
     that follows the projection in its epilogue (aa_swizzle_weights_perm_bf16: [gate; up] pairs / rotation pairs of head_dim-128 heads)."""
     MODES = {'plain': 0, 'glu': 1, 'rope128': 2}
 
-    def __init__(self, w, mode='plain'):
+    def __init__(self, w, mode='plain', kscale=None):
+        """kscale: the weight [K] of the RMSNorm in front of this projection -> the copy holds W diag(kscale) (`folded`), and the strip kernel
+        takes the un-normalised residual stream and an eps (aa_gemm_skinny_swz_norm_*: the norm's own launch disappears)."""
         if w.dim() != 2 or w.dtype != bf16 or w.stride(1) != 1 or w.shape[1] % 32:
             raise RuntimeError(f'SwizzledWeight: expected a row-major bf16 [N, K] matrix with K % 32 == 0, got {tuple(w.shape)} {w.dtype}')
         self.N, self.K, self.mode = int(w.shape[0]), int(w.shape[1]), mode
         if (mode == 'glu' and self.N % 16) or (mode == 'rope128' and self.N % 128) or mode not in self.MODES:
             raise RuntimeError(f'SwizzledWeight: mode {mode!r} does not fit N = {self.N}')
+        if kscale is not None and (kscale.dtype != bf16 or kscale.numel() != self.K or not kscale.is_contiguous()):
+            raise RuntimeError(f'SwizzledWeight: kscale must be a contiguous bf16 vector of K = {self.K} elements')
+        self.kscale = kscale
         self.data = torch.empty(((self.N + 15) // 16) * 16 * self.K, dtype=bf16, device=w.device)
         self.update(w)
 
+    @property
+    def folded(self):
+        return self.kscale is not None
+
     def update(self, w):
-        """Re-arrange the current values of `w` into the existing storage (the weights moved since the last rollout)."""
+        """Re-arrange the current values of `w` (and of the folded norm weight) into the existing storage (the weights moved since the last rollout)."""
         if tuple(w.shape) != (self.N, self.K) or w.dtype != bf16 or w.stride(1) != 1:
             raise RuntimeError(f'SwizzledWeight.update: expected bf16 {(self.N, self.K)}, got {tuple(w.shape)} {w.dtype}')
-        if self.mode == 'plain':
+        if self.kscale is not None:
+            call('aa_swizzle_weights_scaled_bf16', w.data_ptr(), w.stride(0), self.data.data_ptr(), self.N, self.K, self.MODES[self.mode], self.kscale.data_ptr(), stream())
+        elif self.mode == 'plain':
             call('aa_swizzle_weights_bf16', w.data_ptr(), w.stride(0), self.data.data_ptr(), self.N, self.K, stream())
         else:
             call('aa_swizzle_weights_perm_bf16', w.data_ptr(), w.stride(0), self.data.data_ptr(), self.N, self.K, self.MODES[self.mode], stream())
@@ -911,18 +922,29 @@ class SwizzledWeight:
         return (self.N, self.K)
 
 
-def gemm_skinny_glu(x, w):
+def _fold_eps(w, eps, name):
+    """A folded copy (W diag(norm weight)) takes the un-normalised rows and the norm's eps; a plain copy must not get one."""
+    if w.folded != (eps is not None):
+        raise RuntimeError(f'{name}: ' + ('this weight copy has the RMSNorm weight folded in: pass the un-normalised rows and eps' if w.folded
+                                          else 'eps given, but the weight copy was made without a norm weight (SwizzledWeight(kscale=...))'))
+    return w.folded
+
+
+def gemm_skinny_glu(x, w, eps=None):
     """act [M, F] = silu(x Wg^T) * (x Wu^T) of a decode position from the 'glu' strip-major copy of the fused [gate; up] weight: the GEMV and
-    aa_swiglu_fwd in one launch (bit-identical to the pair)."""
+    aa_swiglu_fwd in one launch (bit-identical to the pair).  eps (folded copy): x is the un-normalised residual stream, act = swiglu(rmsnorm(x) W^T)."""
     if not isinstance(w, SwizzledWeight) or w.mode != 'glu' or x.shape[0] > 16 or x.shape[1] != w.K or x.dtype != bf16:
         raise RuntimeError('gemm_skinny_glu: needs a SwizzledWeight(mode="glu"), M <= 16 bf16 rows of width K')
     M, F = x.shape[0], w.N // 2
     act = torch.empty((M, F), dtype=bf16, device=x.device)
-    call('aa_gemm_skinny_swz_glu_bf16', x.data_ptr(), w.data.data_ptr(), act.data_ptr(), M, F, w.K, x.stride(0), act.stride(0), stream())
+    if _fold_eps(w, eps, 'gemm_skinny_glu'):
+        call('aa_gemm_skinny_swz_norm_glu_bf16', x.data_ptr(), w.data.data_ptr(), act.data_ptr(), M, F, w.K, x.stride(0), act.stride(0), float(eps), stream())
+    else:
+        call('aa_gemm_skinny_swz_glu_bf16', x.data_ptr(), w.data.data_ptr(), act.data_ptr(), M, F, w.K, x.stride(0), act.stride(0), stream())
     return act
 
 
-def gemm_skinny_rope_cache(x, w, bias, H, Hkv, pos, cos_t, sin_t, cache, Tmax, slot):
+def gemm_skinny_rope_cache(x, w, bias, H, Hkv, pos, cos_t, sin_t, cache, Tmax, slot, eps=None):
     """q [M, H * 128] (rotated) of a decode position; the rotated k heads and the v heads go straight into cache slot `slot[m]`: the q/k/v GEMV
     and aa_decode_rope_cache in one launch, from the 'rope128' strip-major copy of the fused projection (bit-identical to the pair)."""
     if not isinstance(w, SwizzledWeight) or w.mode != 'rope128' or x.shape[0] > 16 or x.shape[1] != w.K or w.N != (H + 2 * Hkv) * 128:
@@ -931,17 +953,29 @@ def gemm_skinny_rope_cache(x, w, bias, H, Hkv, pos, cos_t, sin_t, cache, Tmax, s
         raise RuntimeError('gemm_skinny_rope_cache: bf16 activations / tables / cache, int32 pos, int64 slot')
     M = x.shape[0]
     q = torch.empty((M, H * 128), dtype=bf16, device=x.device)
+    if _fold_eps(w, eps, 'gemm_skinny_rope_cache'):       # x = the un-normalised residual stream
+        call('aa_gemm_skinny_swz_norm_rope_cache_bf16', x.data_ptr(), w.data.data_ptr(), q.data_ptr(), M, int(H), int(Hkv), w.K, x.stride(0), q.stride(0), _p(bias),
+             pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), cache.data_ptr(), cache.stride(0), int(Tmax), slot.data_ptr(), float(eps), stream())
+        return q
     call('aa_gemm_skinny_swz_rope_cache_bf16', x.data_ptr(), w.data.data_ptr(), q.data_ptr(), M, int(H), int(Hkv), w.K, x.stride(0), q.stride(0), _p(bias),
          pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), cache.data_ptr(), cache.stride(0), int(Tmax), slot.data_ptr(), stream())
     return q
 
 
-def linear_small(x, w, bias=None, residual=None, out=None, norm=None, swiglu=False):
+def linear_small(x, w, bias=None, residual=None, out=None, norm=None, swiglu=False, fold_eps=None):
     """y = x W^T for a handful of rows (decode): HBM-streaming skinny kernel for M <= 16, tiled GEMM beyond.
     norm = (weight, eps): y = RMSNorm(x) W^T; swiglu: x = [gate | up], y = (silu(gate) * up) W^T -- folded into the weight
     stream for M <= 16 (aa_gemm_skinny_fused_bf16), the separate kernels beyond."""
     M = x.shape[0]
     N = w.shape[0]
+    if isinstance(w, SwizzledWeight) and _fold_eps(w, fold_eps, 'linear_small'):
+        # fold_eps: w is a strip-major copy of W diag(norm weight) -> y = rmsnorm(x) W^T from the un-normalised rows in one launch
+        if M > 16 or norm is not None or swiglu or w.mode != 'plain' or w.K != x.shape[1]:
+            raise RuntimeError('linear_small(fold_eps=): a plain folded strip-major copy, M <= 16 rows of width K')
+        out = torch.empty((M, N), dtype=bf16, device=x.device) if out is None else out
+        call('aa_gemm_skinny_swz_norm_bf16', x.data_ptr(), w.data.data_ptr(), out.data_ptr(), M, N, w.K, x.stride(0), out.stride(0), _p(bias),
+             _p(residual), residual.stride(0) if residual is not None else 0, float(fold_eps), stream())
+        return out
     if M > 16 or not DECODE_FUSED:
         if norm is not None:
             x = rmsnorm_fwd(x, norm[0], norm[1])[0]

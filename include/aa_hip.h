@@ -326,6 +326,18 @@ int aa_gemm_skinny_swz_glu_bf16(const void* x, const void* Wswz, void* act, int 
 int aa_gemm_skinny_swz_rope_cache_bf16(const void* x, const void* Wswz, void* q_out, int M, int H, int Hkv, int K, long ldx, long ldq,
                                        const void* bias, const int* pos, const void* cos_t, const void* sin_t, void* cache, long ldc, int Tmax,
                                        const int64_t* slot, void* stream);
+/* The RMSNorm that PRECEDES a projection of a decode position folded into the strip kernel (hf LlamaRMSNorm + q/k/v, gate/up or lm_head:
+ * hf:models/llama/modeling_llama.py:62-67, :243-281, :163-176, :413).  rmsnorm(x; w, eps) W^T = rstd(x) * x (W diag(w))^T: the rollout-only copy is
+ * made of W diag(w) (aa_swizzle_weights_scaled_bf16, mode 0 / 1 / 2 = the plain / [gate; up] / head_dim-128 row orders above, kscale = w [K]), the
+ * strip kernel accumulates sum(x^2) from the fragments it feeds the MFMA and scales the finished dot products by rstd.  x is the UN-normalised
+ * residual stream.  Rounding differs from the separate kernel (bf16(W w) instead of w * bf16(x rstd)): bf16 noise, rollout sampling only. */
+int aa_swizzle_weights_scaled_bf16(const void* W, long ld, void* out, int N, int K, int mode, const void* kscale, void* stream);
+int aa_gemm_skinny_swz_norm_bf16(const void* x, const void* Wswz, void* out, int M, int N, int K, long ldx, long ldo, const void* bias,
+                                 const void* residual, long ldr, float eps, void* stream);
+int aa_gemm_skinny_swz_norm_glu_bf16(const void* x, const void* Wswz, void* act, int M, int F, int K, long ldx, long ldo, float eps, void* stream);
+int aa_gemm_skinny_swz_norm_rope_cache_bf16(const void* x, const void* Wswz, void* q_out, int M, int H, int Hkv, int K, long ldx, long ldq,
+                                            const void* bias, const int* pos, const void* cos_t, const void* sin_t, void* cache, long ldc, int Tmax,
+                                            const int64_t* slot, float eps, void* stream);
 /* new token of every sequence: rotate the q heads of the fused [q|k|v] row in place (aa_rope_inplace rounding), rotate the k heads
  * into cache[(n*Tmax + slot[n]), 0:Hkv*hd] and copy the v heads to [.., Hkv*hd:2*Hkv*hd] (HF DynamicCache.update) */
 int aa_decode_rope_cache(void* qkv, long ld, int N, int H, int Hkv, int hd, const int* pos, const void* cos_t, const void* sin_t,

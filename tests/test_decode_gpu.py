@@ -281,15 +281,21 @@ def test_generate_greedy_llava_with_image_prefill():
     ids, mask, pix = T(z['input_ids'])[:, :30].clone(), T(z['attention_mask'])[:, :30].clone(), T(z['pixel_values'])
     fn = lambda i, a: om.llava_logits(sd, cfg, i, a, pix)
     import os
-    seq = _check_greedy(m, fn, ids, mask, 8, None, 301, 'llava', pixel_values=pix.to(dev()))
-    # the rollout ran on strip-major weight copies (LlamaStack.prepare_decode); the row-major kernels give the same tokens
-    assert m.stack.prepare_decode(4) is not None
-    os.environ['AA_DECODE_SWIZZLE'] = '0'
+    _check_greedy(m, fn, ids, mask, 8, None, 301, 'llava', pixel_values=pix.to(dev()))          # default: strip-major copies with the norms folded in
+    assert m.stack.prepare_decode(4)[0]['qkv'].folded and m.head.prepare_decode(4).folded
+    os.environ['AA_DECODE_NORM_FOLD'] = '0'
     try:
-        assert m.stack.prepare_decode(4) is None
-        assert torch.equal(_check_greedy(m, fn, ids, mask, 8, None, 301, 'llava_rowmajor', pixel_values=pix.to(dev())), seq)
+        seq = _check_greedy(m, fn, ids, mask, 8, None, 301, 'llava_unfolded', pixel_values=pix.to(dev()))
+        # the rollout ran on strip-major weight copies (LlamaStack.prepare_decode); the row-major kernels give the same tokens
+        assert m.stack.prepare_decode(4) is not None and not m.stack.prepare_decode(4)[0]['qkv'].folded
+        os.environ['AA_DECODE_SWIZZLE'] = '0'
+        try:
+            assert m.stack.prepare_decode(4) is None
+            assert torch.equal(_check_greedy(m, fn, ids, mask, 8, None, 301, 'llava_rowmajor', pixel_values=pix.to(dev())), seq)
+        finally:
+            del os.environ['AA_DECODE_SWIZZLE']
     finally:
-        del os.environ['AA_DECODE_SWIZZLE']
+        del os.environ['AA_DECODE_NORM_FOLD']
 
 
 def test_generate_sampling_runs_and_respects_length_cap():
@@ -360,6 +366,68 @@ def test_strip_kernel_fused_epilogues_are_bit_identical_to_the_kernel_pairs(M):
         assert torch.equal(ca, cb), (M, H, Hkv, 'cache')
 
 
+@pytest.mark.parametrize('M', [1, 4, 16])
+def test_strip_kernel_with_the_rmsnorm_folded_into_the_weight_copy(M):
+    """Round 4: the RMSNorm IN FRONT of a projection folded into the strip kernel (csrc/decode.hip PRO 4): the rollout-only copy holds
+    W diag(norm weight) (aa_swizzle_weights_scaled_bf16), the kernel accumulates sum(x^2) from its own fragments and scales the dot products by
+    rstd -- for the plain projection (lm_head: + bias / residual exercised too), the [gate; up] copy with the SwiGLU epilogue and the head_dim-128
+    q/k/v copy with the rotary + cache-write epilogue.  Yardsticks: fp64 math of norm -> projection (-> epilogue), and the unfolded native chain
+    (aa_rmsnorm_fwd + the strip kernel), which the folded kernel must match as closely as that chain matches fp64."""
+    from align_anything_amd import ops
+    from align_anything_amd.modeling import rope_tables
+    eps = 1e-6
+    norm64 = lambda x, nw: x.double() * torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + eps) * nw.double()
+    for (N, K) in [(64, 128), (1000, 2048), (152064 // 8, 3584), (12288, 4096)]:
+        x, w = randn_bf16(M, K, scale=1.5, seed=1), randn_bf16(N, K, scale=0.05, seed=2)
+        nw = (1 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16).to(dev())
+        bias, res = randn_bf16(N, seed=4), randn_bf16(M, N, seed=5)
+        ref = norm64(x, nw) @ w.double().t()
+        sw = ops.SwizzledWeight(w, kscale=nw)
+        assert sw.folded
+        got = ops.linear_small(x, sw, fold_eps=eps)
+        unf = ops.linear_small(ops.rmsnorm_fwd(x, nw, eps)[0], ops.SwizzledWeight(w))
+        tol = 1e-2 * float(ref.abs().mean()) + 1e-3
+        assert_close(got, ref.float(), rtol=1e-2, atol=tol, what=f'folded norm -> strip {M}x{N}x{K}')
+        assert float((got.double() - ref).abs().mean()) < 1.5 * float((unf.double() - ref).abs().mean()) + 1e-4
+        got = ops.linear_small(x, sw, bias=bias, residual=res, fold_eps=eps)
+        assert_close(got, (ref.float() + bias.float()).to(torch.bfloat16).float() + res.float(), rtol=1e-2, atol=tol + 2e-2, what='folded norm -> strip, bias + residual')
+        with pytest.raises(RuntimeError):
+            ops.linear_small(x, sw)                                    # a folded copy without eps would silently skip the norm
+        with pytest.raises(RuntimeError):
+            ops.linear_small(x, ops.SwizzledWeight(w), fold_eps=eps)
+    for (F, K) in [(64, 128), (18944, 3584)]:
+        x, wgu = randn_bf16(M, K, scale=1.5, seed=1), randn_bf16(2 * F, K, scale=0.05, seed=2)
+        nw = (1 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16).to(dev())
+        gu = norm64(x, nw) @ wgu.double().t()
+        ref = torch.nn.functional.silu(gu[:, :F]) * gu[:, F:]
+        got = ops.gemm_skinny_glu(x, ops.SwizzledWeight(wgu, 'glu', kscale=nw), eps=eps)
+        unf = ops.gemm_skinny_glu(ops.rmsnorm_fwd(x, nw, eps)[0], ops.SwizzledWeight(wgu, 'glu'))
+        # silu(gate) * up of two bf16-rounded projections: an element's error scales with the FACTORS (a small product of large factors keeps their
+        # absolute error), so the element-wise bound is set by the tensor's rms; the mean-error yardstick below is the sharp one
+        tol = 2e-2 * float(ref.pow(2).mean().sqrt()) + 1e-3
+        assert_close(got, ref.float(), rtol=2e-2, atol=tol, what=f'folded norm -> glu strip {M}x{F}x{K}')
+        assert float((got.double() - ref).abs().mean()) < 1.5 * float((unf.double() - ref).abs().mean()) + 1e-4
+    for (H, Hkv, K, with_bias, Tmax) in [(4, 4, 256, False, 9), (28, 4, 3584, True, 33)]:
+        hd, kw = 128, Hkv * 128
+        x, w = randn_bf16(M, K, scale=1.5, seed=3), randn_bf16((H + 2 * Hkv) * hd, K, scale=0.05, seed=4)
+        nw = (1 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16).to(dev())
+        bias = randn_bf16((H + 2 * Hkv) * hd, seed=5) if with_bias else None
+        cos, sin = rope_tables(64, hd, 1000000.0, dev(), torch.bfloat16)
+        pos = torch.randint(0, 64, (M,), generator=torch.Generator().manual_seed(6)).to(torch.int32).to(dev())
+        slot = torch.randint(0, Tmax, (M,), generator=torch.Generator().manual_seed(7)).to(dev())
+        ca = randn_bf16(M * Tmax, 2 * kw, seed=8)
+        cb = ca.clone()
+        qa = ops.gemm_skinny_rope_cache(ops.rmsnorm_fwd(x, nw, eps)[0], ops.SwizzledWeight(w, 'rope128'), bias, H, Hkv, pos, cos, sin, ca, Tmax, slot)
+        qb = ops.gemm_skinny_rope_cache(x, ops.SwizzledWeight(w, 'rope128', kscale=nw), bias, H, Hkv, pos, cos, sin, cb, Tmax, slot, eps=eps)
+        scale = float(qa.float().abs().mean())
+        assert_close(qb, qa.float(), rtol=3e-2, atol=3e-2 * scale, what=f'folded norm -> rope strip q {M} {H}/{Hkv}')
+        rows = (torch.arange(M, device=dev()) * Tmax + slot)
+        assert_close(cb[rows], ca[rows].float(), rtol=3e-2, atol=3e-2 * scale, what='folded norm -> rope strip cache rows')
+        other = torch.ones(M * Tmax, dtype=torch.bool, device=dev())
+        other[rows] = False
+        assert torch.equal(ca[other], cb[other])                         # no other cache slot touched
+
+
 def test_generate_with_and_without_the_fused_decode_epilogues_gives_the_same_tokens(monkeypatch):
     """The whole rollout with the epilogue fusions on (default) and off (AA_DECODE_EPI=0): identical sequences, greedy and sampled, on a Llama-family
     stack with head_dim 128 (q/k/v bias, GQA) -- the path tools/bench_ppo.py times."""
@@ -375,6 +443,7 @@ def test_generate_with_and_without_the_fused_decode_epilogues_gives_the_same_tok
     mask = torch.ones_like(ids)
     mask[1, :4] = 0
     outs = []
+    monkeypatch.setenv('AA_DECODE_NORM_FOLD', '0')           # bit identity is between the UNFOLDED chains; the folded norm is checked below
     for epi in ('1', '0'):
         monkeypatch.setenv('AA_DECODE_EPI', epi)
         greedy = generate(m, ids, mask, max_new_tokens=12, do_sample=False, pad_token_id=0)
@@ -384,3 +453,12 @@ def test_generate_with_and_without_the_fused_decode_epilogues_gives_the_same_tok
         assert modes == ({'qkv': 'rope128', 'o': 'plain', 'gu': 'glu', 'down': 'plain'} if epi == '1' else dict.fromkeys(('qkv', 'o', 'gu', 'down'), 'plain'))
         outs.append((greedy.cpu(), sampled.cpu()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # default rollout path: RMSNorm folded into the q/k/v, gate/up and lm_head copies (bf16 noise on the logits: greedy tokens may part ways
+    # with the unfolded chain at a near-tie, never before the first generated position is compared on real margins in the oracle tests)
+    monkeypatch.setenv('AA_DECODE_EPI', '1')
+    monkeypatch.setenv('AA_DECODE_NORM_FOLD', '1')
+    folded = generate(m, ids, mask, max_new_tokens=12, do_sample=False, pad_token_id=0).cpu()
+    assert all(W[k].folded == (k in ('qkv', 'gu')) for W in m.stack._dw for k in W) and m.head._dw.folded
+    assert folded.shape == outs[0][0].shape and torch.equal(folded[:, :20], ids.cpu())
+    agree = (folded[:, 20:] == outs[0][0][:, 20:]).float().mean()
+    assert float(agree) >= 0.5, float(agree)

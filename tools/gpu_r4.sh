@@ -82,6 +82,17 @@ PY
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r04_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_prof -o p -- python $R/bench.py --steps 3 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > $R/gpurun_out/r04_bench_under_rocprof.json 2> $R/gpurun_out/r04_prof.err )
       f=$(find gpurun_out/r04_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r04_dpo7b_kernel_stats.csv && head -25 "$f" | cut -c1-220
       find gpurun_out/r04_prof -name "*kernel_trace.csv" -delete ;;
+    ppo_prof)        # kernel trace of one PPO iteration (Qwen2-VL-7B geometry): per-kernel split of the DECODE window (first .. last skinny GEMM), busy vs span
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r04_ppo_prof && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_ppo_prof -o p -- python $R/tools/bench_ppo.py --iters 1 --new-tokens 128 > $R/gpurun_out/r04_bench_ppo_under_rocprof.json 2> $R/gpurun_out/r04_ppo_prof.err )
+      t=$(find gpurun_out/r04_ppo_prof -name "*kernel_trace.csv" | head -1)
+      [ -n "$t" ] && python3 tools/decode_trace_summary.py "$t" > gpurun_out/r04_decode_trace_summary.txt; cat gpurun_out/r04_decode_trace_summary.txt | cut -c1-200
+      find gpurun_out/r04_ppo_prof -name "*kernel_trace.csv" -delete ;;
+    decode_fold)     # RMSNorm folded into the strip-major copies (AA_DECODE_NORM_FOLD, default 1): tests, then the PPO iteration both ways on one box
+      timeout 300 python -m pytest tests/test_decode_gpu.py tests/test_qwen2vl_gpu.py tests/test_ppo_gpu.py -q -x -m gpu -p no:cacheprovider 2>&1 | tail -8
+      for f in 0 1 0 1; do
+        AA_DECODE_NORM_FOLD=$f timeout 200 python tools/bench_ppo.py --iters 2 > gpurun_out/r04_bench_ppo_fold$f.json 2> gpurun_out/r04_bench_ppo_fold$f.err
+        python -c "import json; d=json.load(open('gpurun_out/r04_bench_ppo_fold$f.json')); print('fold $f', round(d['decode_ms_per_position'],4), 'ms/pos', round(d['iteration_ms'],1), 'ms/iter', round(d['decode_weight_stream_frac_of_hbm_peak'],4))" || tail -3 gpurun_out/r04_bench_ppo_fold$f.err
+      done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
