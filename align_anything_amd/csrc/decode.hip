@@ -859,3 +859,48 @@ extern "C" int aa_move_padding_left(const int64_t* in, long ldi, int64_t* out, l
     AA_CHECK_LAUNCH("aa_move_padding_left");
     return AA_OK;
 }
+
+// ------------------------------------------------------------------ the decode loop's bookkeeping in two launches
+// `generate` keeps everything a step needs in device buffers (one fixed launch sequence per position, hipGraph-capturable).  Written with torch
+// ops that bookkeeping was ~11 one-element kernels per position, each at the ~4.8 us launch floor (profiles/r04_decode_trace_summary_before_norm_fold.txt).
+//   aa_decode_record : after the selection kernel.  nact += any(unfinished) (the columns hf's stopping criteria keep); tok[n] = unfinished[n] ?
+//                      selected[n] : pad; out[n, tslot[n]] = tok[n]; unfinished[n] &= tok[n] != eos (eos < 0: no EOS) -- hf GenerationMixin._sample's
+//                      `next_tokens * unfinished + pad * (1 - unfinished)` and EosTokenCriteria, per row.
+//   aa_decode_tick   : after the decode pass.  tslot / pos / length += 1 per row, step += 1.
+__global__ __launch_bounds__(256) void decode_record_kernel(const int64_t* __restrict__ selected, uint8_t* __restrict__ unfinished, int64_t* __restrict__ out,
+                                                            long ldo, const int64_t* __restrict__ tslot, int64_t* __restrict__ tok, int64_t* __restrict__ nact,
+                                                            int N, int64_t pad, int64_t eos) {
+    __shared__ int any_s;
+    if (threadIdx.x == 0) any_s = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const bool u = unfinished[n] != 0;
+        mine |= u ? 1 : 0;
+        const int64_t t = u ? selected[n] : pad;
+        tok[n] = t;
+        out[(long)n * ldo + tslot[n]] = t;
+        if (eos >= 0 && u && t == eos) unfinished[n] = 0;
+    }
+    if (mine) atomicOr(&any_s, 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && any_s) *nact += 1;
+}
+extern "C" int aa_decode_record(const int64_t* selected, uint8_t* unfinished, int64_t* out, long ldo, const int64_t* tslot, int64_t* tok, int64_t* nact,
+                                int N, int64_t pad, int64_t eos, void* stream) {
+    AA_REQUIRE(N >= 0 && ldo > 0, "aa_decode_record: bad arguments (N=%d ldo=%ld)", N, ldo);
+    if (N == 0) return AA_OK;
+    hipLaunchKernelGGL(decode_record_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, selected, unfinished, out, ldo, tslot, tok, nact, N, pad, eos);
+    AA_CHECK_LAUNCH("aa_decode_record");
+    return AA_OK;
+}
+__global__ __launch_bounds__(256) void decode_tick_kernel(int64_t* __restrict__ tslot, int* __restrict__ pos, int* __restrict__ length, int64_t* __restrict__ step, int N) {
+    for (int n = threadIdx.x; n < N; n += 256) { tslot[n] += 1; pos[n] += 1; length[n] += 1; }
+    if (threadIdx.x == 0) *step += 1;
+}
+extern "C" int aa_decode_tick(int64_t* tslot, int* pos, int* length, int64_t* step, int N, void* stream) {
+    AA_REQUIRE(N >= 0, "aa_decode_tick: N=%d", N);
+    hipLaunchKernelGGL(decode_tick_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tslot, pos, length, step, N);
+    AA_CHECK_LAUNCH("aa_decode_tick");
+    return AA_OK;
+}

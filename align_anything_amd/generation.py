@@ -124,19 +124,19 @@ def generate(model, input_ids, attention_mask, *, max_length=None, max_new_token
 
     def one_step():
         """select token from st['logits'], record it, run one decode pass, leave next logits in st['logits']."""
-        st['nact'].add_(st['unfinished'].any().to(torch.int64))
         nxt = select(st['logits'], st['U'].index_select(0, st['step'])[0] if do_sample else None)
-        nxt = torch.where(st['unfinished'], nxt, padv)
-        out.scatter_(1, st['tslot'][:, None], nxt[:, None])
+        # nact += any(unfinished); nxt = where(unfinished, nxt, pad); out[n, tslot[n]] = nxt[n]; unfinished &= nxt != eos -- one launch (aa_decode_record)
+        nxt = ops.decode_record(nxt, st['unfinished'], out, st['tslot'], st['nact'], pad_token_id, eos)
         if seen is not None:
             ops.mark_seen_(seen, nxt[:, None])
-        if eos >= 0:
-            st['unfinished'].logical_and_(nxt != eos)
         emb_pos = (st['pos'] + 2) if is_opt else None        # OPT learned positions carry an offset of 2
         xt = model.embed_tokens(nxt, emb_pos)
         xt = stack.decode_step(xt, cache, st['tslot'], Tmax, st['pos'], start, st['length'], **step_kw)
-        st['logits'].copy_(model.head.logits_rows(xt, head_w) if head_w is not None else model.head.logits_rows(xt))
-        st['tslot'].add_(1); st['pos'].add_(1); st['length'].add_(1); st['step'].add_(1)
+        if head_w is not None:
+            model.head.logits_rows(xt, head_w, out=st['logits'])       # the strip kernel writes the next position's logits in place
+        else:
+            st['logits'].copy_(model.head.logits_rows(xt))
+        ops.decode_tick(st['tslot'], st['pos'], st['length'], st['step'])
 
     graph = None
     if use_graph and max_new_tokens > 4 and ep is None:      # collectives cannot be captured: expert-parallel rollouts launch eagerly

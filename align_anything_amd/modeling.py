@@ -449,11 +449,13 @@ class LMHead:
             self._dw.update(self._w())
         return self._dw
 
-    def logits_rows(self, x_rows, w=None):
-        """Logits of a handful of rows (decode): norm + skinny lm_head (w: `prepare_decode` result or None)."""
+    def logits_rows(self, x_rows, w=None, out=None):
+        """Logits of a handful of rows (decode): norm + skinny lm_head (w: `prepare_decode` result or None; out: written in place when given)."""
         P = self.store.p
         if w is not None and getattr(w, 'folded', False):
-            return ops.linear_small(x_rows, w, fold_eps=self.eps)
+            return ops.linear_small(x_rows, w, fold_eps=self.eps, out=out)
+        if out is not None:
+            return out.copy_(self.logits_rows(x_rows, w))
         if self.kind == 'rms':
             if x_rows.dtype == bf16 and w is None:
                 return ops.linear_small(x_rows, self._w(), norm=(P[self.norm_w], self.eps))     # (norm folded in with ops.DECODE_FUSED)

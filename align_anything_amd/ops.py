@@ -1054,6 +1054,26 @@ def move_padding_left(seq, pad_token_id):
     return out
 
 
+def decode_record(selected, unfinished, out, tslot, nact, pad_token_id, eos_token_id):
+    """Bookkeeping of one decode position after the selection kernel (aa_decode_record): returns tok [N] (pad for finished rows), writes it into
+    out[n, tslot[n]], counts the step in `nact` if any row was unfinished, clears `unfinished` of rows that emitted eos (eos < 0: none)."""
+    N = selected.shape[0]
+    if selected.dtype != torch.int64 or unfinished.dtype != torch.bool or out.dtype != torch.int64 or tslot.dtype != torch.int64 or nact.dtype != torch.int64 \
+            or out.stride(1) != 1 or not (selected.is_contiguous() and unfinished.is_contiguous() and tslot.is_contiguous()):
+        raise RuntimeError('decode_record: int64 selected / out / tslot / nact, bool unfinished, contiguous')
+    tok = torch.empty_like(selected)
+    call('aa_decode_record', selected.data_ptr(), unfinished.data_ptr(), out.data_ptr(), out.stride(0), tslot.data_ptr(), tok.data_ptr(), nact.data_ptr(), N,
+         int(pad_token_id), int(eos_token_id), stream())
+    return tok
+
+
+def decode_tick(tslot, pos, length, step):
+    """tslot / pos / length += 1 per row, step += 1 (aa_decode_tick): the end of a decode position."""
+    if tslot.dtype != torch.int64 or pos.dtype != torch.int32 or length.dtype != torch.int32 or step.dtype != torch.int64:
+        raise RuntimeError('decode_tick: int64 tslot / step, int32 pos / length')
+    call('aa_decode_tick', tslot.data_ptr(), pos.data_ptr(), length.data_ptr(), step.data_ptr(), tslot.shape[0], stream())
+
+
 def argmax_rows(logits, seen=None, repetition_penalty=1.0):
     rows, V = logits.shape
     out = torch.empty(rows, dtype=torch.int64, device=logits.device)

@@ -366,6 +366,13 @@ int aa_sample_top_k_top_p(const void* logits, long ld, int rows, int V, float te
 
 /* trainers/text_image_to_text/ppo.py:56-86 move_padding_left on the generated sequences (circular shift per row, bit-exact) */
 int aa_move_padding_left(const int64_t* in, long ldi, int64_t* out, long ldo, int rows, int L, int64_t pad, void* stream);
+/* The decode loop's per-position bookkeeping (hf GenerationMixin._sample: `next_tokens * unfinished + pad * (1 - unfinished)`, the scatter into the
+ * output, EosTokenCriteria; then the cache slot / position / length counters) in two launches instead of ~11 one-element torch kernels:
+ * aa_decode_record after the selection kernel (tok[n] = unfinished[n] ? selected[n] : pad; out[n, tslot[n]] = tok[n]; nact += any(unfinished);
+ * unfinished[n] &= tok[n] != eos, eos < 0 = none; unfinished = one byte per row), aa_decode_tick after the decode pass (tslot, pos, length, step += 1). */
+int aa_decode_record(const int64_t* selected, uint8_t* unfinished, int64_t* out, long ldo, const int64_t* tslot, int64_t* tok, int64_t* nact, int N,
+                     int64_t pad, int64_t eos, void* stream);
+int aa_decode_tick(int64_t* tslot, int* pos, int* length, int64_t* step, int N, void* stream);
 
 /* ---- optimizer (DeepSpeed FusedAdam + gradient_clipping, supervised_trainer.py:245-249) ------ */
 /* *out_accum += sum((g*scale)^2); deterministic (no float atomics): ws = caller-owned scratch of AA_SUMSQ_WS floats, so the

@@ -462,3 +462,33 @@ def test_generate_with_and_without_the_fused_decode_epilogues_gives_the_same_tok
     assert folded.shape == outs[0][0].shape and torch.equal(folded[:, :20], ids.cpu())
     agree = (folded[:, 20:] == outs[0][0][:, 20:]).float().mean()
     assert float(agree) >= 0.5, float(agree)
+
+
+def test_decode_loop_bookkeeping_kernels_equal_the_torch_ops():
+    """aa_decode_record / aa_decode_tick against the torch statements they replace in generation.py (hf GenerationMixin._sample's masking of
+    finished rows, the scatter into the output, EosTokenCriteria; the per-row counters): with and without an EOS id, pad == eos included, more
+    rows than one block's threads."""
+    from align_anything_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for N, eos, pad in [(1, -1, 0), (4, 7, 0), (16, 7, 7), (700, 3, 1)]:
+        Tmax = 12
+        sel = torch.randint(0, 10, (N,), generator=g).to(dev())
+        unf = (torch.rand(N, generator=g) < 0.7).to(dev())
+        out = torch.randint(0, 10, (N, Tmax), generator=g).to(dev())
+        tslot = torch.randint(0, Tmax, (N,), generator=g).to(dev())
+        nact = torch.tensor([5], device=dev())
+        want_out, want_unf = out.clone(), unf.clone()
+        want_nact = nact + want_unf.any().to(torch.int64)
+        want_tok = torch.where(want_unf, sel, torch.full_like(sel, pad))
+        want_out.scatter_(1, tslot[:, None], want_tok[:, None])
+        if eos >= 0:
+            want_unf.logical_and_(want_tok != eos)
+        tok = ops.decode_record(sel, unf, out, tslot, nact, pad, eos)
+        assert torch.equal(tok, want_tok) and torch.equal(out, want_out) and torch.equal(unf, want_unf) and torch.equal(nact, want_nact), (N, eos, pad)
+        none = torch.zeros(N, dtype=torch.bool, device=dev())
+        ops.decode_record(sel, none, out, tslot, nact, pad, eos)                 # every row finished: the step is not counted
+        assert torch.equal(nact, want_nact)
+        pos, length, step = torch.arange(N, dtype=torch.int32, device=dev()), torch.full((N,), 3, dtype=torch.int32, device=dev()), torch.tensor([9], device=dev())
+        t0 = tslot.clone()
+        ops.decode_tick(tslot, pos, length, step)
+        assert torch.equal(tslot, t0 + 1) and torch.equal(pos, torch.arange(1, N + 1, dtype=torch.int32, device=dev())) and int(length.min()) == 4 == int(length.max()) and int(step) == 10

@@ -769,10 +769,27 @@ def test_text_image_trainers_build_themselves_from_cfgs(launches, tmp_path):
     del launches[:]
     decode = ppo.tokenizer.batch_decode          # the sampler is stubbed out here: "sampled" ids are whatever torch.empty held
     ppo.tokenizer.batch_decode = lambda ids, **kw: decode(ids.clamp(0, 319), **kw)
-    hist = ppo.train()
-    assert len(hist) == 3 and 'train/reward_critic_loss' in hist[-1] and ppo.actor_model.global_steps == 3
-    # evaluated before the first step and at step 2 (eval_strategy 'steps', interval 2): prompt / completion texts of the 4 evaluation prompts
-    assert [s for s, _ in ppo.eval_history] == [0, 2]
-    ev = ppo.eval_history[-1][1]
-    assert len(ev['eval/prompts']) == 4 and len(ev['eval/generated']) == 4 and all(isinstance(x, str) for x in ev['eval/generated'])
-    assert 'aa_attn_decode' in launches and 'aa_ppo_actor_loss' in launches
+    # ... and so would be the two kernels whose OUTPUT steers host control flow (the response lengths): stand-ins with defined values
+    from align_anything_amd import ops
+
+    def record(selected, unfinished, out, tslot, nact, pad, eos):
+        launches.append('aa_decode_record')
+        tok = torch.full_like(selected, 7)
+        out.scatter_(1, tslot[:, None], tok[:, None])
+        return tok
+
+    def pad_left(seq, pad):
+        launches.append('aa_move_padding_left')
+        rows = [torch.cat([r[r == pad], r[r != pad]]) for r in seq]
+        return torch.stack(rows)
+
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setattr(ops, 'decode_record', record)
+        mp.setattr(ops, 'move_padding_left', pad_left)
+        hist = ppo.train()
+        assert len(hist) == 3 and 'train/reward_critic_loss' in hist[-1] and ppo.actor_model.global_steps == 3
+        # evaluated before the first step and at step 2 (eval_strategy 'steps', interval 2): prompt / completion texts of the 4 evaluation prompts
+        assert [s for s, _ in ppo.eval_history] == [0, 2]
+        ev = ppo.eval_history[-1][1]
+        assert len(ev['eval/prompts']) == 4 and len(ev['eval/generated']) == 4 and all(isinstance(x, str) for x in ev['eval/generated'])
+    assert 'aa_attn_decode' in launches and 'aa_ppo_actor_loss' in launches and 'aa_decode_tick' in launches
