@@ -17,7 +17,9 @@ def main():
     out = sys.argv[1]
     rank = int(os.environ['RANK'])
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo')
+    import datetime
+    # a rank that dies must fail its peer within minutes, not after gloo's default half hour (the GPU suite runs under the driver's clock)
+    dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=240))
     z = load_golden('opt_tiny_dpo.npz')
     b = _batch(z, with_pixels=False)
     rows = [rank, rank + 2]          # pair i = (chosen i, rejected i)

@@ -97,7 +97,9 @@ def main():
     out = sys.argv[1]
     rank = int(os.environ['RANK'])
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo')
+    import datetime
+    # a rank that dies must fail its peer within minutes, not after gloo's default half hour (the GPU suite runs under the driver's clock)
+    dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=240))
     z = load_golden('qwen3moe_tiny_dpo.npz')
     res = {dt: run(z, dt, rank) for dt in ('fp32', 'bf16')}
     padded = {dt: run(z, dt, rank, capacity_factor=2.0) for dt in ('fp32', 'bf16')}

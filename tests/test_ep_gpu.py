@@ -40,7 +40,7 @@ def test_two_rank_expert_parallel_step_equals_single_rank(tmp_path):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29577', os.path.join(ROOT, 'tests', 'ep_worker.py'), out]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         dump('ep_worker_failure.log', r.stdout + '\n' + r.stderr)
     assert r.returncode == 0, r.stderr[-3000:]
