@@ -7,10 +7,39 @@ The named constructors give the BASELINE.json geometries without touching the ne
 from __future__ import annotations
 
 
+def rope_scaling_of(c) -> dict | None:
+    """The RoPE frequency scaling of an HF (text) config, from `rope_parameters` (transformers >= 5) or `rope_scaling` (4.x; key 'rope_type' or
+    'type').  None for the plain rotary embedding (and for M-RoPE, whose sections are read elsewhere).  Built: 'linear' (position interpolation)
+    and 'llama3' (Llama-3.1's frequency-dependent scaling: meta-llama/Llama-3.1-8B-Instruct is the reference's text-to-text default,
+    scripts/llama/*.sh).  Anything else RAISES: a scaling that is silently dropped gives wrong logits at every position."""
+    rp = getattr(c, 'rope_parameters', None) or getattr(c, 'rope_scaling', None) or {}
+    kind = rp.get('rope_type', rp.get('type', 'default')) or 'default'
+    if kind in ('default', 'mrope'):
+        return None
+    if kind == 'linear':
+        return {'type': 'linear', 'factor': float(rp['factor'])}
+    if kind == 'llama3':
+        return {'type': 'llama3', 'factor': float(rp['factor']), 'low_freq_factor': float(rp['low_freq_factor']),
+                'high_freq_factor': float(rp['high_freq_factor']),
+                'original_max_position_embeddings': int(rp.get('original_max_position_embeddings') or c.max_position_embeddings)}
+    raise ValueError(f'rope scaling type {kind!r} has no native implementation (default, linear and llama3 are built)')
+
+
+def check_llama_family(c, what: str) -> None:
+    """Options of an HF Llama-family text config that the native decoder does not implement must not be dropped silently."""
+    if getattr(c, 'mlp_bias', False):
+        raise ValueError(f'{what}: mlp_bias has no native implementation')
+    if getattr(c, 'hidden_act', 'silu') not in ('silu', 'swish'):
+        raise ValueError(f'{what}: hidden_act {c.hidden_act!r} has no native implementation (silu is built)')
+    if float(getattr(c, 'partial_rotary_factor', 1.0) or 1.0) != 1.0 or float((getattr(c, 'rope_parameters', None) or {}).get('partial_rotary_factor', 1.0) or 1.0) != 1.0:
+        raise ValueError(f'{what}: partial rotary embeddings have no native implementation')
+
+
 def llama_cfg(hidden_size, intermediate_size, num_layers, num_heads, num_kv_heads, vocab_size,
-              rms_eps=1e-5, rope_theta=10000.0, head_dim=None, max_position_embeddings=4096, attention_bias=False):
+              rms_eps=1e-5, rope_theta=10000.0, head_dim=None, max_position_embeddings=4096, attention_bias=False, rope_scaling=None,
+              tie_word_embeddings=False):
     return {
-        'attention_bias': attention_bias,
+        'attention_bias': attention_bias, 'rope_scaling': rope_scaling, 'tie_word_embeddings': bool(tie_word_embeddings),
         'kind': 'llama', 'hidden_size': hidden_size, 'intermediate_size': intermediate_size,
         'num_layers': num_layers, 'num_heads': num_heads, 'num_kv_heads': num_kv_heads,
         'head_dim': head_dim or hidden_size // num_heads, 'vocab_size': vocab_size, 'rms_eps': rms_eps,
@@ -107,9 +136,17 @@ def from_hf_config(c) -> dict:
         t, v = c.text_config, c.vision_config
         rp = getattr(t, 'rope_parameters', None) or {}
         theta = rp.get('rope_theta', getattr(t, 'rope_theta', 10000.0))
+        check_llama_family(t, 'llava text_config')
+        if getattr(c, 'vision_feature_select_strategy', 'default') != 'default' or getattr(c, 'projector_hidden_act', 'gelu') != 'gelu' \
+                or not getattr(c, 'multimodal_projector_bias', True) or isinstance(c.vision_feature_layer, (list, tuple)):
+            raise ValueError('llava: vision_feature_select_strategy / projector_hidden_act / multimodal_projector_bias / a list of feature layers other than '
+                             'the LLaVA-1.5 defaults (default, gelu, biased, one layer) have no native implementation')
         text = llama_cfg(t.hidden_size, t.intermediate_size, t.num_hidden_layers, t.num_attention_heads,
                          t.num_key_value_heads, t.vocab_size, t.rms_norm_eps, theta,
-                         getattr(t, 'head_dim', None), t.max_position_embeddings)
+                         getattr(t, 'head_dim', None), t.max_position_embeddings, attention_bias=bool(getattr(t, 'attention_bias', False)),
+                         rope_scaling=rope_scaling_of(t))
+        if getattr(c, 'tie_word_embeddings', False):
+            raise ValueError('llava with tied input / output embeddings has no native implementation (text-only llama / qwen2 checkpoints are built)')
         vision = clip_vision_cfg(v.hidden_size, v.intermediate_size, v.num_hidden_layers,
                                  v.num_attention_heads, v.image_size, v.patch_size, v.layer_norm_eps,
                                  v.num_channels)
@@ -118,17 +155,21 @@ def from_hf_config(c) -> dict:
     if mt == 'llama':
         rp = getattr(c, 'rope_parameters', None) or {}
         theta = rp.get('rope_theta', getattr(c, 'rope_theta', 10000.0))
+        check_llama_family(c, 'llama')
         return llama_cfg(c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads,
                          c.num_key_value_heads, c.vocab_size, c.rms_norm_eps, theta,
-                         getattr(c, 'head_dim', None), c.max_position_embeddings)
+                         getattr(c, 'head_dim', None), c.max_position_embeddings, attention_bias=bool(getattr(c, 'attention_bias', False)),
+                         rope_scaling=rope_scaling_of(c), tie_word_embeddings=getattr(c, 'tie_word_embeddings', False))
     if mt == 'qwen2':   # Llama block + q/k/v biases (align_anything/models/qwen2.py -> hf Qwen2ForCausalLM)
         rp = getattr(c, 'rope_parameters', None) or {}
         theta = rp.get('rope_theta', getattr(c, 'rope_theta', 1000000.0))
         if getattr(c, 'use_sliding_window', False):
             raise ValueError('qwen2 with sliding-window attention has no native implementation yet')
+        check_llama_family(c, 'qwen2')
         return llama_cfg(c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads,
                          c.num_key_value_heads, c.vocab_size, c.rms_norm_eps, theta, getattr(c, 'head_dim', None),
-                         c.max_position_embeddings, attention_bias=True)
+                         c.max_position_embeddings, attention_bias=True, rope_scaling=rope_scaling_of(c),
+                         tie_word_embeddings=getattr(c, 'tie_word_embeddings', False))
     if mt == 'qwen2_vl':   # align_anything/models/qwen2_vl.py -> hf Qwen2VLForConditionalGeneration
         t, v = c.text_config, c.vision_config
         rp = getattr(t, 'rope_parameters', None) or getattr(t, 'rope_scaling', None) or {}
@@ -136,6 +177,11 @@ def from_hf_config(c) -> dict:
         text = llama_cfg(t.hidden_size, t.intermediate_size, t.num_hidden_layers, t.num_attention_heads, t.num_key_value_heads,
                          t.vocab_size, t.rms_norm_eps, theta, getattr(t, 'head_dim', None), t.max_position_embeddings,
                          attention_bias=True)
+        check_llama_family(t, 'qwen2_vl text_config')
+        if getattr(c, 'tie_word_embeddings', False):
+            raise ValueError('qwen2_vl with tied input / output embeddings (the 2B checkpoints) has no native implementation')
+        if rope_scaling_of(t) is not None:
+            raise ValueError('qwen2_vl: a scaled M-RoPE has no native implementation')
         vision = qwen2vl_vision_cfg(v.embed_dim, v.depth, v.num_heads, v.mlp_ratio, v.hidden_size, v.patch_size,
                                     v.temporal_patch_size, v.spatial_merge_size, v.in_channels)
         return qwen2vl_cfg(text, vision, c.image_token_id, rp['mrope_section'], getattr(c, 'pad_token_id', None))
@@ -146,6 +192,9 @@ def from_hf_config(c) -> dict:
         text = llama_cfg(t.hidden_size, t.intermediate_size, t.num_hidden_layers, t.num_attention_heads, t.num_key_value_heads,
                          t.vocab_size, t.rms_norm_eps, theta, getattr(t, 'head_dim', None), t.max_position_embeddings,
                          attention_bias=True)
+        check_llama_family(t, 'qwen2_audio text_config')
+        if rope_scaling_of(t) is not None:
+            raise ValueError('qwen2_audio: RoPE scaling has no native implementation')
         audio = qwen2audio_tower_cfg(a.d_model, a.encoder_layers, a.encoder_attention_heads, a.encoder_ffn_dim, a.num_mel_bins,
                                      a.max_source_positions)
         return qwen2audio_cfg(text, audio, c.audio_token_id, getattr(c, 'pad_token_id', None))
@@ -156,10 +205,15 @@ def from_hf_config(c) -> dict:
             raise ValueError('qwen3_moe with dense layers (mlp_only_layers / decoder_sparse_step) has no native implementation yet')
         if getattr(c, 'attention_bias', False):
             raise ValueError('qwen3_moe with attention_bias has no native implementation yet')
+        if rope_scaling_of(c) is not None:
+            raise ValueError('qwen3_moe: RoPE scaling has no native implementation')
         return qwen3moe_cfg(c.hidden_size, c.moe_intermediate_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads,
                             c.vocab_size, c.num_experts, c.num_experts_per_tok, getattr(c, 'head_dim', None) or c.hidden_size // c.num_attention_heads,
                             c.norm_topk_prob, c.rms_norm_eps, theta, c.max_position_embeddings)
     if mt == 'opt':
+        if not getattr(c, 'do_layer_norm_before', True) or getattr(c, 'word_embed_proj_dim', c.hidden_size) != c.hidden_size \
+                or getattr(c, 'activation_function', 'relu') != 'relu' or not getattr(c, 'enable_bias', True) or not getattr(c, 'layer_norm_elementwise_affine', True):
+            raise ValueError('opt: post-layer-norm blocks (opt-350m), a projected word embedding, a non-ReLU activation or bias-free layers have no native implementation')
         return opt_cfg(c.hidden_size, c.ffn_dim, c.num_hidden_layers, c.num_attention_heads, c.vocab_size,
                        c.max_position_embeddings)
     raise ValueError(f'model_type {mt!r} has no native MI355X implementation (llava, llama, qwen2, qwen2_vl, qwen2_audio, qwen3_moe, opt are built)')

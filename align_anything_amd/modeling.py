@@ -14,6 +14,7 @@ Memory: nothing is recomputed -- 288 GB HBM holds all saved activations of a 7B 
 """
 from __future__ import annotations
 
+import math
 import os
 
 import torch
@@ -28,9 +29,33 @@ def _pad64(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
-def rope_tables(max_pos: int, hd: int, theta: float, device, dtype=bf16):
-    """hf:models/llama/modeling_llama.py:113-127: inv_freq / freqs in fp32, cos & sin cast to the activation dtype."""
+def rope_inv_freq(hd: int, theta: float, scaling=None) -> torch.Tensor:
+    """Inverse frequencies of the rotary embedding, fp32 on the host (hf:modeling_rope_utils.py ROPE_INIT_FUNCTIONS; all three types have an
+    attention factor of 1, so cos / sin are not rescaled).  scaling (configs.rope_scaling_of):
+      None      theta^(-2i/d)
+      linear    position interpolation: every frequency divided by `factor`
+      llama3    Llama-3.1: wavelengths longer than old_ctx / low_freq_factor are stretched by `factor`, those shorter than old_ctx / high_freq_factor
+                are kept, the band between is blended linearly in old_ctx / wavelength."""
     inv_freq = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.int64).to(torch.float32) / hd))
+    if not scaling:
+        return inv_freq
+    if scaling['type'] == 'linear':
+        return inv_freq / float(scaling['factor'])
+    if scaling['type'] == 'llama3':
+        factor, lo, hi = float(scaling['factor']), float(scaling['low_freq_factor']), float(scaling['high_freq_factor'])
+        old_ctx = float(scaling['original_max_position_embeddings'])
+        wavelen = 2.0 * math.pi / inv_freq
+        stretched = torch.where(wavelen > old_ctx / lo, inv_freq / factor, inv_freq)
+        blend = (old_ctx / wavelen - lo) / (hi - lo)
+        mid = (1.0 - blend) * stretched / factor + blend * stretched
+        in_band = ~(wavelen < old_ctx / hi) & ~(wavelen > old_ctx / lo)
+        return torch.where(in_band, mid, stretched)
+    raise ValueError(f'rope scaling {scaling!r} has no native implementation')
+
+
+def rope_tables(max_pos: int, hd: int, theta: float, device, dtype=bf16, scaling=None):
+    """hf:models/llama/modeling_llama.py:113-127: inv_freq / freqs in fp32, cos & sin cast to the activation dtype."""
+    inv_freq = rope_inv_freq(hd, theta, scaling)
     freqs = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv_freq[None, :]
     return freqs.cos().to(dtype).to(device).contiguous(), freqs.sin().to(dtype).to(device).contiguous()
 
@@ -104,7 +129,7 @@ class LlamaStack:
     def _tables(self, T):
         if self.cos is None or self.cos.shape[0] < T:
             n = max(T, self.cfg.get('max_position_embeddings', 0) or T)
-            self.cos, self.sin = rope_tables(n, self.cfg['head_dim'], self.cfg['rope_theta'], self.store.device, self.store.dtype)
+            self.cos, self.sin = rope_tables(n, self.cfg['head_dim'], self.cfg['rope_theta'], self.store.device, self.store.dtype, self.cfg.get('rope_scaling'))
 
     def forward(self, x, N, T, start, pos, save, kv_sink=None, tables=None):
         """tables = (cos, sin) [rows, hd/2]: per-token rope rows (multimodal RoPE), indexed by pos[row]; default = the
@@ -1394,7 +1419,7 @@ class Qwen3MoeStack:
     def _tables(self, T):
         if self.cos is None or self.cos.shape[0] < T:
             n = max(T, self.cfg.get('max_position_embeddings', 0) or T)
-            self.cos, self.sin = rope_tables(n, self.cfg['head_dim'], self.cfg['rope_theta'], self.store.device, self.store.dtype)
+            self.cos, self.sin = rope_tables(n, self.cfg['head_dim'], self.cfg['rope_theta'], self.store.device, self.store.dtype, self.cfg.get('rope_scaling'))
 
     def kv_width(self):
         return 2 * self.cfg['num_kv_heads'] * self.cfg['head_dim']
@@ -1693,13 +1718,28 @@ class NativeLlama(NativeCausalLM):
         st = self.store
         self.embed = st.add('model.embed_tokens.weight', (cfg['vocab_size'], cfg['hidden_size']), trainable, f32_grad=True)
         self.stack = LlamaStack(cfg, st, 'model.', trainable)
+        # config.tie_word_embeddings (Llama-3.2-1B / 3B, Qwen2.5-0.5B ... 3B): lm_head IS the embedding matrix -- one parameter, whose fp32 gradient
+        # buffer takes the head's dW (accumulated) and the embedding's scatter-add, as NativeOPT does it
+        self.tied = bool(cfg.get('tie_word_embeddings')) and head == 'lm'
         if head == 'lm':
-            lm = st.add('lm_head.weight', (cfg['vocab_size'], cfg['hidden_size']), trainable)
+            lm = self.embed if self.tied else st.add('lm_head.weight', (cfg['vocab_size'], cfg['hidden_size']), trainable)
             self.head = LMHead(st, 'rms', self.stack.norm, None, lm, cfg['rms_eps'], trainable)
         else:
             sw = st.add('score_head.weight', (1, cfg['hidden_size']), trainable, f32_grad=True)
             self.head = ScoreHead(st, 'rms', self.stack.norm, None, sw, cfg['rms_eps'], trainable)
         self.finalize()
+
+    def load_state_dict(self, sd, strict=True):
+        if self.tied and isinstance(sd, dict):
+            sd = dict(sd)
+            sd.pop('lm_head.weight', None)      # tied: the store has no tensor of that name (a lazy checkpoint's copy, if any, is never read)
+        return super().load_state_dict(sd, strict)
+
+    def state_dict(self):
+        sd = super().state_dict()
+        if self.tied:
+            sd['lm_head.weight'] = sd['model.embed_tokens.weight']
+        return sd
 
     def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
                        position_ids=None, kv_sink=None):

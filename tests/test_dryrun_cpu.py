@@ -793,3 +793,31 @@ def test_text_image_trainers_build_themselves_from_cfgs(launches, tmp_path):
         ev = ppo.eval_history[-1][1]
         assert len(ev['eval/prompts']) == 4 and len(ev['eval/generated']) == 4 and all(isinstance(x, str) for x in ev['eval/generated'])
     assert 'aa_attn_decode' in launches and 'aa_ppo_actor_loss' in launches and 'aa_decode_tick' in launches
+
+
+def test_dpo_step_on_a_llama_with_tied_embeddings(launches):
+    """tie_word_embeddings on the Llama family (host flow; the launches are recorded): the head's weight gradient goes into the EMBEDDING's fp32
+    gradient buffer with accumulate = 1 (the embedding's own scatter-add lands in the same buffer later in the backward), the optimizer sees one
+    parameter, and the frozen reference model carries no second matrix either."""
+    from align_anything_amd import configs, ops
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    z = load_golden('opt_tiny_dpo.npz')
+    cfg = configs.llama_cfg(128, 256, 2, 2, 2, 320, rms_eps=1e-5, max_position_embeddings=256, tie_word_embeddings=True)
+    seen = []
+    real = ops.lmhead_logprob_bwd
+
+    def spy(n, w, labels, lse, dlogp, dw=None, accumulate=False):
+        seen.append((w.data_ptr(), None if dw is None else (dw.data_ptr(), dw.dtype, bool(accumulate))))
+        return real(n, w, labels, lse, dlogp, dw=dw, accumulate=accumulate)
+
+    tr = DPOTrainer(_cfgs(z), {'gradient_clipping': 1.0}, model_cfg=cfg, device='cpu')
+    assert tr.policy.tied and tr.reference.tied and 'lm_head.weight' not in tr.policy.store.specs
+    n_untied = DPOTrainer(_cfgs(z), {'gradient_clipping': 1.0}, model_cfg=dict(cfg, tie_word_embeddings=False), device='cpu').policy.parameters_count()
+    assert n_untied - tr.policy.parameters_count() == 320 * 128
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setattr(ops, 'lmhead_logprob_bwd', spy)
+        info = tr.train_step(_pref_batch(z))
+    assert 'train/loss' in info and tr.model.global_steps == 1 and 'aa_embed_bwd' in launches
+    st = tr.policy.store
+    assert seen and all(w == st.p[tr.policy.embed].data_ptr() for w, _ in seen)
+    assert all(g == (st.g[tr.policy.embed].data_ptr(), torch.float32, True) for _, g in seen)

@@ -987,3 +987,65 @@ def test_device_prefetcher_retires_the_producer_of_an_abandoned_iterator():
     while threading.active_count() > before and time.time() < deadline:
         time.sleep(0.01)
     assert threading.active_count() == before
+
+
+def test_rope_scaling_matches_hf_and_unknown_types_raise():
+    """configs.rope_scaling_of + modeling.rope_inv_freq against transformers' own rotary embedding: 'llama3' (meta-llama/Llama-3.1-8B-Instruct's
+    published parameters: the reference's text-to-text default, scripts/llama/*.sh) and 'linear'; a type that is not built raises instead of
+    being dropped (wrong logits at every position otherwise)."""
+    from types import SimpleNamespace
+    import transformers as tf
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
+    from align_anything_amd import configs
+    from align_anything_amd.modeling import rope_inv_freq, rope_tables
+    base = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=2, vocab_size=64, max_position_embeddings=131072)
+    cases = {'llama3': {'rope_type': 'llama3', 'rope_theta': 500000.0, 'factor': 8.0, 'low_freq_factor': 1.0, 'high_freq_factor': 4.0, 'original_max_position_embeddings': 8192},
+             'linear': {'rope_type': 'linear', 'rope_theta': 10000.0, 'factor': 4.0},
+             'default': {'rope_type': 'default', 'rope_theta': 10000.0}}
+    for name, rp in cases.items():
+        hf_cfg = tf.LlamaConfig(**base, rope_parameters=dict(rp))
+        cfg = configs.from_hf_config(hf_cfg)
+        assert (cfg['rope_scaling'] or {}).get('type') == (None if name == 'default' else name)
+        rot = LlamaRotaryEmbedding(hf_cfg)
+        inv = rope_inv_freq(cfg['head_dim'], cfg['rope_theta'], cfg['rope_scaling'])
+        assert torch.equal(inv, rot.inv_freq.float()), (name, float((inv - rot.inv_freq).abs().max()))
+        pos = torch.tensor([[0, 1, 17, 4095, 8191, 8192, 60000]])
+        cos, sin = rot(torch.zeros(1, 7, 8), pos)
+        mine_c, mine_s = rope_tables(60001, cfg['head_dim'], cfg['rope_theta'], 'cpu', torch.float32, cfg['rope_scaling'])
+        assert torch.allclose(mine_c[pos[0]], cos[0, :, :cfg['head_dim'] // 2], atol=1e-6) and torch.allclose(mine_s[pos[0]], sin[0, :, :cfg['head_dim'] // 2], atol=1e-6), name
+    assert not torch.equal(rope_inv_freq(128, 500000.0, configs.rope_scaling_of(tf.LlamaConfig(**base, rope_parameters=dict(cases['llama3'])))), rope_inv_freq(128, 500000.0))
+    # transformers-4.x spelling: `rope_scaling` with the key 'type'
+    old = SimpleNamespace(rope_parameters=None, rope_scaling={'type': 'linear', 'factor': 2.0}, max_position_embeddings=4096)
+    assert configs.rope_scaling_of(old) == {'type': 'linear', 'factor': 2.0}
+    with pytest.raises(ValueError, match='yarn'):
+        configs.rope_scaling_of(SimpleNamespace(rope_parameters={'rope_type': 'yarn', 'factor': 4.0}, max_position_embeddings=4096))
+    with pytest.raises(ValueError, match='post-layer-norm'):
+        configs.from_hf_config(tf.OPTConfig(hidden_size=64, ffn_dim=128, num_hidden_layers=1, num_attention_heads=2, vocab_size=50, do_layer_norm_before=False))
+    with pytest.raises(ValueError, match='mlp_bias'):
+        configs.from_hf_config(tf.LlamaConfig(**base, mlp_bias=True))
+
+
+def test_llama_family_checkpoint_with_tied_embeddings_loads_and_saves(tmp_path):
+    """config.tie_word_embeddings (Llama-3.2-1B / 3B, Qwen2.5-0.5B ... 3B): the checkpoint has no lm_head tensor; the native model keeps ONE
+    parameter for both roles (as NativeOPT does), `state_dict()` shows it under both names, and a save -> HF load round trip keeps the tie."""
+    import transformers as tf
+    from align_anything_amd.checkpoint import load_pretrained
+    torch.manual_seed(0)
+    hf_cfg = tf.Qwen2Config(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=320,
+                            max_position_embeddings=256, tie_word_embeddings=True)
+    hf = tf.Qwen2ForCausalLM(hf_cfg).eval()
+    d = str(tmp_path / 'tied')
+    hf.save_pretrained(d)
+    m, _, _, _ = load_pretrained(d, 'cpu', trainable=True, with_tokenizer=False)
+    assert m.tied and m.cfg['attention_bias'] and 'lm_head.weight' not in m.store.specs and m.head.lm_w == m.embed
+    sd = m.state_dict()
+    assert torch.equal(sd['lm_head.weight'], sd['model.embed_tokens.weight'])
+    assert torch.equal(sd['model.embed_tokens.weight'].float(), hf.state_dict()['model.embed_tokens.weight'].to(torch.bfloat16).float())
+    m.init_training()
+    assert m.store.g[m.embed].dtype == torch.float32          # the shared gradient buffer: head dW accumulates into it, the embedding scatter-adds
+    m.load_state_dict(sd)                                      # its own state dict (with the alias) loads back
+    untied = tf.Qwen2Config(**{**hf_cfg.to_dict(), 'tie_word_embeddings': False})
+    d2 = str(tmp_path / 'untied')
+    tf.Qwen2ForCausalLM(untied).save_pretrained(d2)
+    m2, _, _, _ = load_pretrained(d2, 'cpu', trainable=False, with_tokenizer=False)
+    assert not m2.tied and 'lm_head.weight' in m2.store.specs
