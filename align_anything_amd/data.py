@@ -234,7 +234,12 @@ class DevicePrefetcher:
         t.start()
         try:
             while True:
-                item = q.get()
+                try:
+                    item = q.get(timeout=0.2)
+                except Empty:
+                    if cancel.is_set():       # a newer iteration of the same loader retired this one's producer: fail, do not wait forever
+                        raise RuntimeError('DevicePrefetcher: this iterator was retired by a newer iteration of the same loader') from None
+                    continue
                 if item is stop:
                     break
                 if isinstance(item, BaseException):

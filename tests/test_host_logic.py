@@ -1049,3 +1049,14 @@ def test_llama_family_checkpoint_with_tied_embeddings_loads_and_saves(tmp_path):
     tf.Qwen2ForCausalLM(untied).save_pretrained(d2)
     m2, _, _, _ = load_pretrained(d2, 'cpu', trainable=False, with_tokenizer=False)
     assert not m2.tied and 'lm_head.weight' in m2.store.specs
+
+
+def test_device_prefetcher_nested_iteration_fails_instead_of_hanging():
+    from align_anything_amd.data import DevicePrefetcher
+    pf = DevicePrefetcher([{'input_ids': torch.full((1, 2), i)} for i in range(6)], 'cpu', depth=1)
+    outer = iter(pf)
+    next(outer)
+    assert [int(b['input_ids'][0, 0]) for b in pf] == list(range(6))       # a second iteration retires the first one's producer ...
+    with pytest.raises(RuntimeError, match='retired'):
+        for _ in range(6):
+            next(outer)                                                      # ... whose consumer is told so (after the batches already staged)
