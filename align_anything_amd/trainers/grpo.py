@@ -23,32 +23,50 @@ class GRPOTrainer:
 
     def __init__(self, cfgs, ds_cfgs=None, *, model_cfg=None, reward_model_cfg=None, actor_state=None, reference_state=None,
                  reward_state=None, reward_fn=None, device='cuda:0'):
-        t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
-        self.cfgs, self.device = cfgs, torch.device(device)
+        """`GRPOTrainer(cfgs, ds_cfgs)` alone, as the reference's constructor (text_to_text/grpo.py:55-75): actor / reference from
+        model_cfgs.actor_model_name_or_path, reward model from reward_model_name_or_path (grpo.py:84-133), prompts from data_cfgs (:135-139);
+        the keyword arguments inject pre-built pieces.  Phases = the reference's methods in its order (grpo.py:69-75)."""
+        self.cfgs, self.ds_train_cfgs, self.device = cfgs, ds_cfgs, torch.device(device)
+        self.model_cfg, self.reward_model_cfg, self.reward_fn = model_cfg, reward_model_cfg, reward_fn
         self.tokenizer = self.processor = self.hf_config = None
         self.prompt_only_dataloader = self.eval_dataloader = None
-        from_paths = model_cfg is None
-        if from_paths:
-            # `GRPOTrainer(cfgs, ds_cfgs)` alone, as the reference's constructor (text_to_text/grpo.py:55-75): actor / reference from
-            # model_cfgs.actor_model_name_or_path, reward model from reward_model_name_or_path (grpo.py:84-133), prompts from data_cfgs (:135-139)
-            from transformers import AutoConfig
-            from .. import configs as _configs
-            ap_, rp_ = cfg_get(cfgs, 'model_cfgs.actor_model_name_or_path', None), cfg_get(cfgs, 'model_cfgs.reward_model_name_or_path', None)
-            if not ap_ or (reward_fn is None and not rp_):
+        self.global_step = 0
+        self.init_check()
+        self.init_models(actor_state, reference_state, reward_state)
+        self.init_datasets()
+        self.init_engines()
+        self.init_logger()
+
+    # ------------------------------------------------------------------ init_* (grpo.py:69-196)
+    def init_check(self) -> None:
+        cfgs = self.cfgs
+        t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
+        self._from_paths = self.model_cfg is None
+        if self._from_paths:
+            self._paths = (cfg_get(cfgs, 'model_cfgs.actor_model_name_or_path', None), cfg_get(cfgs, 'model_cfgs.reward_model_name_or_path', None))
+            if not self._paths[0] or (self.reward_fn is None and not self._paths[1]):
                 raise ValueError('GRPOTrainer: model_cfg, or model_cfgs.actor_model_name_or_path (+ reward_model_name_or_path or a reward_fn), is required')
-            model_cfg = _configs.from_hf_config(AutoConfig.from_pretrained(ap_, trust_remote_code=True))
-            reward_model_cfg = _configs.from_hf_config(AutoConfig.from_pretrained(rp_, trust_remote_code=True)) if rp_ else None
         self.beta = float(t('beta', 0.04))                       # grpo.py:67 default
         self.num_generations = int(t('num_generations', 4))      # grpo.py:66
         self.pad_token_id = int(cfg_get(cfgs, 'model_cfgs.pad_token_id', 0))
         self.eos_token_id = int(cfg_get(cfgs, 'model_cfgs.eos_token_id', 2))
-        self.reward_fn = reward_fn
-        dt = compute_dtype(t('compute_dtype', 'bf16'))   # fp32 = parity mode (sequences / rewards must then be injected)
+
+    def init_models(self, actor_state=None, reference_state=None, reward_state=None) -> None:
+        cfgs, device = self.cfgs, self.device
+        model_cfg, reward_model_cfg = self.model_cfg, self.reward_model_cfg
+        dt = compute_dtype(cfg_get(cfgs, 'train_cfgs.compute_dtype', 'bf16'))   # fp32 = parity mode (sequences / rewards must then be injected)
+        if self._from_paths:
+            from transformers import AutoConfig
+            from .. import configs as _configs
+            ap_, rp_ = self._paths
+            model_cfg = _configs.from_hf_config(AutoConfig.from_pretrained(ap_, trust_remote_code=True))
+            reward_model_cfg = _configs.from_hf_config(AutoConfig.from_pretrained(rp_, trust_remote_code=True)) if rp_ else None
         # train_cfgs.expert_parallel (Qwen3-MoE, BASELINE configs[4]): actor, reference and reward model hold 1/world of the experts;
         # the rollout then exchanges tokens per decode position with every rank stepping in lockstep (generation.py)
         epk = expert_parallel_kwargs(cfgs, model_cfg)
         rpk = epk if (reward_model_cfg or model_cfg).get('kind') == 'qwen3moe' else {}
-        if from_paths:
+        reward = None
+        if self._from_paths:
             from ..checkpoint import load_pretrained
             mml = int(cfg_get(cfgs, 'model_cfgs.model_max_length', 512))
             actor, self.tokenizer, self.processor, self.hf_config = load_pretrained(ap_, device, trainable=True, dtype=dt, model_max_length=mml, padding_side='left',
@@ -57,6 +75,9 @@ class GRPOTrainer:
             if cfg_get(cfgs, 'model_cfgs.pad_token_id', None) is None and self.tokenizer is not None:
                 self.pad_token_id = int(self.tokenizer.pad_token_id)
                 self.eos_token_id = int(self.tokenizer.eos_token_id) if self.tokenizer.eos_token_id is not None else self.eos_token_id
+            if self.reward_fn is None:
+                reward = load_pretrained(rp_, device, trainable=False, head='score', dtype=dt, model_max_length=mml, padding_side='right', build_kwargs=rpk)[0]
+            model_cfg = actor.cfg
         else:
             actor = build_model(model_cfg, device, trainable=True, dtype=dt, **epk)
             ref = build_model(model_cfg, device, trainable=False, dtype=dt, **epk)
@@ -64,33 +85,43 @@ class GRPOTrainer:
                 actor.load_state_dict(actor_state)
             if reference_state is not None or actor_state is not None:
                 ref.load_state_dict(reference_state if reference_state is not None else actor_state)
-        # grpo.py:153-181: the schedule length comes from the prompt dataloader that train() receives; until then it is unknown
+            if self.reward_fn is None:
+                reward = build_model(reward_model_cfg or model_cfg, device, trainable=False, head='score', dtype=dt, **rpk)
+                if reward_state is not None:
+                    reward.load_state_dict(reward_state)
+        self.model_cfg, self.reward_model_cfg = model_cfg, reward_model_cfg
+        self._modules = {'actor': actor, 'ref': ref, 'reward': reward}
+
+    def init_datasets(self) -> None:
+        """grpo.py:135-139 `get_dataloaders(PromptOnlyDataset, PromptOnlyDataset, None)` through the reference's own dataset / template plugins."""
+        if not self._from_paths:
+            return               # injected models carry no tokenizer: the caller hands train() its dataloader
+        from .common import get_dataloaders
+        self.prompt_only_dataloader, self.eval_dataloader = get_dataloaders(self, 'PromptOnlyDataset', 'PromptOnlyDataset', rl=True)
+
+    def init_engines(self) -> None:
+        # grpo.py:153-181: the schedule length comes from the prompt dataloader that train() may still receive; until then it is unknown
         # (an explicit train_cfgs.total_training_steps wins) and a cosine engine refuses to step rather than decay to 0
+        cfgs, ds_cfgs, mods = self.cfgs, self.ds_train_cfgs, self._modules
+        t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
         self.gas = int(cfg_get(ds_cfgs, 'gradient_accumulation_steps', t('gradient_accumulation_steps', 1)))
         total = t('total_training_steps', None)
         total = None if total is None else max(1, int(total) // self.gas)
         self.actor_model = NativeEngine(
-            actor, lr=float(t('actor_lr', 1e-6)), betas=[float(b) for b in t('adam_betas', [0.9, 0.95])],
+            mods['actor'], lr=float(t('actor_lr', 1e-6)), betas=[float(b) for b in t('adam_betas', [0.9, 0.95])],
             weight_decay=float(t('actor_weight_decay', 0.01)), max_grad_norm=float(cfg_get(ds_cfgs, 'gradient_clipping', 1.0)),
             total_steps=total, warmup_steps=int(float(t('actor_lr_warmup_ratio', 0.03)) * (total or 0)),
             lr_scheduler_type=t('actor_lr_scheduler_type', 'cosine'), gradient_accumulation_steps=self.gas)
-        self.actor_reference_model = NativeEngine(ref, trainable=False)
-        self.reward_model = None
-        if reward_fn is None:
-            if from_paths:
-                reward = load_pretrained(rp_, device, trainable=False, head='score', dtype=dt, model_max_length=mml, padding_side='right', build_kwargs=rpk)[0]
-            else:
-                reward = build_model(reward_model_cfg or model_cfg, device, trainable=False, head='score', dtype=dt, **rpk)
-                if reward_state is not None:
-                    reward.load_state_dict(reward_state)
-            self.reward_model = NativeEngine(reward, trainable=False)
-        if from_paths:
-            self.init_datasets()
+        self.actor_reference_model = NativeEngine(mods['ref'], trainable=False)
+        self.reward_model = NativeEngine(mods['reward'], trainable=False) if mods['reward'] is not None else None
+        self._modules = None
 
-    def init_datasets(self) -> None:
-        """grpo.py:135-139 `get_dataloaders(PromptOnlyDataset, PromptOnlyDataset, None)` through the reference's own dataset / template plugins."""
-        from .common import get_dataloaders
-        self.prompt_only_dataloader, self.eval_dataloader = get_dataloaders(self, 'PromptOnlyDataset', 'PromptOnlyDataset', rl=True)
+    def init_logger(self) -> None:
+        self.logger = None          # observability is out of scope (SURVEY.md section 2 row 12); train() returns the metrics
+
+    def set_train(self, mode: bool = True) -> None:
+        """base/rl_trainer.py:274-286."""
+        self.actor_model.module.train(mode)
 
     # ------------------------------------------------------------------ grpo.py:212-227
     def generate_completions(self, prompt_batch, generator=None):

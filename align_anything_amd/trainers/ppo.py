@@ -71,37 +71,56 @@ class PPOTrainer(PPOMath):
                  critic_state=None, device='cuda:0', reward_fn=None, use_ptx=None):
         """reward_fn(input_ids, attention_mask) -> [N] scores replaces the learned reward model: the rule / remote reward of
         trainers/text_to_text/ppo_remote_rm.py:321-347 (decode prompts + responses on the host, score them over HTTP with
-        `remote_rm_client.score`; that string work stays the caller's Python) -- the critic still comes from `reward_model_cfg`."""
-        t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
+        `remote_rm_client.score`; that string work stays the caller's Python) -- the critic still comes from `reward_model_cfg`.
+        The phases are the reference's own methods in its order (text_to_text/ppo.py:62-91): init_check, init_models, init_datasets,
+        init_engines, init_logger -- a modality subclass overrides `init_models` / `init_datasets` as the reference's do."""
+        self.cfgs, self.ds_train_cfgs, self.device = cfgs, ds_cfgs, torch.device(device)
+        self.model_cfg, self.reward_model_cfg, self.reward_fn = model_cfg, reward_model_cfg, reward_fn
+        self._use_ptx_arg = use_ptx
+        self.tokenizer = self.processor = self.hf_config = None
+        self.prompt_only_dataloader = self.eval_dataloader = self.ptx_dataloader = None
+        self.global_step = 0
+        self.init_check()
+        self.init_models(actor_state, reward_state, critic_state)
+        self.init_datasets()
+        self.init_engines()
+        self.init_logger()
+
+    # ------------------------------------------------------------------ init_* (ppo.py:62-207, base/rl_trainer.py:217-272)
+    def init_check(self) -> None:
+        t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
         PPOMath.__init__(self, kl_coeff=float(t('kl_coeff', 0.02)), clip_range_score=float(t('clip_range_score', 50.0)),
                          gamma=float(t('gamma', 1.0)), gae_lambda=float(t('gae_lambda', 0.95)),
                          clip_range_ratio=float(t('clip_range_ratio', 0.2)), clip_range_value=float(t('clip_range_value', 5.0)))
-        self.cfgs, self.device = cfgs, torch.device(device)
         self.ptx_coeff = float(t('ptx_coeff', 16.0))        # configs/train/text_to_text/ppo.yaml:71
-        dt = compute_dtype(t('compute_dtype', 'bf16'))   # fp32 = parity mode for the update phase (rollouts need bf16)
-        self.tokenizer = self.processor = self.hf_config = None
-        self.prompt_only_dataloader = self.eval_dataloader = self.ptx_dataloader = None
-        from_paths = model_cfg is None
-        if from_paths:
-            # `PPOTrainer(cfgs, ds_cfgs)` alone, as the reference's constructor (text_to_text/ppo.py:62-91): geometry of the four models from the
-            # config.json under model_cfgs.{actor,reward,reward_critic}_model_name_or_path (ppo.py:93-147); the weights are streamed in below
-            from transformers import AutoConfig
-            from .. import configs as _configs
-            m_ = lambda k: cfg_get(cfgs, 'model_cfgs.' + k, None)
+        self._from_paths = self.model_cfg is None
+        if self._from_paths:
+            m_ = lambda k: cfg_get(self.cfgs, 'model_cfgs.' + k, None)
             if not m_('actor_model_name_or_path'):
                 raise ValueError('PPOTrainer: model_cfg or model_cfgs.actor_model_name_or_path is required')
             self._paths = {'actor': m_('actor_model_name_or_path'), 'reward': m_('reward_model_name_or_path'),
                            'critic': m_('reward_critic_model_name_or_path') or m_('reward_model_name_or_path')}
-            if reward_fn is None and not self._paths['reward']:
+            if self.reward_fn is None and not self._paths['reward']:
                 raise ValueError('PPOTrainer: model_cfgs.reward_model_name_or_path (or a reward_fn) is required')
+
+    def init_models(self, actor_state=None, reward_state=None, critic_state=None) -> None:
+        """ppo.py:93-147: actor (trainable, left padding), reference (frozen, same checkpoint), reward model (frozen score model, right padding;
+        absent with a reward_fn), reward critic (trainable score model, from reward_critic_model_name_or_path or the reward model's directory)."""
+        cfgs, device = self.cfgs, self.device
+        dt = compute_dtype(cfg_get(cfgs, 'train_cfgs.compute_dtype', 'bf16'))   # fp32 = parity mode for the update phase (rollouts need bf16)
+        model_cfg, reward_fn = self.model_cfg, self.reward_fn
+        if self._from_paths:
+            # `PPOTrainer(cfgs, ds_cfgs)` alone, as the reference's constructor: geometry of the four models from the config.json under
+            # model_cfgs.{actor,reward,reward_critic}_model_name_or_path; the weights are streamed in below
+            from transformers import AutoConfig
+            from .. import configs as _configs
             model_cfg = _configs.from_hf_config(AutoConfig.from_pretrained(self._paths['actor'], trust_remote_code=True))
             rp = self._paths['critic'] or self._paths['actor']
-            reward_model_cfg = _configs.from_hf_config(AutoConfig.from_pretrained(rp, trust_remote_code=True))
-        rcfg = reward_model_cfg or model_cfg
+            self.reward_model_cfg = _configs.from_hf_config(AutoConfig.from_pretrained(rp, trust_remote_code=True))
+        rcfg = self.reward_model_cfg or model_cfg
         epk = expert_parallel_kwargs(cfgs, model_cfg)            # train_cfgs.expert_parallel on a Qwen3-MoE actor (see trainers/grpo.py)
-        self.reward_fn = reward_fn
         rpk = epk if rcfg.get('kind') == 'qwen3moe' else {}
-        if from_paths:
+        if self._from_paths:
             from ..checkpoint import load_pretrained
             mml = int(cfg_get(cfgs, 'model_cfgs.model_max_length', 512))
             actor, self.tokenizer, self.processor, self.hf_config = load_pretrained(self._paths['actor'], device, trainable=True, dtype=dt, model_max_length=mml,
@@ -126,32 +145,55 @@ class PPOTrainer(PPOMath):
             reward.load_state_dict(reward_state)
         if critic_state is not None or reward_state is not None:
             critic.load_state_dict(critic_state if critic_state is not None else reward_state)
+        self.model_cfg, self.reward_model_cfg = model_cfg, rcfg
+        self._modules = {'actor': actor, 'ref': ref, 'reward': reward, 'critic': critic}
+
+    def init_engines(self) -> None:
+        cfgs, ds_cfgs = self.cfgs, self.ds_train_cfgs
+        t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
+        mods = self._modules
         clip = float(cfg_get(ds_cfgs, 'gradient_clipping', 1.0))
         betas = [float(b) for b in t('actor_betas', t('adam_betas', [0.9, 0.95]))]
-        # base/rl_trainer.py:217-260: the schedule length comes from the prompt dataloader, which train() receives -> the engines start
+        # base/rl_trainer.py:217-260: the schedule length comes from the prompt dataloader, which train() may still receive -> the engines start
         # with an unknown total (explicit train_cfgs.total_training_steps = number of MICRO steps wins) and train() fills it in.
         # With a PTX dataset the actor accumulates over (rl_step, ptx_step) pairs: its accumulation depth and micro-step total double
         # (:231-234), so both losses are scaled by 1 / (2 gas) and land in ONE optimizer update.
-        self.use_ptx = bool(cfg_get(cfgs, 'data_cfgs.ptx_datasets', None)) if use_ptx is None else bool(use_ptx)
+        self.use_ptx = bool(cfg_get(cfgs, 'data_cfgs.ptx_datasets', None)) if self._use_ptx_arg is None else bool(self._use_ptx_arg)
         self.gas = int(cfg_get(ds_cfgs, 'gradient_accumulation_steps', t('gradient_accumulation_steps', 1)))
         total = t('total_training_steps', None)
         a_gas = self.gas * (2 if self.use_ptx else 1)
         a_total = None if total is None else max(1, int(total) * (2 if self.use_ptx else 1) // a_gas)
         c_total = None if total is None else max(1, int(total) // self.gas)
-        self.actor_model = NativeEngine(actor, lr=float(t('actor_lr', 1e-5)), betas=betas, weight_decay=float(t('actor_weight_decay', 0.01)),
+        self.actor_model = NativeEngine(mods['actor'], lr=float(t('actor_lr', 1e-5)), betas=betas, weight_decay=float(t('actor_weight_decay', 0.01)),
                                         max_grad_norm=clip, total_steps=a_total, warmup_steps=int(float(t('actor_lr_warmup_ratio', 0.03)) * (a_total or 0)),
                                         lr_scheduler_type=t('actor_lr_scheduler_type', 'cosine'), gradient_accumulation_steps=a_gas)
-        self.reward_critic_model = NativeEngine(critic, lr=float(t('critic_lr', 5e-6)), betas=betas, weight_decay=float(t('critic_weight_decay', 0.0)),
+        self.reward_critic_model = NativeEngine(mods['critic'], lr=float(t('critic_lr', 5e-6)), betas=betas, weight_decay=float(t('critic_weight_decay', 0.0)),
                                                 max_grad_norm=clip, total_steps=c_total, warmup_steps=int(float(t('critic_lr_warmup_ratio', 0.03)) * (c_total or 0)),
                                                 lr_scheduler_type=t('critic_lr_scheduler_type', 'constant'), gradient_accumulation_steps=self.gas)
-        self.actor_reference_model = NativeEngine(ref, trainable=False)
-        self.reward_model = NativeEngine(reward, trainable=False) if reward is not None else None
-        if from_paths:
-            self.init_datasets()
+        self.actor_reference_model = NativeEngine(mods['ref'], trainable=False)
+        self.reward_model = NativeEngine(mods['reward'], trainable=False) if mods['reward'] is not None else None
+        self._modules = None
+
+    def init_logger(self) -> None:
+        self.logger = None          # observability is out of scope; train() returns the metrics
+
+    def set_train(self, mode: bool = True) -> None:
+        """ppo.py:400-408 / base/rl_trainer.py:274-286: training mode for the two trainable engines (the native models carry no dropout; the
+        flag is kept for callers that branch on it)."""
+        self.actor_model.module.train(mode)
+        self.reward_critic_model.module.train(mode)
+
+    @staticmethod
+    def split_ptx_micro_batches(ptx_batch) -> list:
+        """ppo.py:195-207: a PTX batch becomes ONE-row micro-batches (`split_ptx_micro_batches` slices with micro_batch_size = 1 ... in
+        steps of per_device_train_batch_size; the reference's quirk kept: one row each)."""
+        return [{k: (v[i:i + 1] if isinstance(v, torch.Tensor) else v) for k, v in ptx_batch.items()} for i in range(ptx_batch['input_ids'].shape[0])]
 
     def init_datasets(self) -> None:
         """ppo.py:149-154 `get_dataloaders(PromptOnlyDataset, PromptOnlyDataset, SupervisedDataset)` through the reference's own dataset / template
         plugins (common.get_dataloaders, RL batch sizes); `train()` falls back to these loaders when called without arguments."""
+        if not self._from_paths:
+            return               # injected models carry no tokenizer: the caller hands train() its dataloaders
         from .common import get_dataloaders
         self.pad_token_id = cfg_get(self.cfgs, 'model_cfgs.pad_token_id', getattr(self.tokenizer, 'pad_token_id', None))
         self.prompt_only_dataloader, self.eval_dataloader, self.ptx_dataloader = get_dataloaders(self, 'PromptOnlyDataset', 'PromptOnlyDataset',
@@ -302,7 +344,7 @@ class PPOTrainer(PPOMath):
                 rollouts = [self.rollout(self._rows(prompt_batch, i, i + step), generator) for i in range(0, n, step)]
                 if use_ptx:
                     pb = next(ptx_iter)
-                    ptx_batches = [self._rows(pb, i, i + 1) for i in range(pb['input_ids'].shape[0])]
+                    ptx_batches = self.split_ptx_micro_batches(pb)
                 else:
                     ptx_batches = [None] * len(rollouts)
                 for _ in range(update_iters):

@@ -13,40 +13,68 @@ from .common import END_AT_LAST_POSITION_KINDS, cfg_get, eval_due, compute_dtype
 
 
 class RMTrainer:
+    dataset_types = ('PreferenceDataset', 'PreferenceDataset')          # rm.py:87-91
+
     def __init__(self, cfgs, ds_cfgs=None, *, model_cfg=None, state=None, device='cuda:0', train_dataloader=None):
         """`RMTrainer(cfgs, ds_cfgs)` alone follows the reference's constructor (text_to_text/rm.py:52-72): the score model, tokenizer and
         processor come from `model_cfgs.model_name_or_path` (rm.py:76-85: `is_reward_model=True`, right padding; a language-model checkpoint
         without a score head starts with the native initialisation of it) and the dataloaders from `data_cfgs` (rm.py:87-91); the keyword
-        arguments inject pre-built pieces instead."""
-        t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
-        self.cfgs, self.device = cfgs, torch.device(device)
-        self.regularization = float(t('regularization', 0.001))
+        arguments inject pre-built pieces instead.  The phases are the reference's own methods, in its order (rm.py:57-67), so a subclass
+        overrides `init_models` / `init_datasets` / `loss` as the reference's modality trainers do."""
+        self.cfgs, self.ds_train_cfgs, self.device = cfgs, ds_cfgs, torch.device(device)
+        self.model_cfg = model_cfg
         self.tokenizer = self.processor = self.hf_config = None
         self.train_dataloader, self.eval_dataloader = train_dataloader, None
-        if model_cfg is None:
+        self.global_step = 0
+        self.infer_batch = lambda batch: {k: v for k, v in batch.items() if k != 'meta_info'}
+        self.init_check()
+        self.init_models(state)
+        self.init_datasets()
+        self.init_engines()
+        self.init_logger()
+
+    # ------------------------------------------------------------------ init_* (rm.py:57-95)
+    def init_check(self) -> None:
+        if self.model_cfg is None and not cfg_get(self.cfgs, 'model_cfgs.model_name_or_path', None):
+            raise ValueError('RMTrainer: model_cfg or model_cfgs.model_name_or_path is required')
+        self.regularization = float(cfg_get(self.cfgs, 'train_cfgs.regularization', 0.001))
+
+    def init_models(self, state=None) -> None:
+        dt = compute_dtype(cfg_get(self.cfgs, 'train_cfgs.compute_dtype', 'bf16'))
+        if self.model_cfg is None:
             from ..checkpoint import load_pretrained
-            path = cfg_get(cfgs, 'model_cfgs.model_name_or_path', None)
-            if not path:
-                raise ValueError('RMTrainer: model_cfg or model_cfgs.model_name_or_path is required')
-            module, self.tokenizer, self.processor, self.hf_config = load_pretrained(
-                path, device, trainable=True, head='score', dtype=compute_dtype(t('compute_dtype', 'bf16')),
-                model_max_length=int(cfg_get(cfgs, 'model_cfgs.model_max_length', 512)), padding_side='right')
+            self.module, self.tokenizer, self.processor, self.hf_config = load_pretrained(
+                cfg_get(self.cfgs, 'model_cfgs.model_name_or_path', None), self.device, trainable=True, head='score', dtype=dt,
+                model_max_length=int(cfg_get(self.cfgs, 'model_cfgs.model_max_length', 512)), padding_side='right')
+            self.model_cfg = self.module.cfg
             self.pad_token_id = getattr(self.tokenizer, 'pad_token_id', None)
-            if self.train_dataloader is None:
-                from .common import get_dataloaders
-                self.train_dataloader, self.eval_dataloader = get_dataloaders(self, 'PreferenceDataset', 'PreferenceDataset')
-        else:
-            module = build_model(model_cfg, device, trainable=True, head='score', dtype=compute_dtype(t('compute_dtype', 'bf16')))
-            if state is not None:
-                module.load_state_dict(state)
+            self._from_path = True
+            return
+        self._from_path = False
+        self.module = build_model(self.model_cfg, self.device, trainable=True, head='score', dtype=dt)
+        if state is not None:
+            self.module.load_state_dict(state)
+
+    def init_datasets(self) -> None:
+        """rm.py:87-91 `get_dataloaders(PreferenceDataset, PreferenceDataset)` through the reference's own dataset / template plugins
+        (common.get_dataloaders) when the model came from a directory (its tokenizer is needed) and no dataloader was handed in."""
+        if self.train_dataloader is None and self._from_path:
+            from .common import get_dataloaders
+            self.train_dataloader, self.eval_dataloader = get_dataloaders(self, *self.dataset_types)
+
+    def init_engines(self) -> None:
         # base/supervised_trainer.py:236-257: epochs x ceil(len(dataloader) / gas) updates -- known once train() has the dataloader
-        self.gas = int(t('gradient_accumulation_steps', cfg_get(ds_cfgs, 'gradient_accumulation_steps', 1)))
+        t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
+        self.gas = int(t('gradient_accumulation_steps', cfg_get(self.ds_train_cfgs, 'gradient_accumulation_steps', 1)))
         total = t('total_training_steps', None)
         total = None if total is None else int(total)
-        self.model = NativeEngine(module, lr=float(t('learning_rate', 2e-5)), betas=[float(b) for b in t('adam_betas', [0.9, 0.95])],
-                                  weight_decay=float(t('weight_decay', 0.1)), max_grad_norm=float(cfg_get(ds_cfgs, 'gradient_clipping', 1.0)),
+        self.model = NativeEngine(self.module, lr=float(t('learning_rate', 2e-5)), betas=[float(b) for b in t('adam_betas', [0.9, 0.95])],
+                                  weight_decay=float(t('weight_decay', 0.1)), max_grad_norm=float(cfg_get(self.ds_train_cfgs, 'gradient_clipping', 1.0)),
                                   total_steps=total, warmup_steps=int(float(t('lr_warmup_ratio', 0.03)) * (total or 0)),
                                   lr_scheduler_type=t('lr_scheduler_type', 'cosine'), gradient_accumulation_steps=self.gas)
+
+    def init_logger(self) -> None:
+        self.logger = None          # observability is out of scope (SURVEY.md section 2 row 12); train() returns the metrics
 
     def _end_window(self, input_ids, attention_mask):
         """One row per sequence: the backbone's end position (device-side index math, no host sync)."""

@@ -1060,3 +1060,50 @@ def test_device_prefetcher_nested_iteration_fails_instead_of_hanging():
     with pytest.raises(RuntimeError, match='retired'):
         for _ in range(6):
             next(outer)                                                      # ... whose consumer is told so (after the batches already staged)
+
+
+def test_trainers_expose_the_reference_s_phase_methods():
+    """SURVEY.md section 8(b), trainer surface: the reference's trainers are built from init_check / init_models / init_datasets / init_engines /
+    init_logger (text_to_text/dpo.py:59-77, rm.py:57-67, ppo.py:62-91, grpo.py:69-75) and its modality subclasses override exactly those; the
+    native trainers keep the names so such a subclass ports over."""
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    from align_anything_amd.trainers.grpo import GRPOTrainer
+    from align_anything_amd.trainers.ppo import PPOTrainer
+    from align_anything_amd.trainers.ppo_ti2t import PPOTrainerTI2T
+    from align_anything_amd.trainers.rm import RMTrainer
+    from align_anything_amd.trainers.sft import SupervisedTrainer
+    phases = ['init_check', 'init_models', 'init_datasets', 'init_engines', 'init_logger']
+    for cls in (DPOTrainer, SupervisedTrainer, RMTrainer, PPOTrainer, PPOTrainerTI2T, GRPOTrainer):
+        assert all(callable(getattr(cls, n, None)) for n in phases + ['train', 'eval', 'save']), cls.__name__
+    for cls in (DPOTrainer, SupervisedTrainer, RMTrainer):
+        assert all(callable(getattr(cls, n, None)) for n in ('loss', 'train_step')), cls.__name__
+    for cls in (PPOTrainer, PPOTrainerTI2T):
+        assert all(callable(getattr(cls, n, None)) for n in ('rollout', 'rl_step', 'ptx_step', 'actor_step', 'set_train', 'split_ptx_micro_batches', 'actor_loss_fn',
+                                                             'critic_loss_fn', 'add_kl_divergence_regularization', 'get_advantages_and_returns')), cls.__name__
+    assert all(callable(getattr(GRPOTrainer, n, None)) for n in ('generate_completions', 'compute_rewards', 'train_step', 'set_train'))
+    # the phases run in the reference's order, and an overridden phase is the one that runs
+    order = []
+
+    class Probe(RMTrainer):
+        def init_check(self):
+            order.append('check')
+            super().init_check()
+
+        def init_models(self, state=None):
+            order.append('models')
+            self.module, self._from_path = None, False
+
+        def init_datasets(self):
+            order.append('datasets')
+
+        def init_engines(self):
+            order.append('engines')
+
+        def init_logger(self):
+            order.append('logger')
+
+    Probe({'train_cfgs': {}, 'model_cfgs': {'model_name_or_path': 'x'}}, None, device='cpu')
+    assert order == ['check', 'models', 'datasets', 'engines', 'logger']
+    pb = {'input_ids': torch.arange(6).reshape(3, 2), 'labels': torch.arange(6).reshape(3, 2), 'meta_info': {'k': 1}}
+    mb = PPOTrainer.split_ptx_micro_batches(pb)
+    assert len(mb) == 3 and mb[1]['input_ids'].tolist() == [[2, 3]] and mb[2]['meta_info'] == {'k': 1}
