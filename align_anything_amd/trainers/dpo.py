@@ -238,6 +238,7 @@ class DPOTrainer:
             history.append({'eval/step': 0, **self.eval()})
         for epoch in range(int(remain_epoch)):
             self.model.train()
+            self._epoch_begin()
             for batch_idx, batch in enumerate(self.train_dataloader):
                 if epoch == 0 and batch_idx < start_batch_idx:
                     continue
@@ -253,6 +254,9 @@ class DPOTrainer:
                 history.append({'eval/step': self.global_step, **self.eval()})
             self.model.tput_timer.update_epoch_count()
         return history
+
+    def _epoch_begin(self) -> None:
+        """Hook at the start of every epoch of `train()` (KTO refreshes its KL estimate here, kto.py:211-215)."""
 
     def eval(self) -> dict[str, Any]:
         return {}  # the reference's DPO eval is a stub (dpo.py:310-313)

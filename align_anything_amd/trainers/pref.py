@@ -77,24 +77,44 @@ class KTOTrainer(_SlicedPreferenceTrainer):
         return (float(cfg_get(self.cfgs, 'train_cfgs.scale_better', 1.0)), float(cfg_get(self.cfgs, 'train_cfgs.scale_worse', 1.0)),
                 float(self.kl))
 
-    def train(self, kl_dataloader=None):
-        """kto.py:196-240: at the start of every epoch whose first step index is a multiple of `kl_steps`, the KL estimate is refreshed
-        over the unmatched batches (`kl_dataloader`: prompts paired with a neighbour's response, datasets/text_to_text/supervised.py
-        UnmatchedSupervisedDataset) -- each batch overwrites the estimate, the last one stands, as in the reference's loop -- then the
-        ordinary preference steps run."""
-        history = []
-        epochs = int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))
-        kl_steps = max(1, int(cfg_get(self.cfgs, 'train_cfgs.kl_steps', 1)))
-        self.model.train()
-        for _ in range(epochs):
-            if kl_dataloader is not None and self.global_step % kl_steps == 0:
-                for b in kl_dataloader:
-                    self.compute_kl(b)
-            for batch in self.train_dataloader:
-                info = self.train_step(batch)
-                self.global_step += 1
-                info['train/epoch'] = self.global_step / max(1, len(self.train_dataloader))
-                history.append(info)
-            self.model.tput_timer.update_epoch_count()
-        return history
+    def build_kl_dataloader(self):
+        """kto.py:50-69: the reference's own `UnmatchedSupervisedDataset` (prompt i with the response of sample i - 1) over
+        `data_cfgs.train_datasets` with the training template, batches of `train_cfgs.per_device_kl_batch_size`, shuffled -- built when the
+        trainer came from `model_cfgs.model_name_or_path` (it needs the tokenizer and the template `init_datasets()` made).  None otherwise:
+        the caller hands `train()` its unmatched batches."""
+        template = getattr(self, 'train_template', None)
+        path = cfg_get(self.cfgs, 'data_cfgs.train_datasets', None)
+        if self.tokenizer is None or template is None or not path or isinstance(template, (list, tuple)):
+            return None
+        import importlib
+        import torch.distributed as dist
+        from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
+        from ..data import DevicePrefetcher
+        from .common import infer_modality
+        d = lambda k, default=None: cfg_get(self.cfgs, 'data_cfgs.' + k, default)
+        mod = importlib.import_module(f'align_anything.datasets.{infer_modality(self)}.supervised')
+        ds = mod.UnmatchedSupervisedDataset(path=path, template=template, tokenizer=self.tokenizer, processor=self.processor, name=d('train_name'), size=d('train_size'),
+                                            split=d('train_split'), data_files=d('train_data_files'), optional_args=d('train_optional_args', []))
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank() if world > 1 else 0
+        loader = DataLoader(ds, collate_fn=ds.get_collator(), sampler=DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True),
+                            batch_size=int(cfg_get(self.cfgs, 'train_cfgs.per_device_kl_batch_size', 64)))
+        return DevicePrefetcher(loader, self.device, self.pad_token_id)
 
+    def train(self, kl_dataloader=None):
+        """kto.py:196-250 = the DPO loop (evaluation, checkpoint and resume schedule included: DPOTrainer.train) with one addition: at the start
+        of every epoch whose first step index is a multiple of `kl_steps`, the KL estimate is refreshed over the unmatched batches
+        (`kl_dataloader`, or the reference's own UnmatchedSupervisedDataset built from data_cfgs: build_kl_dataloader) -- each batch overwrites
+        the estimate, the last one stands, as in the reference's loop -- then the ordinary preference steps run."""
+        self._kl_loader = kl_dataloader if kl_dataloader is not None else self.build_kl_dataloader()
+        try:
+            return super().train()
+        finally:
+            self._kl_loader = None
+
+    def _epoch_begin(self) -> None:
+        kl_steps = max(1, int(cfg_get(self.cfgs, 'train_cfgs.kl_steps', 1)))
+        if getattr(self, '_kl_loader', None) is not None and self.global_step % kl_steps == 0:
+            for b in self._kl_loader:
+                self.compute_kl(b)

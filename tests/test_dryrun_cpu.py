@@ -821,3 +821,43 @@ def test_dpo_step_on_a_llama_with_tied_embeddings(launches):
     st = tr.policy.store
     assert seen and all(w == st.p[tr.policy.embed].data_ptr() for w, _ in seen)
     assert all(g == (st.g[tr.policy.embed].data_ptr(), torch.float32, True) for _, g in seen)
+
+
+def test_kto_trainer_builds_its_unmatched_kl_batches_from_cfgs(launches, tmp_path):
+    """`KTOTrainer(cfgs, ds_cfgs)` alone: besides the preference loader, `train()` builds the reference's own UnmatchedSupervisedDataset (prompt i
+    with the response of sample i - 1, right-padded; kto.py:50-69) over the training set and refreshes the KL estimate from it at the start of
+    the epoch (kto.py:211-215) -- `aa_window_kl` once per unmatched batch."""
+    import os
+    pref = '/root/reference/assets/text_to_text/preference/train.json'
+    if not os.path.exists(pref):
+        pytest.skip('the reference package (dataset / template plugins) is only present in the build container')
+    from oracle import _shim
+    _shim.install()
+    import transformers as tf
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from align_anything_amd.trainers.pref import KTOTrainer
+    vocab = {w: i for i, w in enumerate(['<s>', '</s>', '<unk>', '<pad>'] + [f'w{i}' for i in range(316)])}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token='<unk>'))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    fast = tf.PreTrainedTokenizerFast(tokenizer_object=tk, bos_token='<s>', eos_token='</s>', unk_token='<unk>', pad_token='<pad>')
+    fast.chat_template = "{% for m in messages %}{{ m['role'] }} : {{ m['content'] }} </s> {% endfor %}"
+    torch.manual_seed(0)
+    hf = tf.OPTForCausalLM(tf.OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=320, max_position_embeddings=700,
+                                        word_embed_proj_dim=128, dropout=0.0, pad_token_id=3)).eval()
+    d = str(tmp_path / 'opt')
+    hf.save_pretrained(d)
+    fast.save_pretrained(d)
+    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'per_device_train_batch_size': 8,
+                           'per_device_kl_batch_size': 16, 'kl_steps': 1, 'epochs': 1},
+            'model_cfgs': {'model_name_or_path': d, 'model_max_length': 600},
+            'data_cfgs': {'train_datasets': pref, 'train_template': 'PKUSafeRLHF', 'train_size': None, 'train_split': None, 'train_name': None, 'train_data_files': None,
+                          'train_optional_args': [], 'eval_datasets': None}}
+    tr = KTOTrainer(cfgs, {'gradient_clipping': 1.0}, device='cpu')
+    kl = tr.build_kl_dataloader()
+    assert type(kl.loader.dataset).__name__ == 'UnmatchedSupervisedDataset' and len(kl) == 2
+    b = next(iter(kl))
+    assert b['input_ids'].shape[0] == 16 and len(b['meta_info']['response_lens']) == 16 and '_window' in b
+    assert bool((b['input_ids'][:, 0] != 3).all()) and bool((b['input_ids'][:, -1] == 3).any())          # right-padded rows
+    del launches[:]
+    hist = tr.train()
+    assert len(hist) == 4 and launches.count('aa_window_kl') == 2 and 'aa_pref_loss_fwd_bwd' in launches
