@@ -137,6 +137,9 @@ def from_hf_config(c) -> dict:
         rp = getattr(t, 'rope_parameters', None) or {}
         theta = rp.get('rope_theta', getattr(t, 'rope_theta', 10000.0))
         check_llama_family(t, 'llava text_config')
+        if getattr(v, 'model_type', 'clip_vision_model') != 'clip_vision_model' or getattr(v, 'hidden_act', 'quick_gelu') != 'quick_gelu':
+            raise ValueError(f'llava: vision tower {getattr(v, "model_type", None)!r} with activation {getattr(v, "hidden_act", None)!r} has no native implementation '
+                             '(the CLIP tower with quick_gelu is built)')
         if getattr(c, 'vision_feature_select_strategy', 'default') != 'default' or getattr(c, 'projector_hidden_act', 'gelu') != 'gelu' \
                 or not getattr(c, 'multimodal_projector_bias', True) or isinstance(c.vision_feature_layer, (list, tuple)):
             raise ValueError('llava: vision_feature_select_strategy / projector_hidden_act / multimodal_projector_bias / a list of feature layers other than '
@@ -178,6 +181,8 @@ def from_hf_config(c) -> dict:
                          t.vocab_size, t.rms_norm_eps, theta, getattr(t, 'head_dim', None), t.max_position_embeddings,
                          attention_bias=True)
         check_llama_family(t, 'qwen2_vl text_config')
+        if getattr(v, 'hidden_act', 'quick_gelu') != 'quick_gelu' or getattr(t, 'use_sliding_window', False):
+            raise ValueError('qwen2_vl: a vision activation other than quick_gelu / sliding-window attention has no native implementation')
         if getattr(c, 'tie_word_embeddings', False):
             raise ValueError('qwen2_vl with tied input / output embeddings (the 2B checkpoints) has no native implementation')
         if rope_scaling_of(t) is not None:
@@ -193,6 +198,8 @@ def from_hf_config(c) -> dict:
                          t.vocab_size, t.rms_norm_eps, theta, getattr(t, 'head_dim', None), t.max_position_embeddings,
                          attention_bias=True)
         check_llama_family(t, 'qwen2_audio text_config')
+        if getattr(a, 'activation_function', 'gelu') != 'gelu' or getattr(a, 'scale_embedding', False) or getattr(t, 'use_sliding_window', False):
+            raise ValueError('qwen2_audio: an encoder activation other than gelu / scaled embeddings / sliding-window attention has no native implementation')
         if rope_scaling_of(t) is not None:
             raise ValueError('qwen2_audio: RoPE scaling has no native implementation')
         audio = qwen2audio_tower_cfg(a.d_model, a.encoder_layers, a.encoder_attention_heads, a.encoder_ffn_dim, a.num_mel_bins,
@@ -207,6 +214,8 @@ def from_hf_config(c) -> dict:
             raise ValueError('qwen3_moe with attention_bias has no native implementation yet')
         if rope_scaling_of(c) is not None:
             raise ValueError('qwen3_moe: RoPE scaling has no native implementation')
+        if getattr(c, 'hidden_act', 'silu') != 'silu' or getattr(c, 'use_sliding_window', False):
+            raise ValueError('qwen3_moe: an activation other than silu / sliding-window attention has no native implementation')
         return qwen3moe_cfg(c.hidden_size, c.moe_intermediate_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads,
                             c.vocab_size, c.num_experts, c.num_experts_per_tok, getattr(c, 'head_dim', None) or c.hidden_size // c.num_attention_heads,
                             c.norm_topk_prob, c.rms_norm_eps, theta, c.max_position_embeddings)
