@@ -59,3 +59,84 @@ def test_tied_embeddings_and_llama3_rope_dpo_step_vs_hf(dtype):
     for n in ('model.embed_tokens.weight', 'model.layers.0.self_attn.q_proj.weight', 'model.layers.1.self_attn.k_proj.bias', 'model.layers.1.mlp.down_proj.weight'):
         got = tr.policy.store.grad_view(n).float().cpu().reshape(want[n].grad.shape)
         assert rel_err(got, want[n].grad) < (2e-4 if tight else 8e-2), (n, rel_err(got, want[n].grad))
+
+
+@pytest.mark.parametrize('M', [1, 4])
+def test_persistent_layer_kernel_vs_the_per_step_launches(M):
+    """csrc/decode_layer.hip (one launch per decoder layer and decode position) against the validated per-step launches on identical inputs: the
+    residual stream after the layer, the rotated queries, and the KV-cache slot of the position.  Same strips, same operands; the K split of the
+    gate / up strips (16 waves here, 4 there) and the attention merge (16 waves, 8 there) change the fp32 summation ORDER only -> agreement to
+    bf16 rounding of values that are rounded to bf16 at the same points.  Qwen2-VL-7B's layer geometry and a small one; the status word must stay 0."""
+    from align_anything_amd import ops
+    from align_anything_amd.modeling import rope_tables
+    from tests.gpu_util import assert_close, randn_bf16
+    for (h, H, Hkv, F, Tmax, with_bias) in [(256, 2, 1, 512, 24, True), (3584, 28, 4, 18944, 600, True), (4096, 32, 32, 11008, 96, False)]:
+        hd, kw = 128, Hkv * 128
+        eps = 1e-6
+        x = randn_bf16(M, h, scale=1.5, seed=1)
+        w = {'qkv': randn_bf16((H + 2 * Hkv) * hd, h, scale=0.03, seed=2), 'o': randn_bf16(h, H * hd, scale=0.03, seed=3),
+             'gu': randn_bf16(2 * F, h, scale=0.03, seed=4), 'down': randn_bf16(h, F, scale=0.03, seed=5)}
+        n1 = (1 + 0.2 * torch.randn(h, generator=torch.Generator().manual_seed(6))).to(torch.bfloat16).to(dev())
+        n2 = (1 + 0.2 * torch.randn(h, generator=torch.Generator().manual_seed(7))).to(torch.bfloat16).to(dev())
+        bias = randn_bf16((H + 2 * Hkv) * hd, seed=8) if with_bias else None
+        W = {'qkv': ops.SwizzledWeight(w['qkv'], 'rope128', kscale=n1), 'o': ops.SwizzledWeight(w['o']), 'gu': ops.SwizzledWeight(w['gu'], 'glu', kscale=n2),
+             'down': ops.SwizzledWeight(w['down'])}
+        cos, sin = rope_tables(Tmax + 8, hd, 1000000.0, dev(), torch.bfloat16)
+        g = torch.Generator().manual_seed(9)
+        length = torch.randint(Tmax // 2, Tmax, (M,), generator=g).to(torch.int32).to(dev())       # keys per sequence, the new token included
+        slot = (length - 1).to(torch.int64)
+        start = torch.randint(0, 5, (M,), generator=g).to(torch.int32).to(dev())
+        pos = (length - 1 - start).to(torch.int32)
+        cache_a = randn_bf16(M * Tmax, 2 * kw, seed=10)
+        cache_b = cache_a.clone()
+        # per-step launches (the validated default path of LlamaStack.decode_step)
+        q = ops.gemm_skinny_rope_cache(x, W['qkv'], bias, H, Hkv, pos, cos, sin, cache_a, Tmax, slot, eps=eps)
+        attn = ops.attn_decode(q, cache_a, cache_a[:, kw:], Tmax, start, length, M, H, Hkv, hd, hd ** -0.5)
+        x_mid = ops.linear_small(attn, W['o'], residual=x)
+        act = ops.gemm_skinny_glu(x_mid, W['gu'], eps=eps)
+        want = ops.linear_small(act, W['down'], residual=x_mid)
+        # one launch
+        st = ops.DecodeLayerState(dev(), M, h, H, F)
+        assert st.grid > 0
+        got = ops.decode_layer(st, x, W, bias, H, Hkv, F, eps, hd ** -0.5, pos, cos, sin, cache_b, Tmax, slot, start, length, 0)
+        torch.cuda.synchronize()
+        assert not st.failed()
+        rows = torch.arange(M, device=dev()) * Tmax + slot
+        if h >= 3584 and (H + 2 * Hkv) * 8 < 768:      # the per-step launch also takes 16 waves per strip here (narrow and deep): every bit
+            assert torch.equal(st.q, q) and torch.equal(cache_b[rows], cache_a[rows])
+        else:
+            qs = float(q.float().abs().mean())
+            assert_close(st.q, q.float(), rtol=2e-2, atol=2e-2 * qs, what=f'layer kernel q {h} M={M}')
+            assert_close(cache_b[rows], cache_a[rows].float(), rtol=2e-2, atol=2e-2 * qs, what=f'layer kernel cache rows {h} M={M}')
+        other = torch.ones(M * Tmax, dtype=torch.bool, device=dev())
+        other[rows] = False
+        assert torch.equal(cache_a[other], cache_b[other])
+        scale = float(want.float().abs().mean())
+        assert_close(st.attn, attn.float(), rtol=2e-2, atol=2e-2 * float(attn.float().abs().mean()) + 1e-3, what=f'layer kernel attention {h}/{H}/{Hkv} M={M}')
+        assert_close(st.x_mid, x_mid.float(), rtol=2e-2, atol=2e-2 * scale, what=f'layer kernel x_mid {h} M={M}')
+        assert_close(got, want.float(), rtol=3e-2, atol=3e-2 * scale, what=f'layer kernel x_out {h} M={M}')
+        # a second launch reuses the barrier words (generation 4 -> 8) and the other output buffer
+        got2 = ops.decode_layer(st, x, W, bias, H, Hkv, F, eps, hd ** -0.5, pos, cos, sin, cache_b, Tmax, slot, start, length, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(got2, got) and got2.data_ptr() != got.data_ptr() and not st.failed()
+
+
+def test_generate_with_the_persistent_layer_kernel(monkeypatch):
+    """The whole rollout on the one-launch-per-layer path (AA_DECODE_PERSISTENT=1): greedy tokens against the default path on a Llama-family stack with
+    head_dim 128, q/k/v bias and GQA (the geometry family tools/bench_ppo.py times); near-ties may part ways, the first tokens must not."""
+    from align_anything_amd import configs
+    from align_anything_amd.generation import generate
+    from align_anything_amd.modeling import build_model
+    from bench import random_init_
+    text = configs.llama_cfg(512, 1024, 2, 4, 2, 1000, rms_eps=1e-6, rope_theta=1000000.0, head_dim=128, max_position_embeddings=256, attention_bias=True)
+    m = build_model(text, 'cuda:0', trainable=False)
+    random_init_(m, seed=3, std=0.05)
+    ids = torch.randint(3, 1000, (3, 20), generator=torch.Generator().manual_seed(1)).to(dev())
+    mask = torch.ones_like(ids)
+    mask[1, :4] = 0
+    base = generate(m, ids, mask, max_new_tokens=12, do_sample=False, pad_token_id=0).cpu()
+    monkeypatch.setenv('AA_DECODE_PERSISTENT', '1')
+    pers = generate(m, ids, mask, max_new_tokens=12, do_sample=False, pad_token_id=0).cpu()
+    assert m.stack._pstate is not None and m.stack._pstate.checked and not getattr(m.stack, '_persistent_bad', False)
+    assert pers.shape == base.shape and torch.equal(pers[:, :21], base[:, :21])
+    assert float((pers[:, 20:] == base[:, 20:]).float().mean()) >= 0.6
