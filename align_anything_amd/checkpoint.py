@@ -224,6 +224,16 @@ def load_pretrained(path, device, *, trainable=True, head='lm', dtype=torch.bflo
     sd = LazyCheckpoint(os.path.expanduser(str(state_from)) if state_from else path, cfg['kind'])
     src = _WithNewRows(sd, _embedding_names(sd), extra) if extra else sd
     missing = model.load_state_dict(src, strict=False)
+    # tensors of the checkpoint that the native model has no place for: with HF's `strict=False` semantics they would vanish without a word (a
+    # bias the config did not announce, an adapter, a second tower) and the model would compute something else than the checkpoint's author ran
+    names = model.fuse_expert_keys(src) if hasattr(model, 'fuse_expert_keys') else src
+    known = model.store.alias
+    benign = lambda k: (k.endswith('rotary_emb.inv_freq')                                   # a buffer old checkpoints carry
+                        or (k == 'lm_head.weight' and (head != 'lm' or getattr(model, 'tied', False) or cfg['kind'] == 'opt'))   # unused by a score model / tied
+                        or (k.startswith('score_head.') and head == 'lm'))                 # a reward model's head when its backbone is loaded as a language model
+    unexpected = [k for k in names if k not in known and not benign(k)]
+    if unexpected:
+        raise RuntimeError(f'{path}: the checkpoint holds {len(unexpected)} tensors the native {cfg["kind"]} model does not implement, e.g. {unexpected[:4]}')
     # a reward / critic model initialised from a language-model checkpoint has no score head yet (models/reward_model.py): everything else must be there
     bad = [m for m in missing if not m.startswith('score_head')]
     if bad:

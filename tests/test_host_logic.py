@@ -1107,3 +1107,27 @@ def test_trainers_expose_the_reference_s_phase_methods():
     pb = {'input_ids': torch.arange(6).reshape(3, 2), 'labels': torch.arange(6).reshape(3, 2), 'meta_info': {'k': 1}}
     mb = PPOTrainer.split_ptx_micro_batches(pb)
     assert len(mb) == 3 and mb[1]['input_ids'].tolist() == [[2, 3]] and mb[2]['meta_info'] == {'k': 1}
+
+
+def test_checkpoint_tensors_without_a_native_home_raise(tmp_path):
+    """A checkpoint tensor the native model cannot place (here: an MLP bias a llama config did not announce, saved by hand) must stop the load;
+    benign extras (the rotary buffer of old checkpoints, the lm_head of a language model loaded as a score model) pass."""
+    import safetensors.torch as st
+    import transformers as tf
+    from align_anything_amd.checkpoint import load_pretrained
+    torch.manual_seed(0)
+    hf = tf.LlamaForCausalLM(tf.LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=2, vocab_size=64,
+                                            max_position_embeddings=64))
+    d = str(tmp_path / 'm')
+    hf.save_pretrained(d)
+    f = d + '/model.safetensors'
+    sd = st.load_file(f)
+    sd['model.layers.0.self_attn.rotary_emb.inv_freq'] = torch.ones(32)
+    st.save_file(sd, f, metadata={'format': 'pt'})
+    load_pretrained(d, 'cpu', trainable=False, with_tokenizer=False)                      # the rotary buffer is benign
+    m = load_pretrained(d, 'cpu', trainable=False, head='score', with_tokenizer=False)[0]   # ... and so is lm_head for a score model
+    assert 'score_head.weight' in m.store.specs
+    sd['model.layers.0.mlp.gate_proj.bias'] = torch.zeros(256)
+    st.save_file(sd, f, metadata={'format': 'pt'})
+    with pytest.raises(RuntimeError, match='does not implement'):
+        load_pretrained(d, 'cpu', trainable=False, with_tokenizer=False)
