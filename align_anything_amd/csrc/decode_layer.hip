@@ -299,6 +299,60 @@ __global__ __launch_bounds__(DL_NWAVE * 64) void decode_layer_kernel(const Decod
     }
 }
 
+// All layers of a decode position in one launch: the per-layer parameter blocks sit in a device array (aa_decode_layers_pack), a fifth barrier
+// separates layer l's down-projection from layer l + 1's q/k/v projection.
+__global__ __launch_bounds__(DL_NWAVE * 64) void decode_layers_kernel(const DecodeLayerParams* __restrict__ layers, const int L) {
+    __shared__ float smem[2 * DL_NWAVE * 4 + DL_NWAVE * 4 * 128];
+    float (*red)[16][17] = reinterpret_cast<float (*)[16][17]>(smem);
+    float (*ssred)[16] = reinterpret_cast<float (*)[16]>(smem + DL_NWAVE * 16 * 17);
+    const int G = gridDim.x;
+    for (int li = 0; li < L; ++li) {
+        const DecodeLayerParams& p = layers[li];      // fields are read where they are used (uniform scalar loads), not held across the phases
+        const int qw = p.H * 128, kw = p.Hkv * 128;
+        for (int s = blockIdx.x; s < (p.H + 2 * p.Hkv) * 8; s += G) {
+            dl_strip<1, 2>(p.x_in, p.h, p.Wqkv, p.q, qw, p.bqkv, nullptr, 0, p.M, (p.H + 2 * p.Hkv) * 128, p.h, p.eps, p.epi, s, red, ssred);
+            __syncthreads();
+        }
+        dl_grid_barrier(p.bar, p.status);
+        for (int it = blockIdx.x; it < p.H * p.M; it += G) {
+            dl_attention(p.q, qw, p.epi.cache, p.epi.cache + kw, p.epi.ldc, p.epi.Tmax, p.start, p.len, p.attn, qw, p.H, p.Hkv, p.scale, it % p.H, it / p.H, smem);
+            __syncthreads();
+        }
+        dl_grid_barrier(p.bar, p.status);
+        for (int s = blockIdx.x; s < (p.h + 15) / 16; s += G) {
+            dl_strip<0, 0>(p.attn, qw, p.Wo, p.x_mid, p.h, nullptr, p.x_in, p.h, p.M, p.h, qw, 0.f, p.epi, s, red, ssred);
+            __syncthreads();
+        }
+        dl_grid_barrier(p.bar, p.status);
+        for (int s = blockIdx.x; s < p.F / 8; s += G) {
+            dl_strip<1, 1>(p.x_mid, p.h, p.Wgu, p.act, p.F, nullptr, nullptr, 0, p.M, 2 * p.F, p.h, p.eps, p.epi, s, red, ssred);
+            __syncthreads();
+        }
+        dl_grid_barrier(p.bar, p.status);
+        for (int s = blockIdx.x; s < (p.h + 15) / 16; s += G) {
+            dl_strip<0, 0>(p.act, p.F, p.Wdown, p.x_out, p.h, nullptr, p.x_mid, p.h, p.M, p.h, p.F, 0.f, p.epi, s, red, ssred);
+            __syncthreads();
+        }
+        if (li + 1 < L) dl_grid_barrier(p.bar, p.status);
+    }
+}
+
+static int dl_fill(DecodeLayerParams& p, const void* x_in, void* x_mid, void* x_out, void* q, void* attn, void* act, const void* Wqkv, const void* Wo,
+                   const void* Wgu, const void* Wdown, const void* bqkv, int M, int h, int H, int Hkv, int F, float eps, float scale, const int* pos,
+                   const void* cos_t, const void* sin_t, void* cache, long ldc, int Tmax, const int64_t* slot, const int* start, const int* len, void* bar,
+                   int* status, const char* who) {
+    AA_REQUIRE(M >= 1 && M <= 16, "%s: M=%d must be in [1, 16]", who, M);
+    AA_REQUIRE(h > 0 && h % 32 == 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && F > 0 && F % 32 == 0, "%s: h=%d (multiple of 32) H=%d Hkv=%d F=%d (multiple of 32)", who, h, H, Hkv, F);
+    AA_REQUIRE(ldc >= 2L * Hkv * 128 && ldc % 8 == 0 && Tmax > 0, "%s: ldc >= 2 * Hkv * 128 (multiple of 8), Tmax > 0", who);
+    AA_REQUIRE(len != nullptr && bar != nullptr && status != nullptr, "%s: len, bar and status are required", who);
+    p.x_in = (const bf16_t*)x_in; p.x_mid = (bf16_t*)x_mid; p.x_out = (bf16_t*)x_out; p.q = (bf16_t*)q; p.attn = (bf16_t*)attn; p.act = (bf16_t*)act;
+    p.Wqkv = (const bf16_t*)Wqkv; p.Wo = (const bf16_t*)Wo; p.Wgu = (const bf16_t*)Wgu; p.Wdown = (const bf16_t*)Wdown; p.bqkv = (const bf16_t*)bqkv;
+    p.M = M; p.h = h; p.H = H; p.Hkv = Hkv; p.F = F; p.eps = eps; p.scale = scale;
+    p.epi = LayerEpi{pos, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)cache, ldc, Tmax, slot, H, Hkv};
+    p.start = start; p.len = len; p.bar = (unsigned int*)bar; p.status = status;
+    return AA_OK;
+}
+
 }  // namespace
 
 // How many workgroups the persistent kernel may use on the current device: one per compute unit, provided the device can hold that many at once
@@ -328,17 +382,44 @@ extern "C" int aa_decode_layer_bf16(const void* x_in, void* x_mid, void* x_out, 
                                     const void* Wgu, const void* Wdown, const void* bqkv, int M, int h, int H, int Hkv, int F, float eps, float scale,
                                     const int* pos, const void* cos_t, const void* sin_t, void* cache, long ldc, int Tmax, const int64_t* slot,
                                     const int* start, const int* len, void* bar, int* status, int grid, void* stream) {
-    AA_REQUIRE(M >= 1 && M <= 16, "aa_decode_layer_bf16: M=%d must be in [1, 16]", M);
-    AA_REQUIRE(h > 0 && h % 32 == 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && F > 0 && F % 32 == 0, "aa_decode_layer_bf16: h=%d (multiple of 32) H=%d Hkv=%d F=%d (multiple of 32)", h, H, Hkv, F);
-    AA_REQUIRE(ldc >= 2L * Hkv * 128 && ldc % 8 == 0 && Tmax > 0, "aa_decode_layer_bf16: ldc >= 2 * Hkv * 128 (multiple of 8), Tmax > 0");
-    AA_REQUIRE(len != nullptr && bar != nullptr && status != nullptr && grid > 0, "aa_decode_layer_bf16: len, bar, status and a grid from aa_decode_layer_grid are required");
+    AA_REQUIRE(grid > 0, "aa_decode_layer_bf16: a grid from aa_decode_layer_grid is required");
     DecodeLayerParams p;
-    p.x_in = (const bf16_t*)x_in; p.x_mid = (bf16_t*)x_mid; p.x_out = (bf16_t*)x_out; p.q = (bf16_t*)q; p.attn = (bf16_t*)attn; p.act = (bf16_t*)act;
-    p.Wqkv = (const bf16_t*)Wqkv; p.Wo = (const bf16_t*)Wo; p.Wgu = (const bf16_t*)Wgu; p.Wdown = (const bf16_t*)Wdown; p.bqkv = (const bf16_t*)bqkv;
-    p.M = M; p.h = h; p.H = H; p.Hkv = Hkv; p.F = F; p.eps = eps; p.scale = scale;
-    p.epi = LayerEpi{pos, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)cache, ldc, Tmax, slot, H, Hkv};
-    p.start = start; p.len = len; p.bar = (unsigned int*)bar; p.status = status;
+    const int rc = dl_fill(p, x_in, x_mid, x_out, q, attn, act, Wqkv, Wo, Wgu, Wdown, bqkv, M, h, H, Hkv, F, eps, scale, pos, cos_t, sin_t, cache, ldc, Tmax, slot,
+                           start, len, bar, status, "aa_decode_layer_bf16");
+    if (rc != AA_OK) return rc;
     hipLaunchKernelGGL(decode_layer_kernel, dim3(grid), dim3(DL_NWAVE * 64), 0, (hipStream_t)stream, p);
     AA_CHECK_LAUNCH("aa_decode_layer_bf16");
+    return AA_OK;
+}
+
+// All L layers of a decode position in ONE launch.  The per-layer arguments of aa_decode_layer_bf16 are packed once per rollout into a device array
+// (`blocks`: L x aa_decode_layers_block_bytes bytes; layer l's x_out is layer l + 1's x_in: two alternating buffers), then every position is
+// aa_decode_layers_bf16(blocks, L, grid, stream).  The copy of a block is stream-ordered (hipMemcpyAsync from a host struct that is consumed before the
+// call returns: pageable memory, so the runtime stages it).
+extern "C" int aa_decode_layers_block_bytes(int* bytes) {
+    AA_REQUIRE(bytes != nullptr, "aa_decode_layers_block_bytes: bytes is null");
+    *bytes = (int)sizeof(DecodeLayerParams);
+    return AA_OK;
+}
+extern "C" int aa_decode_layers_pack(void* blocks, int layer, const void* x_in, void* x_mid, void* x_out, void* q, void* attn, void* act, const void* Wqkv,
+                                     const void* Wo, const void* Wgu, const void* Wdown, const void* bqkv, int M, int h, int H, int Hkv, int F, float eps,
+                                     float scale, const int* pos, const void* cos_t, const void* sin_t, void* cache, long ldc, int Tmax, const int64_t* slot,
+                                     const int* start, const int* len, void* bar, int* status, void* stream) {
+    AA_REQUIRE(blocks != nullptr && layer >= 0, "aa_decode_layers_pack: blocks / layer");
+    DecodeLayerParams p;
+    const int rc = dl_fill(p, x_in, x_mid, x_out, q, attn, act, Wqkv, Wo, Wgu, Wdown, bqkv, M, h, H, Hkv, F, eps, scale, pos, cos_t, sin_t, cache, ldc, Tmax, slot,
+                           start, len, bar, status, "aa_decode_layers_pack");
+    if (rc != AA_OK) return rc;
+    const hipError_t e = hipMemcpyAsync((char*)blocks + (size_t)layer * sizeof(DecodeLayerParams), &p, sizeof(DecodeLayerParams), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        aa_set_error("aa_decode_layers_pack: %s", hipGetErrorString(e));
+        return AA_ERR_LAUNCH;
+    }
+    return AA_OK;
+}
+extern "C" int aa_decode_layers_bf16(const void* blocks, int L, int grid, void* stream) {
+    AA_REQUIRE(blocks != nullptr && L >= 1 && grid > 0, "aa_decode_layers_bf16: blocks, L=%d >= 1 and a grid from aa_decode_layer_grid are required", L);
+    hipLaunchKernelGGL(decode_layers_kernel, dim3(grid), dim3(DL_NWAVE * 64), 0, (hipStream_t)stream, (const DecodeLayerParams*)blocks, L);
+    AA_CHECK_LAUNCH("aa_decode_layers_bf16");
     return AA_OK;
 }

@@ -237,16 +237,24 @@ class LlamaStack:
         qw, kw = H * hd, Hkv * hd
         N = x.shape[0]
         self._tables(Tmax)
-        if dw is not None and os.environ.get('AA_DECODE_PERSISTENT', '0') == '1' and hd == 128 and N <= 16:
+        if dw is not None and os.environ.get('AA_DECODE_PERSISTENT', '0') in ('1', '2') and hd == 128 and N <= 16:
             # one launch per layer (csrc/decode_layer.hip: the five steps as phases of a persistent kernel behind grid barriers).  NOT yet run on
             # hardware -> opt-in.  The first position of a rollout checks the kernel's status word (a barrier that timed out) and, if set, redoes
             # the position with the per-step launches below and stays on them.
             st = self._persistent_state(N, dw)
             if st is not None:
                 x0 = x
-                for li, L in enumerate(self.layers):
-                    x = ops.decode_layer(st, x, dw[li], L['qkv'].b, H, Hkv, c['intermediate_size'], eps, hd ** -0.5, pos, self.cos, self.sin, cache[li], Tmax, t,
-                                         start, length, li)
+                if os.environ.get('AA_DECODE_PERSISTENT') == '2':
+                    # ALL layers in one launch: the per-layer argument blocks are packed once per rollout (same buffers, counters updated in place)
+                    key = ((id(dw), cache[0].data_ptr(), t.data_ptr(), pos.data_ptr(), length.data_ptr(), 0 if start is None else start.data_ptr(), Tmax),
+                           (H, Hkv, c['intermediate_size'], eps, hd ** -0.5, pos, self.cos, self.sin, Tmax, t, start, length))
+                    if st.pack_key is None or st.pack_key[0] != key[0]:
+                        st.pack(key, [(dw[li], L['qkv'].b, cache[li]) for li, L in enumerate(self.layers)])
+                    x = st.run_all(x)
+                else:
+                    for li, L in enumerate(self.layers):
+                        x = ops.decode_layer(st, x, dw[li], L['qkv'].b, H, Hkv, c['intermediate_size'], eps, hd ** -0.5, pos, self.cos, self.sin, cache[li], Tmax, t,
+                                             start, length, li)
                 if st.checked or not st.failed():
                     return x
                 self._persistent_bad = True

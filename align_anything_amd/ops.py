@@ -1068,6 +1068,32 @@ class DecodeLayerState:
         e = lambda *sz: torch.empty(sz, dtype=bf16, device=device)
         self.x_mid, self.q, self.attn, self.act, self.x_alt = e(M, h), e(M, H * 128), e(M, H * 128), e(M, F), [e(M, h), e(M, h)]
         self.checked = False
+        self.x0 = e(M, h)              # layer 0's input of the all-layers launch (the embedding row is copied here: a fixed address)
+        self.blocks, self.pack_key = None, None
+
+    def pack(self, key, layers):
+        """Per-layer argument blocks of the all-layers launch (aa_decode_layers_pack), rebuilt when `key` (the rollout's buffers) changes.
+        layers: one tuple (W, bias, cache) per layer + the shared arguments in `key`."""
+        (H, Hkv, F, eps, scale, pos, cos_t, sin_t, Tmax, slot, start, length) = key[1]
+        M, h = self.shape[0], self.shape[1]
+        nb = ctypes.c_int(0)
+        call('aa_decode_layers_block_bytes', ctypes.byref(nb))
+        self.blocks = torch.empty(len(layers) * max(int(nb.value), 1), dtype=torch.uint8, device=self.x0.device)
+        x_in = self.x0
+        for li, (W, bias, cache) in enumerate(layers):
+            out = self.x_alt[li & 1]
+            call('aa_decode_layers_pack', self.blocks.data_ptr(), li, x_in.data_ptr(), self.x_mid.data_ptr(), out.data_ptr(), self.q.data_ptr(), self.attn.data_ptr(),
+                 self.act.data_ptr(), W['qkv'].data.data_ptr(), W['o'].data.data_ptr(), W['gu'].data.data_ptr(), W['down'].data.data_ptr(), _p(bias), M, h, int(H), int(Hkv),
+                 int(F), float(eps), float(scale), pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), cache.data_ptr(), cache.stride(0), int(Tmax), slot.data_ptr(),
+                 _p(start), length.data_ptr(), self.bar.data_ptr(), self.status.data_ptr(), stream())
+            x_in = out
+        self.n_layers, self.pack_key = len(layers), key
+
+    def run_all(self, x):
+        """One launch for all packed layers: x [M, h] -> the last layer's output buffer."""
+        self.x0.copy_(x)
+        call('aa_decode_layers_bf16', self.blocks.data_ptr(), self.n_layers, self.grid, stream())
+        return self.x_alt[(self.n_layers - 1) & 1]
 
     def failed(self) -> bool:
         """One host read: did any grid barrier time out so far?  (Checked after the first position of a rollout.)"""

@@ -348,6 +348,15 @@ int aa_gemm_skinny_swz_norm_rope_cache_bf16(const void* x, const void* Wswz, voi
  * the per-step launches; the wait is bounded so that a workgroup that never became resident cannot hang the device).  grid: aa_decode_layer_grid()
  * (one workgroup per compute unit; 0 = the device cannot hold them all at once). */
 int aa_decode_layer_grid(int* grid);
+/* All L layers of a decode position in ONE launch: aa_decode_layers_pack writes layer `layer`'s arguments (those of aa_decode_layer_bf16; layer l's
+ * x_out = layer l + 1's x_in) into a device array of L x *bytes (aa_decode_layers_block_bytes) bytes, once per rollout (the pointers must stay valid and the
+ * counters be updated in place); aa_decode_layers_bf16 then runs a position.  Same status as aa_decode_layer_bf16: not yet run on hardware. */
+int aa_decode_layers_block_bytes(int* bytes);
+int aa_decode_layers_pack(void* blocks, int layer, const void* x_in, void* x_mid, void* x_out, void* q, void* attn, void* act, const void* Wqkv, const void* Wo,
+                          const void* Wgu, const void* Wdown, const void* bqkv, int M, int h, int H, int Hkv, int F, float eps, float scale, const int* pos,
+                          const void* cos_t, const void* sin_t, void* cache, long ldc, int Tmax, const int64_t* slot, const int* start, const int* len, void* bar,
+                          int* status, void* stream);
+int aa_decode_layers_bf16(const void* blocks, int L, int grid, void* stream);
 int aa_decode_layer_bf16(const void* x_in, void* x_mid, void* x_out, void* q, void* attn, void* act, const void* Wqkv, const void* Wo, const void* Wgu,
                          const void* Wdown, const void* bqkv, int M, int h, int H, int Hkv, int F, float eps, float scale, const int* pos, const void* cos_t,
                          const void* sin_t, void* cache, long ldc, int Tmax, const int64_t* slot, const int* start, const int* len, void* bar, int* status,

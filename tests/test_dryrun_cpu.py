@@ -879,6 +879,8 @@ def test_persistent_layer_kernel_plumbing_and_fallback(launches, monkeypatch):
         launches.append(name)
         if name == 'aa_decode_layer_grid':
             a[0]._obj.value = grid['value']
+        if name == 'aa_decode_layers_block_bytes':
+            a[0]._obj.value = 208
 
     monkeypatch.setattr(ops, 'call', call)
     monkeypatch.setenv('AA_DECODE_PERSISTENT', '1')
@@ -907,6 +909,16 @@ def test_persistent_layer_kernel_plumbing_and_fallback(launches, monkeypatch):
     del launches[:]
     generate(m3, ids, mask, max_new_tokens=3, do_sample=False, pad_token_id=0)
     assert 'aa_decode_layer_bf16' not in launches and launches.count('aa_attn_decode') == 2 * 2
+    # mode 2: all layers of a position in one launch; the argument blocks are packed once per rollout (2 layers) and again for the next rollout
+    grid['value'] = 256
+    monkeypatch.setenv('AA_DECODE_PERSISTENT', '2')
+    m5 = build_model(text, 'cpu', trainable=False)
+    del launches[:]
+    generate(m5, ids, mask, max_new_tokens=4, do_sample=False, pad_token_id=0)
+    assert launches.count('aa_decode_layers_pack') == 2 and launches.count('aa_decode_layers_bf16') == 3 and 'aa_decode_layer_bf16' not in launches
+    assert m5.stack._pstate.blocks.numel() == 2 * 208
+    generate(m5, ids, mask, max_new_tokens=3, do_sample=False, pad_token_id=0)
+    assert launches.count('aa_decode_layers_pack') == 4 and launches.count('aa_decode_layers_bf16') == 5
     # default: off
     monkeypatch.delenv('AA_DECODE_PERSISTENT')
     m4 = build_model(text, 'cpu', trainable=False)

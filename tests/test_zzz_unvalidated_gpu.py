@@ -140,3 +140,8 @@ def test_generate_with_the_persistent_layer_kernel(monkeypatch):
     assert m.stack._pstate is not None and m.stack._pstate.checked and not getattr(m.stack, '_persistent_bad', False)
     assert pers.shape == base.shape and torch.equal(pers[:, :21], base[:, :21])
     assert float((pers[:, 20:] == base[:, 20:]).float().mean()) >= 0.6
+    # all layers of a position in one launch: the same phases in the same order -> the same tokens as the one-launch-per-layer form, bit for bit
+    monkeypatch.setenv('AA_DECODE_PERSISTENT', '2')
+    allp = generate(m, ids, mask, max_new_tokens=12, do_sample=False, pad_token_id=0).cpu()
+    assert m.stack._pstate.blocks is not None and not getattr(m.stack, '_persistent_bad', False) and not m.stack._pstate.failed()
+    assert torch.equal(allp, pers)

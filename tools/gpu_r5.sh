@@ -3,7 +3,7 @@
 #   unvalidated        the tests written after round 4's last GPU call (tests/test_zzz_unvalidated_gpu.py): tied embeddings + llama3 RoPE vs HF,
 #                      the persistent per-layer decode kernel vs the per-step launches.  Run FIRST; every stage below assumes it is green.
 #                      The layer kernel's grid barriers are bounded (0.2 s) -- still, the whole stage runs under `timeout`.
-#   decode_persistent  same-box A/B of AA_DECODE_PERSISTENT = 0 / 1 on the PPO iteration (tools/bench_ppo.py), alternating runs
+#   decode_persistent  same-box A/B of AA_DECODE_PERSISTENT = 0 / 1 (one launch per layer) / 2 (one launch per position) on the PPO iteration (tools/bench_ppo.py), alternating runs
 #   decode_trace       kernel trace of the decode window with the layer kernel on (launches per position, per-kernel split)
 R=$(cd "$(dirname "$0")/.." && pwd); cd "$R"; mkdir -p gpurun_out
 for stage in "$@"; do
@@ -12,7 +12,7 @@ for stage in "$@"; do
     unvalidated)
       AA_GPU_UNVALIDATED=1 timeout 420 python -m pytest tests/test_zzz_unvalidated_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r05_unvalidated.log 2>&1; echo "rc=$?"; tail -15 gpurun_out/r05_unvalidated.log | cut -c1-300 ;;
     decode_persistent)
-      for f in 0 1 0 1; do
+      for f in 0 1 2 0 1 2; do
         AA_DECODE_PERSISTENT=$f timeout 200 python tools/bench_ppo.py --iters 2 > gpurun_out/r05_bench_ppo_persistent$f.json 2> gpurun_out/r05_bench_ppo_persistent$f.err
         python -c "import json; d=json.load(open('gpurun_out/r05_bench_ppo_persistent$f.json')); print('persistent $f', round(d['decode_ms_per_position'],4), 'ms/pos', round(d['iteration_ms'],1), 'ms/iter')" || tail -3 gpurun_out/r05_bench_ppo_persistent$f.err
       done ;;
