@@ -248,7 +248,7 @@ __device__ __forceinline__ void dl_grid_barrier(unsigned int* bar, int* status) 
             __hip_atomic_store(bar + 1, gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             const long long t0 = wall_clock64();
-            while (__hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {      // the acquire is the fence after the barrier
                 __builtin_amdgcn_s_sleep(1);
                 if (wall_clock64() - t0 > 20000000LL) {          // 0.2 s of the 100 MHz wall clock: a workgroup never became resident
                     atomicExch(status, 1);
