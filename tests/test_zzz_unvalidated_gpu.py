@@ -145,3 +145,62 @@ def test_generate_with_the_persistent_layer_kernel(monkeypatch):
     allp = generate(m, ids, mask, max_new_tokens=12, do_sample=False, pad_token_id=0).cpu()
     assert m.stack._pstate.blocks is not None and not getattr(m.stack, '_persistent_bad', False) and not m.stack._pstate.failed()
     assert torch.equal(allp, pers)
+
+
+# ---- meta-llama/Llama-3.1-8B-Instruct (the reference's text-to-text default, scripts/llama/*.sh): h 4096, ffn 14336, GQA 32 / 8, head_dim 128,
+# V 128256, llama3 RoPE scaling.  Its GEMM shapes, GQA ratio and vocabulary are not among the geometries the validated suite runs
+# (LLaVA-1.5-7B 32 / 32 + 11008 + 32064, Qwen2-VL-7B 28 / 4 + 18944 + 152064).
+H31, F31, V31, QKV31 = 4096, 14336, 128256, (32 + 2 * 8) * 128
+LLAMA31_GEMMS = [
+    ('qkv.fwd', 'nt', 8192, QKV31, H31), ('gate_up.fwd', 'nt', 8192, 2 * F31, H31), ('down.fwd', 'nt', 8192, H31, F31),
+    ('qkv.dx', 'nn', 8192, H31, QKV31), ('gate_up.dx', 'nn', 8192, H31, 2 * F31), ('down.dx', 'nn', 8192, F31, H31),
+    ('qkv.dw', 'tn', QKV31, H31, 8192), ('gate_up.dw', 'tn', 2 * F31, H31, 8192), ('down.dw', 'tn', H31, F31, 8192),
+    ('lm_head.fwd', 'nt', 2048, V31, H31), ('lm_head.dx', 'nn', 2048, H31, V31), ('lm_head.dw', 'tn', V31, H31, 2048),
+]
+
+
+@pytest.mark.parametrize('case', LLAMA31_GEMMS, ids=[c[0] for c in LLAMA31_GEMMS])
+def test_llama31_8b_hot_gemm_shapes(case):
+    import gc
+    from tests.test_bench_geometry_gpu import check_gemm_case
+    check_gemm_case(case)
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_llama31_8b_gqa_attention_and_fused_lm_head():
+    """GQA 32 / 8 at T = 2048 (forward + backward, one key-head group against the fp32 softmax reference) and the fused lm_head x log-prob pass
+    at V = 128256 against logits -> log_softmax -> gather in fp32."""
+    from align_anything_amd import ops
+    from tests.gpu_util import assert_close
+    from tests.test_attention_gpu import ref_attention
+    from tests.test_bench_geometry_gpu import _rand
+    N, T, H, Hkv, hd = 2, 2048, 32, 8, 128
+    rep_h, scale = H // Hkv, hd ** -0.5
+    qkv = _rand(N * T, (H + 2 * Hkv) * hd, 21, 0.7)
+    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:(H + Hkv) * hd], qkv[:, (H + Hkv) * hd:]
+    do = _rand(N * T, H * hd, 22)
+    start = torch.tensor([0, 300], dtype=torch.int32, device=dev())
+    valid = (torch.arange(T, device=dev())[None, :] >= start[:, None].long()).reshape(N * T)
+    do = do * valid[:, None].to(do.dtype)
+    o, lse = ops.attn_fwd(q, k, v, N, T, H, Hkv, hd, True, scale, start)
+    dqkv = torch.empty_like(qkv)
+    dq, dk, dv = dqkv[:, :H * hd], dqkv[:, H * hd:(H + Hkv) * hd], dqkv[:, (H + Hkv) * hd:]
+    ops.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, True, scale, start)
+    torch.cuda.synchronize()
+    vm = valid[:, None].float()
+    kvh = 5
+    qs, ks = slice(kvh * rep_h * hd, (kvh + 1) * rep_h * hd), slice(kvh * hd, (kvh + 1) * hd)
+    ro, rdq, rdk, rdv, _ = ref_attention(q[:, qs], k[:, ks], v[:, ks], do[:, qs], N, T, rep_h, 1, hd, True, scale, start)
+    assert_close(o[:, qs].float() * vm, ro * vm, rtol=2e-2, atol=2e-2, what='O (GQA 32 / 8)')
+    for nm, got, want in (('dQ', dq[:, qs].float() * vm, rdq * vm), ('dK', dk[:, ks], rdk), ('dV', dv[:, ks], rdv)):
+        assert_close(got, want, rtol=3e-2, atol=2e-2 * max(float(want.abs().max()), 1e-3), what=f'{nm} (GQA 32 / 8)')
+    del qkv, dqkv, o, do, ro, rdq, rdk, rdv
+    torch.cuda.empty_cache()
+    rows = 1024
+    n = _rand(rows, H31, 31, 1.0)
+    w = _rand(V31, H31, 32, 0.02)
+    labels = torch.randint(0, V31, (rows,), generator=torch.Generator().manual_seed(33)).to(dev())
+    logp, lse2 = ops.lmhead_logprob_fwd(n, w, labels, False)
+    want = torch.log_softmax(n.float() @ w.float().t(), dim=-1).gather(1, labels[:, None])[:, 0]
+    assert_close(logp[:rows].float(), want, rtol=2e-2, atol=5e-2, what='fused lm_head log-prob at V = 128256')
