@@ -466,8 +466,8 @@ class NativeEngine:
         os.makedirs(save_dir, exist_ok=True)
         if save_filename.endswith('.safetensors'):
             from safetensors.torch import save_file
-            save_file({k: v.contiguous() for k, v in sd.items() if k != 'lm_head.weight' or self.module.kind != 'opt'},
-                      path, metadata={'format': 'pt'})
+            tied = self.module.kind == 'opt' or getattr(self.module, 'tied', False)      # one tensor under two names: safetensors stores it once (HF re-ties on load)
+            save_file({k: v.contiguous() for k, v in sd.items() if k != 'lm_head.weight' or not tied}, path, metadata={'format': 'pt'})
         else:
             torch.save(sd, path)
         return path

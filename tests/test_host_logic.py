@@ -1044,6 +1044,17 @@ def test_llama_family_checkpoint_with_tied_embeddings_loads_and_saves(tmp_path):
     m.init_training()
     assert m.store.g[m.embed].dtype == torch.float32          # the shared gradient buffer: head dW accumulates into it, the embedding scatter-adds
     m.load_state_dict(sd)                                      # its own state dict (with the alias) loads back
+    # save -> transformers loads it back with the tie intact (both file formats of save_16bit_model)
+    from align_anything_amd.engine import NativeEngine
+    eng = NativeEngine(m, trainable=False)
+    for fn in ('model.safetensors', 'pytorch_model.bin'):
+        out = str(tmp_path / ('saved_' + fn.split('.')[0]))
+        eng.save_16bit_model(out, save_filename=fn)
+        hf_cfg.save_pretrained(out)
+        back = tf.Qwen2ForCausalLM.from_pretrained(out, dtype=torch.float32)
+        assert back.lm_head.weight.data_ptr() == back.model.embed_tokens.weight.data_ptr()
+        assert torch.equal(back.model.embed_tokens.weight.float(), sd['model.embed_tokens.weight'].float())
+        assert torch.equal(back.model.layers[1].mlp.down_proj.weight.float(), sd['model.layers.1.mlp.down_proj.weight'].float())
     untied = tf.Qwen2Config(**{**hf_cfg.to_dict(), 'tie_word_embeddings': False})
     d2 = str(tmp_path / 'untied')
     tf.Qwen2ForCausalLM(untied).save_pretrained(d2)
