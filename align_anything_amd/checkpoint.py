@@ -150,17 +150,22 @@ class Derived(Mapping):
 
 
 class _WithNewRows(Mapping):
-    """The pad-token resize of pretrained_model.py:112-150 on a lazy checkpoint: the named [vocab, ...] tensors get `extra` rows equal to
-    the mean of the existing ones (`init_new_embeddings`), everything else passes through."""
+    """The pad-token resize of pretrained_model.py:112-150 on a lazy checkpoint: `model.resize_token_embeddings(len(tokenizer))` followed by
+    `init_new_embeddings` -- the named [vocab, ...] tensors are cut or grown to EXACTLY `rows` rows (a checkpoint whose embedding is larger than
+    its tokenizer shrinks, as it does in the reference) and their last `extra` rows become the mean of the rows before them; everything else
+    passes through."""
 
-    def __init__(self, base, names, extra):
-        self.base, self.names, self.extra = base, set(names), int(extra)
+    def __init__(self, base, names, extra, rows=None):
+        self.base, self.names, self.extra, self.rows = base, set(names), int(extra), rows
 
     def __getitem__(self, name):
         t = self.base[name]
         if name in self.names and self.extra > 0:
-            mean = t.float().mean(dim=0, keepdim=True).to(t.dtype)
-            t = torch.cat([t, mean.expand(self.extra, *t.shape[1:])], dim=0)
+            rows = int(self.rows) if self.rows is not None else t.shape[0] + self.extra
+            keep = t[:rows - self.extra] if rows - self.extra <= t.shape[0] else torch.cat(
+                [t, torch.zeros((rows - self.extra - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)], dim=0)
+            mean = keep.float().mean(dim=0, keepdim=True).to(t.dtype)
+            t = torch.cat([keep, mean.expand(self.extra, *t.shape[1:])], dim=0)
         return t
 
     def __iter__(self):
@@ -175,6 +180,17 @@ class _WithNewRows(Mapping):
 
 def _embedding_names(names):
     return [n for n in names if n.endswith('embed_tokens.weight') or n == 'lm_head.weight']
+
+
+def check_vocab_rows(rows: int, path: str = '') -> None:
+    """The native lm_head / log-prob kernels take vocabularies that are multiples of 4 (aa_lmhead_logprob_fwd).  The reference's pad-token resize
+    can leave an odd row count (its own note: "may make your embedding size not be divisible by 64", pretrained_model.py:65): say so at load time,
+    with the way out, instead of at the first step."""
+    if rows % 4:
+        raise RuntimeError(
+            f'{path}: the tokenizer has no pad token; adding {DEFAULT_PAD_TOKEN!r} as the reference does (pretrained_model.py:112-150) resizes the embeddings to '
+            f'{rows} rows, and the native lm_head / log-prob kernels take vocabularies that are multiples of 4.  Give the tokenizer a pad token that is already '
+            'in its vocabulary (tokenizer_config.json "pad_token", e.g. the eos token): the embeddings then keep their size.')
 
 
 def load_tokenizer_and_processor(path, model_max_length=512, padding_side='left', processor_kwargs=None):
@@ -216,13 +232,17 @@ def load_pretrained(path, device, *, trainable=True, head='lm', dtype=torch.bflo
                 setattr(hf_config, k, getattr(tokenizer, k))
     text_cfg = getattr(hf_config, 'text_config', hf_config)
     if extra:
-        text_cfg.vocab_size = int(text_cfg.vocab_size) + extra                  # model.resize_token_embeddings(len(tokenizer))
+        # model.resize_token_embeddings(len(tokenizer)) (pretrained_model.py:131-146): the embeddings take EXACTLY len(tokenizer) rows -- one more
+        # than before for the usual checkpoint, fewer for one whose embedding was padded beyond its tokenizer
+        text_cfg.vocab_size = len(tokenizer)
         if text_cfg is not hf_config and hasattr(hf_config, 'vocab_size'):
             hf_config.vocab_size = text_cfg.vocab_size
+        if torch.device(device).type == 'cuda':          # (host-side dry runs launch nothing)
+            check_vocab_rows(text_cfg.vocab_size, path)
     cfg = configs.from_hf_config(hf_config)
     model = build_model(cfg, device, trainable=trainable, head=head, dtype=dtype, **(build_kwargs or {}))
     sd = LazyCheckpoint(os.path.expanduser(str(state_from)) if state_from else path, cfg['kind'])
-    src = _WithNewRows(sd, _embedding_names(sd), extra) if extra else sd
+    src = _WithNewRows(sd, _embedding_names(sd), extra, rows=text_cfg.vocab_size) if extra else sd
     missing = model.load_state_dict(src, strict=False)
     # tensors of the checkpoint that the native model has no place for: with HF's `strict=False` semantics they would vanish without a word (a
     # bias the config did not announce, an adapter, a second tower) and the model would compute something else than the checkpoint's author ran

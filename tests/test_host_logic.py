@@ -811,6 +811,29 @@ def test_load_pretrained_adds_the_pad_row_like_the_reference(tmp_path):
         old = hf.state_dict()[k]
         assert sd[k].shape == (65, 128) and torch.equal(sd[k][:64], old) and torch.equal(sd[k][64], old.mean(dim=0))
     assert torch.equal(sd['model.layers.0.mlp.down_proj.weight'], hf.state_dict()['model.layers.0.mlp.down_proj.weight'])
+    # a checkpoint whose embedding is LARGER than its tokenizer (72 rows, 64 tokens): the reference's resize_token_embeddings(len(tokenizer)) SHRINKS it
+    # to 65 rows and writes the mean of the first 64 into the new one -- checked against transformers' own resize + the reference's initialisation
+    torch.manual_seed(6)
+    big = tf.LlamaForCausalLM(tf.LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                                             vocab_size=72, max_position_embeddings=128, tie_word_embeddings=False)).eval()
+    d2 = str(tmp_path / 'big')
+    big.save_pretrained(d2)
+    fast2 = tf.PreTrainedTokenizerFast(tokenizer_object=tk, bos_token='<s>', eos_token='</s>', unk_token='<unk>')
+    fast2.save_pretrained(d2)
+    m2, tok2, _, hc2 = load_pretrained(d2, 'cpu', trainable=False, dtype=torch.float32)
+    want = tf.LlamaForCausalLM.from_pretrained(d2, dtype=torch.float32)
+    want.resize_token_embeddings(65)
+    for emb in (want.get_input_embeddings(), want.get_output_embeddings()):
+        emb.weight.data[-1:] = emb.weight.data[:-1].mean(dim=0, keepdim=True)
+    assert len(tok2) == 65 and hc2.vocab_size == 65 and m2.cfg['vocab_size'] == 65
+    sd2 = m2.state_dict()
+    assert torch.allclose(sd2['model.embed_tokens.weight'], want.get_input_embeddings().weight.data, atol=1e-7)
+    assert torch.allclose(sd2['lm_head.weight'], want.get_output_embeddings().weight.data, atol=1e-7)
+    # on a GPU such a row count is refused at load time, with the way out, not at the first step
+    from align_anything_amd.checkpoint import check_vocab_rows
+    check_vocab_rows(128256)
+    with pytest.raises(RuntimeError, match='multiples of 4'):
+        check_vocab_rows(128257, d2)
 
 
 def test_library_contexts_isolate_switches_and_plans_per_thread():
