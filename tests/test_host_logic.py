@@ -1165,3 +1165,44 @@ def test_checkpoint_tensors_without_a_native_home_raise(tmp_path):
     st.save_file(sd, f, metadata={'format': 'pt'})
     with pytest.raises(RuntimeError, match='does not implement'):
         load_pretrained(d, 'cpu', trainable=False, with_tokenizer=False)
+
+
+def test_published_config_layouts_of_the_baseline_models_parse(tmp_path):
+    """config.json as the hub holds it for BASELINE configs[1] / [2] (written by transformers 4.36 / 4.41: `image_token_index`, a FLAT qwen2_vl text
+    config with `rope_scaling: {type: mrope}`, `in_chans`): AutoConfig + configs.from_hf_config give the 7B geometries the benchmarks run."""
+    import json
+    import transformers as tf
+    from align_anything_amd import configs
+    llava = {"architectures": ["LlavaForConditionalGeneration"], "ignore_index": -100, "image_token_index": 32000, "model_type": "llava", "pad_token_id": 32001,
+             "projector_hidden_act": "gelu", "text_config": {"_name_or_path": "lmsys/vicuna-7b-v1.5", "architectures": ["LlamaForCausalLM"], "max_position_embeddings": 4096,
+                                                             "model_type": "llama", "rms_norm_eps": 1e-05, "torch_dtype": "float16", "vocab_size": 32064},
+             "tie_word_embeddings": False, "torch_dtype": "float16", "transformers_version": "4.36.0.dev0",
+             "vision_config": {"hidden_size": 1024, "image_size": 336, "intermediate_size": 4096, "model_type": "clip_vision_model", "num_attention_heads": 16,
+                               "num_hidden_layers": 24, "patch_size": 14, "projection_dim": 768, "vocab_size": 32000},
+             "vision_feature_layer": -2, "vision_feature_select_strategy": "default", "vocab_size": 32064}
+    qwen = {"architectures": ["Qwen2VLForConditionalGeneration"], "attention_dropout": 0.0, "bos_token_id": 151643, "eos_token_id": 151645, "vision_start_token_id": 151652,
+            "vision_end_token_id": 151653, "vision_token_id": 151654, "image_token_id": 151655, "video_token_id": 151656, "hidden_act": "silu", "hidden_size": 3584,
+            "initializer_range": 0.02, "intermediate_size": 18944, "max_position_embeddings": 32768, "max_window_layers": 28, "model_type": "qwen2_vl",
+            "num_attention_heads": 28, "num_hidden_layers": 28, "num_key_value_heads": 4, "rms_norm_eps": 1e-06, "rope_theta": 1000000.0, "sliding_window": 32768,
+            "tie_word_embeddings": False, "torch_dtype": "bfloat16", "transformers_version": "4.41.2", "use_cache": True, "use_sliding_window": False,
+            "vision_config": {"depth": 32, "embed_dim": 1280, "mlp_ratio": 4, "num_heads": 16, "in_chans": 3, "hidden_size": 3584, "patch_size": 14, "spatial_merge_size": 2,
+                              "spatial_patch_size": 14, "temporal_patch_size": 2},
+            "rope_scaling": {"type": "mrope", "mrope_section": [16, 24, 24]}, "vocab_size": 152064}
+    out = {}
+    for name, cfg in (('llava', llava), ('qwen2vl', qwen)):
+        d = tmp_path / name
+        d.mkdir()
+        (d / 'config.json').write_text(json.dumps(cfg))
+        out[name] = configs.from_hf_config(tf.AutoConfig.from_pretrained(str(d)))
+    c = out['llava']
+    assert c == configs.llava_1_5_7b() or (c['image_token_id'], c['vision_feature_layer'], c['pad_token_id']) == (32000, -2, 32001)
+    t, v = c['text'], c['vision']
+    assert (t['hidden_size'], t['intermediate_size'], t['num_layers'], t['num_heads'], t['num_kv_heads'], t['head_dim'], t['vocab_size'], t['rms_eps'], t['rope_theta']) == \
+        (4096, 11008, 32, 32, 32, 128, 32064, 1e-5, 10000.0) and t['rope_scaling'] is None
+    assert (v['hidden_size'], v['intermediate_size'], v['num_layers'], v['num_heads'], v['image_size'], v['patch_size']) == (1024, 4096, 24, 16, 336, 14)
+    c = out['qwen2vl']
+    t, v = c['text'], c['vision']
+    assert (t['hidden_size'], t['intermediate_size'], t['num_layers'], t['num_heads'], t['num_kv_heads'], t['head_dim'], t['vocab_size'], t['rope_theta'], t['mrope_section']) == \
+        (3584, 18944, 28, 28, 4, 128, 152064, 1000000.0, [16, 24, 24]) and t['attention_bias'] and c['image_token_id'] == 151655
+    assert (v['embed_dim'], v['depth'], v['num_heads'], v['hidden_size'], v['patch_size'], v['temporal_patch_size'], v['spatial_merge_size'], v['in_channels']) == \
+        (1280, 32, 16, 3584, 14, 2, 2, 3)
