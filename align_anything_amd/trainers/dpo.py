@@ -205,6 +205,9 @@ class DPOTrainer:
     def train_step(self, batch) -> dict[str, Any]:
         """dpo.py:205-237; the six scalar all-reduces + six .item() syncs are fused into one each."""
         loss_dict = self.loss(batch)
+        if not getattr(self, '_first_batch_checked', False):
+            self._first_batch_checked = True
+            self._check_first_batch(batch)
         self.model.backward(loss_dict['loss'])
         self.model.step()
         means = get_all_reduce_mean(loss_dict['_means'].clone())
@@ -214,6 +217,24 @@ class DPOTrainer:
             'train/worse_sample_reward': m[4], 'train/reward_accuracy': m[1], 'train/reward_margin': m[5],
             'train/lr': self.model.optimizer.param_groups[0]['lr'],
         }
+
+    def _check_first_batch(self, batch) -> None:
+        """Once per trainer, after the first forward (two host syncs that the hot loop must not pay per step; AA_VALIDATE_FIRST_BATCH=0 skips them):
+        (1) what hf raises on every forward -- "Image features and image tokens do not match" (hf:models/llava/modeling_llava.py:191-213; a
+        processor that did not expand `<image>`, a truncated prompt) -- instead of scattering a wrong number of feature rows silently;
+        (2) the shared-tower shortcut of `_features` rests on the reference collator's layout (`images * 2`: the rejected row carries the chosen
+        row's image, datasets/text_image_to_text/preference.py:219-222): a batch whose halves differ needs `share_vision_tower=False`."""
+        import os
+        if os.environ.get('AA_VALIDATE_FIRST_BATCH', '1') == '0':
+            return
+        mod = self.model.module
+        if getattr(mod, '_last_image_token_count', None) is not None and hasattr(mod, 'validate_batch'):
+            mod.validate_batch()
+        pv = batch.get('pixel_values')
+        if (pv is not None and self.policy.kind == 'llava' and self.share_vision_tower and not getattr(self.policy, 'train_tower', False)
+                and pv.shape[0] % 2 == 0 and not torch.equal(pv[:pv.shape[0] // 2], pv[pv.shape[0] // 2:])):
+            raise ValueError('DPOTrainer: the images of the chosen and the rejected rows differ, but the vision tower is run once per pair (the reference collator '
+                             'stacks `images * 2`); construct the trainer with share_vision_tower=False for batches laid out differently')
 
     def train(self) -> list[dict[str, Any]]:
         """dpo.py:239-308 without the per-step torch_gc() (a ZeRO-3 memory work-around): resumes at

@@ -28,6 +28,7 @@ def launches(monkeypatch):
         raise RuntimeError(f'{name}: expected bfloat16 or float32 activations, got {t.dtype}')
 
     monkeypatch.setattr(ops, 'call', lambda name, *a: seen.append(name))
+    monkeypatch.setenv('AA_VALIDATE_FIRST_BATCH', '0')      # the first-batch checks read kernel OUTPUTS (the image-token count), which do not exist here
     monkeypatch.setattr(ops, '_sfx', sfx)
     monkeypatch.setattr(ops, '_chk', lambda t, dtype, name: None)
     monkeypatch.setattr(ops, 'stream', lambda: 0)
@@ -925,3 +926,29 @@ def test_persistent_layer_kernel_plumbing_and_fallback(launches, monkeypatch):
     del launches[:]
     generate(m4, ids, mask, max_new_tokens=3, do_sample=False, pad_token_id=0)
     assert 'aa_decode_layer_bf16' not in launches and 'aa_decode_layer_grid' not in launches
+
+
+def test_first_batch_checks_of_the_dpo_trainer(launches, monkeypatch):
+    """DPOTrainer._check_first_batch (once, after the first forward): hf's "Image features and image tokens do not match" check is consulted, and a
+    batch whose chosen / rejected rows carry DIFFERENT images stops a trainer that runs the tower once per pair (share_vision_tower=True)."""
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    z = load_golden('llava_tiny_dpo.npz')
+    monkeypatch.setenv('AA_VALIDATE_FIRST_BATCH', '1')
+    asked = []
+
+    def make(**kw):
+        tr = DPOTrainer(_cfgs(z), {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                        reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cpu', **kw)
+        monkeypatch.setattr(tr.policy, 'validate_batch', lambda: asked.append(1))      # (reads a kernel output that does not exist in a dry run)
+        return tr
+
+    tr = make()
+    tr.train_step(_pref_batch(z, pixels=True))
+    tr.train_step(_pref_batch(z, pixels=True))
+    assert asked == [1]                                                               # once per trainer, not per step
+    b = _pref_batch(z, pixels=True)
+    b['pixel_values'] = b['pixel_values'].clone()
+    b['pixel_values'][-1] += 1.0
+    with pytest.raises(ValueError, match='share_vision_tower=False'):
+        make().train_step(b)
+    make(share_vision_tower=False).train_step(b)                                      # every row's image goes through the tower: any layout is fine
