@@ -133,6 +133,14 @@ class PPOTrainer(PPOMath):
             critic, self.reward_critic_tokenizer, _, _ = load_pretrained(self._paths['critic'] or self._paths['actor'], device, trainable=True, head='score', dtype=dt,
                                                                          model_max_length=mml, padding_side='left', build_kwargs=rpk)
             model_cfg, rcfg = actor.cfg, critic.cfg
+            # ppo.py:142-143 `is_same_tokenizer` (same class and vocabulary): otherwise reward_model_step re-tokenises, as the reference does.  The
+            # critic reads the ACTOR's ids (ppo.py:237-239), so its tokenizer must be the actor's.
+            same = lambda a, b: a is b or (a.__class__ == b.__class__ and a.get_vocab() == b.get_vocab())
+            rt = getattr(self, 'reward_tokenizer', None)
+            self.retokenize_for_reward = bool(reward is not None and rt is not None and self.tokenizer is not None and not same(self.tokenizer, rt))
+            ct = getattr(self, 'reward_critic_tokenizer', None)
+            if ct is not None and self.tokenizer is not None and not same(self.tokenizer, ct):
+                raise ValueError('PPOTrainer: the reward critic scores the actor\'s token ids (ppo.py:237-239); its checkpoint must share the actor\'s tokenizer')
         else:
             actor = build_model(model_cfg, device, trainable=True, dtype=dt, **epk)
             ref = build_model(model_cfg, device, trainable=False, dtype=dt, **epk)
@@ -246,8 +254,15 @@ class PPOTrainer(PPOMath):
             if reward.shape != (N,):
                 raise ValueError(f'reward_fn returned shape {tuple(reward.shape)}, expected ({N},)')
         else:
-            scores = self.reward_model.module.scores(input_ids, attention_mask)
-            end = end_index(self.reward_model.module.kind, attention_mask)
+            r_ids, r_am = input_ids, attention_mask
+            if getattr(self, 'retokenize_for_reward', False):
+                # ppo.py:226-235 `batch_retokenize`: the reward model has a tokenizer of its own -> the sequences are decoded with the actor's and
+                # encoded with the reward model's (+ its eos, padded to the longest on the reward tokenizer's side); host string work, as in the reference
+                texts = self.tokenizer.batch_decode(input_ids, skip_special_tokens=True)
+                enc = self.reward_tokenizer([t + self.reward_tokenizer.eos_token for t in texts], padding=True, truncation=False, return_tensors='pt')
+                r_ids, r_am = enc['input_ids'].to(input_ids.device), enc['attention_mask'].to(input_ids.device)
+            scores = self.reward_model.module.scores(r_ids, r_am)
+            end = end_index(self.reward_model.module.kind, r_am)
             reward = scores[torch.arange(N, device=scores.device), end]
         self.reward_critic_model.wait_optimizer()
         values = self.reward_critic_model.module.scores(input_ids, attention_mask)[:, :-1]

@@ -952,3 +952,49 @@ def test_first_batch_checks_of_the_dpo_trainer(launches, monkeypatch):
     with pytest.raises(ValueError, match='share_vision_tower=False'):
         make().train_step(b)
     make(share_vision_tower=False).train_step(b)                                      # every row's image goes through the tower: any layout is fine
+
+
+def test_ppo_retokenizes_for_a_reward_model_with_its_own_tokenizer(launches, tmp_path):
+    """ppo.py:142-143, :226-235: a reward model whose tokenizer differs from the actor's (other vocabulary) is scored on the sequences DECODED with the
+    actor's tokenizer and ENCODED with its own (+ eos, padded on its side) -- `batch_retokenize`; with the same tokenizer the ids go through as they are."""
+    import transformers as tf
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from align_anything_amd.trainers.ppo import PPOTrainer
+    words = [f'w{i}' for i in range(316)]
+
+    def save(dirname, vocab_words):
+        vocab = {w: i for i, w in enumerate(['<s>', '</s>', '<unk>', '<pad>'] + vocab_words)}
+        tk = Tokenizer(models.WordLevel(vocab, unk_token='<unk>'))
+        tk.pre_tokenizer = pre_tokenizers.Whitespace()
+        fast = tf.PreTrainedTokenizerFast(tokenizer_object=tk, bos_token='<s>', eos_token='</s>', unk_token='<unk>', pad_token='<pad>')
+        torch.manual_seed(0)
+        hf = tf.OPTForCausalLM(tf.OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=1, num_attention_heads=2, vocab_size=320, max_position_embeddings=128,
+                                            word_embed_proj_dim=128, dropout=0.0, pad_token_id=3))
+        d = str(tmp_path / dirname)
+        hf.save_pretrained(d)
+        fast.save_pretrained(d)
+        return d
+
+    actor_dir, reward_dir = save('actor', words), save('reward', words[::-1])            # same words, other ids
+    cfgs = lambda r: {'train_cfgs': {'actor_lr_scheduler_type': 'constant', 'critic_lr_scheduler_type': 'constant'},
+                      'model_cfgs': {'actor_model_name_or_path': actor_dir, 'reward_model_name_or_path': r, 'reward_critic_model_name_or_path': actor_dir, 'model_max_length': 64}}
+    same = PPOTrainer(cfgs(actor_dir), {'gradient_clipping': 1.0}, device='cpu')
+    assert not same.retokenize_for_reward
+    tr = PPOTrainer(cfgs(reward_dir), {'gradient_clipping': 1.0}, device='cpu')
+    assert tr.retokenize_for_reward and tr.reward_tokenizer.padding_side == 'right'
+    seen = []
+    real = tr.reward_model.module.scores
+    tr.reward_model.module.scores = lambda ids, am, *a, **k: (seen.append((ids.clone(), am.clone())), real(ids, am, *a, **k))[1]
+    ids = torch.tensor([[3, 3, 0, 4, 5, 6, 1], [0, 10, 11, 12, 13, 14, 1]])              # left-padded actor ids: <s> w0 w1 w2 </s>, <s> w6 .. w10 </s>
+    am = (ids != 3).long()
+    am[0, :2] = 0
+    out = tr.reward_model_step(ids, am)
+    r_ids, r_am = seen[0]
+    assert out['reward'].shape == (2,) and out['reward_values'].shape == (2, 6)
+    # decoded without special tokens, re-encoded with the reversed vocabulary + eos, right-padded to the longest
+    want0 = [tr.reward_tokenizer.convert_tokens_to_ids(w) for w in ('w0', 'w1', 'w2')] + [1]
+    want1 = [tr.reward_tokenizer.convert_tokens_to_ids(w) for w in ('w6', 'w7', 'w8', 'w9', 'w10')] + [1]
+    assert r_ids[1].tolist() == want1 and r_ids[0, :4].tolist() == want0 and r_am[0].tolist() == [1, 1, 1, 1, 0, 0] and int(r_ids[0, 0]) == 4 + 315
+    with pytest.raises(ValueError, match='critic'):
+        PPOTrainer({'train_cfgs': {}, 'model_cfgs': {'actor_model_name_or_path': actor_dir, 'reward_model_name_or_path': actor_dir,
+                                                     'reward_critic_model_name_or_path': reward_dir}}, None, device='cpu')
