@@ -18,8 +18,8 @@ from .common import build_span_window, cfg_get, eval_due, rl_eval, compute_dtype
 
 class GRPOTrainer:
     """Three engines as in grpo.py:153-196: trainable actor, frozen actor reference, frozen reward (score) model.
-    The reference re-tokenises completions for the reward model (`batch_retokenize`); here actor and reward model
-    share one tokenizer, so the masked completion ids are scored directly (`reward_fn` overrides that)."""
+    The reference re-tokenises completions for the reward model (`batch_retokenize`, grpo.py:243-250): so does `compute_rewards` when the trainer
+    loaded its tokenizers (the cfgs-only constructor); built from injected models it scores the masked completion ids directly (`reward_fn` overrides both)."""
 
     def __init__(self, cfgs, ds_cfgs=None, *, model_cfg=None, reward_model_cfg=None, actor_state=None, reference_state=None,
                  reward_state=None, reward_fn=None, device='cuda:0'):
@@ -28,7 +28,7 @@ class GRPOTrainer:
         the keyword arguments inject pre-built pieces.  Phases = the reference's methods in its order (grpo.py:69-75)."""
         self.cfgs, self.ds_train_cfgs, self.device = cfgs, ds_cfgs, torch.device(device)
         self.model_cfg, self.reward_model_cfg, self.reward_fn = model_cfg, reward_model_cfg, reward_fn
-        self.tokenizer = self.processor = self.hf_config = None
+        self.tokenizer = self.reward_tokenizer = self.processor = self.hf_config = None
         self.prompt_only_dataloader = self.eval_dataloader = None
         self.global_step = 0
         self.init_check()
@@ -76,7 +76,8 @@ class GRPOTrainer:
                 self.pad_token_id = int(self.tokenizer.pad_token_id)
                 self.eos_token_id = int(self.tokenizer.eos_token_id) if self.tokenizer.eos_token_id is not None else self.eos_token_id
             if self.reward_fn is None:
-                reward = load_pretrained(rp_, device, trainable=False, head='score', dtype=dt, model_max_length=mml, padding_side='right', build_kwargs=rpk)[0]
+                reward, self.reward_tokenizer, _, _ = load_pretrained(rp_, device, trainable=False, head='score', dtype=dt, model_max_length=mml, padding_side='right',
+                                                                      build_kwargs=rpk)
             model_cfg = actor.cfg
         else:
             actor = build_model(model_cfg, device, trainable=True, dtype=dt, **epk)
@@ -143,11 +144,19 @@ class GRPOTrainer:
         keep = ops.completion_mask(completions, self.eos_token_id)
         if self.reward_fn is not None:
             return self.reward_fn(completions * keep.to(completions.dtype)).to(torch.float32)
-        # same-tokenizer form of batch_retokenize(skip_special_tokens=True): the kept tokens are the reward model's
-        # input, everything after the first EOS is padding
-        ids = torch.where(keep.bool(), completions, torch.full_like(completions, self.pad_token_id))
-        am = keep.to(torch.int64)
-        T = ids.shape[1]
+        tok, rtok = getattr(self, 'tokenizer', None), getattr(self, 'reward_tokenizer', None)
+        if tok is not None and rtok is not None:
+            # grpo.py:243-250 `batch_retokenize`, as the reference does it whatever the tokenizers are: the masked ids (0 after the first eos) are DECODED
+            # with the actor's tokenizer without special tokens, the reward tokenizer's eos is appended to every text (also to a completion that was
+            # cut at the length cap) and the texts are ENCODED with the reward tokenizer (its bos, if it adds one; padded to the longest on its side).
+            # Host string work, exactly the reference's; the id shortcut below is for trainers built from injected models, which carry no tokenizer.
+            texts = tok.batch_decode(completions * keep.to(completions.dtype), skip_special_tokens=True)
+            enc = rtok([t + rtok.eos_token for t in texts], padding=True, truncation=False, return_tensors='pt')
+            ids, am = enc['input_ids'].to(sequences.device), enc['attention_mask'].to(sequences.device)
+        else:
+            # same-tokenizer shortcut: the kept tokens are the reward model's input, everything after the first EOS is padding
+            ids = torch.where(keep.bool(), completions, torch.full_like(completions, self.pad_token_id))
+            am = keep.to(torch.int64)
         scores = self.reward_model.module.scores(ids, am)
         end = end_index(self.reward_model.module.kind, am)
         return scores[torch.arange(ids.shape[0], device=ids.device), end].float()

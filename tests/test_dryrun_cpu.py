@@ -998,3 +998,52 @@ def test_ppo_retokenizes_for_a_reward_model_with_its_own_tokenizer(launches, tmp
     with pytest.raises(ValueError, match='critic'):
         PPOTrainer({'train_cfgs': {}, 'model_cfgs': {'actor_model_name_or_path': actor_dir, 'reward_model_name_or_path': actor_dir,
                                                      'reward_critic_model_name_or_path': reward_dir}}, None, device='cpu')
+
+
+def test_grpo_reward_inputs_equal_the_reference_s_batch_retokenize(launches, tmp_path):
+    """grpo.py:229-255: the reward model of the reference NEVER sees the actor's ids -- `compute_rewards` decodes the masked completions (ids after the
+    first eos zeroed) without special tokens, appends the reward tokenizer's eos and re-encodes.  The native trainer built from directories does the
+    same host work; the ids and mask it hands to the reward model equal the output of the reference's own `batch_retokenize` on the same completions
+    (one ends with eos, one was cut at the length cap and gets an eos it never generated, one is empty after masking)."""
+    import os
+    if not os.path.isdir('/root/reference/align_anything'):
+        pytest.skip('the reference package is only present in the build container')
+    from oracle import _shim
+    _shim.install()
+    from align_anything.utils.tools import batch_retokenize
+    import transformers as tf
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from align_anything_amd.trainers.grpo import GRPOTrainer
+    vocab = {w: i for i, w in enumerate(['<pad>', '</s>', '<unk>', '<s>'] + [f'w{i}' for i in range(316)])}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token='<unk>'))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    fast = tf.PreTrainedTokenizerFast(tokenizer_object=tk, bos_token='<s>', eos_token='</s>', unk_token='<unk>', pad_token='<pad>')
+    torch.manual_seed(0)
+    hf = tf.OPTForCausalLM(tf.OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=1, num_attention_heads=2, vocab_size=320, max_position_embeddings=128,
+                                        word_embed_proj_dim=128, dropout=0.0, pad_token_id=0, eos_token_id=1, bos_token_id=3))
+    d = str(tmp_path / 'm')
+    hf.save_pretrained(d)
+    fast.save_pretrained(d)
+    tr = GRPOTrainer({'train_cfgs': {'num_generations': 1, 'actor_lr_scheduler_type': 'constant'}, 'model_cfgs': {'actor_model_name_or_path': d, 'reward_model_name_or_path': d}},
+                     {'gradient_clipping': 1.0}, device='cpu')
+    assert tr.reward_tokenizer is not None and tr.pad_token_id == 0 and tr.eos_token_id == 1
+    P = 3
+    seq = torch.tensor([[3, 10, 11, 20, 21, 1, 0, 0],          # prompt | w16 w17 </s> pad pad
+                        [3, 10, 11, 30, 31, 32, 33, 34],       # prompt | five words, no eos: cut at the cap
+                        [3, 10, 11, 1, 40, 41, 0, 0]])         # prompt | </s> first: everything after it is masked
+    seen = []
+    real = tr.reward_model.module.scores
+    tr.reward_model.module.scores = lambda ids, am, *a, **k: (seen.append((ids.clone(), am.clone())), real(ids, am, *a, **k))[1]
+    from align_anything_amd import ops
+    with pytest.MonkeyPatch.context() as mp:      # aa_completion_mask is a kernel: its defined value here = ones up to and including the first eos
+        def cmask(c, eos):
+            first = torch.where((c == eos).any(1), (c == eos).float().argmax(1), torch.full((c.shape[0],), c.shape[1]))
+            return (torch.arange(c.shape[1])[None] <= first[:, None]).to(torch.uint8)
+        mp.setattr(ops, 'completion_mask', cmask)
+        tr.compute_rewards(seq, P)
+    ids, am = seen[0]
+    comp = seq[:, P:]
+    masked = comp * cmask(comp, 1).to(comp.dtype)
+    want = batch_retokenize(masked, src_tokenizer=tr.tokenizer, dest_tokenizer=tr.reward_tokenizer, skip_special_tokens=True, device='cpu')
+    assert torch.equal(ids, want['input_ids']) and torch.equal(am, want['attention_mask'])
+    assert ids[1].tolist()[-1] == 1 and ids[2].tolist()[0] == 1 and int(am[2].sum()) == 1        # the forced eos; the empty completion is just "</s>"
