@@ -93,6 +93,9 @@ class PPOTrainer(PPOMath):
                          gamma=float(t('gamma', 1.0)), gae_lambda=float(t('gae_lambda', 0.95)),
                          clip_range_ratio=float(t('clip_range_ratio', 0.2)), clip_range_value=float(t('clip_range_value', 5.0)))
         self.ptx_coeff = float(t('ptx_coeff', 16.0))        # configs/train/text_to_text/ppo.yaml:71
+        pb, tb = t('per_device_prompt_batch_size', None), t('per_device_train_batch_size', None)
+        if pb is not None and tb is not None and int(pb) % int(tb) != 0:      # ppo.py:172-182
+            raise ValueError('The number of prompt-only samples must be divisible by the micro batch size.')
         self._from_paths = self.model_cfg is None
         if self._from_paths:
             m_ = lambda k: cfg_get(self.cfgs, 'model_cfgs.' + k, None)
@@ -257,7 +260,9 @@ class PPOTrainer(PPOMath):
             r_ids, r_am = input_ids, attention_mask
             if getattr(self, 'retokenize_for_reward', False):
                 # ppo.py:226-235 `batch_retokenize`: the reward model has a tokenizer of its own -> the sequences are decoded with the actor's and
-                # encoded with the reward model's (+ its eos, padded to the longest on the reward tokenizer's side); host string work, as in the reference
+                # encoded with the reward model's (+ its eos, padded to the longest on the reward tokenizer's side); host string work, as in the reference.
+                # (The reference then ALSO hands the re-tokenised ids to rl_step as the actor's input, ppo.py:279 -- with the actor's mask, whose shape no
+                # longer fits: a defect of that rarely used path that is not reproduced; the update runs on the actor's own ids.)
                 texts = self.tokenizer.batch_decode(input_ids, skip_special_tokens=True)
                 enc = self.reward_tokenizer([t + self.reward_tokenizer.eos_token for t in texts], padding=True, truncation=False, return_tensors='pt')
                 r_ids, r_am = enc['input_ids'].to(input_ids.device), enc['attention_mask'].to(input_ids.device)
