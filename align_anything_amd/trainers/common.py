@@ -105,6 +105,15 @@ def cfg_get(cfgs, path: str, default=None):
     return default if cur is None else cur
 
 
+def refuse_unsupported_options(cfgs) -> None:
+    """Options of the reference's yaml that change WHAT is trained and have no native implementation must stop the trainer, not be dropped:
+    `lora_cfgs.use_lora` (base/supervised_trainer.py:53-58: peft adapters instead of full fine-tuning) and `bnb_cfgs.use_bnb` (4 / 8-bit weights)."""
+    if cfg_get(cfgs, 'lora_cfgs.use_lora', False):
+        raise NotImplementedError('lora_cfgs.use_lora: LoRA adapters have no native implementation (the native trainers fine-tune the full weights)')
+    if cfg_get(cfgs, 'bnb_cfgs.use_bnb', False):
+        raise NotImplementedError('bnb_cfgs.use_bnb: quantised base weights have no native implementation')
+
+
 def build_span_window(input_ids: torch.Tensor, start: int):
     """Rows for `gather_log_probabilities(logits[:, :-1], input_ids[:, 1:])[:, start:]` and
     `scores[:, :-1][:, start:]` (align_anything/trainers/text_to_text/ppo.py:339-356): row (n, j) for

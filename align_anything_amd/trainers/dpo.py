@@ -58,6 +58,8 @@ class DPOTrainer:
 
     # ------------------------------------------------------------------ init_*
     def init_check(self) -> None:
+        from .common import refuse_unsupported_options
+        refuse_unsupported_options(self.cfgs)
         if self.model_cfg is None:
             raise ValueError('model_cfg (align_anything_amd.configs dict) or model_cfgs.model_name_or_path is required')
         self.scale_coeff = float(cfg_get(self.cfgs, 'train_cfgs.scale_coeff', 0.1))

@@ -39,6 +39,8 @@ class GRPOTrainer:
 
     # ------------------------------------------------------------------ init_* (grpo.py:69-196)
     def init_check(self) -> None:
+        from .common import refuse_unsupported_options
+        refuse_unsupported_options(self.cfgs)
         cfgs = self.cfgs
         t = lambda k, d: cfg_get(cfgs, 'train_cfgs.' + k, d)
         self._from_paths = self.model_cfg is None

@@ -88,6 +88,8 @@ class PPOTrainer(PPOMath):
 
     # ------------------------------------------------------------------ init_* (ppo.py:62-207, base/rl_trainer.py:217-272)
     def init_check(self) -> None:
+        from .common import refuse_unsupported_options
+        refuse_unsupported_options(self.cfgs)
         t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
         PPOMath.__init__(self, kl_coeff=float(t('kl_coeff', 0.02)), clip_range_score=float(t('clip_range_score', 50.0)),
                          gamma=float(t('gamma', 1.0)), gae_lambda=float(t('gae_lambda', 0.95)),

@@ -35,6 +35,8 @@ class RMTrainer:
 
     # ------------------------------------------------------------------ init_* (rm.py:57-95)
     def init_check(self) -> None:
+        from .common import refuse_unsupported_options
+        refuse_unsupported_options(self.cfgs)
         if self.model_cfg is None and not cfg_get(self.cfgs, 'model_cfgs.model_name_or_path', None):
             raise ValueError('RMTrainer: model_cfg or model_cfgs.model_name_or_path is required')
         self.regularization = float(cfg_get(self.cfgs, 'train_cfgs.regularization', 0.001))

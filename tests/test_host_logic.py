@@ -1206,3 +1206,16 @@ def test_published_config_layouts_of_the_baseline_models_parse(tmp_path):
         (3584, 18944, 28, 28, 4, 128, 152064, 1000000.0, [16, 24, 24]) and t['attention_bias'] and c['image_token_id'] == 151655
     assert (v['embed_dim'], v['depth'], v['num_heads'], v['hidden_size'], v['patch_size'], v['temporal_patch_size'], v['spatial_merge_size'], v['in_channels']) == \
         (1280, 32, 16, 3584, 14, 2, 2, 3)
+
+
+def test_lora_and_quantised_training_are_refused_not_ignored():
+    """`lora_cfgs.use_lora` / `bnb_cfgs.use_bnb` change what the reference trains (base/supervised_trainer.py:53-58); the native trainers implement
+    neither and say so in init_check instead of silently fine-tuning the full bf16 weights."""
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    from align_anything_amd.trainers.grpo import GRPOTrainer
+    from align_anything_amd.trainers.ppo import PPOTrainer
+    from align_anything_amd.trainers.rm import RMTrainer
+    for cls in (DPOTrainer, RMTrainer, PPOTrainer, GRPOTrainer):
+        for bad in ({'lora_cfgs': {'use_lora': True}}, {'bnb_cfgs': {'use_bnb': True}}):
+            with pytest.raises(NotImplementedError):
+                cls(dict({'train_cfgs': {}, 'model_cfgs': {}}, **bad), None, model_cfg=tiny_opt_cfg(), device='cpu')
