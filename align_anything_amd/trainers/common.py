@@ -105,6 +105,20 @@ def cfg_get(cfgs, path: str, default=None):
     return default if cur is None else cur
 
 
+def resume_from_slice(trainer, engine) -> None:
+    """`train_cfgs.load_checkpoint` (supervised_trainer.py:76-77, :267-268): `model_cfgs.model_name_or_path` is a `slice_<step>` directory written with
+    `save_checkpoint` -- the step counter continues at <step> and the engine takes its fp32 masters, Adam moments and update count from the slice
+    (`engine.load_checkpoint`), after the 16-bit weights were loaded from the same directory like any other checkpoint."""
+    if not cfg_get(trainer.cfgs, 'train_cfgs.load_checkpoint', False):
+        return
+    path = str(cfg_get(trainer.cfgs, 'model_cfgs.model_name_or_path', '') or '')
+    try:
+        trainer.global_step = int(path.rstrip('/').split('slice_')[-1])
+    except ValueError:
+        raise ValueError(f'train_cfgs.load_checkpoint: model_cfgs.model_name_or_path must be a slice_<step> directory, got {path!r}') from None
+    engine.load_checkpoint(load_dir=path)
+
+
 def refuse_unsupported_options(cfgs) -> None:
     """Options of the reference's yaml that change WHAT is trained and have no native implementation must stop the trainer, not be dropped:
     `lora_cfgs.use_lora` (base/supervised_trainer.py:53-58: peft adapters instead of full fine-tuning) and `bnb_cfgs.use_bnb` (4 / 8-bit weights)."""
@@ -236,6 +250,10 @@ def save_slice(trainer, engine, tag=None, output_dir=None) -> str:
     out = output_dir or cfg_get(trainer.cfgs, 'logger_cfgs.output_dir', './output')
     d = os.path.join(out, f'slice_{tag or "end"}')
     engine.save_16bit_model(d, save_filename='pytorch_model.bin')          # every rank calls it (expert shards are gathered), rank 0 writes
+    # supervised_trainer.py:435-436 / rl_trainer.py:362-363: `train_cfgs.save_checkpoint` adds the engine's own training state (fp32 masters, Adam
+    # moments, step count -- DeepSpeed's save_checkpoint) to the slice, which `train_cfgs.load_checkpoint` resumes from
+    if cfg_get(trainer.cfgs, 'train_cfgs.save_checkpoint', False) and getattr(engine, 'trainable', False):
+        engine.save_checkpoint(d)
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0:
         for obj in (getattr(trainer, 'hf_config', None), getattr(trainer, 'tokenizer', None), getattr(trainer, 'processor', None)):

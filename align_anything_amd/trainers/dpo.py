@@ -55,6 +55,8 @@ class DPOTrainer:
         self.init_datasets()
         self.init_engines()
         self.init_logger()
+        from .common import resume_from_slice
+        resume_from_slice(self, self.model)
 
     # ------------------------------------------------------------------ init_*
     def init_check(self) -> None:

@@ -32,6 +32,8 @@ class RMTrainer:
         self.init_datasets()
         self.init_engines()
         self.init_logger()
+        from .common import resume_from_slice
+        resume_from_slice(self, self.model)
 
     # ------------------------------------------------------------------ init_* (rm.py:57-95)
     def init_check(self) -> None:
