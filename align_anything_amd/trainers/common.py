@@ -105,7 +105,7 @@ def cfg_get(cfgs, path: str, default=None):
     return default if cur is None else cur
 
 
-def resume_from_slice(trainer, engine) -> None:
+def resume_from_slice(trainer, engine_attr: str = 'model') -> None:
     """`train_cfgs.load_checkpoint` (supervised_trainer.py:76-77, :267-268): `model_cfgs.model_name_or_path` is a `slice_<step>` directory written with
     `save_checkpoint` -- the step counter continues at <step> and the engine takes its fp32 masters, Adam moments and update count from the slice
     (`engine.load_checkpoint`), after the 16-bit weights were loaded from the same directory like any other checkpoint."""
@@ -116,7 +116,7 @@ def resume_from_slice(trainer, engine) -> None:
         trainer.global_step = int(path.rstrip('/').split('slice_')[-1])
     except ValueError:
         raise ValueError(f'train_cfgs.load_checkpoint: model_cfgs.model_name_or_path must be a slice_<step> directory, got {path!r}') from None
-    engine.load_checkpoint(load_dir=path)
+    getattr(trainer, engine_attr).load_checkpoint(load_dir=path)
 
 
 def refuse_unsupported_options(cfgs) -> None:

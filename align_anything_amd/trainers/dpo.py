@@ -56,7 +56,7 @@ class DPOTrainer:
         self.init_engines()
         self.init_logger()
         from .common import resume_from_slice
-        resume_from_slice(self, self.model)
+        resume_from_slice(self)
 
     # ------------------------------------------------------------------ init_*
     def init_check(self) -> None:

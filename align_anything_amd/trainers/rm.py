@@ -33,7 +33,7 @@ class RMTrainer:
         self.init_engines()
         self.init_logger()
         from .common import resume_from_slice
-        resume_from_slice(self, self.model)
+        resume_from_slice(self)
 
     # ------------------------------------------------------------------ init_* (rm.py:57-95)
     def init_check(self) -> None:
