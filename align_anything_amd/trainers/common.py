@@ -121,11 +121,14 @@ def resume_from_slice(trainer, engine_attr: str = 'model') -> None:
 
 def refuse_unsupported_options(cfgs) -> None:
     """Options of the reference's yaml that change WHAT is trained and have no native implementation must stop the trainer, not be dropped:
-    `lora_cfgs.use_lora` (base/supervised_trainer.py:53-58: peft adapters instead of full fine-tuning) and `bnb_cfgs.use_bnb` (4 / 8-bit weights)."""
+    `lora_cfgs.use_lora` (base/supervised_trainer.py:53-58: peft adapters instead of full fine-tuning), `bnb_cfgs.use_bnb` (4 / 8-bit weights) and
+    `train_cfgs.fp16` (DeepSpeed fp16 with loss scaling)."""
     if cfg_get(cfgs, 'lora_cfgs.use_lora', False):
         raise NotImplementedError('lora_cfgs.use_lora: LoRA adapters have no native implementation (the native trainers fine-tune the full weights)')
     if cfg_get(cfgs, 'bnb_cfgs.use_bnb', False):
         raise NotImplementedError('bnb_cfgs.use_bnb: quantised base weights have no native implementation')
+    if cfg_get(cfgs, 'train_cfgs.fp16', False):
+        raise NotImplementedError('train_cfgs.fp16: fp16 training with loss scaling has no native implementation (bf16, the reference\'s default, and the fp32 parity mode are built)')
 
 
 def build_span_window(input_ids: torch.Tensor, start: int):

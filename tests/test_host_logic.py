@@ -1216,6 +1216,6 @@ def test_lora_and_quantised_training_are_refused_not_ignored():
     from align_anything_amd.trainers.ppo import PPOTrainer
     from align_anything_amd.trainers.rm import RMTrainer
     for cls in (DPOTrainer, RMTrainer, PPOTrainer, GRPOTrainer):
-        for bad in ({'lora_cfgs': {'use_lora': True}}, {'bnb_cfgs': {'use_bnb': True}}):
+        for bad in ({'lora_cfgs': {'use_lora': True}}, {'bnb_cfgs': {'use_bnb': True}}, {'train_cfgs': {'fp16': True}}):
             with pytest.raises(NotImplementedError):
                 cls(dict({'train_cfgs': {}, 'model_cfgs': {}}, **bad), None, model_cfg=tiny_opt_cfg(), device='cpu')
