@@ -265,7 +265,18 @@ class NativeEngine:
             return cosine_with_warmup(step, self.base_lr, self.warmup_steps, self.total_steps)
         if self.sched == 'constant':
             return self.base_lr
-        raise ValueError(f'lr_scheduler_type {self.sched!r} not supported (cosine, constant)')
+        if self.sched == 'constant_with_warmup':      # transformers get_constant_schedule_with_warmup
+            return self.base_lr * min(1.0, step / max(1, self.warmup_steps)) if self.warmup_steps else self.base_lr
+        if self.sched == 'linear':                    # transformers get_linear_schedule_with_warmup: up to base_lr, then straight down to 0 at `total`
+            if self.total_steps is None:
+                if step == 0:
+                    return 0.0 if self.warmup_steps else self.base_lr
+                raise RuntimeError("lr_scheduler_type 'linear' needs the number of optimizer updates (train(), engine.set_schedule(total) or "
+                                   "train_cfgs.total_training_steps)")
+            if step < self.warmup_steps:
+                return self.base_lr * step / max(1, self.warmup_steps)
+            return self.base_lr * max(0.0, (self.total_steps - step) / max(1, self.total_steps - self.warmup_steps))
+        raise ValueError(f'lr_scheduler_type {self.sched!r} not supported (cosine, linear, constant, constant_with_warmup)')
 
     def _compute_layer_slices(self):
         """For every decoder layer: the contiguous range of the flat 'mat' gradient buffer it owns."""

@@ -1219,3 +1219,24 @@ def test_lora_and_quantised_training_are_refused_not_ignored():
         for bad in ({'lora_cfgs': {'use_lora': True}}, {'bnb_cfgs': {'use_bnb': True}}, {'train_cfgs': {'fp16': True}}):
             with pytest.raises(NotImplementedError):
                 cls(dict({'train_cfgs': {}, 'model_cfgs': {}}, **bad), None, model_cfg=tiny_opt_cfg(), device='cpu')
+
+
+def test_lr_schedules_equal_transformers_get_scheduler():
+    """base/supervised_trainer.py:251-257 builds `get_scheduler(name=train_cfgs.lr_scheduler_type, ...)`: the native engine's closed forms for cosine, linear,
+    constant and constant_with_warmup against transformers' own schedulers, step by step."""
+    import transformers as tf
+    from types import SimpleNamespace
+    from align_anything_amd.engine import NativeEngine
+    for name in ('cosine', 'linear', 'constant', 'constant_with_warmup'):
+        for warm, total in ((0, 10), (3, 17)):
+            p = torch.nn.Parameter(torch.zeros(1))
+            opt = torch.optim.SGD([p], lr=2e-3)
+            sch = tf.get_scheduler(name=name, optimizer=opt, num_warmup_steps=warm, num_training_steps=total)
+            eng = SimpleNamespace(sched=name, base_lr=2e-3, warmup_steps=warm, total_steps=total)
+            for step in range(total + 1):
+                want = opt.param_groups[0]['lr']
+                assert abs(NativeEngine._lr_at(eng, step) - want) < 1e-12, (name, warm, total, step, NativeEngine._lr_at(eng, step), want)
+                opt.step()
+                sch.step()
+    with pytest.raises(ValueError, match='not supported'):
+        NativeEngine._lr_at(SimpleNamespace(sched='polynomial', base_lr=1.0, warmup_steps=0, total_steps=5), 1)
