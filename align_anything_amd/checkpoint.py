@@ -201,6 +201,8 @@ def load_tokenizer_and_processor(path, model_max_length=512, padding_side='left'
         tokenizer = AutoTokenizer.from_pretrained(path, model_max_length=model_max_length, padding_side=padding_side, trust_remote_code=True)
     except Exception:
         tokenizer = None
+    if processor_kwargs is not None and not isinstance(processor_kwargs, dict):      # the reference hands a namedtuple (namedtuple_to_dict, pretrained_model.py:295)
+        processor_kwargs = processor_kwargs._asdict() if hasattr(processor_kwargs, '_asdict') else dict(vars(processor_kwargs))
     try:
         processor = AutoProcessor.from_pretrained(path, trust_remote_code=True, **(processor_kwargs or {}))
     except Exception:
@@ -213,7 +215,7 @@ def load_tokenizer_and_processor(path, model_max_length=512, padding_side='left'
 
 
 def load_pretrained(path, device, *, trainable=True, head='lm', dtype=torch.bfloat16, model_max_length=512, padding_side='left',
-                    state_from=None, build_kwargs=None, with_tokenizer=True):
+                    state_from=None, build_kwargs=None, with_tokenizer=True, processor_kwargs=None):
     """Native `load_pretrained_models`: returns (model, tokenizer, processor, hf_config).  `state_from`: another directory to take the
     weights from (same geometry).  The tokenizer gains `<pad>` when it has no pad token and the embeddings grow by that row."""
     from transformers import AutoConfig
@@ -224,7 +226,7 @@ def load_pretrained(path, device, *, trainable=True, head='lm', dtype=torch.bflo
     tokenizer = processor = None
     extra = 0
     if with_tokenizer:
-        tokenizer, processor = load_tokenizer_and_processor(path, model_max_length, padding_side)
+        tokenizer, processor = load_tokenizer_and_processor(path, model_max_length, padding_side, processor_kwargs)      # pretrained_model.py:183, :295
         if tokenizer is not None:
             if tokenizer.pad_token is None:
                 extra = tokenizer.add_special_tokens({'pad_token': DEFAULT_PAD_TOKEN})

@@ -328,7 +328,7 @@ def resolve_pretrained(cfgs, device, *, trainable, head='lm', dtype=None, path_k
         raise ValueError(f'{path_key} is not set and no model_cfg / state was handed to the trainer')
     return load_pretrained(path, device, trainable=trainable, head=head, dtype=dtype or compute_dtype(cfg_get(cfgs, 'train_cfgs.compute_dtype', 'bf16')),
                            model_max_length=int(cfg_get(cfgs, 'model_cfgs.model_max_length', 512)), padding_side='left',
-                           build_kwargs=build_kwargs, with_tokenizer=with_tokenizer)
+                           build_kwargs=build_kwargs, with_tokenizer=with_tokenizer, processor_kwargs=cfg_get(cfgs, 'train_cfgs.processor_kwargs', None))
 
 
 def infer_modality(trainer) -> str:
