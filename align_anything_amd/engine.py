@@ -108,25 +108,32 @@ class GradReducer:
         for mode in ('ring', 'direct'):
             buf = src.clone()
             run = (lambda b: self._direct(b)) if mode == 'direct' else (lambda b: dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group))
+            # a form that raises on ONE rank only must not leave that rank out of the timed collectives its peers still issue:
+            # the ranks agree on the warm-up's success (MIN) before anything else of this form runs
             try:
                 run(buf)                                   # warm-up (communicator setup, workspaces) and the value check below
                 outs[mode] = buf.clone()
-                if like.is_cuda:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(reps):
-                        run(buf)
-                    e1.record()
-                    e1.synchronize()
-                    ms = e0.elapsed_time(e1) / reps
-                else:
-                    t0 = time.perf_counter()
-                    for _ in range(reps):
-                        run(buf)
-                    ms = (time.perf_counter() - t0) * 1e3 / reps
+                good = 1.0
             except RuntimeError as ex:                   # a backend without one of the collectives: the other form is used
+                good, outs[mode] = 0.0, None
+                self.autotune_report = {**(self.autotune_report or {}), 'error_' + mode: repr(ex)[:200]}
+            gt = torch.tensor([good], device=like.device if like.is_cuda else 'cpu')
+            dist.all_reduce(gt, op=dist.ReduceOp.MIN, group=self.group)
+            if not bool(gt.item()):
                 ms, outs[mode] = float('inf'), None
-                self.autotune_report = {'error_' + mode: repr(ex)[:200]}
+            elif like.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    run(buf)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+            else:
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    run(buf)
+                ms = (time.perf_counter() - t0) * 1e3 / reps
             t = torch.tensor([ms if ms != float('inf') else 1e30], dtype=torch.float64, device=like.device if like.is_cuda else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             times[mode] = float(t.item())
@@ -240,8 +247,10 @@ class NativeEngine:
     def set_schedule(self, total_steps: int, warmup_ratio: float | None = None, gradient_accumulation_steps: int | None = None):
         """Length of the LR schedule in OPTIMIZER updates (what the reference hands to transformers.get_scheduler,
         base/rl_trainer.py:190-197, base/supervised_trainer.py:236-257) and, optionally, the accumulation depth.  May be called
-        until the first update; the trainers' train() use it once the dataloader length is known."""
-        if self.global_steps:
+        until the first update; the trainers' train() use it once the dataloader length is known.  A RESUMED engine whose schedule length
+        was never known (load_checkpoint set global_steps, total_steps still None: ADVICE r4, the RM resume under a cosine schedule) may
+        still learn it -- nothing has been evaluated with a different length."""
+        if self.global_steps and self.total_steps is not None:
             raise RuntimeError('set_schedule() after the first optimizer update')
         if gradient_accumulation_steps is not None:
             if self.micro_steps % self.gas:
@@ -252,7 +261,7 @@ class NativeEngine:
         if warmup_ratio is not None:
             self.warmup_steps = int(self.total_steps * float(warmup_ratio))
         for pg in self.optimizer.param_groups:
-            pg['lr'] = self._lr_at(0)
+            pg['lr'] = self._lr_at(self.global_steps)
 
     def _lr_at(self, step):
         if self.sched == 'cosine':
@@ -494,7 +503,7 @@ class NativeEngine:
         tag = tag or 'latest'
         pick = lambda groups: {k: {g: t.cpu() for g, t in d.items() if g in groups} for k, d in (('master', st.master), ('m', st.m), ('v', st.v))}
         if rank == 0:
-            torch.save({'global_steps': self.global_steps, **pick([g for g in st.master if g != 'exp'])},
+            torch.save({'global_steps': self.global_steps, 'micro_steps': self.micro_steps, **pick([g for g in st.master if g != 'exp'])},
                        os.path.join(save_dir, f'native_engine_{tag}.pt'))
         if 'exp' in st.master:
             torch.save(pick(['exp']), os.path.join(save_dir, f'native_engine_{tag}_ep{rank}.pt'))
@@ -505,6 +514,10 @@ class NativeEngine:
         tag = tag or 'latest'
         ck = torch.load(os.path.join(load_dir, f'native_engine_{tag}.pt'), map_location='cpu')
         self.global_steps = ck['global_steps']
+        self.micro_steps = ck.get('micro_steps', self.global_steps * self.gas)        # a slice saved inside an accumulation window resumes inside it
+        if not (self.total_steps is None and self.sched in ('cosine', 'linear')):      # else: set_schedule() refreshes it once the length is known
+            for pg in self.optimizer.param_groups:
+                pg['lr'] = self._lr_at(self.global_steps)
         if 'exp' in st.master:
             rank = dist.get_rank(self.reducer.group) if dist.is_initialized() else 0
             shard = torch.load(os.path.join(load_dir, f'native_engine_{tag}_ep{rank}.pt'), map_location='cpu')

@@ -66,6 +66,8 @@ class ExpertParallel:
         self.dense_below = int(dense_below)
         self._overflow = None          # 0-d bool on the device: some rank block of this step was larger than its capacity
         self._pending = None           # (pinned host copy, event) of the previous step's flag
+        self._shared = None            # 0-d bool: the all-reduced flag of an engine step (watch_shared)
+        self._engine = False           # an engine folds the local flag into its all-reduce: polls then read only the shared flag
         # host integers (block sizes) are agreed on a gloo group: an RCCL all-reduce would need a device tensor and a blocking read.
         # Collective over the members of `group` (like the constructor's caller `dist.new_group()`); only the padded exchange needs it.
         self.host_group = group
@@ -197,14 +199,18 @@ class ExpertParallel:
         return torch.where(flag.to(device), float('-inf'), 0.0).to(torch.float32)
 
     def watch_shared(self, sumsq: torch.Tensor) -> None:
-        """After the all-reduce: start the asynchronous host copy of "some rank overflowed" (identical on every rank) for `poll_overflow`."""
+        """After the all-reduce: start the asynchronous host copy of "some rank overflowed" (identical on every rank) for `poll_overflow`.
+        From the first call on an engine owns the LOCAL flag: it is consumed only by `overflow_sentinel` (so that it always reaches the
+        all-reduce, whatever polls happen in between -- ADVICE r4), and `poll_overflow` reads only this shared one."""
+        self._engine = True
         flag = (sumsq.reshape(-1)[0] == float('-inf'))
-        self._overflow = flag if self._overflow is None else (self._overflow | flag)
+        self._shared = flag if self._shared is None else (self._shared | flag)
         if self._pending is None:
-            self._start_copy()
+            self._start_copy('_shared')
 
-    def _start_copy(self):
-        flag, self._overflow = self._overflow, None
+    def _start_copy(self, which='_overflow'):
+        flag = getattr(self, which)
+        setattr(self, which, None)
         if flag.is_cuda:
             host = torch.empty((), dtype=torch.bool).pin_memory()
             host.copy_(flag, non_blocking=True)
@@ -216,8 +222,9 @@ class ExpertParallel:
 
     def poll_overflow(self, block: bool = False) -> None:
         """Never blocks unless asked to: raises if a flag whose host copy has landed was set, then starts the asynchronous read of the flag
-        accumulated since.  With an engine the flag is the shared one (`watch_shared`: same value, same step on every rank, and the optimizer
-        update of that step was skipped on the device); without one (rollouts) it is this rank's own."""
+        accumulated since.  With an engine (`watch_shared` has run) the flag is the shared one: same value, same step on every rank, and the
+        optimizer update of that step was skipped on the device; this rank's own flag is then left for `overflow_sentinel`.  Without an engine
+        (stand-alone rollouts) it is this rank's own."""
         if self._pending is not None:
             host, ev = self._pending
             if block and ev is not None:
@@ -229,8 +236,9 @@ class ExpertParallel:
                                        f'rank more rows than a block holds and those rows were NOT processed -- the step is invalid (its optimizer update was '
                                        f'skipped on the device).  Raise '
                                        f'train_cfgs.expert_parallel_capacity_factor (<= {self.size} always fits) or set it to 0 for the exact exchange')
-        if self._overflow is not None and self._pending is None:
-            self._start_copy()
+        which = '_shared' if self._engine else '_overflow'
+        if getattr(self, which) is not None and self._pending is None:
+            self._start_copy(which)
             if block:
                 self.poll_overflow(block=True)
 

@@ -50,6 +50,12 @@ class DPOTrainer:
         # the reference's constructor order (text_to_text/dpo.py:59-77): init_check, init_models, init_datasets, init_engines, init_logger.
         # `DPOTrainer(cfgs, ds_cfgs)` alone works like the reference's: the models come from model_cfgs.model_name_or_path, the
         # dataloaders from data_cfgs; the keyword arguments inject pre-built pieces instead (tests, bench.py, INTEGRATION.md level B)
+        # everything that can refuse a configuration runs BEFORE both models are streamed into HBM; only what needs the loaded
+        # tokenizer / config (pad_token_id) waits for init_models
+        from .common import refuse_unsupported_options
+        refuse_unsupported_options(self.cfgs)
+        if self.model_cfg is None and not cfg_get(self.cfgs, 'model_cfgs.model_name_or_path', None):
+            raise ValueError('model_cfg (align_anything_amd.configs dict) or model_cfgs.model_name_or_path is required')
         self.init_models(policy_state, reference_state)
         self.init_check()
         self.init_datasets()
@@ -248,7 +254,7 @@ class DPOTrainer:
         history = []
         epochs = int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))
         n_batches = len(self.train_dataloader) if hasattr(self.train_dataloader, '__len__') else None
-        if self.model.total_steps is None and not self.model.global_steps and n_batches is not None:   # dataloader attached after __init__
+        if self.model.total_steps is None and n_batches is not None:   # dataloader attached after __init__
             self.model.set_schedule(epochs * ((n_batches + self.model.gas - 1) // self.model.gas),
                                     float(cfg_get(self.cfgs, 'train_cfgs.lr_warmup_ratio', 0.03)))
         per_epoch = max(1, n_batches or 1)

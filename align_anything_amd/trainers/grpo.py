@@ -74,9 +74,13 @@ class GRPOTrainer:
             actor, self.tokenizer, self.processor, self.hf_config = load_pretrained(ap_, device, trainable=True, dtype=dt, model_max_length=mml, padding_side='left',
                                                                                     build_kwargs=epk)
             ref = load_pretrained(ap_, device, trainable=False, dtype=dt, model_max_length=mml, padding_side='left', build_kwargs=epk)[0]
-            if cfg_get(cfgs, 'model_cfgs.pad_token_id', None) is None and self.tokenizer is not None:
-                self.pad_token_id = int(self.tokenizer.pad_token_id)
-                self.eos_token_id = int(self.tokenizer.eos_token_id) if self.tokenizer.eos_token_id is not None else self.eos_token_id
+            if self.tokenizer is not None:
+                # pad and eos are resolved INDEPENDENTLY (as PPOTrainer._token_id): the yaml's value when set, else the tokenizer's
+                # (grpo.py takes both from the tokenizer), else the default -- a yaml that sets only pad_token_id must not freeze eos at 2
+                if cfg_get(cfgs, 'model_cfgs.pad_token_id', None) is None and self.tokenizer.pad_token_id is not None:
+                    self.pad_token_id = int(self.tokenizer.pad_token_id)
+                if cfg_get(cfgs, 'model_cfgs.eos_token_id', None) is None and self.tokenizer.eos_token_id is not None:
+                    self.eos_token_id = int(self.tokenizer.eos_token_id)
             if self.reward_fn is None:
                 reward, self.reward_tokenizer, _, _ = load_pretrained(rp_, device, trainable=False, head='score', dtype=dt, model_max_length=mml, padding_side='right',
                                                                       build_kwargs=rpk)
@@ -215,7 +219,7 @@ class GRPOTrainer:
         t = lambda k, d: cfg_get(self.cfgs, 'train_cfgs.' + k, d)
         epochs = int(t('epochs', 1))
         n = len(prompt_only_dataloader) if hasattr(prompt_only_dataloader, '__len__') else None
-        if self.actor_model.total_steps is None and not self.actor_model.global_steps and n is not None:
+        if self.actor_model.total_steps is None and n is not None:
             total = (n * epochs * int(t('update_iters', 1)) * int(t('per_device_prompt_batch_size', 1))
                      // max(1, int(t('per_device_train_batch_size', 1))))            # grpo.py:157-163
             self.actor_model.set_schedule(max(1, total // self.gas), float(t('actor_lr_warmup_ratio', 0.03)))

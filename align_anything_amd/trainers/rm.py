@@ -141,7 +141,7 @@ class RMTrainer:
         self.global_step = getattr(self, 'global_step', 0)
         epochs = int(cfg_get(self.cfgs, 'train_cfgs.epochs', 1))
         n = len(dl) if hasattr(dl, '__len__') else None
-        if self.model.total_steps is None and not self.model.global_steps and n is not None:
+        if self.model.total_steps is None and n is not None:
             self.model.set_schedule(epochs * ((n + self.gas - 1) // self.gas), float(cfg_get(self.cfgs, 'train_cfgs.lr_warmup_ratio', 0.03)))
         remain = epochs - self.global_step // n if n else epochs
         skip = self.global_step % n if n else 0

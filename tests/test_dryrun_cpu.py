@@ -564,6 +564,20 @@ def test_rm_grpo_ppo_loops_resume_and_save_on_the_reference_schedules(launches, 
     assert sorted(os.listdir(tmp_path / 'rm')) == ['slice_6'] and os.path.exists(tmp_path / 'rm' / 'slice_6' / 'pytorch_model.bin')
     saved = torch.load(tmp_path / 'rm' / 'slice_6' / 'pytorch_model.bin')
     assert 'score_head.weight' in saved and 'lm_head.weight' not in saved
+    # ---- an RM engine resumed by load_checkpoint under the DEFAULT cosine schedule: the constructor cannot know the schedule length (the
+    # dataloader is handed to train()), load_checkpoint sets global_steps > 0 -- train() must still give the schedule its length instead of raising
+    c2 = _cfgs(z, epochs=2)
+    c2['train_cfgs'].update(lr_scheduler_type='cosine', lr_warmup_ratio=0.0, learning_rate=1e-3)
+    rm2 = RMTrainer(c2, {'gradient_clipping': 1.0}, model_cfg=cfg, state=rm_sd, device='cpu')
+    assert rm2.model.total_steps is None
+    rm2.model.save_checkpoint(str(tmp_path / 'eng'))
+    rm2.model.global_steps = 99
+    rm2.model.load_checkpoint(str(tmp_path / 'eng'))
+    assert rm2.model.global_steps == 0 and rm2.model.micro_steps == 0
+    rm2.model.global_steps, rm2.model.micro_steps, rm2.global_step = 4, 4, 4          # = a slice taken after step 4 of 6
+    hist2 = rm2.train([_pref_batch(z)] * 3)
+    from align_anything_amd.engine import cosine_with_warmup
+    assert len(hist2) == 2 and rm2.model.total_steps == 6 and abs(hist2[0]['train/lr'] - cosine_with_warmup(5, 1e-3, 0, 6)) < 1e-12
     # ---- GRPO: 1 epoch x 4 prompt batches, limit 2 -> slices at 2 and 4, and the final actor (output_dir is configured)
     prompts = T(z['input_ids'])[:2, :20]
     pb = {'input_ids': prompts, 'attention_mask': torch.ones_like(prompts)}

@@ -174,6 +174,90 @@ def _padded_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _engine_step_worker(rank, world, port, q):
+    """NativeEngine.step() itself, with one rank overflowing.  step() polls BEFORE it folds the local flag into the squared-norm
+    all-reduce; the poll must not eat that flag.  The three optimizer kernels are replaced by their contract on CPU tensors (csrc/optim.hip:
+    sumsq == -inf -> coefficient -1 -> AdamW returns without touching anything); everything else -- the poll, the sentinel, the all-reduce, the
+    shared watch -- is the engine's own code.  Every rank must skip the update and every rank must raise at its next poll."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from align_anything_amd import engine as eng, ops
+    from align_anything_amd.expert_parallel import ExpertParallel
+    from align_anything_amd.params import ParamStore
+    touched = []
+
+    def grad_sumsq_(g, out, scale=1.0, ws=None):
+        out += (g.float() * scale).pow(2).sum()
+
+    def clip_coef(sumsq, max_norm, coef, norm=None):
+        if float(sumsq) == float('-inf'):
+            coef.fill_(-1.0)
+            norm.fill_(-1.0)
+        else:
+            norm.copy_(sumsq.sqrt())
+            coef.fill_(min(1.0, max_norm / (float(norm) + 1e-6)) if max_norm else 1.0)
+
+    def adamw_flat_(master, m, v, p16, g, lr, b1, b2, eps, wd, step, gscale=1.0, clip=None):
+        if gscale * float(clip) < 0:
+            return
+        touched.append(step)
+        master -= lr * g.float() * gscale * float(clip)
+
+    ops.grad_sumsq_, ops.clip_coef, ops.adamw_flat_, ops.adamw_set_thin = grad_sumsq_, clip_coef, adamw_flat_, lambda on: None
+    st = ParamStore('cpu', torch.float32)
+    st.add('experts.w', (8 // world, 3), trainable=True, shard=(rank * (8 // world), 8))
+    st.add('dense.w', (3, 4), trainable=True)
+    st.allocate()
+    ep = ExpertParallel(dist.new_group(), capacity_factor=1.0, dense_below=0)
+    module = SimpleNamespace(store=st, ep=ep, device=torch.device('cpu'), init_training=st.init_training)
+    e = eng.NativeEngine(module, lr=0.1, lr_scheduler_type='constant', weight_decay=0.0)
+    ok = e.world == world and ep.padded
+
+    def one_step(overflow_here):
+        for g in st.gflat.values():
+            g.fill_(0.5)
+        if overflow_here:             # what padded_send_layout does when a block does not fit
+            ep._overflow = torch.tensor(True)
+        e.micro_steps += 1
+        e.step()
+
+    before = {g: t.clone() for g, t in st.master.items()}
+    one_step(False)                                                    # a clean step first: the poll inside the NEXT step has a landed, clear flag to consume
+    ok = ok and touched and float(e._coef) > 0 and all(not torch.equal(before[g], st.master[g]) for g in before)
+    before = {g: t.clone() for g, t in st.master.items()}
+    n = len(touched)
+    one_step(rank == world - 1)                                        # only the last rank overflows
+    ok = ok and float(e._coef) == -1.0 and float(e._gnorm) == -1.0 and len(touched) == n           # skipped on EVERY rank
+    ok = ok and all(torch.equal(before[g], st.master[g]) for g in before)
+    raised = False
+    try:
+        e.grad_norm()
+    except RuntimeError as err:
+        raised = 'skipped' in str(err)
+    ok = ok and raised                                                 # ... and every rank raises, in the same step
+    one_step(False)                                                    # the flags were consumed: training can go on (a caller that catches the error)
+    ok = ok and float(e._coef) > 0 and len(touched) > n
+    e.grad_norm()
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_engine_step_shares_the_overflow_flag(world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_engine_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
 @pytest.mark.parametrize('world', [2, 4, 8])
 def test_capacity_padded_exchange_equals_exact_exchange(world):
     ctx = mp.get_context('spawn')

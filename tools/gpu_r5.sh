@@ -21,6 +21,14 @@ for stage in "$@"; do
       t=$(find gpurun_out/r05_ppo_prof -name "*kernel_trace.csv" | head -1)
       [ -n "$t" ] && python3 tools/decode_trace_summary.py "$t" > gpurun_out/r05_decode_trace_summary.txt; cut -c1-200 gpurun_out/r05_decode_trace_summary.txt
       find gpurun_out/r05_ppo_prof -name "*kernel_trace.csv" -delete ;;
+    attn_pmc_instep)   # clock-vs-fabric for the in-step attention kernels: GRBM_GUI_ACTIVE + SQ_BUSY_CYCLES (effective clock = cycles / trace duration) and FETCH_SIZE, three separate --pmc passes over the bench step itself
+      ( cd /tmp && export TMPDIR=/tmp
+        for set in "GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES" "FETCH_SIZE"; do
+          rm -rf $R/gpurun_out/r05_pmc_$set
+          timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/r05_pmc_$set -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-events --traffic committed --no-per-batch > $R/gpurun_out/r05_pmc_$set.log 2>&1
+        done )
+      python3 tools/pmc_instep_summary.py gpurun_out > gpurun_out/r05_attn_instep_pmc.txt; cat gpurun_out/r05_attn_instep_pmc.txt | cut -c1-220
+      find gpurun_out/r05_pmc_* -name "*kernel_trace.csv" -delete; find gpurun_out/r05_pmc_* -name "*counter_collection.csv" -size +8M -delete ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
