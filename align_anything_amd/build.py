@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libaa_hip.so')
-SOURCES = ['runtime.hip', 'comm.hip', 'rl_math.hip', 'lmhead.hip', 'pref_losses.hip', 'elementwise.hip', 'elementwise_f32.hip', 'optim.hip', 'gemm.hip', 'gemm4.hip', 'attention.hip', 'decode.hip', 'decode_layer.hip',
+SOURCES = ['runtime.hip', 'comm.hip', 'rl_math.hip', 'lmhead.hip', 'pref_losses.hip', 'elementwise.hip', 'elementwise_f32.hip', 'optim.hip', 'gemm.hip', 'gemm4.hip', 'attention.hip', 'decode.hip',
            'gemm_f32.hip', 'attention_f32.hip', 'moe.hip', 'moe_f32.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wno-unused-result']

@@ -208,25 +208,6 @@ class LlamaStack:
     def release_decode(self):
         """Free the rollout-only weight copies."""
         self._dw = None
-        self._pstate = None
-
-    def _persistent_state(self, N, dw):
-        """ops.DecodeLayerState for N sequences, or None when the persistent layer kernel cannot serve this stack (copies not in the folded rope128 /
-        glu layout, a device that cannot hold one workgroup per compute unit, or a barrier that timed out earlier)."""
-        if getattr(self, '_persistent_bad', False):
-            return None
-        W = dw[0]
-        if not (W['qkv'].mode == 'rope128' and W['qkv'].folded and W['gu'].mode == 'glu' and W['gu'].folded):
-            return None
-        c = self.cfg
-        key = (N, c['hidden_size'], c['num_heads'], c['intermediate_size'])
-        st = getattr(self, '_pstate', None)
-        if st is None or st.shape != key:
-            st = self._pstate = ops.DecodeLayerState(self.store.device, *key)
-        if st.grid <= 0:
-            self._persistent_bad = True
-            return None
-        return st
 
     def decode_step(self, x, cache, t, Tmax, pos, start, length, dw=None):
         """One new token per sequence (x [N, h]) against the KV cache (csrc/decode.hip): every GEMM streams its
@@ -237,28 +218,6 @@ class LlamaStack:
         qw, kw = H * hd, Hkv * hd
         N = x.shape[0]
         self._tables(Tmax)
-        if dw is not None and os.environ.get('AA_DECODE_PERSISTENT', '0') in ('1', '2') and hd == 128 and N <= 16:
-            # one launch per layer (csrc/decode_layer.hip: the five steps as phases of a persistent kernel behind grid barriers).  NOT yet run on
-            # hardware -> opt-in.  The first position of a rollout checks the kernel's status word (a barrier that timed out) and, if set, redoes
-            # the position with the per-step launches below and stays on them.
-            st = self._persistent_state(N, dw)
-            if st is not None:
-                x0 = x
-                if os.environ.get('AA_DECODE_PERSISTENT') == '2':
-                    # ALL layers in one launch: the per-layer argument blocks are packed once per rollout (same buffers, counters updated in place)
-                    key = ((id(dw), cache[0].data_ptr(), t.data_ptr(), pos.data_ptr(), length.data_ptr(), 0 if start is None else start.data_ptr(), Tmax),
-                           (H, Hkv, c['intermediate_size'], eps, hd ** -0.5, pos, self.cos, self.sin, Tmax, t, start, length))
-                    if st.pack_key is None or st.pack_key[0] != key[0]:
-                        st.pack(key, [(dw[li], L['qkv'].b, cache[li]) for li, L in enumerate(self.layers)])
-                    x = st.run_all(x)
-                else:
-                    for li, L in enumerate(self.layers):
-                        x = ops.decode_layer(st, x, dw[li], L['qkv'].b, H, Hkv, c['intermediate_size'], eps, hd ** -0.5, pos, self.cos, self.sin, cache[li], Tmax, t,
-                                             start, length, li)
-                if st.checked or not st.failed():
-                    return x
-                self._persistent_bad = True
-                x = x0
         for li, L in enumerate(self.layers):
             # RoPE and the cache write are one pass over the new row (aa_decode_rope_cache); linear_small(norm= / swiglu=) runs the
             # RMSNorm / SwiGLU kernels itself unless ops.DECODE_FUSED folds them into the weight stream (measured slower, off)

@@ -1054,69 +1054,6 @@ def move_padding_left(seq, pad_token_id):
     return out
 
 
-class DecodeLayerState:
-    """Per-device state of the persistent per-layer decode kernel (aa_decode_layer_bf16): the grid it may use, its barrier words (zeroed once), the
-    status word a timed-out barrier sets, and the workspaces of one layer (reused by every layer and position of a rollout)."""
-
-    def __init__(self, device, M, h, H, F):
-        g = ctypes.c_int(0)
-        call('aa_decode_layer_grid', ctypes.byref(g))
-        self.grid = int(g.value)
-        self.bar = torch.zeros(2, dtype=torch.int32, device=device)
-        self.status = torch.zeros(1, dtype=torch.int32, device=device)
-        self.shape = (M, h, H, F)
-        e = lambda *sz: torch.empty(sz, dtype=bf16, device=device)
-        self.x_mid, self.q, self.attn, self.act, self.x_alt = e(M, h), e(M, H * 128), e(M, H * 128), e(M, F), [e(M, h), e(M, h)]
-        self.checked = False
-        self.x0 = e(M, h)              # layer 0's input of the all-layers launch (the embedding row is copied here: a fixed address)
-        self.blocks, self.pack_key = None, None
-
-    def pack(self, key, layers):
-        """Per-layer argument blocks of the all-layers launch (aa_decode_layers_pack), rebuilt when `key` (the rollout's buffers) changes.
-        layers: one tuple (W, bias, cache) per layer + the shared arguments in `key`."""
-        (H, Hkv, F, eps, scale, pos, cos_t, sin_t, Tmax, slot, start, length) = key[1]
-        M, h = self.shape[0], self.shape[1]
-        nb = ctypes.c_int(0)
-        call('aa_decode_layers_block_bytes', ctypes.byref(nb))
-        self.blocks = torch.empty(len(layers) * max(int(nb.value), 1), dtype=torch.uint8, device=self.x0.device)
-        x_in = self.x0
-        for li, (W, bias, cache) in enumerate(layers):
-            out = self.x_alt[li & 1]
-            call('aa_decode_layers_pack', self.blocks.data_ptr(), li, x_in.data_ptr(), self.x_mid.data_ptr(), out.data_ptr(), self.q.data_ptr(), self.attn.data_ptr(),
-                 self.act.data_ptr(), W['qkv'].data.data_ptr(), W['o'].data.data_ptr(), W['gu'].data.data_ptr(), W['down'].data.data_ptr(), _p(bias), M, h, int(H), int(Hkv),
-                 int(F), float(eps), float(scale), pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), cache.data_ptr(), cache.stride(0), int(Tmax), slot.data_ptr(),
-                 _p(start), length.data_ptr(), self.bar.data_ptr(), self.status.data_ptr(), stream())
-            x_in = out
-        self.n_layers, self.pack_key = len(layers), key
-
-    def run_all(self, x):
-        """One launch for all packed layers: x [M, h] -> the last layer's output buffer."""
-        self.x0.copy_(x)
-        call('aa_decode_layers_bf16', self.blocks.data_ptr(), self.n_layers, self.grid, stream())
-        return self.x_alt[(self.n_layers - 1) & 1]
-
-    def failed(self) -> bool:
-        """One host read: did any grid barrier time out so far?  (Checked after the first position of a rollout.)"""
-        self.checked = True
-        return bool(int(self.status.item()))
-
-
-def decode_layer(st, x, W, bias, H, Hkv, F, eps, scale, pos, cos_t, sin_t, cache, Tmax, slot, start, length, flip):
-    """One decoder layer of a decode position in one launch (csrc/decode_layer.hip).  W: the layer's strip-major copies {'qkv' (rope128, folded), 'o',
-    'gu' (glu, folded), 'down'}; returns x_out (one of the state's two alternating buffers: `flip`)."""
-    M, h = x.shape
-    if not (W['qkv'].mode == 'rope128' and W['qkv'].folded and W['gu'].mode == 'glu' and W['gu'].folded and W['o'].mode == 'plain' and W['down'].mode == 'plain'):
-        raise RuntimeError('decode_layer: needs the folded rope128 / glu strip-major copies (LlamaStack.prepare_decode defaults)')
-    if x.dtype != bf16 or cache.dtype != bf16 or slot.dtype != torch.int64 or pos.dtype != torch.int32 or length.dtype != torch.int32 or st.shape != (M, h, H, F) or st.grid <= 0:
-        raise RuntimeError('decode_layer: bf16 activations / cache, int32 pos / length, int64 slot, a state built for this geometry on a device that can hold the grid')
-    out = st.x_alt[flip & 1]
-    call('aa_decode_layer_bf16', x.data_ptr(), st.x_mid.data_ptr(), out.data_ptr(), st.q.data_ptr(), st.attn.data_ptr(), st.act.data_ptr(), W['qkv'].data.data_ptr(),
-         W['o'].data.data_ptr(), W['gu'].data.data_ptr(), W['down'].data.data_ptr(), _p(bias), M, h, int(H), int(Hkv), int(F), float(eps), float(scale), pos.data_ptr(),
-         cos_t.data_ptr(), sin_t.data_ptr(), cache.data_ptr(), cache.stride(0), int(Tmax), slot.data_ptr(), _p(start), length.data_ptr(), st.bar.data_ptr(),
-         st.status.data_ptr(), st.grid, stream())
-    return out
-
-
 def decode_record(selected, unfinished, out, tslot, nact, pad_token_id, eos_token_id):
     """Bookkeeping of one decode position after the selection kernel (aa_decode_record): returns tok [N] (pad for finished rows), writes it into
     out[n, tslot[n]], counts the step in `nact` if any row was unfinished, clears `unfinished` of rows that emitted eos (eos < 0: none)."""

@@ -218,6 +218,7 @@ def main():
                          '(two rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1` at full depth, ~3 min); committed: read profiles/r02_gemm_traffic.json; '
                          'auto (default): measure at N=1 when rocprofv3 is on PATH, else committed.  roofline.traffic_source says which one the line carries')
     ap.add_argument('--measure-traffic', action='store_true', help='same as --traffic measure (kept for the round-2 command lines)')
+    ap.add_argument('--no-power', action='store_true', help='do not start the power / clock sidecar (tools/power_sampler.py)')
     ap.add_argument('--no-per-batch', action='store_true', help='skip the B=1 / B=2 pairs-per-GPU datapoints measured after the timed region (N=1 only)')
     ap.add_argument('--rccl-channels', type=int, default=int(os.environ.get('AA_RCCL_CHANNELS', 0)),
                     help='N>1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS; one channel = one workgroup = one CU taken from the GEMMs while a '
@@ -331,6 +332,18 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # package power + shader clock over the timed region, from a sidecar PROCESS (tools/power_sampler.py) so that the poller
+    # shares no interpreter lock with the launch loop; rank 0 samples its own device
+    sampler, sampler_path = None, None
+    if rank == 0 and not args.no_power and not in_pmc_child:
+        import tempfile
+        sampler_path = os.path.join(tempfile.gettempdir(), f'aa_power_{os.getpid()}.jsonl')
+        try:
+            sampler = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'power_sampler.py'), '--device', str(local), '--out', sampler_path, '--hz', '20'],
+                                       stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except OSError:
+            sampler = None
+
     for i in range(args.warmup):
         if i == args.warmup - 1 and not args.no_gemm_events:
             ops.GEMM_PROF = []                      # count the GEMM launches of one step ...
@@ -352,6 +365,7 @@ def main():
     ops.GEMM_PROF = gemm_events
     ops.FLOPS['gemm'] = ops.FLOPS['attn'] = 0.0
     torch.cuda.synchronize()
+    wall0 = time.time()
     t0 = time.perf_counter()
     losses = []
     for i in range(args.steps):
@@ -360,8 +374,22 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    wall1 = time.time()
     ops.GEMM_PROF = None
     executed = dict(ops.FLOPS)
+    power = None
+    if sampler is not None:
+        try:
+            sampler.stdin.close()                       # the sidecar leaves at its next tick; SIGTERM to exactly this PID if it does not
+            sampler.wait(timeout=3)
+        except (OSError, subprocess.TimeoutExpired):
+            sampler.terminate()
+        from tools.power_sampler import summarise
+        power = summarise(sampler_path, wall0, wall1, PEAK_BF16_TFLOPS)
+        try:
+            os.remove(sampler_path)
+        except OSError:
+            pass
 
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -497,17 +525,30 @@ def main():
                                'avg_flops_per_launch': tot_fl / n,
                                'gemm_share_of_step_time': tot_ms * ops.GEMM_PROF_STRIDE / (dt * 1e3),     # sample scaled to all launches
                                'by_kind_top12': by_kind}
+            if power is not None:
+                # measured over exactly the timed region: what "power-limited" means in numbers.  peak_at_sclk = the dense bf16 peak scaled by the mean
+                # shader clock over the guide's 2400 MHz; frac_of_peak_at_sclk = the dominant kernel against THAT (how much of the clock it was
+                # given it turned into MFMA work); j_per_tflop = package energy per executed TFLOP of the whole step
+                out['roofline'].update(power)
+                if power.get('peak_at_sclk'):
+                    out['roofline']['frac_of_peak_at_sclk'] = ach / power['peak_at_sclk']
+                if power.get('power_w_mean'):
+                    out['roofline']['j_per_tflop_step'] = power['power_w_mean'] / exe_tflops
+                    out['roofline']['joules_per_step'] = power['power_w_mean'] * step_s
             if big:
                 out['roofline']['all_gemm_launches_sampled'] = {'achieved': all_ach, 'launches': all_n, 'avg_launch_ms': all_ms / all_n,
                                                                 'note': 'incl. the small CLIP-tower / projector GEMMs (see the comment in bench.py)'}
                 out['roofline']['gemm_share_of_step_time'] = all_ms * ops.GEMM_PROF_STRIDE / (dt * 1e3)
+        if power is not None and 'roofline' not in out:
+            out['power'] = power
         if per_batch:
             per_batch[f'B{B}'] = {'pairs_per_gpu_step': B, 'value': value / world, 'unit': 'pairs/s', 'ms_per_step': step_s * 1e3, 'steps': args.steps,
                                   'warmup': args.warmup, 'headline': True}
-            per_batch['note'] = (f'headline = {B} pairs/GPU/step: one optimizer step over {B} pairs is what the reference reaches with per_device_train_batch_size 1 x '
-                                 f'gradient_accumulation_steps {B} (configs/train/text_image_to_text/dpo.yaml:30,34) -- same update, and activations for {B} pairs fit '
-                                 'the 288 GB of one MI355X without recomputation, so the native step does them in one pass (longer GEMM M = fewer partial tile '
-                                 'rounds, one AdamW per 4 pairs).  B1 / B2 = the same step at the yaml default micro-batch and at 2, measured after the timed region.')
+            per_batch['note'] = (f'headline = {B} pairs/GPU/step = the largest micro-batch SURVEY.md section 8(d) allows (B in 1, 2, 4).  The reference yaml default is '
+                                 'per_device_train_batch_size 1 x gradient_accumulation_steps 1 (configs/train/text_image_to_text/dpo.yaml:30,34): a user who drops the '
+                                 'native trainer in with the STOCK yaml gets the B1 line below, not the headline; the headline needs per_device_train_batch_size '
+                                 f'{B} in the yaml (activations for {B} pairs fit the 288 GB of one MI355X without recomputation; longer GEMM M = fewer partial tile '
+                                 f'rounds, one AdamW per {B} pairs).  B1 / B2 = the same step at the yaml default micro-batch and at 2, measured after the timed region.')
             out['per_batch'] = per_batch
         if ops.GLU_BWD_PROBE_LOG:
             out['glu_bwd_plan'] = [{'M': m, 'F': f, 'K': k, 'fused_ms': round(a, 4), 'unfused_ms': round(b, 4), 'chosen': 'fused' if a <= b else 'unfused'}

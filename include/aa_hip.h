@@ -338,29 +338,6 @@ int aa_gemm_skinny_swz_norm_glu_bf16(const void* x, const void* Wswz, void* act,
 int aa_gemm_skinny_swz_norm_rope_cache_bf16(const void* x, const void* Wswz, void* q_out, int M, int H, int Hkv, int K, long ldx, long ldq,
                                             const void* bias, const int* pos, const void* cos_t, const void* sin_t, void* cache, long ldc, int Tmax,
                                             const int64_t* slot, float eps, void* stream);
-/* One decoder layer of a decode position in ONE launch (csrc/decode_layer.hip; hf LlamaDecoderLayer, hf:models/llama/modeling_llama.py:284-325, at one
- * new token per sequence): the five per-layer launches above (norm + q/k/v + rotary + cache write, aa_attn_decode, o-projection + residual, norm +
- * gate/up + SwiGLU, down-projection + residual) as phases of one persistent kernel with device-side grid barriers between them -- every launch of a
- * decode position costs >= ~4.8 us whatever its size, and three of the five stream 25-34 MB.  STATUS: cross-compiled, NOT yet run on hardware; off by
- * default (AA_DECODE_PERSISTENT=1).  head_dim 128, SwiGLU MLP, M <= 16.  Wqkv / Wgu: aa_swizzle_weights_scaled_bf16 copies (mode 2 / 1) with the two
- * RMSNorm weights, Wo / Wdown: aa_swizzle_weights_bf16 copies.  x_mid [M, h], q / attn [M, H * 128], act [M, F]: caller-owned workspaces.
- * bar: 2 x uint32, zeroed once by the caller; status: int32, set to 1 if a barrier timed out (results are then garbage -- the caller falls back to
- * the per-step launches; the wait is bounded so that a workgroup that never became resident cannot hang the device).  grid: aa_decode_layer_grid()
- * (one workgroup per compute unit; 0 = the device cannot hold them all at once). */
-int aa_decode_layer_grid(int* grid);
-/* All L layers of a decode position in ONE launch: aa_decode_layers_pack writes layer `layer`'s arguments (those of aa_decode_layer_bf16; layer l's
- * x_out = layer l + 1's x_in) into a device array of L x *bytes (aa_decode_layers_block_bytes) bytes, once per rollout (the pointers must stay valid and the
- * counters be updated in place); aa_decode_layers_bf16 then runs a position.  Same status as aa_decode_layer_bf16: not yet run on hardware. */
-int aa_decode_layers_block_bytes(int* bytes);
-int aa_decode_layers_pack(void* blocks, int layer, const void* x_in, void* x_mid, void* x_out, void* q, void* attn, void* act, const void* Wqkv, const void* Wo,
-                          const void* Wgu, const void* Wdown, const void* bqkv, int M, int h, int H, int Hkv, int F, float eps, float scale, const int* pos,
-                          const void* cos_t, const void* sin_t, void* cache, long ldc, int Tmax, const int64_t* slot, const int* start, const int* len, void* bar,
-                          int* status, void* stream);
-int aa_decode_layers_bf16(const void* blocks, int L, int grid, void* stream);
-int aa_decode_layer_bf16(const void* x_in, void* x_mid, void* x_out, void* q, void* attn, void* act, const void* Wqkv, const void* Wo, const void* Wgu,
-                         const void* Wdown, const void* bqkv, int M, int h, int H, int Hkv, int F, float eps, float scale, const int* pos, const void* cos_t,
-                         const void* sin_t, void* cache, long ldc, int Tmax, const int64_t* slot, const int* start, const int* len, void* bar, int* status,
-                         int grid, void* stream);
 /* new token of every sequence: rotate the q heads of the fused [q|k|v] row in place (aa_rope_inplace rounding), rotate the k heads
  * into cache[(n*Tmax + slot[n]), 0:Hkv*hd] and copy the v heads to [.., Hkv*hd:2*Hkv*hd] (HF DynamicCache.update) */
 int aa_decode_rope_cache(void* qkv, long ld, int N, int H, int Hkv, int hd, const int* pos, const void* cos_t, const void* sin_t,

@@ -1051,6 +1051,60 @@ def gen_llava7b_width():
     print('llava7b_width_dpo.npz', len(out), 'arrays; total grad norm', float(np.sqrt(sum(g * g for g in gnorm if g >= 0))), f'({time.time() - t0:.0f}s)')
 
 
+def gen_llava7b_width_bf16ref():
+    """the bf16 envelope at width, DERIVED instead of asserted.  The same fixture as gen_llava7b_width through the same
+    unmodified reference trainer, but in the precision the reference trains in (models loaded in bf16, pretrained_model.py:172; pixel values cast by the
+    collator): loss, both log-prob tensors, gradient norms and leading gradient blocks of the REFERENCE'S OWN bf16 run.  Next to the fp32 fixture it
+    gives reference-bf16-vs-reference-fp32 per quantity, which is what the native bf16 path's deviation from fp32 is held against
+    (tests/test_secondary_geometry_gpu.py: native <= 1.5 x reference, per quantity)."""
+    import time
+    from align_anything.trainers.text_image_to_text.dpo import DPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+    t0 = time.time()
+    from transformers import LlavaForConditionalGeneration
+    cfg, sd, ref_sd, batch = llava7b_width()
+    policy, refm = LlavaForConditionalGeneration(cfg).eval(), LlavaForConditionalGeneration(cfg).eval()
+    assert policy.load_state_dict(sd, strict=True) and refm.load_state_dict(ref_sd, strict=True)
+    del sd, ref_sd
+    policy, refm = policy.to(torch.bfloat16), refm.to(torch.bfloat16)          # lossless: the fixture's weights are bf16-representable
+    batch['pixel_values'] = batch['pixel_values'].to(torch.bfloat16)
+    print(f'bf16 models built ({time.time() - t0:.0f}s)', flush=True)
+    tr = DPOTrainer.__new__(DPOTrainer)
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+    tr.tokenizer = SimpleNamespace(pad_token_id=32001)
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    tr.model = SimpleNamespace(module=policy)
+    tr.reference_model = SimpleNamespace(module=refm)
+    for n, p in policy.named_parameters():
+        p.requires_grad_('vision_tower' not in n)
+    policy.zero_grad()
+    seq_lp = tr.compute_log_probs(policy, batch).detach()
+    ref_lp = tr.compute_log_probs(refm, batch).detach()
+    ld = tr.loss(batch)
+    ld['loss'].backward()
+    z = np.load(os.path.join(GOLD, 'llava7b_width_dpo.npz'))
+    out = {'seq_log_probs': seq_lp.float().numpy(), 'ref_seq_log_probs': ref_lp.float().numpy(), 'torch_version': np.array(torch.__version__)}
+    for k, v in ld.items():
+        out['loss_' + k] = v.detach().float().numpy()
+    names, gnorm = [], []
+    for n, p in policy.named_parameters():
+        names.append(n)
+        if p.grad is None:
+            gnorm.append(-1.0)
+            continue
+        gnorm.append(float(p.grad.double().norm()))
+        out['gblk.' + n] = p.grad.float().reshape(p.grad.shape[0], -1)[:32, :32].contiguous().numpy()
+    assert names == [str(n) for n in z['names']]
+    out.update(names=np.array(names), grad_norm=np.array(gnorm))
+    np.savez_compressed(os.path.join(GOLD, 'llava7b_width_dpo_bf16ref.npz'), **out)
+    # the envelope, for the log: reference bf16 against reference fp32
+    w_lp, w_ref = torch.from_numpy(z['seq_log_probs']), torch.from_numpy(z['ref_seq_log_probs'])
+    e_n = max(abs(g - float(g0)) / float(g0) for n, g, g0 in zip(names, gnorm, z['grad_norm']) if g0 > 0 and 'norm' not in n and not n.endswith('bias'))
+    print(f'reference bf16 vs reference fp32: loss {abs(float(ld["loss"]) - float(z["loss_loss"])):.3e}, per-token log-probs policy {float((seq_lp.float() - w_lp).abs().max()):.3e} '
+          f'reference model {float((ref_lp.float() - w_ref).abs().max()):.3e}, summed {float((seq_lp.float().sum(1) - w_lp.sum(1)).abs().max()):.3e}, '
+          f'worst matrix gradient-norm rel {e_n:.3e} ({time.time() - t0:.0f}s)')
+
+
 def _opt125m_reference_trainer(nthreads):
     """The reference's unmodified DPOTrainer (trainers/text_to_text/dpo.py) on config 1 with the DeepSpeed engine replaced by
     torch.optim.AdamW over the reference's own parameter groups + clip_grad_norm_(1.0) + HF cosine schedule (see gen_opt125m_curve).

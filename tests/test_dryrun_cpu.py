@@ -878,70 +878,6 @@ def test_kto_trainer_builds_its_unmatched_kl_batches_from_cfgs(launches, tmp_pat
     assert len(hist) == 4 and launches.count('aa_window_kl') == 2 and 'aa_pref_loss_fwd_bwd' in launches
 
 
-def test_persistent_layer_kernel_plumbing_and_fallback(launches, monkeypatch):
-    """AA_DECODE_PERSISTENT=1 (csrc/decode_layer.hip, opt-in until it has run on hardware): one `aa_decode_layer_bf16` per layer and position in
-    place of the five per-step launches; a status word set by a timed-out barrier sends the position back through the per-step launches and
-    keeps the rollout there; a device that cannot hold the grid never uses the kernel."""
-    from align_anything_amd import configs, ops
-    from align_anything_amd.generation import generate
-    from align_anything_amd.modeling import build_model
-    text = configs.llama_cfg(256, 512, 2, 2, 1, 320, rms_eps=1e-6, head_dim=128, max_position_embeddings=64, attention_bias=True)
-    ids = torch.randint(3, 320, (2, 6))
-    mask = torch.ones_like(ids)
-    grid = {'value': 256}
-
-    def call(name, *a):
-        launches.append(name)
-        if name == 'aa_decode_layer_grid':
-            a[0]._obj.value = grid['value']
-        if name == 'aa_decode_layers_block_bytes':
-            a[0]._obj.value = 208
-
-    monkeypatch.setattr(ops, 'call', call)
-    monkeypatch.setenv('AA_DECODE_PERSISTENT', '1')
-    m = build_model(text, 'cpu', trainable=False)
-    generate(m, ids, mask, max_new_tokens=4, do_sample=False, pad_token_id=0)
-    assert launches.count('aa_decode_layer_bf16') == 2 * 3 and 'aa_attn_decode' not in launches        # 3 decode passes x 2 layers, nothing per step
-    st = m.stack._pstate
-    assert st.checked and st.grid == 256 and st.x_mid.shape == (2, 256) and st.act.shape == (2, 512)
-    # a barrier timed out on the first position: redo it with the per-step launches, and stay there
-    m2 = build_model(text, 'cpu', trainable=False)
-    del launches[:]
-    real_state = ops.DecodeLayerState
-
-    class Failing(real_state):
-        def failed(self):
-            self.checked = True
-            return True
-
-    monkeypatch.setattr(ops, 'DecodeLayerState', Failing)
-    generate(m2, ids, mask, max_new_tokens=4, do_sample=False, pad_token_id=0)
-    assert launches.count('aa_decode_layer_bf16') == 2 and launches.count('aa_attn_decode') == 2 * 3 and m2.stack._persistent_bad
-    # no room for one workgroup per compute unit: never launched
-    monkeypatch.setattr(ops, 'DecodeLayerState', real_state)
-    grid['value'] = 0
-    m3 = build_model(text, 'cpu', trainable=False)
-    del launches[:]
-    generate(m3, ids, mask, max_new_tokens=3, do_sample=False, pad_token_id=0)
-    assert 'aa_decode_layer_bf16' not in launches and launches.count('aa_attn_decode') == 2 * 2
-    # mode 2: all layers of a position in one launch; the argument blocks are packed once per rollout (2 layers) and again for the next rollout
-    grid['value'] = 256
-    monkeypatch.setenv('AA_DECODE_PERSISTENT', '2')
-    m5 = build_model(text, 'cpu', trainable=False)
-    del launches[:]
-    generate(m5, ids, mask, max_new_tokens=4, do_sample=False, pad_token_id=0)
-    assert launches.count('aa_decode_layers_pack') == 2 and launches.count('aa_decode_layers_bf16') == 3 and 'aa_decode_layer_bf16' not in launches
-    assert m5.stack._pstate.blocks.numel() == 2 * 208
-    generate(m5, ids, mask, max_new_tokens=3, do_sample=False, pad_token_id=0)
-    assert launches.count('aa_decode_layers_pack') == 4 and launches.count('aa_decode_layers_bf16') == 5
-    # default: off
-    monkeypatch.delenv('AA_DECODE_PERSISTENT')
-    m4 = build_model(text, 'cpu', trainable=False)
-    del launches[:]
-    generate(m4, ids, mask, max_new_tokens=3, do_sample=False, pad_token_id=0)
-    assert 'aa_decode_layer_bf16' not in launches and 'aa_decode_layer_grid' not in launches
-
-
 def test_first_batch_checks_of_the_dpo_trainer(launches, monkeypatch):
     """DPOTrainer._check_first_batch (once, after the first forward): hf's "Image features and image tokens do not match" check is consulted, and a
     batch whose chosen / rejected rows carry DIFFERENT images stops a trainer that runs the tower once per pair (share_vision_tower=True)."""
