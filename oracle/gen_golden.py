@@ -1105,6 +1105,107 @@ def gen_llava7b_width_bf16ref():
           f'worst matrix gradient-norm rel {e_n:.3e} ({time.time() - t0:.0f}s)')
 
 
+def gen_dropin_e2e(threads=8, alt_threads=3):
+    """the fixture of the end-to-end drop-in test (tests/test_dropin_gpu.py).  The reference's OWN text-to-text pipeline on its OWN asset
+    file: PreferenceDataset + ChatTemplate('PKUSafeRLHF') + PreferenceCollator (datasets/text_to_text/preference.py:52-201) over
+    assets/text_to_text/preference/train.json with a word-level tokenizer (the 396 most frequent words of the asset; left padding, dpo.py:94),
+    DataLoader + DistributedSampler(shuffle=True) as base/supervised_trainer.py:107 builds it, and 8 optimizer steps of the unmodified
+    DPOTrainer.train_step (text_to_text/dpo.py:205-237) in fp32 on a 2-layer OPT, policy and reference loaded from the same checkpoint (dpo.py:89-105):
+    AdamW over the reference's parameter groups, weight decay 0.05, betas (0.9, 0.95), clip 1.0, HF cosine schedule -- the stand-in for the DeepSpeed engine
+    every oracle run of this repo uses.  Stored: the checkpoint's weights, every sample PRE-TOKENISED (ids only: the asset's text is not committed), the
+    eight batches as the reference's loader produced them, the per-step metrics at `threads` and at `alt_threads` CPU threads (the reference's own
+    reproducibility floor) and the final weights."""
+    from collections import Counter
+    import json
+    import re
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from transformers import OPTForCausalLM, get_scheduler
+    from align_anything.configs.template import ChatTemplate
+    from align_anything.datasets.text_to_text import PreferenceDataset
+    from align_anything.trainers.text_to_text.dpo import DPOTrainer
+    import align_anything.trainers.text_to_text.dpo as dpo_mod
+    from align_anything.utils.tools import dict_to_namedtuple, get_optimizer_grouped_parameters
+    from tests.util import DROPIN_SPECIALS, dropin_hf_config, dropin_tokenizer
+    dpo_mod.get_all_reduce_mean = lambda x: x
+    asset = '/root/reference/assets/text_to_text/preference/train.json'
+    raw = json.load(open(asset))
+    cnt = Counter(w for r in raw for k in ('prompt', 'response_0', 'response_1') for w in re.findall(r"\w+|[^\w\s]", r[k]))
+    words = [w for w, _ in cnt.most_common(396)]
+    tok = dropin_tokenizer(words)
+    V = len(DROPIN_SPECIALS) + len(words)
+    ds = PreferenceDataset(path=asset, template=ChatTemplate(tok, 'PKUSafeRLHF'), tokenizer=tok, processor=None)
+    enc = lambda t: np.array(tok(t, add_special_tokens=False)['input_ids'], dtype=np.int32)
+    items = [ds[i] for i in range(len(ds))]
+    b_ids, w_ids = [enc(it['better_conversation']) for it in items], [enc(it['worse_conversation']) for it in items]
+    off = lambda rows: np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    B, lr, wd, beta = 4, 1e-4, 0.05, 0.1
+
+    def loader():
+        return DataLoader(ds, collate_fn=ds.get_collator(), sampler=DistributedSampler(ds, num_replicas=1, rank=0, shuffle=True), batch_size=B)
+
+    def run(nthreads):
+        torch.set_num_threads(nthreads)
+        torch.manual_seed(0)
+        policy = OPTForCausalLM(dropin_hf_config(V)).eval()
+        with torch.no_grad():
+            for p in policy.parameters():
+                p.copy_(p.to(torch.bfloat16).float())
+        refm = OPTForCausalLM(dropin_hf_config(V)).eval()
+        refm.load_state_dict(policy.state_dict())
+        w0 = {n: t.clone() for n, t in policy.state_dict().items()}
+        dl = loader()
+        steps = len(dl)
+        opt = torch.optim.AdamW(get_optimizer_grouped_parameters(policy, wd), lr=lr, betas=(0.9, 0.95), eps=1e-8)
+        sched = get_scheduler('cosine', opt, num_warmup_steps=int(0.03 * steps), num_training_steps=steps)
+
+        class Engine:
+            def __init__(self, m): self.module, self.optimizer, self.last_grad_norm = m, opt, None
+            def backward(self, loss): loss.backward()
+            def step(self):
+                self.last_grad_norm = float(torch.nn.utils.clip_grad_norm_(self.module.parameters(), 1.0))
+                opt.step(); sched.step(); opt.zero_grad(set_to_none=True)
+
+        tr = DPOTrainer.__new__(DPOTrainer)
+        tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': beta}})
+        tr.tokenizer = tok
+        tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+        eng = Engine(policy)
+        tr.model, tr.reference_model = eng, SimpleNamespace(module=refm)
+        rows, batches = [], []
+        for b in dl:
+            info = tr.train_step(b)
+            rows.append([info[k] for k in KEYS] + [eng.last_grad_norm])
+            batches.append(b)
+        return w0, policy.state_dict(), np.array(rows, dtype=np.float64), batches
+
+    KEYS = ['train/loss', 'train/reward', 'train/better_sample_reward', 'train/worse_sample_reward', 'train/reward_accuracy', 'train/reward_margin', 'train/lr']
+    w0, w1, rows, batches = run(threads)
+    _, _, rows_alt, _ = run(alt_threads)
+    torch.set_num_threads(threads)
+    out = {'vocab_size': np.array(V), 'batch_pairs': np.array(B), 'learning_rate': np.array(lr), 'weight_decay': np.array(wd), 'scale_coeff': np.array(beta),
+           'b_ids': np.concatenate(b_ids), 'b_off': off(b_ids), 'w_ids': np.concatenate(w_ids), 'w_off': off(w_ids),
+           'b_resp_len': np.array([it['better_response_lens'] for it in items]), 'w_resp_len': np.array([it['worse_response_lens'] for it in items]),
+           'metrics': rows, 'metrics_alt_threads': rows_alt, 'metric_keys': np.array(KEYS + ['grad_norm']), 'steps': np.array(len(batches))}
+    for i, b in enumerate(batches):
+        out[f'batch{i}.input_ids'], out[f'batch{i}.attention_mask'] = b['input_ids'].numpy().astype(np.int32), b['attention_mask'].numpy().astype(np.int8)
+        out[f'batch{i}.response_lens'] = np.array(b['meta_info']['response_lens'])
+    for n, t in w0.items():
+        out['w.' + n] = bf16_bits(t)
+    # the final weights: three tensors in full, every tensor's sum and norm
+    for n in ('model.decoder.layers.0.self_attn.q_proj.weight', 'model.decoder.layers.1.fc2.weight', 'model.decoder.final_layer_norm.weight'):
+        out['final.' + n] = w1[n].numpy()
+    out['final_names'] = np.array(list(w1))
+    out['final_sum'] = np.array([float(t.double().sum()) for t in w1.values()])
+    out['final_norm'] = np.array([float(t.double().norm()) for t in w1.values()])
+    out['update_norm'] = np.array([float((w1[n].double() - w0[n].double()).norm()) for n in w1])
+    np.savez_compressed(os.path.join(GOLD, 'dropin_e2e.npz'), **out)
+    print('dropin_e2e.npz:', len(items), 'pairs,', len(batches), 'steps of', B, 'pairs; longest row', max(len(r) for r in b_ids + w_ids), 'tokens; unk share',
+          float(np.mean(np.concatenate(b_ids + w_ids) == 2)))
+    print('loss', rows[:, 0].round(6).tolist())
+    print('max |loss(8 threads) - loss(3 threads)|', float(np.abs(rows[:, 0] - rows_alt[:, 0]).max()), ' grad norms', rows[:, -1].round(4).tolist())
+
+
 def _opt125m_reference_trainer(nthreads):
     """The reference's unmodified DPOTrainer (trainers/text_to_text/dpo.py) on config 1 with the DeepSpeed engine replaced by
     torch.optim.AdamW over the reference's own parameter groups + clip_grad_norm_(1.0) + HF cosine schedule (see gen_opt125m_curve).

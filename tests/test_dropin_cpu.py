@@ -1,0 +1,94 @@
+"""CPU side of the end-to-end drop-in test (tests/test_dropin_gpu.py, fixture tests/golden/dropin_e2e.npz).
+
+1. The stand-in plugin classes of tests/util.py (used on the GPU box, where the reference package does not exist) produce, through the same
+   DataLoader + DistributedSampler(shuffle=True) the native `init_datasets` builds, exactly the batches the reference's own loader produced when the
+   fixture was generated -- runs anywhere.
+2. In the build container, where /root/reference is importable: the reference's REAL PreferenceDataset + ChatTemplate('PKUSafeRLHF') + PreferenceCollator
+   on its own asset file still produce those batches (the fixture is not stale), i.e. stand-in == reference, batch for batch.
+3. The whole constructor -> train() -> save() -> resume flow of the GPU test with the kernel launches recorded instead of executed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_dryrun_cpu import launches  # noqa: F401  (the kernel-launch recorder fixture)
+from tests.util import GOLD, DROPIN_SPECIALS, DropinPreferenceDataset, dropin_checkpoint, dropin_tokenizer, install_dropin_plugins, load_golden
+
+
+def _loader(ds, B):
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    return DataLoader(ds, collate_fn=ds.get_collator(), sampler=DistributedSampler(ds, num_replicas=1, rank=0, shuffle=True), batch_size=B)
+
+
+def _same(b, z, i):
+    return (np.array_equal(b['input_ids'].numpy(), z[f'batch{i}.input_ids']) and np.array_equal(b['attention_mask'].numpy(), z[f'batch{i}.attention_mask'])
+            and list(b['meta_info']['response_lens']) == z[f'batch{i}.response_lens'].tolist())
+
+
+def test_stand_in_plugin_reproduces_the_reference_batches():
+    z = load_golden('dropin_e2e.npz')
+    tok = dropin_tokenizer([f'w{i}' for i in range(int(z['vocab_size']) - len(DROPIN_SPECIALS))])
+    ds = DropinPreferenceDataset(os.path.join(GOLD, 'dropin_e2e.npz'), template=None, tokenizer=tok)
+    assert len(ds) == 32 and tok.pad_token_id == 3 and tok.padding_side == 'left'
+    batches = list(_loader(ds, int(z['batch_pairs'])))
+    assert len(batches) == int(z['steps'])
+    for i, b in enumerate(batches):
+        assert _same(b, z, i), i
+        # the response windows the step will gather are inside the rows: the last R tokens of every row are the response + the closing </s>
+        for r, L in enumerate(b['meta_info']['response_lens']):
+            assert 0 < L <= int(b['attention_mask'][r].sum())
+
+
+def test_reference_plugins_still_produce_the_fixture():
+    asset = '/root/reference/assets/text_to_text/preference/train.json'
+    if not os.path.exists(asset):
+        pytest.skip('the reference package is only present in the build container')
+    import json
+    import re
+    from collections import Counter
+    from oracle import _shim
+    _shim.install()
+    from align_anything.configs.template import ChatTemplate
+    from align_anything.datasets.text_to_text import PreferenceDataset
+    z = load_golden('dropin_e2e.npz')
+    raw = json.load(open(asset))
+    cnt = Counter(w for r in raw for k in ('prompt', 'response_0', 'response_1') for w in re.findall(r"\w+|[^\w\s]", r[k]))
+    tok = dropin_tokenizer([w for w, _ in cnt.most_common(int(z['vocab_size']) - len(DROPIN_SPECIALS))])
+    ds = PreferenceDataset(path=asset, template=ChatTemplate(tok, 'PKUSafeRLHF'), tokenizer=tok, processor=None)
+    batches = list(_loader(ds, int(z['batch_pairs'])))
+    assert len(batches) == int(z['steps'])
+    for i, b in enumerate(batches):
+        b = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+        assert _same(b, z, i), i
+
+
+def test_drop_in_flow_with_recorded_launches(launches, monkeypatch, tmp_path):
+    """The GPU test's control flow on CPU: nothing computes (ops.call is a recorder), but the checkpoint directory is loaded, the plugin surface builds the
+    loader, train() runs the epoch on the reference's schedule, slices are written in the HF layout and a slice resumes."""
+    from align_anything_amd import ops
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    from tests.test_dropin_gpu import _cfgs
+    seen = launches
+    z = load_golden('dropin_e2e.npz')
+    install_dropin_plugins(monkeypatch)
+    ckpt, out = str(tmp_path / 'ckpt'), str(tmp_path / 'run')
+    dropin_checkpoint(ckpt, z)
+    tr = DPOTrainer(_cfgs(z, ckpt, out, 'fp32'), {'gradient_clipping': 1.0}, device='cpu')
+    assert len(tr.train_dataloader) == 8 and tr.model.total_steps == 8 and tr.model.weight_decay == 0.05
+    for i, b in enumerate(tr.train_dataloader):
+        assert _same({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}, z, i)
+    hist = tr.train()
+    assert len(hist) == 8 and seen.count('aa_dpo_loss_fwd_bwd_f32') + seen.count('aa_dpo_loss_fwd_bwd') == 8
+    want_lr = z['metrics'][:, 6]
+    assert np.abs(np.array([h['train/lr'] for h in hist]) - want_lr).max() < 1e-15          # the schedule needs no kernel: equal to the reference's on CPU already
+    tr.save()
+    assert sorted(os.listdir(out)) == ['slice_4', 'slice_8', 'slice_end']
+    assert {'config.json', 'pytorch_model.bin', 'tokenizer.json', 'native_engine_latest.pt'} <= set(os.listdir(os.path.join(out, 'slice_4')))
+    import transformers as tf
+    tf.OPTForCausalLM.from_pretrained(os.path.join(out, 'slice_end'))                        # the layout loads
+    again = DPOTrainer(_cfgs(z, os.path.join(out, 'slice_4'), str(tmp_path / 'run2'), 'fp32', load_checkpoint=True), {'gradient_clipping': 1.0}, device='cpu')
+    assert again.global_step == 4 and again.model.global_steps == 4
+    hist2 = again.train()
+    assert len(hist2) == 4 and abs(hist2[0]['train/lr'] - want_lr[4]) < 1e-15

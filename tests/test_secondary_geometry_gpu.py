@@ -554,6 +554,32 @@ def test_llava7b_width_pair_vs_the_reference_trainer():
             assert e_loss < 2e-4 and e_lp < 2e-4 and e_ref < 2e-4 and worst_norm < 1e-3 and worst_blk < 2e-3, rep[-1]
         else:
             assert e_loss < 1e-2 and e_sum < 0.3 and worst_norm < 2e-2 and worst_blk < 0.15, rep[-1]     # ~3 x the first hardware run: 3.3e-3 / 0.093 / 5.7e-3 / 4.9e-2
+            # the envelope DERIVED, not asserted.  tests/golden/llava7b_width_dpo_bf16ref.npz is the reference trainer's OWN
+            # bf16 run of this fixture (oracle/gen_golden.py::gen_llava7b_width_bf16ref: models in bf16 as pretrained_model.py:172 loads them, CPU);
+            # per quantity, native-bf16-vs-fp32 must stay within 1.5 x reference-bf16-vs-fp32
+            zb = load_golden('llava7b_width_dpo_bf16ref.npz')
+            r_lp, r_ref = torch.from_numpy(zb['seq_log_probs']), torch.from_numpy(zb['ref_seq_log_probs'])
+            env = {'loss': (e_loss, abs(float(zb['loss_loss']) - float(z['loss_loss']))),
+                   'margin': (e_margin, float(np.abs(zb['loss_reward_margin'].reshape(-1) - z['loss_reward_margin'].reshape(-1)).max())),
+                   'per-token log-probs (policy)': (e_lp, float((r_lp - want_lp).abs().max())),
+                   'per-token log-probs (reference model)': (e_ref, float((r_ref - want_ref).abs().max())),
+                   'summed log-probs': (e_sum, float((r_lp.sum(1) - want_lp.sum(1)).abs().max()))}
+            rn, rb = 0.0, 0.0
+            for n, gn, gb_ in zip(names, z['grad_norm'], zb['grad_norm']):
+                if gn < 0 or 'vision_tower' in n or len(tr.policy.store.grad_view(n).shape) < 2:
+                    continue
+                rn = max(rn, abs(float(gb_) - float(gn)) / float(gn))
+                blk = torch.from_numpy(z['gblk.' + n])
+                if float(blk.norm()) > 1e-3 * float(gn) / max(1.0, (tr.policy.store.grad_view(n).numel() / blk.numel()) ** 0.5):
+                    rb = max(rb, rel_err(torch.from_numpy(zb['gblk.' + n]), blk))
+            env['worst matrix gradient norm (rel)'] = (worst_norm, rn)
+            env['worst leading gradient block (rel_err)'] = (worst_blk, rb)
+            rep.append('bf16 envelope at width, native vs the reference\'s own bf16 run (both against the reference\'s fp32 run of the same fixture):')
+            for k, (mine, theirs) in env.items():
+                rep.append(f'  {k}: native {mine:.3e}   reference bf16 {theirs:.3e}   ratio {mine / max(theirs, 1e-30):.2f}')
+            dump('parity_llava7b_width_vs_reference.txt', '\n'.join(rep) + '\n')
+            for k, (mine, theirs) in env.items():
+                assert mine <= 1.5 * theirs, (k, mine, theirs)
         assert n_g >= 30
         del tr
         _free()

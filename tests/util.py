@@ -101,3 +101,94 @@ def ti2t_parquet_dataset(path: str, n: int = 12, seed: int = 0) -> str:
     os.makedirs(path, exist_ok=True)
     ds.to_parquet(os.path.join(path, 'train.parquet'))
     return path
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The end-to-end drop-in fixture (tests/golden/dropin_e2e.npz, oracle/gen_golden.py::gen_dropin_e2e)
+DROPIN_SPECIALS = ['<s>', '</s>', '<unk>', '<pad>']
+DROPIN_TEMPLATE = "{% for m in messages %}{{ m['role'] }} : {{ m['content'] }} </s> {% endfor %}"
+
+
+def dropin_tokenizer(words):
+    """Word-level fast tokenizer: the four specials + `words` (ids 4 ..), whitespace pre-tokenisation, left padding as the reference's DPO trainer
+    loads it (text_to_text/dpo.py:94).  The fixture generator passes the most frequent words of the reference's asset file; the GPU test, which
+    only needs the ids the generator stored, passes anonymous names of the same count."""
+    import transformers as tf
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    vocab = {w: i for i, w in enumerate(DROPIN_SPECIALS + list(words))}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token='<unk>'))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    fast = tf.PreTrainedTokenizerFast(tokenizer_object=tk, bos_token='<s>', eos_token='</s>', unk_token='<unk>', pad_token='<pad>', padding_side='left',
+                                      model_max_length=512)
+    fast.chat_template = DROPIN_TEMPLATE
+    return fast
+
+
+def dropin_hf_config(vocab_size):
+    import transformers as tf
+    return tf.OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=int(vocab_size), max_position_embeddings=600,
+                        word_embed_proj_dim=128, dropout=0.0, attention_dropout=0.0, pad_token_id=3, bos_token_id=0, eos_token_id=1)
+
+
+def dropin_checkpoint(path: str, z) -> None:
+    """The HF checkpoint directory the drop-in test hands to `model_cfgs.model_name_or_path`: config.json + model.safetensors (the fixture's weights,
+    bf16-representable fp32) + the tokenizer files (anonymous vocabulary of the fixture's size)."""
+    import transformers as tf
+    cfg = dropin_hf_config(int(z['vocab_size']))
+    hf = tf.OPTForCausalLM(cfg)
+    sd = state_dict_from_golden(z, 'w.', torch.float32)
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not unexpected and set(missing) <= {'lm_head.weight'}, (missing, unexpected)
+    hf.save_pretrained(path)
+    dropin_tokenizer([f'w{i}' for i in range(int(z['vocab_size']) - len(DROPIN_SPECIALS))]).save_pretrained(path)
+
+
+class DropinPreferenceDataset:
+    """Stand-in for `align_anything.datasets.text_to_text.PreferenceDataset` where the reference package is absent (the GPU box): same constructor
+    signature, `get_collator()`, `__len__` / `__getitem__` -- but the samples are the PRE-TOKENISED output of the reference's own dataset + template +
+    tokenizer on its own asset file (the fixture's `b_ids` / `w_ids`), so the collator pads ids where the reference's tokenises text.  tests/
+    test_dropin_cpu.py checks, in the build container, that its batches equal the real plugin's batch for batch."""
+
+    def __init__(self, path, template, tokenizer, processor=None, name=None, size=None, split=None, data_files=None, optional_args=[]):
+        z = np.load(path)
+        self.tokenizer = tokenizer
+        cut = lambda flat, off: [flat[off[i]:off[i + 1]].astype(np.int64) for i in range(len(off) - 1)]
+        self.b, self.w = cut(z['b_ids'], z['b_off']), cut(z['w_ids'], z['w_off'])
+        self.bl, self.wl = z['b_resp_len'], z['w_resp_len']
+
+    def __len__(self):
+        return len(self.b)
+
+    def __getitem__(self, i):
+        return {'better_ids': self.b[i], 'worse_ids': self.w[i], 'better_response_lens': int(self.bl[i]), 'worse_response_lens': int(self.wl[i])}
+
+    def get_collator(self):
+        pad, left = int(self.tokenizer.pad_token_id), self.tokenizer.padding_side == 'left'
+
+        def collate(samples):
+            rows = [s['better_ids'] for s in samples] + [s['worse_ids'] for s in samples]        # chosen rows, then rejected rows (preference.py:186-188)
+            L = max(len(r) for r in rows)
+            ids = torch.full((len(rows), L), pad, dtype=torch.long)
+            am = torch.zeros((len(rows), L), dtype=torch.long)
+            for i, r in enumerate(rows):
+                sl = slice(L - len(r), L) if left else slice(0, len(r))
+                ids[i, sl] = torch.from_numpy(r)
+                am[i, sl] = 1
+            return {'input_ids': ids, 'attention_mask': am,
+                    'meta_info': {'response_lens': [s['better_response_lens'] for s in samples] + [s['worse_response_lens'] for s in samples]}}
+        return collate
+
+
+def install_dropin_plugins(monkeypatch) -> None:
+    """Register the stand-in plugin package under the names `common.get_dataloaders` imports (align_anything.datasets.text_to_text,
+    align_anything.configs.template) for the duration of a test."""
+    import sys
+    import types
+    pk = {n: types.ModuleType(n) for n in ('align_anything', 'align_anything.datasets', 'align_anything.datasets.text_to_text', 'align_anything.configs',
+                                           'align_anything.configs.template')}
+    for m in pk.values():
+        m.__path__ = []
+    pk['align_anything.datasets.text_to_text'].PreferenceDataset = DropinPreferenceDataset
+    pk['align_anything.configs.template'].ChatTemplate = lambda formatter, name, custom=None: types.SimpleNamespace(formatter=formatter, name=name)
+    for n, m in pk.items():
+        monkeypatch.setitem(sys.modules, n, m)
