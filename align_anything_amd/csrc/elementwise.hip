@@ -39,6 +39,71 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const elem_t* __restri
     }
 }
 
+// Two block reductions behind ONE barrier pair, each in block_sum's order (wave butterfly, then the waves' sums in wave order): bit-identical to two block_sum calls.
+template <int NT>
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+    a = wave_sum(a); b = wave_sum(b);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) { red[w] = a; red[NT / 64 + w] = b; }
+    __syncthreads();
+    float ta = 0.f, tb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) { ta += red[i]; tb += red[NT / 64 + i]; }
+    a = ta; b = tb;
+}
+
+// h <= 2048 MAXV: a block walks TWO rows per iteration and keeps them in registers between the sum and the output pass -- twice the bytes in flight per
+// barrier pair and x read once (round 4's form read every row twice, the second time through L2: 5.2 TB/s in the step).  Per row the
+// arithmetic and its order are those of rmsnorm_fwd_kernel: results are bit-identical.
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_fwd2_kernel(const elem_t* __restrict__ x, const elem_t* __restrict__ w, elem_t* __restrict__ y,
+                                                           float* __restrict__ rstd_out, int rows, int h, float eps) {
+    __shared__ float red[8];
+    const int nv = h >> 3;
+    for (long row0 = 2L * blockIdx.x; row0 < rows; row0 += 2L * gridDim.x) {
+        const bool two = row0 + 1 < rows;
+        ev8 v[2][MAXV];
+        float ss[2] = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int a = 0; a < MAXV; ++a) {
+                const int i = threadIdx.x + a * 256;
+                if (i < nv && (u == 0 || two)) v[u][a] = *reinterpret_cast<const ev8*>(x + (row0 + u) * h + i * 8);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int a = 0; a < MAXV; ++a) {
+                const int i = threadIdx.x + a * 256;
+                if (i < nv && (u == 0 || two)) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float f = e2f(v[u][a][j]); ss[u] += f * f; }
+                }
+            }
+        block_sum2<256>(ss[0], ss[1], red);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const float rstd = rsqrtf(ss[u] / (float)h + eps);
+            if (threadIdx.x == 0 && rstd_out) rstd_out[row0 + u] = rstd;
+            elem_t* yr = y + (row0 + u) * h;
+#pragma unroll
+            for (int a = 0; a < MAXV; ++a) {
+                const int i = threadIdx.x + a * 256;
+                if (i < nv) {
+                    const ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
+                    ev8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = f2e(e2f(wv[j]) * ernd(e2f(v[u][a][j]) * rstd));
+                    *reinterpret_cast<ev8*>(yr + i * 8) = o;
+                }
+            }
+        }
+    }
+}
+
 // h <= 512 (per-head q / k norms of Qwen3: head_dim 128 over tokens x heads "rows").  LPR = lanes per row (the power of two >= h / 8): a wave holds 64 / LPR rows
 // at once and every group walks TWO rows per iteration, so all 64 lanes load 16 bytes and a wave keeps 2 KB in flight (round 3's one-wave-per-row form had 16
 // of 64 lanes active and one 256-byte load in flight per wave at head_dim 128: 391 us for 270 MB = latency-bound at 0.7 TB/s).  The row sum
@@ -178,7 +243,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_small_kernel(const elem_t* __
 }
 
 // dx = rstd * (dy*w - xhat * mean(dy*w*xhat)),  dw[c] += sum_rows dy*bf16(xhat)
-// dw partials are kept per thread in registers across the block's rows and flushed with fp32 atomics.
+// dw partials are kept per thread in registers across the block's rows and written as one partial row per block (reduce_rows_kernel sums them).
+// A block walks TWO rows per iteration (round 5): their x / dy / residual vectors are all requested before the first is used and the two row
+// reductions share one barrier pair -- twice the bytes in flight per block and half the barriers.  Per row, and per column of dw (row order kept), the
+// arithmetic is that of the one-row form: results are bit-identical to round 4's kernel.  Bytes per launch with the residual gradient added
+// (add_to_dx, every call of the decoder stack): read x + dy + dx, write dx = 8 h bytes per row.
 template <int MAXV>  // max 16-byte vectors per thread (h <= 256*8*MAXV)
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const elem_t* __restrict__ dy,
                                                           const elem_t* __restrict__ x,
@@ -194,47 +263,63 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const elem_t* __restri
     for (int a = 0; a < MAXV; ++a)
 #pragma unroll
         for (int j = 0; j < 8; ++j) dwacc[a][j] = 0.f;
-    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-        const float rstd = rstd_in[row];
-        const elem_t* xr = x + row * h;
-        const elem_t* gr = dy + row * h;
-        float dot = 0.f;
-        // the row's x / dy / (residual) vectors stay in registers between the reduction pass and the output pass: the second pass
-        // re-read them through L2 before (same arithmetic, same order -> same bits)
-        ev8 xk[MAXV], gk[MAXV], ok[MAXV];
-        elem_t* dxr = dx + row * h;
+    // rows of a block: blockIdx.x, + gridDim.x, + 2 gridDim.x ... (as before), taken two at a time
+    for (long row0 = blockIdx.x; row0 < rows; row0 += 2L * gridDim.x) {
+        const long row1 = row0 + gridDim.x;
+        const bool two = row1 < rows;
+        const long rws[2] = {row0, row1};
+        float rstd[2], dot[2] = {0.f, 0.f};
+        rstd[0] = rstd_in[row0];
+        rstd[1] = two ? rstd_in[row1] : 0.f;
+        ev8 xk[2][MAXV], gk[2][MAXV], ok[2][MAXV];
 #pragma unroll
-        for (int a = 0; a < MAXV; ++a) {
-            const int i = threadIdx.x + a * 256;
-            if (i < nv) {
-                xk[a] = *reinterpret_cast<const ev8*>(xr + i * 8);
-                gk[a] = *reinterpret_cast<const ev8*>(gr + i * 8);
-                if (add_to_dx) ok[a] = *reinterpret_cast<const ev8*>(dxr + i * 8);
-                const ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xh = e2f(xk[a][j]) * rstd;
-                    const float g = e2f(gk[a][j]);
-                    dot += g * e2f(wv[j]) * xh;
-                    dwacc[a][j] += g * ernd(xh);
+            for (int a = 0; a < MAXV; ++a) {
+                const int i = threadIdx.x + a * 256;
+                if (i < nv && (u == 0 || two)) {
+                    xk[u][a] = *reinterpret_cast<const ev8*>(x + rws[u] * h + i * 8);
+                    gk[u][a] = *reinterpret_cast<const ev8*>(dy + rws[u] * h + i * 8);
+                    if (add_to_dx) ok[u][a] = *reinterpret_cast<const ev8*>(dx + rws[u] * h + i * 8);
                 }
             }
-        }
-        dot = block_sum<256>(dot, red) / (float)h;
 #pragma unroll
-        for (int a = 0; a < MAXV; ++a) {
-            const int i = threadIdx.x + a * 256;
-            if (i < nv) {
-                const ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
-                ev8 o;
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xh = e2f(xk[a][j]) * rstd;
-                    float d = rstd * (e2f(gk[a][j]) * e2f(wv[j]) - xh * dot);
-                    if (add_to_dx) d += e2f(ok[a][j]);
-                    o[j] = f2e(d);
+            for (int a = 0; a < MAXV; ++a) {
+                const int i = threadIdx.x + a * 256;
+                if (i < nv && (u == 0 || two)) {
+                    const ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xh = e2f(xk[u][a][j]) * rstd[u];
+                        const float g = e2f(gk[u][a][j]);
+                        dot[u] += g * e2f(wv[j]) * xh;
+                        dwacc[a][j] += g * ernd(xh);
+                    }
                 }
-                *reinterpret_cast<ev8*>(dxr + i * 8) = o;
+            }
+        block_sum2<256>(dot[0], dot[1], red);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const float dm = dot[u] / (float)h;
+            elem_t* dxr = dx + rws[u] * h;
+#pragma unroll
+            for (int a = 0; a < MAXV; ++a) {
+                const int i = threadIdx.x + a * 256;
+                if (i < nv) {
+                    const ev8 wv = *reinterpret_cast<const ev8*>(w + i * 8);
+                    ev8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xh = e2f(xk[u][a][j]) * rstd[u];
+                        float d = rstd[u] * (e2f(gk[u][a][j]) * e2f(wv[j]) - xh * dm);
+                        if (add_to_dx) d += e2f(ok[u][a][j]);
+                        o[j] = f2e(d);
+                    }
+                    *reinterpret_cast<ev8*>(dxr + i * 8) = o;
+                }
             }
         }
     }
@@ -283,6 +368,16 @@ extern "C" int AA_FN(aa_rmsnorm_fwd)(const void* x, const void* w, void* y, floa
     } while (0)
         if (h <= 64) LAUNCH_RMSF_SMALL(8); else if (h <= 128) LAUNCH_RMSF_SMALL(16); else if (h <= 256) LAUNCH_RMSF_SMALL(32); else LAUNCH_RMSF_SMALL(64);
 #undef LAUNCH_RMSF_SMALL
+        AA_CHECK_LAUNCH("aa_rmsnorm_fwd");
+        return AA_OK;
+    }
+    if (h <= 8192) {
+        const int pairs = (rows + 1) / 2, grid2 = pairs < 4096 ? pairs : 4096;
+#define LAUNCH_RMSF2(MV)                                                                                                     \
+    hipLaunchKernelGGL(rmsnorm_fwd2_kernel<MV>, dim3(grid2), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, (const elem_t*)w, \
+                       (elem_t*)y, rstd, rows, h, eps)
+        if (h <= 2048) LAUNCH_RMSF2(1); else if (h <= 4096) LAUNCH_RMSF2(2); else LAUNCH_RMSF2(4);
+#undef LAUNCH_RMSF2
         AA_CHECK_LAUNCH("aa_rmsnorm_fwd");
         return AA_OK;
     }
@@ -368,9 +463,23 @@ extern "C" int AA_FN(aa_rmsnorm_bwd)(const void* dy, const void* x, const void* 
         AA_CHECK_LAUNCH("aa_rmsnorm_bwd");
         return AA_OK;
     }
+    // one round of co-resident blocks: the two-row kernel holds 2 x 3 row vectors per thread (168 VGPRs at h = 4096: three blocks per CU), and a grid
+    // larger than what is resident would run a part-empty second round; every block walks rows / grid rows, so a smaller grid costs nothing
 #define LAUNCH_RMSB(MV)                                                                             \
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const elem_t*)dy,     \
-                       (const elem_t*)x, (const elem_t*)w, rstd, (elem_t*)dx, part, rows, h, add_to_dx)
+    do {                                                                                            \
+        static int slots = 0;                                                                       \
+        if (slots == 0) {                                                                           \
+            int per_cu = 0, dev = 0, cus = 0;                                                       \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmsnorm_bwd_kernel<MV>, 256, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess || \
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu <= 0 || cus <= 0)                         \
+                slots = 1024;                                                                       \
+            else                                                                                    \
+                slots = per_cu * cus;                                                               \
+        }                                                                                           \
+        if (grid > slots) grid = slots;                                                             \
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const elem_t*)dy, \
+                           (const elem_t*)x, (const elem_t*)w, rstd, (elem_t*)dx, part, rows, h, add_to_dx); \
+    } while (0)
     if (h <= 2048) LAUNCH_RMSB(1);
     else if (h <= 4096) LAUNCH_RMSB(2);
     else if (h <= 8192) LAUNCH_RMSB(4);

@@ -114,3 +114,36 @@ extern "C" int aa_probe_tr16(const int* addr64, float* out256, void* stream) {
     AA_CHECK_LAUNCH("aa_probe_tr16");
     return AA_OK;
 }
+
+// ---- a one-GPU MODEL of what a resident collective costs the compute stream (tools/dp_shadow.py).
+// RCCL's kernels hold C compute units for the length of the backward pass and move the gradient buckets through HBM at link speed.  Two pieces
+// reproduce that on one device: (1) a stream whose kernels may only use a subset of the CUs (hipExtStreamCreateWithCUMask) -- the compute stream with
+// the collective's CUs taken away; (2) a traffic kernel of C long-lived workgroups that stream `bytes` from src to dst `passes` times -- the
+// collective's HBM reads / writes, at the ~50 GB/s one CU sustains, from CUs the GEMMs then cannot use.
+extern "C" int aa_stream_create_cu_mask(const unsigned int* mask, int words, void** stream_out) {
+    AA_REQUIRE(mask != nullptr && words > 0 && stream_out != nullptr, "aa_stream_create_cu_mask: mask / words / stream_out");
+    hipStream_t st;
+    hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+    if (e != hipSuccess) { aa_set_error("aa_stream_create_cu_mask: %s", hipGetErrorString(e)); return AA_ERR_LAUNCH; }
+    *stream_out = (void*)st;
+    return AA_OK;
+}
+extern "C" int aa_stream_destroy(void* stream) {
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) { aa_set_error("aa_stream_destroy: %s", hipGetErrorString(e)); return AA_ERR_LAUNCH; }
+    return AA_OK;
+}
+__global__ __launch_bounds__(256) void shadow_traffic_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n16, int passes) {
+    for (int p = 0; p < passes; ++p)
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+            f32x4 v = __builtin_nontemporal_load(src + i);
+            v[0] += (float)p;                          // passes must not collapse into one
+            __builtin_nontemporal_store(v, dst + i);
+        }
+}
+extern "C" int aa_shadow_traffic(const void* src, void* dst, long bytes, int workgroups, int passes, void* stream) {
+    AA_REQUIRE(src && dst && bytes >= 16 && (bytes & 15) == 0 && workgroups > 0 && passes > 0, "aa_shadow_traffic: 16-byte multiples, workgroups, passes > 0");
+    hipLaunchKernelGGL(shadow_traffic_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, bytes / 16, passes);
+    AA_CHECK_LAUNCH("aa_shadow_traffic");
+    return AA_OK;
+}

@@ -51,6 +51,13 @@ int aa_event_create(void** ev);
 int aa_event_record(void* ev, void* stream);
 int aa_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
 int aa_event_destroy(void* ev);
+/* A one-GPU MODEL of a resident collective beside the compute stream (tools/dp_shadow.py -> profiles/r05_dp_shadow.json; the reference overlaps DeepSpeed's
+ * gradient reduction with backward, base/supervised_trainer.py:258-264): a stream restricted to the compute units whose bit is set in `mask`
+ * (`words` x 32 bits; hipExtStreamCreateWithCUMask), and a traffic kernel of `workgroups` long-lived workgroups streaming `bytes` src -> dst `passes` times.
+ * Measurement utilities: no trainer calls them. */
+int aa_stream_create_cu_mask(const unsigned int* mask, int words, void** stream_out);
+int aa_stream_destroy(void* stream);
+int aa_shadow_traffic(const void* src, void* dst, long bytes, int workgroups, int passes, void* stream);
 int aa_probe_mfma(float* out256, int row_sel, void* stream);
 int aa_probe_tr16(const int* addr64, float* out256, void* stream);
 

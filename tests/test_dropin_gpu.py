@@ -47,74 +47,82 @@ def test_drop_in_trainer_end_to_end_vs_the_reference_run(tmp_path, monkeypatch, 
     for i, b in enumerate(tr.train_dataloader):
         assert np.array_equal(b['input_ids'].cpu().numpy(), z[f'batch{i}.input_ids']) and np.array_equal(b['attention_mask'].cpu().numpy(), z[f'batch{i}.attention_mask'])
         assert list(b['meta_info']['response_lens']) == z[f'batch{i}.response_lens'].tolist()
-    hist = tr.train()
-    assert len(hist) == steps and tr.global_step == steps
-    got = np.array([[h[k] for k in KEYS] for h in hist], dtype=np.float64)
-    want = z['metrics'][:, :7]
-    floor = float(np.abs(z['metrics'][:, 0] - z['metrics_alt_threads'][:, 0]).max())          # the reference against itself at another thread count
-    err = np.abs(got - want).max(0)
-    rep = [f'{dtype}: native DPOTrainer(cfgs, ds_cfgs) from a checkpoint directory vs the reference pipeline, {steps} steps of {int(z["batch_pairs"])} pairs '
-           f'(reference reproducibility floor on the loss, 8 vs 3 CPU threads: {floor:.1e})']
-    for i in range(steps):
-        rep.append(f'  step {i}: loss native {got[i, 0]:.6f} reference {want[i, 0]:.6f} |diff| {abs(got[i, 0] - want[i, 0]):.2e}   margin {got[i, 5]:+.5f} / {want[i, 5]:+.5f}   lr {got[i, 6]:.3e}')
-    rep.append('  max |diff| per metric: ' + ', '.join(f'{k.split("/")[1]} {e:.2e}' for k, e in zip(KEYS, err)))
-    assert np.abs(got[:, 6] - want[:, 6]).max() < 1e-12                                       # the schedule is closed-form
-    assert got[0, 0] == pytest.approx(float(np.log(2.0)), abs=2e-6 if dtype == 'fp32' else 1e-3)     # policy == reference at step 0
-    # fp32 parity mode: north_star's 1e-4 on the loss curve, free-running (no teacher forcing) over the 8 steps; bf16: the production precision's bound,
-    # stated here: 3e-2 on the loss, 0.25 on the accuracy (one pair of four may flip)
-    tol_loss, tol_margin, tol_acc = (1e-4, 1e-3, 1e-9) if dtype == 'fp32' else (3e-2, 6e-2, 0.2500001)
-    ok = err[0] < tol_loss and err[5] < tol_margin and err[4] < tol_acc
-    # ---- save() -> from_pretrained
-    d_end = tr.save()
-    assert sorted(os.listdir(out)) == ['slice_4', 'slice_8', 'slice_end'] and {'config.json', 'pytorch_model.bin', 'tokenizer.json'} <= set(os.listdir(d_end))
-    hf = tf.OPTForCausalLM.from_pretrained(d_end, torch_dtype=torch.float32).eval()
-    eng = {k: v.float().cpu() for k, v in tr.policy.state_dict().items()}
-    hf_sd = hf.state_dict()
-    for k, v in eng.items():
-        assert torch.equal(hf_sd[k].float(), v), f'{k}: the saved slice is not the engine\'s weights'
-    names, worst = [str(n) for n in z['final_names']], 0.0
-    for n, s, nr, un in zip(names, z['final_sum'], z['final_norm'], z['update_norm']):
-        if n not in eng:
-            continue
-        w = eng[n].double()
-        if 'final.' + n in z.files:
-            d = float((w - torch.from_numpy(z['final.' + n]).double()).norm())
-            worst = max(worst, d / max(float(un), 1e-30))
-            rep.append(f'  final {n}: |native - reference| / |reference update| = {d / max(float(un), 1e-30):.2e}')
-        assert abs(float(w.norm()) - float(nr)) <= (1e-5 if dtype == 'fp32' else 2e-3) * float(nr), n
-    rep.append(f'  saved slice == engine weights bit for bit ({len(eng)} tensors), loads with transformers.from_pretrained')
-    ok = ok and worst < (5e-2 if dtype == 'fp32' else 0.6)          # the 8-step UPDATE itself, relative: fp32 Adam sign noise on near-zero gradients aside
-    # the loaded HF model is the model the engine trained: the reference's DPO loss on batch 0, HF modules (fp32) vs the native trainer after training
-    from oracle import rl_math as orl
-    b0 = {'input_ids': torch.from_numpy(z['batch0.input_ids']).long(), 'attention_mask': torch.from_numpy(z['batch0.attention_mask']).long()}
-    lens = z['batch0.response_lens'].tolist()
-    hf0 = tf.OPTForCausalLM.from_pretrained(ckpt, torch_dtype=torch.float32).eval()
-    with torch.no_grad():
-        lp = orl.compute_log_probs(hf(**b0).logits, b0['input_ids'], lens, 3)
-        rlp = orl.compute_log_probs(hf0(**b0).logits, b0['input_ids'], lens, 3)
-    want_loss = float(orl.dpo_loss(lp, rlp, float(z['scale_coeff']))['loss'])
-    ld = tr.loss({'input_ids': b0['input_ids'].cuda(), 'attention_mask': b0['attention_mask'].cuda(), 'meta_info': {'response_lens': lens}})
-    tr.model._pending = None
-    e_hf = abs(float(ld['loss']) - want_loss)
-    rep.append(f'  DPO loss of batch 0 after training: native {float(ld["loss"]):.6f}, HF modules on the saved slice {want_loss:.6f} (|diff| {e_hf:.2e})')
-    ok = ok and e_hf < (2e-5 if dtype == 'fp32' else 2e-2)
-    # ---- resume: slice_4 carries the engine state (train_cfgs.save_checkpoint); a trainer built on it with load_checkpoint continues at step 5
-    s4 = os.path.join(out, 'slice_4')
-    again = DPOTrainer(_cfgs(z, s4, str(tmp_path / 'run2'), dtype, load_checkpoint=True), {'gradient_clipping': 1.0}, device='cuda:0')
-    assert again.global_step == 4 and again.model.global_steps == 4
-    ck = torch.load(os.path.join(s4, 'native_engine_latest.pt'), map_location='cpu')
-    st = again.policy.store
-    for g in st.master:                                      # the restored state IS the saved state, bit for bit
-        assert torch.equal(st.master[g].cpu(), ck['master'][g]) and torch.equal(st.m[g].cpu(), ck['m'][g]) and torch.equal(st.v[g].cpu(), ck['v'][g]), g
-    # the reference loads BOTH models from model_name_or_path (dpo.py:89-105), so a resumed run's frozen model would be slice_4 as well; to compare with the
-    # uninterrupted run the frozen model gets the original checkpoint back
-    again.reference.load_state_dict(tr.reference.state_dict())
-    hist2 = again.train()
-    assert len(hist2) == steps - 4 and again.global_step == steps
-    got2 = np.array([[h[k] for k in KEYS] for h in hist2], dtype=np.float64)
-    e_res = np.abs(got2 - got[4:]).max(0)
-    rep.append(f'  resumed from slice_4: steps 5..8 against the uninterrupted run: max |diff| loss {e_res[0]:.2e} margin {e_res[5]:.2e} lr {e_res[6]:.1e} '
-               '(fp32 atomics in the bias / embedding gradients make two runs differ in the last bits; the restored state itself is bit-identical)')
-    ok = ok and e_res[0] < (2e-6 if dtype == 'fp32' else 2e-3) and e_res[6] == 0.0
-    dump(f'parity_dropin_e2e_{dtype}.txt', '\n'.join(rep) + '\n')
-    assert ok, '\n'.join(rep)
+    rep = []
+    try:
+        hist = tr.train()
+        assert len(hist) == steps and tr.global_step == steps
+        got = np.array([[h[k] for k in KEYS] for h in hist], dtype=np.float64)
+        want = z['metrics'][:, :7]
+        floor = float(np.abs(z['metrics'][:, 0] - z['metrics_alt_threads'][:, 0]).max())          # the reference against itself at another thread count
+        err = np.abs(got - want).max(0)
+        rep += [f'{dtype}: native DPOTrainer(cfgs, ds_cfgs) from a checkpoint directory vs the reference pipeline, {steps} steps of {int(z["batch_pairs"])} pairs '
+               f'(reference reproducibility floor on the loss, 8 vs 3 CPU threads: {floor:.1e})']
+        for i in range(steps):
+            rep.append(f'  step {i}: loss native {got[i, 0]:.6f} reference {want[i, 0]:.6f} |diff| {abs(got[i, 0] - want[i, 0]):.2e}   margin {got[i, 5]:+.5f} / {want[i, 5]:+.5f}   lr {got[i, 6]:.3e}')
+        rep.append('  max |diff| per metric: ' + ', '.join(f'{k.split("/")[1]} {e:.2e}' for k, e in zip(KEYS, err)))
+        assert np.abs(got[:, 6] - want[:, 6]).max() < 1e-12                                       # the schedule is closed-form
+        assert got[0, 0] == pytest.approx(float(np.log(2.0)), abs=2e-6 if dtype == 'fp32' else 1e-3)     # policy == reference at step 0
+        # fp32 parity mode: north_star's 1e-4 on the loss curve, free-running (no teacher forcing) over the 8 steps; bf16: the production precision's bound,
+        # stated here: 3e-2 on the loss, 0.25 on the accuracy (one pair of four may flip)
+        tol_loss, tol_margin, tol_acc = (1e-4, 1e-3, 1e-9) if dtype == 'fp32' else (3e-2, 6e-2, 0.2500001)
+        ok = err[0] < tol_loss and err[5] < tol_margin and err[4] < tol_acc
+        # ---- save() -> from_pretrained
+        d_end = tr.save()
+        assert sorted(os.listdir(out)) == ['slice_4', 'slice_8', 'slice_end'] and {'config.json', 'pytorch_model.bin', 'tokenizer.json'} <= set(os.listdir(d_end))
+        hf = tf.OPTForCausalLM.from_pretrained(d_end, torch_dtype=torch.float32).eval()
+        eng = {k: v.float().cpu() for k, v in tr.policy.state_dict().items()}
+        hf_sd = hf.state_dict()
+        for k, v in eng.items():
+            assert torch.equal(hf_sd[k].float(), v), f'{k}: the saved slice is not the engine\'s weights'
+        names, worst = [str(n) for n in z['final_names']], 0.0
+        for n, s, nr, un in zip(names, z['final_sum'], z['final_norm'], z['update_norm']):
+            if n not in eng:
+                continue
+            w = eng[n].double()
+            if 'final.' + n in z.files:
+                d = float((w - torch.from_numpy(z['final.' + n]).double()).norm())
+                worst = max(worst, d / max(float(un), 1e-30))
+                rep.append(f'  final {n}: |native - reference| / |reference update| = {d / max(float(un), 1e-30):.2e}')
+            if n.endswith('k_proj.bias'):
+                # the gradient of a key bias is identically zero in exact arithmetic (softmax is shift-invariant along the keys): what reaches Adam is rounding
+                # noise, which it normalises to +-lr steps in a random direction; no two fp32 implementations agree on it (oracle/teacher.py NOISE_ONLY)
+                assert float((w - 0.0).abs().max()) <= 2.0 * steps * float(z['learning_rate']), n
+                continue
+            assert abs(float(w.norm()) - float(nr)) <= (1e-5 if dtype == 'fp32' else 2e-3) * float(nr), n
+        rep.append(f'  saved slice == engine weights bit for bit ({len(eng)} tensors), loads with transformers.from_pretrained')
+        ok = ok and worst < (5e-2 if dtype == 'fp32' else 0.6)          # the 8-step UPDATE itself, relative: fp32 Adam sign noise on near-zero gradients aside
+        # the loaded HF model is the model the engine trained: the reference's DPO loss on batch 0, HF modules (fp32) vs the native trainer after training
+        from oracle import rl_math as orl
+        b0 = {'input_ids': torch.from_numpy(z['batch0.input_ids']).long(), 'attention_mask': torch.from_numpy(z['batch0.attention_mask']).long()}
+        lens = z['batch0.response_lens'].tolist()
+        hf0 = tf.OPTForCausalLM.from_pretrained(ckpt, torch_dtype=torch.float32).eval()
+        with torch.no_grad():
+            lp = orl.compute_log_probs(hf(**b0).logits, b0['input_ids'], lens, 3)
+            rlp = orl.compute_log_probs(hf0(**b0).logits, b0['input_ids'], lens, 3)
+        want_loss = float(orl.dpo_loss(lp, rlp, float(z['scale_coeff']))['loss'])
+        ld = tr.loss({'input_ids': b0['input_ids'].cuda(), 'attention_mask': b0['attention_mask'].cuda(), 'meta_info': {'response_lens': lens}})
+        tr.model._pending = None
+        e_hf = abs(float(ld['loss']) - want_loss)
+        rep.append(f'  DPO loss of batch 0 after training: native {float(ld["loss"]):.6f}, HF modules on the saved slice {want_loss:.6f} (|diff| {e_hf:.2e})')
+        ok = ok and e_hf < (2e-5 if dtype == 'fp32' else 2e-2)
+        # ---- resume: slice_4 carries the engine state (train_cfgs.save_checkpoint); a trainer built on it with load_checkpoint continues at step 5
+        s4 = os.path.join(out, 'slice_4')
+        again = DPOTrainer(_cfgs(z, s4, str(tmp_path / 'run2'), dtype, load_checkpoint=True), {'gradient_clipping': 1.0}, device='cuda:0')
+        assert again.global_step == 4 and again.model.global_steps == 4
+        ck = torch.load(os.path.join(s4, 'native_engine_latest.pt'), map_location='cpu')
+        st = again.policy.store
+        for g in st.master:                                      # the restored state IS the saved state, bit for bit
+            assert torch.equal(st.master[g].cpu(), ck['master'][g]) and torch.equal(st.m[g].cpu(), ck['m'][g]) and torch.equal(st.v[g].cpu(), ck['v'][g]), g
+        # the reference loads BOTH models from model_name_or_path (dpo.py:89-105), so a resumed run's frozen model would be slice_4 as well; to compare with the
+        # uninterrupted run the frozen model gets the original checkpoint back
+        again.reference.load_state_dict(tr.reference.state_dict())
+        hist2 = again.train()
+        assert len(hist2) == steps - 4 and again.global_step == steps
+        got2 = np.array([[h[k] for k in KEYS] for h in hist2], dtype=np.float64)
+        e_res = np.abs(got2 - got[4:]).max(0)
+        rep.append(f'  resumed from slice_4: steps 5..8 against the uninterrupted run: max |diff| loss {e_res[0]:.2e} margin {e_res[5]:.2e} lr {e_res[6]:.1e} '
+                   '(fp32 atomics in the bias / embedding gradients make two runs differ in the last bits; the restored state itself is bit-identical)')
+        ok = ok and e_res[0] < (2e-6 if dtype == 'fp32' else 2e-3) and e_res[6] == 0.0
+        assert ok, '\n'.join(rep)
+    finally:
+        dump(f'parity_dropin_e2e_{dtype}.txt', '\n'.join(rep) + '\n')      # whatever was measured, also when a check fails

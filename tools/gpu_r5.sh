@@ -29,6 +29,18 @@ for stage in "$@"; do
         done )
       python3 tools/pmc_instep_summary.py gpurun_out > gpurun_out/r05_attn_instep_pmc.txt; cat gpurun_out/r05_attn_instep_pmc.txt | cut -c1-220
       find gpurun_out/r05_pmc_* -name "*kernel_trace.csv" -delete; find gpurun_out/r05_pmc_* -name "*counter_collection.csv" -size +8M -delete ;;
+    dropin)          # the end-to-end drop-in test and the derived bf16 envelope at width
+      timeout 900 python -m pytest tests/test_dropin_gpu.py tests/test_secondary_geometry_gpu.py -q -x -m gpu -p no:cacheprovider -k "drop_in or llava7b_width" > gpurun_out/r05_dropin.log 2>&1; echo "rc=$?"; tail -30 gpurun_out/r05_dropin.log | cut -c1-400 ;;
+    norm)            # RMSNorm forward / backward at the step's shapes + their numerics tests
+      timeout 300 python tools/bench_norm.py r05_bench_norm.json 2>&1 | cut -c1-200
+      timeout 600 python -m pytest tests/test_elementwise_gpu.py tests/test_twin_gpu.py -q -x -m gpu -p no:cacheprovider -k "norm" > gpurun_out/r05_norm_tests.log 2>&1; echo "rc=$?"; tail -5 gpurun_out/r05_norm_tests.log | cut -c1-300 ;;
+    bench_quick)     # headline step without the PMC passes / CPU leg / batch sweep; power + clock sidecar on
+      timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r05_bench_quick.json 2> gpurun_out/r05_bench_quick.err; python -c "import json; d=json.load(open('gpurun_out/r05_bench_quick.json')); r=d['roofline']; print('ms/step', d['ms_per_step'], 'pairs/s', d['value'], 'gemm frac', r['frac'], {k: r.get(k) for k in ('power_source','power_w_mean','sclk_mhz_mean','peak_at_sclk','frac_of_peak_at_sclk','j_per_tflop_step','power_samples','power_source_errors')})" || tail -5 gpurun_out/r05_bench_quick.err
+      python tools/power_sampler.py --out gpurun_out/r05_power_probe.jsonl --seconds 1; head -c 1500 gpurun_out/r05_power_probe.jsonl ;;
+    tests)
+      timeout 1700 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/r05_pytest.log 2>&1; tail -15 gpurun_out/r05_pytest.log ;;
+    dp_shadow)       # one-GPU model of a resident collective beside backward (CU-masked stream, traffic kernel)
+      timeout 900 python tools/dp_shadow.py --steps 4 > gpurun_out/r05_dp_shadow.log 2> gpurun_out/r05_dp_shadow.err; echo "rc=$?"; cut -c1-200 gpurun_out/r05_dp_shadow.log; tail -3 gpurun_out/r05_dp_shadow.err | cut -c1-300 ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
