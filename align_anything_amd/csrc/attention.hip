@@ -393,6 +393,7 @@ struct AttnParams {
     // backward only: the transpose rotary rotation of dQ / dK in the kernels' epilogues (aa_attn_bwd_rope): position of token row r = rope_pos[r],
     // cos / sin tables [., HD / 2] bf16; null = plain dQ / dK (aa_attn_bwd)
     const int* rope_pos; const bf16_t* rope_cos; const bf16_t* rope_sin;
+    int pair;            // a128 forward only: a workgroup runs the query blocks nqb - 1 - r and r (causal load balance, see attn128.inc)
 };
 
 // ------------------------------------------------------------------ workgroup -> (sequence, head, block)
@@ -416,6 +417,18 @@ __device__ __forceinline__ void q_block_of(const AttnParams& p, int nqb, int& n,
     n = hkn / p.Hkv; hk = hkn % p.Hkv;
     h = hk * group + r % group;
     qb = nqb - 1 - r / group;
+}
+// a128 forward with p.pair: block b -> (sequence, query head, pair index r in [0, npair)); all npair * group workgroups that stream one kv head's K / V sit
+// back to back in ONE XCD's dispatch sequence when the kv heads can be dealt to the 8 XCDs evenly, else kv heads fastest (any order is balanced: equal pairs)
+__device__ __forceinline__ void pair_block_of(const AttnParams& p, int npair, int& n, int& h, int& hk, int& r) {
+    const int HkN = p.Hkv * p.N, group = p.H / p.Hkv, per = npair * group;
+    const int b = blockIdx.x;
+    int hkn, rr;
+    if ((HkN & 7) == 0) { hkn = (b & 7) + 8 * ((b >> 3) / per); rr = (b >> 3) % per; }
+    else                { hkn = b % HkN; rr = b / HkN; }
+    n = hkn / p.Hkv; hk = hkn % p.Hkv;
+    h = hk * group + rr % group;
+    r = rr / group;
 }
 __device__ __forceinline__ void kv_block_of(const AttnParams& p, int nkvb, int& n, int& hk, int& kvb) {
     const int HkN = p.Hkv * p.N;
@@ -997,7 +1010,7 @@ static int attn_impl() {
     return aa_ctx_cur()->attn_impl;
 }
 extern "C" int aa_attn_set_impl(int impl) {
-    AA_REQUIRE(impl >= 0 && impl <= 3, "aa_attn_set_impl: %d (bit 0 = forward, bit 1 = backward on the 32x32x16 kernels)", impl);
+    AA_REQUIRE(impl >= 0 && impl <= 7, "aa_attn_set_impl: %d (bit 0 = forward, bit 1 = backward on the 32x32x16 kernels, bit 2 = paired query blocks)", impl);
     aa_ctx_cur()->attn_impl = impl;
     return AA_OK;
 }
@@ -1017,7 +1030,9 @@ extern "C" int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O,
     const int lds = 4 * 64 * hd * 2;
     if (hd == 128 && attn128_enabled()) {
         if ((rc = set_lds(a128::attn128_fwd_kernel<128>, a128::LDS_FWD, "aa_attn_fwd"))) return rc;
-        hipLaunchKernelGGL(a128::attn128_fwd_kernel<128>, dim3(aa_cdiv(T, 256) * H * N), dim3(256), a128::LDS_FWD, (hipStream_t)stream, p);
+        const int nqb = aa_cdiv(T, 256);
+        p.pair = (causal && (nqb & 1) == 0 && (attn_impl() & 4)) ? 1 : 0;      // bit 2 of AA_ATTN128 / aa_attn_set_impl: paired query blocks, XCD-local
+        hipLaunchKernelGGL(a128::attn128_fwd_kernel<128>, dim3((p.pair ? nqb / 2 : nqb) * H * N), dim3(256), a128::LDS_FWD, (hipStream_t)stream, p);
     } else if (hd == 128) {
         if ((rc = set_lds(attn_fwd_kernel<128>, lds, "aa_attn_fwd"))) return rc;
         hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, p);

@@ -88,7 +88,8 @@ def test_drop_in_trainer_end_to_end_vs_the_reference_run(tmp_path, monkeypatch, 
                 # noise, which it normalises to +-lr steps in a random direction; no two fp32 implementations agree on it (oracle/teacher.py NOISE_ONLY)
                 assert float((w - 0.0).abs().max()) <= 2.0 * steps * float(z['learning_rate']), n
                 continue
-            assert abs(float(w.norm()) - float(nr)) <= (1e-5 if dtype == 'fp32' else 2e-3) * float(nr), n
+            # |w| against the reference's, with room for the 8-step update itself (a bias that starts at 0 IS its update): relative + a share of the update norm
+            assert abs(float(w.norm()) - float(nr)) <= ((1e-5 if dtype == 'fp32' else 2e-3) * float(nr) + (2e-3 if dtype == 'fp32' else 0.2) * float(un)), n
         rep.append(f'  saved slice == engine weights bit for bit ({len(eng)} tensors), loads with transformers.from_pretrained')
         ok = ok and worst < (5e-2 if dtype == 'fp32' else 0.6)          # the 8-step UPDATE itself, relative: fp32 Adam sign noise on near-zero gradients aside
         # the loaded HF model is the model the engine trained: the reference's DPO loss on batch 0, HF modules (fp32) vs the native trainer after training

@@ -104,6 +104,7 @@ def main():
             torch.cuda.synchronize()
             outs[impl] = d
         new, old = outs[a.impl], outs[a.base]
+        c['o_bit_identical_to_base'] = bool(torch.equal(new['o'], old['o'])) and bool(torch.equal(new['lse'], old['lse']))
         if a.bwd:
             for t_ in ('dq', 'dk', 'dv'):
                 c['%s_bit_identical_to_base' % t_] = bool(torch.equal(new[t_], old[t_]))

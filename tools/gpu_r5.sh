@@ -41,6 +41,38 @@ for stage in "$@"; do
       timeout 1700 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/r05_pytest.log 2>&1; tail -15 gpurun_out/r05_pytest.log ;;
     dp_shadow)       # one-GPU model of a resident collective beside backward (CU-masked stream, traffic kernel)
       timeout 900 python tools/dp_shadow.py --steps 4 > gpurun_out/r05_dp_shadow.log 2> gpurun_out/r05_dp_shadow.err; echo "rc=$?"; cut -c1-200 gpurun_out/r05_dp_shadow.log; tail -3 gpurun_out/r05_dp_shadow.err | cut -c1-300 ;;
+    attn_pair)       # round 5: paired query blocks + XCD-local order of the head_dim-128 forward (AA_ATTN128 bit 2) vs kv heads fastest: numerics, standalone, in-step, fetch
+      timeout 400 python tools/attn128_check.py --base 3 --impl 7 --out r05_attn_pair_check.json > gpurun_out/r05_attn_pair_check.txt 2>&1; python3 - <<'PY'
+import json
+for c in json.load(open('gpurun_out/r05_attn_pair_check.json')):
+    print(c['case'], 'ok' if c['ok'] else 'MISMATCH', {k: v for k, v in c.items() if 'identical' in k or k.endswith('_us')})
+PY
+      tail -1 gpurun_out/r05_attn_pair_check.txt
+      for rep in 1 2; do for v in 3 7; do
+        AA_ATTN128=$v timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r05_bench_attn$v.json 2> gpurun_out/r05_bench_attn$v.err
+        python -c "import json; d=json.load(open('gpurun_out/r05_bench_attn$v.json')); r=d['roofline']; print('AA_ATTN128=$v rep $rep', round(d['ms_per_step'],2), round(d['value'],4), 'W', round(r.get('power_w_mean') or 0), 'MHz', round(r.get('sclk_mhz_mean') or 0))" || tail -3 gpurun_out/r05_bench_attn$v.err
+      done; done
+      ( cd /tmp && export TMPDIR=/tmp
+        for v in 3 7; do
+          rm -rf $R/gpurun_out/r05_pmc_attn$v
+          AA_ATTN128=$v timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r05_pmc_attn$v -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-events --traffic committed --no-per-batch --no-power > $R/gpurun_out/r05_pmc_attn$v.log 2>&1
+          python3 - $R/gpurun_out/r05_pmc_attn$v <<'PY'
+import csv, glob, sys, collections
+dur = {}
+for f in glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[r['Dispatch_Id']] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+acc = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'attn' in r['Kernel_Name'] and r['Counter_Name'] == 'FETCH_SIZE':
+            acc[r['Kernel_Name'].split('(')[0][-40:]].append((float(r['Counter_Value']), dur.get(r['Dispatch_Id'], 0.0)))
+for k, v in acc.items():
+    fs = sum(x for x, _ in v) / len(v); us = sum(y for _, y in v) / len(v)
+    print(sys.argv[1][-5:], k, 'n', len(v), 'avg us', round(us, 1), 'fetch GB (2 x KiB)', round(fs * 2048 / 1e9, 3))
+PY
+          find $R/gpurun_out/r05_pmc_attn$v -name "*.csv" -size +4M -delete
+        done ) ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
