@@ -1003,10 +1003,11 @@ static int set_lds(K kern, int bytes, const char* name) {
 }
 
 // head_dim 128 runs on the one-wave-per-SIMD 32x32x16 kernels of attn128.inc; AA_ATTN128=0 / aa_attn_set_impl(0) keeps the 16x16x32 kernels above
-// (same-box A/B, bisecting; both stay tested).  Bit 0: forward, bit 1: backward.
+// (same-box A/B, bisecting; both stay tested).  Bit 0: forward, bit 1: backward, bit 2 (round 5, default on): the forward's workgroups run PAIRS of query blocks
+// in the XCD-local order (attn128.inc; bit-identical outputs; in the step 405.8 -> 386.8 us and 1.34 -> 0.59 GB fetched per launch, profiles/r05_attn_fwd_pair.txt).
 // aa_ctx::attn_impl (-1: read AA_ATTN128 once)
 static int attn_impl() {
-    if (aa_ctx_cur()->attn_impl < 0) { const char* e = getenv("AA_ATTN128"); aa_ctx_cur()->attn_impl = e ? atoi(e) : 3; }
+    if (aa_ctx_cur()->attn_impl < 0) { const char* e = getenv("AA_ATTN128"); aa_ctx_cur()->attn_impl = e ? atoi(e) : 7; }
     return aa_ctx_cur()->attn_impl;
 }
 extern "C" int aa_attn_set_impl(int impl) {

@@ -159,7 +159,7 @@ def main():
         print(json.dumps(c), flush=True)
         del outs, qkv, q, k, v, do
         torch.cuda.empty_cache()
-    LIB.call('aa_attn_set_impl', 3)
+    LIB.call('aa_attn_set_impl', 7)
     print('ALL OK' if all(c['ok'] for c in res) else 'MISMATCH: ' + ', '.join(c['case'] for c in res if not c['ok']), flush=True)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     with open(os.path.join(ROOT, 'gpurun_out', a.out), 'w') as f:
