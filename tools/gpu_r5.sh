@@ -73,6 +73,14 @@ for k, v in acc.items():
 PY
           find $R/gpurun_out/r05_pmc_attn$v -name "*.csv" -size +4M -delete
         done ) ;;
+    decode)          # sampler with 8 loads in flight: the decode / sampling tests and the PPO iteration
+      timeout 900 python -m pytest tests/test_decode_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r05_decode_tests.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/r05_decode_tests.log | cut -c1-300
+      timeout 300 python tools/bench_ppo.py --iters 2 > gpurun_out/r05_bench_ppo.json 2> gpurun_out/r05_bench_ppo.err
+      python -c "import json; d=json.load(open('gpurun_out/r05_bench_ppo.json')); print('decode', round(d['decode_ms_per_position'],4), 'ms/pos', round(d['iteration_ms'],1), 'ms/iter', d['split_ms'])" || tail -3 gpurun_out/r05_bench_ppo.err ;;
+    moe)             # configs[4] at 2 (the number quoted since round 2) and 4 pairs per step
+      for b in 2 4; do
+        timeout 400 python tools/bench_qwen3moe.py --pairs $b --steps 4 --warmup 2 > gpurun_out/r05_bench_qwen3moe_b$b.json 2> gpurun_out/r05_bench_qwen3moe_b$b.err; cut -c1-500 gpurun_out/r05_bench_qwen3moe_b$b.json; tail -2 gpurun_out/r05_bench_qwen3moe_b$b.err
+      done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
