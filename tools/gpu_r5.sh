@@ -81,6 +81,10 @@ PY
       for b in 2 4; do
         timeout 400 python tools/bench_qwen3moe.py --pairs $b --steps 4 --warmup 2 > gpurun_out/r05_bench_qwen3moe_b$b.json 2> gpurun_out/r05_bench_qwen3moe_b$b.err; cut -c1-500 gpurun_out/r05_bench_qwen3moe_b$b.json; tail -2 gpurun_out/r05_bench_qwen3moe_b$b.err
       done ;;
+    decode_stats)    # per-kernel averages of the decode window (sampler, strip GEMVs) under rocprofv3
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r05_ppo_prof && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r05_ppo_prof -o p -- python $R/tools/bench_ppo.py --iters 1 --new-tokens 128 > $R/gpurun_out/r05_bench_ppo_under_rocprof.json 2> $R/gpurun_out/r05_ppo_prof.err )
+      f=$(find gpurun_out/r05_ppo_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r05_ppo_kernel_stats.csv && grep -i "sample\|skinny\|attn_decode\|argmax" "$f" | cut -c1-60,200-330
+      find gpurun_out/r05_ppo_prof -name "*kernel_trace.csv" -delete ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
