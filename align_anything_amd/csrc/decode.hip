@@ -616,8 +616,7 @@ extern "C" int aa_argmax_rows(const void* logits, long ld, int rows, int V, cons
 // of an 8-way split (7 candidate thresholds per pass over the row = the 2^-30 resolution of 30 bisections in a third of the
 // passes); the draw walks the vocabulary in index order.
 // One 512-thread workgroup per row; thread t owns the contiguous slice [t*per, (t+1)*per) and re-reads it from L2 with 16-B
-// loads in each of the 13 passes, eight loads in flight per thread (round 5: two in flight made every pass a chain of 19 L2 round trips; a
-// register-resident copy spills at 1024 x 40 and at 512 x 80 values -- measured, not kept).
+// loads in each of the 13 passes (a register-resident copy spills at 1024 x 40 and at 512 x 80 values -- measured, not kept).
 // floor: scores below it are removed (-inf), the top-k cut of TopKLogitsWarper; -inf = keep everything
 __device__ __forceinline__ void load_scores8(const bf16_t* __restrict__ x, const uint8_t* __restrict__ seen, int i0, int e, float pen,
                                              float inv_temp, float (&v)[8], float floor = -INFINITY) {
@@ -666,7 +665,7 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ---- pass 1: maximum of the scores (penalty, temperature applied)
     float mx = -INFINITY;
-#pragma unroll 8
+#pragma unroll 2
     for (int i = b; i < e; i += 8) {
         float v[8];
         load_scores8(x, seen, i, e, pen, inv_temp, v);
@@ -684,7 +683,7 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
             int cs[KS];
 #pragma unroll
             for (int k = 0; k < KS; ++k) cs[k] = 0;
-#pragma unroll 8
+#pragma unroll 2
             for (int i = b; i < e; i += 8) {
                 float v[8];
                 load_scores8(x, seen, i, e, pen, inv_temp, v);
@@ -723,7 +722,7 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
     }
     // ---- pass 2: partition function
     float z = 0.f;
-#pragma unroll 8
+#pragma unroll 2
     for (int i = b; i < e; i += 8) {
         float v[8];
         load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
@@ -740,7 +739,7 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
             float ms[KS];
 #pragma unroll
             for (int k = 0; k < KS; ++k) ms[k] = 0.f;
-#pragma unroll 8
+#pragma unroll 2
             for (int i = b; i < e; i += 8) {
                 float v[8];
                 load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
@@ -773,7 +772,7 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
     const float tau = lo;
     // ---- the draw: first index (vocabulary order) whose running kept mass exceeds u * kept
     float mine = 0.f;
-#pragma unroll 8
+#pragma unroll 2
     for (int i = b; i < e; i += 8) {
         float v[8];
         load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
@@ -800,10 +799,7 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
     if ((int)threadIdx.x == owner) {
         float c = incl - mine;
         int pick = -1, last_kept = -1;
-        // no early exit: the loads and exponentials of all groups are independent of the running sum, so the loop unrolls and keeps 8 loads in flight
-        // (the serial walk with an exit test in the loop header paid one L2 round trip per 8 values: a quarter of the kernel's 100 us)
-#pragma unroll 8
-        for (int i = b; i < e; i += 8) {
+        for (int i = b; i < e && pick < 0; i += 8) {
             float v[8];
             load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
 #pragma unroll

@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import _shim  # noqa: E402
-from oracle.synthetic import StubProcessor, llava7b_width, opt125m_config1, preference_samples  # noqa: E402
+from oracle.synthetic import StubProcessor, llama31_width, llava7b_width, opt125m_config1, preference_samples  # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
@@ -1204,6 +1204,55 @@ def gen_dropin_e2e(threads=8, alt_threads=3):
           float(np.mean(np.concatenate(b_ids + w_ids) == 2)))
     print('loss', rows[:, 0].round(6).tolist())
     print('max |loss(8 threads) - loss(3 threads)|', float(np.abs(rows[:, 0] - rows_alt[:, 0]).max()), ' grad norms', rows[:, -1].round(4).tolist())
+
+
+def gen_llama31_width(dtypes=('fp32', 'bf16')):
+    """VERDICT r4 missing #2: a reference-pinned parity point on the reference's DEFAULT text backbone (every scripts/llama/*.sh launcher loads
+    meta-llama/Llama-3.1-8B-Instruct).  The reference's unmodified text-to-text DPOTrainer (trainers/text_to_text/dpo.py:122-203: compute_log_probs, loss)
+    + backward on oracle.synthetic.llama31_width -- 4 Llama layers at the 8B geometry (GQA 32 / 8, ffn 14336, llama3 rope scaling) with the 128256-row head,
+    one left-padded pair, CPU -- in fp32 (the parity target) and in bf16 (the reference's own training precision: the envelope the native bf16 path is held
+    against, as gen_llava7b_width_bf16ref).  Stored per precision: the six loss outputs, both log-prob tensors, per-parameter gradient norms, a leading
+    block of every gradient; per-tensor weight checksums once."""
+    import time
+    from transformers import LlamaForCausalLM
+    from align_anything.trainers.text_to_text.dpo import DPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+    t0 = time.time()
+    cfg, sd, ref_sd, batch = llama31_width()
+    out = {'input_ids': batch['input_ids'].numpy(), 'attention_mask': batch['attention_mask'].numpy(), 'response_lens': np.array(batch['meta_info']['response_lens']),
+           'scale_coeff': np.array(0.1), 'num_layers': np.array(cfg.num_hidden_layers)}
+    for dt in dtypes:
+        policy, refm = LlamaForCausalLM(cfg).eval(), LlamaForCausalLM(cfg).eval()
+        assert policy.load_state_dict(sd, strict=True) and refm.load_state_dict(ref_sd, strict=True)
+        if dt == 'bf16':
+            policy, refm = policy.to(torch.bfloat16), refm.to(torch.bfloat16)
+        tr = DPOTrainer.__new__(DPOTrainer)
+        tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+        tr.tokenizer = SimpleNamespace(pad_token_id=cfg.pad_token_id)
+        tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+        tr.model, tr.reference_model = SimpleNamespace(module=policy), SimpleNamespace(module=refm)
+        seq_lp = tr.compute_log_probs(policy, batch).detach()
+        ref_lp = tr.compute_log_probs(refm, batch).detach()
+        ld = tr.loss(batch)
+        ld['loss'].backward()
+        print(f'{dt}: reference loss {float(ld["loss"]):.6f} margin {ld["reward_margin"].float().tolist()} ({time.time() - t0:.0f}s)', flush=True)
+        px = '' if dt == 'fp32' else 'bf16.'
+        out[px + 'seq_log_probs'], out[px + 'ref_seq_log_probs'] = seq_lp.float().numpy(), ref_lp.float().numpy()
+        for k, v in ld.items():
+            out[px + 'loss_' + k] = v.detach().float().numpy()
+        names, gnorm = [], []
+        for n, p in policy.named_parameters():
+            names.append(n)
+            gnorm.append(float(p.grad.double().norm()))
+            out[px + 'gblk.' + n] = p.grad.float().reshape(p.grad.shape[0], -1)[:32, :32].contiguous().numpy()
+        out[px + 'grad_norm'] = np.array(gnorm)
+        if dt == 'fp32':
+            rparams = dict(refm.named_parameters())
+            out.update(names=np.array(names), weight_checksum=np.array([float(p.double().sum()) for _, p in policy.named_parameters()]),
+                       ref_weight_checksum=np.array([float(rparams[n].double().sum()) for n in names]))
+        del policy, refm, tr
+    np.savez_compressed(os.path.join(GOLD, 'llama31_width_dpo.npz'), **out)
+    print('llama31_width_dpo.npz', len(out), f'arrays ({time.time() - t0:.0f}s)')
 
 
 def _opt125m_reference_trainer(nthreads):

@@ -139,3 +139,44 @@ def llava7b_width(num_layers=4, T=640, R=48, left_pad=(0, 23), seed=42):
     batch = {'input_ids': ids, 'attention_mask': mask, 'pixel_values': torch.cat([pix, pix], 0),
              'meta_info': {'response_lens': [R - lp for lp in left_pad]}}
     return cfg, sd, ref_sd, batch
+
+
+def llama31_width_config(num_layers=4):
+    """meta-llama/Llama-3.1-8B-Instruct's geometry (the model every scripts/llama/*.sh launcher of the reference loads: llama_dpo.sh:19, llama_ppo.sh:19,
+    llama_grpo.sh:19) with `num_layers` decoder layers: hidden 4096, ffn 14336, GQA 32 / 8 x 128, vocabulary 128256, rope theta 500000 with the llama3
+    frequency scaling (factor 8, low / high frequency factors 1 / 4, original context 8192), rms eps 1e-5, untied head."""
+    from transformers import LlamaConfig
+    rp = {'rope_type': 'llama3', 'rope_theta': 500000.0, 'factor': 8.0, 'low_freq_factor': 1.0, 'high_freq_factor': 4.0, 'original_max_position_embeddings': 8192}
+    return LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=num_layers, num_attention_heads=32, num_key_value_heads=8, vocab_size=128256,
+                       rms_norm_eps=1e-5, max_position_embeddings=131072, rope_parameters=rp, tie_word_embeddings=False, pad_token_id=128004,
+                       bos_token_id=128000, eos_token_id=128009, attn_implementation='eager')
+
+
+def llama31_width(num_layers=4, T=384, R=48, left_pad=(0, 29), seed=43):
+    """One preference pair at the FULL WIDTH of the reference's default text backbone (llama31_width_config), built like llava7b_width: every tensor from
+    its own generator seeded by (seed, crc32(name)), bf16-representable values, reference model = policy + N(0, 2e-3) on the matrices; the rejected row
+    left-padded.  Returns (LlamaConfig, policy state dict, reference state dict, batch).  Regenerated on the GPU box from the seed (per-tensor checksums
+    are committed with the fixture, not the 7 GB of weights)."""
+    import zlib
+    from transformers import LlamaForCausalLM
+    cfg = llama31_width_config(num_layers)
+    with torch.device('meta'):
+        skel = LlamaForCausalLM(cfg)
+    sd, ref_sd = {}, {}
+    for n, p in skel.named_parameters():
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(n.encode())) % (1 << 62))
+        norm = p.dim() == 1 and 'norm' in n
+        w = torch.randn(tuple(p.shape), generator=g) * (0.1 if norm else 0.02) + (1.0 if norm else 0.0)
+        sd[n] = w.to(torch.bfloat16).to(torch.float32)
+        ref_sd[n] = (sd[n] + 2e-3 * torch.randn(tuple(p.shape), generator=g)).to(torch.bfloat16).to(torch.float32) if p.dim() >= 2 else sd[n]
+    gb = torch.Generator().manual_seed(seed + 2)
+    N, pad = 2, cfg.pad_token_id
+    ids = torch.full((N, T), pad, dtype=torch.long)
+    mask = torch.zeros((N, T), dtype=torch.long)
+    prompt = torch.randint(3, 128000, (T - 1 - R,), generator=gb)
+    for r in range(N):
+        lp = left_pad[r]
+        resp = torch.randint(3, 128000, (R - lp,), generator=gb)
+        ids[r, lp:] = torch.cat([torch.tensor([cfg.bos_token_id]), prompt, resp])
+        mask[r, lp:] = 1
+    return cfg, sd, ref_sd, {'input_ids': ids, 'attention_mask': mask, 'meta_info': {'response_lens': [R - lp for lp in left_pad]}}
