@@ -85,6 +85,17 @@ PY
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r05_ppo_prof && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r05_ppo_prof -o p -- python $R/tools/bench_ppo.py --iters 1 --new-tokens 128 > $R/gpurun_out/r05_bench_ppo_under_rocprof.json 2> $R/gpurun_out/r05_ppo_prof.err )
       f=$(find gpurun_out/r05_ppo_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r05_ppo_kernel_stats.csv && grep -i "sample\|skinny\|attn_decode\|argmax" "$f" | cut -c1-60,200-330
       find gpurun_out/r05_ppo_prof -name "*kernel_trace.csv" -delete ;;
+    llama31)         # the reference's default text backbone at width vs the reference trainer's fixture
+      timeout 600 python -m pytest tests/test_llama3_gpu.py -q -x -m gpu -p no:cacheprovider -k "width" > gpurun_out/r05_llama31_width.log 2>&1; echo "rc=$?"; tail -12 gpurun_out/r05_llama31_width.log | cut -c1-400; cat gpurun_out/parity_llama31_width_vs_reference.txt | cut -c1-300 ;;
+    bench_b1)        # the headline step at the reference yaml's micro-batch (1 pair): full roofline split at M = 4096
+      timeout 600 python bench.py --pairs-per-gpu 1 --steps 8 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r05_bench_b1.json 2> gpurun_out/r05_bench_b1.err; python -c "
+import json; d=json.load(open('gpurun_out/r05_bench_b1.json')); r=d['roofline']; print('B1 ms/step', d['ms_per_step'], 'pairs/s', d['value'], 'gemm frac', r['frac'], 'share', r['gemm_share_of_step_time'], 'W', r.get('power_w_mean'), 'MHz', r.get('sclk_mhz_mean'))
+for k in r['by_kind_top12'][:8]: print(k)" || tail -5 gpurun_out/r05_bench_b1.err ;;
+    tower_prefetch)  # the next batch's frozen-tower features between backward and the optimizer launch (AA_TOWER_PREFETCH=1, default) vs at the start of the next step
+      for rep in 1 2; do for v in 0 1; do for b in 4 1; do
+        AA_TOWER_PREFETCH=$v timeout 600 python bench.py --pairs-per-gpu $b --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r05_bench_tp${v}_b$b.json 2> gpurun_out/r05_bench_tp${v}_b$b.err
+        python -c "import json; d=json.load(open('gpurun_out/r05_bench_tp${v}_b$b.json')); r=d['roofline']; print('AA_TOWER_PREFETCH=$v B=$b rep $rep', round(d['ms_per_step'],2), 'ms', round(d['value'],4), 'pairs/s  W', round(r.get('power_w_mean') or 0), 'MHz', round(r.get('sclk_mhz_mean') or 0), 'losses', d['config']['losses_timed_steps'][:3])" || tail -3 gpurun_out/r05_bench_tp${v}_b$b.err
+      done; done; done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
