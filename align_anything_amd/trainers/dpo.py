@@ -24,19 +24,6 @@ from ..modeling import build_model
 from .common import build_window, cfg_get, compute_dtype, expert_parallel_kwargs, flat_to_padded, get_all_reduce_mean, save_slice
 
 
-def _with_next(iterable):
-    """(item, the item after it or None) for every item: the training loop's one-batch look-ahead (DPOTrainer.prefetch)."""
-    it = iter(iterable)
-    try:
-        cur = next(it)
-    except StopIteration:
-        return
-    for nxt in it:
-        yield cur, nxt
-        cur = nxt
-    yield cur, None
-
-
 class DPOTrainer:
     uses_reference = True     # SimPO / ORPO (trainers/pref.py) never evaluate the reference model
     skip_identical_pairs = False   # set by __init__ for the audio trainer, whose reference `loss` skips identical pairs
@@ -225,36 +212,13 @@ class DPOTrainer:
             'reward_accuracy': out6[1], 'reward_margin': sel(per[3]), '_means': out6,
         }
 
-    @property
-    def _step_takes_next(self) -> bool:
-        """A subclass (or the reference's own `train_step` bound to this object, INTEGRATION.md level B) may keep the one-argument signature."""
-        import inspect
-        try:
-            return 'next_batch' in inspect.signature(self.train_step).parameters
-        except (TypeError, ValueError):
-            return False
-
-    def prefetch(self, batch) -> None:
-        """Input-pipeline work of a LATER batch that depends on no trainable weight: its response-window plan and, with a frozen shared vision tower, the
-        tower's features ("run vision tower once per image").  `train_step(batch, next_batch=...)` calls it between backward and
-        the optimizer launch: the tower's 74 small GEMMs (K <= 4096, ~300 workgroups) then run alone (4.4 ms at 4 pairs) instead of at the start of the next
-        step beside the asynchronous AdamW, where they crawl (21.9 ms at 4 pairs, ~48 ms at 1: profiles/r05_tower_prefetch.txt) while the HBM-bound update
-        holds the memory system -- the large decoder GEMMs that overlap the update instead are MFMA-bound and share the chip with it far better."""
-        if batch is None or '_vision_features' in batch:
-            return
-        self._window(batch)
-        self._features(batch)
-
-    def train_step(self, batch, next_batch=None) -> dict[str, Any]:
-        """dpo.py:205-237; the six scalar all-reduces + six .item() syncs are fused into one each.  next_batch (optional, the batch of the following step,
-        already on the device): see `prefetch`."""
+    def train_step(self, batch) -> dict[str, Any]:
+        """dpo.py:205-237; the six scalar all-reduces + six .item() syncs are fused into one each."""
         loss_dict = self.loss(batch)
         if not getattr(self, '_first_batch_checked', False):
             self._first_batch_checked = True
             self._check_first_batch(batch)
         self.model.backward(loss_dict['loss'])
-        if next_batch is not None and os.environ.get('AA_TOWER_PREFETCH', '1') != '0':
-            self.prefetch(next_batch)
         self.model.step()
         means = get_all_reduce_mean(loss_dict['_means'].clone())
         m = means.tolist()  # the single device->host sync of the step
@@ -306,10 +270,10 @@ class DPOTrainer:
         for epoch in range(int(remain_epoch)):
             self.model.train()
             self._epoch_begin()
-            for batch_idx, (batch, upcoming) in enumerate(_with_next(self.train_dataloader)):
+            for batch_idx, batch in enumerate(self.train_dataloader):
                 if epoch == 0 and batch_idx < start_batch_idx:
                     continue
-                info = self.train_step(batch, next_batch=upcoming) if self._step_takes_next else self.train_step(batch)
+                info = self.train_step(batch)
                 self.global_step += 1
                 info['train/epoch'] = self.global_step / per_epoch
                 history.append(info)

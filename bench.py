@@ -324,8 +324,7 @@ def main():
     for g in tr.policy.store.master:
         tr.policy.store.master[g].copy_(tr.policy.store.flat[g])
     # one fresh batch per step (warm-up and timed), all resident in HBM before the clock starts
-    n_b = args.warmup + args.steps + 1          # + 1: the last timed step prefetches the frozen tower's features of one more batch (DPOTrainer.prefetch), so
-                                                # every timed step runs exactly one tower pass -- its successor's -- and none is skipped or cached across the clock
+    n_b = args.warmup + args.steps
     batches = [make_batch(cfg, B, T, R, device, seed=1234 + rank * 100003 + i) for i in range(n_b)]
     torch.cuda.synchronize()
 
@@ -348,7 +347,7 @@ def main():
     for i in range(args.warmup):
         if i == args.warmup - 1 and not args.no_gemm_events:
             ops.GEMM_PROF = []                      # count the GEMM launches of one step ...
-        tr.train_step(batches[i], next_batch=batches[i + 1])
+        tr.train_step(batches[i])
     torch.cuda.synchronize()
     if not args.no_gemm_events:                     # ... and create every event the timed region will record up front
         per_step = len(ops.GEMM_PROF) if ops.GEMM_PROF else 600
@@ -370,7 +369,7 @@ def main():
     t0 = time.perf_counter()
     losses = []
     for i in range(args.steps):
-        last = tr.train_step(batches[args.warmup + i], next_batch=batches[args.warmup + i + 1])
+        last = tr.train_step(batches[args.warmup + i])
         losses.append(round(last['train/loss'], 5))
     torch.cuda.synchronize()
     barrier()
@@ -429,12 +428,11 @@ def main():
             if b2 == B:
                 continue
             bb = [make_batch(cfg, b2, T, R, device, seed=777 + 10 * b2 + i) for i in range(4)]
-            bb.append(make_batch(cfg, b2, T, R, device, seed=777 + 10 * b2 + 4))
-            tr.train_step(bb[0], next_batch=bb[1])
+            tr.train_step(bb[0])
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(1, 4):
-                tr.train_step(bb[i], next_batch=bb[i + 1])
+                tr.train_step(bb[i])
             torch.cuda.synchronize()
             d1 = (time.perf_counter() - t1) / 3
             per_batch[f'B{b2}'] = {'pairs_per_gpu_step': b2, 'value': b2 / d1, 'unit': 'pairs/s', 'ms_per_step': d1 * 1e3, 'steps': 3, 'warmup': 1}

@@ -91,11 +91,6 @@ PY
       timeout 600 python bench.py --pairs-per-gpu 1 --steps 8 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r05_bench_b1.json 2> gpurun_out/r05_bench_b1.err; python -c "
 import json; d=json.load(open('gpurun_out/r05_bench_b1.json')); r=d['roofline']; print('B1 ms/step', d['ms_per_step'], 'pairs/s', d['value'], 'gemm frac', r['frac'], 'share', r['gemm_share_of_step_time'], 'W', r.get('power_w_mean'), 'MHz', r.get('sclk_mhz_mean'))
 for k in r['by_kind_top12'][:8]: print(k)" || tail -5 gpurun_out/r05_bench_b1.err ;;
-    tower_prefetch)  # the next batch's frozen-tower features between backward and the optimizer launch (AA_TOWER_PREFETCH=1, default) vs at the start of the next step
-      for rep in 1 2; do for v in 0 1; do for b in 4 1; do
-        AA_TOWER_PREFETCH=$v timeout 600 python bench.py --pairs-per-gpu $b --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r05_bench_tp${v}_b$b.json 2> gpurun_out/r05_bench_tp${v}_b$b.err
-        python -c "import json; d=json.load(open('gpurun_out/r05_bench_tp${v}_b$b.json')); r=d['roofline']; print('AA_TOWER_PREFETCH=$v B=$b rep $rep', round(d['ms_per_step'],2), 'ms', round(d['value'],4), 'pairs/s  W', round(r.get('power_w_mean') or 0), 'MHz', round(r.get('sclk_mhz_mean') or 0), 'losses', d['config']['losses_timed_steps'][:3])" || tail -3 gpurun_out/r05_bench_tp${v}_b$b.err
-      done; done; done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
