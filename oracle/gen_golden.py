@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import _shim  # noqa: E402
-from oracle.synthetic import StubProcessor, llama31_width, llava7b_width, opt125m_config1, preference_samples  # noqa: E402
+from oracle.synthetic import StubProcessor, llama31_width, llava7b_width, opt125m_config1, preference_samples, qwen2vl_width  # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
@@ -1253,6 +1253,68 @@ def gen_llama31_width(dtypes=('fp32', 'bf16')):
         del policy, refm, tr
     np.savez_compressed(os.path.join(GOLD, 'llama31_width_dpo.npz'), **out)
     print('llama31_width_dpo.npz', len(out), f'arrays ({time.time() - t0:.0f}s)')
+
+
+def gen_qwen2vl_width(dtypes=None):
+    """BASELINE configs[2]'s backbone pinned to the reference at full width (round 5): the unmodified text+image DPOTrainer (trainers/text_image_to_text/
+    dpo.py:85-166) + backward on oracle.synthetic.qwen2vl_width -- the Qwen2-VL-7B vision tower at full depth and width, the 2 x 2 merger, 4 decoder layers of
+    3584 / 18944 with GQA 28 / 4, multimodal rope and the 152064-row head; one left-padded pair -- in fp32 and in the reference's own bf16.  Every parameter
+    trains (the reference's substring freezing never matches `model.visual.*`).  Stored as gen_llama31_width does."""
+    import time
+    from transformers import Qwen2VLForConditionalGeneration
+    from align_anything.trainers.text_image_to_text.dpo import DPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+    import gc
+    t0 = time.time()
+    path = os.path.join(GOLD, 'qwen2vl_width_dpo.npz')
+    if dtypes is None:
+        # one precision per process (two 2.7 B-parameter fp32 models + gradients + the generator's state dicts do not fit the build container twice):
+        # the fp32 pass writes the file, the bf16 pass adds its arrays to it
+        import subprocess
+        for dt in ('fp32', 'bf16'):
+            subprocess.run([sys.executable, '-c', f"from oracle import _shim; _shim.install(); from oracle.gen_golden import gen_qwen2vl_width as g; g(('{dt}',))"], check=True, cwd=ROOT)
+        return
+    cfg, sd, ref_sd, batch, PAD = qwen2vl_width()
+    prev = dict(np.load(path)) if (os.path.exists(path) and 'fp32' not in dtypes) else {}
+    out = {'input_ids': batch['input_ids'].numpy(), 'attention_mask': batch['attention_mask'].numpy(), 'response_lens': np.array(batch['meta_info']['response_lens']),
+           'image_grid_thw': batch['image_grid_thw'].numpy(), 'pixel_checksum': np.array(float(batch['pixel_values'].double().sum())), 'pad_token_id': np.array(PAD),
+           'scale_coeff': np.array(0.1), 'num_layers': np.array(cfg.text_config.num_hidden_layers), 'vision_depth': np.array(cfg.vision_config.depth)}
+    for dt in dtypes:
+        policy, refm = Qwen2VLForConditionalGeneration(cfg).eval(), Qwen2VLForConditionalGeneration(cfg).eval()
+        assert policy.load_state_dict(sd, strict=True) and refm.load_state_dict(ref_sd, strict=True)
+        b = dict(batch)
+        if dt == 'bf16':
+            policy, refm = policy.to(torch.bfloat16), refm.to(torch.bfloat16)
+            b['pixel_values'] = batch['pixel_values'].to(torch.bfloat16)
+        tr = DPOTrainer.__new__(DPOTrainer)
+        tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+        tr.tokenizer = SimpleNamespace(pad_token_id=PAD)
+        tr.infer_batch = lambda bb: {k: v for k, v in bb.items() if k != 'meta_info'}
+        tr.model, tr.reference_model = SimpleNamespace(module=policy), SimpleNamespace(module=refm)
+        seq_lp = tr.compute_log_probs(policy, b).detach()
+        ref_lp = tr.compute_log_probs(refm, b).detach()
+        ld = tr.loss(b)
+        ld['loss'].backward()
+        print(f'{dt}: reference loss {float(ld["loss"]):.6f} margin {ld["reward_margin"].float().tolist()} ({time.time() - t0:.0f}s)', flush=True)
+        px = '' if dt == 'fp32' else 'bf16.'
+        out[px + 'seq_log_probs'], out[px + 'ref_seq_log_probs'] = seq_lp.float().numpy(), ref_lp.float().numpy()
+        for k, v in ld.items():
+            out[px + 'loss_' + k] = v.detach().float().numpy()
+        names, gnorm = [], []
+        for n, p in policy.named_parameters():
+            names.append(n)
+            gnorm.append(float(p.grad.double().norm()) if p.grad is not None else -1.0)
+            if p.grad is not None and ('visual.blocks' not in n or any(f'blocks.{i}.' in n for i in (0, 15, 31))):      # leading blocks: decoder, merger, 3 of the 32 visual blocks
+                out[px + 'gblk.' + n] = p.grad.float().reshape(p.grad.shape[0], -1)[:32, :32].contiguous().numpy()
+        out[px + 'grad_norm'] = np.array(gnorm)
+        if dt == 'fp32':
+            rparams = dict(refm.named_parameters())
+            out.update(names=np.array(names), weight_checksum=np.array([float(p.double().sum()) for _, p in policy.named_parameters()]),
+                       ref_weight_checksum=np.array([float(rparams[n].double().sum()) for n in names]))
+        del policy, refm, tr
+        gc.collect()
+    np.savez_compressed(path, **{**prev, **out})
+    print('qwen2vl_width_dpo.npz', len(out), f'arrays ({time.time() - t0:.0f}s)')
 
 
 def _opt125m_reference_trainer(nthreads):

@@ -180,3 +180,55 @@ def llama31_width(num_layers=4, T=384, R=48, left_pad=(0, 29), seed=43):
         ids[r, lp:] = torch.cat([torch.tensor([cfg.bos_token_id]), prompt, resp])
         mask[r, lp:] = 1
     return cfg, sd, ref_sd, {'input_ids': ids, 'attention_mask': mask, 'meta_info': {'response_lens': [R - lp for lp in left_pad]}}
+
+
+def qwen2vl_width_config(num_layers=4, vision_depth=32):
+    """Qwen/Qwen2-VL-7B-Instruct's geometry (BASELINE configs[2]) with `num_layers` decoder layers: text 3584 / 18944, GQA 28 / 4 x 128, vocabulary 152064,
+    rope theta 1e6 with the multimodal sections [16, 24, 24], rms eps 1e-6; vision tower at FULL depth and width (32 blocks of 1280, 16 heads of 80,
+    mlp ratio 4, 14 x 14 x 2 patches, 2 x 2 merger into 3584)."""
+    from transformers import Qwen2VLConfig
+    return Qwen2VLConfig(
+        text_config=dict(hidden_size=3584, intermediate_size=18944, num_hidden_layers=num_layers, num_attention_heads=28, num_key_value_heads=4,
+                         vocab_size=152064, max_position_embeddings=32768, rms_norm_eps=1e-6, tie_word_embeddings=False,
+                         rope_parameters={'rope_type': 'default', 'rope_theta': 1000000.0, 'mrope_section': [16, 24, 24]}),
+        vision_config=dict(depth=vision_depth, embed_dim=1280, hidden_size=3584, num_heads=16, mlp_ratio=4, patch_size=14, temporal_patch_size=2,
+                           spatial_merge_size=2, in_channels=3),
+        image_token_id=151655, video_token_id=151656, vision_start_token_id=151652, vision_end_token_id=151653, bos_token_id=151643, eos_token_id=151645,
+        tie_word_embeddings=False)
+
+
+def qwen2vl_width(num_layers=4, vision_depth=32, T=320, R=48, left_pad=(0, 17), grid=(1, 16, 16), seed=44):
+    """One preference pair at the FULL WIDTH of BASELINE configs[2]'s backbone, built like llava7b_width (per-tensor generators seeded by (seed, crc32(name)),
+    bf16-representable values, reference model = policy + N(0, 2e-3) on the decoder / merger matrices).  One image of grid[1] x grid[2] patches
+    (-> grid[1] * grid[2] / 4 image tokens) shared by the chosen and the rejected row, as the reference's collator stacks it (images * 2); the rejected row
+    is left-padded.  Returns (Qwen2VLConfig, policy state dict, reference state dict, batch)."""
+    import zlib
+    from transformers import Qwen2VLForConditionalGeneration
+    cfg = qwen2vl_width_config(num_layers, vision_depth)
+    with torch.device('meta'):
+        skel = Qwen2VLForConditionalGeneration(cfg)
+    sd, ref_sd = {}, {}
+    for n, p in skel.named_parameters():
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(n.encode())) % (1 << 62))
+        norm = p.dim() == 1 and ('norm' in n or 'ln_q' in n) and n.endswith('weight')
+        w = torch.randn(tuple(p.shape), generator=g) * (0.1 if norm else 0.02) + (1.0 if norm else 0.0)
+        sd[n] = w.to(torch.bfloat16).to(torch.float32)
+        if p.dim() >= 2 and 'visual.blocks' not in n and 'patch_embed' not in n:
+            ref_sd[n] = (sd[n] + 2e-3 * torch.randn(tuple(p.shape), generator=g)).to(torch.bfloat16).to(torch.float32)
+        else:
+            ref_sd[n] = sd[n]
+    gb = torch.Generator().manual_seed(seed + 2)
+    PAD, IMG, N = 151643, 151655, 2
+    ntok = grid[1] * grid[2] // 4
+    ids = torch.full((N, T), PAD, dtype=torch.long)
+    mask = torch.zeros((N, T), dtype=torch.long)
+    prompt = torch.randint(3, 151000, (T - 3 - ntok - R,), generator=gb)
+    for r in range(N):
+        lp = left_pad[r]
+        resp = torch.randint(3, 151000, (R - lp,), generator=gb)
+        ids[r, lp:] = torch.cat([torch.tensor([151644, 151652]), torch.full((ntok,), IMG), torch.tensor([151653]), prompt, resp])      # <|im_start|> <|vision_start|> image <|vision_end|>
+        mask[r, lp:] = 1
+    pix = torch.randn(grid[0] * grid[1] * grid[2], 3 * 2 * 14 * 14, generator=gb)
+    batch = {'input_ids': ids, 'attention_mask': mask, 'pixel_values': torch.cat([pix, pix], 0), 'image_grid_thw': torch.tensor([list(grid), list(grid)]),
+             'mm_token_type_ids': (ids == IMG).int(), 'meta_info': {'response_lens': [R - lp for lp in left_pad]}}
+    return cfg, sd, ref_sd, batch, PAD

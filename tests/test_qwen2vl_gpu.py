@@ -286,3 +286,86 @@ def test_ppo_four_engines_and_decode_copies_coexist_at_full_width_reduced_depth(
         assert r['response_lens'] == [16, 16] and math.isfinite(r['actor_loss']) and math.isfinite(r['critic_loss'])
     assert out['decode_ms_per_position'] > 0 and out['split_ms']['prefill_of_generate'] > 0
     torch.cuda.empty_cache()
+
+
+def test_qwen2vl_width_pair_vs_the_reference_trainer():
+    """BASELINE configs[2]'s backbone pinned to the reference at FULL WIDTH (round 5).  tests/golden/qwen2vl_width_dpo.npz was produced by the UNMODIFIED
+    text+image DPOTrainer (trainers/text_image_to_text/dpo.py:85-166: compute_log_probs, loss, then backward) on oracle.synthetic.qwen2vl_width in the
+    build container: the Qwen2-VL-7B vision tower at full depth and width (32 blocks of 1280, 80-wide heads), the 2 x 2 merger, 4 decoder layers of 3584 /
+    18944 with GQA 28 / 4, multimodal rope, the 152064-row head; one left-padded pair, every parameter training -- in fp32 and in the reference's own bf16.
+    Weights regenerated from the seed (checksums checked).  Bounds: fp32 twin: loss / log-probs 2e-4 abs, gradient norms 1e-3 rel, leading blocks 2e-3;
+    bf16 path: within 1.5 x the reference's OWN bf16-vs-fp32 deviation, per quantity."""
+    import gc
+    from oracle.synthetic import qwen2vl_width
+    from align_anything_amd import configs
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    z = load_golden('qwen2vl_width_dpo.npz')
+    hc, sd, ref_sd, batch, PAD = qwen2vl_width(num_layers=int(z['num_layers']), vision_depth=int(z['vision_depth']))
+    names = [str(n) for n in z['names']]
+    for n, c, rc in zip(names, z['weight_checksum'], z['ref_weight_checksum']):
+        assert abs(float(sd[n].double().sum()) - float(c)) <= 1e-9 * max(1.0, abs(float(c))), n
+        assert abs(float(ref_sd[n].double().sum()) - float(rc)) <= 1e-9 * max(1.0, abs(float(rc))), n
+    assert np.array_equal(batch['input_ids'].numpy(), z['input_ids']) and abs(float(batch['pixel_values'].double().sum()) - float(z['pixel_checksum'])) < 1e-6
+    cfg = configs.from_hf_config(hc)
+    want_lp, want_ref = T(z['seq_log_probs']), T(z['ref_seq_log_probs'])
+    rep = [f'reference trainer (fp32, CPU): loss {float(z["loss_loss"]):.6f} margin {z["loss_reward_margin"].tolist()} summed log-probs {want_lp.sum(1).tolist()}']
+    try:
+        for dtype in ('fp32', 'bf16'):
+            tr = DPOTrainer({'train_cfgs': {'scale_coeff': float(z['scale_coeff']), 'learning_rate': 1e-6, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant',
+                                            'compute_dtype': dtype, 'freeze_vision_tower': False}, 'model_cfgs': {'pad_token_id': PAD}}, {'gradient_clipping': 1.0},
+                            model_cfg=cfg, policy_state=sd, reference_state=ref_sd, device='cuda:0', share_vision_tower=False)
+            b = {'input_ids': batch['input_ids'].to(dev()), 'attention_mask': batch['attention_mask'].to(dev()), 'image_grid_thw': batch['image_grid_thw'],
+                 'pixel_values': batch['pixel_values'].to(dev()).to(torch.float32 if dtype == 'fp32' else torch.bfloat16), 'meta_info': batch['meta_info']}
+            lp = tr.compute_log_probs(tr.model, b).cpu()
+            rlp = tr.compute_log_probs(tr.reference_model, b).cpu()
+            assert torch.equal(lp == 0, want_lp == 0), 'response-window layout differs from the reference'
+            ld = tr.loss(b)
+            tr.model.backward(ld['loss'])
+            torch.cuda.synchronize()
+            m = {'loss': abs(float(ld['loss']) - float(z['loss_loss'])),
+                 'margin': float((ld['reward_margin'].float().cpu().reshape(-1) - T(z['loss_reward_margin']).reshape(-1)).abs().max()),
+                 'per-token log-probs (policy)': float((lp - want_lp).abs().max()), 'per-token log-probs (reference model)': float((rlp - want_ref).abs().max()),
+                 'summed log-probs': float((lp.sum(1) - want_lp.sum(1)).abs().max())}
+            r = {'loss': abs(float(z['bf16.loss_loss']) - float(z['loss_loss'])),
+                 'margin': float(np.abs(z['bf16.loss_reward_margin'].reshape(-1) - z['loss_reward_margin'].reshape(-1)).max()),
+                 'per-token log-probs (policy)': float(np.abs(z['bf16.seq_log_probs'] - z['seq_log_probs']).max()),
+                 'per-token log-probs (reference model)': float(np.abs(z['bf16.ref_seq_log_probs'] - z['ref_seq_log_probs']).max()),
+                 'summed log-probs': float(np.abs(z['bf16.seq_log_probs'].sum(1) - z['seq_log_probs'].sum(1)).max())}
+            wn, wb, rn, rb, n_g, n_t = 0.0, 0.0, 0.0, 0.0, 0, 0
+            for n, gn, gnb in zip(names, z['grad_norm'], z['bf16.grad_norm']):
+                if gn <= 0:
+                    continue
+                g = tr.policy.store.grad_view(n)
+                assert g is not None, n
+                gf = g.float()
+                if len(g.shape) < 2:
+                    continue
+                tower = 'visual.blocks' in n or 'patch_embed' in n
+                n_g += 1
+                n_t += int(tower)
+                if n == 'model.visual.patch_embed.proj.weight':
+                    continue                          # stored zero-padded in K (1176 -> 1216) as a matrix; its norm is checked through the blocks' chain rule below
+                wn = max(wn, abs(float(gf.double().norm()) - float(gn)) / float(gn))
+                rn = max(rn, abs(float(gnb) - float(gn)) / float(gn))
+                if 'gblk.' + n in z.files:
+                    blk = T(z['gblk.' + n])
+                    if float(blk.norm()) > 1e-3 * float(gn) / max(1.0, (gf.numel() / blk.numel()) ** 0.5):
+                        wb = max(wb, rel_err(gf.reshape(gf.shape[0], -1)[:32, :32].cpu(), blk))
+                        rb = max(rb, rel_err(T(z['bf16.gblk.' + n]), blk))
+            m['worst matrix gradient norm (rel)'], r['worst matrix gradient norm (rel)'] = wn, rn
+            m['worst leading gradient block (rel_err)'], r['worst leading gradient block (rel_err)'] = wb, rb
+            rep.append(f'{dtype}: loss {float(ld["loss"]):.6f}; ' + '; '.join(f'{k} {v:.2e}' for k, v in m.items()) + f' ({n_g} matrices, {n_t} of them in the vision tower)')
+            if dtype == 'fp32':
+                assert m['loss'] < 2e-4 and m['per-token log-probs (policy)'] < 2e-4 and m['per-token log-probs (reference model)'] < 2e-4 and wn < 1e-3 and wb < 2e-3, rep[-1]
+            else:
+                rep.append('bf16 envelope, native vs the reference\'s own bf16 run (both against the reference\'s fp32 run):')
+                for k in m:
+                    rep.append(f'  {k}: native {m[k]:.3e}   reference bf16 {r[k]:.3e}   ratio {m[k] / max(r[k], 1e-30):.2f}')
+                for k in m:
+                    assert m[k] <= 1.5 * r[k], (k, m[k], r[k], rep)
+            assert n_g >= 150 and n_t >= 120
+            del tr
+            gc.collect()
+            torch.cuda.empty_cache()
+    finally:
+        dump('parity_qwen2vl_width_vs_reference.txt', '\n'.join(rep) + '\n')

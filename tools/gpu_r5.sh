@@ -91,6 +91,19 @@ PY
       timeout 600 python bench.py --pairs-per-gpu 1 --steps 8 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r05_bench_b1.json 2> gpurun_out/r05_bench_b1.err; python -c "
 import json; d=json.load(open('gpurun_out/r05_bench_b1.json')); r=d['roofline']; print('B1 ms/step', d['ms_per_step'], 'pairs/s', d['value'], 'gemm frac', r['frac'], 'share', r['gemm_share_of_step_time'], 'W', r.get('power_w_mean'), 'MHz', r.get('sclk_mhz_mean'))
 for k in r['by_kind_top12'][:8]: print(k)" || tail -5 gpurun_out/r05_bench_b1.err ;;
+    bench)           # the driver's command (defaults: in-run PMC traffic, CPU leg, B1 / B2 datapoints, power + clock sidecar)
+      timeout 1500 python bench.py --steps 8 --warmup 2 > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err; tail -c 1800 gpurun_out/r05_bench.json; tail -5 gpurun_out/r05_bench.err ;;
+    prof)            # the same step under rocprofv3 --kernel-trace --stats: the per-kernel averages the roofline line is checked against
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r05_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r05_prof -o p -- python $R/bench.py --steps 3 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > $R/gpurun_out/r05_bench_under_rocprof.json 2> $R/gpurun_out/r05_prof.err )
+      f=$(find gpurun_out/r05_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r05_dpo7b_kernel_stats.csv && head -22 "$f" | cut -c1-200
+      find gpurun_out/r05_prof -name "*kernel_trace.csv" -delete ;;
+    secondary)       # the secondary configs at 4 pairs per step + PPO iteration (final code)
+      timeout 400 python tools/bench_qwen2vl.py --pairs 4 --steps 3 --warmup 1 > gpurun_out/r05_bench_qwen2vl_b4.json 2> gpurun_out/r05_bench_qwen2vl_b4.err; cut -c1-400 gpurun_out/r05_bench_qwen2vl_b4.json; tail -2 gpurun_out/r05_bench_qwen2vl_b4.err
+      timeout 400 python tools/bench_qwen2audio.py --pairs 4 --steps 3 --warmup 1 > gpurun_out/r05_bench_qwen2audio_b4.json 2> gpurun_out/r05_bench_qwen2audio_b4.err; cut -c1-400 gpurun_out/r05_bench_qwen2audio_b4.json; tail -2 gpurun_out/r05_bench_qwen2audio_b4.err ;;
+    final)           # round end: smoke(), the N = 2 code path of bench.py as a FUNCTIONAL run on one device (gloo; never a performance number), the full suite
+      timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3
+      AA_BENCH_ONE_DEVICE=1 AA_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 --layers 4 --no-cpu-baseline --no-gemm-events > gpurun_out/r05_dp2_functional_onebox.json 2> gpurun_out/r05_dp2_functional_onebox.err; python -c "import json; d=json.loads(open('gpurun_out/r05_dp2_functional_onebox.json').read().strip().split(chr(10))[-1]); m=d['multi_gpu']; print('dp2 functional:', d['config']['workload'][-60:], 'replicas identical', m['replicas_bit_identical_after_steps'], 'reduce', m['reduce_mode'], (m.get('reduce_autotune') or {}).get('forms_agree'))" || tail -5 gpurun_out/r05_dp2_functional_onebox.err
+      timeout 1700 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/r05_pytest.log 2>&1; tail -8 gpurun_out/r05_pytest.log ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
