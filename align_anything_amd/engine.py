@@ -72,11 +72,7 @@ class GradReducer:
         if n % (8 * w) or flat.data_ptr() % 16:
             return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)      # a ragged slice (never the engine's 64-element-aligned buckets)
         c = n // w
-        recv, mine = self._ws.get(flat.dtype, (None, None))
-        if recv is None or recv.numel() < n:
-            recv = torch.empty(n, dtype=flat.dtype, device=flat.device)
-            mine = torch.empty(-(-n // w), dtype=flat.dtype, device=flat.device)
-            self._ws[flat.dtype] = (recv, mine)
+        recv, mine = self._workspace(flat.dtype, flat.device, n)
         recv, mine = recv[:n], mine[:c]
         if flat.is_cuda:
             dist.all_to_all_single(recv, flat, group=self.group)
@@ -88,6 +84,16 @@ class GradReducer:
             parts = [torch.empty_like(mine).view(torch.uint8) for _ in range(w)]
             dist.all_gather(parts, mine.view(torch.uint8), group=self.group)
             flat.view(torch.uint8).copy_(torch.cat(parts))
+
+    def _workspace(self, dtype, device, n):
+        """(receive buffer [>= n], reduced chunk [>= n / w]) of the direct form, grow-only.  The one step of that form that can fail on ONE rank alone
+        (an allocation), which is why `_autotune` runs it first and lets the ranks agree on it before any rank enters the form's collectives."""
+        recv, mine = self._ws.get(dtype, (None, None))
+        if recv is None or recv.numel() < n:
+            recv = torch.empty(n, dtype=dtype, device=device)
+            mine = torch.empty(-(-n // self.world), dtype=dtype, device=device)
+            self._ws[dtype] = (recv, mine)
+        return recv, mine
 
     def _exchange(self, flat: torch.Tensor):
         if self.mode == 'auto':
@@ -108,18 +114,32 @@ class GradReducer:
         for mode in ('ring', 'direct'):
             buf = src.clone()
             run = (lambda b: self._direct(b)) if mode == 'direct' else (lambda b: dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group))
-            # a form that raises on ONE rank only must not leave that rank out of the timed collectives its peers still issue:
-            # the ranks agree on the warm-up's success (MIN) before anything else of this form runs
+            # a form must never be entered by some ranks only.  Two agreements (MIN over the ranks), each BEFORE the next collective of the form:
+            # (1) what can fail on one rank alone -- the direct form's workspace allocation -- runs first, outside any collective; (2) the warm-up's own
+            # failures are symmetric by construction (a backend without one of the collectives raises on every rank at the same call), and its success is
+            # agreed again before the timed repetitions
+            def agreed(flag: float) -> bool:
+                gt = torch.tensor([flag], device=like.device if like.is_cuda else 'cpu')
+                dist.all_reduce(gt, op=dist.ReduceOp.MIN, group=self.group)
+                return bool(gt.item())
+
+            good = 1.0
+            if mode == 'direct':
+                try:
+                    self._workspace(like.dtype, like.device, n)
+                except RuntimeError as ex:
+                    good = 0.0
+                    self.autotune_report = {**(self.autotune_report or {}), 'error_' + mode: repr(ex)[:200]}
+            if not agreed(good):
+                times[mode], outs[mode] = 1e30, None
+                continue
             try:
-                run(buf)                                   # warm-up (communicator setup, workspaces) and the value check below
+                run(buf)                                   # warm-up (communicator setup) and the value check below
                 outs[mode] = buf.clone()
-                good = 1.0
             except RuntimeError as ex:                   # a backend without one of the collectives: the other form is used
                 good, outs[mode] = 0.0, None
                 self.autotune_report = {**(self.autotune_report or {}), 'error_' + mode: repr(ex)[:200]}
-            gt = torch.tensor([good], device=like.device if like.is_cuda else 'cpu')
-            dist.all_reduce(gt, op=dist.ReduceOp.MIN, group=self.group)
-            if not bool(gt.item()):
+            if not agreed(good):
                 ms, outs[mode] = float('inf'), None
             elif like.is_cuda:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

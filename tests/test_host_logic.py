@@ -1240,3 +1240,29 @@ def test_lr_schedules_equal_transformers_get_scheduler():
                 sch.step()
     with pytest.raises(ValueError, match='not supported'):
         NativeEngine._lr_at(SimpleNamespace(sched='polynomial', base_lr=1.0, warmup_steps=0, total_steps=5), 1)
+
+
+def test_power_sampler_summary_and_header(tmp_path):
+    """tools/power_sampler.py (bench.py's sidecar): `summarise` keeps only the samples inside the timed region and derives the clock-scaled peak; without any
+    SMI source (this container) the sidecar writes a header naming what failed and exits non-zero instead of hanging -- bench.py then reports nulls."""
+    import json
+    import subprocess
+    import sys
+    from tools.power_sampler import summarise
+    f = tmp_path / 's.jsonl'
+    rows = [{'header': {'source': 'amdsmi', 'errors': {}, 'hz': 20.0}}] + \
+           [{'t': 100.0 + 0.05 * i, 'power_w': 1000.0 + i, 'sclk_mhz': 1800.0 + 10 * (i % 3)} for i in range(40)]
+    f.write_text('\n'.join(json.dumps(r) for r in rows) + '\nnot json\n')
+    s = summarise(str(f), 100.5, 101.0, peak_tflops=2500.0)
+    inside = [r for r in rows[1:] if 100.5 <= r['t'] <= 101.0]
+    assert s['power_samples'] == len(inside) == s['sclk_samples'] and s['power_source'] == 'amdsmi'
+    assert abs(s['power_w_mean'] - sum(r['power_w'] for r in inside) / len(inside)) < 1e-9 and s['power_w_max'] == max(r['power_w'] for r in inside)
+    assert abs(s['peak_at_sclk'] - 2500.0 * s['sclk_mhz_mean'] / 2400.0) < 1e-9 and s['sclk_mhz_min'] == 1800.0
+    empty = summarise(str(f), 500.0, 501.0)
+    assert empty['power_w_mean'] is None and empty['sclk_mhz_mean'] is None and 'peak_at_sclk' not in empty
+    assert summarise(str(tmp_path / 'missing.jsonl'), 0, 1)['power_w_mean'] is None
+    out = tmp_path / 'live.jsonl'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'power_sampler.py'), '--out', str(out), '--seconds', '0.2'], timeout=60)
+    hdr = json.loads(out.read_text().split('\n')[0])['header']
+    if hdr['source'] is None:          # no GPU here: every source reports why
+        assert r.returncode != 0 and set(hdr['errors']) == {'amdsmi', 'sysfs', 'smi'}

@@ -104,6 +104,8 @@ for k in r['by_kind_top12'][:8]: print(k)" || tail -5 gpurun_out/r05_bench_b1.er
       timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3
       AA_BENCH_ONE_DEVICE=1 AA_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 --layers 4 --no-cpu-baseline --no-gemm-events > gpurun_out/r05_dp2_functional_onebox.json 2> gpurun_out/r05_dp2_functional_onebox.err; python -c "import json; d=json.loads(open('gpurun_out/r05_dp2_functional_onebox.json').read().strip().split(chr(10))[-1]); m=d['multi_gpu']; print('dp2 functional:', d['config']['workload'][-60:], 'replicas identical', m['replicas_bit_identical_after_steps'], 'reduce', m['reduce_mode'], (m.get('reduce_autotune') or {}).get('forms_agree'))" || tail -5 gpurun_out/r05_dp2_functional_onebox.err
       timeout 1700 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/r05_pytest.log 2>&1; tail -8 gpurun_out/r05_pytest.log ;;
+    qwen2vl_width)   # BASELINE configs[2]'s backbone at width vs the reference trainer's fixture
+      timeout 900 python -m pytest tests/test_qwen2vl_gpu.py -q -x -m gpu -p no:cacheprovider -k "width_pair" > gpurun_out/r05_qwen2vl_width.log 2>&1; echo "rc=$?"; tail -12 gpurun_out/r05_qwen2vl_width.log | cut -c1-400; cat gpurun_out/parity_qwen2vl_width_vs_reference.txt | cut -c1-400 ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
