@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import _shim  # noqa: E402
-from oracle.synthetic import StubProcessor, llama31_width, llava7b_width, opt125m_config1, preference_samples, qwen2vl_width  # noqa: E402
+from oracle.synthetic import StubProcessor, llama31_width, llava7b_width, opt125m_config1, preference_samples, qwen2audio_width, qwen2vl_width, qwen3moe_width  # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
@@ -1315,6 +1315,84 @@ def gen_qwen2vl_width(dtypes=None):
         gc.collect()
     np.savez_compressed(path, **{**prev, **out})
     print('qwen2vl_width_dpo.npz', len(out), f'arrays ({time.time() - t0:.0f}s)')
+
+
+def _gen_width(name, build, model_cls, trainer_mod, dtypes, float_keys=(), block_filter=None):
+    """Common body of the full-width fixtures whose models do not fit the build container twice (one precision per process: the fp32 pass writes the file, the
+    bf16 pass adds its `bf16.*` arrays): the reference's unmodified DPOTrainer.{compute_log_probs, loss} of `trainer_mod` + backward on the pair `build()` returns,
+    every parameter training.  Stored: ids / masks, both log-prob tensors, the six loss outputs, per-parameter gradient norms, the leading 32 x 32 block of every
+    matrix gradient `block_filter` keeps, per-tensor weight checksums."""
+    import gc
+    import importlib
+    import time
+    path = os.path.join(GOLD, name + '.npz')
+    if dtypes is None:
+        import subprocess
+        for dt in ('fp32', 'bf16'):
+            subprocess.run([sys.executable, '-c', f"from oracle import _shim; _shim.install(); import oracle.gen_golden as g; g.gen_{name.replace('_dpo', '')}(('{dt}',))"], check=True, cwd=ROOT)
+        return
+    from align_anything.utils.tools import dict_to_namedtuple
+    DPOTrainer = importlib.import_module(trainer_mod).DPOTrainer
+    t0 = time.time()
+    cfg, sd, ref_sd, batch, PAD = build()
+    prev = dict(np.load(path)) if (os.path.exists(path) and 'fp32' not in dtypes) else {}
+    out = {'input_ids': batch['input_ids'].numpy(), 'attention_mask': batch['attention_mask'].numpy(), 'response_lens': np.array(batch['meta_info']['response_lens']),
+           'pad_token_id': np.array(PAD), 'scale_coeff': np.array(0.1)}
+    for dt in dtypes:
+        policy, refm = model_cls(cfg).eval(), model_cls(cfg).eval()
+        assert policy.load_state_dict(sd, strict=True) and refm.load_state_dict(ref_sd, strict=True)
+        if dt == dtypes[-1]:
+            sd = ref_sd = None                              # 2 x 11 GB the build container needs for the gradients and the saved activations
+            gc.collect()
+        b = dict(batch)
+        if dt == 'bf16':
+            policy, refm = policy.to(torch.bfloat16), refm.to(torch.bfloat16)
+            for k in float_keys:
+                b[k] = batch[k].to(torch.bfloat16)
+        tr = DPOTrainer.__new__(DPOTrainer)
+        tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+        tr.tokenizer = SimpleNamespace(pad_token_id=PAD)
+        tr.infer_batch = lambda bb: {k: v for k, v in bb.items() if k != 'meta_info'}
+        tr.model, tr.reference_model = SimpleNamespace(module=policy), SimpleNamespace(module=refm)
+        seq_lp = tr.compute_log_probs(policy, b).detach()
+        ref_lp = tr.compute_log_probs(refm, b).detach()
+        ld = tr.loss(b)
+        ld['loss'].backward()
+        print(f'{name} {dt}: reference loss {float(ld["loss"]):.6f} margin {ld["reward_margin"].float().tolist()} ({time.time() - t0:.0f}s)', flush=True)
+        px = '' if dt == 'fp32' else 'bf16.'
+        out[px + 'seq_log_probs'], out[px + 'ref_seq_log_probs'] = seq_lp.float().numpy(), ref_lp.float().numpy()
+        for k, v in ld.items():
+            out[px + 'loss_' + k] = v.detach().float().numpy()
+        names, gnorm = [], []
+        for n, p in policy.named_parameters():
+            names.append(n)
+            gnorm.append(float(p.grad.double().norm()) if p.grad is not None else -1.0)
+            if p.grad is not None and p.dim() >= 2 and (block_filter is None or block_filter(n)):
+                out[px + 'gblk.' + n] = p.grad.float().reshape(p.grad.shape[0], -1)[:32, :32].contiguous().numpy()
+        out[px + 'grad_norm'] = np.array(gnorm)
+        if dt == 'fp32':
+            rparams = dict(refm.named_parameters())
+            out.update(names=np.array(names), weight_checksum=np.array([float(p.double().sum()) for _, p in policy.named_parameters()]),
+                       ref_weight_checksum=np.array([float(rparams[n].double().sum()) for n in names]))
+        del policy, refm, tr
+        gc.collect()
+    np.savez_compressed(path, **{**prev, **out})
+    print(name + '.npz', len(out), f'arrays ({time.time() - t0:.0f}s)')
+
+
+def gen_qwen2audio_width(dtypes=None):
+    """BASELINE configs[3]'s backbone pinned to the reference at full width (round 5): trainers/text_audio_to_text/dpo.py:86-166 on oracle.synthetic.qwen2audio_width
+    -- the whole 32-layer audio encoder on one 30 s clip (750 audio tokens), projector, 4 decoder layers of 4096 / 11008, the 156032-row head."""
+    from transformers import Qwen2AudioForConditionalGeneration
+    _gen_width('qwen2audio_width_dpo', qwen2audio_width, Qwen2AudioForConditionalGeneration, 'align_anything.trainers.text_audio_to_text.dpo', dtypes,
+               float_keys=('input_features',), block_filter=lambda n: 'audio_tower.layers' not in n or any(f'layers.{i}.' in n for i in (0, 15, 31)))
+
+
+def gen_qwen3moe_width(dtypes=None):
+    """BASELINE configs[4]'s backbone pinned to the reference at full width (round 5): trainers/text_to_text/dpo.py:122-203 on oracle.synthetic.qwen3moe_width --
+    2 sparse layers of the Qwen3-30B-A3B geometry with ALL 128 experts (top-8, normalised), per-head q / k norms, GQA 32 / 4, the 151936-row head."""
+    from transformers import Qwen3MoeForCausalLM
+    _gen_width('qwen3moe_width_dpo', qwen3moe_width, Qwen3MoeForCausalLM, 'align_anything.trainers.text_to_text.dpo', dtypes)
 
 
 def _opt125m_reference_trainer(nthreads):

@@ -232,3 +232,97 @@ def qwen2vl_width(num_layers=4, vision_depth=32, T=320, R=48, left_pad=(0, 17), 
     batch = {'input_ids': ids, 'attention_mask': mask, 'pixel_values': torch.cat([pix, pix], 0), 'image_grid_thw': torch.tensor([list(grid), list(grid)]),
              'mm_token_type_ids': (ids == IMG).int(), 'meta_info': {'response_lens': [R - lp for lp in left_pad]}}
     return cfg, sd, ref_sd, batch, PAD
+
+
+def _seeded_state(skel, seed, frozen_like=(), norm_like=('norm', 'layer_norm', 'ln_')):
+    """Every parameter of a meta-device skeleton from its OWN generator (seed, crc32(name)): matrices / embeddings / biases N(0, 0.02), norm weights
+    1 + N(0, 0.1), bf16-representable; reference model = policy + N(0, 2e-3) on every matrix whose name holds none of `frozen_like`."""
+    import zlib
+    sd, ref_sd = {}, {}
+    for n, p in skel.named_parameters():
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(n.encode())) % (1 << 62))
+        norm = p.dim() == 1 and any(t in n for t in norm_like) and n.endswith('weight')
+        w = torch.randn(tuple(p.shape), generator=g) * (0.1 if norm else 0.02) + (1.0 if norm else 0.0)
+        sd[n] = w.to(torch.bfloat16).to(torch.float32)
+        if p.dim() >= 2 and not any(t in n for t in frozen_like):
+            ref_sd[n] = (sd[n] + 2e-3 * torch.randn(tuple(p.shape), generator=g)).to(torch.bfloat16).to(torch.float32)
+        else:
+            ref_sd[n] = sd[n]
+    return sd, ref_sd
+
+
+def qwen2audio_width_config(num_layers=4, encoder_layers=32):
+    """Qwen/Qwen2-Audio-7B-Instruct's geometry (BASELINE configs[3]) with `num_layers` decoder layers: text 4096 / 11008, 32 heads x 128 (MHA), vocabulary
+    156032; audio encoder at FULL depth and width (32 layers of 1280, 20 heads of 64, ffn 5120, 128 mel bins, 1500 source positions -> 750 audio tokens per
+    30 s clip)."""
+    from transformers import Qwen2AudioConfig
+    return Qwen2AudioConfig(
+        audio_config=dict(num_mel_bins=128, encoder_layers=encoder_layers, encoder_attention_heads=20, encoder_ffn_dim=5120, d_model=1280, max_source_positions=1500),
+        text_config=dict(model_type='qwen2', hidden_size=4096, intermediate_size=11008, num_hidden_layers=num_layers, num_attention_heads=32,
+                         num_key_value_heads=32, vocab_size=156032, max_position_embeddings=8192, rms_norm_eps=1e-5, rope_theta=10000.0, tie_word_embeddings=False),
+        audio_token_id=151646)
+
+
+def qwen2audio_width(num_layers=4, encoder_layers=32, T=896, R=48, left_pad=(0, 21), frames=3000, seed=45):
+    """One preference pair at the FULL WIDTH of BASELINE configs[3]'s backbone (see llava7b_width for the recipe): one 30 s clip (`frames` mel frames -> 750
+    audio tokens) shared by the chosen and the rejected row as the reference's collator stacks it; the rejected row left-padded.  Returns
+    (Qwen2AudioConfig, policy state dict, reference state dict, batch, pad id)."""
+    from transformers import Qwen2AudioForConditionalGeneration
+    cfg = qwen2audio_width_config(num_layers, encoder_layers)
+    with torch.device('meta'):
+        skel = Qwen2AudioForConditionalGeneration(cfg)
+    sd, ref_sd = _seeded_state(skel, seed, frozen_like=('embed_positions',))
+    gb = torch.Generator().manual_seed(seed + 2)
+    PAD, AUD, N = 151643, 151646, 2
+    olen = ((frames - 1) // 2 + 1 - 2) // 2 + 1
+    ids = torch.full((N, T), PAD, dtype=torch.long)
+    mask = torch.zeros((N, T), dtype=torch.long)
+    prompt = torch.randint(3, 151000, (T - 2 - olen - R,), generator=gb)
+    for r in range(N):
+        lp = left_pad[r]
+        resp = torch.randint(3, 151000, (R - lp,), generator=gb)
+        ids[r, lp:] = torch.cat([torch.tensor([151644]), torch.full((olen,), AUD), torch.tensor([151645]), prompt, resp])
+        mask[r, lp:] = 1
+    feat = torch.randn(1, 128, 3000, generator=gb)
+    fmask = torch.zeros(1, 3000, dtype=torch.long)
+    fmask[0, :frames] = 1
+    feat[0, :, frames:] = 0.0
+    batch = {'input_ids': ids, 'attention_mask': mask, 'input_features': torch.cat([feat, feat], 0), 'feature_attention_mask': torch.cat([fmask, fmask], 0),
+             'meta_info': {'response_lens': [R - lp for lp in left_pad]}}
+    return cfg, sd, ref_sd, batch, PAD
+
+
+def qwen3moe_width_config(num_layers=2):
+    """Qwen/Qwen3-30B-A3B's layer geometry (BASELINE configs[4]) with `num_layers` sparse layers: hidden 2048, 128 experts of width 768 with top-8 routing
+    (normalised), 32 query / 4 kv heads of 128 with per-head q / k norms, vocabulary 151936, rope theta 1e6."""
+    from transformers import Qwen3MoeConfig
+    return Qwen3MoeConfig(hidden_size=2048, intermediate_size=6144, moe_intermediate_size=768, num_hidden_layers=num_layers, num_attention_heads=32,
+                          num_key_value_heads=4, head_dim=128, vocab_size=151936, num_experts=128, num_experts_per_tok=8, norm_topk_prob=True,
+                          max_position_embeddings=40960, rms_norm_eps=1e-6, rope_parameters={'rope_type': 'default', 'rope_theta': 1000000.0},
+                          tie_word_embeddings=False, pad_token_id=151643)
+
+
+def qwen3moe_width(num_layers=2, T=320, R=48, left_pad=(0, 19), seed=46):
+    """One preference pair at the FULL WIDTH of BASELINE configs[4]'s backbone (all 128 experts per layer; recipe of llava7b_width).  The router matrices are
+    drawn wider (N(0, 0.2)) so that the top-8 cut is not a field of near-ties: which experts a token visits is then a property of the model, not of the last
+    bit of a dot product.  Returns (Qwen3MoeConfig, policy state dict, reference state dict, batch, pad id)."""
+    from transformers import Qwen3MoeForCausalLM
+    cfg = qwen3moe_width_config(num_layers)
+    with torch.device('meta'):
+        skel = Qwen3MoeForCausalLM(cfg)
+    sd, ref_sd = _seeded_state(skel, seed)
+    for n in sd:
+        if n.endswith('mlp.gate.weight'):
+            sd[n] = (sd[n] * 10.0).to(torch.bfloat16).to(torch.float32)
+            ref_sd[n] = sd[n]                      # the frozen model routes like the policy (its other matrices differ)
+    gb = torch.Generator().manual_seed(seed + 2)
+    PAD, N = 151643, 2
+    ids = torch.full((N, T), PAD, dtype=torch.long)
+    mask = torch.zeros((N, T), dtype=torch.long)
+    prompt = torch.randint(3, 151000, (T - R,), generator=gb)
+    for r in range(N):
+        lp = left_pad[r]
+        resp = torch.randint(3, 151000, (R - lp,), generator=gb)
+        ids[r, lp:] = torch.cat([prompt, resp])
+        mask[r, lp:] = 1
+    return cfg, sd, ref_sd, {'input_ids': ids, 'attention_mask': mask, 'meta_info': {'response_lens': [R - lp for lp in left_pad]}}, PAD

@@ -107,3 +107,17 @@ def test_conv1d_and_avgpool_kernels_vs_torch():
     assert rel_err(p[:37].cpu(), 0.5 * (y[0::2] + y[1::2])) < 1e-6
     back = ops.avgpool2(p, 37, backward=True)
     assert rel_err(back[:74].cpu(), (0.5 * p[:37].cpu()).repeat_interleave(2, 0)) < 1e-6
+
+
+def test_qwen2audio_width_pair_vs_the_reference_trainer():
+    """BASELINE configs[3]'s backbone pinned to the reference at FULL WIDTH (round 5).  tests/golden/qwen2audio_width_dpo.npz: the UNMODIFIED text+audio DPOTrainer
+    (trainers/text_audio_to_text/dpo.py:86-166: compute_log_probs, loss, then backward) on oracle.synthetic.qwen2audio_width in the build container -- the whole
+    32-layer audio encoder (1280 wide, 20 heads) on one 30 s clip = 750 audio tokens, the projector, 4 decoder layers of 4096 / 11008, the 156032-row head; one
+    left-padded pair, the audio tower training (configs/train/text_audio_to_text/dpo.yaml:63) -- in fp32 and in the reference's own bf16.  Bounds: tests/width_parity.py."""
+    from oracle.synthetic import qwen2audio_width
+    from tests.util import load_golden
+    from tests.width_parity import width_parity
+    z = load_golden('qwen2audio_width_dpo.npz')
+    hc, sd, ref_sd, batch, PAD = qwen2audio_width()
+    width_parity(z, hc, sd, ref_sd, batch, PAD, 'parity_qwen2audio_width_vs_reference.txt', float_keys=('input_features',),
+                 batch_keys=('feature_attention_mask',), min_matrices=150)

@@ -343,3 +343,16 @@ def test_capacity_padded_expert_parallel_block_never_reads_the_device():
     finally:
         if own:
             dist.destroy_process_group()
+
+
+def test_qwen3moe_width_pair_vs_the_reference_trainer():
+    """BASELINE configs[4]'s backbone pinned to the reference at FULL WIDTH (round 5).  tests/golden/qwen3moe_width_dpo.npz: the UNMODIFIED text-to-text DPOTrainer
+    (trainers/text_to_text/dpo.py:122-203) on oracle.synthetic.qwen3moe_width in the build container -- 2 sparse layers of the Qwen3-30B-A3B geometry with all 128
+    experts (top-8 of 128, normalised weights), per-head q / k norms, GQA 32 / 4, the 151936-row head; one left-padded pair -- in fp32 and in the reference's own
+    bf16.  The native path: device-side routing + expert-major plan + row-grouped expert GEMMs.  Bounds: tests/width_parity.py."""
+    from oracle.synthetic import qwen3moe_width
+    from tests.util import load_golden
+    from tests.width_parity import width_parity
+    z = load_golden('qwen3moe_width_dpo.npz')
+    hc, sd, ref_sd, batch, PAD = qwen3moe_width()
+    width_parity(z, hc, sd, ref_sd, batch, PAD, 'parity_qwen3moe_width_vs_reference.txt', min_matrices=14)

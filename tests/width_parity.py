@@ -1,0 +1,91 @@
+"""Shared body of the full-WIDTH parity tests against the reference trainer's fixtures (tests/golden/*_width_dpo.npz, oracle/gen_golden.py::gen_*_width):
+the native DPO pair -- fp32 twin and bf16 production path -- against the reference's fp32 run, with the bf16 path held to the envelope DERIVED from the
+reference's OWN bf16 run of the same fixture (native-bf16-vs-fp32 <= 1.5 x reference-bf16-vs-fp32, per quantity)."""
+import gc
+
+import numpy as np
+import torch
+
+from tests.gpu_util import dev, dump
+from tests.util import rel_err
+
+
+def width_parity(z, hf_config, sd, ref_sd, batch, pad_token_id, report, *, extra_train_cfgs=None, trainer_kwargs=None, batch_keys=(), float_keys=(),
+                 skip_norm_of=(), min_matrices=29, fp32_bounds=(2e-4, 2e-4, 1e-3, 2e-3)):
+    """z: the fixture; (hf_config, sd, ref_sd, batch): the regenerated model / pair (oracle.synthetic.*_width); batch_keys: extra batch entries handed to the
+    trainer as they are (grids, masks); float_keys: batch entries cast to the compute dtype (pixels, mel features); skip_norm_of: parameters whose stored
+    layout differs from HF's (norm compared through the others).  fp32_bounds: loss & log-probs abs, (unused), gradient-norm rel, leading-block rel_err."""
+    from align_anything_amd import configs
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    T = torch.from_numpy
+    names = [str(n) for n in z['names']]
+    for n, c, rc in zip(names, z['weight_checksum'], z['ref_weight_checksum']):       # the identical weights were regenerated from the seed
+        assert abs(float(sd[n].double().sum()) - float(c)) <= 1e-9 * max(1.0, abs(float(c))), n
+        assert abs(float(ref_sd[n].double().sum()) - float(rc)) <= 1e-9 * max(1.0, abs(float(rc))), n
+    assert np.array_equal(batch['input_ids'].numpy(), z['input_ids'])
+    cfg = configs.from_hf_config(hf_config)
+    want_lp, want_ref = T(z['seq_log_probs']), T(z['ref_seq_log_probs'])
+    rep = [f'reference trainer (fp32, CPU): loss {float(z["loss_loss"]):.6f} margin {z["loss_reward_margin"].tolist()} summed log-probs {want_lp.sum(1).tolist()}']
+    try:
+        for dtype in ('fp32', 'bf16'):
+            tc = {'scale_coeff': float(z['scale_coeff']), 'learning_rate': 1e-6, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'compute_dtype': dtype}
+            tc.update(extra_train_cfgs or {})
+            tr = DPOTrainer({'train_cfgs': tc, 'model_cfgs': {'pad_token_id': int(pad_token_id)}}, {'gradient_clipping': 1.0}, model_cfg=cfg, policy_state=sd,
+                            reference_state=ref_sd, device='cuda:0', **(trainer_kwargs or {}))
+            b = {'input_ids': batch['input_ids'].to(dev()), 'attention_mask': batch['attention_mask'].to(dev()), 'meta_info': batch['meta_info']}
+            for k in batch_keys:
+                b[k] = batch[k]
+            for k in float_keys:
+                b[k] = batch[k].to(dev()).to(torch.float32 if dtype == 'fp32' else torch.bfloat16)
+            lp = tr.compute_log_probs(tr.model, b).cpu()
+            rlp = tr.compute_log_probs(tr.reference_model, b).cpu()
+            assert torch.equal(lp == 0, want_lp == 0), 'response-window layout differs from the reference'
+            ld = tr.loss(b)
+            tr.model.backward(ld['loss'])
+            torch.cuda.synchronize()
+            m = {'loss': abs(float(ld['loss']) - float(z['loss_loss'])),
+                 'margin': float((ld['reward_margin'].float().cpu().reshape(-1) - T(z['loss_reward_margin']).reshape(-1)).abs().max()),
+                 'per-token log-probs (policy)': float((lp - want_lp).abs().max()), 'per-token log-probs (reference model)': float((rlp - want_ref).abs().max()),
+                 'summed log-probs': float((lp.sum(1) - want_lp.sum(1)).abs().max())}
+            r = {'loss': abs(float(z['bf16.loss_loss']) - float(z['loss_loss'])),
+                 'margin': float(np.abs(z['bf16.loss_reward_margin'].reshape(-1) - z['loss_reward_margin'].reshape(-1)).max()),
+                 'per-token log-probs (policy)': float(np.abs(z['bf16.seq_log_probs'] - z['seq_log_probs']).max()),
+                 'per-token log-probs (reference model)': float(np.abs(z['bf16.ref_seq_log_probs'] - z['ref_seq_log_probs']).max()),
+                 'summed log-probs': float(np.abs(z['bf16.seq_log_probs'].sum(1) - z['seq_log_probs'].sum(1)).max())}
+            wn, wb, rn, rb, n_g = 0.0, 0.0, 0.0, 0.0, 0
+            for n, gn, gnb in zip(names, z['grad_norm'], z['bf16.grad_norm']):
+                if gn <= 0:
+                    continue
+                g = tr.policy.store.grad_view(n)
+                assert g is not None, n
+                if len(g.shape) < 2:
+                    continue
+                gf = g.float()
+                n_g += 1
+                if n in skip_norm_of:
+                    continue
+                wn = max(wn, abs(float(gf.double().norm()) - float(gn)) / float(gn))
+                rn = max(rn, abs(float(gnb) - float(gn)) / float(gn))
+                if 'gblk.' + n in z.files:
+                    blk = T(z['gblk.' + n])
+                    if float(blk.norm()) > 1e-3 * float(gn) / max(1.0, (gf.numel() / blk.numel()) ** 0.5):
+                        wb = max(wb, rel_err(gf.reshape(gf.shape[0], -1)[:32, :32].cpu(), blk))
+                        rb = max(rb, rel_err(T(z['bf16.gblk.' + n]), blk))
+            m['worst matrix gradient norm (rel)'], r['worst matrix gradient norm (rel)'] = wn, rn
+            m['worst leading gradient block (rel_err)'], r['worst leading gradient block (rel_err)'] = wb, rb
+            rep.append(f'{dtype}: loss {float(ld["loss"]):.6f}; ' + '; '.join(f'{k} {v:.2e}' for k, v in m.items()) + f' ({n_g} matrices)')
+            if dtype == 'fp32':
+                assert m['loss'] < fp32_bounds[0] and m['per-token log-probs (policy)'] < fp32_bounds[1] and m['per-token log-probs (reference model)'] < fp32_bounds[1] \
+                    and wn < fp32_bounds[2] and wb < fp32_bounds[3], rep[-1]
+            else:
+                rep.append('bf16 envelope, native vs the reference\'s own bf16 run (both against the reference\'s fp32 run):')
+                for k in m:
+                    rep.append(f'  {k}: native {m[k]:.3e}   reference bf16 {r[k]:.3e}   ratio {m[k] / max(r[k], 1e-30):.2f}')
+                for k in m:
+                    assert m[k] <= 1.5 * r[k], (k, m[k], r[k], rep)
+            assert n_g >= min_matrices, n_g
+            del tr
+            gc.collect()
+            torch.cuda.empty_cache()
+    finally:
+        dump(report, '\n'.join(rep) + '\n')

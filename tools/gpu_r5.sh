@@ -106,6 +106,9 @@ for k in r['by_kind_top12'][:8]: print(k)" || tail -5 gpurun_out/r05_bench_b1.er
       timeout 1700 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/r05_pytest.log 2>&1; tail -8 gpurun_out/r05_pytest.log ;;
     qwen2vl_width)   # BASELINE configs[2]'s backbone at width vs the reference trainer's fixture
       timeout 900 python -m pytest tests/test_qwen2vl_gpu.py -q -x -m gpu -p no:cacheprovider -k "width_pair" > gpurun_out/r05_qwen2vl_width.log 2>&1; echo "rc=$?"; tail -12 gpurun_out/r05_qwen2vl_width.log | cut -c1-400; cat gpurun_out/parity_qwen2vl_width_vs_reference.txt | cut -c1-400 ;;
+    widths)          # the configs[3] / [4] backbones at width vs the reference trainer's fixtures
+      timeout 1200 python -m pytest tests/test_qwen2audio_gpu.py tests/test_qwen3moe_gpu.py -q -m gpu -p no:cacheprovider -k "width_pair" > gpurun_out/r05_widths.log 2>&1; echo "rc=$?"; tail -14 gpurun_out/r05_widths.log | cut -c1-400
+      cat gpurun_out/parity_qwen2audio_width_vs_reference.txt gpurun_out/parity_qwen3moe_width_vs_reference.txt | cut -c1-400 ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
