@@ -379,9 +379,12 @@ class NativeEngine:
 
     def step(self):
         """Clip + AdamW.  On a GPU the optimizer kernels (HBM-bound, ~28 B/param) are enqueued on a side HIP
-        stream so they overlap with whatever the main stream does next that does not touch the policy -- in the
-        DPO step that is the (MFMA-bound) reference forward of the NEXT batch.  `wait_optimizer()` is the
-        join; the trainer calls it before the next policy forward, and every reader of the weights goes through it."""
+        stream so that they MAY overlap with whatever the main stream does next that does not touch the policy (the
+        reference forward of the next batch).  Measured (profiles/r05_adam_window.txt): on the dense path they overlap
+        with nothing -- a gemm4 workgroup needs whole SIMD register files and cannot start while AdamW's waves sit on
+        every compute unit, so the step is the same with the update on the main stream (743 - 749 ms either way); what
+        does co-run are small-register kernels (vision towers, the MoE stack's 8-wave grouped GEMMs).  `wait_optimizer()`
+        is the join; the trainer calls it before the next policy forward, and every reader of the weights goes through it."""
         st = self.module.store
         if self.micro_steps % self.gas != 0:
             return  # not at a gradient-accumulation boundary (DeepSpeedEngine.step semantics)
