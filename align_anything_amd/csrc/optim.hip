@@ -154,21 +154,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
     if (gs < 0.f) return;          // clip_coef_kernel's skip sentinel: this step's update is dropped on every rank
     const float inv_bc1 = 1.f / bc1, inv_bc2 = 1.f / bc2;
     const long n4 = n >> 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        f32x4 pw = *reinterpret_cast<const f32x4*>(master + i * 4);
-        f32x4 mm = *reinterpret_cast<const f32x4*>(m + i * 4);
-        f32x4 vv = *reinterpret_cast<const f32x4*>(v + i * 4);
-        float gg[4];
-        if constexpr (sizeof(TG) == 2) {
-            u16x4 gr = *reinterpret_cast<const u16x4*>(g + i * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) gg[j] = bf2f(gr[j]) * gs;
-        } else {
-            f32x4 gr = *reinterpret_cast<const f32x4*>(g + i * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) gg[j] = gr[j] * gs;
-        }
-        u16x4 o;
+    // Round 5: every operand is touched exactly once per step (189 GB at 7B: nothing here is worth a cache line) -> nontemporal loads and stores, and TWO
+    // independent 16-element groups per thread and iteration (all eight loads requested before the first use).  Same expressions per element (the compiler's fma
+    // contraction may differ by an ulp from round 4's loop shape).  Same box, alternating: 7.79 / 7.83 -> 7.40 / 7.68 ms per 1.6 G elements (5.78 -> 5.98 TB/s);
+    // the step at 1 pair 218.8 -> 217.6 ms, at 4 pairs inside the noise (the update is fully exposed either way: profiles/r05_adam_window.txt).
+    auto update4 = [&](f32x4& pw, f32x4& mm, f32x4& vv, const float (&gg)[4], u16x4& o) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             mm[j] = b1 * mm[j] + (1.f - b1) * gg[j];
@@ -178,10 +168,41 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
             pw[j] = pw[j] - lr * upd;
             o[j] = f2bf(pw[j]);
         }
-        *reinterpret_cast<f32x4*>(master + i * 4) = pw;
-        *reinterpret_cast<f32x4*>(m + i * 4) = mm;
-        *reinterpret_cast<f32x4*>(v + i * 4) = vv;
-        if (p16) *reinterpret_cast<u16x4*>(p16 + i * 4) = o;
+    };
+    const long stride = (long)gridDim.x * 256;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+        const long i1 = i0 + stride;
+        const bool two = i1 < n4;
+        f32x4 pw[2], mm[2], vv[2];
+        float gg[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const long i = u ? i1 : i0;
+            pw[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(master + i * 4));
+            mm[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + i * 4));
+            vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + i * 4));
+            if constexpr (sizeof(TG) == 2) {
+                const u16x4 gr = __builtin_nontemporal_load(reinterpret_cast<const u16x4*>(g + i * 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gg[u][j] = bf2f(gr[j]) * gs;
+            } else {
+                const f32x4 gr = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i * 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gg[u][j] = gr[j] * gs;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const long i = u ? i1 : i0;
+            u16x4 o;
+            update4(pw[u], mm[u], vv[u], gg[u], o);
+            __builtin_nontemporal_store(pw[u], reinterpret_cast<f32x4*>(master + i * 4));
+            __builtin_nontemporal_store(mm[u], reinterpret_cast<f32x4*>(m + i * 4));
+            __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v + i * 4));
+            if (p16) __builtin_nontemporal_store(o, reinterpret_cast<u16x4*>(p16 + i * 4));
+        }
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float gq;
