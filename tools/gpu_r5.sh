@@ -1,26 +1,11 @@
 #!/bin/bash
-# Round-5 GPU stages, prepared at the end of round 4 (whose GPU budget was spent).  Usage on the GPU box: bash tools/gpu_r5.sh <stage> [<stage> ...]
-#   unvalidated        the tests written after round 4's last GPU call (tests/test_zzz_unvalidated_gpu.py): tied embeddings + llama3 RoPE vs HF,
-#                      the persistent per-layer decode kernel vs the per-step launches.  Run FIRST; every stage below assumes it is green.
-#                      The layer kernel's grid barriers are bounded (0.2 s) -- still, the whole stage runs under `timeout`.
-#   decode_persistent  same-box A/B of AA_DECODE_PERSISTENT = 0 / 1 (one launch per layer) / 2 (one launch per position) on the PPO iteration (tools/bench_ppo.py), alternating runs
-#   decode_trace       kernel trace of the decode window with the layer kernel on (launches per position, per-kernel split)
+# Round-5 GPU stages.  Usage on the GPU box: bash tools/gpu_r5.sh <stage> [<stage> ...]; every stage writes under gpurun_out/ (merged back by gpurun).
+# The stages of experiments that were measured and removed again (persistent decode, sampler unroll, tower prefetch, MoE dW on the gemm4 tile, the AdamW lab A/B)
+# went with their code: their numbers are in profiles/r05_*_negative.txt / r05_adam_window.txt, their commands in git history.
 R=$(cd "$(dirname "$0")/.." && pwd); cd "$R"; mkdir -p gpurun_out
 for stage in "$@"; do
   echo "=== stage $stage  $(date +%T)"
   case $stage in
-    unvalidated)
-      AA_GPU_UNVALIDATED=1 timeout 420 python -m pytest tests/test_zzz_unvalidated_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r05_unvalidated.log 2>&1; echo "rc=$?"; tail -15 gpurun_out/r05_unvalidated.log | cut -c1-300 ;;
-    decode_persistent)
-      for f in 0 1 2 0 1 2; do
-        AA_DECODE_PERSISTENT=$f timeout 200 python tools/bench_ppo.py --iters 2 > gpurun_out/r05_bench_ppo_persistent$f.json 2> gpurun_out/r05_bench_ppo_persistent$f.err
-        python -c "import json; d=json.load(open('gpurun_out/r05_bench_ppo_persistent$f.json')); print('persistent $f', round(d['decode_ms_per_position'],4), 'ms/pos', round(d['iteration_ms'],1), 'ms/iter')" || tail -3 gpurun_out/r05_bench_ppo_persistent$f.err
-      done ;;
-    decode_trace)
-      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r05_ppo_prof && AA_DECODE_PERSISTENT=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r05_ppo_prof -o p -- python $R/tools/bench_ppo.py --iters 1 --new-tokens 128 > $R/gpurun_out/r05_bench_ppo_under_rocprof.json 2> $R/gpurun_out/r05_ppo_prof.err )
-      t=$(find gpurun_out/r05_ppo_prof -name "*kernel_trace.csv" | head -1)
-      [ -n "$t" ] && python3 tools/decode_trace_summary.py "$t" > gpurun_out/r05_decode_trace_summary.txt; cut -c1-200 gpurun_out/r05_decode_trace_summary.txt
-      find gpurun_out/r05_ppo_prof -name "*kernel_trace.csv" -delete ;;
     attn_pmc_instep)   # clock-vs-fabric for the in-step attention kernels: GRBM_GUI_ACTIVE + SQ_BUSY_CYCLES (effective clock = cycles / trace duration) and FETCH_SIZE, three separate --pmc passes over the bench step itself
       ( cd /tmp && export TMPDIR=/tmp
         for set in "GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES" "FETCH_SIZE"; do
@@ -73,7 +58,7 @@ for k, v in acc.items():
 PY
           find $R/gpurun_out/r05_pmc_attn$v -name "*.csv" -size +4M -delete
         done ) ;;
-    decode)          # sampler with 8 loads in flight: the decode / sampling tests and the PPO iteration
+    decode)          # the decode / sampling tests and the PPO iteration
       timeout 900 python -m pytest tests/test_decode_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r05_decode_tests.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/r05_decode_tests.log | cut -c1-300
       timeout 300 python tools/bench_ppo.py --iters 2 > gpurun_out/r05_bench_ppo.json 2> gpurun_out/r05_bench_ppo.err
       python -c "import json; d=json.load(open('gpurun_out/r05_bench_ppo.json')); print('decode', round(d['decode_ms_per_position'],4), 'ms/pos', round(d['iteration_ms'],1), 'ms/iter', d['split_ms'])" || tail -3 gpurun_out/r05_bench_ppo.err ;;
