@@ -94,6 +94,18 @@ for k in r['by_kind_top12'][:8]: print(k)" || tail -5 gpurun_out/r05_bench_b1.er
     widths)          # the configs[3] / [4] backbones at width vs the reference trainer's fixtures
       timeout 1200 python -m pytest tests/test_qwen2audio_gpu.py tests/test_qwen3moe_gpu.py -q -m gpu -p no:cacheprovider -k "width_pair" > gpurun_out/r05_widths.log 2>&1; echo "rc=$?"; tail -14 gpurun_out/r05_widths.log | cut -c1-400
       cat gpurun_out/parity_qwen2audio_width_vs_reference.txt gpurun_out/parity_qwen3moe_width_vs_reference.txt | cut -c1-400 ;;
+    energy_ab)       # the two open energy questions under the power / clock fields: gemm4's tile-group height (AA_GEMM_GM 3 / 4 / 8; default =
+                     # the shape heuristic) and the attention forward's defer-max threshold (lab library libaa_hip_thr0.so: AT_THR = 0 = rescale on every new maximum)
+      for rep in 1 2; do
+        for gm in 0 3 4 8; do
+          AA_GEMM_GM=$gm timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r05_bench_gm$gm.json 2> gpurun_out/r05_bench_gm$gm.err
+          python -c "import json; d=json.load(open('gpurun_out/r05_bench_gm$gm.json')); r=d['roofline']; print('AA_GEMM_GM=$gm rep $rep', round(d['ms_per_step'],2), 'ms  gemm4', round(r['achieved']), 'TF/s  W', round(r['power_w_mean']), 'MHz', round(r['sclk_mhz_mean']), 'J/TFLOP', round(r['j_per_tflop_step'],4), 'frac@sclk', round(r['frac_of_peak_at_sclk'],4))" || tail -3 gpurun_out/r05_bench_gm$gm.err
+        done
+        for lib in libaa_hip.so libaa_hip_thr0.so; do
+          AA_HIP_LIB=$R/align_anything_amd/$lib timeout 600 python bench.py --steps 6 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r05_bench_$lib.json 2> gpurun_out/r05_bench_$lib.err
+          python -c "import json; d=json.load(open('gpurun_out/r05_bench_$lib.json')); r=d['roofline']; print('$lib rep $rep', round(d['ms_per_step'],2), 'ms  W', round(r['power_w_mean']), 'MHz', round(r['sclk_mhz_mean']), 'J/TFLOP', round(r['j_per_tflop_step'],4))" || tail -3 gpurun_out/r05_bench_$lib.err
+        done
+      done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
