@@ -1395,6 +1395,103 @@ def gen_qwen3moe_width(dtypes=None):
     _gen_width('qwen3moe_width_dpo', qwen3moe_width, Qwen3MoeForCausalLM, 'align_anything.trainers.text_to_text.dpo', dtypes)
 
 
+def gen_dropin_e2e_ti2t(threads=8):
+    """The end-to-end drop-in fixture on the HEADLINE's own modality (round 5; text-to-text sibling: gen_dropin_e2e).  The reference's text+image pipeline --
+    text_image_to_text PreferenceDataset + ChatTemplate('AA_TI2T') + PreferenceCollator with a real LlavaProcessor (datasets/text_image_to_text/
+    preference.py:77-263) over a local parquet dataset with an Image column (tests/util.ti2t_parquet_dataset), DataLoader + DistributedSampler(shuffle=True) as
+    base/supervised_trainer.py:107 -- and 6 optimizer steps of the unmodified text+image DPOTrainer.train_step (trainers/text_image_to_text/dpo.py:85-166 +
+    text_to_text/dpo.py:205-237) in fp32 on a tiny LLaVA (tests/util.tiny_llava_checkpoint: CLIP tower 3 x 128 on 28 x 28 images, 4 image tokens, Llama 2 x 128),
+    the vision tower frozen, projector and language model training (dpo.yaml:60-64), AdamW over the reference's parameter groups, weight decay 0 (dpo.yaml),
+    clip 1.0, cosine schedule.  Stored: the checkpoint's weights, every sample PRE-PROCESSED (token ids + the processor's pixel values), the batches as the
+    reference's loader produced them, the per-step metrics and the final weights' fingerprints."""
+    import tempfile
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from transformers import get_scheduler
+    from align_anything.configs.template import ChatTemplate
+    from align_anything.datasets.text_image_to_text import PreferenceDataset
+    from align_anything.trainers.text_image_to_text.dpo import DPOTrainer
+    import align_anything.trainers.text_to_text.dpo as dpo_mod
+    from align_anything.utils.tools import dict_to_namedtuple, get_optimizer_grouped_parameters
+    from tests.util import ti2t_parquet_dataset, tiny_llava_checkpoint
+    dpo_mod.get_all_reduce_mean = lambda x: x
+    torch.set_num_threads(threads)
+    tmp = tempfile.mkdtemp()
+    ck = os.path.join(tmp, 'llava')
+    policy, processor = tiny_llava_checkpoint(ck, seed=5)
+    with torch.no_grad():
+        for p in policy.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    policy = policy.float().eval()
+    import copy
+    refm = copy.deepcopy(policy).eval()
+    w0 = {n: t.clone() for n, t in policy.state_dict().items()}
+    data_dir = ti2t_parquet_dataset(os.path.join(tmp, 'data'), n=24, seed=3)
+    tok = processor.tokenizer
+    tok.padding_side = 'left'
+    tok.model_max_length = 256                                           # model_cfgs.model_max_length of the run (the reference hands it to from_pretrained)
+    ds = PreferenceDataset(path=data_dir, template=ChatTemplate(processor, 'AA_TI2T'), tokenizer=tok, processor=processor, split='train')
+    coll = ds.get_collator()
+    B, lr, beta = 4, 1e-3, 0.1
+    PAD = int(tok.pad_token_id)
+    # every sample on its own through the reference's collator: its two unpadded rows and the processor's pixel values
+    b_ids, w_ids, bl, wl, pix = [], [], [], [], []
+    for i in range(len(ds)):
+        one = coll([ds[i]])
+        ids, am = one['input_ids'].cpu(), one['attention_mask'].cpu().bool()
+        b_ids.append(ids[0][am[0]].numpy().astype(np.int32)); w_ids.append(ids[1][am[1]].numpy().astype(np.int32))
+        bl.append(int(one['meta_info']['response_lens'][0])); wl.append(int(one['meta_info']['response_lens'][1]))
+        assert torch.equal(one['pixel_values'][0], one['pixel_values'][1])
+        pix.append(one['pixel_values'][0].cpu().float().numpy())
+    for n, p in policy.named_parameters():
+        p.requires_grad_('vision_tower' not in n)                      # freeze_vision_tower: True, freeze_mm_proj / freeze_language_model: False (dpo.yaml:60-64)
+    dl = DataLoader(ds, collate_fn=coll, sampler=DistributedSampler(ds, num_replicas=1, rank=0, shuffle=True), batch_size=B)
+    steps = len(dl)
+    opt = torch.optim.AdamW(get_optimizer_grouped_parameters(policy, 0.0), lr=lr, betas=(0.9, 0.95), eps=1e-8)
+    sched = get_scheduler('cosine', opt, num_warmup_steps=int(0.03 * steps), num_training_steps=steps)
+
+    class Engine:
+        def __init__(self, m): self.module, self.optimizer, self.last_grad_norm = m, opt, None
+        def backward(self, loss): loss.backward()
+        def step(self):
+            self.last_grad_norm = float(torch.nn.utils.clip_grad_norm_([p for p in self.module.parameters() if p.requires_grad], 1.0))
+            opt.step(); sched.step(); opt.zero_grad(set_to_none=True)
+
+    tr = DPOTrainer.__new__(DPOTrainer)
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': beta}})
+    tr.tokenizer = tok
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    eng = Engine(policy)
+    tr.model, tr.reference_model = eng, SimpleNamespace(module=refm)
+    KEYS = ['train/loss', 'train/reward', 'train/better_sample_reward', 'train/worse_sample_reward', 'train/reward_accuracy', 'train/reward_margin', 'train/lr']
+    rows, batches = [], []
+    for b in dl:
+        info = tr.train_step(b)
+        rows.append([info[k] for k in KEYS] + [eng.last_grad_norm])
+        batches.append(b)
+    w1 = policy.state_dict()
+    off = lambda rr: np.concatenate([[0], np.cumsum([len(r) for r in rr])]).astype(np.int64)
+    out = {'vocab_size': np.array(320), 'batch_pairs': np.array(B), 'learning_rate': np.array(lr), 'scale_coeff': np.array(beta), 'pad_token_id': np.array(PAD),
+           'b_ids': np.concatenate(b_ids), 'b_off': off(b_ids), 'w_ids': np.concatenate(w_ids), 'w_off': off(w_ids), 'b_resp_len': np.array(bl), 'w_resp_len': np.array(wl),
+           'pixel_values': np.stack(pix).astype(np.float32), 'metrics': np.array(rows, dtype=np.float64), 'metric_keys': np.array(KEYS + ['grad_norm']), 'steps': np.array(steps)}
+    for i, b in enumerate(batches):
+        out[f'batch{i}.input_ids'], out[f'batch{i}.attention_mask'] = b['input_ids'].cpu().numpy().astype(np.int32), b['attention_mask'].cpu().numpy().astype(np.int8)
+        out[f'batch{i}.response_lens'] = np.array(b['meta_info']['response_lens'])
+        out[f'batch{i}.pixel_checksum'] = np.array(float(b['pixel_values'].double().sum()))
+    for n, t in w0.items():
+        out['w.' + n] = bf16_bits(t)
+    names = list(w1)
+    out['final_names'] = np.array(names)
+    out['final_norm'] = np.array([float(w1[n].double().norm()) for n in names])
+    out['update_norm'] = np.array([float((w1[n].double() - w0[n].double()).norm()) for n in names])
+    for n in names:
+        if n.endswith(('multi_modal_projector.linear_1.weight', 'layers.1.mlp.down_proj.weight', 'language_model.norm.weight')):
+            out['final.' + n] = w1[n].numpy()
+    np.savez_compressed(os.path.join(GOLD, 'dropin_e2e_ti2t.npz'), **out)
+    print('dropin_e2e_ti2t.npz:', len(ds), 'pairs,', steps, 'steps of', B, 'pairs; rows of', [len(r) for r in b_ids[:4]], 'tokens; loss', np.array(rows)[:, 0].round(6).tolist())
+    print('grad norms', np.array(rows)[:, -1].round(4).tolist(), 'frozen tower update norm', max(float((w1[n] - w0[n]).abs().max()) for n in names if 'vision_tower' in n))
+
+
 def _opt125m_reference_trainer(nthreads):
     """The reference's unmodified DPOTrainer (trainers/text_to_text/dpo.py) on config 1 with the DeepSpeed engine replaced by
     torch.optim.AdamW over the reference's own parameter groups + clip_grad_norm_(1.0) + HF cosine schedule (see gen_opt125m_curve).

@@ -92,3 +92,44 @@ def test_drop_in_flow_with_recorded_launches(launches, monkeypatch, tmp_path):
     assert again.global_step == 4 and again.model.global_steps == 4
     hist2 = again.train()
     assert len(hist2) == 4 and abs(hist2[0]['train/lr'] - want_lr[4]) < 1e-15
+
+
+def test_text_image_stand_in_plugin_reproduces_the_reference_batches():
+    """The text+image sibling: tests/golden/dropin_e2e_ti2t.npz holds the batches the reference's text_image_to_text PreferenceDataset + AA_TI2T template +
+    PreferenceCollator (a real LlavaProcessor) produced; the stand-in used on the GPU box reproduces them -- ids, masks, response lengths, and the pixel values
+    (same image for the chosen and the rejected row)."""
+    from tests.util import DropinTI2TPreferenceDataset
+    z = load_golden('dropin_e2e_ti2t.npz')
+    import types
+    tok = types.SimpleNamespace(pad_token_id=int(z['pad_token_id']), padding_side='left')
+    ds = DropinTI2TPreferenceDataset(os.path.join(GOLD, 'dropin_e2e_ti2t.npz'), template=None, tokenizer=tok)
+    batches = list(_loader(ds, int(z['batch_pairs'])))
+    assert len(ds) == 24 and len(batches) == int(z['steps'])
+    for i, b in enumerate(batches):
+        assert _same(b, z, i), i
+        B = b['input_ids'].shape[0] // 2
+        assert b['pixel_values'].shape == (2 * B, 3, 28, 28) and torch.equal(b['pixel_values'][:B], b['pixel_values'][B:])
+        assert abs(float(b['pixel_values'].double().sum()) - float(z[f'batch{i}.pixel_checksum'])) < 1e-6
+        assert bool(((b['input_ids'] == 4).sum(1) == 4).all())          # the processor expanded <image> to the tower's 4 image tokens in every row
+
+
+def test_text_image_drop_in_flow_with_recorded_launches(launches, monkeypatch, tmp_path):
+    """The text+image GPU test's control flow on CPU (kernel launches recorded, nothing computes): the LLaVA checkpoint directory loads with its real processor,
+    the text_image_to_text plugin surface builds the loader whose batches carry pixel values, train() runs the epoch through the tower, slices are saved."""
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    from tests.test_dropin_gpu import _cfgs_ti2t
+    from tests.util import dropin_ti2t_checkpoint, install_dropin_ti2t_plugins
+    z = load_golden('dropin_e2e_ti2t.npz')
+    install_dropin_ti2t_plugins(monkeypatch)
+    ckpt, out = str(tmp_path / 'ckpt'), str(tmp_path / 'run')
+    dropin_ti2t_checkpoint(ckpt, z)
+    tr = DPOTrainer(_cfgs_ti2t(z, ckpt, out, 'bf16'), {'gradient_clipping': 1.0}, device='cpu')
+    assert tr.model_cfg['kind'] == 'llava' and type(tr.processor).__name__ == 'LlavaProcessor' and len(tr.train_dataloader) == 6 and tr.pad_token_id == int(z['pad_token_id'])
+    for i, b in enumerate(tr.train_dataloader):
+        assert _same({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}, z, i) and b['pixel_values'].shape[1:] == (3, 28, 28)
+    del launches[:]
+    hist = tr.train()
+    assert len(hist) == 6 and 'aa_patch_im2col' in launches and 'aa_image_slot_index' in launches and launches.count('aa_dpo_loss_fwd_bwd') == 6
+    assert np.abs(np.array([h['train/lr'] for h in hist]) - z['metrics'][:, 6]).max() < 1e-15
+    d_end = tr.save()
+    assert sorted(os.listdir(out)) == ['slice_3', 'slice_6', 'slice_end'] and 'config.json' in os.listdir(d_end)

@@ -131,3 +131,84 @@ def test_drop_in_trainer_end_to_end_vs_the_reference_run(tmp_path, monkeypatch, 
         assert ok, '\n'.join(rep)
     finally:
         dump(f'parity_dropin_e2e_{dtype}.txt', '\n'.join(rep) + '\n')      # whatever was measured, also when a check fails
+
+
+def _cfgs_ti2t(z, ckpt, out, dtype, **train):
+    return {'train_cfgs': dict({'scale_coeff': float(z['scale_coeff']), 'learning_rate': float(z['learning_rate']), 'lr_warmup_ratio': 0.03, 'lr_scheduler_type': 'cosine',
+                                'weight_decay': 0.0, 'adam_betas': [0.9, 0.95], 'per_device_train_batch_size': int(z['batch_pairs']), 'epochs': 1, 'compute_dtype': dtype,
+                                'freeze_vision_tower': True, 'freeze_mm_proj': False, 'freeze_language_model': False, 'save_checkpoint': True}, **train),
+            'model_cfgs': {'model_name_or_path': ckpt, 'model_max_length': 256},
+            'logger_cfgs': {'output_dir': out, 'save_total_limit': 2},
+            'data_cfgs': {'train_datasets': os.path.join(GOLD, 'dropin_e2e_ti2t.npz'), 'train_template': 'AA_TI2T', 'train_size': None, 'train_split': 'train',
+                          'train_name': None, 'train_data_files': None, 'train_optional_args': []}}
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_drop_in_text_image_trainer_end_to_end_vs_the_reference_run(tmp_path, monkeypatch, dtype):
+    """The same end-to-end check on the HEADLINE's own modality: `DPOTrainer(cfgs, ds_cfgs)` from a LLaVA checkpoint directory (weights + a real LlavaProcessor)
+    -> init_datasets (text_image_to_text plugin surface, pixel values in the batch) -> train() (frozen CLIP tower, trainable projector + decoder) -> save() ->
+    `LlavaForConditionalGeneration.from_pretrained(slice_end)`, against what the reference's own text+image pipeline and trainer produced on CPU in fp32
+    (tests/golden/dropin_e2e_ti2t.npz, oracle/gen_golden.py::gen_dropin_e2e_ti2t: 6 steps of 4 pairs)."""
+    import transformers as tf
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    from tests.gpu_util import dump
+    from tests.util import dropin_ti2t_checkpoint, install_dropin_ti2t_plugins
+    z = load_golden('dropin_e2e_ti2t.npz')
+    install_dropin_ti2t_plugins(monkeypatch)
+    ckpt, out = str(tmp_path / 'ckpt'), str(tmp_path / 'run')
+    dropin_ti2t_checkpoint(ckpt, z)
+    tr = DPOTrainer(_cfgs_ti2t(z, ckpt, out, dtype), {'gradient_clipping': 1.0}, device='cuda:0')
+    steps = int(z['steps'])
+    assert tr.model_cfg['kind'] == 'llava' and type(tr.processor).__name__ == 'LlavaProcessor' and len(tr.train_dataloader) == steps and tr.model.total_steps == steps
+    for i, b in enumerate(tr.train_dataloader):
+        assert np.array_equal(b['input_ids'].cpu().numpy(), z[f'batch{i}.input_ids']) and np.array_equal(b['attention_mask'].cpu().numpy(), z[f'batch{i}.attention_mask'])
+        assert list(b['meta_info']['response_lens']) == z[f'batch{i}.response_lens'].tolist()
+        assert abs(float(b['pixel_values'].double().sum()) - float(z[f'batch{i}.pixel_checksum'])) < 1e-6
+    rep = []
+    try:
+        hist = tr.train()
+        assert len(hist) == steps
+        got = np.array([[h[k] for k in KEYS] for h in hist], dtype=np.float64)
+        want = z['metrics'][:, :7]
+        err = np.abs(got - want).max(0)
+        rep += [f'{dtype}: native text+image DPOTrainer(cfgs, ds_cfgs) from a LLaVA checkpoint directory vs the reference pipeline, {steps} steps of {int(z["batch_pairs"])} pairs']
+        for i in range(steps):
+            rep.append(f'  step {i}: loss native {got[i, 0]:.6f} reference {want[i, 0]:.6f} |diff| {abs(got[i, 0] - want[i, 0]):.2e}   margin {got[i, 5]:+.5f} / {want[i, 5]:+.5f}   lr {got[i, 6]:.3e}')
+        rep.append('  max |diff| per metric: ' + ', '.join(f'{k.split("/")[1]} {e:.2e}' for k, e in zip(KEYS, err)))
+        assert np.abs(got[:, 6] - want[:, 6]).max() < 1e-12
+        tol_loss, tol_margin = (1e-4, 1e-3) if dtype == 'fp32' else (3e-2, 6e-2)
+        ok = err[0] < tol_loss and err[5] < tol_margin
+        d_end = tr.save()
+        assert sorted(os.listdir(out)) == ['slice_3', 'slice_6', 'slice_end'] and {'config.json', 'pytorch_model.bin', 'tokenizer.json'} <= set(os.listdir(d_end))
+        assert any(f.startswith('preprocessor_config') or f.startswith('processor_config') for f in os.listdir(d_end))      # the processor travels with the slice
+        hf = tf.LlavaForConditionalGeneration.from_pretrained(d_end, torch_dtype=torch.float32).eval()
+        eng = {k: v.float().cpu() for k, v in tr.policy.state_dict().items()}
+        hf_sd = hf.state_dict()
+        hits = 0
+        for k, v in eng.items():
+            cand = [n for n in hf_sd if n == k or n.endswith(k.split('model.', 1)[-1])]
+            if len(cand) == 1:
+                hits += 1
+                assert torch.equal(hf_sd[cand[0]].float(), v), f'{k}: the saved slice is not the engine\'s weights'
+        assert hits >= 40, hits
+        worst = 0.0
+        names = [str(n) for n in z['final_names']]
+        for n, nr, un in zip(names, z['final_norm'], z['update_norm']):
+            mine = [k for k in eng if k == n or k.endswith(n.split('model.', 1)[-1])]
+            if len(mine) != 1:
+                continue
+            k = mine[0]
+            if 'vision_tower' in n:
+                assert float(un) == 0.0 and abs(float(eng[k].double().norm()) - float(nr)) <= 1e-6 * max(float(nr), 1.0), n       # frozen on both sides
+                continue
+            if 'final.' + n in z.files:
+                mv = tr.policy.store.opt_state_views(k)
+                wm = mv[0].double().cpu().reshape(eng[k].shape) if mv is not None else eng[k].double()
+                d = float((wm - torch.from_numpy(z['final.' + n]).double()).norm())
+                worst = max(worst, d / max(float(un), 1e-30))
+                rep.append(f'  final {n}: |native - reference| / |reference update| = {d / max(float(un), 1e-30):.2e}')
+        rep.append(f'  saved slice == engine weights bit for bit ({hits} tensors), loads with LlavaForConditionalGeneration.from_pretrained; vision tower unchanged')
+        ok = ok and worst < (5e-2 if dtype == 'fp32' else 0.6)
+        assert ok, '\n'.join(rep)
+    finally:
+        dump(f'parity_dropin_e2e_ti2t_{dtype}.txt', '\n'.join(rep) + '\n')

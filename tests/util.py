@@ -192,3 +192,49 @@ def install_dropin_plugins(monkeypatch) -> None:
     pk['align_anything.configs.template'].ChatTemplate = lambda formatter, name, custom=None: types.SimpleNamespace(formatter=formatter, name=name)
     for n, m in pk.items():
         monkeypatch.setitem(sys.modules, n, m)
+
+
+# ---- the text+image sibling (tests/golden/dropin_e2e_ti2t.npz, oracle/gen_golden.py::gen_dropin_e2e_ti2t)
+def dropin_ti2t_checkpoint(path: str, z) -> None:
+    """The LLaVA checkpoint directory of the text+image drop-in test: tests/util.tiny_llava_checkpoint's files (config, a REAL LlavaProcessor with its
+    tokenizer / image processor / chat template) with the fixture's weights."""
+    import transformers as tf
+    hf, _ = tiny_llava_checkpoint(path, seed=5)
+    sd = state_dict_from_golden(z, 'w.', torch.float32)
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not unexpected and not [m for m in missing if 'lm_head' not in m], (missing, unexpected)
+    hf.save_pretrained(path)
+
+
+class DropinTI2TPreferenceDataset(DropinPreferenceDataset):
+    """Stand-in for `align_anything.datasets.text_image_to_text.PreferenceDataset` (see DropinPreferenceDataset): the reference's pre-processed samples -- token
+    ids AND the LlavaProcessor's pixel values; the collator stacks the images twice (chosen rows, then rejected rows), as preference.py:219-222 does."""
+
+    def __init__(self, path, template, tokenizer, processor=None, name=None, size=None, split=None, data_files=None, optional_args=[]):
+        super().__init__(path, template, tokenizer, processor, name, size, split, data_files, optional_args)
+        self.pix = np.load(path)['pixel_values']
+
+    def __getitem__(self, i):
+        d = super().__getitem__(i)
+        d['pixel_values'] = self.pix[i]
+        return d
+
+    def get_collator(self):
+        base = super().get_collator()
+
+        def collate(samples):
+            out = base(samples)
+            pv = torch.from_numpy(np.stack([s['pixel_values'] for s in samples]))
+            out['pixel_values'] = torch.cat([pv, pv], 0)
+            return out
+        return collate
+
+
+def install_dropin_ti2t_plugins(monkeypatch) -> None:
+    import sys
+    import types
+    install_dropin_plugins(monkeypatch)
+    m = types.ModuleType('align_anything.datasets.text_image_to_text')
+    m.__path__ = []
+    m.PreferenceDataset = DropinTI2TPreferenceDataset
+    monkeypatch.setitem(sys.modules, 'align_anything.datasets.text_image_to_text', m)
