@@ -1492,6 +1492,89 @@ def gen_dropin_e2e_ti2t(threads=8):
     print('grad norms', np.array(rows)[:, -1].round(4).tolist(), 'frozen tower update norm', max(float((w1[n] - w0[n]).abs().max()) for n in names if 'vision_tower' in n))
 
 
+def gen_dropin_e2e_rm(threads=8):
+    """The end-to-end drop-in fixture of the REWARD-MODEL trainer (round 5; siblings: gen_dropin_e2e, gen_dropin_e2e_ti2t).  The reference's own pipeline on its own
+    asset file -- text_to_text PreferenceDataset + PKUSafeRLHF template + PreferenceCollator with RIGHT padding (rm.py:76-91) -- and 8 optimizer steps of the
+    unmodified RMTrainer.train_step (trainers/text_to_text/rm.py:97-153: pairwise -logsigmoid(higher - lower) + 0.001 x the squared end scores) in fp32 on the reference's
+    own AccustomedOPTRewardModel (models/opt.py:31-97: OPT backbone + score head, end score at the last attended token), AdamW over the reference's parameter
+    groups, weight decay 0 (rm.yaml:44), clip 1.0, cosine schedule.  Same samples and word-level tokenizer as gen_dropin_e2e."""
+    from collections import Counter
+    import json
+    import re
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from transformers import get_scheduler
+    from align_anything.configs.template import ChatTemplate
+    from align_anything.datasets.text_to_text import PreferenceDataset
+    from align_anything.models.opt import AccustomedOPTRewardModel
+    from align_anything.trainers.text_to_text.rm import RMTrainer
+    import align_anything.trainers.text_to_text.rm as rm_mod
+    from align_anything.utils.tools import dict_to_namedtuple, get_optimizer_grouped_parameters
+    from tests.util import DROPIN_SPECIALS, dropin_hf_config, dropin_tokenizer
+    rm_mod.get_all_reduce_mean = lambda x: x
+    torch.set_num_threads(threads)
+    asset = '/root/reference/assets/text_to_text/preference/train.json'
+    raw = json.load(open(asset))
+    cnt = Counter(w for r in raw for k in ('prompt', 'response_0', 'response_1') for w in re.findall(r"\w+|[^\w\s]", r[k]))
+    tok = dropin_tokenizer([w for w, _ in cnt.most_common(396)])
+    tok.padding_side = 'right'
+    V = len(DROPIN_SPECIALS) + 396
+    ds = PreferenceDataset(path=asset, template=ChatTemplate(tok, 'PKUSafeRLHF'), tokenizer=tok, processor=None)
+    enc = lambda t: np.array(tok(t, add_special_tokens=False)['input_ids'], dtype=np.int32)
+    items = [ds[i] for i in range(len(ds))]
+    b_ids, w_ids = [enc(it['better_conversation']) for it in items], [enc(it['worse_conversation']) for it in items]
+    off = lambda rows: np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    B, lr, reg = 4, 1e-4, 0.001
+    torch.manual_seed(1)
+    model = AccustomedOPTRewardModel(dropin_hf_config(V)).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    w0 = {n: t.clone() for n, t in model.state_dict().items()}
+    dl = DataLoader(ds, collate_fn=ds.get_collator(), sampler=DistributedSampler(ds, num_replicas=1, rank=0, shuffle=True), batch_size=B)
+    steps = len(dl)
+    opt = torch.optim.AdamW(get_optimizer_grouped_parameters(model, 0.0), lr=lr, betas=(0.9, 0.95), eps=1e-8)
+    sched = get_scheduler('cosine', opt, num_warmup_steps=int(0.03 * steps), num_training_steps=steps)
+
+    class Engine:
+        def __init__(self, m): self.module, self.optimizer, self.last_grad_norm = m, opt, None
+        def __call__(self, **kw): return self.module(**kw)
+        def backward(self, loss): loss.backward()
+        def step(self):
+            self.last_grad_norm = float(torch.nn.utils.clip_grad_norm_(self.module.parameters(), 1.0))
+            opt.step(); sched.step(); opt.zero_grad(set_to_none=True)
+
+    tr = RMTrainer.__new__(RMTrainer)
+    tr.cfgs = dict_to_namedtuple({'train_cfgs': {'regularization': reg}})
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    eng = Engine(model)
+    tr.model = eng
+    rows, batches = [], []
+    for b in dl:
+        info = tr.train_step(b)
+        rows.append([info['train/loss'], info['train/accuracy'], info['train/lr'], eng.last_grad_norm])
+        batches.append(b)
+    w1 = model.state_dict()
+    out = {'vocab_size': np.array(V), 'batch_pairs': np.array(B), 'learning_rate': np.array(lr), 'regularization': np.array(reg),
+           'b_ids': np.concatenate(b_ids), 'b_off': off(b_ids), 'w_ids': np.concatenate(w_ids), 'w_off': off(w_ids),
+           'b_resp_len': np.array([it['better_response_lens'] for it in items]), 'w_resp_len': np.array([it['worse_response_lens'] for it in items]),
+           'metrics': np.array(rows, dtype=np.float64), 'metric_keys': np.array(['loss', 'accuracy', 'lr', 'grad_norm']), 'steps': np.array(steps)}
+    for i, b in enumerate(batches):
+        out[f'batch{i}.input_ids'], out[f'batch{i}.attention_mask'] = b['input_ids'].numpy().astype(np.int32), b['attention_mask'].numpy().astype(np.int8)
+        out[f'batch{i}.response_lens'] = np.array(b['meta_info']['response_lens'])
+    for n, t in w0.items():
+        out['w.' + n] = bf16_bits(t)
+    names = list(w1)
+    out['final_names'] = np.array(names)
+    out['final_norm'] = np.array([float(w1[n].double().norm()) for n in names])
+    out['update_norm'] = np.array([float((w1[n].double() - w0[n].double()).norm()) for n in names])
+    for n in ('score_head.weight', 'model.decoder.layers.1.fc1.weight', 'model.decoder.final_layer_norm.weight'):
+        out['final.' + n] = w1[n].numpy()
+    np.savez_compressed(os.path.join(GOLD, 'dropin_e2e_rm.npz'), **out)
+    r = np.array(rows)
+    print('dropin_e2e_rm.npz:', len(items), 'pairs,', steps, 'steps; loss', r[:, 0].round(6).tolist(), 'accuracy', r[:, 1].tolist(), 'grad norms', r[:, 3].round(3).tolist())
+
+
 def _opt125m_reference_trainer(nthreads):
     """The reference's unmodified DPOTrainer (trainers/text_to_text/dpo.py) on config 1 with the DeepSpeed engine replaced by
     torch.optim.AdamW over the reference's own parameter groups + clip_grad_norm_(1.0) + HF cosine schedule (see gen_opt125m_curve).

@@ -133,3 +133,28 @@ def test_text_image_drop_in_flow_with_recorded_launches(launches, monkeypatch, t
     assert np.abs(np.array([h['train/lr'] for h in hist]) - z['metrics'][:, 6]).max() < 1e-15
     d_end = tr.save()
     assert sorted(os.listdir(out)) == ['slice_3', 'slice_6', 'slice_end'] and 'config.json' in os.listdir(d_end)
+
+
+def test_reward_model_drop_in_flow_with_recorded_launches(launches, monkeypatch, tmp_path):
+    """The reward-model GPU test's control flow on CPU: the score-model directory loads (backbone + score head, no lm_head), the plugin surface serves the
+    reference's RIGHT-padded batches bit for bit, train() runs the epoch on the reference's schedule and saves slices without an lm_head."""
+    from align_anything_amd.trainers.rm import RMTrainer
+    from tests.util import dropin_rm_checkpoint
+    z = load_golden('dropin_e2e_rm.npz')
+    install_dropin_plugins(monkeypatch)
+    ckpt, out = str(tmp_path / 'ckpt'), str(tmp_path / 'run')
+    dropin_rm_checkpoint(ckpt, z)
+    cfgs = {'train_cfgs': {'learning_rate': float(z['learning_rate']), 'lr_warmup_ratio': 0.03, 'lr_scheduler_type': 'cosine', 'weight_decay': 0.0, 'regularization': 0.001,
+                           'per_device_train_batch_size': 4, 'epochs': 1, 'compute_dtype': 'fp32'},
+            'model_cfgs': {'model_name_or_path': ckpt, 'model_max_length': 512}, 'logger_cfgs': {'output_dir': out, 'save_total_limit': 2},
+            'data_cfgs': {'train_datasets': os.path.join(GOLD, 'dropin_e2e_rm.npz'), 'train_template': 'PKUSafeRLHF', 'train_size': None, 'train_split': None,
+                          'train_name': None, 'train_data_files': None, 'train_optional_args': []}}
+    tr = RMTrainer(cfgs, {'gradient_clipping': 1.0}, device='cpu')
+    assert len(tr.train_dataloader) == 8 and tr.tokenizer.padding_side == 'right'
+    assert float(tr.model.module.store.p['score_head.weight'].float().abs().sum()) > 0
+    for i, b in enumerate(tr.train_dataloader):
+        assert _same({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}, z, i)
+        assert bool((b['attention_mask'][:, 0] == 1).all())          # right padding: every row starts with a token
+    hist = tr.train()
+    assert len(hist) == 8 and np.abs(np.array([h['train/lr'] for h in hist]) - z['metrics'][:, 2]).max() < 1e-15
+    assert sorted(os.listdir(out)) == ['slice_4', 'slice_8']

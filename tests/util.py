@@ -238,3 +238,16 @@ def install_dropin_ti2t_plugins(monkeypatch) -> None:
     m.__path__ = []
     m.PreferenceDataset = DropinTI2TPreferenceDataset
     monkeypatch.setitem(sys.modules, 'align_anything.datasets.text_image_to_text', m)
+
+
+def dropin_rm_checkpoint(path: str, z) -> None:
+    """The reward-model checkpoint directory of the RM drop-in test: OPT config.json + model.safetensors holding the backbone AND `score_head.weight` (the layout the
+    reference's AccustomedOPTRewardModel saves, models/opt.py:31-97) + the anonymous word-level tokenizer."""
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    cfg = dropin_hf_config(int(z['vocab_size']))
+    cfg.architectures = ['OPTForCausalLM']
+    cfg.save_pretrained(path)
+    sd = state_dict_from_golden(z, 'w.', torch.float32)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, 'model.safetensors'), metadata={'format': 'pt'})
+    dropin_tokenizer([f'w{i}' for i in range(int(z['vocab_size']) - len(DROPIN_SPECIALS))]).save_pretrained(path)
