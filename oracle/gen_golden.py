@@ -1575,6 +1575,83 @@ def gen_dropin_e2e_rm(threads=8):
     print('dropin_e2e_rm.npz:', len(items), 'pairs,', steps, 'steps; loss', r[:, 0].round(6).tolist(), 'accuracy', r[:, 1].tolist(), 'grad norms', r[:, 3].round(3).tolist())
 
 
+def gen_dropin_e2e_sft(threads=8):
+    """The end-to-end drop-in fixture of the SUPERVISED trainer (round 5; siblings gen_dropin_e2e / _ti2t / _rm): the reference's SupervisedDataset + Alpaca template
+    + SupervisedCollator (datasets/text_to_text/supervised.py:48-157: prompt tokens and right padding labelled -100) on its own asset file
+    assets/text_to_text/supervised/train.json, and 8 optimizer steps of the unmodified SupervisedTrainer.train_step (trainers/text_to_text/sft.py:94-108: the HF
+    causal-LM loss of `model(**batch)`) in fp32 on the 2-layer OPT of gen_dropin_e2e, AdamW over the reference's parameter groups, weight decay 0 (sft.yaml), clip 1.0,
+    cosine schedule.  Word-level tokenizer from the 396 most frequent words of THIS asset; samples stored pre-tokenised (ids + labels)."""
+    from collections import Counter
+    import json
+    import re
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from transformers import OPTForCausalLM, get_scheduler
+    from align_anything.configs.template import ChatTemplate
+    from align_anything.datasets.text_to_text import SupervisedDataset
+    from align_anything.trainers.text_to_text.sft import SupervisedTrainer
+    from align_anything.utils.tools import get_optimizer_grouped_parameters
+    from tests.util import DROPIN_SPECIALS, dropin_hf_config, dropin_tokenizer
+    torch.set_num_threads(threads)
+    asset = '/root/reference/assets/text_to_text/supervised/train.json'
+    raw = json.load(open(asset))
+    cnt = Counter(w for r in raw for k in ('instruction', 'input', 'output') for w in re.findall(r"\w+|[^\w\s]", r[k]))
+    tok = dropin_tokenizer([w for w, _ in cnt.most_common(396)])
+    tok.padding_side = 'right'
+    V = len(DROPIN_SPECIALS) + 396
+    ds = SupervisedDataset(path=asset, template=ChatTemplate(tok, 'Alpaca'), tokenizer=tok, processor=None)
+    items = [ds[i] for i in range(len(ds))]
+    B, lr = 4, 1e-4
+    torch.manual_seed(2)
+    model = OPTForCausalLM(dropin_hf_config(V)).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    w0 = {n: t.clone() for n, t in model.state_dict().items()}
+    dl = DataLoader(ds, collate_fn=ds.get_collator(), sampler=DistributedSampler(ds, num_replicas=1, rank=0, shuffle=True), batch_size=B)
+    steps = len(dl)
+    opt = torch.optim.AdamW(get_optimizer_grouped_parameters(model, 0.0), lr=lr, betas=(0.9, 0.95), eps=1e-8)
+    sched = get_scheduler('cosine', opt, num_warmup_steps=int(0.03 * steps), num_training_steps=steps)
+
+    class Engine:
+        def __init__(self, m): self.module, self.optimizer, self.last_grad_norm = m, opt, None
+        def __call__(self, **kw): return self.module(**kw)
+        def backward(self, loss): loss.backward()
+        def step(self):
+            self.last_grad_norm = float(torch.nn.utils.clip_grad_norm_(self.module.parameters(), 1.0))
+            opt.step(); sched.step(); opt.zero_grad(set_to_none=True)
+
+    tr = SupervisedTrainer.__new__(SupervisedTrainer)
+    tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+    eng = Engine(model)
+    tr.model = eng
+    rows, batches = [], []
+    for b in dl:
+        info = tr.train_step(b)
+        rows.append([info['train/loss'], info['train/lr'], eng.last_grad_norm])
+        batches.append(b)
+    w1 = model.state_dict()
+    off = lambda rr: np.concatenate([[0], np.cumsum([len(r) for r in rr])]).astype(np.int64)
+    ids = [it['input_ids'].numpy().astype(np.int32) for it in items]
+    labs = [it['labels'].numpy().astype(np.int32) for it in items]
+    out = {'vocab_size': np.array(V), 'batch_size': np.array(B), 'learning_rate': np.array(lr), 'ids': np.concatenate(ids), 'labels': np.concatenate(labs), 'off': off(ids),
+           'metrics': np.array(rows, dtype=np.float64), 'metric_keys': np.array(['loss', 'lr', 'grad_norm']), 'steps': np.array(steps)}
+    for i, b in enumerate(batches):
+        out[f'batch{i}.input_ids'], out[f'batch{i}.labels'] = b['input_ids'].numpy().astype(np.int32), b['labels'].numpy().astype(np.int32)
+        out[f'batch{i}.attention_mask'] = b['attention_mask'].numpy().astype(np.int8)
+    for n, t in w0.items():
+        out['w.' + n] = bf16_bits(t)
+    names = list(w1)
+    out['final_names'] = np.array(names)
+    out['update_norm'] = np.array([float((w1[n].double() - w0[n].double()).norm()) for n in names])
+    for n in ('model.decoder.layers.0.self_attn.q_proj.weight', 'model.decoder.layers.1.fc2.weight', 'model.decoder.final_layer_norm.weight'):
+        out['final.' + n] = w1[n].numpy()
+    np.savez_compressed(os.path.join(GOLD, 'dropin_e2e_sft.npz'), **out)
+    r = np.array(rows)
+    print('dropin_e2e_sft.npz:', len(items), 'samples,', steps, 'steps; loss', r[:, 0].round(6).tolist(), 'grad norms', r[:, 2].round(3).tolist(),
+          'labelled share', float(np.mean(np.concatenate(labs) != -100)))
+
+
 def _opt125m_reference_trainer(nthreads):
     """The reference's unmodified DPOTrainer (trainers/text_to_text/dpo.py) on config 1 with the DeepSpeed engine replaced by
     torch.optim.AdamW over the reference's own parameter groups + clip_grad_norm_(1.0) + HF cosine schedule (see gen_opt125m_curve).

@@ -158,3 +158,22 @@ def test_reward_model_drop_in_flow_with_recorded_launches(launches, monkeypatch,
     hist = tr.train()
     assert len(hist) == 8 and np.abs(np.array([h['train/lr'] for h in hist]) - z['metrics'][:, 2]).max() < 1e-15
     assert sorted(os.listdir(out)) == ['slice_4', 'slice_8']
+
+
+def test_supervised_drop_in_flow_with_recorded_launches(launches, monkeypatch, tmp_path):
+    """The supervised GPU test's control flow on CPU: checkpoint directory, SupervisedDataset plugin surface (ids / labels / mask == the reference's batches bit for
+    bit), the label window of every batch built on the host, train() on the reference's schedule."""
+    from align_anything_amd.trainers.sft import SupervisedTrainer
+    from tests.test_dropin_gpu import _sft_cfgs
+    from tests.util import install_dropin_sft_plugins
+    z = load_golden('dropin_e2e_sft.npz')
+    install_dropin_sft_plugins(monkeypatch)
+    ckpt, out = str(tmp_path / 'ckpt'), str(tmp_path / 'run')
+    dropin_checkpoint(ckpt, z)
+    tr = SupervisedTrainer(_sft_cfgs(z, ckpt, out, 'fp32'), {'gradient_clipping': 1.0}, device='cpu')
+    assert len(tr.train_dataloader) == 8 and tr.model.total_steps == 8
+    for i, b in enumerate(tr.train_dataloader):
+        assert np.array_equal(b['input_ids'].numpy(), z[f'batch{i}.input_ids']) and np.array_equal(b['labels'].numpy(), z[f'batch{i}.labels'])
+        assert '_window' in b and b['_window']['rows'] == int((b['labels'][:, 1:] != -100).sum())      # the supervised rows: labels[:, 1:] != -100 (hf ForCausalLMLoss)
+    hist = tr.train()
+    assert len(hist) == 8 and np.abs(np.array([h['train/lr'] for h in hist]) - z['metrics'][:, 1]).max() < 1e-15 and launches.count('aa_sft_loss_fwd_bwd_f32') + launches.count('aa_sft_loss_fwd_bwd') == 8

@@ -271,3 +271,63 @@ def test_drop_in_reward_model_trainer_end_to_end_vs_the_reference_run(tmp_path, 
         assert ok, '\n'.join(rep)
     finally:
         dump(f'parity_dropin_e2e_rm_{dtype}.txt', '\n'.join(rep) + '\n')
+
+
+def _sft_cfgs(z, ckpt, out, dtype):
+    return {'train_cfgs': {'learning_rate': float(z['learning_rate']), 'lr_warmup_ratio': 0.03, 'lr_scheduler_type': 'cosine', 'weight_decay': 0.0, 'adam_betas': [0.9, 0.95],
+                           'per_device_train_batch_size': int(z['batch_size']), 'epochs': 1, 'compute_dtype': dtype},
+            'model_cfgs': {'model_name_or_path': ckpt, 'model_max_length': 512}, 'logger_cfgs': {'output_dir': out, 'save_total_limit': 2},
+            'data_cfgs': {'train_datasets': os.path.join(GOLD, 'dropin_e2e_sft.npz'), 'train_template': 'Alpaca', 'train_size': None, 'train_split': None,
+                          'train_name': None, 'train_data_files': None, 'train_optional_args': []}}
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_drop_in_supervised_trainer_end_to_end_vs_the_reference_run(tmp_path, monkeypatch, dtype):
+    """The cfgs-only SUPERVISED trainer end to end (the first stage of the reference's pipeline, scripts/opt/sft.sh): `SupervisedTrainer(cfgs, ds_cfgs)` from a
+    checkpoint directory -> init_datasets (SupervisedDataset / Alpaca through the plugin surface: ids, labels, mask) -> train() -> save() -> HF `from_pretrained`,
+    against the reference's own SupervisedDataset + collator + `SupervisedTrainer.train_step` on its asset file (tests/golden/dropin_e2e_sft.npz,
+    oracle/gen_golden.py::gen_dropin_e2e_sft: 8 steps of 4 samples, fp32, CPU)."""
+    import transformers as tf
+    from align_anything_amd.trainers.sft import SupervisedTrainer
+    from tests.gpu_util import dump
+    from tests.util import install_dropin_sft_plugins
+    z = load_golden('dropin_e2e_sft.npz')
+    install_dropin_sft_plugins(monkeypatch)
+    ckpt, out = str(tmp_path / 'ckpt'), str(tmp_path / 'run')
+    dropin_checkpoint(ckpt, z)
+    tr = SupervisedTrainer(_sft_cfgs(z, ckpt, out, dtype), {'gradient_clipping': 1.0}, device='cuda:0')
+    steps = int(z['steps'])
+    assert len(tr.train_dataloader) == steps
+    for i, b in enumerate(tr.train_dataloader):
+        assert np.array_equal(b['input_ids'].cpu().numpy(), z[f'batch{i}.input_ids']) and np.array_equal(b['labels'].cpu().numpy(), z[f'batch{i}.labels'])
+        assert np.array_equal(b['attention_mask'].cpu().numpy().astype(np.int8), z[f'batch{i}.attention_mask'])
+    rep = []
+    try:
+        hist = tr.train()
+        assert len(hist) == steps
+        got = np.array([[h['train/loss'], h['train/lr']] for h in hist], dtype=np.float64)
+        want = z['metrics'][:, :2]
+        err = np.abs(got - want).max(0)
+        rep += [f'{dtype}: native SupervisedTrainer(cfgs, ds_cfgs) from a checkpoint directory vs the reference pipeline, {steps} steps of {int(z["batch_size"])} samples']
+        for i in range(steps):
+            rep.append(f'  step {i}: loss native {got[i, 0]:.6f} reference {want[i, 0]:.6f} |diff| {abs(got[i, 0] - want[i, 0]):.2e}   lr {got[i, 1]:.3e}')
+        rep.append(f'  max |diff|: loss {err[0]:.2e}, lr {err[1]:.1e}')
+        assert err[1] < 1e-12
+        ok = err[0] < (1e-4 if dtype == 'fp32' else 5e-2)             # a cross-entropy of ~5.7: 1e-4 abs in fp32; bf16: 1 % of it
+        d_end = tr.save()
+        hf = tf.OPTForCausalLM.from_pretrained(d_end, torch_dtype=torch.float32).eval()
+        eng = {k: v.float().cpu() for k, v in tr.policy.state_dict().items()}
+        for k, v in eng.items():
+            assert torch.equal(hf.state_dict()[k].float(), v), k
+        worst = 0.0
+        for n, un in zip([str(n) for n in z['final_names']], z['update_norm']):
+            if 'final.' + n in z.files:
+                mv = tr.policy.store.opt_state_views(n)
+                wm = mv[0].double().cpu() if mv is not None else eng[n].double()
+                d = float((wm.reshape(-1) - torch.from_numpy(z['final.' + n]).double().reshape(-1)).norm())
+                worst = max(worst, d / max(float(un), 1e-30))
+                rep.append(f'  final {n}: |native - reference| / |reference update| = {d / max(float(un), 1e-30):.2e}')
+        ok = ok and worst < (5e-2 if dtype == 'fp32' else 0.6)
+        assert ok, '\n'.join(rep)
+    finally:
+        dump(f'parity_dropin_e2e_sft_{dtype}.txt', '\n'.join(rep) + '\n')

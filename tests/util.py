@@ -251,3 +251,40 @@ def dropin_rm_checkpoint(path: str, z) -> None:
     sd = state_dict_from_golden(z, 'w.', torch.float32)
     save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, 'model.safetensors'), metadata={'format': 'pt'})
     dropin_tokenizer([f'w{i}' for i in range(int(z['vocab_size']) - len(DROPIN_SPECIALS))]).save_pretrained(path)
+
+
+class DropinSupervisedDataset:
+    """Stand-in for `align_anything.datasets.text_to_text.SupervisedDataset` (see DropinPreferenceDataset): the reference's PRE-TOKENISED samples (ids + labels with
+    the prompt at -100); the collator right-pads ids with the pad token and labels with -100 and derives the mask from the ids, as supervised.py:134-157 does."""
+
+    def __init__(self, path, template, tokenizer, processor=None, name=None, size=None, split=None, data_files=None, optional_args=[]):
+        z = np.load(path)
+        off = z['off']
+        self.ids = [z['ids'][off[i]:off[i + 1]].astype(np.int64) for i in range(len(off) - 1)]
+        self.labels = [z['labels'][off[i]:off[i + 1]].astype(np.int64) for i in range(len(off) - 1)]
+        self.pad = int(tokenizer.pad_token_id)
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, i):
+        return {'input_ids': torch.from_numpy(self.ids[i]), 'labels': torch.from_numpy(self.labels[i])}
+
+    def get_collator(self):
+        pad = self.pad
+
+        def collate(samples):
+            L = max(len(s['input_ids']) for s in samples)
+            ids = torch.full((len(samples), L), pad, dtype=torch.long)
+            lab = torch.full((len(samples), L), -100, dtype=torch.long)
+            for i, s in enumerate(samples):
+                ids[i, :len(s['input_ids'])] = s['input_ids']
+                lab[i, :len(s['labels'])] = s['labels']
+            return {'input_ids': ids, 'labels': lab, 'attention_mask': ids.ne(pad)}
+        return collate
+
+
+def install_dropin_sft_plugins(monkeypatch) -> None:
+    import sys
+    install_dropin_plugins(monkeypatch)
+    sys.modules['align_anything.datasets.text_to_text'].SupervisedDataset = DropinSupervisedDataset
