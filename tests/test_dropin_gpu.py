@@ -331,3 +331,68 @@ def test_drop_in_supervised_trainer_end_to_end_vs_the_reference_run(tmp_path, mo
         assert ok, '\n'.join(rep)
     finally:
         dump(f'parity_dropin_e2e_sft_{dtype}.txt', '\n'.join(rep) + '\n')
+
+
+def test_cfgs_only_ppo_and_grpo_trainers_run_on_hardware(tmp_path, monkeypatch):
+    """The cfgs-only PPO and GRPO constructors EXECUTED on the GPU (until round 5 they had only run with the launches recorded).  Sampled rollouts
+    cannot be compared with a reference trajectory, so this checks what is checkable: four PPO models from three checkpoint directories (actor; reward and critic
+    from a score-model directory), prompts through the PromptOnlyDataset plugin surface, `train()` = native rollouts + `rl_step`s on the reference's schedule with
+    slices saved; in the FIRST update the actor equals the reference model, so the KL term is exactly 0 and the reward is the reward model's end score -- recomputed
+    here with HF's OPT modules + the score head in fp32; the saved actor reloads with transformers.  GRPO: actor / reference / reward from directories, one step."""
+    import transformers as tf
+    from align_anything_amd.trainers.grpo import GRPOTrainer
+    from align_anything_amd.trainers.ppo import PPOTrainer
+    from tests.gpu_util import dump
+    from tests.util import dropin_rm_checkpoint, install_dropin_rl_plugins
+    z, zr = load_golden('dropin_e2e.npz'), load_golden('dropin_e2e_rm.npz')
+    install_dropin_rl_plugins(monkeypatch)
+    actor_dir, rm_dir, out = str(tmp_path / 'actor'), str(tmp_path / 'rm'), str(tmp_path / 'run')
+    dropin_checkpoint(actor_dir, z)
+    dropin_rm_checkpoint(rm_dir, zr)
+    data = {'train_datasets': os.path.join(GOLD, 'dropin_e2e.npz'), 'train_template': 'PKUSafeRLHF', 'train_size': 8, 'train_split': None, 'train_name': None,
+            'train_data_files': None, 'train_optional_args': [], 'eval_datasets': None, 'ptx_datasets': None}
+    cfgs = {'train_cfgs': {'per_device_prompt_batch_size': 4, 'per_device_train_batch_size': 4, 'epochs': 1, 'update_iters': 1, 'actor_lr': 1e-5, 'critic_lr': 1e-5,
+                           'actor_lr_scheduler_type': 'constant', 'critic_lr_scheduler_type': 'constant', 'compute_dtype': 'fp32', 'kl_coeff': 0.02},
+            'model_cfgs': {'actor_model_name_or_path': actor_dir, 'reward_model_name_or_path': rm_dir, 'reward_critic_model_name_or_path': rm_dir, 'model_max_length': 400,
+                           'max_new_tokens': 12, 'temperature': 1.0, 'top_p': 1.0},
+            'logger_cfgs': {'output_dir': out, 'save_total_limit': 2}, 'data_cfgs': data}
+    ppo = PPOTrainer(cfgs, {'gradient_clipping': 1.0}, device='cuda:0')
+    assert len(ppo.prompt_only_dataloader) == 2 and ppo.tokenizer.padding_side == 'left' and ppo.reward_critic_model.module.kind == 'opt'
+    # one rollout by hand first: the reward of the sampled sequences against HF's OPT + the score head (fp32, CPU)
+    pb = next(iter(ppo.prompt_only_dataloader))
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    inf, training = ppo.rollout(pb, gen)
+    seq, am = inf['input_ids'].cpu(), inf['attention_mask'].cpu().long()
+    hf = tf.OPTModel(tf.OPTConfig.from_pretrained(rm_dir)).eval().float()
+    from tests.util import state_dict_from_golden
+    w = state_dict_from_golden(zr, 'w.', torch.float32)
+    hf.load_state_dict({k[len('model.'):]: v for k, v in w.items() if k.startswith('model.')})
+    with torch.no_grad():
+        h = hf(input_ids=seq, attention_mask=am).last_hidden_state
+        scores = (h @ w['score_head.weight'].t())[..., 0]
+        end = torch.stack([m.nonzero()[-1, 0] for m in am])
+        want_reward = scores[torch.arange(seq.shape[0]), end]
+    got_reward = training['reward'].float().cpu()
+    rep = [f'PPO cfgs-only on hardware: reward of 4 sampled rollouts native {got_reward.tolist()} vs HF OPT + score head {want_reward.tolist()}']
+    assert (got_reward - want_reward).abs().max() < 2e-4, rep
+    assert float((training['log_probs'].float() - training['ref_log_probs'].float()).abs().max()) == 0.0          # actor == reference before the first update
+    hist = ppo.train(generator=gen)
+    assert len(hist) == 2 and ppo.global_step == 2
+    for k in ('train/actor_loss', 'train/reward_critic_loss', 'train/reward', 'train/kl_divergence', 'train/mean_generated_length'):
+        assert all(np.isfinite(h_[k]) for h_ in hist), k
+    assert hist[0]['train/kl_divergence'] == 0.0 and 0 < hist[0]['train/mean_generated_length'] <= 12
+    rep.append(f'  train(): {[(round(h_["train/actor_loss"], 5), round(h_["train/reward"], 4), round(h_["train/kl_divergence"], 6)) for h_ in hist]} (actor loss, reward, KL)')
+    d = ppo.save()
+    tf.OPTForCausalLM.from_pretrained(d, torch_dtype=torch.float32)
+    assert sorted(os.listdir(out)) == ['slice_1', 'slice_2', 'slice_end']
+    del ppo
+    torch.cuda.empty_cache()
+    gc_ = {'train_cfgs': {'per_device_prompt_batch_size': 4, 'num_generations': 2, 'actor_lr': 1e-5, 'actor_lr_scheduler_type': 'constant', 'compute_dtype': 'fp32', 'epochs': 1},
+           'model_cfgs': {'actor_model_name_or_path': actor_dir, 'reward_model_name_or_path': rm_dir, 'model_max_length': 400, 'max_new_tokens': 8},
+           'logger_cfgs': {'output_dir': str(tmp_path / 'grpo'), 'save_total_limit': 1}, 'data_cfgs': data}
+    gr = GRPOTrainer(gc_, {'gradient_clipping': 1.0}, device='cuda:0')
+    assert gr.pad_token_id == 3 and gr.eos_token_id == 1 and len(gr.prompt_only_dataloader) == 2
+    gh = gr.train(generator=torch.Generator(device='cuda').manual_seed(5))
+    assert len(gh) == 2 and all(np.isfinite(h_['train/loss']) and np.isfinite(h_['train/reward']) for h_ in gh)
+    rep.append(f'GRPO cfgs-only on hardware: {[(round(h_["train/loss"], 6), round(h_["train/reward"], 4)) for h_ in gh]} (loss, mean reward)')
+    dump('parity_dropin_rl_trainers.txt', '\n'.join(rep) + '\n')

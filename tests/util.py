@@ -288,3 +288,42 @@ def install_dropin_sft_plugins(monkeypatch) -> None:
     import sys
     install_dropin_plugins(monkeypatch)
     sys.modules['align_anything.datasets.text_to_text'].SupervisedDataset = DropinSupervisedDataset
+
+
+class DropinPromptOnlyDataset:
+    """Stand-in for `align_anything.datasets.text_to_text.PromptOnlyDataset`: the PROMPT of every pre-tokenised preference sample (its tokens before the chosen
+    response); the collator left-pads, as prompt_only.py's PromptOnlyCollator does."""
+
+    def __init__(self, path, template, tokenizer, processor=None, name=None, size=None, split=None, data_files=None, optional_args=[]):
+        z = np.load(path)
+        off = z['b_off']
+        self.rows = [z['b_ids'][off[i]:off[i + 1] - int(z['b_resp_len'][i])].astype(np.int64) for i in range(len(off) - 1)]
+        if size:
+            self.rows = self.rows[:int(size)]
+        self.pad = int(tokenizer.pad_token_id)
+
+    def __len__(self):
+        return len(self.rows)
+
+    def __getitem__(self, i):
+        return {'input_ids': torch.from_numpy(self.rows[i])}
+
+    def get_collator(self):
+        pad = self.pad
+
+        def collate(samples):
+            L = max(len(s['input_ids']) for s in samples)
+            ids = torch.full((len(samples), L), pad, dtype=torch.long)
+            am = torch.zeros((len(samples), L), dtype=torch.bool)
+            for i, s in enumerate(samples):
+                ids[i, L - len(s['input_ids']):] = s['input_ids']
+                am[i, L - len(s['input_ids']):] = True
+            return {'input_ids': ids, 'attention_mask': am}
+        return collate
+
+
+def install_dropin_rl_plugins(monkeypatch) -> None:
+    import sys
+    install_dropin_plugins(monkeypatch)
+    sys.modules['align_anything.datasets.text_to_text'].PromptOnlyDataset = DropinPromptOnlyDataset
+    sys.modules['align_anything.datasets.text_to_text'].SupervisedDataset = DropinSupervisedDataset
