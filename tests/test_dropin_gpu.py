@@ -352,9 +352,9 @@ def test_cfgs_only_ppo_and_grpo_trainers_run_on_hardware(tmp_path, monkeypatch):
     data = {'train_datasets': os.path.join(GOLD, 'dropin_e2e.npz'), 'train_template': 'PKUSafeRLHF', 'train_size': 8, 'train_split': None, 'train_name': None,
             'train_data_files': None, 'train_optional_args': [], 'eval_datasets': None, 'ptx_datasets': None}
     cfgs = {'train_cfgs': {'per_device_prompt_batch_size': 4, 'per_device_train_batch_size': 4, 'epochs': 1, 'update_iters': 1, 'actor_lr': 1e-5, 'critic_lr': 1e-5,
-                           'actor_lr_scheduler_type': 'constant', 'critic_lr_scheduler_type': 'constant', 'compute_dtype': 'fp32', 'kl_coeff': 0.02},
-            'model_cfgs': {'actor_model_name_or_path': actor_dir, 'reward_model_name_or_path': rm_dir, 'reward_critic_model_name_or_path': rm_dir, 'model_max_length': 400,
-                           'max_new_tokens': 12, 'temperature': 1.0, 'top_p': 1.0},
+                           'actor_lr_scheduler_type': 'constant', 'critic_lr_scheduler_type': 'constant', 'kl_coeff': 0.02},          # bf16: the HIP rollout kernels are bf16 only
+            'model_cfgs': {'actor_model_name_or_path': actor_dir, 'reward_model_name_or_path': rm_dir, 'reward_critic_model_name_or_path': rm_dir, 'model_max_length': 96,
+                           'temperature': 1.0, 'top_p': 1.0},          # the reference generates up to model_max_length (ppo.py:161-170): prompts of 14 - 37 tokens + whatever is left of the 96
             'logger_cfgs': {'output_dir': out, 'save_total_limit': 2}, 'data_cfgs': data}
     ppo = PPOTrainer(cfgs, {'gradient_clipping': 1.0}, device='cuda:0')
     assert len(ppo.prompt_only_dataloader) == 2 and ppo.tokenizer.padding_side == 'left' and ppo.reward_critic_model.module.kind == 'opt'
@@ -374,21 +374,21 @@ def test_cfgs_only_ppo_and_grpo_trainers_run_on_hardware(tmp_path, monkeypatch):
         want_reward = scores[torch.arange(seq.shape[0]), end]
     got_reward = training['reward'].float().cpu()
     rep = [f'PPO cfgs-only on hardware: reward of 4 sampled rollouts native {got_reward.tolist()} vs HF OPT + score head {want_reward.tolist()}']
-    assert (got_reward - want_reward).abs().max() < 2e-4, rep
+    assert (got_reward - want_reward).abs().max() < 3e-2 * max(1.0, float(want_reward.abs().max())), rep          # bf16 scoring forward against fp32 HF modules
     assert float((training['log_probs'].float() - training['ref_log_probs'].float()).abs().max()) == 0.0          # actor == reference before the first update
     hist = ppo.train(generator=gen)
     assert len(hist) == 2 and ppo.global_step == 2
     for k in ('train/actor_loss', 'train/reward_critic_loss', 'train/reward', 'train/kl_divergence', 'train/mean_generated_length'):
         assert all(np.isfinite(h_[k]) for h_ in hist), k
-    assert hist[0]['train/kl_divergence'] == 0.0 and 0 < hist[0]['train/mean_generated_length'] <= 12
+    assert hist[0]['train/kl_divergence'] == 0.0 and 0 < hist[0]['train/mean_generated_length'] <= 96
     rep.append(f'  train(): {[(round(h_["train/actor_loss"], 5), round(h_["train/reward"], 4), round(h_["train/kl_divergence"], 6)) for h_ in hist]} (actor loss, reward, KL)')
     d = ppo.save()
     tf.OPTForCausalLM.from_pretrained(d, torch_dtype=torch.float32)
     assert sorted(os.listdir(out)) == ['slice_1', 'slice_2', 'slice_end']
     del ppo
     torch.cuda.empty_cache()
-    gc_ = {'train_cfgs': {'per_device_prompt_batch_size': 4, 'num_generations': 2, 'actor_lr': 1e-5, 'actor_lr_scheduler_type': 'constant', 'compute_dtype': 'fp32', 'epochs': 1},
-           'model_cfgs': {'actor_model_name_or_path': actor_dir, 'reward_model_name_or_path': rm_dir, 'model_max_length': 400, 'max_new_tokens': 8},
+    gc_ = {'train_cfgs': {'per_device_prompt_batch_size': 4, 'num_generations': 2, 'actor_lr': 1e-5, 'actor_lr_scheduler_type': 'constant', 'epochs': 1},
+           'model_cfgs': {'actor_model_name_or_path': actor_dir, 'reward_model_name_or_path': rm_dir, 'model_max_length': 96},
            'logger_cfgs': {'output_dir': str(tmp_path / 'grpo'), 'save_total_limit': 1}, 'data_cfgs': data}
     gr = GRPOTrainer(gc_, {'gradient_clipping': 1.0}, device='cuda:0')
     assert gr.pad_token_id == 3 and gr.eos_token_id == 1 and len(gr.prompt_only_dataloader) == 2
