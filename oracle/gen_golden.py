@@ -1652,6 +1652,74 @@ def gen_dropin_e2e_sft(threads=8):
           'labelled share', float(np.mean(np.concatenate(labs) != -100)))
 
 
+def gen_dropin_e2e_pref(threads=8):
+    """SimPO through the same end-to-end drop-in check (round 5): the reference's unmodified SimPOTrainer (trainers/text_to_text/simpo.py:41-108; `train_step`
+    inherited from DPOTrainer) on the SAME checkpoint, samples, batches and optimizer recipe as gen_dropin_e2e (whose file holds them; this
+    one only adds the metric trajectory), with the yaml defaults scale_coeff 2.5 / gamma 1.4 (simpo.yaml:59-61)."""
+    from collections import Counter
+    import json
+    import re
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from transformers import OPTForCausalLM, get_scheduler
+    from align_anything.configs.template import ChatTemplate
+    from align_anything.datasets.text_to_text import PreferenceDataset
+    from align_anything.trainers.text_to_text.orpo import ORPOTrainer
+    from align_anything.trainers.text_to_text.simpo import SimPOTrainer
+    import align_anything.trainers.text_to_text.dpo as dpo_mod
+    from align_anything.utils.tools import dict_to_namedtuple, get_optimizer_grouped_parameters
+    from tests.util import DROPIN_SPECIALS, dropin_hf_config, dropin_tokenizer
+    dpo_mod.get_all_reduce_mean = lambda x: x
+    torch.set_num_threads(threads)
+    base = np.load(os.path.join(GOLD, 'dropin_e2e.npz'))
+    asset = '/root/reference/assets/text_to_text/preference/train.json'
+    raw = json.load(open(asset))
+    cnt = Counter(w for r in raw for k in ('prompt', 'response_0', 'response_1') for w in re.findall(r"\w+|[^\w\s]", r[k]))
+    tok = dropin_tokenizer([w for w, _ in cnt.most_common(396)])
+    V = len(DROPIN_SPECIALS) + 396
+    ds = PreferenceDataset(path=asset, template=ChatTemplate(tok, 'PKUSafeRLHF'), tokenizer=tok, processor=None)
+    B, lr, wd = int(base['batch_pairs']), float(base['learning_rate']), float(base['weight_decay'])
+    KEYS = ['train/loss', 'train/reward', 'train/better_sample_reward', 'train/worse_sample_reward', 'train/reward_accuracy', 'train/reward_margin', 'train/lr']
+    out = {}
+    # (ORPO is NOT part of this fixture: on these rows of 60 - 290 tokens the reference's own ORPOTrainer returns inf / nan losses from step 0 -- its odds ratio of
+    # SUMMED log-probs -- so there is no trajectory to compare with; its loss is pinned on short rows by gen_pref / tests/test_pref_gpu.py)
+    for tag, cls, tcfg in (('simpo', SimPOTrainer, {'scale_coeff': 2.5, 'gamma': 1.4}),):
+        torch.manual_seed(0)
+        policy = OPTForCausalLM(dropin_hf_config(V)).eval()
+        with torch.no_grad():
+            for p in policy.parameters():
+                p.copy_(p.to(torch.bfloat16).float())
+        for n, t in policy.state_dict().items():           # the checkpoint of gen_dropin_e2e, to the bit
+            assert np.array_equal(bf16_bits(t), base['w.' + n]), n
+        dl = DataLoader(ds, collate_fn=ds.get_collator(), sampler=DistributedSampler(ds, num_replicas=1, rank=0, shuffle=True), batch_size=B)
+        steps = len(dl)
+        opt = torch.optim.AdamW(get_optimizer_grouped_parameters(policy, wd), lr=lr, betas=(0.9, 0.95), eps=1e-8)
+        sched = get_scheduler('cosine', opt, num_warmup_steps=int(0.03 * steps), num_training_steps=steps)
+
+        class Engine:
+            def __init__(self, m): self.module, self.optimizer = m, opt
+            def backward(self, loss): loss.backward()
+            def step(self):
+                torch.nn.utils.clip_grad_norm_(self.module.parameters(), 1.0)
+                opt.step(); sched.step(); opt.zero_grad(set_to_none=True)
+
+        tr = cls.__new__(cls)
+        tr.cfgs = dict_to_namedtuple({'train_cfgs': tcfg})
+        tr.tokenizer = tok
+        tr.infer_batch = lambda b: {k: v for k, v in b.items() if k != 'meta_info'}
+        tr.model = Engine(policy)
+        rows = []
+        for i, b in enumerate(dl):
+            assert np.array_equal(b['input_ids'].numpy(), base[f'batch{i}.input_ids'])
+            info = tr.train_step(b)
+            rows.append([info[k] for k in KEYS])
+        out['metrics_' + tag] = np.array(rows, dtype=np.float64)
+        for k, v in tcfg.items():
+            out[f'{tag}_{k}'] = np.array(v)
+        print(tag, 'loss', np.array(rows)[:, 0].round(6).tolist())
+    np.savez_compressed(os.path.join(GOLD, 'dropin_e2e_pref.npz'), **out)
+
+
 def _opt125m_reference_trainer(nthreads):
     """The reference's unmodified DPOTrainer (trainers/text_to_text/dpo.py) on config 1 with the DeepSpeed engine replaced by
     torch.optim.AdamW over the reference's own parameter groups + clip_grad_norm_(1.0) + HF cosine schedule (see gen_opt125m_curve).

@@ -397,3 +397,29 @@ def test_cfgs_only_ppo_and_grpo_trainers_run_on_hardware(tmp_path, monkeypatch):
     assert len(gh) == 2 and all(np.isfinite(h_['train/loss']) and np.isfinite(h_['train/reward']) for h_ in gh)
     rep.append(f'GRPO cfgs-only on hardware: {[(round(h_["train/loss"], 6), round(h_["train/reward"], 4)) for h_ in gh]} (loss, mean reward)')
     dump('parity_dropin_rl_trainers.txt', '\n'.join(rep) + '\n')
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_drop_in_simpo_trainer_end_to_end_vs_the_reference_run(tmp_path, monkeypatch, dtype):
+    """`SimPOTrainer(cfgs, ds_cfgs)` (no reference model; length-normalised log-probs, margin gamma) from the checkpoint directory and plugin surface of the DPO
+    test, against the reference's own SimPOTrainer on the same batches (tests/golden/dropin_e2e_pref.npz, oracle/gen_golden.py::gen_dropin_e2e_pref: simpo.yaml's
+    scale_coeff 2.5 / gamma 1.4, 8 free-running steps)."""
+    from align_anything_amd.trainers.pref import SimPOTrainer
+    from tests.gpu_util import dump
+    z, zp = load_golden('dropin_e2e.npz'), load_golden('dropin_e2e_pref.npz')
+    install_dropin_plugins(monkeypatch)
+    ckpt, out = str(tmp_path / 'ckpt'), str(tmp_path / 'run')
+    dropin_checkpoint(ckpt, z)
+    cfgs = _cfgs(z, ckpt, out, dtype, scale_coeff=float(zp['simpo_scale_coeff']), gamma=float(zp['simpo_gamma']), save_checkpoint=False)
+    tr = SimPOTrainer(cfgs, {'gradient_clipping': 1.0}, device='cuda:0')
+    assert tr.reference is None
+    hist = tr.train()
+    got = np.array([[h[k] for k in KEYS] for h in hist], dtype=np.float64)
+    want = zp['metrics_simpo']
+    err = np.abs(got - want).max(0)
+    rep = [f'{dtype}: native SimPOTrainer(cfgs, ds_cfgs) vs the reference SimPOTrainer, {len(hist)} steps']
+    for i in range(len(hist)):
+        rep.append(f'  step {i}: loss native {got[i, 0]:.6f} reference {want[i, 0]:.6f} |diff| {abs(got[i, 0] - want[i, 0]):.2e}   margin {got[i, 5]:+.5f} / {want[i, 5]:+.5f}')
+    rep.append('  max |diff| per metric: ' + ', '.join(f'{k.split("/")[1]} {e:.2e}' for k, e in zip(KEYS, err)))
+    dump(f'parity_dropin_e2e_simpo_{dtype}.txt', '\n'.join(rep) + '\n')
+    assert err[6] < 1e-12 and err[0] < (2e-4 if dtype == 'fp32' else 0.15) and err[4] < (1e-9 if dtype == 'fp32' else 0.2500001), '\n'.join(rep)     # losses of 1.3 - 6.0: 2e-4 abs in fp32
