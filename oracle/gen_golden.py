@@ -1868,3 +1868,14 @@ if __name__ == '__main__':
     gen_opt125m_curve()
     gen_opt125m_teacher()
     gen_llava7b_width()
+    # round 5
+    gen_llava7b_width_bf16ref()
+    gen_llama31_width()
+    gen_qwen2vl_width()
+    gen_qwen2audio_width()
+    gen_qwen3moe_width()
+    gen_dropin_e2e()
+    gen_dropin_e2e_pref()
+    gen_dropin_e2e_ti2t()
+    gen_dropin_e2e_rm()
+    gen_dropin_e2e_sft()
