@@ -648,17 +648,17 @@ __device__ __forceinline__ float key_float(uint32_t k) {
     return __builtin_bit_cast(float, b);
 }
 
-// COAL (round 5, V <= 163840): thread t owns the 8-element groups s * 512 + t of every 4096-element SEGMENT s -- a wave's load is 1 KB of consecutive bytes
-// instead of 64 cache lines 608 bytes apart (the contiguous-slice form re-fetched every line from L2 ~5 times per pass: 100 us per position at V = 152064, one
-// CU's L1 thrashing on 64 KB per load step).  All passes but the draw are order-independent sums / counts; the draw needs the vocabulary order, which the segments
-// give back in two levels: per-segment kept masses (40 registers per thread, one transposed reduction), the segment that holds the target, one block scan inside it.
-template <bool COAL>
+// exp on the hardware's exp2 (v_exp_f32, ~1 ulp): the sampler evaluates it V times in each of its >= 3 passes on ONE compute unit -- with libm's expf (range reduction +
+// polynomial, ~20 VALU instructions) that was ~60 of the kernel's 100 us at V = 152064 (round 5: coalescing the loads instead changed nothing, it is not the memory system).
+// exp(-inf) = 0 and exp(0) = 1 exactly, as before.
+__device__ __forceinline__ float sexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restrict__ logits, long ld, int V,
                                                            float inv_temp, float top_p, int top_k,
                                                            const float* __restrict__ u,
                                                            const uint8_t* __restrict__ seen_all, long ld_seen, float pen,
                                                            int64_t* __restrict__ out) {
-    constexpr int NT = 512, NW = NT / 64, KS = 7, MAXS = 40;
+    constexpr int NT = 512, NW = NT / 64, KS = 7;
     __shared__ float red[NW];
     __shared__ float red7[NW][KS];
     __shared__ float wtot[NW];
@@ -666,30 +666,17 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
     const bf16_t* x = logits + (long)blockIdx.x * ld;
     const uint8_t* seen = seen_all ? seen_all + (long)blockIdx.x * ld_seen : nullptr;
     const int per = (((V + NT - 1) / NT) + 7) & ~7;
-    const int b = COAL ? 0 : min(V, (int)threadIdx.x * per), e = COAL ? V : min(V, b + per);
-    const int nseg = (V + NT * 8 - 1) / (NT * 8);
+    const int b = min(V, (int)threadIdx.x * per), e = min(V, b + per);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // f(i0) for every 8-element group this thread owns
-    auto each = [&](auto&& f) {
-        if constexpr (COAL) {
-#pragma unroll 4
-            for (int sg = 0; sg < nseg; ++sg) {
-                const int i0 = (sg * NT + (int)threadIdx.x) * 8;
-                if (i0 < V) f(i0);
-            }
-        } else {
-#pragma unroll 2
-            for (int i0 = b; i0 < e; i0 += 8) f(i0);
-        }
-    };
     // ---- pass 1: maximum of the scores (penalty, temperature applied)
     float mx = -INFINITY;
-    each([&](int i0) {
+#pragma unroll 2
+    for (int i = b; i < e; i += 8) {
         float v[8];
-        load_scores8(x, seen, i0, e, pen, inv_temp, v);
+        load_scores8(x, seen, i, e, pen, inv_temp, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[j]);
-    });
+    }
     mx = block_max<NT>(mx, red);
     // ---- top-k: floor = the k-th largest score (exact).  Invariant: count(score >= lo) >= k > count(score >= hi), on integer keys.
     float floor = -INFINITY;
@@ -701,16 +688,17 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
             int cs[KS];
 #pragma unroll
             for (int k = 0; k < KS; ++k) cs[k] = 0;
-            each([&](int i0) {
+#pragma unroll 2
+            for (int i = b; i < e; i += 8) {
                 float v[8];
-                load_scores8(x, seen, i0, e, pen, inv_temp, v);
+                load_scores8(x, seen, i, e, pen, inv_temp, v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const unsigned long long kj = float_key(v[j]);
 #pragma unroll
                     for (int k = 0; k < KS; ++k) cs[k] += (kj >= lo + width * (unsigned long long)(k + 1) / 8ull) ? 1 : 0;
                 }
-            });
+            }
 #pragma unroll
             for (int k = 0; k < KS; ++k) {
 #pragma unroll
@@ -739,12 +727,13 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
     }
     // ---- pass 2: partition function
     float z = 0.f;
-    each([&](int i0) {
+#pragma unroll 2
+    for (int i = b; i < e; i += 8) {
         float v[8];
-        load_scores8(x, seen, i0, e, pen, inv_temp, v, floor);
+        load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z += expf(v[j] - mx);          // exp(-inf) = 0 for the slots beyond e
-    });
+        for (int j = 0; j < 8; ++j) z += sexp(v[j] - mx);          // exp(-inf) = 0 for the slots beyond e
+    }
     z = block_sum<NT>(z, red);
     const float invz = 1.f / z;
     // ---- threshold search: largest tau with mass(p >= tau) >= top_p   (p in (0, 1], p_max = 1/z)
@@ -755,16 +744,17 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
             float ms[KS];
 #pragma unroll
             for (int k = 0; k < KS; ++k) ms[k] = 0.f;
-            each([&](int i0) {
+#pragma unroll 2
+            for (int i = b; i < e; i += 8) {
                 float v[8];
-                load_scores8(x, seen, i0, e, pen, inv_temp, v, floor);
+                load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float pj = expf(v[j] - mx) * invz;
+                    const float pj = sexp(v[j] - mx) * invz;
 #pragma unroll
                     for (int k = 0; k < KS; ++k) ms[k] += (pj >= lo + step * (float)(k + 1)) ? pj : 0.f;
                 }
-            });
+            }
 #pragma unroll
             for (int k = 0; k < KS; ++k) ms[k] = wave_sum(ms[k]);
             __syncthreads();
@@ -786,75 +776,15 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
     }
     const float tau = lo;
     // ---- the draw: first index (vocabulary order) whose running kept mass exceeds u * kept
-    float mine = 0.f, base0 = 0.f;     // this thread's kept mass inside the scanned range; kept mass in front of that range
-    int i_own = b, e_own = e;          // the groups the owner thread walks: its slice, or its ONE group of the chosen segment
-    if constexpr (COAL) {
-        __shared__ float segw[NW][MAXS];
-        __shared__ float segs[MAXS + 2];
-        float a[MAXS];
-#pragma unroll
-        for (int sg = 0; sg < MAXS; ++sg) {
-            a[sg] = 0.f;
-            const int i0 = (sg * NT + (int)threadIdx.x) * 8;
-            if (sg < nseg && i0 < V) {
-                float v[8];
-                load_scores8(x, seen, i0, e, pen, inv_temp, v, floor);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float pj = expf(v[j] - mx) * invz; a[sg] += (pj >= tau) ? pj : 0.f; }
-            }
-        }
-#pragma unroll
-        for (int sg = 0; sg < MAXS; ++sg) {
-            const float t = wave_sum(a[sg]);
-            if (lane == 0) segw[wave][sg] = t;
-        }
-        __syncthreads();
-        if (threadIdx.x < MAXS) {
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) t += segw[w][threadIdx.x];
-            segs[threadIdx.x] = t;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {          // 40 values: the segment whose running kept mass first exceeds the target (else the last one that keeps anything)
-            float tot = 0.f;
-            for (int sg = 0; sg < nseg; ++sg) tot += segs[sg];
-            const float target0 = u[blockIdx.x] * (top_p >= 1.f ? tot : kept);
-            float c = 0.f;
-            int pick = -1, last = 0;
-            for (int sg = 0; sg < nseg; ++sg) {
-                if (segs[sg] > 0.f) last = sg;
-                if (pick < 0 && c + segs[sg] > target0 && segs[sg] > 0.f) pick = sg;
-                if (pick < 0) c += segs[sg];
-            }
-            if (pick < 0) {              // u ~ 1 and rounding: the last segment that keeps anything
-                pick = last;
-                c = 0.f;
-                for (int sg = 0; sg < last; ++sg) c += segs[sg];
-            }
-            segs[MAXS] = c;
-            segs[MAXS + 1] = tot;
-            sel[0] = pick;
-        }
-        __syncthreads();
-        const int sstar = sel[0];
-        base0 = segs[MAXS];
-        if (top_p >= 1.f) kept = segs[MAXS + 1];
-#pragma unroll
-        for (int sg = 0; sg < MAXS; ++sg) mine = (sg == sstar) ? a[sg] : mine;
-        i_own = (sstar * NT + (int)threadIdx.x) * 8;
-        e_own = min(V, i_own + 8);
-        __syncthreads();                 // sel is reused below
-    } else {
+    float mine = 0.f;
 #pragma unroll 2
-        for (int i = b; i < e; i += 8) {
-            float v[8];
-            load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
+    for (int i = b; i < e; i += 8) {
+        float v[8];
+        load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float pj = expf(v[j] - mx) * invz; mine += (pj >= tau) ? pj : 0.f; }
-        }
-        if (top_p >= 1.f) kept = block_sum<NT>(mine, red);          // (the search did not run: kept = total mass as summed here)
+        for (int j = 0; j < 8; ++j) { const float pj = sexp(v[j] - mx) * invz; mine += (pj >= tau) ? pj : 0.f; }
     }
+    if (top_p >= 1.f) kept = block_sum<NT>(mine, red);          // (the search did not run: kept = total mass as summed here)
     const float target = u[blockIdx.x] * kept;
     float incl = mine;                                           // inclusive scan over the threads: wave level, then wave totals
 #pragma unroll
@@ -863,7 +793,7 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
     __syncthreads();
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    float base = base0;
+    float base = 0.f;
     for (int w = 0; w < wave; ++w) base += wtot[w];
     incl += base;
     if (incl > target && mine > 0.f) atomicMin(&sel[0], (int)threadIdx.x);
@@ -874,16 +804,16 @@ __global__ __launch_bounds__(512) void sample_top_p_kernel(const bf16_t* __restr
     if ((int)threadIdx.x == owner) {
         float c = incl - mine;
         int pick = -1, last_kept = -1;
-        for (int i = i_own; i < e_own && pick < 0; i += 8) {
+        for (int i = b; i < e && pick < 0; i += 8) {
             float v[8];
             load_scores8(x, seen, i, e, pen, inv_temp, v, floor);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float pj = expf(v[j] - mx) * invz;
+                const float pj = sexp(v[j] - mx) * invz;
                 if (pick < 0 && i + j < e && pj >= tau) { last_kept = i + j; c += pj; if (c > target) pick = i + j; }
             }
         }
-        out[blockIdx.x] = pick >= 0 ? pick : (last_kept >= 0 ? last_kept : i_own);
+        out[blockIdx.x] = pick >= 0 ? pick : (last_kept >= 0 ? last_kept : b);
     }
     if (owner < 0 && threadIdx.x == 0) out[blockIdx.x] = 0;      // unreachable: p_max >= tau always keeps one token
 }
@@ -894,15 +824,8 @@ extern "C" int aa_sample_top_k_top_p(const void* logits, long ld, int rows, int 
     AA_REQUIRE(repetition_penalty > 0.f, "aa_sample_top_k_top_p: repetition_penalty must be > 0");
     AA_REQUIRE(temperature > 0.f && top_p > 0.f && top_p <= 1.f, "aa_sample_top_k_top_p: temperature=%f / top_p=%f out of range", temperature, top_p);
     AA_REQUIRE(top_k >= 0, "aa_sample_top_k_top_p: top_k %d (0 = no cut)", top_k);
-    // segment-interleaved ownership (coalesced loads) for V <= 40 x 4096; AA_SAMPLER_COALESCED=0 keeps the contiguous-slice form (same-box A/B), which also serves larger V
-    static int coal = -1;
-    if (coal < 0) { const char* e = getenv("AA_SAMPLER_COALESCED"); coal = e ? atoi(e) : 1; }
-    if (coal && V <= 40 * 512 * 8)
-        hipLaunchKernelGGL(sample_top_p_kernel<true>, dim3(rows), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
-                           1.f / temperature, top_p, top_k, uniform, seen, ld_seen, repetition_penalty, out);
-    else
-        hipLaunchKernelGGL(sample_top_p_kernel<false>, dim3(rows), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
-                           1.f / temperature, top_p, top_k, uniform, seen, ld_seen, repetition_penalty, out);
+    hipLaunchKernelGGL(sample_top_p_kernel, dim3(rows), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
+                       1.f / temperature, top_p, top_k, uniform, seen, ld_seen, repetition_penalty, out);
     AA_CHECK_LAUNCH("aa_sample_top_k_top_p");
     return AA_OK;
 }

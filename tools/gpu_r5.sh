@@ -106,14 +106,10 @@ for k in r['by_kind_top12'][:8]: print(k)" || tail -5 gpurun_out/r05_bench_b1.er
           python -c "import json; d=json.load(open('gpurun_out/r05_bench_$lib.json')); r=d['roofline']; print('$lib rep $rep', round(d['ms_per_step'],2), 'ms  W', round(r['power_w_mean']), 'MHz', round(r['sclk_mhz_mean']), 'J/TFLOP', round(r['j_per_tflop_step'],4))" || tail -3 gpurun_out/r05_bench_$lib.err
         done
       done ;;
-    sampler)         # round 5: the sampler on segment-interleaved ownership (coalesced loads) vs the contiguous-slice form: tests, per-kernel time, PPO iteration
-      timeout 600 python -m pytest tests/test_decode_gpu.py tests/test_grpo_gpu.py tests/test_ppo_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r05_sampler_tests.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/r05_sampler_tests.log | cut -c1-300
-      AA_SAMPLER_COALESCED=0 timeout 600 python -m pytest tests/test_decode_gpu.py -q -x -m gpu -p no:cacheprovider -k "selection or top_k" 2>&1 | tail -2
+    sampler)         # round 5: the sampler's exponentials on v_exp_f32: tests, per-kernel time, PPO iteration
+      timeout 600 python -m pytest tests/test_decode_gpu.py tests/test_grpo_gpu.py tests/test_ppo_gpu.py tests/test_dropin_gpu.py -q -x -m gpu -p no:cacheprovider -k "not end_to_end" > gpurun_out/r05_sampler_tests.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/r05_sampler_tests.log | cut -c1-300
       python - <<'PY'
-import os, sys, torch, subprocess, json
-sys.path.insert(0, os.getcwd())
-code = """
-import torch, sys, os
+import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from align_anything_amd import ops
 from tools.bench_kernels import timeit
@@ -124,14 +120,10 @@ for V in (152064, 32064, 128256):
     for top_p, top_k in ((1.0, 0), (0.9, 50)):
         ms = timeit(lambda: ops.sample_top_p(lg, 1.0, top_p, u, None, 1.0, top_k=top_k), iters=200, warm=20)
         print('V', V, 'top_p', top_p, 'top_k', top_k, 'us', round(ms * 1e3, 1), flush=True)
-"""
-for v in ('0', '1', '0', '1'):
-    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, AA_SAMPLER_COALESCED=v), capture_output=True, text=True)
-    print('AA_SAMPLER_COALESCED=' + v, ' | '.join(l.strip() for l in r.stdout.strip().split(chr(10))), r.stderr[-300:] if r.returncode else '')
 PY
-      for v in 0 1 0 1; do
-        AA_SAMPLER_COALESCED=$v timeout 300 python tools/bench_ppo.py --iters 2 > gpurun_out/r05_bench_ppo_sampler$v.json 2> gpurun_out/r05_bench_ppo_sampler$v.err
-        python -c "import json; d=json.load(open('gpurun_out/r05_bench_ppo_sampler$v.json')); print('AA_SAMPLER_COALESCED=$v', round(d['decode_ms_per_position'],4), 'ms/pos', round(d['iteration_ms'],1), 'ms/iter')" || tail -3 gpurun_out/r05_bench_ppo_sampler$v.err
+      for v in 1 2; do
+        timeout 300 python tools/bench_ppo.py --iters 2 > gpurun_out/r05_bench_ppo_sampler$v.json 2> gpurun_out/r05_bench_ppo_sampler$v.err
+        python -c "import json; d=json.load(open('gpurun_out/r05_bench_ppo_sampler$v.json')); print('run $v', round(d['decode_ms_per_position'],4), 'ms/pos', round(d['iteration_ms'],1), 'ms/iter')" || tail -3 gpurun_out/r05_bench_ppo_sampler$v.err
       done ;;
     *) echo "unknown stage $stage" ;;
   esac
