@@ -538,6 +538,11 @@ class NativeEngine:
         ck = torch.load(os.path.join(load_dir, f'native_engine_{tag}.pt'), map_location='cpu')
         self.global_steps = ck['global_steps']
         self.micro_steps = ck.get('micro_steps', self.global_steps * self.gas)        # a slice saved inside an accumulation window resumes inside it
+        if self.micro_steps % self.gas:
+            # ... with the window's earlier micro-batches lost (DeepSpeed's checkpoint does not carry the accumulation buffers either): the next backward
+            # ACCUMULATES (it is not the window's first), so whatever this engine's gradient buffers held must not leak into the resumed window
+            for t in st.gflat.values():
+                t.zero_()
         if not (self.total_steps is None and self.sched in ('cosine', 'linear')):      # else: set_schedule() refreshes it once the length is known
             for pg in self.optimizer.param_groups:
                 pg['lr'] = self._lr_at(self.global_steps)

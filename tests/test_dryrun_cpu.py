@@ -574,6 +574,16 @@ def test_rm_grpo_ppo_loops_resume_and_save_on_the_reference_schedules(launches, 
     rm2.model.global_steps = 99
     rm2.model.load_checkpoint(str(tmp_path / 'eng'))
     assert rm2.model.global_steps == 0 and rm2.model.micro_steps == 0
+    # a slice taken INSIDE an accumulation window: micro_steps travels with it, and the gradient buffers of the loading engine are cleared (the window's
+    # earlier micro-batches are lost, as with DeepSpeed; nothing stale may be accumulated into)
+    rm2.model.gas, rm2.model.micro_steps, rm2.model.global_steps = 2, 3, 1
+    rm2.model.save_checkpoint(str(tmp_path / 'eng2'))
+    for g in rm2.model.module.store.gflat.values():
+        g.fill_(1.0)
+    rm2.model.micro_steps = 0
+    rm2.model.load_checkpoint(str(tmp_path / 'eng2'))
+    assert rm2.model.micro_steps == 3 and rm2.model.global_steps == 1 and all(float(g.float().abs().sum()) == 0.0 for g in rm2.model.module.store.gflat.values())
+    rm2.model.gas = 1
     rm2.model.global_steps, rm2.model.micro_steps, rm2.global_step = 4, 4, 4          # = a slice taken after step 4 of 6
     hist2 = rm2.train([_pref_batch(z)] * 3)
     from align_anything_amd.engine import cosine_with_warmup
