@@ -15,7 +15,8 @@ boundary hands over device tensors): the CLIP tower, the response-window plan an
 the timed region for every step -- nothing is cached across steps, and the loss stays at its random-data level.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the bf16 MFMA GEMM, measured with
-HIP event pairs around a 1-in-11 sample of the GEMM launches of the timed steps), `step_mfma` (whole-step MFMA fraction on the FLOPs the step
+HIP event pairs around a 1-in-11 sample of the GEMM launches of the timed steps; since round 5 also `power_w_mean` / `sclk_mhz_mean` over exactly the timed region from a
+sidecar process, tools/power_sampler.py, and with them `peak_at_sclk`, `frac_of_peak_at_sclk`, `j_per_tflop_step`), `step_mfma` (whole-step MFMA fraction on the FLOPs the step
 EXECUTES, with SURVEY.md's algorithmic figure beside it) `cpu_baseline` (the CPU oracle port, bounded sample, live; + the committed figure of the reference's own trainer timed in the build
 container), `per_batch` (the same step at 1 and 2 pairs per GPU) and `glu_bwd_plan` (the per-box choice between the fused and the
 unfused SwiGLU-backward, csrc/gemm.hip).
