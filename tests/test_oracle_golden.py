@@ -477,3 +477,32 @@ def test_teacher_reproduces_the_reference_first_steps_without_the_reference():
         assert abs(info['grad_norm'] - float(z['ref'][k, 1])) < 2e-4 * float(z['ref'][k, 1])
         assert abs(info['train/lr'] - float(z['ref'][k, 2])) < 1e-15
         assert float((fingerprint(w, index) - torch.from_numpy(z['fingerprint'][k + 1])).abs().max()) <= 2.5e-7
+
+
+def test_teacher_free_running_reproduces_the_reference_drop_in_trajectory():
+    """The oracle's per-step function (oracle/teacher.py: reference `compute_log_probs` + `loss` restated in oracle/rl_math.py, HF's own OPT arithmetic, torch AdamW form,
+    clip, cosine schedule), run FREE from the checkpoint of tests/golden/dropin_e2e.npz over the eight ragged, left-padded batches the reference's own loader produced,
+    reproduces the loss / margin / lr trajectory of the UNMODIFIED reference trainer stored there (oracle/gen_golden.py::gen_dropin_e2e) -- a second, independent pin of the
+    oracle besides the 64 teacher-forced OPT-125m steps, on the reference's real asset data."""
+    from oracle.teacher import Teacher
+    from align_anything_amd import configs
+    from tests.util import dropin_hf_config
+    z = load_golden('dropin_e2e.npz')
+    hc = dropin_hf_config(int(z['vocab_size']))
+    w = {k: v.clone() for k, v in state_dict_from_golden(z, 'w.', torch.float32).items()}
+    steps = int(z['steps'])
+    torch.set_num_threads(8)
+    t = Teacher(configs.from_hf_config(hc), w, 3, steps, beta=float(z['scale_coeff']), lr=float(z['learning_rate']), weight_decay=float(z['weight_decay']), hf_config=hc)
+    names = Teacher.names(w)
+    m = {n: torch.zeros_like(w[n]) for n in names}
+    v = {n: torch.zeros_like(w[n]) for n in names}
+    want = z['metrics']
+    worst = 0.0
+    for k in range(steps):
+        b = {'input_ids': torch.from_numpy(z[f'batch{k}.input_ids']).long(), 'attention_mask': torch.from_numpy(z[f'batch{k}.attention_mask']).long(),
+             'meta_info': {'response_lens': z[f'batch{k}.response_lens'].tolist()}}
+        info, w, m, v = t.step(w, m, v, k, b)
+        worst = max(worst, abs(info['train/loss'] - want[k, 0]))
+        assert abs(info['train/lr'] - want[k, 6]) < 1e-15 and abs(info['grad_norm'] - want[k, 7]) < 2e-4 * want[k, 7], (k, info['grad_norm'], want[k, 7])
+        assert abs(info['train/reward_margin'] - want[k, 5]) < 2e-5 and info['train/reward_accuracy'] == want[k, 4], k
+    assert worst < 5e-6, worst          # free-running; the reference against itself at another thread count: 2.0e-6
