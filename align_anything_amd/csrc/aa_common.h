@@ -19,6 +19,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 
 #define AA_WAVE 64
+#define AA_MAX_DEVICES 16     // per-device caches of launch parameters (one node: 8 GPUs)
 
 __device__ __forceinline__ float bf2f(bf16_t u) {
     return __builtin_bit_cast(float, (uint32_t)u << 16);

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_small_kernel(const elem_t* __
 // dw partials are kept per thread in registers across the block's rows and written as one partial row per block (reduce_rows_kernel sums them).
 // A block walks TWO rows per iteration (round 5): their x / dy / residual vectors are all requested before the first is used and the two row
 // reductions share one barrier pair -- twice the bytes in flight per block and half the barriers.  Per row, and per column of dw (row order kept), the
-// arithmetic is that of the one-row form: results are bit-identical to round 4's kernel.  Bytes per launch with the residual gradient added
+// arithmetic is that of the one-row form: dx is bit-identical to round 4's kernel (dw: equal up to the fp32 summation order of the per-block partials, which the grid fixes).  Bytes per launch with the residual gradient added
 // (add_to_dx, every call of the decoder stack): read x + dy + dx, write dx = 8 h bytes per row.
 template <int MAXV>  // max 16-byte vectors per thread (h <= 256*8*MAXV)
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const elem_t* __restrict__ dy,
@@ -465,16 +465,23 @@ extern "C" int AA_FN(aa_rmsnorm_bwd)(const void* dy, const void* x, const void* 
     }
     // one round of co-resident blocks: the two-row kernel holds 2 x 3 row vectors per thread (168 VGPRs at h = 4096: three blocks per CU), and a grid
     // larger than what is resident would run a part-empty second round; every block walks rows / grid rows, so a smaller grid costs nothing
+    // (the slot count is cached per DEVICE -- ADVICE r5: one process-wide static took the first caller's device for every later one; the race of two host
+    // threads on a first call is benign, both compute the same value.  dx is bit-identical whatever the grid; the dw partial sums are grouped by the grid,
+    // so dw is equal up to fp32 summation order across grids.)
 #define LAUNCH_RMSB(MV)                                                                             \
     do {                                                                                            \
-        static int slots = 0;                                                                       \
+        static int slots_of[AA_MAX_DEVICES] = {0};                                                  \
+        int dev = 0;                                                                                \
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= AA_MAX_DEVICES) dev = -1;         \
+        int slots = dev >= 0 ? slots_of[dev] : 0;                                                   \
         if (slots == 0) {                                                                           \
-            int per_cu = 0, dev = 0, cus = 0;                                                       \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmsnorm_bwd_kernel<MV>, 256, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess || \
+            int per_cu = 0, cus = 0;                                                                \
+            if (dev < 0 || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmsnorm_bwd_kernel<MV>, 256, 0) != hipSuccess ||                        \
                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu <= 0 || cus <= 0)                         \
                 slots = 1024;                                                                       \
             else                                                                                    \
                 slots = per_cu * cus;                                                               \
+            if (dev >= 0) slots_of[dev] = slots;                                                    \
         }                                                                                           \
         if (grid > slots) grid = slots;                                                             \
         hipLaunchKernelGGL(rmsnorm_bwd_kernel<MV>, dim3(grid), dim3(256), 0, st, (const elem_t*)dy, \

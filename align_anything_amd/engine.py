@@ -241,6 +241,8 @@ class NativeEngine:
         if ep is not None and ep.size != self.world:
             raise ValueError(f'expert-parallel degree {ep.size} must equal the data-parallel world size {self.world}')
         if trainable:
+            if ep is not None and ep.padded:
+                ep.attach_engine()      # before any step or rollout: polls never consume the local capacity flag of an engine-owned exchange
             module.init_training()
             dev = module.device
             self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -276,7 +278,7 @@ class NativeEngine:
             if self.micro_steps % self.gas:
                 raise RuntimeError('set_schedule(): cannot change the accumulation depth inside an accumulation window')
             self.gas = max(1, int(gradient_accumulation_steps))
-            self.micro_steps = 0
+            self.micro_steps = self.global_steps * self.gas          # 0 on a fresh engine; a resumed one stays at the boundary of its last update
         self.total_steps = max(1, int(total_steps))
         if warmup_ratio is not None:
             self.warmup_steps = int(self.total_steps * float(warmup_ratio))
@@ -526,7 +528,7 @@ class NativeEngine:
         tag = tag or 'latest'
         pick = lambda groups: {k: {g: t.cpu() for g, t in d.items() if g in groups} for k, d in (('master', st.master), ('m', st.m), ('v', st.v))}
         if rank == 0:
-            torch.save({'global_steps': self.global_steps, 'micro_steps': self.micro_steps, **pick([g for g in st.master if g != 'exp'])},
+            torch.save({'global_steps': self.global_steps, 'micro_steps': self.micro_steps, 'gas': self.gas, **pick([g for g in st.master if g != 'exp'])},
                        os.path.join(save_dir, f'native_engine_{tag}.pt'))
         if 'exp' in st.master:
             torch.save(pick(['exp']), os.path.join(save_dir, f'native_engine_{tag}_ep{rank}.pt'))
@@ -538,6 +540,13 @@ class NativeEngine:
         ck = torch.load(os.path.join(load_dir, f'native_engine_{tag}.pt'), map_location='cpu')
         self.global_steps = ck['global_steps']
         self.micro_steps = ck.get('micro_steps', self.global_steps * self.gas)        # a slice saved inside an accumulation window resumes inside it
+        saved_gas = ck.get('gas', self.gas)
+        if saved_gas != self.gas:
+            # the saved window phase means nothing at another accumulation depth -- restart at the boundary of the last COMPLETED update (a partial
+            # window's micro-batches are dropped, they were scaled by 1 / saved_gas) instead of resuming a window built from fewer, wrongly scaled micro-batches
+            if self.micro_steps != self.global_steps * saved_gas:
+                print(f'[engine] checkpoint saved with gradient_accumulation_steps={saved_gas} inside a window, loaded with {self.gas}: the partial window is dropped', flush=True)
+            self.micro_steps = self.global_steps * self.gas
         if self.micro_steps % self.gas:
             # ... with the window's earlier micro-batches lost (DeepSpeed's checkpoint does not carry the accumulation buffers either): the next backward
             # ACCUMULATES (it is not the window's first), so whatever this engine's gradient buffers held must not leak into the resumed window

@@ -198,10 +198,14 @@ class ExpertParallel:
             return torch.zeros((), dtype=torch.float32, device=device)
         return torch.where(flag.to(device), float('-inf'), 0.0).to(torch.float32)
 
+    def attach_engine(self) -> None:
+        """A TRAINABLE engine owns the local flag from its construction on (ownership decided by the first `watch_shared` left the engine's
+        very first step -- and any rollouts before it -- on the stand-alone branch, whose poll consumed the flag before the sentinel could carry it):
+        the flag is consumed only by `overflow_sentinel`, so it always reaches the all-reduce, and `poll_overflow` reads only the shared one."""
+        self._engine = True
+
     def watch_shared(self, sumsq: torch.Tensor) -> None:
-        """After the all-reduce: start the asynchronous host copy of "some rank overflowed" (identical on every rank) for `poll_overflow`.
-        From the first call on an engine owns the LOCAL flag: it is consumed only by `overflow_sentinel` (so that it always reaches the
-        all-reduce, whatever polls happen in between -- ADVICE r4), and `poll_overflow` reads only this shared one."""
+        """After the all-reduce: start the asynchronous host copy of "some rank overflowed" (identical on every rank) for `poll_overflow`."""
         self._engine = True
         flag = (sumsq.reshape(-1)[0] == float('-inf'))
         self._shared = flag if self._shared is None else (self._shared | flag)

@@ -320,13 +320,15 @@ class PPOTrainer(PPOMath):
             if a.gas != a_gas and not a.global_steps and a.micro_steps % a.gas == 0:
                 a.gas, a.micro_steps = a_gas, 0
             return           # unsized iterable and no explicit total: a cosine engine will refuse to step (engine._lr_at)
-        if a.global_steps or c.global_steps:
-            return           # a resumed / second train() call keeps the schedule it started with
         total = int(explicit) if explicit is not None else (
             len(prompt_only_dataloader) * int(t('epochs', 1)) * int(t('update_iters', 1)) * int(t('per_device_train_batch_size', 8))
             * int(t('per_device_prompt_batch_size', 1)))
-        a.set_schedule(max(1, total * (2 if use_ptx else 1) // a_gas), float(t('actor_lr_warmup_ratio', 0.03)), a_gas)
-        c.set_schedule(max(1, total // self.gas), float(t('critic_lr_warmup_ratio', 0.03)), self.gas)
+        # A second train() call keeps the schedule it started with; an engine RESUMED through load_checkpoint under a decaying schedule has steps behind it
+        # but no schedule length yet (total_steps None) and must still learn it, or its next step() raises (the RM / DPO / GRPO fix, here too)
+        if not (a.global_steps and a.total_steps is not None):
+            a.set_schedule(max(1, total * (2 if use_ptx else 1) // a_gas), float(t('actor_lr_warmup_ratio', 0.03)), a_gas)
+        if not (c.global_steps and c.total_steps is not None):
+            c.set_schedule(max(1, total // self.gas), float(t('critic_lr_warmup_ratio', 0.03)), self.gas)
 
     @staticmethod
     def _rows(batch, lo, hi):

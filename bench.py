@@ -385,12 +385,19 @@ def main():
             sampler.wait(timeout=3)
         except (OSError, subprocess.TimeoutExpired):
             sampler.terminate()
-        from tools.power_sampler import summarise
-        power = summarise(sampler_path, wall0, wall1, PEAK_BF16_TFLOPS)
+            try:
+                sampler.wait(timeout=2)                 # reaped, and done writing, before the jsonl is read
+            except subprocess.TimeoutExpired:
+                sampler.kill()
+                sampler.wait()
         try:
-            os.remove(sampler_path)
-        except OSError:
-            pass
+            from tools.power_sampler import summarise
+            power = summarise(sampler_path, wall0, wall1, PEAK_BF16_TFLOPS)
+        finally:
+            try:
+                os.remove(sampler_path)
+            except OSError:
+                pass
 
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:

@@ -1105,6 +1105,99 @@ def gen_llava7b_width_bf16ref():
           f'worst matrix gradient-norm rel {e_n:.3e} ({time.time() - t0:.0f}s)')
 
 
+FULL_DEPTH = dict(num_layers=32, T=2048, R=512, left_pad=(0, 37))          # BASELINE configs[1]'s depth and sequence shape, one pair
+FULL_DEPTH_GRADS = ('layers.0.', 'layers.15.', 'layers.31.', 'lm_head', 'language_model.norm', 'multi_modal_projector', 'embed_tokens')
+
+
+def gen_llava7b_full_depth(dtypes=('fp32', 'bf16')):
+    """the headline configuration pinned to the reference AT ITS REAL DEPTH.  The unmodified text+image DPOTrainer
+    (trainers/text_image_to_text/dpo.py:85-166: compute_log_probs, loss) + backward on oracle.synthetic.llava7b_width at L = 32, T = 2048, R = 512,
+    fp32 on CPU -- and once more in bf16, the precision the reference trains in (pretrained_model.py:172), for the derived envelope.
+
+    One 27 GB module is built and refilled: first with the REFERENCE model's weights (one forward under no_grad; `reference_model.module` then replays
+    those logits, so `loss` still runs as written), then with the policy's.  HF gradient checkpointing (what the reference's yaml enables,
+    supervised_trainer.py:270-271) bounds the activations; requires_grad is set on layers 0 / 15 / 31, lm_head, the final norm, the projector and the
+    token embedding only, so 3.6 GB of gradients instead of 27 -- the chain through every layer's dX is the full one either way.
+    Stored per run: the six loss outputs, both log-prob tensors, norms + leading blocks of the 36 gradients; per-tensor weight checksums."""
+    import gc
+    import time
+    from align_anything.trainers.text_image_to_text.dpo import DPOTrainer
+    from align_anything.utils.tools import dict_to_namedtuple
+    from transformers import LlavaForConditionalGeneration
+    t0 = time.time()
+    cfg, sd, ref_sd, batch = llava7b_width(lazy=True, **FULL_DEPTH)
+    model = LlavaForConditionalGeneration(cfg)
+    print(f'module built ({time.time() - t0:.0f}s)', flush=True)
+    names = [n for n, _ in model.named_parameters()]
+    out = {'input_ids': batch['input_ids'].numpy(), 'attention_mask': batch['attention_mask'].numpy(), 'response_lens': np.array(batch['meta_info']['response_lens']),
+           'pixel_checksum': np.array(float(batch['pixel_values'].double().sum())), 'scale_coeff': np.array(0.1), 'num_layers': np.array(FULL_DEPTH['num_layers']),
+           'T': np.array(FULL_DEPTH['T']), 'R': np.array(FULL_DEPTH['R']), 'left_pad': np.array(FULL_DEPTH['left_pad']), 'names': np.array(names),
+           'torch_version': np.array(torch.__version__)}
+
+    def fill(state, key):
+        from concurrent.futures import ThreadPoolExecutor
+        sums = []
+        params = dict(model.named_parameters())
+        with torch.no_grad(), ThreadPoolExecutor(8) as ex:
+            for n, w in zip(names, ex.map(state.bf16, names)):
+                params[n].data = w.to(params[n].dtype)
+                sums.append(float(w.double().sum()))
+        if key not in out:
+            out[key] = np.array(sums)
+        assert np.array_equal(out[key], np.array(sums))
+
+    for dtype in dtypes:
+        pre = '' if dtype == 'fp32' else 'bf16.'
+        td = torch.float32 if dtype == 'fp32' else torch.bfloat16
+        model.to(td)
+        b = dict(batch, pixel_values=batch['pixel_values'].to(td))
+        tr = DPOTrainer.__new__(DPOTrainer)
+        tr.cfgs = dict_to_namedtuple({'train_cfgs': {'scale_coeff': 0.1}})
+        tr.tokenizer = SimpleNamespace(pad_token_id=32001)
+        tr.infer_batch = lambda bb: {k: v for k, v in bb.items() if k != 'meta_info'}
+        # -- the reference model: one forward, its logits replayed to `loss`
+        fill(ref_sd, 'ref_weight_checksum')
+        model.eval().requires_grad_(False)
+        with torch.no_grad():
+            ref_logits = model(**tr.infer_batch(b)).logits
+        print(f'{dtype}: reference-model forward done ({time.time() - t0:.0f}s)', flush=True)
+        tr.reference_model = SimpleNamespace(module=lambda **kw: SimpleNamespace(logits=ref_logits))
+        # -- the policy
+        fill(sd, 'weight_checksum')
+        for n, p in model.named_parameters():
+            p.requires_grad_('vision_tower' not in n and any(k in n for k in FULL_DEPTH_GRADS))
+        model.train()                                                           # dropout is 0 everywhere; train() is what arms HF's checkpointing
+        model.gradient_checkpointing_enable(gradient_checkpointing_kwargs={'use_reentrant': False})
+        model.zero_grad()
+        tr.model = SimpleNamespace(module=model)
+        seen = []
+        inner = tr.compute_log_probs
+        tr.compute_log_probs = lambda m, bb: (seen.append(inner(m, bb)), seen[-1])[1]      # records what `loss` computes; changes nothing
+        ld = tr.loss(b)
+        print(f'{dtype}: loss {float(ld["loss"]):.6f} margin {ld["reward_margin"].tolist()} ({time.time() - t0:.0f}s)', flush=True)
+        ld['loss'].backward()
+        out[pre + 'seq_log_probs'], out[pre + 'ref_seq_log_probs'] = seen[0].detach().float().numpy(), seen[1].detach().float().numpy()
+        for k, v in ld.items():
+            out[pre + 'loss_' + k] = v.detach().float().numpy()
+        gnorm = []
+        for n, p in model.named_parameters():
+            if p.grad is None:
+                gnorm.append(-1.0)
+                continue
+            gnorm.append(float(p.grad.double().norm()))
+            out[pre + 'gblk.' + n] = p.grad.float().reshape(p.grad.shape[0], -1)[:32, :32].contiguous().numpy()
+        out[pre + 'grad_norm'] = np.array(gnorm)
+        print(f'{dtype}: backward done, {sum(g >= 0 for g in gnorm)} gradients, total norm {float(np.sqrt(sum(g * g for g in gnorm if g >= 0))):.6e} ({time.time() - t0:.0f}s)', flush=True)
+        model.gradient_checkpointing_disable()
+        model.zero_grad(set_to_none=True)
+        del ref_logits, ld, seen, tr
+        gc.collect()
+        np.savez_compressed(os.path.join(GOLD, 'llava7b_full_depth_dpo.npz'), **out)
+    if 'bf16.loss_loss' in out and 'loss_loss' in out:
+        print(f'reference bf16 vs reference fp32 at L = 32: loss {abs(float(out["bf16.loss_loss"]) - float(out["loss_loss"])):.3e}, per-token '
+              f'{float(np.abs(out["bf16.seq_log_probs"] - out["seq_log_probs"]).max()):.3e}')
+
+
 def gen_dropin_e2e(threads=8, alt_threads=3):
     """the fixture of the end-to-end drop-in test (tests/test_dropin_gpu.py).  The reference's OWN text-to-text pipeline on its OWN asset
     file: PreferenceDataset + ChatTemplate('PKUSafeRLHF') + PreferenceCollator (datasets/text_to_text/preference.py:52-201) over
@@ -1879,3 +1972,5 @@ if __name__ == '__main__':
     gen_dropin_e2e_ti2t()
     gen_dropin_e2e_rm()
     gen_dropin_e2e_sft()
+    # round 6
+    gen_llava7b_full_depth()

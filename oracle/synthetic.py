@@ -98,7 +98,54 @@ def llava7b_width_config(num_layers=4):
     return LlavaConfig(vision_config=vc, text_config=tc, image_token_id=32000, image_seq_length=576, pad_token_id=32001)
 
 
-def llava7b_width(num_layers=4, T=640, R=48, left_pad=(0, 23), seed=42):
+def _width_tensor(name, shape, dim, seed, reference=False, trainable_matrix=True):
+    """One tensor of a *_width fixture from its OWN generator, seeded by (seed, crc32 of the parameter name): matrices, embeddings and biases N(0, 0.02),
+    norm weights 1 + N(0, 0.1), rounded to bf16-representable values; the reference model's copy = policy + N(0, 2e-3) (drawn AFTER the policy's numbers from
+    the same generator) on the trainable matrices."""
+    import zlib
+    g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (1 << 62))
+    norm = dim == 1 and ('norm' in name or 'layrnorm' in name) and name.endswith('weight')
+    w = (torch.randn(tuple(shape), generator=g) * (0.1 if norm else 0.02) + (1.0 if norm else 0.0)).to(torch.bfloat16)
+    if reference and dim >= 2 and trainable_matrix:
+        w = (w.to(torch.float32) + 2e-3 * torch.randn(tuple(shape), generator=g)).to(torch.bfloat16)
+    return w
+
+
+class LazyWidthState:
+    """Mapping name -> fp32 tensor (bf16-representable values) of llava7b_width's policy or reference model, generated on access: the full-depth fixture's
+    27 GB per model never sit in host memory twice.  `materialize()` draws every tensor in a thread pool (each has its own generator, so the values do not
+    depend on the order or the thread count) and returns a plain dict of bf16 tensors (lossless)."""
+
+    def __init__(self, shapes, seed, reference):
+        self.shapes, self.seed, self.reference = dict(shapes), seed, reference
+
+    def __contains__(self, n):
+        return n in self.shapes
+
+    def __iter__(self):
+        return iter(self.shapes)
+
+    def __len__(self):
+        return len(self.shapes)
+
+    def keys(self):
+        return self.shapes.keys()
+
+    def bf16(self, n):
+        shape = self.shapes[n]
+        return _width_tensor(n, shape, len(shape), self.seed, self.reference, 'vision_tower' not in n)
+
+    def __getitem__(self, n):
+        return self.bf16(n).to(torch.float32)
+
+    def materialize(self, workers=16):
+        from concurrent.futures import ThreadPoolExecutor
+        names = list(self.shapes)
+        with ThreadPoolExecutor(workers) as ex:
+            return dict(zip(names, ex.map(self.bf16, names)))
+
+
+def llava7b_width(num_layers=4, T=640, R=48, left_pad=(0, 23), seed=42, lazy=False):
     """One preference pair at the FULL WIDTH of BASELINE.json configs[1] (LLaVA-1.5-7B: CLIP-L/14-336 tower of 24 x 1024, projector, Llama
     layers of 4096 / 11008 / 32 heads x 128, vocabulary 32064) but `num_layers` decoder layers, so that the UNMODIFIED reference trainer runs
     it in fp32 on the build container's CPU in minutes (a full-width parity point that is not HIP-vs-HIP).
@@ -108,22 +155,17 @@ def llava7b_width(num_layers=4, T=640, R=48, left_pad=(0, 23), seed=42):
     norm weights 1 + N(0, 0.1), all rounded to bf16-representable values (the bf16 path and the fp32 twin then load identical numbers);
     reference model = policy + N(0, 2e-3) on the decoder / projector matrices.  Sequence: BOS + 576 image tokens + text, the rejected row
     left-padded; R response tokens.  Returns (LlavaConfig, policy state dict, reference state dict, batch).  Pure torch CPU RNG + the HF config
-    classes: regenerated on the GPU box, the 9 GB of weights are not committed (per-tensor checksums are)."""
-    import zlib
+    classes: regenerated on the GPU box, the 9 GB of weights are not committed (per-tensor checksums are).  lazy=True (the FULL-DEPTH fixture,
+    num_layers=32, T=2048, R=512: VERDICT r5 next #1) returns LazyWidthState mappings instead of dicts."""
     from transformers import LlavaForConditionalGeneration
     cfg = llava7b_width_config(num_layers)
     with torch.device('meta'):
         skel = LlavaForConditionalGeneration(cfg)
-    sd, ref_sd = {}, {}
-    for n, p in skel.named_parameters():
-        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(n.encode())) % (1 << 62))
-        norm = p.dim() == 1 and ('norm' in n or 'layrnorm' in n) and n.endswith('weight')
-        w = torch.randn(tuple(p.shape), generator=g) * (0.1 if norm else 0.02) + (1.0 if norm else 0.0)
-        sd[n] = w.to(torch.bfloat16).to(torch.float32)
-        if p.dim() >= 2 and 'vision_tower' not in n:
-            ref_sd[n] = (sd[n] + 2e-3 * torch.randn(tuple(p.shape), generator=g)).to(torch.bfloat16).to(torch.float32)
-        else:
-            ref_sd[n] = sd[n]
+    shapes = {n: tuple(p.shape) for n, p in skel.named_parameters()}
+    sd, ref_sd = LazyWidthState(shapes, seed, False), LazyWidthState(shapes, seed, True)
+    if not lazy:
+        sd = {n: sd[n] for n in shapes}
+        ref_sd = {n: (ref_sd[n] if len(shapes[n]) >= 2 and 'vision_tower' not in n else sd[n]) for n in shapes}
     gb = torch.Generator().manual_seed(seed + 2)
     N = 2
     ids = torch.full((N, T), 32001, dtype=torch.long)

@@ -107,7 +107,7 @@ def test_supervised_step_and_prefetched_window(launches):
     assert tr.model.global_steps == 2
 
 
-def test_ppo_rollout_update_and_ptx_steps(launches):
+def test_ppo_rollout_update_and_ptx_steps(launches, tmp_path):
     from align_anything_amd.trainers.ppo import PPOTrainer
     z = load_golden('opt_tiny_dpo.npz')
     cfg = tiny_opt_cfg()
@@ -160,6 +160,28 @@ def test_ppo_rollout_update_and_ptx_steps(launches):
     assert tr5.actor_model.total_steps == 8 and tr5.reward_critic_model.total_steps == 8
     lrs = [h['train/actor_lr'] for h in hist]
     assert len(lrs) == 8 and all(a > b for a, b in zip(lrs, lrs[1:])) and lrs[1] > 0.5e-3 and lrs[-1] == 0.0, lrs
+    # an actor / critic RESUMED through load_checkpoint under the default cosine schedule has steps behind it but no schedule length; train() must
+    # still hand it one (the RM / DPO / GRPO fix, here too) -- and a second train() on the same trainer keeps the schedule it started with
+    tr5.actor_model.save_checkpoint(str(tmp_path / 'ppo_actor'))
+    tr5.reward_critic_model.save_checkpoint(str(tmp_path / 'ppo_critic'))
+    tr6 = PPOTrainer(cfgs3, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, reward_state=rm_sd, device='cpu')
+    tr6.actor_model.load_checkpoint(str(tmp_path / 'ppo_actor'))
+    tr6.reward_critic_model.load_checkpoint(str(tmp_path / 'ppo_critic'))
+    assert tr6.actor_model.global_steps == 8 and tr6.actor_model.total_steps is None
+    tr6._set_schedules([pbatch, pbatch, pbatch], False)
+    assert tr6.actor_model.total_steps == 12 and tr6.actor_model.global_steps == 8 and tr6.actor_model.micro_steps == 8
+    from align_anything_amd.engine import cosine_with_warmup
+    assert abs(tr6.actor_model.optimizer.param_groups[0]['lr'] - cosine_with_warmup(8, tr6.actor_model.base_lr, 0, 12)) < 1e-15
+    tr6._set_schedules([pbatch], False)                    # already scheduled and stepped: kept
+    assert tr6.actor_model.total_steps == 12
+    # ... and a slice saved at one accumulation depth, loaded at another, restarts at the boundary of its last completed update
+    e6 = tr6.actor_model
+    e6.gas, e6.micro_steps = 4, 8 * 4 + 3
+    e6.save_checkpoint(str(tmp_path / 'ppo_actor_gas4'))
+    e6.gas = 2
+    e6.load_checkpoint(str(tmp_path / 'ppo_actor_gas4'))
+    assert e6.micro_steps == 16 and e6.global_steps == 8 and e6.micro_steps % e6.gas == 0
+    e6.gas = 1
     # a rule reward instead of the reward model
     tr2 = PPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, actor_state=actor_sd, critic_state=rm_sd, device='cpu', reward_fn=lambda i, a: [1.0] * i.shape[0])
     assert tr2.reward_model is None and tr2.reward_model_step(prompts, torch.ones_like(prompts))['reward'].tolist() == [1.0] * 4

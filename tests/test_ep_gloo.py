@@ -174,7 +174,7 @@ def _padded_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _engine_step_worker(rank, world, port, q):
+def _engine_step_worker(rank, world, port, q, first_overflows=False):
     """NativeEngine.step() itself, with one rank overflowing.  step() polls BEFORE it folds the local flag into the squared-norm
     all-reduce; the poll must not eat that flag.  The three optimizer kernels are replaced by their contract on CPU tensors (csrc/optim.hip:
     sumsq == -inf -> coefficient -1 -> AdamW returns without touching anything); everything else -- the poll, the sentinel, the all-reduce, the
@@ -222,6 +222,23 @@ def _engine_step_worker(rank, world, port, q):
         e.micro_steps += 1
         e.step()
 
+    if first_overflows:
+        # the engine's VERY FIRST step overflows on one rank, after a stand-alone poll (what a PPO / GRPO rollout before the first update does).
+        # The engine owns the flag since its construction, so neither that poll nor step()'s leading one may eat it.
+        ok = ok and ep._engine
+        before = {g: t.clone() for g, t in st.master.items()}
+        if rank == world - 1:
+            ep._overflow = torch.tensor(True)
+        ep.poll_overflow(block=True)                                   # a rollout's poll: reads only the (empty) shared flag, raises nothing, consumes nothing
+        ok = ok and ((ep._overflow is not None) == (rank == world - 1))
+        one_step(False)                                                # the flag set above is still there for the sentinel
+        ok = ok and float(e._coef) == -1.0 and not touched and all(torch.equal(before[g], st.master[g]) for g in before)
+        raised = False
+        try:
+            e.grad_norm()
+        except RuntimeError as err:
+            raised = 'skipped' in str(err)
+        ok = ok and raised
     before = {g: t.clone() for g, t in st.master.items()}
     one_step(False)                                                    # a clean step first: the poll inside the NEXT step has a landed, clear flag to consume
     ok = ok and touched and float(e._coef) > 0 and all(not torch.equal(before[g], st.master[g]) for g in before)
@@ -244,12 +261,12 @@ def _engine_step_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 4])
-def test_engine_step_shares_the_overflow_flag(world):
+@pytest.mark.parametrize('world,first_overflows', [(2, False), (4, False), (2, True)])
+def test_engine_step_shares_the_overflow_flag(world, first_overflows):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 35500 + os.getpid() % 2000 + world
-    procs = [ctx.Process(target=_engine_step_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 35500 + os.getpid() % 2000 + world + 10 * first_overflows
+    procs = [ctx.Process(target=_engine_step_worker, args=(r, world, port, q, first_overflows)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
