@@ -222,6 +222,29 @@ GEMM_PROF_STRIDE = 1
 _gemm_seq = 0
 
 
+# The same for the kernels below the GEMMs ("fraction of HBM peak per memory-bound kernel"): bench.py sets KPROF = {} and
+# every KPROF_STRIDE-th launch of a kernel kind (every launch of the kinds in KPROF_EVERY: three per step) carries an event pair on its launch stream, with
+# the ALGORITHMIC bytes (and FLOPs for attention) of that launch.  None = off: one `is None` test per call.
+KPROF = None
+KPROF_STRIDE = 7
+KPROF_EVERY = ('adamw_flat', 'grad_sumsq')
+_kseq: dict = {}
+
+
+def _kprof_begin(kind):
+    if KPROF is None:
+        return None
+    n = _kseq[kind] = _kseq.get(kind, 0) + 1
+    if kind not in KPROF_EVERY and n % KPROF_STRIDE:
+        return None
+    return (kind, event_record())
+
+
+def _kprof_end(tok, nbytes, flops=0.0):
+    if tok is not None:
+        KPROF.setdefault(tok[0], []).append((tok[1], event_record(), float(nbytes), float(flops)))
+
+
 EVENT_POOL: list = []   # pre-created HIP events (bench.py fills it so that creation stays out of the timed region)
 
 
@@ -274,7 +297,9 @@ def rmsnorm_fwd(x, w, eps, out=None, rstd=None):
     rows, h = x.shape
     out = torch.empty_like(x) if out is None else out
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if rstd is None else rstd
+    tok = _kprof_begin('rmsnorm_fwd')
     call('aa_rmsnorm_fwd' + _sfx(x, 'rmsnorm_fwd'), x.data_ptr(), w.data_ptr(), out.data_ptr(), rstd.data_ptr(), rows, h, float(eps), stream())
+    _kprof_end(tok, x.element_size() * (2 * rows * h + h) + 4 * rows)            # x read, y written, the weight row, rstd
     return out, rstd
 
 
@@ -314,8 +339,10 @@ def rmsnorm_bwd(dy, x, w, rstd, dw, dx=None, add_to_dx=False):
     rows, h = x.shape
     dx = torch.empty_like(x) if dx is None else dx
     ws = _norm_ws(x.device, h, 1) if dw is not None else None
+    tok = _kprof_begin('rmsnorm_bwd')
     call('aa_rmsnorm_bwd' + _sfx(x, 'rmsnorm_bwd'), dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dw),
          _p(ws), NORM_WS_ROWS, rows, h, int(add_to_dx), stream())
+    _kprof_end(tok, x.element_size() * ((4 if add_to_dx else 3) * rows * h + h) + 4 * rows)      # x, dy (and the residual gradient) read, dx written
     return dx
 
 
@@ -390,7 +417,9 @@ def swiglu_fwd(gate_up, out=None):
 def swiglu_bwd(gate_up, dact, out=None):
     M, F2 = gate_up.shape
     out = torch.empty_like(gate_up) if out is None else out
+    tok = _kprof_begin('swiglu_bwd')
     call('aa_swiglu_bwd' + _sfx(gate_up, 'swiglu_bwd'), gate_up.data_ptr(), dact.data_ptr(), out.data_ptr(), M, F2 // 2, stream())
+    _kprof_end(tok, gate_up.element_size() * M * (F2 // 2) * 5)                  # gate | up and d act read, d gate | d up written
     return out
 
 
@@ -620,9 +649,12 @@ def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None, kv_
     """q/k/v: 2-D views [N*T, >=H*hd] (column slices of the fused qkv buffer are fine)."""
     out = torch.empty((N * T, H * hd), dtype=q.dtype, device=q.device) if out is None else out
     lse = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
-    FLOPS['attn'] += 4.0 * N * H * T * T * hd * (0.5 if causal else 1.0)
+    fl = 4.0 * N * H * T * T * hd * (0.5 if causal else 1.0)
+    FLOPS['attn'] += fl
+    tok = _kprof_begin('attn_fwd' if (hd == 128 and causal) else 'attn_fwd_other')
     call('aa_attn_fwd' + _sfx(q, 'attn_fwd'), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(start), _p(kv_len),
          q.stride(0), k.stride(0), v.stride(0), out.stride(0), N, T, H, Hkv, hd, int(causal), float(scale), stream())
+    _kprof_end(tok, q.element_size() * N * T * hd * (2 * H + 2 * Hkv) + 4 * N * H * T, fl)
     return out, lse
 
 
@@ -630,7 +662,9 @@ def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, s
     """rope = (pos int32 [rows], cos_t, sin_t bf16 [., hd / 2]): dq and dk leave the kernels already rotated back (the backward of the rotary embedding
     of the forward, `rope_(..., inverse=True)`), bf16 only -- bit-identical to the separate launch."""
     delta = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
-    FLOPS['attn'] += 10.0 * N * H * T * T * hd * (0.5 if causal else 1.0)
+    fl = 10.0 * N * H * T * T * hd * (0.5 if causal else 1.0)       # the five matmuls of the algorithm (S, dP, dV, dK, dQ)
+    FLOPS['attn'] += fl
+    tok = _kprof_begin('attn_bwd' if (hd == 128 and causal) else 'attn_bwd_other')
     args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
             delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(start), _p(kv_len), q.stride(0), k.stride(0),
             v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), N, T, H, Hkv, hd, int(causal), float(scale))
@@ -641,6 +675,7 @@ def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, s
         call('aa_attn_bwd_rope', *args, pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), stream())
     else:
         call('aa_attn_bwd' + _sfx(q, 'attn_bwd'), *args, stream())
+    _kprof_end(tok, q.element_size() * N * T * hd * (4 * H + 4 * Hkv) + 8 * N * H * T, fl)      # q, o, do read, dq written; k, v read, dk, dv written; lse, delta
     return dq, dk, dv
 
 
@@ -849,7 +884,9 @@ def grad_sumsq_(g, out_accum, scale=1.0, ws=None):
     dt = 0 if g.dtype == bf16 else 1
     if ws is None:
         ws = torch.empty(SUMSQ_WS, dtype=torch.float32, device=g.device)
+    tok = _kprof_begin('grad_sumsq')
     call('aa_grad_sumsq', g.data_ptr(), dt, g.numel(), float(scale), out_accum.data_ptr(), ws.data_ptr(), stream())
+    _kprof_end(tok, g.element_size() * g.numel())
 
 
 def chunk_sum(recv, out, world):
@@ -869,9 +906,11 @@ def adamw_set_thin(on: bool) -> None:
 
 def adamw_flat_(master, m, v, p16, g, lr, beta1, beta2, eps, wd, step, gscale=1.0, clip=None):
     dt = 0 if g.dtype == bf16 else 1
+    tok = _kprof_begin('adamw_flat')
     call('aa_adamw_flat', master.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p16), g.data_ptr(), dt,
          master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), float(gscale),
          _p(clip), stream())
+    _kprof_end(tok, master.numel() * (24 + g.element_size() + (2 if p16 is not None else 0)))      # 28 B per bf16 parameter
 
 
 # ------------------------------------------------------------------ decode

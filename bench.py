@@ -359,11 +359,15 @@ def main():
         ops.GEMM_PROF_STRIDE = max(1, args.gemm_event_stride)
         while ops.GEMM_PROF_STRIDE > 1 and math.gcd(per_step, ops.GEMM_PROF_STRIDE) != 1:
             ops.GEMM_PROF_STRIDE += 1
-        ops.event_pool_fill(2 * (per_step * args.steps // ops.GEMM_PROF_STRIDE + 8) + 64)
+        ops.event_pool_fill(2 * (per_step * args.steps // ops.GEMM_PROF_STRIDE + 8) + 64 + 2 * 64 * args.steps)      # + the ~55 sampled non-GEMM launches per step
     barrier()
 
     gemm_events = None if args.no_gemm_events else []
     ops.GEMM_PROF = gemm_events
+    # the kernels below the GEMMs (HBM fraction per memory-bound kernel; the attention kernels against the MFMA peak): event pairs on every
+    # 7th launch of each kind, every AdamW / squared-norm launch (ops.KPROF)
+    ops.KPROF = None if args.no_gemm_events else {}
+    ops._kseq.clear()
     ops.FLOPS['gemm'] = ops.FLOPS['attn'] = 0.0
     torch.cuda.synchronize()
     wall0 = time.time()
@@ -377,6 +381,7 @@ def main():
     dt = time.perf_counter() - t0
     wall1 = time.time()
     ops.GEMM_PROF = None
+    kprof, ops.KPROF = ops.KPROF, None
     executed = dict(ops.FLOPS)
     power = None
     if sampler is not None:
@@ -547,6 +552,41 @@ def main():
                 out['roofline']['all_gemm_launches_sampled'] = {'achieved': all_ach, 'launches': all_n, 'avg_launch_ms': all_ms / all_n,
                                                                 'note': 'incl. the small CLIP-tower / projector GEMMs (see the comment in bench.py)'}
                 out['roofline']['gemm_share_of_step_time'] = all_ms * ops.GEMM_PROF_STRIDE / (dt * 1e3)
+        if kprof and 'roofline' in out:
+            # VERDICT r5 next #3.  Per kind: the sampled launches of the timed steps, ALGORITHMIC bytes of each (ops.py states them next to the launch),
+            # HIP-event duration on the launch stream.  rocprofv3's per-kernel averages of the same command: profiles/r06_dpo7b_kernel_stats.csv.
+            names = {'adamw_flat': 'adamw_kernel (csrc/optim.hip; 28 B per bf16 parameter: g, fp32 master / m / v read + written, bf16 weight written)',
+                     'grad_sumsq': 'sumsq_kernel (csrc/optim.hip; the clip norm: one read of the gradients)',
+                     'rmsnorm_fwd': 'rmsnorm_fwd2_kernel (csrc/elementwise.hip)', 'rmsnorm_bwd': 'rmsnorm_bwd_kernel<2> (csrc/elementwise.hip)',
+                     'swiglu_bwd': 'swiglu_bwd_kernel (csrc/elementwise.hip)'}
+            hbm = []
+            for kind, label in names.items():
+                ev = kprof.get(kind)
+                if not ev:
+                    continue
+                ms = [ops.event_elapsed_ms(e0, e1) for e0, e1, _, _ in ev]
+                by = sum(e[2] for e in ev)
+                calls = ops._kseq.get(kind, 0)
+                hbm.append({'kernel': label, 'sampled_launches': len(ev), 'algorithmic_bytes': by / len(ev), 'avg_ms': sum(ms) / len(ms),
+                            'gb_per_s': by / sum(ms) / 1e6, 'frac_of_8TBs': by / sum(ms) / 1e6 / PEAK_HBM_GBS,
+                            'launches_per_step': calls / args.steps, 'ms_per_step': sum(ms) / len(ms) * calls / args.steps})
+            out['roofline']['hbm_kernels'] = hbm
+            att = {}
+            for kind, label in (('attn_fwd', 'fwd'), ('attn_bwd', 'bwd')):
+                ev = kprof.get(kind)
+                if not ev:
+                    continue
+                ms = [ops.event_elapsed_ms(e0, e1) for e0, e1, _, _ in ev]
+                fl = sum(e[3] for e in ev)
+                att[label + '_tflops'] = fl / sum(ms) / 1e9
+                att[label + '_avg_ms'] = sum(ms) / len(ms)
+                att[label + '_frac'] = fl / sum(ms) / 1e9 / PEAK_BF16_TFLOPS
+                att[label + '_sampled_launches'] = len(ev)
+                att[label + '_ms_per_step'] = sum(ms) / len(ms) * ops._kseq.get(kind, 0) / args.steps
+            if att:
+                att['note'] = ('algorithmic FLOPs: causal 4 T^2 hd / 2 per (row, head) forward, 2.5 x that backward (five matmuls); the policy, reference-model and '
+                               'launches of the step are in the forward sample (the head_dim-64 non-causal launches are a kind of their own and not reported)')
+                out['roofline']['attention'] = att
         if power is not None and 'roofline' not in out:
             out['power'] = power
         if per_batch:

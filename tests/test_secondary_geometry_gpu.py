@@ -17,9 +17,9 @@
 """
 import gc
 import math
+import os
 
 import numpy as np
-
 import pytest
 import torch
 
@@ -492,6 +492,29 @@ def test_full_depth_llava_7b_bf16_step_vs_fp32_twin():
     dump('parity_full_depth_llava7b_bf16_vs_twin.txt', '\n'.join(rep) + '\n')
     assert torch.equal(lp16 == 0, lp32 == 0)
     assert abs(l16 - l32) < 2e-1 and e_lp < 1.3 and worst_a < 5e-3 and worst_r < 1e-1, rep
+
+
+def test_llava7b_full_depth_pair_vs_the_reference_trainer():
+    """the headline configuration pinned to the REFERENCE at its real depth -- no HIP-vs-HIP link under the number the driver times.
+    tests/golden/llava7b_full_depth_dpo.npz is the UNMODIFIED reference trainer (trainers/text_image_to_text/dpo.py:85-166: compute_log_probs, loss, then
+    backward under HF gradient checkpointing) on oracle.synthetic.llava7b_width at L = 32, T = 2048, R = 512 (one left-padded pair, 576 image tokens), run
+    in the build container in fp32 AND in bf16 (oracle/gen_golden.py::gen_llava7b_full_depth; 36 gradients: layers 0 / 15 / 31 whole, lm_head, final norm,
+    projector, token embedding).  The 2 x 6.76 B weights are regenerated here from the seed (thread pool, one generator per tensor; per-tensor checksums
+    checked) and run through (a) the fp32 twin kernels -- stated bounds: loss 1e-4, per-token log-probs 2e-4, every gradient norm 1e-3 rel -- and (b) the
+    bf16 production kernels, held per quantity to 1.5 x the deviation of the reference's OWN bf16 run from its fp32 run."""
+    from oracle.synthetic import llava7b_width
+    from tests.width_parity import width_parity
+    z = load_golden('llava7b_full_depth_dpo.npz')
+    hc, sd, ref_sd, batch = llava7b_width(num_layers=int(z['num_layers']), T=int(z['T']), R=int(z['R']), left_pad=tuple(int(x) for x in z['left_pad']), lazy=True)
+    assert int(z['num_layers']) == 32 and int(z['T']) == 2048
+    workers = min(32, os.cpu_count() or 8)
+    sd, ref_sd = sd.materialize(workers), ref_sd.materialize(workers)
+    assert abs(float(batch['pixel_values'].double().sum()) - float(z['pixel_checksum'])) < 1e-6
+    n_grad = int((z['grad_norm'] > 0).sum())
+    assert n_grad >= 30
+    width_parity(z, hc, sd, ref_sd, batch, 32001, 'parity_llava7b_full_depth_vs_reference.txt', float_keys=('pixel_values',),
+                 min_matrices=sum(1 for n, g in zip(z['names'], z['grad_norm']) if g > 0 and 'norm' not in str(n) and not str(n).endswith('bias')),
+                 fp32_bounds=(1e-4, 2e-4, 1e-3, 2e-3), check_vectors=True)
 
 
 def test_llava7b_width_pair_vs_the_reference_trainer():

@@ -11,10 +11,11 @@ from tests.util import rel_err
 
 
 def width_parity(z, hf_config, sd, ref_sd, batch, pad_token_id, report, *, extra_train_cfgs=None, trainer_kwargs=None, batch_keys=(), float_keys=(),
-                 skip_norm_of=(), min_matrices=29, fp32_bounds=(2e-4, 2e-4, 1e-3, 2e-3)):
+                 skip_norm_of=(), min_matrices=29, fp32_bounds=(2e-4, 2e-4, 1e-3, 2e-3), check_vectors=False):
     """z: the fixture; (hf_config, sd, ref_sd, batch): the regenerated model / pair (oracle.synthetic.*_width); batch_keys: extra batch entries handed to the
     trainer as they are (grids, masks); float_keys: batch entries cast to the compute dtype (pixels, mel features); skip_norm_of: parameters whose stored
-    layout differs from HF's (norm compared through the others).  fp32_bounds: loss & log-probs abs, (unused), gradient-norm rel, leading-block rel_err."""
+    layout differs from HF's (norm compared through the others).  fp32_bounds: loss abs, per-token log-probs abs, gradient-norm rel, leading-block rel_err.
+    check_vectors: the 1-D gradients the fixture holds (norm weights, biases) are compared as well (norm rel, fp32 asserted at fp32_bounds[2])."""
     from align_anything_amd import configs
     from align_anything_amd.trainers.dpo import DPOTrainer
     T = torch.from_numpy
@@ -52,13 +53,17 @@ def width_parity(z, hf_config, sd, ref_sd, batch, pad_token_id, report, *, extra
                  'per-token log-probs (policy)': float(np.abs(z['bf16.seq_log_probs'] - z['seq_log_probs']).max()),
                  'per-token log-probs (reference model)': float(np.abs(z['bf16.ref_seq_log_probs'] - z['ref_seq_log_probs']).max()),
                  'summed log-probs': float(np.abs(z['bf16.seq_log_probs'].sum(1) - z['seq_log_probs'].sum(1)).max())}
-            wn, wb, rn, rb, n_g = 0.0, 0.0, 0.0, 0.0, 0
+            wn, wb, rn, rb, n_g, wv = 0.0, 0.0, 0.0, 0.0, 0, 0.0
             for n, gn, gnb in zip(names, z['grad_norm'], z['bf16.grad_norm']):
                 if gn <= 0:
                     continue
                 g = tr.policy.store.grad_view(n)
                 assert g is not None, n
                 if len(g.shape) < 2:
+                    if check_vectors:
+                        ev = abs(float(g.float().double().norm()) - float(gn)) / float(gn)
+                        wv = max(wv, ev)
+                        assert dtype != 'fp32' or ev < fp32_bounds[2], (n, ev)
                     continue
                 gf = g.float()
                 n_g += 1
@@ -73,9 +78,11 @@ def width_parity(z, hf_config, sd, ref_sd, batch, pad_token_id, report, *, extra
                         rb = max(rb, rel_err(T(z['bf16.gblk.' + n]), blk))
             m['worst matrix gradient norm (rel)'], r['worst matrix gradient norm (rel)'] = wn, rn
             m['worst leading gradient block (rel_err)'], r['worst leading gradient block (rel_err)'] = wb, rb
-            rep.append(f'{dtype}: loss {float(ld["loss"]):.6f}; ' + '; '.join(f'{k} {v:.2e}' for k, v in m.items()) + f' ({n_g} matrices)')
+            rep.append(f'{dtype}: loss {float(ld["loss"]):.6f}; ' + '; '.join(f'{k} {v:.2e}' for k, v in m.items()) + f' ({n_g} matrices)'
+                       + (f'; worst vector gradient norm (rel) {wv:.2e}' if check_vectors else ''))
             if dtype == 'fp32':
-                assert m['loss'] < fp32_bounds[0] and m['per-token log-probs (policy)'] < fp32_bounds[1] and m['per-token log-probs (reference model)'] < fp32_bounds[1] \
+                assert m['loss'] < fp32_bounds[0] and m['margin'] < 10 * fp32_bounds[0] and m['per-token log-probs (policy)'] < fp32_bounds[1] \
+                    and m['per-token log-probs (reference model)'] < fp32_bounds[1] \
                     and wn < fp32_bounds[2] and wb < fp32_bounds[3], rep[-1]
             else:
                 rep.append('bf16 envelope, native vs the reference\'s own bf16 run (both against the reference\'s fp32 run):')

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round-6 GPU stages.  Usage on the GPU box: bash tools/gpu_r6.sh <stage> [<stage> ...]; every stage writes under gpurun_out/ (merged back by gpurun).
+R=$(cd "$(dirname "$0")/.." && pwd); cd "$R"; mkdir -p gpurun_out
+for stage in "$@"; do
+  echo "=== stage $stage  $(date +%T)"
+  case $stage in
+    full_depth)      # the headline configuration at L = 32 against the reference trainer's fixture (fp32 twin + derived bf16 envelope)
+      timeout 1500 python -m pytest tests/test_secondary_geometry_gpu.py -q -x -m gpu -p no:cacheprovider -k "full_depth_pair" > gpurun_out/r06_full_depth.log 2>&1; echo "rc=$?"; tail -12 gpurun_out/r06_full_depth.log | cut -c1-400
+      cat gpurun_out/parity_llava7b_full_depth_vs_reference.txt | cut -c1-500 ;;
+    atomic)          # lab: fp32 global atomic throughput in the dQ pattern of a single-pass attention backward
+      hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics tools/lab/ubench/atomic_f32.hip -o /tmp/atomic_f32 && timeout 120 /tmp/atomic_f32 | tee gpurun_out/r06_atomic_f32.txt ;;
+    tests)
+      timeout 1900 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider --deselect tests/test_secondary_geometry_gpu.py::test_llava7b_full_depth_pair_vs_the_reference_trainer > gpurun_out/r06_pytest.log 2>&1; tail -15 gpurun_out/r06_pytest.log | cut -c1-300 ;;
+    bench)           # the driver's command, full line
+      timeout 900 python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err; echo "rc=$?"
+      python - <<'PY'
+import json
+d = json.load(open('gpurun_out/r06_bench.json')); r = d['roofline']
+print('ms/step', round(d['ms_per_step'], 2), 'pairs/s', round(d['value'], 4), 'gemm frac', round(r['frac'], 4), 'W', r.get('power_w_mean'), 'MHz', r.get('sclk_mhz_mean'))
+for k in r.get('hbm_kernels', []):
+    print('  ', k['kernel'][:44], 'n', k['sampled_launches'], 'MB', round(k['algorithmic_bytes'] / 1e6, 1), 'ms', round(k['avg_ms'], 4), 'frac', round(k['frac_of_8TBs'], 3), 'ms/step', round(k['ms_per_step'], 2))
+print('  attention', {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.get('attention', {}).items() if k != 'note'})
+print('  per_batch', {k: round(v['value'], 3) for k, v in d.get('per_batch', {}).items() if isinstance(v, dict)})
+PY
+      ;;
+    bench_quick)     # headline step without the PMC passes / CPU leg / batch sweep
+      timeout 600 python bench.py --steps 8 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r06_bench_quick.json 2> gpurun_out/r06_bench_quick.err
+      python -c "import json; d=json.load(open('gpurun_out/r06_bench_quick.json')); r=d['roofline']; print('ms/step', d['ms_per_step'], 'pairs/s', d['value'], 'gemm frac', r['frac'], 'W', r.get('power_w_mean'), 'MHz', r.get('sclk_mhz_mean')); print(r.get('attention'))" || tail -5 gpurun_out/r06_bench_quick.err ;;
+    rocprof)         # rocprofv3 --kernel-trace --stats of the bench step: per-kernel averages for profiles/r06_dpo7b_kernel_stats.csv
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r06_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-events --traffic committed --no-per-batch --no-power > $R/gpurun_out/r06_prof.log 2>&1 )
+      f=$(find gpurun_out/r06_prof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r06_dpo7b_kernel_stats.csv; head -25 gpurun_out/r06_dpo7b_kernel_stats.csv | cut -c1-200
+      find gpurun_out/r06_prof -name "*kernel_trace.csv" -delete ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
