@@ -231,7 +231,11 @@ class NativeEngine:
         self._pending = None
         self.gas = max(1, int(gradient_accumulation_steps))
         self.micro_steps = 0
-        self.async_optimizer = True
+        # The update runs on the launch stream.  Rounds 1 - 4 enqueued it on a side stream so that it "could overlap" the next batch's reference forward; measured
+        # in round 5 (profiles/r05_adam_window.txt) it overlaps nothing on the dense path -- a gemm4 workgroup needs whole SIMD register files and AdamW's
+        # workgroups sit on every CU -- so the default path no longer pays a stream switch and two events per step for it.
+        # AA_ADAM_ASYNC=1 restores the side stream (it does co-run with small-register kernels: vision towers, the MoE stack's 8-wave grouped GEMMs).
+        self.async_optimizer = os.environ.get('AA_ADAM_ASYNC', '0') == '1'
         # optional <= 16-VGPR AdamW kernel that can share CUs with the next step's GEMMs (2 x 248 of the 512 VGPRs per lane are
         # theirs).  Measured: no gain over the default kernel (4.655 / 4.623 vs 4.642 / 4.644 pairs/s) -> off.
         self.thin_optimizer = os.environ.get('AA_ADAM_THIN', '0') == '1'
@@ -380,13 +384,8 @@ class NativeEngine:
                     self.reducer.reduce_async(st.gflat[g])
 
     def step(self):
-        """Clip + AdamW.  On a GPU the optimizer kernels (HBM-bound, ~28 B/param) are enqueued on a side HIP
-        stream so that they MAY overlap with whatever the main stream does next that does not touch the policy (the
-        reference forward of the next batch).  Measured (profiles/r05_adam_window.txt): on the dense path they overlap
-        with nothing -- a gemm4 workgroup needs whole SIMD register files and cannot start while AdamW's waves sit on
-        every compute unit, so the step is the same with the update on the main stream (743 - 749 ms either way); what
-        does co-run are small-register kernels (vision towers, the MoE stack's 8-wave grouped GEMMs).  `wait_optimizer()`
-        is the join; the trainer calls it before the next policy forward, and every reader of the weights goes through it."""
+        """Clip + AdamW (three streaming kernels over the flat buffers, csrc/optim.hip) on the launch stream; `async_optimizer` (AA_ADAM_ASYNC=1) moves them
+        to a side HIP stream, `wait_optimizer()` is then the join every reader of the weights goes through (a no-op otherwise)."""
         st = self.module.store
         if self.micro_steps % self.gas != 0:
             return  # not at a gradient-accumulation boundary (DeepSpeedEngine.step semantics)

@@ -558,7 +558,7 @@ def main():
             names = {'adamw_flat': 'adamw_kernel (csrc/optim.hip; 28 B per bf16 parameter: g, fp32 master / m / v read + written, bf16 weight written)',
                      'grad_sumsq': 'sumsq_kernel (csrc/optim.hip; the clip norm: one read of the gradients)',
                      'rmsnorm_fwd': 'rmsnorm_fwd2_kernel (csrc/elementwise.hip)', 'rmsnorm_bwd': 'rmsnorm_bwd_kernel<2> (csrc/elementwise.hip)',
-                     'swiglu_bwd': 'swiglu_bwd_kernel (csrc/elementwise.hip)'}
+                     'swiglu_bwd': 'swiglu_bwd_kernel (csrc/elementwise.hip)'}       # (only when the caller launches it itself: MoE / unfused paths)
             hbm = []
             for kind, label in names.items():
                 ev = kprof.get(kind)
@@ -570,6 +570,25 @@ def main():
                 hbm.append({'kernel': label, 'sampled_launches': len(ev), 'algorithmic_bytes': by / len(ev), 'avg_ms': sum(ms) / len(ms),
                             'gb_per_s': by / sum(ms) / 1e6, 'frac_of_8TBs': by / sum(ms) / 1e6 / PEAK_HBM_GBS,
                             'launches_per_step': calls / args.steps, 'ms_per_step': sum(ms) / len(ms) * calls / args.steps})
+            # swiglu_bwd_kernel is launched INSIDE aa_gemm_glu_bwd_bf16 when the per-shape plan chose the unfused pair: no host event can go around it.  Timed
+            # here, outside the timed region, at the step's own shape with HIP events on the launch stream (its in-step average: profiles/r06_dpo7b_kernel_stats.csv)
+            if any(a > b_ for _, _, _, a, b_ in ops.GLU_BWD_PROBE_LOG):
+                Mtok, Fw = 2 * B * T, cfg['text']['intermediate_size']
+                gu_ = torch.randn(Mtok, 2 * Fw, device=device, dtype=torch.bfloat16)
+                da_ = torch.randn(Mtok, Fw, device=device, dtype=torch.bfloat16)
+                o_ = torch.empty_like(gu_)
+                for _ in range(3):
+                    ops.swiglu_bwd(gu_, da_, out=o_)
+                e0_ = ops.event_record()
+                for _ in range(10):
+                    ops.swiglu_bwd(gu_, da_, out=o_)
+                e1_ = ops.event_record()
+                ms_ = ops.event_elapsed_ms(e0_, e1_) / 10
+                by_ = 2.0 * Mtok * Fw * 5
+                hbm.append({'kernel': 'swiglu_bwd_kernel (csrc/elementwise.hip)', 'sampled_launches': 10, 'algorithmic_bytes': by_, 'avg_ms': ms_, 'gb_per_s': by_ / ms_ / 1e6,
+                            'frac_of_8TBs': by_ / ms_ / 1e6 / PEAK_HBM_GBS, 'launches_per_step': args.layers, 'ms_per_step': ms_ * args.layers,
+                            'where': 'standalone after the timed region (in the step it is launched inside aa_gemm_glu_bwd_bf16)'})
+                del gu_, da_, o_
             out['roofline']['hbm_kernels'] = hbm
             att = {}
             for kind, label in (('attn_fwd', 'fwd'), ('attn_bwd', 'bwd')):
