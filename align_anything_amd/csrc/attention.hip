@@ -1073,8 +1073,14 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
         if ((rc = set_lds(attn_bwd_dq_kernel<128, 4>, lds, "aa_attn_bwd"))) return rc;
         if (AA_BWD_LAB_ONLY != 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 4>), gq, dim3(256), lds, st, p);
         if (AA_BWD_LAB_ONLY == 1) { AA_CHECK_LAUNCH("aa_attn_bwd"); return AA_OK; }
-        if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4>, lds + 1024, "aa_attn_bwd"))) return rc;
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4>), gkv, dim3(256), lds + 1024, st, p);
+        static const bool dkv32 = getenv("AA_ATTN_DKV32") && atoi(getenv("AA_ATTN_DKV32")) != 0;      // lab: dK / dV on the 32 x 32 x 16 scheme (attn_bwd1.inc, DQ = false)
+        if (dkv32) {
+            if ((rc = set_lds(b1::attn_bwd1_kernel<128, false>, b1::LDS_BYTES, "aa_attn_bwd"))) return rc;
+            hipLaunchKernelGGL((b1::attn_bwd1_kernel<128, false>), dim3(aa_cdiv(T, b1::KB) * Hkv * N), dim3(256), b1::LDS_BYTES, st, p, (float*)nullptr);
+        } else {
+            if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4>, lds + 1024, "aa_attn_bwd"))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4>), gkv, dim3(256), lds + 1024, st, p);
+        }
     } else {
         const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
         if (!AA_ATTN_DELTA_IN_DQ) hipLaunchKernelGGL(attn_delta_kernel<64>, dim3(aa_cdiv(groups * 8, 256)), dim3(256), 0, st, p);
@@ -1134,8 +1140,8 @@ extern "C" int aa_attn_bwd_onepass(const void* Q, const void* K, const void* V, 
     hipError_t e = hipMemsetAsync(dq_ws, 0, (size_t)groups * 128 * sizeof(float), st);
     if (e != hipSuccess) { aa_set_error("aa_attn_bwd_onepass: memset: %s", hipGetErrorString(e)); return AA_ERR_LAUNCH; }
     hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(aa_cdiv(groups * 16, 256)), dim3(256), 0, st, p);
-    if ((rc = set_lds(b1::attn_bwd1_kernel<128>, b1::LDS_BYTES, "aa_attn_bwd_onepass"))) return rc;
-    hipLaunchKernelGGL(b1::attn_bwd1_kernel<128>, dim3(aa_cdiv(T, b1::KB) * Hkv * N), dim3(256), b1::LDS_BYTES, st, p, dq_ws);
+    if ((rc = set_lds((b1::attn_bwd1_kernel<128, true>), b1::LDS_BYTES, "aa_attn_bwd_onepass"))) return rc;
+    hipLaunchKernelGGL((b1::attn_bwd1_kernel<128, true>), dim3(aa_cdiv(T, b1::KB) * Hkv * N), dim3(256), b1::LDS_BYTES, st, p, dq_ws);
     hipLaunchKernelGGL(b1::dq_convert_kernel, dim3(aa_cdiv(groups * 8, 256)), dim3(256), 0, st, p, (const float*)dq_ws);
     AA_CHECK_LAUNCH("aa_attn_bwd_onepass");
     return AA_OK;

@@ -12,6 +12,36 @@ pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 
 
+def test_moe_route_tie_rule_is_pinned():
+    """the router's top-k TIE behaviour, stated and pinned.  bf16 router logits collide often (8 mantissa bits, 128 experts), and
+    equal logits are equal probabilities; hf's `torch.topk(routing_weights, top_k)` (modeling_qwen3_moe.py:210-282, what models/qwen3_moe.py:28-60 runs)
+    has NO defined order among equal values -- on CPU it differs from index-ascending in ~20 % of rows with a tie at the k-th place (measured in the build
+    container), so no fixture can pin it.  aa_moe_route's rule is: probability descending, then expert index ASCENDING (csrc/moe.hip: k rounds of a
+    wave-wide argmax with the (value, -index) order) -- deterministic, identical on every rank of an expert-parallel job, and a valid top-k wherever the
+    reference's is: the selected VALUES are the same multiset.  Rows without ties equal torch.topk exactly (test_moe_kernels_vs_torch)."""
+    from align_anything_amd import ops
+    g = torch.Generator().manual_seed(11)
+    rows, E, k = 512, 128, 8
+    logits = torch.randn(rows, E, generator=g).to(torch.bfloat16)
+    for r in range(rows):                                   # force ties, in most rows AT the k-th place: copy the k-th largest logit into 1 - 6 other experts
+        v, i = torch.topk(logits[r].float(), k)
+        n = int(torch.randint(1, 7, (1,), generator=g))
+        others = torch.randperm(E, generator=g)[:n]
+        logits[r, others] = logits[r, i[k - 1]] if r % 4 else logits[r, i[0]]
+    probs, idx, w = ops.moe_route(logits.to(dev()), k, True)
+    p = torch.softmax(logits.float(), -1)
+    order = torch.tensor([sorted(range(E), key=lambda e: (-float(p[r, e]), e))[:k] for r in range(rows)])
+    assert torch.equal(idx.long().cpu(), order), 'tie rule: probability descending, then expert index ascending'
+    tv, ti = torch.topk(p, k, -1)
+    assert torch.equal(torch.sort(torch.gather(p, 1, order), -1).values, torch.sort(tv, -1).values)       # the same VALUES as the reference's call, whatever it picked
+    n_boundary = sum(float(p[r, order[r, -1]]) == float(torch.sort(p[r], descending=True).values[k]) for r in range(rows))
+    assert n_boundary > rows // 2                            # the case is exercised: a tie across the k-th place in most rows
+    sel = torch.gather(p, 1, order)
+    assert rel_err(w.float().cpu(), (sel / sel.sum(-1, keepdim=True))) < 1e-2
+    again = ops.moe_route(logits.to(dev()), k, True)[1]
+    assert torch.equal(again, idx)
+
+
 def test_moe_kernels_vs_torch():
     from align_anything_amd import ops
     g = torch.Generator().manual_seed(2)
