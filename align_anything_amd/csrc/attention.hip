@@ -977,7 +977,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnPara
 }
 
 #include "attn128.inc"
-#include "attn_bwd1.inc"
 
 // ================================================================== C ABI
 static int check_common(const char* fn, int N, int T, int H, int Hkv, int hd) {
@@ -1073,14 +1072,8 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
         if ((rc = set_lds(attn_bwd_dq_kernel<128, 4>, lds, "aa_attn_bwd"))) return rc;
         if (AA_BWD_LAB_ONLY != 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 4>), gq, dim3(256), lds, st, p);
         if (AA_BWD_LAB_ONLY == 1) { AA_CHECK_LAUNCH("aa_attn_bwd"); return AA_OK; }
-        static const bool dkv32 = getenv("AA_ATTN_DKV32") && atoi(getenv("AA_ATTN_DKV32")) != 0;      // lab: dK / dV on the 32 x 32 x 16 scheme (attn_bwd1.inc, DQ = false)
-        if (dkv32) {
-            if ((rc = set_lds(b1::attn_bwd1_kernel<128, false>, b1::LDS_BYTES, "aa_attn_bwd"))) return rc;
-            hipLaunchKernelGGL((b1::attn_bwd1_kernel<128, false>), dim3(aa_cdiv(T, b1::KB) * Hkv * N), dim3(256), b1::LDS_BYTES, st, p, (float*)nullptr);
-        } else {
-            if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4>, lds + 1024, "aa_attn_bwd"))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4>), gkv, dim3(256), lds + 1024, st, p);
-        }
+        if ((rc = set_lds(attn_bwd_dkv_kernel<128, 4>, lds + 1024, "aa_attn_bwd"))) return rc;
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 4>), gkv, dim3(256), lds + 1024, st, p);
     } else {
         const dim3 gq(aa_cdiv(T, 128) * H * N), gkv(aa_cdiv(T, 64) * Hkv * N);
         if (!AA_ATTN_DELTA_IN_DQ) hipLaunchKernelGGL(attn_delta_kernel<64>, dim3(aa_cdiv(groups * 8, 256)), dim3(256), 0, st, p);
@@ -1113,36 +1106,3 @@ extern "C" int aa_attn_bwd_rope(const void* Q, const void* K, const void* V, con
                          pos, cos_t, sin_t, stream);
 }
 
-// The single-pass backward of attn_bwd1.inc (head_dim 128): five matmuls per (query tile, key block), dK / dV accumulated in registers, dQ through fp32
-// atomics into `dq_ws` ([N, H, T, 128] fp32, caller-owned; zeroed here) and one convert pass that also applies the rotary backward when pos / cos_t / sin_t
-// are given (then dK leaves the kernel rotated back as well, as aa_attn_bwd_rope).  dK / dV are bit-reproducible; dQ is summed in arrival order.
-extern "C" int aa_attn_bwd_onepass(const void* Q, const void* K, const void* V, const void* O, const void* dO,
-                                   const float* lse, float* delta, void* dQ, void* dK, void* dV,
-                                   const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo,
-                                   long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
-                                   int causal, float scale, const int* pos, const void* cos_t, const void* sin_t, float* dq_ws, void* stream) {
-    int rc = check_common("aa_attn_bwd_onepass", N, T, H, Hkv, hd);
-    if (rc) return rc;
-    AA_REQUIRE(hd == 128, "aa_attn_bwd_onepass: head_dim %d (128 only)", hd);
-    AA_REQUIRE((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) % 8 == 0, "aa_attn_bwd_onepass: leading dims must be multiples of 8");
-    AA_REQUIRE(dq_ws != nullptr && ((uintptr_t)dq_ws & 15) == 0, "aa_attn_bwd_onepass: dq_ws = [N, H, T, 128] fp32, 16-byte aligned");
-    AA_REQUIRE((pos == nullptr) == (cos_t == nullptr) && (pos == nullptr) == (sin_t == nullptr), "aa_attn_bwd_onepass: pos / cos_t / sin_t together or not at all");
-    AA_REQUIRE(pos == nullptr || ((((uintptr_t)cos_t | (uintptr_t)sin_t) & 15) == 0), "aa_attn_bwd_onepass: tables must be 16-byte aligned");
-    AttnParams p{};
-    p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O;
-    p.dO = (const bf16_t*)dO; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
-    p.lse = const_cast<float*>(lse); p.delta = delta; p.start = start; p.kvlen = kv_len;
-    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
-    p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
-    p.rope_pos = pos; p.rope_cos = (const bf16_t*)cos_t; p.rope_sin = (const bf16_t*)sin_t;
-    hipStream_t st = (hipStream_t)stream;
-    const long groups = (long)N * T * H;
-    hipError_t e = hipMemsetAsync(dq_ws, 0, (size_t)groups * 128 * sizeof(float), st);
-    if (e != hipSuccess) { aa_set_error("aa_attn_bwd_onepass: memset: %s", hipGetErrorString(e)); return AA_ERR_LAUNCH; }
-    hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(aa_cdiv(groups * 16, 256)), dim3(256), 0, st, p);
-    if ((rc = set_lds((b1::attn_bwd1_kernel<128, true>), b1::LDS_BYTES, "aa_attn_bwd_onepass"))) return rc;
-    hipLaunchKernelGGL((b1::attn_bwd1_kernel<128, true>), dim3(aa_cdiv(T, b1::KB) * Hkv * N), dim3(256), b1::LDS_BYTES, st, p, dq_ws);
-    hipLaunchKernelGGL(b1::dq_convert_kernel, dim3(aa_cdiv(groups * 8, 256)), dim3(256), 0, st, p, (const float*)dq_ws);
-    AA_CHECK_LAUNCH("aa_attn_bwd_onepass");
-    return AA_OK;
-}

@@ -645,11 +645,6 @@ def moe_combine_bwd(dout, yp, pos, w, src=None):
 
 
 # ------------------------------------------------------------------ attention
-# AA_ATTN_ONEPASS=1: the head_dim-128 backward as ONE pass (aa_attn_bwd_onepass, csrc/attn_bwd1.inc: five matmuls, dQ through fp32 atomics) instead of the
-# dQ + dK/dV kernel pair.  dQ's last fp32 bits then depend on arrival order; default off (same-box A/B: profiles/r06_attn_onepass.txt).
-ATTN_ONEPASS = os.environ.get('AA_ATTN_ONEPASS', '0') == '1'
-
-
 def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None, kv_len=None):
     """q/k/v: 2-D views [N*T, >=H*hd] (column slices of the fused qkv buffer are fine)."""
     out = torch.empty((N * T, H * hd), dtype=q.dtype, device=q.device) if out is None else out
@@ -677,14 +672,6 @@ def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, s
         pos, cos_t, sin_t = rope
         if q.dtype != bf16 or cos_t.dtype != bf16 or pos.dtype != torch.int32 or pos.numel() < N * T:
             raise RuntimeError('attn_bwd(rope=): bf16 activations and tables, int32 positions for every token row')
-    if ATTN_ONEPASS and hd == 128 and q.dtype == bf16:
-        key = ('dq_ws', q.device)
-        ws = _ws_cache.get(key)
-        if ws is None or ws.numel() < N * H * T * 128:
-            ws = _ws_cache[key] = torch.empty(N * H * T * 128, dtype=torch.float32, device=q.device)       # stream-ordered reuse, like the norm scratch
-        r3 = (None, None, None) if rope is None else (rope[0].data_ptr(), rope[1].data_ptr(), rope[2].data_ptr())
-        call('aa_attn_bwd_onepass', *args, *r3, ws.data_ptr(), stream())
-    elif rope is not None:
         call('aa_attn_bwd_rope', *args, pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), stream())
     else:
         call('aa_attn_bwd' + _sfx(q, 'attn_bwd'), *args, stream())

@@ -291,17 +291,6 @@ int aa_attn_bwd_rope(const void* Q, const void* K, const void* V, const void* O,
                      long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
                      int causal, float scale, const int* pos, const void* cos_t, const void* sin_t, void* stream);
 
-/* The same backward in ONE pass over the (query tile, key block) pairs (csrc/attn_bwd1.inc; head_dim 128): S and dP are recomputed once instead of twice
- * (five matmuls instead of seven), dK / dV accumulate in registers, dQ through fp32 atomics into dq_ws = [N, H, T, 128] fp32 (caller-owned scratch, zeroed
- * by the call) followed by one convert pass.  pos / cos_t / sin_t: all NULL = plain dQ / dK (aa_attn_bwd), all given = rotated back (aa_attn_bwd_rope).
- * dK / dV are bit-reproducible; dQ's fp32 partial sums are added in arrival order.  Replaces the same reference call site as aa_attn_bwd:
- * trainers/text_image_to_text/dpo.py:85-105 -> hf modeling_llama.py:243-281 (backward of SDPA). */
-int aa_attn_bwd_onepass(const void* Q, const void* K, const void* V, const void* O, const void* dO,
-                        const float* lse, float* delta, void* dQ, void* dK, void* dV,
-                        const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo,
-                        long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
-                        int causal, float scale, const int* pos, const void* cos_t, const void* sin_t, float* dq_ws, void* stream);
-
 /* ---- data-parallel exchange for non-Python hosts (csrc/comm.hip; the Python host side uses torch.distributed for the same three
  * operations).  RCCL is bound at run time (dlopen librccl.so); one communicator per process = per GPU.
  * reference: DeepSpeed's gradient all-reduce behind engine.backward / step (trainers/text_to_text/dpo.py:212-213) and

@@ -121,56 +121,3 @@ def test_attention_backward_rope_epilogue_is_bit_identical(case):
         ops.attn_bwd(q, k, v, o, do, lse, one[:, :H * hd], one[:, H * hd:(H + Hkv) * hd], one[:, (H + Hkv) * hd:], N, T, H, Hkv, hd, causal, scale, start,
                      rope=(pos.long(), cos_t, sin_t))
 
-
-ONEPASS_CASES = [c for c in CASES if c[4] == 128] + [
-    (2, 512, 4, 2, 128, True, [0, 150]),          # GQA 4 / 2, two 128-key blocks per row and more, left padding into the second block
-    (1, 333, 2, 1, 128, True, [5]),               # ragged T (not a multiple of 64), GQA 2 / 1
-    (1, 384, 2, 2, 128, False, None),             # non-causal
-    (2, 1024, 7, 1, 128, True, [0, 77]),          # GQA 7 / 1 (Qwen2-VL's group size)
-]
-
-
-@pytest.mark.parametrize('case', ONEPASS_CASES)
-@pytest.mark.parametrize('with_rope', [False, True])
-def test_attention_backward_one_pass(case, with_rope, monkeypatch):
-    """aa_attn_bwd_onepass (csrc/attn_bwd1.inc: five matmuls, key blocks outer, dQ through fp32 atomics + a convert pass) against the fp32 reference with the
-    two-kernel backward's tolerances, and against the two-kernel backward itself: dK / dV / dQ agree to bf16 rounding of sums formed in another order."""
-    from align_anything_amd import ops
-    N, T, H, Hkv, hd, causal, starts = case
-    scale = hd ** -0.5
-    qkv = randn_bf16(N * T, (H + 2 * Hkv) * hd, seed=31)
-    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:(H + Hkv) * hd], qkv[:, (H + Hkv) * hd:]
-    do = randn_bf16(N * T, H * hd, seed=32)
-    start = torch.tensor(starts, dtype=torch.int32, device=dev()) if starts is not None else None
-    o, lse = ops.attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start)
-    ro, rdq, rdk, rdv, valid = ref_attention(q, k, v, do, N, T, H, Hkv, hd, causal, scale, start)
-    do = do * valid[:, None].to(do.dtype)
-    rope = None
-    if with_rope:
-        g = torch.Generator().manual_seed(5)
-        pos = torch.randint(0, 4096, (N * T,), generator=g).to(torch.int32).to(dev())
-        ang = torch.arange(4096, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(0, hd, 2, dtype=torch.float32) / hd))[None, :]
-        rope = (pos, ang.cos().to(torch.bfloat16).to(dev()), ang.sin().to(torch.bfloat16).to(dev()))
-
-    def run(onepass):
-        monkeypatch.setattr(ops, 'ATTN_ONEPASS', onepass)
-        d = torch.full_like(qkv, float('nan'))          # every element of dq / dk / dv must be written
-        dq, dk, dv = d[:, :H * hd], d[:, H * hd:(H + Hkv) * hd], d[:, (H + Hkv) * hd:]
-        ops.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start, rope=rope)
-        torch.cuda.synchronize()
-        return d
-
-    one, two = run(True), run(False)
-    assert torch.isfinite(one.float()).all()
-    vm = valid[:, None].float()
-    parts = lambda d: (d[:, :H * hd].float() * vm, d[:, H * hd:(H + Hkv) * hd].float(), d[:, (H + Hkv) * hd:].float())
-    for name, a, b in zip(('dQ', 'dK', 'dV'), parts(one), parts(two)):
-        assert_close(a, b, rtol=3e-2, atol=2e-2 * max(float(b.abs().max()), 1e-3), what=f'{name} one-pass vs two-kernel {case}')
-    if not with_rope:
-        dq1, dk1, dv1 = parts(one)
-        assert_close(dq1, rdq * vm, rtol=3e-2, atol=2e-2 * max(float(rdq.abs().max()), 1e-3), what=f'dQ {case}')
-        assert_close(dk1, rdk, rtol=3e-2, atol=2e-2 * max(float(rdk.abs().max()), 1e-3), what=f'dK {case}')
-        assert_close(dv1, rdv, rtol=3e-2, atol=2e-2 * max(float(rdv.abs().max()), 1e-3), what=f'dV {case}')
-        # dK / dV of the one-pass kernel are deterministic: a second run is bit-identical (dQ's fp32 partials arrive in any order)
-        again = run(True)
-        assert torch.equal(again[:, H * hd:].view(torch.int16), one[:, H * hd:].view(torch.int16))

@@ -27,7 +27,7 @@ def test_moe_route_tie_rule_is_pinned():
         v, i = torch.topk(logits[r].float(), k)
         n = int(torch.randint(1, 7, (1,), generator=g))
         others = torch.randperm(E, generator=g)[:n]
-        logits[r, others] = logits[r, i[k - 1]] if r % 4 else logits[r, i[0]]
+        logits[r, others] = (logits[r, i[k - 1]] if r % 4 else logits[r, i[0]]).clone()
     probs, idx, w = ops.moe_route(logits.to(dev()), k, True)
     p = torch.softmax(logits.float(), -1)
     order = torch.tensor([sorted(range(E), key=lambda e: (-float(p[r, e]), e))[:k] for r in range(rows)])

@@ -30,24 +30,6 @@ PY
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r06_prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-events --traffic committed --no-per-batch --no-power > $R/gpurun_out/r06_prof.log 2>&1 )
       f=$(find gpurun_out/r06_prof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r06_dpo7b_kernel_stats.csv; head -25 gpurun_out/r06_dpo7b_kernel_stats.csv | cut -c1-200
       find gpurun_out/r06_prof -name "*kernel_trace.csv" -delete ;;
-    onepass)         # the single-pass attention backward: numerics, then same-box timing against the kernel pair, then per-kernel split
-      timeout 900 python -m pytest tests/test_attention_gpu.py -q -x -m gpu -p no:cacheprovider -k "one_pass" > gpurun_out/r06_onepass_tests.log 2>&1; echo "rc=$?"; tail -12 gpurun_out/r06_onepass_tests.log | cut -c1-400
-      timeout 600 python tools/attn_onepass_lab.py r06_attn_onepass_lab.json 2>&1 | tail -40
-      ( cd /tmp && export TMPDIR=/tmp
-        for v in two one; do
-          rm -rf $R/gpurun_out/r06_prof_onepass_$v
-          AA_LAB_ONLY=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof_onepass_$v -o p -- python $R/tools/attn_onepass_lab.py > /dev/null 2>&1
-          f=$(find $R/gpurun_out/r06_prof_onepass_$v -name "*kernel_stats.csv" | head -1); echo "--- $v"; head -8 "$f" | cut -c1-180
-          find $R/gpurun_out/r06_prof_onepass_$v -name "*kernel_trace.csv" -delete
-        done ) ;;
-    dkv32)           # the dK / dV half of the backward on the 32 x 32 x 16 one-wave-per-SIMD scheme (attn_bwd1.inc, DQ = false) against attn_bwd_dkv_kernel
-      AA_ATTN_DKV32=1 timeout 900 python -m pytest tests/test_attention_gpu.py tests/test_bench_geometry_gpu.py -q -x -m gpu -p no:cacheprovider -k "attention and not one_pass" > gpurun_out/r06_dkv32_tests.log 2>&1; echo "rc=$?"; tail -6 gpurun_out/r06_dkv32_tests.log | cut -c1-300
-      for v in 0 1 0 1; do AA_ATTN_DKV32=$v AA_LAB_ONLY=two timeout 300 python tools/attn_onepass_lab.py 2>&1 | grep -E "two_us|two_tflops" | tr -d '\n'; echo " <- AA_ATTN_DKV32=$v"; done
-      ( cd /tmp && export TMPDIR=/tmp
-        rm -rf $R/gpurun_out/r06_prof_dkv32
-        AA_ATTN_DKV32=1 AA_LAB_ONLY=two timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof_dkv32 -o p -- python $R/tools/attn_onepass_lab.py > /dev/null 2>&1
-        f=$(find $R/gpurun_out/r06_prof_dkv32 -name "*kernel_stats.csv" | head -1); head -5 "$f" | cut -c1-180
-        find $R/gpurun_out/r06_prof_dkv32 -name "*kernel_trace.csv" -delete ) ;;
     glue)            # which python lines launch torch copy / fill kernels inside the step
       timeout 600 python tools/lab/glue_prof.py 8 2>&1 | tail -90 | cut -c1-200 ;;
     *) echo "unknown stage $stage" ;;
