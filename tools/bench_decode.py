@@ -18,6 +18,8 @@ import itertools
 from align_anything_amd import ops
 quick = os.environ.get('AA_BENCH_DECODE_QUICK') == '1'      # one configuration, default kernels: the run rocprofv3 wraps
 cases = itertools.product(((4, 512, 32),) if os.environ.get("AA_BENCH_DECODE_AB") != "1" else ((4, 512, 64), (16, 512, 64)), (False,)) if quick else itertools.product(((4, 512, 64), (16, 512, 64), (16, 1536, 64)), (False,))
+if os.environ.get('AA_BENCH_DECODE_CASES'):      # 'N,prompt,new;N,prompt,new;...' (round 6: the batches the reference rolls out -- PPO 1, GRPO B x num_generations = 10)
+    cases = [(tuple(int(x) for x in c.split(',')), False) for c in os.environ['AA_BENCH_DECODE_CASES'].split(';')]
 for (N, Tp, new), fused in cases:
     ops.DECODE_FUSED = fused; ug = os.environ.get('AA_BENCH_DECODE_GRAPH') == '1'
     ids = torch.randint(3, 32000, (N, Tp), device=dev)
@@ -36,4 +38,4 @@ for (N, Tp, new), fused in cases:
     row = dict(N=N, prompt=Tp, new=new, fused=fused, strip_major_weights=os.environ.get('AA_DECODE_SWIZZLE', '1') != '0', hipgraph=ug, graph_used=generate.last_used_graph, prefill_ms=t_prefill * 1e3, ms_per_step=ms_tok, tokens_per_s=N * new / dt,
                weight_stream_GBs=wbytes / (ms_tok * 1e-3) / 1e9, frac_hbm_peak=wbytes / (ms_tok * 1e-3) / 8e12)
     print(row, flush=True); res.append(row)
-json.dump(res, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'bench_decode_quick.json' if quick else 'bench_decode.json'), 'w'), indent=1)
+json.dump(res, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', os.environ.get('AA_BENCH_DECODE_OUT') or ('bench_decode_quick.json' if quick else 'bench_decode.json')), 'w'), indent=1)

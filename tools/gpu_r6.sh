@@ -32,6 +32,12 @@ PY
       find gpurun_out/r06_prof -name "*kernel_trace.csv" -delete ;;
     glue)            # which python lines launch torch copy / fill kernels inside the step
       timeout 600 python tools/lab/glue_prof.py 8 2>&1 | tail -90 | cut -c1-200 ;;
+    decode)          # decode of the FINAL code at the batches the reference rolls out (PPO: 1; GRPO: B x num_generations = 10, grpo.py:216-226, grpo.yaml:70) and 4 / 16
+      AA_BENCH_DECODE_CASES="1,512,64;4,512,64;10,512,64;16,512,64" AA_BENCH_DECODE_OUT=r06_bench_decode.json timeout 900 python tools/bench_decode.py 2>&1 | grep -E "^\{" | cut -c1-330 ;;
+    ppo)             # BASELINE configs[2] on one GPU: Qwen2-VL-7B actor + reference + reward + critic, one PPO iteration
+      timeout 900 python tools/bench_ppo.py --iters 2 > gpurun_out/r06_bench_ppo.log 2>&1; tail -4 gpurun_out/r06_bench_ppo.log | cut -c1-600 ;;
+    moe_tie)
+      timeout 300 python -m pytest tests/test_qwen3moe_gpu.py -q -x -m gpu -p no:cacheprovider -k "tie_rule or kernels_vs_torch" 2>&1 | tail -4 ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
