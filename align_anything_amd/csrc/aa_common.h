@@ -19,6 +19,16 @@ typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 
 #define AA_WAVE 64
+// Inline-asm statements that contain `s_add_u32` write SCC, and the compiler must be told: AA_SCC is that clobber.  Rounds 2 - 5 shipped the LDS-DMA
+// statements of gemm4.hip / attn128.inc without it; round 6 found hipcc scheduling 64-bit address adds ACROSS them (s_add_u32 lo ... asm ... s_addc_u32 hi:
+// eight sites in five gemm4 kernels, the carry of the low word replaced by the asm's) -- wrong only when an operand's first stages straddle a 4 GB boundary,
+// i.e. silently and almost never -- and a compare / select pair in a lab kernel (profiles/r06_scc_clobber.txt).  tests/test_host_logic.py scans the
+// generated ISA for the pattern.  -DAA_NO_DECLARE_SCC rebuilds the old behaviour for the same-box A/B.
+#ifdef AA_NO_DECLARE_SCC
+#define AA_SCC
+#else
+#define AA_SCC , "scc"
+#endif
 #define AA_MAX_DEVICES 16     // per-device caches of launch parameters (one node: 8 GPUs)
 
 __device__ __forceinline__ float bf2f(bf16_t u) {

@@ -64,7 +64,7 @@ __device__ __forceinline__ void G4_DMA_PIECE_BUF(unsigned vA0, unsigned vA1, uns
     const unsigned v = J < NP ? ((A_T && (j & 1)) ? vA1 : vA0) : ((B_N && (j & 1)) ? vB1 : vB0);
     const int so = J < NP ? soA[j] : soB[j];
     if constexpr (J < 2 * NP - 1) {
-        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, %3" ::"v"(v), "s"(J < NP ? srdA : srdB), "s"(so), "i"(NW * 1024) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, %3" ::"v"(v), "s"(J < NP ? srdA : srdB), "s"(so), "i"(NW * 1024) : "memory" AA_SCC);
     } else {
         asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(v), "s"(srdB), "s"(so) : "memory");
     }
@@ -74,9 +74,9 @@ __device__ __forceinline__ void G4_DMA_PIECE_BUF(unsigned vA0, unsigned vA1, uns
 template <int J>
 __device__ __forceinline__ void G4_DMA_PIECE(const unsigned (&offA)[NP], const unsigned (&offB)[NP], const char* srcA, const char* srcB) {
     if constexpr (J < NP) {
-        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(offA[J]), "s"(srcA), "i"(NW * 1024) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(offA[J]), "s"(srcA), "i"(NW * 1024) : "memory" AA_SCC);
     } else if constexpr (J < 2 * NP - 1) {
-        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(offB[J - NP]), "s"(srcB), "i"(NW * 1024) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(offB[J - NP]), "s"(srcB), "i"(NW * 1024) : "memory" AA_SCC);
     } else {
         asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(offB[J - NP]), "s"(srcB) : "memory");
     }
@@ -393,7 +393,7 @@ constexpr int NT_B0 = 3 * 32768, NT_LDS = 5 * 32768;          // B buffers behin
 template <int J>
 __device__ __forceinline__ void G4NT_DMA_PIECE_BUF(unsigned v, const int (&so)[NP8], g4_srd_t srd) {
     if constexpr (J < NP8 - 1) {
-        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, %3" ::"v"(v), "s"(srd), "s"(so[J]), "i"(NW * 1024) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, %3" ::"v"(v), "s"(srd), "s"(so[J]), "i"(NW * 1024) : "memory" AA_SCC);
     } else {
         asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(v), "s"(srd), "s"(so[J]) : "memory");
     }
@@ -401,7 +401,7 @@ __device__ __forceinline__ void G4NT_DMA_PIECE_BUF(unsigned v, const int (&so)[N
 template <int J>
 __device__ __forceinline__ void G4NT_DMA_PIECE(unsigned v, const char* src) {
     if constexpr (J < NP8 - 1) {
-        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(v), "s"(src), "i"(NW * 1024) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2" ::"v"(v), "s"(src), "i"(NW * 1024) : "memory" AA_SCC);
     } else {
         asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(v), "s"(src) : "memory");
     }

@@ -616,6 +616,54 @@ def test_gemm4_kernels_keep_everything_in_registers():
     _check_ring_gemm_isa('gemm4.hip', r'gemm4(?:nt)?_kernel', 'v_mfma_f32_16x16x32_bf16', 256, 10)
 
 
+def _scc_hazards(asm_text: str):
+    """Instructions that READ SCC (s_cselect*, s_cbranch_scc*, s_addc / s_subb, s_cmov) whose reaching SCC definition, inside one basic block, is a
+    scalar ALU instruction INSIDE an inline-asm block -- i.e. the compiler kept a compare / carry alive across a statement that overwrites it."""
+    writers = ('s_cmp', 's_add_', 's_addc', 's_sub_', 's_subb', 's_and_', 's_or_', 's_xor_', 's_lshl', 's_lshr', 's_ashr', 's_andn2', 's_orn2', 's_nand', 's_nor', 's_xnor',
+               's_min', 's_max', 's_bitcmp', 's_abs', 's_not', 's_bfe', 's_bcnt', 's_ff', 's_flbit', 's_wqm', 's_quadmask', 's_absdiff')
+    readers = ('s_cselect', 's_cbranch_scc', 's_addc_u32', 's_subb_u32', 's_cmov')
+    hits = []
+    for m in re.finditer(r'^(_Z\S+):[^\n]*\n(.*?)\n\.Lfunc_end', asm_text, flags=re.S | re.M):
+        in_asm, last = False, None
+        for i, line in enumerate(m.group(2).split('\n')):
+            ls = line.strip()
+            if 'ASMSTART' in ls:
+                in_asm = True
+            elif 'ASMEND' in ls:
+                in_asm = False
+            elif not ls or ls.startswith(';'):
+                continue
+            elif ls.startswith('.L'):
+                last = None                                  # a label: the reaching definition is not known from this walk
+            else:
+                op = ls.split()[0]
+                if op.startswith(readers) and last == 'asm':
+                    hits.append((m.group(1)[:70], i, ls))
+                if op.startswith(writers):
+                    last = 'asm' if in_asm else 'compiler'
+    return hits
+
+
+def test_no_scalar_condition_code_is_kept_alive_across_inline_asm():
+    """Round 6: the LDS-DMA statements of gemm4.hip / attn128.inc contain `s_add_u32 m0, ...`, which writes SCC.  Without the clobber in their asm
+    declaration hipcc split 64-bit address adds around them (s_add_u32 lo; <asm>; s_addc_u32 hi) in five shipped gemm4 kernels -- the high word then takes the
+    asm's carry: wrong whenever an operand's first stages cross a 4 GB boundary.  Every asm statement that writes SCC now declares it (AA_SCC, aa_common.h);
+    this test walks the generated ISA of every source with hand-written asm and fails on the pattern, and checks that the scanner still finds it in the
+    old build (-DAA_NO_DECLARE_SCC)."""
+    import subprocess
+    import tempfile
+    from align_anything_amd import build as b
+    with tempfile.TemporaryDirectory() as d:
+        def isa(src, extra=()):
+            out = os.path.join(d, src + ('.old' if extra else '') + '.s')
+            r = subprocess.run([b.HIPCC, *b.FLAGS, *extra, '--cuda-device-only', '-S', os.path.join(b.CSRC, src), '-o', out], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            return open(out).read()
+        for src in ('gemm4.hip', 'attention.hip', 'gemm.hip', 'decode.hip', 'lmhead.hip'):
+            assert _scc_hazards(isa(src)) == [], src
+        assert len(_scc_hazards(isa('gemm4.hip', ('-DAA_NO_DECLARE_SCC=1',)))) >= 1          # the scanner sees what it is there to see
+
+
 def test_attention_kernels_keep_fragments_in_registers_and_the_prefetch_in_flight():
     """csrc/attention.hip issues its transpose reads and DMA pieces as inline asm (the compiler neither tracks their completion nor orders
     them against each other).  That is only sound -- and only fast -- while (1) nothing spills: a spilled fragment register would be stored

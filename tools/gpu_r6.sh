@@ -38,6 +38,12 @@ PY
       timeout 900 python tools/bench_ppo.py --iters 2 > gpurun_out/r06_bench_ppo.log 2>&1; tail -4 gpurun_out/r06_bench_ppo.log | cut -c1-600 ;;
     moe_tie)
       timeout 300 python -m pytest tests/test_qwen3moe_gpu.py -q -x -m gpu -p no:cacheprovider -k "tie_rule or kernels_vs_torch" 2>&1 | tail -4 ;;
+    scc_ab)          # the SCC clobber on the LDS-DMA asm statements (default since round 6) against the old build (libaa_hip_noscc.so): numerics of the touched kernels, then the headline step, alternating
+      timeout 900 python -m pytest tests/test_gemm_gpu.py tests/test_attention_gpu.py tests/test_bench_geometry_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r06_scc_tests.log 2>&1; echo "rc=$?"; tail -3 gpurun_out/r06_scc_tests.log | cut -c1-200
+      for v in libaa_hip_noscc.so libaa_hip.so libaa_hip_noscc.so libaa_hip.so; do
+        AA_HIP_LIB=$R/align_anything_amd/$v timeout 600 python bench.py --steps 8 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r06_bench_scc.json 2> gpurun_out/r06_bench_scc.err
+        python -c "import json; d=json.load(open('gpurun_out/r06_bench_scc.json')); r=d['roofline']; print('$v', round(d['ms_per_step'],2), 'ms', round(d['value'],4), 'pairs/s  gemm4', round(r['achieved'],1), 'TF/s  W', round(r.get('power_w_mean') or 0), 'MHz', round(r.get('sclk_mhz_mean') or 0), 'losses', d['config'].get('losses_timed_steps', [])[-2:])" || tail -3 gpurun_out/r06_bench_scc.err
+      done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
