@@ -511,7 +511,10 @@ static int pick_tile(int M, int N, int K) {
     if (g4 < 0) { const char* e = getenv("AA_GEMM_G4"); g4 = e ? atoi(e) : 1; }
     struct Cfg { int bm, bn, slots; float eff; };
     // slots = concurrently resident tiles on the chip; eff = relative per-flop efficiency of the config
-    const Cfg cfgs[4] = {{256, 256, 256, 1.00f}, {128, 128, 512, 0.72f}, {256, 128, 256, 0.86f}, {128, 256, 256, 0.86f}};
+    // (round 6: the 8-wave tiles are rated against gemm4, which runs the 256 x 256 tile since round 2, not against the 8-wave kernel of that tile: measured
+    // 1035 TFLOP/s on 256 x 128 against ~1400 on gemm4 at M = 10240, N = 4096 (profiles/r06_dpo7b_packed_kernel_stats.csv) -- with 0.86 the model sent the
+    // 640-tile shapes of the packed step to five half rounds of the 8-wave kernel instead of three rounds of gemm4.  No shape of the unpacked step changes.)
+    const Cfg cfgs[4] = {{256, 256, 256, 1.00f}, {128, 128, 512, g4 ? 0.62f : 0.72f}, {256, 128, 256, g4 ? 0.76f : 0.86f}, {128, 256, 256, g4 ? 0.76f : 0.86f}};
     // Short contractions (K < 2048: the CLIP / ViT / Whisper towers, OPT-125m): a 256 x 256 tile spends its time in the pipeline fill and in the epilogue of
     // 65536 outputs, not in its 16 k-steps -- the tower's fc1 (M 2308, N 4096, K 1024, bias + quick-GELU) ran 292 us on the one-wave-per-SIMD kernel and
     // 137 us on the 8-wave 256 x 256 one against 59 us on 256 x 128 although that needs two rounds (tools/bench_clip_gemms.py, profiles/r04_clip_gemms.json):

@@ -124,6 +124,44 @@ extern "C" int AA_FN(aa_moe_gather)(const void* x, const int* src_row, void* out
     return AA_OK;
 }
 
+// out[r, :] = (a[r] >= 0 ? x[a[r], :] : 0) + (b[r] >= 0 ? x[b[r], :] : 0), the sum rounded once to the activation dtype: the pack-reduce of shared-prompt
+// packing (trainers/common.py::build_pack_plan) -- a packed row's q | k | v gradient is the sum over the (one or two) slots of the reference layout that hold a
+// copy of it.  Bit-identical to aa_moe_gather twice + aa_add (the gathers are exact, the add rounds once), one pass instead of three.
+__global__ __launch_bounds__(256) void gather2_add_kernel(const elem_t* __restrict__ x, const int* __restrict__ a, const int* __restrict__ b,
+                                                          elem_t* __restrict__ out, long rows_out, int h) {
+    const int nv = h >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows_out * nv; i += (long)gridDim.x * 256) {
+        const long r = i / nv;
+        const int v = (int)(i % nv);
+        const int sa = a[r], sb = b[r];
+        ev8 o;
+        if (sa >= 0 && sb >= 0) {
+            const ev8 p = *reinterpret_cast<const ev8*>(x + (long)sa * h + v * 8);
+            const ev8 q = *reinterpret_cast<const ev8*>(x + (long)sb * h + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2e(e2f(p[j]) + e2f(q[j]));
+        } else if (sa >= 0 || sb >= 0) {
+            const ev8 p = *reinterpret_cast<const ev8*>(x + (long)(sa >= 0 ? sa : sb) * h + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2e(e2f(p[j]) + 0.f);          // (+ 0: what the separate add does to the gathered zero row; -0 -> +0)
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2e(0.f);
+        }
+        *reinterpret_cast<ev8*>(out + r * h + v * 8) = o;
+    }
+}
+extern "C" int AA_FN(aa_gather2_add)(const void* x, const int* row_a, const int* row_b, void* out, long rows_out, int h, void* stream) {
+    AA_REQUIRE(h > 0 && (h & 7) == 0, "aa_gather2_add: hidden %d must be a multiple of 8", h);
+    AA_REQUIRE(row_a != nullptr && row_b != nullptr, "aa_gather2_add: both index vectors are required (-1 = no row)");
+    if (rows_out == 0) return AA_OK;
+    const long total = rows_out * (h >> 3);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(gather2_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, row_a, row_b, (elem_t*)out, rows_out, h);
+    AA_CHECK_LAUNCH("aa_gather2_add");
+    return AA_OK;
+}
+
 // out[t, :] = (residual ? residual[t, :] : 0) + sum_j w[t, j] * Yp[pos[t, j], :]   (w == NULL -> unit weights; pos < 0 -> the slot is skipped)
 // hf :244-246: each expert output is multiplied by the (activation-dtype) weight, rounded, then index_add'ed in expert order.
 // Round 3: every slot's row is requested before the first one is used (the rows are 4 KB apart in HBM; the round-1 form loaded and accumulated slot by

@@ -131,9 +131,11 @@ class LlamaStack:
             n = max(T, self.cfg.get('max_position_embeddings', 0) or T)
             self.cos, self.sin = rope_tables(n, self.cfg['head_dim'], self.cfg['rope_theta'], self.store.device, self.store.dtype, self.cfg.get('rope_scaling'))
 
-    def forward(self, x, N, T, start, pos, save, kv_sink=None, tables=None):
+    def forward(self, x, N, T, start, pos, save, kv_sink=None, tables=None, pack=None):
         """tables = (cos, sin) [rows, hd/2]: per-token rope rows (multimodal RoPE), indexed by pos[row]; default = the
-        1-D position tables."""
+        1-D position tables.
+        pack (trainers.common.build_pack_plan; shared-prompt packing): x / pos are PACKED token rows (a pair's common prefix once); every row-wise
+        kernel runs on them as it is, and attention runs on the reference's [N, T] layout between two row gathers (slot2row / row2slot)."""
         c, P = self.cfg, self.store.p
         H, Hkv, hd, eps = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps']
         if tables is None:
@@ -157,8 +159,15 @@ class LlamaStack:
                 ops.rope_(qkv, 0, H + Hkv, hd, pos, tables[0], tables[1])
             if kv_sink is not None:
                 kv_sink(li, qkv[:N * T, qw:])  # post-RoPE keys | values of this layer -> KV cache (prefill)
-            attn, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
-                                     hd ** -0.5, start, out=self._attn_out(x, N * T, H * hd), kv_len=kv_len)
+            if pack is not None:
+                qkv = ops.moe_gather(qkv, pack['slot2row'])          # the reference layout (pad slots: zero rows); kept for the backward instead of the packed rows
+                attn_full, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True, hd ** -0.5, start,
+                                              out=self._attn_out(qkv, N * T, H * hd), kv_len=kv_len)
+                attn = ops.moe_gather(attn_full, pack['row2slot'])
+            else:
+                attn, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
+                                         hd ** -0.5, start, out=self._attn_out(x, N * T, H * hd), kv_len=kv_len)
+                attn_full = attn
             x_mid = L['o'].fwd(attn, residual=x)
             n2, rstd2 = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
             if x.dtype == bf16:
@@ -168,7 +177,7 @@ class LlamaStack:
                 act = ops.swiglu_fwd(gu)
             x_out = L['down'].fwd(act, residual=x_mid)
             if save:
-                self.saved.append((x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act))
+                self.saved.append((x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act) + ((attn_full,) if pack is not None else ()))
             x = x_out
         return x
 
@@ -253,15 +262,16 @@ class LlamaStack:
         # pad rows (Mp > N*T) are never written by the attention kernel: they must read as zeros
         return None if x.shape[0] == real_rows else torch.zeros((x.shape[0], width), dtype=x.dtype, device=x.device)
 
-    def backward(self, dres, N, T, start, pos, on_layer_done=None):
+    def backward(self, dres, N, T, start, pos, on_layer_done=None, pack=None):
         """dres: gradient of the residual stream after the last layer [Mp, h]; updated in place and returned
-        as the gradient w.r.t. the stack input.  Weight gradients go to store.g."""
+        as the gradient w.r.t. the stack input.  Weight gradients go to store.g.  pack: as in forward (pos = the full layout's positions then)."""
         c, P, G = self.cfg, self.store.p, self.store.g
         H, Hkv, hd = c['num_heads'], c['num_kv_heads'], c['head_dim']
         qw, kw = H * hd, Hkv * hd
         tr = self.trainable
         for L, sv in zip(reversed(self.layers), reversed(self.saved)):
-            x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act = sv
+            x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act = sv[:11]
+            attn_full = sv[11] if pack is not None else attn
             sv = None
             # ---- MLP
             if dres.dtype == bf16:
@@ -278,14 +288,18 @@ class LlamaStack:
             d_attn = L['o'].dx(dres)
             if tr:
                 L['o'].dw(dres, attn)
+            if pack is not None:
+                d_attn = ops.moe_gather(d_attn, pack['owner'])       # the copy of a shared prefix row in the rejected sequence is nobody's output: zero gradient
             d_qkv = torch.zeros_like(qkv) if qkv.shape[0] != N * T else torch.empty_like(qkv)
             fuse_rope = d_qkv.dtype == bf16 and ops.attn_rope_fused()      # the rotary backward rides in the dQ / dK epilogues (bit-identical)
-            ops.attn_bwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], attn, d_attn, lse,
+            ops.attn_bwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], attn_full, d_attn, lse,
                          d_qkv[:, :qw], d_qkv[:, qw:qw + kw], d_qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
                          hd ** -0.5, start, kv_len=getattr(self, '_kv_len_saved', None),
                          rope=(pos, self._rope[0], self._rope[1]) if fuse_rope else None)
             if not fuse_rope:
                 ops.rope_(d_qkv, 0, H + Hkv, hd, pos, self._rope[0], self._rope[1], inverse=True)
+            if pack is not None:                                      # a shared row's gradient = the sum over its two copies (q of the second copy is exactly 0)
+                d_qkv = ops.gather2_add(d_qkv, pack['row2slot'], pack['row2slot_b'])
             d_n1 = L['qkv'].dx(d_qkv)
             if tr:
                 L['qkv'].dw(d_qkv, n1)
@@ -642,9 +656,13 @@ class NativeCausalLM:
 
     # -- the DPO/PPO entry points
     def response_logprobs(self, input_ids, attention_mask, window, pixel_values=None, save=False,
-                          image_features=None, round_bf16=False, **mm):
+                          image_features=None, round_bf16=False, pack=None, **mm):
         """window: dict(row_idx int64[rows_pad], labels int64[rows_pad], inv_map int32[Mp]) built by
-        trainers.common.build_window.  Returns flat fp32 log-probs [rows_pad] (pad rows meaningless)."""
+        trainers.common.build_window.  Returns flat fp32 log-probs [rows_pad] (pad rows meaningless).
+        pack: trainers.common.build_pack_plan (shared-prompt packing; its own `window` indexes the packed rows)."""
+        if pack is not None:
+            window = pack['window']
+            mm = dict(mm, pack=pack)
         for k in ('row_idx', 'labels', 'inv_map'):      # a host-side plan handed to the kernels would be a wild device pointer
             if window[k].device.type != self.device.type:
                 raise RuntimeError(f'response_logprobs: window[{k!r}] lives on {window[k].device}, the model on {self.device}')
@@ -737,13 +755,19 @@ class NativeLlava(NativeCausalLM):
         return self.vision.forward(pixel_values)
 
     def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
-                       position_ids=None, kv_sink=None, kv_len=None):
-        """kv_len (int32 [N], optional): keys at or beyond it are masked in the decoder (right padding; see LlamaStack.forward)."""
+                       position_ids=None, kv_sink=None, kv_len=None, pack=None):
+        """kv_len (int32 [N], optional): keys at or beyond it are masked in the decoder (right padding; see LlamaStack.forward).
+        pack: shared-prompt packing plan (trainers.common.build_pack_plan): token ids / positions / image features are per PACKED row -- one set of image
+        features per pair."""
         N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask, position_ids)
         self.stack.kv_len = kv_len
         P = self.store.p
         ids = input_ids.reshape(-1)
-        if Mp != N * T:
+        if pack is not None:
+            if position_ids is not None or kv_sink is not None:
+                raise RuntimeError('shared-prompt packing is a training-forward layout (no explicit position ids, no KV-cache prefill)')
+            ids, pos = pack['ids'], pack['pos']
+        elif Mp != N * T:
             ids = torch.cat([ids, torch.zeros(Mp - N * T, dtype=ids.dtype, device=ids.device)])
         slot = feat = f1 = a1 = vfeat = None
         if pixel_values is not None or image_features is not None:
@@ -759,8 +783,8 @@ class NativeLlava(NativeCausalLM):
             self._last_feature_rows = n_feat
         x = ops.embed_fwd(ids, P[self.embed], slot, feat)
         if save:
-            self._ctx = dict(ids=ids, slot=slot, f1=f1, a1=a1, vfeat=vfeat, N=N, T=T, start=start, pos=pos)
-        return self.stack.forward(x, N, T, start, pos, save, kv_sink)
+            self._ctx = dict(ids=ids, slot=slot, f1=f1, a1=a1, vfeat=vfeat, N=N, T=T, start=start, pos=pos if pack is None else pack['pos_full'], pack=pack)
+        return self.stack.forward(x, N, T, start, pos, save, kv_sink, pack=pack)
 
     def embed_tokens(self, ids, pos=None):
         return ops.embed_fwd(ids, self.store.p[self.embed])
@@ -774,7 +798,7 @@ class NativeLlava(NativeCausalLM):
 
     def backward_stream(self, dres, on_layer_done=None):
         cx = self._ctx
-        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done)
+        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done, pack=cx.get('pack'))
         G = self.store.g
         tower = self.train_tower and self.vision._ctx is not None
         want_feat = cx['slot'] is not None and (self.train_proj or tower)
@@ -1742,22 +1766,27 @@ class NativeLlama(NativeCausalLM):
         return sd
 
     def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
-                       position_ids=None, kv_sink=None):
+                       position_ids=None, kv_sink=None, pack=None):
+        """pack: shared-prompt packing plan (trainers.common.build_pack_plan), as in NativeLlava.forward_stream."""
         N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask, position_ids)
         ids = input_ids.reshape(-1)
-        if Mp != N * T:
+        if pack is not None:
+            if position_ids is not None or kv_sink is not None:
+                raise RuntimeError('shared-prompt packing is a training-forward layout (no explicit position ids, no KV-cache prefill)')
+            ids, pos = pack['ids'], pack['pos']
+        elif Mp != N * T:
             ids = torch.cat([ids, torch.zeros(Mp - N * T, dtype=ids.dtype, device=ids.device)])
         x = ops.embed_fwd(ids, self.store.p[self.embed])
         if save:
-            self._ctx = dict(ids=ids, N=N, T=T, start=start, pos=pos)
-        return self.stack.forward(x, N, T, start, pos, save, kv_sink)
+            self._ctx = dict(ids=ids, N=N, T=T, start=start, pos=pos if pack is None else pack['pos_full'], pack=pack)
+        return self.stack.forward(x, N, T, start, pos, save, kv_sink, pack=pack)
 
     def embed_tokens(self, ids, pos=None):
         return ops.embed_fwd(ids, self.store.p[self.embed])
 
     def backward_stream(self, dres, on_layer_done=None):
         cx = self._ctx
-        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done)
+        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done, pack=cx.get('pack'))
         if self.trainable:
             ops.embed_bwd(cx['ids'], dx, self.cfg['vocab_size'], dE=self.store.g[self.embed])
 

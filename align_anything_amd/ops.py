@@ -623,6 +623,16 @@ def moe_gather(x, src_row):
     return out
 
 
+def gather2_add(x, row_a, row_b):
+    """out[r] = x[row_a[r]] + x[row_b[r]] (-1: zero row), one rounding: == add(moe_gather(x, row_a), moe_gather(x, row_b)) bit for bit, in one pass."""
+    rows_out, h = row_a.numel(), x.shape[1]
+    out = torch.empty((rows_out, h), dtype=x.dtype, device=x.device)
+    if rows_out == 0:
+        return out
+    call('aa_gather2_add' + _sfx(x, 'gather2_add'), x.data_ptr(), row_a.data_ptr(), row_b.data_ptr(), out.data_ptr(), rows_out, h, stream())
+    return out
+
+
 def moe_combine(yp, pos, w, rows, residual=None):
     k, h = pos.shape[1], yp.shape[1]
     out = torch.empty((rows, h), dtype=yp.dtype, device=yp.device)

@@ -55,6 +55,103 @@ def build_window(input_ids: torch.Tensor, response_lens, pad_token_id: int):
     return w
 
 
+def build_pack_plan(input_ids: torch.Tensor, attention_mask, window, meta_info=None):
+    """Shared-prompt packing (round 6; opt-in: train_cfgs.share_prompt_prefix).  The chosen and the rejected row of a preference pair start with the SAME
+    tokens -- BOS, the image tokens, the prompt (datasets/text_image_to_text/preference.py:132-160 formats both conversations from one prompt) -- and under a
+    causal mask the hidden states of those positions do not depend on what follows them: the reference computes them twice (rows [0, B) and [B, 2B) of
+    `model(**batch)`, trainers/text_image_to_text/dpo.py:85-105).  Here every row-wise operation of the decoder (norms, the four projections, SwiGLU,
+    residuals, embedding, lm_head window) runs on a PACKED token set -- per pair: the shared prefix once, then the rest of the chosen and of the rejected
+    sequence -- and only attention, the one operation that mixes positions, runs on the reference's [2B, T] layout, fed by a row gather of the packed
+    q | k | v and followed by a row gather back.  At T = 2048, R = 512 that is 62.5 % of the token rows: the GEMMs, 95 % of the step's FLOPs, shrink with it.
+
+    Exactness.  A packed row's value is the value the unpacked computation gives the chosen row's copy of that position (row-wise kernels do not see the
+    other rows; the attention kernel sees the reference layout) -- bit for bit in the forward pass when both rows carry the same left padding.  With
+    different response lengths the collator pads the two rows differently; HF numbers positions by slot (SURVEY 8(a'): `arange(T)` counts the pads), so the
+    two copies of the prefix sit at rotary positions that differ by delta = pad_r - pad_c.  The packed computation gives BOTH rows of a pair one frame, the
+    longer row's (token j of either sequence at position min(pad_c, pad_r) + j, always < T): the shorter row is evaluated delta positions to the left of where
+    HF puts it, all RELATIVE positions, hence all attention scores, are those of the reference up to the rounding of the rotary tables at another absolute
+    position (SURVEY measured 1e-7 in fp32; against the reference trainer at full depth: profiles/parity/parity_llava7b_full_depth_packed_vs_reference.txt).  In the backward pass the gradient of a shared row is the
+    sum of its two copies' gradients, formed in the activation dtype before the weight-gradient GEMM instead of inside its fp32 accumulator.
+
+    Returns None when nothing can be shared (no pair has a common prefix of >= 64 tokens).  Host integers come from `meta_info` when the collator provides
+    them (`seq_lens`, `shared_prefix_lens`: no device read); otherwise they are read from the batch (one device -> host sync per batch)."""
+    N, T = input_ids.shape
+    if N % 2:
+        return None
+    B = N // 2
+    meta_info = meta_info or {}
+    R = np.asarray([int(r) for r in meta_info['response_lens']], dtype=np.int64)
+    if 'seq_lens' in meta_info:
+        lens = np.asarray([int(x) for x in meta_info['seq_lens']], dtype=np.int64)
+    elif attention_mask is None:
+        lens = np.full(N, T, dtype=np.int64)
+    else:
+        lens = attention_mask.sum(1).cpu().numpy().astype(np.int64)
+    pad = T - lens
+    if 'shared_prefix_lens' in meta_info:
+        Lp = np.asarray([int(x) for x in meta_info['shared_prefix_lens']], dtype=np.int64)
+    else:
+        ids_h = input_ids.cpu().numpy()
+        Lp = np.zeros(B, dtype=np.int64)
+        for i in range(B):
+            a, b = ids_h[i, pad[i]:], ids_h[B + i, pad[B + i]:]
+            m = min(len(a), len(b))
+            ne = np.nonzero(a[:m] != b[:m])[0]
+            Lp[i] = int(ne[0]) if len(ne) else m
+    Lp = np.minimum(Lp, np.minimum(lens[:B] - R[:B], lens[B:] - R[B:]))          # the prompt only: every response-window row stays a row of its own
+    Lp = np.where(Lp >= 64, Lp, 0)
+    if not Lp.any():
+        return None
+    Mp = (N * T + 63) // 64 * 64
+    slot2row = np.full(Mp, -1, dtype=np.int32)          # full slot (n, t) -> packed row (-1: a pad slot)
+    owner = np.full(Mp, -1, dtype=np.int32)             # ... only where that slot OWNS the row (the rejected copy of a shared prefix does not)
+    rows = int((lens[:B] + lens[B:] - Lp).sum())
+    Mq = (rows + 63) // 64 * 64
+    row2slot = np.full(Mq, -1, dtype=np.int32)          # packed row -> owning slot
+    row2slot_b = np.full(Mq, -1, dtype=np.int32)        # packed row -> the second slot that holds a copy of it (shared prefix rows), else -1
+    pos = np.zeros(Mq, dtype=np.int32)
+    r0 = 0
+    for i in range(B):
+        c, rj = i, B + i
+        lp, lc, lr = int(Lp[i]), int(lens[c]), int(lens[rj])
+        sc = c * T + pad[c] + np.arange(lc)              # chosen row: slots of its tokens
+        sr = rj * T + pad[rj] + np.arange(lr)
+        rows_c = r0 + np.arange(lc)                      # prefix + chosen remainder, in sequence order
+        rows_r = np.concatenate([r0 + np.arange(lp), r0 + lc + np.arange(lr - lp)])
+        slot2row[sc] = rows_c; owner[sc] = rows_c
+        slot2row[sr] = rows_r; owner[sr[lp:]] = rows_r[lp:]
+        row2slot[rows_c] = sc
+        row2slot[rows_r[lp:]] = sr[lp:]
+        row2slot_b[rows_r[:lp]] = sr[:lp]
+        f0 = min(pad[c], pad[rj])                        # HF: position = slot index within the row.  The pair's frame is the LONGER row's (smaller left pad):
+        pos[rows_c] = f0 + np.arange(lc)                 # that row keeps its own positions, the other moves by |pad_r - pad_c|, and every position stays < T
+        pos[rows_r[lp:]] = f0 + lp + np.arange(lr - lp)
+        r0 += lc + lr - lp
+    assert r0 == rows
+    dev = input_ids.device
+    up = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
+    s2r = up(slot2row)
+    plan = {'N': N, 'T': T, 'Mq': Mq, 'rows': rows, 'full_rows': N * T, 'slot2row': s2r, 'owner': up(owner), 'row2slot': up(row2slot),
+            'row2slot_b': up(row2slot_b), 'pos': up(pos), 'shared_rows': int(Lp.sum()), 'prefix_lens': Lp.tolist()}
+    # packed token ids (pad rows: id 0, never an image token) and rotary positions of the FULL layout in the packed frame (the attention backward's epilogue)
+    ids_full = input_ids.reshape(-1)
+    r2s = plan['row2slot'].long().clamp(min=0)
+    plan['ids'] = torch.where(plan['row2slot'] >= 0, ids_full[r2s.clamp(max=N * T - 1)], torch.zeros_like(ids_full[:1]))
+    plan['pos_full'] = torch.where(s2r >= 0, plan['pos'][s2r.long().clamp(min=0)], torch.zeros_like(plan['pos'][:1]))
+    # the response window in packed rows
+    w = dict(window)
+    ri = window['row_idx']
+    w['row_idx'] = s2r[ri].long().clamp(min=0)
+    inv = np.full(Mq, -1, dtype=np.int32)
+    plan['_inv_host'] = inv          # filled on the device below (row_idx lives there)
+    inv_t = torch.full((Mq,), -1, dtype=torch.int32, device=dev)
+    inv_t[w['row_idx'][:window['rows']]] = torch.arange(window['rows'], dtype=torch.int32, device=dev)
+    w['inv_map'] = inv_t
+    plan['window'] = w
+    del plan['_inv_host']
+    return plan
+
+
 def flat_to_padded(flat_logp: torch.Tensor, w) -> torch.Tensor:
     """pad_sequence(..., padding_value=0.0) layout of dpo.py:140-142: [N, max(R)-1], right padded with 0."""
     L = max(w['max_len'], 1)

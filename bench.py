@@ -72,7 +72,9 @@ def make_batch(cfg, B, T, R, device, seed):
     pix = torch.randn(B, 3, S, S, generator=g)
     return {
         'input_ids': ids.to(device), 'attention_mask': torch.ones(N, T, dtype=torch.long, device=device),
-        'pixel_values': torch.cat([pix, pix], 0).to(device), 'meta_info': {'response_lens': [R] * N},
+        'pixel_values': torch.cat([pix, pix], 0).to(device),
+        # host integers a collator knows anyway (no padding here; the pair shares its prompt): read by the opt-in shared-prompt packing, ignored otherwise
+        'meta_info': {'response_lens': [R] * N, 'seq_lens': [T] * N, 'shared_prefix_lens': [T - R] * B},
     }
 
 
@@ -209,6 +211,9 @@ def main():
     ap.add_argument('--layers', type=int, default=32, help='LLM depth (32 = LLaVA-1.5-7B; anything else is NOT the headline config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-events', action='store_true')
+    ap.add_argument('--share-prompt', action='store_true',
+                    help='run the TIMED steps with shared-prompt packing (train_cfgs.share_prompt_prefix: a pair\'s common prefix once per model).  Off by default: the '
+                         'headline keeps the reference\'s row-per-sequence layout; the packed step is always measured after the timed region and reported as `shared_prompt`')
     ap.add_argument('--gemm-event-stride', type=int, default=11,
                     help='time every k-th GEMM launch of the timed steps with a HIP event pair (1 = all).  An event pair isolates its launch from '
                          'its neighbours (no tail / head overlap with the next kernel): around EVERY launch that costs the one-wave-per-SIMD '
@@ -315,8 +320,8 @@ def main():
     B, T, R = args.pairs_per_gpu, args.seq_len, args.response_len
     cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-6, 'lr_warmup_ratio': 0.03, 'weight_decay': 0.0,
                            'adam_betas': [0.9, 0.95], 'lr_scheduler_type': 'cosine',
-                           'total_training_steps': args.steps + args.warmup + 16, 'freeze_mm_proj': False,
-                           'freeze_language_model': False, 'freeze_vision_tower': True},
+                           'total_training_steps': args.steps + args.warmup + 32, 'freeze_mm_proj': False,
+                           'freeze_language_model': False, 'freeze_vision_tower': True, 'share_prompt_prefix': bool(args.share_prompt)},
             'model_cfgs': {'pad_token_id': cfg['pad_token_id']}}
     tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, device=device)
     random_init_(tr.policy, seed=42)
@@ -451,6 +456,33 @@ def main():
             per_batch[f'B{b2}'] = {'pairs_per_gpu_step': b2, 'value': b2 / d1, 'unit': 'pairs/s', 'ms_per_step': d1 * 1e3, 'steps': 3, 'warmup': 1}
             del bb
 
+    # N=1, outside the timed region: the same step with shared-prompt packing (opt-in train_cfgs.share_prompt_prefix; trainers/common.py::build_pack_plan): the
+    # pair's common prefix -- 1536 of 2048 positions here -- is computed once per model.  Reported beside the headline, never as it (unless --share-prompt).
+    shared_prompt = None
+    if world == 1 and not args.no_per_batch and not in_pmc_child:
+        was = tr.share_prompt_prefix
+        tr.share_prompt_prefix = not was
+        ops.GEMM_PROF = None
+        f0 = dict(ops.FLOPS)
+        bb = [make_batch(cfg, B, T, R, device, seed=555 + i) for i in range(5)]
+        tr.train_step(bb[0])
+        torch.cuda.synchronize()
+        ops.FLOPS['gemm'] = ops.FLOPS['attn'] = 0.0
+        t1 = time.perf_counter()
+        for i in range(1, 5):
+            last_sp = tr.train_step(bb[i])
+        torch.cuda.synchronize()
+        d1 = (time.perf_counter() - t1) / 4
+        plan = bb[1].get('_pack')
+        shared_prompt = {'share_prompt_prefix': not was, 'value': B / d1, 'unit': 'pairs/s', 'ms_per_step': d1 * 1e3, 'steps': 4, 'warmup': 1,
+                         'token_rows_per_step': plan['rows'] if plan else 2 * B * T, 'token_rows_reference_layout': 2 * B * T,
+                         'executed_tflop_per_pair': (ops.FLOPS['gemm'] + ops.FLOPS['attn']) / (4 * B) / 1e12, 'loss_last_step': round(last_sp['train/loss'], 5),
+                         'note': 'the same DPO step, the same losses up to rounding (tests/test_pack_gpu.py; against the reference trainer at full depth: '
+                                 'tests/test_secondary_geometry_gpu.py); fewer FLOPs are EXECUTED per pair -- utilisation figures must use executed_tflop_per_pair'}
+        tr.share_prompt_prefix = was
+        ops.FLOPS.update(f0)
+        del bb
+
     if rank == 0:
         n_img = (cfg['vision']['image_size'] // cfg['vision']['patch_size']) ** 2
         fl_pair, _ = flops_per_pair(cfg, T, R, n_img)
@@ -467,7 +499,7 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: LLaVA-1.5-7B DPO, bf16, 336px/576 patches, seq_len={T}, response={R}, '
                                    f'{B} pairs/GPU/step, CLIP tower + policy+ref fwd, bwd, clip, AdamW; a fresh batch every step'
-                                   + ('' if args.layers == 32 else f' [REDUCED DEPTH {args.layers}]')
+                                   + (' [shared-prompt packing ON: --share-prompt]' if args.share_prompt else '') + ('' if args.layers == 32 else f' [REDUCED DEPTH {args.layers}]')
                                    + (' [FUNCTIONAL CHECK: ranks share one device, gloo]' if one_device or backend != 'nccl' else ''),
                        'global_batch_pairs': B * world, 'seq_len': T, 'parallelism': f'dp{world}',
                        'shapes': {'hidden': cfg['text']['hidden_size'], 'heads': cfg['text']['num_heads'], 'head_dim': cfg['text']['head_dim'],
@@ -617,6 +649,9 @@ def main():
                                  f'{B} in the yaml (activations for {B} pairs fit the 288 GB of one MI355X without recomputation; longer GEMM M = fewer partial tile '
                                  f'rounds, one AdamW per {B} pairs).  B1 / B2 = the same step at the yaml default micro-batch and at 2, measured after the timed region.')
             out['per_batch'] = per_batch
+        if shared_prompt:
+            shared_prompt['frac_of_mfma_peak_on_executed_flops'] = shared_prompt['executed_tflop_per_pair'] * shared_prompt['value'] / PEAK_BF16_TFLOPS
+            out['shared_prompt'] = shared_prompt
         if ops.GLU_BWD_PROBE_LOG:
             out['glu_bwd_plan'] = [{'M': m, 'F': f, 'K': k, 'fused_ms': round(a, 4), 'unfused_ms': round(b, 4), 'chosen': 'fused' if a <= b else 'unfused'}
                                    for m, f, k, a, b in ops.GLU_BWD_PROBE_LOG]

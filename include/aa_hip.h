@@ -243,6 +243,10 @@ int aa_moe_route(const void* logits, long ld, long rows, int E, int k, int norm_
 int aa_moe_route_bwd(const float* probs, const int* idx, const float* dweights, long rows, int E, int k, int norm_topk,
                      void* dlogits, long ld, void* stream);
 int aa_moe_gather(const void* x, const int* src_row, void* out, long rows_out, int h, void* stream);
+/* out[r] = x[row_a[r]] + x[row_b[r]] (an index of -1 contributes a zero row; one rounding of the sum): the pack-reduce of shared-prompt packing -- the
+ * gradient of a token row that the reference layout holds twice (the common prompt of a preference pair, rows [0, B) and [B, 2B) of
+ * trainers/text_image_to_text/dpo.py:85-105) is the sum over its copies.  Bit-identical to aa_moe_gather x 2 + aa_add. */
+int aa_gather2_add(const void* x, const int* row_a, const int* row_b, void* out, long rows_out, int h, void* stream);
 int aa_moe_combine(const void* yp, const int* pos, const void* weights, const void* residual, void* out, long rows, int k, int h,
                    void* stream);
 /* dyp rows no (token, slot) pair maps to carry no gradient: src_row (aa_moe_plan's row -> token table, -1 = pad) + cap_rows make the launch zero them;

@@ -98,6 +98,7 @@ int aa_moe_route_f32(const void* logits, long ld, long rows, int E, int k, int n
 int aa_moe_route_bwd_f32(const float* probs, const int* idx, const float* dweights, long rows, int E, int k, int norm_topk,
                          void* dlogits, long ld, void* stream);
 int aa_moe_gather_f32(const void* x, const int* src_row, void* out, long rows_out, int h, void* stream);
+int aa_gather2_add_f32(const void* x, const int* row_a, const int* row_b, void* out, long rows_out, int h, void* stream);
 int aa_moe_combine_f32(const void* yp, const int* pos, const void* weights, const void* residual, void* out, long rows, int k, int h,
                        void* stream);
 int aa_moe_combine_bwd_f32(const void* dout, const void* yp, const int* pos, const void* weights, void* dyp, float* dweights,

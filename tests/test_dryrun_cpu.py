@@ -93,6 +93,55 @@ def test_llava_and_moe_dpo_steps(launches):
         assert k in launches, k
 
 
+def test_llava_dpo_step_with_shared_prompt_packing_host_flow(launches):
+    """train_cfgs.share_prompt_prefix: the host flow of a packed DPO step on CPU tensors (launches recorded): the plan is built from the batch, every row-wise
+    kernel is handed the PACKED row count, attention the reference layout between two row gathers, and the backward gathers / sums the copies."""
+    from align_anything_amd import ops
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    z = load_golden('llava_tiny_dpo.npz')
+    g = torch.Generator().manual_seed(0)
+    B, Tn, P, Rc, Rr = 2, 192, (100, 120), (40, 30), (64, 30)
+    ids = torch.full((2 * B, Tn), 301, dtype=torch.long)
+    mask = torch.zeros_like(ids)
+    for i in range(B):
+        prompt = torch.cat([torch.tensor([1]), torch.full((4,), 300), torch.randint(3, 299, (P[i] - 5,), generator=g)])
+        for row, R in ((i, Rc[i]), (B + i, Rr[i])):
+            seq = torch.cat([prompt, torch.randint(3, 299, (R,), generator=g)])
+            ids[row, Tn - len(seq):] = seq
+            mask[row, Tn - len(seq):] = 1
+    pix = torch.randn(B, 3, 28, 28, generator=g)
+    batch = {'input_ids': ids, 'attention_mask': mask, 'pixel_values': torch.cat([pix, pix], 0), 'meta_info': {'response_lens': list(Rc) + list(Rr)}}
+    tr = DPOTrainer(_cfgs(z, share_prompt_prefix=True), {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                    reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cpu')
+    rows = []
+    real_gather = ops.moe_gather
+    ops_gemm = ops.gemm
+
+    def gemm(a, b, out=None, **kw):
+        rows.append(a.shape[1] if kw.get('a_t') else a.shape[0])
+        return ops_gemm(a, b, out=out, **kw)
+    ops.gemm = gemm
+    try:
+        info = tr.train_step(batch)
+    finally:
+        ops.gemm = ops_gemm
+    assert real_gather is ops.moe_gather and np.isfinite(info['train/lr'])
+    plan = batch['_pack']
+    tokens = int(mask.sum())
+    assert plan is not None and plan['prefix_lens'] == [100, 120] and plan['rows'] == tokens - 220 and plan['Mq'] % 64 == 0
+    # 2 layers x (qkv gather + attention-output gather) per forward, policy + reference; per layer the backward gathers d_attn and sums the copies of d_qkv
+    assert launches.count('aa_moe_gather') == 2 * 2 * 2 + 2 and launches.count('aa_gather2_add') == 2
+    assert plan['Mq'] in rows and 2 * B * Tn not in rows          # the projections ran on the packed rows, none on the reference layout
+    assert 'aa_attn_fwd' in launches and 'aa_attn_bwd_rope' in launches and 'aa_dpo_loss_fwd_bwd' in launches
+    # off by default: the same batch without the switch takes the reference layout
+    tr0 = DPOTrainer(_cfgs(z), {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                     reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cpu')
+    b0 = {k: v for k, v in batch.items() if not k.startswith('_')}
+    del launches[:]
+    tr0.train_step(b0)
+    assert b0.get('_pack') is None and 'aa_moe_gather' not in launches
+
+
 def test_supervised_step_and_prefetched_window(launches):
     from align_anything_amd.data import DevicePrefetcher
     from align_anything_amd.trainers.sft import SupervisedTrainer

@@ -1,0 +1,133 @@
+"""GPU: shared-prompt packing (trainers.common.build_pack_plan, train_cfgs.share_prompt_prefix) against the unpacked computation of the same trainer.
+The reference (trainers/text_image_to_text/dpo.py:85-105) runs every row of the [2B, T] batch through the model; the packed path runs a pair's common
+prefix once.  Claims: (1) with equal left padding the packed forward is BIT-IDENTICAL (row-wise kernels never see other rows, attention sees the
+reference layout); (2) with ragged pairs the rejected row is evaluated in the chosen row's rotary frame -- equal up to the rounding of the rotary tables;
+(3) gradients agree up to the rounding of the sum of a shared row's two gradient copies in the activation dtype.  The same switch is held against the
+UNMODIFIED reference trainer at full depth in tests/test_secondary_geometry_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import dev, dump
+from tests.util import load_golden, rel_err, state_dict_from_golden, tiny_llava_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair_batch(B, T, prompt_lens, resp_c, resp_r, seed=0, image_tokens=4):
+    g = torch.Generator().manual_seed(seed)
+    N = 2 * B
+    ids = torch.full((N, T), 301, dtype=torch.long)
+    mask = torch.zeros((N, T), dtype=torch.long)
+    for i in range(B):
+        prompt = torch.cat([torch.tensor([1]), torch.full((image_tokens,), 300, dtype=torch.long), torch.randint(3, 299, (prompt_lens[i] - 1 - image_tokens,), generator=g)])
+        for row, R in ((i, resp_c[i]), (B + i, resp_r[i])):
+            seq = torch.cat([prompt, torch.randint(3, 299, (R,), generator=g)])
+            ids[row, T - len(seq):] = seq
+            mask[row, T - len(seq):] = 1
+    pix = torch.randn(B, 3, 28, 28, generator=g)
+    return {'input_ids': ids.to(dev()), 'attention_mask': mask.to(dev()), 'pixel_values': torch.cat([pix, pix], 0).to(dev()),
+            'meta_info': {'response_lens': list(resp_c) + list(resp_r)}}
+
+
+def _run(dtype, share, batch_args):
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    z = load_golden('llava_tiny_dpo.npz')
+    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'compute_dtype': dtype,
+                           'share_prompt_prefix': share}, 'model_cfgs': {'pad_token_id': 301}}
+    tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                    reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cuda:0')
+    b = _pair_batch(*batch_args)
+    lp = tr.compute_log_probs(tr.model, b)
+    rlp = tr.compute_log_probs(tr.reference_model, b)
+    ld = tr.loss(b)
+    tr.model.backward(ld['loss'])
+    torch.cuda.synchronize()
+    st = tr.policy.store
+    grads = {n: st.grad_view(n).float().clone() for n in st.hf_names() if st.grad_view(n) is not None}
+    plan = b.get('_pack')
+    return lp.float().cpu(), rlp.float().cpu(), float(ld['loss']), grads, plan
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_packing_with_equal_padding_is_bit_identical_in_the_forward_pass(dtype):
+    args = (3, 256, (150, 100, 192), (64, 100, 40), (64, 100, 40), 1)          # chosen / rejected responses of equal length: the same left padding in both rows
+    lp0, rlp0, loss0, g0, plan0 = _run(dtype, False, args)
+    lp1, rlp1, loss1, g1, plan1 = _run(dtype, True, args)
+    assert plan0 is None and plan1 is not None and plan1['prefix_lens'] == [150, 100, 192]
+    assert plan1['rows'] == 2 * (214 + 200 + 232) - (150 + 100 + 192)
+    assert torch.equal(lp0, lp1) and torch.equal(rlp0, rlp1), float((lp0 - lp1).abs().max())
+    assert loss0 == loss1
+    worst = max(rel_err(g1[n], g0[n]) for n in g0 if float(g0[n].norm()) > 1e-6)
+    dump(f'parity_pack_equal_padding_{dtype}.txt', f'forward bit-identical; worst gradient rel_err packed vs unpacked {worst:.3e} over {len(g0)} tensors\n')
+    assert worst < (2e-2 if dtype == 'bf16' else 2e-6), worst
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_packing_of_ragged_pairs_matches_the_unpacked_computation(dtype):
+    args = (3, 256, (150, 100, 80), (64, 30, 120), (20, 100, 96), 2)           # different response lengths: different left padding, the rejected row moves into the chosen row's rotary frame
+    lp0, rlp0, loss0, g0, _ = _run(dtype, False, args)
+    lp1, rlp1, loss1, g1, plan = _run(dtype, True, args)
+    assert plan is not None and plan['prefix_lens'] == [150, 100, 80]
+    assert torch.equal(lp0 == 0, lp1 == 0)
+    e_lp = float((lp0 - lp1).abs().max())
+    worst = max(rel_err(g1[n], g0[n]) for n in g0 if float(g0[n].norm()) > 1e-6)
+    dump(f'parity_pack_ragged_{dtype}.txt', f'per-token log-probs packed vs unpacked {e_lp:.3e}; loss {abs(loss0 - loss1):.3e}; worst gradient rel_err {worst:.3e}\n')
+    if dtype == 'fp32':
+        assert e_lp < 2e-5 and abs(loss0 - loss1) < 1e-6 and worst < 1e-4, (e_lp, loss0 - loss1, worst)
+    else:
+        assert e_lp < 6e-2 and abs(loss0 - loss1) < 5e-3 and worst < 3e-2, (e_lp, loss0 - loss1, worst)
+
+
+def test_a_pair_without_a_common_prefix_keeps_the_reference_layout():
+    from align_anything_amd.trainers.common import build_pack_plan, build_window
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(3, 299, (4, 128), generator=g).to(dev())
+    w = build_window(ids, [16] * 4, 301)
+    assert build_pack_plan(ids, torch.ones_like(ids), w, {'response_lens': [16] * 4}) is None
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_gather2_add_equals_two_gathers_and_an_add(dtype):
+    from align_anything_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(300, 256, generator=g).to(dtype).to(dev())
+    a = torch.randint(-1, 300, (257,), generator=g).to(torch.int32).to(dev())
+    b = torch.randint(-1, 300, (257,), generator=g).to(torch.int32).to(dev())
+    b[::3] = -1
+    got = ops.gather2_add(x, a, b)
+    want = ops.add(ops.moe_gather(x, a), ops.moe_gather(x, b))
+    assert torch.equal(got, want)
+    assert ops.gather2_add(x, a[:0], b[:0]).shape == (0, 256)
+
+
+def test_packing_on_the_text_llama_trainer_gqa_ragged():
+    """The text-to-text DPO path (trainers/text_to_text/dpo.py on a Llama-family decoder, GQA 4 / 2): packed against unpacked on ragged pairs, fp32 twin."""
+    from align_anything_amd import configs
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    cfg = configs.llama_cfg(128, 256, 2, 4, 2, 320, rms_eps=1e-5, max_position_embeddings=256)
+    out = {}
+    for share in (False, True):
+        cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'compute_dtype': 'fp32',
+                               'share_prompt_prefix': share}, 'model_cfgs': {'pad_token_id': 301}}
+        tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, device='cuda:0')
+        g = torch.Generator().manual_seed(9)
+        for n in tr.policy.store.hf_names():
+            v = tr.policy.store.view(n)
+            w = torch.randn(tuple(v.shape), generator=g) * 0.05 + (1.0 if 'norm' in n else 0.0)
+            v.copy_(w.to(dev())); tr.reference.store.view(n).copy_((w * 1.01).to(dev()))
+        for gname in tr.policy.store.master:
+            if tr.policy.store.master[gname] is not tr.policy.store.flat[gname]:
+                tr.policy.store.master[gname].copy_(tr.policy.store.flat[gname])
+        b = _pair_batch(2, 192, (100, 70), (30, 60), (80, 20), seed=5, image_tokens=0)
+        b.pop('pixel_values')
+        lp = tr.compute_log_probs(tr.model, b).float().cpu()
+        ld = tr.loss(b)
+        tr.model.backward(ld['loss'])
+        torch.cuda.synchronize()
+        st = tr.policy.store
+        out[share] = (lp, float(ld['loss']), {n: st.grad_view(n).float().clone() for n in st.hf_names() if st.grad_view(n) is not None}, b.get('_pack'))
+    (lp0, l0, g0, p0), (lp1, l1, g1, p1) = out[False], out[True]
+    assert p0 is None and p1 is not None and p1['prefix_lens'] == [100, 70]
+    worst = max(rel_err(g1[n], g0[n]) for n in g0 if float(g0[n].norm()) > 1e-6)
+    assert float((lp0 - lp1).abs().max()) < 2e-5 and abs(l0 - l1) < 1e-6 and worst < 1e-4, (float((lp0 - lp1).abs().max()), l0 - l1, worst)

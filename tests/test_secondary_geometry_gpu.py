@@ -521,6 +521,21 @@ def test_llava7b_full_depth_pair_vs_the_reference_trainer():
                  fp32_bounds=(2e-4, 2e-4, 1e-3, 2e-3), check_vectors=True)
 
 
+def test_llava7b_full_depth_pair_with_shared_prompt_packing_vs_the_reference_trainer():
+    """The same fixture (the UNMODIFIED reference trainer at L = 32, T = 2048) with train_cfgs.share_prompt_prefix on: the pair's 1536 common positions are
+    computed once per model (2560 token rows instead of 4096).  The rejected row is left-padded by 37 more slots than the chosen one here, so this is the
+    ragged case: its tokens are evaluated in the chosen row's rotary frame.  Same bounds as the unpacked test."""
+    from oracle.synthetic import llava7b_width
+    from tests.width_parity import width_parity
+    z = load_golden('llava7b_full_depth_dpo.npz')
+    hc, sd, ref_sd, batch = llava7b_width(num_layers=int(z['num_layers']), T=int(z['T']), R=int(z['R']), left_pad=tuple(int(x) for x in z['left_pad']), lazy=True)
+    workers = min(32, os.cpu_count() or 8)
+    sd, ref_sd = sd.materialize(workers), ref_sd.materialize(workers)
+    width_parity(z, hc, sd, ref_sd, batch, 32001, 'parity_llava7b_full_depth_packed_vs_reference.txt', float_keys=('pixel_values',),
+                 min_matrices=sum(1 for n, g in zip(z['names'], z['grad_norm']) if g > 0 and 'norm' not in str(n) and not str(n).endswith('bias')),
+                 fp32_bounds=(2e-4, 2e-4, 1e-3, 2e-3), check_vectors=True, extra_train_cfgs={'share_prompt_prefix': True}, expect_packed_rows=2 * 2048 - 37 - 1536)
+
+
 def test_llava7b_width_pair_vs_the_reference_trainer():
     """a parity point at the FULL WIDTH of BASELINE configs[1] that is not HIP-vs-HIP.  The fixture
     tests/golden/llava7b_width_dpo.npz was produced by the UNMODIFIED reference trainer (trainers/text_image_to_text/dpo.py:85-166: compute_log_probs,

@@ -11,7 +11,7 @@ from tests.util import rel_err
 
 
 def width_parity(z, hf_config, sd, ref_sd, batch, pad_token_id, report, *, extra_train_cfgs=None, trainer_kwargs=None, batch_keys=(), float_keys=(),
-                 skip_norm_of=(), min_matrices=29, fp32_bounds=(2e-4, 2e-4, 1e-3, 2e-3), check_vectors=False):
+                 skip_norm_of=(), min_matrices=29, fp32_bounds=(2e-4, 2e-4, 1e-3, 2e-3), check_vectors=False, expect_packed_rows=None):
     """z: the fixture; (hf_config, sd, ref_sd, batch): the regenerated model / pair (oracle.synthetic.*_width); batch_keys: extra batch entries handed to the
     trainer as they are (grids, masks); float_keys: batch entries cast to the compute dtype (pixels, mel features); skip_norm_of: parameters whose stored
     layout differs from HF's (norm compared through the others).  fp32_bounds: loss abs, per-token log-probs abs, gradient-norm rel, leading-block rel_err.
@@ -39,6 +39,9 @@ def width_parity(z, hf_config, sd, ref_sd, batch, pad_token_id, report, *, extra
             for k in float_keys:
                 b[k] = batch[k].to(dev()).to(torch.float32 if dtype == 'fp32' else torch.bfloat16)
             lp = tr.compute_log_probs(tr.model, b).cpu()
+            if expect_packed_rows is not None:            # the shared-prompt layout was really taken
+                assert b.get('_pack') is not None and b['_pack']['rows'] == expect_packed_rows, (b.get('_pack') or {}).get('rows')
+                rep.append(f'shared-prompt packing: {b["_pack"]["rows"]} token rows instead of {int(batch["attention_mask"].sum())} ({b["_pack"]["shared_rows"]} shared)')
             rlp = tr.compute_log_probs(tr.reference_model, b).cpu()
             assert torch.equal(lp == 0, want_lp == 0), 'response-window layout differs from the reference'
             ld = tr.loss(b)

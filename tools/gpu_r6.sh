@@ -44,6 +44,14 @@ PY
         AA_HIP_LIB=$R/align_anything_amd/$v timeout 600 python bench.py --steps 8 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r06_bench_scc.json 2> gpurun_out/r06_bench_scc.err
         python -c "import json; d=json.load(open('gpurun_out/r06_bench_scc.json')); r=d['roofline']; print('$v', round(d['ms_per_step'],2), 'ms', round(d['value'],4), 'pairs/s  gemm4', round(r['achieved'],1), 'TF/s  W', round(r.get('power_w_mean') or 0), 'MHz', round(r.get('sclk_mhz_mean') or 0), 'losses', d['config'].get('losses_timed_steps', [])[-2:])" || tail -3 gpurun_out/r06_bench_scc.err
       done ;;
+    pack)            # shared-prompt packing (train_cfgs.share_prompt_prefix): packed vs unpacked, packed vs the reference trainer at full depth, then the bench line (its `shared_prompt` section)
+      timeout 600 python -m pytest tests/test_pack_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r06_pack_tests.log 2>&1; echo "rc=$?"; tail -8 gpurun_out/r06_pack_tests.log | cut -c1-300; cat gpurun_out/parity_pack_*.txt
+      if [ -z "$AA_PACK_SKIP_FULL" ]; then timeout 1500 python -m pytest tests/test_secondary_geometry_gpu.py -q -x -m gpu -p no:cacheprovider -k "shared_prompt_packing" > gpurun_out/r06_pack_full_depth.log 2>&1; echo "rc=$?"; tail -6 gpurun_out/r06_pack_full_depth.log | cut -c1-300; cut -c1-400 gpurun_out/parity_llava7b_full_depth_packed_vs_reference.txt; fi
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r06_prof_pack && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof_pack -o p -- python $R/bench.py --share-prompt --steps 4 --warmup 2 --no-cpu-baseline --no-gemm-events --traffic committed --no-per-batch --no-power > $R/gpurun_out/r06_prof_pack.log 2>&1 )
+      f=$(find gpurun_out/r06_prof_pack -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r06_dpo7b_packed_kernel_stats.csv; head -22 gpurun_out/r06_dpo7b_packed_kernel_stats.csv | cut -c1-170; tail -2 gpurun_out/r06_prof_pack.log | cut -c1-300
+      find gpurun_out/r06_prof_pack -name "*kernel_trace.csv" -delete
+      timeout 900 python bench.py --steps 8 --warmup 2 --traffic committed --no-cpu-baseline > gpurun_out/r06_bench_pack.json 2> gpurun_out/r06_bench_pack.err; echo "rc=$?"
+      python -c "import json; d=json.load(open('gpurun_out/r06_bench_pack.json')); print('headline', round(d['ms_per_step'],2), 'ms', round(d['value'],4), 'pairs/s'); print('shared_prompt', {k: (round(v,4) if isinstance(v,float) else v) for k,v in d['shared_prompt'].items() if k != 'note'}); print(d['config']['losses_timed_steps'][-2:])" || tail -5 gpurun_out/r06_bench_pack.err ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
