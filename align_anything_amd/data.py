@@ -76,6 +76,16 @@ class CachedPreferenceCollator:
                 ids[r, :n] = row; mask[r, :n] = 1
         batch = {'input_ids': _pin(ids), 'attention_mask': _pin(mask),
                  'meta_info': {'response_lens': [it['better_response_lens'] for it in items] + [it['worse_response_lens'] for it in items]}}
+        if self.padding_side == 'left':
+            # host integers for the opt-in shared-prompt packing (trainers/common.py::build_pack_plan): known here for free, a device read there
+            n = len(items)
+            shared = []
+            for a, b in zip(rows[:n], rows[n:]):
+                m = min(int(a.numel()), int(b.numel()))
+                ne = (a[:m] != b[:m]).nonzero()
+                shared.append(int(ne[0]) if ne.numel() else m)
+            batch['meta_info']['seq_lens'] = [int(r.numel()) for r in rows]
+            batch['meta_info']['shared_prefix_lens'] = shared
         if 'pixel_values' in items[0]:
             pv = torch.stack([it['pixel_values'] for it in items])
             batch['pixel_values'] = _pin(torch.cat([pv, pv], 0))      # images * 2 (preference.py:219-222)
