@@ -393,6 +393,9 @@ struct AttnParams {
     // backward only: the transpose rotary rotation of dQ / dK in the kernels' epilogues (aa_attn_bwd_rope): position of token row r = rope_pos[r],
     // cos / sin tables [., HD / 2] bf16; null = plain dQ / dK (aa_attn_bwd)
     const int* rope_pos; const bf16_t* rope_cos; const bf16_t* rope_sin;
+    // optional (shared-prompt packing): query rows below qskip[n] of sequence n have no consumer -- the caller never reads their O / lse and hands the backward
+    // dO = 0 for them.  Whole query blocks below it are not computed (forward), get dQ = 0 without being visited (dQ kernel) and are left out of the dK / dV loop
+    const int* qskip;
     int pair;            // a128 forward only: a workgroup runs the query blocks nqb - 1 - r and r (causal load balance, see attn128.inc)
 };
 
@@ -457,6 +460,7 @@ __global__ __launch_bounds__(256, AA_ATTN_QI == 2 ? 2 : 1) void attn_fwd_kernel(
     int n, h, hk, qb;
     q_block_of<AA_ATTN_XCD_LOCAL_FWD>(p, nqb, n, h, hk, qb);
     const int q0 = qb * QROWS, qw = q0 + wave * 16 * QI;
+    if (p.qskip && q0 + QROWS <= p.qskip[n]) return;
     const int T = p.T;
     const int start = p.start ? p.start[n] : 0;
     const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
@@ -667,6 +671,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
     q_block_of<true>(p, nqb, n, h, hk, qb);
     const int q0 = qb * QROWS, qw = q0 + wave * 32;
     const int T = p.T;
+    if (p.qskip && q0 + QROWS <= p.qskip[n]) {      // nobody consumes these query rows (dO = 0): dQ = 0, no visit
+        for (int i = threadIdx.x; i < QROWS * (HD / 8); i += 64 * NW) {
+            const int r = q0 + i / (HD / 8);
+            if (r < T) *reinterpret_cast<f32x4*>(p.dQ + ((long)n * T + r) * p.lddq + h * HD + (i % (HD / 8)) * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
     const int start = p.start ? p.start[n] : 0;
     const int KT = p.kvlen ? min(p.kvlen[n], p.T) : p.T;   // keys [start, KT) are attendable
     const bf16_t* Qb = p.Q + (long)n * T * p.ldq + h * HD;
@@ -874,8 +885,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnPara
 #pragma unroll
     for (int db = 0; db < DB; ++db) { dkacc[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    const int q_begin = p.causal ? (kv0 / 64) * 64 : 0;
-    const int ntq = (T - q_begin + 63) / 64;
+    int q_begin = p.causal ? (kv0 / 64) * 64 : 0;
+    if (p.qskip) q_begin = max(q_begin, (p.qskip[n] / 64) * 64);      // query tiles wholly below qskip carry dO = 0 (and unspecified lse): left out
+    const int ntq = max(0, (T - q_begin + 63) / 64);
     const int total = ntq * group;  // iteration = (head in group, q tile)
     const bool kv_valid_block = kv0 + KVB - 1 >= start;  // some key of this block can be attended
 
@@ -1017,16 +1029,16 @@ extern "C" int aa_attn_set_impl(int impl) {
 }
 static bool attn128_enabled() { return (attn_impl() & 1) != 0; }
 
-extern "C" int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse,
-                           const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, int N, int T,
-                           int H, int Hkv, int hd, int causal, float scale, void* stream) {
+static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, float* lse,
+                         const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, int N, int T,
+                         int H, int Hkv, int hd, int causal, float scale, const int* q_skip, void* stream) {
     int rc = check_common("aa_attn_fwd", N, T, H, Hkv, hd);
     if (rc) return rc;
     AA_REQUIRE((ldq | ldk | ldv | ldo) % 8 == 0, "aa_attn_fwd: leading dims must be multiples of 8");
     AttnParams p{};
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O;
     p.lse = lse; p.start = start; p.kvlen = kv_len; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
-    p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
+    p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal; p.scale = scale; p.qskip = q_skip;
     dim3 grid(aa_cdiv(T, 64 * AA_ATTN_QI) * H * N);
     const int lds = 4 * 64 * hd * 2;
     if (hd == 128 && attn128_enabled()) {
@@ -1045,11 +1057,25 @@ extern "C" int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O,
     return AA_OK;
 }
 
+extern "C" int aa_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse,
+                           const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, int N, int T,
+                           int H, int Hkv, int hd, int causal, float scale, void* stream) {
+    return attn_fwd_impl(Q, K, V, O, lse, start, kv_len, ldq, ldk, ldv, ldo, N, T, H, Hkv, hd, causal, scale, nullptr, stream);
+}
+// aa_attn_fwd with q_skip[N]: query rows below q_skip[n] have no consumer (shared-prompt packing: the rejected row's copy of the pair's common prefix) -- whole
+// query blocks below it are not computed and their O / lse rows stay unwritten.
+extern "C" int aa_attn_fwd_qskip(const void* Q, const void* K, const void* V, void* O, float* lse,
+                                 const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, int N, int T,
+                                 int H, int Hkv, int hd, int causal, float scale, const int* q_skip, void* stream) {
+    AA_REQUIRE(q_skip != nullptr, "aa_attn_fwd_qskip: q_skip is required (aa_attn_fwd is the form without it)");
+    return attn_fwd_impl(Q, K, V, O, lse, start, kv_len, ldq, ldk, ldv, ldo, N, T, H, Hkv, hd, causal, scale, q_skip, stream);
+}
+
 static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO,
                          const float* lse, float* delta, void* dQ, void* dK, void* dV,
                          const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo,
                          long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
-                         int causal, float scale, const int* rope_pos, const void* rope_cos, const void* rope_sin, void* stream) {
+                         int causal, float scale, const int* rope_pos, const void* rope_cos, const void* rope_sin, void* stream, const int* q_skip = nullptr) {
     int rc = check_common("aa_attn_bwd", N, T, H, Hkv, hd);
     if (rc) return rc;
     AA_REQUIRE((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) % 8 == 0,
@@ -1060,7 +1086,7 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
     p.lse = const_cast<float*>(lse); p.delta = delta; p.start = start; p.kvlen = kv_len;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.N = N; p.T = T; p.H = H; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
-    p.rope_pos = rope_pos; p.rope_cos = (const bf16_t*)rope_cos; p.rope_sin = (const bf16_t*)rope_sin;
+    p.rope_pos = rope_pos; p.rope_cos = (const bf16_t*)rope_cos; p.rope_sin = (const bf16_t*)rope_sin; p.qskip = q_skip;
     hipStream_t st = (hipStream_t)stream;
     const long groups = (long)N * T * H;
     const int lds = 4 * 64 * hd * 2;
@@ -1105,4 +1131,17 @@ extern "C" int aa_attn_bwd_rope(const void* Q, const void* K, const void* V, con
     return attn_bwd_impl(Q, K, V, O, dO, lse, delta, dQ, dK, dV, start, kv_len, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, N, T, H, Hkv, hd, causal, scale,
                          pos, cos_t, sin_t, stream);
 }
-
+// aa_attn_bwd / aa_attn_bwd_rope (pos / cos_t / sin_t all NULL or all given) with q_skip[N] as in aa_attn_fwd_qskip: the caller guarantees dO = 0 for the
+// query rows below q_skip[n]; whole query blocks below it get dQ = 0 without being visited and are left out of the dK / dV accumulation.
+extern "C" int aa_attn_bwd_qskip(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                                 const float* lse, float* delta, void* dQ, void* dK, void* dV,
+                                 const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo,
+                                 long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
+                                 int causal, float scale, const int* pos, const void* cos_t, const void* sin_t, const int* q_skip, void* stream) {
+    AA_REQUIRE(q_skip != nullptr, "aa_attn_bwd_qskip: q_skip is required");
+    AA_REQUIRE((pos == nullptr) == (cos_t == nullptr) && (pos == nullptr) == (sin_t == nullptr), "aa_attn_bwd_qskip: pos / cos_t / sin_t together or not at all");
+    AA_REQUIRE(pos == nullptr || ((((uintptr_t)cos_t | (uintptr_t)sin_t) & 15) == 0), "aa_attn_bwd_qskip: tables must be 16-byte aligned");
+    AA_REQUIRE(AA_ATTN_DELTA_IN_DQ, "aa_attn_bwd_qskip: built without the in-kernel delta");
+    return attn_bwd_impl(Q, K, V, O, dO, lse, delta, dQ, dK, dV, start, kv_len, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, N, T, H, Hkv, hd, causal, scale,
+                         pos, cos_t, sin_t, stream, q_skip);
+}

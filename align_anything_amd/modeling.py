@@ -162,7 +162,7 @@ class LlamaStack:
             if pack is not None:
                 qkv = ops.moe_gather(qkv, pack['slot2row'])          # the reference layout (pad slots: zero rows); kept for the backward instead of the packed rows
                 attn_full, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True, hd ** -0.5, start,
-                                              out=self._attn_out(qkv, N * T, H * hd), kv_len=kv_len)
+                                              out=self._attn_out(qkv, N * T, H * hd), kv_len=kv_len, q_skip=pack.get('qskip'), work_frac=pack.get('attn_frac', 1.0))
                 attn = ops.moe_gather(attn_full, pack['row2slot'])
             else:
                 attn, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
@@ -295,7 +295,8 @@ class LlamaStack:
             ops.attn_bwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], attn_full, d_attn, lse,
                          d_qkv[:, :qw], d_qkv[:, qw:qw + kw], d_qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
                          hd ** -0.5, start, kv_len=getattr(self, '_kv_len_saved', None),
-                         rope=(pos, self._rope[0], self._rope[1]) if fuse_rope else None)
+                         rope=(pos, self._rope[0], self._rope[1]) if fuse_rope else None, q_skip=pack.get('qskip') if pack is not None else None,
+                         work_frac=pack.get('attn_frac', 1.0) if pack is not None else 1.0)
             if not fuse_rope:
                 ops.rope_(d_qkv, 0, H + Hkv, hd, pos, self._rope[0], self._rope[1], inverse=True)
             if pack is not None:                                      # a shared row's gradient = the sum over its two copies (q of the second copy is exactly 0)

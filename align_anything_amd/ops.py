@@ -655,24 +655,29 @@ def moe_combine_bwd(dout, yp, pos, w, src=None):
 
 
 # ------------------------------------------------------------------ attention
-def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None, kv_len=None):
-    """q/k/v: 2-D views [N*T, >=H*hd] (column slices of the fused qkv buffer are fine)."""
+def attn_fwd(q, k, v, N, T, H, Hkv, hd, causal, scale, start=None, out=None, kv_len=None, q_skip=None, work_frac=1.0):
+    """q/k/v: 2-D views [N*T, >=H*hd] (column slices of the fused qkv buffer are fine).
+    q_skip (int32 [N], bf16 only): query rows below it have no consumer (aa_attn_fwd_qskip) -- their O / lse rows may stay unwritten."""
     out = torch.empty((N * T, H * hd), dtype=q.dtype, device=q.device) if out is None else out
     lse = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
-    fl = 4.0 * N * H * T * T * hd * (0.5 if causal else 1.0)
+    fl = 4.0 * N * H * T * T * hd * (0.5 if causal else 1.0) * work_frac      # work_frac: the share of the causal triangle a q_skip leaves (host arithmetic of the plan)
     FLOPS['attn'] += fl
     tok = _kprof_begin('attn_fwd' if (hd == 128 and causal) else 'attn_fwd_other')
-    call('aa_attn_fwd' + _sfx(q, 'attn_fwd'), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(start), _p(kv_len),
-         q.stride(0), k.stride(0), v.stride(0), out.stride(0), N, T, H, Hkv, hd, int(causal), float(scale), stream())
+    if q_skip is not None and q.dtype == bf16:
+        call('aa_attn_fwd_qskip', q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(start), _p(kv_len),
+             q.stride(0), k.stride(0), v.stride(0), out.stride(0), N, T, H, Hkv, hd, int(causal), float(scale), q_skip.data_ptr(), stream())
+    else:
+        call('aa_attn_fwd' + _sfx(q, 'attn_fwd'), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(start), _p(kv_len),
+             q.stride(0), k.stride(0), v.stride(0), out.stride(0), N, T, H, Hkv, hd, int(causal), float(scale), stream())
     _kprof_end(tok, q.element_size() * N * T * hd * (2 * H + 2 * Hkv) + 4 * N * H * T, fl)
     return out, lse
 
 
-def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start=None, kv_len=None, rope=None):
+def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, start=None, kv_len=None, rope=None, q_skip=None, work_frac=1.0):
     """rope = (pos int32 [rows], cos_t, sin_t bf16 [., hd / 2]): dq and dk leave the kernels already rotated back (the backward of the rotary embedding
     of the forward, `rope_(..., inverse=True)`), bf16 only -- bit-identical to the separate launch."""
     delta = torch.empty((N, H, T), dtype=torch.float32, device=q.device)
-    fl = 10.0 * N * H * T * T * hd * (0.5 if causal else 1.0)       # the five matmuls of the algorithm (S, dP, dV, dK, dQ)
+    fl = 10.0 * N * H * T * T * hd * (0.5 if causal else 1.0) * work_frac       # the five matmuls of the algorithm (S, dP, dV, dK, dQ)
     FLOPS['attn'] += fl
     tok = _kprof_begin('attn_bwd' if (hd == 128 and causal) else 'attn_bwd_other')
     args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
@@ -682,6 +687,10 @@ def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, N, T, H, Hkv, hd, causal, scale, s
         pos, cos_t, sin_t = rope
         if q.dtype != bf16 or cos_t.dtype != bf16 or pos.dtype != torch.int32 or pos.numel() < N * T:
             raise RuntimeError('attn_bwd(rope=): bf16 activations and tables, int32 positions for every token row')
+    if q_skip is not None and q.dtype == bf16:       # (the caller's do is zero on the skipped query rows)
+        r3 = (None, None, None) if rope is None else (rope[0].data_ptr(), rope[1].data_ptr(), rope[2].data_ptr())
+        call('aa_attn_bwd_qskip', *args, *r3, q_skip.data_ptr(), stream())
+    elif rope is not None:
         call('aa_attn_bwd_rope', *args, pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), stream())
     else:
         call('aa_attn_bwd' + _sfx(q, 'attn_bwd'), *args, stream())

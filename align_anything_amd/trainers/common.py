@@ -110,6 +110,7 @@ def build_pack_plan(input_ids: torch.Tensor, attention_mask, window, meta_info=N
     row2slot = np.full(Mq, -1, dtype=np.int32)          # packed row -> owning slot
     row2slot_b = np.full(Mq, -1, dtype=np.int32)        # packed row -> the second slot that holds a copy of it (shared prefix rows), else -1
     pos = np.zeros(Mq, dtype=np.int32)
+    qskip = np.zeros(N, dtype=np.int32)                # per row of the reference layout: first query slot anyone consumes (attention skips whole blocks below)
     r0 = 0
     for i in range(B):
         c, rj = i, B + i
@@ -123,6 +124,7 @@ def build_pack_plan(input_ids: torch.Tensor, attention_mask, window, meta_info=N
         row2slot[rows_c] = sc
         row2slot[rows_r[lp:]] = sr[lp:]
         row2slot_b[rows_r[:lp]] = sr[:lp]
+        qskip[rj] = pad[rj] + lp                         # the rejected row's copy of the prefix: its outputs are taken from the chosen row
         f0 = min(pad[c], pad[rj])                        # HF: position = slot index within the row.  The pair's frame is the LONGER row's (smaller left pad):
         pos[rows_c] = f0 + np.arange(lc)                 # that row keeps its own positions, the other moves by |pad_r - pad_c|, and every position stays < T
         pos[rows_r[lp:]] = f0 + lp + np.arange(lr - lp)
@@ -131,8 +133,10 @@ def build_pack_plan(input_ids: torch.Tensor, attention_mask, window, meta_info=N
     dev = input_ids.device
     up = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
     s2r = up(slot2row)
+    skipped = (qskip // 256 * 256).astype(np.float64)      # whole 256-row query blocks below qskip: the part of the causal triangle attention leaves out
+    attn_frac = float(1.0 - (skipped ** 2).sum() / (N * float(T) ** 2))
     plan = {'N': N, 'T': T, 'Mq': Mq, 'rows': rows, 'full_rows': N * T, 'slot2row': s2r, 'owner': up(owner), 'row2slot': up(row2slot),
-            'row2slot_b': up(row2slot_b), 'pos': up(pos), 'shared_rows': int(Lp.sum()), 'prefix_lens': Lp.tolist()}
+            'row2slot_b': up(row2slot_b), 'pos': up(pos), 'qskip': up(qskip), 'attn_frac': attn_frac, 'shared_rows': int(Lp.sum()), 'prefix_lens': Lp.tolist()}
     # packed token ids (pad rows: id 0, never an image token) and rotary positions of the FULL layout in the packed frame (the attention backward's epilogue)
     ids_full = input_ids.reshape(-1)
     r2s = plan['row2slot'].long().clamp(min=0)

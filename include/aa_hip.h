@@ -295,6 +295,19 @@ int aa_attn_bwd_rope(const void* Q, const void* K, const void* V, const void* O,
                      long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
                      int causal, float scale, const int* pos, const void* cos_t, const void* sin_t, void* stream);
 
+/* aa_attn_fwd / aa_attn_bwd(_rope) with q_skip[N] (shared-prompt packing, trainers/common.py::build_pack_plan): query rows below q_skip[n] of sequence n have
+ * no consumer -- the rejected row's copy of the pair's common prefix, whose outputs the packed layout takes from the chosen row.  Whole query blocks below it
+ * are not computed (O / lse rows stay unwritten), get dQ = 0 and are left out of the dK / dV accumulation; the caller hands dO = 0 for those rows.  pos / cos_t /
+ * sin_t of the backward: all NULL (aa_attn_bwd) or all given (aa_attn_bwd_rope).  bf16 only.  Same reference call site as aa_attn_fwd. */
+int aa_attn_fwd_qskip(const void* Q, const void* K, const void* V, void* O, float* lse, const int* start, const int* kv_len,
+                      long ldq, long ldk, long ldv, long ldo, int N, int T, int H, int Hkv, int hd, int causal, float scale,
+                      const int* q_skip, void* stream);
+int aa_attn_bwd_qskip(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                      const float* lse, float* delta, void* dQ, void* dK, void* dV,
+                      const int* start, const int* kv_len, long ldq, long ldk, long ldv, long ldo, long lddo,
+                      long lddq, long lddk, long lddv, int N, int T, int H, int Hkv, int hd,
+                      int causal, float scale, const int* pos, const void* cos_t, const void* sin_t, const int* q_skip, void* stream);
+
 /* ---- data-parallel exchange for non-Python hosts (csrc/comm.hip; the Python host side uses torch.distributed for the same three
  * operations).  RCCL is bound at run time (dlopen librccl.so); one communicator per process = per GPU.
  * reference: DeepSpeed's gradient all-reduce behind engine.backward / step (trainers/text_to_text/dpo.py:212-213) and

@@ -121,3 +121,41 @@ def test_attention_backward_rope_epilogue_is_bit_identical(case):
         ops.attn_bwd(q, k, v, o, do, lse, one[:, :H * hd], one[:, H * hd:(H + Hkv) * hd], one[:, (H + Hkv) * hd:], N, T, H, Hkv, hd, causal, scale, start,
                      rope=(pos.long(), cos_t, sin_t))
 
+
+@pytest.mark.parametrize('case', [(2, 1024, 4, 2, 128, [0, 100], [0, 700]), (3, 512, 2, 2, 128, None, [256, 0, 300]), (2, 384, 2, 2, 64, [0, 10], [0, 200])])
+def test_attention_q_skip_leaves_out_only_what_nobody_consumes(case):
+    """aa_attn_fwd_qskip / aa_attn_bwd_qskip (shared-prompt packing): query rows below q_skip[n] have no consumer and carry dO = 0.  Every row at or above
+    q_skip[n] of O / lse, and ALL of dQ / dK / dV, equal the kernels without the skip (run on the same zeroed dO) bit for bit."""
+    from align_anything_amd import ops
+    N, T, H, Hkv, hd, starts, skips = case
+    scale = hd ** -0.5
+    qkv = randn_bf16(N * T, (H + 2 * Hkv) * hd, seed=41)
+    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:(H + Hkv) * hd], qkv[:, (H + Hkv) * hd:]
+    do = randn_bf16(N * T, H * hd, seed=42)
+    start = torch.tensor(starts, dtype=torch.int32, device=dev()) if starts is not None else None
+    qs = torch.tensor(skips, dtype=torch.int32, device=dev())
+    keep = (torch.arange(T, device=dev())[None, :] >= qs[:, None]).reshape(-1)
+    do = do * keep[:, None].to(do.dtype)
+    g = torch.Generator().manual_seed(5)
+    pos = torch.randint(0, 4096, (N * T,), generator=g).to(torch.int32).to(dev())
+    ang = torch.arange(4096, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(0, hd, 2, dtype=torch.float32) / hd))[None, :]
+    rope = (pos, ang.cos().to(torch.bfloat16).to(dev()), ang.sin().to(torch.bfloat16).to(dev()))
+
+    def run(skip, with_rope):
+        o = torch.full((N * T, H * hd), float('nan'), dtype=torch.bfloat16, device=dev())
+        o, lse = ops.attn_fwd(q, k, v, N, T, H, Hkv, hd, True, scale, start, out=o, q_skip=qs if skip else None)
+        oo = torch.where(keep[:, None], o, torch.zeros_like(o))          # what the consumer reads (the backward's delta = rowsum(dO O) sees O only where dO != 0)
+        d = torch.full_like(qkv, float('nan'))
+        ops.attn_bwd(q, k, v, oo, do, lse, d[:, :H * hd], d[:, H * hd:(H + Hkv) * hd], d[:, (H + Hkv) * hd:], N, T, H, Hkv, hd, True, scale, start,
+                     rope=rope if with_rope else None, q_skip=qs if skip else None)
+        torch.cuda.synchronize()
+        return oo, lse, d
+
+    for with_rope in (False, True):
+        o0, lse0, d0 = run(False, with_rope)
+        o1, lse1, d1 = run(True, with_rope)
+        assert torch.equal(o0, o1)
+        keep_h = keep.view(N, 1, T).expand(N, H, T)
+        assert torch.equal(torch.nan_to_num(lse0[keep_h], neginf=-1e30), torch.nan_to_num(lse1[keep_h], neginf=-1e30))
+        assert torch.isfinite(d1.float()).all()
+        assert torch.equal(d0.float(), d1.float()), float((d0.float() - d1.float()).abs().max())          # (float compare: -0 == +0)

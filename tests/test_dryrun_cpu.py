@@ -132,7 +132,7 @@ def test_llava_dpo_step_with_shared_prompt_packing_host_flow(launches):
     # 2 layers x (qkv gather + attention-output gather) per forward, policy + reference; per layer the backward gathers d_attn and sums the copies of d_qkv
     assert launches.count('aa_moe_gather') == 2 * 2 * 2 + 2 and launches.count('aa_gather2_add') == 2
     assert plan['Mq'] in rows and 2 * B * Tn not in rows          # the projections ran on the packed rows, none on the reference layout
-    assert 'aa_attn_fwd' in launches and 'aa_attn_bwd_rope' in launches and 'aa_dpo_loss_fwd_bwd' in launches
+    assert 'aa_attn_fwd_qskip' in launches and 'aa_attn_bwd_qskip' in launches and 'aa_dpo_loss_fwd_bwd' in launches      # attention leaves out the query blocks nobody consumes
     # off by default: the same batch without the switch takes the reference layout
     tr0 = DPOTrainer(_cfgs(z), {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
                      reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cpu')

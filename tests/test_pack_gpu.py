@@ -105,7 +105,7 @@ def test_packing_on_the_text_llama_trainer_gqa_ragged():
     """The text-to-text DPO path (trainers/text_to_text/dpo.py on a Llama-family decoder, GQA 4 / 2): packed against unpacked on ragged pairs, fp32 twin."""
     from align_anything_amd import configs
     from align_anything_amd.trainers.dpo import DPOTrainer
-    cfg = configs.llama_cfg(128, 256, 2, 4, 2, 320, rms_eps=1e-5, max_position_embeddings=256)
+    cfg = configs.llama_cfg(256, 512, 2, 4, 2, 320, rms_eps=1e-5, max_position_embeddings=256)
     out = {}
     for share in (False, True):
         cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'compute_dtype': 'fp32',
