@@ -52,6 +52,10 @@ PY
       find gpurun_out/r06_prof_pack -name "*kernel_trace.csv" -delete
       timeout 900 python bench.py --steps 8 --warmup 2 --traffic committed --no-cpu-baseline > gpurun_out/r06_bench_pack.json 2> gpurun_out/r06_bench_pack.err; echo "rc=$?"
       python -c "import json; d=json.load(open('gpurun_out/r06_bench_pack.json')); print('headline', round(d['ms_per_step'],2), 'ms', round(d['value'],4), 'pairs/s'); print('shared_prompt', {k: (round(v,4) if isinstance(v,float) else v) for k,v in d['shared_prompt'].items() if k != 'note'}); print(d['config']['losses_timed_steps'][-2:])" || tail -5 gpurun_out/r06_bench_pack.err ;;
+    secondary)       # the other 7B backbones at 4 pairs per step + the MoE step, on the final code (tile-model change, SCC clobber)
+      timeout 400 python tools/bench_qwen2vl.py --pairs 4 --steps 3 --warmup 1 > gpurun_out/r06_bench_qwen2vl_b4.json 2> gpurun_out/r06_bench_qwen2vl_b4.err; cut -c1-420 gpurun_out/r06_bench_qwen2vl_b4.json; tail -2 gpurun_out/r06_bench_qwen2vl_b4.err | cut -c1-200
+      timeout 400 python tools/bench_qwen2audio.py --pairs 4 --steps 3 --warmup 1 > gpurun_out/r06_bench_qwen2audio_b4.json 2> gpurun_out/r06_bench_qwen2audio_b4.err; cut -c1-420 gpurun_out/r06_bench_qwen2audio_b4.json; tail -2 gpurun_out/r06_bench_qwen2audio_b4.err | cut -c1-200
+      for b in 2 4; do timeout 400 python tools/bench_qwen3moe.py --pairs $b --steps 4 --warmup 2 > gpurun_out/r06_bench_qwen3moe_b$b.json 2> gpurun_out/r06_bench_qwen3moe_b$b.err; cut -c1-420 gpurun_out/r06_bench_qwen3moe_b$b.json; tail -2 gpurun_out/r06_bench_qwen3moe_b$b.err | cut -c1-200; done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
