@@ -182,8 +182,13 @@ class DPOTrainer:
         if '_pack' not in batch:
             plan = None
             ok = self.policy.kind in ('llava', 'llama') and not getattr(self.policy, 'tied', False) and not getattr(self.policy, 'train_tower', False)
-            if ok and batch.get('pixel_values') is not None:
+            pv = batch.get('pixel_values')
+            if ok and pv is not None:
                 ok = self.share_vision_tower and self._features(batch) is not None
+                # image placeholder ids look alike whatever the image: rows may only share their image positions when they carry the SAME image.  A collator that
+                # states the shared prefix (meta_info.shared_prefix_lens) vouches for it (the reference's stacks `images * 2`); otherwise look (one device read)
+                if ok and 'shared_prefix_lens' not in batch['meta_info']:
+                    ok = pv.shape[0] % 2 == 0 and bool(torch.equal(pv[:pv.shape[0] // 2], pv[pv.shape[0] // 2:]))
             if ok:
                 plan = build_pack_plan(batch['input_ids'], batch.get('attention_mask'), self._window(batch), batch['meta_info'])
             batch['_pack'] = plan

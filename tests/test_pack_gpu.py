@@ -131,3 +131,28 @@ def test_packing_on_the_text_llama_trainer_gqa_ragged():
     assert p0 is None and p1 is not None and p1['prefix_lens'] == [100, 70]
     worst = max(rel_err(g1[n], g0[n]) for n in g0 if float(g0[n].norm()) > 1e-6)
     assert float((lp0 - lp1).abs().max()) < 2e-5 and abs(l0 - l1) < 1e-6 and worst < 1e-4, (float((lp0 - lp1).abs().max()), l0 - l1, worst)
+
+
+def test_packing_is_inherited_by_the_sibling_preference_trainers_and_refuses_unshared_images():
+    """SimPOTrainer overrides `loss` only (trainers/text_to_text/simpo.py:41-108): with the switch on its loss on equal-padding pairs equals the unpacked one bit
+    for bit.  And rows that carry DIFFERENT images are never packed, although their image placeholder ids look alike."""
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    from align_anything_amd.trainers.pref import SimPOTrainer
+    z = load_golden('llava_tiny_dpo.npz')
+    args = (2, 256, (150, 100), (64, 100), (64, 100), 7)
+    losses = []
+    for share in (False, True):
+        cfgs = {'train_cfgs': {'scale_coeff': 2.5, 'gamma': 1.4, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant',
+                               'share_prompt_prefix': share}, 'model_cfgs': {'pad_token_id': 301}}
+        tr = SimPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16), device='cuda:0')
+        b = _pair_batch(*args)
+        losses.append(float(tr.loss(b)['loss']))
+        assert (b.get('_pack') is not None) == share
+    assert losses[0] == losses[1]
+    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'share_prompt_prefix': True},
+            'model_cfgs': {'pad_token_id': 301}}
+    tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                    reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cuda:0')
+    b = _pair_batch(*args)
+    b['pixel_values'][2:] += 1.0                       # the rejected rows now carry other images
+    assert tr._pack_plan(b) is None
