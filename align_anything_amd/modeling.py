@@ -1346,11 +1346,20 @@ class NativeQwen2Audio(NativeCausalLM):
         return self.tower.unpad()
 
     def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
-                       position_ids=None, kv_sink=None, input_features=None, feature_attention_mask=None):
+                       position_ids=None, kv_sink=None, input_features=None, feature_attention_mask=None, pack=None):
+        """pack: shared-prompt packing plan (trainers.common.build_pack_plan).  The audio tokens of a pair then appear ONCE in the packed ids, so the tower runs on
+        the first half of `input_features` only (the collator stacks the clips twice, datasets/text_audio_to_text/preference.py:178-229; the trainer checks it)."""
         N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask, position_ids)
         P = self.store.p
         ids = input_ids.reshape(-1)
-        if Mp != N * T:
+        if pack is not None:
+            if position_ids is not None or kv_sink is not None:
+                raise RuntimeError('shared-prompt packing is a training-forward layout (no explicit position ids, no KV-cache prefill)')
+            ids, pos = pack['ids'], pack['pos']
+            if input_features is not None:
+                input_features = input_features[:N // 2]
+                feature_attention_mask = feature_attention_mask[:N // 2] if feature_attention_mask is not None else None
+        elif Mp != N * T:
             ids = torch.cat([ids, torch.zeros(Mp - N * T, dtype=ids.dtype, device=ids.device)])
         slot = feat = None
         actx = None
@@ -1375,8 +1384,8 @@ class NativeQwen2Audio(NativeCausalLM):
             actx = dict(idx=idx, n_feat=n_feat, tower_out=tower_out, rows_all=proj_all.shape[0])
         x = ops.embed_fwd(ids, P[self.embed], slot, feat)
         if save:
-            self._ctx = dict(ids=ids, slot=slot, N=N, T=T, start=start, pos=pos, audio=actx)
-        return self.stack.forward(x, N, T, start, pos, save, kv_sink)
+            self._ctx = dict(ids=ids, slot=slot, N=N, T=T, start=start, pos=pos if pack is None else pack['pos_full'], audio=actx, pack=pack)
+        return self.stack.forward(x, N, T, start, pos, save, kv_sink, pack=pack)
 
     def embed_tokens(self, ids, pos=None):
         return ops.embed_fwd(ids, self.store.p[self.embed])
@@ -1388,7 +1397,7 @@ class NativeQwen2Audio(NativeCausalLM):
 
     def backward_stream(self, dres, on_layer_done=None):
         cx = self._ctx
-        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done)
+        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done, pack=cx.get('pack'))
         G, a = self.store.g, cx['audio']
         want_feat = a is not None and (self.train_proj or self.train_tower)
         dfeat = torch.zeros((_pad64(a['n_feat']), self.hidden_size), dtype=self.dtype, device=self.device) if want_feat else None

@@ -176,12 +176,18 @@ class DPOTrainer:
 
     def _pack_plan(self, batch):
         """train_cfgs.share_prompt_prefix (default off): trainers.common.build_pack_plan for this batch, or None when the model / batch does not qualify
-        (LLaVA and Llama-family decoders in the left-padded pair layout; a training vision tower or unshared images keep the reference layout)."""
+        (LLaVA, Llama-family and Qwen2-Audio decoders in the left-padded pair layout; a training vision tower or unshared images / clips keep the reference layout)."""
         if not self.share_prompt_prefix:
             return None
         if '_pack' not in batch:
             plan = None
-            ok = self.policy.kind in ('llava', 'llama') and not getattr(self.policy, 'tied', False) and not getattr(self.policy, 'train_tower', False)
+            kind = self.policy.kind
+            ok = kind in ('llava', 'llama', 'qwen2audio') and not getattr(self.policy, 'tied', False) and not (kind == 'llava' and getattr(self.policy, 'train_tower', False))
+            fa = batch.get('input_features')
+            if ok and kind == 'qwen2audio' and fa is not None:       # the clips are stacked twice like the images (one device read unless the collator vouches)
+                fm, h = batch.get('feature_attention_mask'), fa.shape[0] // 2
+                ok = fa.shape[0] % 2 == 0 and ('shared_prefix_lens' in batch['meta_info']
+                                               or (bool(torch.equal(fa[:h], fa[h:])) and (fm is None or bool(torch.equal(fm[:h], fm[h:])))))
             pv = batch.get('pixel_values')
             if ok and pv is not None:
                 ok = self.share_vision_tower and self._features(batch) is not None
@@ -204,8 +210,9 @@ class DPOTrainer:
         feats = self._features(batch) if (self.share_vision_tower or module is self.policy) else None
         pack = self._pack_plan(batch)
         if pack is not None:
+            mm = {k: batch[k] for k in ('input_features', 'feature_attention_mask') if k in batch}
             return module.response_logprobs(batch['input_ids'], batch.get('attention_mask'), w, save=save, round_bf16=self.emulate_bf16_logp, pack=pack,
-                                            image_features=batch.get('_vision_features_unique') if feats is not None else None)
+                                            image_features=batch.get('_vision_features_unique') if feats is not None else None, **mm)
         mm = {k: batch[k] for k in ('image_grid_thw', 'position_ids3', 'input_features', 'feature_attention_mask') if k in batch}   # Qwen2-VL / Qwen2-Audio processor outputs
         return module.response_logprobs(batch['input_ids'], batch.get('attention_mask'), w,
                                         pixel_values=batch.get('pixel_values') if feats is None else None,

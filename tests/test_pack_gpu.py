@@ -156,3 +156,53 @@ def test_packing_is_inherited_by_the_sibling_preference_trainers_and_refuses_uns
     b = _pair_batch(*args)
     b['pixel_values'][2:] += 1.0                       # the rejected rows now carry other images
     assert tr._pack_plan(b) is None
+
+
+def test_packing_on_the_qwen2audio_trainer_runs_the_tower_once_per_pair():
+    """The text-audio DPO path (trainers/text_audio_to_text/dpo.py; Qwen2-Audio: trainable tower, q/k/v biases in the decoder): the clip of a pair is stacked
+    twice by the collator (datasets/text_audio_to_text/preference.py:178-229); packed, its audio tokens appear once, the tower runs on the first half only, and
+    the tower's gradient (chosen + rejected contributions through ONE set of rows) equals the unpacked one.  Ragged pairs, clips of 64 and 37 frames, fp32 twin."""
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    from tests.test_qwen2audio_gpu import _sd
+    from tests.util import tiny_qwen2audio_cfg
+    z = load_golden('qwen2audio_tiny_dpo.npz')
+    B, T = 2, 224
+    g = torch.Generator().manual_seed(3)
+    ids = torch.full((2 * B, T), 304, dtype=torch.long); mask = torch.zeros((2 * B, T), dtype=torch.long)
+    frames, ntok, plen, rc, rr = (64, 37), (16, 9), (120, 90), (40, 70), (90, 25)
+    for i in range(B):
+        prompt = torch.cat([torch.tensor([1]), torch.full((ntok[i],), 300, dtype=torch.long), torch.randint(3, 299, (plen[i] - 1 - ntok[i],), generator=g)])
+        for row, R in ((i, rc[i]), (B + i, rr[i])):
+            seq = torch.cat([prompt, torch.randint(3, 299, (R,), generator=g)])
+            ids[row, T - len(seq):] = seq; mask[row, T - len(seq):] = 1
+    feat = torch.randn(B, 64, 64, generator=g)
+    fmask = torch.zeros(B, 64, dtype=torch.long)
+    for i in range(B):
+        fmask[i, :frames[i]] = 1
+    out = {}
+    for share in (False, True):
+        cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-3, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'weight_decay': 0.0,
+                               'compute_dtype': 'fp32', 'share_prompt_prefix': share}, 'model_cfgs': {'pad_token_id': 304}}
+        tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_qwen2audio_cfg(), policy_state=_sd(z, 'w.', torch.float32),
+                        reference_state=_sd(z, 'r.', torch.float32), device='cuda:0')
+        b = {'input_ids': ids.to(dev()), 'attention_mask': mask.to(dev()), 'input_features': torch.cat([feat, feat], 0).to(dev()),
+             'feature_attention_mask': torch.cat([fmask, fmask], 0).to(dev()), 'meta_info': {'response_lens': list(rc) + list(rr)}}
+        lp = tr.compute_log_probs(tr.model, b).float().cpu()
+        ld = tr.loss(b)
+        tr.model.backward(ld['loss'])
+        torch.cuda.synchronize()
+        st = tr.policy.store
+        out[share] = (lp, float(ld['loss']), {n: st.grad_view(n).float().clone() for n in st.hf_names() if st.grad_view(n) is not None}, b.get('_pack'))
+        if share:
+            b2 = dict(b); b2.pop('_pack', None)
+            b2['input_features'] = b['input_features'].clone(); b2['input_features'][B:] += 1.0       # other clips on the rejected rows: never packed
+            assert tr._pack_plan(b2) is None
+    (lp0, l0, g0, p0), (lp1, l1, g1, p1) = out[False], out[True]
+    assert p0 is None and p1 is not None and p1['prefix_lens'] == [120, 90]
+    groups = {n.split('.')[1] if n.startswith('model.') else n.split('.')[0] for n in g0}
+    worst = max(rel_err(g1[n], g0[n]) for n in g0 if float(g0[n].norm()) > 1e-6)
+    tower = max(rel_err(g1[n], g0[n]) for n in g0 if 'audio_tower' in n and float(g0[n].norm()) > 1e-6)
+    dump('parity_pack_qwen2audio.txt', f'packed vs unpacked, fp32 twin: max |dlogp| {float((lp0 - lp1).abs().max()):.2e}, loss {l0:.6f} / {l1:.6f}, worst gradient rel_err {worst:.2e} '
+         f'(audio tower {tower:.2e}) over {len(g0)} tensors; prefix_lens {p1["prefix_lens"]}, packed rows {p1["rows"]} of {2 * B * T}\n')
+    assert any('audio_tower' in n for n in g0), groups
+    assert float((lp0 - lp1).abs().max()) < 2e-5 and abs(l0 - l1) < 1e-6 and worst < 1e-4, (float((lp0 - lp1).abs().max()), l0 - l1, worst)

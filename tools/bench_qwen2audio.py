@@ -25,11 +25,12 @@ def main():
     ap.add_argument('--audio-layers', type=int, default=32)
     ap.add_argument('--seq-len', type=int, default=2048)
     ap.add_argument('--response-len', type=int, default=512)
+    ap.add_argument('--share-prompt', action='store_true', help='train_cfgs.share_prompt_prefix: the pair\'s common prefix (and its clip) once per model')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     cfg = configs.qwen2_audio_7b(a.layers, a.audio_layers)
     B, T, R = a.pairs, a.seq_len, a.response_len
-    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-6, 'lr_warmup_ratio': 0.03, 'weight_decay': 0.0, 'total_training_steps': a.steps + a.warmup},
+    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-6, 'lr_warmup_ratio': 0.03, 'weight_decay': 0.0, 'total_training_steps': a.steps + a.warmup, 'share_prompt_prefix': a.share_prompt},
             'model_cfgs': {'pad_token_id': cfg['pad_token_id']}}
     tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, device=dev)
     random_init_(tr.policy, seed=42)
@@ -46,7 +47,7 @@ def main():
         feat = torch.randn(B, 128, 3000, generator=g)
         return {'input_ids': ids.to(dev), 'attention_mask': torch.ones(2 * B, T, dtype=torch.long, device=dev),
                 'input_features': torch.cat([feat, feat], 0).to(dev), 'feature_attention_mask': torch.ones(2 * B, 3000, dtype=torch.long, device=dev),
-                'meta_info': {'response_lens': [R] * (2 * B)}}
+                'meta_info': {'response_lens': [R] * (2 * B), 'shared_prefix_lens': [T - R] * B}}
 
     bs = [batch(1), batch(2)]
     for i in range(a.warmup):
@@ -68,7 +69,7 @@ def main():
     enc_pair = 8 * enc_row                # same 2 + 2 + 2x2 passes: the tower trains
     print(json.dumps({'workload': f'Qwen2-Audio-7B geometry DPO step, bf16, T={T}, R={R}, {B} pairs/step, one 30 s clip (750 audio tokens) per pair, audio tower trainable'
                                   + ('' if (a.layers, a.audio_layers) == (32, 32) else f' [REDUCED DEPTH {a.layers}/{a.audio_layers}]'),
-                      'pairs_per_s': B / dt, 'ms_per_step': dt * 1e3, 'llm_tflop_per_pair': llm_pair / 1e12, 'encoder_tflop_per_pair': enc_pair / 1e12,
+                      'share_prompt_prefix': a.share_prompt, 'pairs_per_s': B / dt, 'ms_per_step': dt * 1e3, 'llm_tflop_per_pair': llm_pair / 1e12, 'encoder_tflop_per_pair': enc_pair / 1e12,
                       'llm_frac_of_dense_bf16_peak': llm_pair * B / dt / 2.5e15, 'total_frac_of_dense_bf16_peak': (llm_pair + enc_pair) * B / dt / 2.5e15,
                       'losses': losses, 'trainable_params': tr.policy.store.num_trainable()}))
 

@@ -56,6 +56,9 @@ PY
       timeout 400 python tools/bench_qwen2vl.py --pairs 4 --steps 3 --warmup 1 > gpurun_out/r06_bench_qwen2vl_b4.json 2> gpurun_out/r06_bench_qwen2vl_b4.err; cut -c1-420 gpurun_out/r06_bench_qwen2vl_b4.json; tail -2 gpurun_out/r06_bench_qwen2vl_b4.err | cut -c1-200
       timeout 400 python tools/bench_qwen2audio.py --pairs 4 --steps 3 --warmup 1 > gpurun_out/r06_bench_qwen2audio_b4.json 2> gpurun_out/r06_bench_qwen2audio_b4.err; cut -c1-420 gpurun_out/r06_bench_qwen2audio_b4.json; tail -2 gpurun_out/r06_bench_qwen2audio_b4.err | cut -c1-200
       for b in 2 4; do timeout 400 python tools/bench_qwen3moe.py --pairs $b --steps 4 --warmup 2 > gpurun_out/r06_bench_qwen3moe_b$b.json 2> gpurun_out/r06_bench_qwen3moe_b$b.err; cut -c1-420 gpurun_out/r06_bench_qwen3moe_b$b.json; tail -2 gpurun_out/r06_bench_qwen3moe_b$b.err | cut -c1-200; done ;;
+    pack_audio)      # shared-prompt packing on the Qwen2-Audio DPO path (BASELINE configs[3] backbone): packed against unpacked (fp32 twin), then the step, both ways
+      timeout 600 python -m pytest tests/test_pack_gpu.py tests/test_qwen2audio_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r06_pack_audio_tests.log 2>&1; echo "rc=$?"; tail -8 gpurun_out/r06_pack_audio_tests.log | cut -c1-300; cat gpurun_out/parity_pack_qwen2audio.txt
+      for f in "" "--share-prompt"; do timeout 400 python tools/bench_qwen2audio.py --pairs 4 --steps 3 --warmup 1 $f > gpurun_out/r06_bench_qwen2audio_b4$f.json 2> gpurun_out/r06_bench_qwen2audio_b4$f.err; cut -c1-520 gpurun_out/r06_bench_qwen2audio_b4$f.json; tail -2 gpurun_out/r06_bench_qwen2audio_b4$f.err | cut -c1-200; done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
