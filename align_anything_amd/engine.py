@@ -254,15 +254,6 @@ class NativeEngine:
             self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
             self._sumsq_ws = torch.empty(ops.SUMSQ_WS, dtype=torch.float32, device=dev)
             self._layer_slices = self._compute_layer_slices()
-            # Data-parallel runs: the collective's workgroups hold compute units for a part of the backward pass, and a GEMM launch of 256-row tiles then pays
-            # a whole extra round for them (1024 tiles on 248 CUs: 5 rounds, +25 %).  The decoder stack therefore issues its weight-gradient GEMMs on a second
-            # stream (modeling.LlamaStack.backward): two queues keep the remaining CUs busy whatever their number.  Modelled on one GPU with CU-masked streams
-            # (tools/dp_shadow.py --dw-stream, profiles/r06_dp_shadow.txt).  Alone on the chip it is a measured loss (profiles/r06_dw_stream_negative.txt), so
-            # the default follows the world size; AA_DW_STREAM=0 / 1 forces it.
-            want = os.environ.get('AA_DW_STREAM', '')
-            stack = getattr(module, 'stack', None)
-            if dev.type == 'cuda' and hasattr(stack, 'dw_stream_ok') and (want == '1' or (want != '0' and self.world > 1)):
-                stack.dw_stream = torch.cuda.Stream(device=dev)
 
     # ---- DeepSpeedEngine-shaped conveniences
     def train(self, mode=True):

@@ -125,9 +125,6 @@ class LlamaStack:
         self.norm = store.add(prefix + 'norm.weight', (h,), trainable)
         self.cos = self.sin = None
         self.saved = []
-        self.dw_stream = None          # torch.cuda.Stream: weight-gradient GEMMs of `backward` run there (set by the engine in data-parallel runs)
-
-    dw_stream_ok = True
 
     def _tables(self, T):
         if self.cos is None or self.cos.shape[0] < T:
@@ -272,57 +269,24 @@ class LlamaStack:
         H, Hkv, hd = c['num_heads'], c['num_kv_heads'], c['head_dim']
         qw, kw = H * hd, Hkv * hd
         tr = self.trainable
-        # Weight-gradient GEMMs on a second stream (`dw_stream`, set by the engine when a collective shares the chip with backward: engine.py).  The four dW
-        # GEMMs of a layer are leaves of the backward graph; next to the dX chain they give the dispatcher two queues to draw workgroups from, so a launch
-        # whose last round of 256-row tiles is cut short (a collective holds CUs: 1024 tiles on 248 CUs = 5 rounds, not 4) no longer idles the chip for the
-        # rest of that round.  Same kernels, same order per buffer: bit-identical.  Not used alone on the chip (N = 1): there the idle tail is power budget
-        # (profiles/r06_dw_stream_negative.txt).  Order rules: `dres` is updated in place by the two norm backwards, so the main stream waits for the dW that
-        # reads it (down before ln2, o before ln1); a layer is handed to `on_layer_done` only after the main stream has waited for its last dW.
-        side = self.dw_stream if tr else None
-        main = torch.cuda.current_stream() if side is not None else None
-        held, done_L = [], None
-
-        def on_side(after, fn, *tensors):
-            """fn(*tensors) on the side stream once the main stream's work up to here (`after`) is done; returns the event that marks its end."""
-            side.wait_event(after)
-            with torch.cuda.stream(side):
-                fn(*tensors)
-            held.append(tensors)                              # the caching allocator knows nothing of the side stream: keep the operands alive until the main stream has waited
-            ev = torch.cuda.Event(); ev.record(side)
-            return ev
-
-        def mark():
-            ev = torch.cuda.Event(); ev.record(main)
-            return ev
-
         for L, sv in zip(reversed(self.layers), reversed(self.saved)):
             x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act = sv[:11]
             attn_full = sv[11] if pack is not None else attn
             sv = None
             # ---- MLP
-            e_down = on_side(mark(), L['down'].dw, dres, act) if side is not None else None
             if dres.dtype == bf16:
                 d_gu = ops.gemm_glu_bwd(dres, L['down'].w, gu, c['intermediate_size'])   # dX GEMM of the down projection with the SwiGLU backward as epilogue
             else:
                 d_gu = ops.swiglu_bwd(gu, L['down'].dx(dres))
-            if tr and side is None:
+            if tr:
                 L['down'].dw(dres, act)
-            if side is not None:
-                on_side(mark(), L['gu'].dw, d_gu, n2)
             d_n2 = L['gu'].dx(d_gu)
-            if tr and side is None:
+            if tr:
                 L['gu'].dw(d_gu, n2)
-            if side is not None:
-                main.wait_event(e_down)                       # in stream order after the previous layer's q/k/v dW: that layer is complete
-                if done_L is not None and on_layer_done is not None:
-                    on_layer_done(done_L)
-                done_L = None
-                del held[:-1]                                 # (the gate_up dW just queued may still be running)
             ops.rmsnorm_bwd(d_n2, x_mid, P[L['ln2']], rstd2, G.get(L['ln2']) if tr else None, dx=dres, add_to_dx=True)
             # ---- attention
-            e_o = on_side(mark(), L['o'].dw, dres, attn) if side is not None else None
             d_attn = L['o'].dx(dres)
-            if tr and side is None:
+            if tr:
                 L['o'].dw(dres, attn)
             if pack is not None:
                 d_attn = ops.moe_gather(d_attn, pack['owner'])       # the copy of a shared prefix row in the rejected sequence is nobody's output: zero gradient
@@ -337,23 +301,12 @@ class LlamaStack:
                 ops.rope_(d_qkv, 0, H + Hkv, hd, pos, self._rope[0], self._rope[1], inverse=True)
             if pack is not None:                                      # a shared row's gradient = the sum over its two copies (q of the second copy is exactly 0)
                 d_qkv = ops.gather2_add(d_qkv, pack['row2slot'], pack['row2slot_b'])
-            if side is not None:
-                e_qkv = on_side(mark(), L['qkv'].dw, d_qkv, n1)
             d_n1 = L['qkv'].dx(d_qkv)
-            if tr and side is None:
+            if tr:
                 L['qkv'].dw(d_qkv, n1)
-            if side is not None:
-                main.wait_event(e_o)
             ops.rmsnorm_bwd(d_n1, x, P[L['ln1']], rstd1, G.get(L['ln1']) if tr else None, dx=dres, add_to_dx=True)
-            if side is not None:
-                done_L = L
-            elif on_layer_done is not None:
+            if on_layer_done is not None:
                 on_layer_done(L)
-        if side is not None:
-            main.wait_stream(side)
-            if done_L is not None and on_layer_done is not None:
-                on_layer_done(done_L)
-            held.clear()
         self.saved = []
         return dres
 

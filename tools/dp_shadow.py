@@ -50,8 +50,6 @@ def main():
     ap.add_argument('--layers', type=int, default=32)
     ap.add_argument('--cus', type=int, nargs='*', default=[8, 16, 32])
     ap.add_argument('--out', default='r05_dp_shadow.json')
-    ap.add_argument('--dw-stream', action='store_true', help='round 6: every mask also with the weight-gradient GEMMs on a second stream of the SAME CU mask '
-                    '(modeling.LlamaStack.dw_stream: what the engine switches on when world_size > 1); traffic variants are left out')
     a = ap.parse_args()
     from align_anything_amd.trainers.dpo import DPOTrainer
     device = torch.device('cuda', 0)
@@ -99,9 +97,8 @@ def main():
 
     tr.model.backward = backward
 
-    def run(label, mask=None, traffic=0, dw=None):
+    def run(label, mask=None, traffic=0):
         state.update(mask=mask, traffic=traffic, bwd=[])
-        tr.policy.stack.dw_stream = dw
         tr.train_step(batches[0])
         torch.cuda.synchronize()
         state['bwd'] = []
@@ -120,19 +117,11 @@ def main():
     res = {'what': 'one-GPU MODEL of a resident collective beside the backward pass (tools/dp_shadow.py) -- not a multi-GPU measurement',
            'workload': f'bench.py trainer, {B} pairs, T {T}, {a.layers} layers', 'compute_units': n_cus, 'gradient_bytes_per_step': grad_bytes, 'runs': []}
     res['runs'].append(run('baseline'))
-    if a.dw_stream:
-        res['runs'].append(run('dw-stream, all CUs', dw=torch.cuda.Stream()))
-        res['runs'].append(run('baseline'))
     for C in a.cus:
         ms, mask = masked_stream(n_cus, C)
         r = run(f'mask {C}', mask=ms)
         r['cu_mask'] = mask
         res['runs'].append(r)
-        if a.dw_stream:
-            ms2, _ = masked_stream(n_cus, C)
-            res['runs'].append(run(f'mask {C} + dw-stream', mask=ms, dw=ms2))
-            res['runs'].append(run('baseline'))
-            continue
         res['runs'].append(run(f'traffic {C}', traffic=C))
         res['runs'].append(run(f'both {C}', mask=ms, traffic=C))
         res['runs'].append(run('baseline'))
