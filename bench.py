@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+MEASURED_COPY_GBS = 6290.0     # /opt/skills/guides/MI355X_MICROARCH.md: "8.0 TB/s spec; 6.29 TB/s measured (float4 copy, 79%)"
 TRAFFIC_PROFILES = ('r02_gemm_traffic.json', 'r01_gemm_traffic.json')   # newest first (tools/pmc_traffic.sh writes them)
 
 
@@ -621,6 +622,8 @@ def main():
                             'frac_of_8TBs': by_ / ms_ / 1e6 / PEAK_HBM_GBS, 'launches_per_step': args.layers, 'ms_per_step': ms_ * args.layers,
                             'where': 'standalone after the timed region (in the step it is launched inside aa_gemm_glu_bwd_bf16)'})
                 del gu_, da_, o_
+            for k_ in hbm:      # the guide's own ceiling for a streaming kernel on this part: 6.29 TB/s measured float4 copy (MI355X_MICROARCH.md, HBM3E row) against the 8 TB/s spec
+                k_['frac_of_measured_copy_6290GBs'] = k_['gb_per_s'] / MEASURED_COPY_GBS
             out['roofline']['hbm_kernels'] = hbm
             att = {}
             for kind, label in (('attn_fwd', 'fwd'), ('attn_bwd', 'bwd')):
