@@ -23,6 +23,7 @@ from . import ops
 from .params import ParamStore
 
 bf16 = torch.bfloat16
+TAIL_PRUNE = os.environ.get('AA_TAIL_PRUNE', '1') != '0'       # last decoder layer on the window rows only (LlamaStack.forward `tail`; results unchanged)
 
 
 def _pad64(n: int) -> int:
@@ -125,6 +126,7 @@ class LlamaStack:
         self.norm = store.add(prefix + 'norm.weight', (h,), trainable)
         self.cos = self.sin = None
         self.saved = []
+        self.tail, self.tail_used = None, False      # dead-row elimination in the last layer: see forward
 
     def _tables(self, T):
         if self.cos is None or self.cos.shape[0] < T:
@@ -148,6 +150,15 @@ class LlamaStack:
         # the DPO / PPO paths: their right-padded rows are never read at a masked position.  Set by the caller (attribute `kv_len`) for the one
         # consumer that is: the vision-language reward models' end score at position -1 (models/llava.py:64-68) on a right-padded batch.
         kv_len = self._kv_len_saved = getattr(self, 'kv_len', None)
+        # `tail` (set by NativeCausalLM.response_logprobs for this one call): the caller consumes the stack's output on the window rows only.  After the LAST
+        # layer's keys and values nothing reads the other rows: that layer's queries, attention output, o-projection and MLP then run on the window rows alone
+        # (the result comes back as [rows_pad, h] in window order).  Dead-row elimination: every consumed number is computed by the same kernels on the same
+        # operands -- log-probs bit-identical; weight gradients of that layer differ by the order of fp32 partial sums only.
+        tail, self.tail = self.tail, None
+        if tail is not None and (pack is not None or kv_sink is not None or kv_len is not None or not self.layers):
+            tail = None
+        self._tail_saved = tail if save else None
+        self.tail_used = tail is not None
         for li, L in enumerate(self.layers):
             n1, rstd1 = ops.rmsnorm_fwd(x, P[L['ln1']], eps)
             if x.dtype == bf16 and L['qkv'].b is None:
@@ -164,6 +175,11 @@ class LlamaStack:
                 attn_full, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True, hd ** -0.5, start,
                                               out=self._attn_out(qkv, N * T, H * hd), kv_len=kv_len, q_skip=pack.get('qskip'), work_frac=pack.get('attn_frac', 1.0))
                 attn = ops.moe_gather(attn_full, pack['row2slot'])
+            elif tail is not None and li == len(self.layers) - 1:
+                attn_full, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True, hd ** -0.5, start,
+                                              out=self._attn_out(x, N * T, H * hd), q_skip=tail['qskip'], work_frac=tail['frac'])
+                attn = ops.embed_fwd(tail['row_idx'], attn_full)      # window rows (pad rows: copies of row 0; their gradient is exactly 0)
+                x_in, x = x, ops.embed_fwd(tail['row_idx'], x)
             else:
                 attn, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
                                          hd ** -0.5, start, out=self._attn_out(x, N * T, H * hd), kv_len=kv_len)
@@ -177,7 +193,10 @@ class LlamaStack:
                 act = ops.swiglu_fwd(gu)
             x_out = L['down'].fwd(act, residual=x_mid)
             if save:
-                self.saved.append((x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act) + ((attn_full,) if pack is not None else ()))
+                if tail is not None and li == len(self.layers) - 1:
+                    self.saved.append((x_in, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act, attn_full))
+                else:
+                    self.saved.append((x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act) + ((attn_full,) if pack is not None else ()))
             x = x_out
         return x
 
@@ -269,9 +288,10 @@ class LlamaStack:
         H, Hkv, hd = c['num_heads'], c['num_kv_heads'], c['head_dim']
         qw, kw = H * hd, Hkv * hd
         tr = self.trainable
+        tail, self._tail_saved = getattr(self, '_tail_saved', None), None        # set: `dres` arrives as [rows_pad, h] in window order (see forward)
         for L, sv in zip(reversed(self.layers), reversed(self.saved)):
             x, rstd1, n1, qkv, attn, lse, x_mid, rstd2, n2, gu, act = sv[:11]
-            attn_full = sv[11] if pack is not None else attn
+            attn_full = sv[11] if (pack is not None or tail is not None) else attn
             sv = None
             # ---- MLP
             if dres.dtype == bf16:
@@ -290,13 +310,17 @@ class LlamaStack:
                 L['o'].dw(dres, attn)
             if pack is not None:
                 d_attn = ops.moe_gather(d_attn, pack['owner'])       # the copy of a shared prefix row in the rejected sequence is nobody's output: zero gradient
+            if tail is not None:                                      # back to the [N, T] layout: rows outside the windows have zero gradient
+                d_attn = ops.moe_gather(d_attn, tail['inv_map'])
+                dres = ops.moe_gather(dres, tail['inv_map'])
             d_qkv = torch.zeros_like(qkv) if qkv.shape[0] != N * T else torch.empty_like(qkv)
             fuse_rope = d_qkv.dtype == bf16 and ops.attn_rope_fused()      # the rotary backward rides in the dQ / dK epilogues (bit-identical)
             ops.attn_bwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], attn_full, d_attn, lse,
                          d_qkv[:, :qw], d_qkv[:, qw:qw + kw], d_qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
                          hd ** -0.5, start, kv_len=getattr(self, '_kv_len_saved', None),
-                         rope=(pos, self._rope[0], self._rope[1]) if fuse_rope else None, q_skip=pack.get('qskip') if pack is not None else None,
-                         work_frac=pack.get('attn_frac', 1.0) if pack is not None else 1.0)
+                         rope=(pos, self._rope[0], self._rope[1]) if fuse_rope else None,
+                         q_skip=pack.get('qskip') if pack is not None else (tail['qskip'] if tail is not None else None),
+                         work_frac=pack.get('attn_frac', 1.0) if pack is not None else (tail['frac'] if tail is not None else 1.0))
             if not fuse_rope:
                 ops.rope_(d_qkv, 0, H + Hkv, hd, pos, self._rope[0], self._rope[1], inverse=True)
             if pack is not None:                                      # a shared row's gradient = the sum over its two copies (q of the second copy is exactly 0)
@@ -305,6 +329,7 @@ class LlamaStack:
             if tr:
                 L['qkv'].dw(d_qkv, n1)
             ops.rmsnorm_bwd(d_n1, x, P[L['ln1']], rstd1, G.get(L['ln1']) if tr else None, dx=dres, add_to_dx=True)
+            tail = None                                               # the last layer only
             if on_layer_done is not None:
                 on_layer_done(L)
         self.saved = []
@@ -510,8 +535,8 @@ class LMHead:
             return ops.rmsnorm_fwd(x_last, P[self.norm_w], self.eps)[0]
         return ops.layernorm_fwd(x_last, P[self.norm_w], P[self.norm_b], self.eps, want_stats=False)[0]
 
-    def backward(self, dlogp, inv_map, zero_row):
-        """dlogp f32[rows_pad] -> gradient of the residual stream [Mp, h] (rows outside the windows are 0)."""
+    def backward(self, dlogp, inv_map, zero_row, compact=False):
+        """dlogp f32[rows_pad] -> gradient of the residual stream [Mp, h] (rows outside the windows are 0); compact: [rows_pad, h] in window order instead."""
         sel, mean, rstd, n, logits, lse, labels = self.saved
         P, G = self.store.p, self.store.g
         gw = None
@@ -534,6 +559,8 @@ class LMHead:
             d_sel = ops.layernorm_bwd(d_n, sel, P[self.norm_w], mean, rstd, G.get(self.norm_w) if tr else None,
                                       G.get(self.norm_b) if tr else None)
         self.saved = None
+        if compact:
+            return d_sel
         zeros_ids = torch.zeros(inv_map.shape[0], dtype=torch.int64, device=inv_map.device)
         return ops.embed_fwd(zeros_ids, zero_row, slot=inv_map, feat=d_sel)
 
@@ -667,10 +694,22 @@ class NativeCausalLM:
         for k in ('row_idx', 'labels', 'inv_map'):      # a host-side plan handed to the kernels would be a wild device pointer
             if window[k].device.type != self.device.type:
                 raise RuntimeError(f'response_logprobs: window[{k!r}] lives on {window[k].device}, the model on {self.device}')
-        x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features, **mm)
-        logp = self.head.forward(x, window['row_idx'], window['labels'], save, round_bf16)
+        # dead-row elimination in the last decoder layer (LlamaStack.forward, `tail`): the log-prob head reads the window rows only.  AA_TAIL_PRUNE=0: off (A/B)
+        stack = getattr(self, 'stack', None)
+        want_tail = (pack is None and TAIL_PRUNE and 'tail_qskip' in window and hasattr(stack, 'tail_used')
+                     and 'position_ids' not in mm and 'kv_sink' not in mm)
+        if want_tail:
+            stack.tail = {'row_idx': window['row_idx'], 'inv_map': window['inv_map'], 'qskip': window['tail_qskip'], 'frac': window['tail_frac']}
+        try:
+            x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features, **mm)
+        finally:
+            if want_tail:
+                stack.tail = None
+        compact = want_tail and stack.tail_used
+        logp = self.head.forward(x, window['row_idx_id'] if compact else window['row_idx'], window['labels'], save, round_bf16)
         if save:
             self._ctx['window'] = window
+            self._ctx['tail'] = compact
         return logp
 
     def response_scores(self, input_ids, attention_mask, window, pixel_values=None, save=False, image_features=None,
@@ -694,7 +733,10 @@ class NativeCausalLM:
         return self.head.scores_all(x)[:N * T].view(N, T)
 
     def backward_from_dlogp(self, dlogp, on_layer_done=None):
-        dres = self.head.backward(dlogp, self._ctx['window']['inv_map'], self._zero_row)
+        if self._ctx.get('tail', False):
+            dres = self.head.backward(dlogp, self._ctx['window']['inv_map'], self._zero_row, compact=True)
+        else:
+            dres = self.head.backward(dlogp, self._ctx['window']['inv_map'], self._zero_row)
         self.backward_stream(dres, on_layer_done)
         self._ctx = None
 

@@ -48,6 +48,11 @@ def build_window(input_ids: torch.Tensor, response_lens, pad_token_id: int):
         'flat_to_padded': torch.from_numpy(seq_of_row * max(int(cnt.max()), 1) + col_of_row).to(dev, non_blocking=True),
         'resp_len': torch.from_numpy(R.astype(np.int32)).to(dev, non_blocking=True),
         'row_off': torch.from_numpy(off[:-1].astype(np.int32)).to(dev, non_blocking=True),
+        # for the dead-row elimination of the last decoder layer (modeling.LlamaStack.forward `tail`): the window rows as an identity gather, the first query
+        # position anybody consumes per sequence, and the share of the causal attention work that remains (host ints: the bench's FLOP count)
+        'row_idx_id': torch.arange(rows_pad, dtype=torch.int64, device=dev),
+        'tail_qskip': torch.from_numpy((T - R).astype(np.int32)).to(dev, non_blocking=True),
+        'tail_frac': float(np.mean(1.0 - ((T - R) // 64 * 64 / T) ** 2)) if N else 1.0,
     }
     labels = torch.zeros(rows_pad, dtype=torch.int64, device=dev)
     ops.window_labels(input_ids.contiguous(), pad_token_id, w['resp_len'], w['row_off'], labels)

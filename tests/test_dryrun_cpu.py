@@ -139,7 +139,10 @@ def test_llava_dpo_step_with_shared_prompt_packing_host_flow(launches):
     b0 = {k: v for k, v in batch.items() if not k.startswith('_')}
     del launches[:]
     tr0.train_step(b0)
-    assert b0.get('_pack') is None and 'aa_moe_gather' not in launches
+    # ... and there the only gathers are the two of the last layer's dead-row elimination (d_attn and the residual gradient back to the [N, T] layout), with the
+    # attention of that layer leaving out the queries nobody consumes (policy + reference forward, policy backward)
+    assert b0.get('_pack') is None and launches.count('aa_moe_gather') == 2 and 'aa_gather2_add' not in launches
+    assert launches.count('aa_attn_fwd_qskip') == 2 and launches.count('aa_attn_bwd_qskip') == 1
 
 
 def test_supervised_step_and_prefetched_window(launches):

@@ -1,0 +1,62 @@
+"""Dead-row elimination in the last decoder layer (modeling.LlamaStack.forward `tail`): the log-prob head reads the response-window rows only
+(dpo.py:128-136 slices the logits), so after the last layer's keys and values nothing consumes the other rows -- that layer's queries, attention output,
+o-projection and MLP run on the window rows alone.  Every consumed number is computed by the same kernels on the same operands: log-probs and loss must be
+BIT-identical to the full computation (AA_TAIL_PRUNE=0), gradients equal up to the order of fp32 partial sums in that layer's weight gradients."""
+import pytest
+import torch
+
+from tests.gpu_util import dev, dump
+from tests.test_pack_gpu import _pair_batch
+from tests.util import load_golden, rel_err, state_dict_from_golden, tiny_llava_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(dtype, prune, monkeypatch):
+    from align_anything_amd import modeling
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    monkeypatch.setattr(modeling, 'TAIL_PRUNE', prune)
+    z = load_golden('llava_tiny_dpo.npz')
+    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'compute_dtype': dtype},
+            'model_cfgs': {'pad_token_id': 301}}
+    tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                    reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cuda:0')
+    b = _pair_batch(2, 256, (150, 90), (64, 100), (30, 77), seed=11)
+    lp = tr.compute_log_probs(tr.model, b)
+    used = tr.policy.stack.tail_used
+    rlp = tr.compute_log_probs(tr.reference_model, b)
+    ld = tr.loss(b)
+    tr.model.backward(ld['loss'])
+    torch.cuda.synchronize()
+    st = tr.policy.store
+    return lp.float().cpu(), rlp.float().cpu(), float(ld['loss']), {n: st.grad_view(n).float().clone() for n in st.hf_names() if st.grad_view(n) is not None}, used
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_last_layer_on_the_window_rows_only_changes_no_consumed_number(dtype, monkeypatch):
+    lp0, rlp0, l0, g0, u0 = _step(dtype, False, monkeypatch)
+    lp1, rlp1, l1, g1, u1 = _step(dtype, True, monkeypatch)
+    assert u1 and not u0
+    assert torch.equal(lp0, lp1) and torch.equal(rlp0, rlp1) and l0 == l1
+    worst = max((rel_err(g1[n], g0[n]), n) for n in g0 if float(g0[n].norm()) > 1e-6)
+    last = [n for n in g0 if '.layers.1.' in n and 'language_model' in n]
+    assert last and len(g0) > 20
+    dump(f'parity_tail_prune_{dtype}.txt', f'{dtype}: log-probs / loss bit-identical with and without the last-layer dead-row elimination; worst gradient rel_err {worst[0]:.2e} ({worst[1]}) '
+         f'over {len(g0)} tensors\n')
+    assert worst[0] < (2e-6 if dtype == 'fp32' else 4e-3), worst
+
+
+def test_other_consumers_of_the_stack_keep_every_row(monkeypatch):
+    """`logits()` (all positions), the score heads and the KV-cache prefill read rows outside the windows: the switch must not reach them."""
+    from align_anything_amd import modeling
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    monkeypatch.setattr(modeling, 'TAIL_PRUNE', True)
+    z = load_golden('llava_tiny_dpo.npz')
+    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant'}, 'model_cfgs': {'pad_token_id': 301}}
+    tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                    reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cuda:0')
+    b = _pair_batch(2, 256, (150, 90), (64, 100), (30, 77), seed=11)
+    tr.compute_log_probs(tr.model, b)
+    assert tr.policy.stack.tail_used and tr.policy.stack.tail is None
+    full = tr.policy.logits(b['input_ids'], b['attention_mask'], pixel_values=b['pixel_values'])
+    assert not tr.policy.stack.tail_used and full.shape[:2] == b['input_ids'].shape and bool(torch.isfinite(full.float()).all())
