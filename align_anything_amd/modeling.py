@@ -155,7 +155,7 @@ class LlamaStack:
         # (the result comes back as [rows_pad, h] in window order).  Dead-row elimination: every consumed number is computed by the same kernels on the same
         # operands -- log-probs bit-identical; weight gradients of that layer differ by the order of fp32 partial sums only.
         tail, self.tail = self.tail, None
-        if tail is not None and (pack is not None or kv_sink is not None or kv_len is not None or not self.layers):
+        if tail is not None and (kv_sink is not None or kv_len is not None or not self.layers):
             tail = None
         self._tail_saved = tail if save else None
         self.tail_used = tail is not None
@@ -172,14 +172,15 @@ class LlamaStack:
                 kv_sink(li, qkv[:N * T, qw:])  # post-RoPE keys | values of this layer -> KV cache (prefill)
             if pack is not None:
                 qkv = ops.moe_gather(qkv, pack['slot2row'])          # the reference layout (pad slots: zero rows); kept for the backward instead of the packed rows
+            if tail is not None and li == len(self.layers) - 1:
+                attn_full, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True, hd ** -0.5, start,
+                                              out=self._attn_out(qkv, N * T, H * hd), q_skip=tail['qskip'], work_frac=tail['frac'])
+                attn = ops.embed_fwd(tail['gather_attn'], attn_full)  # window rows (pad rows: copies of row 0; their gradient is exactly 0)
+                x_in, x = x, ops.embed_fwd(tail['gather_x'], x)
+            elif pack is not None:
                 attn_full, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True, hd ** -0.5, start,
                                               out=self._attn_out(qkv, N * T, H * hd), kv_len=kv_len, q_skip=pack.get('qskip'), work_frac=pack.get('attn_frac', 1.0))
                 attn = ops.moe_gather(attn_full, pack['row2slot'])
-            elif tail is not None and li == len(self.layers) - 1:
-                attn_full, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True, hd ** -0.5, start,
-                                              out=self._attn_out(x, N * T, H * hd), q_skip=tail['qskip'], work_frac=tail['frac'])
-                attn = ops.embed_fwd(tail['row_idx'], attn_full)      # window rows (pad rows: copies of row 0; their gradient is exactly 0)
-                x_in, x = x, ops.embed_fwd(tail['row_idx'], x)
             else:
                 attn, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
                                          hd ** -0.5, start, out=self._attn_out(x, N * T, H * hd), kv_len=kv_len)
@@ -308,19 +309,19 @@ class LlamaStack:
             d_attn = L['o'].dx(dres)
             if tr:
                 L['o'].dw(dres, attn)
-            if pack is not None:
+            if tail is not None:                                      # back to the [N, T] layout / the stack's row layout: rows outside the windows have zero gradient
+                d_attn = ops.moe_gather(d_attn, tail['scatter_attn'])
+                dres = ops.moe_gather(dres, tail['scatter_x'])
+            elif pack is not None:
                 d_attn = ops.moe_gather(d_attn, pack['owner'])       # the copy of a shared prefix row in the rejected sequence is nobody's output: zero gradient
-            if tail is not None:                                      # back to the [N, T] layout: rows outside the windows have zero gradient
-                d_attn = ops.moe_gather(d_attn, tail['inv_map'])
-                dres = ops.moe_gather(dres, tail['inv_map'])
             d_qkv = torch.zeros_like(qkv) if qkv.shape[0] != N * T else torch.empty_like(qkv)
             fuse_rope = d_qkv.dtype == bf16 and ops.attn_rope_fused()      # the rotary backward rides in the dQ / dK epilogues (bit-identical)
             ops.attn_bwd(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], attn_full, d_attn, lse,
                          d_qkv[:, :qw], d_qkv[:, qw:qw + kw], d_qkv[:, qw + kw:], N, T, H, Hkv, hd, True,
                          hd ** -0.5, start, kv_len=getattr(self, '_kv_len_saved', None),
                          rope=(pos, self._rope[0], self._rope[1]) if fuse_rope else None,
-                         q_skip=pack.get('qskip') if pack is not None else (tail['qskip'] if tail is not None else None),
-                         work_frac=pack.get('attn_frac', 1.0) if pack is not None else (tail['frac'] if tail is not None else 1.0))
+                         q_skip=tail['qskip'] if tail is not None else (pack.get('qskip') if pack is not None else None),
+                         work_frac=tail['frac'] if tail is not None else (pack.get('attn_frac', 1.0) if pack is not None else 1.0))
             if not fuse_rope:
                 ops.rope_(d_qkv, 0, H + Hkv, hd, pos, self._rope[0], self._rope[1], inverse=True)
             if pack is not None:                                      # a shared row's gradient = the sum over its two copies (q of the second copy is exactly 0)
@@ -696,10 +697,12 @@ class NativeCausalLM:
                 raise RuntimeError(f'response_logprobs: window[{k!r}] lives on {window[k].device}, the model on {self.device}')
         # dead-row elimination in the last decoder layer (LlamaStack.forward, `tail`): the log-prob head reads the window rows only.  AA_TAIL_PRUNE=0: off (A/B)
         stack = getattr(self, 'stack', None)
-        want_tail = (pack is None and TAIL_PRUNE and 'tail_qskip' in window and hasattr(stack, 'tail_used')
+        want_tail = (TAIL_PRUNE and 'tail_qskip' in window and hasattr(stack, 'tail_used') and (pack is None or 'tail' in pack)
                      and 'position_ids' not in mm and 'kv_sink' not in mm)
-        if want_tail:
-            stack.tail = {'row_idx': window['row_idx'], 'inv_map': window['inv_map'], 'qskip': window['tail_qskip'], 'frac': window['tail_frac']}
+        if want_tail:       # gather_*: window row -> row of the attention output ([N, T] layout) / of the stack's rows; scatter_*: the inverse maps (-1: not a window row)
+            stack.tail = pack['tail'] if pack is not None else {
+                'gather_attn': window['row_idx'], 'gather_x': window['row_idx'], 'scatter_attn': window['inv_map'], 'scatter_x': window['inv_map'],
+                'qskip': window['tail_qskip'], 'frac': window['tail_frac']}
         try:
             x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features, **mm)
         finally:

@@ -157,6 +157,9 @@ def build_pack_plan(input_ids: torch.Tensor, attention_mask, window, meta_info=N
     inv_t[w['row_idx'][:window['rows']]] = torch.arange(window['rows'], dtype=torch.int32, device=dev)
     w['inv_map'] = inv_t
     plan['window'] = w
+    if 'tail_qskip' in window:       # the last layer on the window rows only (modeling.LlamaStack.forward `tail`): attention rows by [N, T] slot, stack rows by packed row
+        plan['tail'] = {'gather_attn': ri, 'gather_x': w['row_idx'], 'scatter_attn': window['inv_map'], 'scatter_x': inv_t,
+                        'qskip': window['tail_qskip'], 'frac': window['tail_frac']}
     del plan['_inv_host']
     return plan
 

@@ -129,8 +129,9 @@ def test_llava_dpo_step_with_shared_prompt_packing_host_flow(launches):
     plan = batch['_pack']
     tokens = int(mask.sum())
     assert plan is not None and plan['prefix_lens'] == [100, 120] and plan['rows'] == tokens - 220 and plan['Mq'] % 64 == 0
-    # 2 layers x (qkv gather + attention-output gather) per forward, policy + reference; per layer the backward gathers d_attn and sums the copies of d_qkv
-    assert launches.count('aa_moe_gather') == 2 * 2 * 2 + 2 and launches.count('aa_gather2_add') == 2
+    # per forward (policy + reference): layer 0 gathers qkv and the attention output, the LAST layer qkv only (its attention output goes straight to the window
+    # rows: dead-row elimination); the backward gathers d_attn and the residual gradient back in the last layer, d_attn in layer 0, and sums the copies of d_qkv per layer
+    assert launches.count('aa_moe_gather') == 2 * 3 + 3 and launches.count('aa_gather2_add') == 2
     assert plan['Mq'] in rows and 2 * B * Tn not in rows          # the projections ran on the packed rows, none on the reference layout
     assert 'aa_attn_fwd_qskip' in launches and 'aa_attn_bwd_qskip' in launches and 'aa_dpo_loss_fwd_bwd' in launches      # attention leaves out the query blocks nobody consumes
     # off by default: the same batch without the switch takes the reference layout

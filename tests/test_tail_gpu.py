@@ -12,12 +12,12 @@ from tests.util import load_golden, rel_err, state_dict_from_golden, tiny_llava_
 pytestmark = pytest.mark.gpu
 
 
-def _step(dtype, prune, monkeypatch):
+def _step(dtype, prune, monkeypatch, share=False):
     from align_anything_amd import modeling
     from align_anything_amd.trainers.dpo import DPOTrainer
     monkeypatch.setattr(modeling, 'TAIL_PRUNE', prune)
     z = load_golden('llava_tiny_dpo.npz')
-    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'compute_dtype': dtype},
+    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'compute_dtype': dtype, 'share_prompt_prefix': share},
             'model_cfgs': {'pad_token_id': 301}}
     tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
                     reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cuda:0')
@@ -32,16 +32,18 @@ def _step(dtype, prune, monkeypatch):
     return lp.float().cpu(), rlp.float().cpu(), float(ld['loss']), {n: st.grad_view(n).float().clone() for n in st.hf_names() if st.grad_view(n) is not None}, used
 
 
+@pytest.mark.parametrize('share', [False, True])
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-def test_last_layer_on_the_window_rows_only_changes_no_consumed_number(dtype, monkeypatch):
-    lp0, rlp0, l0, g0, u0 = _step(dtype, False, monkeypatch)
-    lp1, rlp1, l1, g1, u1 = _step(dtype, True, monkeypatch)
+def test_last_layer_on_the_window_rows_only_changes_no_consumed_number(dtype, share, monkeypatch):
+    """share: on top of shared-prompt packing (the stack's rows are then the packed token rows; the attention output is still read by [N, T] slot)."""
+    lp0, rlp0, l0, g0, u0 = _step(dtype, False, monkeypatch, share)
+    lp1, rlp1, l1, g1, u1 = _step(dtype, True, monkeypatch, share)
     assert u1 and not u0
     assert torch.equal(lp0, lp1) and torch.equal(rlp0, rlp1) and l0 == l1
     worst = max((rel_err(g1[n], g0[n]), n) for n in g0 if float(g0[n].norm()) > 1e-6)
     last = [n for n in g0 if '.layers.1.' in n and 'language_model' in n]
     assert last and len(g0) > 20
-    dump(f'parity_tail_prune_{dtype}.txt', f'{dtype}: log-probs / loss bit-identical with and without the last-layer dead-row elimination; worst gradient rel_err {worst[0]:.2e} ({worst[1]}) '
+    dump(f'parity_tail_prune_{dtype}{"_packed" if share else ""}.txt', f'{dtype}{" + shared-prompt packing" if share else ""}: log-probs / loss bit-identical with and without the last-layer dead-row elimination; worst gradient rel_err {worst[0]:.2e} ({worst[1]}) '
          f'over {len(g0)} tensors\n')
     assert worst[0] < (2e-6 if dtype == 'fp32' else 4e-3), worst
 
