@@ -516,7 +516,8 @@ def main():
                           'algorithmic_tflop_per_pair': fl_pair / 1e12, 'algorithmic_frac_of_dense_bf16_peak': alg_tflops / PEAK_BF16_TFLOPS,
                           'note': 'headline = FLOPs counted at the launches of the timed steps (2MNK per GEMM, causal attention at half, '
                                   'backward 2.5x forward); algorithmic = SURVEY.md §8(d) accounting (lm_head over all T, 4 vision passes), '
-                                  'larger because lm_head runs on the response rows only and the frozen tower once per image'},
+                                  'larger because lm_head runs on the response rows only, the frozen tower once per image, and (round 6) the last decoder layer after its '
+                                  'keys / values on the response rows only -- nothing reads its other rows; log-probs bit-identical, AA_TAIL_PRUNE=0 switches it off'},
         }
         if gemm_events:
             tot_ms, tot_fl = 0.0, 0.0
