@@ -1165,15 +1165,23 @@ class NativeQwen2VL(NativeCausalLM):
         return valid + self._deltas.to(valid.dtype) if self._deltas is not None else valid
 
     def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
-                       position_ids=None, kv_sink=None, image_grid_thw=None, position_ids3=None, kv_len=None):
+                       position_ids=None, kv_sink=None, image_grid_thw=None, position_ids3=None, kv_len=None, pack=None):
         """position_ids3 (int32 [3, N, T], e.g. precomputed by the input pipeline on the host) avoids the device->host
         copy of input_ids that computing the 3-D rope index needs.  kv_len (int32 [N], optional): keys at or beyond it are masked
-        in the decoder (right padding, as for NativeLlava: the reward model reads position -1, models/qwen2_vl.py:61-64)."""
+        in the decoder (right padding, as for NativeLlava: the reward model reads position -1, models/qwen2_vl.py:61-64).
+        pack: shared-prompt packing plan (trainers.common.build_pack_plan).  The image tokens of a pair then appear ONCE in the packed ids, so the tower runs on
+        the first half of the images only (the collator stacks them twice; the trainer checks it).  The 3-D rope index is still that of the [N, T] layout --
+        it counts attended tokens, not slots, so both rows of a pair give their common prefix the same positions whatever their padding -- and a packed row
+        is rotated with the table row of the slot that owns it."""
         N, T, Mp, start, _ = self._token_geometry(input_ids, attention_mask, None)
         self.stack.kv_len = kv_len
         P, t = self.store.p, self.cfg['text']
         ids = input_ids.reshape(-1)
-        if Mp != N * T:
+        if pack is not None:
+            if kv_sink is not None or kv_len is not None:
+                raise RuntimeError('shared-prompt packing is a training-forward layout (no KV-cache prefill, no right padding)')
+            ids = pack['ids']
+        elif Mp != N * T:
             ids = torch.cat([ids, torch.zeros(Mp - N * T, dtype=ids.dtype, device=ids.device)])
         slot = feat = None
         has_img = pixel_values is not None or image_features is not None
@@ -1182,6 +1190,10 @@ class NativeQwen2VL(NativeCausalLM):
                 raise ValueError('Qwen2-VL needs image_grid_thw with pixel_values (the processor returns both)')
             if image_features is not None:
                 feat, nf = image_features, None
+            elif pack is not None:
+                grid = image_grid_thw.tolist() if isinstance(image_grid_thw, torch.Tensor) else [list(g) for g in image_grid_thw]
+                half = grid[:len(grid) // 2]
+                feat, nf = self.vision.forward(pixel_values[:sum(a * b * c for a, b, c in half)], half, save=save and self.train_proj)
             else:
                 feat, nf = self.vision.forward(pixel_values, image_grid_thw, save=save and self.train_proj)
             slot, count = ops.image_slot_index(ids, self.cfg['image_token_id'])
@@ -1206,7 +1218,9 @@ class NativeQwen2VL(NativeCausalLM):
         rows = torch.arange(Mp, dtype=torch.int32, device=self.device)
         x = ops.embed_fwd(ids, P[self.embed], slot, feat)
         if save:
-            self._ctx = dict(ids=ids, slot=slot, feat_rows=None if feat is None else feat.shape[0], N=N, T=T, start=start, pos=rows)
+            self._ctx = dict(ids=ids, slot=slot, feat_rows=None if feat is None else feat.shape[0], N=N, T=T, start=start, pos=rows, pack=pack)
+        if pack is not None:
+            return self.stack.forward(x, N, T, start, pack['row2slot'].clamp(min=0), save, None, tables=tables, pack=pack)
         return self.stack.forward(x, N, T, start, rows, save, kv_sink, tables=tables)
 
     def embed_tokens(self, ids, pos=None):
@@ -1219,7 +1233,7 @@ class NativeQwen2VL(NativeCausalLM):
 
     def backward_stream(self, dres, on_layer_done=None):
         cx = self._ctx
-        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done)
+        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done, pack=cx.get('pack'))
         G = self.store.g
         want_feat = cx['slot'] is not None and self.train_proj and self.vision._ctx is not None
         dfeat = torch.zeros((cx['feat_rows'], self.hidden_size), dtype=self.dtype, device=self.device) if want_feat else None

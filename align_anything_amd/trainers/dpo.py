@@ -176,20 +176,25 @@ class DPOTrainer:
 
     def _pack_plan(self, batch):
         """train_cfgs.share_prompt_prefix (default off): trainers.common.build_pack_plan for this batch, or None when the model / batch does not qualify
-        (LLaVA, Llama-family and Qwen2-Audio decoders in the left-padded pair layout; a training vision tower or unshared images / clips keep the reference layout)."""
+        (LLaVA, Llama-family, Qwen2-VL and Qwen2-Audio decoders in the left-padded pair layout; a training vision tower or unshared images / clips keep the reference layout)."""
         if not self.share_prompt_prefix:
             return None
         if '_pack' not in batch:
             plan = None
             kind = self.policy.kind
-            ok = kind in ('llava', 'llama', 'qwen2audio') and not getattr(self.policy, 'tied', False) and not (kind == 'llava' and getattr(self.policy, 'train_tower', False))
+            ok = kind in ('llava', 'llama', 'qwen2audio', 'qwen2vl') and not getattr(self.policy, 'tied', False) and not (kind == 'llava' and getattr(self.policy, 'train_tower', False))
             fa = batch.get('input_features')
             if ok and kind == 'qwen2audio' and fa is not None:       # the clips are stacked twice like the images (one device read unless the collator vouches)
                 fm, h = batch.get('feature_attention_mask'), fa.shape[0] // 2
                 ok = fa.shape[0] % 2 == 0 and ('shared_prefix_lens' in batch['meta_info']
                                                or (bool(torch.equal(fa[:h], fa[h:])) and (fm is None or bool(torch.equal(fm[:h], fm[h:])))))
             pv = batch.get('pixel_values')
-            if ok and pv is not None:
+            if ok and pv is not None and kind == 'qwen2vl':           # flattened patches of all images + their grids: both stacked twice (the module runs its own tower, on one half)
+                grid = batch.get('image_grid_thw')
+                grid = grid.tolist() if isinstance(grid, torch.Tensor) else [list(g) for g in (grid or [])]
+                ok = len(grid) > 0 and len(grid) % 2 == 0 and grid[:len(grid) // 2] == grid[len(grid) // 2:] and pv.shape[0] % 2 == 0 \
+                    and ('shared_prefix_lens' in batch['meta_info'] or bool(torch.equal(pv[:pv.shape[0] // 2], pv[pv.shape[0] // 2:])))
+            elif ok and pv is not None:
                 ok = self.share_vision_tower and self._features(batch) is not None
                 # image placeholder ids look alike whatever the image: rows may only share their image positions when they carry the SAME image.  A collator that
                 # states the shared prefix (meta_info.shared_prefix_lens) vouches for it (the reference's stacks `images * 2`); otherwise look (one device read)
@@ -210,8 +215,9 @@ class DPOTrainer:
         feats = self._features(batch) if (self.share_vision_tower or module is self.policy) else None
         pack = self._pack_plan(batch)
         if pack is not None:
-            mm = {k: batch[k] for k in ('input_features', 'feature_attention_mask') if k in batch}
+            mm = {k: batch[k] for k in ('image_grid_thw', 'position_ids3', 'input_features', 'feature_attention_mask') if k in batch}
             return module.response_logprobs(batch['input_ids'], batch.get('attention_mask'), w, save=save, round_bf16=self.emulate_bf16_logp, pack=pack,
+                                            pixel_values=batch.get('pixel_values') if module.kind == 'qwen2vl' else None,
                                             image_features=batch.get('_vision_features_unique') if feats is not None else None, **mm)
         mm = {k: batch[k] for k in ('image_grid_thw', 'position_ids3', 'input_features', 'feature_attention_mask') if k in batch}   # Qwen2-VL / Qwen2-Audio processor outputs
         return module.response_logprobs(batch['input_ids'], batch.get('attention_mask'), w,

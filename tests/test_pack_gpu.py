@@ -206,3 +206,48 @@ def test_packing_on_the_qwen2audio_trainer_runs_the_tower_once_per_pair():
          f'(audio tower {tower:.2e}) over {len(g0)} tensors; prefix_lens {p1["prefix_lens"]}, packed rows {p1["rows"]} of {2 * B * T}\n')
     assert any('audio_tower' in n for n in g0), groups
     assert float((lp0 - lp1).abs().max()) < 2e-5 and abs(l0 - l1) < 1e-6 and worst < 1e-4, (float((lp0 - lp1).abs().max()), l0 - l1, worst)
+
+
+@pytest.mark.parametrize('train_tower', [False, True])
+def test_packing_on_the_qwen2vl_trainer_under_multimodal_rope(train_tower):
+    """The Qwen2-VL DPO path (the configs[2] backbone; q/k/v biases, GQA, multimodal RoPE from the 3-D position index of the [N, T] layout): ragged pairs, images of
+    6 and 4 merged tokens stacked twice (flattened patches + grids), packed against unpacked on the fp32 twin -- also with the vision tower training, whose
+    gradient then arrives through ONE set of image rows per pair."""
+    from tests.test_qwen2vl_gpu import _trainer
+    z = load_golden('qwen2vl_tiny_dpo.npz')
+    B, T = 2, 224
+    g = torch.Generator().manual_seed(4)
+    ids = torch.full((2 * B, T), 304, dtype=torch.long); mask = torch.zeros((2 * B, T), dtype=torch.long)
+    grids, ntok, plen, rc, rr = [[1, 4, 6], [1, 4, 4]], (6, 4), (110, 84), (50, 72), (96, 31)
+    for i in range(B):
+        prompt = torch.cat([torch.tensor([1, 302]), torch.full((ntok[i],), 300, dtype=torch.long), torch.tensor([303]), torch.randint(3, 299, (plen[i] - 3 - ntok[i],), generator=g)])
+        for row, R in ((i, rc[i]), (B + i, rr[i])):
+            seq = torch.cat([prompt, torch.randint(3, 299, (R,), generator=g)])
+            ids[row, T - len(seq):] = seq; mask[row, T - len(seq):] = 1
+    pix = torch.randn(24 + 16, 1176, generator=g)
+    out = {}
+    for share in (False, True):
+        tr = _trainer(z, 'fp32', train_tower)
+        tr.share_prompt_prefix = share
+        b = {'input_ids': ids.to(dev()), 'attention_mask': mask.to(dev()), 'pixel_values': torch.cat([pix, pix], 0).to(dev()),
+             'image_grid_thw': torch.tensor(grids + grids), 'meta_info': {'response_lens': list(rc) + list(rr)}}
+        lp = tr.compute_log_probs(tr.model, b).float().cpu()
+        tr.policy.validate_batch()
+        ld = tr.loss(b)
+        tr.model.backward(ld['loss'])
+        torch.cuda.synchronize()
+        st = tr.policy.store
+        out[share] = (lp, float(ld['loss']), {n: st.grad_view(n).float().clone() for n in st.hf_names() if st.grad_view(n) is not None}, b.get('_pack'))
+        if share:
+            b2 = {k: v for k, v in b.items() if not k.startswith('_')}
+            b2['pixel_values'] = b['pixel_values'].clone(); b2['pixel_values'][40:] += 1.0            # other images on the rejected rows: never packed
+            assert tr._pack_plan(b2) is None
+    (lp0, l0, g0, p0), (lp1, l1, g1, p1) = out[False], out[True]
+    assert p0 is None and p1 is not None and p1['prefix_lens'] == [110, 84]
+    worst = max((rel_err(g1[n], g0[n]), n) for n in g0 if float(g0[n].norm()) > 1e-6)
+    vis = [rel_err(g1[n], g0[n]) for n in g0 if n.startswith('model.visual.') and float(g0[n].norm()) > 1e-6]
+    dump(f'parity_pack_qwen2vl{"_tower" if train_tower else ""}.txt', f'packed vs unpacked, fp32 twin{", vision tower training" if train_tower else ""}: max |dlogp| '
+         f'{float((lp0 - lp1).abs().max()):.2e}, loss {l0:.6f} / {l1:.6f}, worst gradient rel_err {worst[0]:.2e} ({worst[1]}; visual.* {max(vis):.2e} over {len(vis)}) over {len(g0)} '
+         f'tensors; prefix_lens {p1["prefix_lens"]}, packed rows {p1["rows"]} of {2 * B * T}\n')
+    assert len(vis) > (10 if train_tower else 1)
+    assert float((lp0 - lp1).abs().max()) < 2e-5 and abs(l0 - l1) < 1e-6 and worst[0] < 1e-4, (float((lp0 - lp1).abs().max()), l0 - l1, worst)

@@ -24,11 +24,12 @@ def main():
     ap.add_argument('--vision-depth', type=int, default=32)
     ap.add_argument('--seq-len', type=int, default=2048)
     ap.add_argument('--response-len', type=int, default=512)
+    ap.add_argument('--share-prompt', action='store_true', help="train_cfgs.share_prompt_prefix: the pair's common prefix (and its image) once per model")
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     cfg = configs.qwen2_vl_7b(a.layers, a.vision_depth)
     B, T, R = a.pairs, a.seq_len, a.response_len
-    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-6, 'lr_warmup_ratio': 0.03, 'weight_decay': 0.0, 'total_training_steps': a.steps + a.warmup},
+    cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-6, 'lr_warmup_ratio': 0.03, 'weight_decay': 0.0, 'total_training_steps': a.steps + a.warmup, 'share_prompt_prefix': a.share_prompt},
             'model_cfgs': {'pad_token_id': cfg['pad_token_id']}}
     tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, device=dev, share_vision_tower=False)
     random_init_(tr.policy, seed=42)
@@ -47,7 +48,7 @@ def main():
         ids[B:, :T - R] = ids[:B, :T - R]
         pix = torch.randn(B * 1024, 1176, generator=g)
         return {'input_ids': ids.to(dev), 'attention_mask': torch.ones(2 * B, T, dtype=torch.long, device=dev),
-                'pixel_values': torch.cat([pix, pix], 0).to(dev), 'image_grid_thw': grid, 'meta_info': {'response_lens': [R] * (2 * B)}}
+                'pixel_values': torch.cat([pix, pix], 0).to(dev), 'image_grid_thw': grid, 'meta_info': {'response_lens': [R] * (2 * B), 'shared_prefix_lens': [T - R] * B}}
 
     bs = [batch(1), batch(2)]
     for i in range(a.warmup):
@@ -66,7 +67,7 @@ def main():
     per_pair = 8 * (gemm + attn)          # policy fwd 2 rows + ref fwd 2 rows + policy bwd (2x) ; vision excluded
     print(json.dumps({'workload': f'Qwen2-VL-7B geometry DPO step, bf16, T={T}, R={R}, {B} pairs/step, 1 image (1024 patches) per pair'
                                   + ('' if a.layers == 28 else f' [REDUCED DEPTH {a.layers}/{a.vision_depth}]'),
-                      'pairs_per_s': B / dt, 'ms_per_step': dt * 1e3, 'llm_tflop_per_pair': per_pair / 1e12,
+                      'share_prompt_prefix': a.share_prompt, 'pairs_per_s': B / dt, 'ms_per_step': dt * 1e3, 'llm_tflop_per_pair': per_pair / 1e12,
                       'llm_frac_of_dense_bf16_peak': per_pair * B / dt / 2.5e15, 'losses': losses,
                       'trainable_params': tr.policy.store.num_trainable()}))
 

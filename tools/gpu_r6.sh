@@ -65,6 +65,9 @@ PY
         AA_TAIL_PRUNE=$v timeout 600 python bench.py --steps 8 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r06_bench_tail$v.json 2> gpurun_out/r06_bench_tail$v.err
         python -c "import json; d=json.load(open('gpurun_out/r06_bench_tail$v.json')); r=d['roofline']; sp=d.get('shared_prompt',{}); print('AA_TAIL_PRUNE=$v', round(d['ms_per_step'],2), 'ms', round(d['value'],4), 'pairs/s  W', round(r.get('power_w_mean') or 0), 'MHz', round(r.get('sclk_mhz_mean') or 0), 'executed TF/pair', round(d['step_mfma']['executed_tflop_per_pair'],2), 'packed', round(sp.get('ms_per_step',0),2), 'ms losses', d['config'].get('losses_timed_steps', [])[-2:])" || tail -3 gpurun_out/r06_bench_tail$v.err
       done ;;
+    pack_vl)         # shared-prompt packing on the Qwen2-VL DPO path (the configs[2] backbone; multimodal RoPE): packed against unpacked (fp32 twin), then the step, both ways
+      timeout 600 python -m pytest tests/test_pack_gpu.py tests/test_qwen2vl_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r06_pack_vl_tests.log 2>&1; echo "rc=$?"; tail -8 gpurun_out/r06_pack_vl_tests.log | cut -c1-300; cat gpurun_out/parity_pack_qwen2vl*.txt
+      for f in "" "--share-prompt"; do timeout 400 python tools/bench_qwen2vl.py --pairs 4 --steps 3 --warmup 1 $f > gpurun_out/r06_bench_qwen2vl_b4$f.json 2> gpurun_out/r06_bench_qwen2vl_b4$f.err; cut -c1-520 gpurun_out/r06_bench_qwen2vl_b4$f.json; tail -2 gpurun_out/r06_bench_qwen2vl_b4$f.err | cut -c1-200; done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
