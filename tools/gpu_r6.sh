@@ -68,6 +68,8 @@ PY
     pack_vl)         # shared-prompt packing on the Qwen2-VL DPO path (the configs[2] backbone; multimodal RoPE): packed against unpacked (fp32 twin), then the step, both ways
       timeout 600 python -m pytest tests/test_pack_gpu.py tests/test_qwen2vl_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r06_pack_vl_tests.log 2>&1; echo "rc=$?"; tail -8 gpurun_out/r06_pack_vl_tests.log | cut -c1-300; cat gpurun_out/parity_pack_qwen2vl*.txt
       for f in "" "--share-prompt"; do timeout 400 python tools/bench_qwen2vl.py --pairs 4 --steps 3 --warmup 1 $f > gpurun_out/r06_bench_qwen2vl_b4$f.json 2> gpurun_out/r06_bench_qwen2vl_b4$f.err; cut -c1-520 gpurun_out/r06_bench_qwen2vl_b4$f.json; tail -2 gpurun_out/r06_bench_qwen2vl_b4$f.err | cut -c1-200; done ;;
+    glue_moe)        # torch ops inside one Qwen3-MoE DPO step, by python site
+      timeout 600 python tools/lab/glue_prof.py moe 2>&1 | tail -70 | cut -c1-220 ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
