@@ -70,6 +70,10 @@ PY
       for f in "" "--share-prompt"; do timeout 400 python tools/bench_qwen2vl.py --pairs 4 --steps 3 --warmup 1 $f > gpurun_out/r06_bench_qwen2vl_b4$f.json 2> gpurun_out/r06_bench_qwen2vl_b4$f.err; cut -c1-520 gpurun_out/r06_bench_qwen2vl_b4$f.json; tail -2 gpurun_out/r06_bench_qwen2vl_b4$f.err | cut -c1-200; done ;;
     glue_moe)        # torch ops inside one Qwen3-MoE DPO step, by python site
       timeout 600 python tools/lab/glue_prof.py moe 2>&1 | tail -70 | cut -c1-220 ;;
+    rocprof_moe)     # rocprofv3 --kernel-trace --stats of the Qwen3-MoE step (tools/bench_qwen3moe.py, 2 pairs)
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r06_prof_moe && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof_moe -o p -- python $R/tools/bench_qwen3moe.py --pairs 2 --steps 4 --warmup 2 > $R/gpurun_out/r06_prof_moe.log 2>&1 )
+      f=$(find gpurun_out/r06_prof_moe -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r06_qwen3moe_kernel_stats.csv; head -40 gpurun_out/r06_qwen3moe_kernel_stats.csv | cut -c1-190; tail -1 gpurun_out/r06_prof_moe.log | cut -c1-300
+      find gpurun_out/r06_prof_moe -name "*kernel_trace.csv" -delete ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
