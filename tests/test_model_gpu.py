@@ -282,7 +282,7 @@ def test_llava_trainable_clip_tower_gradients_match_reference_fixture(dtype):
     b = _batch(z)
     ld = tr.loss(b)
     tight = dtype == 'fp32'
-    assert abs(float(ld['loss']) - float(z['loss_loss'])) < (2e-5 if tight else 1e-2)
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < (2e-5 if tight else 6e-3)
     tr.model.backward(ld['loss'])
     torch.cuda.synchronize()
     worst, n = 0.0, 0
@@ -300,7 +300,7 @@ def test_llava_trainable_clip_tower_gradients_match_reference_fixture(dtype):
             continue
         e = rel_err(got.reshape(want.shape), want)
         worst = max(worst, e); n += 1
-        assert e < (3e-4 if tight else 9e-2), (k, e)
+        assert e < (3e-4 if tight else 4e-2), (k, e)      # bf16 measured 2.0e-2
     dump(f'parity_llava_tower_{dtype}.txt', f'{dtype}: worst vision-tower gradient rel_err {worst:.2e} over {n} tensors\n')
     assert n >= 28
     info = tr.train_step(b)

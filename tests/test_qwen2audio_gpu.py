@@ -43,13 +43,15 @@ def test_qwen2audio_dpo_matches_reference_fixture(dtype):
     valid = T(z['attention_mask']).bool()
     e_log = rel_err(logits[valid], T(z['policy_logits'])[valid])
     rep = [f'{dtype}: logits rel_err {e_log:.2e}']
-    assert e_log < (2e-5 if tight else 3e-2), rep
+    assert e_log < (2e-5 if tight else 1.5e-2), rep      # bf16 measured 7.4e-3
     lp = tr.compute_log_probs(tr.model, b).cpu()
     assert torch.equal(lp == 0, T(z['seq_log_probs']) == 0)
-    assert (lp - T(z['seq_log_probs'])).abs().max() < (1e-4 if tight else 8e-2)
+    e_lp = float((lp - T(z['seq_log_probs'])).abs().max())
+    rep.append(f'max |d log-prob| per token {e_lp:.2e}')
+    assert e_lp < (1e-4 if tight else 2.5e-2), rep      # bf16 measured 1.2e-2
     ld = tr.loss(b)
     rep.append(f"loss native {float(ld['loss']):.6f} reference {float(z['loss_loss']):.6f}")
-    assert abs(float(ld['loss']) - float(z['loss_loss'])) < (3e-5 if tight else 2e-2)
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < (3e-5 if tight else 3e-3), rep      # bf16 measured 9.2e-4
     tr.model.backward(ld['loss'])
     torch.cuda.synchronize()
     worst, n, groups = 0.0, 0, set()
@@ -65,7 +67,7 @@ def test_qwen2audio_dpo_matches_reference_fixture(dtype):
             continue
         e = rel_err(got, want)
         worst = max(worst, e); n += 1; groups.add(k.split('.')[2])
-        assert e < (5e-4 if tight else 9e-2), (k, e)
+        assert e < (5e-4 if tight else 3.2e-2), (k, e)      # bf16 measured 1.6e-2
     rep.append(f'worst gradient rel_err {worst:.2e} over {n} tensors in {sorted(groups)}')
     dump(f'parity_qwen2audio_{dtype}.txt', '\n'.join(rep) + '\n')
     assert {'audio_tower', 'multi_modal_projector', 'language_model'} <= groups and n > 55

@@ -44,13 +44,15 @@ def test_qwen2vl_dpo_matches_reference_fixture(dtype, train_tower):
     valid = T(z['attention_mask']).bool()
     e_log = rel_err(logits[valid], T(z['policy_logits'])[valid])
     rep = [f'{dtype}: vision features rel_err {e_feat:.2e}, logits rel_err {e_log:.2e}']
-    assert e_feat < (2e-5 if tight else 2e-2) and e_log < (2e-5 if tight else 3e-2), rep
+    assert e_feat < (2e-5 if tight else 1.3e-2) and e_log < (2e-5 if tight else 1.8e-2), rep      # bf16: 2 x the measured 6.4e-3 / 9.3e-3
     lp = tr.compute_log_probs(tr.model, b).cpu()
     assert torch.equal(lp == 0, T(z['seq_log_probs']) == 0)
-    assert (lp - T(z['seq_log_probs'])).abs().max() < (1e-4 if tight else 8e-2)
+    e_lp = float((lp - T(z['seq_log_probs'])).abs().max())
+    rep.append(f'max |d log-prob| per token {e_lp:.2e}')
+    assert e_lp < (1e-4 if tight else 4e-2), rep      # bf16 measured 1.9e-2
     ld = tr.loss(b)
     rep.append(f"loss native {float(ld['loss']):.6f} reference {float(z['loss_loss']):.6f}")
-    assert abs(float(ld['loss']) - float(z['loss_loss'])) < (3e-5 if tight else 2e-2)
+    assert abs(float(ld['loss']) - float(z['loss_loss'])) < (3e-5 if tight else 2e-3), rep      # bf16 measured 3.5e-4
     assert_close(ld['reward_margin'].cpu(), T(z['loss_reward_margin']), rtol=1e-2, atol=(3e-5 if tight else 5e-2), what='margin')
     tr.model.backward(ld['loss'])
     torch.cuda.synchronize()
@@ -71,7 +73,7 @@ def test_qwen2vl_dpo_matches_reference_fixture(dtype, train_tower):
             continue
         e = rel_err(g.float().cpu().reshape(want.shape), want)
         worst = max(worst, e); n += 1
-        assert e < (3e-4 if tight else 9e-2), (k, e)
+        assert e < (3e-4 if tight else 4e-2), (k, e)      # bf16 measured 2.0e-2
     rep.append(f'worst gradient rel_err {worst:.2e} over {n} tensors (language model + merger' + (' + visual blocks + patch embedding)' if train_tower else ')'))
     dump(f'parity_qwen2vl_{dtype}' + ('_tower' if train_tower else '') + '.txt', '\n'.join(rep) + '\n')
     assert n > (55 if train_tower else 25)

@@ -208,7 +208,9 @@ def test_qwen3moe_dpo_matches_reference_fixture(dtype):
     assert e_log < (2e-5 if tight else 4e-2), rep
     lp = tr.compute_log_probs(tr.model, b).cpu()
     assert torch.equal(lp == 0, T(z['seq_log_probs']) == 0)
-    assert (lp - T(z['seq_log_probs'])).abs().max() < (1e-4 if tight else 1e-1)
+    e_lp = float((lp - T(z['seq_log_probs'])).abs().max())
+    rep.append(f'max |d log-prob| per token {e_lp:.2e}')
+    assert e_lp < (1e-4 if tight else 4.5e-2), rep      # bf16 measured 2.2e-2
     ld = tr.loss(b)
     rep.append(f"loss native {float(ld['loss']):.6f} reference {float(z['loss_loss']):.6f}")
     assert abs(float(ld['loss']) - float(z['loss_loss'])) < (3e-5 if tight else 2e-2)
