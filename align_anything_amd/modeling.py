@@ -1628,12 +1628,17 @@ class Qwen3MoeStack:
         dxs = ep.exchange_rows(dxr, ctx['recv'], ctx['send'])
         return ops.moe_combine(dxs, lay['pos'], None, Mp), dw
 
-    def forward(self, x, N, T, start, pos, save, kv_sink=None):
+    def forward(self, x, N, T, start, pos, save, kv_sink=None, pack=None):
+        """pack (trainers.common.build_pack_plan; shared-prompt packing, as LlamaStack.forward): x / pos are PACKED token rows -- norms, projections, per-head
+        norms + rotary embedding, the router and the experts see a pair's common prefix once (its routing is that of either copy: same hidden state, same
+        top-k) -- and attention runs on the [N, T] layout between row gathers."""
         c, P = self.cfg, self.store.p
         H, Hkv, hd, eps, E, k = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['rms_eps'], c['num_experts'], c['num_experts_per_tok']
         self._tables(T)
         self.saved = []
         Mp = x.shape[0]
+        if pack is not None and (self.ep is not None or kv_sink is not None):
+            raise RuntimeError('shared-prompt packing of the MoE stack: single-rank experts, training forward only')
         if self.ep is not None and self.ep.padded and self.ep._scope is None:
             # every MoE block of this forward exchanges Mp x k pairs: the ranks agree on the block size once (expert_parallel.pass_scope)
             with self.ep.pass_scope(Mp * k):
@@ -1649,8 +1654,20 @@ class Qwen3MoeStack:
             qn, kn = qn.view(Mp, H * hd), kn.view(Mp, Hkv * hd)
             if kv_sink is not None:     # post-norm, post-RoPE keys | values of this layer -> KV cache (prefill)
                 kv_sink(li, torch.cat([kn[:N * T], v[:N * T]], dim=1))
-            attn, lse = ops.attn_fwd(qn, kn, v, N, T, H, Hkv, hd, True, hd ** -0.5, start,
-                                     out=None if Mp == N * T else torch.zeros((Mp, H * hd), dtype=x.dtype, device=x.device))
+            if pack is not None:
+                qf = ops.moe_gather(qn, pack['slot2row'])                      # the [N, T] layout (pad slots: zero rows), kept for the backward
+                kvf = ops.moe_gather(torch.cat([kn, v], dim=1), pack['slot2row'])
+                kf, vf = kvf[:, :Hkv * hd], kvf[:, Hkv * hd:]
+                Mf = qf.shape[0]
+                attn_full, lse = ops.attn_fwd(qf, kf, vf, N, T, H, Hkv, hd, True, hd ** -0.5, start,
+                                              out=None if Mf == N * T else torch.zeros((Mf, H * hd), dtype=x.dtype, device=x.device),
+                                              q_skip=pack.get('qskip'), work_frac=pack.get('attn_frac', 1.0))
+                attn = ops.moe_gather(attn_full, pack['row2slot'])
+                qn, kn, v = qf, kf, vf
+            else:
+                attn, lse = ops.attn_fwd(qn, kn, v, N, T, H, Hkv, hd, True, hd ** -0.5, start,
+                                         out=None if Mp == N * T else torch.zeros((Mp, H * hd), dtype=x.dtype, device=x.device))
+                attn_full = attn
             x_mid = L['o'].fwd(attn, residual=x)
             n2, rstd2 = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
             logits = L['gate'].fwd(n2)
@@ -1663,17 +1680,17 @@ class Qwen3MoeStack:
                 gu, act, yp = self._local_experts_fwd(L, xp, plan)
                 x_out = ops.moe_combine(yp, plan['pos'], w, Mp, residual=x_mid)
             if save:
-                self.saved.append((x, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp))
+                self.saved.append((x, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp, attn_full))
             x = x_out
         return x
 
-    def backward(self, dres, N, T, start, pos, on_layer_done=None):
+    def backward(self, dres, N, T, start, pos, on_layer_done=None, pack=None):
         c, P, G = self.cfg, self.store.p, self.store.g
         H, Hkv, hd, E = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['num_experts']
         tr, st = self.trainable, self.store
         Mp = dres.shape[0]
         for L, sv in zip(reversed(self.layers), reversed(self.saved)):
-            x, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp = sv
+            x, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp, attn_full = sv
             sv = None
             # ---- sparse MoE block
             if 'lay' in plan:
@@ -1696,17 +1713,30 @@ class Qwen3MoeStack:
             d_attn = L['o'].dx(dres)
             if tr:
                 L['o'].dw(dres, attn)
-            z = lambda t: torch.zeros_like(t) if Mp != N * T else torch.empty_like(t)
-            dqn, dkn = z(qn), z(kn)
+            Mf = qn.shape[0]                                                  # rows of the [N, T] layout (== Mp unless packed)
+            z = lambda t: torch.zeros_like(t) if Mf != N * T else torch.empty_like(t)
             # the gradient of the fused projection output: attention writes dV into its slice, the per-head norm backward dq / dk into theirs
-            d_qkv = torch.zeros((Mp, (H + 2 * Hkv) * hd), dtype=qn.dtype, device=qn.device) if Mp != N * T else torch.empty((Mp, (H + 2 * Hkv) * hd), dtype=qn.dtype, device=qn.device)
-            dv = d_qkv[:, (H + Hkv) * hd:]
+            d_qkv = torch.zeros((Mp, (H + 2 * Hkv) * hd), dtype=qn.dtype, device=qn.device) if (Mp != N * T and pack is None) else torch.empty((Mp, (H + 2 * Hkv) * hd), dtype=qn.dtype, device=qn.device)
+            if pack is not None:
+                d_attn = ops.moe_gather(d_attn, pack['owner'])                # the rejected copy of a shared prefix row is nobody's output
+                dqn = z(qn)
+                dkv = torch.zeros((Mf, 2 * Hkv * hd), dtype=qn.dtype, device=qn.device) if Mf != N * T else torch.empty((Mf, 2 * Hkv * hd), dtype=qn.dtype, device=qn.device)
+                dkn, dv = dkv[:, :Hkv * hd], dkv[:, Hkv * hd:]
+            else:
+                dqn, dkn = z(qn), z(kn)
+                dv = d_qkv[:, (H + Hkv) * hd:]
             fuse_rope = dqn.dtype == bf16 and ops.attn_rope_fused()         # as LlamaStack.backward
-            ops.attn_bwd(qn, kn, v, attn, d_attn, lse, dqn, dkn, dv, N, T, H, Hkv, hd, True, hd ** -0.5, start,
-                         rope=(pos, self.cos, self.sin) if fuse_rope else None)
+            ops.attn_bwd(qn, kn, v, attn_full, d_attn, lse, dqn, dkn, dv, N, T, H, Hkv, hd, True, hd ** -0.5, start,
+                         rope=(pos, self.cos, self.sin) if fuse_rope else None, q_skip=pack.get('qskip') if pack is not None else None,
+                         work_frac=pack.get('attn_frac', 1.0) if pack is not None else 1.0)
             if not fuse_rope:
                 ops.rope_(dqn, 0, H, hd, pos, self.cos, self.sin, inverse=True)
                 ops.rope_(dkn, 0, Hkv, hd, pos, self.cos, self.sin, inverse=True)
+            if pack is not None:                                              # a shared row's gradient = the sum over its two copies
+                dqn = ops.gather2_add(dqn, pack['row2slot'], pack['row2slot_b'])
+                dkv = ops.gather2_add(dkv, pack['row2slot'], pack['row2slot_b'])
+                dkn = dkv[:, :Hkv * hd].contiguous()
+                d_qkv[:, (H + Hkv) * hd:] = dkv[:, Hkv * hd:]
             ops.rmsnorm_heads_bwd(dqn.view(Mp * H, hd), q, P[L['qn']], rq, G.get(L['qn']) if tr else None, d_qkv[:, :H * hd], H, hd)
             ops.rmsnorm_heads_bwd(dkn.view(Mp * Hkv, hd), kk, P[L['kn']], rk, G.get(L['kn']) if tr else None, d_qkv[:, H * hd:(H + Hkv) * hd], Hkv, hd)
             d_n1 = L['qkv'].dx(d_qkv)
@@ -1741,15 +1771,19 @@ class NativeQwen3Moe(NativeCausalLM):
         self.finalize()
 
     def forward_stream(self, input_ids, attention_mask=None, pixel_values=None, save=False, image_features=None,
-                       position_ids=None, kv_sink=None):
+                       position_ids=None, kv_sink=None, pack=None):
         N, T, Mp, start, pos = self._token_geometry(input_ids, attention_mask, position_ids)
         ids = input_ids.reshape(-1)
-        if Mp != N * T:
+        if pack is not None:
+            if position_ids is not None or kv_sink is not None:
+                raise RuntimeError('shared-prompt packing is a training-forward layout (no explicit position ids, no KV-cache prefill)')
+            ids, pos = pack['ids'], pack['pos']
+        elif Mp != N * T:
             ids = torch.cat([ids, torch.zeros(Mp - N * T, dtype=ids.dtype, device=ids.device)])
         x = ops.embed_fwd(ids, self.store.p[self.embed])
         if save:
-            self._ctx = dict(ids=ids, N=N, T=T, start=start, pos=pos)
-        return self.stack.forward(x, N, T, start, pos, save, kv_sink)
+            self._ctx = dict(ids=ids, N=N, T=T, start=start, pos=pos if pack is None else pack['pos_full'], pack=pack)
+        return self.stack.forward(x, N, T, start, pos, save, kv_sink, pack=pack)
 
     def embed_tokens(self, ids, pos=None):
         return ops.embed_fwd(ids, self.store.p[self.embed])
@@ -1792,7 +1826,7 @@ class NativeQwen3Moe(NativeCausalLM):
 
     def backward_stream(self, dres, on_layer_done=None):
         cx = self._ctx
-        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done)
+        dx = self.stack.backward(dres, cx['N'], cx['T'], cx['start'], cx['pos'], on_layer_done, pack=cx.get('pack'))
         if self.trainable:
             ops.embed_bwd(cx['ids'], dx, self.cfg['vocab_size'], dE=self.store.g.get(self.embed))
 

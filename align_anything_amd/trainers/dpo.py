@@ -176,13 +176,14 @@ class DPOTrainer:
 
     def _pack_plan(self, batch):
         """train_cfgs.share_prompt_prefix (default off): trainers.common.build_pack_plan for this batch, or None when the model / batch does not qualify
-        (LLaVA, Llama-family, Qwen2-VL and Qwen2-Audio decoders in the left-padded pair layout; a training vision tower or unshared images / clips keep the reference layout)."""
+        (LLaVA, Llama-family, Qwen2-VL, Qwen2-Audio and single-rank Qwen3-MoE decoders in the left-padded pair layout; a training vision tower or unshared images / clips keep the reference layout)."""
         if not self.share_prompt_prefix:
             return None
         if '_pack' not in batch:
             plan = None
             kind = self.policy.kind
-            ok = kind in ('llava', 'llama', 'qwen2audio', 'qwen2vl') and not getattr(self.policy, 'tied', False) and not (kind == 'llava' and getattr(self.policy, 'train_tower', False))
+            ok = kind in ('llava', 'llama', 'qwen2audio', 'qwen2vl', 'qwen3moe') and not getattr(self.policy, 'tied', False) \
+                and not (kind == 'llava' and getattr(self.policy, 'train_tower', False)) and not (kind == 'qwen3moe' and getattr(self.policy, 'ep', None) is not None)
             fa = batch.get('input_features')
             if ok and kind == 'qwen2audio' and fa is not None:       # the clips are stacked twice like the images (one device read unless the collator vouches)
                 fm, h = batch.get('feature_attention_mask'), fa.shape[0] // 2

@@ -251,3 +251,35 @@ def test_packing_on_the_qwen2vl_trainer_under_multimodal_rope(train_tower):
          f'tensors; prefix_lens {p1["prefix_lens"]}, packed rows {p1["rows"]} of {2 * B * T}\n')
     assert len(vis) > (10 if train_tower else 1)
     assert float((lp0 - lp1).abs().max()) < 2e-5 and abs(l0 - l1) < 1e-6 and worst[0] < 1e-4, (float((lp0 - lp1).abs().max()), l0 - l1, worst)
+
+
+@pytest.mark.parametrize('ragged', [False, True])
+def test_packing_on_the_qwen3moe_trainer_routes_the_shared_prefix_once(ragged):
+    """The Qwen3-MoE DPO path (models/qwen3_moe.py; per-head q / k norms, router + top-k experts per token): a shared prefix row is normalised, routed and sent
+    through its experts ONCE -- its routing is that of either copy (same hidden state).  Equal padding: log-probs bit-identical to the unpacked step; ragged
+    pairs: one rotary frame per pair, compared on the fp32 twin (a flipped top-k choice would show as a gross difference)."""
+    from tests.test_qwen3moe_gpu import _trainer
+    z = load_golden('qwen3moe_tiny_dpo.npz')
+    args = (2, 224, (120, 90), (40, 70), (90, 25), 6, 0) if ragged else (2, 224, (150, 100), (60, 110), (60, 110), 6, 0)
+    out = {}
+    for share in (False, True):
+        tr = _trainer(z, 'fp32')
+        tr.share_prompt_prefix = share
+        tr.pad_token_id = 301
+        b = _pair_batch(*args)
+        b.pop('pixel_values')
+        b['input_ids'] = b['input_ids'].clamp(max=int(z['input_ids'].max()))
+        lp = tr.compute_log_probs(tr.model, b).float().cpu()
+        ld = tr.loss(b)
+        tr.model.backward(ld['loss'])
+        torch.cuda.synchronize()
+        st = tr.policy.store
+        out[share] = (lp, float(ld['loss']), {n: st.grad_view(n).float().clone() for n in st.hf_names() if st.grad_view(n) is not None}, b.get('_pack'))
+    (lp0, l0, g0, p0), (lp1, l1, g1, p1) = out[False], out[True]
+    assert p0 is None and p1 is not None and p1['prefix_lens'] == ([120, 90] if ragged else [150, 100])
+    worst = max((rel_err(g1[n], g0[n]), n) for n in g0 if float(g0[n].norm()) > 1e-6)
+    dump(f'parity_pack_qwen3moe_{"ragged" if ragged else "equal_padding"}.txt', f'packed vs unpacked, fp32 twin: max |dlogp| {float((lp0 - lp1).abs().max()):.2e}, loss {l0:.6f} / {l1:.6f}, '
+         f'worst gradient rel_err {worst[0]:.2e} ({worst[1]}) over {len(g0)} tensors; packed rows {p1["rows"]} of {4 * 224}\n')
+    if not ragged:
+        assert torch.equal(lp0, lp1) and l0 == l1
+    assert float((lp0 - lp1).abs().max()) < 2e-5 and abs(l0 - l1) < 1e-6 and worst[0] < 1e-4, (float((lp0 - lp1).abs().max()), l0 - l1, worst)

@@ -74,6 +74,10 @@ PY
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r06_prof_moe && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof_moe -o p -- python $R/tools/bench_qwen3moe.py --pairs 2 --steps 4 --warmup 2 > $R/gpurun_out/r06_prof_moe.log 2>&1 )
       f=$(find gpurun_out/r06_prof_moe -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r06_qwen3moe_kernel_stats.csv; head -40 gpurun_out/r06_qwen3moe_kernel_stats.csv | cut -c1-190; tail -1 gpurun_out/r06_prof_moe.log | cut -c1-300
       find gpurun_out/r06_prof_moe -name "*kernel_trace.csv" -delete ;;
+    pack_moe)        # shared-prompt packing on the Qwen3-MoE DPO path (single-rank experts): packed against unpacked, then the step, both ways
+      timeout 600 python -m pytest tests/test_pack_gpu.py tests/test_qwen3moe_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r06_pack_moe_tests.log 2>&1; echo "rc=$?"; tail -8 gpurun_out/r06_pack_moe_tests.log | cut -c1-300; cat gpurun_out/parity_pack_qwen3moe*.txt
+      for f in "" "--share-prompt"; do timeout 400 python tools/bench_qwen3moe.py --pairs 2 --steps 4 --warmup 2 $f > gpurun_out/r06_bench_qwen3moe_b2$f.json 2> gpurun_out/r06_bench_qwen3moe_b2$f.err; cut -c1-520 gpurun_out/r06_bench_qwen3moe_b2$f.json; tail -2 gpurun_out/r06_bench_qwen3moe_b2$f.err | cut -c1-200; done
+      timeout 400 python tools/bench_qwen3moe.py --pairs 4 --steps 4 --warmup 2 --share-prompt > gpurun_out/r06_bench_qwen3moe_b4--share-prompt.json 2> gpurun_out/r06_bench_qwen3moe_b4--share-prompt.err; cut -c1-520 gpurun_out/r06_bench_qwen3moe_b4--share-prompt.json ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
