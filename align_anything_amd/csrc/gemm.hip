@@ -559,7 +559,7 @@ static SplitPlan plan_split(int M, int N, bool a_t, bool b_n) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("AA_GEMM_SPLIT"); on = e ? atoi(e) : 1; }
     SplitPlan none{0, 0, 0};
-    if (!on || aa_ctx_cur()->force_tile >= 0) return none;
+    if (!(on & (a_t ? 2 : 1)) || aa_ctx_cur()->force_tile >= 0) return none;     // bit 0: NT / NN launches, bit 1: the weight-gradient (TN) launches
     const int tm = aa_cdiv(M, 256), tn = aa_cdiv(N, 256);
     const long tiles = (long)tm * tn;
     const int rem = (int)(tiles % 256);
@@ -578,7 +578,7 @@ static SplitPlan plan_split(int M, int N, bool a_t, bool b_n) {
             if ((float)ra + tb < best) { best = (float)ra + tb; plan = SplitPlan{axis, a * 256, cfg}; }
         }
     }
-    (void)a_t; (void)b_n;
+    (void)b_n;
     return plan;
 }
 

@@ -204,6 +204,7 @@ def test_a_mostly_empty_last_round_goes_to_a_smaller_tile_with_the_same_bits(cas
     on the one-wave-per-SIMD kernel; the launch is cut where its part is whole rounds and the remainder runs on the 8-wave kernel's smaller tile.  Every
     output element stays one k-ordered chain of 16 x 16 x 32 MFMAs: bit-identical to the single launch (forced tile 5 disables the cut), whatever the axis,
     layout and epilogue."""
+    from align_anything_amd import ops
     g = torch.Generator(device='cpu').manual_seed(5)
     mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(torch.bfloat16).to(dev())
     kw, out0 = {}, None
