@@ -16,7 +16,6 @@ constexpr int AA_GLU_PLANS = 64;
 struct aa_ctx {
     // csrc/gemm.hip
     int gm = 0;                       // tile-group height of the grouped tile order; 0 = heuristic
-    int last_split[3] = {0, 0, 0};   // aa_gemm_last_split
     int force_tile = -2;              // -2: read AA_GEMM_TILE once; -1: heuristic
     int fuse = -1;                    // -1: read AA_GEMM_FUSE once
     int glu_mode = -1;                // AA_GLU_BWD: -1 follow the records, 0 unfused, 1 fused

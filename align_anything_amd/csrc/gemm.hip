@@ -537,66 +537,6 @@ static int pick_tile(int M, int N, int K) {
     return best;
 }
 
-// ---- a launch whose LAST round of 256 x 256 tiles is mostly empty (round 6).  640 tiles -- the 10240 packed token rows of the shared-prompt step against a
-// 4096-wide weight -- are 2.5 rounds of 256 workgroups and cost 3; 1376 (the gate_up weight gradient) are 5.4 and cost 6.  The launch is cut along its rows
-// or columns where the one-wave-per-SIMD kernel's part is a whole number of rounds, and the remainder runs on the 8-wave kernel's smaller tile (two
-// launches, one after the other on the same stream; every output element is still one k-ordered chain of 16 x 16 x 32 MFMAs: the same bits whichever kernel
-// owns it, tests/test_gemm_gpu.py).  The cost model is pick_tile's: time in units of one gemm4 round.  AA_GEMM_SPLIT=0: off (A/B).
-struct SplitPlan { int axis, cut, tile; };      // axis 0: none, 1: rows (M), 2: columns (N); cut: first row / column of the remainder; tile: its config
-static float small_tile_rounds(int M, int N, int* cfg_out) {
-    struct Cfg { int id, bm, bn, slots; float eff; };
-    const Cfg cfgs[3] = {{1, 128, 128, 512, 0.62f}, {2, 256, 128, 256, 0.76f}, {3, 128, 256, 256, 0.76f}};
-    float best = 1e30f;
-    for (const Cfg& c : cfgs) {
-        const long tiles = (long)aa_cdiv(M, c.bm) * aa_cdiv(N, c.bn);
-        const long rounds = (tiles + c.slots - 1) / c.slots;
-        const float t = rounds * ((float)c.bm * c.bn / 65536.f) / c.eff * (c.slots / 256.f);
-        if (t < best) { best = t; *cfg_out = c.id; }
-    }
-    return best;
-}
-static SplitPlan plan_split(int M, int N, bool a_t, bool b_n) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("AA_GEMM_SPLIT"); on = e ? atoi(e) : 1; }
-    SplitPlan none{0, 0, 0};
-    if (!(on & (a_t ? 2 : 1)) || aa_ctx_cur()->force_tile >= 0) return none;     // bit 0: NT / NN launches, bit 1: the weight-gradient (TN) launches
-    const int tm = aa_cdiv(M, 256), tn = aa_cdiv(N, 256);
-    const long tiles = (long)tm * tn;
-    const int rem = (int)(tiles % 256);
-    if (tiles <= 256 || rem == 0 || rem > 179) return none;          // one round, whole rounds, or a last round that is > 70 % full
-    float best = 0.96f * (float)((tiles + 255) / 256);
-    SplitPlan plan = none;
-    for (int axis = 1; axis <= 2; ++axis) {
-        const int tA = axis == 1 ? tm : tn, tO = axis == 1 ? tn : tm;
-        for (int a = tA - 1; a >= 1; --a) {
-            const long ta = (long)a * tO;
-            if (ta < 256) break;
-            const long ra = (ta + 255) / 256;
-            if (ra * 256 - ta > 12) continue;                        // the big-tile part must be (nearly) whole rounds
-            int cfg = 1;
-            const float tb = axis == 1 ? small_tile_rounds(M - a * 256, N, &cfg) : small_tile_rounds(M, N - a * 256, &cfg);
-            if ((float)ra + tb < best) { best = (float)ra + tb; plan = SplitPlan{axis, a * 256, cfg}; }
-        }
-    }
-    (void)b_n;
-    return plan;
-}
-
-template <bool A_T, bool B_N> static int launch_layout(GemmParams& p, int tile, hipStream_t st);
-static int launch_any(GemmParams p, int tile, bool a_t, bool b_n, hipStream_t st) {
-    if (tile == 5) {
-        p.tiles_m = aa_cdiv(p.M, 256);
-        p.tiles_n = aa_cdiv(p.N, 256);
-        p.gm = pick_group(a_t, b_n, p.tiles_n, p.K);
-        return aa_gemm4_dispatch(p, a_t, b_n, st);
-    }
-    if (!a_t && !b_n) return launch_layout<false, false>(p, tile, st);
-    if (!a_t && b_n) return launch_layout<false, true>(p, tile, st);
-    if (a_t && b_n) return launch_layout<true, true>(p, tile, st);
-    aa_set_error("aa_gemm_bf16: layout A^T with K-contiguous B is not built (unused by the hot path)");
-    return AA_ERR_ARG;
-}
-
 extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda,
                             long ldb, long ldc, const void* bias, const void* residual, long ldr,
                             int act, int flags, void* stream) {
@@ -618,31 +558,17 @@ extern "C" int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N,
     int tile = pick_tile(M, N, K);
     hipStream_t st = (hipStream_t)stream;
     if (tile == 5 && !aa_gemm4_supports(K)) tile = 0;      // K not a multiple of 128: the 8-wave kernel of the same tile
-    aa_ctx_cur()->last_split[0] = 0;
-    if (tile == 5 && (a_t ? b_n : true)) {
-        const SplitPlan sp = plan_split(M, N, a_t, b_n);
-        aa_ctx_cur()->last_split[0] = sp.axis; aa_ctx_cur()->last_split[1] = sp.cut; aa_ctx_cur()->last_split[2] = sp.tile;
-        if (sp.axis) {      // whole rounds on the one-wave-per-SIMD kernel, the remainder on a smaller tile (see plan_split)
-            const long esz = (flags & AA_GEMM_OUT_F32) ? 4 : 2;
-            GemmParams pa = p, pb = p;
-            if (sp.axis == 1) {
-                pa.M = sp.cut; pb.M = M - sp.cut;
-                pb.A = a_t ? p.A + sp.cut : p.A + (long)sp.cut * lda;
-                pb.C = (char*)C + (long)sp.cut * ldc * esz;
-                if (p.residual) pb.residual = p.residual + (long)sp.cut * ldr;
-            } else {
-                pa.N = sp.cut; pb.N = N - sp.cut;
-                pb.B = b_n ? p.B + sp.cut : p.B + (long)sp.cut * ldb;
-                pb.C = (char*)C + (long)sp.cut * esz;
-                if (p.bias) pb.bias = p.bias + sp.cut;
-                if (p.residual) pb.residual = p.residual + sp.cut;
-            }
-            const int rc = launch_any(pa, 5, a_t, b_n, st);
-            if (rc != AA_OK) return rc;
-            return launch_any(pb, sp.tile, a_t, b_n, st);
-        }
+    if (tile == 5) {   // one-wave-per-SIMD 256x256 tile with accumulator-file MFMAs (gemm4.hip)
+        p.tiles_m = aa_cdiv(p.M, 256);
+        p.tiles_n = aa_cdiv(p.N, 256);
+        p.gm = pick_group(a_t, b_n, p.tiles_n, p.K);
+        return aa_gemm4_dispatch(p, a_t, b_n, st);
     }
-    return launch_any(p, tile, a_t, b_n, st);
+    if (!a_t && !b_n) return launch_layout<false, false>(p, tile, st);
+    if (!a_t && b_n) return launch_layout<false, true>(p, tile, st);
+    if (a_t && b_n) return launch_layout<true, true>(p, tile, st);
+    aa_set_error("aa_gemm_bf16: layout A^T with K-contiguous B is not built (unused by the hot path)");
+    return AA_ERR_ARG;
 }
 
 // ---- grouped (mixture-of-experts) GEMM: the 128x256 tile, so expert segments are aligned to AA_MOE_ALIGN = 128 rows
@@ -888,13 +814,6 @@ extern "C" int aa_gemm_glu_bwd_bf16(const void* dY, const void* Wdown, const voi
 }
 
 // test hook: force a tile config (-1 = heuristic)
-extern "C" int aa_gemm_last_split(int* axis, int* cut, int* tile) {
-    const int* l = aa_ctx_cur()->last_split;
-    if (axis) *axis = l[0];
-    if (cut) *cut = l[1];
-    if (tile) *tile = l[2];
-    return AA_OK;
-}
 extern "C" int aa_gemm_set_tile(int tile) { aa_ctx_cur()->force_tile = tile; return AA_OK; }
 // test/bench hook: 1 = software-pipelined K loop (default), 0 = simple one-barrier schedule
 extern "C" int aa_gemm_set_group(int gm) { aa_ctx_cur()->gm = gm < 0 ? 0 : gm; return AA_OK; }   // 0 = heuristic; +256 = group tile columns instead of rows

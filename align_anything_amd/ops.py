@@ -278,14 +278,6 @@ def gemm_set_tile(tile: int) -> None:
     call('aa_gemm_set_tile', int(tile))
 
 
-def gemm_last_split():
-    """(axis, cut, tile) of the last ops.gemm launch: axis 0 = one launch, 1 / 2 = cut along rows / columns (csrc/gemm.hip plan_split)."""
-    import ctypes
-    a, c, t = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    call('aa_gemm_last_split', ctypes.byref(a), ctypes.byref(c), ctypes.byref(t))
-    return a.value, c.value, t.value
-
-
 # ------------------------------------------------------------------ norms
 NORM_WS_ROWS = 512
 _ws_cache: dict = {}

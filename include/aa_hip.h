@@ -148,9 +148,6 @@ int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, lon
                  long ldc, const void* bias, const void* residual, long ldr, int act, int flags,
                  void* stream);
 int aa_gemm_set_tile(int tile);
-/* How the LAST aa_gemm_bf16 call of this thread's context was launched: axis 0 = one launch, 1 / 2 = cut along the rows / columns at `cut` with the remainder on
- * tile config `tile` (csrc/gemm.hip plan_split: a mostly empty last round of 256 x 256 tiles goes to a smaller tile; AA_GEMM_SPLIT=0 switches it off).  Tests and lab tools. */
-int aa_gemm_last_split(int* axis, int* cut, int* tile);
 int aa_gemm_set_group(int gm);   /* tile-group height of the L2-aware tile order (0 = heuristic: 4, or 3 for NN with wide N) */
 /* hf:models/llama/modeling_llama.py:62-67 LlamaRMSNorm */
 int aa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int h, float eps,

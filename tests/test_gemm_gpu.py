@@ -3,7 +3,6 @@ import pytest
 import torch
 
 from tests.gpu_util import assert_close, dev, randn_bf16
-from tests.util import rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -196,48 +195,3 @@ def test_fused_epilogues_are_bit_identical_to_the_unfused_kernels():
             assert_close(res[0], ops.swiglu_bwd(gu, dact), rtol=1.6e-2, atol=2e-2, what='glu bwd vs unfused pieces')
     finally:
         ops.gemm_set_fuse(True)
-
-
-@pytest.mark.parametrize('case', ['nt_rows_residual', 'nn_rows', 'tn_rows_f32_accumulate', 'tn_cols', 'nt_cols_bias', 'tn_688_tiles_stay_whole'])
-def test_a_mostly_empty_last_round_goes_to_a_smaller_tile_with_the_same_bits(case):
-    """csrc/gemm.hip plan_split: 640 tiles of 256 x 256 (the packed step's 10240 rows against a 4096-wide weight) are 2.5 rounds of 256 workgroups and cost 3
-    on the one-wave-per-SIMD kernel; the launch is cut where its part is whole rounds and the remainder runs on the 8-wave kernel's smaller tile.  Every
-    output element stays one k-ordered chain of 16 x 16 x 32 MFMAs: bit-identical to the single launch (forced tile 5 disables the cut), whatever the axis,
-    layout and epilogue."""
-    from align_anything_amd import ops
-    g = torch.Generator(device='cpu').manual_seed(5)
-    mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(torch.bfloat16).to(dev())
-    kw, out0 = {}, None
-    if case == 'nt_rows_residual':      # o-projection / down-projection forward of the packed step: [10240, K] x [4096, K]^T + residual
-        a, b = mk(10240, 2048), mk(4096, 2048); kw = dict(residual=mk(10240, 4096)); want = (1, 8192)
-    elif case == 'nn_rows':             # dX: [10240, K] x [K, 4096]
-        a, b = mk(10240, 2176), mk(2176, 4096); kw = dict(b_n=True); want = (1, 8192)
-    elif case == 'tn_rows_f32_accumulate':      # gate_up weight gradient: [K, 22016]^T x [K, 4096] -> 86 x 16 = 1376 tiles (5.4 rounds), fp32 accumulate
-        a, b = mk(2048, 22016), mk(2048, 4096); kw = dict(a_t=True, b_n=True, accumulate=True); want = (1, 20480)
-        out0 = torch.randn(22016, 4096, generator=g).to(dev())
-    elif case == 'tn_cols':             # 16 x 40 tiles: only a cut along the columns gives whole rounds
-        a, b = mk(2048, 4096), mk(2048, 10240); kw = dict(a_t=True, b_n=True); want = (2, 8192)
-    elif case == 'nt_cols_bias':        # columns of an NT launch, with a bias: [4096, K] x [10240, K]^T
-        a, b = mk(4096, 2048), mk(10240, 2048); kw = dict(bias=mk(10240)); want = (2, 8192)
-    else:                               # the down weight gradient of the 7B step: 16 x 43 = 688 tiles (2.7 rounds) -- no cut pays by the model, one launch
-        a, b = mk(2048, 4096), mk(2048, 11008); kw = dict(a_t=True, b_n=True); want = (0, 0)
-    got = []
-    for tile in (5, -1):
-        ops.gemm_set_tile(tile)
-        try:
-            o = out0.clone() if out0 is not None else None
-            got.append(ops.gemm(a, b, out=o, **kw))
-            assert ops.gemm_last_split()[:2] == ((0, 0) if tile == 5 else want), (tile, ops.gemm_last_split())
-        finally:
-            ops.gemm_set_tile(-1)
-    torch.cuda.synchronize()
-    assert torch.equal(got[0], got[1])
-    ref = (a.float().t() if kw.get('a_t') else a.float()) @ (b.float() if kw.get('b_n') else b.float().t())
-    if 'bias' in kw:
-        ref = ref + kw['bias'].float()
-    if 'residual' in kw:
-        ref = ref.to(torch.bfloat16).float() + kw['residual'].float()
-    kw.pop('bias', None); kw.pop('residual', None)
-    if out0 is not None:
-        ref = ref + out0
-    assert rel_err(got[1].float(), ref) < 6e-3

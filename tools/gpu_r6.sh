@@ -78,12 +78,6 @@ PY
       timeout 600 python -m pytest tests/test_pack_gpu.py tests/test_qwen3moe_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r06_pack_moe_tests.log 2>&1; echo "rc=$?"; tail -8 gpurun_out/r06_pack_moe_tests.log | cut -c1-300; cat gpurun_out/parity_pack_qwen3moe*.txt
       for f in "" "--share-prompt"; do timeout 400 python tools/bench_qwen3moe.py --pairs 2 --steps 4 --warmup 2 $f > gpurun_out/r06_bench_qwen3moe_b2$f.json 2> gpurun_out/r06_bench_qwen3moe_b2$f.err; cut -c1-520 gpurun_out/r06_bench_qwen3moe_b2$f.json; tail -2 gpurun_out/r06_bench_qwen3moe_b2$f.err | cut -c1-200; done
       timeout 400 python tools/bench_qwen3moe.py --pairs 4 --steps 4 --warmup 2 --share-prompt > gpurun_out/r06_bench_qwen3moe_b4--share-prompt.json 2> gpurun_out/r06_bench_qwen3moe_b4--share-prompt.err; cut -c1-520 gpurun_out/r06_bench_qwen3moe_b4--share-prompt.json ;;
-    split_ab)        # csrc/gemm.hip plan_split (a mostly empty last round of 256 x 256 tiles goes to a smaller tile): same bits (tests), then the headline + packed step with and without it, alternating
-      timeout 900 python -m pytest tests/test_gemm_gpu.py tests/test_bench_geometry_gpu.py tests/test_pack_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r06_split_tests.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/r06_split_tests.log | cut -c1-300
-      for v in 0 1 3 0 1 3; do
-        AA_GEMM_SPLIT=$v timeout 600 python bench.py --share-prompt --steps 8 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r06_bench_split$v.json 2> gpurun_out/r06_bench_split$v.err
-        python -c "import json; d=json.load(open('gpurun_out/r06_bench_split$v.json')); r=d['roofline']; sp=d.get('shared_prompt',{}); print('AA_GEMM_SPLIT=$v', round(d['ms_per_step'],2), 'ms', round(d['value'],4), 'pairs/s  W', round(r.get('power_w_mean') or 0), 'MHz', round(r.get('sclk_mhz_mean') or 0), ' packed', round(sp.get('ms_per_step',0),2), 'ms', round(sp.get('value',0),4), 'pairs/s  losses', d['config'].get('losses_timed_steps', [])[-2:])" || tail -3 gpurun_out/r06_bench_split$v.err
-      done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
