@@ -105,8 +105,9 @@ def build_pack_plan(input_ids: torch.Tensor, attention_mask, window, meta_info=N
             Lp[i] = int(ne[0]) if len(ne) else m
     Lp = np.minimum(Lp, np.minimum(lens[:B] - R[:B], lens[B:] - R[B:]))          # the prompt only: every response-window row stays a row of its own
     Lp = np.where(Lp >= 64, Lp, 0)
-    if not Lp.any():
-        return None
+    if not Lp.any() and int(pad.sum()) * 8 < N * T:
+        return None          # nothing to share and less than 1/8 of the slots are padding: the reference layout as it is
+    # (nothing to share but a lot of padding: the plan still drops the pad slots from every row-wise kernel -- each row keeps its own positions, bit-identical)
     Mp = (N * T + 63) // 64 * 64
     slot2row = np.full(Mp, -1, dtype=np.int32)          # full slot (n, t) -> packed row (-1: a pad slot)
     owner = np.full(Mp, -1, dtype=np.int32)             # ... only where that slot OWNS the row (the rejected copy of a shared prefix does not)
@@ -131,8 +132,9 @@ def build_pack_plan(input_ids: torch.Tensor, attention_mask, window, meta_info=N
         row2slot_b[rows_r[:lp]] = sr[:lp]
         qskip[rj] = pad[rj] + lp                         # the rejected row's copy of the prefix: its outputs are taken from the chosen row
         f0 = min(pad[c], pad[rj])                        # HF: position = slot index within the row.  The pair's frame is the LONGER row's (smaller left pad):
-        pos[rows_c] = f0 + np.arange(lc)                 # that row keeps its own positions, the other moves by |pad_r - pad_c|, and every position stays < T
-        pos[rows_r[lp:]] = f0 + lp + np.arange(lr - lp)
+        fc, fr = (f0, f0) if lp else (pad[c], pad[rj])   # that row keeps its own positions, the other moves by |pad_r - pad_c|, and every position stays < T
+        pos[rows_c] = fc + np.arange(lc)                 # (no shared prefix: no common frame is needed, both rows keep their own)
+        pos[rows_r[lp:]] = fr + lp + np.arange(lr - lp)
         r0 += lc + lr - lp
     assert r0 == rows
     dev = input_ids.device

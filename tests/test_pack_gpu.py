@@ -283,3 +283,34 @@ def test_packing_on_the_qwen3moe_trainer_routes_the_shared_prefix_once(ragged):
     if not ragged:
         assert torch.equal(lp0, lp1) and l0 == l1
     assert float((lp0 - lp1).abs().max()) < 2e-5 and abs(l0 - l1) < 1e-6 and worst[0] < 1e-4, (float((lp0 - lp1).abs().max()), l0 - l1, worst)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_heavily_padded_pairs_without_a_common_prefix_are_packed_for_their_padding_alone(dtype):
+    """Nothing to share (the two rows differ from their first token on) but more than 1/8 of the slots are left padding: the plan still takes the pad slots out
+    of every row-wise kernel.  Each row keeps its own positions, so the forward is bit-identical to the reference layout."""
+    from align_anything_amd.trainers.dpo import DPOTrainer
+    z = load_golden('llava_tiny_dpo.npz')
+    out = {}
+    for share in (False, True):
+        cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'compute_dtype': dtype,
+                               'share_prompt_prefix': share}, 'model_cfgs': {'pad_token_id': 301}}
+        tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                        reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cuda:0')
+        b = _pair_batch(2, 256, (90, 60), (40, 70), (80, 30), seed=13)
+        N, T = b['input_ids'].shape
+        for i in range(2):                      # break the common prefix right after BOS + the image tokens ... and the images themselves are per row
+            r = 2 + i
+            first = int((b['attention_mask'][r] == 1).nonzero()[0])
+            b['input_ids'][r, first + 5] = (b['input_ids'][r, first + 5] + 7) % 290 + 3
+        lp = tr.compute_log_probs(tr.model, b).float().cpu()
+        ld = tr.loss(b)
+        tr.model.backward(ld['loss'])
+        torch.cuda.synchronize()
+        st = tr.policy.store
+        out[share] = (lp, float(ld['loss']), {n: st.grad_view(n).float().clone() for n in st.hf_names() if st.grad_view(n) is not None}, b.get('_pack'))
+    (lp0, l0, g0, p0), (lp1, l1, g1, p1) = out[False], out[True]
+    assert p0 is None and p1 is not None and p1['prefix_lens'] == [0, 0] and p1['shared_rows'] == 0 and p1['rows'] < 0.6 * 4 * 256
+    assert torch.equal(lp0, lp1) and l0 == l1
+    worst = max(rel_err(g1[n], g0[n]) for n in g0 if float(g0[n].norm()) > 1e-6)
+    assert worst < (1e-5 if dtype == 'fp32' else 4e-3), worst
