@@ -203,6 +203,17 @@ class DPOTrainer:
                     ok = pv.shape[0] % 2 == 0 and bool(torch.equal(pv[:pv.shape[0] // 2], pv[pv.shape[0] // 2:]))
             if ok:
                 plan = build_pack_plan(batch['input_ids'], batch.get('attention_mask'), self._window(batch), batch['meta_info'])
+                # The multimodal forward feeds ONE set of features per pair, so every image / audio placeholder of a pair must lie inside its shared prefix
+                # (a pair without a common prefix, or whose rows part before the placeholders, would need its own copy): count them in the packed ids -- one
+                # device read, skipped when the collator states the shared prefix.
+                tok = self.policy.cfg.get('image_token_id', self.policy.cfg.get('audio_token_id')) if isinstance(getattr(self.policy, 'cfg', None), dict) else None
+                if plan is not None and tok is not None and (pv is not None or fa is not None):
+                    if min(plan['prefix_lens']) == 0:
+                        plan = None
+                    elif 'shared_prefix_lens' not in batch['meta_info']:
+                        ids = batch['input_ids']
+                        if int((plan['ids'] == tok).sum()) != int((ids[:ids.shape[0] // 2] == tok).sum()):
+                            plan = None
             batch['_pack'] = plan
         return batch['_pack']
 

@@ -287,22 +287,30 @@ def test_packing_on_the_qwen3moe_trainer_routes_the_shared_prefix_once(ragged):
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_heavily_padded_pairs_without_a_common_prefix_are_packed_for_their_padding_alone(dtype):
-    """Nothing to share (the two rows differ from their first token on) but more than 1/8 of the slots are left padding: the plan still takes the pad slots out
-    of every row-wise kernel.  Each row keeps its own positions, so the forward is bit-identical to the reference layout."""
+    """Nothing to share (the two rows differ from their first tokens on) but more than 1/8 of the slots are left padding: the plan still takes the pad slots out
+    of every row-wise kernel (text-to-text DPO on a Llama-family decoder).  Each row keeps its own positions, so the forward is bit-identical to the reference
+    layout.  A MULTIMODAL pair without a shared prefix is never packed: its rows would each need their own copy of the image features."""
+    from align_anything_amd import configs
     from align_anything_amd.trainers.dpo import DPOTrainer
-    z = load_golden('llava_tiny_dpo.npz')
+    cfg = configs.llama_cfg(256, 512, 2, 4, 2, 320, rms_eps=1e-5, max_position_embeddings=256)
     out = {}
     for share in (False, True):
         cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'compute_dtype': dtype,
                                'share_prompt_prefix': share}, 'model_cfgs': {'pad_token_id': 301}}
-        tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
-                        reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cuda:0')
-        b = _pair_batch(2, 256, (90, 60), (40, 70), (80, 30), seed=13)
-        N, T = b['input_ids'].shape
-        for i in range(2):                      # break the common prefix right after BOS + the image tokens ... and the images themselves are per row
-            r = 2 + i
+        tr = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=cfg, device='cuda:0')
+        g = torch.Generator().manual_seed(9)
+        for n in tr.policy.store.hf_names():
+            v = tr.policy.store.view(n)
+            w = torch.randn(tuple(v.shape), generator=g) * 0.05 + (1.0 if 'norm' in n else 0.0)
+            v.copy_(w.to(dev())); tr.reference.store.view(n).copy_((w * 1.01).to(dev()))
+        for gname in tr.policy.store.master:
+            if tr.policy.store.master[gname] is not tr.policy.store.flat[gname]:
+                tr.policy.store.master[gname].copy_(tr.policy.store.flat[gname])
+        b = _pair_batch(2, 256, (90, 60), (40, 70), (80, 30), seed=13, image_tokens=0)
+        b.pop('pixel_values')
+        for r in (2, 3):                        # break the common prefix right after BOS
             first = int((b['attention_mask'][r] == 1).nonzero()[0])
-            b['input_ids'][r, first + 5] = (b['input_ids'][r, first + 5] + 7) % 290 + 3
+            b['input_ids'][r, first + 1] = (b['input_ids'][r, first + 1] + 7) % 290 + 3
         lp = tr.compute_log_probs(tr.model, b).float().cpu()
         ld = tr.loss(b)
         tr.model.backward(ld['loss'])
@@ -314,3 +322,14 @@ def test_heavily_padded_pairs_without_a_common_prefix_are_packed_for_their_paddi
     assert torch.equal(lp0, lp1) and l0 == l1
     worst = max(rel_err(g1[n], g0[n]) for n in g0 if float(g0[n].norm()) > 1e-6)
     assert worst < (1e-5 if dtype == 'fp32' else 4e-3), worst
+    if dtype == 'fp32':
+        z = load_golden('llava_tiny_dpo.npz')
+        cfgs = {'train_cfgs': {'scale_coeff': 0.1, 'learning_rate': 1e-4, 'lr_warmup_ratio': 0.0, 'lr_scheduler_type': 'constant', 'share_prompt_prefix': True},
+                'model_cfgs': {'pad_token_id': 301}}
+        tv = DPOTrainer(cfgs, {'gradient_clipping': 1.0}, model_cfg=tiny_llava_cfg(), policy_state=state_dict_from_golden(z, 'w.', torch.bfloat16),
+                        reference_state=state_dict_from_golden(z, 'r.', torch.bfloat16), device='cuda:0')
+        bv = _pair_batch(2, 256, (90, 60), (40, 70), (80, 30), seed=13)
+        for r in (2, 3):                        # the rows part right after BOS + the image tokens: nothing to share, each row would need its own features
+            first = int((bv['attention_mask'][r] == 1).nonzero()[0])
+            bv['input_ids'][r, first + 5] = (bv['input_ids'][r, first + 5] + 7) % 290 + 3
+        assert tv._pack_plan(bv) is None
