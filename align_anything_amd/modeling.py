@@ -1508,6 +1508,7 @@ class Qwen3MoeStack:
         self.norm = store.add(prefix + 'norm.weight', (h,), tr)
         self.cos = self.sin = None
         self.saved = []
+        self.tail, self.tail_used = None, False      # dead-row elimination in the last layer, as LlamaStack
 
     def _tables(self, T):
         if self.cos is None or self.cos.shape[0] < T:
@@ -1639,6 +1640,12 @@ class Qwen3MoeStack:
         Mp = x.shape[0]
         if pack is not None and (self.ep is not None or kv_sink is not None):
             raise RuntimeError('shared-prompt packing of the MoE stack: single-rank experts, training forward only')
+        # `tail` (LlamaStack.forward): the last layer's attention queries, o-projection, router and experts on the response-window rows only
+        tail, self.tail = self.tail, None
+        if tail is not None and (kv_sink is not None or self.ep is not None or not self.layers):
+            tail = None
+        self._tail_saved = tail if save else None
+        self.tail_used = tail is not None
         if self.ep is not None and self.ep.padded and self.ep._scope is None:
             # every MoE block of this forward exchanges Mp x k pairs: the ranks agree on the block size once (expert_parallel.pass_scope)
             with self.ep.pass_scope(Mp * k):
@@ -1659,15 +1666,24 @@ class Qwen3MoeStack:
                 kvf = ops.moe_gather(torch.cat([kn, v], dim=1), pack['slot2row'])
                 kf, vf = kvf[:, :Hkv * hd], kvf[:, Hkv * hd:]
                 Mf = qf.shape[0]
+                last = tail is not None and li == len(self.layers) - 1
                 attn_full, lse = ops.attn_fwd(qf, kf, vf, N, T, H, Hkv, hd, True, hd ** -0.5, start,
                                               out=None if Mf == N * T else torch.zeros((Mf, H * hd), dtype=x.dtype, device=x.device),
-                                              q_skip=pack.get('qskip'), work_frac=pack.get('attn_frac', 1.0))
-                attn = ops.moe_gather(attn_full, pack['row2slot'])
+                                              q_skip=tail['qskip'] if last else pack.get('qskip'), work_frac=tail['frac'] if last else pack.get('attn_frac', 1.0))
+                attn = ops.embed_fwd(tail['gather_attn'], attn_full) if last else ops.moe_gather(attn_full, pack['row2slot'])
                 qn, kn, v = qf, kf, vf
             else:
+                last = tail is not None and li == len(self.layers) - 1
                 attn, lse = ops.attn_fwd(qn, kn, v, N, T, H, Hkv, hd, True, hd ** -0.5, start,
-                                         out=None if Mp == N * T else torch.zeros((Mp, H * hd), dtype=x.dtype, device=x.device))
+                                         out=None if Mp == N * T else torch.zeros((Mp, H * hd), dtype=x.dtype, device=x.device),
+                                         q_skip=tail['qskip'] if last else None, work_frac=tail['frac'] if last else 1.0)
                 attn_full = attn
+                if last:
+                    attn = ops.embed_fwd(tail['gather_attn'], attn_full)
+            x_in = x
+            if last:                                                           # from here on this layer lives on the window rows
+                x = ops.embed_fwd(tail['gather_x'], x)
+                Mp = x.shape[0]
             x_mid = L['o'].fwd(attn, residual=x)
             n2, rstd2 = ops.rmsnorm_fwd(x_mid, P[L['ln2']], eps)
             logits = L['gate'].fwd(n2)
@@ -1680,7 +1696,7 @@ class Qwen3MoeStack:
                 gu, act, yp = self._local_experts_fwd(L, xp, plan)
                 x_out = ops.moe_combine(yp, plan['pos'], w, Mp, residual=x_mid)
             if save:
-                self.saved.append((x, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp, attn_full))
+                self.saved.append((x_in, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp, attn_full))
             x = x_out
         return x
 
@@ -1689,6 +1705,7 @@ class Qwen3MoeStack:
         H, Hkv, hd, E = c['num_heads'], c['num_kv_heads'], c['head_dim'], c['num_experts']
         tr, st = self.trainable, self.store
         Mp = dres.shape[0]
+        tail, self._tail_saved = getattr(self, '_tail_saved', None), None        # set: `dres` arrives as [rows_pad, h] in window order (see forward)
         for L, sv in zip(reversed(self.layers), reversed(self.saved)):
             x, rstd1, n1, q, kk, v, rq, rk, qn, kn, attn, lse, x_mid, rstd2, n2, probs, idx, w, plan, xp, gu, act, yp, attn_full = sv
             sv = None
@@ -1713,12 +1730,17 @@ class Qwen3MoeStack:
             d_attn = L['o'].dx(dres)
             if tr:
                 L['o'].dw(dres, attn)
+            if tail is not None:                                              # back to the stack's rows / the [N, T] layout: zero gradient outside the windows
+                d_attn = ops.moe_gather(d_attn, tail['scatter_attn'])
+                dres = ops.moe_gather(dres, tail['scatter_x'])
+                Mp = dres.shape[0]
             Mf = qn.shape[0]                                                  # rows of the [N, T] layout (== Mp unless packed)
             z = lambda t: torch.zeros_like(t) if Mf != N * T else torch.empty_like(t)
             # the gradient of the fused projection output: attention writes dV into its slice, the per-head norm backward dq / dk into theirs
             d_qkv = torch.zeros((Mp, (H + 2 * Hkv) * hd), dtype=qn.dtype, device=qn.device) if (Mp != N * T and pack is None) else torch.empty((Mp, (H + 2 * Hkv) * hd), dtype=qn.dtype, device=qn.device)
             if pack is not None:
-                d_attn = ops.moe_gather(d_attn, pack['owner'])                # the rejected copy of a shared prefix row is nobody's output
+                if tail is None:
+                    d_attn = ops.moe_gather(d_attn, pack['owner'])            # the rejected copy of a shared prefix row is nobody's output
                 dqn = z(qn)
                 dkv = torch.zeros((Mf, 2 * Hkv * hd), dtype=qn.dtype, device=qn.device) if Mf != N * T else torch.empty((Mf, 2 * Hkv * hd), dtype=qn.dtype, device=qn.device)
                 dkn, dv = dkv[:, :Hkv * hd], dkv[:, Hkv * hd:]
@@ -1727,8 +1749,10 @@ class Qwen3MoeStack:
                 dv = d_qkv[:, (H + Hkv) * hd:]
             fuse_rope = dqn.dtype == bf16 and ops.attn_rope_fused()         # as LlamaStack.backward
             ops.attn_bwd(qn, kn, v, attn_full, d_attn, lse, dqn, dkn, dv, N, T, H, Hkv, hd, True, hd ** -0.5, start,
-                         rope=(pos, self.cos, self.sin) if fuse_rope else None, q_skip=pack.get('qskip') if pack is not None else None,
-                         work_frac=pack.get('attn_frac', 1.0) if pack is not None else 1.0)
+                         rope=(pos, self.cos, self.sin) if fuse_rope else None,
+                         q_skip=tail['qskip'] if tail is not None else (pack.get('qskip') if pack is not None else None),
+                         work_frac=tail['frac'] if tail is not None else (pack.get('attn_frac', 1.0) if pack is not None else 1.0))
+            tail = None                                                       # the last layer only
             if not fuse_rope:
                 ops.rope_(dqn, 0, H, hd, pos, self.cos, self.sin, inverse=True)
                 ops.rope_(dkn, 0, Hkv, hd, pos, self.cos, self.sin, inverse=True)

@@ -62,3 +62,33 @@ def test_other_consumers_of_the_stack_keep_every_row(monkeypatch):
     assert tr.policy.stack.tail_used and tr.policy.stack.tail is None
     full = tr.policy.logits(b['input_ids'], b['attention_mask'], pixel_values=b['pixel_values'])
     assert not tr.policy.stack.tail_used and full.shape[:2] == b['input_ids'].shape and bool(torch.isfinite(full.float()).all())
+
+
+@pytest.mark.parametrize('share', [False, True])
+def test_last_moe_layer_on_the_window_rows_only(share, monkeypatch):
+    """Qwen3MoeStack: the last layer's attention queries, o-projection, ROUTER and experts run on the response-window rows only -- a token's routing and its
+    expert outputs do not depend on which other rows share its tile, so log-probs stay bit-identical (fp32 twin; also on top of shared-prompt packing)."""
+    from align_anything_amd import modeling
+    from tests.test_qwen3moe_gpu import _trainer
+    z = load_golden('qwen3moe_tiny_dpo.npz')
+    out = {}
+    for prune in (False, True):
+        monkeypatch.setattr(modeling, 'TAIL_PRUNE', prune)
+        tr = _trainer(z, 'fp32')
+        tr.share_prompt_prefix = share
+        tr.pad_token_id = 301
+        b = _pair_batch(2, 224, (120, 90), (40, 70), (90, 25), 6, 0)
+        b.pop('pixel_values')
+        lp = tr.compute_log_probs(tr.model, b).float().cpu()
+        used = tr.policy.stack.tail_used
+        ld = tr.loss(b)
+        tr.model.backward(ld['loss'])
+        torch.cuda.synchronize()
+        st = tr.policy.store
+        out[prune] = (lp, float(ld['loss']), {n: st.grad_view(n).float().clone() for n in st.hf_names() if st.grad_view(n) is not None}, used, b.get('_pack'))
+    (lp0, l0, g0, u0, p0), (lp1, l1, g1, u1, p1) = out[False], out[True]
+    assert u1 and not u0 and (p1 is not None) == share
+    assert torch.equal(lp0, lp1) and l0 == l1
+    worst = max((rel_err(g1[n], g0[n]), n) for n in g0 if float(g0[n].norm()) > 1e-6)
+    dump(f'parity_tail_prune_qwen3moe{"_packed" if share else ""}.txt', f'fp32{" + shared-prompt packing" if share else ""}: log-probs / loss bit-identical; worst gradient rel_err {worst[0]:.2e} ({worst[1]}) over {len(g0)} tensors\n')
+    assert worst[0] < 5e-6, worst
