@@ -596,7 +596,7 @@ class ScoreHead:
     def scores_all(self, x_last):
         return ops.rowdot_fwd(self.hidden_all(x_last), self.store.p[self.score_w].view(-1))
 
-    def backward(self, dscores, inv_map, zero_row):
+    def backward(self, dscores, inv_map, zero_row, compact=False):
         sel, mean, rstd, n = self.saved
         P, G = self.store.p, self.store.g
         tr = self.trainable
@@ -608,6 +608,8 @@ class ScoreHead:
             d_sel = ops.layernorm_bwd(d_n, sel, P[self.norm_w], mean, rstd, G.get(self.norm_w) if tr else None,
                                       G.get(self.norm_b) if tr else None)
         self.saved = None
+        if compact:
+            return d_sel
         zeros_ids = torch.zeros(inv_map.shape[0], dtype=torch.int64, device=inv_map.device)
         return ops.embed_fwd(zeros_ids, zero_row, slot=inv_map, feat=d_sel)
 
@@ -695,10 +697,19 @@ class NativeCausalLM:
         for k in ('row_idx', 'labels', 'inv_map'):      # a host-side plan handed to the kernels would be a wild device pointer
             if window[k].device.type != self.device.type:
                 raise RuntimeError(f'response_logprobs: window[{k!r}] lives on {window[k].device}, the model on {self.device}')
-        # dead-row elimination in the last decoder layer (LlamaStack.forward, `tail`): the log-prob head reads the window rows only.  AA_TAIL_PRUNE=0: off (A/B)
+        x, compact = self._forward_to_window(window, pack, mm, input_ids, attention_mask, pixel_values, save, image_features)
+        logp = self.head.forward(x, window['row_idx_id'] if compact else window['row_idx'], window['labels'], save, round_bf16)
+        if save:
+            self._ctx['window'] = window
+            self._ctx['tail'] = compact
+        return logp
+
+    def _forward_to_window(self, window, pack, mm, input_ids, attention_mask, pixel_values, save, image_features):
+        """forward_stream for a caller that reads the window rows only -> (x, compact).  Dead-row elimination in the last decoder layer (LlamaStack.forward,
+        `tail`): with compact the result is [rows_pad, h] in window order.  AA_TAIL_PRUNE=0: off (A/B)."""
         stack = getattr(self, 'stack', None)
         want_tail = (TAIL_PRUNE and 'tail_qskip' in window and hasattr(stack, 'tail_used') and (pack is None or 'tail' in pack)
-                     and 'position_ids' not in mm and 'kv_sink' not in mm)
+                     and 'position_ids' not in mm and 'kv_sink' not in mm and mm.get('kv_len') is None)
         if want_tail:       # gather_*: window row -> row of the attention output ([N, T] layout) / of the stack's rows; scatter_*: the inverse maps (-1: not a window row)
             stack.tail = pack['tail'] if pack is not None else {
                 'gather_attn': window['row_idx'], 'gather_x': window['row_idx'], 'scatter_attn': window['inv_map'], 'scatter_x': window['inv_map'],
@@ -708,22 +719,21 @@ class NativeCausalLM:
         finally:
             if want_tail:
                 stack.tail = None
-        compact = want_tail and stack.tail_used
-        logp = self.head.forward(x, window['row_idx_id'] if compact else window['row_idx'], window['labels'], save, round_bf16)
-        if save:
-            self._ctx['window'] = window
-            self._ctx['tail'] = compact
-        return logp
+        return x, bool(want_tail and stack.tail_used)
 
     def response_scores(self, input_ids, attention_mask, window, pixel_values=None, save=False, image_features=None,
                         all_scores=False, **mm):
         """Score-head models: fp32 scores on the window rows (critic values / reward scores).  all_scores=True additionally
         returns ScoreModelOutput.scores [N, T] of the same forward (no gradient flows through it): what the reference's
         RMTrainer.loss reports as higher_rewards / lower_rewards (trainers/text_to_text/rm.py:110-130)."""
-        x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features, **mm)
-        sc = self.head.forward(x, window['row_idx'], None, save)
+        if all_scores:
+            x, compact = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features, **mm), False
+        else:       # critic values / reward scores on the window rows: nothing else of the last layer is read
+            x, compact = self._forward_to_window(window, None, mm, input_ids, attention_mask, pixel_values, save, image_features)
+        sc = self.head.forward(x, window['row_idx_id'] if compact else window['row_idx'], None, save)
         if save:
             self._ctx['window'] = window
+            self._ctx['tail'] = compact
         if all_scores:
             N, T = input_ids.shape
             return sc, self.head.scores_all(x)[:N * T].view(N, T)
@@ -736,10 +746,7 @@ class NativeCausalLM:
         return self.head.scores_all(x)[:N * T].view(N, T)
 
     def backward_from_dlogp(self, dlogp, on_layer_done=None):
-        if self._ctx.get('tail', False):
-            dres = self.head.backward(dlogp, self._ctx['window']['inv_map'], self._zero_row, compact=True)
-        else:
-            dres = self.head.backward(dlogp, self._ctx['window']['inv_map'], self._zero_row)
+        dres = self.head.backward(dlogp, self._ctx['window']['inv_map'], self._zero_row, compact=bool(self._ctx.get('tail', False)))
         self.backward_stream(dres, on_layer_done)
         self._ctx = None
 

@@ -50,14 +50,24 @@ def build_window(input_ids: torch.Tensor, response_lens, pad_token_id: int):
         'row_off': torch.from_numpy(off[:-1].astype(np.int32)).to(dev, non_blocking=True),
         # for the dead-row elimination of the last decoder layer (modeling.LlamaStack.forward `tail`): the window rows as an identity gather, the first query
         # position anybody consumes per sequence, and the share of the causal attention work that remains (host ints: the bench's FLOP count)
-        'row_idx_id': torch.arange(rows_pad, dtype=torch.int64, device=dev),
-        'tail_qskip': torch.from_numpy((T - R).astype(np.int32)).to(dev, non_blocking=True),
-        'tail_frac': float(np.mean(1.0 - ((T - R) // 64 * 64 / T) ** 2)) if N else 1.0,
+        **tail_fields(row_idx, rows, rows_pad, N, T, dev),
     }
     labels = torch.zeros(rows_pad, dtype=torch.int64, device=dev)
     ops.window_labels(input_ids.contiguous(), pad_token_id, w['resp_len'], w['row_off'], labels)
     w['labels'] = labels
     return w
+
+
+def tail_fields(row_idx: np.ndarray, rows: int, rows_pad: int, N: int, T: int, dev) -> dict:
+    """What the dead-row elimination of the last decoder layer (modeling.LlamaStack.forward `tail`) needs from a window: the window rows as an identity
+    gather, per sequence the first query position anybody consumes (T: none) and the share of the causal attention work that remains.  Host arithmetic."""
+    q = np.full(N, T, dtype=np.int64)
+    if rows:
+        r = row_idx[:rows]
+        np.minimum.at(q, r // T, r % T)
+    return {'row_idx_id': torch.arange(rows_pad, dtype=torch.int64, device=dev),
+            'tail_qskip': torch.from_numpy(q.astype(np.int32)).to(dev, non_blocking=True),
+            'tail_frac': float(np.mean(1.0 - (q // 64 * 64 / T) ** 2)) if N else 1.0}
 
 
 def build_pack_plan(input_ids: torch.Tensor, attention_mask, window, meta_info=None):
@@ -263,7 +273,7 @@ def build_span_window(input_ids: torch.Tensor, start: int):
     labels[:rows] = input_ids[:, start + 1:].reshape(-1)
     return {'N': N, 'T': T, 'W': W, 'rows': rows, 'rows_pad': rows_pad,
             'row_idx': torch.from_numpy(row_idx).to(dev, non_blocking=True),
-            'inv_map': torch.from_numpy(inv).to(dev, non_blocking=True), 'labels': labels}
+            'inv_map': torch.from_numpy(inv).to(dev, non_blocking=True), 'labels': labels, **tail_fields(row_idx, rows, rows_pad, N, T, dev)}
 
 
 def build_tail_window(input_ids: torch.Tensor, response_lens):
@@ -292,7 +302,7 @@ def build_tail_window(input_ids: torch.Tensor, response_lens):
     return {'N': N, 'T': T, 'rows': rows, 'rows_pad': rows_pad, 'max_len': L, 'row_idx': ridx,
             'inv_map': torch.from_numpy(inv).to(dev, non_blocking=True),
             'seq_off': torch.from_numpy(off.astype(np.int32)).to(dev, non_blocking=True),
-            'flat_to_padded': torch.from_numpy(f2p).to(dev, non_blocking=True), 'labels': labels}
+            'flat_to_padded': torch.from_numpy(f2p).to(dev, non_blocking=True), 'labels': labels, **tail_fields(row_idx, rows, rows_pad, N, T, dev)}
 
 
 def build_label_window(labels: torch.Tensor, ignore_index: int = -100, device=None):
@@ -317,7 +327,8 @@ def build_label_window(labels: torch.Tensor, ignore_index: int = -100, device=No
     lbl[:rows] = tgt[n_i, j_i]
     dev = labels.device if device is None else torch.device(device)
     return {'N': N, 'T': T, 'rows': rows, 'rows_pad': rows_pad, 'row_idx': torch.from_numpy(row_idx).to(dev, non_blocking=True),
-            'inv_map': torch.from_numpy(inv).to(dev, non_blocking=True), 'labels': torch.from_numpy(lbl).to(dev, non_blocking=True)}
+            'inv_map': torch.from_numpy(inv).to(dev, non_blocking=True), 'labels': torch.from_numpy(lbl).to(dev, non_blocking=True),
+            **tail_fields(row_idx, rows, rows_pad, N, T, dev)}
 
 
 def pad_rows(flat_2d: torch.Tensor, rows_pad: int) -> torch.Tensor:
