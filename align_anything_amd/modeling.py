@@ -712,7 +712,7 @@ class NativeCausalLM:
                      and 'position_ids' not in mm and 'kv_sink' not in mm and mm.get('kv_len') is None)
         if want_tail:       # gather_*: window row -> row of the attention output ([N, T] layout) / of the stack's rows; scatter_*: the inverse maps (-1: not a window row)
             stack.tail = pack['tail'] if pack is not None else {
-                'gather_attn': window['row_idx'], 'gather_x': window['row_idx'], 'scatter_attn': window['inv_map'], 'scatter_x': window['inv_map'],
+                'gather_attn': window['tail_gather'], 'gather_x': window['tail_gather'], 'scatter_attn': window['inv_map'], 'scatter_x': window['inv_map'],
                 'qskip': window['tail_qskip'], 'frac': window['tail_frac']}
         try:
             x = self.forward_stream(input_ids, attention_mask, pixel_values, save, image_features, **mm)

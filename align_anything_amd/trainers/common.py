@@ -65,7 +65,13 @@ def tail_fields(row_idx: np.ndarray, rows: int, rows_pad: int, N: int, T: int, d
     if rows:
         r = row_idx[:rows]
         np.minimum.at(q, r // T, r % T)
+    # the gather index of the window rows with its PAD entries pointing at the first window row, not at row 0: the attention output of a skipped query block is
+    # never written (uninitialised memory, possibly NaN), and a pad row that copied it would meet its exactly-zero gradient as 0 x NaN in the weight gradients
+    # (and send a NaN through the MoE router)
+    ga = row_idx.copy()
+    ga[rows:] = row_idx[0] if rows else 0
     return {'row_idx_id': torch.arange(rows_pad, dtype=torch.int64, device=dev),
+            'tail_gather': torch.from_numpy(ga).to(dev, non_blocking=True),
             'tail_qskip': torch.from_numpy(q.astype(np.int32)).to(dev, non_blocking=True),
             'tail_frac': float(np.mean(1.0 - (q // 64 * 64 / T) ** 2)) if N else 1.0}
 
@@ -170,7 +176,8 @@ def build_pack_plan(input_ids: torch.Tensor, attention_mask, window, meta_info=N
     w['inv_map'] = inv_t
     plan['window'] = w
     if 'tail_qskip' in window:       # the last layer on the window rows only (modeling.LlamaStack.forward `tail`): attention rows by [N, T] slot, stack rows by packed row
-        plan['tail'] = {'gather_attn': ri, 'gather_x': w['row_idx'], 'scatter_attn': window['inv_map'], 'scatter_x': inv_t,
+        ga = window['tail_gather']
+        plan['tail'] = {'gather_attn': ga, 'gather_x': s2r[ga].long().clamp(min=0), 'scatter_attn': window['inv_map'], 'scatter_x': inv_t,
                         'qskip': window['tail_qskip'], 'frac': window['tail_frac']}
     del plan['_inv_host']
     return plan
