@@ -109,3 +109,24 @@ def test_last_moe_layer_on_the_window_rows_only(share, monkeypatch):
     worst = max((rel_err(g1[n], g0[n]), n) for n in g0 if float(g0[n].norm()) > 1e-6)
     dump(f'parity_tail_prune_qwen3moe{"_packed" if share else ""}.txt', f'fp32{" + shared-prompt packing" if share else ""}: log-probs / loss bit-identical; worst gradient rel_err {worst[0]:.2e} ({worst[1]}) over {len(g0)} tensors\n')
     assert worst[0] < 5e-6, worst
+
+
+@pytest.mark.parametrize('share', [False, True])
+def test_no_kernel_of_the_step_reads_uninitialised_memory(share, monkeypatch):
+    """torch's deterministic mode fills every `torch.empty` with NaN (torch.utils.deterministic.fill_uninitialized_memory).  A whole DPO step under it -- default
+    path and shared-prompt packing, dead-row elimination on -- must give the bits of the ordinary run: no kernel reads a row it (or a predecessor) did not write."""
+    outs = []
+    for fill in (False, True):
+        if fill:
+            torch.use_deterministic_algorithms(True, warn_only=True)
+            torch.utils.deterministic.fill_uninitialized_memory = True
+            assert bool(torch.isnan(torch.empty(4096, device=dev())).all()) and bool(torch.isnan(torch.empty((64, 64), dtype=torch.bfloat16, device=dev()).float()).all())
+        try:
+            lp, rlp, loss, grads, used = _step('bf16', True, monkeypatch, share)
+        finally:
+            torch.use_deterministic_algorithms(False)
+        outs.append((lp, rlp, loss, grads))
+        assert used
+    (lp0, rlp0, l0, g0), (lp1, rlp1, l1, g1) = outs
+    assert l0 == l1 and torch.equal(lp0, lp1) and torch.equal(rlp0, rlp1)
+    assert all(bool(torch.isfinite(g1[n]).all()) and torch.equal(g0[n], g1[n]) for n in g0)
