@@ -110,6 +110,15 @@ void gemm_kernel(const GemmParams p) {
             }
             return;
         }
+    } else if constexpr (GRP == 3) {
+        // split-K (aa_gemm_splitk_bf16): blockIdx.y = chunk of the contraction, [k0, k0 + grp_strideB); the fp32 partial product goes to C + chunk * grp_strideC
+        // and splitk_reduce_kernel sums the chunks in order and applies the epilogue.  For few-row launches (a rollout's scoring forwards, M ~ 1000) whose
+        // weight matrix would otherwise stream through a quarter of the compute units.
+        const int k0 = blockIdx.y * (int)p.grp_strideB;
+        Kp = min((int)p.grp_strideB, p.K - k0);
+        Ap += A_T ? (long)k0 * p.lda : (long)k0;
+        Bp += B_N ? (long)k0 * p.ldb : (long)k0;
+        Cp = (void*)(reinterpret_cast<float*>(p.C) + (long)blockIdx.y * p.grp_strideC);
     }
 
     // ---- per-lane DMA source pointers (advance by one K-tile per stage)
@@ -590,6 +599,102 @@ static int launch_grouped(GemmParams& p, int E, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, GRP == 2 ? E : 1), dim3(WM * WN * 64), lds, st, p);
     AA_CHECK_LAUNCH("aa_gemm_grouped_bf16");
+    return AA_OK;
+}
+
+// ---- split-K for few-row launches.  out = epilogue(sum_s partial_s), the chunks summed in order (deterministic; fp32 association differs from the one-launch
+// kernel's single k-ordered chain, so results agree to fp32 rounding of the accumulator, not bit for bit).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long strideS, const GemmParams p) {
+    const long n4 = p.N >> 2, total = (long)p.M * n4;
+    const bool out_f32 = p.flags & AA_GEMM_OUT_F32, accum = p.flags & AA_GEMM_ACCUM;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / n4;
+        const int n = (int)(i % n4) * 4;
+        f32x4 a = *reinterpret_cast<const f32x4*>(ws + m * p.N + n);
+        for (int s2 = 1; s2 < S; ++s2) a += *reinterpret_cast<const f32x4*>(ws + (long)s2 * strideS + m * p.N + n);
+        float v[4] = {a[0], a[1], a[2], a[3]};
+        if (p.bias) {
+            const u16x4 b = *reinterpret_cast<const u16x4*>(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
+        }
+        if (p.act != AA_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gemm_act(rbf(v[e]), p.act);
+        }
+        if (p.residual) {
+            const u16x4 r = *reinterpret_cast<const u16x4*>(p.residual + m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) + bf2f(r[e]);
+        }
+        if (out_f32) {
+            float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            if (accum) o += *reinterpret_cast<const f32x4*>(c);
+            *reinterpret_cast<f32x4*>(c) = o;
+        } else {
+            bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n;
+            if (accum) {
+                const u16x4 old = *reinterpret_cast<const u16x4*>(c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bf2f(old[e]);
+            }
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+            *reinterpret_cast<u16x4*>(c) = o;
+        }
+    }
+}
+
+template <bool A_T, bool B_N>
+static int launch_splitk(GemmParams& q, int S, hipStream_t st) {
+    constexpr int BM = 256, BN = 128, WM = 4, WN = 2;
+    q.tiles_m = aa_cdiv(q.M, BM);
+    q.tiles_n = aa_cdiv(q.N, BN);
+    q.gm = pick_group(A_T, B_N, q.tiles_n, q.K);
+    constexpr int lds = 2 * (BM + BN) * BK * 2;
+    auto kern = gemm_kernel<BM, BN, WM, WN, A_T, B_N, true, 0, 3>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { aa_set_error("aa_gemm_splitk_bf16: cannot reserve %d B LDS: %s", lds, hipGetErrorString(e)); return AA_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(q.tiles_m * q.tiles_n, S), dim3(WM * WN * 64), lds, st, q);
+    AA_CHECK_LAUNCH("aa_gemm_splitk_bf16");
+    return AA_OK;
+}
+
+extern "C" int aa_gemm_splitk_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, const void* bias,
+                                   const void* residual, long ldr, int act, int flags, float* ws, int S, void* stream) {
+    AA_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0,
+               "aa_gemm_splitk_bf16: bad shape M=%d N=%d K=%d lda=%ld ldb=%ld ldc=%ld", M, N, K, lda, ldb, ldc);
+    AA_REQUIRE(S >= 2 && S <= 64 && ws != nullptr, "aa_gemm_splitk_bf16: %d chunks need an fp32 workspace of chunks x M x N", S);
+    AA_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)ws & 15) == 0, "aa_gemm_splitk_bf16: operands must be 16-byte aligned");
+    const bool a_t = flags & AA_GEMM_A_T, b_n = flags & AA_GEMM_B_N;
+    AA_REQUIRE(!a_t || b_n, "aa_gemm_splitk_bf16: layout A^T with K-contiguous B is not built");
+    if (a_t) AA_REQUIRE(M % 8 == 0, "aa_gemm_splitk_bf16: transposed A needs M %% 8 == 0 (got %d)", M);
+    int kc = aa_cdiv(aa_cdiv(K, S), BK) * BK;            // chunk length: a multiple of the k-tile
+    S = aa_cdiv(K, kc);
+    hipStream_t st = (hipStream_t)stream;
+    GemmParams q{};
+    q.A = (const bf16_t*)A; q.B = (const bf16_t*)B; q.C = ws;
+    q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = N;
+    q.act = AA_ACT_NONE; q.flags = (flags & (AA_GEMM_A_T | AA_GEMM_B_N)) | AA_GEMM_OUT_F32;
+    q.grp_strideB = kc; q.grp_strideC = (long)M * N;
+    int rc;
+    if (!a_t && !b_n) rc = launch_splitk<false, false>(q, S, st);
+    else if (!a_t && b_n) rc = launch_splitk<false, true>(q, S, st);
+    else rc = launch_splitk<true, true>(q, S, st);
+    if (rc != AA_OK) return rc;
+    GemmParams p{};
+    p.C = C; p.bias = (const bf16_t*)bias; p.residual = (const bf16_t*)residual;
+    p.M = M; p.N = N; p.K = K; p.ldc = ldc; p.ldr = ldr; p.act = act; p.flags = flags;
+    const long total = (long)M * (N >> 2);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)ws, S, (long)M * N, p);
+    AA_CHECK_LAUNCH("aa_gemm_splitk_bf16");
     return AA_OK;
 }
 

@@ -89,11 +89,43 @@ def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=Fals
     if sfx and out.dtype != f32:
         raise RuntimeError('gemm: fp32 operands need an fp32 output')
     FLOPS['gemm'] += 2.0 * M * N * K
-    call('aa_gemm_f32' if sfx else 'aa_gemm_bf16', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0),
-         b.stride(0), out.stride(0), _p(bias), _p(residual), ldr, int(act), flags, stream())
+    S = 0 if sfx else _splitk_chunks(M, N, K)
+    if S:       # few rows against a large weight matrix: the contraction in S chunks side by side (csrc/gemm.hip aa_gemm_splitk_bf16)
+        call('aa_gemm_splitk_bf16', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0), _p(bias), _p(residual),
+             ldr, int(act), flags, _splitk_ws(S * M * N, a.device).data_ptr(), S, stream())
+    else:
+        call('aa_gemm_f32' if sfx else 'aa_gemm_bf16', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0),
+             b.stride(0), out.stride(0), _p(bias), _p(residual), ldr, int(act), flags, stream())
     if prof is not None:
         prof.append((e0, event_record(), 2.0 * M * N * K, float(a.element_size()) * (M * K + N * K) + out.element_size() * M * N))
     return out
+
+
+# Split-K for few-row GEMMs (round 6).  A PPO rollout scores ONE sequence of ~800 tokens with four 7B models and trains on it: every projection is an
+# [~800, K] x [N, K]^T launch whose 256 x 128 tiles number 4 x N / 128 -- 112 workgroups for N = 3584, each streaming its slab of the weight matrix alone
+# (the down projection, K = 18944: 350 us against a 27 us weight stream; the gate_up input gradient, K = 37888: 800 us).  With the contraction cut into chunks
+# that run side by side every compute unit streams weights.  Rule: at most 1024 rows, K >= 2048, fewer than 192 tiles -> enough chunks (<= 8, >= 512 deep) for
+# ~450 work items.  AA_GEMM_SPLITK=0: off (A/B).
+SPLITK = os.environ.get('AA_GEMM_SPLITK', '1') != '0'
+_SPLITK_WS = {}
+
+
+def _splitk_chunks(M, N, K):
+    if not SPLITK or M > 1024 or K < 2048 or N % 8:
+        return 0
+    tiles = -(-M // 256) * -(-N // 128)
+    if tiles >= 192:
+        return 0
+    S = min(8, K // 512, -(-448 // tiles))
+    return S if S >= 2 else 0
+
+
+def _splitk_ws(n, device):
+    key = str(device)
+    ws = _SPLITK_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _SPLITK_WS[key] = torch.empty(max(n, 1 << 24), dtype=torch.float32, device=device)
+    return ws
 
 
 # executed-work counters (bench.py: MFMA fraction on the FLOPs the step really executes): 2*M*N*K per GEMM launch,

@@ -147,6 +147,12 @@ int aa_attn_set_impl(int impl);
 int aa_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,
                  long ldc, const void* bias, const void* residual, long ldr, int act, int flags,
                  void* stream);
+/* Split-K form of aa_gemm_bf16 for few-row launches (M ~ 1000 rows against a 7B weight matrix: a PPO rollout's scoring forwards and its rl_step,
+ * align_anything/trainers/text_to_text/ppo.py:224-289): the contraction is cut into S chunks that run side by side (blockIdx.y), their fp32 partial products
+ * land in `ws` (S x M x N floats, caller-owned) and one pass sums them in order and applies the same epilogue.  Deterministic; equal to aa_gemm_bf16 up to the
+ * fp32 association of the accumulator. */
+int aa_gemm_splitk_bf16(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, const void* bias,
+                        const void* residual, long ldr, int act, int flags, float* ws, int S, void* stream);
 int aa_gemm_set_tile(int tile);
 int aa_gemm_set_group(int gm);   /* tile-group height of the L2-aware tile order (0 = heuristic: 4, or 3 for NN with wide N) */
 /* hf:models/llama/modeling_llama.py:62-67 LlamaRMSNorm */

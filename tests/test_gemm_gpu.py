@@ -195,3 +195,44 @@ def test_fused_epilogues_are_bit_identical_to_the_unfused_kernels():
             assert_close(res[0], ops.swiglu_bwd(gu, dact), rtol=1.6e-2, atol=2e-2, what='glu bwd vs unfused pieces')
     finally:
         ops.gemm_set_fuse(True)
+
+
+@pytest.mark.parametrize('case', ['nt_residual', 'nt_bias_act', 'nn', 'tn_f32_accumulate'])
+def test_split_k_for_few_row_launches_matches_the_one_launch_kernel(case, monkeypatch):
+    """ops.gemm cuts the contraction of a few-row launch ([~800, K] against a 7B weight matrix: a PPO rollout's scoring forwards, ppo.py:224-289) into chunks that
+    run side by side (aa_gemm_splitk_bf16) and sums their fp32 partial products in order.  Against the one-launch kernel (AA_GEMM_SPLITK off): equal up to the
+    fp32 association of the accumulator -- at most one bf16 ulp on an output --, and both within the usual bound of the fp32 reference."""
+    from align_anything_amd import ops
+    from tests.util import rel_err
+    g = torch.Generator(device='cpu').manual_seed(11)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    M = 832
+    kw, out0 = {}, None
+    if case == 'nt_residual':           # down projection of Qwen2-VL-7B at one 832-token sequence
+        a, b = mk(M, 18944), mk(3584, 18944); kw = dict(residual=mk(M, 3584))
+    elif case == 'nt_bias_act':
+        a, b = mk(M, 3584), mk(4608, 3584); kw = dict(bias=mk(4608), act=1)
+    elif case == 'nn':                  # gate_up input gradient: K = 37888
+        a, b = mk(M, 37888), mk(37888, 3584); kw = dict(b_n=True)
+    else:                               # a weight gradient with few output rows, fp32 accumulate
+        a, b = mk(4096, 1024), mk(4096, 3584); kw = dict(a_t=True, b_n=True, accumulate=True)
+        out0 = torch.randn(1024, 3584, generator=g).to(dev())
+    got = []
+    for on in (False, True):
+        monkeypatch.setattr(ops, 'SPLITK', on)
+        Mq, Nq, Kq = (a.shape[1] if kw.get('a_t') else a.shape[0]), (b.shape[1] if kw.get('b_n') else b.shape[0]), (a.shape[0] if kw.get('a_t') else a.shape[1])
+        assert bool(ops._splitk_chunks(Mq, Nq, Kq)) == on
+        got.append(ops.gemm(a, b, out=out0.clone() if out0 is not None else None, **kw).float())
+    torch.cuda.synchronize()
+    ref = (a.float().t() if kw.get('a_t') else a.float()) @ (b.float() if kw.get('b_n') else b.float().t())
+    if 'bias' in kw:
+        ref = ref + kw['bias'].float()
+    if kw.get('act') == 1:
+        ref = torch.nn.functional.gelu(ref.to(torch.bfloat16).float())
+    if 'residual' in kw:
+        ref = ref.to(torch.bfloat16).float() + kw['residual'].float()
+    if out0 is not None:
+        ref = ref + out0
+    e = rel_err(got[1], got[0])
+    assert e < (1e-6 if out0 is not None else 2e-3), e
+    assert rel_err(got[1], ref) < 6e-3 and rel_err(got[0], ref) < 6e-3

@@ -84,6 +84,10 @@ PY
         AA_RMSB_WAVE=$v timeout 600 python bench.py --steps 8 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r06_bench_rmsb$v.json 2> gpurun_out/r06_bench_rmsb$v.err
         python -c "import json; d=json.load(open('gpurun_out/r06_bench_rmsb$v.json')); r=d['roofline']; k=[x for x in r['hbm_kernels'] if 'rmsnorm_bwd' in x['kernel']][0]; print('AA_RMSB_WAVE=$v', round(d['ms_per_step'],2), 'ms  rmsnorm_bwd', round(k['avg_ms']*1e3,1), 'us', round(k['frac_of_8TBs'],3), 'of 8 TB/s', round(k['ms_per_step'],2), 'ms/step  W', round(r.get('power_w_mean') or 0), 'MHz', round(r.get('sclk_mhz_mean') or 0), d['config'].get('losses_timed_steps', [])[:2])" || tail -3 gpurun_out/r06_bench_rmsb$v.err
       done ;;
+    rocprof_ppo)     # rocprofv3 --kernel-trace --stats of the PPO iteration (tools/bench_ppo.py)
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r06_prof_ppo && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof_ppo -o p -- python $R/tools/bench_ppo.py --iters 2 > $R/gpurun_out/r06_prof_ppo.log 2>&1 )
+      f=$(find gpurun_out/r06_prof_ppo -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r06_ppo_kernel_stats.csv; head -45 gpurun_out/r06_ppo_kernel_stats.csv | cut -c1-170; tail -2 gpurun_out/r06_prof_ppo.log | cut -c1-900
+      find gpurun_out/r06_prof_ppo -name "*kernel_trace.csv" -delete ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
