@@ -104,19 +104,37 @@ def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=Fals
 # Split-K for few-row GEMMs (round 6).  A PPO rollout scores ONE sequence of ~800 tokens with four 7B models and trains on it: every projection is an
 # [~800, K] x [N, K]^T launch whose 256 x 128 tiles number 4 x N / 128 -- 112 workgroups for N = 3584, each streaming its slab of the weight matrix alone
 # (the down projection, K = 18944: 350 us against a 27 us weight stream; the gate_up input gradient, K = 37888: 800 us).  With the contraction cut into chunks
-# that run side by side every compute unit streams weights.  Rule: at most 1024 rows, K >= 2048, fewer than 192 tiles -> enough chunks (<= 8, >= 512 deep) for
-# ~450 work items.  AA_GEMM_SPLITK=0: off (A/B).
-SPLITK = os.environ.get('AA_GEMM_SPLITK', '1') != '0'
+# that run side by side every compute unit streams weights.  Rule: at most 1024 rows, K >= 1024, fewer than 192 tiles -> enough chunks (<= 8, >= 256 deep) for
+# ~450 work items.  AA_GEMM_SPLITK=0: off everywhere (A/B).
+SPLITK_ALLOWED = os.environ.get('AA_GEMM_SPLITK', '1') != '0'
+SPLITK = False          # on inside `few_row_gemms` scopes only: the PPO / GRPO rollout, scoring forwards and update (their M is one or a few sequences)
 _SPLITK_WS = {}
 
 
+def few_row_gemms(fn):
+    """Decorator: ops.gemm may cut few-row launches along K inside `fn` (see _splitk_chunks).  Scoped to the RL trainers' steps rather than switched on for the
+    process: the split changes the fp32 association of the accumulator, and the preference trainers' parity envelopes (random-init, chaotic at 32 layers; the MoE
+    router's top-k) are pinned with the one-launch kernel."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        global SPLITK
+        old, SPLITK = SPLITK, SPLITK_ALLOWED
+        try:
+            return fn(*a, **kw)
+        finally:
+            SPLITK = old
+    return wrapped
+
+
 def _splitk_chunks(M, N, K):
-    if not SPLITK or M > 1024 or K < 2048 or N % 8:
+    if not SPLITK or M > 1024 or K < 1024 or N % 8:
         return 0
     tiles = -(-M // 256) * -(-N // 128)
     if tiles >= 192:
         return 0
-    S = min(8, K // 512, -(-448 // tiles))
+    S = min(8, K // 256, -(-448 // tiles))
     return S if S >= 2 else 0
 
 

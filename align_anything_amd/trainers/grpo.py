@@ -131,6 +131,7 @@ class GRPOTrainer:
         self.actor_model.module.train(mode)
 
     # ------------------------------------------------------------------ grpo.py:212-227
+    @ops.few_row_gemms
     def generate_completions(self, prompt_batch, generator=None):
         """`generate(num_return_sequences=G, do_sample=True)`: row b*G+g is sample g of prompt b (HF expands the
         batch with repeat_interleave before sampling)."""
@@ -178,6 +179,7 @@ class GRPOTrainer:
         return lp[:w['rows']].view(w['N'], w['W']), w
 
     # ------------------------------------------------------------------ grpo.py:257-329
+    @ops.few_row_gemms
     def train_step(self, prompt_batch, generator=None, sequences=None, rewards=None):
         """`sequences` / `rewards` may be injected (tests, external samplers or rule-based rewards); otherwise they come
         from `generate_completions` / `compute_rewards` as in the reference."""
@@ -243,6 +245,7 @@ class GRPOTrainer:
             self.save()
         return history
 
+    @ops.few_row_gemms
     def actor_step(self, prompt_batch, generator=None):
         """One sampled completion per prompt (the evaluation loop's `generate`, base/rl_trainer.py:302-309)."""
         from ..generation import generate

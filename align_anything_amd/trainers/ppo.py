@@ -221,6 +221,7 @@ class PPOTrainer(PPOMath):
         return default if v is None else int(v)
 
     # ------------------------------------------------------------------ rollout (ppo.py:209-222, 244-289)
+    @ops.few_row_gemms
     def actor_step(self, prompt_batch, generator=None, sequences=None):
         """`self.actor_model.module.generate(**batch, generation_config=..., do_sample=True)` natively (ppo.py:209-222).
         `sequences` injects already generated rows (tests against the reference's fixture, external samplers)."""
@@ -237,6 +238,7 @@ class PPOTrainer(PPOMath):
                        pixel_values=prompt_batch.get('pixel_values'), generator=generator)
         return {'input_ids': seq, 'attention_mask': seq.ne(pad)}
 
+    @ops.few_row_gemms
     def rollout(self, prompt_only_batch, generator=None, sequences=None):
         """One micro-batch of experience: generate, score, log-probs of actor and reference (all no-grad)."""
         actor_batch = self.actor_step(prompt_only_batch, generator, sequences)
@@ -284,6 +286,7 @@ class PPOTrainer(PPOMath):
         return lp[:w['rows']].view(w['N'], w['W']), w
 
     # ------------------------------------------------------------------ PTX mix-in (ppo.py:400-408)
+    @ops.few_row_gemms
     def ptx_step(self, ptx_batch):
         """One supervised micro-step on the actor with the pre-training / SFT batch (`input_ids`, `labels`, `attention_mask`):
         backward of ptx_coeff * (HF causal-LM loss), logged unscaled -- the native form of the supervised loss is trainers/sft.py.
@@ -395,6 +398,7 @@ class PPOTrainer(PPOMath):
         return save_slice(self, model or self.actor_model, tag, output_dir)
 
     # ------------------------------------------------------------------ update (ppo.py:309-398)
+    @ops.few_row_gemms
     def rl_step(self, inference_batch, training_batch):
         old_log_probs = training_batch['log_probs'].float()
         ref_log_probs = training_batch['ref_log_probs'].float()

@@ -40,6 +40,7 @@ class PPOTrainerTI2T(PPOTrainer):
         lens = (am.sum(1) - prompt_batch['input_ids'].ne(pad).sum(1)).tolist()      # one host read per rollout
         return dict(self._mm(prompt_batch), input_ids=seq, attention_mask=am.to(torch.int64)), [int(x) for x in lens]
 
+    @ops.few_row_gemms
     def actor_step(self, prompt_batch, generator=None):
         from ..generation import generate
         from .common import cfg_get
@@ -65,6 +66,7 @@ class PPOTrainerTI2T(PPOTrainer):
         flat = fn(batch['input_ids'], batch['attention_mask'], w, pixel_values=mm.pop('pixel_values', None), save=save, **mm)
         return flat_to_padded(flat, w)
 
+    @ops.few_row_gemms
     def rollout(self, prompt_batch, generator=None, sequences=None):
         actor_batch, response_lens = (self.actor_step(prompt_batch, generator) if sequences is None
                                       else self.finish_sequences(prompt_batch, sequences))
@@ -84,6 +86,7 @@ class PPOTrainerTI2T(PPOTrainer):
         return actor_batch, training
 
     # ------------------------------------------------------------------ ppo.py:271-379
+    @ops.few_row_gemms
     def rl_step(self, inference_batch, training_batch):
         old_log_probs = training_batch['log_probs'].float().contiguous()
         ref_log_probs = training_batch['ref_log_probs'].float().contiguous()
