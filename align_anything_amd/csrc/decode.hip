@@ -203,6 +203,25 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     }
 }
 
+// AA_DECODE_R6=0: the round-5 launch rules (16 waves for every narrow deep strip launch, two key steps in flight in the cache attention) -- same-box A/B
+static bool decode_r6() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("AA_DECODE_R6"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+
+// compute units of the current device (cached per device)
+static int skinny_cus() {
+    static int cus_of[AA_MAX_DEVICES] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= AA_MAX_DEVICES) return 256;
+    if (cus_of[dev] == 0) {
+        int cus = 0;
+        cus_of[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
+    }
+    return cus_of[dev];
+}
+
 template <int PRO, int EPI = 0>
 static void launch_skinny(const void* x, const void* W, void* out, int M, int N, int K, long ldx, long ldw, long ldo,
                           const void* bias, const void* residual, long ldr, const void* norm_w, float eps, hipStream_t st,
@@ -210,8 +229,11 @@ static void launch_skinny(const void* x, const void* W, void* out, int M, int N,
     // few column strips (N/16 < ~3 per CU): split K over 8 waves so enough loads are in flight per CU
     const bool wide = (N / 16) >= 768 || K < 2048;
     // narrow AND deep (the o / down / qkv projections of a 7B decoder: 224-288 strips on 256 CUs, K >= 3584): 16 waves per strip -- the launch is
-    // bound by its fixed costs, and twice the waves halve each wave's share of the stream (same-box PPO A/B: 3.181 -> 3.118 ms per position)
-    if (!wide && K >= 3584) {
+    // bound by its fixed costs, and twice the waves halve each wave's share of the stream (same-box PPO A/B: 3.181 -> 3.118 ms per position).
+    // Only while every strip finds a CU at once: a 16-wave workgroup of 66 - 107 VGPRs has a CU to itself (4 - 7 waves per SIMD), so a launch of more
+    // strips than CUs runs in TWO rounds -- the q/k/v projection of Qwen2-VL-7B (288 strips) took 12.3 us against 5.7 us for the o projection's 224
+    // strips of the same depth (profiles/r05_ppo_kernel_stats.csv).  Such launches get 8 waves per strip (two workgroups per CU: one round).
+    if (!wide && K >= 3584 && (aa_cdiv(N, 16) <= skinny_cus() || !decode_r6())) {
         hipLaunchKernelGGL((gemm_skinny_kernel<16, PRO, EPI>), dim3(aa_cdiv(N, 16)), dim3(1024), 0, st,
                            (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
                            (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1, (const bf16_t*)norm_w, eps, epi);
@@ -451,7 +473,7 @@ extern "C" int aa_decode_rope_cache(void* qkv, long ld, int N, int H, int Hkv, i
 // either is used: the loop is a chain of dependent online-softmax updates, so memory parallelism has to come from the
 // loads); partial (m, l, acc) merged through LDS.  NW = 8 when H*N alone would leave CUs idle and waves scarce
 // (a 4-sequence rollout of a 32-head model is 128 workgroups on 256 CUs), 4 otherwise.
-template <int HD, int NW>
+template <int HD, int NW, int U>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __restrict__ q, long ldq,
                                                               const bf16_t* __restrict__ Kc,
                                                               const bf16_t* __restrict__ Vc, long ldc, int Tmax,
@@ -476,28 +498,53 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
     float m = -INFINITY, l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bf16_t* kb = Kc + (long)n * Tmax * ldc + hk * HD + sub * 8;
     const bf16_t* vb = Vc + (long)n * Tmax * ldc + hk * HD + sub * 8;
-    for (int j0 = s0 + wave * KPW; j0 < s1; j0 += 2 * STRIDE) {
-        const int ja = j0 + kg, jb = ja + STRIDE;
-        const bool oka = ja < s1, okb = jb < s1;
-        const long ra = oka ? ja : s1 - 1, rb = okb ? jb : s1 - 1;
-        const u16x8 ka = *reinterpret_cast<const u16x8*>(kb + ra * ldc);
-        const u16x8 kb2 = *reinterpret_cast<const u16x8*>(kb + rb * ldc);
-        const u16x8 va = *reinterpret_cast<const u16x8*>(vb + ra * ldc);
-        const u16x8 vb2 = *reinterpret_cast<const u16x8*>(vb + rb * ldc);
-        float sa = 0.f, sb = 0.f;
+    // U wave steps per trip (2, or 4 when the launch is a handful of workgroups: one sequence of a 28-head model is 28 workgroups walking ~800 keys in
+    // trips of dependent loads -- the trip count, not the bytes, is its time): all 2 U rows are requested before any is used
+    for (int j0 = s0 + wave * KPW; j0 < s1; j0 += U * STRIDE) {
+        bool ok[U];
+        u16x8 kf[U], vf[U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { sa += qv[e] * bf2f(ka[e]); sb += qv[e] * bf2f(kb2[e]); }
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + kg + u * STRIDE;
+            ok[u] = j < s1;
+            const long r = ok[u] ? j : s1 - 1;
+            kf[u] = *reinterpret_cast<const u16x8*>(kb + r * ldc);
+            vf[u] = *reinterpret_cast<const u16x8*>(vb + r * ldc);
+        }
+        float sc[U];
 #pragma unroll
-        for (int off = LPK / 2; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
-        sa = oka ? sa : -INFINITY;
-        sb = okb ? sb : -INFINITY;
-        const float mn = fmaxf(m, fmaxf(sa, sb));
+        for (int u = 0; u < U; ++u) {
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t += qv[e] * bf2f(kf[u][e]);
+            sc[u] = t;
+        }
+#pragma unroll
+        for (int off = LPK / 2; off > 0; off >>= 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) sc[u] += __shfl_xor(sc[u], off, 64);
+        }
+        float smax = -INFINITY;
+#pragma unroll
+        for (int u = U - 1; u >= 0; --u) { sc[u] = ok[u] ? sc[u] : -INFINITY; smax = fmaxf(sc[u], smax); }
+        const float mn = fmaxf(m, smax);
         const float ms = (mn == -INFINITY) ? 0.f : mn;
-        const float alpha = exp2f(m - ms), pa = exp2f(sa - ms), pb = exp2f(sb - ms);
-        m = mn;
-        l = l * alpha + pa + pb;
+        const float alpha = exp2f(m - ms);
+        float p[U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = acc[e] * alpha + pa * bf2f(va[e]) + pb * bf2f(vb2[e]);
+        for (int u = 0; u < U; ++u) p[u] = exp2f(sc[u] - ms);
+        m = mn;
+        float lt = l * alpha;
+#pragma unroll
+        for (int u = 0; u < U; ++u) lt += p[u];
+        l = lt;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = acc[e] * alpha;
+#pragma unroll
+            for (int u = 0; u < U; ++u) t += p[u] * bf2f(vf[u][e]);
+            acc[e] = t;
+        }
     }
     if (sub == 0) { sm_m[wave][kg] = m; sm_l[wave][kg] = l; }
 #pragma unroll
@@ -531,11 +578,12 @@ extern "C" int aa_attn_decode(const void* q, long ldq, const void* Kc, const voi
     AA_REQUIRE((ldq | ldc | ldo) % 8 == 0, "aa_attn_decode: leading dims must be multiples of 8");
     hipStream_t st = (hipStream_t)stream;
     const bool few = (long)H * N < 512;      // fewer than two workgroups per CU: give each one 8 waves
-#define AA_LAUNCH_ATTN_DECODE(HD_, NW_)                                                                                       \
-    hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_>), dim3(H, N), dim3(NW_ * 64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)Kc, \
+    const bool handful = (long)H * N < 128 && decode_r6();   // one or two sequences: four key steps in flight per wave (half the dependent trips)
+#define AA_LAUNCH_ATTN_DECODE(HD_, NW_, U_)                                                                                   \
+    hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_, U_>), dim3(H, N), dim3(NW_ * 64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)Kc, \
                        (const bf16_t*)Vc, ldc, Tmax, start, len, (bf16_t*)o, ldo, H, Hkv, scale)
-    if (hd == 128) { if (few) AA_LAUNCH_ATTN_DECODE(128, 8); else AA_LAUNCH_ATTN_DECODE(128, 4); }
-    else { if (few) AA_LAUNCH_ATTN_DECODE(64, 8); else AA_LAUNCH_ATTN_DECODE(64, 4); }
+    if (hd == 128) { if (handful) AA_LAUNCH_ATTN_DECODE(128, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(128, 8, 2); else AA_LAUNCH_ATTN_DECODE(128, 4, 2); }
+    else { if (handful) AA_LAUNCH_ATTN_DECODE(64, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(64, 8, 2); else AA_LAUNCH_ATTN_DECODE(64, 4, 2); }
 #undef AA_LAUNCH_ATTN_DECODE
     AA_CHECK_LAUNCH("aa_attn_decode");
     return AA_OK;

@@ -92,20 +92,26 @@ def test_decode_rope_cache_equals_rope_then_index_put():
         assert torch.equal(a[:, :H * hd], b[:, :H * hd]) and torch.equal(ca, cb), (N, H, Hkv, hd)
 
 
-@pytest.mark.parametrize('hd,H,Hkv', [(128, 4, 4), (64, 4, 2)])
-def test_decode_attention_vs_reference(hd, H, Hkv):
+@pytest.mark.parametrize('hd,H,Hkv,N,Tmax', [(128, 4, 4, 3, 300), (64, 4, 2, 3, 300), (128, 28, 4, 1, 900), (128, 32, 8, 5, 300), (64, 32, 32, 16, 300)])
+def test_decode_attention_vs_reference(hd, H, Hkv, N, Tmax):
+    """aa_attn_decode against softmax(q K^T) V in fp32 on every launch form: H N < 128 (one or two sequences: four key steps in flight per wave, round 6),
+    < 512 (8 waves, two steps), beyond (4 waves); left-padded and full rows, a one-key row."""
     from align_anything_amd import ops
-    N, Tmax = 3, 300
     q = randn_bf16(N, H * hd, seed=1)
     cache = randn_bf16(N * Tmax, 2 * Hkv * hd, seed=2)
     kw = Hkv * hd
-    start = torch.tensor([0, 17, 120], dtype=torch.int32, device=dev())
-    length = torch.tensor([300, 131, 121], dtype=torch.int32, device=dev())
+    s_list = [0, 17, Tmax - 180, 3, 0][:N] + [5 * i % 40 for i in range(max(0, N - 5))]
+    l_list = [Tmax, 131, Tmax - 179, Tmax - 1, 64][:N] + [Tmax - 7 * i % 50 for i in range(max(0, N - 5))]
+    if N == 1:
+        s_list, l_list = [0], [Tmax - 70]
+    start = torch.tensor(s_list, dtype=torch.int32, device=dev())
+    length = torch.tensor(l_list, dtype=torch.int32, device=dev())
     o = ops.attn_decode(q, cache, cache[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
     torch.cuda.synchronize()
     cf = cache.float().view(N, Tmax, 2, Hkv, hd)
     for n in range(N):
         s0, s1 = int(start[n]), int(length[n])
+        assert 0 <= s0 < s1 <= Tmax
         for h in range(H):
             hk = h // (H // Hkv)
             k = cf[n, s0:s1, 0, hk]; v = cf[n, s0:s1, 1, hk]

@@ -88,6 +88,12 @@ PY
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r06_prof_ppo && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof_ppo -o p -- python $R/tools/bench_ppo.py --iters 2 > $R/gpurun_out/r06_prof_ppo.log 2>&1 )
       f=$(find gpurun_out/r06_prof_ppo -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r06_ppo_kernel_stats.csv; head -45 gpurun_out/r06_ppo_kernel_stats.csv | cut -c1-170; tail -2 gpurun_out/r06_prof_ppo.log | cut -c1-900
       find gpurun_out/r06_prof_ppo -name "*kernel_trace.csv" -delete ;;
+    decode_ab)       # round-6 decode launch rules (8 waves per strip when a narrow launch has more strips than CUs; four key steps in flight in the cache attention at one or two sequences) against round 5's (AA_DECODE_R6=0): numerics, then the PPO iteration, alternating
+      timeout 900 python -m pytest tests/test_decode_gpu.py tests/test_llama3_gpu.py tests/test_ppo_gpu.py tests/test_grpo_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r06_decode_ab_tests.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/r06_decode_ab_tests.log | cut -c1-300
+      for v in 0 1 0 1; do
+        AA_DECODE_R6=$v timeout 400 python tools/bench_ppo.py --iters 2 > gpurun_out/r06_bench_ppo_r6_$v.json 2> gpurun_out/r06_bench_ppo_r6_$v.err
+        python -c "import json; d=json.loads([l for l in open('gpurun_out/r06_bench_ppo_r6_$v.json') if l.startswith('{')][-1]); print('AA_DECODE_R6=$v iteration', round(d['iteration_ms'],1), 'ms', {k: round(x,2) for k,x in d['split_ms'].items()}, {k: d[k] for k in d if 'position' in k})" || tail -3 gpurun_out/r06_bench_ppo_r6_$v.err
+      done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
