@@ -77,6 +77,25 @@ __device__ __forceinline__ void skinny_trip(const bf16_t* __restrict__ wp, const
     }
 }
 
+// The same k-steps in groups of four, software-pipelined (PIPE): the next group's fragments are requested BEFORE the MFMAs of the group that has arrived,
+// so a wave never drains its load queue between trips (a deep strip -- the down projection, 1184 k per wave -- is nine such trips).  Same k order and the
+// same accumulator per step parity as skinny_trip: bit-identical sums.
+template <int PRO>
+__device__ __forceinline__ void skinny_load4(const bf16_t* __restrict__ wp, const bf16_t* __restrict__ xp, const bf16_t* __restrict__ nwp,
+                                             int k, int K, float& ss, bf16x8 (&wf)[4], bf16x8 (&xf)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        wf[s] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + ((PRO == 3 || PRO == 4) ? (long)(k + s * 32) * 16 : (long)(k + s * 32))));
+        xf[s] = skinny_x<PRO>(xp, nwp, k + s * 32, K, ss);
+    }
+}
+__device__ __forceinline__ void skinny_mfma4(const bf16x8 (&wf)[4], const bf16x8 (&xf)[4], f32x4& acc0, f32x4& acc1) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], xf[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], xf[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2], xf[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[3], xf[3], acc1, 0, 0, 0);
+}
+
 // EPI: what the strip's 16 finished columns turn into (strip-major weights only, whose row ORDER inside a strip is free):
 //   0: out[m, n0 + 0..15]  (+ bias, + residual)
 //   1: SwiGLU.  The strip holds gate columns 8 s .. 8 s + 7 and the up values of the SAME columns (aa_swizzle_weights_perm_bf16 mode 1 of
@@ -90,7 +109,7 @@ struct SkinnyEpi {
     const int* pos; const bf16_t* cos_t; const bf16_t* sin_t; bf16_t* cache; long ldc; int Tmax; const int64_t* slot; int H, Hkv;
 };
 
-template <int NWAVE, int PRO, int EPI>
+template <int NWAVE, int PRO, int EPI, bool PIPE = false>
 __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                   const bf16_t* __restrict__ W, long ldw,
                                                                   bf16_t* __restrict__ out, long ldo,
@@ -128,8 +147,37 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     // fragments would otherwise push the kernel past 128 VGPRs and halve the waves that keep the HBM queue full).
     // (16 in flight -- 512 k per trip -- measured no different: 4.19 vs 4.20 ms per position, tools/gpu_skinny_ab.sh.)
     constexpr int S = PRO == 1 ? 4 : 8;
-    for (; k + S * 32 <= k_hi; k += S * 32) skinny_trip<PRO, S>(wp, xp, nwp, k, K, ss, acc0, acc1);
-    if constexpr (S > 4) { for (; k + 128 <= k_hi; k += 128) skinny_trip<PRO, 4>(wp, xp, nwp, k, K, ss, acc0, acc1); }   // a 16-wave strip's 224-k share: 4 + 2 + 1 steps
+    if constexpr (PIPE) {
+        if (k + 128 <= k_hi) {
+            bf16x8 wa[4], xa[4], wb[4], xb[4];
+            skinny_load4<PRO>(wp, xp, nwp, k, K, ss, wa, xa);
+            k += 128;
+            // the scheduling fences keep hipcc from sinking a group's loads below the MFMAs of the other one (it otherwise re-uses the fragment registers
+            // and drains the load queue to vmcnt(0) in the middle of the loop)
+            for (; k + 256 <= k_hi; k += 256) {
+                skinny_load4<PRO>(wp, xp, nwp, k, K, ss, wb, xb);
+                __builtin_amdgcn_sched_barrier(0);
+                skinny_mfma4(wa, xa, acc0, acc1);
+                __builtin_amdgcn_sched_barrier(0);
+                skinny_load4<PRO>(wp, xp, nwp, k + 128, K, ss, wa, xa);
+                __builtin_amdgcn_sched_barrier(0);
+                skinny_mfma4(wb, xb, acc0, acc1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (k + 128 <= k_hi) {
+                skinny_load4<PRO>(wp, xp, nwp, k, K, ss, wb, xb);
+                __builtin_amdgcn_sched_barrier(0);
+                skinny_mfma4(wa, xa, acc0, acc1);
+                skinny_mfma4(wb, xb, acc0, acc1);
+                k += 128;
+            } else {
+                skinny_mfma4(wa, xa, acc0, acc1);
+            }
+        }
+    } else {
+        for (; k + S * 32 <= k_hi; k += S * 32) skinny_trip<PRO, S>(wp, xp, nwp, k, K, ss, acc0, acc1);
+        if constexpr (S > 4) { for (; k + 128 <= k_hi; k += 128) skinny_trip<PRO, 4>(wp, xp, nwp, k, K, ss, acc0, acc1); }   // a 16-wave strip's 224-k share: 4 + 2 + 1 steps
+    }
     for (; k + 64 <= k_hi; k += 64) skinny_trip<PRO, 2>(wp, xp, nwp, k, K, ss, acc0, acc1);
     if (k < k_hi) {
         const bf16x8 wf = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (SWZ ? (long)k * 16 : (long)k)));
@@ -203,11 +251,19 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     }
 }
 
-// AA_DECODE_R6=0: the round-5 launch rules (16 waves for every narrow deep strip launch, two key steps in flight in the cache attention) -- same-box A/B
-static bool decode_r6() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("AA_DECODE_R6"); on = e ? atoi(e) : 1; }
-    return on != 0;
+// Launch rules (aa_decode_set_rules; env AA_DECODE_R6 sets the initial mask).  0: the round-5 rules (16 waves for every narrow deep strip launch, two key
+// steps in flight in the cache attention) -- same-box A/B.  bit 0: the round-6 wave rule + four key steps at a handful of sequences; bit 1: software-pipelined
+// trips in the deep 16-wave strips (the down projection); bit 2: eight key steps in flight instead of four.
+static int g_decode_rules = -1;
+static int decode_r6() {
+    if (g_decode_rules < 0) { const char* e = getenv("AA_DECODE_R6"); g_decode_rules = e ? atoi(e) : 1; }
+    return g_decode_rules;
+}
+extern "C" int aa_decode_set_rules(int mask, int* old) {
+    AA_REQUIRE(mask >= 0 && mask <= 7, "aa_decode_set_rules: mask %d (bits 0 - 2)", mask);
+    if (old) *old = decode_r6();
+    g_decode_rules = mask;
+    return AA_OK;
 }
 
 // compute units of the current device (cached per device)
@@ -233,10 +289,15 @@ static void launch_skinny(const void* x, const void* W, void* out, int M, int N,
     // Only while every strip finds a CU at once: a 16-wave workgroup of 66 - 107 VGPRs has a CU to itself (4 - 7 waves per SIMD), so a launch of more
     // strips than CUs runs in TWO rounds -- the q/k/v projection of Qwen2-VL-7B (288 strips) took 12.3 us against 5.7 us for the o projection's 224
     // strips of the same depth (profiles/r05_ppo_kernel_stats.csv).  Such launches get 8 waves per strip (two workgroups per CU: one round).
-    if (!wide && K >= 3584 && (aa_cdiv(N, 16) <= skinny_cus() || !decode_r6())) {
-        hipLaunchKernelGGL((gemm_skinny_kernel<16, PRO, EPI>), dim3(aa_cdiv(N, 16)), dim3(1024), 0, st,
-                           (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
-                           (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1, (const bf16_t*)norm_w, eps, epi);
+    if (!wide && K >= 3584 && (aa_cdiv(N, 16) <= skinny_cus() || !(decode_r6() & 1))) {
+        if (K >= 8192 && (decode_r6() & 2))      // deep: software-pipelined trips (bit-identical sums)
+            hipLaunchKernelGGL((gemm_skinny_kernel<16, PRO, EPI, true>), dim3(aa_cdiv(N, 16)), dim3(1024), 0, st,
+                               (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
+                               (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1, (const bf16_t*)norm_w, eps, epi);
+        else
+            hipLaunchKernelGGL((gemm_skinny_kernel<16, PRO, EPI>), dim3(aa_cdiv(N, 16)), dim3(1024), 0, st,
+                               (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, (const bf16_t*)bias,
+                               (const bf16_t*)residual, ldr, M, N, K, nullptr, 0, 1, (const bf16_t*)norm_w, eps, epi);
         return;
     }
     if (wide)
@@ -578,12 +639,13 @@ extern "C" int aa_attn_decode(const void* q, long ldq, const void* Kc, const voi
     AA_REQUIRE((ldq | ldc | ldo) % 8 == 0, "aa_attn_decode: leading dims must be multiples of 8");
     hipStream_t st = (hipStream_t)stream;
     const bool few = (long)H * N < 512;      // fewer than two workgroups per CU: give each one 8 waves
-    const bool handful = (long)H * N < 128 && decode_r6();   // one or two sequences: four key steps in flight per wave (half the dependent trips)
+    const bool handful = (long)H * N < 128 && (decode_r6() & 1);   // one or two sequences: four key steps in flight per wave (half the dependent trips)
 #define AA_LAUNCH_ATTN_DECODE(HD_, NW_, U_)                                                                                   \
     hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_, U_>), dim3(H, N), dim3(NW_ * 64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)Kc, \
                        (const bf16_t*)Vc, ldc, Tmax, start, len, (bf16_t*)o, ldo, H, Hkv, scale)
-    if (hd == 128) { if (handful) AA_LAUNCH_ATTN_DECODE(128, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(128, 8, 2); else AA_LAUNCH_ATTN_DECODE(128, 4, 2); }
-    else { if (handful) AA_LAUNCH_ATTN_DECODE(64, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(64, 8, 2); else AA_LAUNCH_ATTN_DECODE(64, 4, 2); }
+    const bool deep8 = handful && (decode_r6() & 4);         // bit 2: eight steps (512 keys of a head_dim-128 head per trip: a PPO rollout's 320 - 830 keys are one or two trips)
+    if (hd == 128) { if (deep8) AA_LAUNCH_ATTN_DECODE(128, 8, 8); else if (handful) AA_LAUNCH_ATTN_DECODE(128, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(128, 8, 2); else AA_LAUNCH_ATTN_DECODE(128, 4, 2); }
+    else { if (deep8) AA_LAUNCH_ATTN_DECODE(64, 8, 8); else if (handful) AA_LAUNCH_ATTN_DECODE(64, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(64, 8, 2); else AA_LAUNCH_ATTN_DECODE(64, 4, 2); }
 #undef AA_LAUNCH_ATTN_DECODE
     AA_CHECK_LAUNCH("aa_attn_decode");
     return AA_OK;

@@ -1140,6 +1140,15 @@ def moe_gemv(x, w3, row_expert, x_div):
     return out
 
 
+def decode_set_rules(mask: int) -> int:
+    """Launch rules of the decode kernels (aa_decode_set_rules: bit 0 = round-6 wave rule + four key steps in flight, bit 1 = pipelined deep strips; 0 = the
+    round-5 rules).  Returns the previous mask (A/B runs and the bit-identity tests)."""
+    import ctypes
+    old = ctypes.c_int(0)
+    call('aa_decode_set_rules', int(mask), ctypes.addressof(old))
+    return int(old.value)
+
+
 def attn_decode(q, kcache, vcache, Tmax, start, length, N, H, Hkv, hd, scale):
     out = torch.empty((N, H * hd), dtype=bf16, device=q.device)
     call('aa_attn_decode', q.data_ptr(), q.stride(0), kcache.data_ptr(), vcache.data_ptr(), kcache.stride(0), int(Tmax),

@@ -94,8 +94,8 @@ def test_decode_rope_cache_equals_rope_then_index_put():
 
 @pytest.mark.parametrize('hd,H,Hkv,N,Tmax', [(128, 4, 4, 3, 300), (64, 4, 2, 3, 300), (128, 28, 4, 1, 900), (128, 32, 8, 5, 300), (64, 32, 32, 16, 300)])
 def test_decode_attention_vs_reference(hd, H, Hkv, N, Tmax):
-    """aa_attn_decode against softmax(q K^T) V in fp32 on every launch form: H N < 128 (one or two sequences: four key steps in flight per wave, round 6),
-    < 512 (8 waves, two steps), beyond (4 waves); left-padded and full rows, a one-key row."""
+    """aa_attn_decode against softmax(q K^T) V in fp32 on every launch form: H N < 128 (one or two sequences: four or eight key steps in flight per wave,
+    round 6, aa_decode_set_rules), < 512 (8 waves, two steps), beyond (4 waves); left-padded and full rows, a one-key row."""
     from align_anything_amd import ops
     q = randn_bf16(N, H * hd, seed=1)
     cache = randn_bf16(N * Tmax, 2 * Hkv * hd, seed=2)
@@ -106,8 +106,17 @@ def test_decode_attention_vs_reference(hd, H, Hkv, N, Tmax):
         s_list, l_list = [0], [Tmax - 70]
     start = torch.tensor(s_list, dtype=torch.int32, device=dev())
     length = torch.tensor(l_list, dtype=torch.int32, device=dev())
-    o = ops.attn_decode(q, cache, cache[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
+    outs = {}
+    old = ops.decode_set_rules(0)
+    try:
+        for mask in (0, 1, 5):          # two, four and eight key steps in flight (the last two only when H N < 128)
+            ops.decode_set_rules(mask)
+            outs[mask] = ops.attn_decode(q, cache, cache[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
+    finally:
+        ops.decode_set_rules(old)
     torch.cuda.synchronize()
+    if H * N >= 128:
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[5])
     cf = cache.float().view(N, Tmax, 2, Hkv, hd)
     for n in range(N):
         s0, s1 = int(start[n]), int(length[n])
@@ -116,7 +125,8 @@ def test_decode_attention_vs_reference(hd, H, Hkv, N, Tmax):
             hk = h // (H // Hkv)
             k = cf[n, s0:s1, 0, hk]; v = cf[n, s0:s1, 1, hk]
             p = torch.softmax((k @ q[n, h * hd:(h + 1) * hd].float()) * hd ** -0.5, 0)
-            assert_close(o[n, h * hd:(h + 1) * hd], p @ v, rtol=2e-2, atol=1e-2, what=f'decode attn n{n} h{h}')
+            for mask, o in outs.items():
+                assert_close(o[n, h * hd:(h + 1) * hd], p @ v, rtol=2e-2, atol=1e-2, what=f'decode attn n{n} h{h} rules {mask}')
 
 
 def test_token_selection_kernels():
@@ -370,6 +380,38 @@ def test_strip_kernel_fused_epilogues_are_bit_identical_to_the_kernel_pairs(M):
         q = ops.gemm_skinny_rope_cache(x, ops.SwizzledWeight(w, 'rope128'), bias, H, Hkv, pos, cos, sin, cb, Tmax, slot)
         assert torch.equal(q, qkv[:, :H * hd]), (M, H, Hkv, 'q')
         assert torch.equal(ca, cb), (M, H, Hkv, 'cache')
+
+
+@pytest.mark.parametrize('M', [1, 5, 16])
+def test_decode_launch_rules_keep_the_numbers(M):
+    """Round 6 (aa_decode_set_rules).  Bit 1 -- software-pipelined trips in the deep 16-wave strips (the down projection, K = 18944 / 11008 / 14336: same k
+    order, same accumulator per step parity) -- must give every bit of the plain trips, on row-major and strip-major weights, with the residual epilogue.  Bit 0
+    changes the waves per strip of a narrow launch with more strips than CUs (q/k/v of Qwen2-VL-7B: 288 strips; fp32 partial sums are grouped differently):
+    equal to the 16-wave launch within fp32 rounding of the accumulator, and both within the usual bound of the fp32 reference."""
+    from align_anything_amd import ops
+    from tests.util import rel_err
+    old = ops.decode_set_rules(0)
+    try:
+        for (N, K) in [(3584, 18944), (4096, 11008), (4096, 14336), (3584, 8192 + 32)]:
+            x, w, res = randn_bf16(M, K, seed=1), randn_bf16(N, K, scale=0.05, seed=2), randn_bf16(M, N, seed=3)
+            sw = ops.SwizzledWeight(w)
+            got = {}
+            for mask in (0, 2):
+                ops.decode_set_rules(mask)
+                got[mask] = (ops.linear_small(x, w, residual=res), ops.linear_small(x, sw, residual=res))
+            assert torch.equal(got[0][0], got[2][0]) and torch.equal(got[0][1], got[2][1]) and torch.equal(got[2][0], got[2][1]), (M, N, K)
+            assert rel_err(got[2][0].float(), (x.float() @ w.float().t()).to(torch.bfloat16).float() + res.float()) < 6e-3
+        N, K = 4608, 3584          # 288 strips
+        x, w, b = randn_bf16(M, K, seed=4), randn_bf16(N, K, scale=0.05, seed=5), randn_bf16(N, seed=6)
+        sw = ops.SwizzledWeight(w)
+        outs = []
+        for mask in (0, 1):
+            ops.decode_set_rules(mask)
+            outs.append(ops.linear_small(x, sw, bias=b).float())
+        ref = x.float() @ w.float().t() + b.float()
+        assert rel_err(outs[1], outs[0]) < 2e-3 and rel_err(outs[0], ref) < 6e-3 and rel_err(outs[1], ref) < 6e-3
+    finally:
+        ops.decode_set_rules(old)
 
 
 @pytest.mark.parametrize('M', [1, 4, 16])

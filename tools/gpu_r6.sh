@@ -94,6 +94,12 @@ PY
         AA_DECODE_R6=$v timeout 400 python tools/bench_ppo.py --iters 2 > gpurun_out/r06_bench_ppo_r6_$v.json 2> gpurun_out/r06_bench_ppo_r6_$v.err
         python -c "import json; d=json.loads([l for l in open('gpurun_out/r06_bench_ppo_r6_$v.json') if l.startswith('{')][-1]); print('AA_DECODE_R6=$v iteration', round(d['iteration_ms'],1), 'ms', {k: round(x,2) for k,x in d['split_ms'].items()}, {k: d[k] for k in d if 'position' in k})" || tail -3 gpurun_out/r06_bench_ppo_r6_$v.err
       done ;;
+    decode_ab2)      # the further decode rules of round 6 (bit 1: pipelined deep strips; bit 2: eight key steps in flight): numerics, then the PPO iteration under masks 1 / 3 / 5 / 7, twice around
+      timeout 600 python -m pytest tests/test_decode_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r06_decode_ab2_tests.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/r06_decode_ab2_tests.log | cut -c1-300
+      for v in ${AA_AB2_MASKS:-1 3 5 7 1 3 5 7}; do
+        AA_DECODE_R6=$v timeout 400 python tools/bench_ppo.py --iters 2 > gpurun_out/r06_bench_ppo_r6_$v.json 2> gpurun_out/r06_bench_ppo_r6_$v.err
+        python -c "import json; d=json.loads([l for l in open('gpurun_out/r06_bench_ppo_r6_$v.json') if l.startswith('{')][-1]); print('AA_DECODE_R6=$v iteration', round(d['iteration_ms'],1), 'ms', {k: round(x,2) for k,x in d['split_ms'].items()}, {k: d[k] for k in d if 'position' in k})" || tail -3 gpurun_out/r06_bench_ppo_r6_$v.err
+      done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
