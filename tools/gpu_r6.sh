@@ -100,6 +100,12 @@ PY
         AA_DECODE_R6=$v timeout 400 python tools/bench_ppo.py --iters 2 > gpurun_out/r06_bench_ppo_r6_$v.json 2> gpurun_out/r06_bench_ppo_r6_$v.err
         python -c "import json; d=json.loads([l for l in open('gpurun_out/r06_bench_ppo_r6_$v.json') if l.startswith('{')][-1]); print('AA_DECODE_R6=$v iteration', round(d['iteration_ms'],1), 'ms', {k: round(x,2) for k,x in d['split_ms'].items()}, {k: d[k] for k in d if 'position' in k})" || tail -3 gpurun_out/r06_bench_ppo_r6_$v.err
       done ;;
+    decode_ab3)      # the strip kernel's epilogue operands (bias / residual; position -> cos / sin, cache slot) requested above the weight stream, against the build before it (libaa_hip_nohoist.so), both under rules 3: numerics, then the PPO iteration, alternating
+      timeout 900 python -m pytest tests/test_decode_gpu.py tests/test_llama3_gpu.py tests/test_ppo_gpu.py tests/test_grpo_gpu.py tests/test_qwen2vl_gpu.py tests/test_qwen3moe_gpu.py -q -x -m gpu -p no:cacheprovider -k "not width_pair" > gpurun_out/r06_decode_ab3_tests.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/r06_decode_ab3_tests.log | cut -c1-300
+      for v in libaa_hip_nohoist.so libaa_hip.so libaa_hip_nohoist.so libaa_hip.so; do
+        AA_DECODE_R6=3 AA_HIP_LIB=$R/align_anything_amd/$v timeout 400 python tools/bench_ppo.py --iters 2 > gpurun_out/r06_bench_ppo_$v.json 2> gpurun_out/r06_bench_ppo_$v.err
+        python -c "import json; d=json.loads([l for l in open('gpurun_out/r06_bench_ppo_$v.json') if l.startswith('{')][-1]); print('$v iteration', round(d['iteration_ms'],1), 'ms', {k: round(x,2) for k,x in d['split_ms'].items()}, {k: d[k] for k in d if 'position' in k})" || tail -3 gpurun_out/r06_bench_ppo_$v.err
+      done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
