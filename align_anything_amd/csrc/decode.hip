@@ -138,41 +138,6 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     const bf16_t* nwp = PRO == 1 ? norm_w + g * 8 : nullptr;
     float ss = 0.f;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // The epilogue's own operands (bias, residual; position -> cos / sin, cache slot) are requested HERE, above the weight stream: read after the reduction
-    // they are one (EPI 0) or two (EPI 2: pos -> table row) dependent global round trips at the very end of a launch that lasts 6 - 10 us.  Same values.
-    // The dependent half of EPI 2 (cos / sin at the row's position) is requested after the first trip of the weight stream (`skinny_epi_stage2`): loads
-    // return in order, so waiting for the position there costs nothing once a trip of younger loads has come back.
-    // (raw bf16 bits are kept and pinned by AA_KEEP_RAW until the epilogue: hipcc otherwise moves the conversion up to the load and waits for it on the spot)
-#define AA_KEEP_RAW(v) asm volatile("" : "+v"(v))
-    unsigned int e_b1 = 0, e_b2 = 0, e_res = 0, e_cos = 0, e_sin = 0;
-    long e_slot = 0;
-    int e_pos = -1;
-    if constexpr (EPI == 0) {
-        const int m = threadIdx.x >> 4, n = n0 + (threadIdx.x & 15);
-        if (threadIdx.x < 256 && m < M && n < N) {
-            if (bias) e_b1 = bias[n];
-            if (residual) e_res = residual[(long)m * ldr + n];
-        }
-    } else if constexpr (EPI == 2) {
-        const int m = threadIdx.x >> 3, c = threadIdx.x & 7;
-        if (threadIdx.x < 128 && m < M) {
-            const int head = blockIdx.x >> 3, d = (blockIdx.x & 7) * 8 + c;
-            const int col = head * 128 + d;
-            if (bias) { e_b1 = bias[col]; e_b2 = bias[col + 64]; }
-            e_slot = epi.slot[m];
-            if (head < epi.H + epi.Hkv) e_pos = epi.pos[m];
-        }
-    }
-    auto skinny_epi_stage2 = [&]() {
-        if constexpr (EPI == 2) {
-            if (e_pos >= 0) {
-                const long tb = (long)e_pos * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x & 7);
-                e_cos = epi.cos_t[tb];
-                e_sin = epi.sin_t[tb];
-                e_pos = -1;
-            }
-        }
-    };
     // wave w owns k in [w*kq, (w+1)*kq), kq = K/NWAVE rounded up to 32; 8 MFMA k-steps (256 k) per trip keep
     // 16 x 16-B loads per lane in flight (the weight stream is read exactly once: no LDS round trip)
     const int kq = ((K / NWAVE + 31) / 32) * 32;
@@ -183,7 +148,6 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
     // (16 in flight -- 512 k per trip -- measured no different: 4.19 vs 4.20 ms per position, tools/gpu_skinny_ab.sh.)
     constexpr int S = PRO == 1 ? 4 : 8;
     if constexpr (PIPE) {
-        skinny_epi_stage2();
         if (k + 128 <= k_hi) {
             bf16x8 wa[4], xa[4], wb[4], xb[4];
             skinny_load4<PRO>(wp, xp, nwp, k, K, ss, wa, xa);
@@ -211,13 +175,10 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
             }
         }
     } else {
-        if (k + S * 32 <= k_hi) { skinny_trip<PRO, S>(wp, xp, nwp, k, K, ss, acc0, acc1); k += S * 32; }
-        skinny_epi_stage2();
         for (; k + S * 32 <= k_hi; k += S * 32) skinny_trip<PRO, S>(wp, xp, nwp, k, K, ss, acc0, acc1);
-        if constexpr (S > 4) { for (; k + 128 <= k_hi; k += 128) { skinny_trip<PRO, 4>(wp, xp, nwp, k, K, ss, acc0, acc1); skinny_epi_stage2(); } }   // a 16-wave strip's 224-k share: 4 + 2 + 1 steps
+        if constexpr (S > 4) { for (; k + 128 <= k_hi; k += 128) skinny_trip<PRO, 4>(wp, xp, nwp, k, K, ss, acc0, acc1); }   // a 16-wave strip's 224-k share: 4 + 2 + 1 steps
     }
-    for (; k + 64 <= k_hi; k += 64) { skinny_trip<PRO, 2>(wp, xp, nwp, k, K, ss, acc0, acc1); skinny_epi_stage2(); }
-    skinny_epi_stage2();
+    for (; k + 64 <= k_hi; k += 64) skinny_trip<PRO, 2>(wp, xp, nwp, k, K, ss, acc0, acc1);
     if (k < k_hi) {
         const bf16x8 wf = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (SWZ ? (long)k * 16 : (long)k)));
         const bf16x8 xf = skinny_x<PRO>(xp, nwp, k, K, ss);
@@ -252,16 +213,16 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
             } else {
                 const int head = blockIdx.x >> 3, d = (blockIdx.x & 7) * 8 + c;          // head_dim 128: 8 strips per head
                 const int col = head * 128 + d;
-                AA_KEEP_RAW(e_b1); AA_KEEP_RAW(e_b2); AA_KEEP_RAW(e_cos); AA_KEEP_RAW(e_sin);
-                if (bias) { v1 += bf2f((bf16_t)e_b1); v2 += bf2f((bf16_t)e_b2); }
+                if (bias) { v1 += bf2f(bias[col]); v2 += bf2f(bias[col + 64]); }
                 const float a = rbf(v1), b = rbf(v2);
-                bf16_t* crow = epi.cache + ((long)m * epi.Tmax + e_slot) * epi.ldc;
+                bf16_t* crow = epi.cache + ((long)m * epi.Tmax + epi.slot[m]) * epi.ldc;
                 if (head >= epi.H + epi.Hkv) {                                            // value head: copy into the cache
                     bf16_t* dst = crow + (long)epi.Hkv * 128 + (long)(head - epi.H - epi.Hkv) * 128 + d;
                     dst[0] = f2bf(a);
                     dst[64] = f2bf(b);
                 } else {
-                    const float cc = bf2f((bf16_t)e_cos), ss = bf2f((bf16_t)e_sin);
+                    const long tb = (long)epi.pos[m] * 64 + d;
+                    const float cc = bf2f(epi.cos_t[tb]), ss = bf2f(epi.sin_t[tb]);
                     const bf16_t o1 = f2bf(rbf(a * cc) + rbf(-b * ss)), o2 = f2bf(rbf(b * cc) + rbf(a * ss));
                     bf16_t* dst = head < epi.H ? out + (long)m * ldo + col : crow + (long)(head - epi.H) * 128 + d;
                     dst[0] = o1;
@@ -284,16 +245,16 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
             for (int w = 0; w < NWAVE; ++w) q += ssred[w][m];
             v *= rsqrtf(q / (float)K + eps);
         }
-        AA_KEEP_RAW(e_b1); AA_KEEP_RAW(e_res);
-        if (bias) v += bf2f((bf16_t)e_b1);
-        if (residual) v = rbf(v) + bf2f((bf16_t)e_res);
+        if (bias) v += bf2f(bias[n]);
+        if (residual) v = rbf(v) + bf2f(residual[(long)m * ldr + n]);
         out[(long)m * ldo + n] = f2bf(v);
     }
 }
 
 // Launch rules (aa_decode_set_rules; env AA_DECODE_R6 sets the initial mask).  0: the round-5 rules (16 waves for every narrow deep strip launch, two key
 // steps in flight in the cache attention) -- same-box A/B.  bit 0: the round-6 wave rule + four key steps at a handful of sequences; bit 1: software-pipelined
-// trips in the deep 16-wave strips (the down projection); bit 2: eight key steps in flight instead of four.
+// trips in the deep 16-wave strips (the down projection); bit 2: four key steps in flight for every launch of fewer than 512 workgroups (eight steps at a
+// handful of sequences measured neutral: profiles/r06_decode_rules.txt).
 static int g_decode_rules = -1;
 static int decode_r6() {
     if (g_decode_rules < 0) { const char* e = getenv("AA_DECODE_R6"); g_decode_rules = e ? atoi(e) : 3; }
@@ -683,9 +644,9 @@ extern "C" int aa_attn_decode(const void* q, long ldq, const void* Kc, const voi
 #define AA_LAUNCH_ATTN_DECODE(HD_, NW_, U_)                                                                                   \
     hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_, U_>), dim3(H, N), dim3(NW_ * 64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)Kc, \
                        (const bf16_t*)Vc, ldc, Tmax, start, len, (bf16_t*)o, ldo, H, Hkv, scale)
-    const bool deep8 = handful && (decode_r6() & 4);         // bit 2: eight steps (512 keys of a head_dim-128 head per trip: a PPO rollout's 320 - 830 keys are one or two trips)
-    if (hd == 128) { if (deep8) AA_LAUNCH_ATTN_DECODE(128, 8, 8); else if (handful) AA_LAUNCH_ATTN_DECODE(128, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(128, 8, 2); else AA_LAUNCH_ATTN_DECODE(128, 4, 2); }
-    else { if (deep8) AA_LAUNCH_ATTN_DECODE(64, 8, 8); else if (handful) AA_LAUNCH_ATTN_DECODE(64, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(64, 8, 2); else AA_LAUNCH_ATTN_DECODE(64, 4, 2); }
+    const bool four = handful || (few && (decode_r6() & 4));  // bit 2: four steps for every launch of fewer than 512 workgroups (a GRPO rollout's 10 sequences x 28 heads)
+    if (hd == 128) { if (four) AA_LAUNCH_ATTN_DECODE(128, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(128, 8, 2); else AA_LAUNCH_ATTN_DECODE(128, 4, 2); }
+    else { if (four) AA_LAUNCH_ATTN_DECODE(64, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(64, 8, 2); else AA_LAUNCH_ATTN_DECODE(64, 4, 2); }
 #undef AA_LAUNCH_ATTN_DECODE
     AA_CHECK_LAUNCH("aa_attn_decode");
     return AA_OK;

@@ -376,10 +376,10 @@ int aa_decode_rope_cache(void* qkv, long ld, int N, int H, int Hkv, int hd, cons
  * out[r, :] = x[r / x_div, :] W3[row_expert[r]]^T for R routed rows r = (token, choice); W3 [E, N, K], expert stride strideE */
 int aa_moe_gemv_bf16(const void* x, const void* W3, void* out, int R, int N, int K, long ldx, long ldw, long ldo,
                      const int* row_expert, long strideE, int x_div, void* stream);
-/* launch rules of the decode kernels (a bit mask; process-wide; the previous mask is returned through *old when given; initial value: env AA_DECODE_R6, default 1).
+/* launch rules of the decode kernels (a bit mask; process-wide; the previous mask is returned through *old when given; initial value: env AA_DECODE_R6, default 3).
  * bit 0: a narrow deep strip launch with more strips than compute units gets 8 waves per strip (one round instead of two), and aa_attn_decode keeps four key
  *        steps in flight per wave when H * N < 128;  bit 1: the deep 16-wave strips (K >= 8192: the down projection) run software-pipelined trips (same sums,
- *        bit for bit);  bit 2: eight key steps in flight instead of four.  0 = the round-5 rules (same-box A/B; generate() has no reference-side counterpart: hf generate, ppo.py:209-222) */
+ *        bit for bit);  bit 2: four key steps in flight whenever H * N < 512.  0 = the round-5 rules (same-box A/B; generate() has no reference-side counterpart: hf generate, ppo.py:209-222) */
 int aa_decode_set_rules(int mask, int* old);
 /* one query per sequence against the token-major KV cache [N, Tmax, Hkv*hd] (row stride ldc); keys [start[n], len[n]) */
 int aa_attn_decode(const void* q, long ldq, const void* Kc, const void* Vc, long ldc, int Tmax, const int* start,

@@ -94,8 +94,8 @@ def test_decode_rope_cache_equals_rope_then_index_put():
 
 @pytest.mark.parametrize('hd,H,Hkv,N,Tmax', [(128, 4, 4, 3, 300), (64, 4, 2, 3, 300), (128, 28, 4, 1, 900), (128, 32, 8, 5, 300), (64, 32, 32, 16, 300)])
 def test_decode_attention_vs_reference(hd, H, Hkv, N, Tmax):
-    """aa_attn_decode against softmax(q K^T) V in fp32 on every launch form: H N < 128 (one or two sequences: four or eight key steps in flight per wave,
-    round 6, aa_decode_set_rules), < 512 (8 waves, two steps), beyond (4 waves); left-padded and full rows, a one-key row."""
+    """aa_attn_decode against softmax(q K^T) V in fp32 on every launch form: H N < 128 (one or two sequences: four key steps in flight per wave,
+    round 6, aa_decode_set_rules), < 512 (8 waves, two steps; four under rule bit 2), beyond (4 waves); left-padded and full rows, a one-key row."""
     from align_anything_amd import ops
     q = randn_bf16(N, H * hd, seed=1)
     cache = randn_bf16(N * Tmax, 2 * Hkv * hd, seed=2)
@@ -109,14 +109,16 @@ def test_decode_attention_vs_reference(hd, H, Hkv, N, Tmax):
     outs = {}
     old = ops.decode_set_rules(0)
     try:
-        for mask in (0, 1, 5):          # two, four and eight key steps in flight (the last two only when H N < 128)
+        for mask in (0, 1, 5):          # two key steps in flight; four when H N < 128; four when H N < 512
             ops.decode_set_rules(mask)
             outs[mask] = ops.attn_decode(q, cache, cache[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
     finally:
         ops.decode_set_rules(old)
     torch.cuda.synchronize()
     if H * N >= 128:
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[5])
+        assert torch.equal(outs[0], outs[1])
+    if H * N >= 512:
+        assert torch.equal(outs[0], outs[5])
     cf = cache.float().view(N, Tmax, 2, Hkv, hd)
     for n in range(N):
         s0, s1 = int(start[n]), int(length[n])

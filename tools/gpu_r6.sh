@@ -106,6 +106,13 @@ PY
         AA_DECODE_R6=3 AA_HIP_LIB=$R/align_anything_amd/$v timeout 400 python tools/bench_ppo.py --iters 2 > gpurun_out/r06_bench_ppo_$v.json 2> gpurun_out/r06_bench_ppo_$v.err
         python -c "import json; d=json.loads([l for l in open('gpurun_out/r06_bench_ppo_$v.json') if l.startswith('{')][-1]); print('$v iteration', round(d['iteration_ms'],1), 'ms', {k: round(x,2) for k,x in d['split_ms'].items()}, {k: d[k] for k in d if 'position' in k})" || tail -3 gpurun_out/r06_bench_ppo_$v.err
       done ;;
+    decode_batches_ab)   # rule bit 2 (four key steps in flight whenever H x N < 512) at the batches between PPO's 1 and the 4-wave form: 4 / 10 (GRPO: B x num_generations) / 16 sequences, masks 3 and 7 alternating
+      timeout 300 python -m pytest tests/test_decode_gpu.py -q -x -m gpu -p no:cacheprovider -k "attention or launch_rules" 2>&1 | tail -2 | cut -c1-200
+      for v in 3 7 3 7; do
+        AA_DECODE_R6=$v AA_BENCH_DECODE_CASES="4,512,64;10,512,64;16,512,64" AA_BENCH_DECODE_OUT=r06_bench_decode_rules$v.json timeout 600 python tools/bench_decode.py 2>&1 | grep -E "^\{" | python -c "
+import sys, ast
+print('AA_DECODE_R6=$v', [(r['N'], round(r['ms_per_step'], 4), round(r['tokens_per_s'])) for r in map(ast.literal_eval, sys.stdin)])"
+      done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
