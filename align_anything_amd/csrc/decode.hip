@@ -254,14 +254,14 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
 // Launch rules (aa_decode_set_rules; env AA_DECODE_R6 sets the initial mask).  0: the round-5 rules (16 waves for every narrow deep strip launch, two key
 // steps in flight in the cache attention) -- same-box A/B.  bit 0: the round-6 wave rule + four key steps at a handful of sequences; bit 1: software-pipelined
 // trips in the deep 16-wave strips (the down projection); bit 2: four key steps in flight for every launch of fewer than 512 workgroups (eight steps at a
-// handful of sequences measured neutral: profiles/r06_decode_rules.txt); bit 3: XCD-local order of the cache attention's workgroups.
+// handful of sequences measured neutral: profiles/r06_decode_rules.txt).
 static int g_decode_rules = -1;
 static int decode_r6() {
     if (g_decode_rules < 0) { const char* e = getenv("AA_DECODE_R6"); g_decode_rules = e ? atoi(e) : 3; }
     return g_decode_rules;
 }
 extern "C" int aa_decode_set_rules(int mask, int* old) {
-    AA_REQUIRE(mask >= 0 && mask <= 15, "aa_decode_set_rules: mask %d (bits 0 - 3)", mask);
+    AA_REQUIRE(mask >= 0 && mask <= 7, "aa_decode_set_rules: mask %d (bits 0 - 2)", mask);
     if (old) *old = decode_r6();
     g_decode_rules = mask;
     return AA_OK;
@@ -541,22 +541,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ Vc, long ldc, int Tmax,
                                                               const int* __restrict__ start,
                                                               const int* __restrict__ len, bf16_t* __restrict__ o,
-                                                              long ldo, int H, int Hkv, float scale, int xcd_local) {
+                                                              long ldo, int H, int Hkv, float scale) {
     constexpr int LPK = HD / 8;        // lanes per key
     constexpr int KPW = 64 / LPK;      // keys per wave step
     constexpr int STRIDE = NW * KPW;   // keys per workgroup step
     __shared__ float sm_m[NW][KPW], sm_l[NW][KPW];
     __shared__ float sm_acc[NW][KPW][HD];
-    // Workgroup b runs on XCD b % 8 and every XCD has its own L2.  With heads fastest over the grid (round 1 - 5) the H / Hkv query heads that read the SAME
-    // K / V rows land on H / Hkv different XCDs and every one of them pulls the rows from HBM / the Infinity Cache itself (7 x at Qwen2-VL's 28 / 4 heads).
-    // xcd_local: XCD x takes a CONTIGUOUS chunk of the (sequence, head) list -- the heads of a kv group sit on one XCD (two at a chunk boundary), back to back
-    // in its dispatch order, and share one fetch.  A bijection for any grid size: XCD x hosts q + (x < r) workgroups, q = T / 8, r = T % 8.
-    int w = blockIdx.x + gridDim.x * blockIdx.y;
-    if (xcd_local) {
-        const int T = gridDim.x * gridDim.y, x = w & 7, q = T >> 3, r = T & 7;
-        w = x * q + min(x, r) + (w >> 3);
-    }
-    const int h = w % H, n = w / H, hk = h / (H / Hkv);
+    const int h = blockIdx.x, n = blockIdx.y, hk = h / (H / Hkv);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPK, kg = lane / LPK;
     const int s0 = start ? start[n] : 0, s1 = len[n];
@@ -652,8 +643,7 @@ extern "C" int aa_attn_decode(const void* q, long ldq, const void* Kc, const voi
     const bool handful = (long)H * N < 128 && (decode_r6() & 1);   // one or two sequences: four key steps in flight per wave (half the dependent trips)
 #define AA_LAUNCH_ATTN_DECODE(HD_, NW_, U_)                                                                                   \
     hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_, U_>), dim3(H, N), dim3(NW_ * 64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)Kc, \
-                       (const bf16_t*)Vc, ldc, Tmax, start, len, (bf16_t*)o, ldo, H, Hkv, scale, xcd_local)
-    const int xcd_local = (H > Hkv && (decode_r6() & 8)) ? 1 : 0;   // bit 3: the query heads of a kv group on one XCD (grouped-query models)
+                       (const bf16_t*)Vc, ldc, Tmax, start, len, (bf16_t*)o, ldo, H, Hkv, scale)
     const bool four = handful || (few && (decode_r6() & 4));  // bit 2: four steps for every launch of fewer than 512 workgroups (a GRPO rollout's 10 sequences x 28 heads)
     if (hd == 128) { if (four) AA_LAUNCH_ATTN_DECODE(128, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(128, 8, 2); else AA_LAUNCH_ATTN_DECODE(128, 4, 2); }
     else { if (four) AA_LAUNCH_ATTN_DECODE(64, 8, 4); else if (few) AA_LAUNCH_ATTN_DECODE(64, 8, 2); else AA_LAUNCH_ATTN_DECODE(64, 4, 2); }

@@ -379,9 +379,7 @@ int aa_moe_gemv_bf16(const void* x, const void* W3, void* out, int R, int N, int
 /* launch rules of the decode kernels (a bit mask; process-wide; the previous mask is returned through *old when given; initial value: env AA_DECODE_R6, default 3).
  * bit 0: a narrow deep strip launch with more strips than compute units gets 8 waves per strip (one round instead of two), and aa_attn_decode keeps four key
  *        steps in flight per wave when H * N < 128;  bit 1: the deep 16-wave strips (K >= 8192: the down projection) run software-pipelined trips (same sums,
- *        bit for bit);  bit 2: four key steps in flight whenever H * N < 512;
- *        bit 3: aa_attn_decode deals its (sequence, head) workgroups to the XCDs in contiguous chunks, so the query heads of a kv group share one L2 (same numbers).
- *        0 = the round-5 rules (same-box A/B; generate() has no reference-side counterpart: hf generate, ppo.py:209-222) */
+ *        bit for bit);  bit 2: four key steps in flight whenever H * N < 512.  0 = the round-5 rules (same-box A/B; generate() has no reference-side counterpart: hf generate, ppo.py:209-222) */
 int aa_decode_set_rules(int mask, int* old);
 /* one query per sequence against the token-major KV cache [N, Tmax, Hkv*hd] (row stride ldc); keys [start[n], len[n]) */
 int aa_attn_decode(const void* q, long ldq, const void* Kc, const void* Vc, long ldc, int Tmax, const int* start,

@@ -109,14 +109,12 @@ def test_decode_attention_vs_reference(hd, H, Hkv, N, Tmax):
     outs = {}
     old = ops.decode_set_rules(0)
     try:
-        for mask in (0, 1, 5, 8, 13):   # two key steps in flight; four when H N < 128; four when H N < 512; + 8: XCD-local workgroup order (same numbers)
+        for mask in (0, 1, 5):          # two key steps in flight; four when H N < 128; four when H N < 512
             ops.decode_set_rules(mask)
             outs[mask] = ops.attn_decode(q, cache, cache[:, kw:], Tmax, start, length, N, H, Hkv, hd, hd ** -0.5)
     finally:
         ops.decode_set_rules(old)
     torch.cuda.synchronize()
-    assert torch.equal(outs[8], outs[0]) and torch.equal(outs[13], outs[5])
-    del outs[8], outs[13]
     if H * N >= 128:
         assert torch.equal(outs[0], outs[1])
     if H * N >= 512:

@@ -108,8 +108,10 @@ def bench(prompts=1, new_tokens=512, iters=2, layers=28, vision_depth=32, device
         info, ms_rl = clock(lambda: tr.rl_step(inf, training))
         if it == iters:                                           # prefill alone (one generated token), after the timed iterations
             mm = {'image_grid_thw': pb['image_grid_thw']}
-            _, prefill_ms = clock(lambda: generate(tr.actor_model.module, pb['input_ids'], pb['attention_mask'], max_new_tokens=1, do_sample=False,
-                                                   pad_token_id=cfg['pad_token_id'], pixel_values=pb['pixel_values'], **mm))
+            # inside the same few-row GEMM scope as tr.actor_step (ops.few_row_gemms: split-K prefill), so that generate - prefill is the decode loop alone
+            from align_anything_amd import ops
+            _, prefill_ms = clock(ops.few_row_gemms(lambda: generate(tr.actor_model.module, pb['input_ids'], pb['attention_mask'], max_new_tokens=1, do_sample=False,
+                                                                     pad_token_id=cfg['pad_token_id'], pixel_values=pb['pixel_values'], **mm)))
         rows.append({'iteration': it, 'warmup': it == 0, 'generate_ms': round(ms_gen, 2), 'score_ms': round(ms_score, 2), 'rl_step_ms': round(ms_rl, 2),
                      'response_lens': lens, 'actor_loss': info['train/actor_loss'], 'critic_loss': info['train/reward_critic_loss'],
                      'kl': info['train/kl_divergence'], 'mean_generated_length': info['train/mean_generated_length']})

@@ -113,16 +113,11 @@ PY
 import sys, ast
 print('AA_DECODE_R6=$v', [(r['N'], round(r['ms_per_step'], 4), round(r['tokens_per_s'])) for r in map(ast.literal_eval, sys.stdin)])"
       done ;;
-    decode_xcd_ab)   # rule bit 3 (XCD-local order of the cache attention's workgroups: the query heads of a kv group on one L2): numerics, decode at 4 / 10 / 16 sequences and the PPO iteration (1 sequence), masks 3 and 11 alternating
-      timeout 300 python -m pytest tests/test_decode_gpu.py -q -x -m gpu -p no:cacheprovider -k "attention or launch_rules or generate" 2>&1 | tail -2 | cut -c1-200
-      for v in 3 11 3 11; do
-        AA_DECODE_R6=$v AA_BENCH_DECODE_CASES="4,512,64;10,512,64;16,512,64" AA_BENCH_DECODE_OUT=r06_bench_decode_rules$v.json timeout 600 python tools/bench_decode.py 2>&1 | grep -E "^\{" | python -c "
-import sys, ast
-print('AA_DECODE_R6=$v', [(r['N'], round(r['ms_per_step'], 4), round(r['tokens_per_s'])) for r in map(ast.literal_eval, sys.stdin)])"
-      done
-      for v in 3 11 3 11; do
-        AA_DECODE_R6=$v timeout 400 python tools/bench_ppo.py --iters 2 > gpurun_out/r06_bench_ppo_r6_$v.json 2> gpurun_out/r06_bench_ppo_r6_$v.err
-        python -c "import json; d=json.loads([l for l in open('gpurun_out/r06_bench_ppo_r6_$v.json') if l.startswith('{')][-1]); print('AA_DECODE_R6=$v iteration', round(d['iteration_ms'],1), 'ms', {k: d[k] for k in d if 'position' in k})" || tail -3 gpurun_out/r06_bench_ppo_r6_$v.err
+    rocprof_decode)  # rocprofv3 --kernel-trace --stats of the decode loop at 1 and at 10 sequences (GRPO's B x num_generations): which kernels grow with the batch
+      for n in 1 10; do
+        ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r06_prof_dec$n && AA_BENCH_DECODE_CASES="$n,512,128" AA_BENCH_DECODE_OUT=r06_bench_decode_prof$n.json timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof_dec$n -o p -- python $R/tools/bench_decode.py > $R/gpurun_out/r06_prof_dec$n.log 2>&1 )
+        f=$(find gpurun_out/r06_prof_dec$n -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r06_decode_kernel_stats_n$n.csv; echo "--- $n sequence(s)"; head -12 gpurun_out/r06_decode_kernel_stats_n$n.csv | cut -c1-60,200-330
+        find gpurun_out/r06_prof_dec$n -name "*kernel_trace.csv" -delete
       done ;;
     *) echo "unknown stage $stage" ;;
   esac
