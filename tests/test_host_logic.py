@@ -31,6 +31,49 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.LIB._dll.aa_version() == 101      # 101: library contexts (aa_ctx_*)
 
 
+def test_round6_switches_are_scoped_and_validated():
+    """Two host-side rules of round 6 that need no device.  (1) ops.few_row_gemms: split-K for few-row GEMMs is on only inside the decorated RL-trainer
+    methods (the preference trainers' pinned envelopes stay on the one-launch kernel), nests, and is restored when the call raises.  (2) aa_decode_set_rules
+    hands back the previous mask and refuses masks it does not know."""
+    from align_anything_amd import lib, ops
+    from align_anything_amd.trainers import dpo, grpo, ppo, ppo_ti2t
+    assert ops.SPLITK is False and ops._splitk_chunks(832, 3584, 18944) == 0
+    seen = []
+
+    @ops.few_row_gemms
+    def inner(fail=False):
+        seen.append((ops.SPLITK, ops._splitk_chunks(832, 3584, 18944), ops._splitk_chunks(4096, 3584, 18944), ops._splitk_chunks(832, 37888, 3584)))
+        if fail:
+            raise ValueError('x')
+
+    @ops.few_row_gemms
+    def outer():
+        inner()
+        seen.append(ops.SPLITK)
+
+    outer()
+    with pytest.raises(ValueError):
+        inner(fail=True)
+    assert ops.SPLITK is False
+    allowed = ops.SPLITK_ALLOWED
+    assert seen[0][0] is allowed and seen[1] is allowed
+    if allowed:
+        assert 2 <= seen[0][1] <= 8 and seen[0][2] == 0 and seen[0][3] == 0          # few rows x few tiles only: not M > 1024, not a launch that fills the chip
+    for cls, names in ((ppo.PPOTrainer, ('actor_step', 'rollout', 'rl_step', 'ptx_step')), (ppo_ti2t.PPOTrainerTI2T, ('actor_step', 'rollout', 'rl_step')),
+                       (grpo.GRPOTrainer, ('generate_completions', 'train_step', 'actor_step'))):
+        for n in names:
+            assert hasattr(getattr(cls, n), '__wrapped__'), (cls.__name__, n)
+    assert not hasattr(dpo.DPOTrainer.train_step, '__wrapped__')
+    old = ops.decode_set_rules(0)
+    try:
+        assert ops.decode_set_rules(3) == 0 and ops.decode_set_rules(1) == 3
+        with pytest.raises(lib.AAHipError):
+            ops.decode_set_rules(64)
+        assert ops.decode_set_rules(1) == 1                                           # a refused mask changes nothing
+    finally:
+        ops.decode_set_rules(old)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from align_anything_amd import lib
     l = lib._Lib()
