@@ -119,6 +119,10 @@ print('AA_DECODE_R6=$v', [(r['N'], round(r['ms_per_step'], 4), round(r['tokens_p
         f=$(find gpurun_out/r06_prof_dec$n -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r06_decode_kernel_stats_n$n.csv; echo "--- $n sequence(s)"; head -12 gpurun_out/r06_decode_kernel_stats_n$n.csv | cut -c1-60,200-330
         find gpurun_out/r06_prof_dec$n -name "*kernel_trace.csv" -delete
       done ;;
+    dp2)             # smoke(), then the N = 2 code path of bench.py as a FUNCTIONAL run on one device (gloo; never a performance number) on the round's final code
+      timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3
+      AA_BENCH_ONE_DEVICE=1 AA_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 --layers 4 --no-cpu-baseline --no-gemm-events > gpurun_out/r06_dp2_functional_onebox.json 2> gpurun_out/r06_dp2_functional_onebox.err; echo "rc=$?"
+      python -c "import json; d=json.loads(open('gpurun_out/r06_dp2_functional_onebox.json').read().strip().split(chr(10))[-1]); m=d['multi_gpu']; print('dp2 functional:', d['config']['workload'][-60:], 'n_gpus', d['n_gpus'], 'value', round(d['value'], 3), 'replicas identical', m['replicas_bit_identical_after_steps'], 'reduce', m['reduce_mode'], (m.get('reduce_autotune') or {}).get('forms_agree'))" || tail -8 gpurun_out/r06_dp2_functional_onebox.err ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
