@@ -31,6 +31,10 @@ import subprocess
 import sys
 import time
 
+# dmabuf IPC: the host driver of the GPU boxes supports no other, and RCCL / CUDA-tensor sharing across the ranks fails without it (hipIpcGetMemHandle: invalid
+# argument).  The driver's launcher exports it; this covers a bare `python -m torch.distributed.run ... bench.py` too.  Before the HIP runtime is loaded.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
