@@ -336,74 +336,6 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const elem_t* __restri
     }
 }
 
-// One row per WAVE (round 6; h = NV * 512: 2048 / 4096 / ...): a lane owns NV 16-byte vectors of the row (vector a = columns (64 a + lane) * 8 ...), the row's
-// x / dy / residual-gradient vectors -- 3 NV loads per lane -- are all requested before the first is used, the row reduction is a butterfly inside the wave
-// and NO block barrier sits in the row loop: the four waves of a block drift apart and the CU's loads and stores stop arriving in bursts (the two-row block
-// kernel above: load phase, two barriers, store phase per pair of rows).  The four waves' dw partials meet in LDS once, at the end: one partial row per block
-// as before.  Arithmetic per element is that of rmsnorm_bwd_kernel; the row dot product and the dw column sums associate differently (fp32).
-template <int NV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void rmsnorm_bwd_wave_kernel(const elem_t* __restrict__ dy, const elem_t* __restrict__ x, const elem_t* __restrict__ w,
-                                                               const float* __restrict__ rstd_in, elem_t* __restrict__ dx, float* __restrict__ dw_part,
-                                                               int rows, int h, int add_to_dx) {
-    extern __shared__ float wave_part[];          // [4][h] when dw_part
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float dwacc[NV][8];
-#pragma unroll
-    for (int a = 0; a < NV; ++a)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dwacc[a][j] = 0.f;
-    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
-        const long base = row * h + lane * 8;
-        ev8 xk[NV], gk[NV], ok[NV];
-#pragma unroll
-        for (int a = 0; a < NV; ++a) {
-            xk[a] = *reinterpret_cast<const ev8*>(x + base + a * 512);
-            gk[a] = *reinterpret_cast<const ev8*>(dy + base + a * 512);
-            if (add_to_dx) ok[a] = *reinterpret_cast<const ev8*>(dx + base + a * 512);
-        }
-        const float rs = rstd_in[row];
-        float dot = 0.f;
-#pragma unroll
-        for (int a = 0; a < NV; ++a) {
-            const ev8 wv = *reinterpret_cast<const ev8*>(w + lane * 8 + a * 512);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = e2f(xk[a][j]) * rs, g = e2f(gk[a][j]);
-                dot += g * e2f(wv[j]) * xh;
-                dwacc[a][j] += g * ernd(xh);
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-        const float dm = dot / (float)h;
-        // the second pass converts the PACKED vectors again: kept as floats across the reduction they would be 2 x 8 NV more registers (spills at 2 waves / SIMD)
-#pragma unroll
-        for (int a = 0; a < NV; ++a) asm volatile("" : "+v"(xk[a]), "+v"(gk[a]));
-#pragma unroll
-        for (int a = 0; a < NV; ++a) {
-            const ev8 wv = *reinterpret_cast<const ev8*>(w + lane * 8 + a * 512);
-            ev8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = e2f(xk[a][j]) * rs;
-                float d = rs * (e2f(gk[a][j]) * e2f(wv[j]) - xh * dm);
-                if (add_to_dx) d += e2f(ok[a][j]);
-                o[j] = f2e(d);
-            }
-            *reinterpret_cast<ev8*>(dx + base + a * 512) = o;
-        }
-    }
-    if (dw_part) {
-#pragma unroll
-        for (int a = 0; a < NV; ++a)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) wave_part[wave * h + (a * 64 + lane) * 8 + j] = dwacc[a][j];
-        __syncthreads();
-        float* pr = dw_part + (long)blockIdx.x * h;
-        for (int c = threadIdx.x; c < h; c += 256) pr[c] = wave_part[c] + wave_part[h + c] + wave_part[2 * h + c] + wave_part[3 * h + c];
-    }
-}
-
 // out[c] += sum_r part[r, c]; grid = (ceil(h/64), RS); block = 256 (64 columns x 4 row lanes)
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int nrows,
                                                           int h, float* __restrict__ out) {
@@ -528,37 +460,6 @@ extern "C" int AA_FN(aa_rmsnorm_bwd)(const void* dy, const void* x, const void* 
         if (h <= 64) LAUNCH_RMSB_SMALL(8); else if (h <= 128) LAUNCH_RMSB_SMALL(16); else if (h <= 256) LAUNCH_RMSB_SMALL(32); else LAUNCH_RMSB_SMALL(64);
 #undef LAUNCH_RMSB_SMALL
         if (dw) launch_reduce_rows(part, g2, h, dw, st);
-        AA_CHECK_LAUNCH("aa_rmsnorm_bwd");
-        return AA_OK;
-    }
-    // h a multiple of 512 up to 4096 (every 7B decoder): one row per wave, no barrier in the row loop (rmsnorm_bwd_wave_kernel).  AA_RMSB_WAVE=0: the block kernel (A/B)
-    static int wave_on = -1;
-    if (wave_on < 0) { const char* e = getenv("AA_RMSB_WAVE"); wave_on = e ? atoi(e) : 1; }
-    if (wave_on && sizeof(elem_t) == 2 && h % 512 == 0 && h >= 2048 && h <= 4096 && rows >= 4096) {
-        const int NVv = h / 512;
-        static int wslots[AA_MAX_DEVICES] = {0};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= AA_MAX_DEVICES) dev = -1;
-        int slots = dev >= 0 ? wslots[dev] : 0;
-        const size_t lds = dw ? (size_t)4 * h * sizeof(float) : 0;
-        if (slots == 0) {
-            int cus = 0;
-            slots = (dev >= 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? 2 * cus : 512;
-            if (dev >= 0) wslots[dev] = slots;
-        }
-        int g3 = (rows + 3) / 4;
-        if (g3 > slots) g3 = slots;
-        if (dw && g3 > ws_rows) g3 = ws_rows;
-#define LAUNCH_RMSW(NV)                                                                                                                              \
-    do {                                                                                                                                             \
-        static bool attr = false;                                                                                                                    \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_wave_kernel<NV>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4); attr = true; } \
-        hipLaunchKernelGGL(rmsnorm_bwd_wave_kernel<NV>, dim3(g3), dim3(256), lds, st, (const elem_t*)dy, (const elem_t*)x, (const elem_t*)w, rstd,   \
-                           (elem_t*)dx, part, rows, h, add_to_dx);                                                                                   \
-    } while (0)
-        if (NVv == 4) LAUNCH_RMSW(4); else if (NVv == 5) LAUNCH_RMSW(5); else if (NVv == 6) LAUNCH_RMSW(6); else if (NVv == 7) LAUNCH_RMSW(7); else LAUNCH_RMSW(8);
-#undef LAUNCH_RMSW
-        if (dw) launch_reduce_rows(part, g3, h, dw, st);
         AA_CHECK_LAUNCH("aa_rmsnorm_bwd");
         return AA_OK;
     }

@@ -78,12 +78,6 @@ PY
       timeout 600 python -m pytest tests/test_pack_gpu.py tests/test_qwen3moe_gpu.py -q -x -m gpu -p no:cacheprovider > gpurun_out/r06_pack_moe_tests.log 2>&1; echo "rc=$?"; tail -8 gpurun_out/r06_pack_moe_tests.log | cut -c1-300; cat gpurun_out/parity_pack_qwen3moe*.txt
       for f in "" "--share-prompt"; do timeout 400 python tools/bench_qwen3moe.py --pairs 2 --steps 4 --warmup 2 $f > gpurun_out/r06_bench_qwen3moe_b2$f.json 2> gpurun_out/r06_bench_qwen3moe_b2$f.err; cut -c1-520 gpurun_out/r06_bench_qwen3moe_b2$f.json; tail -2 gpurun_out/r06_bench_qwen3moe_b2$f.err | cut -c1-200; done
       timeout 400 python tools/bench_qwen3moe.py --pairs 4 --steps 4 --warmup 2 --share-prompt > gpurun_out/r06_bench_qwen3moe_b4--share-prompt.json 2> gpurun_out/r06_bench_qwen3moe_b4--share-prompt.err; cut -c1-520 gpurun_out/r06_bench_qwen3moe_b4--share-prompt.json ;;
-    rmsb_ab)         # rmsnorm_bwd_wave_kernel (one row per wave, no block barrier) against the two-row block kernel: numerics, then the headline step's own event-timed figure, alternating
-      timeout 900 python -m pytest tests -q -x -m gpu -p no:cacheprovider -k "rmsnorm or norm or twin or bench_geometry or tail" > gpurun_out/r06_rmsb_tests.log 2>&1; echo "rc=$?"; tail -3 gpurun_out/r06_rmsb_tests.log | cut -c1-200
-      for v in 0 1 0 1; do
-        AA_RMSB_WAVE=$v timeout 600 python bench.py --steps 8 --warmup 2 --traffic committed --no-cpu-baseline --no-per-batch > gpurun_out/r06_bench_rmsb$v.json 2> gpurun_out/r06_bench_rmsb$v.err
-        python -c "import json; d=json.load(open('gpurun_out/r06_bench_rmsb$v.json')); r=d['roofline']; k=[x for x in r['hbm_kernels'] if 'rmsnorm_bwd' in x['kernel']][0]; print('AA_RMSB_WAVE=$v', round(d['ms_per_step'],2), 'ms  rmsnorm_bwd', round(k['avg_ms']*1e3,1), 'us', round(k['frac_of_8TBs'],3), 'of 8 TB/s', round(k['ms_per_step'],2), 'ms/step  W', round(r.get('power_w_mean') or 0), 'MHz', round(r.get('sclk_mhz_mean') or 0), d['config'].get('losses_timed_steps', [])[:2])" || tail -3 gpurun_out/r06_bench_rmsb$v.err
-      done ;;
     rocprof_ppo)     # rocprofv3 --kernel-trace --stats of the PPO iteration (tools/bench_ppo.py)
       ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r06_prof_ppo && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof_ppo -o p -- python $R/tools/bench_ppo.py --iters 2 > $R/gpurun_out/r06_prof_ppo.log 2>&1 )
       f=$(find gpurun_out/r06_prof_ppo -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r06_ppo_kernel_stats.csv; head -45 gpurun_out/r06_ppo_kernel_stats.csv | cut -c1-170; tail -2 gpurun_out/r06_prof_ppo.log | cut -c1-900
