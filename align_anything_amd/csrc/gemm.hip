@@ -672,6 +672,8 @@ extern "C" int aa_gemm_splitk_bf16(const void* A, const void* B, void* C, int M,
                "aa_gemm_splitk_bf16: bad shape M=%d N=%d K=%d lda=%ld ldb=%ld ldc=%ld", M, N, K, lda, ldb, ldc);
     AA_REQUIRE(S >= 2 && S <= 64 && ws != nullptr, "aa_gemm_splitk_bf16: %d chunks need an fp32 workspace of chunks x M x N", S);
     AA_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)ws & 15) == 0, "aa_gemm_splitk_bf16: operands must be 16-byte aligned");
+    AA_REQUIRE(residual == nullptr || (ldr % 4 == 0 && ((uintptr_t)residual & 7) == 0), "aa_gemm_splitk_bf16: residual rows must be 8-byte aligned (ldr = %ld)", ldr);
+    AA_REQUIRE(((uintptr_t)bias & 7) == 0, "aa_gemm_splitk_bf16: bias must be 8-byte aligned");
     const bool a_t = flags & AA_GEMM_A_T, b_n = flags & AA_GEMM_B_N;
     AA_REQUIRE(!a_t || b_n, "aa_gemm_splitk_bf16: layout A^T with K-contiguous B is not built");
     if (a_t) AA_REQUIRE(M % 8 == 0, "aa_gemm_splitk_bf16: transposed A needs M %% 8 == 0 (got %d)", M);

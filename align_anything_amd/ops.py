@@ -89,7 +89,8 @@ def gemm(a, b, out=None, *, bias=None, residual=None, act=0, a_t=False, b_n=Fals
     if sfx and out.dtype != f32:
         raise RuntimeError('gemm: fp32 operands need an fp32 output')
     FLOPS['gemm'] += 2.0 * M * N * K
-    S = 0 if sfx else _splitk_chunks(M, N, K)
+    # (shapes / layouts aa_gemm_splitk_bf16 does not take stay on the one-launch kernel: K-tile multiple, A^T only with row-major-K B, 8-row multiples under A^T)
+    S = 0 if (sfx or K % 64 or (a_t and (not b_n or M % 8)) or ldr % 4) else _splitk_chunks(M, N, K)
     if S:       # few rows against a large weight matrix: the contraction in S chunks side by side (csrc/gemm.hip aa_gemm_splitk_bf16)
         call('aa_gemm_splitk_bf16', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0), _p(bias), _p(residual),
              ldr, int(act), flags, _splitk_ws(S * M * N, a.device).data_ptr(), S, stream())
