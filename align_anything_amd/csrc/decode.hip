@@ -71,28 +71,9 @@ __device__ __forceinline__ void skinny_trip(const bf16_t* __restrict__ wp, const
         xf[s] = skinny_x<PRO>(xp, nwp, k + s * 32, K, ss);
     }
 #pragma unroll
-    for (int s = 0; s + 1 < S; s += 2) {
+    for (int s = 0; s < S; s += 2) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf[s], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s + 1], xf[s + 1], acc1, 0, 0, 0);
-    }
-    if constexpr (S & 1) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[S - 1], xf[S - 1], acc0, 0, 0, 0);
-}
-
-// What is left of a wave's share after the whole trips (1 .. 7 k-steps) as ONE trip: all its fragments requested together.  Rounds 1 - 5 walked it as a
-// 4-step, a 2-step and a single step -- three dependent memory round trips where the share is short (the o projection of a 7B decoder on 16 waves per strip:
-// 224 k = 7 steps, its whole stream).  Same k order, same accumulator per step parity (even steps acc0, odd acc1): bit-identical sums.
-template <int PRO>
-__device__ __forceinline__ void skinny_tail(const bf16_t* __restrict__ wp, const bf16_t* __restrict__ xp, const bf16_t* __restrict__ nwp,
-                                            int k, int K, int r, float& ss, f32x4& acc0, f32x4& acc1) {
-    switch (r) {
-        case 1: skinny_trip<PRO, 1>(wp, xp, nwp, k, K, ss, acc0, acc1); break;
-        case 2: skinny_trip<PRO, 2>(wp, xp, nwp, k, K, ss, acc0, acc1); break;
-        case 3: skinny_trip<PRO, 3>(wp, xp, nwp, k, K, ss, acc0, acc1); break;
-        case 4: skinny_trip<PRO, 4>(wp, xp, nwp, k, K, ss, acc0, acc1); break;
-        case 5: skinny_trip<PRO, 5>(wp, xp, nwp, k, K, ss, acc0, acc1); break;
-        case 6: skinny_trip<PRO, 6>(wp, xp, nwp, k, K, ss, acc0, acc1); break;
-        case 7: skinny_trip<PRO, 7>(wp, xp, nwp, k, K, ss, acc0, acc1); break;
-        default: break;
     }
 }
 
@@ -195,16 +176,13 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm_skinny_kernel(const bf16_t* _
         }
     } else {
         for (; k + S * 32 <= k_hi; k += S * 32) skinny_trip<PRO, S>(wp, xp, nwp, k, K, ss, acc0, acc1);
+        if constexpr (S > 4) { for (; k + 128 <= k_hi; k += 128) skinny_trip<PRO, 4>(wp, xp, nwp, k, K, ss, acc0, acc1); }   // a 16-wave strip's 224-k share: 4 + 2 + 1 steps
     }
-    if constexpr (NWAVE >= 8) {
-        // short shares (8 / 16 waves per strip): the remaining 1 .. 7 k-steps in one trip (K and the shares are multiples of 32)
-        if (k < k_hi) skinny_tail<PRO>(wp, xp, nwp, k, K, (k_hi - k) >> 5, ss, acc0, acc1);
-    } else {
-        // 4 waves per strip (the wide launches: gate | up, lm_head): shares of 28+ steps, the tail is noise and the 7-way switch would cost the kernel a wave per
-        // SIMD (98 -> 115 VGPRs) -- the 4 / 2 / 1 walk stays
-        if constexpr (S > 4) { for (; k + 128 <= k_hi; k += 128) skinny_trip<PRO, 4>(wp, xp, nwp, k, K, ss, acc0, acc1); }
-        for (; k + 64 <= k_hi; k += 64) skinny_trip<PRO, 2>(wp, xp, nwp, k, K, ss, acc0, acc1);
-        if (k < k_hi) skinny_trip<PRO, 1>(wp, xp, nwp, k, K, ss, acc0, acc1);
+    for (; k + 64 <= k_hi; k += 64) skinny_trip<PRO, 2>(wp, xp, nwp, k, K, ss, acc0, acc1);
+    if (k < k_hi) {
+        const bf16x8 wf = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (SWZ ? (long)k * 16 : (long)k)));
+        const bf16x8 xf = skinny_x<PRO>(xp, nwp, k, K, ss);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc0, 0, 0, 0);
     }
     // D[i = n (4g + r)][j = m (l15)]
 #pragma unroll
